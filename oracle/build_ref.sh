@@ -1,0 +1,163 @@
+#!/bin/bash
+# build_ref.sh -- TEST INFRASTRUCTURE ONLY.
+#
+# Compiles the UNMODIFIED reference sources where they lie under
+# /root/reference (never copied into this repo) with amdflang into
+# oracle/_ref/ (git-ignored, travels to the GPU box with gpurun):
+#
+#   kernels [NDIM]   -> oracle/_ref/libref_kernels{NDIM}d.so
+#                       the reference's unsplit/ctoprim/uslope/trace*/cmpflxm/
+#                       riemann_*/cmpdt behind oracle/ref_shim.f90 (bind(C))
+#   ramses  [NDIM] [mpi|serial] [PATCHDIR]
+#                    -> oracle/_ref/ramses{NDIM}d[_mpi][_<patchname>]
+#                       the whole reference program (own recipe: the ordered
+#                       object list below; the reference's Makefile is not run)
+#
+# The x86-64 baseline target has no FMA, so the objects are bit-reproducible
+# against the reference's own gfortran-made goldens.
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+REF="${RAMSES_REFERENCE:-/root/reference}"
+OUT="$HERE/_ref"
+F90="${F90:-amdflang}"
+OPT="${REF_OPT:--O2}"
+NVECTOR="${NVECTOR:-32}"
+
+if [ ! -d "$REF/hydro" ]; then
+  echo "build_ref.sh: reference tree not found at $REF (prebuilt oracle/_ref is used as is)" >&2
+  exit 0
+fi
+mkdir -p "$OUT"
+
+defines() { # ndim [nvar]
+  local ndim=$1 nvar=${2:-$(( $1 + 2 ))}
+  echo "-cpp -DNVECTOR=$NVECTOR -DNDIM=$ndim -DNPRE=8 -DNENER=0 -DNVAR=$nvar -DSOLVERhydro"
+}
+
+build_kernels() { # ndim [nvar]: nvar>ndim+2 adds passive scalars (tag _vN)
+  local ndim=$1 nvar=${2:-$(( $1 + 2 ))}
+  local tag="${ndim}d"
+  [ "$nvar" != "$((ndim+2))" ] && tag="${ndim}d_v${nvar}"
+  local obj="$OUT/obj_kernels${tag}"
+  mkdir -p "$obj"
+  local flags="$(defines $ndim $nvar) -DWITHOUTMPI -fPIC $OPT -module-dir $obj -I$obj"
+  local srcs=(amr/amr_parameters.f90 hydro/hydro_parameters.f90 hydro/hydro_commons.f90
+              hydro/umuscl.f90 hydro/uplmde.f90 hydro/godunov_utils.f90)
+  local objs=()
+  # hydro_commons needs amr_commons only for its module 'const'? compile the
+  # minimal chain and let the compiler tell us if something is missing.
+  for s in "${srcs[@]}"; do
+    local o="$obj/$(basename "${s%.f90}").o"
+    $F90 $flags -c "$REF/$s" -o "$o"
+    objs+=("$o")
+  done
+  $F90 $flags -c "$HERE/ref_shim.f90" -o "$obj/ref_shim.o"
+  $F90 -shared -o "$OUT/libref_kernels${tag}.so" "${objs[@]}" "$obj/ref_shim.o"
+  echo "built $OUT/libref_kernels${tag}.so"
+}
+
+# Ordered object list of the full program (module files first), resolved
+# through the same search order the reference uses: PATCH, hydro, pm, poisson,
+# amr, io.
+MODSRC="mpi_mod amr_parameters amr_commons random pm_parameters sink_feedback_parameters
+ pm_commons poisson_parameters dump_utils constants file_module
+ poisson_commons hydro_parameters hydro_commons cooling_module bisection sparse_mat
+ clfind_commons gadgetreadfile write_makefile write_patch write_gitinfo sink_sn_feedback"
+AMRSRC="read_params init_amr init_time init_refine tracer_utils adaptive_loop amr_step
+ update_time output_amr flag_utils physical_boundaries virtual_boundaries refine_utils
+ nbors_utils hilbert load_balance title sort cooling_fine eos units light_cone movie
+ memory end"
+PMSRC="init_part output_part rho_fine synchro_fine move_fine newdt_fine particle_tree
+ add_list remove_list star_formation sink_particle feedback clump_finder clump_merger
+ output_clump flag_formation_sites init_sink output_sink unbinding merger_tree
+ move_tracer init_tracer read_sink_feedback_params sink_rt_feedback stellar_particle
+ init_stellar output_stellar"
+POISSONSRC="init_poisson phi_fine_cg interpol_phi force_fine multigrid_coarse
+ multigrid_fine_commons multigrid_fine_fine multigrid_fine_coarse gravana
+ boundary_potential rho_ana output_poisson"
+HYDROSRC="init_hydro init_flow_fine write_screen output_hydro courant_fine godunov_fine
+ uplmde umuscl interpol_hydro godunov_utils condinit hydro_flag hydro_boundary boundana
+ read_hydro_params synchro_hydro_fine cooling_module_ism"
+
+build_ramses() {
+  local ndim=$1 mode=${2:-serial} patch=${3:-}
+  local tag="ramses${ndim}d"
+  [ "$mode" = mpi ] && tag="${tag}_mpi"
+  [ -n "$patch" ] && tag="${tag}_$(basename "$patch")"
+  local obj="$OUT/obj_$tag" gen="$OUT/gen_$tag"
+  mkdir -p "$obj" "$gen"
+  local flags="$(defines $ndim) $OPT -module-dir $obj -I$obj -I$REF"
+  local libs=""
+  if [ "$mode" = mpi ]; then
+    flags="$flags -DMPI_OLD -I/opt/conda/include"
+    libs="-L/opt/conda/lib -lmpifort -lmpi -Wl,-rpath,/opt/conda/lib"
+  else
+    flags="$flags -DWITHOUTMPI"
+  fi
+  local extra_objs=""
+  if [ -n "$patch" ] && [ -f "$patch/build_flags.sh" ]; then
+    # a patch may add compile flags / extra objects / link libraries
+    # shellcheck disable=SC1090
+    source "$patch/build_flags.sh"
+    flags="$flags ${PATCH_FFLAGS:-}"
+    libs="$libs ${PATCH_LIBS:-}"
+    extra_objs="${PATCH_EXTRA_SRC:-}"
+  fi
+  # generated stubs the reference's Makefile would create with shell scripts
+  cat > "$gen/write_makefile.f90" <<'EOF'
+subroutine output_makefile(filename)
+  character(LEN=80)::filename
+  open(unit=11,file=TRIM(filename),form='formatted')
+  write(11,'(A)')'built by oracle/build_ref.sh'
+  close(11)
+end subroutine output_makefile
+EOF
+  cat > "$gen/write_patch.f90" <<'EOF'
+subroutine output_patch(filename)
+  character(LEN=80)::filename
+  open(unit=11,file=TRIM(filename),form='formatted')
+  write(11,'(A)')'see oracle/build_ref.sh'
+  close(11)
+end subroutine output_patch
+EOF
+  if [ "$ndim" != 3 ]; then
+    # flang rejects a rank-mismatched assignment in dead NDIM<3 code of
+    # pm/sink_sn_feedback.f90; fix it on the fly.
+    sed 's/xx(i,:)=xg(ind_grid(i),:)+xc(ind,:)/xx(i,1:ndim)=xg(ind_grid(i),1:ndim)+xc(ind,1:ndim)/' \
+        "$REF/pm/sink_sn_feedback.f90" > "$gen/sink_sn_feedback.f90"
+  fi
+  find_src() { # name -> path
+    local n=$1
+    for d in "$patch" "$gen" "$REF/hydro" "$REF/pm" "$REF/poisson" "$REF/amr" "$REF/io"; do
+      [ -n "$d" ] || continue
+      for ext in f90 F; do
+        if [ -f "$d/$n.$ext" ]; then echo "$d/$n.$ext"; return; fi
+      done
+    done
+    echo "MISSING:$n" >&2; return 1
+  }
+  local objs=()
+  local gitdefs="-DPATCH='$(basename "${patch:-none}")' -DGITBRANCH='ref' -DGITHASH='\"ref\"' -DGITREPO='ref' -DBUILDDATE='\"oracle\"'"
+  for n in $MODSRC $extra_objs $AMRSRC $HYDROSRC $PMSRC $POISSONSRC ramses; do
+    local src; src=$(find_src "$n")
+    local o="$obj/$n.o"
+    if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "${FORCE:-0}" = 1 ]; then
+      if [ "$n" = write_gitinfo ]; then
+        eval $F90 -O0 -cpp $gitdefs -module-dir "$obj" -I"$obj" -c "$src" -o "$o"
+      else
+        $F90 $flags -c "$src" -o "$o" 2> "$obj/$n.log" || { cat "$obj/$n.log"; exit 1; }
+      fi
+    fi
+    objs+=("$o")
+  done
+  $F90 "${objs[@]}" -o "$OUT/$tag" $libs
+  echo "built $OUT/$tag"
+}
+
+cmd=${1:-kernels}
+case "$cmd" in
+  kernels) build_kernels "${2:-3}" "${3:-}";;
+  ramses) build_ramses "${2:-3}" "${3:-serial}" "${4:-}";;
+  all) build_kernels 3; build_kernels 1; build_kernels 2; build_kernels 3 7; build_ramses 3 serial;;
+  *) echo "usage: $0 kernels [NDIM] | ramses [NDIM] [serial|mpi] [PATCHDIR] | all"; exit 2;;
+esac

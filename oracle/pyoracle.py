@@ -1,0 +1,199 @@
+"""pyoracle.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes bindings for oracle/liboracle.so (the C restatement) and, when present,
+oracle/_ref/libref_kernels{N}d.so (the reference's own routines compiled by
+oracle/build_ref.sh).  Imported only by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by the product package ramses_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+RIEMANN = {"llf": 0, "hllc": 1, "hll": 2, "acoustic": 3, "exact": 4}
+SCHEME = {"muscl": 0, "plmde": 1}
+
+
+class HydroParams(C.Structure):
+    _fields_ = [
+        ("ndim", C.c_int), ("nvar", C.c_int),
+        ("gamma", C.c_double), ("smallr", C.c_double), ("smallc", C.c_double),
+        ("slope_type", C.c_int), ("slope_theta", C.c_double),
+        ("riemann", C.c_int), ("scheme", C.c_int), ("niter_riemann", C.c_int),
+        ("difmag", C.c_double),
+    ]
+
+
+def make_params(ndim=3, nvar=None, gamma=1.4, smallr=1e-10, smallc=1e-10,
+                slope_type=1, slope_theta=1.5, riemann="llf", scheme="muscl",
+                niter_riemann=10, difmag=0.0):
+    """Defaults are hydro/hydro_parameters.f90:75-89."""
+    return HydroParams(ndim, nvar if nvar else ndim + 2, gamma, smallr, smallc,
+                       slope_type, slope_theta, RIEMANN[riemann], SCHEME[scheme],
+                       niter_riemann, difmag)
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", HERE, "liboracle.so"])
+
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build_oracle()
+        L = C.CDLL(path)
+        L.ora_unsplit.argtypes = [C.POINTER(HydroParams), _dp, _dp, _dp, _dp,
+                                  C.c_double, C.c_double, C.c_double, C.c_double,
+                                  C.c_int, C.c_int]
+        L.ora_unsplit.restype = None
+        L.ora_riemann.argtypes = [C.POINTER(HydroParams), _dp, _dp, _dp, C.c_int, C.c_int]
+        L.ora_riemann.restype = None
+        L.ora_godunov_uniform.argtypes = [C.POINTER(HydroParams), _dp, C.c_void_p, _dp,
+                                          C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.ora_godunov_uniform.restype = None
+        L.ora_courant_uniform.argtypes = [C.POINTER(HydroParams), _dp, C.c_void_p,
+                                          C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.ora_courant_uniform.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def patch_shapes(ndim, nvar, nvector):
+    """Fortran-order shapes of the reference's patch arrays, returned as the
+    equivalent C-order numpy shapes (reversed)."""
+    nc = [6 if d < ndim else 1 for d in range(3)]
+    nf = [3 if d < ndim else 1 for d in range(3)]
+    uin = (nvar, nc[2], nc[1], nc[0], nvector)
+    grav = (ndim, nc[2], nc[1], nc[0], nvector)
+    flux = (ndim, nvar, nf[2], nf[1], nf[0], nvector)
+    tmp = (ndim, 2, nf[2], nf[1], nf[0], nvector)
+    return uin, grav, flux, tmp
+
+
+def unsplit(p, uin, gravin, dx, dt, ngrid=None):
+    """ora_unsplit on arrays shaped as patch_shapes(); returns (flux, tmp)."""
+    nvector = uin.shape[-1]
+    ngrid = nvector if ngrid is None else ngrid
+    _, _, fs, ts = patch_shapes(p.ndim, p.nvar, nvector)
+    flux = np.zeros(fs)
+    tmp = np.zeros(ts)
+    lib().ora_unsplit(C.byref(p), np.ascontiguousarray(uin), np.ascontiguousarray(gravin),
+                      flux, tmp, dx, dx, dx, dt, ngrid, nvector)
+    return flux, tmp
+
+
+def riemann(p, qleft, qright):
+    """qleft/qright: (nvar, nvector) -> fgdnv (nvar+1, nvector)."""
+    nvector = qleft.shape[-1]
+    fg = np.zeros((p.nvar + 1, nvector))
+    lib().ora_riemann(C.byref(p), np.ascontiguousarray(qleft), np.ascontiguousarray(qright),
+                      fg, nvector, nvector)
+    return fg
+
+
+def godunov_uniform(p, uold, dx, dt, grav=None):
+    """One godunov_fine sweep on a periodic uniform brick uold[nvar,nz,ny,nx];
+    returns unew (set_unew + godfine1 updates)."""
+    nvar, nz, ny, nx = uold.shape
+    uold = np.ascontiguousarray(uold)
+    unew = uold.copy()
+    gptr = None
+    if grav is not None:
+        grav = np.ascontiguousarray(grav)
+        gptr = grav.ctypes.data_as(C.c_void_p)
+    lib().ora_godunov_uniform(C.byref(p), uold, gptr, unew, nx, ny, nz, dx, dt)
+    return unew
+
+
+def courant_uniform(p, uold, dx, courant_factor, grav=None):
+    nvar, nz, ny, nx = uold.shape
+    gptr = None
+    if grav is not None:
+        grav = np.ascontiguousarray(grav)
+        gptr = grav.ctypes.data_as(C.c_void_p)
+    return lib().ora_courant_uniform(C.byref(p), np.ascontiguousarray(uold), gptr,
+                                     nx, ny, nz, dx, courant_factor)
+
+
+# --------------------------------------------------------------------------
+# the reference's own routines (oracle/_ref, built from /root/reference)
+# --------------------------------------------------------------------------
+_ref = {}
+
+
+def _ref_path(ndim, nvar=None):
+    tag = "%dd" % ndim if nvar in (None, ndim + 2) else "%dd_v%d" % (ndim, nvar)
+    return os.path.join(HERE, "_ref", "libref_kernels%s.so" % tag)
+
+
+def ref_available(ndim=3, nvar=None):
+    return os.path.exists(_ref_path(ndim, nvar))
+
+
+def ref(ndim=3, nvar=None):
+    key = (ndim, nvar if nvar else ndim + 2)
+    if key not in _ref:
+        L = C.CDLL(_ref_path(ndim, nvar))
+        L.ref_get_dims.argtypes = [C.POINTER(C.c_int)] * 3
+        L.ref_set_hydro_params.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int,
+                                           C.c_double, C.c_int, C.c_int, C.c_int,
+                                           C.c_double, C.c_double]
+        L.ref_unsplit.argtypes = [_dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double,
+                                  C.c_double, C.c_int]
+        L.ref_riemann.argtypes = [_dp, _dp, _dp, C.c_int]
+        L.ref_cmpdt.argtypes = [_dp, _dp, C.c_double, C.POINTER(C.c_double), C.c_int]
+        _ref[key] = L
+    return _ref[key]
+
+
+def ref_dims(ndim=3, nvar=None):
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    ref(ndim, nvar).ref_get_dims(C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def ref_set_params(p, courant_factor=0.5):
+    ref(p.ndim, p.nvar).ref_set_hydro_params(p.gamma, p.smallr, p.smallc, p.slope_type,
+                                     p.slope_theta, p.riemann, p.scheme,
+                                     p.niter_riemann, p.difmag, courant_factor)
+
+
+def ref_unsplit(p, uin, gravin, dx, dt, ngrid=None):
+    nvector = uin.shape[-1]
+    ngrid = nvector if ngrid is None else ngrid
+    assert ref_dims(p.ndim, p.nvar) == (p.ndim, p.nvar, nvector)
+    ref_set_params(p)
+    _, _, fs, ts = patch_shapes(p.ndim, p.nvar, nvector)
+    flux = np.zeros(fs)
+    tmp = np.zeros(ts)
+    ref(p.ndim, p.nvar).ref_unsplit(np.ascontiguousarray(uin), np.ascontiguousarray(gravin),
+                            flux, tmp, dx, dx, dx, dt, ngrid)
+    return flux, tmp
+
+
+def ref_riemann(p, qleft, qright):
+    nvector = qleft.shape[-1]
+    assert ref_dims(p.ndim, p.nvar) == (p.ndim, p.nvar, nvector)
+    ref_set_params(p)
+    fg = np.zeros((p.nvar + 1, nvector))
+    ref(p.ndim, p.nvar).ref_riemann(np.ascontiguousarray(qleft), np.ascontiguousarray(qright), fg, nvector)
+    return fg
+
+
+def ref_cmpdt(p, uu, gg, dx, courant_factor):
+    """uu: (nvar, nvector) conservative, gg: (ndim, nvector)."""
+    nvector = uu.shape[-1]
+    ref_set_params(p, courant_factor)
+    dt = C.c_double()
+    ref(p.ndim, p.nvar).ref_cmpdt(np.ascontiguousarray(uu).copy(), np.ascontiguousarray(gg), dx,
+                          C.byref(dt), nvector)
+    return dt.value
