@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""bench.py -- cell-updates/s of the Godunov sweep on a uniform Sedov3D level.
+
+    python bench.py --gpus N --steps K --warmup W [--n 512] [--fast 0|1]
+
+One "step" = one godunov_fine pass over this rank's level brick (+ the halo
+exchange of uold for N>1): the fused set_unew+godunov_fine+set_uold kernel of
+libramses_amd.so, with the state already resident in HBM.  Weak scaling: every
+rank owns an n^3 brick of a (n*px, n*py, n*pz) periodic Sedov3D box.
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md "Measurement").
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_CELL_UPDATE = 80   # read uold + write unew, nvar=5, FP64
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=512, help="cells per direction of each rank's brick")
+    ap.add_argument("--fast", type=int, default=1, help="1: FMA-contracted build (<=1e-12 of strict), 0: strict")
+    ap.add_argument("--zchunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def rank_grid(nranks):
+    """Octant-style decomposition (the Hilbert split of a uniform grid gives
+    axis-aligned bricks for 2^k ranks)."""
+    p = [1, 1, 1]
+    d = 0
+    r = nranks
+    while r > 1:
+        assert r % 2 == 0, "rank count must be a power of two"
+        p[d] *= 2
+        r //= 2
+        d = (d + 1) % 3
+    return tuple(p)
+
+
+def cpu_baseline(n_ref=48, steps=1):
+    """Time the CPU oracle (a scalar C port of the reference algorithm) on a
+    bounded sample of the same workload: `steps` sweeps of an n_ref^3 Sedov box."""
+    from oracle import pyoracle
+    from ramses_amd import ic
+    u, dx = ic.sedov3d(n_ref)
+    p = pyoracle.make_params()
+    dt = pyoracle.courant_uniform(p, u, dx, 0.8)
+    pyoracle.godunov_uniform(p, u[:, :8, :8, :8].copy(), dx, dt)  # warm the library
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        u = pyoracle.godunov_uniform(p, u, dx, dt)
+    t = time.perf_counter() - t0
+    return {"value": n_ref ** 3 * steps / t, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": "%d sweep(s) of a %d^3 Sedov3D level, oracle/hydro_oracle.c (godfine1+unsplit restatement), %.1f s"
+                      % (steps, n_ref, t)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import ramses_amd
+    from ramses_amd import ic
+    from ramses_amd.hydro import HydroLevel
+    from ramses_amd._capi import lib, check
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.n
+    pgrid = rank_grid(world)
+    if args.zchunk:
+        check(lib().ramses_amd_godunov_tune(0, args.zchunk))
+    params = ramses_amd.make_params(courant_factor=0.8, fast_math=bool(args.fast))
+    if world == 1:
+        lev = HydroLevel(n, n, n, 0.5 / n, params=params, ng=0)
+        u, dx = ic.sedov3d(n) if n <= 256 else (None, 0.5 / n)
+        if u is None:
+            # build the IC on the device to avoid a 5 GB host array
+            lev.uold[0].fill_(1.0)
+            gam = 1.4
+            lev.uold[4].fill_(1e-5 / (gam - 1.0))
+            lev.uold[4, 0, 0, 0] = (1e-5 + 0.4 * 0.125 / dx ** 3) / (gam - 1.0)
+        else:
+            lev.upload(u)
+        exchange = None
+    else:
+        from ramses_amd.parallel import BrickDecomposition
+        dec = BrickDecomposition(pgrid, rank, n, boxlen=0.5 * pgrid[0])
+        lev = dec.make_level(params)
+        dec.init_sedov(lev)
+        exchange = dec
+        dx = lev.dx
+        exchange.make_virtual_fine_dp(lev)
+
+    # one CFL step size for the whole run (min over ranks): dt only shrinks the
+    # update, never changes the work per cell
+    dt = lev.courant_fine()[0]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        dt = float(t.item())
+
+    def step():
+        lev.godunov_fine(dt)
+        lev.set_uold()
+        if exchange is not None:
+            exchange.make_virtual_fine_dp(lev)
+
+    for _ in range(args.warmup):
+        step()
+
+    # ---- timed region --------------------------------------------------------
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()           # same (current) stream the kernels launch on
+        lev.godunov_fine(dt)
+        ev[i][1].record()
+        lev.set_uold()
+        if exchange is not None:
+            exchange.make_virtual_fine_dp(lev)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+
+    # sanity: the state must still be physical
+    chk = lev.courant_fine()
+    assert chk[0] > 0 and chk[1] > 0
+
+    if rank == 0:
+        cells = n ** 3
+        value = cells * world * args.steps / elapsed
+        achieved = cells * BYTES_PER_CELL_UPDATE / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "cell-updates/s (Godunov sweep), uniform Sedov3D",
+            "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "sedov3d.nml uniform %d^3 per GPU (%dx%dx%d ranks, global %dx%dx%d), "
+                                   "hydro-only Godunov sweep, LLF + minmod, muscl"
+                                   % (n, pgrid[0], pgrid[1], pgrid[2], n * pgrid[0], n * pgrid[1], n * pgrid[2]),
+                       "arithmetic": "fast (FMA contraction, <=1e-12 rel of strict)" if args.fast else "strict (bit-identical to the reference)",
+                       "halo": "none (single rank, in-kernel periodic wrap)" if world == 1 else "RCCL send/recv of 2-cell face slabs, all nvar fused"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "godunov_sweep_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL_UPDATE},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+/*
+ * ramses_amd.h -- C ABI of libramses_amd.so, the MI355X (gfx950) native
+ * implementation of the RAMSES per-level hot path: Godunov hydro sweep,
+ * multigrid Poisson smoother and virtual-boundary halo packing.
+ *
+ * Plain C types only (pointers, sizes, PODs): this is what the reference's
+ * Fortran side binds through ISO_C_BINDING (see ramses_amd/patch/ and
+ * INTEGRATION.md) and what the Python host mirror binds through ctypes.
+ *
+ * Every entry point returns 0 on success, a negative RAMSES_AMD_E* code on
+ * failure; ramses_amd_last_error() returns a description.  The reference has
+ * no error returns on this path (it prints and calls clean_stop ->
+ * MPI_ABORT, amr/end.f90:26-46); the Fortran shims call clean_stop when a
+ * status is non-zero.  There is NO CPU fallback anywhere behind this ABI.
+ *
+ * Device layout ("level brick").  A fully refined level (or one rank's
+ * Hilbert/octant share of it) is stored as one dense SoA block per conserved
+ * variable:      u[ivar][k][j][i]     (i fastest, FP64)
+ * with variable order rho, rho*u, rho*v, rho*w, E (hydro/condinit.f90:17-20)
+ * and optional ghost layers of width g (0 or >=2 cells) on every side.  With
+ * g = 0 the sweep wraps periodically in-kernel (single-rank periodic box);
+ * with g >= 2 the ghost cells must have been filled (halo exchange or
+ * physical boundary fill) before the sweep, exactly like the reference's
+ * virtual-boundary octs (amr/virtual_boundaries.f90:373-528).
+ */
+#ifndef RAMSES_AMD_H
+#define RAMSES_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAMSES_AMD_OK 0
+#define RAMSES_AMD_EINVAL (-1)      /* bad argument                          */
+#define RAMSES_AMD_EUNSUPPORTED (-2)/* knob combination not implemented      */
+#define RAMSES_AMD_EHIP (-3)        /* HIP runtime error                     */
+#define RAMSES_AMD_ENODEVICE (-4)   /* no gfx950 device visible              */
+
+/* riemann= of &HYDRO_PARAMS (hydro/umuscl.f90:791-804) */
+enum { RAMSES_AMD_RIEMANN_LLF = 0, RAMSES_AMD_RIEMANN_HLLC = 1,
+       RAMSES_AMD_RIEMANN_HLL = 2, RAMSES_AMD_RIEMANN_ACOUSTIC = 3,
+       RAMSES_AMD_RIEMANN_EXACT = 4 };
+/* scheme= of &HYDRO_PARAMS (hydro/umuscl.f90:73-94) */
+enum { RAMSES_AMD_SCHEME_MUSCL = 0, RAMSES_AMD_SCHEME_PLMDE = 1 };
+
+/* Solver knobs = the &HYDRO_PARAMS namelist group
+ * (hydro/read_hydro_params.f90:43-54, defaults hydro/hydro_parameters.f90:75-89).
+ * Replaces the module variables of hydro_parameters that the reference's
+ * unsplit() reads implicitly. */
+typedef struct ramses_amd_hydro_params {
+  int32_t ndim;           /* NDIM of the RAMSES build (3 supported on device) */
+  int32_t nvar;           /* NVAR (= ndim+2, NENER=0)                         */
+  double gamma;
+  double smallr;
+  double smallc;
+  int32_t slope_type;     /* 1 minmod, 2 moncen, 3 positivity, 7 van Leer, 8 theta */
+  int32_t riemann;        /* RAMSES_AMD_RIEMANN_*                             */
+  double slope_theta;
+  int32_t scheme;         /* RAMSES_AMD_SCHEME_*                              */
+  int32_t niter_riemann;
+  double difmag;
+  double courant_factor;
+  /* arithmetic mode: 0 = strict (operation order of the reference, no FMA
+   * contraction, IEEE division: bit-identical to the reference's x86-64
+   * build), 1 = fast (FMA contraction + reciprocal reuse; <=1e-12 relative
+   * L-infinity of the strict path, the tolerance north_star states). */
+  int32_t fast_math;
+  int32_t reserved;
+} ramses_amd_hydro_params;
+
+/* Geometry of one level brick on the device. */
+typedef struct ramses_amd_brick {
+  int32_t nx, ny, nz;     /* interior cells per direction                     */
+  int32_t ng;             /* ghost width on every side: 0 (periodic wrap) or >=2 */
+  int64_t pitch_y;        /* stride between j rows, in doubles                */
+  int64_t pitch_z;        /* stride between k planes, in doubles              */
+  int64_t pitch_var;      /* stride between variables, in doubles             */
+} ramses_amd_brick;
+
+/* Fills pitches for a densely packed brick of (n+2*ng)^3 cells. */
+void ramses_amd_brick_dense(ramses_amd_brick *b, int nx, int ny, int nz, int ng);
+
+const char *ramses_amd_last_error(void);
+/* ABI guard for foreign-language bindings: pass the binding's own sizeof of
+ * the two structs; returns 0 when they match this library's layout. */
+int ramses_amd_abi_check(size_t sizeof_hydro_params, size_t sizeof_brick);
+/* Number of HIP devices; fills name (<=255 chars) of device 0. */
+int ramses_amd_device_info(char *name, size_t name_len, int *n_cu, size_t *hbm_bytes);
+
+/* ---------------------------------------------------------------------------
+ * godunov_fine(ilevel) on a fully refined level brick.
+ * Replaces: hydro/godunov_fine.f90:5-35 (godunov_fine) + :486-911 (godfine1)
+ *           + hydro/umuscl.f90:22-171 (unsplit) and everything it calls, and
+ *           fuses set_unew (hydro/godunov_fine.f90:40-130): on exit
+ *           unew = uold + sum_d (F_left - F_right)   (x, then y, then z).
+ * d_uold, d_unew: device pointers, brick layout b (distinct buffers).
+ * d_grav: device pointer to the gravitational acceleration f(:,1:ndim) in the
+ *         same brick layout with ndim variables, or NULL when poisson=.false.
+ * dx = cell size of the level, dt = dtnew(ilevel).
+ * stream: hipStream_t (as void*), NULL = default stream.  Asynchronous.
+ * ------------------------------------------------------------------------- */
+int ramses_amd_godunov_brick(const ramses_amd_hydro_params *p,
+                             const ramses_amd_brick *b, const double *d_uold,
+                             const double *d_grav, double *d_unew, double dx,
+                             double dt, void *stream);
+
+/* Tuning knobs of the sweep (tile rows per workgroup, planes per z-chunk);
+ * 0 keeps the built-in default.  Results do not depend on them. */
+int ramses_amd_godunov_tune(int tile_rows, int zchunk);
+
+/* ---------------------------------------------------------------------------
+ * courant_fine(ilevel) on a level brick: the CFL time step.
+ * Replaces: hydro/courant_fine.f90:1-159 + cmpdt hydro/godunov_utils.f90:5-120.
+ * d_out: device pointer to 4 doubles {dt, mass, e_kin+e_int (total energy),
+ *        e_int}; dt = min over cells, the sums are over interior cells * dx^3
+ *        (courant_fine.f90:100-124).  d_out must be initialised by the caller
+ *        through ramses_amd_courant_init().  Asynchronous on stream.
+ * ------------------------------------------------------------------------- */
+int ramses_amd_courant_init(const ramses_amd_hydro_params *p, double dx,
+                            double *d_out, void *stream);
+int ramses_amd_courant_brick(const ramses_amd_hydro_params *p,
+                             const ramses_amd_brick *b, const double *d_uold,
+                             const double *d_grav, double dx, double *d_out,
+                             void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Periodic ghost fill of a brick with ng>=2 from its own interior (the
+ * single-rank limit of make_virtual_fine_dp, amr/virtual_boundaries.f90:373-528:
+ * on one rank a periodic neighbour oct IS the oct on the other side).
+ * axes: bit 0 = x, bit 1 = y, bit 2 = z.  nvar variables.
+ * ------------------------------------------------------------------------- */
+int ramses_amd_fill_ghosts_periodic(const ramses_amd_brick *b, double *d_u,
+                                    int nvar, int axes, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Halo pack / unpack for the multi-rank exchange.
+ * Replaces the pack (amr/virtual_boundaries.f90:454-464) and unpack
+ * (:492-506) loops of make_virtual_fine_dp, with all nvar fields fused in one
+ * message per peer.  A face slab is the 2-cell-thick (= one oct) layer next
+ * to face `face` (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z).  pack copies the INTERIOR
+ * slab adjacent to the face into d_buf; unpack copies d_buf into the GHOST
+ * slab beyond the face.  Slabs span the full allocated extent (ghosts
+ * included) of the axes already exchanged, so exchanging x, then y, then z
+ * also fills edges and corners (the 26-neighbour stencil of godfine1).
+ * Returns the number of doubles in the slab (also when d_buf is NULL).
+ * ------------------------------------------------------------------------- */
+int64_t ramses_amd_halo_slab_size(const ramses_amd_brick *b, int nvar, int face);
+int ramses_amd_halo_pack(const ramses_amd_brick *b, const double *d_u, int nvar,
+                         int face, double *d_buf, void *stream);
+int ramses_amd_halo_unpack(const ramses_amd_brick *b, double *d_u, int nvar,
+                           int face, const double *d_buf, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAMSES_AMD_H */

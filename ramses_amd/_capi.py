@@ -1,0 +1,99 @@
+"""ctypes binding of libramses_amd.so (the C ABI in include/ramses_amd.h).
+
+The library is the product: if it is missing or cannot be loaded this module
+raises -- there is no Python/CPU fallback for any compute entry point.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libramses_amd.so")
+
+RIEMANN = {"llf": 0, "hllc": 1, "hll": 2, "acoustic": 3, "exact": 4}
+SCHEME = {"muscl": 0, "plmde": 1}
+
+
+class RamsesAmdError(RuntimeError):
+    pass
+
+
+class HydroParams(C.Structure):
+    """struct ramses_amd_hydro_params (= &HYDRO_PARAMS, hydro/hydro_parameters.f90:75-89)."""
+    _fields_ = [
+        ("ndim", C.c_int32), ("nvar", C.c_int32),
+        ("gamma", C.c_double), ("smallr", C.c_double), ("smallc", C.c_double),
+        ("slope_type", C.c_int32), ("riemann", C.c_int32),
+        ("slope_theta", C.c_double),
+        ("scheme", C.c_int32), ("niter_riemann", C.c_int32),
+        ("difmag", C.c_double), ("courant_factor", C.c_double),
+        ("fast_math", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class Brick(C.Structure):
+    """struct ramses_amd_brick."""
+    _fields_ = [
+        ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("ng", C.c_int32),
+        ("pitch_y", C.c_int64), ("pitch_z", C.c_int64), ("pitch_var", C.c_int64),
+    ]
+
+
+_lib = None
+
+# every symbol include/ramses_amd.h declares: (name, restype, argtypes)
+_vp, _i, _d, _i64 = C.c_void_p, C.c_int, C.c_double, C.c_int64
+_PP, _PB = C.POINTER(HydroParams), C.POINTER(Brick)
+SYMBOLS = [
+    ("ramses_amd_last_error", C.c_char_p, []),
+    ("ramses_amd_abi_check", _i, [C.c_size_t, C.c_size_t]),
+    ("ramses_amd_brick_dense", None, [_PB, _i, _i, _i, _i]),
+    ("ramses_amd_device_info", _i, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    ("ramses_amd_godunov_brick", _i, [_PP, _PB, _vp, _vp, _vp, _d, _d, _vp]),
+    ("ramses_amd_godunov_tune", _i, [_i, _i]),
+    ("ramses_amd_courant_init", _i, [_PP, _d, _vp, _vp]),
+    ("ramses_amd_courant_brick", _i, [_PP, _PB, _vp, _vp, _d, _vp, _vp]),
+    ("ramses_amd_fill_ghosts_periodic", _i, [_PB, _vp, _i, _i, _vp]),
+    ("ramses_amd_halo_slab_size", _i64, [_PB, _i, _i]),
+    ("ramses_amd_halo_pack", _i, [_PB, _vp, _i, _i, _vp, _vp]),
+    ("ramses_amd_halo_unpack", _i, [_PB, _vp, _i, _i, _vp, _vp]),
+]
+
+
+def lib():
+    """Load libramses_amd.so; raise loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RamsesAmdError(
+                "%s is missing: build it with `python -m ramses_amd.build` "
+                "(__graft_entry__.build()). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        if L.ramses_amd_abi_check(C.sizeof(HydroParams), C.sizeof(Brick)) != 0:
+            raise RamsesAmdError(L.ramses_amd_last_error().decode())
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RamsesAmdError("libramses_amd: error %d: %s" % (rc, lib().ramses_amd_last_error().decode()))
+
+
+def make_params(ndim=3, nvar=None, gamma=1.4, smallr=1e-10, smallc=1e-10, slope_type=1,
+                slope_theta=1.5, riemann="llf", scheme="muscl", niter_riemann=10,
+                difmag=0.0, courant_factor=0.5, fast_math=False):
+    """Defaults are the reference's (hydro/hydro_parameters.f90:75-89)."""
+    return HydroParams(ndim, nvar if nvar else ndim + 2, gamma, smallr, smallc, slope_type,
+                       RIEMANN[riemann] if isinstance(riemann, str) else riemann, slope_theta,
+                       SCHEME[scheme] if isinstance(scheme, str) else scheme, niter_riemann,
+                       difmag, courant_factor, 1 if fast_math else 0, 0)
+
+
+def dense_brick(nx, ny, nz, ng):
+    b = Brick()
+    lib().ramses_amd_brick_dense(C.byref(b), nx, ny, nz, ng)
+    return b

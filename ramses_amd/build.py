@@ -1,0 +1,89 @@
+"""Build libramses_amd.so (hand-written HIP kernels + C ABI) for gfx950.
+
+hipcc cross-compiles without a GPU.  Objects are cached on source mtimes under
+ramses_amd/build/ and the shared library is written IN-TREE to
+ramses_amd/lib/libramses_amd.so so that it travels to the GPU box.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+BUILD = os.path.join(HERE, "build")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libramses_amd.so")
+ARCH = "gfx950"
+
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
+          "-I", os.path.join(HERE, "..", "include")]
+
+# (object name, source, extra flags)
+UNITS = [
+    ("hydro_sweep_strict.o", "hydro_sweep.hip", ["-ffp-contract=off"]),
+    ("hydro_sweep_fast.o", "hydro_sweep.hip", ["-ffp-contract=fast", "-DRAMSES_AMD_FAST=1"]),
+    ("hydro_misc.o", "hydro_misc.hip", ["-ffp-contract=off"]),
+    ("mg_kernels.o", "mg_kernels.hip", ["-ffp-contract=off"]),
+    ("octree_pack.o", "octree_pack.hip", ["-ffp-contract=off"]),
+    ("capi.o", "capi.hip", ["-ffp-contract=off"]),
+]
+
+
+def _hipcc():
+    for c in ("hipcc", "/opt/rocm/bin/hipcc"):
+        try:
+            subprocess.check_output([c, "--version"], stderr=subprocess.STDOUT)
+            return c
+        except (OSError, subprocess.CalledProcessError):
+            continue
+    raise RuntimeError("hipcc not found: libramses_amd.so cannot be built")
+
+
+def _deps():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))] + \
+           [os.path.join(HERE, "..", "include", "ramses_amd.h")]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(BUILD, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    deps = _deps()
+    jobs = []
+    objs = []
+    for obj, src, flags in UNITS:
+        srcp = os.path.join(CSRC, src)
+        if not os.path.exists(srcp):
+            continue
+        objp = os.path.join(BUILD, obj)
+        objs.append(objp)
+        if force or _stale(objp, [srcp] + deps):
+            jobs.append([hipcc] + COMMON + flags + ["-c", srcp, "-o", objp])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stdout))
+        return r.stdout
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 2)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or _stale(LIB, objs):
+        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, verbose=True)
+    print("built", path)

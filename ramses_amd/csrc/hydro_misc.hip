@@ -1,0 +1,143 @@
+// hydro_misc.hip -- streaming kernels around the sweep: CFL reduction
+// (courant_fine/cmpdt), periodic ghost fill and halo slab pack/unpack
+// (the pack/unpack loops of make_virtual_fine_dp).  All are pure HBM-bound
+// copies/reductions: coalesced 512 B row segments per wavefront, wavefront
+// shuffles + one atomic per workgroup for the reductions.
+#include <hip/hip_runtime.h>
+
+#include "hydro_core.hpp"
+#include "misc_args.hpp"
+
+namespace ramses_amd {
+
+// ---------------------------------------------------------------------------
+// courant_fine (hydro/courant_fine.f90:1-159) + cmpdt
+// out[0] = min dt (bit pattern min: valid for positive doubles)
+// out[1] = sum rho*vol, out[2] = sum E*vol, out[3] = sum e_int*vol
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = __builtin_fmin(v, __shfl_down(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <bool GRAV>
+__global__ __launch_bounds__(256) void courant_kernel(CourantArgs A) {
+  constexpr int NV = 5;
+  const HydroConst &P = A.P;
+  const long nrow = (long)A.ny * A.nz;
+  double dtmin = A.dt_init;
+  double mass = 0.0, etot = 0.0, eint = 0.0;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long nwaves = (long)gridDim.x * 4;
+  for (long row = (long)blockIdx.x * 4 + wave; row < nrow; row += nwaves) {
+    const int k = (int)(row / A.ny), j = (int)(row % A.ny);
+    const long base = (long)(j + A.ng) * A.pitch_y + (long)(k + A.ng) * A.pitch_z + A.ng;
+    for (int i = lane; i < A.nx; i += 64) {
+      double u[NV], g[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int n = 0; n < NV; n++) u[n] = A.uold[base + i + (long)n * A.pitch_var];
+      if (GRAV) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) g[d] = A.grav[base + i + (long)d * A.pitch_var];
+      }
+      dtmin = __builtin_fmin(dtmin, cmpdt_cell<NV, GRAV>(u, g, A.dx, A.courant_factor, P));
+      mass += u[0] * A.vol;
+      etot += u[4] * A.vol;
+      double ei = u[4] * A.vol;
+      const double rho = __builtin_fmax(u[0], P.smallr);
+      ei -= 0.5 * (u[1] * u[1]) / rho * A.vol;
+      ei -= 0.5 * (u[2] * u[2]) / rho * A.vol;
+      ei -= 0.5 * (u[3] * u[3]) / rho * A.vol;
+      eint += ei;
+    }
+  }
+  dtmin = wave_min(dtmin);
+  mass = wave_sum(mass); etot = wave_sum(etot); eint = wave_sum(eint);
+  __shared__ double red[4][4];
+  if (lane == 0) { red[wave][0] = dtmin; red[wave][1] = mass; red[wave][2] = etot; red[wave][3] = eint; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double d = red[0][0], m = red[0][1], e = red[0][2], ei = red[0][3];
+    for (int w = 1; w < 4; w++) { d = __builtin_fmin(d, red[w][0]); m += red[w][1]; e += red[w][2]; ei += red[w][3]; }
+    // positive doubles order like their bit patterns
+    atomicMin(reinterpret_cast<unsigned long long *>(A.out), (unsigned long long)__double_as_longlong(d));
+    atomicAdd(A.out + 1, m);
+    atomicAdd(A.out + 2, e);
+    atomicAdd(A.out + 3, ei);
+  }
+}
+
+__global__ void courant_init_kernel(double *out, double dt_init) {
+  out[0] = dt_init; out[1] = 0.0; out[2] = 0.0; out[3] = 0.0;
+}
+
+hipError_t launch_courant_init(double *out, double dt_init, hipStream_t s) {
+  hipLaunchKernelGGL(courant_init_kernel, dim3(1), dim3(1), 0, s, out, dt_init);
+  return hipGetLastError();
+}
+
+hipError_t launch_courant(const CourantArgs &A, bool grav, hipStream_t s) {
+  const long nrow = (long)A.ny * A.nz;
+  int grid = (int)((nrow + 3) / 4);
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  if (grav) hipLaunchKernelGGL(courant_kernel<true>, dim3(grid), dim3(256), 0, s, A);
+  else hipLaunchKernelGGL(courant_kernel<false>, dim3(grid), dim3(256), 0, s, A);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Generic box copy between two strided SoA layouts: the one kernel behind the
+// periodic ghost fill and the halo slab pack/unpack.  One wavefront copies one
+// x-row segment (coalesced on the side whose x stride is 1, which is both
+// sides for y/z slabs; for x slabs the row is only 2 cells long and the slab
+// is tiny).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void box_copy_kernel(BoxCopyArgs A) {
+  const long nrows = (long)A.ey * A.ez * A.nvar;
+  const int lane = threadIdx.x & 63;
+  const long w0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nw = (long)gridDim.x * 4;
+  if (A.ex >= 16) {
+    for (long row = w0; row < nrows; row += nw) {
+      const int j = (int)(row % A.ey);
+      const int k = (int)((row / A.ey) % A.ez);
+      const int n = (int)(row / ((long)A.ey * A.ez));
+      const long so = A.s_off + (long)j * A.s_py + (long)k * A.s_pz + (long)n * A.s_pv;
+      const long dof = A.d_off + (long)j * A.d_py + (long)k * A.d_pz + (long)n * A.d_pv;
+      for (int i = lane; i < A.ex; i += 64) A.dst[dof + i] = A.src[so + i];
+    }
+  } else {
+    // thin-x boxes: flatten (i,j) across lanes
+    const long nplanes = (long)A.ez * A.nvar;
+    const int rowlen = A.ex * A.ey;
+    for (long pl = w0; pl < nplanes; pl += nw) {
+      const int k = (int)(pl % A.ez);
+      const int n = (int)(pl / A.ez);
+      const long so = A.s_off + (long)k * A.s_pz + (long)n * A.s_pv;
+      const long dof = A.d_off + (long)k * A.d_pz + (long)n * A.d_pv;
+      for (int t = lane; t < rowlen; t += 64) {
+        const int i = t % A.ex, j = t / A.ex;
+        A.dst[dof + i + (long)j * A.d_py] = A.src[so + i + (long)j * A.s_py];
+      }
+    }
+  }
+}
+
+hipError_t launch_box_copy(const BoxCopyArgs &A, hipStream_t s) {
+  const long nrows = A.ex >= 16 ? (long)A.ey * A.ez * A.nvar : (long)A.ez * A.nvar;
+  if (nrows <= 0 || A.ex <= 0) return hipSuccess;
+  long grid = (nrows + 3) / 4;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(box_copy_kernel, dim3((int)grid), dim3(256), 0, s, A);
+  return hipGetLastError();
+}
+
+}  // namespace ramses_amd

@@ -1,0 +1,30 @@
+// misc_args.hpp -- argument blocks of the streaming kernels.
+#pragma once
+#include "hydro_core.hpp"
+
+namespace ramses_amd {
+
+struct CourantArgs {
+  const double *uold;
+  const double *grav;
+  double *out;          // {dt, mass, etot, eint}
+  int nx, ny, nz, ng;
+  long pitch_y, pitch_z, pitch_var;
+  double dx, vol, courant_factor, dt_init;
+  HydroConst P;
+};
+
+// copy an (ex,ey,ez) box of nvar variables between two strided layouts
+struct BoxCopyArgs {
+  const double *src;
+  double *dst;
+  int ex, ey, ez, nvar;
+  long s_off, s_py, s_pz, s_pv;
+  long d_off, d_py, d_pz, d_pv;
+};
+
+hipError_t launch_courant_init(double *out, double dt_init, hipStream_t s);
+hipError_t launch_courant(const CourantArgs &A, bool grav, hipStream_t s);
+hipError_t launch_box_copy(const BoxCopyArgs &A, hipStream_t s);
+
+}  // namespace ramses_amd

@@ -1,0 +1,75 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every
+symbol include/ramses_amd.h declares; argument validation fails loudly.
+No compute entry point is executed without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from ramses_amd import build
+    path = build.build()
+    assert os.path.exists(path)
+    return C.CDLL(path)
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "ramses_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(ramses_amd_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_exported(built_lib):
+    names = _declared_symbols()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(built_lib, n), "libramses_amd.so does not export %s" % n
+
+
+def test_python_binding_covers_header():
+    from ramses_amd import _capi
+    bound = {s[0] for s in _capi.SYMBOLS}
+    assert bound == set(_declared_symbols())
+
+
+def test_struct_layout_matches_header(built_lib):
+    from ramses_amd import _capi
+    # ramses_amd_brick_dense fills pitches: checks the Brick layout end to end
+    b = _capi.dense_brick(10, 6, 4, 2)
+    assert (b.nx, b.ny, b.nz, b.ng) == (10, 6, 4, 2)
+    assert b.pitch_y == 14 and b.pitch_z == 14 * 10 and b.pitch_var == 14 * 10 * 8
+    assert built_lib.ramses_amd_abi_check(C.c_size_t(C.sizeof(_capi.HydroParams)),
+                                          C.c_size_t(C.sizeof(_capi.Brick))) == 0
+    assert built_lib.ramses_amd_abi_check(C.c_size_t(8), C.c_size_t(8)) != 0
+
+
+def test_argument_validation_is_loud():
+    from ramses_amd import _capi
+    L = _capi.lib()
+    p = _capi.make_params(ndim=2)
+    b = _capi.dense_brick(8, 8, 8, 0)
+    rc = L.ramses_amd_godunov_brick(C.byref(p), C.byref(b), C.c_void_p(8), None, C.c_void_p(16), 0.1, 0.1, None)
+    assert rc == -2 and b"NDIM=3" in L.ramses_amd_last_error()
+    p = _capi.make_params(scheme="plmde")
+    rc = L.ramses_amd_godunov_brick(C.byref(p), C.byref(b), C.c_void_p(8), None, C.c_void_p(16), 0.1, 0.1, None)
+    assert rc == -2
+    p = _capi.make_params()
+    rc = L.ramses_amd_godunov_brick(C.byref(p), C.byref(b), C.c_void_p(8), None, C.c_void_p(8), 0.1, 0.1, None)
+    assert rc == -1  # uold == unew
+    with pytest.raises(_capi.RamsesAmdError):
+        _capi.check(rc)
+
+
+def test_no_gpu_means_no_silent_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ramses_amd import RamsesAmdError
+    from ramses_amd.hydro import HydroLevel
+    with pytest.raises(RamsesAmdError):
+        HydroLevel(8, 8, 8, 0.1)
