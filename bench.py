@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--n", type=int, default=512, help="cells per direction of each rank's brick")
     ap.add_argument("--fast", type=int, default=1, help="1: FMA-contracted build (<=1e-12 of strict), 0: strict")
     ap.add_argument("--zchunk", type=int, default=0)
+    ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -87,8 +88,8 @@ def main():
 
     n = args.n
     pgrid = rank_grid(world)
-    if args.zchunk:
-        check(lib().ramses_amd_godunov_tune(0, args.zchunk))
+    if args.zchunk or args.tile_rows:
+        check(lib().ramses_amd_godunov_tune(args.tile_rows, args.zchunk))
     params = ramses_amd.make_params(courant_factor=0.8, fast_math=bool(args.fast))
     if world == 1:
         lev = HydroLevel(n, n, n, 0.5 / n, params=params, ng=0)

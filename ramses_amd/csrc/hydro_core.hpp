@@ -40,6 +40,40 @@ RA_DEV double dmind(double a, double b) { return __builtin_fmin(a, b); }
 RA_DEV double fsignd(double a, double b) { return __builtin_copysign(a, b); }
 
 // ---------------------------------------------------------------------------
+// Arithmetic policy.  Strict build: IEEE division and square root (correctly
+// rounded, bit-identical to the reference's x86-64 build).  Fast build
+// (-DRAMSES_AMD_FAST): v_rcp_f64 / v_rsq_f64 seeds + Newton steps, ~1 ulp, no
+// denormal/overflow rescaling (the operands here are densities, pressures and
+// their ratios); held to <=1e-12 relative L-infinity of the strict result.
+// ---------------------------------------------------------------------------
+#ifdef RAMSES_AMD_FAST
+RA_DEV double rcp_fast(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+RA_DEV double ddiv(double a, double b) { return a * rcp_fast(b); }
+RA_DEV double dsqrt(double x) {
+  // Goldschmidt: g -> sqrt(x), h -> 1/(2 sqrt(x))
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  const double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return x == 0.0 ? 0.0 : g;
+}
+#else
+RA_DEV double ddiv(double a, double b) { return a / b; }
+RA_DEV double dsqrt(double x) { return __builtin_sqrt(x); }
+#endif
+
+// ---------------------------------------------------------------------------
 // ctoprim (hydro/umuscl.f90:861-965) for one cell, 3-D, NENER=0.
 // u = (rho, mx, my, mz, E [, scalars]); g = gravity (or 0); q = (rho,u,v,w,P[,s])
 // The sound speed is not produced: only scheme='plmde' reads it.
@@ -48,7 +82,7 @@ template <int NV, bool GRAV>
 RA_DEV void ctoprim_cell(const double (&u)[NV], const double (&g)[3],
                          double dtxhalf, const HydroConst &P, double (&q)[NV]) {
   const double rho = dmaxd(u[0], P.smallr);
-  const double oneoverrho = 1.0 / rho;
+  const double oneoverrho = ddiv(1.0, rho);
   const double vx = u[1] * oneoverrho;
   const double vy = u[2] * oneoverrho;
   const double vz = u[3] * oneoverrho;
@@ -85,6 +119,10 @@ RA_DEV double slope1(double qm1, double q0, double qp1, const HydroConst &P) {
   if (ST == 1) {  // minmod, umuscl.f90:1246-1279
     const double dlft = q0 - qm1;
     const double drgt = qp1 - q0;
+#ifdef RAMSES_AMD_FAST
+    // branch-free form; differs from the reference only when dlft*drgt underflows
+    return dmaxd(dmind(dlft, drgt), dmind(dmaxd(dlft, drgt), 0.0));
+#endif
     const double s = dlft > 0 ? dmind(dlft, drgt) : dmaxd(dlft, drgt);
     return (dlft * drgt) <= 0.0 ? 0.0 : s;
   }
@@ -131,9 +169,16 @@ RA_DEV void trace3d_cell(const double (&q)[NV], const double (&dq)[3][NV],
   const double div = dux + dvy + dwz;
   const double sr0 = -u * drx - v * dry - w * drz - (div)*r;
   const double sp0 = -u * dpx - v * dpy - w * dpz - (div)*P.gamma * p;
+#ifdef RAMSES_AMD_FAST
+  const double rinv = rcp_fast(r);
+  const double su0 = -u * dux - v * duy - w * duz - (dpx)*rinv;
+  const double sv0 = -u * dvx - v * dvy - w * dvz - (dpy)*rinv;
+  const double sw0 = -u * dwx - v * dwy - w * dwz - (dpz)*rinv;
+#else
   const double su0 = -u * dux - v * duy - w * duz - (dpx) / r;
   const double sv0 = -u * dvx - v * dvy - w * dvz - (dpy) / r;
   const double sw0 = -u * dwx - v * dwy - w * dwz - (dpz) / r;
+#endif
   const double s0[5] = {sr0, su0, sv0, sw0, sp0};
   const double dtd[3] = {dtdx, dtdy, dtdz};
 #pragma unroll
@@ -173,10 +218,10 @@ RA_DEV void riemann_llf(const double (&ql)[NV], const double (&qr)[NV],
   // godunov_utils.f90:660-820
   const double rl = dmaxd(ql[0], P.smallr), ul = ql[1];
   const double pl = dmaxd(ql[2], rl * P.smallp);
-  const double cl = __builtin_sqrt(P.gamma * pl / rl);
+  const double cl = dsqrt(ddiv(P.gamma * pl, rl));
   const double rr = dmaxd(qr[0], P.smallr), ur = qr[1];
   const double pr = dmaxd(qr[2], rr * P.smallp);
-  const double cr = __builtin_sqrt(P.gamma * pr / rr);
+  const double cr = dsqrt(ddiv(P.gamma * pr, rr));
   const double cmax = dmaxd(__builtin_fabs(ul) + cl, __builtin_fabs(ur) + cr);
   double uL[NV + 1], uR[NV + 1], fL[NV + 1], fR[NV + 1];
   uL[0] = ql[0]; uR[0] = qr[0];
@@ -205,10 +250,10 @@ RA_DEV void riemann_hll(const double (&ql)[NV], const double (&qr)[NV],
   // godunov_utils.f90:825-983
   const double rl = dmaxd(ql[0], P.smallr), ul = ql[1];
   const double pl = dmaxd(ql[2], rl * P.smallp);
-  const double cl = __builtin_sqrt(P.gamma * pl / rl);
+  const double cl = dsqrt(ddiv(P.gamma * pl, rl));
   const double rr = dmaxd(qr[0], P.smallr), ur = qr[1];
   const double pr = dmaxd(qr[2], rr * P.smallp);
-  const double cr = __builtin_sqrt(P.gamma * pr / rr);
+  const double cr = dsqrt(ddiv(P.gamma * pr, rr));
   const double SL = dmind(dmind(ul, ur) - dmaxd(cl, cr), 0.0);
   const double SR = dmaxd(dmaxd(ul, ur) + dmaxd(cl, cr), 0.0);
   double uL[NV + 1], uR[NV + 1], fL[NV + 1], fR[NV + 1];
@@ -253,8 +298,8 @@ RA_DEV void riemann_hllc(const double (&ql)[NV], const double (&qr)[NV],
   ecinr = ecinr + 0.5 * rr * (qr[3] * qr[3]);
   ecinr = ecinr + 0.5 * rr * (qr[4] * qr[4]);
   const double etotr = er + ecinr;
-  const double cfastl = __builtin_sqrt(dmaxd(P.gamma * Pl / rl, P.smallc2));
-  const double cfastr = __builtin_sqrt(dmaxd(P.gamma * Pr / rr, P.smallc2));
+  const double cfastl = dsqrt(dmaxd(ddiv(P.gamma * Pl, rl), P.smallc2));
+  const double cfastr = dsqrt(dmaxd(ddiv(P.gamma * Pr, rr), P.smallc2));
   const double SL = dmind(ul, ur) - dmaxd(cfastl, cfastr);
   const double SR = dmaxd(ul, ur) + dmaxd(cfastl, cfastr);
   const double rcl = rl * (ul - SL);
@@ -300,8 +345,8 @@ RA_DEV void riemann_acoustic(const double (&ql)[NV], const double (&qr)[NV],
   // godunov_utils.f90:500-655
   const double rl = dmaxd(ql[0], P.smallr), ul = ql[1], pl = dmaxd(ql[2], rl * P.smallp);
   const double rr = dmaxd(qr[0], P.smallr), ur = qr[1], pr = dmaxd(qr[2], rr * P.smallp);
-  const double cl = __builtin_sqrt(P.gamma * pl / rl);
-  const double cr = __builtin_sqrt(P.gamma * pr / rr);
+  const double cl = dsqrt(ddiv(P.gamma * pl, rl));
+  const double cr = dsqrt(ddiv(P.gamma * pr, rr));
   const double wl = cl * rl, wr = cr * rr;
   const double pstar = ((wr * pl + wl * pr) + wl * wr * (ul - ur)) / (wl + wr);
   const double ustar = ((wr * ur + wl * ul) + (pl - pr)) / (wl + wr);
@@ -436,6 +481,74 @@ RA_DEV void interface_flux(const double (&qL)[NV], const double (&qR)[NV],
   for (int n = 5; n < NV; n++) flux[n] = f[n];
   unorm = 0.5 * (a[1] + b[1]);
   eflux = f[NV];
+}
+
+// ---------------------------------------------------------------------------
+// Scaled interface flux  flux*dt/dx  (hydro/umuscl.f90:101-163).  Strict build:
+// the reference's two operations ((f*dt)/dx; an exact multiply by 1/dx when dx
+// is a power of two).  Fast build + LLF: one fused routine (FMA forms, rsq-based
+// sound speed, the dt/dx factor folded into the Lax-Friedrichs average).
+// ---------------------------------------------------------------------------
+#ifdef RAMSES_AMD_FAST
+RA_DEV double rsqrt_fast(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(-(x * y), y, 1.0);
+  return __builtin_fma(0.5 * y, e, y);
+}
+template <int DIR>
+RA_DEV void llf_flux_fast(const double (&qL)[5], const double (&qR)[5],
+                          const HydroConst &P, double dtdx, double (&flux)[5]) {
+  constexpr int ln = DIR == 0 ? 1 : (DIR == 1 ? 2 : 3);
+  constexpr int lt1 = DIR == 0 ? 2 : 1;
+  constexpr int lt2 = DIR == 2 ? 2 : 3;
+  const double rl = dmaxd(qL[0], P.smallr), pl = dmaxd(qL[4], rl * P.smallp);
+  const double rr = dmaxd(qR[0], P.smallr), pr = dmaxd(qR[4], rr * P.smallp);
+  const double gl = P.gamma * pl, gr = P.gamma * pr;
+  const double cl = gl * rsqrt_fast(gl * rl);   // sqrt(gamma p / rho)
+  const double cr = gr * rsqrt_fast(gr * rr);
+  const double ul = qL[ln], ur = qR[ln];
+  const double cmax = dmaxd(__builtin_fabs(ul) + cl, __builtin_fabs(ur) + cr);
+  const double hs = 0.5 * dtdx;           // 0.5*dt/dx
+  const double hc = cmax * hs;            // 0.5*cmax*dt/dx
+  // conserved states
+  const double mL = qL[0] * ul, mR = qR[0] * ur;
+  double kL = ul * ul; kL = __builtin_fma(qL[lt1], qL[lt1], kL); kL = __builtin_fma(qL[lt2], qL[lt2], kL);
+  double kR = ur * ur; kR = __builtin_fma(qR[lt1], qR[lt1], kR); kR = __builtin_fma(qR[lt2], qR[lt2], kR);
+  const double eL = __builtin_fma(0.5 * qL[0], kL, qL[4] * P.entho);
+  const double eR = __builtin_fma(0.5 * qR[0], kR, qR[4] * P.entho);
+  const double t1L = qL[0] * qL[lt1], t1R = qR[0] * qR[lt1];
+  const double t2L = qL[0] * qL[lt2], t2R = qR[0] * qR[lt2];
+  // physical fluxes
+  const double fnL = __builtin_fma(ul, mL, qL[4]), fnR = __builtin_fma(ur, mR, qR[4]);
+  const double feL = ul * (eL + qL[4]), feR = ur * (eR + qR[4]);
+  flux[0] = __builtin_fma(hc, qL[0] - qR[0], hs * (mL + mR));
+  flux[ln] = __builtin_fma(hc, mL - mR, hs * (fnL + fnR));
+  flux[lt1] = __builtin_fma(hc, t1L - t1R, hs * __builtin_fma(ul, t1L, ur * t1R));
+  flux[lt2] = __builtin_fma(hc, t2L - t2R, hs * __builtin_fma(ul, t2L, ur * t2R));
+  flux[4] = __builtin_fma(hc, eL - eR, hs * (feL + feR));
+}
+#endif
+
+template <int RS, int NV, int DIR, bool DXPOW2>
+RA_DEV void scaled_interface_flux(const double (&qL)[NV], const double (&qR)[NV],
+                                  const HydroConst &P, double dt, double dx, double rdx,
+                                  double dtdx, double (&flux)[NV]) {
+#ifdef RAMSES_AMD_FAST
+  if (RS == RIEMANN_LLF && NV == 5) {
+    llf_flux_fast<DIR>(qL, qR, P, dtdx, flux);
+    return;
+  }
+#endif
+  double un_, ef_;
+  interface_flux<RS, NV, DIR>(qL, qR, P, flux, un_, ef_);
+#pragma unroll
+  for (int n = 0; n < NV; n++) {
+#ifdef RAMSES_AMD_FAST
+    flux[n] = flux[n] * dtdx;
+#else
+    flux[n] = DXPOW2 ? flux[n] * dt * rdx : flux[n] * dt / dx;
+#endif
+  }
 }
 
 // ---------------------------------------------------------------------------

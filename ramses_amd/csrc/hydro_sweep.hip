@@ -6,20 +6,22 @@
 //  * a workgroup owns a (64-4) x (BY-4) column tile in (x,y) and MARCHES along
 //    z; one wavefront = one y row of 64 x-columns, so every HBM access of a
 //    wave is a contiguous 512 B row segment;
-//  * a thread keeps its own column's z-neighbours (3 primitive planes, the
-//    previous z traced state and z flux) in registers; only the in-plane
-//    neighbours go through LDS: the primitive plane (double buffered), the
-//    +x/+y traced states and the x/y interface fluxes;
+//  * the primitive planes c-1, c, c+1 live in an LDS ring (y/x neighbours and
+//    the thread's own z neighbours are LDS reads); the traced +y state and the
+//    y flux cross waves through LDS; the traced +x state and the x flux cross
+//    lanes with wavefront DPP shifts (no LDS); the z direction stays in
+//    registers (previous plane's +z state, z flux, partial update);
 //  * every cell is converted to primitives once, traced once, and every
 //    interface flux is computed once per tile (the reference recomputes a 6^3
 //    stencil per 2^3 oct: 27x load and ~8x flop redundancy);
-//  * halo rows/lanes exit early by role (wave-uniform for rows), so the 2-cell
-//    ghost ring costs ctoprim+trace only;
-//  * uold is read once (+ tile halo from L2) and unew written once: 80 B per
-//    cell update algorithmic HBM traffic.
+//  * halo rows exit early by role (wave-uniform), so the 2-cell ghost ring
+//    costs ctoprim+trace only;
+//  * uold is read once from HBM (+ tile halo and one L2 re-read) and unew
+//    written once: 80 B per cell update algorithmic HBM traffic.
 //
-// Compiled twice: strict (-ffp-contract=off, bit-identical to the reference)
-// and fast (-DRAMSES_AMD_FAST, FMA contraction allowed).
+// Compiled twice: strict (-ffp-contract=off, reference operation order,
+// bit-identical to the reference) and fast (-DRAMSES_AMD_FAST: FMA
+// contraction, rcp/rsq-based division and square root, fused LLF).
 #include <hip/hip_runtime.h>
 
 #include "hydro_core.hpp"
@@ -44,20 +46,34 @@ struct Plane {
   double v[NV][BY][BX];
 };
 
+// wavefront shift by one lane: lane i receives the value of lane i-1 (shr) or
+// i+1 (shl); the edge lane keeps its own value (a halo lane, never stored).
+__device__ __forceinline__ double wave_shr1(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_shl1(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 template <int ST, int RS, int BY, bool GRAV, bool DXPOW2>
 __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  Plane<BY> *qbuf = reinterpret_cast<Plane<BY> *>(smem_raw);  // [2] primitives of plane c / c+1
-  Plane<BY> *smx = qbuf + 2;                                   // qm along x (state on +x face)
-  Plane<BY> *smy = qbuf + 3;                                   // qm along y
-  Plane<BY> *fxb = qbuf + 4;                                   // flux through the -x face
-  Plane<BY> *fyb = qbuf + 5;                                   // flux through the -y face
+  Plane<BY> *qring = reinterpret_cast<Plane<BY> *>(smem_raw);  // [3] primitives of planes c-1, c, c+1
+  Plane<BY> *smy = qring + 3;                                   // qm along y (state on the +y face)
+  Plane<BY> *fyb = qring + 4;                                   // flux through the -y face
 
   const int tx = threadIdx.x, ty = threadIdx.y;
   const HydroConst &P = A.P;
 
-  // ---- tile decode (XCD-aware: consecutive tiles of one z-chunk column
-  // share an XCD's L2 for their halo re-reads) ------------------------------
+  // ---- tile decode (XCD-aware: block b runs on XCD b%8; give each XCD a
+  // contiguous run of tiles so the halo re-reads of neighbouring tiles hit
+  // the same L2) -------------------------------------------------------------
   int bid = blockIdx.x;
   {
     const int nblk = gridDim.x;
@@ -93,7 +109,7 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
   double *__restrict__ unew = A.unew;
   const double *__restrict__ grav = A.grav;
 
-  // roles
+  // roles (wave-uniform: one wave = one row)
   const bool r_trace = (ty >= 1) && (ty <= BY - 2);
   const bool r_fy = (ty >= 2) && (ty <= BY - 2);
   const bool r_fxz = (ty >= 2) && (ty <= BY - 3);
@@ -124,139 +140,122 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
   };
 
   // ---- register state carried along z --------------------------------------
-  double qa[NV], qb[NV], qc[NV];  // primitives of planes c-1, c, c+1
-  double ucur[NV];                // conservative u of plane c
-  double unxt[NV];                // conservative u of plane c+1
   double qmz[NV];                 // qm along z of plane c-1 (state on its +z face)
   double part[NV];                // u + x and y flux differences of plane c-1
   double fzlo[NV];                // z flux through the -z face of plane c-1
-  double upre[NV], gpre[3];       // prefetch of plane c+2
+  double upre[NV], gpre[3];       // prefetch: plane c+1 on entry of iteration c
 
-  // prologue: planes z0-2, z0-1, z0  (c starts at z0-1)
+  // ring slots of planes c-1, c, c+1
+  int sa = 0, sb = 1, sc = 2;
+
+  // prologue: primitives of planes z0-2 -> slot sa, z0-1 -> slot sb; c starts at z0-1
   {
-    double u[NV], g[3];
+    double u[NV], g[3], q[NV];
     load_u(z0 - 2, u); load_g(z0 - 2, g);
-    ctoprim_cell<NV, GRAV>(u, g, dtxhalf, P, qa);
-    load_u(z0 - 1, ucur); load_g(z0 - 1, g);
-    ctoprim_cell<NV, GRAV>(ucur, g, dtxhalf, P, qb);
+    ctoprim_cell<NV, GRAV>(u, g, dtxhalf, P, q);
+#pragma unroll
+    for (int n = 0; n < NV; n++) qring[sa].v[n][ty][tx] = q[n];
+    load_u(z0 - 1, u); load_g(z0 - 1, g);
+    ctoprim_cell<NV, GRAV>(u, g, dtxhalf, P, q);
+#pragma unroll
+    for (int n = 0; n < NV; n++) qring[sb].v[n][ty][tx] = q[n];
     load_u(z0, upre); load_g(z0, gpre);
 #pragma unroll
     for (int n = 0; n < NV; n++) { qmz[n] = 0.0; part[n] = 0.0; fzlo[n] = 0.0; }
-    // primitives of plane c = z0-1 into LDS
-    Plane<BY> &qs = qbuf[(z0 - 1) & 1];
-#pragma unroll
-    for (int n = 0; n < NV; n++) qs.v[n][ty][tx] = qb[n];
   }
   __syncthreads();
 
   const int txm = max(tx - 1, 0), txp = min(tx + 1, BX - 1);
   const int tym = max(ty - 1, 0), typ = min(ty + 1, BY - 1);
 
+#pragma unroll 2
   for (int c = z0 - 1; c <= z1; c++) {
-    // ---- plane c+1 arrives; prefetch plane c+2 ------------------------------
-    {
-      double g[3];
-#pragma unroll
-      for (int n = 0; n < NV; n++) unxt[n] = upre[n];
-#pragma unroll
-      for (int d = 0; d < 3; d++) g[d] = gpre[d];
-      if (c + 2 <= z1 + 1) { load_u(c + 2, upre); load_g(c + 2, gpre); }
-      ctoprim_cell<NV, GRAV>(unxt, g, dtxhalf, P, qc);
-      Plane<BY> &qn = qbuf[(c + 1) & 1];
-#pragma unroll
-      for (int n = 0; n < NV; n++) qn.v[n][ty][tx] = qc[n];
-    }
-    // No barrier here: plane c's primitives were written one iteration ago
-    // (two barriers back); qbuf[(c+1)&1] was last read before B2 of c-1.
-
     const bool do_xy = (c >= z0) && (c < z1);
-    double qpx[NV], qpy[NV], qpz[NV], qmz_new[NV];
+    // ---- plane c+1 arrives: primitives into ring slot sc ---------------------
+    double qc[NV];
+    ctoprim_cell<NV, GRAV>(upre, gpre, dtxhalf, P, qc);
+#pragma unroll
+    for (int n = 0; n < NV; n++) qring[sc].v[n][ty][tx] = qc[n];
+    // prefetch plane c+2 (HBM) and re-read plane c's conserved state (L2) for
+    // the update at the end of this iteration
+    double ucur[NV];
+    if (c + 2 <= z1 + 1) { load_u(c + 2, upre); load_g(c + 2, gpre); }
+    if (do_xy && r_fxz) load_u(c, ucur);
+    // Slot sc was last read (as plane c-2) before barrier B2 of iteration c-1;
+    // plane c's neighbours were written one iteration (two barriers) ago.
+
+    double qpy[NV], fx[NV], fz[NV];
+#pragma unroll
+    for (int n = 0; n < NV; n++) { fx[n] = 0.0; fz[n] = 0.0; }
     if (r_trace) {
-      const Plane<BY> &qs = qbuf[c & 1];
-      double dq[3][NV];
+      const Plane<BY> &qs = qring[sb];
+      const Plane<BY> &qprev = qring[sa];
+      double qb[NV], dq[3][NV];
 #pragma unroll
       for (int n = 0; n < NV; n++) {
-        const double q0 = qb[n];
-        dq[0][n] = slope1<ST>(qs.v[n][ty][txm], q0, qs.v[n][ty][txp], P);
-        dq[1][n] = slope1<ST>(qs.v[n][tym][tx], q0, qs.v[n][typ][tx], P);
-        dq[2][n] = slope1<ST>(qa[n], q0, qc[n], P);
+        qb[n] = qs.v[n][ty][tx];
+        dq[0][n] = slope1<ST>(qs.v[n][ty][txm], qb[n], qs.v[n][ty][txp], P);
+        dq[1][n] = slope1<ST>(qs.v[n][tym][tx], qb[n], qs.v[n][typ][tx], P);
+        dq[2][n] = slope1<ST>(qprev.v[n][ty][tx], qb[n], qc[n], P);
       }
       double qm[3][NV], qp[3][NV];
       trace3d_cell<NV>(qb, dq, dtdx, dtdx, dtdx, P, qm, qp);
 #pragma unroll
       for (int n = 0; n < NV; n++) {
-        smx->v[n][ty][tx] = qm[0][n];
         smy->v[n][ty][tx] = qm[1][n];
-        qpx[n] = qp[0][n]; qpy[n] = qp[1][n]; qpz[n] = qp[2][n];
-        qmz_new[n] = qm[2][n];
+        qpy[n] = qp[1][n];
       }
-    }
-    __syncthreads();  // (B2) traced states visible
-
-    double fx[NV], fy[NV], fz[NV];
+      if (r_fxz) {
+        if (do_xy) {
+          double qL[NV];
 #pragma unroll
-    for (int n = 0; n < NV; n++) { fx[n] = 0.0; fy[n] = 0.0; fz[n] = 0.0; }
-    double un_, ef_;
+          for (int n = 0; n < NV; n++) qL[n] = wave_shr1(qm[0][n]);  // +x state of column tx-1
+          scaled_interface_flux<RS, NV, 0, DXPOW2>(qL, qp[0], P, A.dt, A.dx, A.rdx, dtdx, fx);
+        }
+        if (c >= z0) {
+          // z flux through the face between planes c-1 and c
+          scaled_interface_flux<RS, NV, 2, DXPOW2>(qmz, qp[2], P, A.dt, A.dx, A.rdx, dtdx, fz);
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < NV; n++) qmz[n] = qm[2][n];
+    }
+    __syncthreads();  // (B2) +y traced states visible
+
+    double fy[NV];
+#pragma unroll
+    for (int n = 0; n < NV; n++) fy[n] = 0.0;
     if (r_fy && do_xy) {
       double qL[NV];
 #pragma unroll
       for (int n = 0; n < NV; n++) qL[n] = smy->v[n][tym][tx];
-      interface_flux<RS, NV, 1>(qL, qpy, P, fy, un_, ef_);
+      scaled_interface_flux<RS, NV, 1, DXPOW2>(qL, qpy, P, A.dt, A.dx, A.rdx, dtdx, fy);
 #pragma unroll
-      for (int n = 0; n < NV; n++) {
-        fy[n] = DXPOW2 ? fy[n] * A.dt * A.rdx : fy[n] * A.dt / A.dx;
-        fyb->v[n][ty][tx] = fy[n];
-      }
+      for (int n = 0; n < NV; n++) fyb->v[n][ty][tx] = fy[n];
     }
-    if (r_fxz) {
-      if (do_xy) {
-        double qL[NV];
-#pragma unroll
-        for (int n = 0; n < NV; n++) qL[n] = smx->v[n][ty][txm];
-        interface_flux<RS, NV, 0>(qL, qpx, P, fx, un_, ef_);
-#pragma unroll
-        for (int n = 0; n < NV; n++) {
-          fx[n] = DXPOW2 ? fx[n] * A.dt * A.rdx : fx[n] * A.dt / A.dx;
-          fxb->v[n][ty][tx] = fx[n];
-        }
-      }
-      if (c >= z0) {
-        // z flux through the face between planes c-1 and c
-        interface_flux<RS, NV, 2>(qmz, qpz, P, fz, un_, ef_);
-#pragma unroll
-        for (int n = 0; n < NV; n++)
-          fz[n] = DXPOW2 ? fz[n] * A.dt * A.rdx : fz[n] * A.dt / A.dx;
-      }
-    }
-    __syncthreads();  // (B3) x/y fluxes visible
+    __syncthreads();  // (B3) y fluxes visible
 
     if (r_fxz) {
       // finish plane c-1: its +z face flux is fz
-      if (c >= z0 + 1) {
-        if (r_upd) {
-          const long o = plane_off(c - 1);
+      if (c >= z0 + 1 && r_upd) {
+        const long o = plane_off(c - 1);
 #pragma unroll
-          for (int n = 0; n < NV; n++)
-            unew[o + (long)n * A.pitch_var] = part[n] + (fzlo[n] - fz[n]);
-        }
+        for (int n = 0; n < NV; n++)
+          unew[o + (long)n * A.pitch_var] = part[n] + (fzlo[n] - fz[n]);
       }
       if (do_xy) {
 #pragma unroll
         for (int n = 0; n < NV; n++) {
-          double t = ucur[n] + (fx[n] - fxb->v[n][ty][txp]);
+          const double fxhi = wave_shl1(fx[n]);  // -x face flux of column tx+1
+          const double t = ucur[n] + (fx[n] - fxhi);
           part[n] = t + (fy[n] - fyb->v[n][typ][tx]);
         }
       }
 #pragma unroll
       for (int n = 0; n < NV; n++) fzlo[n] = fz[n];
     }
-    // rotate the z window
-#pragma unroll
-    for (int n = 0; n < NV; n++) {
-      qa[n] = qb[n]; qb[n] = qc[n];
-      ucur[n] = unxt[n];
-      qmz[n] = qmz_new[n];
-    }
+    // rotate the ring
+    const int t = sa; sa = sb; sb = sc; sc = t;
   }
 }
 
@@ -265,7 +264,7 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
 // ---------------------------------------------------------------------------
 template <int ST, int RS, int BY, bool GRAV>
 static hipError_t launch2(const SweepArgs &A, bool pow2, hipStream_t s) {
-  const size_t lds = 6 * sizeof(Plane<BY>);
+  const size_t lds = 5 * sizeof(Plane<BY>);
   dim3 block(BX, BY);
   dim3 grid(A.ntx * A.nty * A.ntz);
   hipError_t e;
@@ -285,10 +284,12 @@ static hipError_t launch2(const SweepArgs &A, bool pow2, hipStream_t s) {
 
 template <int ST, int RS>
 static hipError_t launch1(SweepArgs &A, int by, bool grav, bool pow2, hipStream_t s) {
+  if (by == 0) by = (RS == RIEMANN_EXACT) ? 8 : 12;  // the Newton solver needs the registers of 2 waves/SIMD
   A.ntx = (A.nx + (BX - 4) - 1) / (BX - 4);
   A.nty = (A.ny + (by - 4) - 1) / (by - 4);
   A.ntz = (A.nz + A.zchunk - 1) / A.zchunk;
   if (by == 8) return grav ? launch2<ST, RS, 8, true>(A, pow2, s) : launch2<ST, RS, 8, false>(A, pow2, s);
+  if (by == 12) return grav ? launch2<ST, RS, 12, true>(A, pow2, s) : launch2<ST, RS, 12, false>(A, pow2, s);
   return hipErrorInvalidValue;
 }
 

@@ -26,6 +26,12 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def godunov_tune(tile_rows=0, zchunk=0):
+    """Tuning knobs of the sweep kernel (0 = built-in default); results do not
+    depend on them."""
+    check(lib().ramses_amd_godunov_tune(int(tile_rows), int(zchunk)))
+
+
 class HydroLevel:
     """One fully refined level (or one rank's share of it) on one MI355X.
 

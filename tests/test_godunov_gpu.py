@@ -28,14 +28,18 @@ def _oracle_params(oracle, **kw):
     return oracle.make_params(**kw)
 
 
-@pytest.mark.parametrize("shape", [(16, 12, 20), (64, 8, 8), (70, 10, 6), (8, 8, 8)])
-def test_llf_minmod_bit_exact(gpu_lib, oracle, shape):
+@pytest.mark.parametrize("tile_rows,zchunk", [(0, 0), (8, 0), (12, 0), (12, 4), (8, 6)])
+@pytest.mark.parametrize("shape", [(16, 12, 20), (64, 8, 8), (70, 10, 6), (8, 8, 8), (130, 22, 14)])
+def test_llf_minmod_bit_exact(gpu_lib, oracle, shape, tile_rows, zchunk):
+    from ramses_amd.hydro import godunov_tune
+    godunov_tune(tile_rows, zchunk)
     nx, ny, nz = shape
     u = random_brick(nx, ny, nz, seed=nx * 1000 + ny)
     dx = 1.0 / 64
     dt = 0.05 * dx
     ref = oracle.godunov_uniform(_oracle_params(oracle), u, dx, dt)
     out = _sweep_gpu(u, dx, dt)
+    godunov_tune(0, 0)
     assert np.isfinite(out).all()
     assert rel_linf(out, ref) <= 1e-13
     assert np.array_equal(out, ref), "strict mode must be bit-identical (max diff %g)" % np.abs(out - ref).max()
