@@ -1,0 +1,135 @@
+"""Multi-GPU decomposition and the virtual-boundary halo exchange.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  The
+reference's Hilbert decomposition of a uniform level into 2^k ranks yields
+axis-aligned bricks; `BrickDecomposition` reproduces that
+partition (x fastest) and implements
+
+    make_virtual_fine_dp      amr/virtual_boundaries.f90:373-528
+
+GPU-resident: pack kernels gather the 2-cell (one oct) face slabs of ALL nvar
+fields into one message per peer (the reference sends nvar separate rounds,
+amr/amr_step.f90:503-510), grouped RCCL send/recv moves them, unpack kernels
+scatter into the ghost octs.  Axes are exchanged x, y, z with slabs spanning
+the already-filled ghosts, which also fills edge and corner octs (the
+reference's reception lists contain those octs explicitly).
+
+There is no reverse (accumulating) exchange on a single fully refined level:
+make_virtual_reverse_dp only carries coarse-fine flux corrections, which are
+zero here because set_unew zeroes the reception cells
+(hydro/godunov_fine.f90:92-104).
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from ._capi import check, lib
+from .hydro import HydroLevel, _ptr, _stream
+
+
+def rank_coords(rank, pgrid):
+    px, py, pz = pgrid
+    return (rank % px, (rank // px) % py, rank // (px * py))
+
+
+def coords_rank(c, pgrid):
+    px, py, pz = pgrid
+    return (c[0] % px) + px * ((c[1] % py) + py * (c[2] % pz))
+
+
+class BrickDecomposition:
+    """pgrid=(px,py,pz) ranks, each owning an n^3 brick (weak scaling) of the
+    periodic (n*px, n*py, n*pz) level; boxlen is the x extent of the box."""
+
+    def __init__(self, pgrid, rank, n, boxlen=0.5, ng=2):
+        self.pgrid = tuple(pgrid)
+        self.rank = rank
+        self.n = n
+        self.ng = ng
+        self.coords = rank_coords(rank, self.pgrid)
+        self.dx = boxlen / (n * self.pgrid[0])
+        self.lo = tuple(c * n for c in self.coords)
+        self._bufs = {}
+
+    # -- construction ----------------------------------------------------------
+    def make_level(self, params, poisson=False):
+        return HydroLevel(self.n, self.n, self.n, self.dx, params=params, ng=self.ng, poisson=poisson)
+
+    def init_sedov(self, lev, gamma=1.4):
+        """namelist/sedov3d.nml on the global level, restricted to this brick
+        (hydro/init_flow_fine.f90:455-596: the 'point' region deposits into the
+        cell whose centre is within dx of the origin -- global cell (0,0,0))."""
+        g = lev.ng
+        u = lev.interior(lev.uold)
+        u.zero_()
+        u[0].fill_(1.0)
+        u[4].fill_(1e-5 / (gamma - 1.0))
+        if self.lo == (0, 0, 0):
+            u[4, 0, 0, 0] = (1e-5 + 0.4 * 0.125 / lev.dx ** 3) / (gamma - 1.0)
+        del g
+
+    def neighbour(self, axis, direction):
+        c = list(self.coords)
+        c[axis] += direction
+        return coords_rank(c, self.pgrid)
+
+    # -- slab movers (C ABI; overridable in CPU protocol tests) ------------------
+    def _slab_size(self, lev, nvar, face):
+        n = lib().ramses_amd_halo_slab_size(C.byref(lev.brick), nvar, face)
+        if n < 0:
+            check(int(n))
+        return int(n)
+
+    def _pack(self, lev, t, nvar, face, buf):
+        check(lib().ramses_amd_halo_pack(C.byref(lev.brick), _ptr(t), nvar, face, _ptr(buf), _stream()))
+
+    def _unpack(self, lev, t, nvar, face, buf):
+        check(lib().ramses_amd_halo_unpack(C.byref(lev.brick), _ptr(t), nvar, face, _ptr(buf), _stream()))
+
+    def _fill_periodic(self, lev, t, nvar, axes):
+        check(lib().ramses_amd_fill_ghosts_periodic(C.byref(lev.brick), _ptr(t), nvar, axes, _stream()))
+
+    def _buffers(self, lev, t, nvar, axis):
+        key = (id(lev), nvar, axis)
+        if key not in self._bufs:
+            n = self._slab_size(lev, nvar, 2 * axis)
+            mk = lambda: torch.empty(n, dtype=torch.float64, device=t.device)  # noqa: E731
+            self._bufs[key] = (mk(), mk(), mk(), mk())
+        return self._bufs[key]
+
+    # -- the exchange ------------------------------------------------------------
+    def exchange(self, lev, t, nvar):
+        """Forward halo of the nvar-field brick tensor t (all fields fused)."""
+        for axis in range(3):
+            if self.pgrid[axis] == 1:
+                self._fill_periodic(lev, t, nvar, 1 << axis)
+                continue
+            send_lo, send_hi, recv_lo, recv_hi = self._buffers(lev, t, nvar, axis)
+            lo_nbr = self.neighbour(axis, -1)
+            hi_nbr = self.neighbour(axis, +1)
+            self._pack(lev, t, nvar, 2 * axis, send_lo)       # my low interior slab -> low neighbour's high ghosts
+            self._pack(lev, t, nvar, 2 * axis + 1, send_hi)   # my high interior slab -> high neighbour's low ghosts
+            # One grouped launch (ncclGroupStart/End).  With 2 ranks on the axis
+            # both messages go to the same peer; sends and receives are posted in
+            # matching order (peer's first send = its low slab = my high ghosts).
+            ops = [dist.P2POp(dist.isend, send_lo, lo_nbr),
+                   dist.P2POp(dist.isend, send_hi, hi_nbr),
+                   dist.P2POp(dist.irecv, recv_hi, hi_nbr),
+                   dist.P2POp(dist.irecv, recv_lo, lo_nbr)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            self._unpack(lev, t, nvar, 2 * axis, recv_lo)
+            self._unpack(lev, t, nvar, 2 * axis + 1, recv_hi)
+
+    def make_virtual_fine_dp(self, lev):
+        """Refresh the ghost octs of uold (and of f when poisson) on every rank."""
+        self.exchange(lev, lev.uold, lev.nvar)
+        if lev.f is not None:
+            self.exchange(lev, lev.f, 3)
+
+    def allreduce_min(self, value, device):
+        """dt = min over ranks (MPI_ALLREDUCE MIN of hydro/courant_fine.f90:140)."""
+        t = torch.tensor([value], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item())

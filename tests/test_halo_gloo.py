@@ -1,0 +1,124 @@
+"""Multi-rank halo exchange protocol on CPU (gloo): the message pattern of
+BrickDecomposition.exchange (who sends which face slab to whom, in which
+order, including the 2-ranks-per-axis case where both faces go to one peer)
+with the HIP slab movers replaced by an independent torch-slicing mover that
+lives in this test.  The HIP movers themselves are checked against the same
+slicing code in test_halo_gpu.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ramses_amd.parallel import BrickDecomposition, rank_coords
+
+
+def slab_slices(n, ng, face, ghost):
+    """Python restatement of the slab geometry of include/ramses_amd.h:
+    returns (z,y,x) slices in allocated coordinates."""
+    axis, hi = face // 2, face & 1
+    sl = []
+    for d in range(3):
+        if d < axis:
+            sl.append(slice(0, n[d] + 2 * ng))
+        elif d > axis:
+            sl.append(slice(ng, ng + n[d]))
+        else:
+            if ghost:
+                o = n[d] + ng if hi else 0
+            else:
+                o = n[d] if hi else ng
+            sl.append(slice(o, o + ng))
+    return (sl[2], sl[1], sl[0])
+
+
+class FakeLevel:
+    def __init__(self, n, ng, nvar):
+        self.nx = self.ny = self.nz = n
+        self.ng, self.nvar = ng, nvar
+        self.brick = None
+        self.f = None
+        self.uold = torch.zeros((nvar, n + 2 * ng, n + 2 * ng, n + 2 * ng), dtype=torch.float64)
+
+
+class TorchMoverDecomposition(BrickDecomposition):
+    def _n(self, lev):
+        return (lev.nx, lev.ny, lev.nz)
+
+    def _slab_size(self, lev, nvar, face):
+        s = slab_slices(self._n(lev), lev.ng, face, False)
+        return nvar * int(np.prod([x.stop - x.start for x in s]))
+
+    def _pack(self, lev, t, nvar, face, buf):
+        s = slab_slices(self._n(lev), lev.ng, face, False)
+        buf.copy_(t[(slice(None),) + s].reshape(-1))
+
+    def _unpack(self, lev, t, nvar, face, buf):
+        s = slab_slices(self._n(lev), lev.ng, face, True)
+        view = t[(slice(None),) + s]
+        view.copy_(buf.reshape(view.shape))
+
+    def _fill_periodic(self, lev, t, nvar, axes):
+        for axis in range(3):
+            if axes & (1 << axis):
+                for hi in (0, 1):
+                    dst = slab_slices(self._n(lev), lev.ng, 2 * axis + hi, True)
+                    src = slab_slices(self._n(lev), lev.ng, 2 * axis + (1 - hi), False)
+                    t[(slice(None),) + dst] = t[(slice(None),) + src]
+
+
+def global_field(nvar, gz, gy, gx):
+    """Unique value per (var, global cell)."""
+    z, y, x = np.meshgrid(np.arange(gz), np.arange(gy), np.arange(gx), indexing="ij")
+    base = (z * gy + y) * gx + x
+    return np.stack([base + 1e7 * v for v in range(nvar)]).astype(np.float64)
+
+
+def _worker(rank, world, pgrid, n, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ng, nvar = 2, 3
+        dec = TorchMoverDecomposition(pgrid, rank, n, boxlen=1.0, ng=ng)
+        lev = FakeLevel(n, ng, nvar)
+        G = global_field(nvar, n * pgrid[2], n * pgrid[1], n * pgrid[0])
+        cx, cy, cz = rank_coords(rank, pgrid)
+        own = G[:, cz * n:(cz + 1) * n, cy * n:(cy + 1) * n, cx * n:(cx + 1) * n]
+        lev.uold[:, ng:ng + n, ng:ng + n, ng:ng + n] = torch.from_numpy(own.copy())
+        dec.exchange(lev, lev.uold, nvar)
+        # expected: the periodic global field around this brick, ghosts included
+        idx = lambda c, ext: (np.arange(c * n - ng, (c + 1) * n + ng)) % ext  # noqa: E731
+        exp = G[:, idx(cz, G.shape[1])][:, :, idx(cy, G.shape[2])][:, :, :, idx(cx, G.shape[3])]
+        ok = np.array_equal(lev.uold.numpy(), exp)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("pgrid", [(2, 1, 1), (1, 2, 1), (2, 2, 1), (2, 2, 2)])
+def test_halo_exchange_fills_all_ghosts(pgrid):
+    world = pgrid[0] * pgrid[1] * pgrid[2]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, pgrid, 6, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world and all(ret.values()), dict(ret)
+
+
+def test_weak_scaling_rank_grid_matches_bench():
+    import bench
+    assert bench.rank_grid(1) == (1, 1, 1)
+    assert bench.rank_grid(2) == (2, 1, 1)
+    assert bench.rank_grid(4) == (2, 2, 1)
+    assert bench.rank_grid(8) == (2, 2, 2)
