@@ -120,6 +120,16 @@ subroutine output_patch(filename)
   close(11)
 end subroutine output_patch
 EOF
+  cat > "$gen/write_gitinfo.f90" <<'EOF'
+subroutine write_gitinfo
+  use amr_commons, ONLY:builddate,patchdir,gitrepo,gitbranch,githash
+  builddate = 'oracle/build_ref.sh'
+  patchdir  = 'see build tag'
+  gitrepo   = 'tatary/ramses'
+  gitbranch = 'reference'
+  githash   = 'reference'
+end subroutine write_gitinfo
+EOF
   if [ "$ndim" != 3 ]; then
     # flang rejects a rank-mismatched assignment in dead NDIM<3 code of
     # pm/sink_sn_feedback.f90; fix it on the fly.
@@ -137,16 +147,11 @@ EOF
     echo "MISSING:$n" >&2; return 1
   }
   local objs=()
-  local gitdefs="-DPATCH='$(basename "${patch:-none}")' -DGITBRANCH='ref' -DGITHASH='\"ref\"' -DGITREPO='ref' -DBUILDDATE='\"oracle\"'"
   for n in $MODSRC $extra_objs $AMRSRC $HYDROSRC $PMSRC $POISSONSRC ramses; do
     local src; src=$(find_src "$n")
     local o="$obj/$n.o"
     if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "${FORCE:-0}" = 1 ]; then
-      if [ "$n" = write_gitinfo ]; then
-        eval $F90 -O0 -cpp $gitdefs -module-dir "$obj" -I"$obj" -c "$src" -o "$o"
-      else
-        $F90 $flags -c "$src" -o "$o" 2> "$obj/$n.log" || { cat "$obj/$n.log"; exit 1; }
-      fi
+      $F90 $flags -c "$src" -o "$o" 2> "$obj/$n.log" || { cat "$obj/$n.log"; exit 1; }
     fi
     objs+=("$o")
   done
