@@ -84,9 +84,12 @@ build_ramses() {
   local tag="ramses${ndim}d"
   [ "$mode" = mpi ] && tag="${tag}_mpi"
   [ -n "$patch" ] && tag="${tag}_$(basename "$patch")"
+  # extra cpp defines of the reference itself, e.g. REF_DEFS=-DOUTPUT_PARTICLE_DENSITY
+  # (backup_poisson then also writes rho) with REF_TAG=rho
+  [ -n "${REF_TAG:-}" ] && tag="${tag}_${REF_TAG}"
   local obj="$OUT/obj_$tag" gen="$OUT/gen_$tag"
   mkdir -p "$obj" "$gen"
-  local flags="$(defines $ndim) $OPT -module-dir $obj -I$obj -I$REF"
+  local flags="$(defines $ndim) ${REF_DEFS:-} $OPT -module-dir $obj -I$obj -I$REF"
   local libs=""
   if [ "$mode" = mpi ]; then
     flags="$flags -DMPI_OLD -I/opt/conda/include"
@@ -163,6 +166,7 @@ cmd=${1:-kernels}
 case "$cmd" in
   kernels) build_kernels "${2:-3}" "${3:-}";;
   ramses) build_ramses "${2:-3}" "${3:-serial}" "${4:-}";;
-  all) build_kernels 3; build_kernels 1; build_kernels 2; build_kernels 3 7; build_ramses 3 serial;;
+  all) build_kernels 3; build_kernels 1; build_kernels 2; build_kernels 3 7; build_ramses 3 serial;
+       REF_DEFS=-DOUTPUT_PARTICLE_DENSITY REF_TAG=rho build_ramses 3 serial;;
   *) echo "usage: $0 kernels [NDIM] | ramses [NDIM] [serial|mpi] [PATCHDIR] | all"; exit 2;;
 esac

@@ -63,6 +63,19 @@ def lib():
         L.ora_courant_uniform.argtypes = [C.POINTER(HydroParams), _dp, C.c_void_p,
                                           C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
         L.ora_courant_uniform.restype = C.c_double
+        L.ora_mg_gauss_seidel.argtypes = [_dp, _dp, C.c_int, C.c_double, C.c_int]
+        L.ora_mg_residual.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double]
+        L.ora_mg_norm2.argtypes = [_dp, C.c_int, C.c_double]
+        L.ora_mg_norm2.restype = C.c_double
+        L.ora_mg_restrict.argtypes = [_dp, _dp, C.c_int]
+        L.ora_mg_interp_correct.argtypes = [_dp, _dp, C.c_int]
+        L.ora_mg_solve_uniform.argtypes = [_dp, C.c_double, C.c_int, C.c_double, C.c_double,
+                                           C.POINTER(C.c_int), _dp, _dp, _dp, C.POINTER(C.c_double)]
+        L.ora_mg_solve_uniform.restype = C.c_int
+        L.ora_gradient_phi_uniform.argtypes = [_dp, C.c_int, _dp]
+        for fn in (L.ora_mg_gauss_seidel, L.ora_mg_residual, L.ora_mg_restrict, L.ora_mg_interp_correct,
+                   L.ora_gradient_phi_uniform):
+            fn.restype = None
         _lib = L
     return _lib
 
@@ -122,6 +135,33 @@ def courant_uniform(p, uold, dx, courant_factor, grav=None):
         gptr = grav.ctypes.data_as(C.c_void_p)
     return lib().ora_courant_uniform(C.byref(p), np.ascontiguousarray(uold), gptr,
                                      nx, ny, nz, dx, courant_factor)
+
+
+TWOPI_REF = 6.2831853   # amr/constants.f90:5 (the reference's truncated 2*pi)
+
+
+def mg_solve_uniform(rho, rho_tot, boxlen=1.0, epsilon=1e-4, phi0=None, safe_mode=False):
+    """multigrid_fine on a fully refined periodic level: rho[n,n,n] -> dict(phi, f1, f2, iters, err)."""
+    n = rho.shape[0]
+    level = int(round(np.log2(n)))
+    assert rho.shape == (n, n, n) and 2 ** level == n
+    fourpi = 2 * TWOPI_REF * boxlen          # 2*twopi*scale, scale = boxlen/nx_loc, nx_loc = 1
+    phi = np.zeros_like(rho) if phi0 is None else np.ascontiguousarray(phi0).copy()
+    f1 = np.zeros_like(rho)
+    f2 = np.zeros_like(rho)
+    safe = C.c_int(1 if safe_mode else 0)
+    err = C.c_double()
+    it = lib().ora_mg_solve_uniform(np.ascontiguousarray(rho), rho_tot, level, fourpi, epsilon,
+                                    C.byref(safe), phi, f1, f2, C.byref(err))
+    return dict(phi=phi, f1=f1, f2=f2, iters=it, err=err.value, safe_mode=bool(safe.value))
+
+
+def gradient_phi_uniform(phi):
+    n = phi.shape[0]
+    level = int(round(np.log2(n)))
+    f = np.zeros((3,) + phi.shape)
+    lib().ora_gradient_phi_uniform(np.ascontiguousarray(phi), level, f)
+    return f
 
 
 # --------------------------------------------------------------------------
