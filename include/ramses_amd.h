@@ -153,6 +153,48 @@ int ramses_amd_halo_pack(const ramses_amd_brick *b, const double *d_u, int nvar,
 int ramses_amd_halo_unpack(const ramses_amd_brick *b, double *d_u, int nvar,
                            int face, const double *d_buf, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * multigrid_fine(ilevel,icount) + force_fine on a fully refined PERIODIC level
+ * (n = 2^level cells per direction, dense brick phi[k][j][i], no ghosts).
+ * Replaces: poisson/multigrid_fine_commons.f90:25-296 (V-cycle driver,
+ *   recursive_multigrid_coarse :307-390), the operators of
+ *   poisson/multigrid_fine_fine.f90 (gauss_seidel_mg_fine :332-451,
+ *   cmp_residual_mg_fine :147-249, cmp_residual_norm2_fine :254-287,
+ *   restrict_residual_fine_reverse :528-590, interpolate_and_correct_fine
+ *   :596-698) and their coarse twins in multigrid_fine_coarse.f90, with the
+ *   per-solve communicator construction (build_parent_comms_mg) replaced by
+ *   arithmetic indexing; make_fine_bc_rhs (:1058-1159) on an unmasked level.
+ * d_rho: source (rho), rho_tot: box mean, fourpi = 2*twopi*scale (or the
+ *   cosmological 1.5*omega_m*aexp*scale) as the reference computes it.
+ * d_phi: in = first guess (zero at levelmin), out = potential.
+ * d_f1 / d_f2: the reference's f(:,1) (minus residual) and f(:,2) (RHS).
+ * d_work: ramses_amd_mg_workspace_doubles(level) doubles of device scratch
+ *   (the coarse hierarchy active_mg(:,l)%u(:,1:3) for l = 1..level-1).
+ * safe_mode: in/out, the reference's safe_mode(ilevel).
+ * iters / err: V-cycles done and the final error
+ *   sqrt(res^2/(res0^2+1e-20 rho_tot^2)); constants MAXITER=10, ngs=2.
+ * Synchronises the stream once per V-cycle (the convergence test).
+ * ------------------------------------------------------------------------- */
+int64_t ramses_amd_mg_workspace_doubles(int level);
+int ramses_amd_multigrid_fine_brick(int level, const double *d_rho, double rho_tot,
+                                    double fourpi, double epsilon, int *safe_mode,
+                                    double *d_phi, double *d_f1, double *d_f2,
+                                    double *d_work, int *iters, double *err,
+                                    void *stream);
+/* gradient_phi (poisson/force_fine.f90:199-324): d_f holds f(:,1:3), 3*n^3. */
+int ramses_amd_gradient_phi_brick(int level, const double *d_phi, double *d_f,
+                                  void *stream);
+/* The individual operators (n^3 periodic bricks), exposed for parity tests. */
+int ramses_amd_mg_gauss_seidel(double *d_phi, const double *d_rhs, int n, double dx2,
+                               int redstep, void *stream);
+int ramses_amd_mg_residual(const double *d_phi, const double *d_rhs, double *d_res,
+                           int n, double dx, double *d_work, double *d_norm2,
+                           void *stream);
+int ramses_amd_mg_restrict(const double *d_res_f, double *d_rhs_c, double *d_u1_c,
+                           int nf, void *stream);
+int ramses_amd_mg_interp_correct(double *d_phi_f, const double *d_corr_c, int nf,
+                                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

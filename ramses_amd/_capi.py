@@ -56,6 +56,14 @@ SYMBOLS = [
     ("ramses_amd_halo_slab_size", _i64, [_PB, _i, _i]),
     ("ramses_amd_halo_pack", _i, [_PB, _vp, _i, _i, _vp, _vp]),
     ("ramses_amd_halo_unpack", _i, [_PB, _vp, _i, _i, _vp, _vp]),
+    ("ramses_amd_mg_workspace_doubles", _i64, [_i]),
+    ("ramses_amd_multigrid_fine_brick", _i, [_i, _vp, _d, _d, _d, C.POINTER(C.c_int), _vp, _vp, _vp, _vp,
+                                             C.POINTER(C.c_int), C.POINTER(C.c_double), _vp]),
+    ("ramses_amd_gradient_phi_brick", _i, [_i, _vp, _vp, _vp]),
+    ("ramses_amd_mg_gauss_seidel", _i, [_vp, _vp, _i, _d, _i, _vp]),
+    ("ramses_amd_mg_residual", _i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _vp]),
+    ("ramses_amd_mg_restrict", _i, [_vp, _vp, _vp, _i, _vp]),
+    ("ramses_amd_mg_interp_correct", _i, [_vp, _vp, _i, _vp]),
 ]
 
 

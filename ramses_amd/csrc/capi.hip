@@ -10,6 +10,7 @@
 #include <cstring>
 
 #include "../../include/ramses_amd.h"
+#include "mg_args.hpp"
 #include "misc_args.hpp"
 #include "sweep_args.hpp"
 
@@ -246,6 +247,145 @@ int ramses_amd_fill_ghosts_periodic(const ramses_amd_brick *b, double *d_u, int 
       if (e != hipSuccess) return hipfail(e, "periodic ghost fill launch");
     }
   }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// multigrid Poisson solver on a fully refined periodic level
+// ---------------------------------------------------------------------------
+static size_t mg_level_cells(int l) { return (size_t)1 << (3 * l); }
+// workspace: for l = 1..level-1: u1, u2, u3 (8^l doubles each); then the
+// residual partial sums and two norm scalars
+static size_t mg_hier_offset(int level, int l, int which) {
+  size_t off = 0;
+  for (int m = 1; m < l; m++) off += 3 * mg_level_cells(m);
+  (void)level;
+  return off + (size_t)which * mg_level_cells(l);
+}
+static size_t mg_hier_size(int level) {
+  size_t off = 0;
+  for (int m = 1; m < level; m++) off += 3 * mg_level_cells(m);
+  return off;
+}
+
+int64_t ramses_amd_mg_workspace_doubles(int level) {
+  if (level < 1 || level > 11) return fail(RAMSES_AMD_EINVAL, "multigrid level must be in [1,11] (got %d)", level);
+  return (int64_t)(mg_hier_size(level) + MG_MAX_PARTIALS + 8);
+}
+
+#define MGCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipfail(e_, what); } while (0)
+
+int ramses_amd_mg_gauss_seidel(double *d_phi, const double *d_rhs, int n, double dx2, int redstep, void *stream) {
+  if (!d_phi || !d_rhs || n < 2 || (n & 1)) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  MGCHK(mg_launch_gs(d_phi, d_rhs, n, dx2, redstep ? 0 : 1, reinterpret_cast<hipStream_t>(stream)), "mg gs launch");
+  return 0;
+}
+int ramses_amd_mg_residual(const double *d_phi, const double *d_rhs, double *d_res, int n, double dx,
+                           double *d_work, double *d_norm2, void *stream) {
+  if (!d_phi || !d_rhs || !d_res || n < 2) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  if (d_norm2 && !d_work) return fail(RAMSES_AMD_EINVAL, "norm needs a workspace of %d doubles", MG_MAX_PARTIALS);
+  MGCHK(mg_launch_residual(d_phi, d_rhs, d_res, n, dx, d_work, d_norm2, reinterpret_cast<hipStream_t>(stream)), "mg residual launch");
+  return 0;
+}
+int ramses_amd_mg_restrict(const double *d_res_f, double *d_rhs_c, double *d_u1_c, int nf, void *stream) {
+  if (!d_res_f || !d_rhs_c || !d_u1_c || nf < 2 || (nf & 1)) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  MGCHK(mg_launch_restrict(d_res_f, d_rhs_c, d_u1_c, nf, reinterpret_cast<hipStream_t>(stream)), "mg restrict launch");
+  return 0;
+}
+int ramses_amd_mg_interp_correct(double *d_phi_f, const double *d_corr_c, int nf, void *stream) {
+  if (!d_phi_f || !d_corr_c || nf < 2 || (nf & 1)) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  MGCHK(mg_launch_interp(d_phi_f, d_corr_c, nf, reinterpret_cast<hipStream_t>(stream)), "mg interp launch");
+  return 0;
+}
+
+int ramses_amd_gradient_phi_brick(int level, const double *d_phi, double *d_f, void *stream) {
+  if (level < 1 || level > 11 || !d_phi || !d_f) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  const int n = 1 << level;
+  const double dx = std::ldexp(1.0, -level);
+  const double a = 0.50 * 4.0 / 3.0 / dx;   // force_fine.f90:233-234
+  const double b = 0.25 * 1.0 / 3.0 / dx;
+  MGCHK(mg_launch_gradient(d_phi, d_f, n, a, b, reinterpret_cast<hipStream_t>(stream)), "gradient_phi launch");
+  return 0;
+}
+
+// recursive_multigrid_coarse (multigrid_fine_commons.f90:307-390), levelmin_mg = 1
+static hipError_t mg_coarse_cycle(double *w, int level, int l, int safe, hipStream_t s) {
+  const int ngs_coarse = 2, ncycles_coarse_safe = 1;
+  const int n = 1 << l;
+  const double dx = std::ldexp(1.0, -l), dx2 = dx * dx;
+  double *u1 = w + mg_hier_offset(level, l, 0), *u2 = w + mg_hier_offset(level, l, 1), *u3 = w + mg_hier_offset(level, l, 2);
+  hipError_t e;
+  if (l <= 1) {
+    for (int i = 0; i < 2 * ngs_coarse; i++) {
+      if ((e = mg_launch_gs(u1, u2, n, dx2, 0, s)) != hipSuccess) return e;
+      if ((e = mg_launch_gs(u1, u2, n, dx2, 1, s)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
+  const int ncycle = safe ? ncycles_coarse_safe : 1;
+  for (int cyc = 0; cyc < ncycle; cyc++) {
+    for (int i = 0; i < ngs_coarse; i++) {
+      if ((e = mg_launch_gs(u1, u2, n, dx2, 0, s)) != hipSuccess) return e;
+      if ((e = mg_launch_gs(u1, u2, n, dx2, 1, s)) != hipSuccess) return e;
+    }
+    if ((e = mg_launch_residual(u1, u2, u3, n, dx, nullptr, nullptr, s)) != hipSuccess) return e;
+    if ((e = mg_launch_restrict(u3, w + mg_hier_offset(level, l - 1, 1), w + mg_hier_offset(level, l - 1, 0), n, s)) != hipSuccess) return e;
+    if ((e = mg_coarse_cycle(w, level, l - 1, safe, s)) != hipSuccess) return e;
+    if ((e = mg_launch_interp(u1, w + mg_hier_offset(level, l - 1, 0), n, s)) != hipSuccess) return e;
+    for (int i = 0; i < ngs_coarse; i++) {
+      if ((e = mg_launch_gs(u1, u2, n, dx2, 0, s)) != hipSuccess) return e;
+      if ((e = mg_launch_gs(u1, u2, n, dx2, 1, s)) != hipSuccess) return e;
+    }
+  }
+  return hipSuccess;
+}
+
+int ramses_amd_multigrid_fine_brick(int level, const double *d_rho, double rho_tot, double fourpi,
+                                    double epsilon, int *safe_mode, double *d_phi, double *d_f1,
+                                    double *d_f2, double *d_work, int *iters_out, double *err_out,
+                                    void *stream) {
+  if (level < 1 || level > 11) return fail(RAMSES_AMD_EINVAL, "multigrid level must be in [1,11] (got %d)", level);
+  if (!d_rho || !d_phi || !d_f1 || !d_f2 || !d_work || !safe_mode) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  const int MAXITER = 10, ngs_fine = 2;          // multigrid_fine_commons.f90:34, poisson_parameters.f90
+  const double SAFE_FACTOR = 0.5;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int n = 1 << level;
+  const long N = (long)n * n * n;
+  const double dx = std::ldexp(1.0, -level), dx2 = dx * dx;
+  double *partial = d_work + mg_hier_size(level);
+  double *d_norm = partial + MG_MAX_PARTIALS;
+  MGCHK(mg_launch_rhs(d_rho, d_f2, N, fourpi, rho_tot, s), "mg rhs launch");
+  int iter = 0;
+  double err = 1.0, last_err, i_res_norm2 = 0.0, res_norm2 = 0.0;
+  for (;;) {
+    iter++;
+    for (int i = 0; i < ngs_fine; i++) {
+      MGCHK(mg_launch_gs(d_phi, d_f2, n, dx2, 0, s), "mg gs launch");
+      MGCHK(mg_launch_gs(d_phi, d_f2, n, dx2, 1, s), "mg gs launch");
+    }
+    MGCHK(mg_launch_residual(d_phi, d_f2, d_f1, n, dx, partial, iter == 1 ? d_norm : nullptr, s), "mg residual launch");
+    if (iter == 1) {
+      MGCHK(hipMemcpyAsync(&i_res_norm2, d_norm, sizeof(double), hipMemcpyDeviceToHost, s), "norm copy");
+    }
+    if (level > 1) {
+      MGCHK(mg_launch_restrict(d_f1, d_work + mg_hier_offset(level, level - 1, 1), d_work + mg_hier_offset(level, level - 1, 0), n, s), "mg restrict launch");
+      MGCHK(mg_coarse_cycle(d_work, level, level - 1, *safe_mode, s), "mg coarse cycle");
+      MGCHK(mg_launch_interp(d_phi, d_work + mg_hier_offset(level, level - 1, 0), n, s), "mg interp launch");
+    }
+    for (int i = 0; i < ngs_fine; i++) {
+      MGCHK(mg_launch_gs(d_phi, d_f2, n, dx2, 0, s), "mg gs launch");
+      MGCHK(mg_launch_gs(d_phi, d_f2, n, dx2, 1, s), "mg gs launch");
+    }
+    MGCHK(mg_launch_residual(d_phi, d_f2, d_f1, n, dx, partial, d_norm + 1, s), "mg residual launch");
+    MGCHK(hipMemcpyAsync(&res_norm2, d_norm + 1, sizeof(double), hipMemcpyDeviceToHost, s), "norm copy");
+    MGCHK(hipStreamSynchronize(s), "stream sync");
+    last_err = err;
+    err = std::sqrt(res_norm2 / (i_res_norm2 + 1e-20 * (rho_tot * rho_tot)));
+    if (err < epsilon || iter >= MAXITER) break;
+    if (err > last_err * SAFE_FACTOR && !*safe_mode) *safe_mode = 1;
+  }
+  if (iters_out) *iters_out = iter;
+  if (err_out) *err_out = err;
   return 0;
 }
 

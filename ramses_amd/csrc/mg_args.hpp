@@ -1,0 +1,18 @@
+// mg_args.hpp -- launch helpers of the multigrid kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ramses_amd {
+
+constexpr int MG_MAX_PARTIALS = 4096;
+
+hipError_t mg_launch_rhs(const double *rho, double *f2, long N, double fourpi, double rho_tot, hipStream_t s);
+hipError_t mg_launch_gs(double *phi, const double *rhs, int n, double dx2, int color, hipStream_t s);
+int mg_residual_blocks(int n);
+hipError_t mg_launch_residual(const double *phi, const double *rhs, double *res, int n, double dx,
+                              double *partial, double *norm_out, hipStream_t s);
+hipError_t mg_launch_restrict(const double *res_f, double *rhs_c, double *u1_c, int nf, hipStream_t s);
+hipError_t mg_launch_interp(double *phi_f, const double *corr_c, int nf, hipStream_t s);
+hipError_t mg_launch_gradient(const double *phi, double *f, int n, double a, double b, hipStream_t s);
+
+}  // namespace ramses_amd

@@ -1,0 +1,105 @@
+"""GPU parity tests of the multigrid Poisson path (through the C ABI) against
+the oracle and against the reference-run goldens (tests/golden/poisson_ref_runs.npz)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "poisson_ref_runs.npz")
+
+
+def _dev(a):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).cuda()
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 32, 64])
+def test_operators_bit_exact(gpu_lib, oracle, n):
+    import torch
+    L = gpu_lib
+    OL = oracle.lib()
+    rng = np.random.default_rng(n)
+    phi = rng.normal(size=(n, n, n))
+    rhs = rng.normal(size=(n, n, n))
+    dx = 1.0 / n
+    # Gauss-Seidel, both colours
+    for red in (1, 0):
+        ref = phi.copy()
+        OL.ora_mg_gauss_seidel(ref, rhs, n, dx * dx, red)
+        d = _dev(phi)
+        assert L.ramses_amd_mg_gauss_seidel(_p(d), _p(_dev(rhs)), n, dx * dx, red, None) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(d.cpu().numpy(), ref)
+        phi = ref
+    # residual + norm
+    ref = np.zeros_like(phi)
+    OL.ora_mg_residual(phi, rhs, ref, n, dx)
+    dres = _dev(np.zeros_like(phi))
+    work = _dev(np.zeros(4096 + 8))
+    norm = _dev(np.zeros(1))
+    assert L.ramses_amd_mg_residual(_p(_dev(phi)), _p(_dev(rhs)), _p(dres), n, dx, _p(work), _p(norm), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(dres.cpu().numpy(), ref)
+    nref = OL.ora_mg_norm2(ref, n, dx)
+    assert abs(norm.item() - nref) <= 1e-13 * nref
+    if n >= 4:
+        # restriction
+        cref = np.zeros((n // 2,) * 3)
+        OL.ora_mg_restrict(ref, cref, n)
+        dc = _dev(np.ones_like(cref))
+        du = _dev(np.ones_like(cref))
+        assert L.ramses_amd_mg_restrict(_p(dres), _p(dc), _p(du), n, None) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(dc.cpu().numpy(), cref)
+        assert (du.cpu().numpy() == 0).all()
+        # prolongation
+        corr = rng.normal(size=(n // 2,) * 3)
+        pref = phi.copy()
+        OL.ora_mg_interp_correct(pref, corr, n)
+        dp = _dev(phi)
+        assert L.ramses_amd_mg_interp_correct(_p(dp), _p(_dev(corr)), n, None) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(dp.cpu().numpy(), pref)
+
+
+@pytest.mark.parametrize("key", ["l4_b1_e4", "l4_b2_e6", "l5_b1_e6"])
+def test_solve_matches_reference_run(gpu_lib, key):
+    import torch
+    from ramses_amd.poisson import PoissonLevel
+    z = np.load(GOLD)
+    rho_tot, boxlen, eps, iters, err = z[key + "_meta"]
+    level = int(np.log2(z[key + "_rho"].shape[0]))
+    lev = PoissonLevel(level, boxlen=boxlen, epsilon=eps)
+    lev.rho.copy_(_dev(z[key + "_rho"]))
+    it, e = lev.multigrid_fine(rho_tot)
+    lev.force_fine()
+    torch.cuda.synchronize()
+    assert it == int(iters)
+    assert abs(e - err) <= 6e-4 * err
+    assert np.array_equal(lev.phi.cpu().numpy(), z[key + "_phi"])
+    assert np.array_equal(lev.f.cpu().numpy(), z[key + "_f"])
+
+
+def test_solve_64_matches_oracle(gpu_lib, oracle):
+    import torch
+    from ramses_amd.poisson import PoissonLevel
+    n = 64
+    rng = np.random.default_rng(1)
+    rho = 1.0 + 0.5 * rng.random((n, n, n))
+    rho[20:30, 10:40, 5:9] += 20.0
+    rho_tot = float(rho.mean())
+    r = oracle.mg_solve_uniform(rho, rho_tot, boxlen=1.0, epsilon=1e-6)
+    lev = PoissonLevel(6, boxlen=1.0, epsilon=1e-6)
+    lev.rho.copy_(_dev(rho))
+    it, e = lev.multigrid_fine(rho_tot)
+    lev.force_fine()
+    torch.cuda.synchronize()
+    assert it == r["iters"]
+    assert np.array_equal(lev.phi.cpu().numpy(), r["phi"])
+    assert np.array_equal(lev.f.cpu().numpy(), oracle.gradient_phi_uniform(r["phi"]))
