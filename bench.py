@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--zchunk", type=int, default=0)
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--vcycle-level", type=int, default=9, help="level of the multigrid V-cycle measurement (0 = skip)")
     return ap.parse_args()
 
 
@@ -67,6 +68,34 @@ def cpu_baseline(n_ref=48, steps=1):
     return {"value": n_ref ** 3 * steps / t, "unit": "cell-updates/s", "cores": 1, "kind": "port",
             "sample": "%d sweep(s) of a %d^3 Sedov3D level, oracle/hydro_oracle.c (godfine1+unsplit restatement), %.1f s"
                       % (steps, n_ref, t)}
+
+
+BYTES_PER_DOF_VCYCLE = 227   # 202 B fine level + 178/7 B coarse hierarchy
+
+
+def vcycle_bench(level):
+    """Second half of the metric: V-cycle DOF/s of multigrid_fine on a uniform
+    periodic level (blob stand-in for cosmo.nml), one GPU."""
+    import torch
+    from ramses_amd.poisson import PoissonLevel
+    n = 2 ** level
+    lev = PoissonLevel(level, boxlen=1.0, epsilon=1e-30)   # never converges: exactly MAXITER=10 V-cycles
+    lev.rho.fill_(1.0)
+    a, b = int(0.375 * n), int(0.625 * n)
+    lev.rho[a:b, a:b, a:b] = 10.0
+    rho_tot = float(lev.rho.mean().item())
+    lev.multigrid_fine(rho_tot)                              # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    iters, err = lev.multigrid_fine(rho_tot)
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    dof = n ** 3 * iters / t
+    gbs = dof * BYTES_PER_DOF_VCYCLE / 1e9
+    return {"metric": "V-cycle DOF/s (multigrid_fine)", "value": dof, "unit": "DOF/s", "level": level,
+            "vcycles": iters, "ms_per_vcycle": t / iters * 1e3, "final_error": err,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "bytes_per_dof": BYTES_PER_DOF_VCYCLE}}
 
 
 def main():
@@ -177,6 +206,10 @@ def main():
                          "kernel": "godunov_sweep_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL_UPDATE},
         }
+        if world == 1 and args.vcycle_level > 0:
+            del lev
+            torch.cuda.empty_cache()
+            out["vcycle"] = vcycle_bench(args.vcycle_level)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -19,7 +19,7 @@ rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- $BENCH --steps 10 
 pass() { # name counters...
   local name=$1; shift
   echo "== pmc $name: $* ==" >> $OUT/log.txt
-  timeout 600 rocprofv3 --pmc "$@" --kernel-include-regex godunov -f csv -d $OUT/$name -o c -- $BENCH --steps 2 --warmup 1 >> $OUT/log.txt 2>&1
+  timeout 600 rocprofv3 --pmc "$@" --kernel-include-regex "${KREGEX:-godunov}" -f csv -d $OUT/$name -o c -- $BENCH --steps 2 --warmup 1 >> $OUT/log.txt 2>&1
 }
 pass pmc_sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 pass pmc_sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS
