@@ -195,6 +195,34 @@ int ramses_amd_mg_restrict(const double *d_res_f, double *d_rhs_c, double *d_u1_
 int ramses_amd_mg_interp_correct(double *d_phi_f, const double *d_corr_c, int nf,
                                  void *stream);
 
+/* ---------------------------------------------------------------------------
+ * godunov_fine(ilevel) on the reference's OWN arrays (host memory, Fortran
+ * layout): the entry point the Fortran shim ramses_amd/patch/godunov_fine.f90
+ * binds.  Replaces hydro/godunov_fine.f90:5-35 + :486-911 for a level that is
+ * fully refined on this rank (periodic box, nx=ny=nz=1).
+ *   igrid[ngrid]      = active(ilevel)%igrid(1:ngrid)        (1-based oct slots)
+ *   xg                = xg(1:ngridmax,1:3)                    (oct centres)
+ *   uold, unew        = (1:ncell,1:nvar), ncell = ncoarse+8*ngridmax
+ *   f                 = f(1:ncell,1:3) or NULL when poisson=.false.
+ * Cell addressing icell = ncoarse+(ind-1)*ngridmax+igrid (hydro/godunov_fine.f90:600).
+ * On exit unew(active cells of the level) holds uold + flux differences, as
+ * after the reference's set_unew + godunov_fine.  Synchronous.  Anything the
+ * device path does not cover (AMR level, several ranks, nx>1) is an error:
+ * there is no CPU fallback behind this entry.
+ * ------------------------------------------------------------------------- */
+int ramses_amd_godunov_fine_host(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                 const int *igrid, const double *xg, int64_t ngridmax,
+                                 int64_t ncoarse, int nx_loc, const double *uold,
+                                 double *unew, const double *f, double dx, double dt);
+
+/* Same, for Fortran callers that cannot pass a NULL array: f_or_dummy must be a
+ * valid address and is read only when has_f != 0. */
+int ramses_amd_godunov_fine_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                const int *igrid, const double *xg, int64_t ngridmax,
+                                int64_t ncoarse, int nx_loc, const double *uold,
+                                double *unew, const double *f_or_dummy, int has_f,
+                                double dx, double dt);
+
 #ifdef __cplusplus
 }
 #endif

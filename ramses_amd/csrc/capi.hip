@@ -12,6 +12,7 @@
 #include "../../include/ramses_amd.h"
 #include "mg_args.hpp"
 #include "misc_args.hpp"
+#include "pack_args.hpp"
 #include "sweep_args.hpp"
 
 using namespace ramses_amd;
@@ -387,6 +388,109 @@ int ramses_amd_multigrid_fine_brick(int level, const double *d_rho, double rho_t
   if (iters_out) *iters_out = iter;
   if (err_out) *err_out = err;
   return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Host-array entry points: what the Fortran shims of ramses_amd/patch/ bind.
+// They take the reference's own arrays (Fortran-owned, host memory), stage
+// them on the device, run the brick kernels and write the results back.
+// ---------------------------------------------------------------------------
+extern "C++" {
+namespace {
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+struct HostCtx {
+  DevBuf uold, unew, fvec, igrid, xg, octorg, bold, bnew, bf, flag;
+};
+HostCtx g_host;
+}  // namespace
+}  // extern "C++"
+
+int ramses_amd_godunov_fine_host(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                 const int *igrid, const double *xg, int64_t ngridmax,
+                                 int64_t ncoarse, int nx_loc, const double *uold, double *unew,
+                                 const double *f, double dx, double dt) {
+  if (!p || !igrid || !xg || !uold || !unew) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (p->ndim != 3 || p->nvar != 5) return fail(RAMSES_AMD_EUNSUPPORTED, "device path implements NDIM=3, NVAR=5");
+  if (nx_loc != 1) return fail(RAMSES_AMD_EUNSUPPORTED, "device path needs a periodic box with nx=ny=nz=1 (got nx_loc=%d)", nx_loc);
+  if (ilevel < 1 || ilevel > 11) return fail(RAMSES_AMD_EINVAL, "level out of range");
+  const int n = 1 << ilevel;
+  const long ncells_level = (long)n * n * n;
+  if ((long)ngrid * 8 != ncells_level)
+    return fail(RAMSES_AMD_EUNSUPPORTED,
+                "level %d is not fully refined on this rank (ngrid=%d, need %ld): AMR / multi-rank levels are not on the device yet",
+                ilevel, ngrid, ncells_level / 8);
+  const long ncell = ncoarse + 8 * ngridmax;
+  const int nvar = p->nvar;
+  hipStream_t s = nullptr;
+  HostCtx &H = g_host;
+#define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipfail(e_, what); } while (0)
+  HCHK(H.uold.ensure(sizeof(double) * nvar * ncell), "hipMalloc uold");
+  HCHK(H.unew.ensure(sizeof(double) * nvar * ncell), "hipMalloc unew");
+  HCHK(H.igrid.ensure(sizeof(int) * ngrid), "hipMalloc igrid");
+  HCHK(H.xg.ensure(sizeof(double) * 3 * ngridmax), "hipMalloc xg");
+  HCHK(H.octorg.ensure(sizeof(long) * ngrid), "hipMalloc octorg");
+  HCHK(H.bold.ensure(sizeof(double) * nvar * ncells_level), "hipMalloc brick");
+  HCHK(H.bnew.ensure(sizeof(double) * nvar * ncells_level), "hipMalloc brick");
+  HCHK(H.flag.ensure(sizeof(int)), "hipMalloc flag");
+  HCHK(hipMemcpyAsync(H.uold.p, uold, sizeof(double) * nvar * ncell, hipMemcpyHostToDevice, s), "H2D uold");
+  HCHK(hipMemcpyAsync(H.unew.p, unew, sizeof(double) * nvar * ncell, hipMemcpyHostToDevice, s), "H2D unew");
+  HCHK(hipMemcpyAsync(H.igrid.p, igrid, sizeof(int) * ngrid, hipMemcpyHostToDevice, s), "H2D igrid");
+  HCHK(hipMemcpyAsync(H.xg.p, xg, sizeof(double) * 3 * ngridmax, hipMemcpyHostToDevice, s), "H2D xg");
+  HCHK(hipMemsetAsync(H.flag.p, 0, sizeof(int), s), "memset");
+  const double skip[3] = {0.0, 0.0, 0.0};   // icoarse_min = 0 for nx = 1
+  HCHK(launch_oct_origin(H.igrid.as<int>(), H.xg.as<double>(), ngridmax, ngrid, n, skip, H.octorg.as<long>(), H.flag.as<int>(), s), "oct origin launch");
+  int bad = 0;
+  HCHK(hipMemcpyAsync(&bad, H.flag.p, sizeof(int), hipMemcpyDeviceToHost, s), "D2H flag");
+  HCHK(hipStreamSynchronize(s), "sync");
+  if (bad) return fail(RAMSES_AMD_EINVAL, "%d octs of level %d do not sit on the level-%d lattice (xg inconsistent)", bad, ilevel, ilevel);
+  PackArgs A;
+  A.igrid = H.igrid.as<int>(); A.octorg = H.octorg.as<long>();
+  A.ngrid = ngrid; A.n = n; A.nvar = nvar;
+  A.ncoarse = ncoarse; A.ngridmax = ngridmax; A.ncell = ncell; A.pitch_var = ncells_level;
+  A.brick = H.bold.as<double>(); A.cellvec = H.uold.as<double>();
+  HCHK(launch_oct_copy(A, true, s), "gather launch");
+  const double *d_grav = nullptr;
+  if (f) {
+    HCHK(H.fvec.ensure(sizeof(double) * 3 * ncell), "hipMalloc f");
+    HCHK(H.bf.ensure(sizeof(double) * 3 * ncells_level), "hipMalloc f brick");
+    HCHK(hipMemcpyAsync(H.fvec.p, f, sizeof(double) * 3 * ncell, hipMemcpyHostToDevice, s), "H2D f");
+    PackArgs G = A;
+    G.nvar = 3; G.brick = H.bf.as<double>(); G.cellvec = H.fvec.as<double>();
+    HCHK(launch_oct_copy(G, true, s), "gather launch");
+    d_grav = H.bf.as<double>();
+  }
+  ramses_amd_brick b;
+  ramses_amd_brick_dense(&b, n, n, n, 0);
+  if (int rc = ramses_amd_godunov_brick(p, &b, H.bold.as<double>(), d_grav, H.bnew.as<double>(), dx, dt, s)) return rc;
+  // The reference adds flux differences to the unew that set_unew prepared
+  // (= uold on active cells); the brick kernel returns uold + differences, so
+  // scattering it over unew's active cells gives the same array.
+  A.brick = H.bnew.as<double>(); A.cellvec = H.unew.as<double>();
+  HCHK(launch_oct_copy(A, false, s), "scatter launch");
+  HCHK(hipMemcpyAsync(unew, H.unew.p, sizeof(double) * nvar * ncell, hipMemcpyDeviceToHost, s), "D2H unew");
+  HCHK(hipStreamSynchronize(s), "sync");
+#undef HCHK
+  return 0;
+}
+
+// Fortran-friendly variant: f is always a valid array (ignored when has_f==0)
+int ramses_amd_godunov_fine_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                const int *igrid, const double *xg, int64_t ngridmax,
+                                int64_t ncoarse, int nx_loc, const double *uold, double *unew,
+                                const double *f_or_dummy, int has_f, double dx, double dt) {
+  return ramses_amd_godunov_fine_host(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, uold, unew,
+                                      has_f ? f_or_dummy : nullptr, dx, dt);
 }
 
 }  // extern "C"

@@ -1,0 +1,152 @@
+!==============================================================================
+! ramses_amd_iface -- ISO_C_BINDING view of libramses_amd.so (include/ramses_amd.h)
+! for the RAMSES patch directory ramses_amd/patch (make PATCH=...).
+!
+! Only plain C types cross the boundary: the shims pass the reference's own
+! module arrays by address (sequence association to assumed-size dummies) plus
+! a POD of solver knobs; C never touches Fortran module variables.
+!==============================================================================
+module ramses_amd_iface
+  use iso_c_binding
+  implicit none
+
+  ! struct ramses_amd_hydro_params (include/ramses_amd.h)
+  type, bind(C) :: ramses_amd_hydro_params
+     integer(c_int32_t) :: ndim, nvar
+     real(c_double)     :: gamma, smallr, smallc
+     integer(c_int32_t) :: slope_type, riemann
+     real(c_double)     :: slope_theta
+     integer(c_int32_t) :: scheme, niter_riemann
+     real(c_double)     :: difmag, courant_factor
+     integer(c_int32_t) :: fast_math, reserved
+  end type ramses_amd_hydro_params
+
+  ! struct ramses_amd_brick, only needed for the ABI size check
+  type, bind(C) :: ramses_amd_brick
+     integer(c_int32_t) :: nx, ny, nz, ng
+     integer(c_int64_t) :: pitch_y, pitch_z, pitch_var
+  end type ramses_amd_brick
+
+  interface
+     function ramses_amd_abi_check(sz_params, sz_brick) bind(C, name='ramses_amd_abi_check') result(rc)
+       import :: c_size_t, c_int
+       integer(c_size_t), value :: sz_params, sz_brick
+       integer(c_int) :: rc
+     end function ramses_amd_abi_check
+
+     function ramses_amd_last_error() bind(C, name='ramses_amd_last_error') result(msg)
+       import :: c_ptr
+       type(c_ptr) :: msg
+     end function ramses_amd_last_error
+
+     ! f_or_dummy: f(1,1) when has_f/=0, any valid array otherwise (not read)
+     function ramses_amd_godunov_fine_f90(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, &
+          & uold, unew, f_or_dummy, has_f, dx, dt) bind(C, name='ramses_amd_godunov_fine_f90') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_int64_t, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ilevel, ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: xg(*)
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       integer(c_int), value :: nx_loc
+       real(c_double) :: uold(*), unew(*), f_or_dummy(*)
+       integer(c_int), value :: has_f
+       real(c_double), value :: dx, dt
+       integer(c_int) :: rc
+     end function ramses_amd_godunov_fine_f90
+  end interface
+
+  logical, save :: ramses_amd_checked = .false.
+  logical, save :: ramses_amd_on = .true.
+
+contains
+
+  !---------------------------------------------------------------------------
+  ! Run-time A/B switch: RAMSES_AMD=0 in the environment selects the untouched
+  ! reference routines (compiled into the same binary under *_reference names).
+  !---------------------------------------------------------------------------
+  logical function ramses_amd_enabled()
+    character(len=16) :: val
+    integer :: stat, rc
+    type(ramses_amd_hydro_params) :: p
+    type(ramses_amd_brick) :: b
+    if (.not. ramses_amd_checked) then
+       call get_environment_variable('RAMSES_AMD', val, status=stat)
+       if (stat == 0) ramses_amd_on = (trim(val) /= '0')
+       if (ramses_amd_on) then
+          rc = ramses_amd_abi_check(c_sizeof(p), c_sizeof(b))
+          if (rc /= 0) call ramses_amd_fatal('ramses_amd_abi_check')
+       end if
+       ramses_amd_checked = .true.
+    end if
+    ramses_amd_enabled = ramses_amd_on
+  end function ramses_amd_enabled
+
+  !---------------------------------------------------------------------------
+  ! The reference has no error returns on this path: print and clean_stop
+  ! (amr/end.f90:26-46), as it does itself.
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_fatal(where)
+    character(len=*), intent(in) :: where
+    character(kind=c_char), pointer :: cmsg(:)
+    type(c_ptr) :: cp
+    integer :: i
+    character(len=512) :: msg
+    msg = ' '
+    cp = ramses_amd_last_error()
+    if (c_associated(cp)) then
+       call c_f_pointer(cp, cmsg, [512])
+       do i = 1, 512
+          if (cmsg(i) == c_null_char) exit
+          msg(i:i) = cmsg(i)
+       end do
+    end if
+    write(*,*) 'ramses_amd: FATAL in ', where, ': ', trim(msg)
+    write(*,*) 'ramses_amd: no CPU fallback is taken; set RAMSES_AMD=0 to run the reference path'
+    call clean_stop
+  end subroutine ramses_amd_fatal
+
+  !---------------------------------------------------------------------------
+  ! &HYDRO_PARAMS -> POD (hydro/hydro_parameters.f90:75-89)
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_fill_hydro_params(p)
+    use amr_parameters, only: ndim
+    use hydro_parameters
+    type(ramses_amd_hydro_params), intent(out) :: p
+    character(len=16) :: val
+    integer :: stat
+    p%ndim = ndim
+    p%nvar = nvar
+    p%gamma = gamma
+    p%smallr = smallr
+    p%smallc = smallc
+    p%slope_type = slope_type
+    p%slope_theta = slope_theta
+    select case (trim(riemann))
+    case ('llf');      p%riemann = 0
+    case ('hllc');     p%riemann = 1
+    case ('hll');      p%riemann = 2
+    case ('acoustic'); p%riemann = 3
+    case ('exact');    p%riemann = 4
+    case default;      p%riemann = -1
+    end select
+    if (trim(scheme) == 'muscl') then
+       p%scheme = 0
+    else if (trim(scheme) == 'plmde') then
+       p%scheme = 1
+    else
+       p%scheme = -1
+    end if
+    p%niter_riemann = niter_riemann
+    p%difmag = difmag
+    p%courant_factor = courant_factor
+    ! strict arithmetic (bit-identical to the reference) unless RAMSES_AMD_FAST=1
+    p%fast_math = 0
+    call get_environment_variable('RAMSES_AMD_FAST', val, status=stat)
+    if (stat == 0) then
+       if (trim(val) == '1') p%fast_math = 1
+    end if
+    p%reserved = 0
+  end subroutine ramses_amd_fill_hydro_params
+
+end module ramses_amd_iface

@@ -1,0 +1,103 @@
+"""GPU tests of the drop-in boundary.
+
+1. ramses_amd_godunov_fine_host on a synthetic RAMSES-layout octree (octs in
+   random slot order, cell vectors (1:ncell,1:nvar)) against the oracle.
+2. The REAL thing: the reference program linked with the patch directory
+   ramses_amd/patch (oracle/_ref/ramses3d_patch, built by
+   `oracle/build_ref.sh ramses 3 serial ramses_amd/patch`): same namelist in,
+   snapshots out, compared bit-for-bit with the goldens produced by the
+   untouched reference (tests/golden/sedov3d_ref_runs.npz)."""
+import ctypes as C
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from helpers import random_brick
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATCHED = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch")
+GOLD = os.path.join(ROOT, "tests", "golden", "sedov3d_ref_runs.npz")
+
+
+def _octree_layout(u, level, rng, ngridmax, ncoarse=1):
+    """Scatter brick u[nvar,n,n,n] into RAMSES cell vectors with octs of the
+    level placed in random slots; returns (cellvec[nvar,ncell], igrid, xg)."""
+    nvar, n = u.shape[0], u.shape[1]
+    no = n // 2
+    ngrid = no ** 3
+    ncell = ncoarse + 8 * ngridmax
+    slots = rng.permutation(ngridmax)[:ngrid] + 1            # 1-based oct slots
+    igrid = rng.permutation(slots).astype(np.int32)          # active list order
+    xg = np.zeros((3, ngridmax))
+    vec = rng.normal(size=(nvar, ncell))                     # garbage elsewhere
+    # oct g of the active list sits at a random oct position
+    pos = rng.permutation(ngrid)
+    oz, oy, ox = np.unravel_index(pos, (no, no, no))
+    for d, o in enumerate((ox, oy, oz)):
+        xg[d, igrid - 1] = (2 * o + 1) / n
+    for ind in range(8):
+        ix, iy, iz = ind & 1, (ind >> 1) & 1, (ind >> 2) & 1
+        icell = ncoarse + ind * ngridmax + (igrid - 1)
+        vec[:, icell] = u[:, 2 * oz + iz, 2 * oy + iy, 2 * ox + ix]
+    return vec, igrid, xg, (ox, oy, oz)
+
+
+def test_host_entry_on_synthetic_octree(gpu_lib, oracle):
+    import ramses_amd
+    rng = np.random.default_rng(3)
+    level, n = 4, 16
+    u = random_brick(n, n, n, seed=9)
+    dx, dt = 1.0 / n, 0.003
+    ngridmax = 700
+    uold, igrid, xg, (ox, oy, oz) = _octree_layout(u, level, rng, ngridmax)
+    unew = uold.copy()
+    other = unew.copy()
+    p = ramses_amd.make_params()
+    rc = gpu_lib.ramses_amd_godunov_fine_host(C.byref(p), level, len(igrid), igrid.ctypes.data_as(C.c_void_p),
+                                              xg.ctypes.data_as(C.c_void_p), ngridmax, 1, 1,
+                                              uold.ctypes.data_as(C.c_void_p), unew.ctypes.data_as(C.c_void_p),
+                                              None, dx, dt)
+    assert rc == 0, gpu_lib.ramses_amd_last_error()
+    ref = oracle.godunov_uniform(oracle.make_params(), u, dx, dt)
+    touched = np.zeros(unew.shape[1], bool)
+    for ind in range(8):
+        ix, iy, iz = ind & 1, (ind >> 1) & 1, (ind >> 2) & 1
+        icell = 1 + ind * ngridmax + (igrid - 1)
+        touched[icell] = True
+        assert np.array_equal(unew[:, icell], ref[:, 2 * oz + iz, 2 * oy + iy, 2 * ox + ix])
+    # cells of other octs / levels are untouched
+    assert np.array_equal(unew[:, ~touched], other[:, ~touched])
+    # a level that is not fully refined is refused loudly
+    rc = gpu_lib.ramses_amd_godunov_fine_host(C.byref(p), level, len(igrid) - 1, igrid.ctypes.data_as(C.c_void_p),
+                                              xg.ctypes.data_as(C.c_void_p), ngridmax, 1, 1,
+                                              uold.ctypes.data_as(C.c_void_p), unew.ctypes.data_as(C.c_void_p),
+                                              None, dx, dt)
+    assert rc == -2
+
+
+@pytest.mark.parametrize("riemann,slope", [("llf", 1), ("hllc", 2), ("hll", 7), ("acoustic", 8)])
+def test_patched_reference_program_reproduces_goldens(gpu_lib, riemann, slope):
+    if not os.path.exists(PATCHED):
+        pytest.skip("oracle/_ref/ramses3d_patch not built (needs the reference tree at build time)")
+    from oracle import ramses_snapshot as rs
+    z = np.load(GOLD)
+    key = "%s_s%d_muscl" % (riemann, slope)
+    nml = rs.sedov3d_namelist(level=4, nstepmax=4, foutput=1, riemann=riemann, slope_type=slope)
+    env_before = os.environ.get("RAMSES_AMD")
+    os.environ["RAMSES_AMD"] = "1"
+    try:
+        work, out = rs.run_reference(nml, binary=PATCHED)
+    finally:
+        if env_before is None:
+            os.environ.pop("RAMSES_AMD", None)
+        else:
+            os.environ["RAMSES_AMD"] = env_before
+    try:
+        for k in range(1, 5):
+            snap = rs.load_uniform_level(os.path.join(work, "output_%05d" % k), 4)
+            assert np.array_equal(snap["prim"], z["%s_prim%d" % (key, k - 1)]), (key, k)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
