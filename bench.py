@@ -52,9 +52,9 @@ def rank_grid(nranks):
     return tuple(p)
 
 
-def cpu_baseline(n_ref=48, steps=1):
-    """Time the CPU oracle (a scalar C port of the reference algorithm) on a
-    bounded sample of the same workload: `steps` sweeps of an n_ref^3 Sedov box."""
+def _cpu_baseline_port(n_ref=48, steps=1):
+    """Scalar C port (oracle/hydro_oracle.c) on 1 core: fallback when the
+    reference binaries are not present."""
     from oracle import pyoracle
     from ramses_amd import ic
     u, dx = ic.sedov3d(n_ref)
@@ -68,6 +68,52 @@ def cpu_baseline(n_ref=48, steps=1):
     return {"value": n_ref ** 3 * steps / t, "unit": "cell-updates/s", "cores": 1, "kind": "port",
             "sample": "%d sweep(s) of a %d^3 Sedov3D level, oracle/hydro_oracle.c (godfine1+unsplit restatement), %.1f s"
                       % (steps, n_ref, t)}
+
+
+def cpu_baseline():
+    """The reference itself (oracle/_ref/ramses3d[_mpi], the unmodified F90
+    program built by oracle/build_ref.sh) on the host cores of this box, on a
+    bounded sample of the same workload: sedov3d.nml at 128^3 (MPI) or 64^3
+    (serial); the rate comes from its own 'hydro - godunov' timer row."""
+    import re
+    import shutil
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    mpi_bin, ser_bin = os.path.join(ref, "ramses3d_mpi"), os.path.join(ref, "ramses3d")
+    mpiexec = "/opt/conda/bin/mpiexec"
+    try:
+        from oracle import ramses_snapshot as rs
+        ncores = os.cpu_count() or 1
+        try:
+            import psutil
+            ncores = psutil.cpu_count(logical=False) or ncores
+        except Exception:
+            pass
+        if os.path.exists(mpi_bin) and os.path.exists(mpiexec) and ncores >= 2:
+            P = 1
+            while P * 2 <= min(ncores, 64):
+                P *= 2
+            level, nstep, binary = 7, 10, mpi_bin
+        elif os.path.exists(ser_bin):
+            P, level, nstep, binary = 1, 6, 8, ser_bin
+        else:
+            return _cpu_baseline_port()
+        nml = rs.sedov3d_namelist(level=level, nstepmax=nstep, foutput=1000, mem_factor=3.0 if P > 1 else 1.3)
+        t0 = time.perf_counter()
+        work, out = rs.run_reference(nml, nproc=P, binary=binary, timeout=600)
+        wall = time.perf_counter() - t0
+        shutil.rmtree(work, ignore_errors=True)
+        nsweeps = len(re.findall(r"Fine step=", out))
+        row = [l for l in out.splitlines() if "hydro - godunov" in l][-1].split()
+        tg = float(row[2]) if P > 1 else float(row[0])     # MPI table: min avg MAX ...; serial: seconds
+        n = 2 ** level
+        return {"value": n ** 3 * nsweeps / tg, "unit": "cell-updates/s", "cores": P, "kind": "reference",
+                "sample": "unmodified reference F90 (amdflang -O2, NVECTOR=32%s), sedov3d.nml at %d^3, %d godunov_fine sweeps, "
+                          "'hydro - godunov' timer %s %.2f s (run wall %.1f s)"
+                          % (", MPICH %d ranks" % P if P > 1 else ", serial", n, nsweeps, "max over ranks" if P > 1 else "=", tg, wall)}
+    except Exception as exc:  # the baseline is a report, never a reason to lose the GPU number
+        out = _cpu_baseline_port()
+        out["sample"] += " (reference binary unavailable: %s)" % str(exc)[:200]
+        return out
 
 
 BYTES_PER_DOF_VCYCLE = 227   # SURVEY.md 8d: 202 B fine level + 178/7 B coarse hierarchy

@@ -296,8 +296,9 @@ p_region=1e-5,0.4"""
 
 
 def sedov3d_namelist(level, nstepmax, foutput=1, riemann="llf", slope_type=1, scheme="muscl", boxlen=0.5,
-                     poisson=False, init=SEDOV_INIT, extra=""):
-    ngridtot = int(1.3 * sum(8 ** l for l in range(level))) + 1000
+                     poisson=False, init=SEDOV_INIT, extra="", mem_factor=1.3):
+    """mem_factor: ngridtot / number of octs; use ~3 for MPI runs (ghost octs per rank)."""
+    ngridtot = int(mem_factor * sum(8 ** l for l in range(level))) + 1000
     return SEDOV3D_NML.format(level=level, nstepmax=nstepmax, foutput=foutput, riemann=riemann,
                               slope_type=slope_type, scheme=scheme, boxlen=boxlen, ngridtot=ngridtot,
                               poisson="poisson=.true." if poisson else "", init=init, extra=extra)
