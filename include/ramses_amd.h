@@ -194,6 +194,16 @@ int ramses_amd_mg_restrict(const double *d_res_f, double *d_rhs_c, double *d_u1_
                            int nf, void *stream);
 int ramses_amd_mg_interp_correct(double *d_phi_f, const double *d_corr_c, int nf,
                                  void *stream);
+/* Fused smoother: npass (2 or 4) red/black colour passes from d_phi_in into
+ * d_phi_out (distinct buffers) in one time-skewed pass; with d_res != NULL also
+ * the residual, with d_norm2 != NULL its dx^3-scaled squared norm.  Same values
+ * as npass calls of ramses_amd_mg_gauss_seidel (+ ramses_amd_mg_residual). */
+int ramses_amd_mg_smooth_fused(const double *d_phi_in, double *d_phi_out,
+                               const double *d_rhs, double *d_res, double *d_work,
+                               double *d_norm2, int n, double dx, int npass, void *stream);
+/* 1 (default): levels with n>=64 use the fused smoother inside multigrid_fine;
+ * 0: one kernel per colour pass.  Results do not depend on it. */
+int ramses_amd_mg_tune(int fused);
 
 /* ---------------------------------------------------------------------------
  * godunov_fine(ilevel) on the reference's OWN arrays (host memory, Fortran

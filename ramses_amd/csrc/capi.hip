@@ -20,6 +20,7 @@ using namespace ramses_amd;
 static thread_local char g_err[512] = "";
 static int g_tile_rows = 0;  // 0 = per-variant default
 static int g_zchunk = 128;
+static int g_mg_fused = 1;
 
 static int fail(int code, const char *fmt, ...) {
   va_list ap;
@@ -257,17 +258,18 @@ int ramses_amd_fill_ghosts_periodic(const ramses_amd_brick *b, double *d_u, int 
 static size_t mg_level_cells(int l) { return (size_t)1 << (3 * l); }
 // workspace: for l = 1..level-1: u1, u2, u3 (8^l doubles each); then the
 // residual partial sums and two norm scalars
+// which: 0 = u1 (correction), 1 = u2 (rhs), 2 = u3 (residual), 3 = ping-pong copy of u1
 static size_t mg_hier_offset(int level, int l, int which) {
-  size_t off = 0;
-  for (int m = 1; m < l; m++) off += 3 * mg_level_cells(m);
-  (void)level;
+  size_t off = mg_level_cells(level);           // fine-level ping-pong copy of phi comes first
+  for (int m = 1; m < l; m++) off += 4 * mg_level_cells(m);
   return off + (size_t)which * mg_level_cells(l);
 }
 static size_t mg_hier_size(int level) {
-  size_t off = 0;
-  for (int m = 1; m < level; m++) off += 3 * mg_level_cells(m);
+  size_t off = mg_level_cells(level);
+  for (int m = 1; m < level; m++) off += 4 * mg_level_cells(m);
   return off;
 }
+static const int MG_FUSED_MIN_N = 64;           // levels with n >= 64 use the fused time-skewed smoother
 
 int64_t ramses_amd_mg_workspace_doubles(int level) {
   if (level < 1 || level > 11) return fail(RAMSES_AMD_EINVAL, "multigrid level must be in [1,11] (got %d)", level);
@@ -299,6 +301,18 @@ int ramses_amd_mg_interp_correct(double *d_phi_f, const double *d_corr_c, int nf
   return 0;
 }
 
+int ramses_amd_mg_tune(int fused) { g_mg_fused = fused ? 1 : 0; return 0; }
+
+int ramses_amd_mg_smooth_fused(const double *d_phi_in, double *d_phi_out, const double *d_rhs, double *d_res,
+                               double *d_work, double *d_norm2, int n, double dx, int npass, void *stream) {
+  if (!d_phi_in || !d_phi_out || !d_rhs || d_phi_in == d_phi_out || n < 2 || (n & 1)) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  if (npass != 2 && npass != 4) return fail(RAMSES_AMD_EINVAL, "npass must be 2 or 4");
+  if (n < 64) return fail(RAMSES_AMD_EINVAL, "the fused smoother needs n >= 64 (got %d); use the per-colour kernels", n);
+  if (d_res && !d_work) return fail(RAMSES_AMD_EINVAL, "residual needs a workspace of %d doubles", MG_MAX_PARTIALS);
+  MGCHK(mg_launch_smooth_fused(d_phi_in, d_phi_out, d_rhs, d_res, d_work, d_norm2, n, dx, npass, reinterpret_cast<hipStream_t>(stream)), "mg fused smoother launch");
+  return 0;
+}
+
 int ramses_amd_gradient_phi_brick(int level, const double *d_phi, double *d_f, void *stream) {
   if (level < 1 || level > 11 || !d_phi || !d_f) return fail(RAMSES_AMD_EINVAL, "bad argument");
   const int n = 1 << level;
@@ -324,7 +338,18 @@ static hipError_t mg_coarse_cycle(double *w, int level, int l, int safe, hipStre
     return hipSuccess;
   }
   const int ncycle = safe ? ncycles_coarse_safe : 1;
+  double *partial = w + mg_hier_size(level);
   for (int cyc = 0; cyc < ncycle; cyc++) {
+    if (n >= MG_FUSED_MIN_N) {
+      // pre-smoothing + residual in one pass (u1 -> u4), correction on u4, post-smoothing back into u1
+      double *u4 = w + mg_hier_offset(level, l, 3);
+      if ((e = mg_launch_smooth_fused(u1, u4, u2, u3, partial, nullptr, n, dx, 2 * ngs_coarse, s)) != hipSuccess) return e;
+      if ((e = mg_launch_restrict(u3, w + mg_hier_offset(level, l - 1, 1), w + mg_hier_offset(level, l - 1, 0), n, s)) != hipSuccess) return e;
+      if ((e = mg_coarse_cycle(w, level, l - 1, safe, s)) != hipSuccess) return e;
+      if ((e = mg_launch_interp(u4, w + mg_hier_offset(level, l - 1, 0), n, s)) != hipSuccess) return e;
+      if ((e = mg_launch_smooth_fused(u4, u1, u2, nullptr, nullptr, nullptr, n, dx, 2 * ngs_coarse, s)) != hipSuccess) return e;
+      continue;
+    }
     for (int i = 0; i < ngs_coarse; i++) {
       if ((e = mg_launch_gs(u1, u2, n, dx2, 0, s)) != hipSuccess) return e;
       if ((e = mg_launch_gs(u1, u2, n, dx2, 1, s)) != hipSuccess) return e;
@@ -358,26 +383,38 @@ int ramses_amd_multigrid_fine_brick(int level, const double *d_rho, double rho_t
   MGCHK(mg_launch_rhs(d_rho, d_f2, N, fourpi, rho_tot, s), "mg rhs launch");
   int iter = 0;
   double err = 1.0, last_err, i_res_norm2 = 0.0, res_norm2 = 0.0;
+  const bool fused = (n >= MG_FUSED_MIN_N) && g_mg_fused;
+  double *d_phi2 = d_work;   // fine-level ping-pong copy
   for (;;) {
     iter++;
-    for (int i = 0; i < ngs_fine; i++) {
-      MGCHK(mg_launch_gs(d_phi, d_f2, n, dx2, 0, s), "mg gs launch");
-      MGCHK(mg_launch_gs(d_phi, d_f2, n, dx2, 1, s), "mg gs launch");
+    double *cur = d_phi;
+    if (fused) {
+      MGCHK(mg_launch_smooth_fused(d_phi, d_phi2, d_f2, d_f1, partial, iter == 1 ? d_norm : nullptr, n, dx, 2 * ngs_fine, s), "mg fused smoother launch");
+      cur = d_phi2;
+    } else {
+      for (int i = 0; i < ngs_fine; i++) {
+        MGCHK(mg_launch_gs(d_phi, d_f2, n, dx2, 0, s), "mg gs launch");
+        MGCHK(mg_launch_gs(d_phi, d_f2, n, dx2, 1, s), "mg gs launch");
+      }
+      MGCHK(mg_launch_residual(d_phi, d_f2, d_f1, n, dx, partial, iter == 1 ? d_norm : nullptr, s), "mg residual launch");
     }
-    MGCHK(mg_launch_residual(d_phi, d_f2, d_f1, n, dx, partial, iter == 1 ? d_norm : nullptr, s), "mg residual launch");
     if (iter == 1) {
       MGCHK(hipMemcpyAsync(&i_res_norm2, d_norm, sizeof(double), hipMemcpyDeviceToHost, s), "norm copy");
     }
     if (level > 1) {
       MGCHK(mg_launch_restrict(d_f1, d_work + mg_hier_offset(level, level - 1, 1), d_work + mg_hier_offset(level, level - 1, 0), n, s), "mg restrict launch");
       MGCHK(mg_coarse_cycle(d_work, level, level - 1, *safe_mode, s), "mg coarse cycle");
-      MGCHK(mg_launch_interp(d_phi, d_work + mg_hier_offset(level, level - 1, 0), n, s), "mg interp launch");
+      MGCHK(mg_launch_interp(cur, d_work + mg_hier_offset(level, level - 1, 0), n, s), "mg interp launch");
     }
-    for (int i = 0; i < ngs_fine; i++) {
-      MGCHK(mg_launch_gs(d_phi, d_f2, n, dx2, 0, s), "mg gs launch");
-      MGCHK(mg_launch_gs(d_phi, d_f2, n, dx2, 1, s), "mg gs launch");
+    if (fused) {
+      MGCHK(mg_launch_smooth_fused(d_phi2, d_phi, d_f2, d_f1, partial, d_norm + 1, n, dx, 2 * ngs_fine, s), "mg fused smoother launch");
+    } else {
+      for (int i = 0; i < ngs_fine; i++) {
+        MGCHK(mg_launch_gs(d_phi, d_f2, n, dx2, 0, s), "mg gs launch");
+        MGCHK(mg_launch_gs(d_phi, d_f2, n, dx2, 1, s), "mg gs launch");
+      }
+      MGCHK(mg_launch_residual(d_phi, d_f2, d_f1, n, dx, partial, d_norm + 1, s), "mg residual launch");
     }
-    MGCHK(mg_launch_residual(d_phi, d_f2, d_f1, n, dx, partial, d_norm + 1, s), "mg residual launch");
     MGCHK(hipMemcpyAsync(&res_norm2, d_norm + 1, sizeof(double), hipMemcpyDeviceToHost, s), "norm copy");
     MGCHK(hipStreamSynchronize(s), "stream sync");
     last_err = err;

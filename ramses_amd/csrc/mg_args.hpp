@@ -13,6 +13,9 @@ hipError_t mg_launch_residual(const double *phi, const double *rhs, double *res,
                               double *partial, double *norm_out, hipStream_t s);
 hipError_t mg_launch_restrict(const double *res_f, double *rhs_c, double *u1_c, int nf, hipStream_t s);
 hipError_t mg_launch_interp(double *phi_f, const double *corr_c, int nf, hipStream_t s);
+hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const double *rhs, double *res,
+                                  double *partial, double *norm_out, int n, double dx, int npass,
+                                  hipStream_t s);
 hipError_t mg_launch_gradient(const double *phi, double *f, int n, double a, double b, hipStream_t s);
 
 }  // namespace ramses_amd

@@ -32,6 +32,17 @@ __device__ __forceinline__ double nb_sum6(const double *__restrict__ phi, int i,
   return s;
 }
 
+// x/6 correctly rounded without the IEEE division sequence: q = RN(x*z),
+// r = x - 6q (exact in an FMA), q' = RN(q + r*z) with z = RN(1/6) -- Markstein's
+// division by a constant; checked against true division on 4e5 random and
+// adversarial operands (and by the bit-parity tests on the GPU).
+__device__ __forceinline__ double div6(double x) {
+  const double z = 1.0 / 6.0;
+  const double q = x * z;
+  const double r = __builtin_fma(-6.0, q, x);
+  return __builtin_fma(r, z, q);
+}
+
 // f2 = fourpi*(rho - rho_tot): make_fine_bc_rhs on an unmasked periodic level
 __global__ __launch_bounds__(256) void mg_rhs_kernel(const double *__restrict__ rho, double *__restrict__ f2,
                                                       long N, double fourpi, double rho_tot) {
@@ -51,7 +62,7 @@ __global__ __launch_bounds__(256) void mg_gs_kernel(double *__restrict__ phi, co
     const int i = 2 * ih + ((j + k + color) & 1);
     const double nb = nb_sum6(phi, i, j, k, n);
     const long c = (long)i + (long)n * (j + (long)n * k);
-    phi[c] = (nb - dx2 * rhs[c]) / 6.0;
+    phi[c] = div6(nb - dx2 * rhs[c]);
   }
 }
 
@@ -215,6 +226,267 @@ hipError_t mg_launch_interp(double *phi_f, const double *corr_c, int nf, hipStre
 }
 hipError_t mg_launch_gradient(const double *phi, double *f, int n, double a, double b, hipStream_t s) {
   hipLaunchKernelGGL(mg_gradient_kernel, dim3(grid_for((long)n * n * n, 8192)), dim3(256), 0, s, phi, f, n, a, b);
+  return hipGetLastError();
+}
+
+// ===========================================================================
+// Fused, time-skewed smoother: P colour passes (P/2 full red-black sweeps) and
+// optionally the residual with its norm in ONE pass over the level.
+//
+// A workgroup owns an (LX-2P) x (LY-2P) column tile and marches along z.  The
+// P colour passes run as pipeline stages lagging 2 planes each: at step m stage
+// s applies pass s to plane m-2(s-1), reading planes z-1, z, z+1 that stage s-1
+// finished one step earlier.  Planes live in an LDS ring of 2P+4 slots; every
+// pass updates only cells whose whole dependency cone was loaded (the region
+// shrinks by one cell per pass), so the values are exactly those of the global
+// red-black sweeps -- bit-identical -- while phi is read ~1.7x and written once
+// per TWO sweeps instead of 4 reads + 4 partial-line writes.  One barrier per
+// step.  Within a step stage s writes only plane m-2(s-1) (cells of its colour)
+// and reads that plane's other colour plus planes at odd offsets from m, which
+// no stage writes in that step.  Out of place (phi_in -> phi_out): tile halos
+// must see the values from before the sweeps while other workgroups store.
+// ===========================================================================
+// H = halo width: P for the smoother alone; P+1 when the residual is fused (it
+// reads FINAL values one cell beyond the tile interior).
+template <int P, bool RESID>
+struct SmoothGeom {
+  static constexpr int LX = 64, LY = 24;
+  static constexpr int H = RESID ? P + 1 : P;
+  static constexpr int IX = LX - 2 * H, IY = LY - 2 * H;
+  static constexpr int R = 2 * P + 4;
+  static constexpr int PLANE = LX * LY;
+};
+
+constexpr int SMOOTH_THREADS = 384;   // 6 wavefronts
+
+template <int P, bool RESID>
+__global__ __launch_bounds__(SMOOTH_THREADS) void mg_smooth_fused_kernel(const double *__restrict__ phi_in,
+                                                                          double *__restrict__ phi_out,
+                                                                          const double *__restrict__ rhs,
+                                                                          double *__restrict__ res,
+                                                                          double *__restrict__ partial, int n,
+                                                                          double dx2, double oneoverdx2,
+                                                                          int zchunk, int ntx, int nty) {
+  using G = SmoothGeom<P, RESID>;
+  constexpr int H = G::H;
+  constexpr int NW = SMOOTH_THREADS / 64;                  // 6 waves
+  constexpr int NROW = G::LY / NW;                         // 4 full rows per wave (loads, final stage)
+  constexpr int NPAIR = G::LY / (2 * NW);                  // 2 row pairs per wave (colour passes)
+  static_assert(G::LY % (2 * NW) == 0, "tile rows must split evenly over the wavefronts");
+  extern __shared__ __attribute__((aligned(16))) double ring[];  // [R][LY][LX]
+  __shared__ double sm[SMOOTH_THREADS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int bid = blockIdx.x;
+  const int tix = bid % ntx, tiy = (bid / ntx) % nty, tiz = bid / (ntx * nty);
+  const int x0 = tix * G::IX - H, y0 = tiy * G::IY - H;   // global coords of tile cell (0,0)
+  const int z0 = tiz * zchunk;
+  const int z1 = min(z0 + zchunk, n);                     // planes [z0,z1) are produced
+  const long nn = (long)n * n;
+  // n >= LX (the launcher guarantees it): one conditional wrap is enough
+  auto wrap1 = [&](int v) { return v < 0 ? v + n : (v >= n ? v - n : v); };
+  auto slot = [&](int z) { int s = z % G::R; return s < 0 ? s + G::R : s; };
+
+  // (a) row mapping: lane = x, wave wv owns rows wv + NW*i -- coalesced loads/stores
+  const int gxu = x0 + lane;
+  int goffR[NROW], lofsR[NROW];
+#pragma unroll
+  for (int i = 0; i < NROW; i++) {
+    const int ly = wv + NW * i;
+    goffR[i] = wrap1(y0 + ly) * n + wrap1(gxu);
+    lofsR[i] = ly * G::LX + lane;
+  }
+  // (b) colour mapping: a wave owns row pairs; lanes 0-31 take the even row of the
+  // pair, lanes 32-63 the odd row, each lane one (2p, 2p+1) cell pair: every lane
+  // updates exactly one cell per colour pass (no half-masked wavefronts)
+  const int pr = lane & 31, sub = lane >> 5;
+  int lyC[NPAIR], goffC[NPAIR][2];
+#pragma unroll
+  for (int j = 0; j < NPAIR; j++) {
+    lyC[j] = 2 * (wv + NW * j) + sub;
+    const int gy = wrap1(y0 + lyC[j]) * n;
+    goffC[j][0] = gy + wrap1(x0 + 2 * pr);
+    goffC[j][1] = gy + wrap1(x0 + 2 * pr + 1);
+  }
+  double acc = 0.0;
+
+  const int m_begin = z0 - H - 2;
+  const int m_end = (z1 - 1) + 2 * P;
+
+  // All global reads of a step (the new phi plane, the rhs of the P colour
+  // passes and of the residual plane) are issued one step AHEAD into registers:
+  // every address is valid (wrapped), so the loads are unconditional and their
+  // latency hides behind the previous step's stencil work.
+  struct StepLoads { double ph[NROW]; double rv[P][NPAIR]; double rf[NROW]; };
+  // which cell of the pair has colour c on plane z in row ly: lx = 2p + off
+  auto pair_off = [&](int ly, int z, int color) { return ((x0 + y0 + ly + z) & 1) ^ color; };
+  auto issue = [&](int m, StepLoads &L) {
+    {
+      const double *__restrict__ base = phi_in + (long)wrap1(m + 2) * nn;
+#pragma unroll
+      for (int i = 0; i < NROW; i++) L.ph[i] = base[goffR[i]];
+    }
+#pragma unroll
+    for (int s = 1; s <= P; s++) {
+      const int z = m - 2 * (s - 1);
+      const double *__restrict__ base = rhs + (long)wrap1(z) * nn;
+#pragma unroll
+      for (int j = 0; j < NPAIR; j++) L.rv[s - 1][j] = base[goffC[j][pair_off(lyC[j], z, (s & 1) ? 0 : 1)]];
+    }
+    if (RESID) {
+      const double *__restrict__ base = rhs + (long)wrap1(m - 2 * P) * nn;
+#pragma unroll
+      for (int i = 0; i < NROW; i++) L.rf[i] = base[goffR[i]];
+    }
+  };
+  StepLoads cur, nxt;
+  issue(m_begin, cur);
+  for (int m = m_begin; m <= m_end; m++) {
+    issue(m + 1, nxt);
+    const int zl = m + 2;
+    const bool do_load = (zl >= z0 - H) && (zl <= z1 - 1 + H);
+    // ---- gather phase: every LDS read of this step is issued before any LDS
+    // write.  No stage reads a cell that another stage (or another lane of the
+    // same stage) writes in the same step, so hoisting the reads is exact and
+    // gives the scheduler independent stencil sums instead of a serial chain.
+    double nbv[P][NPAIR];
+    int cidx[P][NPAIR];
+    bool on[P][NPAIR];
+#pragma unroll
+    for (int s = 1; s <= P; s++) {
+      const int z = m - 2 * (s - 1);
+      const bool zin = !(z < z0 - (H - s) || z > z1 - 1 + (H - s));
+      const int color = (s & 1) ? 0 : 1;                  // odd passes red, even black
+      const double *pc = ring + slot(z) * G::PLANE;
+      const double *pm = ring + slot(z - 1) * G::PLANE;
+      const double *pp = ring + slot(z + 1) * G::PLANE;
+#pragma unroll
+      for (int j = 0; j < NPAIR; j++) {
+        const int ly = lyC[j];
+        const int lx = 2 * pr + pair_off(ly, z, color);
+        const int c = ly * G::LX + lx;
+        cidx[s - 1][j] = c;
+        on[s - 1][j] = zin && (lx >= s) && (lx < G::LX - s) && (ly >= s) && (ly < G::LY - s);
+        double nb = 0.0;
+        if (on[s - 1][j]) {
+          nb = nb + pc[c - 1];
+          nb = nb + pc[c - G::LX];
+          nb = nb + pm[c];
+          nb = nb + pc[c + 1];
+          nb = nb + pc[c + G::LX];
+          nb = nb + pp[c];
+        }
+        nbv[s - 1][j] = nb;
+      }
+    }
+    double nbf[NROW], phf[NROW];
+    bool onf[NROW];
+    const int zf = m - 2 * P;
+    {
+      const bool zin = (zf >= z0) && (zf <= z1 - 1);
+      const double *pc = ring + slot(zf) * G::PLANE;
+      const double *pm = ring + slot(zf - 1) * G::PLANE;
+      const double *pp = ring + slot(zf + 1) * G::PLANE;
+      const bool xin = zin && (lane >= H) && (lane < G::LX - H) && (gxu < n);
+#pragma unroll
+      for (int i = 0; i < NROW; i++) {
+        const int ly = wv + NW * i;
+        onf[i] = xin && ly >= H && ly < G::LY - H && (y0 + ly) < n;
+        double nb = 0.0, ph = 0.0;
+        if (onf[i]) {
+          const int c = lofsR[i];
+          ph = pc[c];
+          if (RESID) {
+            nb = nb + pc[c - 1];
+            nb = nb + pc[c - G::LX];
+            nb = nb + pm[c];
+            nb = nb + pc[c + 1];
+            nb = nb + pc[c + G::LX];
+            nb = nb + pp[c];
+          }
+        }
+        nbf[i] = nb; phf[i] = ph;
+      }
+    }
+    // ---- update phase: colour passes write their cells -------------------------
+#pragma unroll
+    for (int s = 1; s <= P; s++) {
+      double *pc = ring + slot(m - 2 * (s - 1)) * G::PLANE;
+#pragma unroll
+      for (int j = 0; j < NPAIR; j++)
+        if (on[s - 1][j]) pc[cidx[s - 1][j]] = div6(nbv[s - 1][j] - dx2 * cur.rv[s - 1][j]);
+    }
+    // ---- final stage: store phi (+ residual and its norm) of plane m-2P -------
+    {
+      const long zoff = (long)zf * nn;
+#pragma unroll
+      for (int i = 0; i < NROW; i++) {
+        if (onf[i]) {
+          const long g = zoff + goffR[i];
+          phi_out[g] = phf[i];
+          if (RESID) {
+            const double r = -oneoverdx2 * (nbf[i] - 6.0 * phf[i]) + cur.rf[i];
+            res[g] = r;
+            acc = acc + r * r;
+          }
+        }
+      }
+    }
+    // ---- stage 0: plane m+2 (values from before the sweeps) into its ring slot --
+    if (do_load) {
+      double *pl = ring + slot(zl) * G::PLANE;
+#pragma unroll
+      for (int i = 0; i < NROW; i++) pl[lofsR[i]] = cur.ph[i];
+    }
+    __syncthreads();
+    cur = nxt;
+  }
+  if (RESID && partial) {
+    sm[tid] = acc;
+    __syncthreads();
+    // deterministic fixed-order tree over the 384 threads
+    if (tid < 128) sm[tid] = sm[tid] + sm[tid + 256];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) sm[tid] = sm[tid] + sm[tid + s];
+      __syncthreads();
+    }
+    if (tid == 0) partial[blockIdx.x] = sm[0];
+  }
+}
+
+// P colour passes (P = 2 or 4) from phi_in into phi_out; with res != NULL also
+// the residual, and with norm_out != NULL its dx^3-scaled squared norm.
+hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const double *rhs, double *res,
+                                  double *partial, double *norm_out, int n, double dx, int npass,
+                                  hipStream_t s) {
+  if (npass != 4 && npass != 2) return hipErrorInvalidValue;
+  if (n < 64) return hipErrorInvalidValue;   // tile wider than the level: use the per-colour kernels
+  const int P = npass;
+  const int H = res ? P + 1 : P;
+  const int IX = 64 - 2 * H, IY = 24 - 2 * H;
+  const int ntx = (n + IX - 1) / IX, nty = (n + IY - 1) / IY;
+  int zchunk = n >= 256 ? 128 : (n >= 128 ? 64 : n);
+  const int ntz = (n + zchunk - 1) / zchunk;
+  const int blocks = ntx * nty * ntz;
+  if (res && blocks > MG_MAX_PARTIALS) return hipErrorInvalidValue;
+  const size_t lds = sizeof(double) * (size_t)(2 * P + 4) * 64 * 24;
+  const double dx2 = dx * dx, oneoverdx2 = 1.0 / (dx * dx);
+  hipError_t e;
+#define SM_LAUNCH(PP, RR)                                                                                     \
+  do {                                                                                                        \
+    auto k = mg_smooth_fused_kernel<PP, RR>;                                                                  \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                            (int)lds);                                                                        \
+    if (e != hipSuccess) return e;                                                                            \
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(SMOOTH_THREADS), lds, s, phi_in, phi_out, rhs, res, partial, n, dx2,        \
+                       oneoverdx2, zchunk, ntx, nty);                                                         \
+  } while (0)
+  if (P == 4) { if (res) SM_LAUNCH(4, true); else SM_LAUNCH(4, false); }
+  else { if (res) SM_LAUNCH(2, true); else SM_LAUNCH(2, false); }
+#undef SM_LAUNCH
+  if (res && norm_out)
+    hipLaunchKernelGGL(mg_sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, blocks, dx * dx * dx, norm_out);
   return hipGetLastError();
 }
 

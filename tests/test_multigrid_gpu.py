@@ -103,3 +103,56 @@ def test_solve_64_matches_oracle(gpu_lib, oracle):
     assert it == r["iters"]
     assert np.array_equal(lev.phi.cpu().numpy(), r["phi"])
     assert np.array_equal(lev.f.cpu().numpy(), oracle.gradient_phi_uniform(r["phi"]))
+
+
+@pytest.mark.parametrize("n,npass", [(64, 4), (64, 2), (128, 4), (70, 4), (100, 2)])
+def test_fused_smoother_bit_exact(gpu_lib, oracle, n, npass):
+    """The time-skewed fused smoother (+ residual + norm) equals npass colour
+    passes of the plain red-black sweep, bit for bit (also for n that is not a
+    multiple of the tile and smaller than it)."""
+    import torch
+    L, OL = gpu_lib, oracle.lib()
+    rng = np.random.default_rng(n + npass)
+    phi = rng.normal(size=(n, n, n))
+    rhs = rng.normal(size=(n, n, n))
+    dx = 1.0 / 64
+    ref = phi.copy()
+    for p in range(npass):
+        OL.ora_mg_gauss_seidel(ref, rhs, n, dx * dx, 1 if p % 2 == 0 else 0)
+    rres = np.zeros_like(ref)
+    OL.ora_mg_residual(ref, rhs, rres, n, dx)
+    din, dout, dres = _dev(phi), _dev(np.zeros_like(phi)), _dev(np.zeros_like(phi))
+    work, norm = _dev(np.zeros(4096 + 8)), _dev(np.zeros(1))
+    rc = L.ramses_amd_mg_smooth_fused(_p(din), _p(dout), _p(_dev(rhs)), _p(dres), _p(work), _p(norm), n, dx, npass, None)
+    assert rc == 0, L.ramses_amd_last_error()
+    torch.cuda.synchronize()
+    assert np.array_equal(din.cpu().numpy(), phi)          # input untouched
+    assert np.array_equal(dout.cpu().numpy(), ref)
+    assert np.array_equal(dres.cpu().numpy(), rres)
+    nref = OL.ora_mg_norm2(rres, n, dx)
+    assert abs(norm.item() - nref) <= 1e-13 * nref
+    # smoother only
+    dout2 = _dev(np.zeros_like(phi))
+    assert L.ramses_amd_mg_smooth_fused(_p(din), _p(dout2), _p(_dev(rhs)), None, None, None, n, dx, npass, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(dout2.cpu().numpy(), ref)
+
+
+def test_solve_fused_equals_unfused(gpu_lib):
+    import torch
+    from ramses_amd.poisson import PoissonLevel
+    n = 128
+    rng = np.random.default_rng(5)
+    rho = 1.0 + rng.random((n, n, n))
+    rho[30:60, 40:90, 10:30] += 9.0
+    outs = []
+    for fused in (1, 0):
+        gpu_lib.ramses_amd_mg_tune(fused)
+        lev = PoissonLevel(7, boxlen=1.0, epsilon=1e-7)
+        lev.rho.copy_(_dev(rho))
+        it, e = lev.multigrid_fine(float(rho.mean()))
+        torch.cuda.synchronize()
+        outs.append((it, lev.phi.cpu().numpy()))
+    gpu_lib.ramses_amd_mg_tune(1)
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1])
