@@ -233,6 +233,21 @@ int ramses_amd_godunov_fine_f90(const ramses_amd_hydro_params *p, int ilevel, in
                                 double *unew, const double *f_or_dummy, int has_f,
                                 double dx, double dt);
 
+/* ---------------------------------------------------------------------------
+ * multigrid_fine(ilevel,icount) on the reference's OWN arrays: the entry point
+ * ramses_amd/patch/multigrid_fine_commons.f90 binds.  Replaces
+ * poisson/multigrid_fine_commons.f90:25-296 at levelmin of a periodic
+ * single-rank run (first guess phi=0 as make_multipole_phi sets it, all cells
+ * unmasked).  rho, phi = (1:ncell) cell vectors; on exit phi of the level's
+ * cells holds the potential.  safe_mode in/out (0/1), iters/err as printed by
+ * the reference ('==> Level= Step= Error=').  Synchronous; no CPU fallback.
+ * ------------------------------------------------------------------------- */
+int ramses_amd_multigrid_fine_f90(int ilevel, int ngrid, const int *igrid, const double *xg,
+                                  int64_t ngridmax, int64_t ncoarse, int nx_loc,
+                                  const double *rho, double *phi, double rho_tot,
+                                  double fourpi, double epsilon, int *safe_mode,
+                                  int *iters, double *err);
+
 #ifdef __cplusplus
 }
 #endif

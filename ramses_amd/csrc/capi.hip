@@ -530,4 +530,63 @@ int ramses_amd_godunov_fine_f90(const ramses_amd_hydro_params *p, int ilevel, in
                                       has_f ? f_or_dummy : nullptr, dx, dt);
 }
 
+// multigrid_fine(ilevel,icount) on the reference's own arrays (levelmin of a
+// periodic single-rank run: first guess phi = 0, every cell unmasked).
+int ramses_amd_multigrid_fine_f90(int ilevel, int ngrid, const int *igrid, const double *xg,
+                                  int64_t ngridmax, int64_t ncoarse, int nx_loc, const double *rho,
+                                  double *phi, double rho_tot, double fourpi, double epsilon,
+                                  int *safe_mode, int *iters, double *err) {
+  if (!igrid || !xg || !rho || !phi || !safe_mode) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (nx_loc != 1) return fail(RAMSES_AMD_EUNSUPPORTED, "device multigrid needs a periodic box with nx=ny=nz=1 (got nx_loc=%d)", nx_loc);
+  if (ilevel < 1 || ilevel > 11) return fail(RAMSES_AMD_EINVAL, "level out of range");
+  const int n = 1 << ilevel;
+  const long N = (long)n * n * n;
+  if ((long)ngrid * 8 != N)
+    return fail(RAMSES_AMD_EUNSUPPORTED, "level %d is not fully refined on this rank (ngrid=%d): masked/AMR multigrid is not on the device yet", ilevel, ngrid);
+  const long ncell = ncoarse + 8 * ngridmax;
+  hipStream_t s = nullptr;
+  HostCtx &H = g_host;
+  static DevBuf rhovec, phivec, brho, bphi, bf1, bf2, work;
+#define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipfail(e_, what); } while (0)
+  const int64_t nwork = ramses_amd_mg_workspace_doubles(ilevel);
+  HCHK(rhovec.ensure(sizeof(double) * ncell), "hipMalloc");
+  HCHK(phivec.ensure(sizeof(double) * ncell), "hipMalloc");
+  HCHK(brho.ensure(sizeof(double) * N), "hipMalloc");
+  HCHK(bphi.ensure(sizeof(double) * N), "hipMalloc");
+  HCHK(bf1.ensure(sizeof(double) * N), "hipMalloc");
+  HCHK(bf2.ensure(sizeof(double) * N), "hipMalloc");
+  HCHK(work.ensure(sizeof(double) * nwork), "hipMalloc");
+  HCHK(H.igrid.ensure(sizeof(int) * ngrid), "hipMalloc igrid");
+  HCHK(H.xg.ensure(sizeof(double) * 3 * ngridmax), "hipMalloc xg");
+  HCHK(H.octorg.ensure(sizeof(long) * ngrid), "hipMalloc octorg");
+  HCHK(H.flag.ensure(sizeof(int)), "hipMalloc flag");
+  HCHK(hipMemcpyAsync(rhovec.p, rho, sizeof(double) * ncell, hipMemcpyHostToDevice, s), "H2D rho");
+  HCHK(hipMemcpyAsync(phivec.p, phi, sizeof(double) * ncell, hipMemcpyHostToDevice, s), "H2D phi");
+  HCHK(hipMemcpyAsync(H.igrid.p, igrid, sizeof(int) * ngrid, hipMemcpyHostToDevice, s), "H2D igrid");
+  HCHK(hipMemcpyAsync(H.xg.p, xg, sizeof(double) * 3 * ngridmax, hipMemcpyHostToDevice, s), "H2D xg");
+  HCHK(hipMemsetAsync(H.flag.p, 0, sizeof(int), s), "memset");
+  const double skip[3] = {0.0, 0.0, 0.0};
+  HCHK(launch_oct_origin(H.igrid.as<int>(), H.xg.as<double>(), ngridmax, ngrid, n, skip, H.octorg.as<long>(), H.flag.as<int>(), s), "oct origin launch");
+  int bad = 0;
+  HCHK(hipMemcpyAsync(&bad, H.flag.p, sizeof(int), hipMemcpyDeviceToHost, s), "D2H flag");
+  HCHK(hipStreamSynchronize(s), "sync");
+  if (bad) return fail(RAMSES_AMD_EINVAL, "%d octs of level %d do not sit on the level lattice", bad, ilevel);
+  PackArgs A;
+  A.igrid = H.igrid.as<int>(); A.octorg = H.octorg.as<long>();
+  A.ngrid = ngrid; A.n = n; A.nvar = 1;
+  A.ncoarse = ncoarse; A.ngridmax = ngridmax; A.ncell = ncell; A.pitch_var = N;
+  A.brick = brho.as<double>(); A.cellvec = rhovec.as<double>();
+  HCHK(launch_oct_copy(A, true, s), "gather launch");
+  HCHK(hipMemsetAsync(bphi.p, 0, sizeof(double) * N, s), "memset phi");   // make_multipole_phi, periodic: phi = 0
+  if (int rc = ramses_amd_multigrid_fine_brick(ilevel, brho.as<double>(), rho_tot, fourpi, epsilon, safe_mode,
+                                               bphi.as<double>(), bf1.as<double>(), bf2.as<double>(),
+                                               work.as<double>(), iters, err, s)) return rc;
+  A.brick = bphi.as<double>(); A.cellvec = phivec.as<double>();
+  HCHK(launch_oct_copy(A, false, s), "scatter launch");
+  HCHK(hipMemcpyAsync(phi, phivec.p, sizeof(double) * ncell, hipMemcpyDeviceToHost, s), "D2H phi");
+  HCHK(hipStreamSynchronize(s), "sync");
+#undef HCHK
+  return 0;
+}
+
 }  // extern "C"

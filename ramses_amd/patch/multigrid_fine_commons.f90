@@ -1,0 +1,66 @@
+!==============================================================================
+! multigrid_fine_commons.f90 of the ramses_amd patch directory.
+!
+! Shadows poisson/multigrid_fine_commons.f90 (bin/Makefile:153 VPATH).  The
+! untouched reference file is pulled in by the preprocessor with
+! multigrid_fine renamed to multigrid_fine_reference, so every other symbol of
+! that file (recursive_multigrid_coarse, build_parent_comms_mg, make_fine_mask,
+! make_fine_bc_rhs, make_virtual_mg_*, ...) stays the reference's; the new
+! multigrid_fine(ilevel,icount) keeps the reference's name, arguments and
+! meaning and runs the V-cycles on the MI355X through the C ABI.
+!==============================================================================
+#define multigrid_fine multigrid_fine_reference
+#include "poisson/multigrid_fine_commons.f90"
+#undef multigrid_fine
+
+subroutine multigrid_fine(ilevel,icount)
+  use amr_commons
+  use poisson_commons
+  use poisson_parameters
+  use constants, only: twopi
+  use ramses_amd_iface
+  implicit none
+  integer, intent(in) :: ilevel,icount
+  !--------------------------------------------------------------------------
+  ! Same contract as the reference (poisson/multigrid_fine_commons.f90:25-296):
+  ! on entry rho and rho_tot hold the source; on exit phi holds the potential
+  ! of the level.  f(:,1:3) is scratch in the reference (force_fine overwrites
+  ! it next) and is left untouched here.
+  !--------------------------------------------------------------------------
+  integer::rc,nx_loc,isafe,iters
+  real(dp)::scale,fourpi
+  real(kind=8)::err
+
+  if(gravity_type>0)return
+  if(numbtot(1,ilevel)==0)return
+
+  if(.not.ramses_amd_enabled())then
+     call multigrid_fine_reference(ilevel,icount)
+     return
+  end if
+  if(verbose) print '(A,I2)','Entering fine multigrid (MI355X) at level ',ilevel
+
+  ! What the device path does not implement stops the run (no silent fallback)
+  if(ncpu>1.or.ilevel>levelmin.or.nboundary>0)then
+     write(*,*)'ramses_amd: device multigrid_fine handles levelmin of a periodic single-rank run;'
+     write(*,*)'            got ncpu=',ncpu,' ilevel=',ilevel,' levelmin=',levelmin,' nboundary=',nboundary
+     call ramses_amd_fatal('multigrid_fine (AMR level / several ranks / physical boundaries)')
+  end if
+
+  nx_loc=icoarse_max-icoarse_min+1
+  scale=boxlen/dble(nx_loc)
+  fourpi=2*twopi*scale
+  if(cosmo)fourpi=1.5D0*omega_m*aexp*scale
+
+  isafe=0
+  if(safe_mode(ilevel))isafe=1
+  rc=ramses_amd_multigrid_fine_f90(ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+       & int(ngridmax,8),int(ncoarse,8),nx_loc,rho,phi,rho_tot,fourpi,epsilon,isafe,iters,err)
+  if(rc/=0)call ramses_amd_fatal('multigrid_fine')
+  safe_mode(ilevel)=(isafe/=0)
+
+  if(myid==1) print '(A,I5,A,I5,A,1pE10.3)','   ==> Level=',ilevel, ' Step=', &
+       iters,' Error=',err
+  if(myid==1 .and. iters==10) print *,'WARN: Fine multigrid Poisson failed to converge...'
+
+end subroutine multigrid_fine

@@ -54,6 +54,21 @@ module ramses_amd_iface
        real(c_double), value :: dx, dt
        integer(c_int) :: rc
      end function ramses_amd_godunov_fine_f90
+     function ramses_amd_multigrid_fine_f90(ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, &
+          & rho, phi, rho_tot, fourpi, epsilon, safe_mode, iters, err) &
+          & bind(C, name='ramses_amd_multigrid_fine_f90') result(rc)
+       import :: c_int, c_int64_t, c_double
+       integer(c_int), value :: ilevel, ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: xg(*)
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       integer(c_int), value :: nx_loc
+       real(c_double) :: rho(*), phi(*)
+       real(c_double), value :: rho_tot, fourpi, epsilon
+       integer(c_int) :: safe_mode, iters
+       real(c_double) :: err
+       integer(c_int) :: rc
+     end function ramses_amd_multigrid_fine_f90
   end interface
 
   logical, save :: ramses_amd_checked = .false.
