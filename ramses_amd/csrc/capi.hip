@@ -117,10 +117,10 @@ int ramses_amd_godunov_brick(const ramses_amd_hydro_params *p, const ramses_amd_
   if (d_uold == d_unew) return fail(RAMSES_AMD_EINVAL, "uold and unew must be distinct buffers");
   if (p->ndim != 3) return fail(RAMSES_AMD_EUNSUPPORTED, "device sweep implements NDIM=3 (got %d)", p->ndim);
   if (p->nvar != 5) return fail(RAMSES_AMD_EUNSUPPORTED, "device sweep implements NVAR=5 (got %d)", p->nvar);
-  if (p->scheme != RAMSES_AMD_SCHEME_MUSCL) return fail(RAMSES_AMD_EUNSUPPORTED, "scheme='plmde' is not implemented on the device yet");
+  if (p->scheme != RAMSES_AMD_SCHEME_MUSCL && p->scheme != RAMSES_AMD_SCHEME_PLMDE) return fail(RAMSES_AMD_EINVAL, "unknown scheme %d", p->scheme);
   if (p->difmag > 0.0) return fail(RAMSES_AMD_EUNSUPPORTED, "difmag>0 is not implemented on the device yet");
-  if (!(p->slope_type == 0 || p->slope_type == 1 || p->slope_type == 2 || p->slope_type == 7 || p->slope_type == 8))
-    return fail(RAMSES_AMD_EUNSUPPORTED, "slope_type=%d is not implemented on the device (0,1,2,7,8 are)", p->slope_type);
+  if (!(p->slope_type == 0 || p->slope_type == 1 || p->slope_type == 2 || p->slope_type == 3 || p->slope_type == 7 || p->slope_type == 8))
+    return fail(RAMSES_AMD_EUNSUPPORTED, "slope_type=%d is not a 3-D slope type of the reference (0,1,2,3,7,8 are)", p->slope_type);
   if (p->riemann < 0 || p->riemann > 4) return fail(RAMSES_AMD_EINVAL, "unknown Riemann solver %d", p->riemann);
   if (!(dx > 0.0) || !(dt >= 0.0)) return fail(RAMSES_AMD_EINVAL, "dx must be >0 and dt >=0");
 
@@ -134,8 +134,8 @@ int ramses_amd_godunov_brick(const ramses_amd_hydro_params *p, const ramses_amd_
   const bool pow2 = is_pow2(dx);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipError_t e = p->fast_math
-                     ? fastmode::launch_godunov_sweep(A, p->slope_type, p->riemann, g_tile_rows, d_grav != nullptr, pow2, s)
-                     : strictmode::launch_godunov_sweep(A, p->slope_type, p->riemann, g_tile_rows, d_grav != nullptr, pow2, s);
+                     ? fastmode::launch_godunov_sweep(A, p->slope_type, p->riemann, g_tile_rows, p->scheme, d_grav != nullptr, pow2, s)
+                     : strictmode::launch_godunov_sweep(A, p->slope_type, p->riemann, g_tile_rows, p->scheme, d_grav != nullptr, pow2, s);
   if (e != hipSuccess) return hipfail(e, "godunov sweep launch");
   return 0;
 }

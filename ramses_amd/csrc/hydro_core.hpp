@@ -152,6 +152,28 @@ RA_DEV double slope1(double qm1, double q0, double qp1, const HydroConst &P) {
   return 0.0;
 }
 
+// positivity-preserving unsplit slope (slope_type=3, umuscl.f90:1326-1386):
+// nb[27] = the 3x3x3 neighbourhood of one variable, index (di+1)+3*(dj+1)+9*(dk+1)
+RA_DEV void slope3_var(const double (&nb)[27], double (&d)[3]) {
+  const double q0 = nb[13];
+  double vmin = nb[0] - q0, vmax = vmin;
+#pragma unroll
+  for (int t = 1; t < 27; t++) {
+    const double df = nb[t] - q0;
+    vmin = dmind(vmin, df);
+    vmax = dmaxd(vmax, df);
+  }
+  const double dfx = 0.5 * (nb[14] - nb[12]);
+  const double dfy = 0.5 * (nb[16] - nb[10]);
+  const double dfz = 0.5 * (nb[22] - nb[4]);
+  const double dff = 0.5 * (__builtin_fabs(dfx) + __builtin_fabs(dfy) + __builtin_fabs(dfz));
+  double slop = 1.0;
+  if (dff > 0.0) slop = dmind(1.0, dmind(__builtin_fabs(vmin), __builtin_fabs(vmax)) / dff);
+  d[0] = slop * dfx;
+  d[1] = slop * dfy;
+  d[2] = slop * dfz;
+}
+
 // ---------------------------------------------------------------------------
 // trace3d (hydro/umuscl.f90:483-708) for one cell.
 // dq[d][n]: slope of variable n along d.  Outputs qm[d][n] (state on the +d
@@ -202,6 +224,79 @@ RA_DEV void trace3d_cell(const double (&q)[NV], const double (&dq)[3][NV],
     for (int d = 0; d < 3; d++) {
       qp[d][n] = a - 0.5 * dq[d][n] + sa0 * dtd[d] * 0.5;
       qm[d][n] = a + 0.5 * dq[d][n] + sa0 * dtd[d] * 0.5;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// tracexyz (hydro/uplmde.f90:375-696): PLMDE characteristic tracing for one
+// cell, 3-D.  cc = sound speed of ctoprim.  The reference's quirk is kept: all
+// transverse terms are scaled with half*dtdx (uplmde.f90:453-469).
+// ---------------------------------------------------------------------------
+template <int NV>
+RA_DEV void tracexyz_cell(const double (&q)[NV], const double (&dq)[3][NV], double cc,
+                          double dtdx, double dtdy, double dtdz, const HydroConst &P,
+                          double (&qm)[3][NV], double (&qp)[3][NV]) {
+  const double r = q[0], p = q[4];
+  const double vel[3] = {q[1], q[2], q[3]};
+  const double csq = P.gamma * p / r;
+  const double dtd[3] = {dtdx, dtdy, dtdz};
+  const double fac = 0.5 * dtdx;
+  // transverse direction pairs in the reference's order of subtraction
+  constexpr int T[3][2] = {{1, 2}, {0, 2}, {1, 0}};
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const int t0 = T[d][0], t1 = T[d][1];
+    // transverse derivative terms
+    const double ar = -vel[t0] * dq[t0][0] - vel[t1] * dq[t1][0];
+    const double ap = -vel[t0] * dq[t0][4] - vel[t1] * dq[t1][4];
+    const double divt = dq[t0][1 + t0] + dq[t1][1 + t1];
+    const double sr = fac * (ar - (divt)*r);
+    const double sp = fac * (ap - (divt)*P.gamma * p);
+    double sv[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const double av = -vel[t0] * dq[t0][1 + c] - vel[t1] * dq[t1][1 + c];
+      sv[c] = (c == d) ? fac * (av) : fac * (av - (dq[c][4]) / r);
+    }
+    // characteristic analysis along d
+    const double vn = vel[d];
+    const double dvn = dq[d][1 + d];
+    const double alpham = 0.5 * (dq[d][4] / csq - dvn * r / cc);
+    const double alphap = 0.5 * (dq[d][4] / csq + dvn * r / cc);
+    const double alpha0r = dq[d][0] - dq[d][4] / csq;
+    double ccc = cc;
+    if (__builtin_fabs(dvn) > 3.0 * cc) ccc = 0.0;
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+      double spminus = (vn - ccc) * dtd[d];
+      double spplus = (vn + ccc) * dtd[d];
+      double spzero = (vn)*dtd[d];
+      double sg;
+      if (side == 0) {  // right state at the left interface (qp)
+        if ((vn + ccc) > 0.0) spplus = -1.0;
+        if ((vn - ccc) > 0.0) spminus = -1.0;
+        if (vn > 0.0) spzero = -1.0;
+        sg = -1.0;
+      } else {          // left state at the right interface (qm)
+        if ((vn + ccc) <= 0.0) spplus = 1.0;
+        if ((vn - ccc) <= 0.0) spminus = 1.0;
+        if (vn <= 0.0) spzero = 1.0;
+        sg = 1.0;
+      }
+      const double ap_ = 0.5 * (sg - spplus) * alphap;
+      const double am_ = 0.5 * (sg - spminus) * alpham;
+      const double azr = 0.5 * (sg - spzero) * alpha0r;
+      double(&out)[3][NV] = side == 0 ? qp : qm;
+      out[d][0] = dmaxd(P.smallr, r + (ap_ + am_ + azr) + sr);
+      out[d][1 + d] = vn + (ap_ - am_) * cc / r + sv[d];
+      out[d][4] = p + (ap_ + am_) * csq + sp;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        if (c == d) continue;
+        const double azt = 0.5 * (sg - spzero) * dq[d][1 + c];
+        out[d][1 + c] = vel[c] + (azt) + sv[c];
+      }
     }
   }
 }

@@ -61,7 +61,7 @@ __device__ __forceinline__ double wave_shl1(double v) {
   return __hiloint2double(hi, lo);
 }
 
-template <int ST, int RS, int BY, bool GRAV, bool DXPOW2>
+template <int ST, int RS, int BY, bool GRAV, bool DXPOW2, int SCHEME>
 __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Plane<BY> *qring = reinterpret_cast<Plane<BY> *>(smem_raw);  // [3] primitives of planes c-1, c, c+1
@@ -187,19 +187,45 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
     double qpy[NV], fx[NV], fz[NV];
 #pragma unroll
     for (int n = 0; n < NV; n++) { fx[n] = 0.0; fz[n] = 0.0; }
+    if (ST == 3) __syncthreads();  // the 27-point slope reads the neighbours' plane c+1 just written
     if (r_trace) {
       const Plane<BY> &qs = qring[sb];
       const Plane<BY> &qprev = qring[sa];
       double qb[NV], dq[3][NV];
+      if (ST == 3) {
+        const Plane<BY> &qnext = qring[sc];
+        const int xs[3] = {txm, tx, txp}, ys[3] = {tym, ty, typ};
 #pragma unroll
-      for (int n = 0; n < NV; n++) {
-        qb[n] = qs.v[n][ty][tx];
-        dq[0][n] = slope1<ST>(qs.v[n][ty][txm], qb[n], qs.v[n][ty][txp], P);
-        dq[1][n] = slope1<ST>(qs.v[n][tym][tx], qb[n], qs.v[n][typ][tx], P);
-        dq[2][n] = slope1<ST>(qprev.v[n][ty][tx], qb[n], qc[n], P);
+        for (int n = 0; n < NV; n++) {
+          double nb[27], d3[3];
+#pragma unroll
+          for (int dj = 0; dj < 3; dj++)
+#pragma unroll
+            for (int di = 0; di < 3; di++) {
+              nb[di + 3 * dj] = qprev.v[n][ys[dj]][xs[di]];
+              nb[di + 3 * dj + 9] = qs.v[n][ys[dj]][xs[di]];
+              nb[di + 3 * dj + 18] = qnext.v[n][ys[dj]][xs[di]];
+            }
+          qb[n] = nb[13];
+          slope3_var(nb, d3);
+          dq[0][n] = d3[0]; dq[1][n] = d3[1]; dq[2][n] = d3[2];
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < NV; n++) {
+          qb[n] = qs.v[n][ty][tx];
+          dq[0][n] = slope1<ST>(qs.v[n][ty][txm], qb[n], qs.v[n][ty][txp], P);
+          dq[1][n] = slope1<ST>(qs.v[n][tym][tx], qb[n], qs.v[n][typ][tx], P);
+          dq[2][n] = slope1<ST>(qprev.v[n][ty][tx], qb[n], qc[n], P);
+        }
       }
       double qm[3][NV], qp[3][NV];
-      trace3d_cell<NV>(qb, dq, dtdx, dtdx, dtdx, P, qm, qp);
+      if (SCHEME == 0) {
+        trace3d_cell<NV>(qb, dq, dtdx, dtdx, dtdx, P, qm, qp);
+      } else {
+        const double cc = ctoprim_sound(qb[0], qb[4], P);
+        tracexyz_cell<NV>(qb, dq, cc, dtdx, dtdx, dtdx, P, qm, qp);
+      }
 #pragma unroll
       for (int n = 0; n < NV; n++) {
         smy->v[n][ty][tx] = qm[1][n];
@@ -262,19 +288,19 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
 // ---------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------
-template <int ST, int RS, int BY, bool GRAV>
+template <int ST, int RS, int BY, bool GRAV, int SCHEME>
 static hipError_t launch2(const SweepArgs &A, bool pow2, hipStream_t s) {
   const size_t lds = 5 * sizeof(Plane<BY>);
   dim3 block(BX, BY);
   dim3 grid(A.ntx * A.nty * A.ntz);
   hipError_t e;
   if (pow2) {
-    auto k = godunov_sweep_kernel<ST, RS, BY, GRAV, true>;
+    auto k = godunov_sweep_kernel<ST, RS, BY, GRAV, true, SCHEME>;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, block, lds, s, A);
   } else {
-    auto k = godunov_sweep_kernel<ST, RS, BY, GRAV, false>;
+    auto k = godunov_sweep_kernel<ST, RS, BY, GRAV, false, SCHEME>;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, block, lds, s, A);
@@ -283,36 +309,41 @@ static hipError_t launch2(const SweepArgs &A, bool pow2, hipStream_t s) {
 }
 
 template <int ST, int RS>
-static hipError_t launch1(SweepArgs &A, int by, bool grav, bool pow2, hipStream_t s) {
-  if (by == 0) by = (RS == RIEMANN_EXACT) ? 8 : 12;  // the Newton solver needs the registers of 2 waves/SIMD
+static hipError_t launch1(SweepArgs &A, int by, int scheme, bool grav, bool pow2, hipStream_t s) {
+  // 8-row tiles (2 waves/SIMD, 256 VGPRs) for the register-hungry variants:
+  // the Newton solver, the 27-point slope and the PLMDE tracing
+  const bool heavy = (RS == RIEMANN_EXACT) || (ST == 3) || (scheme != 0);
+  if (by == 0 || heavy) by = heavy ? 8 : 12;
   A.ntx = (A.nx + (BX - 4) - 1) / (BX - 4);
   A.nty = (A.ny + (by - 4) - 1) / (by - 4);
   A.ntz = (A.nz + A.zchunk - 1) / A.zchunk;
-  if (by == 8) return grav ? launch2<ST, RS, 8, true>(A, pow2, s) : launch2<ST, RS, 8, false>(A, pow2, s);
-  if (by == 12) return grav ? launch2<ST, RS, 12, true>(A, pow2, s) : launch2<ST, RS, 12, false>(A, pow2, s);
+  if (scheme == 1) return grav ? launch2<ST, RS, 8, true, 1>(A, pow2, s) : launch2<ST, RS, 8, false, 1>(A, pow2, s);
+  if (by == 8) return grav ? launch2<ST, RS, 8, true, 0>(A, pow2, s) : launch2<ST, RS, 8, false, 0>(A, pow2, s);
+  if (ST != 3 && by == 12) return grav ? launch2<ST, RS, 12, true, 0>(A, pow2, s) : launch2<ST, RS, 12, false, 0>(A, pow2, s);
   return hipErrorInvalidValue;
 }
 
 template <int ST>
-static hipError_t launch0(SweepArgs &A, int rs, int by, bool grav, bool pow2, hipStream_t s) {
+static hipError_t launch0(SweepArgs &A, int rs, int by, int scheme, bool grav, bool pow2, hipStream_t s) {
   switch (rs) {
-    case RIEMANN_LLF: return launch1<ST, RIEMANN_LLF>(A, by, grav, pow2, s);
-    case RIEMANN_HLLC: return launch1<ST, RIEMANN_HLLC>(A, by, grav, pow2, s);
-    case RIEMANN_HLL: return launch1<ST, RIEMANN_HLL>(A, by, grav, pow2, s);
-    case RIEMANN_ACOUSTIC: return launch1<ST, RIEMANN_ACOUSTIC>(A, by, grav, pow2, s);
-    case RIEMANN_EXACT: return launch1<ST, RIEMANN_EXACT>(A, by, grav, pow2, s);
+    case RIEMANN_LLF: return launch1<ST, RIEMANN_LLF>(A, by, scheme, grav, pow2, s);
+    case RIEMANN_HLLC: return launch1<ST, RIEMANN_HLLC>(A, by, scheme, grav, pow2, s);
+    case RIEMANN_HLL: return launch1<ST, RIEMANN_HLL>(A, by, scheme, grav, pow2, s);
+    case RIEMANN_ACOUSTIC: return launch1<ST, RIEMANN_ACOUSTIC>(A, by, scheme, grav, pow2, s);
+    case RIEMANN_EXACT: return launch1<ST, RIEMANN_EXACT>(A, by, scheme, grav, pow2, s);
   }
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by,
+hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme,
                                 bool grav, bool pow2, hipStream_t s) {
   switch (slope_type) {
-    case 0: return launch0<0>(A, riemann, by, grav, pow2, s);
-    case 1: return launch0<1>(A, riemann, by, grav, pow2, s);
-    case 2: return launch0<2>(A, riemann, by, grav, pow2, s);
-    case 7: return launch0<7>(A, riemann, by, grav, pow2, s);
-    case 8: return launch0<8>(A, riemann, by, grav, pow2, s);
+    case 0: return launch0<0>(A, riemann, by, scheme, grav, pow2, s);
+    case 1: return launch0<1>(A, riemann, by, scheme, grav, pow2, s);
+    case 2: return launch0<2>(A, riemann, by, scheme, grav, pow2, s);
+    case 3: return launch0<3>(A, riemann, by, scheme, grav, pow2, s);
+    case 7: return launch0<7>(A, riemann, by, scheme, grav, pow2, s);
+    case 8: return launch0<8>(A, riemann, by, scheme, grav, pow2, s);
   }
   return hipErrorInvalidValue;
 }

@@ -18,11 +18,11 @@ struct SweepArgs {
 };
 
 namespace strictmode {
-hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by,
+hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme,
                                 bool grav, bool pow2, hipStream_t s);
 }
 namespace fastmode {
-hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by,
+hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme,
                                 bool grav, bool pow2, hipStream_t s);
 }
 

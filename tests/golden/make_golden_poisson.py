@@ -59,6 +59,7 @@ def main():
         arrays[key + "_rho"] = g[0]
         arrays[key + "_phi"] = g[1]
         arrays[key + "_f"] = g[2:5]
+        arrays[key + "_prim2"] = snap["prim"]     # hydro state after one step WITH gravity
         arrays[key + "_meta"] = np.array([snap["info"]["rho_tot"], boxlen, float(eps.replace("d", "e")),
                                           float(m.group(2)), float(m.group(3))])
         print(key, "iters", m.group(2), "err", m.group(3), "rho_tot", snap["info"]["rho_tot"])

@@ -55,7 +55,7 @@ def test_argument_validation_is_loud():
     b = _capi.dense_brick(8, 8, 8, 0)
     rc = L.ramses_amd_godunov_brick(C.byref(p), C.byref(b), C.c_void_p(8), None, C.c_void_p(16), 0.1, 0.1, None)
     assert rc == -2 and b"NDIM=3" in L.ramses_amd_last_error()
-    p = _capi.make_params(scheme="plmde")
+    p = _capi.make_params(difmag=0.1)
     rc = L.ramses_amd_godunov_brick(C.byref(p), C.byref(b), C.c_void_p(8), None, C.c_void_p(16), 0.1, 0.1, None)
     assert rc == -2
     p = _capi.make_params()

@@ -130,5 +130,8 @@ def test_patched_program_self_gravity_reproduces_goldens(gpu_lib, case):
         phi, f = (g[1], g[2:5]) if g.shape[0] == 5 else (g[0], g[1:4])
         assert np.array_equal(phi, z[key + "_phi"])
         assert np.array_equal(f, z[key + "_f"])
+        # the hydro step of that coarse step ran with gravity (ctoprim predictor on the
+        # device, the reference's own source-term routines on the host)
+        assert np.array_equal(snap["prim"], z[key + "_prim2"])
     finally:
         shutil.rmtree(work, ignore_errors=True)

@@ -45,14 +45,15 @@ def test_llf_minmod_bit_exact(gpu_lib, oracle, shape, tile_rows, zchunk):
     assert np.array_equal(out, ref), "strict mode must be bit-identical (max diff %g)" % np.abs(out - ref).max()
 
 
+@pytest.mark.parametrize("scheme", ["muscl", "plmde"])
 @pytest.mark.parametrize("riemann", ["llf", "hllc", "hll", "acoustic", "exact"])
-@pytest.mark.parametrize("slope_type", [1, 2, 7, 8])
-def test_solver_matrix(gpu_lib, oracle, riemann, slope_type):
+@pytest.mark.parametrize("slope_type", [1, 2, 3, 7, 8])
+def test_solver_matrix(gpu_lib, oracle, riemann, slope_type, scheme):
     nx, ny, nz = 24, 12, 10
     u = random_brick(nx, ny, nz, seed=7 + slope_type)
     dx = 1.0 / 32
     dt = 0.04 * dx
-    kw = dict(riemann=riemann, slope_type=slope_type)
+    kw = dict(riemann=riemann, slope_type=slope_type, scheme=scheme)
     ref = oracle.godunov_uniform(_oracle_params(oracle, **kw), u, dx, dt)
     out = _sweep_gpu(u, dx, dt, **kw)
     err = rel_linf(out, ref)

@@ -12,7 +12,7 @@ import pytest
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sedov3d_ref_runs.npz")
 CASES = [("llf", 1, "muscl"), ("hllc", 2, "muscl"), ("hll", 7, "muscl"), ("acoustic", 8, "muscl"),
          ("exact", 1, "muscl"), ("hllc", 1, "plmde"), ("llf", 3, "muscl")]
-GPU_CASES = [c for c in CASES if c[2] == "muscl" and c[1] != 3]
+GPU_CASES = CASES
 
 
 def cons_to_prim(u, gamma=1.4, smallr=1e-10):
