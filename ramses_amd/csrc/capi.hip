@@ -116,7 +116,8 @@ int ramses_amd_godunov_brick(const ramses_amd_hydro_params *p, const ramses_amd_
   if (!d_uold || !d_unew) return fail(RAMSES_AMD_EINVAL, "uold/unew device pointers are NULL");
   if (d_uold == d_unew) return fail(RAMSES_AMD_EINVAL, "uold and unew must be distinct buffers");
   if (p->ndim != 3) return fail(RAMSES_AMD_EUNSUPPORTED, "device sweep implements NDIM=3 (got %d)", p->ndim);
-  if (p->nvar != 5) return fail(RAMSES_AMD_EUNSUPPORTED, "device sweep implements NVAR=5 (got %d)", p->nvar);
+  if (p->nvar < 5 || p->nvar > 7) return fail(RAMSES_AMD_EUNSUPPORTED, "device sweep implements NVAR=5..7 (up to two passive scalars; got %d)", p->nvar);
+  if (p->nvar != 5 && p->scheme != RAMSES_AMD_SCHEME_MUSCL) return fail(RAMSES_AMD_EUNSUPPORTED, "passive scalars with scheme='plmde' are not on the device yet");
   if (p->scheme != RAMSES_AMD_SCHEME_MUSCL && p->scheme != RAMSES_AMD_SCHEME_PLMDE) return fail(RAMSES_AMD_EINVAL, "unknown scheme %d", p->scheme);
   if (p->difmag > 0.0) return fail(RAMSES_AMD_EUNSUPPORTED, "difmag>0 is not implemented on the device yet");
   if (!(p->slope_type == 0 || p->slope_type == 1 || p->slope_type == 2 || p->slope_type == 3 || p->slope_type == 7 || p->slope_type == 8))
@@ -131,11 +132,11 @@ int ramses_amd_godunov_brick(const ramses_amd_hydro_params *p, const ramses_amd_
   A.zchunk = g_zchunk < b->nz ? g_zchunk : b->nz;
   A.dt = dt; A.dx = dx; A.rdx = 1.0 / dx;
   A.P = make_const(p);
-  const bool pow2 = is_pow2(dx);
+  A.pow2 = is_pow2(dx) ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipError_t e = p->fast_math
-                     ? fastmode::launch_godunov_sweep(A, p->slope_type, p->riemann, g_tile_rows, p->scheme, d_grav != nullptr, pow2, s)
-                     : strictmode::launch_godunov_sweep(A, p->slope_type, p->riemann, g_tile_rows, p->scheme, d_grav != nullptr, pow2, s);
+                     ? fastmode::launch_godunov_sweep(A, p->slope_type, p->riemann, g_tile_rows, p->scheme, p->nvar, d_grav != nullptr, s)
+                     : strictmode::launch_godunov_sweep(A, p->slope_type, p->riemann, g_tile_rows, p->scheme, p->nvar, d_grav != nullptr, s);
   if (e != hipSuccess) return hipfail(e, "godunov sweep launch");
   return 0;
 }
@@ -458,7 +459,7 @@ int ramses_amd_godunov_fine_host(const ramses_amd_hydro_params *p, int ilevel, i
                                  int64_t ncoarse, int nx_loc, const double *uold, double *unew,
                                  const double *f, double dx, double dt) {
   if (!p || !igrid || !xg || !uold || !unew) return fail(RAMSES_AMD_EINVAL, "NULL argument");
-  if (p->ndim != 3 || p->nvar != 5) return fail(RAMSES_AMD_EUNSUPPORTED, "device path implements NDIM=3, NVAR=5");
+  if (p->ndim != 3 || p->nvar < 5 || p->nvar > 7) return fail(RAMSES_AMD_EUNSUPPORTED, "device path implements NDIM=3, NVAR=5..7");
   if (nx_loc != 1) return fail(RAMSES_AMD_EUNSUPPORTED, "device path needs a periodic box with nx=ny=nz=1 (got nx_loc=%d)", nx_loc);
   if (ilevel < 1 || ilevel > 11) return fail(RAMSES_AMD_EINVAL, "level out of range");
   const int n = 1 << ilevel;

@@ -624,12 +624,12 @@ RA_DEV void llf_flux_fast(const double (&qL)[5], const double (&qR)[5],
 }
 #endif
 
-template <int RS, int NV, int DIR, bool DXPOW2>
+template <int RS, int NV, int DIR>
 RA_DEV void scaled_interface_flux(const double (&qL)[NV], const double (&qR)[NV],
                                   const HydroConst &P, double dt, double dx, double rdx,
-                                  double dtdx, double (&flux)[NV]) {
+                                  double dtdx, bool DXPOW2, double (&flux)[NV]) {
 #ifdef RAMSES_AMD_FAST
-  if (RS == RIEMANN_LLF && NV == 5) {
+  if constexpr (RS == RIEMANN_LLF && NV == 5) {
     llf_flux_fast<DIR>(qL, qR, P, dtdx, flux);
     return;
   }

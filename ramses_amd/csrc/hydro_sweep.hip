@@ -38,10 +38,9 @@ namespace ramses_amd {
 namespace SWEEP_NS {
 
 constexpr int BX = 64;   // lanes along x = one wavefront
-constexpr int NV = 5;    // rho, u, v, w, P
 
-// LDS plane of NV doubles per column: [n][ty][tx]
-template <int BY>
+// LDS plane of NV doubles per column: [n][ty][tx]; NV = rho, u, v, w, P + passive scalars
+template <int BY, int NV>
 struct Plane {
   double v[NV][BY][BX];
 };
@@ -61,12 +60,13 @@ __device__ __forceinline__ double wave_shl1(double v) {
   return __hiloint2double(hi, lo);
 }
 
-template <int ST, int RS, int BY, bool GRAV, bool DXPOW2, int SCHEME>
+template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV>
 __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
+  const bool DXPOW2 = A.pow2 != 0;   // uniform
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  Plane<BY> *qring = reinterpret_cast<Plane<BY> *>(smem_raw);  // [3] primitives of planes c-1, c, c+1
-  Plane<BY> *smy = qring + 3;                                   // qm along y (state on the +y face)
-  Plane<BY> *fyb = qring + 4;                                   // flux through the -y face
+  Plane<BY, NV> *qring = reinterpret_cast<Plane<BY, NV> *>(smem_raw);  // [3] primitives of planes c-1, c, c+1
+  Plane<BY, NV> *smy = qring + 3;                                   // qm along y (state on the +y face)
+  Plane<BY, NV> *fyb = qring + 4;                                   // flux through the -y face
 
   const int tx = threadIdx.x, ty = threadIdx.y;
   const HydroConst &P = A.P;
@@ -144,6 +144,7 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
   double part[NV];                // u + x and y flux differences of plane c-1
   double fzlo[NV];                // z flux through the -z face of plane c-1
   double upre[NV], gpre[3];       // prefetch: plane c+1 on entry of iteration c
+  double rold = 0.0, sold[NV > 5 ? NV - 5 : 1];   // uold density / scalars of plane c-1 (NV>5 only)
 
   // ring slots of planes c-1, c, c+1
   int sa = 0, sb = 1, sc = 2;
@@ -189,11 +190,11 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
     for (int n = 0; n < NV; n++) { fx[n] = 0.0; fz[n] = 0.0; }
     if (ST == 3) __syncthreads();  // the 27-point slope reads the neighbours' plane c+1 just written
     if (r_trace) {
-      const Plane<BY> &qs = qring[sb];
-      const Plane<BY> &qprev = qring[sa];
+      const Plane<BY, NV> &qs = qring[sb];
+      const Plane<BY, NV> &qprev = qring[sa];
       double qb[NV], dq[3][NV];
       if (ST == 3) {
-        const Plane<BY> &qnext = qring[sc];
+        const Plane<BY, NV> &qnext = qring[sc];
         const int xs[3] = {txm, tx, txp}, ys[3] = {tym, ty, typ};
 #pragma unroll
         for (int n = 0; n < NV; n++) {
@@ -236,11 +237,11 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
           double qL[NV];
 #pragma unroll
           for (int n = 0; n < NV; n++) qL[n] = wave_shr1(qm[0][n]);  // +x state of column tx-1
-          scaled_interface_flux<RS, NV, 0, DXPOW2>(qL, qp[0], P, A.dt, A.dx, A.rdx, dtdx, fx);
+          scaled_interface_flux<RS, NV, 0>(qL, qp[0], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fx);
         }
         if (c >= z0) {
           // z flux through the face between planes c-1 and c
-          scaled_interface_flux<RS, NV, 2, DXPOW2>(qmz, qp[2], P, A.dt, A.dx, A.rdx, dtdx, fz);
+          scaled_interface_flux<RS, NV, 2>(qmz, qp[2], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fz);
         }
       }
 #pragma unroll
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
       double qL[NV];
 #pragma unroll
       for (int n = 0; n < NV; n++) qL[n] = smy->v[n][tym][tx];
-      scaled_interface_flux<RS, NV, 1, DXPOW2>(qL, qpy, P, A.dt, A.dx, A.rdx, dtdx, fy);
+      scaled_interface_flux<RS, NV, 1>(qL, qpy, P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fy);
 #pragma unroll
       for (int n = 0; n < NV; n++) fyb->v[n][ty][tx] = fy[n];
     }
@@ -265,9 +266,22 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
       // finish plane c-1: its +z face flux is fz
       if (c >= z0 + 1 && r_upd) {
         const long o = plane_off(c - 1);
+        double un[NV];
 #pragma unroll
-        for (int n = 0; n < NV; n++)
-          unew[o + (long)n * A.pitch_var] = part[n] + (fzlo[n] - fz[n]);
+        for (int n = 0; n < NV; n++) un[n] = part[n] + (fzlo[n] - fz[n]);
+        if (NV > 5) {
+          // set_uold's passive-scalar fix near the density floor
+          // (hydro/godunov_fine.f90:176-190), fused: the kernel's output is the new uold
+          if (rold < P.smallr && un[0] > rold) {
+#pragma unroll
+            for (int n = 5; n < NV; n++) un[n] = sold[n - 5] * dmaxd(un[0], P.smallr) / P.smallr;
+          } else if (un[0] < P.smallr && rold > un[0]) {
+#pragma unroll
+            for (int n = 5; n < NV; n++) un[n] = sold[n - 5] * P.smallr / dmaxd(rold, P.smallr);
+          }
+        }
+#pragma unroll
+        for (int n = 0; n < NV; n++) unew[o + (long)n * A.pitch_var] = un[n];
       }
       if (do_xy) {
 #pragma unroll
@@ -275,6 +289,11 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
           const double fxhi = wave_shl1(fx[n]);  // -x face flux of column tx+1
           const double t = ucur[n] + (fx[n] - fxhi);
           part[n] = t + (fy[n] - fyb->v[n][typ][tx]);
+        }
+        if (NV > 5) {
+          rold = ucur[0];
+#pragma unroll
+          for (int n = 5; n < NV; n++) sold[n - 5] = ucur[n];
         }
       }
 #pragma unroll
@@ -288,62 +307,63 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
 // ---------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------
-template <int ST, int RS, int BY, bool GRAV, int SCHEME>
-static hipError_t launch2(const SweepArgs &A, bool pow2, hipStream_t s) {
-  const size_t lds = 5 * sizeof(Plane<BY>);
+template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV>
+static hipError_t launch3(const SweepArgs &A, hipStream_t s) {
+  const size_t lds = 5 * sizeof(Plane<BY, NV>);
   dim3 block(BX, BY);
   dim3 grid(A.ntx * A.nty * A.ntz);
-  hipError_t e;
-  if (pow2) {
-    auto k = godunov_sweep_kernel<ST, RS, BY, GRAV, true, SCHEME>;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, grid, block, lds, s, A);
-  } else {
-    auto k = godunov_sweep_kernel<ST, RS, BY, GRAV, false, SCHEME>;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, grid, block, lds, s, A);
-  }
+  auto k = godunov_sweep_kernel<ST, RS, BY, GRAV, SCHEME, NV>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, grid, block, lds, s, A);
   return hipGetLastError();
 }
 
+template <int ST, int RS, int BY, int SCHEME, int NV>
+static hipError_t launch2(const SweepArgs &A, bool grav, hipStream_t s) {
+  return grav ? launch3<ST, RS, BY, true, SCHEME, NV>(A, s) : launch3<ST, RS, BY, false, SCHEME, NV>(A, s);
+}
+
 template <int ST, int RS>
-static hipError_t launch1(SweepArgs &A, int by, int scheme, bool grav, bool pow2, hipStream_t s) {
-  // 8-row tiles (2 waves/SIMD, 256 VGPRs) for the register-hungry variants:
-  // the Newton solver, the 27-point slope and the PLMDE tracing
-  const bool heavy = (RS == RIEMANN_EXACT) || (ST == 3) || (scheme != 0);
+static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav, hipStream_t s) {
+  // 8-row tiles (2 waves/SIMD, 256 VGPRs, smaller LDS planes) for the
+  // register/LDS-hungry variants: the Newton solver, the 27-point slope, the
+  // PLMDE tracing and runs with passive scalars
+  const bool heavy = (RS == RIEMANN_EXACT) || (ST == 3) || (scheme != 0) || (nvar != 5);
   if (by == 0 || heavy) by = heavy ? 8 : 12;
   A.ntx = (A.nx + (BX - 4) - 1) / (BX - 4);
   A.nty = (A.ny + (by - 4) - 1) / (by - 4);
   A.ntz = (A.nz + A.zchunk - 1) / A.zchunk;
-  if (scheme == 1) return grav ? launch2<ST, RS, 8, true, 1>(A, pow2, s) : launch2<ST, RS, 8, false, 1>(A, pow2, s);
-  if (by == 8) return grav ? launch2<ST, RS, 8, true, 0>(A, pow2, s) : launch2<ST, RS, 8, false, 0>(A, pow2, s);
-  if (ST != 3 && by == 12) return grav ? launch2<ST, RS, 12, true, 0>(A, pow2, s) : launch2<ST, RS, 12, false, 0>(A, pow2, s);
+  if (nvar == 6) return scheme == 0 ? launch2<ST, RS, 8, 0, 6>(A, grav, s) : hipErrorInvalidValue;
+  if (nvar == 7) return scheme == 0 ? launch2<ST, RS, 8, 0, 7>(A, grav, s) : hipErrorInvalidValue;
+  if (nvar != 5) return hipErrorInvalidValue;
+  if (scheme == 1) return launch2<ST, RS, 8, 1, 5>(A, grav, s);
+  if (by == 8) return launch2<ST, RS, 8, 0, 5>(A, grav, s);
+  if (ST != 3 && by == 12) return launch2<ST, RS, 12, 0, 5>(A, grav, s);
   return hipErrorInvalidValue;
 }
 
 template <int ST>
-static hipError_t launch0(SweepArgs &A, int rs, int by, int scheme, bool grav, bool pow2, hipStream_t s) {
+static hipError_t launch0(SweepArgs &A, int rs, int by, int scheme, int nvar, bool grav, hipStream_t s) {
   switch (rs) {
-    case RIEMANN_LLF: return launch1<ST, RIEMANN_LLF>(A, by, scheme, grav, pow2, s);
-    case RIEMANN_HLLC: return launch1<ST, RIEMANN_HLLC>(A, by, scheme, grav, pow2, s);
-    case RIEMANN_HLL: return launch1<ST, RIEMANN_HLL>(A, by, scheme, grav, pow2, s);
-    case RIEMANN_ACOUSTIC: return launch1<ST, RIEMANN_ACOUSTIC>(A, by, scheme, grav, pow2, s);
-    case RIEMANN_EXACT: return launch1<ST, RIEMANN_EXACT>(A, by, scheme, grav, pow2, s);
+    case RIEMANN_LLF: return launch1<ST, RIEMANN_LLF>(A, by, scheme, nvar, grav, s);
+    case RIEMANN_HLLC: return launch1<ST, RIEMANN_HLLC>(A, by, scheme, nvar, grav, s);
+    case RIEMANN_HLL: return launch1<ST, RIEMANN_HLL>(A, by, scheme, nvar, grav, s);
+    case RIEMANN_ACOUSTIC: return launch1<ST, RIEMANN_ACOUSTIC>(A, by, scheme, nvar, grav, s);
+    case RIEMANN_EXACT: return launch1<ST, RIEMANN_EXACT>(A, by, scheme, nvar, grav, s);
   }
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme,
-                                bool grav, bool pow2, hipStream_t s) {
+hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme, int nvar,
+                                bool grav, hipStream_t s) {
   switch (slope_type) {
-    case 0: return launch0<0>(A, riemann, by, scheme, grav, pow2, s);
-    case 1: return launch0<1>(A, riemann, by, scheme, grav, pow2, s);
-    case 2: return launch0<2>(A, riemann, by, scheme, grav, pow2, s);
-    case 3: return launch0<3>(A, riemann, by, scheme, grav, pow2, s);
-    case 7: return launch0<7>(A, riemann, by, scheme, grav, pow2, s);
-    case 8: return launch0<8>(A, riemann, by, scheme, grav, pow2, s);
+    case 0: return launch0<0>(A, riemann, by, scheme, nvar, grav, s);
+    case 1: return launch0<1>(A, riemann, by, scheme, nvar, grav, s);
+    case 2: return launch0<2>(A, riemann, by, scheme, nvar, grav, s);
+    case 3: return launch0<3>(A, riemann, by, scheme, nvar, grav, s);
+    case 7: return launch0<7>(A, riemann, by, scheme, nvar, grav, s);
+    case 8: return launch0<8>(A, riemann, by, scheme, nvar, grav, s);
   }
   return hipErrorInvalidValue;
 }

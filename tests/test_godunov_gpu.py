@@ -133,3 +133,57 @@ def test_sedov_steps_match_oracle(gpu_lib, oracle):
     known = [3.076e-05, 6.877e-05, 7.752e-05, 9.857e-05]
     for a, b in zip(dts, known):
         assert abs(a - b) <= 5e-4 * b, (dts, known)
+
+
+def _set_uold_scalar_fix(uold, unew, smallr):
+    """numpy restatement of the passive-scalar floor fix of set_uold
+    (hydro/godunov_fine.f90:176-190); test-side only."""
+    out = unew.copy()
+    a = (uold[0] < smallr) & (unew[0] > uold[0])
+    b = ~a & (unew[0] < smallr) & (uold[0] > unew[0])
+    for n in range(5, unew.shape[0]):
+        out[n][a] = (uold[n] * np.maximum(unew[0], smallr) / smallr)[a]
+        out[n][b] = (uold[n] * smallr / np.maximum(uold[0], smallr))[b]
+    return out
+
+
+@pytest.mark.parametrize("nvar", [6, 7])
+@pytest.mark.parametrize("riemann,slope_type", [("llf", 1), ("hllc", 2), ("hll", 3), ("acoustic", 8), ("exact", 7)])
+def test_passive_scalars(gpu_lib, oracle, nvar, riemann, slope_type):
+    nx, ny, nz = 20, 12, 10
+    u = random_brick(nx, ny, nz, seed=nvar * 10 + slope_type, nvar=nvar)
+    dx, dt = 1.0 / 32, 0.04 / 32
+    for smallr in (1e-10, 0.6):      # 0.6 puts part of the box under the density floor
+        kw = dict(riemann=riemann, slope_type=slope_type, nvar=nvar, smallr=smallr)
+        ref = oracle.godunov_uniform(_oracle_params(oracle, **kw), u, dx, dt)
+        ref = _set_uold_scalar_fix(u, ref, smallr)
+        out = _sweep_gpu(u, dx, dt, **kw)
+        if riemann == "exact":
+            assert rel_linf(out, ref) <= 1e-12
+        else:
+            assert np.array_equal(out, ref), "max diff %g" % np.abs(out - ref).max()
+
+
+def test_gravity_predictor_path(gpu_lib, oracle):
+    """poisson=.true.: ctoprim's gravity predictor (gloc) and cmpdt's gravity term."""
+    import torch
+    import ramses_amd
+    from ramses_amd.hydro import HydroLevel
+    nx, ny, nz = 26, 12, 10
+    u = random_brick(nx, ny, nz, seed=77)
+    rng = np.random.default_rng(5)
+    g = rng.normal(0, 2.0, (3, nz, ny, nx))
+    dx, dt = 1.0 / 32, 0.03 / 32
+    for ng in (0, 2):
+        lev = HydroLevel(nx, ny, nz, dx, params=ramses_amd.make_params(riemann="hllc", slope_type=2, courant_factor=0.7),
+                         ng=ng, poisson=True)
+        lev.upload(u)
+        lev.interior(lev.f).copy_(torch.as_tensor(g).cuda())
+        lev.make_virtual_fine_dp()
+        dtc = lev.courant_fine()[0]
+        lev.godunov_fine(dt)
+        torch.cuda.synchronize()
+        po = oracle.make_params(riemann="hllc", slope_type=2)
+        assert dtc == oracle.courant_uniform(po, u, dx, 0.7, grav=g)
+        ref = oracle.godunov_uniform(po, u, dx, dt, grav=g)
+        assert np.array_equal(lev.download(lev.unew), ref)
