@@ -309,7 +309,7 @@ int ramses_amd_mg_smooth_fused(const double *d_phi_in, double *d_phi_out, const 
   if (!d_phi_in || !d_phi_out || !d_rhs || d_phi_in == d_phi_out || n < 2 || (n & 1)) return fail(RAMSES_AMD_EINVAL, "bad argument");
   if (npass != 2 && npass != 4) return fail(RAMSES_AMD_EINVAL, "npass must be 2 or 4");
   if (n < 64) return fail(RAMSES_AMD_EINVAL, "the fused smoother needs n >= 64 (got %d); use the per-colour kernels", n);
-  if (d_res && !d_work) return fail(RAMSES_AMD_EINVAL, "residual needs a workspace of %d doubles", MG_MAX_PARTIALS);
+  if ((d_res || d_norm2) && !d_work) return fail(RAMSES_AMD_EINVAL, "residual/norm need a workspace of %d doubles", MG_MAX_PARTIALS);
   MGCHK(mg_launch_smooth_fused(d_phi_in, d_phi_out, d_rhs, d_res, d_work, d_norm2, n, dx, npass, reinterpret_cast<hipStream_t>(stream)), "mg fused smoother launch");
   return 0;
 }
@@ -408,7 +408,9 @@ int ramses_amd_multigrid_fine_brick(int level, const double *d_rho, double rho_t
       MGCHK(mg_launch_interp(cur, d_work + mg_hier_offset(level, level - 1, 0), n, s), "mg interp launch");
     }
     if (fused) {
-      MGCHK(mg_launch_smooth_fused(d_phi2, d_phi, d_f2, d_f1, partial, d_norm + 1, n, dx, 2 * ngs_fine, s), "mg fused smoother launch");
+      // post-smoothing: only the norm of the residual is needed (f(:,1) is scratch in
+      // the reference and force_fine overwrites it next): it is not written to HBM
+      MGCHK(mg_launch_smooth_fused(d_phi2, d_phi, d_f2, nullptr, partial, d_norm + 1, n, dx, 2 * ngs_fine, s), "mg fused smoother launch");
     } else {
       for (int i = 0; i < ngs_fine; i++) {
         MGCHK(mg_launch_gs(d_phi, d_f2, n, dx2, 0, s), "mg gs launch");

@@ -317,7 +317,10 @@ __global__ __launch_bounds__(SMOOTH_THREADS) void mg_smooth_fused_kernel(const d
   // passes and of the residual plane) are issued one step AHEAD into registers:
   // every address is valid (wrapped), so the loads are unconditional and their
   // latency hides behind the previous step's stencil work.
-  struct StepLoads { double ph[NROW]; double rv[P][NPAIR]; double rf[NROW]; };
+  // rhs of colour pass s on plane z is the value pass s-2 used on the same plane 4 steps
+  // earlier (same cell: the pair offset depends on z only through its parity), so only
+  // passes 1 and 2 load; later passes take it from a register FIFO
+  struct StepLoads { double ph[NROW]; double rv[2][NPAIR]; double rf[NROW]; };
   // which cell of the pair has colour c on plane z in row ly: lx = 2p + off
   auto pair_off = [&](int ly, int z, int color) { return ((x0 + y0 + ly + z) & 1) ^ color; };
   auto issue = [&](int m, StepLoads &L) {
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(SMOOTH_THREADS) void mg_smooth_fused_kernel(const d
       for (int i = 0; i < NROW; i++) L.ph[i] = base[goffR[i]];
     }
 #pragma unroll
-    for (int s = 1; s <= P; s++) {
+    for (int s = 1; s <= 2; s++) {
       const int z = m - 2 * (s - 1);
       const double *__restrict__ base = rhs + (long)wrap1(z) * nn;
 #pragma unroll
@@ -339,10 +342,20 @@ __global__ __launch_bounds__(SMOOTH_THREADS) void mg_smooth_fused_kernel(const d
       for (int i = 0; i < NROW; i++) L.rf[i] = base[goffR[i]];
     }
   };
-  StepLoads cur, nxt;
+  // prefetch distance 2 steps: LDS capacity limits the CU to 6 wavefronts, so
+  // registers are plentiful and memory-level parallelism has to come from here
+  StepLoads cur, nxt, nx2;
+  double fifo[4][2][NPAIR];   // rhs values of passes 1,2 of the last 4 steps; [0] = 4 steps ago
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int j = 0; j < NPAIR; j++) fifo[a][b][j] = 0.0;
   issue(m_begin, cur);
+  issue(m_begin + 1, nxt);
   for (int m = m_begin; m <= m_end; m++) {
-    issue(m + 1, nxt);
+    issue(m + 2, nx2);
     const int zl = m + 2;
     const bool do_load = (zl >= z0 - H) && (zl <= z1 - 1 + H);
     // ---- gather phase: every LDS read of this step is issued before any LDS
@@ -414,7 +427,10 @@ __global__ __launch_bounds__(SMOOTH_THREADS) void mg_smooth_fused_kernel(const d
       double *pc = ring + slot(m - 2 * (s - 1)) * G::PLANE;
 #pragma unroll
       for (int j = 0; j < NPAIR; j++)
-        if (on[s - 1][j]) pc[cidx[s - 1][j]] = div6(nbv[s - 1][j] - dx2 * cur.rv[s - 1][j]);
+        if (on[s - 1][j]) {
+          const double r = s <= 2 ? cur.rv[(s - 1) & 1][j] : fifo[0][(s - 1) & 1][j];
+          pc[cidx[s - 1][j]] = div6(nbv[s - 1][j] - dx2 * r);
+        }
     }
     // ---- final stage: store phi (+ residual and its norm) of plane m-2P -------
     {
@@ -426,7 +442,7 @@ __global__ __launch_bounds__(SMOOTH_THREADS) void mg_smooth_fused_kernel(const d
           phi_out[g] = phf[i];
           if (RESID) {
             const double r = -oneoverdx2 * (nbf[i] - 6.0 * phf[i]) + cur.rf[i];
-            res[g] = r;
+            if (res) res[g] = r;      // norm-only callers pass NULL: the residual never leaves the chip
             acc = acc + r * r;
           }
         }
@@ -439,7 +455,17 @@ __global__ __launch_bounds__(SMOOTH_THREADS) void mg_smooth_fused_kernel(const d
       for (int i = 0; i < NROW; i++) pl[lofsR[i]] = cur.ph[i];
     }
     __syncthreads();
+    if (P > 2) {
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int j = 0; j < NPAIR; j++) {
+          fifo[0][b][j] = fifo[1][b][j]; fifo[1][b][j] = fifo[2][b][j];
+          fifo[2][b][j] = fifo[3][b][j]; fifo[3][b][j] = cur.rv[b][j];
+        }
+    }
     cur = nxt;
+    nxt = nx2;
   }
   if (RESID && partial) {
     sm[tid] = acc;
@@ -463,13 +489,14 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
   if (npass != 4 && npass != 2) return hipErrorInvalidValue;
   if (n < 64) return hipErrorInvalidValue;   // tile wider than the level: use the per-colour kernels
   const int P = npass;
-  const int H = res ? P + 1 : P;
+  const bool resid = (res != nullptr) || (norm_out != nullptr);
+  const int H = resid ? P + 1 : P;
   const int IX = 64 - 2 * H, IY = 24 - 2 * H;
   const int ntx = (n + IX - 1) / IX, nty = (n + IY - 1) / IY;
   int zchunk = n >= 256 ? 128 : (n >= 128 ? 64 : n);
   const int ntz = (n + zchunk - 1) / zchunk;
   const int blocks = ntx * nty * ntz;
-  if (res && blocks > MG_MAX_PARTIALS) return hipErrorInvalidValue;
+  if (resid && blocks > MG_MAX_PARTIALS) return hipErrorInvalidValue;
   const size_t lds = sizeof(double) * (size_t)(2 * P + 4) * 64 * 24;
   const double dx2 = dx * dx, oneoverdx2 = 1.0 / (dx * dx);
   hipError_t e;
@@ -482,10 +509,10 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
     hipLaunchKernelGGL(k, dim3(blocks), dim3(SMOOTH_THREADS), lds, s, phi_in, phi_out, rhs, res, partial, n, dx2,        \
                        oneoverdx2, zchunk, ntx, nty);                                                         \
   } while (0)
-  if (P == 4) { if (res) SM_LAUNCH(4, true); else SM_LAUNCH(4, false); }
-  else { if (res) SM_LAUNCH(2, true); else SM_LAUNCH(2, false); }
+  if (P == 4) { if (resid) SM_LAUNCH(4, true); else SM_LAUNCH(4, false); }
+  else { if (resid) SM_LAUNCH(2, true); else SM_LAUNCH(2, false); }
 #undef SM_LAUNCH
-  if (res && norm_out)
+  if (norm_out)
     hipLaunchKernelGGL(mg_sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, blocks, dx * dx * dx, norm_out);
   return hipGetLastError();
 }

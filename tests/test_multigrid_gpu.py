@@ -131,6 +131,11 @@ def test_fused_smoother_bit_exact(gpu_lib, oracle, n, npass):
     assert np.array_equal(dres.cpu().numpy(), rres)
     nref = OL.ora_mg_norm2(rres, n, dx)
     assert abs(norm.item() - nref) <= 1e-13 * nref
+    # norm only (the residual stays on chip)
+    dout3, norm3 = _dev(np.zeros_like(phi)), _dev(np.zeros(1))
+    assert L.ramses_amd_mg_smooth_fused(_p(din), _p(dout3), _p(_dev(rhs)), None, _p(work), _p(norm3), n, dx, npass, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(dout3.cpu().numpy(), ref) and norm3.item() == norm.item()
     # smoother only
     dout2 = _dev(np.zeros_like(phi))
     assert L.ramses_amd_mg_smooth_fused(_p(din), _p(dout2), _p(_dev(rhs)), None, None, None, n, dx, npass, None) == 0
