@@ -116,6 +116,20 @@ def cpu_baseline():
         return out
 
 
+def pmc_traffic(n, world, args):
+    """HBM bytes per sweep launch from the rocprofv3 PMC passes (FETCH_SIZE with the
+    gfx950 calibration + WRITE_SIZE), measured by scripts/profile_gpu.sh on this
+    same command and committed under profiles/; null when no matching profile."""
+    path = os.path.join(ROOT, "profiles", "r01_sweep_traffic.json")
+    try:
+        t = json.load(open(path))
+        if t["n"] == n and world == 1 and args.fast == 1 and not args.tile_rows and not args.zchunk:
+            return t["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 BYTES_PER_DOF_VCYCLE = 227   # SURVEY.md 8d: 202 B fine level + 178/7 B coarse hierarchy
 
 
@@ -248,7 +262,7 @@ def main():
                        "arithmetic": "fast (FMA contraction, <=1e-12 rel of strict)" if args.fast else "strict (bit-identical to the reference)",
                        "halo": "none (single rank, in-kernel periodic wrap)" if world == 1 else "RCCL send/recv of 2-cell face slabs, all nvar fused"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, world, args),
                          "kernel": "godunov_sweep_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL_UPDATE},
         }

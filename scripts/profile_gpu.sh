@@ -27,5 +27,8 @@ pass pmc_fetch FETCH_SIZE
 pass pmc_write WRITE_SIZE
 pass pmc_grbm GRBM_GUI_ACTIVE GRBM_COUNT
 pass pmc_tcc TCC_HIT_sum TCC_MISS_sum
-python $REPO/scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+# FETCH_SIZE calibration on a kernel of known traffic with the same access shape
+# (8 B/lane coalesced rows): courant_kernel reads exactly nvar*N*8 bytes
+KREGEX=courant pass pmc_cal_fetch FETCH_SIZE
+python $REPO/scripts/summarize_prof.py $OUT "$@" > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
