@@ -107,6 +107,21 @@ int ramses_amd_godunov_brick(const ramses_amd_hydro_params *p,
                              const double *d_grav, double *d_unew, double dx,
                              double dt, void *stream);
 
+/* The same sweep split in two launches sets for communication/computation
+ * overlap (the reference has none: make_virtual_fine_dp runs after the sweep,
+ * amr/amr_step.f90:388-510): _shell updates the tiles and planes that hold the
+ * cells within 2 of a brick face (what the neighbour ranks receive as ghost
+ * octs), _interior everything else.  shell + interior == ramses_amd_godunov_brick
+ * bit for bit; the halo exchange of the new state can start after _shell. */
+int ramses_amd_godunov_brick_shell(const ramses_amd_hydro_params *p,
+                                   const ramses_amd_brick *b, const double *d_uold,
+                                   const double *d_grav, double *d_unew, double dx,
+                                   double dt, void *stream);
+int ramses_amd_godunov_brick_interior(const ramses_amd_hydro_params *p,
+                                      const ramses_amd_brick *b, const double *d_uold,
+                                      const double *d_grav, double *d_unew, double dx,
+                                      double dt, void *stream);
+
 /* Tuning knobs of the sweep (tile rows per workgroup, planes per z-chunk);
  * 0 keeps the built-in default.  Results do not depend on them. */
 int ramses_amd_godunov_tune(int tile_rows, int zchunk);

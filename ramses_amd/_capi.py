@@ -49,6 +49,8 @@ SYMBOLS = [
     ("ramses_amd_brick_dense", None, [_PB, _i, _i, _i, _i]),
     ("ramses_amd_device_info", _i, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     ("ramses_amd_godunov_brick", _i, [_PP, _PB, _vp, _vp, _vp, _d, _d, _vp]),
+    ("ramses_amd_godunov_brick_shell", _i, [_PP, _PB, _vp, _vp, _vp, _d, _d, _vp]),
+    ("ramses_amd_godunov_brick_interior", _i, [_PP, _PB, _vp, _vp, _vp, _d, _d, _vp]),
     ("ramses_amd_godunov_tune", _i, [_i, _i]),
     ("ramses_amd_courant_init", _i, [_PP, _d, _vp, _vp]),
     ("ramses_amd_courant_brick", _i, [_PP, _PB, _vp, _vp, _d, _vp, _vp]),

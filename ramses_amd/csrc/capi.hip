@@ -108,9 +108,9 @@ int ramses_amd_godunov_tune(int tile_rows, int zchunk) {
   return 0;
 }
 
-int ramses_amd_godunov_brick(const ramses_amd_hydro_params *p, const ramses_amd_brick *b,
-                             const double *d_uold, const double *d_grav, double *d_unew,
-                             double dx, double dt, void *stream) {
+static int godunov_brick_region(const ramses_amd_hydro_params *p, const ramses_amd_brick *b,
+                                const double *d_uold, const double *d_grav, double *d_unew,
+                                double dx, double dt, int region_first, int region_last, void *stream) {
   if (!p) return fail(RAMSES_AMD_EINVAL, "params is NULL");
   if (int rc = check_brick(b)) return rc;
   if (!d_uold || !d_unew) return fail(RAMSES_AMD_EINVAL, "uold/unew device pointers are NULL");
@@ -134,11 +134,32 @@ int ramses_amd_godunov_brick(const ramses_amd_hydro_params *p, const ramses_amd_
   A.P = make_const(p);
   A.pow2 = is_pow2(dx) ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipError_t e = p->fast_math
-                     ? fastmode::launch_godunov_sweep(A, p->slope_type, p->riemann, g_tile_rows, p->scheme, p->nvar, d_grav != nullptr, s)
-                     : strictmode::launch_godunov_sweep(A, p->slope_type, p->riemann, g_tile_rows, p->scheme, p->nvar, d_grav != nullptr, s);
-  if (e != hipSuccess) return hipfail(e, "godunov sweep launch");
+  for (int region = region_first; region <= region_last; region++) {
+    A.region = region;
+    hipError_t e = p->fast_math
+                       ? fastmode::launch_godunov_sweep(A, p->slope_type, p->riemann, g_tile_rows, p->scheme, p->nvar, d_grav != nullptr, s)
+                       : strictmode::launch_godunov_sweep(A, p->slope_type, p->riemann, g_tile_rows, p->scheme, p->nvar, d_grav != nullptr, s);
+    if (e != hipSuccess) return hipfail(e, "godunov sweep launch");
+  }
   return 0;
+}
+
+int ramses_amd_godunov_brick(const ramses_amd_hydro_params *p, const ramses_amd_brick *b,
+                             const double *d_uold, const double *d_grav, double *d_unew,
+                             double dx, double dt, void *stream) {
+  return godunov_brick_region(p, b, d_uold, d_grav, d_unew, dx, dt, SWEEP_ALL, SWEEP_ALL, stream);
+}
+
+int ramses_amd_godunov_brick_shell(const ramses_amd_hydro_params *p, const ramses_amd_brick *b,
+                                   const double *d_uold, const double *d_grav, double *d_unew,
+                                   double dx, double dt, void *stream) {
+  return godunov_brick_region(p, b, d_uold, d_grav, d_unew, dx, dt, SWEEP_SHELL_ZLO, SWEEP_SHELL_XHI, stream);
+}
+
+int ramses_amd_godunov_brick_interior(const ramses_amd_hydro_params *p, const ramses_amd_brick *b,
+                                      const double *d_uold, const double *d_grav, double *d_unew,
+                                      double dx, double dt, void *stream) {
+  return godunov_brick_region(p, b, d_uold, d_grav, d_unew, dx, dt, SWEEP_INTERIOR, SWEEP_INTERIOR, stream);
 }
 
 int ramses_amd_courant_init(const ramses_amd_hydro_params *p, double dx, double *d_out, void *stream) {

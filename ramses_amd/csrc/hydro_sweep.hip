@@ -83,13 +83,14 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
       bid = (bid % nxcd) * per + bid / nxcd;
     }
   }
-  const int tix = bid % A.ntx;
-  const int tiy = (bid / A.ntx) % A.nty;
+  // this launch covers tiles [tx0,tx0+ntx) x [ty0,ty0+nty) and planes [zlo,zhi)
+  const int tix = A.tx0 + bid % A.ntx;
+  const int tiy = A.ty0 + (bid / A.ntx) % A.nty;
   const int tiz = bid / (A.ntx * A.nty);
   const int x0 = tix * (BX - 4);
   const int y0 = tiy * (BY - 4);
-  const int z0 = tiz * A.zchunk;
-  const int z1 = min(z0 + A.zchunk, A.nz);
+  const int z0 = A.zlo + tiz * A.zchunk;
+  const int z1 = min(z0 + A.zchunk, A.zhi);
 
   // ---- this thread's column ------------------------------------------------
   const int xu = x0 - 2 + tx;  // unwrapped interior coordinate
@@ -331,9 +332,33 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
   // PLMDE tracing and runs with passive scalars
   const bool heavy = (RS == RIEMANN_EXACT) || (ST == 3) || (scheme != 0) || (nvar != 5);
   if (by == 0 || heavy) by = heavy ? 8 : 12;
-  A.ntx = (A.nx + (BX - 4) - 1) / (BX - 4);
-  A.nty = (A.ny + (by - 4) - 1) / (by - 4);
-  A.ntz = (A.nz + A.zchunk - 1) / A.zchunk;
+  // tiles of the whole brick, then the sub-box this launch covers (A.region)
+  const int NTX = (A.nx + (BX - 4) - 1) / (BX - 4);
+  const int NTY = (A.ny + (by - 4) - 1) / (by - 4);
+  int tx0 = 0, tx1 = NTX, ty0 = 0, ty1 = NTY, zlo = 0, zhi = A.nz;
+  // Boundary shell / interior split used to overlap the halo exchange with the
+  // interior sweep: shell = the tiles and planes that produce the cells within
+  // 2 of a face (what the neighbours receive); zb planes at each z end.
+  const int zb = 2;
+  const bool splittable = NTX >= 3 && NTY >= 3 && A.nz >= 4 * zb;
+  switch (A.region) {
+    case SWEEP_ALL: break;
+    case SWEEP_INTERIOR:
+      if (!splittable) return hipSuccess;   // everything was done by the shell launches
+      tx0 = 1; tx1 = NTX - 1; ty0 = 1; ty1 = NTY - 1; zlo = zb; zhi = A.nz - zb; break;
+    case SWEEP_SHELL_ZLO: if (!splittable) break; zhi = zb; break;
+    case SWEEP_SHELL_ZHI: if (!splittable) return hipSuccess; zlo = A.nz - zb; break;
+    case SWEEP_SHELL_YLO: if (!splittable) return hipSuccess; ty1 = 1; zlo = zb; zhi = A.nz - zb; break;
+    case SWEEP_SHELL_YHI: if (!splittable) return hipSuccess; ty0 = NTY - 1; zlo = zb; zhi = A.nz - zb; break;
+    case SWEEP_SHELL_XLO: if (!splittable) return hipSuccess; tx1 = 1; ty0 = 1; ty1 = NTY - 1; zlo = zb; zhi = A.nz - zb; break;
+    case SWEEP_SHELL_XHI: if (!splittable) return hipSuccess; tx0 = NTX - 1; ty0 = 1; ty1 = NTY - 1; zlo = zb; zhi = A.nz - zb; break;
+    default: return hipErrorInvalidValue;
+  }
+  A.tx0 = tx0; A.ty0 = ty0; A.zlo = zlo; A.zhi = zhi;
+  A.ntx = tx1 - tx0;
+  A.nty = ty1 - ty0;
+  A.ntz = (zhi - zlo + A.zchunk - 1) / A.zchunk;
+  if (A.ntx <= 0 || A.nty <= 0 || A.ntz <= 0) return hipSuccess;
   if (nvar == 6) return scheme == 0 ? launch2<ST, RS, 8, 0, 6>(A, grav, s) : hipErrorInvalidValue;
   if (nvar == 7) return scheme == 0 ? launch2<ST, RS, 8, 0, 7>(A, grav, s) : hipErrorInvalidValue;
   if (nvar != 5) return hipErrorInvalidValue;

@@ -101,6 +101,19 @@ class HydroLevel:
         check(lib().ramses_amd_godunov_brick(C.byref(self.params), C.byref(self.brick), _ptr(self.uold),
                                              _ptr(self.f), _ptr(self.unew), self.dx, float(dt), _stream()))
 
+    def godunov_fine_shell(self, dt=None):
+        """The part of godunov_fine that produces the cells the neighbour ranks
+        receive (tiles/planes touching a brick face); see godunov_fine_interior."""
+        dt = self.dtnew if dt is None else dt
+        check(lib().ramses_amd_godunov_brick_shell(C.byref(self.params), C.byref(self.brick), _ptr(self.uold),
+                                                   _ptr(self.f), _ptr(self.unew), self.dx, float(dt), _stream()))
+
+    def godunov_fine_interior(self, dt=None):
+        """The rest of godunov_fine: shell + interior == godunov_fine bit for bit."""
+        dt = self.dtnew if dt is None else dt
+        check(lib().ramses_amd_godunov_brick_interior(C.byref(self.params), C.byref(self.brick), _ptr(self.uold),
+                                                      _ptr(self.f), _ptr(self.unew), self.dx, float(dt), _stream()))
+
     def set_uold(self):
         """uold = unew (hydro/godunov_fine.f90:193-197): a buffer swap on the device."""
         self.uold, self.unew = self.unew, self.uold

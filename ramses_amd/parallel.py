@@ -128,6 +128,32 @@ class BrickDecomposition:
         if lev.f is not None:
             self.exchange(lev, lev.f, 3)
 
+    def step_overlapped(self, lev, dt):
+        """One hydro step with the halo exchange of the NEW state hidden behind the
+        interior sweep (the reference runs them back to back, amr/amr_step.f90:388-510):
+
+            compute stream:  shell sweep | interior sweep ................ | swap
+            comm stream:                 | pack, RCCL send/recv, unpack    |
+
+        The shell launches produce every cell within 2 of a brick face, i.e. all the
+        data the face slabs carry; the interior launch writes only cells the exchange
+        never touches, and both read the old state, so the result equals
+        godunov_fine -> set_uold -> make_virtual_fine_dp bit for bit."""
+        if getattr(self, "_comm_stream", None) is None:
+            self._comm_stream = torch.cuda.Stream(device=lev.uold.device)
+        comp = torch.cuda.current_stream()
+        lev.godunov_fine_shell(dt)
+        shell_done = torch.cuda.Event()
+        shell_done.record(comp)
+        with torch.cuda.stream(self._comm_stream):
+            self._comm_stream.wait_event(shell_done)
+            self.exchange(lev, lev.unew, lev.nvar)        # ghosts of the new state
+            comm_done = torch.cuda.Event()
+            comm_done.record(self._comm_stream)
+        lev.godunov_fine_interior(dt)
+        comp.wait_event(comm_done)
+        lev.set_uold()
+
     def allreduce_min(self, value, device):
         """dt = min over ranks (MPI_ALLREDUCE MIN of hydro/courant_fine.f90:140)."""
         t = torch.tensor([value], dtype=torch.float64, device=device)
