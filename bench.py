@@ -91,7 +91,7 @@ def cpu_baseline():
             pass
         if os.path.exists(mpi_bin) and os.path.exists(mpiexec) and ncores >= 2:
             P = 1
-            while P * 2 <= min(ncores, 64):
+            while P * 2 <= min(ncores, 32):
                 P *= 2
             level, nstep, binary = 7, 10, mpi_bin
         elif os.path.exists(ser_bin):

@@ -153,7 +153,7 @@ int ramses_amd_godunov_brick(const ramses_amd_hydro_params *p, const ramses_amd_
 int ramses_amd_godunov_brick_shell(const ramses_amd_hydro_params *p, const ramses_amd_brick *b,
                                    const double *d_uold, const double *d_grav, double *d_unew,
                                    double dx, double dt, void *stream) {
-  return godunov_brick_region(p, b, d_uold, d_grav, d_unew, dx, dt, SWEEP_SHELL_ZLO, SWEEP_SHELL_XHI, stream);
+  return godunov_brick_region(p, b, d_uold, d_grav, d_unew, dx, dt, SWEEP_SHELL, SWEEP_SHELL, stream);
 }
 
 int ramses_amd_godunov_brick_interior(const ramses_amd_hydro_params *p, const ramses_amd_brick *b,

@@ -83,14 +83,21 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
       bid = (bid % nxcd) * per + bid / nxcd;
     }
   }
-  // this launch covers tiles [tx0,tx0+ntx) x [ty0,ty0+nty) and planes [zlo,zhi)
-  const int tix = A.tx0 + bid % A.ntx;
-  const int tiy = A.ty0 + (bid / A.ntx) % A.nty;
-  const int tiz = bid / (A.ntx * A.nty);
+  // a launch covers up to 6 boxes of tiles x planes (one for a whole-brick or
+  // interior sweep, six for the boundary shell); find this block's box (uniform)
+  int bi = 0;
+#pragma unroll
+  for (int i = 1; i < 6; i++)
+    if (i < A.nbox && bid >= A.box[i].first) bi = i;
+  const SweepBox &B = A.box[bi];
+  const int lb = bid - B.first;
+  const int tix = B.tx0 + lb % B.ntx;
+  const int tiy = B.ty0 + (lb / B.ntx) % B.nty;
+  const int tiz = lb / (B.ntx * B.nty);
   const int x0 = tix * (BX - 4);
   const int y0 = tiy * (BY - 4);
-  const int z0 = A.zlo + tiz * A.zchunk;
-  const int z1 = min(z0 + A.zchunk, A.zhi);
+  const int z0 = B.zlo + tiz * B.zchunk;
+  const int z1 = min(z0 + B.zchunk, B.zhi);
 
   // ---- this thread's column ------------------------------------------------
   const int xu = x0 - 2 + tx;  // unwrapped interior coordinate
@@ -312,7 +319,7 @@ template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV>
 static hipError_t launch3(const SweepArgs &A, hipStream_t s) {
   const size_t lds = 5 * sizeof(Plane<BY, NV>);
   dim3 block(BX, BY);
-  dim3 grid(A.ntx * A.nty * A.ntz);
+  dim3 grid(A.nblocks);
   auto k = godunov_sweep_kernel<ST, RS, BY, GRAV, SCHEME, NV>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -332,33 +339,44 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
   // PLMDE tracing and runs with passive scalars
   const bool heavy = (RS == RIEMANN_EXACT) || (ST == 3) || (scheme != 0) || (nvar != 5);
   if (by == 0 || heavy) by = heavy ? 8 : 12;
-  // tiles of the whole brick, then the sub-box this launch covers (A.region)
+  // tiles of the whole brick, then the boxes this launch covers (A.region)
   const int NTX = (A.nx + (BX - 4) - 1) / (BX - 4);
   const int NTY = (A.ny + (by - 4) - 1) / (by - 4);
-  int tx0 = 0, tx1 = NTX, ty0 = 0, ty1 = NTY, zlo = 0, zhi = A.nz;
   // Boundary shell / interior split used to overlap the halo exchange with the
   // interior sweep: shell = the tiles and planes that produce the cells within
-  // 2 of a face (what the neighbours receive); zb planes at each z end.
+  // 2 of a face (what the neighbours receive); zb planes at each z end.  The six
+  // shell boxes go into ONE launch, cut into short z-chunks so that the thin
+  // slabs still fill the chip.
   const int zb = 2;
   const bool splittable = NTX >= 3 && NTY >= 3 && A.nz >= 4 * zb;
-  switch (A.region) {
-    case SWEEP_ALL: break;
-    case SWEEP_INTERIOR:
-      if (!splittable) return hipSuccess;   // everything was done by the shell launches
-      tx0 = 1; tx1 = NTX - 1; ty0 = 1; ty1 = NTY - 1; zlo = zb; zhi = A.nz - zb; break;
-    case SWEEP_SHELL_ZLO: if (!splittable) break; zhi = zb; break;
-    case SWEEP_SHELL_ZHI: if (!splittable) return hipSuccess; zlo = A.nz - zb; break;
-    case SWEEP_SHELL_YLO: if (!splittable) return hipSuccess; ty1 = 1; zlo = zb; zhi = A.nz - zb; break;
-    case SWEEP_SHELL_YHI: if (!splittable) return hipSuccess; ty0 = NTY - 1; zlo = zb; zhi = A.nz - zb; break;
-    case SWEEP_SHELL_XLO: if (!splittable) return hipSuccess; tx1 = 1; ty0 = 1; ty1 = NTY - 1; zlo = zb; zhi = A.nz - zb; break;
-    case SWEEP_SHELL_XHI: if (!splittable) return hipSuccess; tx0 = NTX - 1; ty0 = 1; ty1 = NTY - 1; zlo = zb; zhi = A.nz - zb; break;
-    default: return hipErrorInvalidValue;
+  A.nbox = 0;
+  int nblocks = 0;
+  auto add_box = [&](int tx0, int tx1, int ty0, int ty1, int zlo, int zhi, int zchunk) {
+    if (tx1 <= tx0 || ty1 <= ty0 || zhi <= zlo) return;
+    SweepBox &B = A.box[A.nbox++];
+    B.tx0 = tx0; B.ntx = tx1 - tx0; B.ty0 = ty0; B.nty = ty1 - ty0;
+    B.zlo = zlo; B.zhi = zhi; B.zchunk = zchunk < (zhi - zlo) ? zchunk : (zhi - zlo);
+    B.first = nblocks;
+    nblocks += B.ntx * B.nty * ((zhi - zlo + B.zchunk - 1) / B.zchunk);
+  };
+  const int zc = A.zchunk;
+  if (A.region == SWEEP_ALL || (A.region == SWEEP_SHELL && !splittable)) {
+    add_box(0, NTX, 0, NTY, 0, A.nz, zc);
+  } else if (A.region == SWEEP_INTERIOR) {
+    if (splittable) add_box(1, NTX - 1, 1, NTY - 1, zb, A.nz - zb, zc);
+  } else if (A.region == SWEEP_SHELL) {
+    const int zs = 32;
+    add_box(0, NTX, 0, NTY, 0, zb, zs);                                 // z low slab
+    add_box(0, NTX, 0, NTY, A.nz - zb, A.nz, zs);                       // z high slab
+    add_box(0, NTX, 0, 1, zb, A.nz - zb, zs);                           // y low tile row
+    add_box(0, NTX, NTY - 1, NTY, zb, A.nz - zb, zs);                   // y high tile row
+    add_box(0, 1, 1, NTY - 1, zb, A.nz - zb, zs);                       // x low tile column
+    add_box(NTX - 1, NTX, 1, NTY - 1, zb, A.nz - zb, zs);               // x high tile column
+  } else {
+    return hipErrorInvalidValue;
   }
-  A.tx0 = tx0; A.ty0 = ty0; A.zlo = zlo; A.zhi = zhi;
-  A.ntx = tx1 - tx0;
-  A.nty = ty1 - ty0;
-  A.ntz = (zhi - zlo + A.zchunk - 1) / A.zchunk;
-  if (A.ntx <= 0 || A.nty <= 0 || A.ntz <= 0) return hipSuccess;
+  if (nblocks == 0) return hipSuccess;
+  A.nblocks = nblocks;
   if (nvar == 6) return scheme == 0 ? launch2<ST, RS, 8, 0, 6>(A, grav, s) : hipErrorInvalidValue;
   if (nvar == 7) return scheme == 0 ? launch2<ST, RS, 8, 0, 7>(A, grav, s) : hipErrorInvalidValue;
   if (nvar != 5) return hipErrorInvalidValue;

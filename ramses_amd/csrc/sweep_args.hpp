@@ -4,9 +4,14 @@
 
 namespace ramses_amd {
 
-// sub-box selectors of one sweep launch
-enum { SWEEP_ALL = 0, SWEEP_INTERIOR = 1, SWEEP_SHELL_ZLO = 2, SWEEP_SHELL_ZHI = 3, SWEEP_SHELL_YLO = 4,
-       SWEEP_SHELL_YHI = 5, SWEEP_SHELL_XLO = 6, SWEEP_SHELL_XHI = 7 };
+// what one sweep launch covers
+enum { SWEEP_ALL = 0, SWEEP_INTERIOR = 1, SWEEP_SHELL = 2 };
+
+// a box of tiles x planes inside the brick, cut into z-chunks; `first` = index
+// of its first workgroup in the launch
+struct SweepBox {
+  int tx0, ntx, ty0, nty, zlo, zhi, zchunk, first;
+};
 
 struct SweepArgs {
   const double *uold;
@@ -16,9 +21,9 @@ struct SweepArgs {
   int ng;               // ghost width (0 = periodic wrap in-kernel)
   long pitch_y, pitch_z, pitch_var;
   int zchunk;           // planes marched per workgroup
-  int ntx, nty, ntz;    // tiles per direction of this launch (filled by the launcher)
-  int tx0, ty0, zlo, zhi;  // first tile / plane range of this launch
-  int region;           // SWEEP_*
+  int region;           // SWEEP_* (in); the launcher fills the boxes
+  int nbox, nblocks;
+  SweepBox box[6];
   double dt, dx, rdx;   // rdx = 1/dx (exact when dx is a power of two)
   int pow2;             // dx is a power of two: (f*dt)/dx == (f*dt)*rdx bit for bit
   HydroConst P;
