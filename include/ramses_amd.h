@@ -221,6 +221,25 @@ int ramses_amd_mg_smooth_fused(const double *d_phi_in, double *d_phi_out,
 int ramses_amd_mg_tune(int fused);
 
 /* ---------------------------------------------------------------------------
+ * Coarse <-> fine hydro operators between a periodic coarse brick (nc^3) and
+ * its fully refined child brick ((2nc)^3), brick layout, nvar = 5.
+ * ramses_amd_interpol_hydro_brick replaces interpol_hydro + compute_limiter_minmod
+ *   / compute_limiter_central / compute_central (hydro/interpol_hydro.f90:268-444,
+ *   449-637): every coarse cell and its 6 neighbours -> its 8 children, with the
+ *   &REFINE_PARAMS knobs interpol_var (0 conservative, 1 internal energy,
+ *   2 velocity + internal energy) and interpol_type (1 minmod, 2 central-limited,
+ *   3 unlimited central, 4 = 3 for velocities and 2 otherwise).
+ * ramses_amd_upload_fine_brick replaces upload_fine / upl (:5-68, 73-263): every
+ *   coarse cell = mean of its 8 children (density floored), internal-energy
+ *   averaging when interpol_var is 1 or 2.
+ * ------------------------------------------------------------------------- */
+int ramses_amd_interpol_hydro_brick(int nc, int nvar, int interpol_var, int interpol_type,
+                                    double smallr, const double *d_coarse, double *d_fine,
+                                    void *stream);
+int ramses_amd_upload_fine_brick(int nc, int nvar, int interpol_var, double smallr,
+                                 const double *d_fine, double *d_coarse, void *stream);
+
+/* ---------------------------------------------------------------------------
  * godunov_fine(ilevel) on the reference's OWN arrays (host memory, Fortran
  * layout): the entry point the Fortran shim ramses_amd/patch/godunov_fine.f90
  * binds.  Replaces hydro/godunov_fine.f90:5-35 + :486-911 for a level that is

@@ -41,8 +41,9 @@ build_kernels() { # ndim [nvar]: nvar>ndim+2 adds passive scalars (tag _vN)
   local obj="$OUT/obj_kernels${tag}"
   mkdir -p "$obj"
   local flags="$(defines $ndim $nvar) -DWITHOUTMPI -fPIC $OPT -module-dir $obj -I$obj"
-  local srcs=(amr/amr_parameters.f90 hydro/hydro_parameters.f90 hydro/hydro_commons.f90
-              hydro/umuscl.f90 hydro/uplmde.f90 hydro/godunov_utils.f90)
+  local srcs=(amr/amr_parameters.f90 amr/amr_commons.f90 hydro/hydro_parameters.f90 hydro/hydro_commons.f90
+              poisson/poisson_parameters.f90 poisson/poisson_commons.f90
+              hydro/umuscl.f90 hydro/uplmde.f90 hydro/godunov_utils.f90 hydro/interpol_hydro.f90)
   local objs=()
   # hydro_commons needs amr_commons only for its module 'const'? compile the
   # minimal chain and let the compiler tell us if something is missing.

@@ -73,6 +73,10 @@ def lib():
                                            C.POINTER(C.c_int), _dp, _dp, _dp, C.POINTER(C.c_double)]
         L.ora_mg_solve_uniform.restype = C.c_int
         L.ora_gradient_phi_uniform.argtypes = [_dp, C.c_int, _dp]
+        L.ora_interpol_hydro.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
+        L.ora_interpol_hydro.restype = None
+        L.ora_upl.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
+        L.ora_upl.restype = None
         for fn in (L.ora_mg_gauss_seidel, L.ora_mg_residual, L.ora_mg_restrict, L.ora_mg_interp_correct,
                    L.ora_gradient_phi_uniform):
             fn.restype = None
@@ -191,6 +195,9 @@ def ref(ndim=3, nvar=None):
                                   C.c_double, C.c_int]
         L.ref_riemann.argtypes = [_dp, _dp, _dp, C.c_int]
         L.ref_cmpdt.argtypes = [_dp, _dp, C.c_double, C.POINTER(C.c_double), C.c_int]
+        if hasattr(L, "ref_interpol_hydro"):
+            L.ref_interpol_hydro.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double]
+            L.ref_upl.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_double]
         _ref[key] = L
     return _ref[key]
 

@@ -106,3 +106,73 @@ subroutine ref_cmpdt(uu, gg, dx, dt, ncell) bind(C, name='ref_cmpdt')
   call cmpdt(uu, gg, dxl, dtl, nc)
   dt = dtl
 end subroutine ref_cmpdt
+
+! ---------------------------------------------------------------------------
+! coarse<->fine operators: interpol_hydro is a pure routine of its arguments
+! and the interpolation knobs; upl reads the tree (son) and uold, which this
+! shim allocates as a one-oct-per-parent toy tree: parent cell i = coarse-level
+! cell slot i, its son oct = slot i, children at ncoarse+(ind-1)*ngridmax+i.
+! ---------------------------------------------------------------------------
+subroutine ref_interpol_hydro(u1, u2, nn, ivar_in, itype_in, smallr_in) bind(C, name='ref_interpol_hydro')
+  use iso_c_binding
+  use amr_parameters
+  use hydro_parameters
+  implicit none
+  real(c_double) :: u1(*), u2(*)
+  integer(c_int), value :: nn, ivar_in, itype_in
+  real(c_double), value :: smallr_in
+  integer :: n
+  interpol_var = ivar_in
+  interpol_type = itype_in
+  smallr = smallr_in
+  n = nn
+  call interpol_hydro(u1, u2, n)
+end subroutine ref_interpol_hydro
+
+subroutine ref_upl(child, parent, nn, ivar_in, smallr_in) bind(C, name='ref_upl')
+  use iso_c_binding
+  use amr_commons
+  use hydro_commons
+  implicit none
+  real(c_double) :: child(nvector, 8, nvar), parent(nvector, nvar)
+  integer(c_int), value :: nn, ivar_in
+  real(c_double), value :: smallr_in
+  integer :: i, ind, iv, n, ncell
+  integer, dimension(1:nvector) :: ind_cell
+  interpol_var = ivar_in
+  smallr = smallr_in
+  n = nn
+  ! toy tree: ngridmax = 2*nvector oct slots; parents live in octant 1 of octs
+  ! nvector+1..2*nvector, their sons are octs 1..nvector
+  ngridmax = 2 * nvector
+  ncoarse = 1
+  ncell = ncoarse + 8 * ngridmax
+  if (.not. allocated(uold)) allocate(uold(1:ncell, 1:nvar))
+  if (.not. allocated(son)) allocate(son(1:ncell))
+  uold = 0.0d0
+  son = 0
+  do i = 1, n
+     ind_cell(i) = ncoarse + (nvector + i)
+     son(ind_cell(i)) = i
+     do iv = 1, nvar
+        uold(ind_cell(i), iv) = parent(i, iv)
+        do ind = 1, 8
+           uold(ncoarse + (ind - 1) * ngridmax + i, iv) = child(i, ind, iv)
+        end do
+     end do
+  end do
+  call upl(ind_cell, n)
+  do i = 1, n
+     do iv = 1, nvar
+        parent(i, iv) = uold(ind_cell(i), iv)
+     end do
+  end do
+end subroutine ref_upl
+
+! interpol_hydro references clean_stop (amr/end.f90), which is not part of the
+! kernel-level library: a stub with the same effect (the run ends).
+subroutine clean_stop
+  implicit none
+  write(*,*) 'ref_shim: clean_stop called'
+  stop 2
+end subroutine clean_stop

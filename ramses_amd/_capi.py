@@ -69,6 +69,8 @@ SYMBOLS = [
     ("ramses_amd_mg_smooth_fused", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _d, _i, _vp]),
     ("ramses_amd_mg_tune", _i, [_i]),
     ("ramses_amd_godunov_fine_host", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _d, _d]),
+    ("ramses_amd_interpol_hydro_brick", _i, [_i, _i, _i, _i, _d, _vp, _vp, _vp]),
+    ("ramses_amd_upload_fine_brick", _i, [_i, _i, _i, _d, _vp, _vp, _vp]),
     ("ramses_amd_multigrid_fine_f90", _i, [_i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _d, _d, _d,
                                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     ("ramses_amd_godunov_fine_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _i, _d, _d]),

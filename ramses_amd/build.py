@@ -26,6 +26,7 @@ UNITS = [
     ("hydro_misc.o", "hydro_misc.hip", ["-ffp-contract=off"]),
     ("mg_kernels.o", "mg_kernels.hip", ["-ffp-contract=off"]),
     ("octree_pack.o", "octree_pack.hip", ["-ffp-contract=off"]),
+    ("amr_ops.o", "amr_ops.hip", ["-ffp-contract=off"]),
     ("capi.o", "capi.hip", ["-ffp-contract=off"]),
 ]
 

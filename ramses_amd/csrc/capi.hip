@@ -10,6 +10,7 @@
 #include <cstring>
 
 #include "../../include/ramses_amd.h"
+#include "amr_args.hpp"
 #include "mg_args.hpp"
 #include "misc_args.hpp"
 #include "pack_args.hpp"
@@ -611,6 +612,36 @@ int ramses_amd_multigrid_fine_f90(int ilevel, int ngrid, const int *igrid, const
   HCHK(hipStreamSynchronize(s), "sync");
 #undef HCHK
   return 0;
+}
+
+// ---------------------------------------------------------------------------
+// coarse <-> fine hydro operators on a periodic coarse brick and its fully
+// refined child brick
+// ---------------------------------------------------------------------------
+static int amr_op(bool prolong, int nc, int nvar, int interpol_var, int interpol_type, double smallr,
+                  double *d_coarse, double *d_fine, void *stream) {
+  if (!d_coarse || !d_fine) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (nc < 2) return fail(RAMSES_AMD_EINVAL, "coarse brick must have >=2 cells per direction");
+  if (nvar != 5) return fail(RAMSES_AMD_EUNSUPPORTED, "coarse<->fine operators implement NVAR=5 (got %d)", nvar);
+  if (interpol_var < 0 || interpol_var > 2) return fail(RAMSES_AMD_EINVAL, "interpol_var must be 0, 1 or 2");
+  if (prolong && (interpol_type < 1 || interpol_type > 4)) return fail(RAMSES_AMD_EINVAL, "interpol_type must be 1..4");
+  if (prolong && interpol_type == 4 && interpol_var != 2) return fail(RAMSES_AMD_EINVAL, "interpol_type=4 is designed for interpol_var=2");
+  AmrOpArgs A;
+  A.coarse = d_coarse; A.fine = d_fine; A.nc = nc; A.nvar = nvar;
+  A.interpol_var = interpol_var; A.interpol_type = interpol_type; A.smallr = smallr;
+  hipError_t e = launch_amr_op(A, prolong, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hipfail(e, prolong ? "interpol_hydro launch" : "upload_fine launch");
+  return 0;
+}
+
+int ramses_amd_interpol_hydro_brick(int nc, int nvar, int interpol_var, int interpol_type, double smallr,
+                                    const double *d_coarse, double *d_fine, void *stream) {
+  return amr_op(true, nc, nvar, interpol_var, interpol_type, smallr, const_cast<double *>(d_coarse), d_fine, stream);
+}
+
+int ramses_amd_upload_fine_brick(int nc, int nvar, int interpol_var, double smallr, const double *d_fine,
+                                 double *d_coarse, void *stream) {
+  return amr_op(false, nc, nvar, interpol_var, 1, smallr, d_coarse, const_cast<double *>(d_fine), stream);
 }
 
 }  // extern "C"
