@@ -137,7 +137,7 @@ EOF
   if [ "$ndim" != 3 ]; then
     # flang rejects a rank-mismatched assignment in dead NDIM<3 code of
     # pm/sink_sn_feedback.f90; fix it on the fly.
-    sed 's/xx(i,:)=xg(ind_grid(i),:)+xc(ind,:)/xx(i,1:ndim)=xg(ind_grid(i),1:ndim)+xc(ind,1:ndim)/' \
+    sed 's/xx(i, :) = xg(ind_grid(i), :) + xc(ind, :)/xx(i, 1:ndim) = xg(ind_grid(i), 1:ndim) + xc(ind, 1:ndim)/' \
         "$REF/pm/sink_sn_feedback.f90" > "$gen/sink_sn_feedback.f90"
   fi
   find_src() { # name -> path

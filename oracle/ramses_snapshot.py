@@ -189,6 +189,39 @@ def load_uniform_level(outdir, level, with_grav=False, grav_has_rho=False):
     return dict(prim=prim, grav=grav, info=info)
 
 
+def load_leaf_cells(outdir):
+    """All leaf cells (son == 0) of a snapshot, every level and cpu:
+    -> dict(level, x[ncell,ndim] in box units, prim[nvar,ncell], info)."""
+    num = os.path.basename(outdir.rstrip("/")).split("_")[-1]
+    levels, xs, prims = [], [], []
+    info = None
+    for af in sorted(glob.glob(os.path.join(outdir, "amr_%s.out*" % num))):
+        cpu = af.split(".out")[-1]
+        amr = read_amr(af)
+        info = amr
+        ndim = amr["ndim"]
+        hh, hl = _read_cellfile(os.path.join(outdir, "hydro_%s.out%s" % (num, cpu)))
+        icpu = int(cpu) - 1
+        # coarse-grid offset of boxes with physical boundaries (nx = 3: the domain is the middle cell)
+        skip = [1.0 if amr["nx"][d] > 1 else 0.0 for d in range(ndim)]
+        scale = amr["boxlen"] / max(1, amr["nx"][0] - 2 * int(skip[0]))
+        for il in range(amr["nlevelmax"]):
+            dom = amr["levels"][il][icpu]
+            if dom is None:
+                continue
+            dxl = 0.5 ** (il + 1)
+            for ind in range(2 ** ndim):
+                leaf = dom["son"][:, ind] == 0
+                if not leaf.any():
+                    continue
+                pos = np.stack([(dom["xg"][leaf, d] + (((ind >> d) & 1) - 0.5) * dxl - skip[d]) * scale
+                                for d in range(ndim)], axis=1)
+                xs.append(pos)
+                prims.append(hl[il][icpu][:, ind, :][:, leaf])
+                levels.append(np.full(int(leaf.sum()), il + 1))
+    return dict(level=np.concatenate(levels), x=np.concatenate(xs), prim=np.concatenate(prims, axis=1), info=info)
+
+
 def prim_to_cons(prim, gamma):
     """Inverse of backup_hydro's conversion (hydro/output_hydro.f90:83-129),
     only used to seed runs; parity checks go cons -> prim instead."""
