@@ -167,7 +167,13 @@ cmd=${1:-kernels}
 case "$cmd" in
   kernels) build_kernels "${2:-3}" "${3:-}";;
   ramses) build_ramses "${2:-3}" "${3:-serial}" "${4:-}";;
-  all) build_kernels 3; build_kernels 1; build_kernels 2; build_kernels 3 7; build_ramses 3 serial;
-       REF_DEFS=-DOUTPUT_PARTICLE_DENSITY REF_TAG=rho build_ramses 3 serial;;
+  all) # every artefact tests/ and bench.py look for
+       build_kernels 3; build_kernels 1; build_kernels 2; build_kernels 3 7
+       build_ramses 3 serial; build_ramses 1 serial; build_ramses 2 serial
+       REF_DEFS=-DOUTPUT_PARTICLE_DENSITY REF_TAG=rho build_ramses 3 serial
+       if [ -d /opt/conda/include ] && [ -f /opt/conda/lib/libmpifort.so ]; then build_ramses 3 mpi; fi
+       if [ -f "$HERE/../ramses_amd/lib/libramses_amd.so" ]; then
+         build_ramses 3 serial "$HERE/../ramses_amd/patch"
+       fi;;
   *) echo "usage: $0 kernels [NDIM] | ramses [NDIM] [serial|mpi] [PATCHDIR] | all"; exit 2;;
 esac
