@@ -60,10 +60,19 @@ __device__ __forceinline__ double wave_shl1(double v) {
   return __hiloint2double(hi, lo);
 }
 
-template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV>
-__global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
+// Row roles.  One wave = one tile row, and what a row has to produce depends
+// only on its position in the tile, so each role gets its own straight-line
+// instantiation of the marching loop (no per-plane role branches, no dead
+// results kept alive); all of them execute the same barriers.
+//   ROLE_HALO : rows 0 and BY-1   primitives only
+//   ROLE_LOW  : row 1             + slopes, the traced +y state (left state of row 2's y flux)
+//   ROLE_HIGH : row BY-2          + slopes, the traced -y state, the y flux through its -y face
+//   ROLE_FULL : rows 2..BY-3      everything, and the update
+enum { ROLE_HALO = 0, ROLE_LOW = 1, ROLE_HIGH = 2, ROLE_FULL = 3 };
+
+template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV, int ROLE>
+__device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *smem_raw) {
   const bool DXPOW2 = A.pow2 != 0;   // uniform
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Plane<BY, NV> *qring = reinterpret_cast<Plane<BY, NV> *>(smem_raw);  // [3] primitives of planes c-1, c, c+1
   Plane<BY, NV> *smy = qring + 3;                                   // qm along y (state on the +y face)
   Plane<BY, NV> *fyb = qring + 4;                                   // flux through the -y face
@@ -117,10 +126,9 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
   double *__restrict__ unew = A.unew;
   const double *__restrict__ grav = A.grav;
 
-  // roles (wave-uniform: one wave = one row)
-  const bool r_trace = (ty >= 1) && (ty <= BY - 2);
-  const bool r_fy = (ty >= 2) && (ty <= BY - 2);
-  const bool r_fxz = (ty >= 2) && (ty <= BY - 3);
+  constexpr bool r_trace = ROLE != ROLE_HALO;
+  constexpr bool r_fy = ROLE == ROLE_HIGH || ROLE == ROLE_FULL;
+  constexpr bool r_fxz = ROLE == ROLE_FULL;
   const bool r_upd = r_fxz && (tx >= 2) && (tx <= BX - 3) && (xu < A.nx) && (yu < A.ny);
 
   const double dtdx = A.dt / A.dx;
@@ -170,16 +178,14 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
     for (int n = 0; n < NV; n++) qring[sb].v[n][ty][tx] = q[n];
     load_u(z0, upre); load_g(z0, gpre);
 #pragma unroll
-    for (int n = 0; n < NV; n++) { qmz[n] = 0.0; part[n] = 0.0; fzlo[n] = 0.0; }
+    for (int n = 0; n < NV; n++) { qmz[n] = 1.0; part[n] = 0.0; fzlo[n] = 0.0; }
   }
   __syncthreads();
 
   const int txm = max(tx - 1, 0), txp = min(tx + 1, BX - 1);
   const int tym = max(ty - 1, 0), typ = min(ty + 1, BY - 1);
 
-#pragma unroll 2
   for (int c = z0 - 1; c <= z1; c++) {
-    const bool do_xy = (c >= z0) && (c < z1);
     // ---- plane c+1 arrives: primitives into ring slot sc ---------------------
     double qc[NV];
     ctoprim_cell<NV, GRAV>(upre, gpre, dtxhalf, P, qc);
@@ -189,15 +195,16 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
     // the update at the end of this iteration
     double ucur[NV];
     if (c + 2 <= z1 + 1) { load_u(c + 2, upre); load_g(c + 2, gpre); }
-    if (do_xy && r_fxz) load_u(c, ucur);
+    if (r_fxz) load_u(c, ucur);
     // Slot sc was last read (as plane c-2) before barrier B2 of iteration c-1;
     // plane c's neighbours were written one iteration (two barriers) ago.
 
-    double qpy[NV], fx[NV], fz[NV];
-#pragma unroll
-    for (int n = 0; n < NV; n++) { fx[n] = 0.0; fz[n] = 0.0; }
+    // The x and y fluxes of the two end planes (c = z0-1 and c = z1, traced for
+    // their z states only) are computed and dropped: one plane in ~130, cheaper
+    // than carrying the condition through the loop.
+    double qpy[NV], fx[NV], fz[NV], fy[NV];
     if (ST == 3) __syncthreads();  // the 27-point slope reads the neighbours' plane c+1 just written
-    if (r_trace) {
+    if constexpr (r_trace) {
       const Plane<BY, NV> &qs = qring[sb];
       const Plane<BY, NV> &qprev = qring[sa];
       double qb[NV], dq[3][NV];
@@ -235,32 +242,28 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
         const double cc = ctoprim_sound(qb[0], qb[4], P);
         tracexyz_cell<NV>(qb, dq, cc, dtdx, dtdx, dtdx, P, qm, qp);
       }
+      if constexpr (ROLE != ROLE_HIGH) {
 #pragma unroll
-      for (int n = 0; n < NV; n++) {
-        smy->v[n][ty][tx] = qm[1][n];
-        qpy[n] = qp[1][n];
+        for (int n = 0; n < NV; n++) smy->v[n][ty][tx] = qm[1][n];
       }
-      if (r_fxz) {
-        if (do_xy) {
-          double qL[NV];
 #pragma unroll
-          for (int n = 0; n < NV; n++) qL[n] = wave_shr1(qm[0][n]);  // +x state of column tx-1
-          scaled_interface_flux<RS, NV, 0>(qL, qp[0], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fx);
-        }
+      for (int n = 0; n < NV; n++) qpy[n] = qp[1][n];
+      if constexpr (r_fxz) {
+        double qL[NV];
+#pragma unroll
+        for (int n = 0; n < NV; n++) qL[n] = wave_shr1(qm[0][n]);  // +x state of column tx-1
+        scaled_interface_flux<RS, NV, 0>(qL, qp[0], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fx);
         if (c >= z0) {
           // z flux through the face between planes c-1 and c
           scaled_interface_flux<RS, NV, 2>(qmz, qp[2], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fz);
         }
-      }
 #pragma unroll
-      for (int n = 0; n < NV; n++) qmz[n] = qm[2][n];
+        for (int n = 0; n < NV; n++) qmz[n] = qm[2][n];
+      }
     }
     __syncthreads();  // (B2) +y traced states visible
 
-    double fy[NV];
-#pragma unroll
-    for (int n = 0; n < NV; n++) fy[n] = 0.0;
-    if (r_fy && do_xy) {
+    if constexpr (r_fy) {
       double qL[NV];
 #pragma unroll
       for (int n = 0; n < NV; n++) qL[n] = smy->v[n][tym][tx];
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
     }
     __syncthreads();  // (B3) y fluxes visible
 
-    if (r_fxz) {
+    if constexpr (r_fxz) {
       // finish plane c-1: its +z face flux is fz
       if (c >= z0 + 1 && r_upd) {
         const long o = plane_off(c - 1);
@@ -291,25 +294,35 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
 #pragma unroll
         for (int n = 0; n < NV; n++) unew[o + (long)n * A.pitch_var] = un[n];
       }
-      if (do_xy) {
 #pragma unroll
-        for (int n = 0; n < NV; n++) {
-          const double fxhi = wave_shl1(fx[n]);  // -x face flux of column tx+1
-          const double t = ucur[n] + (fx[n] - fxhi);
-          part[n] = t + (fy[n] - fyb->v[n][typ][tx]);
-        }
-        if (NV > 5) {
-          rold = ucur[0];
-#pragma unroll
-          for (int n = 5; n < NV; n++) sold[n - 5] = ucur[n];
-        }
+      for (int n = 0; n < NV; n++) {
+        const double fxhi = wave_shl1(fx[n]);  // -x face flux of column tx+1
+        const double t = ucur[n] + (fx[n] - fxhi);
+        part[n] = t + (fy[n] - fyb->v[n][typ][tx]);
       }
+      if (NV > 5) {
+        rold = ucur[0];
 #pragma unroll
-      for (int n = 0; n < NV; n++) fzlo[n] = fz[n];
+        for (int n = 5; n < NV; n++) sold[n - 5] = ucur[n];
+      }
+      if (c >= z0) {
+#pragma unroll
+        for (int n = 0; n < NV; n++) fzlo[n] = fz[n];
+      }
     }
     // rotate the ring
     const int t = sa; sa = sb; sb = sc; sc = t;
   }
+}
+
+template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV>
+__global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int ty = threadIdx.y;   // wave-uniform
+  if (ty == 0 || ty == BY - 1) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_HALO>(A, smem_raw);
+  else if (ty == 1) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_LOW>(A, smem_raw);
+  else if (ty == BY - 2) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_HIGH>(A, smem_raw);
+  else sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_FULL>(A, smem_raw);
 }
 
 // ---------------------------------------------------------------------------
