@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libramses_amd.so")
+# RAMSES_AMD_LIB: load another build of the same library (kernel A/B measurements)
+LIB_PATH = os.environ.get("RAMSES_AMD_LIB") or os.path.join(HERE, "lib", "libramses_amd.so")
 
 RIEMANN = {"llf": 0, "hllc": 1, "hll": 2, "acoustic": 3, "exact": 4}
 SCHEME = {"muscl": 0, "plmde": 1}

@@ -64,11 +64,42 @@ __device__ __forceinline__ double wave_shl1(double v) {
 // only on its position in the tile, so each role gets its own straight-line
 // instantiation of the marching loop (no per-plane role branches, no dead
 // results kept alive); all of them execute the same barriers.
-//   ROLE_HALO : rows 0 and BY-1   primitives only
-//   ROLE_LOW  : row 1             + slopes, the traced +y state (left state of row 2's y flux)
-//   ROLE_HIGH : row BY-2          + slopes, the traced -y state, the y flux through its -y face
-//   ROLE_FULL : rows 2..BY-3      everything, and the update
-enum { ROLE_HALO = 0, ROLE_LOW = 1, ROLE_HIGH = 2, ROLE_FULL = 3 };
+//   ROLE_HALO    : row 0        primitives only
+//   ROLE_LOW     : row 1        + slopes, the traced +y state (left state of row 2's y flux)
+//   ROLE_FULL    : rows 2..BY-3 everything, and the update
+//   ROLE_HIGH    : row BY-2     + slopes, the traced -y state (handed to row BY-1 through LDS)
+//   ROLE_HALO_HI : row BY-1     primitives, and the y flux through the -y face of row BY-2
+//                               (its wave has nothing else to do: evens out the SIMDs)
+enum { ROLE_HALO = 0, ROLE_LOW = 1, ROLE_HIGH = 2, ROLE_FULL = 3, ROLE_HALO_HI = 4 };
+// Handing row BY-2's y flux to the otherwise idle wave of row BY-1 pays in the
+// strict build (long division/sqrt sequences: VALU-throughput bound, measured
+// 6.25 -> 5.86 ms at 512^3) and costs in the fast build (latency bound: the
+// extra LDS round trip lengthens the short y-flux phase, 3.66 -> 3.75 ms).
+#ifdef RAMSES_AMD_FAST
+constexpr bool OFFLOAD_HI = false;
+#else
+constexpr bool OFFLOAD_HI = true;
+#endif
+
+// Raw buffer access: one scalar resource descriptor per variable (base of the
+// variable's brick), a wave-uniform byte offset of the plane (soffset) and one
+// 32-bit lane byte offset of the column, so that all address arithmetic of the
+// marching loop is scalar.  A lane offset beyond num_records makes the hardware
+// drop that lane's store: masked lanes and masked iterations need no branch,
+// every memory instruction of the loop is issued unconditionally, and the
+// compiler's vmcnt bookkeeping never has to wait for a store to be acknowledged
+// before it can use a prefetched load.
+typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
+constexpr unsigned BUF_RANGE = 0x7fffffffu;     // lane offsets below this are in range
+constexpr unsigned BUF_OOB = 0xffffffffu;       // dropped by the range check
+__device__ __forceinline__ double plane_load(const double *var_base, unsigned plane_bytes, unsigned off) {
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(var_base), 0, BUF_RANGE, 0x00020000);
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, plane_bytes, 0));
+}
+__device__ __forceinline__ void plane_store(double *var_base, unsigned plane_bytes, unsigned off, double x) {
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(var_base, 0, BUF_RANGE, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, x), r, off, plane_bytes, 0);
+}
 
 template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV, int ROLE>
 __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *smem_raw) {
@@ -121,35 +152,38 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     xi = min(max(xu, -A.ng), A.nx + A.ng - 1) + A.ng;
     yi = min(max(yu, -A.ng), A.ny + A.ng - 1) + A.ng;
   }
-  const long col = (long)xi + (long)yi * A.pitch_y;
+  // column offset inside a plane as a 32-bit lane value; plane/variable bases
+  // are wave-uniform (scalar base + 32-bit lane offset addressing)
+  // (byte offset < 2 GB per plane, checked by the launcher)
+  const unsigned colb = (unsigned)(xi + yi * (int)A.pitch_y) * 8u;
   const double *__restrict__ uold = A.uold;
   double *__restrict__ unew = A.unew;
   const double *__restrict__ grav = A.grav;
 
-  constexpr bool r_trace = ROLE != ROLE_HALO;
-  constexpr bool r_fy = ROLE == ROLE_HIGH || ROLE == ROLE_FULL;
+  constexpr bool r_trace = ROLE == ROLE_LOW || ROLE == ROLE_HIGH || ROLE == ROLE_FULL;
   constexpr bool r_fxz = ROLE == ROLE_FULL;
   const bool r_upd = r_fxz && (tx >= 2) && (tx <= BX - 3) && (xu < A.nx) && (yu < A.ny);
+  const unsigned colb_upd = r_upd ? colb : BUF_OOB;   // lanes that own no cell store nowhere
 
   const double dtdx = A.dt / A.dx;
   const double dtxhalf = A.dt * 0.5;
 
-  auto plane_off = [&](int p) -> long {
+  auto plane_off = [&](int p) -> unsigned {   // uniform byte offset of plane p inside a variable
     int pz;
     if (A.ng == 0) { pz = p < 0 ? p + A.nz : (p >= A.nz ? p - A.nz : p); }
     else { pz = p + A.ng; }
-    return col + (long)pz * A.pitch_z;
+    return (unsigned)pz * (unsigned)(A.pitch_z * 8);
   };
   auto load_u = [&](int p, double (&u)[NV]) {
-    const long o = plane_off(p);
+    const unsigned pb = plane_off(p);
 #pragma unroll
-    for (int n = 0; n < NV; n++) u[n] = uold[o + (long)n * A.pitch_var];
+    for (int n = 0; n < NV; n++) u[n] = plane_load(uold + (long)n * A.pitch_var, pb, colb);
   };
   auto load_g = [&](int p, double (&g)[3]) {
     if (GRAV) {
-      const long o = plane_off(p);
+      const unsigned pb = plane_off(p);
 #pragma unroll
-      for (int d = 0; d < 3; d++) g[d] = grav[o + (long)d * A.pitch_var];
+      for (int d = 0; d < 3; d++) g[d] = plane_load(grav + (long)d * A.pitch_var, pb, colb);
     } else {
       g[0] = g[1] = g[2] = 0.0;
     }
@@ -180,6 +214,10 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #pragma unroll
     for (int n = 0; n < NV; n++) { qmz[n] = 1.0; part[n] = 0.0; fzlo[n] = 0.0; }
   }
+  // Enter the loop with no load in flight: otherwise the loop header inherits
+  // "prefetch pending" from this path and waits (in issue order) behind the
+  // stores of the previous iteration on every trip.
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
   __syncthreads();
 
   const int txm = max(tx - 1, 0), txp = min(tx + 1, BX - 1);
@@ -194,7 +232,7 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     // prefetch plane c+2 (HBM) and re-read plane c's conserved state (L2) for
     // the update at the end of this iteration
     double ucur[NV];
-    if (c + 2 <= z1 + 1) { load_u(c + 2, upre); load_g(c + 2, gpre); }
+    { const int pn = min(c + 2, z1 + 1); load_u(pn, upre); load_g(pn, gpre); }   // (last iteration: a harmless re-read)
     if (r_fxz) load_u(c, ucur);
     // Slot sc was last read (as plane c-2) before barrier B2 of iteration c-1;
     // plane c's neighbours were written one iteration (two barriers) ago.
@@ -242,7 +280,11 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
         const double cc = ctoprim_sound(qb[0], qb[4], P);
         tracexyz_cell<NV>(qb, dq, cc, dtdx, dtdx, dtdx, P, qm, qp);
       }
-      if constexpr (ROLE != ROLE_HIGH) {
+      if constexpr (ROLE == ROLE_HIGH && OFFLOAD_HI) {
+        // nobody reads this row's +y state; its smy slot carries the -y state to row BY-1
+#pragma unroll
+        for (int n = 0; n < NV; n++) smy->v[n][ty][tx] = qp[1][n];
+      } else {
 #pragma unroll
         for (int n = 0; n < NV; n++) smy->v[n][ty][tx] = qm[1][n];
       }
@@ -253,17 +295,15 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #pragma unroll
         for (int n = 0; n < NV; n++) qL[n] = wave_shr1(qm[0][n]);  // +x state of column tx-1
         scaled_interface_flux<RS, NV, 0>(qL, qp[0], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fx);
-        if (c >= z0) {
-          // z flux through the face between planes c-1 and c
-          scaled_interface_flux<RS, NV, 2>(qmz, qp[2], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fz);
-        }
+        // z flux through the face between planes c-1 and c
+        scaled_interface_flux<RS, NV, 2>(qmz, qp[2], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fz);
 #pragma unroll
         for (int n = 0; n < NV; n++) qmz[n] = qm[2][n];
       }
     }
     __syncthreads();  // (B2) +y traced states visible
 
-    if constexpr (r_fy) {
+    if constexpr (ROLE == ROLE_FULL || (ROLE == ROLE_HIGH && !OFFLOAD_HI)) {
       double qL[NV];
 #pragma unroll
       for (int n = 0; n < NV; n++) qL[n] = smy->v[n][tym][tx];
@@ -271,29 +311,37 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #pragma unroll
       for (int n = 0; n < NV; n++) fyb->v[n][ty][tx] = fy[n];
     }
+    if constexpr (ROLE == ROLE_HALO_HI && OFFLOAD_HI) {
+      // y flux between rows BY-3 and BY-2, read by row BY-3's update
+      double qL[NV], qR[NV];
+#pragma unroll
+      for (int n = 0; n < NV; n++) { qL[n] = smy->v[n][BY - 3][tx]; qR[n] = smy->v[n][BY - 2][tx]; }
+      scaled_interface_flux<RS, NV, 1>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fy);
+#pragma unroll
+      for (int n = 0; n < NV; n++) fyb->v[n][BY - 2][tx] = fy[n];
+    }
     __syncthreads();  // (B3) y fluxes visible
 
     if constexpr (r_fxz) {
-      // finish plane c-1: its +z face flux is fz
-      if (c >= z0 + 1 && r_upd) {
-        const long o = plane_off(c - 1);
-        double un[NV];
+      // finish plane c-1: its +z face flux is fz.  (The first two iterations of
+      // a chunk produce values from the not yet primed pipeline; they are
+      // computed and dropped by the store's range check.)
+      double un[NV];
 #pragma unroll
-        for (int n = 0; n < NV; n++) un[n] = part[n] + (fzlo[n] - fz[n]);
-        if (NV > 5) {
-          // set_uold's passive-scalar fix near the density floor
-          // (hydro/godunov_fine.f90:176-190), fused: the kernel's output is the new uold
-          if (rold < P.smallr && un[0] > rold) {
+      for (int n = 0; n < NV; n++) un[n] = part[n] + (fzlo[n] - fz[n]);
+      if (NV > 5) {
+        // set_uold's passive-scalar fix near the density floor
+        // (hydro/godunov_fine.f90:176-190), fused: the kernel's output is the new uold
+        if (rold < P.smallr && un[0] > rold) {
 #pragma unroll
-            for (int n = 5; n < NV; n++) un[n] = sold[n - 5] * dmaxd(un[0], P.smallr) / P.smallr;
-          } else if (un[0] < P.smallr && rold > un[0]) {
+          for (int n = 5; n < NV; n++) un[n] = sold[n - 5] * dmaxd(un[0], P.smallr) / P.smallr;
+        } else if (un[0] < P.smallr && rold > un[0]) {
 #pragma unroll
-            for (int n = 5; n < NV; n++) un[n] = sold[n - 5] * P.smallr / dmaxd(rold, P.smallr);
-          }
+          for (int n = 5; n < NV; n++) un[n] = sold[n - 5] * P.smallr / dmaxd(rold, P.smallr);
         }
-#pragma unroll
-        for (int n = 0; n < NV; n++) unew[o + (long)n * A.pitch_var] = un[n];
       }
+      // x and y flux differences of plane c (consumes the re-read conserved
+      // state BEFORE the stores are issued: vmcnt counts in order)
 #pragma unroll
       for (int n = 0; n < NV; n++) {
         const double fxhi = wave_shl1(fx[n]);  // -x face flux of column tx+1
@@ -305,9 +353,13 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #pragma unroll
         for (int n = 5; n < NV; n++) sold[n - 5] = ucur[n];
       }
-      if (c >= z0) {
 #pragma unroll
-        for (int n = 0; n < NV; n++) fzlo[n] = fz[n];
+      for (int n = 0; n < NV; n++) fzlo[n] = fz[n];
+      {
+        const unsigned pb = plane_off(c - 1);
+        const unsigned so = (c >= z0 + 1) ? colb_upd : BUF_OOB;
+#pragma unroll
+        for (int n = 0; n < NV; n++) plane_store(unew + (long)n * A.pitch_var, pb, so, un[n]);
       }
     }
     // rotate the ring
@@ -319,7 +371,8 @@ template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV>
 __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ty = threadIdx.y;   // wave-uniform
-  if (ty == 0 || ty == BY - 1) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_HALO>(A, smem_raw);
+  if (ty == 0) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_HALO>(A, smem_raw);
+  else if (ty == BY - 1) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_HALO_HI>(A, smem_raw);
   else if (ty == 1) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_LOW>(A, smem_raw);
   else if (ty == BY - 2) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_HIGH>(A, smem_raw);
   else sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_FULL>(A, smem_raw);
@@ -395,7 +448,9 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
   if (nvar != 5) return hipErrorInvalidValue;
   if (scheme == 1) return launch2<ST, RS, 8, 1, 5>(A, grav, s);
   if (by == 8) return launch2<ST, RS, 8, 0, 5>(A, grav, s);
-  if (ST != 3 && by == 12) return launch2<ST, RS, 12, 0, 5>(A, grav, s);
+  if constexpr (ST != 3 && RS != RIEMANN_EXACT) {
+    if (by == 12) return launch2<ST, RS, 12, 0, 5>(A, grav, s);
+  }
   return hipErrorInvalidValue;
 }
 
@@ -413,6 +468,9 @@ static hipError_t launch0(SweepArgs &A, int rs, int by, int scheme, int nvar, bo
 
 hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme, int nvar,
                                 bool grav, hipStream_t s) {
+  // lanes address a plane with a 32-bit byte offset
+  if ((unsigned long)A.pitch_z * 8ul >= (1ul << 31) || (unsigned long)A.pitch_var * 8ul >= (1ul << 32))
+    return hipErrorInvalidValue;
   switch (slope_type) {
     case 0: return launch0<0>(A, riemann, by, scheme, nvar, grav, s);
     case 1: return launch0<1>(A, riemann, by, scheme, nvar, grav, s);
