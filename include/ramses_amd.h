@@ -282,6 +282,31 @@ int ramses_amd_multigrid_fine_f90(int ilevel, int ngrid, const int *igrid, const
                                   double fourpi, double epsilon, int *safe_mode,
                                   int *iters, double *err);
 
+/* ---------------------------------------------------------------------------
+ * Device-resident level.  For a fully refined periodic
+ * level of a single-rank hydro-only run the state stays on the GPU across
+ *   newdt_fine/courant_fine   hydro/courant_fine.f90:1-159
+ *   set_unew                  hydro/godunov_fine.f90:40-130   (fused: no-op)
+ *   godunov_fine              hydro/godunov_fine.f90:5-35
+ *   set_uold                  hydro/godunov_fine.f90:135-232  (buffer swap)
+ * and is written back to the reference's host array only on demand
+ * (backup_hydro, hydro/output_hydro.f90:63-163, calls sync_host first).
+ * The first call loads the level from the host array `uold`; later calls
+ * with the same (level, ngrid, array) reuse the device copy.
+ * ------------------------------------------------------------------------- */
+/* out4 = {dt_loc (min with dt_in), mass_loc, sum(E*vol), eint_loc} */
+int ramses_amd_resident_courant_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                    const int *igrid, const double *xg, int64_t ngridmax,
+                                    int64_t ncoarse, int nx_loc, const double *uold, double dx,
+                                    double dt_in, double *out4);
+int ramses_amd_resident_godunov_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                    const int *igrid, const double *xg, int64_t ngridmax,
+                                    int64_t ncoarse, int nx_loc, const double *uold, double dx,
+                                    double dt);
+int ramses_amd_resident_set_uold_f90(int ilevel);
+int ramses_amd_resident_sync_host_f90(double *uold);
+int ramses_amd_resident_invalidate(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,11 @@ SYMBOLS = [
     ("ramses_amd_multigrid_fine_f90", _i, [_i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _d, _d, _d,
                                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     ("ramses_amd_godunov_fine_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _i, _d, _d]),
+    ("ramses_amd_resident_courant_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _d, _vp]),
+    ("ramses_amd_resident_godunov_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _d]),
+    ("ramses_amd_resident_set_uold_f90", _i, [_i]),
+    ("ramses_amd_resident_sync_host_f90", _i, [_vp]),
+    ("ramses_amd_resident_invalidate", _i, []),
 ]
 
 

@@ -177,7 +177,7 @@ int ramses_amd_courant_brick(const ramses_amd_hydro_params *p, const ramses_amd_
                              double *d_out, void *stream) {
   if (!p || !d_uold || !d_out) return fail(RAMSES_AMD_EINVAL, "NULL argument");
   if (int rc = check_brick(b)) return rc;
-  if (p->ndim != 3 || p->nvar != 5) return fail(RAMSES_AMD_EUNSUPPORTED, "device courant implements NDIM=3, NVAR=5");
+  if (p->ndim != 3 || p->nvar < 5) return fail(RAMSES_AMD_EUNSUPPORTED, "device courant implements NDIM=3, NVAR>=5 (passive scalars do not enter cmpdt)");
   CourantArgs A;
   A.uold = d_uold; A.grav = d_grav; A.out = d_out;
   A.nx = b->nx; A.ny = b->ny; A.nz = b->nz; A.ng = b->ng;
@@ -472,7 +472,13 @@ struct DevBuf {
   template <class T> T *as() { return reinterpret_cast<T *>(p); }
 };
 struct HostCtx {
-  DevBuf uold, unew, fvec, igrid, xg, octorg, bold, bnew, bf, flag;
+  DevBuf uold, unew, fvec, igrid, xg, octorg, bold, bnew, bf, flag, red;
+  // device-resident level (ramses_amd_resident_*): the level brick in bold is
+  // the current hydro state; the host array is stale until synced
+  bool res_valid = false, res_host_stale = false, res_new_ready = false;
+  int res_level = 0, res_ngrid = 0, res_nvar = 0;
+  long res_ncell = 0, res_ncoarse = 0, res_ngridmax = 0;
+  const double *res_host_uold = nullptr;
 };
 HostCtx g_host;
 }  // namespace
@@ -613,6 +619,142 @@ int ramses_amd_multigrid_fine_f90(int ilevel, int ngrid, const int *igrid, const
 #undef HCHK
   return 0;
 }
+
+// ---------------------------------------------------------------------------
+// Device-resident level: courant_fine, set_unew,
+// godunov_fine and set_uold of a fully refined periodic level without the
+// state crossing PCIe every step.  The Fortran shims call these instead of the
+// staging entry points when the run configuration guarantees that no host
+// routine touches uold between two hydro steps (ramses_amd_iface.f90:
+// ramses_amd_resident()); the host array is refreshed on demand
+// (ramses_amd_resident_sync_host_f90, called by the backup_hydro shim).
+// ---------------------------------------------------------------------------
+#define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipfail(e_, what); } while (0)
+static int resident_ensure(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid,
+                           const double *xg, int64_t ngridmax, int64_t ncoarse, int nx_loc,
+                           const double *uold) {
+  if (!p || !igrid || !xg || !uold) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (p->ndim != 3 || p->nvar < 5 || p->nvar > 7) return fail(RAMSES_AMD_EUNSUPPORTED, "device path implements NDIM=3, NVAR=5..7");
+  if (nx_loc != 1) return fail(RAMSES_AMD_EUNSUPPORTED, "device path needs a periodic box with nx=ny=nz=1 (got nx_loc=%d)", nx_loc);
+  if (ilevel < 1 || ilevel > 11) return fail(RAMSES_AMD_EINVAL, "level out of range");
+  const int n = 1 << ilevel;
+  const long N = (long)n * n * n;
+  if ((long)ngrid * 8 != N)
+    return fail(RAMSES_AMD_EUNSUPPORTED, "level %d is not fully refined on this rank (ngrid=%d, need %ld)", ilevel, ngrid, N / 8);
+  HostCtx &H = g_host;
+  const long ncell = ncoarse + 8 * ngridmax;
+  const int nvar = p->nvar;
+  if (H.res_valid && H.res_level == ilevel && H.res_ngrid == ngrid && H.res_nvar == nvar && H.res_ncell == ncell &&
+      H.res_host_uold == uold)
+    return 0;
+  hipStream_t s = nullptr;
+  HCHK(H.uold.ensure(sizeof(double) * nvar * ncell), "hipMalloc uold");
+  HCHK(H.igrid.ensure(sizeof(int) * ngrid), "hipMalloc igrid");
+  HCHK(H.xg.ensure(sizeof(double) * 3 * ngridmax), "hipMalloc xg");
+  HCHK(H.octorg.ensure(sizeof(long) * ngrid), "hipMalloc octorg");
+  HCHK(H.bold.ensure(sizeof(double) * nvar * N), "hipMalloc brick");
+  HCHK(H.bnew.ensure(sizeof(double) * nvar * N), "hipMalloc brick");
+  HCHK(H.flag.ensure(sizeof(int)), "hipMalloc flag");
+  HCHK(H.red.ensure(sizeof(double) * 4), "hipMalloc reduction");
+  HCHK(hipMemcpyAsync(H.uold.p, uold, sizeof(double) * nvar * ncell, hipMemcpyHostToDevice, s), "H2D uold");
+  HCHK(hipMemcpyAsync(H.igrid.p, igrid, sizeof(int) * ngrid, hipMemcpyHostToDevice, s), "H2D igrid");
+  HCHK(hipMemcpyAsync(H.xg.p, xg, sizeof(double) * 3 * ngridmax, hipMemcpyHostToDevice, s), "H2D xg");
+  HCHK(hipMemsetAsync(H.flag.p, 0, sizeof(int), s), "memset");
+  const double skip[3] = {0.0, 0.0, 0.0};
+  HCHK(launch_oct_origin(H.igrid.as<int>(), H.xg.as<double>(), ngridmax, ngrid, n, skip, H.octorg.as<long>(), H.flag.as<int>(), s), "oct origin launch");
+  int bad = 0;
+  HCHK(hipMemcpyAsync(&bad, H.flag.p, sizeof(int), hipMemcpyDeviceToHost, s), "D2H flag");
+  HCHK(hipStreamSynchronize(s), "sync");
+  if (bad) return fail(RAMSES_AMD_EINVAL, "%d octs of level %d do not sit on the level lattice (xg inconsistent)", bad, ilevel);
+  PackArgs A;
+  A.igrid = H.igrid.as<int>(); A.octorg = H.octorg.as<long>();
+  A.ngrid = ngrid; A.n = n; A.nvar = nvar;
+  A.ncoarse = ncoarse; A.ngridmax = ngridmax; A.ncell = ncell; A.pitch_var = N;
+  A.brick = H.bold.as<double>(); A.cellvec = H.uold.as<double>();
+  HCHK(launch_oct_copy(A, true, s), "gather launch");
+  H.res_valid = true; H.res_host_stale = false; H.res_new_ready = false;
+  H.res_level = ilevel; H.res_ngrid = ngrid; H.res_nvar = nvar; H.res_ncell = ncell;
+  H.res_ncoarse = ncoarse; H.res_ngridmax = ngridmax; H.res_host_uold = uold;
+  return 0;
+}
+
+// courant_fine (hydro/courant_fine.f90:1-159) on the resident level:
+// out4 = {dt_loc, mass_loc, sum(E*vol) ("ekin_loc"), eint_loc}.  dt is
+// bit-identical (min is order independent); the three sums are accumulated in
+// a different order than the reference's serial loop (diagnostics only).
+int ramses_amd_resident_courant_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                    const int *igrid, const double *xg, int64_t ngridmax,
+                                    int64_t ncoarse, int nx_loc, const double *uold, double dx,
+                                    double dt_in, double *out4) {
+  if (!out4) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (int rc = resident_ensure(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, uold)) return rc;
+  HostCtx &H = g_host;
+  const int n = 1 << ilevel;
+  hipStream_t s = nullptr;
+  ramses_amd_brick b;
+  ramses_amd_brick_dense(&b, n, n, n, 0);
+  if (int rc = ramses_amd_courant_init(p, dx, H.red.as<double>(), s)) return rc;
+  if (int rc = ramses_amd_courant_brick(p, &b, H.bold.as<double>(), nullptr, dx, H.red.as<double>(), s)) return rc;
+  HCHK(hipMemcpyAsync(out4, H.red.p, sizeof(double) * 4, hipMemcpyDeviceToHost, s), "D2H courant");
+  HCHK(hipStreamSynchronize(s), "sync");
+  if (dt_in < out4[0]) out4[0] = dt_in;   // dt_loc starts from dtnew(ilevel)
+  return 0;
+}
+
+// set_unew + godunov_fine on the resident level: bold -> bnew (= uold + flux differences)
+int ramses_amd_resident_godunov_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                    const int *igrid, const double *xg, int64_t ngridmax,
+                                    int64_t ncoarse, int nx_loc, const double *uold, double dx, double dt) {
+  if (int rc = resident_ensure(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, uold)) return rc;
+  HostCtx &H = g_host;
+  const int n = 1 << ilevel;
+  ramses_amd_brick b;
+  ramses_amd_brick_dense(&b, n, n, n, 0);
+  if (int rc = ramses_amd_godunov_brick(p, &b, H.bold.as<double>(), nullptr, H.bnew.as<double>(), dx, dt, nullptr)) return rc;
+  H.res_new_ready = true;
+  return 0;
+}
+
+// set_uold on the resident level: the new state becomes the current one
+int ramses_amd_resident_set_uold_f90(int ilevel) {
+  HostCtx &H = g_host;
+  if (!H.res_valid || H.res_level != ilevel) return fail(RAMSES_AMD_EINVAL, "set_uold: level %d is not resident", ilevel);
+  if (!H.res_new_ready) return fail(RAMSES_AMD_EINVAL, "set_uold: no godunov_fine result pending on level %d", ilevel);
+  DevBuf t = H.bold; H.bold = H.bnew; H.bnew = t;
+  H.res_new_ready = false;
+  H.res_host_stale = true;
+  return 0;
+}
+
+// refresh the host array from the resident level (no-op when it is current)
+int ramses_amd_resident_sync_host_f90(double *uold) {
+  HostCtx &H = g_host;
+  if (!H.res_valid || !H.res_host_stale) return 0;
+  if (uold != H.res_host_uold) return fail(RAMSES_AMD_EINVAL, "sync_host: not the array the level was loaded from");
+  const int n = 1 << H.res_level;
+  const long N = (long)n * n * n;
+  hipStream_t s = nullptr;
+  PackArgs A;
+  A.igrid = H.igrid.as<int>(); A.octorg = H.octorg.as<long>();
+  A.ngrid = H.res_ngrid; A.n = n; A.nvar = H.res_nvar;
+  A.ncoarse = H.res_ncoarse; A.ngridmax = H.res_ngridmax; A.ncell = H.res_ncell; A.pitch_var = N;
+  A.brick = H.bold.as<double>(); A.cellvec = H.uold.as<double>();
+  HCHK(launch_oct_copy(A, false, s), "scatter launch");
+  // cells of other levels come back with the values they were loaded with
+  HCHK(hipMemcpyAsync(uold, H.uold.p, sizeof(double) * H.res_nvar * H.res_ncell, hipMemcpyDeviceToHost, s), "D2H uold");
+  HCHK(hipStreamSynchronize(s), "sync");
+  H.res_host_stale = false;
+  return 0;
+}
+
+// forget the resident level (the host array was modified behind our back)
+int ramses_amd_resident_invalidate(void) {
+  HostCtx &H = g_host;
+  if (H.res_valid && H.res_host_stale) return fail(RAMSES_AMD_EINVAL, "invalidate: the host array is stale; sync first");
+  H.res_valid = false;
+  return 0;
+}
+#undef HCHK
 
 // ---------------------------------------------------------------------------
 // coarse <-> fine hydro operators on a periodic coarse brick and its fully

@@ -1,0 +1,50 @@
+!==============================================================================
+! courant_fine.f90 of the ramses_amd patch directory.
+!
+! Shadows hydro/courant_fine.f90.  The untouched reference routine is pulled
+! in under the name courant_fine_reference; the new courant_fine(ilevel) keeps
+! the reference's name, argument and meaning.  When the level is
+! device-resident the CFL reduction (cmpdt, hydro/godunov_utils.f90:5-120) and
+! the mass/energy sums run on the MI355X over the resident brick; otherwise
+! the reference routine runs on the host arrays.
+!==============================================================================
+#define courant_fine courant_fine_reference
+#include "hydro/courant_fine.f90"
+#undef courant_fine
+
+subroutine courant_fine(ilevel)
+  use amr_commons
+  use hydro_commons
+  use ramses_amd_iface
+  implicit none
+  integer::ilevel
+  type(ramses_amd_hydro_params)::p
+  integer::rc,nx_loc
+  real(dp)::scale,dx
+  real(kind=8),dimension(4)::out4
+
+  if(numbtot(1,ilevel)==0)return
+  if(.not.ramses_amd_resident())then
+     call courant_fine_reference(ilevel)
+     return
+  end if
+  if(verbose)write(*,111)ilevel
+
+  call ramses_amd_fill_hydro_params(p)
+  nx_loc=icoarse_max-icoarse_min+1
+  scale=boxlen/dble(nx_loc)
+  dx=0.5D0**ilevel*scale
+
+  rc=ramses_amd_resident_courant_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+       & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,dx,dtnew(ilevel),out4)
+  if(rc/=0)call ramses_amd_fatal('courant_fine')
+
+  ! same bookkeeping as hydro/courant_fine.f90:150-156 (single rank)
+  mass_tot=mass_tot+out4(2)
+  ekin_tot=ekin_tot+out4(3)
+  eint_tot=eint_tot+out4(4)
+  dtnew(ilevel)=MIN(dtnew(ilevel),out4(1))
+
+111 format('   Entering courant_fine (MI355X) for level ',I2)
+
+end subroutine courant_fine

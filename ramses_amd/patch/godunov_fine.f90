@@ -5,15 +5,50 @@
 ! every external symbol of hydro/godunov_fine.f90: godunov_fine, set_unew,
 ! set_uold, add_gravity_source_terms, add_pdv_source_terms, godfine1.  The
 ! untouched reference file is pulled in by the preprocessor with its
-! godunov_fine renamed to godunov_fine_reference (no reference source is
-! copied); the new godunov_fine below keeps the reference's name, argument and
+! godunov_fine, set_unew and set_uold renamed to *_reference (no reference
+! source is copied); the new godunov_fine below keeps the reference's name, argument and
 ! meaning and hands the level to the MI355X sweep through the C ABI.
 !
 ! Needs -I<ramses root> on the compile line (the patch Makefile adds -I..).
 !==============================================================================
 #define godunov_fine godunov_fine_reference
+#define set_unew set_unew_reference
+#define set_uold set_uold_reference
 #include "hydro/godunov_fine.f90"
 #undef godunov_fine
+#undef set_unew
+#undef set_uold
+
+!------------------------------------------------------------------------------
+! set_unew / set_uold (hydro/godunov_fine.f90:40-130,135-232).  When the level
+! is device-resident (ramses_amd_iface: ramses_amd_resident) the sweep kernel
+! writes uold + flux differences into a second brick, so set_unew has nothing
+! to do and set_uold is a buffer swap; otherwise the reference routines run.
+!------------------------------------------------------------------------------
+subroutine set_unew(ilevel)
+  use amr_commons
+  use ramses_amd_iface
+  implicit none
+  integer::ilevel
+  if(numbtot(1,ilevel)==0)return
+  if(ramses_amd_resident())return
+  call set_unew_reference(ilevel)
+end subroutine set_unew
+
+subroutine set_uold(ilevel)
+  use amr_commons
+  use ramses_amd_iface
+  implicit none
+  integer::ilevel
+  integer::rc
+  if(numbtot(1,ilevel)==0)return
+  if(ramses_amd_resident())then
+     rc=ramses_amd_resident_set_uold_f90(ilevel)
+     if(rc/=0)call ramses_amd_fatal('set_uold')
+     return
+  end if
+  call set_uold_reference(ilevel)
+end subroutine set_uold
 
 subroutine godunov_fine(ilevel)
   use amr_commons
@@ -56,7 +91,11 @@ subroutine godunov_fine(ilevel)
   scale=boxlen/dble(nx_loc)
   dx=0.5d0**ilevel*scale
 
-  if(poisson)then
+  if(ramses_amd_resident())then
+     ! state already on the device (loaded by courant_fine or here); unew stays there
+     rc=ramses_amd_resident_godunov_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+          & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,dx,dtnew(ilevel))
+  else if(poisson)then
      has_f=1
      rc=ramses_amd_godunov_fine_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
           & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,unew,f,has_f,dx,dtnew(ilevel))

@@ -69,10 +69,51 @@ module ramses_amd_iface
        real(c_double) :: err
        integer(c_int) :: rc
      end function ramses_amd_multigrid_fine_f90
+
+     ! ---- device-resident level (include/ramses_amd.h) ----
+     function ramses_amd_resident_courant_f90(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, &
+          & uold, dx, dt_in, out4) bind(C, name='ramses_amd_resident_courant_f90') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_int64_t, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ilevel, ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: xg(*)
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       integer(c_int), value :: nx_loc
+       real(c_double) :: uold(*)
+       real(c_double), value :: dx, dt_in
+       real(c_double) :: out4(4)
+       integer(c_int) :: rc
+     end function ramses_amd_resident_courant_f90
+     function ramses_amd_resident_godunov_f90(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, &
+          & uold, dx, dt) bind(C, name='ramses_amd_resident_godunov_f90') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_int64_t, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ilevel, ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: xg(*)
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       integer(c_int), value :: nx_loc
+       real(c_double) :: uold(*)
+       real(c_double), value :: dx, dt
+       integer(c_int) :: rc
+     end function ramses_amd_resident_godunov_f90
+     function ramses_amd_resident_set_uold_f90(ilevel) bind(C, name='ramses_amd_resident_set_uold_f90') result(rc)
+       import :: c_int
+       integer(c_int), value :: ilevel
+       integer(c_int) :: rc
+     end function ramses_amd_resident_set_uold_f90
+     function ramses_amd_resident_sync_host_f90(uold) bind(C, name='ramses_amd_resident_sync_host_f90') result(rc)
+       import :: c_int, c_double
+       real(c_double) :: uold(*)
+       integer(c_int) :: rc
+     end function ramses_amd_resident_sync_host_f90
   end interface
 
   logical, save :: ramses_amd_checked = .false.
   logical, save :: ramses_amd_on = .true.
+  logical, save :: ramses_amd_res_checked = .false.
+  logical, save :: ramses_amd_res_on = .false.
 
 contains
 
@@ -96,6 +137,40 @@ contains
     end if
     ramses_amd_enabled = ramses_amd_on
   end function ramses_amd_enabled
+
+  !---------------------------------------------------------------------------
+  ! Device residency of the hydro state across courant_fine / set_unew /
+  ! godunov_fine / set_uold (SURVEY.md 8f rank 1).  Only taken when no host
+  ! routine reads or writes uold between two hydro steps: a hydro-only,
+  ! single-rank, periodic run on one fully refined level.  backup_hydro (the
+  ! only remaining host reader) syncs the host array first.  Anything else
+  ! uses the staging path (state copied in and out around each sweep).
+  ! RAMSES_AMD_RESIDENT=0 forces the staging path.
+  !---------------------------------------------------------------------------
+  logical function ramses_amd_resident()
+    use amr_commons
+    use hydro_parameters
+    character(len=16) :: val
+    integer :: stat
+    if (.not. ramses_amd_res_checked) then
+       ramses_amd_res_on = ramses_amd_enabled()
+       call get_environment_variable('RAMSES_AMD_RESIDENT', val, status=stat)
+       if (stat == 0) then
+          if (trim(val) == '0') ramses_amd_res_on = .false.
+       end if
+       if (ncpu > 1 .or. levelmin /= nlevelmax .or. nboundary > 0) ramses_amd_res_on = .false.
+       if (.not. hydro .or. poisson .or. pic .or. rt .or. cooling .or. star .or. sink .or. stellar) ramses_amd_res_on = .false.
+       if (tracer .or. MC_tracer .or. clumpfind .or. lightcone .or. movie .or. aton) ramses_amd_res_on = .false.
+       if (static .or. static_gas .or. neq_chem .or. barotropic_eos .or. isothermal .or. metal) ramses_amd_res_on = .false.
+       if (pressure_fix .or. T2_star > 0.0d0 .or. momentum_feedback > 0 .or. strict_equilibrium > 0) &
+            & ramses_amd_res_on = .false.
+       if (ndim /= 3) ramses_amd_res_on = .false.
+       ramses_amd_res_checked = .true.
+       if (ramses_amd_res_on .and. myid == 1) &
+            & write(*,*) 'ramses_amd: hydro state of level ', levelmin, ' stays resident on the GPU'
+    end if
+    ramses_amd_resident = ramses_amd_res_on
+  end function ramses_amd_resident
 
   !---------------------------------------------------------------------------
   ! The reference has no error returns on this path: print and clean_stop

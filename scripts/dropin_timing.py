@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Wall time of the reference program with and without the ramses_amd patch
+on the GPU box (oracle/_ref binaries; nothing under /root/reference is read).
+
+    python scripts/dropin_timing.py [level] [nstepmax]
+
+Prints one JSON line per configuration: the program's own timer rows
+(amr/update_time.f90:77-178) and the total elapsed time."""
+import json
+import os
+import re
+import shutil
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ramses_snapshot as rs  # noqa: E402
+
+
+def run(tag, binary, level, nstep, env):
+    nml = rs.sedov3d_namelist(level=level, nstepmax=nstep, foutput=1000)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    t0 = time.time()
+    try:
+        work, out = rs.run_reference(nml, binary=binary, timeout=3000)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    wall = time.time() - t0
+    shutil.rmtree(work, ignore_errors=True)
+    rows = {}
+    # serial timer table (amr/update_time.f90): "  seconds   %   STEP"
+    for line in out.splitlines():
+        m = re.match(r"^\s*([0-9.]+)\s+([0-9.]+)\s+([a-zA-Z].*?)\s*$", line)
+        if m and "STEP" not in m.group(3):
+            rows[m.group(3)] = float(m.group(1))
+    tot = None
+    print(json.dumps({"config": tag, "level": level, "steps": nstep, "wall_s": round(wall, 3),
+                      "timers_s": rows}), flush=True)
+
+
+if __name__ == "__main__":
+    level = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+    nstep = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    which = sys.argv[3] if len(sys.argv) > 3 else "all"
+    ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d")
+    pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch")
+    if which in ("all", "gpu"):
+        run("patched, device-resident", pat, level, nstep, {"RAMSES_AMD": "1", "RAMSES_AMD_RESIDENT": "1"})
+        run("patched, staged per sweep", pat, level, nstep, {"RAMSES_AMD": "1", "RAMSES_AMD_RESIDENT": "0"})
+    if which in ("all", "ref"):
+        run("reference (1 core)", ref, level, nstep, {"RAMSES_AMD": "0"})

@@ -78,23 +78,80 @@ def test_host_entry_on_synthetic_octree(gpu_lib, oracle):
     assert rc == -2
 
 
+def test_resident_level_entry_points(gpu_lib, oracle):
+    """courant_fine -> godunov_fine -> set_uold on the device-resident level,
+    then sync to the host array: two steps against the oracle, bit for bit."""
+    import ramses_amd
+    rng = np.random.default_rng(5)
+    level, n = 4, 16
+    u = random_brick(n, n, n, seed=21)
+    dx = 1.0 / n
+    ngridmax = 700
+    uold, igrid, xg, (ox, oy, oz) = _octree_layout(u, level, rng, ngridmax)
+    before = uold.copy()
+    p = ramses_amd.make_params(courant_factor=0.8)
+    po = oracle.make_params()
+    args = (C.byref(p), level, len(igrid), igrid.ctypes.data_as(C.c_void_p), xg.ctypes.data_as(C.c_void_p),
+            ngridmax, 1, 1, uold.ctypes.data_as(C.c_void_p))
+    out4 = np.zeros(4)
+    uo = u.copy()
+    assert gpu_lib.ramses_amd_resident_invalidate() == 0
+    for step in range(2):
+        rc = gpu_lib.ramses_amd_resident_courant_f90(*args, dx, 1e30, out4.ctypes.data_as(C.c_void_p))
+        assert rc == 0, gpu_lib.ramses_amd_last_error()
+        dto = oracle.courant_uniform(po, uo, dx, 0.8)
+        assert out4[0] == dto
+        vol = dx ** 3
+        assert abs(out4[1] - uo[0].sum() * vol) <= 1e-13 * abs(out4[1])
+        assert abs(out4[2] - uo[4].sum() * vol) <= 1e-13 * abs(out4[2])
+        eint = (uo[4] - 0.5 * (uo[1] ** 2 + uo[2] ** 2 + uo[3] ** 2) / np.maximum(uo[0], 1e-10)).sum() * vol
+        assert abs(out4[3] - eint) <= 1e-12 * abs(eint)
+        # set_uold before godunov_fine is an error, not a silent swap
+        if step == 0:
+            assert gpu_lib.ramses_amd_resident_set_uold_f90(level) == -1
+        rc = gpu_lib.ramses_amd_resident_godunov_f90(*args, dx, dto)
+        assert rc == 0, gpu_lib.ramses_amd_last_error()
+        assert gpu_lib.ramses_amd_resident_set_uold_f90(level) == 0
+        uo = oracle.godunov_uniform(po, uo, dx, dto)
+        # the host array is untouched until it is synced
+        assert np.array_equal(uold, before)
+    # forgetting a level whose host copy is stale is refused
+    assert gpu_lib.ramses_amd_resident_invalidate() == -1
+    assert gpu_lib.ramses_amd_resident_sync_host_f90(uold.ctypes.data_as(C.c_void_p)) == 0
+    touched = np.zeros(uold.shape[1], bool)
+    for ind in range(8):
+        ix, iy, iz = ind & 1, (ind >> 1) & 1, (ind >> 2) & 1
+        icell = 1 + ind * ngridmax + (igrid - 1)
+        touched[icell] = True
+        assert np.array_equal(uold[:, icell], uo[:, 2 * oz + iz, 2 * oy + iy, 2 * ox + ix])
+    assert np.array_equal(uold[:, ~touched], before[:, ~touched])
+    assert gpu_lib.ramses_amd_resident_invalidate() == 0
+
+
+@pytest.mark.parametrize("resident", [1, 0])
 @pytest.mark.parametrize("riemann,slope", [("llf", 1), ("hllc", 2), ("hll", 7), ("acoustic", 8)])
-def test_patched_reference_program_reproduces_goldens(gpu_lib, riemann, slope):
+def test_patched_reference_program_reproduces_goldens(gpu_lib, riemann, slope, resident):
+    """resident=1: the state stays on the GPU across courant_fine / set_unew /
+    godunov_fine / set_uold and reaches the host only for the snapshots;
+    resident=0: staged in and out around every sweep.  Same snapshots."""
     if not os.path.exists(PATCHED):
         pytest.skip("oracle/_ref/ramses3d_patch not built (needs the reference tree at build time)")
     from oracle import ramses_snapshot as rs
     z = np.load(GOLD)
     key = "%s_s%d_muscl" % (riemann, slope)
     nml = rs.sedov3d_namelist(level=4, nstepmax=4, foutput=1, riemann=riemann, slope_type=slope)
-    env_before = os.environ.get("RAMSES_AMD")
+    env_before = {k: os.environ.get(k) for k in ("RAMSES_AMD", "RAMSES_AMD_RESIDENT")}
     os.environ["RAMSES_AMD"] = "1"
+    os.environ["RAMSES_AMD_RESIDENT"] = str(resident)
     try:
         work, out = rs.run_reference(nml, binary=PATCHED)
     finally:
-        if env_before is None:
-            os.environ.pop("RAMSES_AMD", None)
-        else:
-            os.environ["RAMSES_AMD"] = env_before
+        for k, v in env_before.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert ("stays resident on the GPU" in out) == bool(resident)
     try:
         for k in range(1, 5):
             snap = rs.load_uniform_level(os.path.join(work, "output_%05d" % k), 4)
