@@ -283,6 +283,33 @@ int ramses_amd_multigrid_fine_f90(int ilevel, int ngrid, const int *igrid, const
                                   int *iters, double *err);
 
 /* ---------------------------------------------------------------------------
+ * Distributed multigrid: one rank's n^3 brick of a periodic level with ng
+ * ghost layers (pitch n+2ng), ghosts filled by the halo exchange
+ * (make_virtual_mg_dp, poisson/multigrid_fine_commons.f90:1172-1270, replaced
+ * by ramses_amd_halo_pack/unpack + RCCL).  The fused smoother recomputes the
+ * neighbours' updates inside its ghost layers, so ONE ng-wide exchange replaces
+ * the exchange after every colour pass (multigrid_fine_commons.f90:197-202).
+ * Same arithmetic and operation order as the dense entry points.
+ * ------------------------------------------------------------------------- */
+int ramses_amd_mg_smooth_fused_ghost(const double *d_phi_in, double *d_phi_out, const double *d_rhs,
+                                     double *d_res, double *d_work, double *d_norm2, int n, int ng,
+                                     double dx, int npass, void *stream);
+/* make_fine_bc_rhs (multigrid_fine_commons.f90:1058-1159), unmasked: f2 = fourpi*(rho-rho_tot) */
+int ramses_amd_mg_rhs(const double *d_rho, double *d_f2, int64_t N, double fourpi, double rho_tot, void *stream);
+/* restrict_residual_fine_reverse (multigrid_fine_fine.f90:528-590) on local bricks */
+int ramses_amd_mg_restrict_ghost(const double *d_res_f, double *d_rhs_c, int nf, int ngf, int ngc, void *stream);
+/* interpolate_and_correct_fine (:596-698): coarse correction = local brick with >= 1 valid
+ * ghost layer (cglob = 0) or a replicated dense periodic cglob^3 level whose cell
+ * coarse_origin[] is this rank's first coarse cell */
+int ramses_amd_mg_interp_correct_ghost(double *d_phi_f, int nf, int ngf, const double *d_corr_c, int ngc,
+                                       int cglob, const int *coarse_origin, void *stream);
+/* gradient_phi (poisson/force_fine.f90:199-324) on a local brick, d_f dense [3][n][n][n] */
+int ramses_amd_gradient_phi_ghost(const double *d_phi, double *d_f, int n, int ng, double dx, void *stream);
+/* recursive_multigrid_coarse (multigrid_fine_commons.f90:307-390) on a dense periodic level */
+int ramses_amd_mg_coarse_solve_dense(int level, const double *d_rhs, double *d_u1, double *d_work, int safe,
+                                     void *stream);
+
+/* ---------------------------------------------------------------------------
  * Device-resident level.  For a fully refined periodic
  * level of a single-rank hydro-only run the state stays on the GPU across
  *   newdt_fine/courant_fine   hydro/courant_fine.f90:1-159

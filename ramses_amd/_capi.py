@@ -75,6 +75,12 @@ SYMBOLS = [
     ("ramses_amd_multigrid_fine_f90", _i, [_i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _d, _d, _d,
                                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     ("ramses_amd_godunov_fine_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _i, _d, _d]),
+    ("ramses_amd_mg_smooth_fused_ghost", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _i, _vp]),
+    ("ramses_amd_mg_rhs", _i, [_vp, _vp, _i64, _d, _d, _vp]),
+    ("ramses_amd_mg_restrict_ghost", _i, [_vp, _vp, _i, _i, _i, _vp]),
+    ("ramses_amd_mg_interp_correct_ghost", _i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    ("ramses_amd_gradient_phi_ghost", _i, [_vp, _vp, _i, _i, _d, _vp]),
+    ("ramses_amd_mg_coarse_solve_dense", _i, [_i, _vp, _vp, _vp, _i, _vp]),
     ("ramses_amd_resident_courant_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _d, _vp]),
     ("ramses_amd_resident_godunov_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _d]),
     ("ramses_amd_resident_set_uold_f90", _i, [_i]),

@@ -15,7 +15,12 @@ hipError_t mg_launch_restrict(const double *res_f, double *rhs_c, double *u1_c, 
 hipError_t mg_launch_interp(double *phi_f, const double *corr_c, int nf, hipStream_t s);
 hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const double *rhs, double *res,
                                   double *partial, double *norm_out, int n, double dx, int npass,
-                                  hipStream_t s);
+                                  hipStream_t s, int ng = 0);
+// one rank's brick of a distributed level (ng ghost layers)
+hipError_t mg_launch_restrict_ghost(const double *res_f, double *rhs_c, int nf, int ngf, int ngc, hipStream_t s);
+hipError_t mg_launch_interp_ghost(double *phi_f, int nf, int ngf, const double *corr_c, int ngc, int cglob,
+                                  int cox, int coy, int coz, hipStream_t s);
+hipError_t mg_launch_gradient_ghost(const double *phi, double *f, int n, int ng, double a, double b, hipStream_t s);
 hipError_t mg_launch_gradient(const double *phi, double *f, int n, double a, double b, hipStream_t s);
 
 }  // namespace ramses_amd

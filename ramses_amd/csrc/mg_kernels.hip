@@ -186,6 +186,92 @@ __global__ __launch_bounds__(256) void mg_gradient_kernel(const double *__restri
 }
 
 // ---------------------------------------------------------------------------
+// Distributed levels: one rank's n^3 brick of a periodic level with ng ghost
+// layers (pitch n+2ng; ghosts filled by the halo exchange).  Same arithmetic
+// and operation order as the dense kernels above.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ long gidx(int i, int j, int k, int ng, int pitch) {
+  return (long)(i + ng) + (long)pitch * ((j + ng) + (long)pitch * (k + ng));
+}
+
+// restriction of the residual of the local fine brick into the local coarse brick
+__global__ __launch_bounds__(256) void mg_restrict_ghost_kernel(const double *__restrict__ res_f,
+                                                                 double *__restrict__ rhs_c, int nf, int ngf,
+                                                                 int ngc) {
+  const int nc = nf >> 1;
+  const long Nc = (long)nc * nc * nc;
+  const int pf = nf + 2 * ngf, pc = nc + 2 * ngc;
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < Nc; c += (long)gridDim.x * blockDim.x) {
+    const int I = (int)(c % nc);
+    const int J = (int)((c / nc) % nc);
+    const int K = (int)(c / ((long)nc * nc));
+    double acc = 0.0;
+#pragma unroll
+    for (int ind = 0; ind < 8; ind++) {
+      const int ix = ind & 1, iy = (ind >> 1) & 1, iz = (ind >> 2) & 1;
+      acc = acc + res_f[gidx(2 * I + ix, 2 * J + iy, 2 * K + iz, ngf, pf)] / 8.0;
+    }
+    rhs_c[gidx(I, J, K, ngc, pc)] = acc;
+  }
+}
+
+// prolongation + correction of the local fine brick.  The coarse correction is
+// either the local coarse brick with >= 1 valid ghost layer (cglob = 0) or a
+// replicated dense periodic level of cglob^3 cells, of which this rank's part
+// starts at (cox, coy, coz).
+__global__ __launch_bounds__(256) void mg_interp_ghost_kernel(double *__restrict__ phi_f, int nf, int ngf,
+                                                               const double *__restrict__ corr_c, int ngc,
+                                                               int cglob, int cox, int coy, int coz) {
+  const int nc = nf >> 1;
+  const long Nf = (long)nf * nf * nf;
+  const int pf = nf + 2 * ngf, pc = nc + 2 * ngc;
+  const double a = 1.0 / 64.0, b = 3 * a, cc = 9 * a, d = 27 * a;
+  const double bbb[8] = {a, b, b, cc, b, cc, cc, d};
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < Nf; c += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(c % nf);
+    const int j = (int)((c / nf) % nf);
+    const int k = (int)(c / ((long)nf * nf));
+    const int I = i >> 1, J = j >> 1, K = k >> 1;
+    const int sx = (i & 1) ? 1 : -1, sy = (j & 1) ? 1 : -1, sz = (k & 1) ? 1 : -1;
+    double corr = 0.0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const int pi = (t & 1) ? I : I + sx;
+      const int pj = (t & 2) ? J : J + sy;
+      const int pk = (t & 4) ? K : K + sz;
+      double v;
+      if (cglob) {
+        v = corr_c[(long)wrapi(pi + cox, cglob) + (long)cglob * (wrapi(pj + coy, cglob) + (long)cglob * wrapi(pk + coz, cglob))];
+      } else {
+        v = corr_c[gidx(pi, pj, pk, ngc, pc)];
+      }
+      corr = corr + bbb[t] * v;
+    }
+    const long g = gidx(i, j, k, ngf, pf);
+    phi_f[g] = phi_f[g] + corr;
+  }
+}
+
+// gradient_phi on the local brick (needs 2 valid ghost layers of phi); f is a
+// dense [3][n][n][n] array
+__global__ __launch_bounds__(256) void mg_gradient_ghost_kernel(const double *__restrict__ phi,
+                                                                 double *__restrict__ f, int n, int ng, double a,
+                                                                 double b) {
+  const long N = (long)n * n * n;
+  const int p = n + 2 * ng;
+  const long pp = (long)p * p;
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(c % n);
+    const int j = (int)((c / n) % n);
+    const int k = (int)(c / ((long)n * n));
+    const long o = gidx(i, j, k, ng, p);
+    f[c] = a * (phi[o - 1] - phi[o + 1]) - b * (phi[o - 2] - phi[o + 2]);
+    f[c + N] = a * (phi[o - p] - phi[o + p]) - b * (phi[o - 2 * p] - phi[o + 2 * p]);
+    f[c + 2 * N] = a * (phi[o - pp] - phi[o + pp]) - b * (phi[o - 2 * pp] - phi[o + 2 * pp]);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------
 static inline int grid_for(long work, int cap = 4096) {
@@ -222,6 +308,22 @@ hipError_t mg_launch_restrict(const double *res_f, double *rhs_c, double *u1_c, 
 }
 hipError_t mg_launch_interp(double *phi_f, const double *corr_c, int nf, hipStream_t s) {
   hipLaunchKernelGGL(mg_interp_kernel, dim3(grid_for((long)nf * nf * nf, 8192)), dim3(256), 0, s, phi_f, corr_c, nf);
+  return hipGetLastError();
+}
+hipError_t mg_launch_restrict_ghost(const double *res_f, double *rhs_c, int nf, int ngf, int ngc, hipStream_t s) {
+  const long Nc = (long)(nf >> 1) * (nf >> 1) * (nf >> 1);
+  hipLaunchKernelGGL(mg_restrict_ghost_kernel, dim3(grid_for(Nc)), dim3(256), 0, s, res_f, rhs_c, nf, ngf, ngc);
+  return hipGetLastError();
+}
+hipError_t mg_launch_interp_ghost(double *phi_f, int nf, int ngf, const double *corr_c, int ngc, int cglob,
+                                  int cox, int coy, int coz, hipStream_t s) {
+  hipLaunchKernelGGL(mg_interp_ghost_kernel, dim3(grid_for((long)nf * nf * nf, 8192)), dim3(256), 0, s, phi_f, nf,
+                     ngf, corr_c, ngc, cglob, cox, coy, coz);
+  return hipGetLastError();
+}
+hipError_t mg_launch_gradient_ghost(const double *phi, double *f, int n, int ng, double a, double b, hipStream_t s) {
+  hipLaunchKernelGGL(mg_gradient_ghost_kernel, dim3(grid_for((long)n * n * n, 8192)), dim3(256), 0, s, phi, f, n, ng,
+                     a, b);
   return hipGetLastError();
 }
 hipError_t mg_launch_gradient(const double *phi, double *f, int n, double a, double b, hipStream_t s) {
@@ -265,7 +367,7 @@ __global__ __launch_bounds__(SMOOTH_THREADS) void mg_smooth_fused_kernel(const d
                                                                           const double *__restrict__ rhs,
                                                                           double *__restrict__ res,
                                                                           double *__restrict__ partial, int n,
-                                                                          double dx2, double oneoverdx2,
+                                                                          int ng, double dx2, double oneoverdx2,
                                                                           int zchunk, int ntx, int nty) {
   using G = SmoothGeom<P, RESID>;
   constexpr int H = G::H;
@@ -282,9 +384,16 @@ __global__ __launch_bounds__(SMOOTH_THREADS) void mg_smooth_fused_kernel(const d
   const int x0 = tix * G::IX - H, y0 = tiy * G::IY - H;   // global coords of tile cell (0,0)
   const int z0 = tiz * zchunk;
   const int z1 = min(z0 + zchunk, n);                     // planes [z0,z1) are produced
-  const long nn = (long)n * n;
+  // ng = 0: dense periodic level, neighbours wrap; ng >= H: one rank's brick of a
+  // distributed level with ghost layers filled by the halo exchange (addresses
+  // outside the allocation are clamped: those values are never used)
+  const int pitch = n + 2 * ng;
+  const long nn = (long)pitch * pitch;
   // n >= LX (the launcher guarantees it): one conditional wrap is enough
-  auto wrap1 = [&](int v) { return v < 0 ? v + n : (v >= n ? v - n : v); };
+  auto wrap1 = [&](int v) {
+    if (ng == 0) return v < 0 ? v + n : (v >= n ? v - n : v);
+    return min(max(v, -ng), n + ng - 1) + ng;
+  };
   auto slot = [&](int z) { int s = z % G::R; return s < 0 ? s + G::R : s; };
 
   // (a) row mapping: lane = x, wave wv owns rows wv + NW*i -- coalesced loads/stores
@@ -293,7 +402,7 @@ __global__ __launch_bounds__(SMOOTH_THREADS) void mg_smooth_fused_kernel(const d
 #pragma unroll
   for (int i = 0; i < NROW; i++) {
     const int ly = wv + NW * i;
-    goffR[i] = wrap1(y0 + ly) * n + wrap1(gxu);
+    goffR[i] = wrap1(y0 + ly) * pitch + wrap1(gxu);
     lofsR[i] = ly * G::LX + lane;
   }
   // (b) colour mapping: a wave owns row pairs; lanes 0-31 take the even row of the
@@ -304,7 +413,7 @@ __global__ __launch_bounds__(SMOOTH_THREADS) void mg_smooth_fused_kernel(const d
 #pragma unroll
   for (int j = 0; j < NPAIR; j++) {
     lyC[j] = 2 * (wv + NW * j) + sub;
-    const int gy = wrap1(y0 + lyC[j]) * n;
+    const int gy = wrap1(y0 + lyC[j]) * pitch;
     goffC[j][0] = gy + wrap1(x0 + 2 * pr);
     goffC[j][1] = gy + wrap1(x0 + 2 * pr + 1);
   }
@@ -434,7 +543,7 @@ __global__ __launch_bounds__(SMOOTH_THREADS) void mg_smooth_fused_kernel(const d
     }
     // ---- final stage: store phi (+ residual and its norm) of plane m-2P -------
     {
-      const long zoff = (long)zf * nn;
+      const long zoff = (long)wrap1(zf) * nn;
 #pragma unroll
       for (int i = 0; i < NROW; i++) {
         if (onf[i]) {
@@ -485,12 +594,13 @@ __global__ __launch_bounds__(SMOOTH_THREADS) void mg_smooth_fused_kernel(const d
 // the residual, and with norm_out != NULL its dx^3-scaled squared norm.
 hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const double *rhs, double *res,
                                   double *partial, double *norm_out, int n, double dx, int npass,
-                                  hipStream_t s) {
+                                  hipStream_t s, int ng) {
   if (npass != 4 && npass != 2) return hipErrorInvalidValue;
   if (n < 64) return hipErrorInvalidValue;   // tile wider than the level: use the per-colour kernels
   const int P = npass;
   const bool resid = (res != nullptr) || (norm_out != nullptr);
   const int H = resid ? P + 1 : P;
+  if (ng != 0 && ng < H) return hipErrorInvalidValue;   // ghost layers must cover the dependency cone
   const int IX = 64 - 2 * H, IY = 24 - 2 * H;
   const int ntx = (n + IX - 1) / IX, nty = (n + IY - 1) / IY;
   int zchunk = n >= 256 ? 128 : (n >= 128 ? 64 : n);
@@ -506,7 +616,7 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,    \
                             (int)lds);                                                                        \
     if (e != hipSuccess) return e;                                                                            \
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(SMOOTH_THREADS), lds, s, phi_in, phi_out, rhs, res, partial, n, dx2,        \
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(SMOOTH_THREADS), lds, s, phi_in, phi_out, rhs, res, partial, n, ng, dx2,    \
                        oneoverdx2, zchunk, ntx, nty);                                                         \
   } while (0)
   if (P == 4) { if (resid) SM_LAUNCH(4, true); else SM_LAUNCH(4, false); }

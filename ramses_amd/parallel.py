@@ -22,10 +22,10 @@ zero here because set_unew zeroes the reception cells
 import ctypes as C
 
 import torch
-import torch.distributed as dist
 
 from ._capi import check, lib
 from .hydro import HydroLevel, _ptr, _stream
+from .transport import DistTransport
 
 
 def rank_coords(rank, pgrid):
@@ -42,9 +42,10 @@ class BrickDecomposition:
     """pgrid=(px,py,pz) ranks, each owning an n^3 brick (weak scaling) of the
     periodic (n*px, n*py, n*pz) level; boxlen is the x extent of the box."""
 
-    def __init__(self, pgrid, rank, n, boxlen=0.5, ng=2):
+    def __init__(self, pgrid, rank, n, boxlen=0.5, ng=2, transport=None):
         self.pgrid = tuple(pgrid)
         self.rank = rank
+        self.transport = transport if transport is not None else DistTransport()
         self.n = n
         self.ng = ng
         self.coords = rank_coords(rank, self.pgrid)
@@ -113,12 +114,8 @@ class BrickDecomposition:
             # One grouped launch (ncclGroupStart/End).  With 2 ranks on the axis
             # both messages go to the same peer; sends and receives are posted in
             # matching order (peer's first send = its low slab = my high ghosts).
-            ops = [dist.P2POp(dist.isend, send_lo, lo_nbr),
-                   dist.P2POp(dist.isend, send_hi, hi_nbr),
-                   dist.P2POp(dist.irecv, recv_hi, hi_nbr),
-                   dist.P2POp(dist.irecv, recv_lo, lo_nbr)]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            self.transport.sendrecv([(send_lo, lo_nbr), (send_hi, hi_nbr)],
+                                    [(recv_hi, hi_nbr), (recv_lo, lo_nbr)])
             self._unpack(lev, t, nvar, 2 * axis, recv_lo)
             self._unpack(lev, t, nvar, 2 * axis + 1, recv_hi)
 
@@ -156,6 +153,4 @@ class BrickDecomposition:
 
     def allreduce_min(self, value, device):
         """dt = min over ranks (MPI_ALLREDUCE MIN of hydro/courant_fine.f90:140)."""
-        t = torch.tensor([value], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return float(t.item())
+        return self.transport.allreduce(value, device, op="min")

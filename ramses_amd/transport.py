@@ -1,0 +1,145 @@
+"""Message transport under the halo exchange and the multigrid driver.
+
+DistTransport    torch.distributed (backend "nccl" = RCCL over xGMI on the GPU
+                 box, "gloo" in the CPU protocol tests): grouped send/recv, the
+                 scalar reductions and the coarse-level all-gather.
+LocalWorld       several virtual ranks inside ONE process (one Python thread
+                 each, mailboxes instead of a network).  Used by the tests to
+                 run the multi-rank code paths on a single GPU and compare them
+                 bit for bit with the single-brick result.
+
+The reference's counterpart is the MPI layer of amr/virtual_boundaries.f90
+(isend/irecv per peer, MPI_ALLREDUCE of scalars).
+"""
+import threading
+
+import torch
+import torch.distributed as dist
+
+
+class DistTransport:
+    def __init__(self):
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+
+    def sendrecv(self, sends, recvs):
+        """sends/recvs: lists of (tensor, peer).  One grouped launch
+        (ncclGroupStart/End); per peer, messages match in posting order."""
+        ops = [dist.P2POp(dist.isend, t, p) for t, p in sends] + [dist.P2POp(dist.irecv, t, p) for t, p in recvs]
+        if not ops:
+            return
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def allreduce(self, value, device, op="sum"):
+        t = torch.tensor([value], dtype=torch.float64, device=device)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN if op == "min" else (dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM))
+        return float(t.item())
+
+    def allgather(self, t):
+        """t: contiguous tensor; returns a tensor [world, *t.shape] in rank order."""
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        if self.world > 1:
+            dist.all_gather_into_tensor(out, t.contiguous())
+        else:
+            out[0].copy_(t)
+        return out
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+
+class LocalWorld:
+    """world virtual ranks in this process: run(fn) calls fn(transport) on one
+    thread per rank and returns the list of results (re-raises the first error)."""
+
+    def __init__(self, world):
+        self.world = world
+        self._cv = threading.Condition()
+        self._mail = {}                      # (src, dst) -> list of tensors, FIFO
+        self._coll = {}                      # collective round -> contributions
+        self._round = [0] * world
+
+    def transport(self, rank):
+        return _LocalTransport(self, rank)
+
+    def run(self, fn):
+        res, err = [None] * self.world, [None] * self.world
+
+        def body(r):
+            try:
+                res[r] = fn(self.transport(r))
+            except BaseException as e:          # noqa: BLE001
+                err[r] = e
+                with self._cv:
+                    self._cv.notify_all()
+
+        th = [threading.Thread(target=body, args=(r,)) for r in range(self.world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for e in err:
+            if e is not None:
+                raise e
+        return res
+
+
+class _LocalTransport:
+    def __init__(self, world, rank):
+        self.w = world
+        self.rank = rank
+        self.world = world.world
+
+    def sendrecv(self, sends, recvs):
+        w = self.w
+        if sends and sends[0][0].is_cuda:
+            torch.cuda.current_stream().synchronize()
+        with w._cv:
+            for t, p in sends:
+                w._mail.setdefault((self.rank, p), []).append(t.clone())
+            w._cv.notify_all()
+        for t, p in recvs:
+            with w._cv:
+                while not w._mail.get((p, self.rank)):
+                    w._cv.wait(timeout=60)
+                    if not w._mail.get((p, self.rank)) and not any(th.is_alive() for th in threading.enumerate() if th is not threading.current_thread() and th is not threading.main_thread()):
+                        raise RuntimeError("LocalWorld: peer died")
+                m = w._mail[(p, self.rank)].pop(0)
+            t.copy_(m)
+        if recvs and recvs[0][0].is_cuda:
+            torch.cuda.current_stream().synchronize()
+
+    def _collect(self, item):
+        w = self.w
+        with w._cv:
+            rnd = w._round[self.rank]
+            w._round[self.rank] += 1
+            slot = w._coll.setdefault(rnd, {})
+            slot[self.rank] = item
+            w._cv.notify_all()
+            while len(w._coll[rnd]) < self.world:
+                w._cv.wait(timeout=60)
+            return [w._coll[rnd][r] for r in range(self.world)]
+
+    def allreduce(self, value, device, op="sum"):
+        vals = self._collect(float(value))
+        if op == "min":
+            return min(vals)
+        if op == "max":
+            return max(vals)
+        s = 0.0
+        for v in vals:                       # rank order: deterministic
+            s += v
+        return s
+
+    def allgather(self, t):
+        if t.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        parts = self._collect(t.clone())
+        return torch.stack(parts, 0)
+
+    def barrier(self):
+        self._collect(None)
