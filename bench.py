@@ -35,7 +35,9 @@ def parse():
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange after the sweep instead of behind it")
-    ap.add_argument("--vcycle-level", type=int, default=9, help="level of the multigrid V-cycle measurement (0 = skip)")
+    ap.add_argument("--vcycle-level", type=int, default=9,
+                    help="multigrid V-cycle measurement: 2^level cells per direction per GPU (0 = skip)")
+    ap.add_argument("--vcycle-deadline", type=int, default=180, help="N>1: seconds before the V-cycle leg is abandoned")
     return ap.parse_args()
 
 
@@ -159,6 +161,49 @@ def vcycle_bench(level):
                          "frac": gbs / HBM_PEAK_GBS, "bytes_per_dof": BYTES_PER_DOF_VCYCLE}}
 
 
+def vcycle_bench_dist(level_local, pgrid, rank, world):
+    """The same measurement on p^3 GPUs (weak scaling: 2^level_local cells per
+    direction per rank): distributed V-cycles with the 5-cell communication-
+    avoiding halo and replicated coarse levels (ramses_amd/poisson_parallel.py).
+    Collective: every rank calls it."""
+    import torch
+    import torch.distributed as dist
+    from ramses_amd.parallel import rank_coords
+    from ramses_amd.poisson_parallel import PoissonDecomposition
+    n = 2 ** level_local
+    p = pgrid[0]
+    pd = PoissonDecomposition(pgrid, rank, n, boxlen=1.0, epsilon=1e-30)   # exactly MAXITER=10 V-cycles
+    N = n * p
+    a, b = int(0.375 * N), int(0.625 * N)
+    c = rank_coords(rank, pgrid)
+    pd.rho.fill_(1.0)
+    sl = []
+    for d in (2, 1, 0):                       # tensor axes are z, y, x
+        lo, hi = max(a - c[d] * n, 0), min(b - c[d] * n, n)
+        sl.append(slice(lo, max(hi, lo)))
+    pd.rho[sl[0], sl[1], sl[2]] = 10.0
+    rho_tot = 1.0 + 9.0 * ((b - a) / N) ** 3
+    pd.multigrid_fine(rho_tot)                # warm-up
+    pd.exchanges = 0
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    iters, err = pd.multigrid_fine(rho_tot)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t = time.perf_counter() - t0
+    t = pd.tr.allreduce(t, "cuda", op="max")
+    dof = float(N) ** 3 * iters / t
+    gbs = dof * BYTES_PER_DOF_VCYCLE / 1e9
+    return {"metric": "V-cycle DOF/s (multigrid_fine)", "value": dof, "unit": "DOF/s", "n_gpus": world,
+            "level": int(round(__import__("math").log2(N))), "cells_per_gpu": "%d^3" % n,
+            "vcycles": iters, "ms_per_vcycle": t / iters * 1e3, "final_error": err,
+            "halo_exchanges_per_vcycle": pd.exchanges / iters,
+            "replicated_levels_from": pd.lrep,
+            "roofline": {"bound": "hbm", "achieved": gbs / world, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
+                         "frac": gbs / world / HBM_PEAK_GBS, "bytes_per_dof": BYTES_PER_DOF_VCYCLE}}
+
+
 def main():
     args = parse()
     import torch
@@ -172,9 +217,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local_rank)
+    # RAMSES_AMD_DIST_BACKEND=gloo: smoke-test the multi-rank path with all ranks on
+    # one GPU (tensors staged through the host); never a measurement
+    backend = os.environ.get("RAMSES_AMD_DIST_BACKEND", "nccl")
+    local_dev = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(backend)
 
     n = args.n
     pgrid = rank_grid(world)
@@ -206,9 +258,7 @@ def main():
     # update, never changes the work per cell
     dt = lev.courant_fine()[0]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        dt = float(t.item())
+        dt = exchange.transport.allreduce(dt, "cuda", op="min")
 
     overlap = exchange is not None and not args.no_overlap
 
@@ -247,9 +297,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = exchange.transport.allreduce(elapsed, "cuda", op="max")
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
 
     # sanity: the state must still be physical
@@ -282,11 +330,47 @@ def main():
             del lev
             torch.cuda.empty_cache()
             out["vcycle"] = vcycle_bench(args.vcycle_level)
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()     # rank 0 at N=1 only
+    else:
+        out = None
+
+    if world > 1 and args.vcycle_level > 0:
+        # second metric on several GPUs; collective, and guarded: whatever happens in
+        # it, the headline line is printed (a watchdog ends every rank after the deadline)
+        import threading
+        note = {"metric": "V-cycle DOF/s (multigrid_fine)", "value": None}
+
+        def bail():
+            if rank == 0:
+                note["error"] = "distributed V-cycle leg exceeded %d s" % args.vcycle_deadline
+                out["vcycle"] = note
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        if pgrid[0] == pgrid[1] == pgrid[2]:
+            wd = threading.Timer(args.vcycle_deadline, bail)
+            wd.daemon = True
+            wd.start()
+            try:
+                del lev, exchange, dec
+                torch.cuda.empty_cache()
+                vc = vcycle_bench_dist(args.vcycle_level, pgrid, rank, world)
+            except Exception as exc:
+                vc = dict(note, error=str(exc)[:300])
+            wd.cancel()
+            if rank == 0:
+                out["vcycle"] = vc
+        elif rank == 0:
+            note["note"] = "the distributed multigrid needs a cubic rank grid (1 or 8 GPUs per node)"
+            out["vcycle"] = note
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

@@ -18,33 +18,48 @@ import torch.distributed as dist
 
 
 class DistTransport:
+    """backend "nccl" (= RCCL): device tensors go straight to the collective.
+    backend "gloo": device tensors are staged through host memory, which lets
+    the multi-process paths be exercised where RCCL cannot run (CPU container,
+    several ranks sharing one GPU)."""
+
     def __init__(self):
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.staged = dist.is_initialized() and dist.get_backend() == "gloo"
 
     def sendrecv(self, sends, recvs):
         """sends/recvs: lists of (tensor, peer).  One grouped launch
         (ncclGroupStart/End); per peer, messages match in posting order."""
-        ops = [dist.P2POp(dist.isend, t, p) for t, p in sends] + [dist.P2POp(dist.irecv, t, p) for t, p in recvs]
-        if not ops:
+        if not sends and not recvs:
             return
+        if self.staged and (sends + recvs)[0][0].is_cuda:
+            hs = [(t.cpu(), p) for t, p in sends]
+            hr = [(torch.empty(t.shape, dtype=t.dtype), p) for t, p in recvs]
+            ops = [dist.P2POp(dist.isend, t, p) for t, p in hs] + [dist.P2POp(dist.irecv, t, p) for t, p in hr]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            for (t, _), (h, _) in zip(recvs, hr):
+                t.copy_(h)
+            return
+        ops = [dist.P2POp(dist.isend, t, p) for t, p in sends] + [dist.P2POp(dist.irecv, t, p) for t, p in recvs]
         for w in dist.batch_isend_irecv(ops):
             w.wait()
 
     def allreduce(self, value, device, op="sum"):
-        t = torch.tensor([value], dtype=torch.float64, device=device)
+        t = torch.tensor([value], dtype=torch.float64, device="cpu" if self.staged else device)
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MIN if op == "min" else (dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM))
         return float(t.item())
 
     def allgather(self, t):
         """t: contiguous tensor; returns a tensor [world, *t.shape] in rank order."""
-        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        if self.world > 1:
-            dist.all_gather_into_tensor(out, t.contiguous())
-        else:
-            out[0].copy_(t)
-        return out
+        if self.world == 1:
+            return t.contiguous().unsqueeze(0).clone()
+        src = t.contiguous().cpu() if self.staged else t.contiguous()
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=src.device)
+        dist.all_gather_into_tensor(out, src)
+        return out.to(t.device)
 
     def barrier(self):
         if self.world > 1:
