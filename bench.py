@@ -29,7 +29,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=512, help="cells per direction of each rank's brick")
+    ap.add_argument("--n", "--cells", dest="n", type=int, default=512, help="cells per direction of each rank's brick")
     ap.add_argument("--fast", type=int, default=1, help="1: FMA-contracted build (<=1e-12 of strict), 0: strict")
     ap.add_argument("--zchunk", type=int, default=0)
     ap.add_argument("--tile-rows", type=int, default=0)

@@ -57,9 +57,10 @@ class DistTransport:
         if self.world == 1:
             return t.contiguous().unsqueeze(0).clone()
         src = t.contiguous().cpu() if self.staged else t.contiguous()
-        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=src.device)
+        # concatenated along dim 0 (the layout every backend accepts), viewed per rank
+        out = torch.empty((self.world * src.shape[0],) + tuple(src.shape[1:]), dtype=t.dtype, device=src.device)
         dist.all_gather_into_tensor(out, src)
-        return out.to(t.device)
+        return out.view((self.world,) + tuple(src.shape)).to(t.device)
 
     def barrier(self):
         if self.world > 1:

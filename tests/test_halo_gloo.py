@@ -94,6 +94,21 @@ def _worker(rank, world, pgrid, n, port, ret):
         idx = lambda c, ext: (np.arange(c * n - ng, (c + 1) * n + ng)) % ext  # noqa: E731
         exp = G[:, idx(cz, G.shape[1])][:, :, idx(cy, G.shape[2])][:, :, :, idx(cx, G.shape[3])]
         ok = np.array_equal(lev.uold.numpy(), exp)
+        # deep halo of the distributed multigrid (5 ghost layers, one field)
+        ng5 = 5 if n >= 5 else n
+        lev5 = FakeLevel(n, ng5, 1)
+        lev5.uold[:, ng5:ng5 + n, ng5:ng5 + n, ng5:ng5 + n] = torch.from_numpy(own[:1].copy())
+        dec5 = TorchMoverDecomposition(pgrid, rank, n, boxlen=1.0, ng=ng5)
+        dec5.exchange(lev5, lev5.uold, 1)
+        idx5 = lambda c, ext: (np.arange(c * n - ng5, (c + 1) * n + ng5)) % ext  # noqa: E731
+        exp5 = G[:1, idx5(cz, G.shape[1])][:, :, idx5(cy, G.shape[2])][:, :, :, idx5(cx, G.shape[3])]
+        ok = ok and np.array_equal(lev5.uold.numpy(), exp5)
+        # the collectives of the multigrid driver
+        tr = dec.transport
+        ok = ok and tr.allreduce(float(rank + 1), "cpu") == world * (world + 1) / 2
+        ok = ok and tr.allreduce(float(rank + 1), "cpu", op="min") == 1.0
+        g = tr.allgather(torch.full((2, 3), float(rank)))
+        ok = ok and g.shape == (world, 2, 3) and all(bool((g[r] == r).all()) for r in range(world))
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
@@ -114,6 +129,32 @@ def test_halo_exchange_fills_all_ghosts(pgrid):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, pgrid, 6, _free_port(), ret), nprocs=world, join=True)
     assert len(ret) == world and all(ret.values()), dict(ret)
+
+
+@pytest.mark.parametrize("pgrid", [(2, 2, 2), (2, 1, 1)])
+def test_virtual_ranks_exchange_like_processes(pgrid):
+    """LocalWorld (threads + mailboxes, used by the GPU tests to run multi-rank
+    code on one device) moves the same slabs as the torch.distributed transport."""
+    from ramses_amd.transport import LocalWorld
+    world = pgrid[0] * pgrid[1] * pgrid[2]
+    n, ng, nvar = 6, 2, 2
+    G = global_field(nvar, n * pgrid[2], n * pgrid[1], n * pgrid[0])
+
+    def body(tr):
+        dec = TorchMoverDecomposition(pgrid, tr.rank, n, boxlen=1.0, ng=ng, transport=tr)
+        lev = FakeLevel(n, ng, nvar)
+        cx, cy, cz = rank_coords(tr.rank, pgrid)
+        own = G[:, cz * n:(cz + 1) * n, cy * n:(cy + 1) * n, cx * n:(cx + 1) * n]
+        lev.uold[:, ng:ng + n, ng:ng + n, ng:ng + n] = torch.from_numpy(own.copy())
+        dec.exchange(lev, lev.uold, nvar)
+        idx = lambda c, ext: (np.arange(c * n - ng, (c + 1) * n + ng)) % ext  # noqa: E731
+        exp = G[:, idx(cz, G.shape[1])][:, :, idx(cy, G.shape[2])][:, :, :, idx(cx, G.shape[3])]
+        s = tr.allreduce(float(tr.rank), "cpu")
+        g = tr.allgather(torch.full((2,), float(tr.rank)))
+        return bool(np.array_equal(lev.uold.numpy(), exp)) and s == world * (world - 1) / 2 and \
+            [float(x) for x in g[:, 0]] == [float(r) for r in range(world)]
+
+    assert all(LocalWorld(world).run(body))
 
 
 def test_weak_scaling_rank_grid_matches_bench():
