@@ -283,6 +283,24 @@ int ramses_amd_multigrid_fine_f90(int ilevel, int ngrid, const int *igrid, const
                                   int *iters, double *err);
 
 /* ---------------------------------------------------------------------------
+ * godunov_fine(ilevel) on an AMR level (hydro/godunov_fine.f90:5-35, godfine1
+ * :486-911 with every AMR branch: stencil cells of missing octs interpolated
+ * from the father level (get3cubefather amr/nbors_utils.f90:5-194,
+ * getnborfather :404-525, interpol_hydro hydro/interpol_hydro.f90:268-444),
+ * fluxes zeroed at refined interfaces (:720-747), unew += flux differences
+ * (:751-792), corrections of the coarser level's leaf cells (:798-908)).
+ * Arrays are the reference's own, by address: son(1:ncell),
+ * nbor(1:ngridmax,1:6), father(1:ngridmax), uold/unew(1:ncell,1:nvar).
+ * nvector = the reference build's NVECTOR: it fixes the order in which the
+ * coarse-level corrections are accumulated (bit parity).  Needs ilevel >= 3.
+ * ------------------------------------------------------------------------- */
+int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                     const int *igrid, const int *son, const int *nbor,
+                                     const int *father, int64_t ngridmax, int64_t ncoarse,
+                                     const double *uold, double *unew, double dx, double dt,
+                                     int nvector, int interpol_var, int interpol_type);
+
+/* ---------------------------------------------------------------------------
  * Distributed multigrid: one rank's n^3 brick of a periodic level with ng
  * ghost layers (pitch n+2ng), ghosts filled by the halo exchange
  * (make_virtual_mg_dp, poisson/multigrid_fine_commons.f90:1172-1270, replaced

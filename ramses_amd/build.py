@@ -27,6 +27,7 @@ UNITS = [
     ("mg_kernels.o", "mg_kernels.hip", ["-ffp-contract=off"]),
     ("octree_pack.o", "octree_pack.hip", ["-ffp-contract=off"]),
     ("amr_ops.o", "amr_ops.hip", ["-ffp-contract=off"]),
+    ("amr_sweep.o", "amr_sweep.hip", ["-ffp-contract=off"]),
     ("capi.o", "capi.hip", ["-ffp-contract=off"]),
 ]
 

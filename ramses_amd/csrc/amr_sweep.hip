@@ -1,0 +1,351 @@
+// amr_sweep.hip -- godunov_fine on an AMR level (partially refined, or with
+// refined cells), directly on the reference's tree arrays:
+//   godfine1            hydro/godunov_fine.f90:486-911
+//   get3cubefather      amr/nbors_utils.f90:5-194   (27 neighbouring father cells)
+//   getnborfather       amr/nbors_utils.f90:404-525 (stencil of the interpolation)
+//   interpol_hydro      hydro/interpol_hydro.f90:268-444
+//   unsplit             hydro/umuscl.f90:22-171
+//
+// One wavefront = one oct (the reference's vector element).  The 6^3 stencil of
+// the oct lives in LDS: cells of existing neighbour octs are copied from uold,
+// cells of missing octs are interpolated from the father level; refined cells
+// carry the `ok` flag.  The 64 lanes then ARE the 4^3 cells the reference
+// computes slopes and traced states for; 36 lanes compute the 36 interface
+// fluxes of the oct; 8 lanes update the oct's cells in the reference's order
+// (unew += fL-fR for x, then y, then z).  Fluxes through faces whose
+// neighbouring oct does not exist are kept per (oct, face) and added to the
+// coarse neighbour cell by a second kernel that replays, per coarse cell, the
+// reference's accumulation order: (batch of nvector octs, idim, left/right,
+// the 4 fine faces) -- bit-identical for a given NVECTOR.
+//
+// Strict arithmetic only (-ffp-contract=off).  HBM access is gather-shaped
+// (cells of an oct are ngridmax doubles apart, hydro/godunov_fine.f90:600-601);
+// the dense brick sweep (hydro_sweep.hip) remains the path of fully refined,
+// unrefined levels.
+#include <hip/hip_runtime.h>
+
+#include "amr_core.hpp"
+#include "amr_sweep_args.hpp"
+#include "hydro_core.hpp"
+
+namespace ramses_amd {
+namespace amrsweep {
+
+constexpr int NV = 5;
+constexpr int OCTS_PER_BLOCK = 4;
+
+struct OctLds {
+  double u[216][NV];        // conserved, then primitive variables of the 6^3 stencil
+  double qm[3][3][2][2][NV];  // traced state on the +d face of trace cell a (a = 0..2), transverse 1..2
+  double qp[3][3][2][2][NV];  // traced state on the -d face of trace cell a+1
+  double fl[3][3][2][2][NV];  // flux through face a of direction d
+  int fc[27];               // the 3^3 neighbouring father cells (1-based cell index)
+  int ex[27];               // their son oct (0: not refined)
+  unsigned char ok[216];    // cell is refined
+};
+
+// cell index (1-based, level >= 2) -> octant position and oct
+__device__ __forceinline__ void cell_split(int c, long ncoarse, long ngridmax, int &pos, int &g) {
+  pos = (int)((c - ncoarse - 1) / ngridmax);
+  g = (int)(c - ncoarse - (long)pos * ngridmax);
+}
+
+// same-level neighbour of cell c in direction dir (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z).
+// Returns the neighbour cell; if its oct does not exist returns -(coarser cell)
+// (the neighbouring father cell of c's oct: getnborfather's fallback).
+__device__ __forceinline__ int nbor_cell(int c, int dir, const AmrSweepArgs &A) {
+  int pos, g;
+  cell_split(c, A.ncoarse, A.ngridmax, pos, g);
+  const int axis = dir >> 1, up = dir & 1;
+  const int bit = (pos >> axis) & 1;
+  if (bit != up) return c + (up ? 1 : -1) * (int)((1 << axis) * A.ngridmax);   // sibling in the same oct
+  const int nb = A.nbor[(long)dir * A.ngridmax + g - 1];
+  const int g2 = A.son[nb - 1];
+  if (g2 == 0) return -nb;
+  return (int)(A.ncoarse + (long)(pos ^ (1 << axis)) * A.ngridmax + g2);
+}
+
+__device__ __forceinline__ int sidx(int i3, int j3, int k3) { return i3 + 6 * (j3 + 6 * k3); }
+
+// lanes of one wavefront exchange data through LDS: order the memory operations
+// for the compiler (the hardware executes a wave's LDS instructions in order)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int ST, int RS>
+__global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSweepArgs A) {
+  __shared__ OctLds lds[OCTS_PER_BLOCK];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int io = blockIdx.x * OCTS_PER_BLOCK + w;
+  if (io >= A.ngrid) return;                   // whole wave: no block-level barrier is used
+  OctLds &L = lds[w];
+  const HydroConst &P = A.P;
+  const int g = A.igrid[io];
+  const long ncell = A.ncell;
+
+  // ---- (A) the 3^3 neighbouring father cells -------------------------------
+  if (lane < 27) {
+    const int d3[3] = {lane % 3 - 1, (lane / 3) % 3 - 1, lane / 9 - 1};
+    int c = A.father[g - 1];
+#pragma unroll
+    for (int axis = 0; axis < 3; axis++) {
+      if (d3[axis] != 0 && c > 0) {
+        c = nbor_cell(c, 2 * axis + (d3[axis] > 0 ? 1 : 0), A);
+        if (c < 0) { atomicAdd(A.err, 1); c = 0; }   // the 3^3 father cells always exist (refinement rules)
+      }
+    }
+    L.fc[lane] = c;
+    L.ex[lane] = c > 0 ? A.son[c - 1] : 0;
+  }
+  wave_sync();
+
+  // ---- (B) gather the 6^3 stencil -------------------------------------------
+  for (int e = lane; e < 216; e += 64) {
+    const int t = e >> 3, ind = e & 7;
+    const int og = L.ex[t];
+    if (og > 0) {
+      const int i3 = 2 * (t % 3) + (ind & 1), j3 = 2 * ((t / 3) % 3) + ((ind >> 1) & 1), k3 = 2 * (t / 9) + (ind >> 2);
+      const long cell = A.ncoarse + (long)ind * A.ngridmax + og;   // 1-based
+      const int s = sidx(i3, j3, k3);
+#pragma unroll
+      for (int v = 0; v < NV; v++) L.u[s][v] = A.uold[(long)v * ncell + cell - 1];
+      L.ok[s] = A.son[cell - 1] > 0;
+    }
+  }
+  if (lane < 27 && L.ex[lane] == 0 && L.fc[lane] > 0) {
+    // missing oct: interpolate the father cell with its 2*ndim neighbours
+    const int c0 = L.fc[lane];
+    double u1[7][NV], u2[8][NV];
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      int c = c0;
+      if (j > 0) {
+        c = nbor_cell(c0, j - 1, A);
+        if (c < 0) c = -c;
+      }
+#pragma unroll
+      for (int v = 0; v < NV; v++) u1[j][v] = A.uold[(long)v * ncell + c - 1];
+    }
+    interpol_hydro_cell<NV>(u1, u2, A.interpol_var, A.interpol_type, P.smallr);
+    const int t = lane;
+#pragma unroll
+    for (int ind = 0; ind < 8; ind++) {
+      const int i3 = 2 * (t % 3) + (ind & 1), j3 = 2 * ((t / 3) % 3) + ((ind >> 1) & 1), k3 = 2 * (t / 9) + (ind >> 2);
+      const int s = sidx(i3, j3, k3);
+#pragma unroll
+      for (int v = 0; v < NV; v++) L.u[s][v] = u2[ind][v];
+      L.ok[s] = 0;
+    }
+  }
+  wave_sync();
+
+  // ---- (C) ctoprim on the 6^3 cells (in place) -------------------------------
+  const double dtxhalf = A.dt * 0.5;
+  for (int e = lane; e < 216; e += 64) {
+    double u[NV], q[NV], gz[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int v = 0; v < NV; v++) u[v] = L.u[e][v];
+    ctoprim_cell<NV, false>(u, gz, dtxhalf, P, q);
+#pragma unroll
+    for (int v = 0; v < NV; v++) L.u[e][v] = q[v];
+  }
+  wave_sync();
+
+  // ---- (D) slopes + trace: lane = one of the 4^3 cells ------------------------
+  const double dtdx = A.dt / A.dx;
+  {
+    const int ti = lane & 3, tj = (lane >> 2) & 3, tk = lane >> 4;
+    const int s = sidx(ti + 1, tj + 1, tk + 1);
+    double qb[NV], dq[3][NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      qb[v] = L.u[s][v];
+      dq[0][v] = slope1<ST>(L.u[s - 1][v], qb[v], L.u[s + 1][v], P);
+      dq[1][v] = slope1<ST>(L.u[s - 6][v], qb[v], L.u[s + 6][v], P);
+      dq[2][v] = slope1<ST>(L.u[s - 36][v], qb[v], L.u[s + 36][v], P);
+    }
+    double qm[3][NV], qp[3][NV];
+    trace3d_cell<NV>(qb, dq, dtdx, dtdx, dtdx, P, qm, qp);
+    const int tc[3] = {ti, tj, tk};
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const int t0 = d == 0 ? 1 : 0, t1 = d == 2 ? 1 : 2;     // transverse axes, increasing
+      const int a = tc[d], b = tc[t0] - 1, c = tc[t1] - 1;
+      if (b >= 0 && b < 2 && c >= 0 && c < 2) {
+        if (a <= 2) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) L.qm[d][a][b][c][v] = qm[d][v];
+        }
+        if (a >= 1) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) L.qp[d][a - 1][b][c][v] = qp[d][v];
+        }
+      }
+    }
+  }
+  wave_sync();
+
+  // ---- (E) the 36 interface fluxes, zeroed at refined interfaces --------------
+  if (lane < 36) {
+    const int d = lane / 12, r = lane % 12, a = r >> 2, b = r & 1, c = (r >> 1) & 1;
+    double qL[NV], qR[NV], fx[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) { qL[v] = L.qm[d][a][b][c][v]; qR[v] = L.qp[d][a][b][c][v]; }
+    const bool pow2 = A.pow2 != 0;
+    if (d == 0) scaled_interface_flux<RS, NV, 0>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
+    else if (d == 1) scaled_interface_flux<RS, NV, 1>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
+    else scaled_interface_flux<RS, NV, 2>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
+    // stencil coordinates of the two cells of the face
+    int cl[3];
+    const int t0 = d == 0 ? 1 : 0, t1 = d == 2 ? 1 : 2;
+    cl[d] = a + 1; cl[t0] = b + 2; cl[t1] = c + 2;
+    const int sl = sidx(cl[0], cl[1], cl[2]);
+    const int stride = d == 0 ? 1 : (d == 1 ? 6 : 36);
+    const bool zero = L.ok[sl] || L.ok[sl + stride];
+#pragma unroll
+    for (int v = 0; v < NV; v++) L.fl[d][a][b][c][v] = zero ? 0.0 : fx[v];
+  }
+  wave_sync();
+
+  // ---- (F) conservative update of the oct's 8 cells ----------------------------
+  if (lane < 8) {
+    const int ic[3] = {lane & 1, (lane >> 1) & 1, lane >> 2};
+    const long cell = A.ncoarse + (long)lane * A.ngridmax + g;
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      double un = A.unew[(long)v * ncell + cell - 1];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const int t0 = d == 0 ? 1 : 0, t1 = d == 2 ? 1 : 2;
+        const int a = ic[d], b = ic[t0], c = ic[t1];
+        un = un + (L.fl[d][a][b][c][v] - L.fl[d][a + 1][b][c][v]);
+      }
+      A.unew[(long)v * ncell + cell - 1] = un;
+    }
+  }
+  // ---- (G) fluxes owed to coarse neighbour cells --------------------------------
+  if (lane >= 8 && lane < 14) {
+    const int f = lane - 8, d = f >> 1, side = f & 1;
+    const int nb = A.nbor[(long)f * A.ngridmax + g - 1];
+    const bool coarse = A.son[nb - 1] == 0;
+    A.corr_tgt[(long)io * 6 + f] = coarse ? nb : 0;
+    if (coarse) {
+      const int a = side ? 2 : 0;
+      double *dst = A.corr + ((long)io * 6 + f) * 4 * NV;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int v = 0; v < NV; v++) dst[q * NV + v] = L.fl[d][a][q & 1][q >> 1][v];
+    }
+  }
+}
+
+// posof[oct-1] = position (0-based) of the oct in the active list
+__global__ void amr_posof_kernel(const int *igrid, int ngrid, int *posof) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ngrid) posof[igrid[i] - 1] = i;
+}
+
+// Conservative update at level ilevel-1 (hydro/godunov_fine.f90:798-908): every
+// (oct, face) whose neighbouring father cell is a leaf owes it 4 fluxes.  A coarse
+// cell has at most 6 such creditors; the thread of the creditor that comes first in
+// the reference's loop order (batch of nvector octs, idim, left before right)
+// replays all of them sequentially.
+__global__ __launch_bounds__(256) void amr_coarse_update_kernel(AmrSweepArgs A, const int *posof, int nvector) {
+  const long ev = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ev >= (long)A.ngrid * 6) return;
+  const int C = A.corr_tgt[ev];
+  if (C <= 0) return;
+  const int io = (int)(ev / 6), f = (int)(ev % 6);
+  const long mykey = ((long)(io / nvector) * 3 + (f >> 1)) * 2 + (f & 1);
+  long key[6];
+  long src[6];
+  int n = 0;
+  bool first = true;
+  for (int e = 0; e < 6; e++) {
+    // the cell on side e of C; if it is refined, its oct borders C with face e^1
+    int pos, gC;
+    int Ne;
+    if (C > A.ncoarse) {
+      Ne = nbor_cell(C, e, A);
+    } else {
+      Ne = -1;   // level-1 father cells: not handled (the launcher refuses ilevel < 3)
+    }
+    (void)pos; (void)gC;
+    if (Ne <= 0) continue;
+    const int g2 = A.son[Ne - 1];
+    if (g2 == 0) continue;
+    const int p2 = posof[g2 - 1];
+    if (p2 < 0) continue;                       // not an active oct of this level (cannot happen on one rank)
+    const int f2 = e ^ 1;
+    if (A.corr_tgt[(long)p2 * 6 + f2] != C) continue;
+    const long k = ((long)(p2 / nvector) * 3 + (f2 >> 1)) * 2 + (f2 & 1);
+    key[n] = k; src[n] = (long)p2 * 6 + f2; n++;
+    if (k < mykey) first = false;
+  }
+  if (!first) return;
+  // insertion sort of <= 6 creditors
+  for (int i = 1; i < n; i++) {
+    const long k = key[i], s = src[i];
+    int j = i - 1;
+    while (j >= 0 && key[j] > k) { key[j + 1] = key[j]; src[j + 1] = src[j]; j--; }
+    key[j + 1] = k; src[j + 1] = s;
+  }
+  const double oneontwotondim = 1.0 / 8.0;
+  for (int v = 0; v < NV; v++) {
+    double val = A.unew[(long)v * A.ncell + C - 1];
+    for (int i = 0; i < n; i++) {
+      const double *c = A.corr + src[i] * 4 * NV;
+      const bool left = ((src[i] % 6) & 1) == 0;
+      for (int q = 0; q < 4; q++) {
+        const double t = c[q * NV + v] * oneontwotondim;
+        val = left ? val - t : val + t;
+      }
+    }
+    A.unew[(long)v * A.ncell + C - 1] = val;
+  }
+}
+
+template <int ST>
+static hipError_t launch1(const AmrSweepArgs &A, int rs, hipStream_t s) {
+  const int blocks = (A.ngrid + OCTS_PER_BLOCK - 1) / OCTS_PER_BLOCK;
+  const dim3 grid(blocks), block(64 * OCTS_PER_BLOCK);
+  switch (rs) {
+    case RIEMANN_LLF: hipLaunchKernelGGL((amr_godunov_kernel<ST, RIEMANN_LLF>), grid, block, 0, s, A); break;
+    case RIEMANN_HLLC: hipLaunchKernelGGL((amr_godunov_kernel<ST, RIEMANN_HLLC>), grid, block, 0, s, A); break;
+    case RIEMANN_HLL: hipLaunchKernelGGL((amr_godunov_kernel<ST, RIEMANN_HLL>), grid, block, 0, s, A); break;
+    case RIEMANN_ACOUSTIC: hipLaunchKernelGGL((amr_godunov_kernel<ST, RIEMANN_ACOUSTIC>), grid, block, 0, s, A); break;
+    case RIEMANN_EXACT: hipLaunchKernelGGL((amr_godunov_kernel<ST, RIEMANN_EXACT>), grid, block, 0, s, A); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace amrsweep
+
+hipError_t launch_amr_godunov(const AmrSweepArgs &A, int slope_type, int riemann, int *posof, int nvector,
+                              hipStream_t s) {
+  using namespace amrsweep;
+  if (A.ngrid <= 0) return hipSuccess;
+  hipError_t e;
+  e = hipMemsetAsync(posof, 0xff, sizeof(int) * A.ngridmax, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(amr_posof_kernel, dim3((A.ngrid + 255) / 256), dim3(256), 0, s, A.igrid, A.ngrid, posof);
+  switch (slope_type) {
+    case 0: e = launch1<0>(A, riemann, s); break;
+    case 1: e = launch1<1>(A, riemann, s); break;
+    case 2: e = launch1<2>(A, riemann, s); break;
+    case 7: e = launch1<7>(A, riemann, s); break;
+    case 8: e = launch1<8>(A, riemann, s); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  const long nev = (long)A.ngrid * 6;
+  hipLaunchKernelGGL(amr_coarse_update_kernel, dim3((int)((nev + 255) / 256)), dim3(256), 0, s, A, posof, nvector);
+  return hipGetLastError();
+}
+
+}  // namespace ramses_amd

@@ -1,0 +1,28 @@
+// amr_sweep_args.hpp -- argument block of the AMR godunov_fine kernels.
+#pragma once
+#include "hydro_core.hpp"
+
+namespace ramses_amd {
+
+struct AmrSweepArgs {
+  const double *uold;   // [nvar][ncell]   (uold(1:ncell,1:nvar), column major)
+  double *unew;         // [nvar][ncell]
+  const int *son;       // [ncell]
+  const int *nbor;      // [6][ngridmax]   (nbor(1:ngridmax,1:twondim))
+  const int *father;    // [ngridmax]
+  const int *igrid;     // active(ilevel)%igrid, 1-based oct indices
+  int ngrid;
+  long ncell, ncoarse, ngridmax;
+  double dt, dx, rdx;
+  int pow2;
+  int interpol_var, interpol_type;
+  double *corr;         // [ngrid][6][4][nvar] fluxes owed to coarse neighbour cells
+  int *corr_tgt;        // [ngrid][6] the coarse cell (1-based) or 0
+  int *err;             // tree inconsistencies found
+  HydroConst P;
+};
+
+hipError_t launch_amr_godunov(const AmrSweepArgs &A, int slope_type, int riemann, int *posof, int nvector,
+                              hipStream_t s);
+
+}  // namespace ramses_amd

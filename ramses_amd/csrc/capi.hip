@@ -11,6 +11,7 @@
 
 #include "../../include/ramses_amd.h"
 #include "amr_args.hpp"
+#include "amr_sweep_args.hpp"
 #include "mg_args.hpp"
 #include "misc_args.hpp"
 #include "pack_args.hpp"
@@ -608,6 +609,68 @@ int ramses_amd_godunov_fine_host(const ramses_amd_hydro_params *p, int ilevel, i
   HCHK(hipMemcpyAsync(unew, H.unew.p, sizeof(double) * nvar * ncell, hipMemcpyDeviceToHost, s), "D2H unew");
   HCHK(hipStreamSynchronize(s), "sync");
 #undef HCHK
+  return 0;
+}
+
+// godunov_fine(ilevel) on an AMR level: the level is partially refined and/or
+// has refined cells (hydro/godunov_fine.f90:486-911, every branch of godfine1:
+// interpolated stencil cells, zeroed fluxes at refined interfaces, += onto the
+// unew that already holds the finer level's corrections, corrections owed to
+// the coarser level).  Works directly on the reference's tree arrays.
+int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                     const int *igrid, const int *son, const int *nbor,
+                                     const int *father, int64_t ngridmax, int64_t ncoarse,
+                                     const double *uold, double *unew, double dx, double dt,
+                                     int nvector, int interpol_var, int interpol_type) {
+  if (!p || !igrid || !son || !nbor || !father || !uold || !unew) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (p->ndim != 3 || p->nvar != 5) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep implements NDIM=3, NVAR=5");
+  if (p->scheme != 0) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep implements scheme='muscl'");
+  if (p->slope_type == 3) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep does not implement slope_type=3");
+  if (p->difmag != 0.0) return fail(RAMSES_AMD_EUNSUPPORTED, "difmag>0 is not on the device");
+  if (ilevel < 3) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep needs ilevel >= 3 (father cells inside octs); got %d", ilevel);
+  if (nvector < 1) return fail(RAMSES_AMD_EINVAL, "nvector must be >= 1");
+  if (interpol_var < 0 || interpol_var > 2 || interpol_type < 0 || interpol_type > 4) return fail(RAMSES_AMD_EINVAL, "interpol_var/interpol_type out of range");
+  if (ngrid <= 0) return 0;
+  const long ncell = ncoarse + 8 * ngridmax;
+  hipStream_t s = nullptr;
+  HostCtx &H = g_host;
+  static DevBuf dson, dnbor, dfather, dcorr, dtgt, dposof;
+#define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipfail(e_, what); } while (0)
+  HCHK(H.uold.ensure(sizeof(double) * 5 * ncell), "hipMalloc uold");
+  HCHK(H.unew.ensure(sizeof(double) * 5 * ncell), "hipMalloc unew");
+  HCHK(H.igrid.ensure(sizeof(int) * ngrid), "hipMalloc igrid");
+  HCHK(dson.ensure(sizeof(int) * ncell), "hipMalloc son");
+  HCHK(dnbor.ensure(sizeof(int) * 6 * ngridmax), "hipMalloc nbor");
+  HCHK(dfather.ensure(sizeof(int) * ngridmax), "hipMalloc father");
+  HCHK(dcorr.ensure(sizeof(double) * (size_t)ngrid * 6 * 4 * 5), "hipMalloc corr");
+  HCHK(dtgt.ensure(sizeof(int) * (size_t)ngrid * 6), "hipMalloc tgt");
+  HCHK(dposof.ensure(sizeof(int) * ngridmax), "hipMalloc posof");
+  HCHK(H.flag.ensure(sizeof(int)), "hipMalloc flag");
+  HCHK(hipMemcpyAsync(H.uold.p, uold, sizeof(double) * 5 * ncell, hipMemcpyHostToDevice, s), "H2D uold");
+  HCHK(hipMemcpyAsync(H.unew.p, unew, sizeof(double) * 5 * ncell, hipMemcpyHostToDevice, s), "H2D unew");
+  HCHK(hipMemcpyAsync(H.igrid.p, igrid, sizeof(int) * ngrid, hipMemcpyHostToDevice, s), "H2D igrid");
+  HCHK(hipMemcpyAsync(dson.p, son, sizeof(int) * ncell, hipMemcpyHostToDevice, s), "H2D son");
+  HCHK(hipMemcpyAsync(dnbor.p, nbor, sizeof(int) * 6 * ngridmax, hipMemcpyHostToDevice, s), "H2D nbor");
+  HCHK(hipMemcpyAsync(dfather.p, father, sizeof(int) * ngridmax, hipMemcpyHostToDevice, s), "H2D father");
+  HCHK(hipMemsetAsync(H.flag.p, 0, sizeof(int), s), "memset");
+  AmrSweepArgs A;
+  A.uold = H.uold.as<double>(); A.unew = H.unew.as<double>();
+  A.son = dson.as<int>(); A.nbor = dnbor.as<int>(); A.father = dfather.as<int>();
+  A.igrid = H.igrid.as<int>(); A.ngrid = ngrid;
+  A.ncell = ncell; A.ncoarse = ncoarse; A.ngridmax = ngridmax;
+  A.dt = dt; A.dx = dx; A.rdx = 1.0 / dx;
+  { int ex; A.pow2 = (std::frexp(dx, &ex) == 0.5) ? 1 : 0; }
+  A.interpol_var = interpol_var; A.interpol_type = interpol_type;
+  A.corr = dcorr.as<double>(); A.corr_tgt = dtgt.as<int>(); A.err = H.flag.as<int>();
+  A.P = make_const(p);
+  HCHK(launch_amr_godunov(A, p->slope_type, p->riemann, dposof.as<int>(), nvector, s), "AMR godunov launch");
+  int bad = 0;
+  HCHK(hipMemcpyAsync(&bad, H.flag.p, sizeof(int), hipMemcpyDeviceToHost, s), "D2H flag");
+  HCHK(hipMemcpyAsync(unew, H.unew.p, sizeof(double) * 5 * ncell, hipMemcpyDeviceToHost, s), "D2H unew");
+  HCHK(hipStreamSynchronize(s), "sync");
+#undef HCHK
+  if (bad) return fail(RAMSES_AMD_EINVAL, "level %d: %d of the 3^3 father cells of an oct do not exist (tree inconsistent)", ilevel, bad);
+  g_host.res_valid = false;   // the staging buffers were reused
   return 0;
 }
 

@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""Golden vectors of the AMR godunov_fine (reference run HERE, vectors committed).
+
+Runs the UNMODIFIED reference program wrapped by oracle/dump_patch (which only
+dumps the arrays around its godunov_fine) on an AMR Sedov namelist and stores,
+for a few calls of godunov_fine(ilevel) on partially refined levels:
+the tree (son, nbor, father, active list), uold, unew before and unew after.
+
+    oracle/build_ref.sh ramses 3 serial oracle/dump_patch     # -> oracle/_ref/ramses3d_dump_patch
+    python tests/golden/make_golden_amr.py                    # -> tests/golden/amr_godunov_ref.npz
+"""
+import os
+import shutil
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import ramses_snapshot as rs  # noqa: E402
+
+REFINE = """&REFINE_PARAMS
+interpol_var={ivar}
+interpol_type={itype}
+err_grad_p=0.1
+/
+"""
+# (tag, levelmin, levelmax, nsubcycle, riemann, slope, interpol_var, interpol_type, nstep, calls to dump)
+CASES = [
+    ("a", 3, 5, "1,1,2,2", "llf", 1, 0, 2, 6, (8, 9, 13)),
+    ("b", 3, 5, "10*1", "hllc", 2, 1, 1, 4, (5, 6, 7)),
+]
+
+
+def read_dump(work, k):
+    fi = os.path.join(work, "godunov_%04d_in.bin" % k)
+    fo = os.path.join(work, "godunov_%04d_out.bin" % k)
+    with open(fi, "rb") as fh:
+        hdr = np.fromfile(fh, np.int32, 9)
+        ilevel, ngrid, ngridmax, ncoarse, nvar, nvector, nlevelmax, ivar, itype = [int(x) for x in hdr]
+        dx, dt, gamma, smallr, smallc = np.fromfile(fh, np.float64, 5)
+        igrid = np.fromfile(fh, np.int32, ngrid)
+        ncell = ncoarse + 8 * ngridmax
+        son = np.fromfile(fh, np.int32, ncell)
+        nbor = np.fromfile(fh, np.int32, ngridmax * 6).reshape(6, ngridmax)
+        father = np.fromfile(fh, np.int32, ngridmax)
+        uold = np.fromfile(fh, np.float64, ncell * nvar).reshape(nvar, ncell)
+        unew = np.fromfile(fh, np.float64, ncell * nvar).reshape(nvar, ncell)
+        assert fh.read() == b""
+    unew_out = np.fromfile(fo, np.float64).reshape(nvar, ncell)
+    return dict(meta=np.array([ilevel, ngrid, ngridmax, ncoarse, nvar, nvector, nlevelmax, ivar, itype], np.int64),
+                real=np.array([dx, dt, gamma, smallr, smallc]), igrid=igrid, son=son, nbor=nbor, father=father,
+                uold=uold, unew=unew, unew_out=unew_out)
+
+
+def main():
+    binary = os.path.join(ROOT, "oracle", "_ref", "ramses3d_dump_patch")
+    out = {}
+    for tag, lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, calls in CASES:
+        nml = rs.sedov3d_namelist(level=lmin, nstepmax=nstep, foutput=1000, riemann=riemann, slope_type=slope,
+                                  extra=REFINE.format(ivar=ivar, itype=itype), mem_factor=1.0)
+        nml = nml.replace("levelmax=%d" % lmin, "levelmax=%d" % lmax).replace("nsubcycle=10*1", "nsubcycle=" + nsub)
+        nml = nml.replace("ngridtot=", "ngridtot=3000 !")
+        os.environ["RAMSES_DUMP_CALLS"] = ",".join(str(c) for c in calls)
+        work, log = rs.run_reference(nml, binary=binary)
+        try:
+            for c in calls:
+                d = read_dump(work, c)
+                print(tag, c, "level", d["meta"][0], "ngrid", d["meta"][1], "changed cells",
+                      int((d["unew"] != d["unew_out"]).any(0).sum()))
+                for k, v in d.items():
+                    out["%s%d_%s" % (tag, c, k)] = v
+            out[tag + "_riemann"] = np.array(riemann)
+            out[tag + "_slope"] = np.array(slope)
+            out[tag + "_calls"] = np.array(calls)
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    path = os.path.join(ROOT, "tests", "golden", "amr_godunov_ref.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
