@@ -299,6 +299,16 @@ int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ileve
                                      const int *father, int64_t ngridmax, int64_t ncoarse,
                                      const double *uold, double *unew, double dx, double dt,
                                      int nvector, int interpol_var, int interpol_type);
+/* the same with every array already on the device; d_work holds
+ * ramses_amd_godunov_fine_amr_workspace(ngrid, ngridmax) bytes, *d_err (zeroed by the
+ * caller) counts tree inconsistencies */
+int64_t ramses_amd_godunov_fine_amr_workspace(int ngrid, int64_t ngridmax);
+int ramses_amd_godunov_fine_amr_device(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                       const int *d_igrid, const int *d_son, const int *d_nbor,
+                                       const int *d_father, int64_t ngridmax, int64_t ncoarse,
+                                       const double *d_uold, double *d_unew, double dx, double dt,
+                                       int nvector, int interpol_var, int interpol_type,
+                                       void *d_work, int *d_err, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Distributed multigrid: one rank's n^3 brick of a periodic level with ng

@@ -77,6 +77,8 @@ SYMBOLS = [
     ("ramses_amd_godunov_fine_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _i, _d, _d]),
     ("ramses_amd_mg_smooth_fused_ghost", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _i, _vp]),
     ("ramses_amd_godunov_fine_amr_host", _i, [_PP, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _d, _d, _i, _i, _i]),
+    ("ramses_amd_godunov_fine_amr_workspace", _i64, [_i, _i64]),
+    ("ramses_amd_godunov_fine_amr_device", _i, [_PP, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _d, _d, _i, _i, _i, _vp, _vp, _vp]),
     ("ramses_amd_mg_rhs", _i, [_vp, _vp, _i64, _d, _d, _vp]),
     ("ramses_amd_mg_restrict_ghost", _i, [_vp, _vp, _i, _i, _i, _vp]),
     ("ramses_amd_mg_interp_correct_ghost", _i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),

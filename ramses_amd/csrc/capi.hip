@@ -617,12 +617,13 @@ int ramses_amd_godunov_fine_host(const ramses_amd_hydro_params *p, int ilevel, i
 // interpolated stencil cells, zeroed fluxes at refined interfaces, += onto the
 // unew that already holds the finer level's corrections, corrections owed to
 // the coarser level).  Works directly on the reference's tree arrays.
-int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
-                                     const int *igrid, const int *son, const int *nbor,
-                                     const int *father, int64_t ngridmax, int64_t ncoarse,
-                                     const double *uold, double *unew, double dx, double dt,
-                                     int nvector, int interpol_var, int interpol_type) {
-  if (!p || !igrid || !son || !nbor || !father || !uold || !unew) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+// workspace of the device entry point, in bytes
+int64_t ramses_amd_godunov_fine_amr_workspace(int ngrid, int64_t ngridmax) {
+  if (ngrid < 0 || ngridmax < 1) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  return (int64_t)(sizeof(double) * (size_t)ngrid * 6 * 4 * 5 + sizeof(int) * (size_t)ngrid * 6 + sizeof(int) * (size_t)ngridmax + 64);
+}
+
+static int amr_check(const ramses_amd_hydro_params *p, int ilevel, int nvector, int interpol_var, int interpol_type) {
   if (p->ndim != 3 || p->nvar != 5) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep implements NDIM=3, NVAR=5");
   if (p->scheme != 0) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep implements scheme='muscl'");
   if (p->slope_type == 3) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep does not implement slope_type=3");
@@ -630,11 +631,53 @@ int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ileve
   if (ilevel < 3) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep needs ilevel >= 3 (father cells inside octs); got %d", ilevel);
   if (nvector < 1) return fail(RAMSES_AMD_EINVAL, "nvector must be >= 1");
   if (interpol_var < 0 || interpol_var > 2 || interpol_type < 0 || interpol_type > 4) return fail(RAMSES_AMD_EINVAL, "interpol_var/interpol_type out of range");
+  return 0;
+}
+
+// all arrays resident on the device; d_work: ramses_amd_godunov_fine_amr_workspace bytes.
+// d_err (one int, zeroed by the caller) counts tree inconsistencies.
+int ramses_amd_godunov_fine_amr_device(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                       const int *d_igrid, const int *d_son, const int *d_nbor,
+                                       const int *d_father, int64_t ngridmax, int64_t ncoarse,
+                                       const double *d_uold, double *d_unew, double dx, double dt,
+                                       int nvector, int interpol_var, int interpol_type,
+                                       void *d_work, int *d_err, void *stream) {
+  if (!p || !d_igrid || !d_son || !d_nbor || !d_father || !d_uold || !d_unew || !d_work || !d_err) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (int rc = amr_check(p, ilevel, nvector, interpol_var, interpol_type)) return rc;
+  if (ngrid <= 0) return 0;
+  AmrSweepArgs A;
+  A.uold = d_uold; A.unew = d_unew;
+  A.son = d_son; A.nbor = d_nbor; A.father = d_father;
+  A.igrid = d_igrid; A.ngrid = ngrid;
+  A.ncell = ncoarse + 8 * ngridmax; A.ncoarse = ncoarse; A.ngridmax = ngridmax;
+  A.dt = dt; A.dx = dx; A.rdx = 1.0 / dx;
+  { int ex; A.pow2 = (std::frexp(dx, &ex) == 0.5) ? 1 : 0; }
+  A.interpol_var = interpol_var; A.interpol_type = interpol_type;
+  char *w = reinterpret_cast<char *>(d_work);
+  A.corr = reinterpret_cast<double *>(w);
+  w += sizeof(double) * (size_t)ngrid * 6 * 4 * 5;
+  A.corr_tgt = reinterpret_cast<int *>(w);
+  w += sizeof(int) * (size_t)ngrid * 6;
+  int *posof = reinterpret_cast<int *>(w);
+  A.err = d_err;
+  A.P = make_const(p);
+  hipError_t e = launch_amr_godunov(A, p->slope_type, p->riemann, posof, nvector, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hipfail(e, "AMR godunov launch");
+  return 0;
+}
+
+int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                     const int *igrid, const int *son, const int *nbor,
+                                     const int *father, int64_t ngridmax, int64_t ncoarse,
+                                     const double *uold, double *unew, double dx, double dt,
+                                     int nvector, int interpol_var, int interpol_type) {
+  if (!p || !igrid || !son || !nbor || !father || !uold || !unew) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (int rc = amr_check(p, ilevel, nvector, interpol_var, interpol_type)) return rc;
   if (ngrid <= 0) return 0;
   const long ncell = ncoarse + 8 * ngridmax;
   hipStream_t s = nullptr;
   HostCtx &H = g_host;
-  static DevBuf dson, dnbor, dfather, dcorr, dtgt, dposof;
+  static DevBuf dson, dnbor, dfather, dwork;
 #define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipfail(e_, what); } while (0)
   HCHK(H.uold.ensure(sizeof(double) * 5 * ncell), "hipMalloc uold");
   HCHK(H.unew.ensure(sizeof(double) * 5 * ncell), "hipMalloc unew");
@@ -642,9 +685,7 @@ int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ileve
   HCHK(dson.ensure(sizeof(int) * ncell), "hipMalloc son");
   HCHK(dnbor.ensure(sizeof(int) * 6 * ngridmax), "hipMalloc nbor");
   HCHK(dfather.ensure(sizeof(int) * ngridmax), "hipMalloc father");
-  HCHK(dcorr.ensure(sizeof(double) * (size_t)ngrid * 6 * 4 * 5), "hipMalloc corr");
-  HCHK(dtgt.ensure(sizeof(int) * (size_t)ngrid * 6), "hipMalloc tgt");
-  HCHK(dposof.ensure(sizeof(int) * ngridmax), "hipMalloc posof");
+  HCHK(dwork.ensure((size_t)ramses_amd_godunov_fine_amr_workspace(ngrid, ngridmax)), "hipMalloc work");
   HCHK(H.flag.ensure(sizeof(int)), "hipMalloc flag");
   HCHK(hipMemcpyAsync(H.uold.p, uold, sizeof(double) * 5 * ncell, hipMemcpyHostToDevice, s), "H2D uold");
   HCHK(hipMemcpyAsync(H.unew.p, unew, sizeof(double) * 5 * ncell, hipMemcpyHostToDevice, s), "H2D unew");
@@ -653,24 +694,17 @@ int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ileve
   HCHK(hipMemcpyAsync(dnbor.p, nbor, sizeof(int) * 6 * ngridmax, hipMemcpyHostToDevice, s), "H2D nbor");
   HCHK(hipMemcpyAsync(dfather.p, father, sizeof(int) * ngridmax, hipMemcpyHostToDevice, s), "H2D father");
   HCHK(hipMemsetAsync(H.flag.p, 0, sizeof(int), s), "memset");
-  AmrSweepArgs A;
-  A.uold = H.uold.as<double>(); A.unew = H.unew.as<double>();
-  A.son = dson.as<int>(); A.nbor = dnbor.as<int>(); A.father = dfather.as<int>();
-  A.igrid = H.igrid.as<int>(); A.ngrid = ngrid;
-  A.ncell = ncell; A.ncoarse = ncoarse; A.ngridmax = ngridmax;
-  A.dt = dt; A.dx = dx; A.rdx = 1.0 / dx;
-  { int ex; A.pow2 = (std::frexp(dx, &ex) == 0.5) ? 1 : 0; }
-  A.interpol_var = interpol_var; A.interpol_type = interpol_type;
-  A.corr = dcorr.as<double>(); A.corr_tgt = dtgt.as<int>(); A.err = H.flag.as<int>();
-  A.P = make_const(p);
-  HCHK(launch_amr_godunov(A, p->slope_type, p->riemann, dposof.as<int>(), nvector, s), "AMR godunov launch");
+  g_host.res_valid = false;   // the staging buffers are reused
+  if (int rc = ramses_amd_godunov_fine_amr_device(p, ilevel, ngrid, H.igrid.as<int>(), dson.as<int>(), dnbor.as<int>(),
+                                                  dfather.as<int>(), ngridmax, ncoarse, H.uold.as<double>(),
+                                                  H.unew.as<double>(), dx, dt, nvector, interpol_var, interpol_type,
+                                                  dwork.p, H.flag.as<int>(), s)) return rc;
   int bad = 0;
   HCHK(hipMemcpyAsync(&bad, H.flag.p, sizeof(int), hipMemcpyDeviceToHost, s), "D2H flag");
   HCHK(hipMemcpyAsync(unew, H.unew.p, sizeof(double) * 5 * ncell, hipMemcpyDeviceToHost, s), "D2H unew");
   HCHK(hipStreamSynchronize(s), "sync");
 #undef HCHK
   if (bad) return fail(RAMSES_AMD_EINVAL, "level %d: %d of the 3^3 father cells of an oct do not exist (tree inconsistent)", ilevel, bad);
-  g_host.res_valid = false;   // the staging buffers were reused
   return 0;
 }
 

@@ -66,6 +66,7 @@ subroutine godunov_fine(ilevel)
   type(ramses_amd_hydro_params)::p
   integer::rc,nx_loc,has_f
   real(dp)::scale,dx
+  logical::amr_level
 
   if(numbtot(1,ilevel)==0)return
   if(static)return
@@ -91,7 +92,23 @@ subroutine godunov_fine(ilevel)
   scale=boxlen/dble(nx_loc)
   dx=0.5d0**ilevel*scale
 
-  if(ramses_amd_resident())then
+  ! A level with refined cells, or one that does not cover the box, takes the AMR
+  ! sweep (one wavefront per oct on the tree arrays); a fully refined level without
+  ! finer octs takes the dense brick sweep.
+  amr_level=.false.
+  if(ilevel<nlevelmax)then
+     if(numbtot(1,ilevel+1)>0)amr_level=.true.
+  end if
+  if(int(active(ilevel)%ngrid,8)*8_8/=(2_8**ilevel)**3*int(nx_loc,8)**3)amr_level=.true.
+
+  if(amr_level)then
+     if(poisson)then
+        write(*,*)'ramses_amd: the AMR sweep has no gravity predictor yet (poisson=.true. on an AMR level)'
+        call ramses_amd_fatal('godunov_fine (AMR level with gravity)')
+     end if
+     rc=ramses_amd_godunov_fine_amr_host(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,son,nbor,father, &
+          & int(ngridmax,8),int(ncoarse,8),uold,unew,dx,dtnew(ilevel),nvector,interpol_var,interpol_type)
+  else if(ramses_amd_resident())then
      ! state already on the device (loaded by courant_fine or here); unew stays there
      rc=ramses_amd_resident_godunov_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
           & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,dx,dtnew(ilevel))

@@ -53,14 +53,18 @@ def read_dump(work, k):
                 uold=uold, unew=unew, unew_out=unew_out)
 
 
+def amr_namelist(lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, foutput=1):
+    nml = rs.sedov3d_namelist(level=lmin, nstepmax=nstep, foutput=foutput, riemann=riemann, slope_type=slope,
+                              extra=REFINE.format(ivar=ivar, itype=itype), mem_factor=1.0)
+    nml = nml.replace("levelmax=%d" % lmin, "levelmax=%d" % lmax).replace("nsubcycle=10*1", "nsubcycle=" + nsub)
+    return nml.replace("ngridtot=", "ngridtot=3000 !")
+
+
 def main():
     binary = os.path.join(ROOT, "oracle", "_ref", "ramses3d_dump_patch")
     out = {}
     for tag, lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, calls in CASES:
-        nml = rs.sedov3d_namelist(level=lmin, nstepmax=nstep, foutput=1000, riemann=riemann, slope_type=slope,
-                                  extra=REFINE.format(ivar=ivar, itype=itype), mem_factor=1.0)
-        nml = nml.replace("levelmax=%d" % lmin, "levelmax=%d" % lmax).replace("nsubcycle=10*1", "nsubcycle=" + nsub)
-        nml = nml.replace("ngridtot=", "ngridtot=3000 !")
+        nml = amr_namelist(lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, foutput=1000)
         os.environ["RAMSES_DUMP_CALLS"] = ",".join(str(c) for c in calls)
         work, log = rs.run_reference(nml, binary=binary)
         try:
@@ -73,6 +77,20 @@ def main():
             out[tag + "_riemann"] = np.array(riemann)
             out[tag + "_slope"] = np.array(slope)
             out[tag + "_calls"] = np.array(calls)
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    # end-to-end: leaf cells of the snapshots of the untouched reference program
+    for tag, lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, calls in CASES:
+        nml = amr_namelist(lmin, lmax, nsub, riemann, slope, ivar, itype, nstep)
+        work, log = rs.run_reference(nml)
+        try:
+            for k in (1, nstep + 1):
+                snap = rs.load_leaf_cells(os.path.join(work, "output_%05d" % k))
+                order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+                out["%s_e2e%d_level" % (tag, k)] = snap["level"][order].astype(np.int8)
+                out["%s_e2e%d_x" % (tag, k)] = snap["x"][order]
+                out["%s_e2e%d_prim" % (tag, k)] = snap["prim"][:, order]
+            print(tag, "e2e leaf cells", snap["level"].size, "levels", np.unique(snap["level"]))
         finally:
             shutil.rmtree(work, ignore_errors=True)
     path = os.path.join(ROOT, "tests", "golden", "amr_godunov_ref.npz")
