@@ -282,6 +282,14 @@ int ramses_amd_multigrid_fine_f90(int ilevel, int ngrid, const int *igrid, const
                                   double fourpi, double epsilon, int *safe_mode,
                                   int *iters, double *err);
 
+/* make_boundary_hydro (hydro/hydro_boundary.f90:5-269) on a ghost-layer brick: fills the
+ * ghost layers of one face (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z) over the full extent of the
+ * other directions.  bound_type is the reference's code: face+1 reflexive, 10+face+1
+ * outflow, 20+face+1 imposed (conserved state `imposed[nvar]`, boundana).  Call the faces
+ * in x, y, z order, after the periodic/halo fill of the other faces. */
+int ramses_amd_make_boundary_hydro(const ramses_amd_hydro_params *p, const ramses_amd_brick *b, double *d_uold,
+                                   int face, int bound_type, const double *imposed, int no_inflow, void *stream);
+
 /* ---------------------------------------------------------------------------
  * godunov_fine(ilevel) on an AMR level (hydro/godunov_fine.f90:5-35, godfine1
  * :486-911 with every AMR branch: stencil cells of missing octs interpolated

@@ -61,7 +61,9 @@ static bool is_pow2(double x) {
 
 static int check_brick(const ramses_amd_brick *b) {
   if (!b) return fail(RAMSES_AMD_EINVAL, "brick is NULL");
-  if (b->nx < 2 || b->ny < 2 || b->nz < 2) return fail(RAMSES_AMD_EINVAL, "brick must have >=2 cells per direction (got %d %d %d)", b->nx, b->ny, b->nz);
+  // a direction of extent 1 (an embedded 1-D/2-D problem) needs ghost layers: the in-kernel wrap assumes n >= 2
+  const int nmin = b->ng >= 2 ? 1 : 2;
+  if (b->nx < 2 || b->ny < nmin || b->nz < nmin) return fail(RAMSES_AMD_EINVAL, "brick must have >=2 cells per direction, or 1 in y/z with ghost layers (got %d %d %d, ng=%d)", b->nx, b->ny, b->nz, b->ng);
   if (b->ng != 0 && b->ng < 2) return fail(RAMSES_AMD_EINVAL, "ghost width must be 0 or >=2 (got %d)", b->ng);
   if (b->pitch_y < b->nx + 2 * b->ng) return fail(RAMSES_AMD_EINVAL, "pitch_y too small");
   if (b->pitch_z < b->pitch_y * (b->ny + 2 * b->ng)) return fail(RAMSES_AMD_EINVAL, "pitch_z too small");
@@ -110,6 +112,17 @@ int ramses_amd_godunov_tune(int tile_rows, int zchunk) {
   return 0;
 }
 
+// NDIM < 3: the 1-D/2-D problem is embedded in the brick (ny and/or nz = 1, ghost
+// layers of the unused directions filled periodically = copies of the cell): the
+// transverse slopes and flux differences vanish identically, so the 3-D kernels
+// return the 1-D/2-D result of the reference bit for bit; cmpdt takes dble(ndim).
+static int check_ndim(const ramses_amd_hydro_params *p, const ramses_amd_brick *b) {
+  if (p->ndim < 1 || p->ndim > 3) return fail(RAMSES_AMD_EINVAL, "NDIM must be 1, 2 or 3 (got %d)", p->ndim);
+  if (p->ndim < 3 && (b->nz != 1 || b->ng < 2)) return fail(RAMSES_AMD_EINVAL, "NDIM=%d needs a brick with nz=1 and ghost layers (got nz=%d, ng=%d)", p->ndim, b->nz, b->ng);
+  if (p->ndim < 2 && b->ny != 1) return fail(RAMSES_AMD_EINVAL, "NDIM=1 needs a brick with ny=nz=1 (got ny=%d)", b->ny);
+  return 0;
+}
+
 static int godunov_brick_region(const ramses_amd_hydro_params *p, const ramses_amd_brick *b,
                                 const double *d_uold, const double *d_grav, double *d_unew,
                                 double dx, double dt, int region_first, int region_last, void *stream) {
@@ -117,7 +130,7 @@ static int godunov_brick_region(const ramses_amd_hydro_params *p, const ramses_a
   if (int rc = check_brick(b)) return rc;
   if (!d_uold || !d_unew) return fail(RAMSES_AMD_EINVAL, "uold/unew device pointers are NULL");
   if (d_uold == d_unew) return fail(RAMSES_AMD_EINVAL, "uold and unew must be distinct buffers");
-  if (p->ndim != 3) return fail(RAMSES_AMD_EUNSUPPORTED, "device sweep implements NDIM=3 (got %d)", p->ndim);
+  if (int rc = check_ndim(p, b)) return rc;
   if (p->nvar < 5 || p->nvar > 7) return fail(RAMSES_AMD_EUNSUPPORTED, "device sweep implements NVAR=5..7 (up to two passive scalars; got %d)", p->nvar);
   if (p->nvar != 5 && p->scheme != RAMSES_AMD_SCHEME_MUSCL) return fail(RAMSES_AMD_EUNSUPPORTED, "passive scalars with scheme='plmde' are not on the device yet");
   if (p->scheme != RAMSES_AMD_SCHEME_MUSCL && p->scheme != RAMSES_AMD_SCHEME_PLMDE) return fail(RAMSES_AMD_EINVAL, "unknown scheme %d", p->scheme);
@@ -178,7 +191,8 @@ int ramses_amd_courant_brick(const ramses_amd_hydro_params *p, const ramses_amd_
                              double *d_out, void *stream) {
   if (!p || !d_uold || !d_out) return fail(RAMSES_AMD_EINVAL, "NULL argument");
   if (int rc = check_brick(b)) return rc;
-  if (p->ndim != 3 || p->nvar < 5) return fail(RAMSES_AMD_EUNSUPPORTED, "device courant implements NDIM=3, NVAR>=5 (passive scalars do not enter cmpdt)");
+  if (int rc = check_ndim(p, b)) return rc;
+  if (p->nvar < 5) return fail(RAMSES_AMD_EUNSUPPORTED, "device courant needs the 5 hydro variables (passive scalars do not enter cmpdt)");
   CourantArgs A;
   A.uold = d_uold; A.grav = d_grav; A.out = d_out;
   A.nx = b->nx; A.ny = b->ny; A.nz = b->nz; A.ng = b->ng;
@@ -186,9 +200,36 @@ int ramses_amd_courant_brick(const ramses_amd_hydro_params *p, const ramses_amd_
   A.dx = dx; A.vol = dx * dx * dx;
   A.courant_factor = p->courant_factor;
   A.dt_init = p->courant_factor * dx / p->smallc;
+  A.ndimf = (double)p->ndim;
   A.P = make_const(p);
   hipError_t e = launch_courant(A, d_grav != nullptr, reinterpret_cast<hipStream_t>(stream));
   if (e != hipSuccess) return hipfail(e, "courant launch");
+  return 0;
+}
+
+// make_boundary_hydro (hydro/hydro_boundary.f90:5-269) for one face of a ghost-layer brick
+int ramses_amd_make_boundary_hydro(const ramses_amd_hydro_params *p, const ramses_amd_brick *b, double *d_uold,
+                                   int face, int bound_type, const double *imposed, int no_inflow, void *stream) {
+  if (!p || !d_uold) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (int rc = check_brick(b)) return rc;
+  if (b->ng < 1) return fail(RAMSES_AMD_EINVAL, "physical boundaries need a brick with ghost layers");
+  if (face < 0 || face > 5) return fail(RAMSES_AMD_EINVAL, "face must be 0..5");
+  if (p->nvar < 5 || p->nvar > 8) return fail(RAMSES_AMD_EUNSUPPORTED, "NVAR=%d", p->nvar);
+  BoundaryArgs A;
+  A.u = d_uold; A.nx = b->nx; A.ny = b->ny; A.nz = b->nz; A.ng = b->ng; A.nvar = p->nvar;
+  A.pitch_y = b->pitch_y; A.pitch_z = b->pitch_z; A.pitch_var = b->pitch_var;
+  A.face = face; A.no_inflow = no_inflow ? 1 : 0; A.smallr = p->smallr;
+  // bound_type: the reference's codes 1..6 reflexive, 11..16 outflow, 21..26 imposed (direction = face)
+  const int kind = bound_type / 10;
+  if (kind < 0 || kind > 2 || bound_type % 10 != face + 1) return fail(RAMSES_AMD_EINVAL, "bound_type %d does not belong to face %d", bound_type, face);
+  A.type = kind + 1;
+  for (int v = 0; v < 8; v++) A.value[v] = 0.0;
+  if (A.type == 3) {
+    if (!imposed) return fail(RAMSES_AMD_EINVAL, "imposed boundary needs the conserved state");
+    for (int v = 0; v < p->nvar; v++) A.value[v] = imposed[v];
+  }
+  hipError_t e = launch_boundary(A, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hipfail(e, "boundary launch");
   return 0;
 }
 

@@ -651,7 +651,7 @@ RA_DEV void scaled_interface_flux(const double (&qL)[NV], const double (&qR)[NV]
 // ---------------------------------------------------------------------------
 template <int NV, bool GRAV>
 RA_DEV double cmpdt_cell(const double (&u)[NV], const double (&g)[3], double dx,
-                         double courant_factor, const HydroConst &P) {
+                         double courant_factor, const HydroConst &P, double ndimf = 3.0) {
   const double rho = dmaxd(u[0], P.smallr);
   const double vx = u[1] / rho, vy = u[2] / rho, vz = u[3] / rho;
   double e = u[4];
@@ -661,7 +661,7 @@ RA_DEV double cmpdt_cell(const double (&u)[NV], const double (&g)[3], double dx,
   double pc = dmaxd(P.gm1 * e, rho * P.smallp);
   pc = P.gamma * pc;
   pc = __builtin_sqrt(pc / rho);
-  pc = 3.0 * pc;
+  pc = ndimf * pc;   // dble(ndim)*c: 1-D/2-D problems embedded in a brick keep their own NDIM
   pc = pc + __builtin_fabs(vx);
   pc = pc + __builtin_fabs(vy);
   pc = pc + __builtin_fabs(vz);

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void courant_kernel(CourantArgs A) {
 #pragma unroll
         for (int d = 0; d < 3; d++) g[d] = A.grav[base + i + (long)d * A.pitch_var];
       }
-      dtmin = __builtin_fmin(dtmin, cmpdt_cell<NV, GRAV>(u, g, A.dx, A.courant_factor, P));
+      dtmin = __builtin_fmin(dtmin, cmpdt_cell<NV, GRAV>(u, g, A.dx, A.courant_factor, P, A.ndimf));
       mass += u[0] * A.vol;
       etot += u[4] * A.vol;
       double ei = u[4] * A.vol;
@@ -137,6 +137,75 @@ hipError_t launch_box_copy(const BoxCopyArgs &A, hipStream_t s) {
   long grid = (nrows + 3) / 4;
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(box_copy_kernel, dim3((int)grid), dim3(256), 0, s, A);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// make_boundary_hydro (hydro/hydro_boundary.f90:5-269) on a ghost-layer brick:
+// the ghost layers of one face, over the full extent of the other directions
+// (call the faces in x, y, z order so that edges and corners are filled from
+// already filled ghosts, as the halo exchange does).
+//   reflexive: ghost cell g layers outside the wall = interior cell g layers
+//              inside (ind_ref = mirror octant), normal momentum sign flipped
+//   outflow:   every ghost layer = the first interior layer (ind_ref = the
+//              boundary-side octant), optional no_inflow clamp with the kinetic
+//              energy removed before and added back after
+//   imposed:   boundana's constant state
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void boundary_kernel(BoundaryArgs A) {
+  const int axis = A.face >> 1, hi = A.face & 1;
+  const int n[3] = {A.nx, A.ny, A.nz};
+  int ext[3] = {A.nx + 2 * A.ng, A.ny + 2 * A.ng, A.nz + 2 * A.ng};
+  ext[axis] = A.ng;
+  const long total = (long)ext[0] * ext[1] * ext[2];
+  const long pitch[3] = {1, A.pitch_y, A.pitch_z};
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    int c[3];
+    c[0] = (int)(t % ext[0]);
+    c[1] = (int)((t / ext[0]) % ext[1]);
+    c[2] = (int)(t / ((long)ext[0] * ext[1]));
+    const int layer = c[axis];                    // 0 .. ng-1, counted from the wall outwards
+    int cg[3] = {c[0], c[1], c[2]}, cr[3] = {c[0], c[1], c[2]};
+    // allocated coordinates of the ghost cell and of its reference cell
+    cg[axis] = hi ? A.ng + n[axis] + layer : A.ng - 1 - layer;
+    const int mirror = A.type == 1 ? layer : 0;
+    cr[axis] = hi ? A.ng + n[axis] - 1 - mirror : A.ng + mirror;
+    const long og = cg[0] * pitch[0] + cg[1] * pitch[1] + cg[2] * pitch[2];
+    const long orf = cr[0] * pitch[0] + cr[1] * pitch[1] + cr[2] * pitch[2];
+    if (A.type == 3) {
+      for (int v = 0; v < A.nvar; v++) A.u[og + (long)v * A.pitch_var] = A.value[v];
+      continue;
+    }
+    double uu[8];
+    for (int v = 0; v < A.nvar; v++) uu[v] = A.u[orf + (long)v * A.pitch_var];
+    if (A.type == 1) {
+      uu[1 + axis] = uu[1 + axis] * -1.0;
+    } else {
+      // free boundary: the reference takes the kinetic energy out and puts it back
+      // (around the optional no_inflow clamp) -- (E - ek) + ek is kept as is
+      double ekin = 0.0;
+      double d = __builtin_fmax(uu[0], A.smallr);
+      for (int k = 0; k < 3; k++) { const double vel = uu[1 + k] / d; ekin = ekin + 0.5 * d * (vel * vel); }
+      uu[4] = uu[4] - ekin;
+      if (A.no_inflow) uu[1 + axis] = hi ? __builtin_fmax(0.0, uu[1 + axis]) : __builtin_fmin(0.0, uu[1 + axis]);
+      ekin = 0.0;
+      d = __builtin_fmax(uu[0], A.smallr);
+      for (int k = 0; k < 3; k++) { const double vel = uu[1 + k] / d; ekin = ekin + 0.5 * d * (vel * vel); }
+      uu[4] = uu[4] + ekin;
+    }
+    for (int v = 0; v < A.nvar; v++) A.u[og + (long)v * A.pitch_var] = uu[v];
+  }
+}
+
+hipError_t launch_boundary(const BoundaryArgs &A, hipStream_t s) {
+  const int axis = A.face >> 1;
+  long ext[3] = {A.nx + 2 * A.ng, A.ny + 2 * A.ng, A.nz + 2 * A.ng};
+  ext[axis] = A.ng;
+  const long total = ext[0] * ext[1] * ext[2];
+  if (total <= 0) return hipSuccess;
+  long grid = (total + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(boundary_kernel, dim3((int)grid), dim3(256), 0, s, A);
   return hipGetLastError();
 }
 

@@ -11,6 +11,7 @@ struct CourantArgs {
   int nx, ny, nz, ng;
   long pitch_y, pitch_z, pitch_var;
   double dx, vol, courant_factor, dt_init;
+  double ndimf;         // NDIM of the problem (1, 2: embedded in the brick with ny and/or nz = 1)
   HydroConst P;
 };
 
@@ -26,5 +27,18 @@ struct BoxCopyArgs {
 hipError_t launch_courant_init(double *out, double dt_init, hipStream_t s);
 hipError_t launch_courant(const CourantArgs &A, bool grav, hipStream_t s);
 hipError_t launch_box_copy(const BoxCopyArgs &A, hipStream_t s);
+
+// physical boundary of one face of a ghost-layer brick (make_boundary_hydro)
+struct BoundaryArgs {
+  double *u;
+  int nx, ny, nz, ng, nvar;
+  long pitch_y, pitch_z, pitch_var;
+  int face;             // 0:-x 1:+x 2:-y 3:+y 4:-z 5:+z
+  int type;             // 1 reflexive, 2 outflow (zero gradient), 3 imposed
+  int no_inflow;
+  double smallr;
+  double value[8];      // imposed conserved state
+};
+hipError_t launch_boundary(const BoundaryArgs &A, hipStream_t s);
 
 }  // namespace ramses_amd

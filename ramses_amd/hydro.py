@@ -41,7 +41,13 @@ class HydroLevel:
     filled by make_virtual_fine_dp (periodic self-copy or the RCCL exchange).
     """
 
-    def __init__(self, nx, ny, nz, dx, params=None, ng=0, device="cuda", poisson=False):
+    def __init__(self, nx, ny, nz, dx, params=None, ng=0, device="cuda", poisson=False, bound_type=None,
+                 bound_state=None, no_inflow=False):
+        """bound_type: {face: code} with the reference's &BOUNDARY_PARAMS codes
+        (face 0:-x 1:+x 2:-y 3:+y 4:-z 5:+z; code face+1 reflexive, 10+face+1
+        outflow, 20+face+1 imposed with bound_state[face] = conserved state);
+        faces without an entry are periodic.  Needs ng >= 2.
+        NDIM < 3 (params.ndim): ny and/or nz = 1, the brick keeps 5 variables."""
         if not torch.cuda.is_available():
             raise _capi.RamsesAmdError("HydroLevel needs a GPU (torch.cuda.is_available() is False); "
                                        "there is no CPU fallback")
@@ -58,6 +64,15 @@ class HydroLevel:
             self.f = torch.zeros((3,) + shape[1:], dtype=torch.float64, device=self.device)
         self._red = torch.zeros(4, dtype=torch.float64, device=self.device)
         self.dtnew = 0.0
+        self.bound_type = dict(bound_type or {})
+        self.bound_state = dict(bound_state or {})
+        self.no_inflow = bool(no_inflow)
+        if self.bound_type and ng < 2:
+            raise _capi.RamsesAmdError("physical boundaries need ghost layers (ng >= 2)")
+        for face in (0, 2, 4):
+            if (face in self.bound_type) != (face + 1 in self.bound_type):
+                raise _capi.RamsesAmdError("a direction is either periodic or has a boundary on both faces")
+        self._periodic_axes = sum(1 << a for a in range(3) if 2 * a not in self.bound_type)
 
     # -- views ---------------------------------------------------------------
     def interior(self, t=None):
@@ -80,11 +95,23 @@ class HydroLevel:
         """Single-rank periodic limit of the forward halo exchange: refresh the
         ghost octs of uold from the opposite interior face (no-op for ng=0)."""
         if self.ng:
-            check(lib().ramses_amd_fill_ghosts_periodic(C.byref(self.brick), _ptr(self.uold),
-                                                        self.nvar, 7, _stream()))
-            if self.f is not None:
-                check(lib().ramses_amd_fill_ghosts_periodic(C.byref(self.brick), _ptr(self.f),
-                                                            3, 7, _stream()))
+            for axis in range(3):
+                if self._periodic_axes & (1 << axis):
+                    check(lib().ramses_amd_fill_ghosts_periodic(C.byref(self.brick), _ptr(self.uold),
+                                                                self.nvar, 1 << axis, _stream()))
+                    if self.f is not None:
+                        check(lib().ramses_amd_fill_ghosts_periodic(C.byref(self.brick), _ptr(self.f),
+                                                                    3, 1 << axis, _stream()))
+                else:
+                    self.make_boundary_hydro(axis)
+
+    def make_boundary_hydro(self, axis):
+        """make_boundary_hydro (hydro/hydro_boundary.f90:5-269) for the two faces of one direction."""
+        for face in (2 * axis, 2 * axis + 1):
+            st = self.bound_state.get(face)
+            buf = (C.c_double * self.nvar)(*st) if st is not None else None
+            check(lib().ramses_amd_make_boundary_hydro(C.byref(self.params), C.byref(self.brick), _ptr(self.uold), face,
+                                                       int(self.bound_type[face]), buf, int(self.no_inflow), _stream()))
 
     def courant_fine(self):
         """CFL time step of the level -> (dt, mass, etot, eint); also sets dtnew."""
