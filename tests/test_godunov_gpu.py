@@ -187,3 +187,40 @@ def test_gravity_predictor_path(gpu_lib, oracle):
         assert dtc == oracle.courant_uniform(po, u, dx, 0.7, grav=g)
         ref = oracle.godunov_uniform(po, u, dx, dt, grav=g)
         assert np.array_equal(lev.download(lev.unew), ref)
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_full_size_properties_512(gpu_lib, fast):
+    """BASELINE's metric configuration (512^3 per GPU) through size-independent
+    properties, no oracle needed:
+      * translation: sweeping a periodically shifted state == shifting the swept
+        state, bit for bit (every tile edge, z-chunk seam and wrap is crossed by
+        different data);
+      * conservation: the periodic sums of the conserved variables do not change
+        beyond rounding."""
+    import torch
+    import ramses_amd
+    from ramses_amd.hydro import HydroLevel
+    n = 512
+    p = ramses_amd.make_params(courant_factor=0.8, fast_math=fast)
+    lev = HydroLevel(n, n, n, 0.5 / n, params=p, ng=0)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    u = lev.uold
+    u[0] = 1.0 + torch.rand((n, n, n), generator=g, device="cuda", dtype=torch.float64)
+    for d in (1, 2, 3):
+        u[d] = u[0] * (torch.rand((n, n, n), generator=g, device="cuda", dtype=torch.float64) - 0.5)
+    u[4] = 1.0 + torch.rand((n, n, n), generator=g, device="cuda", dtype=torch.float64) + \
+        0.5 * (u[1] ** 2 + u[2] ** 2 + u[3] ** 2) / u[0]
+    u[4, 100:110, 200:230, 17:40] *= 50.0          # a strong blast somewhere
+    dt = 0.5 * lev.courant_fine()[0]
+    lev.godunov_fine(dt)
+    ref = lev.unew.clone()
+    before = u.sum(dim=(1, 2, 3))
+    after = ref.sum(dim=(1, 2, 3))
+    assert torch.all((after - before).abs() <= 1e-9 * before.abs().clamp(min=1.0))
+    shift = (37, 5, 201)                          # not a multiple of any tile size
+    lev.uold.copy_(torch.roll(u.clone(), shifts=shift, dims=(1, 2, 3)))
+    lev.godunov_fine(dt)
+    assert torch.equal(lev.unew, torch.roll(ref, shifts=shift, dims=(1, 2, 3)))
+    del ref
+    torch.cuda.empty_cache()
