@@ -88,6 +88,10 @@ const char *ramses_amd_last_error(void);
  * the two structs; returns 0 when they match this library's layout. */
 int ramses_amd_abi_check(size_t sizeof_hydro_params, size_t sizeof_brick);
 /* Number of HIP devices; fills name (<=255 chars) of device 0. */
+/* MPI: one rank per GPU.  Selects device (local rank) mod (device count); the local rank
+ * comes from the launcher's environment (OMPI_COMM_WORLD_LOCAL_RANK, MPI_LOCALRANKID,
+ * PMI_LOCAL_RANK, SLURM_LOCALID, LOCAL_RANK) or, failing that, from world_rank. */
+int ramses_amd_set_device_auto(int world_rank);
 int ramses_amd_device_info(char *name, size_t name_len, int *n_cu, size_t *hbm_bytes);
 
 /* ---------------------------------------------------------------------------

@@ -174,6 +174,10 @@ case "$cmd" in
        if [ -d /opt/conda/include ] && [ -f /opt/conda/lib/libmpifort.so ]; then build_ramses 3 mpi; fi
        if [ -f "$HERE/../ramses_amd/lib/libramses_amd.so" ]; then
          build_ramses 3 serial "$HERE/../ramses_amd/patch"
-       fi;;
+         if [ -d /opt/conda/include ] && [ -f /opt/conda/lib/libmpifort.so ]; then
+           build_ramses 3 mpi "$HERE/../ramses_amd/patch"
+         fi
+       fi
+       build_ramses 3 serial "$HERE/dump_patch";;
   *) echo "usage: $0 kernels [NDIM] | ramses [NDIM] [serial|mpi] [PATCHDIR] | all"; exit 2;;
 esac

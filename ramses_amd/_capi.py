@@ -49,6 +49,7 @@ SYMBOLS = [
     ("ramses_amd_abi_check", _i, [C.c_size_t, C.c_size_t]),
     ("ramses_amd_brick_dense", None, [_PB, _i, _i, _i, _i]),
     ("ramses_amd_device_info", _i, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    ("ramses_amd_set_device_auto", _i, [_i]),
     ("ramses_amd_godunov_brick", _i, [_PP, _PB, _vp, _vp, _vp, _d, _d, _vp]),
     ("ramses_amd_godunov_brick_shell", _i, [_PP, _PB, _vp, _vp, _vp, _d, _d, _vp]),
     ("ramses_amd_godunov_brick_interior", _i, [_PP, _PB, _vp, _vp, _vp, _d, _d, _vp]),

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/ramses_amd.h"
@@ -87,6 +88,25 @@ void ramses_amd_brick_dense(ramses_amd_brick *b, int nx, int ny, int nz, int ng)
   b->pitch_y = (int64_t)nx + 2 * ng;
   b->pitch_z = b->pitch_y * ((int64_t)ny + 2 * ng);
   b->pitch_var = b->pitch_z * ((int64_t)nz + 2 * ng);
+}
+
+// One process per GPU under MPI: pick the device from the launcher's local rank
+// (falls back to the world rank); all ranks share device 0 on a 1-GPU box.
+int ramses_amd_set_device_auto(int world_rank) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return hipfail(e, "hipGetDeviceCount");
+  if (n <= 0) return fail(RAMSES_AMD_ENODEVICE, "no HIP device visible");
+  int local = world_rank;
+  const char *vars[] = {"OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "PMI_LOCAL_RANK", "SLURM_LOCALID", "LOCAL_RANK"};
+  for (const char *v : vars) {
+    const char *x = getenv(v);
+    if (x && *x) { local = atoi(x); break; }
+  }
+  if (local < 0) local = 0;
+  e = hipSetDevice(local % n);
+  if (e != hipSuccess) return hipfail(e, "hipSetDevice");
+  return 0;
 }
 
 int ramses_amd_device_info(char *name, size_t name_len, int *n_cu, size_t *hbm_bytes) {

@@ -78,10 +78,6 @@ subroutine godunov_fine(ilevel)
   if(verbose)write(*,111)ilevel
 
   ! What the device path does not implement stops the run (no silent fallback)
-  if(ncpu>1)then
-     write(*,*)'ramses_amd: godunov_fine on the device needs one rank per level brick; ncpu=',ncpu
-     call ramses_amd_fatal('godunov_fine (ncpu>1)')
-  end if
   if(pressure_fix.or.MC_tracer.or.momentum_feedback>0.or.strict_equilibrium>0)then
      write(*,*)'ramses_amd: pressure_fix/MC_tracer/momentum_feedback/strict_equilibrium are not on the device'
      call ramses_amd_fatal('godunov_fine (unsupported option)')
@@ -100,6 +96,9 @@ subroutine godunov_fine(ilevel)
      if(numbtot(1,ilevel+1)>0)amr_level=.true.
   end if
   if(int(active(ilevel)%ngrid,8)*8_8/=(2_8**ilevel)**3*int(nx_loc,8)**3)amr_level=.true.
+  ! several MPI ranks (each sweeps its own active octs; ghost octs of the other ranks are
+  ! ordinary neighbours in the tree) and physical boundary octs: the tree-walking sweep
+  if(ncpu>1.or.nboundary>0)amr_level=.true.
 
   if(amr_level)then
      if(poisson)then

@@ -34,6 +34,12 @@ module ramses_amd_iface
        integer(c_int) :: rc
      end function ramses_amd_abi_check
 
+     function ramses_amd_set_device_auto(world_rank) bind(C, name='ramses_amd_set_device_auto') result(rc)
+       import :: c_int
+       integer(c_int), value :: world_rank
+       integer(c_int) :: rc
+     end function ramses_amd_set_device_auto
+
      function ramses_amd_last_error() bind(C, name='ramses_amd_last_error') result(msg)
        import :: c_ptr
        type(c_ptr) :: msg
@@ -147,11 +153,18 @@ contains
        if (ramses_amd_on) then
           rc = ramses_amd_abi_check(c_sizeof(p), c_sizeof(b))
           if (rc /= 0) call ramses_amd_fatal('ramses_amd_abi_check')
+          rc = ramses_amd_set_device_auto(ramses_amd_world_rank())
+          if (rc /= 0) call ramses_amd_fatal('ramses_amd_set_device_auto')
        end if
        ramses_amd_checked = .true.
     end if
     ramses_amd_enabled = ramses_amd_on
   end function ramses_amd_enabled
+
+  integer function ramses_amd_world_rank()
+    use amr_commons, only: myid
+    ramses_amd_world_rank = myid - 1
+  end function ramses_amd_world_rank
 
   !---------------------------------------------------------------------------
   ! Device residency of the hydro state across courant_fine / set_unew /

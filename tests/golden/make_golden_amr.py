@@ -60,6 +60,14 @@ def amr_namelist(lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, foutput=1
     return nml.replace("ngridtot=", "ngridtot=3000 !")
 
 
+def MPI_CASES():
+    a = [c for c in CASES if c[0] == "a"][0]
+    _, lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, _ = a
+    amr = amr_namelist(lmin, lmax, nsub, riemann, slope, ivar, itype, nstep).replace("ngridtot=3000 !", "ngridtot=8000 !")
+    uni = rs.sedov3d_namelist(level=4, nstepmax=4, foutput=1, riemann="hllc", slope_type=2, mem_factor=4.0)
+    return [("mpi2_amr", 2, amr, nstep), ("mpi4_uniform", 4, uni, 4)]
+
+
 def main():
     binary = os.path.join(ROOT, "oracle", "_ref", "ramses3d_dump_patch")
     out = {}
@@ -91,6 +99,19 @@ def main():
                 out["%s_e2e%d_x" % (tag, k)] = snap["x"][order]
                 out["%s_e2e%d_prim" % (tag, k)] = snap["prim"][:, order]
             print(tag, "e2e leaf cells", snap["level"].size, "levels", np.unique(snap["level"]))
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    # MPI: the unmodified reference on several ranks (AMR case "a" on 2 ranks, a uniform
+    # level-4 run on 4 ranks); goldens = leaf cells of all ranks' snapshot files
+    for tag, nproc, nml, nstep in MPI_CASES():
+        work, log = rs.run_reference(nml, nproc=nproc, binary=os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi"))
+        try:
+            snap = rs.load_leaf_cells(os.path.join(work, "output_%05d" % (nstep + 1)))
+            order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+            out["%s_level" % tag] = snap["level"][order].astype(np.int8)
+            out["%s_x" % tag] = snap["x"][order]
+            out["%s_prim" % tag] = snap["prim"][:, order]
+            print(tag, "mpi leaf cells", snap["level"].size, "levels", np.unique(snap["level"]))
         finally:
             shutil.rmtree(work, ignore_errors=True)
     path = os.path.join(ROOT, "tests", "golden", "amr_godunov_ref.npz")
