@@ -42,9 +42,10 @@ end subroutine godunov_fine
 subroutine dump_godunov(what,ilevel,ncall)
   use amr_commons
   use hydro_commons
+  use poisson_commons
   implicit none
   character(len=*)::what
-  integer::ilevel,ncall,nx_loc
+  integer::ilevel,ncall,nx_loc,ipoisson
   character(len=64)::fname
   real(dp)::dx
   write(fname,'(A,I4.4,A,A,A)')'godunov_',ncall,'_',trim(what),'.bin'
@@ -52,7 +53,9 @@ subroutine dump_godunov(what,ilevel,ncall)
   nx_loc=icoarse_max-icoarse_min+1
   dx=0.5d0**ilevel*boxlen/dble(nx_loc)
   if(what=='in')then
-     write(77)ilevel,active(ilevel)%ngrid,ngridmax,ncoarse,nvar,nvector,nlevelmax,interpol_var,interpol_type
+     ipoisson=0
+     if(poisson)ipoisson=1
+     write(77)ilevel,active(ilevel)%ngrid,ngridmax,ncoarse,nvar,nvector,nlevelmax,interpol_var,interpol_type,ipoisson
      write(77)dx,dtnew(ilevel),gamma,smallr,smallc
      write(77)active(ilevel)%igrid(1:active(ilevel)%ngrid)
      write(77)son
@@ -60,6 +63,7 @@ subroutine dump_godunov(what,ilevel,ncall)
      write(77)father
      write(77)uold
      write(77)unew
+     if(poisson)write(77)f
   else
      write(77)unew
   end if

@@ -75,7 +75,7 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int ST, int RS>
+template <int ST, int RS, bool GRAV>
 __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSweepArgs A) {
   __shared__ OctLds lds[OCTS_PER_BLOCK];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -102,7 +102,10 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
   }
   wave_sync();
 
-  // ---- (B) gather the 6^3 stencil -------------------------------------------
+  // ---- (B)+(C) gather the 6^3 stencil and convert to primitive variables -----------
+  // (gravity: f of the cell for existing octs, straight injection of the father
+  // cell's f for interpolated cells, hydro/godunov_fine.f90:637-647)
+  const double dtxhalf = A.dt * 0.5;
   for (int e = lane; e < 216; e += 64) {
     const int t = e >> 3, ind = e & 7;
     const int og = L.ex[t];
@@ -110,8 +113,16 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
       const int i3 = 2 * (t % 3) + (ind & 1), j3 = 2 * ((t / 3) % 3) + ((ind >> 1) & 1), k3 = 2 * (t / 9) + (ind >> 2);
       const long cell = A.ncoarse + (long)ind * A.ngridmax + og;   // 1-based
       const int s = sidx(i3, j3, k3);
+      double u[NV], q[NV], gz[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-      for (int v = 0; v < NV; v++) L.u[s][v] = A.uold[(long)v * ncell + cell - 1];
+      for (int v = 0; v < NV; v++) u[v] = A.uold[(long)v * ncell + cell - 1];
+      if (GRAV) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) gz[d] = A.grav[(long)d * ncell + cell - 1];
+      }
+      ctoprim_cell<NV, GRAV>(u, gz, dtxhalf, P, q);
+#pragma unroll
+      for (int v = 0; v < NV; v++) L.u[s][v] = q[v];
       L.ok[s] = A.son[cell - 1] > 0;
     }
   }
@@ -130,27 +141,22 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
       for (int v = 0; v < NV; v++) u1[j][v] = A.uold[(long)v * ncell + c - 1];
     }
     interpol_hydro_cell<NV>(u1, u2, A.interpol_var, A.interpol_type, P.smallr);
+    double gz[3] = {0.0, 0.0, 0.0};
+    if (GRAV) {
+#pragma unroll
+      for (int d = 0; d < 3; d++) gz[d] = A.grav[(long)d * ncell + c0 - 1];
+    }
     const int t = lane;
 #pragma unroll
     for (int ind = 0; ind < 8; ind++) {
       const int i3 = 2 * (t % 3) + (ind & 1), j3 = 2 * ((t / 3) % 3) + ((ind >> 1) & 1), k3 = 2 * (t / 9) + (ind >> 2);
       const int s = sidx(i3, j3, k3);
+      double q[NV];
+      ctoprim_cell<NV, GRAV>(u2[ind], gz, dtxhalf, P, q);
 #pragma unroll
-      for (int v = 0; v < NV; v++) L.u[s][v] = u2[ind][v];
+      for (int v = 0; v < NV; v++) L.u[s][v] = q[v];
       L.ok[s] = 0;
     }
-  }
-  wave_sync();
-
-  // ---- (C) ctoprim on the 6^3 cells (in place) -------------------------------
-  const double dtxhalf = A.dt * 0.5;
-  for (int e = lane; e < 216; e += 64) {
-    double u[NV], q[NV], gz[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int v = 0; v < NV; v++) u[v] = L.u[e][v];
-    ctoprim_cell<NV, false>(u, gz, dtxhalf, P, q);
-#pragma unroll
-    for (int v = 0; v < NV; v++) L.u[e][v] = q[v];
   }
   wave_sync();
 
@@ -309,19 +315,25 @@ __global__ __launch_bounds__(256) void amr_coarse_update_kernel(AmrSweepArgs A, 
   }
 }
 
-template <int ST>
-static hipError_t launch1(const AmrSweepArgs &A, int rs, hipStream_t s) {
+template <int ST, int RS>
+static hipError_t launch2(const AmrSweepArgs &A, hipStream_t s) {
   const int blocks = (A.ngrid + OCTS_PER_BLOCK - 1) / OCTS_PER_BLOCK;
   const dim3 grid(blocks), block(64 * OCTS_PER_BLOCK);
+  if (A.grav) hipLaunchKernelGGL((amr_godunov_kernel<ST, RS, true>), grid, block, 0, s, A);
+  else hipLaunchKernelGGL((amr_godunov_kernel<ST, RS, false>), grid, block, 0, s, A);
+  return hipGetLastError();
+}
+
+template <int ST>
+static hipError_t launch1(const AmrSweepArgs &A, int rs, hipStream_t s) {
   switch (rs) {
-    case RIEMANN_LLF: hipLaunchKernelGGL((amr_godunov_kernel<ST, RIEMANN_LLF>), grid, block, 0, s, A); break;
-    case RIEMANN_HLLC: hipLaunchKernelGGL((amr_godunov_kernel<ST, RIEMANN_HLLC>), grid, block, 0, s, A); break;
-    case RIEMANN_HLL: hipLaunchKernelGGL((amr_godunov_kernel<ST, RIEMANN_HLL>), grid, block, 0, s, A); break;
-    case RIEMANN_ACOUSTIC: hipLaunchKernelGGL((amr_godunov_kernel<ST, RIEMANN_ACOUSTIC>), grid, block, 0, s, A); break;
-    case RIEMANN_EXACT: hipLaunchKernelGGL((amr_godunov_kernel<ST, RIEMANN_EXACT>), grid, block, 0, s, A); break;
+    case RIEMANN_LLF: return launch2<ST, RIEMANN_LLF>(A, s);
+    case RIEMANN_HLLC: return launch2<ST, RIEMANN_HLLC>(A, s);
+    case RIEMANN_HLL: return launch2<ST, RIEMANN_HLL>(A, s);
+    case RIEMANN_ACOUSTIC: return launch2<ST, RIEMANN_ACOUSTIC>(A, s);
+    case RIEMANN_EXACT: return launch2<ST, RIEMANN_EXACT>(A, s);
     default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
 }
 
 }  // namespace amrsweep

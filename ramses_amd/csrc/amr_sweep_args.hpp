@@ -7,6 +7,7 @@ namespace ramses_amd {
 struct AmrSweepArgs {
   const double *uold;   // [nvar][ncell]   (uold(1:ncell,1:nvar), column major)
   double *unew;         // [nvar][ncell]
+  const double *grav;   // f(1:ncell,1:3) or null
   const int *son;       // [ncell]
   const int *nbor;      // [6][ngridmax]   (nbor(1:ngridmax,1:twondim))
   const int *father;    // [ngridmax]

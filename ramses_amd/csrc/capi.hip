@@ -700,14 +700,15 @@ static int amr_check(const ramses_amd_hydro_params *p, int ilevel, int nvector, 
 int ramses_amd_godunov_fine_amr_device(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
                                        const int *d_igrid, const int *d_son, const int *d_nbor,
                                        const int *d_father, int64_t ngridmax, int64_t ncoarse,
-                                       const double *d_uold, double *d_unew, double dx, double dt,
+                                       const double *d_uold, double *d_unew, const double *d_grav,
+                                       double dx, double dt,
                                        int nvector, int interpol_var, int interpol_type,
                                        void *d_work, int *d_err, void *stream) {
   if (!p || !d_igrid || !d_son || !d_nbor || !d_father || !d_uold || !d_unew || !d_work || !d_err) return fail(RAMSES_AMD_EINVAL, "NULL argument");
   if (int rc = amr_check(p, ilevel, nvector, interpol_var, interpol_type)) return rc;
   if (ngrid <= 0) return 0;
   AmrSweepArgs A;
-  A.uold = d_uold; A.unew = d_unew;
+  A.uold = d_uold; A.unew = d_unew; A.grav = d_grav;
   A.son = d_son; A.nbor = d_nbor; A.father = d_father;
   A.igrid = d_igrid; A.ngrid = ngrid;
   A.ncell = ncoarse + 8 * ngridmax; A.ncoarse = ncoarse; A.ngridmax = ngridmax;
@@ -730,7 +731,8 @@ int ramses_amd_godunov_fine_amr_device(const ramses_amd_hydro_params *p, int ile
 int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
                                      const int *igrid, const int *son, const int *nbor,
                                      const int *father, int64_t ngridmax, int64_t ncoarse,
-                                     const double *uold, double *unew, double dx, double dt,
+                                     const double *uold, double *unew, const double *f,
+                                     double dx, double dt,
                                      int nvector, int interpol_var, int interpol_type) {
   if (!p || !igrid || !son || !nbor || !father || !uold || !unew) return fail(RAMSES_AMD_EINVAL, "NULL argument");
   if (int rc = amr_check(p, ilevel, nvector, interpol_var, interpol_type)) return rc;
@@ -755,10 +757,16 @@ int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ileve
   HCHK(hipMemcpyAsync(dnbor.p, nbor, sizeof(int) * 6 * ngridmax, hipMemcpyHostToDevice, s), "H2D nbor");
   HCHK(hipMemcpyAsync(dfather.p, father, sizeof(int) * ngridmax, hipMemcpyHostToDevice, s), "H2D father");
   HCHK(hipMemsetAsync(H.flag.p, 0, sizeof(int), s), "memset");
+  const double *d_grav = nullptr;
+  if (f) {
+    HCHK(H.fvec.ensure(sizeof(double) * 3 * ncell), "hipMalloc f");
+    HCHK(hipMemcpyAsync(H.fvec.p, f, sizeof(double) * 3 * ncell, hipMemcpyHostToDevice, s), "H2D f");
+    d_grav = H.fvec.as<double>();
+  }
   g_host.res_valid = false;   // the staging buffers are reused
   if (int rc = ramses_amd_godunov_fine_amr_device(p, ilevel, ngrid, H.igrid.as<int>(), dson.as<int>(), dnbor.as<int>(),
                                                   dfather.as<int>(), ngridmax, ncoarse, H.uold.as<double>(),
-                                                  H.unew.as<double>(), dx, dt, nvector, interpol_var, interpol_type,
+                                                  H.unew.as<double>(), d_grav, dx, dt, nvector, interpol_var, interpol_type,
                                                   dwork.p, H.flag.as<int>(), s)) return rc;
   int bad = 0;
   HCHK(hipMemcpyAsync(&bad, H.flag.p, sizeof(int), hipMemcpyDeviceToHost, s), "D2H flag");
@@ -767,6 +775,16 @@ int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ileve
 #undef HCHK
   if (bad) return fail(RAMSES_AMD_EINVAL, "level %d: %d of the 3^3 father cells of an oct do not exist (tree inconsistent)", ilevel, bad);
   return 0;
+}
+
+// Fortran-friendly variant of the AMR entry: f is always a valid array (ignored when has_f==0)
+int ramses_amd_godunov_fine_amr_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                    const int *igrid, const int *son, const int *nbor,
+                                    const int *father, int64_t ngridmax, int64_t ncoarse,
+                                    const double *uold, double *unew, const double *f_or_dummy, int has_f,
+                                    double dx, double dt, int nvector, int interpol_var, int interpol_type) {
+  return ramses_amd_godunov_fine_amr_host(p, ilevel, ngrid, igrid, son, nbor, father, ngridmax, ncoarse, uold, unew,
+                                          has_f ? f_or_dummy : nullptr, dx, dt, nvector, interpol_var, interpol_type);
 }
 
 // Fortran-friendly variant: f is always a valid array (ignored when has_f==0)

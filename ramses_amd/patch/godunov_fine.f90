@@ -102,11 +102,12 @@ subroutine godunov_fine(ilevel)
 
   if(amr_level)then
      if(poisson)then
-        write(*,*)'ramses_amd: the AMR sweep has no gravity predictor yet (poisson=.true. on an AMR level)'
-        call ramses_amd_fatal('godunov_fine (AMR level with gravity)')
+        rc=ramses_amd_godunov_fine_amr_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,son,nbor,father, &
+             & int(ngridmax,8),int(ncoarse,8),uold,unew,f,1,dx,dtnew(ilevel),nvector,interpol_var,interpol_type)
+     else
+        rc=ramses_amd_godunov_fine_amr_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,son,nbor,father, &
+             & int(ngridmax,8),int(ncoarse,8),uold,unew,uold,0,dx,dtnew(ilevel),nvector,interpol_var,interpol_type)
      end if
-     rc=ramses_amd_godunov_fine_amr_host(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,son,nbor,father, &
-          & int(ngridmax,8),int(ncoarse,8),uold,unew,dx,dtnew(ilevel),nvector,interpol_var,interpol_type)
   else if(ramses_amd_resident())then
      ! state already on the device (loaded by courant_fine or here); unew stays there
      rc=ramses_amd_resident_godunov_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &

@@ -77,19 +77,20 @@ module ramses_amd_iface
      end function ramses_amd_multigrid_fine_f90
 
      ! ---- AMR level: the reference's tree arrays by address ----
-     function ramses_amd_godunov_fine_amr_host(p, ilevel, ngrid, igrid, son, nbor, father, ngridmax, ncoarse, &
-          & uold, unew, dx, dt, nvector, interpol_var, interpol_type) &
-          & bind(C, name='ramses_amd_godunov_fine_amr_host') result(rc)
+     function ramses_amd_godunov_fine_amr_f90(p, ilevel, ngrid, igrid, son, nbor, father, ngridmax, ncoarse, &
+          & uold, unew, f_or_dummy, has_f, dx, dt, nvector, interpol_var, interpol_type) &
+          & bind(C, name='ramses_amd_godunov_fine_amr_f90') result(rc)
        import :: ramses_amd_hydro_params, c_int, c_int64_t, c_double
        type(ramses_amd_hydro_params), intent(in) :: p
        integer(c_int), value :: ilevel, ngrid
        integer(c_int) :: igrid(*), son(*), nbor(*), father(*)
        integer(c_int64_t), value :: ngridmax, ncoarse
-       real(c_double) :: uold(*), unew(*)
+       real(c_double) :: uold(*), unew(*), f_or_dummy(*)
+       integer(c_int), value :: has_f
        real(c_double), value :: dx, dt
        integer(c_int), value :: nvector, interpol_var, interpol_type
        integer(c_int) :: rc
-     end function ramses_amd_godunov_fine_amr_host
+     end function ramses_amd_godunov_fine_amr_f90
 
      ! ---- device-resident level (include/ramses_amd.h) ----
      function ramses_amd_resident_courant_f90(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, &

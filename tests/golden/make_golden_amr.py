@@ -29,15 +29,23 @@ err_grad_p=0.1
 CASES = [
     ("a", 3, 5, "1,1,2,2", "llf", 1, 0, 2, 6, (8, 9, 13)),
     ("b", 3, 5, "10*1", "hllc", 2, 1, 1, 4, (5, 6, 7)),
+    # analytic point-mass gravity (gravity_type=2: no Poisson solve): the predictor of ctoprim
+    # with f of existing cells and the father cell's f for interpolated ones
+    ("g", 3, 5, "1,1,2,2", "hll", 7, 0, 1, 4, (7, 11)),
 ]
+GRAVITY = """&POISSON_PARAMS
+gravity_type=2
+gravity_params=3.0,0.02,0.2,0.3,0.1
+/
+"""
 
 
 def read_dump(work, k):
     fi = os.path.join(work, "godunov_%04d_in.bin" % k)
     fo = os.path.join(work, "godunov_%04d_out.bin" % k)
     with open(fi, "rb") as fh:
-        hdr = np.fromfile(fh, np.int32, 9)
-        ilevel, ngrid, ngridmax, ncoarse, nvar, nvector, nlevelmax, ivar, itype = [int(x) for x in hdr]
+        hdr = np.fromfile(fh, np.int32, 10)
+        ilevel, ngrid, ngridmax, ncoarse, nvar, nvector, nlevelmax, ivar, itype, ipoisson = [int(x) for x in hdr]
         dx, dt, gamma, smallr, smallc = np.fromfile(fh, np.float64, 5)
         igrid = np.fromfile(fh, np.int32, ngrid)
         ncell = ncoarse + 8 * ngridmax
@@ -46,16 +54,19 @@ def read_dump(work, k):
         father = np.fromfile(fh, np.int32, ngridmax)
         uold = np.fromfile(fh, np.float64, ncell * nvar).reshape(nvar, ncell)
         unew = np.fromfile(fh, np.float64, ncell * nvar).reshape(nvar, ncell)
+        f = np.fromfile(fh, np.float64, ncell * 3).reshape(3, ncell) if ipoisson else np.zeros((0, 0))
         assert fh.read() == b""
     unew_out = np.fromfile(fo, np.float64).reshape(nvar, ncell)
     return dict(meta=np.array([ilevel, ngrid, ngridmax, ncoarse, nvar, nvector, nlevelmax, ivar, itype], np.int64),
                 real=np.array([dx, dt, gamma, smallr, smallc]), igrid=igrid, son=son, nbor=nbor, father=father,
-                uold=uold, unew=unew, unew_out=unew_out)
+                uold=uold, unew=unew, unew_out=unew_out, f=f)
 
 
-def amr_namelist(lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, foutput=1):
+def amr_namelist(lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, foutput=1, tag=""):
+    grav = tag == "g"
     nml = rs.sedov3d_namelist(level=lmin, nstepmax=nstep, foutput=foutput, riemann=riemann, slope_type=slope,
-                              extra=REFINE.format(ivar=ivar, itype=itype), mem_factor=1.0)
+                              extra=REFINE.format(ivar=ivar, itype=itype) + (GRAVITY if grav else ""), mem_factor=1.0,
+                              poisson=grav)
     nml = nml.replace("levelmax=%d" % lmin, "levelmax=%d" % lmax).replace("nsubcycle=10*1", "nsubcycle=" + nsub)
     return nml.replace("ngridtot=", "ngridtot=3000 !")
 
@@ -72,7 +83,7 @@ def main():
     binary = os.path.join(ROOT, "oracle", "_ref", "ramses3d_dump_patch")
     out = {}
     for tag, lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, calls in CASES:
-        nml = amr_namelist(lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, foutput=1000)
+        nml = amr_namelist(lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, foutput=1000, tag=tag)
         os.environ["RAMSES_DUMP_CALLS"] = ",".join(str(c) for c in calls)
         work, log = rs.run_reference(nml, binary=binary)
         try:
@@ -89,7 +100,7 @@ def main():
             shutil.rmtree(work, ignore_errors=True)
     # end-to-end: leaf cells of the snapshots of the untouched reference program
     for tag, lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, calls in CASES:
-        nml = amr_namelist(lmin, lmax, nsub, riemann, slope, ivar, itype, nstep)
+        nml = amr_namelist(lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, tag=tag)
         work, log = rs.run_reference(nml)
         try:
             for k in (1, nstep + 1):

@@ -54,7 +54,8 @@ def test_argument_validation_is_loud():
     p = _capi.make_params(ndim=2)
     b = _capi.dense_brick(8, 8, 8, 0)
     rc = L.ramses_amd_godunov_brick(C.byref(p), C.byref(b), C.c_void_p(8), None, C.c_void_p(16), 0.1, 0.1, None)
-    assert rc == -2 and b"NDIM=3" in L.ramses_amd_last_error()
+    # NDIM=2 is an embedded problem: it needs nz=1 and ghost layers, anything else is refused
+    assert rc == -1 and b"NDIM=2 needs a brick with nz=1" in L.ramses_amd_last_error()
     p = _capi.make_params(difmag=0.1)
     rc = L.ramses_amd_godunov_brick(C.byref(p), C.byref(b), C.c_void_p(8), None, C.c_void_p(16), 0.1, 0.1, None)
     assert rc == -2
