@@ -286,6 +286,13 @@ int ramses_amd_multigrid_fine_f90(int ilevel, int ngrid, const int *igrid, const
                                   double fourpi, double epsilon, int *safe_mode,
                                   int *iters, double *err);
 
+/* One-shot halo: up to 26 regions (faces, edges, corners) of a ghost-layer brick packed into /
+ * unpacked from one buffer by a single launch; the exchange is then one grouped send/recv with
+ * one message per peer (pack/unpack loops of make_virtual_fine_dp, amr/virtual_boundaries.f90:454-506).
+ * boxes: nbox x {org x,y,z (allocated coordinates), ext x,y,z}; offsets (doubles) into d_buf. */
+int ramses_amd_halo_multi(const ramses_amd_brick *b, double *d_u, int nvar, int nbox, const int *boxes,
+                          const int64_t *offsets, double *d_buf, int pack, void *stream);
+
 /* make_boundary_hydro (hydro/hydro_boundary.f90:5-269) on a ghost-layer brick: fills the
  * ghost layers of one face (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z) over the full extent of the
  * other directions.  bound_type is the reference's code: face+1 reflexive, 10+face+1

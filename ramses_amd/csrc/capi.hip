@@ -311,6 +311,34 @@ int ramses_amd_halo_unpack(const ramses_amd_brick *b, double *d_u, int nvar, int
   return slab_copy(b, d_buf, d_u, nvar, face, false, stream);
 }
 
+// One-shot halo (all faces, edges and corners in one launch).  boxes: nbox x 6 ints
+// (org x,y,z in allocated coordinates, ext x,y,z); offsets: nbox positions (in doubles) in d_buf.
+int ramses_amd_halo_multi(const ramses_amd_brick *b, double *d_u, int nvar, int nbox, const int *boxes,
+                          const int64_t *offsets, double *d_buf, int pack, void *stream) {
+  if (int rc = check_brick(b)) return rc;
+  if (!d_u || !d_buf || !boxes || !offsets) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (nbox < 0 || nbox > 26) return fail(RAMSES_AMD_EINVAL, "at most 26 regions");
+  if (nbox == 0) return 0;
+  MultiBoxArgs A;
+  A.brick = d_u; A.buf = d_buf; A.nbox = nbox; A.nvar = nvar; A.pack = pack ? 1 : 0;
+  A.pitch_y = b->pitch_y; A.pitch_z = b->pitch_z; A.pitch_var = b->pitch_var;
+  const int full[3] = {b->nx + 2 * b->ng, b->ny + 2 * b->ng, b->nz + 2 * b->ng};
+  A.rows_before[0] = 0;
+  for (int r = 0; r < nbox; r++) {
+    for (int d = 0; d < 3; d++) {
+      A.org[r][d] = boxes[6 * r + d];
+      A.ext[r][d] = boxes[6 * r + 3 + d];
+      if (A.org[r][d] < 0 || A.ext[r][d] < 1 || A.org[r][d] + A.ext[r][d] > full[d])
+        return fail(RAMSES_AMD_EINVAL, "region %d leaves the brick", r);
+    }
+    A.off[r] = offsets[r];
+    A.rows_before[r + 1] = A.rows_before[r] + (long)A.ext[r][1] * A.ext[r][2] * nvar;
+  }
+  hipError_t e = launch_multi_box(A, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hipfail(e, "halo multi-box launch");
+  return 0;
+}
+
 int ramses_amd_fill_ghosts_periodic(const ramses_amd_brick *b, double *d_u, int nvar, int axes,
                                     void *stream) {
   if (int rc = check_brick(b)) return rc;

@@ -141,6 +141,46 @@ hipError_t launch_box_copy(const BoxCopyArgs &A, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------
+// One-shot halo: every face, edge and corner region of the brick packed into (or
+// unpacked from) one buffer by a single launch, so that the exchange is ONE
+// grouped send/recv with one message per peer, all xGMI links busy at once
+// (instead of three dependent axis rounds over one link each).  One wavefront
+// copies one x-row of one region.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void multi_box_kernel(MultiBoxArgs A) {
+  const long nrows = A.rows_before[A.nbox];
+  const int lane = threadIdx.x & 63;
+  const long nw = (long)gridDim.x * 4;
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += nw) {
+    int r = 0;
+#pragma unroll 1
+    while (r + 1 < A.nbox && row >= A.rows_before[r + 1]) r++;
+    const long lr = row - A.rows_before[r];
+    const int ex = A.ext[r][0], ey = A.ext[r][1], ez = A.ext[r][2];
+    const int j = (int)(lr % ey);
+    const int k = (int)((lr / ey) % ez);
+    const int v = (int)(lr / ((long)ey * ez));
+    const long bo = (long)A.org[r][0] + (long)(A.org[r][1] + j) * A.pitch_y + (long)(A.org[r][2] + k) * A.pitch_z +
+                    (long)v * A.pitch_var;
+    const long po = A.off[r] + ((long)v * ez + k) * (long)ey * ex + (long)j * ex;
+    if (A.pack) {
+      for (int i = lane; i < ex; i += 64) A.buf[po + i] = A.brick[bo + i];
+    } else {
+      for (int i = lane; i < ex; i += 64) A.brick[bo + i] = A.buf[po + i];
+    }
+  }
+}
+
+hipError_t launch_multi_box(const MultiBoxArgs &A, hipStream_t s) {
+  const long nrows = A.rows_before[A.nbox];
+  if (nrows <= 0) return hipSuccess;
+  long grid = (nrows + 3) / 4;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(multi_box_kernel, dim3((int)grid), dim3(256), 0, s, A);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // make_boundary_hydro (hydro/hydro_boundary.f90:5-269) on a ghost-layer brick:
 // the ghost layers of one face, over the full extent of the other directions
 // (call the faces in x, y, z order so that edges and corners are filled from

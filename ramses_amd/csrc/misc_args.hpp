@@ -28,6 +28,19 @@ hipError_t launch_courant_init(double *out, double dt_init, hipStream_t s);
 hipError_t launch_courant(const CourantArgs &A, bool grav, hipStream_t s);
 hipError_t launch_box_copy(const BoxCopyArgs &A, hipStream_t s);
 
+// all 26 neighbour regions of a ghost-layer brick in ONE launch: region r is the box
+// (org,ext) of the brick, packed contiguously ([var][k][j][i]) at buf + off[r]
+struct MultiBoxArgs {
+  double *brick;
+  double *buf;
+  int nbox, nvar, pack;     // pack: brick -> buf, else buf -> brick
+  long pitch_y, pitch_z, pitch_var;
+  int org[26][3], ext[26][3];
+  long off[26];
+  long rows_before[27];     // prefix sum of ext_y*ext_z*nvar per box
+};
+hipError_t launch_multi_box(const MultiBoxArgs &A, hipStream_t s);
+
 // physical boundary of one face of a ghost-layer brick (make_boundary_hydro)
 struct BoundaryArgs {
   double *u;

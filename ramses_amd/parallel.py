@@ -119,11 +119,86 @@ class BrickDecomposition:
             self._unpack(lev, t, nvar, 2 * axis, recv_lo)
             self._unpack(lev, t, nvar, 2 * axis + 1, recv_hi)
 
-    def make_virtual_fine_dp(self, lev):
+    # -- one-shot exchange: all 26 neighbour regions at once ------------------------
+    def _direct_plan(self, lev, nvar, t):
+        """Per (level, nvar): the 26 regions ordered by peer, so that every peer gets ONE
+        message.  Region g (an offset in {-1,0,1}^3) of MY ghost layers is filled from the
+        neighbour at coords+g, which sends its interior region next to its side -g; both
+        sides order a peer's regions by the sender's offset index."""
+        key = ("direct", id(lev), nvar)
+        if key in self._bufs:
+            return self._bufs[key]
+        import numpy as np
+        ng = lev.ng
+        n = (lev.nx, lev.ny, lev.nz)
+        offs = [(ox, oy, oz) for oz in (-1, 0, 1) for oy in (-1, 0, 1) for ox in (-1, 0, 1) if (ox, oy, oz) != (0, 0, 0)]
+        index = {o: i for i, o in enumerate(offs)}
+
+        def send_box(o):      # interior cells next to side o
+            org = [ng if o[d] <= 0 else ng + n[d] - ng for d in range(3)]
+            ext = [n[d] if o[d] == 0 else ng for d in range(3)]
+            return org, ext
+
+        def recv_box(g):      # ghost cells on side g
+            org = [0 if g[d] < 0 else (ng if g[d] == 0 else ng + n[d]) for d in range(3)]
+            ext = [n[d] if g[d] == 0 else ng for d in range(3)]
+            return org, ext
+
+        def peer(o):
+            return coords_rank([self.coords[d] + o[d] for d in range(3)], self.pgrid)
+
+        sends = sorted(offs, key=lambda o: (peer(o), index[o]))
+        recvs = sorted(offs, key=lambda g: (peer(g), index[tuple(-x for x in g)]))
+        plan = {}
+        for name, lst, box in (("send", sends, send_box), ("recv", recvs, recv_box)):
+            boxes, offsets, segs = [], [], []
+            pos = 0
+            for o in lst:
+                org, ext = box(o)
+                boxes += org + ext
+                offsets.append(pos)
+                size = nvar * ext[0] * ext[1] * ext[2]
+                q = peer(o)
+                if segs and segs[-1][0] == q:
+                    segs[-1][2] += size
+                else:
+                    segs.append([q, pos, size])
+                pos += size
+            plan[name] = dict(boxes=np.array(boxes, np.int32), offsets=np.array(offsets, np.int64), segs=segs,
+                              buf=torch.empty(pos, dtype=torch.float64, device=t.device))
+        self._bufs[key] = plan
+        return plan
+
+    def _multi(self, lev, t, nvar, part, pack):
+        check(lib().ramses_amd_halo_multi(C.byref(lev.brick), _ptr(t), nvar, len(part["offsets"]),
+                                          part["boxes"].ctypes.data_as(C.c_void_p),
+                                          part["offsets"].ctypes.data_as(C.c_void_p), _ptr(part["buf"]),
+                                          1 if pack else 0, _stream()))
+
+    def exchange_direct(self, lev, t, nvar):
+        """Forward halo in ONE round: one pack launch, one grouped send/recv with one
+        message per peer (7 peers on a 2x2x2 node: every xGMI link carries its share at
+        the same time), one unpack launch.  Same ghost values as exchange()."""
+        plan = self._direct_plan(lev, nvar, t)
+        S, R = plan["send"], plan["recv"]
+        self._multi(lev, t, nvar, S, True)
+        sends, recvs = [], []
+        for (q, pos, size), (q2, pos2, size2) in zip(S["segs"], R["segs"]):
+            assert q == q2 and size == size2
+            if q == self.rank:
+                R["buf"][pos2:pos2 + size2].copy_(S["buf"][pos:pos + size])   # periodic wrap onto myself
+            else:
+                sends.append((S["buf"][pos:pos + size], q))
+                recvs.append((R["buf"][pos2:pos2 + size2], q))
+        self.transport.sendrecv(sends, recvs)
+        self._multi(lev, t, nvar, R, False)
+
+    def make_virtual_fine_dp(self, lev, direct=True):
         """Refresh the ghost octs of uold (and of f when poisson) on every rank."""
-        self.exchange(lev, lev.uold, lev.nvar)
+        ex = self.exchange_direct if direct else self.exchange
+        ex(lev, lev.uold, lev.nvar)
         if lev.f is not None:
-            self.exchange(lev, lev.f, 3)
+            ex(lev, lev.f, 3)
 
     def step_overlapped(self, lev, dt):
         """One hydro step with the halo exchange of the NEW state hidden behind the
@@ -144,7 +219,7 @@ class BrickDecomposition:
         shell_done.record(comp)
         with torch.cuda.stream(self._comm_stream):
             self._comm_stream.wait_event(shell_done)
-            self.exchange(lev, lev.unew, lev.nvar)        # ghosts of the new state
+            self.exchange_direct(lev, lev.unew, lev.nvar)  # ghosts of the new state
             comm_done = torch.cuda.Event()
             comm_done.record(self._comm_stream)
         lev.godunov_fine_interior(dt)

@@ -18,3 +18,16 @@ for mode in ("plain", "overlap", "plain", "overlap"):
         (dec.step_overlapped(lev, dt) if mode == "overlap" else (lev.godunov_fine(dt), lev.set_uold(), dec.make_virtual_fine_dp(lev)))
     torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 10
     print(mode, "ms/step %.3f" % (t * 1e3), "Gcell/s %.2f" % (n ** 3 / t / 1e9))
+# pieces: sweep on the ghost brick alone, shell alone, interior alone, self-exchange alone
+def timeit(fn, k=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(k):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / k * 1e3
+print("sweep(ng=2) ms %.3f" % timeit(lambda: lev.godunov_fine(dt)))
+print("shell ms %.3f" % timeit(lambda: lev.godunov_fine_shell(dt)))
+print("interior ms %.3f" % timeit(lambda: lev.godunov_fine_interior(dt)))
+print("self-exchange ms %.3f" % timeit(lambda: dec.make_virtual_fine_dp(lev)))

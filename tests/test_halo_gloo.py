@@ -61,6 +61,18 @@ class TorchMoverDecomposition(BrickDecomposition):
         view = t[(slice(None),) + s]
         view.copy_(buf.reshape(view.shape))
 
+    def _multi(self, lev, t, nvar, part, pack):
+        """torch stand-in of ramses_amd_halo_multi (the one-shot 26-region pack/unpack)"""
+        b = part["boxes"].reshape(-1, 6)
+        buf = part["buf"]
+        for (ox, oy, oz, ex, ey, ez), off in zip(b, part["offsets"]):
+            view = t[:, oz:oz + ez, oy:oy + ey, ox:ox + ex]
+            m = nvar * ex * ey * ez
+            if pack:
+                buf[off:off + m] = view.reshape(-1)
+            else:
+                view.copy_(buf[off:off + m].reshape(view.shape))
+
     def _fill_periodic(self, lev, t, nvar, axes):
         for axis in range(3):
             if axes & (1 << axis):
@@ -94,6 +106,11 @@ def _worker(rank, world, pgrid, n, port, ret):
         idx = lambda c, ext: (np.arange(c * n - ng, (c + 1) * n + ng)) % ext  # noqa: E731
         exp = G[:, idx(cz, G.shape[1])][:, :, idx(cy, G.shape[2])][:, :, :, idx(cx, G.shape[3])]
         ok = np.array_equal(lev.uold.numpy(), exp)
+        # the one-shot exchange (one message per peer) fills the same ghosts
+        lev1 = FakeLevel(n, ng, nvar)
+        lev1.uold[:, ng:ng + n, ng:ng + n, ng:ng + n] = torch.from_numpy(own.copy())
+        dec.exchange_direct(lev1, lev1.uold, nvar)
+        ok = ok and np.array_equal(lev1.uold.numpy(), exp)
         # deep halo of the distributed multigrid (5 ghost layers, one field)
         ng5 = 5 if n >= 5 else n
         lev5 = FakeLevel(n, ng5, 1)

@@ -116,3 +116,33 @@ def test_overlapped_step_equals_plain_step(gpu_lib):
         torch.cuda.synchronize()
         outs.append(lev.uold.cpu().numpy())
     assert np.array_equal(outs[0], outs[1])     # ghosts included
+
+
+@pytest.mark.parametrize("pgrid", [(1, 1, 1), (2, 2, 2), (2, 1, 1)])
+def test_one_shot_exchange_equals_axis_exchange(gpu_lib, pgrid):
+    """ramses_amd_halo_multi + one grouped send/recv (exchange_direct) fills exactly the
+    ghosts of the three-round axis exchange; multi-rank grids run as virtual ranks."""
+    import torch
+    import ramses_amd
+    from ramses_amd.parallel import BrickDecomposition, rank_coords
+    from ramses_amd.transport import LocalWorld
+    world = pgrid[0] * pgrid[1] * pgrid[2]
+    n = 12
+    rng = np.random.default_rng(2)
+    G = rng.normal(size=(5, n * pgrid[2], n * pgrid[1], n * pgrid[0]))
+
+    def body(tr):
+        dec = BrickDecomposition(pgrid, tr.rank, n, boxlen=1.0, transport=tr)
+        lev = dec.make_level(ramses_amd.make_params())
+        cx, cy, cz = rank_coords(tr.rank, pgrid)
+        own = np.ascontiguousarray(G[:, cz * n:(cz + 1) * n, cy * n:(cy + 1) * n, cx * n:(cx + 1) * n])
+        lev.upload(own)
+        dec.exchange_direct(lev, lev.uold, lev.nvar)
+        torch.cuda.synchronize()
+        a = lev.uold.cpu().numpy()
+        g = lev.ng
+        idx = lambda c, ext: (np.arange(c * n - g, (c + 1) * n + g)) % ext  # noqa: E731
+        exp = G[:, idx(cz, G.shape[1])][:, :, idx(cy, G.shape[2])][:, :, :, idx(cx, G.shape[3])]
+        return bool(np.array_equal(a, exp))
+
+    assert all(LocalWorld(world).run(body))
