@@ -49,6 +49,7 @@ class _Lev:
 
     def __init__(self, l, n, dev):
         self.l, self.n = l, n
+        self.nx = self.ny = self.nz = n
         self.brick = _capi.dense_brick(n, n, n, NG)
         p = n + 2 * NG
         z = lambda: torch.zeros(p, p, p, dtype=torch.float64, device=dev)  # noqa: E731
@@ -112,7 +113,7 @@ class PoissonDecomposition:
         return self.lev[self.level].interior(self.lev[self.level].u1)
 
     def _exchange(self, L, t):
-        self.dec.exchange(L, t, 1)
+        self.dec.exchange_direct(L, t, 1)      # one round, one message per peer
         self.exchanges += 1
 
     def _fused(self, L, src, dst, rhs, res, norm_slot):
