@@ -34,11 +34,16 @@ namespace amrsweep {
 constexpr int NV = 5;
 constexpr int OCTS_PER_BLOCK = 4;
 
-struct OctLds {
-  double u[216][NV];        // conserved, then primitive variables of the 6^3 stencil
+struct OctFaces {
   double qm[3][3][2][2][NV];  // traced state on the +d face of trace cell a (a = 0..2), transverse 1..2
   double qp[3][3][2][2][NV];  // traced state on the -d face of trace cell a+1
   double fl[3][3][2][2][NV];  // flux through face a of direction d
+};
+struct OctLds {
+  union {
+    double u[216][NV];      // primitive variables of the 6^3 stencil (until the traces are done)
+    OctFaces f;             // then the face states and fluxes reuse the same memory
+  };
   int fc[27];               // the 3^3 neighbouring father cells (1-based cell index)
   int ex[27];               // their son oct (0: not refined)
   unsigned char ok[216];    // cell is refined
@@ -106,8 +111,11 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
   // (gravity: f of the cell for existing octs, straight injection of the father
   // cell's f for interpolated cells, hydro/godunov_fine.f90:637-647)
   const double dtxhalf = A.dt * 0.5;
+  // lanes run over the neighbour octs first, the octant second: cell `ind` of octs that
+  // were created together (siblings, Z-order) is contiguous in uold, so neighbouring
+  // lanes share cache lines instead of striding by ngridmax
   for (int e = lane; e < 216; e += 64) {
-    const int t = e >> 3, ind = e & 7;
+    const int ind = e / 27, t = e - 27 * ind;
     const int og = L.ex[t];
     if (og > 0) {
       const int i3 = 2 * (t % 3) + (ind & 1), j3 = 2 * ((t / 3) % 3) + ((ind >> 1) & 1), k3 = 2 * (t / 9) + (ind >> 2);
@@ -175,6 +183,7 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
     }
     double qm[3][NV], qp[3][NV];
     trace3d_cell<NV>(qb, dq, dtdx, dtdx, dtdx, P, qm, qp);
+    wave_sync();            // every lane has read its stencil values: the memory is reused below
     const int tc[3] = {ti, tj, tk};
 #pragma unroll
     for (int d = 0; d < 3; d++) {
@@ -183,11 +192,11 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
       if (b >= 0 && b < 2 && c >= 0 && c < 2) {
         if (a <= 2) {
 #pragma unroll
-          for (int v = 0; v < NV; v++) L.qm[d][a][b][c][v] = qm[d][v];
+          for (int v = 0; v < NV; v++) L.f.qm[d][a][b][c][v] = qm[d][v];
         }
         if (a >= 1) {
 #pragma unroll
-          for (int v = 0; v < NV; v++) L.qp[d][a - 1][b][c][v] = qp[d][v];
+          for (int v = 0; v < NV; v++) L.f.qp[d][a - 1][b][c][v] = qp[d][v];
         }
       }
     }
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
     const int d = lane / 12, r = lane % 12, a = r >> 2, b = r & 1, c = (r >> 1) & 1;
     double qL[NV], qR[NV], fx[NV];
 #pragma unroll
-    for (int v = 0; v < NV; v++) { qL[v] = L.qm[d][a][b][c][v]; qR[v] = L.qp[d][a][b][c][v]; }
+    for (int v = 0; v < NV; v++) { qL[v] = L.f.qm[d][a][b][c][v]; qR[v] = L.f.qp[d][a][b][c][v]; }
     const bool pow2 = A.pow2 != 0;
     if (d == 0) scaled_interface_flux<RS, NV, 0>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
     else if (d == 1) scaled_interface_flux<RS, NV, 1>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
     const int stride = d == 0 ? 1 : (d == 1 ? 6 : 36);
     const bool zero = L.ok[sl] || L.ok[sl + stride];
 #pragma unroll
-    for (int v = 0; v < NV; v++) L.fl[d][a][b][c][v] = zero ? 0.0 : fx[v];
+    for (int v = 0; v < NV; v++) L.f.fl[d][a][b][c][v] = zero ? 0.0 : fx[v];
   }
   wave_sync();
 
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
       for (int d = 0; d < 3; d++) {
         const int t0 = d == 0 ? 1 : 0, t1 = d == 2 ? 1 : 2;
         const int a = ic[d], b = ic[t0], c = ic[t1];
-        un = un + (L.fl[d][a][b][c][v] - L.fl[d][a + 1][b][c][v]);
+        un = un + (L.f.fl[d][a][b][c][v] - L.f.fl[d][a + 1][b][c][v]);
       }
       A.unew[(long)v * ncell + cell - 1] = un;
     }
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
 #pragma unroll
       for (int q = 0; q < 4; q++)
 #pragma unroll
-        for (int v = 0; v < NV; v++) dst[q * NV + v] = L.fl[d][a][q & 1][q >> 1][v];
+        for (int v = 0; v < NV; v++) dst[q * NV + v] = L.f.fl[d][a][q & 1][q >> 1][v];
     }
   }
 }
