@@ -71,6 +71,23 @@ def amr_namelist(lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, foutput=1
     return nml.replace("ngridtot=", "ngridtot=3000 !")
 
 
+C5_NSTEP = 8
+
+
+def c5_namelist():
+    nml = rs.sedov3d_namelist(level=6, nstepmax=C5_NSTEP, foutput=C5_NSTEP, extra=REFINE.format(ivar=0, itype=2))
+    return nml.replace("levelmax=6", "levelmax=8").replace("ngridtot=", "ngridtot=150000 !")
+
+
+def c5_digest(snap, order):
+    import hashlib
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(snap["level"][order].astype(np.int8)).tobytes())
+    h.update(np.ascontiguousarray(snap["x"][order]).tobytes())
+    h.update(np.ascontiguousarray(snap["prim"][:, order]).tobytes())
+    return h.hexdigest()
+
+
 def MPI_CASES():
     a = [c for c in CASES if c[0] == "a"][0]
     _, lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, _ = a
@@ -125,6 +142,18 @@ def main():
             print(tag, "mpi leaf cells", snap["level"].size, "levels", np.unique(snap["level"]))
         finally:
             shutil.rmtree(work, ignore_errors=True)
+    # BASELINE config C5 at 1/8 linear size (sedov3d.nml + levelmin=6, levelmax=8 + the C5 refine
+    # parameters): too many cells for a fixture, so the golden is a checksum of the sorted leaf data
+    import hashlib
+    work, log = rs.run_reference(c5_namelist())
+    try:
+        snap = rs.load_leaf_cells(os.path.join(work, "output_00002"))   # outputs at step 0 and C5_NSTEP
+        order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+        out["c5_sha256"] = np.array(c5_digest(snap, order))
+        out["c5_ncell"] = np.array([int((snap["level"] == l).sum()) for l in (6, 7, 8)])
+        print("c5 leaf cells per level", out["c5_ncell"], out["c5_sha256"])
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
     path = os.path.join(ROOT, "tests", "golden", "amr_godunov_ref.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
