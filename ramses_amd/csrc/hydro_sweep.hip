@@ -371,6 +371,9 @@ template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV>
 __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ty = threadIdx.y;   // wave-uniform
+  // the full rows are the critical path between two barriers: let them win the issue
+  // arbitration over the light rows (measured: -1.1 % at 512^3)
+  if (ty >= 2 && ty <= BY - 3) __builtin_amdgcn_s_setprio(3);
   if (ty == 0) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_HALO>(A, smem_raw);
   else if (ty == BY - 1) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_HALO_HI>(A, smem_raw);
   else if (ty == 1) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_LOW>(A, smem_raw);
