@@ -367,6 +367,35 @@ int ramses_amd_mg_coarse_solve_dense(int level, const double *d_rhs, double *d_u
                                      void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Multigrid on AMR levels (partially refined level, masked cells, Dirichlet
+ * boundaries captured by the mask).  The reference's driver and per-solve setup
+ * (multigrid_fine, recursive_multigrid_coarse, make_initial_phi, masks,
+ * build_parent_comms_mg, scan flags: poisson/multigrid_fine_commons.f90) stay
+ * host code; the compute routines they call are replaced one for one:
+ *   gauss_seidel   gauss_seidel_mg_fine   multigrid_fine_fine.f90:332-451 / _coarse multigrid_fine_coarse.f90:411-593
+ *   residual       cmp_residual_mg_fine   :147-249 / _coarse :167-329
+ *   norm2          cmp_residual_norm2_fine :254-287
+ *   restrict       restrict_residual_fine_reverse :528-590 / _coarse_reverse :692-764
+ *                  (also zeroes the coarser level's rhs and correction, which the driver resets around it)
+ *   interpolate    interpolate_and_correct_fine :596-698 / _coarse :769-886
+ * begin(): the tree (son(1:ncell), nbor(1:ngridmax,1:6), father, lookup_mg), the fine level's
+ * host arrays (flag2, phi(1:ncell), f(1:ncell,1:3)) and its active oct list; add_level(): a
+ * multigrid level's active_mg(myid,l)%igrid, %u(1:8*ngrid,1:4), %f(1:8*ngrid,1).  All levels
+ * then stay on the device until end() writes phi back.  RAMSES_AMD_MG_SYNC=1: every routine
+ * reloads its inputs from the host arrays and writes its outputs back (debug).
+ * ------------------------------------------------------------------------- */
+int ramses_amd_mgamr_begin(int ilevel, int64_t ngridmax, int64_t ncoarse, const int *son, const int *nbor,
+                           const int *father, const int *lookup_mg, const int *flag2, double *phi, double *f,
+                           int ngrid, const int *igrid);
+int ramses_amd_mgamr_add_level(int level, int ngrid, const int *igrid, double *u, const int *fscan);
+int ramses_amd_mgamr_gauss_seidel(int level, int redstep, int safe);
+int ramses_amd_mgamr_residual(int level);
+int ramses_amd_mgamr_norm2(int level, double *norm2);
+int ramses_amd_mgamr_restrict(int finelevel);
+int ramses_amd_mgamr_interpolate(int finelevel);
+int ramses_amd_mgamr_end(void);
+
+/* ---------------------------------------------------------------------------
  * Device-resident level.  For a fully refined periodic
  * level of a single-rank hydro-only run the state stays on the GPU across
  *   newdt_fine/courant_fine   hydro/courant_fine.f90:1-159

@@ -189,11 +189,11 @@ def load_uniform_level(outdir, level, with_grav=False, grav_has_rho=False):
     return dict(prim=prim, grav=grav, info=info)
 
 
-def load_leaf_cells(outdir):
+def load_leaf_cells(outdir, with_grav=False):
     """All leaf cells (son == 0) of a snapshot, every level and cpu:
-    -> dict(level, x[ncell,ndim] in box units, prim[nvar,ncell], info)."""
+    -> dict(level, x[ncell,ndim] in box units, prim[nvar,ncell], info[, grav[ngv,ncell]])."""
     num = os.path.basename(outdir.rstrip("/")).split("_")[-1]
-    levels, xs, prims = [], [], []
+    levels, xs, prims, gravs = [], [], [], []
     info = None
     for af in sorted(glob.glob(os.path.join(outdir, "amr_%s.out*" % num))):
         cpu = af.split(".out")[-1]
@@ -201,6 +201,9 @@ def load_leaf_cells(outdir):
         info = amr
         ndim = amr["ndim"]
         hh, hl = _read_cellfile(os.path.join(outdir, "hydro_%s.out%s" % (num, cpu)))
+        gl = None
+        if with_grav:
+            gh, gl = _read_cellfile(os.path.join(outdir, "grav_%s.out%s" % (num, cpu)))
         icpu = int(cpu) - 1
         # coarse-grid offset of boxes with physical boundaries (nx = 3: the domain is the middle cell)
         skip = [1.0 if amr["nx"][d] > 1 else 0.0 for d in range(ndim)]
@@ -218,8 +221,13 @@ def load_leaf_cells(outdir):
                                 for d in range(ndim)], axis=1)
                 xs.append(pos)
                 prims.append(hl[il][icpu][:, ind, :][:, leaf])
+                if with_grav:
+                    gravs.append(gl[il][icpu][:, ind, :][:, leaf])
                 levels.append(np.full(int(leaf.sum()), il + 1))
-    return dict(level=np.concatenate(levels), x=np.concatenate(xs), prim=np.concatenate(prims, axis=1), info=info)
+    out = dict(level=np.concatenate(levels), x=np.concatenate(xs), prim=np.concatenate(prims, axis=1), info=info)
+    if with_grav:
+        out["grav"] = np.concatenate(gravs, axis=1)
+    return out
 
 
 def prim_to_cons(prim, gamma):

@@ -88,6 +88,14 @@ SYMBOLS = [
     ("ramses_amd_mg_interp_correct_ghost", _i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     ("ramses_amd_gradient_phi_ghost", _i, [_vp, _vp, _i, _i, _d, _vp]),
     ("ramses_amd_mg_coarse_solve_dense", _i, [_i, _vp, _vp, _vp, _i, _vp]),
+    ("ramses_amd_mgamr_begin", _i, [_i, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    ("ramses_amd_mgamr_add_level", _i, [_i, _i, _vp, _vp, _vp]),
+    ("ramses_amd_mgamr_gauss_seidel", _i, [_i, _i, _i]),
+    ("ramses_amd_mgamr_residual", _i, [_i]),
+    ("ramses_amd_mgamr_norm2", _i, [_i, _vp]),
+    ("ramses_amd_mgamr_restrict", _i, [_i]),
+    ("ramses_amd_mgamr_interpolate", _i, [_i]),
+    ("ramses_amd_mgamr_end", _i, []),
     ("ramses_amd_resident_courant_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _d, _vp]),
     ("ramses_amd_resident_godunov_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _d]),
     ("ramses_amd_resident_set_uold_f90", _i, [_i]),

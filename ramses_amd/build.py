@@ -28,6 +28,7 @@ UNITS = [
     ("octree_pack.o", "octree_pack.hip", ["-ffp-contract=off"]),
     ("amr_ops.o", "amr_ops.hip", ["-ffp-contract=off"]),
     ("amr_sweep.o", "amr_sweep.hip", ["-ffp-contract=off"]),
+    ("mg_amr.o", "mg_amr.hip", ["-ffp-contract=off"]),
     ("capi.o", "capi.hip", ["-ffp-contract=off"]),
 ]
 

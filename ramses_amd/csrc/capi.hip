@@ -13,6 +13,7 @@
 #include "../../include/ramses_amd.h"
 #include "amr_args.hpp"
 #include "amr_sweep_args.hpp"
+#include "mg_amr_args.hpp"
 #include "mg_args.hpp"
 #include "misc_args.hpp"
 #include "pack_args.hpp"
@@ -1016,6 +1017,249 @@ int ramses_amd_resident_invalidate(void) {
   if (H.res_valid && H.res_host_stale) return fail(RAMSES_AMD_EINVAL, "invalidate: the host array is stale; sync first");
   H.res_valid = false;
   return 0;
+}
+#undef HCHK
+
+// ---------------------------------------------------------------------------
+// Multigrid on AMR levels.  The reference's own driver (multigrid_fine and
+// recursive_multigrid_coarse, poisson/multigrid_fine_commons.f90:25-390) and its
+// per-solve setup (initial guess, masks, build_parent_comms_mg, scan flags) stay
+// the reference's host code; the compute routines it calls are shadowed by the
+// patch directory and run here.  begin() registers the tree and the fine level,
+// add_level() the multigrid levels below it; the state of all levels then stays
+// on the device until end() writes phi back (host resets of u(:,1:2) between the
+// routines are folded into the restriction, which zeroes both).
+// RAMSES_AMD_MG_SYNC=1: every routine reloads its inputs from the host arrays and
+// writes its outputs back (debugging aid: any routine can then be switched to the
+// reference individually).
+// ---------------------------------------------------------------------------
+extern "C++" {
+namespace {
+struct MgAmrDev {
+  int level = 0, ngrid = 0;
+  DevBuf igrid, u1, u2, u3, u4, scan;
+  // host arrays (coarse levels: only valid during add_level / sync mode)
+  double *h_u = nullptr;      // u(1:ngrid*8, 1:4)
+  const int *h_f = nullptr;   // f(1:ngrid*8, 1)
+  MgAmrLevel view() {
+    MgAmrLevel L;
+    L.ngrid = ngrid; L.igrid = igrid.as<int>();
+    L.u1 = u1.as<double>(); L.u2 = u2.as<double>(); L.u3 = u3.as<double>(); L.u4 = u4.as<double>();
+    L.scan = scan.as<int>();
+    return L;
+  }
+};
+struct MgAmrCtx {
+  bool open = false, sync = false;
+  int ilevel = 0;
+  long ncoarse = 0, ngridmax = 0, ncell = 0;
+  DevBuf son, nbor, father, lookup, vec, ivec, partial, norm;
+  MgAmrDev lev[32];
+  // host arrays of the fine level
+  double *h_phi = nullptr, *h_f = nullptr;   // f(1:ncell,1:3)
+  const int *h_flag2 = nullptr;
+  MgAmrTree tree() {
+    MgAmrTree T;
+    T.son = son.as<int>(); T.nbor = nbor.as<int>(); T.father = father.as<int>(); T.lookup = lookup.as<int>();
+    T.ncoarse = ncoarse; T.ngridmax = ngridmax;
+    return T;
+  }
+};
+MgAmrCtx g_mg;
+}  // namespace
+}  // extern "C++"
+
+#define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipfail(e_, what); } while (0)
+
+// (re)load the fine level from the host arrays: phi -> u1, f(:,2) -> u2, f(:,3) -> u4, flag2 -> scan
+static int mgamr_load_fine(bool with_residual) {
+  MgAmrCtx &M = g_mg;
+  MgAmrDev &D = M.lev[M.ilevel];
+  hipStream_t s = nullptr;
+  const long ncell = M.ncell;
+  HCHK(M.vec.ensure(sizeof(double) * ncell), "hipMalloc");
+  HCHK(M.ivec.ensure(sizeof(int) * ncell), "hipMalloc");
+  struct { const double *src; double *dst; } cols[4] = {{M.h_phi, D.u1.as<double>()}, {M.h_f + ncell, D.u2.as<double>()},
+                                                       {M.h_f + 2 * ncell, D.u4.as<double>()}, {M.h_f, D.u3.as<double>()}};
+  for (int k = 0; k < (with_residual ? 4 : 3); k++) {
+    HCHK(hipMemcpyAsync(M.vec.p, cols[k].src, sizeof(double) * ncell, hipMemcpyHostToDevice, s), "H2D");
+    HCHK(mgamr_launch_gather(M.vec.as<double>(), cols[k].dst, D.igrid.as<int>(), D.ngrid, M.ncoarse, M.ngridmax, s), "gather");
+  }
+  HCHK(hipMemcpyAsync(M.ivec.p, M.h_flag2, sizeof(int) * ncell, hipMemcpyHostToDevice, s), "H2D flag2");
+  HCHK(mgamr_launch_gather_scan(M.ivec.as<int>(), D.scan.as<int>(), D.igrid.as<int>(), D.ngrid, M.ncoarse, M.ngridmax, s), "gather");
+  return 0;
+}
+// write one array of the fine level back into its host cell vector (other cells untouched)
+static int mgamr_store_fine(double *h_vec, const double *d_col) {
+  MgAmrCtx &M = g_mg;
+  MgAmrDev &D = M.lev[M.ilevel];
+  hipStream_t s = nullptr;
+  HCHK(hipMemcpyAsync(M.vec.p, h_vec, sizeof(double) * M.ncell, hipMemcpyHostToDevice, s), "H2D");
+  HCHK(mgamr_launch_scatter(M.vec.as<double>(), d_col, D.igrid.as<int>(), D.ngrid, M.ncoarse, M.ngridmax, s), "scatter");
+  HCHK(hipMemcpyAsync(h_vec, M.vec.p, sizeof(double) * M.ncell, hipMemcpyDeviceToHost, s), "D2H");
+  HCHK(hipStreamSynchronize(s), "sync");
+  return 0;
+}
+static int mgamr_load_coarse(MgAmrDev &D, bool all) {
+  hipStream_t s = nullptr;
+  const size_t n = sizeof(double) * 8 * (size_t)D.ngrid;
+  if (D.ngrid == 0) return 0;
+  if (all) {
+    HCHK(hipMemcpyAsync(D.u1.p, D.h_u, n, hipMemcpyHostToDevice, s), "H2D u1");
+    HCHK(hipMemcpyAsync(D.u2.p, D.h_u + 8L * D.ngrid, n, hipMemcpyHostToDevice, s), "H2D u2");
+    HCHK(hipMemcpyAsync(D.u3.p, D.h_u + 16L * D.ngrid, n, hipMemcpyHostToDevice, s), "H2D u3");
+  }
+  HCHK(hipMemcpyAsync(D.u4.p, D.h_u + 24L * D.ngrid, n, hipMemcpyHostToDevice, s), "H2D u4");
+  return 0;
+}
+static int mgamr_store_coarse(MgAmrDev &D, int k) {   // k = 1..3
+  hipStream_t s = nullptr;
+  if (D.ngrid == 0) return 0;
+  DevBuf *b[3] = {&D.u1, &D.u2, &D.u3};
+  HCHK(hipMemcpyAsync(D.h_u + (long)(k - 1) * 8 * D.ngrid, b[k - 1]->p, sizeof(double) * 8 * (size_t)D.ngrid, hipMemcpyDeviceToHost, s), "D2H");
+  HCHK(hipStreamSynchronize(s), "sync");
+  return 0;
+}
+__global__ void mgamr_scan_bit_kernel(const int *f, int *scan, long n) {
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (long)gridDim.x * blockDim.x) scan[c] = f[c] & 1;
+}
+
+int ramses_amd_mgamr_begin(int ilevel, int64_t ngridmax, int64_t ncoarse, const int *son, const int *nbor,
+                           const int *father, const int *lookup_mg, const int *flag2, double *phi, double *f,
+                           int ngrid, const int *igrid) {
+  if (!son || !nbor || !father || !lookup_mg || !flag2 || !phi || !f || (!igrid && ngrid > 0)) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (ilevel < 2 || ilevel > 30) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR multigrid on the device needs 2 <= ilevel <= 30 (got %d)", ilevel);
+  MgAmrCtx &M = g_mg;
+  hipStream_t s = nullptr;
+  const char *e = getenv("RAMSES_AMD_MG_SYNC");
+  M.sync = e && e[0] == '1';
+  M.open = true; M.ilevel = ilevel; M.ncoarse = ncoarse; M.ngridmax = ngridmax; M.ncell = ncoarse + 8 * ngridmax;
+  M.h_phi = phi; M.h_f = f; M.h_flag2 = flag2;
+  for (int l = 0; l < 32; l++) { M.lev[l].ngrid = 0; M.lev[l].level = l; M.lev[l].h_u = nullptr; M.lev[l].h_f = nullptr; }
+  HCHK(M.son.ensure(sizeof(int) * M.ncell), "hipMalloc son");
+  HCHK(M.nbor.ensure(sizeof(int) * 6 * ngridmax), "hipMalloc nbor");
+  HCHK(M.father.ensure(sizeof(int) * ngridmax), "hipMalloc father");
+  HCHK(M.lookup.ensure(sizeof(int) * ngridmax), "hipMalloc lookup");
+  HCHK(M.partial.ensure(sizeof(double) * 1024), "hipMalloc partial");
+  HCHK(M.norm.ensure(sizeof(double)), "hipMalloc norm");
+  HCHK(hipMemcpyAsync(M.son.p, son, sizeof(int) * M.ncell, hipMemcpyHostToDevice, s), "H2D son");
+  HCHK(hipMemcpyAsync(M.nbor.p, nbor, sizeof(int) * 6 * ngridmax, hipMemcpyHostToDevice, s), "H2D nbor");
+  HCHK(hipMemcpyAsync(M.father.p, father, sizeof(int) * ngridmax, hipMemcpyHostToDevice, s), "H2D father");
+  HCHK(hipMemcpyAsync(M.lookup.p, lookup_mg, sizeof(int) * ngridmax, hipMemcpyHostToDevice, s), "H2D lookup");
+  MgAmrDev &D = M.lev[ilevel];
+  D.ngrid = ngrid;
+  const size_t n = sizeof(double) * 8 * (size_t)(ngrid > 0 ? ngrid : 1);
+  HCHK(D.igrid.ensure(sizeof(int) * (size_t)(ngrid > 0 ? ngrid : 1)), "hipMalloc");
+  HCHK(D.u1.ensure(n), "hipMalloc"); HCHK(D.u2.ensure(n), "hipMalloc"); HCHK(D.u3.ensure(n), "hipMalloc"); HCHK(D.u4.ensure(n), "hipMalloc");
+  HCHK(D.scan.ensure(sizeof(int) * 8 * (size_t)(ngrid > 0 ? ngrid : 1)), "hipMalloc");
+  if (ngrid > 0) {
+    HCHK(hipMemcpyAsync(D.igrid.p, igrid, sizeof(int) * ngrid, hipMemcpyHostToDevice, s), "H2D igrid");
+    // octs of the fine level are found through the same lookup table (their lookup_mg entries are unused)
+    HCHK(mgamr_launch_lookup(D.igrid.as<int>(), ngrid, M.lookup.as<int>(), s), "lookup");
+  }
+  if (int rc = mgamr_load_fine(false)) return rc;
+  g_host.res_valid = false;
+  return 0;
+}
+
+int ramses_amd_mgamr_add_level(int level, int ngrid, const int *igrid, double *u, const int *fscan) {
+  MgAmrCtx &M = g_mg;
+  if (!M.open) return fail(RAMSES_AMD_EINVAL, "mgamr_add_level outside begin/end");
+  if (level < 1 || level >= M.ilevel) return fail(RAMSES_AMD_EINVAL, "multigrid level %d out of range", level);
+  if (ngrid > 0 && (!igrid || !u || !fscan)) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  hipStream_t s = nullptr;
+  MgAmrDev &D = M.lev[level];
+  D.ngrid = ngrid; D.h_u = u; D.h_f = fscan;
+  const size_t nn = 8 * (size_t)(ngrid > 0 ? ngrid : 1);
+  HCHK(D.igrid.ensure(sizeof(int) * (size_t)(ngrid > 0 ? ngrid : 1)), "hipMalloc");
+  HCHK(D.u1.ensure(sizeof(double) * nn), "hipMalloc"); HCHK(D.u2.ensure(sizeof(double) * nn), "hipMalloc");
+  HCHK(D.u3.ensure(sizeof(double) * nn), "hipMalloc"); HCHK(D.u4.ensure(sizeof(double) * nn), "hipMalloc");
+  HCHK(D.scan.ensure(sizeof(int) * nn), "hipMalloc");
+  if (ngrid == 0) return 0;
+  HCHK(hipMemcpyAsync(D.igrid.p, igrid, sizeof(int) * ngrid, hipMemcpyHostToDevice, s), "H2D igrid");
+  HCHK(M.ivec.ensure(sizeof(int) * nn > sizeof(int) * M.ncell ? sizeof(int) * nn : sizeof(int) * M.ncell), "hipMalloc");
+  HCHK(hipMemcpyAsync(M.ivec.p, fscan, sizeof(int) * nn, hipMemcpyHostToDevice, s), "H2D scan");
+  hipLaunchKernelGGL(mgamr_scan_bit_kernel, dim3(64), dim3(256), 0, s, M.ivec.as<int>(), D.scan.as<int>(), (long)nn);
+  HCHK(hipGetLastError(), "scan launch");
+  if (int rc = mgamr_load_coarse(D, true)) return rc;
+  HCHK(hipStreamSynchronize(s), "sync");   // host buffers of the caller may be temporaries
+  return 0;
+}
+
+static int mgamr_level(int level, MgAmrDev **out) {
+  MgAmrCtx &M = g_mg;
+  if (!M.open) return fail(RAMSES_AMD_EINVAL, "AMR multigrid routine called outside begin/end");
+  if (level < 1 || level > M.ilevel) return fail(RAMSES_AMD_EINVAL, "level %d is not part of the solve", level);
+  *out = &M.lev[level];
+  return 0;
+}
+static int mgamr_sync_in(int level, bool with_residual) {
+  MgAmrCtx &M = g_mg;
+  if (!M.sync) return 0;
+  if (level == M.ilevel) return mgamr_load_fine(with_residual);
+  return mgamr_load_coarse(M.lev[level], true);
+}
+
+int ramses_amd_mgamr_gauss_seidel(int level, int redstep, int safe) {
+  MgAmrDev *D;
+  if (int rc = mgamr_level(level, &D)) return rc;
+  if (int rc = mgamr_sync_in(level, false)) return rc;
+  const double dx = std::ldexp(1.0, -level);
+  HCHK(mgamr_launch_gs(D->view(), g_mg.tree(), redstep ? 0 : 1, safe, dx * dx, nullptr), "gs launch");
+  if (g_mg.sync) return level == g_mg.ilevel ? mgamr_store_fine(g_mg.h_phi, D->u1.as<double>()) : mgamr_store_coarse(*D, 1);
+  return 0;
+}
+int ramses_amd_mgamr_residual(int level) {
+  MgAmrDev *D;
+  if (int rc = mgamr_level(level, &D)) return rc;
+  if (int rc = mgamr_sync_in(level, false)) return rc;
+  const double dx = std::ldexp(1.0, -level);
+  HCHK(mgamr_launch_residual(D->view(), g_mg.tree(), 1.0 / (dx * dx), nullptr), "residual launch");
+  if (g_mg.sync) return level == g_mg.ilevel ? mgamr_store_fine(g_mg.h_f, D->u3.as<double>()) : mgamr_store_coarse(*D, 3);
+  return 0;
+}
+int ramses_amd_mgamr_norm2(int level, double *norm2) {
+  MgAmrDev *D;
+  if (!norm2) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (int rc = mgamr_level(level, &D)) return rc;
+  if (int rc = mgamr_sync_in(level, true)) return rc;
+  const double dx = std::ldexp(1.0, -level);
+  HCHK(mgamr_launch_norm(D->view(), dx * dx * dx, g_mg.partial.as<double>(), g_mg.norm.as<double>(), nullptr), "norm launch");
+  HCHK(hipMemcpy(norm2, g_mg.norm.p, sizeof(double), hipMemcpyDeviceToHost), "D2H norm");
+  return 0;
+}
+// restriction of the residual of `finelevel` into the rhs of finelevel-1; also zeroes that level's correction
+int ramses_amd_mgamr_restrict(int finelevel) {
+  MgAmrDev *F, *C;
+  if (int rc = mgamr_level(finelevel, &F)) return rc;
+  if (int rc = mgamr_level(finelevel - 1, &C)) return rc;
+  if (int rc = mgamr_sync_in(finelevel, true)) return rc;
+  if (g_mg.sync) if (int rc = mgamr_load_coarse(*C, true)) return rc;
+  HCHK(mgamr_launch_restrict(F->view(), C->view(), g_mg.tree(), nullptr), "restrict launch");
+  if (g_mg.sync) {
+    if (int rc = mgamr_store_coarse(*C, 2)) return rc;
+    // the correction is reset by the reference's driver itself; do not touch the host copy
+  }
+  return 0;
+}
+int ramses_amd_mgamr_interpolate(int finelevel) {
+  MgAmrDev *F, *C;
+  if (int rc = mgamr_level(finelevel, &F)) return rc;
+  if (int rc = mgamr_level(finelevel - 1, &C)) return rc;
+  if (int rc = mgamr_sync_in(finelevel, false)) return rc;
+  if (g_mg.sync) if (int rc = mgamr_load_coarse(*C, true)) return rc;
+  HCHK(mgamr_launch_interp(F->view(), C->view(), g_mg.tree(), nullptr), "interp launch");
+  if (g_mg.sync) return finelevel == g_mg.ilevel ? mgamr_store_fine(g_mg.h_phi, F->u1.as<double>()) : mgamr_store_coarse(*F, 1);
+  return 0;
+}
+// end of the solve: phi of the fine level goes back to the host array
+int ramses_amd_mgamr_end(void) {
+  MgAmrCtx &M = g_mg;
+  if (!M.open) return 0;
+  int rc = 0;
+  if (!M.sync) rc = mgamr_store_fine(M.h_phi, M.lev[M.ilevel].u1.as<double>());
+  M.open = false;
+  return rc;
 }
 #undef HCHK
 

@@ -40,11 +40,33 @@ subroutine multigrid_fine(ilevel,icount)
   end if
   if(verbose) print '(A,I2)','Entering fine multigrid (MI355X) at level ',ilevel
 
+  ! An AMR level (it does not cover the box, or it is not levelmin): the reference's own
+  ! driver and per-solve setup run on the host, the compute routines it calls (shadowed by
+  ! multigrid_fine_fine.f90 / multigrid_fine_coarse.f90 of this directory) on the device
+  nx_loc=icoarse_max-icoarse_min+1
+  if(ilevel>levelmin.or.int(active(ilevel)%ngrid,8)*8_8/=(2_8**ilevel)**3*int(nx_loc,8)**3)then
+     if(ncpu>1.or.nboundary>0)then
+        write(*,*)'ramses_amd: device multigrid on AMR levels handles periodic single-rank runs;'
+        write(*,*)'            got ncpu=',ncpu,' nboundary=',nboundary
+        call ramses_amd_fatal('multigrid_fine (AMR level: several ranks / physical boundaries)')
+     end if
+     ramses_amd_mg_active=.true.
+     ramses_amd_mg_started=.false.
+     ramses_amd_mg_level=ilevel
+     call multigrid_fine_reference(ilevel,icount)
+     if(ramses_amd_mg_started)then
+        rc=ramses_amd_mgamr_end()
+        if(rc/=0)call ramses_amd_fatal('multigrid_fine (AMR level, end)')
+     end if
+     ramses_amd_mg_active=.false.
+     return
+  end if
+
   ! What the device path does not implement stops the run (no silent fallback)
-  if(ncpu>1.or.ilevel>levelmin.or.nboundary>0)then
-     write(*,*)'ramses_amd: device multigrid_fine handles levelmin of a periodic single-rank run;'
-     write(*,*)'            got ncpu=',ncpu,' ilevel=',ilevel,' levelmin=',levelmin,' nboundary=',nboundary
-     call ramses_amd_fatal('multigrid_fine (AMR level / several ranks / physical boundaries)')
+  if(ncpu>1.or.nboundary>0)then
+     write(*,*)'ramses_amd: device multigrid_fine handles periodic single-rank runs;'
+     write(*,*)'            got ncpu=',ncpu,' nboundary=',nboundary
+     call ramses_amd_fatal('multigrid_fine (several ranks / physical boundaries)')
   end if
 
   nx_loc=icoarse_max-icoarse_min+1

@@ -92,6 +92,55 @@ module ramses_amd_iface
        integer(c_int) :: rc
      end function ramses_amd_godunov_fine_amr_f90
 
+     ! ---- multigrid on AMR levels (include/ramses_amd.h) ----
+     function ramses_amd_mgamr_begin(ilevel, ngridmax, ncoarse, son, nbor, father, lookup_mg, flag2, phi, f, &
+          & ngrid, igrid) bind(C, name='ramses_amd_mgamr_begin') result(rc)
+       import :: c_int, c_int64_t, c_double
+       integer(c_int), value :: ilevel, ngrid
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       integer(c_int) :: son(*), nbor(*), father(*), lookup_mg(*), flag2(*), igrid(*)
+       real(c_double) :: phi(*), f(*)
+       integer(c_int) :: rc
+     end function ramses_amd_mgamr_begin
+     function ramses_amd_mgamr_add_level(level, ngrid, igrid, u, fscan) &
+          & bind(C, name='ramses_amd_mgamr_add_level') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: level, ngrid
+       integer(c_int) :: igrid(*), fscan(*)
+       real(c_double) :: u(*)
+       integer(c_int) :: rc
+     end function ramses_amd_mgamr_add_level
+     function ramses_amd_mgamr_gauss_seidel(level, redstep, safe) bind(C, name='ramses_amd_mgamr_gauss_seidel') result(rc)
+       import :: c_int
+       integer(c_int), value :: level, redstep, safe
+       integer(c_int) :: rc
+     end function ramses_amd_mgamr_gauss_seidel
+     function ramses_amd_mgamr_residual(level) bind(C, name='ramses_amd_mgamr_residual') result(rc)
+       import :: c_int
+       integer(c_int), value :: level
+       integer(c_int) :: rc
+     end function ramses_amd_mgamr_residual
+     function ramses_amd_mgamr_norm2(level, norm2) bind(C, name='ramses_amd_mgamr_norm2') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: level
+       real(c_double) :: norm2
+       integer(c_int) :: rc
+     end function ramses_amd_mgamr_norm2
+     function ramses_amd_mgamr_restrict(finelevel) bind(C, name='ramses_amd_mgamr_restrict') result(rc)
+       import :: c_int
+       integer(c_int), value :: finelevel
+       integer(c_int) :: rc
+     end function ramses_amd_mgamr_restrict
+     function ramses_amd_mgamr_interpolate(finelevel) bind(C, name='ramses_amd_mgamr_interpolate') result(rc)
+       import :: c_int
+       integer(c_int), value :: finelevel
+       integer(c_int) :: rc
+     end function ramses_amd_mgamr_interpolate
+     function ramses_amd_mgamr_end() bind(C, name='ramses_amd_mgamr_end') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function ramses_amd_mgamr_end
+
      ! ---- device-resident level (include/ramses_amd.h) ----
      function ramses_amd_resident_courant_f90(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, &
           & uold, dx, dt_in, out4) bind(C, name='ramses_amd_resident_courant_f90') result(rc)
@@ -134,6 +183,11 @@ module ramses_amd_iface
 
   logical, save :: ramses_amd_checked = .false.
   logical, save :: ramses_amd_on = .true.
+  ! AMR multigrid: the reference driver is running with the device routines (set by the
+  ! multigrid_fine shim); the level arrays have been handed to the device (first routine call)
+  logical, save :: ramses_amd_mg_active = .false.
+  logical, save :: ramses_amd_mg_started = .false.
+  integer, save :: ramses_amd_mg_level = 0
   logical, save :: ramses_amd_res_checked = .false.
   logical, save :: ramses_amd_res_on = .false.
 
@@ -161,6 +215,49 @@ contains
     end if
     ramses_amd_enabled = ramses_amd_on
   end function ramses_amd_enabled
+
+  !---------------------------------------------------------------------------
+  ! First device routine of an AMR multigrid solve: hand the tree, the fine level and
+  ! the multigrid levels the reference has just built to the device.
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_mg_ensure()
+    use amr_commons
+    use poisson_commons
+    integer :: rc, l, ilevel
+    if (ramses_amd_mg_started) return
+    ilevel = ramses_amd_mg_level
+    rc = ramses_amd_mgamr_begin(ilevel, int(ngridmax, 8), int(ncoarse, 8), son, nbor, father, lookup_mg, flag2(1), &   ! flag2 is (0:ncell)
+         & phi, f, active(ilevel)%ngrid, active(ilevel)%igrid)
+    if (rc /= 0) call ramses_amd_fatal('multigrid_fine (AMR level, begin)')
+    do l = 1, ilevel - 1
+       if (active_mg(myid, l)%ngrid > 0) then
+          rc = ramses_amd_mgamr_add_level(l, active_mg(myid, l)%ngrid, active_mg(myid, l)%igrid, &
+               & active_mg(myid, l)%u, active_mg(myid, l)%f)
+          if (rc /= 0) call ramses_amd_fatal('multigrid_fine (AMR level, add_level)')
+       end if
+    end do
+    ramses_amd_mg_started = .true.
+  end subroutine ramses_amd_mg_ensure
+
+  !---------------------------------------------------------------------------
+  ! Debugging aid (only meaningful with RAMSES_AMD_MG_SYNC=1, where the host arrays stay
+  ! current): RAMSES_AMD_MG_HOST = bit mask of AMR multigrid routines to leave to the
+  ! reference: 1 gs_fine, 2 residual_fine, 4 norm2_fine, 8 restrict_fine, 16 interp_fine,
+  ! 32 gs_coarse, 64 residual_coarse, 128 restrict_coarse, 256 interp_coarse
+  !---------------------------------------------------------------------------
+  logical function ramses_amd_mg_on_device(ibit)
+    integer, intent(in) :: ibit
+    character(len=16) :: val
+    integer :: stat
+    integer, save :: mask = -1
+    if (mask < 0) then
+       mask = 0
+       call get_environment_variable('RAMSES_AMD_MG_HOST', val, status=stat)
+       if (stat == 0) read(val, *, iostat=stat) mask
+       if (stat /= 0) mask = 0
+    end if
+    ramses_amd_mg_on_device = ramses_amd_mg_active .and. iand(mask, ibit) == 0
+  end function ramses_amd_mg_on_device
 
   integer function ramses_amd_world_rank()
     use amr_commons, only: myid

@@ -71,6 +71,43 @@ def amr_namelist(lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, foutput=1
     return nml.replace("ngridtot=", "ngridtot=3000 !")
 
 
+# self-gravity on AMR levels: multigrid_fine on partially refined levels (masks, Dirichlet
+# boundaries interpolated from the coarser level, scan flags, the per-solve multigrid hierarchy)
+SELFGRAV_INIT = """nregion=3
+region_type(1)='square'
+region_type(2)='point'
+region_type(3)='square'
+x_center=0.5,0.0,0.3
+y_center=0.5,0.0,0.2
+z_center=0.5,0.0,0.25
+length_x=10.0,1.0,0.12
+length_y=10.0,1.0,0.12
+length_z=10.0,1.0,0.12
+exp_region=10.0,10.0,10.0
+d_region=1.0,0.0,20.0
+u_region=0.0,0.0,0.0
+v_region=0.0,0.0,0.0
+p_region=1e-5,0.4,1e-3"""
+SELFGRAV_NSTEP = 3
+
+
+def selfgrav_namelist(eps="1e-5"):
+    extra = """&REFINE_PARAMS
+interpol_var=0
+interpol_type=1
+err_grad_p=0.1
+err_grad_d=0.2
+/
+&POISSON_PARAMS
+epsilon=%s
+/
+""" % eps
+    nml = rs.sedov3d_namelist(level=3, nstepmax=SELFGRAV_NSTEP, foutput=SELFGRAV_NSTEP, riemann="llf", slope_type=1,
+                              extra=extra, init=SELFGRAV_INIT, poisson=True)
+    return nml.replace("levelmax=3", "levelmax=5").replace("nsubcycle=10*1", "nsubcycle=1,1,2,2").replace(
+        "ngridtot=", "ngridtot=6000 !")
+
+
 C5_NSTEP = 8
 
 
@@ -142,6 +179,22 @@ def main():
             print(tag, "mpi leaf cells", snap["level"].size, "levels", np.unique(snap["level"]))
         finally:
             shutil.rmtree(work, ignore_errors=True)
+    # AMR + self-gravity
+    work, log = rs.run_reference(selfgrav_namelist())
+    try:
+        import re
+        solves = re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+) Error=\s*(\S+)", log)
+        out["sg_solves"] = np.array([[int(a), int(b)] for a, b, _ in solves])
+        snap = rs.load_leaf_cells(os.path.join(work, "output_00002"), with_grav=True)
+        order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+        out["sg_level"] = snap["level"][order].astype(np.int8)
+        out["sg_x"] = snap["x"][order]
+        out["sg_prim"] = snap["prim"][:, order]
+        out["sg_grav"] = snap["grav"][:, order]
+        print("selfgrav leaf cells", snap["level"].size, "levels", np.unique(snap["level"]), "solves", len(solves),
+              "levels solved", sorted(set(int(a) for a, _, _ in solves)))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
     # BASELINE config C5 at 1/8 linear size (sedov3d.nml + levelmin=6, levelmax=8 + the C5 refine
     # parameters): too many cells for a fixture, so the golden is a checksum of the sorted leaf data
     import hashlib
