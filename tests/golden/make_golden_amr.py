@@ -108,6 +108,28 @@ epsilon=%s
         "ngridtot=", "ngridtot=6000 !")
 
 
+# reflexive walls on all six faces (nboundary=6): boundary octs are ordinary neighbours of the
+# tree-walking sweep, make_boundary_hydro stays the reference's host code
+WALLS = """&BOUNDARY_PARAMS
+nboundary=6
+ibound_min=-1,+1,-1,-1,-1,-1
+ibound_max=-1,+1,+1,+1,+1,+1
+jbound_min= 0, 0,-1,+1,-1,-1
+jbound_max= 0, 0,-1,+1,+1,+1
+kbound_min= 0, 0, 0, 0,-1,+1
+kbound_max= 0, 0, 0, 0,-1,+1
+bound_type= 1, 1, 1, 1, 1, 1
+/
+"""
+WALLS_NSTEP = 12
+
+
+def walls_namelist():
+    nml = rs.sedov3d_namelist(level=3, nstepmax=WALLS_NSTEP, foutput=WALLS_NSTEP, riemann="hllc", slope_type=2,
+                              extra=REFINE.format(ivar=0, itype=2) + WALLS)
+    return nml.replace("levelmax=3", "levelmax=5").replace("ngridtot=", "ngridtot=20000 !")
+
+
 C5_NSTEP = 8
 
 
@@ -179,6 +201,18 @@ def main():
             print(tag, "mpi leaf cells", snap["level"].size, "levels", np.unique(snap["level"]))
         finally:
             shutil.rmtree(work, ignore_errors=True)
+    # AMR in a box with reflexive walls
+    work, log = rs.run_reference(walls_namelist())
+    try:
+        snap = rs.load_leaf_cells(os.path.join(work, "output_00002"))
+        order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+        out["walls_level"] = snap["level"][order].astype(np.int8)
+        out["walls_x"] = snap["x"][order]
+        out["walls_prim"] = snap["prim"][:, order]
+        print("walls leaf cells", snap["level"].size, "levels", np.unique(snap["level"]),
+              "x range", snap["x"].min(), snap["x"].max())
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
     # AMR + self-gravity
     work, log = rs.run_reference(selfgrav_namelist())
     try:
