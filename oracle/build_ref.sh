@@ -90,7 +90,7 @@ build_ramses() {
   [ -n "${REF_TAG:-}" ] && tag="${tag}_${REF_TAG}"
   local obj="$OUT/obj_$tag" gen="$OUT/gen_$tag"
   mkdir -p "$obj" "$gen"
-  local flags="$(defines $ndim) ${REF_DEFS:-} $OPT -module-dir $obj -I$obj -I$REF"
+  local flags="$(defines $ndim ${REF_NVAR:-}) ${REF_DEFS:-} $OPT -module-dir $obj -I$obj -I$REF"   # REF_NVAR: passive scalars
   local libs=""
   if [ "$mode" = mpi ]; then
     flags="$flags -DMPI_OLD -I/opt/conda/include"
@@ -178,6 +178,10 @@ case "$cmd" in
            build_ramses 3 mpi "$HERE/../ramses_amd/patch"
          fi
        fi
-       build_ramses 3 serial "$HERE/dump_patch";;
+       build_ramses 3 serial "$HERE/dump_patch"
+       REF_NVAR=7 REF_TAG=v7 build_ramses 3 serial
+       if [ -f "$HERE/../ramses_amd/lib/libramses_amd.so" ]; then
+         REF_NVAR=7 REF_TAG=v7 build_ramses 3 serial "$HERE/../ramses_amd/patch"
+       fi;;
   *) echo "usage: $0 kernels [NDIM] | ramses [NDIM] [serial|mpi] [PATCHDIR] | all"; exit 2;;
 esac

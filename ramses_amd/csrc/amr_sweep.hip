@@ -31,18 +31,19 @@
 namespace ramses_amd {
 namespace amrsweep {
 
-constexpr int NV = 5;
 constexpr int OCTS_PER_BLOCK = 4;
 
+template <int NV>
 struct OctFaces {
   double qm[3][3][2][2][NV];  // traced state on the +d face of trace cell a (a = 0..2), transverse 1..2
   double qp[3][3][2][2][NV];  // traced state on the -d face of trace cell a+1
   double fl[3][3][2][2][NV];  // flux through face a of direction d
 };
+template <int NV>
 struct OctLds {
   union {
     double u[216][NV];      // primitive variables of the 6^3 stencil (until the traces are done)
-    OctFaces f;             // then the face states and fluxes reuse the same memory
+    OctFaces<NV> f;             // then the face states and fluxes reuse the same memory
   };
   int fc[27];               // the 3^3 neighbouring father cells (1-based cell index)
   int ex[27];               // their son oct (0: not refined)
@@ -80,13 +81,13 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int ST, int RS, bool GRAV>
+template <int ST, int RS, bool GRAV, int NV>
 __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSweepArgs A) {
-  __shared__ OctLds lds[OCTS_PER_BLOCK];
+  __shared__ OctLds<NV> lds[OCTS_PER_BLOCK];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int io = blockIdx.x * OCTS_PER_BLOCK + w;
   if (io >= A.ngrid) return;                   // whole wave: no block-level barrier is used
-  OctLds &L = lds[w];
+  OctLds<NV> &L = lds[w];
   const HydroConst &P = A.P;
   const int g = A.igrid[io];
   const long ncell = A.ncell;
@@ -270,6 +271,7 @@ __global__ void amr_posof_kernel(const int *igrid, int ngrid, int *posof) {
 // the reference's loop order (batch of nvector octs, idim, left before right)
 // replays all of them sequentially.
 __global__ __launch_bounds__(256) void amr_coarse_update_kernel(AmrSweepArgs A, const int *posof, int nvector) {
+  const int NV = A.nvar;
   const long ev = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (ev >= (long)A.ngrid * 6) return;
   const int C = A.corr_tgt[ev];
@@ -324,13 +326,22 @@ __global__ __launch_bounds__(256) void amr_coarse_update_kernel(AmrSweepArgs A, 
   }
 }
 
-template <int ST, int RS>
-static hipError_t launch2(const AmrSweepArgs &A, hipStream_t s) {
+template <int ST, int RS, int NV>
+static hipError_t launch3(const AmrSweepArgs &A, hipStream_t s) {
   const int blocks = (A.ngrid + OCTS_PER_BLOCK - 1) / OCTS_PER_BLOCK;
   const dim3 grid(blocks), block(64 * OCTS_PER_BLOCK);
-  if (A.grav) hipLaunchKernelGGL((amr_godunov_kernel<ST, RS, true>), grid, block, 0, s, A);
-  else hipLaunchKernelGGL((amr_godunov_kernel<ST, RS, false>), grid, block, 0, s, A);
+  if (A.grav) hipLaunchKernelGGL((amr_godunov_kernel<ST, RS, true, NV>), grid, block, 0, s, A);
+  else hipLaunchKernelGGL((amr_godunov_kernel<ST, RS, false, NV>), grid, block, 0, s, A);
   return hipGetLastError();
+}
+template <int ST, int RS>
+static hipError_t launch2(const AmrSweepArgs &A, hipStream_t s) {
+  switch (A.nvar) {
+    case 5: return launch3<ST, RS, 5>(A, s);
+    case 6: return launch3<ST, RS, 6>(A, s);
+    case 7: return launch3<ST, RS, 7>(A, s);
+  }
+  return hipErrorInvalidValue;
 }
 
 template <int ST>

@@ -13,6 +13,7 @@ struct AmrSweepArgs {
   const int *father;    // [ngridmax]
   const int *igrid;     // active(ilevel)%igrid, 1-based oct indices
   int ngrid;
+  int nvar;             // 5 + passive scalars (<= 7)
   long ncell, ncoarse, ngridmax;
   double dt, dx, rdx;
   int pow2;

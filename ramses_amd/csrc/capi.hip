@@ -710,11 +710,11 @@ int ramses_amd_godunov_fine_host(const ramses_amd_hydro_params *p, int ilevel, i
 // workspace of the device entry point, in bytes
 int64_t ramses_amd_godunov_fine_amr_workspace(int ngrid, int64_t ngridmax) {
   if (ngrid < 0 || ngridmax < 1) return fail(RAMSES_AMD_EINVAL, "bad argument");
-  return (int64_t)(sizeof(double) * (size_t)ngrid * 6 * 4 * 5 + sizeof(int) * (size_t)ngrid * 6 + sizeof(int) * (size_t)ngridmax + 64);
+  return (int64_t)(sizeof(double) * (size_t)ngrid * 6 * 4 * 7 + sizeof(int) * (size_t)ngrid * 6 + sizeof(int) * (size_t)ngridmax + 64);
 }
 
 static int amr_check(const ramses_amd_hydro_params *p, int ilevel, int nvector, int interpol_var, int interpol_type) {
-  if (p->ndim != 3 || p->nvar != 5) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep implements NDIM=3, NVAR=5");
+  if (p->ndim != 3 || p->nvar < 5 || p->nvar > 7) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep implements NDIM=3, NVAR=5..7");
   if (p->scheme != 0) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep implements scheme='muscl'");
   if (p->slope_type == 3) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep does not implement slope_type=3");
   if (p->difmag != 0.0) return fail(RAMSES_AMD_EUNSUPPORTED, "difmag>0 is not on the device");
@@ -739,14 +739,14 @@ int ramses_amd_godunov_fine_amr_device(const ramses_amd_hydro_params *p, int ile
   AmrSweepArgs A;
   A.uold = d_uold; A.unew = d_unew; A.grav = d_grav;
   A.son = d_son; A.nbor = d_nbor; A.father = d_father;
-  A.igrid = d_igrid; A.ngrid = ngrid;
+  A.igrid = d_igrid; A.ngrid = ngrid; A.nvar = p->nvar;
   A.ncell = ncoarse + 8 * ngridmax; A.ncoarse = ncoarse; A.ngridmax = ngridmax;
   A.dt = dt; A.dx = dx; A.rdx = 1.0 / dx;
   { int ex; A.pow2 = (std::frexp(dx, &ex) == 0.5) ? 1 : 0; }
   A.interpol_var = interpol_var; A.interpol_type = interpol_type;
   char *w = reinterpret_cast<char *>(d_work);
   A.corr = reinterpret_cast<double *>(w);
-  w += sizeof(double) * (size_t)ngrid * 6 * 4 * 5;
+  w += sizeof(double) * (size_t)ngrid * 6 * 4 * 7;
   A.corr_tgt = reinterpret_cast<int *>(w);
   w += sizeof(int) * (size_t)ngrid * 6;
   int *posof = reinterpret_cast<int *>(w);
@@ -771,16 +771,17 @@ int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ileve
   HostCtx &H = g_host;
   static DevBuf dson, dnbor, dfather, dwork;
 #define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipfail(e_, what); } while (0)
-  HCHK(H.uold.ensure(sizeof(double) * 5 * ncell), "hipMalloc uold");
-  HCHK(H.unew.ensure(sizeof(double) * 5 * ncell), "hipMalloc unew");
+  const int nvar = p->nvar;
+  HCHK(H.uold.ensure(sizeof(double) * nvar * ncell), "hipMalloc uold");
+  HCHK(H.unew.ensure(sizeof(double) * nvar * ncell), "hipMalloc unew");
   HCHK(H.igrid.ensure(sizeof(int) * ngrid), "hipMalloc igrid");
   HCHK(dson.ensure(sizeof(int) * ncell), "hipMalloc son");
   HCHK(dnbor.ensure(sizeof(int) * 6 * ngridmax), "hipMalloc nbor");
   HCHK(dfather.ensure(sizeof(int) * ngridmax), "hipMalloc father");
   HCHK(dwork.ensure((size_t)ramses_amd_godunov_fine_amr_workspace(ngrid, ngridmax)), "hipMalloc work");
   HCHK(H.flag.ensure(sizeof(int)), "hipMalloc flag");
-  HCHK(hipMemcpyAsync(H.uold.p, uold, sizeof(double) * 5 * ncell, hipMemcpyHostToDevice, s), "H2D uold");
-  HCHK(hipMemcpyAsync(H.unew.p, unew, sizeof(double) * 5 * ncell, hipMemcpyHostToDevice, s), "H2D unew");
+  HCHK(hipMemcpyAsync(H.uold.p, uold, sizeof(double) * nvar * ncell, hipMemcpyHostToDevice, s), "H2D uold");
+  HCHK(hipMemcpyAsync(H.unew.p, unew, sizeof(double) * nvar * ncell, hipMemcpyHostToDevice, s), "H2D unew");
   HCHK(hipMemcpyAsync(H.igrid.p, igrid, sizeof(int) * ngrid, hipMemcpyHostToDevice, s), "H2D igrid");
   HCHK(hipMemcpyAsync(dson.p, son, sizeof(int) * ncell, hipMemcpyHostToDevice, s), "H2D son");
   HCHK(hipMemcpyAsync(dnbor.p, nbor, sizeof(int) * 6 * ngridmax, hipMemcpyHostToDevice, s), "H2D nbor");
@@ -799,7 +800,7 @@ int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ileve
                                                   dwork.p, H.flag.as<int>(), s)) return rc;
   int bad = 0;
   HCHK(hipMemcpyAsync(&bad, H.flag.p, sizeof(int), hipMemcpyDeviceToHost, s), "D2H flag");
-  HCHK(hipMemcpyAsync(unew, H.unew.p, sizeof(double) * 5 * ncell, hipMemcpyDeviceToHost, s), "D2H unew");
+  HCHK(hipMemcpyAsync(unew, H.unew.p, sizeof(double) * nvar * ncell, hipMemcpyDeviceToHost, s), "D2H unew");
   HCHK(hipStreamSynchronize(s), "sync");
 #undef HCHK
   if (bad) return fail(RAMSES_AMD_EINVAL, "level %d: %d of the 3^3 father cells of an oct do not exist (tree inconsistent)", ilevel, bad);

@@ -130,6 +130,23 @@ def walls_namelist():
     return nml.replace("levelmax=3", "levelmax=5").replace("ngridtot=", "ngridtot=20000 !")
 
 
+# two passive scalars (NVAR=7 builds): interpolation, sweep and coarse corrections of the scalars
+V7_INIT = SELFGRAV_INIT + """
+var_region(1,1)=0.1
+var_region(1,2)=0.2
+var_region(3,1)=0.9
+var_region(3,2)=0.5"""
+V7_NSTEP = 5
+
+
+def v7_namelist():
+    nml = rs.sedov3d_namelist(level=3, nstepmax=V7_NSTEP, foutput=V7_NSTEP, riemann="hllc", slope_type=1,
+                              extra=REFINE.format(ivar=1, itype=1).replace("err_grad_p=0.1", "err_grad_p=0.1\nerr_grad_d=0.2"),
+                              init=V7_INIT)
+    return nml.replace("levelmax=3", "levelmax=5").replace("nsubcycle=10*1", "nsubcycle=1,1,2,2").replace(
+        "ngridtot=", "ngridtot=8000 !")
+
+
 C5_NSTEP = 8
 
 
@@ -201,6 +218,17 @@ def main():
             print(tag, "mpi leaf cells", snap["level"].size, "levels", np.unique(snap["level"]))
         finally:
             shutil.rmtree(work, ignore_errors=True)
+    # AMR with two passive scalars
+    work, log = rs.run_reference(v7_namelist(), binary=os.path.join(ROOT, "oracle", "_ref", "ramses3d_v7"))
+    try:
+        snap = rs.load_leaf_cells(os.path.join(work, "output_00002"))
+        order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+        out["v7_level"] = snap["level"][order].astype(np.int8)
+        out["v7_prim"] = snap["prim"][:, order]
+        print("v7 leaf cells", snap["level"].size, "levels", np.unique(snap["level"]), "nvar", snap["prim"].shape[0],
+              "scalar range", snap["prim"][5].min(), snap["prim"][5].max())
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
     # AMR in a box with reflexive walls
     work, log = rs.run_reference(walls_namelist())
     try:
