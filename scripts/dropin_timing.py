@@ -44,7 +44,52 @@ def run(tag, binary, level, nstep, env):
                       "timers_s": rows}), flush=True)
 
 
+def run_amr(tag, binary, env, lmin, lmax, nstep):
+    """AMR + self-gravity (the blob + blast setup of tests/golden/make_golden_amr.py at higher levels)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mka", os.path.join(ROOT, "tests", "golden", "make_golden_amr.py"))
+    mka = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mka)
+    nml = mka.selfgrav_namelist().replace("levelmin=3", "levelmin=%d" % lmin).replace("levelmax=5", "levelmax=%d" % lmax)
+    nml = nml.replace("nstepmax=%d" % mka.SELFGRAV_NSTEP, "nstepmax=%d" % nstep).replace("ngridtot=6000 !", "ngridtot=600000 !")
+    nml = nml.replace("foutput=%d" % mka.SELFGRAV_NSTEP, "foutput=1000")
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    t0 = time.time()
+    try:
+        work, out = rs.run_reference(nml, binary=binary, timeout=3000)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    wall = time.time() - t0
+    shutil.rmtree(work, ignore_errors=True)
+    rows = {}
+    for line in out.splitlines():
+        m = re.match(r"^\s*([0-9.]+)\s+([0-9.]+)\s+([a-zA-Z].*?)\s*$", line)
+        if m and "STEP" not in m.group(3):
+            rows[m.group(3)] = float(m.group(1))
+    grids = re.findall(r"Level\s+(\d+) has\s+(\d+) grids", out)
+    last = {}
+    for l, g in grids:
+        last[int(l)] = int(g)
+    print(json.dumps({"config": tag, "levels": [lmin, lmax], "steps": nstep, "wall_s": round(wall, 3),
+                      "octs_per_level": {k: v for k, v in last.items() if k >= lmin}, "timers_s": rows}), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "amr":
+        lmin, lmax, nstep = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+        which = sys.argv[5] if len(sys.argv) > 5 else "all"
+        ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d")
+        pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch")
+        if which in ("all", "gpu"):
+            run_amr("patched (AMR sweep + AMR multigrid on the device, arrays staged per call)", pat, {"RAMSES_AMD": "1"}, lmin, lmax, nstep)
+        if which in ("all", "ref"):
+            run_amr("reference (1 core)", ref, {"RAMSES_AMD": "0"}, lmin, lmax, nstep)
+        sys.exit(0)
     level = int(sys.argv[1]) if len(sys.argv) > 1 else 7
     nstep = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     which = sys.argv[3] if len(sys.argv) > 3 else "all"
