@@ -45,6 +45,8 @@ struct OctLds {
     double u[216][NV];      // primitive variables of the 6^3 stencil (until the traces are done)
     OctFaces<NV> f;             // then the face states and fluxes reuse the same memory
   };
+  double uc[64][NV];        // conserved variables of the inner 4^3 cells (difmag only)
+  double divc[27];          // velocity divergence at the 3^3 cell corners (difmag only)
   int fc[27];               // the 3^3 neighbouring father cells (1-based cell index)
   int ex[27];               // their son oct (0: not refined)
   unsigned char ok[216];    // cell is refined
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
   // (gravity: f of the cell for existing octs, straight injection of the father
   // cell's f for interpolated cells, hydro/godunov_fine.f90:637-647)
   const double dtxhalf = A.dt * 0.5;
+  const bool difmag = A.difmag > 0.0;
   // lanes run over the neighbour octs first, the octant second: cell `ind` of octs that
   // were created together (siblings, Z-order) is contiguous in uold, so neighbouring
   // lanes share cache lines instead of striding by ngridmax
@@ -133,6 +136,11 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
 #pragma unroll
       for (int v = 0; v < NV; v++) L.u[s][v] = q[v];
       L.ok[s] = A.son[cell - 1] > 0;
+      if (difmag && i3 >= 1 && i3 <= 4 && j3 >= 1 && j3 <= 4 && k3 >= 1 && k3 <= 4) {
+        const int cc = (i3 - 1) + 4 * ((j3 - 1) + 4 * (k3 - 1));
+#pragma unroll
+        for (int v = 0; v < NV; v++) L.uc[cc][v] = u[v];
+      }
     }
   }
   if (lane < 27 && L.ex[lane] == 0 && L.fc[lane] > 0) {
@@ -165,9 +173,31 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
 #pragma unroll
       for (int v = 0; v < NV; v++) L.u[s][v] = q[v];
       L.ok[s] = 0;
+      if (difmag && i3 >= 1 && i3 <= 4 && j3 >= 1 && j3 <= 4 && k3 >= 1 && k3 <= 4) {
+        const int cc = (i3 - 1) + 4 * ((j3 - 1) + 4 * (k3 - 1));
+#pragma unroll
+        for (int v = 0; v < NV; v++) L.uc[cc][v] = u2[ind][v];
+      }
     }
   }
   wave_sync();
+
+  // ---- (C') cmpdivu (hydro/uplmde.f90:702-764): velocity divergence at the 3^3 corners ----
+  if (difmag && lane < 27) {
+    // corner (i,j,k), i,j,k = 1..3 in the reference's flux indexing = stencil cells i, i+1
+    const int ci = lane % 3 + 2, cj = (lane / 3) % 3 + 2, ck = lane / 9 + 2;   // stencil coordinate of cell (i,j,k)
+    const double fct = 0.25 / A.dx;
+    auto Q = [&](int di, int dj, int dk, int v) { return L.u[sidx(ci + di, cj + dj, ck + dk)][v]; };
+    double ux = 0.0, vy = 0.0, wz = 0.0;
+    ux = ux + fct * (Q(0, 0, 0, 1) - Q(-1, 0, 0, 1));
+    ux = ux + fct * (Q(0, -1, 0, 1) - Q(-1, -1, 0, 1));
+    vy = vy + fct * (Q(0, 0, 0, 2) - Q(0, -1, 0, 2) + Q(-1, 0, 0, 2) - Q(-1, -1, 0, 2));
+    ux = ux + fct * (Q(0, 0, -1, 1) - Q(-1, 0, -1, 1) + Q(0, -1, -1, 1) - Q(-1, -1, -1, 1));
+    vy = vy + fct * (Q(0, 0, -1, 2) - Q(0, -1, -1, 2) + Q(-1, 0, -1, 2) - Q(-1, -1, -1, 2));
+    wz = wz + fct * (Q(0, 0, 0, 3) - Q(0, 0, -1, 3) + Q(0, -1, 0, 3) - Q(0, -1, -1, 3) + Q(-1, 0, 0, 3) - Q(-1, 0, -1, 3) +
+                     Q(-1, -1, 0, 3) - Q(-1, -1, -1, 3));
+    L.divc[lane] = ux + vy + wz;
+  }
 
   // ---- (D) slopes + trace: lane = one of the 4^3 cells ------------------------
   const double dtdx = A.dt / A.dx;
@@ -214,9 +244,37 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
     if (d == 0) scaled_interface_flux<RS, NV, 0>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
     else if (d == 1) scaled_interface_flux<RS, NV, 1>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
     else scaled_interface_flux<RS, NV, 2>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
+    const int t0 = d == 0 ? 1 : 0, t1 = d == 2 ? 1 : 2;
+    if (difmag) {
+      // consup (hydro/uplmde.f90:769-866): the face's flux index along d is a+1, the own
+      // cells' transverse indices are b+1, c+1; corners (i,j,k) live at divc[(i-1)+3(j-1)+9(k-1)]
+      int fi[3];
+      fi[d] = a + 1; fi[t0] = b + 1; fi[t1] = c + 1;
+      auto DV = [&](int i, int j, int k) { return L.divc[(i - 1) + 3 * (j - 1) + 9 * (k - 1)]; };
+      const int i = fi[0], j = fi[1], k = fi[2];
+      const double factor = 0.25;
+      double div1;
+      if (d == 0) {
+        div1 = factor * DV(i, j, k);
+        div1 = div1 + factor * DV(i, j + 1, k);
+        div1 = div1 + factor * (DV(i, j, k + 1) + DV(i, j + 1, k + 1));
+      } else if (d == 1) {
+        div1 = 0.0;
+        div1 = div1 + factor * (DV(i, j, k) + DV(i + 1, j, k));
+        div1 = div1 + factor * (DV(i, j, k + 1) + DV(i + 1, j, k + 1));
+      } else {
+        div1 = factor * (DV(i, j, k) + DV(i + 1, j, k) + DV(i, j + 1, k) + DV(i + 1, j + 1, k));
+      }
+      div1 = A.difmag * __builtin_fmin(0.0, div1);
+      // conserved variables of the two cells of the face (4^3 coordinates = the reference's cell index)
+      int cr4[3] = {fi[0], fi[1], fi[2]}, cl4[3] = {fi[0], fi[1], fi[2]};
+      cl4[d] -= 1;
+      const int ir = cr4[0] + 4 * (cr4[1] + 4 * cr4[2]), il = cl4[0] + 4 * (cl4[1] + 4 * cl4[2]);
+#pragma unroll
+      for (int v = 0; v < NV; v++) fx[v] = fx[v] + A.dt * div1 * (L.uc[ir][v] - L.uc[il][v]);
+    }
     // stencil coordinates of the two cells of the face
     int cl[3];
-    const int t0 = d == 0 ? 1 : 0, t1 = d == 2 ? 1 : 2;
     cl[d] = a + 1; cl[t0] = b + 2; cl[t1] = c + 2;
     const int sl = sidx(cl[0], cl[1], cl[2]);
     const int stride = d == 0 ? 1 : (d == 1 ? 6 : 36);

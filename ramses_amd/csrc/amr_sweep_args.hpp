@@ -16,6 +16,7 @@ struct AmrSweepArgs {
   int nvar;             // 5 + passive scalars (<= 7)
   long ncell, ncoarse, ngridmax;
   double dt, dx, rdx;
+  double difmag;        // artificial diffusion coefficient (cmpdivu + consup), 0: off
   int pow2;
   int interpol_var, interpol_type;
   double *corr;         // [ngrid][6][4][nvar] fluxes owed to coarse neighbour cells

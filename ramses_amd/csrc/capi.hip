@@ -717,7 +717,7 @@ static int amr_check(const ramses_amd_hydro_params *p, int ilevel, int nvector, 
   if (p->ndim != 3 || p->nvar < 5 || p->nvar > 7) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep implements NDIM=3, NVAR=5..7");
   if (p->scheme != 0) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep implements scheme='muscl'");
   if (p->slope_type == 3) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep does not implement slope_type=3");
-  if (p->difmag != 0.0) return fail(RAMSES_AMD_EUNSUPPORTED, "difmag>0 is not on the device");
+  if (p->difmag < 0.0) return fail(RAMSES_AMD_EINVAL, "difmag must be >= 0");
   if (ilevel < 3) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep needs ilevel >= 3 (father cells inside octs); got %d", ilevel);
   if (nvector < 1) return fail(RAMSES_AMD_EINVAL, "nvector must be >= 1");
   if (interpol_var < 0 || interpol_var > 2 || interpol_type < 0 || interpol_type > 4) return fail(RAMSES_AMD_EINVAL, "interpol_var/interpol_type out of range");
@@ -741,7 +741,7 @@ int ramses_amd_godunov_fine_amr_device(const ramses_amd_hydro_params *p, int ile
   A.son = d_son; A.nbor = d_nbor; A.father = d_father;
   A.igrid = d_igrid; A.ngrid = ngrid; A.nvar = p->nvar;
   A.ncell = ncoarse + 8 * ngridmax; A.ncoarse = ncoarse; A.ngridmax = ngridmax;
-  A.dt = dt; A.dx = dx; A.rdx = 1.0 / dx;
+  A.dt = dt; A.dx = dx; A.rdx = 1.0 / dx; A.difmag = p->difmag;
   { int ex; A.pow2 = (std::frexp(dx, &ex) == 0.5) ? 1 : 0; }
   A.interpol_var = interpol_var; A.interpol_type = interpol_type;
   char *w = reinterpret_cast<char *>(d_work);

@@ -99,6 +99,8 @@ subroutine godunov_fine(ilevel)
   ! several MPI ranks (each sweeps its own active octs; ghost octs of the other ranks are
   ! ordinary neighbours in the tree) and physical boundary octs: the tree-walking sweep
   if(ncpu>1.or.nboundary>0)amr_level=.true.
+  ! artificial diffusion (cmpdivu + consup) is implemented in the tree-walking sweep only
+  if(difmag>0.0d0)amr_level=.true.
 
   if(amr_level)then
      if(poisson)then

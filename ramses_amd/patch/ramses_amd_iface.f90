@@ -288,6 +288,7 @@ contains
        if (.not. hydro .or. poisson .or. pic .or. rt .or. cooling .or. star .or. sink .or. stellar) ramses_amd_res_on = .false.
        if (tracer .or. MC_tracer .or. clumpfind .or. lightcone .or. movie .or. aton) ramses_amd_res_on = .false.
        if (static .or. static_gas .or. neq_chem .or. barotropic_eos .or. isothermal .or. metal) ramses_amd_res_on = .false.
+       if (difmag > 0.0d0) ramses_amd_res_on = .false.
        if (pressure_fix .or. T2_star > 0.0d0 .or. momentum_feedback > 0 .or. strict_equilibrium > 0) &
             & ramses_amd_res_on = .false.
        if (ndim /= 3) ramses_amd_res_on = .false.

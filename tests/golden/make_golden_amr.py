@@ -147,6 +147,13 @@ def v7_namelist():
         "ngridtot=", "ngridtot=8000 !")
 
 
+def difmag_namelist():
+    """case "b" with artificial diffusion (cmpdivu + consup): every level, uniform or not, takes the tree-walking sweep"""
+    b = [c for c in CASES if c[0] == "b"][0]
+    _, lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, _ = b
+    return amr_namelist(lmin, lmax, nsub, riemann, slope, ivar, itype, nstep).replace("riemann='hllc'", "riemann='hllc'\ndifmag=0.1")
+
+
 C5_NSTEP = 8
 
 
@@ -218,6 +225,18 @@ def main():
             print(tag, "mpi leaf cells", snap["level"].size, "levels", np.unique(snap["level"]))
         finally:
             shutil.rmtree(work, ignore_errors=True)
+    # AMR with difmag
+    work, log = rs.run_reference(difmag_namelist())
+    try:
+        nst = [c for c in CASES if c[0] == "b"][0][8]
+        snap = rs.load_leaf_cells(os.path.join(work, "output_%05d" % (nst + 1)))
+        order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+        out["difmag_level"] = snap["level"][order].astype(np.int8)
+        out["difmag_prim"] = snap["prim"][:, order]
+        print("difmag leaf cells", snap["level"].size, "differs from case b:",
+              not np.array_equal(out["difmag_prim"], out.get("b_e2e%d_prim" % (nst + 1))))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
     # AMR with two passive scalars
     work, log = rs.run_reference(v7_namelist(), binary=os.path.join(ROOT, "oracle", "_ref", "ramses3d_v7"))
     try:
