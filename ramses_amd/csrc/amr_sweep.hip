@@ -83,7 +83,7 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int ST, int RS, bool GRAV, int NV>
+template <int ST, int RS, bool GRAV, int NV, int SCHEME>
 __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSweepArgs A) {
   __shared__ OctLds<NV> lds[OCTS_PER_BLOCK];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -208,12 +208,26 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
 #pragma unroll
     for (int v = 0; v < NV; v++) {
       qb[v] = L.u[s][v];
-      dq[0][v] = slope1<ST>(L.u[s - 1][v], qb[v], L.u[s + 1][v], P);
-      dq[1][v] = slope1<ST>(L.u[s - 6][v], qb[v], L.u[s + 6][v], P);
-      dq[2][v] = slope1<ST>(L.u[s - 36][v], qb[v], L.u[s + 36][v], P);
+      if constexpr (ST == 3) {
+        // positivity-preserving multi-D slope: the 3^3 neighbourhood of the cell
+        double nb[27], d3[3];
+#pragma unroll
+        for (int t = 0; t < 27; t++) nb[t] = L.u[s + (t % 3 - 1) + 6 * ((t / 3) % 3 - 1) + 36 * (t / 9 - 1)][v];
+        slope3_var(nb, d3);
+        dq[0][v] = d3[0]; dq[1][v] = d3[1]; dq[2][v] = d3[2];
+      } else {
+        dq[0][v] = slope1<ST>(L.u[s - 1][v], qb[v], L.u[s + 1][v], P);
+        dq[1][v] = slope1<ST>(L.u[s - 6][v], qb[v], L.u[s + 6][v], P);
+        dq[2][v] = slope1<ST>(L.u[s - 36][v], qb[v], L.u[s + 36][v], P);
+      }
     }
     double qm[3][NV], qp[3][NV];
-    trace3d_cell<NV>(qb, dq, dtdx, dtdx, dtdx, P, qm, qp);
+    if constexpr (SCHEME == 0) {
+      trace3d_cell<NV>(qb, dq, dtdx, dtdx, dtdx, P, qm, qp);
+    } else {
+      const double cs = ctoprim_sound(qb[0], qb[4], P);
+      tracexyz_cell<NV>(qb, dq, cs, dtdx, dtdx, dtdx, P, qm, qp);
+    }
     wave_sync();            // every lane has read its stencil values: the memory is reused below
     const int tc[3] = {ti, tj, tk};
 #pragma unroll
@@ -388,8 +402,18 @@ template <int ST, int RS, int NV>
 static hipError_t launch3(const AmrSweepArgs &A, hipStream_t s) {
   const int blocks = (A.ngrid + OCTS_PER_BLOCK - 1) / OCTS_PER_BLOCK;
   const dim3 grid(blocks), block(64 * OCTS_PER_BLOCK);
-  if (A.grav) hipLaunchKernelGGL((amr_godunov_kernel<ST, RS, true, NV>), grid, block, 0, s, A);
-  else hipLaunchKernelGGL((amr_godunov_kernel<ST, RS, false, NV>), grid, block, 0, s, A);
+  if (A.scheme == 1) {
+    // scheme='plmde' (tracexyz): hydro variables only, like the dense sweep
+    if constexpr (NV == 5) {
+      if (A.grav) hipLaunchKernelGGL((amr_godunov_kernel<ST, RS, true, NV, 1>), grid, block, 0, s, A);
+      else hipLaunchKernelGGL((amr_godunov_kernel<ST, RS, false, NV, 1>), grid, block, 0, s, A);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
+  if (A.grav) hipLaunchKernelGGL((amr_godunov_kernel<ST, RS, true, NV, 0>), grid, block, 0, s, A);
+  else hipLaunchKernelGGL((amr_godunov_kernel<ST, RS, false, NV, 0>), grid, block, 0, s, A);
   return hipGetLastError();
 }
 template <int ST, int RS>
@@ -428,6 +452,7 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A, int slope_type, int riemann
     case 0: e = launch1<0>(A, riemann, s); break;
     case 1: e = launch1<1>(A, riemann, s); break;
     case 2: e = launch1<2>(A, riemann, s); break;
+    case 3: e = launch1<3>(A, riemann, s); break;
     case 7: e = launch1<7>(A, riemann, s); break;
     case 8: e = launch1<8>(A, riemann, s); break;
     default: return hipErrorInvalidValue;

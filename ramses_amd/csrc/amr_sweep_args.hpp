@@ -14,6 +14,7 @@ struct AmrSweepArgs {
   const int *igrid;     // active(ilevel)%igrid, 1-based oct indices
   int ngrid;
   int nvar;             // 5 + passive scalars (<= 7)
+  int scheme;           // 0 muscl (trace3d), 1 plmde (tracexyz)
   long ncell, ncoarse, ngridmax;
   double dt, dx, rdx;
   double difmag;        // artificial diffusion coefficient (cmpdivu + consup), 0: off

@@ -715,8 +715,8 @@ int64_t ramses_amd_godunov_fine_amr_workspace(int ngrid, int64_t ngridmax) {
 
 static int amr_check(const ramses_amd_hydro_params *p, int ilevel, int nvector, int interpol_var, int interpol_type) {
   if (p->ndim != 3 || p->nvar < 5 || p->nvar > 7) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep implements NDIM=3, NVAR=5..7");
-  if (p->scheme != 0) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep implements scheme='muscl'");
-  if (p->slope_type == 3) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep does not implement slope_type=3");
+  if (p->scheme != 0 && p->scheme != 1) return fail(RAMSES_AMD_EINVAL, "unknown scheme %d", p->scheme);
+  if (p->scheme == 1 && p->nvar != 5) return fail(RAMSES_AMD_EUNSUPPORTED, "passive scalars with scheme='plmde' are not on the device yet");
   if (p->difmag < 0.0) return fail(RAMSES_AMD_EINVAL, "difmag must be >= 0");
   if (ilevel < 3) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR device sweep needs ilevel >= 3 (father cells inside octs); got %d", ilevel);
   if (nvector < 1) return fail(RAMSES_AMD_EINVAL, "nvector must be >= 1");
@@ -739,7 +739,7 @@ int ramses_amd_godunov_fine_amr_device(const ramses_amd_hydro_params *p, int ile
   AmrSweepArgs A;
   A.uold = d_uold; A.unew = d_unew; A.grav = d_grav;
   A.son = d_son; A.nbor = d_nbor; A.father = d_father;
-  A.igrid = d_igrid; A.ngrid = ngrid; A.nvar = p->nvar;
+  A.igrid = d_igrid; A.ngrid = ngrid; A.nvar = p->nvar; A.scheme = p->scheme;
   A.ncell = ncoarse + 8 * ngridmax; A.ncoarse = ncoarse; A.ngridmax = ngridmax;
   A.dt = dt; A.dx = dx; A.rdx = 1.0 / dx; A.difmag = p->difmag;
   { int ex; A.pow2 = (std::frexp(dx, &ex) == 0.5) ? 1 : 0; }
