@@ -39,6 +39,8 @@ def parse():
                     help="N>1: hide the halo exchange behind the interior sweep (auto: measure both, keep the faster)")
     ap.add_argument("--vcycle-level", type=int, default=9,
                     help="multigrid V-cycle measurement: 2^level cells per direction per GPU (0 = skip)")
+    ap.add_argument("--mg-tune", type=int, default=-1,
+                    help="fused smoother: 1 = 4 colour passes per launch, 12/16 = 2+2 passes on 12/16-row tiles (-1: library default)")
     ap.add_argument("--vcycle-deadline", type=int, default=180, help="N>1: seconds before the V-cycle leg is abandoned")
     return ap.parse_args()
 
@@ -234,6 +236,8 @@ def main():
     pgrid = rank_grid(world)
     if args.zchunk or args.tile_rows:
         check(lib().ramses_amd_godunov_tune(args.tile_rows, args.zchunk))
+    if args.mg_tune >= 0:
+        check(lib().ramses_amd_mg_tune(args.mg_tune))
     params = ramses_amd.make_params(courant_factor=0.8, fast_math=bool(args.fast))
     if world == 1:
         lev = HydroLevel(n, n, n, 0.5 / n, params=params, ng=0)

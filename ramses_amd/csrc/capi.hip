@@ -415,7 +415,29 @@ int ramses_amd_mg_interp_correct(double *d_phi_f, const double *d_corr_c, int nf
   return 0;
 }
 
-int ramses_amd_mg_tune(int fused) { g_mg_fused = fused ? 1 : 0; return 0; }
+// fused: 0 one launch per colour pass, 1 the fused smoother with 4 colour passes per launch (24-row
+// tiles, one workgroup per CU), 12 / 16: two launches of 2 colour passes on 12- / 16-row tiles
+// (three / two workgroups per CU).  Results do not depend on it.
+static int g_mg_split_rows = 0;
+int ramses_amd_mg_tune(int fused) {
+  g_mg_fused = fused ? 1 : 0;
+  g_mg_split_rows = (fused == 12 || fused == 16) ? fused : 0;
+  mg_set_smooth_rows(g_mg_split_rows ? g_mg_split_rows : 24);
+  return 0;
+}
+// 4 colour passes (2 red-black sweeps) from *cur, optionally with the residual (+norm) of the
+// result; on return *cur points at the result and *other at the scratch copy
+static hipError_t mg_smooth4(double **cur, double **other, const double *rhs, double *res, double *partial,
+                             double *norm, int n, double dx, hipStream_t s) {
+  hipError_t e;
+  if (g_mg_split_rows) {
+    if ((e = mg_launch_smooth_fused(*cur, *other, rhs, nullptr, nullptr, nullptr, n, dx, 2, s)) != hipSuccess) return e;
+    return mg_launch_smooth_fused(*other, *cur, rhs, res, partial, norm, n, dx, 2, s);
+  }
+  if ((e = mg_launch_smooth_fused(*cur, *other, rhs, res, partial, norm, n, dx, 4, s)) != hipSuccess) return e;
+  double *t = *cur; *cur = *other; *other = t;
+  return hipSuccess;
+}
 
 int ramses_amd_mg_smooth_fused(const double *d_phi_in, double *d_phi_out, const double *d_rhs, double *d_res,
                                double *d_work, double *d_norm2, int n, double dx, int npass, void *stream) {
@@ -455,13 +477,13 @@ static hipError_t mg_coarse_cycle(double *w, int level, int l, int safe, hipStre
   double *partial = w + mg_hier_size(level);
   for (int cyc = 0; cyc < ncycle; cyc++) {
     if (n >= MG_FUSED_MIN_N) {
-      // pre-smoothing + residual in one pass (u1 -> u4), correction on u4, post-smoothing back into u1
-      double *u4 = w + mg_hier_offset(level, l, 3);
-      if ((e = mg_launch_smooth_fused(u1, u4, u2, u3, partial, nullptr, n, dx, 2 * ngs_coarse, s)) != hipSuccess) return e;
+      // pre-smoothing + residual, correction, post-smoothing; the result ends in u1
+      double *cur = u1, *oth = w + mg_hier_offset(level, l, 3);
+      if ((e = mg_smooth4(&cur, &oth, u2, u3, partial, nullptr, n, dx, s)) != hipSuccess) return e;
       if ((e = mg_launch_restrict(u3, w + mg_hier_offset(level, l - 1, 1), w + mg_hier_offset(level, l - 1, 0), n, s)) != hipSuccess) return e;
       if ((e = mg_coarse_cycle(w, level, l - 1, safe, s)) != hipSuccess) return e;
-      if ((e = mg_launch_interp(u4, w + mg_hier_offset(level, l - 1, 0), n, s)) != hipSuccess) return e;
-      if ((e = mg_launch_smooth_fused(u4, u1, u2, nullptr, nullptr, nullptr, n, dx, 2 * ngs_coarse, s)) != hipSuccess) return e;
+      if ((e = mg_launch_interp(cur, w + mg_hier_offset(level, l - 1, 0), n, s)) != hipSuccess) return e;
+      if ((e = mg_smooth4(&cur, &oth, u2, nullptr, nullptr, nullptr, n, dx, s)) != hipSuccess) return e;
       continue;
     }
     for (int i = 0; i < ngs_coarse; i++) {
@@ -560,10 +582,9 @@ int ramses_amd_multigrid_fine_brick(int level, const double *d_rho, double rho_t
   double *d_phi2 = d_work;   // fine-level ping-pong copy
   for (;;) {
     iter++;
-    double *cur = d_phi;
+    double *cur = d_phi, *oth = d_phi2;
     if (fused) {
-      MGCHK(mg_launch_smooth_fused(d_phi, d_phi2, d_f2, d_f1, partial, iter == 1 ? d_norm : nullptr, n, dx, 2 * ngs_fine, s), "mg fused smoother launch");
-      cur = d_phi2;
+      MGCHK(mg_smooth4(&cur, &oth, d_f2, d_f1, partial, iter == 1 ? d_norm : nullptr, n, dx, s), "mg fused smoother launch");
     } else {
       for (int i = 0; i < ngs_fine; i++) {
         MGCHK(mg_launch_gs(d_phi, d_f2, n, dx2, 0, s), "mg gs launch");
@@ -582,7 +603,8 @@ int ramses_amd_multigrid_fine_brick(int level, const double *d_rho, double rho_t
     if (fused) {
       // post-smoothing: only the norm of the residual is needed (f(:,1) is scratch in
       // the reference and force_fine overwrites it next): it is not written to HBM
-      MGCHK(mg_launch_smooth_fused(d_phi2, d_phi, d_f2, nullptr, partial, d_norm + 1, n, dx, 2 * ngs_fine, s), "mg fused smoother launch");
+      MGCHK(mg_smooth4(&cur, &oth, d_f2, nullptr, partial, d_norm + 1, n, dx, s), "mg fused smoother launch");
+      // the result is back in d_phi (two buffer swaps, or none)
     } else {
       for (int i = 0; i < ngs_fine; i++) {
         MGCHK(mg_launch_gs(d_phi, d_f2, n, dx2, 0, s), "mg gs launch");

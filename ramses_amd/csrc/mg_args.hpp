@@ -21,6 +21,7 @@ hipError_t mg_launch_restrict_ghost(const double *res_f, double *rhs_c, int nf, 
 hipError_t mg_launch_interp_ghost(double *phi_f, int nf, int ngf, const double *corr_c, int ngc, int cglob,
                                   int cox, int coy, int coz, hipStream_t s);
 hipError_t mg_launch_gradient_ghost(const double *phi, double *f, int n, int ng, double a, double b, hipStream_t s);
+void mg_set_smooth_rows(int ly);
 hipError_t mg_launch_gradient(const double *phi, double *f, int n, double a, double b, hipStream_t s);
 
 }  // namespace ramses_amd

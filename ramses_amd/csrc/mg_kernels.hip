@@ -350,33 +350,34 @@ hipError_t mg_launch_gradient(const double *phi, double *f, int n, double a, dou
 // ===========================================================================
 // H = halo width: P for the smoother alone; P+1 when the residual is fused (it
 // reads FINAL values one cell beyond the tile interior).
-template <int P, bool RESID>
+template <int P, bool RESID, int LYT = 24>
 struct SmoothGeom {
-  static constexpr int LX = 64, LY = 24;
+  static constexpr int LX = 64, LY = LYT;
   static constexpr int H = RESID ? P + 1 : P;
   static constexpr int IX = LX - 2 * H, IY = LY - 2 * H;
   static constexpr int R = 2 * P + 4;
   static constexpr int PLANE = LX * LY;
 };
 
-constexpr int SMOOTH_THREADS = 384;   // 6 wavefronts
+// 4 tile rows per wavefront: 24 rows = 6 wavefronts (384 threads), 16 = 4, 12 = 3
 
-template <int P, bool RESID>
-__global__ __launch_bounds__(SMOOTH_THREADS) void mg_smooth_fused_kernel(const double *__restrict__ phi_in,
+template <int P, bool RESID, int LYT = 24>
+__global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double *__restrict__ phi_in,
                                                                           double *__restrict__ phi_out,
                                                                           const double *__restrict__ rhs,
                                                                           double *__restrict__ res,
                                                                           double *__restrict__ partial, int n,
                                                                           int ng, double dx2, double oneoverdx2,
                                                                           int zchunk, int ntx, int nty) {
-  using G = SmoothGeom<P, RESID>;
+  using G = SmoothGeom<P, RESID, LYT>;
   constexpr int H = G::H;
-  constexpr int NW = SMOOTH_THREADS / 64;                  // 6 waves
+  constexpr int SMOOTH_THREADS = LYT * 16;
+  constexpr int NW = SMOOTH_THREADS / 64;                  // 6 waves at 24 rows
   constexpr int NROW = G::LY / NW;                         // 4 full rows per wave (loads, final stage)
   constexpr int NPAIR = G::LY / (2 * NW);                  // 2 row pairs per wave (colour passes)
   static_assert(G::LY % (2 * NW) == 0, "tile rows must split evenly over the wavefronts");
   extern __shared__ __attribute__((aligned(16))) double ring[];  // [R][LY][LX]
-  __shared__ double sm[SMOOTH_THREADS];
+  __shared__ double sm[512];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int bid = blockIdx.x;
@@ -578,11 +579,10 @@ __global__ __launch_bounds__(SMOOTH_THREADS) void mg_smooth_fused_kernel(const d
   }
   if (RESID && partial) {
     sm[tid] = acc;
+    for (int i = SMOOTH_THREADS + tid; i < 512; i += SMOOTH_THREADS) sm[i] = 0.0;
     __syncthreads();
-    // deterministic fixed-order tree over the 384 threads
-    if (tid < 128) sm[tid] = sm[tid] + sm[tid + 256];
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    // deterministic fixed-order tree over 512 slots (the threads' sums, zero padded)
+    for (int s = 256; s > 0; s >>= 1) {
       if (tid < s) sm[tid] = sm[tid] + sm[tid + s];
       __syncthreads();
     }
@@ -590,8 +590,11 @@ __global__ __launch_bounds__(SMOOTH_THREADS) void mg_smooth_fused_kernel(const d
   }
 }
 
-// P colour passes (P = 2 or 4) from phi_in into phi_out; with res != NULL also
-// the residual, and with norm_out != NULL its dx^3-scaled squared norm.
+// tile rows of the fused smoother (24: one 6-wave workgroup per CU with P=4; 12/16 with P=2:
+// two or three workgroups per CU) -- a tuning knob, results do not depend on it
+static int g_smooth_ly = 24;
+void mg_set_smooth_rows(int ly) { g_smooth_ly = (ly == 12 || ly == 16) ? ly : 24; }
+
 hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const double *rhs, double *res,
                                   double *partial, double *norm_out, int n, double dx, int npass,
                                   hipStream_t s, int ng) {
@@ -601,26 +604,29 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
   const bool resid = (res != nullptr) || (norm_out != nullptr);
   const int H = resid ? P + 1 : P;
   if (ng != 0 && ng < H) return hipErrorInvalidValue;   // ghost layers must cover the dependency cone
-  const int IX = 64 - 2 * H, IY = 24 - 2 * H;
+  const int LY = (P == 2) ? g_smooth_ly : 24;
+  const int IX = 64 - 2 * H, IY = LY - 2 * H;
   const int ntx = (n + IX - 1) / IX, nty = (n + IY - 1) / IY;
   int zchunk = n >= 256 ? 128 : (n >= 128 ? 64 : n);
   const int ntz = (n + zchunk - 1) / zchunk;
   const int blocks = ntx * nty * ntz;
   if (resid && blocks > MG_MAX_PARTIALS) return hipErrorInvalidValue;
-  const size_t lds = sizeof(double) * (size_t)(2 * P + 4) * 64 * 24;
+  const size_t lds = sizeof(double) * (size_t)(2 * P + 4) * 64 * LY;
   const double dx2 = dx * dx, oneoverdx2 = 1.0 / (dx * dx);
   hipError_t e;
-#define SM_LAUNCH(PP, RR)                                                                                     \
+#define SM_LAUNCH(PP, RR, LL)                                                                                 \
   do {                                                                                                        \
-    auto k = mg_smooth_fused_kernel<PP, RR>;                                                                  \
+    auto k = mg_smooth_fused_kernel<PP, RR, LL>;                                                              \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,    \
                             (int)lds);                                                                        \
     if (e != hipSuccess) return e;                                                                            \
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(SMOOTH_THREADS), lds, s, phi_in, phi_out, rhs, res, partial, n, ng, dx2,    \
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(LL * 16), lds, s, phi_in, phi_out, rhs, res, partial, n, ng, dx2,    \
                        oneoverdx2, zchunk, ntx, nty);                                                         \
   } while (0)
-  if (P == 4) { if (resid) SM_LAUNCH(4, true); else SM_LAUNCH(4, false); }
-  else { if (resid) SM_LAUNCH(2, true); else SM_LAUNCH(2, false); }
+  if (P == 4) { if (resid) SM_LAUNCH(4, true, 24); else SM_LAUNCH(4, false, 24); }
+  else if (LY == 12) { if (resid) SM_LAUNCH(2, true, 12); else SM_LAUNCH(2, false, 12); }
+  else if (LY == 16) { if (resid) SM_LAUNCH(2, true, 16); else SM_LAUNCH(2, false, 16); }
+  else { if (resid) SM_LAUNCH(2, true, 24); else SM_LAUNCH(2, false, 24); }
 #undef SM_LAUNCH
   if (norm_out)
     hipLaunchKernelGGL(mg_sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, blocks, dx * dx * dx, norm_out);
