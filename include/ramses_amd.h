@@ -312,6 +312,8 @@ int ramses_amd_make_boundary_hydro(const ramses_amd_hydro_params *p, const ramse
  * nbor(1:ngridmax,1:6), father(1:ngridmax), uold/unew(1:ncell,1:nvar).
  * f_or_null = f(1:ncell,1:3) when poisson (the gravity predictor of ctoprim; missing octs take
  * the father cell's f, :637-647), NULL otherwise.
+ * divu_or_null / enew_or_null = divu(1:ncell), enew(1:ncell) when pressure_fix (updated with cmpflxm's
+ * normal-velocity and internal-energy fluxes, :771-786 and the coarse-level twins :825-905), NULL otherwise.
  * nvector = the reference build's NVECTOR: it fixes the order in which the
  * coarse-level corrections are accumulated (bit parity).  Needs ilevel >= 3.
  * ------------------------------------------------------------------------- */
@@ -319,13 +321,14 @@ int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ileve
                                      const int *igrid, const int *son, const int *nbor,
                                      const int *father, int64_t ngridmax, int64_t ncoarse,
                                      const double *uold, double *unew, const double *f_or_null,
-                                     double dx, double dt,
+                                     double *divu_or_null, double *enew_or_null, double dx, double dt,
                                      int nvector, int interpol_var, int interpol_type);
 /* Fortran-friendly: f_or_dummy is always a valid array, read only when has_f != 0 */
 int ramses_amd_godunov_fine_amr_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
                                     const int *igrid, const int *son, const int *nbor,
                                     const int *father, int64_t ngridmax, int64_t ncoarse,
                                     const double *uold, double *unew, const double *f_or_dummy, int has_f,
+                                    double *divu_or_dummy, double *enew_or_dummy, int has_pfix,
                                     double dx, double dt, int nvector, int interpol_var, int interpol_type);
 /* the same with every array already on the device; d_work holds
  * ramses_amd_godunov_fine_amr_workspace(ngrid, ngridmax) bytes, *d_err (zeroed by the
@@ -335,7 +338,7 @@ int ramses_amd_godunov_fine_amr_device(const ramses_amd_hydro_params *p, int ile
                                        const int *d_igrid, const int *d_son, const int *d_nbor,
                                        const int *d_father, int64_t ngridmax, int64_t ncoarse,
                                        const double *d_uold, double *d_unew, const double *d_grav_or_null,
-                                       double dx, double dt,
+                                       double *d_divu_or_null, double *d_enew_or_null, double dx, double dt,
                                        int nvector, int interpol_var, int interpol_type,
                                        void *d_work, int *d_err, void *stream);
 

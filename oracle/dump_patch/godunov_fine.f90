@@ -45,7 +45,7 @@ subroutine dump_godunov(what,ilevel,ncall)
   use poisson_commons
   implicit none
   character(len=*)::what
-  integer::ilevel,ncall,nx_loc,ipoisson
+  integer::ilevel,ncall,nx_loc,ipoisson,ipfix
   character(len=64)::fname
   real(dp)::dx
   write(fname,'(A,I4.4,A,A,A)')'godunov_',ncall,'_',trim(what),'.bin'
@@ -55,7 +55,9 @@ subroutine dump_godunov(what,ilevel,ncall)
   if(what=='in')then
      ipoisson=0
      if(poisson)ipoisson=1
-     write(77)ilevel,active(ilevel)%ngrid,ngridmax,ncoarse,nvar,nvector,nlevelmax,interpol_var,interpol_type,ipoisson
+     ipfix=0
+     if(pressure_fix)ipfix=1
+     write(77)ilevel,active(ilevel)%ngrid,ngridmax,ncoarse,nvar,nvector,nlevelmax,interpol_var,interpol_type,ipoisson,ipfix
      write(77)dx,dtnew(ilevel),gamma,smallr,smallc
      write(77)active(ilevel)%igrid(1:active(ilevel)%ngrid)
      write(77)son
@@ -64,8 +66,16 @@ subroutine dump_godunov(what,ilevel,ncall)
      write(77)uold
      write(77)unew
      if(poisson)write(77)f
+     if(pressure_fix)then
+        write(77)divu
+        write(77)enew
+     end if
   else
      write(77)unew
+     if(pressure_fix)then
+        write(77)divu
+        write(77)enew
+     end if
   end if
   close(77)
 end subroutine dump_godunov

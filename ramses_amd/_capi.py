@@ -77,10 +77,10 @@ SYMBOLS = [
                                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     ("ramses_amd_godunov_fine_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _i, _d, _d]),
     ("ramses_amd_mg_smooth_fused_ghost", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _i, _vp]),
-    ("ramses_amd_godunov_fine_amr_host", _i, [_PP, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _d, _d, _i, _i, _i]),
-    ("ramses_amd_godunov_fine_amr_f90", _i, [_PP, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i, _d, _d, _i, _i, _i]),
+    ("ramses_amd_godunov_fine_amr_host", _i, [_PP, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _d, _d, _i, _i, _i]),
+    ("ramses_amd_godunov_fine_amr_f90", _i, [_PP, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _d, _d, _i, _i, _i]),
     ("ramses_amd_godunov_fine_amr_workspace", _i64, [_i, _i64]),
-    ("ramses_amd_godunov_fine_amr_device", _i, [_PP, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _d, _d, _i, _i, _i, _vp, _vp, _vp]),
+    ("ramses_amd_godunov_fine_amr_device", _i, [_PP, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _d, _d, _i, _i, _i, _vp, _vp, _vp]),
     ("ramses_amd_halo_multi", _i, [_PB, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
     ("ramses_amd_make_boundary_hydro", _i, [_PP, _PB, _vp, _i, _i, _vp, _i, _vp]),
     ("ramses_amd_mg_rhs", _i, [_vp, _vp, _i64, _d, _d, _vp]),

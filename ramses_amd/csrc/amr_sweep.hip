@@ -38,6 +38,7 @@ struct OctFaces {
   double qm[3][3][2][2][NV];  // traced state on the +d face of trace cell a (a = 0..2), transverse 1..2
   double qp[3][3][2][2][NV];  // traced state on the -d face of trace cell a+1
   double fl[3][3][2][2][NV];  // flux through face a of direction d
+  double tp[3][3][2][2][2];   // cmpflxm's tmp: normal velocity and internal-energy flux (pressure_fix)
 };
 template <int NV>
 struct OctLds {
@@ -255,9 +256,17 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
 #pragma unroll
     for (int v = 0; v < NV; v++) { qL[v] = L.f.qm[d][a][b][c][v]; qR[v] = L.f.qp[d][a][b][c][v]; }
     const bool pow2 = A.pow2 != 0;
-    if (d == 0) scaled_interface_flux<RS, NV, 0>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
-    else if (d == 1) scaled_interface_flux<RS, NV, 1>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
-    else scaled_interface_flux<RS, NV, 2>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
+    const bool pfix = A.divu != nullptr;
+    double tp2[2] = {0.0, 0.0};
+    if (pfix) {
+      if (d == 0) scaled_interface_flux_tmp<RS, NV, 0>(qL, qR, P, A.dt, A.dx, A.rdx, pow2, fx, tp2);
+      else if (d == 1) scaled_interface_flux_tmp<RS, NV, 1>(qL, qR, P, A.dt, A.dx, A.rdx, pow2, fx, tp2);
+      else scaled_interface_flux_tmp<RS, NV, 2>(qL, qR, P, A.dt, A.dx, A.rdx, pow2, fx, tp2);
+    } else {
+      if (d == 0) scaled_interface_flux<RS, NV, 0>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
+      else if (d == 1) scaled_interface_flux<RS, NV, 1>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
+      else scaled_interface_flux<RS, NV, 2>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
+    }
     const int t0 = d == 0 ? 1 : 0, t1 = d == 2 ? 1 : 2;
     if (difmag) {
       // consup (hydro/uplmde.f90:769-866): the face's flux index along d is a+1, the own
@@ -295,6 +304,8 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
     const bool zero = L.ok[sl] || L.ok[sl + stride];
 #pragma unroll
     for (int v = 0; v < NV; v++) L.f.fl[d][a][b][c][v] = zero ? 0.0 : fx[v];
+    L.f.tp[d][a][b][c][0] = zero ? 0.0 : tp2[0];
+    L.f.tp[d][a][b][c][1] = zero ? 0.0 : tp2[1];
   }
   wave_sync();
 
@@ -313,6 +324,19 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
       }
       A.unew[(long)v * ncell + cell - 1] = un;
     }
+    if (A.divu) {
+      // pressure_fix: velocity divergence and internal energy (hydro/godunov_fine.f90:771-786)
+      double dv = A.divu[cell - 1], en = A.enew[cell - 1];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const int t0 = d == 0 ? 1 : 0, t1 = d == 2 ? 1 : 2;
+        const int a = ic[d], b = ic[t0], c = ic[t1];
+        dv = dv + (L.f.tp[d][a][b][c][0] - L.f.tp[d][a + 1][b][c][0]);
+        en = en + (L.f.tp[d][a][b][c][1] - L.f.tp[d][a + 1][b][c][1]);
+      }
+      A.divu[cell - 1] = dv;
+      A.enew[cell - 1] = en;
+    }
   }
   // ---- (G) fluxes owed to coarse neighbour cells --------------------------------
   if (lane >= 8 && lane < 14) {
@@ -322,11 +346,15 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
     A.corr_tgt[(long)io * 6 + f] = coarse ? nb : 0;
     if (coarse) {
       const int a = side ? 2 : 0;
-      double *dst = A.corr + ((long)io * 6 + f) * 4 * NV;
+      constexpr int CV = NV + 2;                       // fluxes + the two pressure_fix quantities
+      double *dst = A.corr + ((long)io * 6 + f) * 4 * CV;
 #pragma unroll
-      for (int q = 0; q < 4; q++)
+      for (int q = 0; q < 4; q++) {
 #pragma unroll
-        for (int v = 0; v < NV; v++) dst[q * NV + v] = L.f.fl[d][a][q & 1][q >> 1][v];
+        for (int v = 0; v < NV; v++) dst[q * CV + v] = L.f.fl[d][a][q & 1][q >> 1][v];
+        dst[q * CV + NV] = L.f.tp[d][a][q & 1][q >> 1][0];
+        dst[q * CV + NV + 1] = L.f.tp[d][a][q & 1][q >> 1][1];
+      }
     }
   }
 }
@@ -384,17 +412,20 @@ __global__ __launch_bounds__(256) void amr_coarse_update_kernel(AmrSweepArgs A, 
     key[j + 1] = k; src[j + 1] = s;
   }
   const double oneontwotondim = 1.0 / 8.0;
-  for (int v = 0; v < NV; v++) {
-    double val = A.unew[(long)v * A.ncell + C - 1];
+  const int CV = NV + 2;
+  const int nacc = A.divu ? NV + 2 : NV;       // unew(1:nvar) [, divu, enew]
+  for (int v = 0; v < nacc; v++) {
+    double *tgt = v < NV ? A.unew + (long)v * A.ncell : (v == NV ? A.divu : A.enew);
+    double val = tgt[C - 1];
     for (int i = 0; i < n; i++) {
-      const double *c = A.corr + src[i] * 4 * NV;
+      const double *c = A.corr + src[i] * 4 * CV;
       const bool left = ((src[i] % 6) & 1) == 0;
       for (int q = 0; q < 4; q++) {
-        const double t = c[q * NV + v] * oneontwotondim;
+        const double t = c[q * CV + v] * oneontwotondim;
         val = left ? val - t : val + t;
       }
     }
-    A.unew[(long)v * A.ncell + C - 1] = val;
+    tgt[C - 1] = val;
   }
 }
 

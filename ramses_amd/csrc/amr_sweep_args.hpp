@@ -8,6 +8,7 @@ struct AmrSweepArgs {
   const double *uold;   // [nvar][ncell]   (uold(1:ncell,1:nvar), column major)
   double *unew;         // [nvar][ncell]
   const double *grav;   // f(1:ncell,1:3) or null
+  double *divu, *enew;  // pressure_fix: velocity divergence and internal energy (1:ncell), or null
   const int *son;       // [ncell]
   const int *nbor;      // [6][ngridmax]   (nbor(1:ngridmax,1:twondim))
   const int *father;    // [ngridmax]
@@ -20,7 +21,7 @@ struct AmrSweepArgs {
   double difmag;        // artificial diffusion coefficient (cmpdivu + consup), 0: off
   int pow2;
   int interpol_var, interpol_type;
-  double *corr;         // [ngrid][6][4][nvar] fluxes owed to coarse neighbour cells
+  double *corr;         // [ngrid][6][4][nvar+2] fluxes (+ the two pressure_fix quantities) owed to coarse neighbour cells
   int *corr_tgt;        // [ngrid][6] the coarse cell (1-based) or 0
   int *err;             // tree inconsistencies found
   HydroConst P;

@@ -732,7 +732,7 @@ int ramses_amd_godunov_fine_host(const ramses_amd_hydro_params *p, int ilevel, i
 // workspace of the device entry point, in bytes
 int64_t ramses_amd_godunov_fine_amr_workspace(int ngrid, int64_t ngridmax) {
   if (ngrid < 0 || ngridmax < 1) return fail(RAMSES_AMD_EINVAL, "bad argument");
-  return (int64_t)(sizeof(double) * (size_t)ngrid * 6 * 4 * 7 + sizeof(int) * (size_t)ngrid * 6 + sizeof(int) * (size_t)ngridmax + 64);
+  return (int64_t)(sizeof(double) * (size_t)ngrid * 6 * 4 * 9 + sizeof(int) * (size_t)ngrid * 6 + sizeof(int) * (size_t)ngridmax + 64);
 }
 
 static int amr_check(const ramses_amd_hydro_params *p, int ilevel, int nvector, int interpol_var, int interpol_type) {
@@ -752,14 +752,15 @@ int ramses_amd_godunov_fine_amr_device(const ramses_amd_hydro_params *p, int ile
                                        const int *d_igrid, const int *d_son, const int *d_nbor,
                                        const int *d_father, int64_t ngridmax, int64_t ncoarse,
                                        const double *d_uold, double *d_unew, const double *d_grav,
-                                       double dx, double dt,
+                                       double *d_divu, double *d_enew, double dx, double dt,
                                        int nvector, int interpol_var, int interpol_type,
                                        void *d_work, int *d_err, void *stream) {
+  if ((d_divu == nullptr) != (d_enew == nullptr)) return fail(RAMSES_AMD_EINVAL, "pressure_fix needs both divu and enew");
   if (!p || !d_igrid || !d_son || !d_nbor || !d_father || !d_uold || !d_unew || !d_work || !d_err) return fail(RAMSES_AMD_EINVAL, "NULL argument");
   if (int rc = amr_check(p, ilevel, nvector, interpol_var, interpol_type)) return rc;
   if (ngrid <= 0) return 0;
   AmrSweepArgs A;
-  A.uold = d_uold; A.unew = d_unew; A.grav = d_grav;
+  A.uold = d_uold; A.unew = d_unew; A.grav = d_grav; A.divu = d_divu; A.enew = d_enew;
   A.son = d_son; A.nbor = d_nbor; A.father = d_father;
   A.igrid = d_igrid; A.ngrid = ngrid; A.nvar = p->nvar; A.scheme = p->scheme;
   A.ncell = ncoarse + 8 * ngridmax; A.ncoarse = ncoarse; A.ngridmax = ngridmax;
@@ -768,7 +769,7 @@ int ramses_amd_godunov_fine_amr_device(const ramses_amd_hydro_params *p, int ile
   A.interpol_var = interpol_var; A.interpol_type = interpol_type;
   char *w = reinterpret_cast<char *>(d_work);
   A.corr = reinterpret_cast<double *>(w);
-  w += sizeof(double) * (size_t)ngrid * 6 * 4 * 7;
+  w += sizeof(double) * (size_t)ngrid * 6 * 4 * 9;
   A.corr_tgt = reinterpret_cast<int *>(w);
   w += sizeof(int) * (size_t)ngrid * 6;
   int *posof = reinterpret_cast<int *>(w);
@@ -783,15 +784,16 @@ int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ileve
                                      const int *igrid, const int *son, const int *nbor,
                                      const int *father, int64_t ngridmax, int64_t ncoarse,
                                      const double *uold, double *unew, const double *f,
-                                     double dx, double dt,
+                                     double *divu, double *enew, double dx, double dt,
                                      int nvector, int interpol_var, int interpol_type) {
   if (!p || !igrid || !son || !nbor || !father || !uold || !unew) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if ((divu == nullptr) != (enew == nullptr)) return fail(RAMSES_AMD_EINVAL, "pressure_fix needs both divu and enew");
   if (int rc = amr_check(p, ilevel, nvector, interpol_var, interpol_type)) return rc;
   if (ngrid <= 0) return 0;
   const long ncell = ncoarse + 8 * ngridmax;
   hipStream_t s = nullptr;
   HostCtx &H = g_host;
-  static DevBuf dson, dnbor, dfather, dwork;
+  static DevBuf dson, dnbor, dfather, dwork, ddivu, denew;
 #define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipfail(e_, what); } while (0)
   const int nvar = p->nvar;
   HCHK(H.uold.ensure(sizeof(double) * nvar * ncell), "hipMalloc uold");
@@ -816,13 +818,25 @@ int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ileve
     d_grav = H.fvec.as<double>();
   }
   g_host.res_valid = false;   // the staging buffers are reused
+  double *d_divu = nullptr, *d_enew = nullptr;
+  if (divu) {
+    HCHK(ddivu.ensure(sizeof(double) * ncell), "hipMalloc divu");
+    HCHK(denew.ensure(sizeof(double) * ncell), "hipMalloc enew");
+    HCHK(hipMemcpyAsync(ddivu.p, divu, sizeof(double) * ncell, hipMemcpyHostToDevice, s), "H2D divu");
+    HCHK(hipMemcpyAsync(denew.p, enew, sizeof(double) * ncell, hipMemcpyHostToDevice, s), "H2D enew");
+    d_divu = ddivu.as<double>(); d_enew = denew.as<double>();
+  }
   if (int rc = ramses_amd_godunov_fine_amr_device(p, ilevel, ngrid, H.igrid.as<int>(), dson.as<int>(), dnbor.as<int>(),
                                                   dfather.as<int>(), ngridmax, ncoarse, H.uold.as<double>(),
-                                                  H.unew.as<double>(), d_grav, dx, dt, nvector, interpol_var, interpol_type,
+                                                  H.unew.as<double>(), d_grav, d_divu, d_enew, dx, dt, nvector, interpol_var, interpol_type,
                                                   dwork.p, H.flag.as<int>(), s)) return rc;
   int bad = 0;
   HCHK(hipMemcpyAsync(&bad, H.flag.p, sizeof(int), hipMemcpyDeviceToHost, s), "D2H flag");
   HCHK(hipMemcpyAsync(unew, H.unew.p, sizeof(double) * nvar * ncell, hipMemcpyDeviceToHost, s), "D2H unew");
+  if (divu) {
+    HCHK(hipMemcpyAsync(divu, ddivu.p, sizeof(double) * ncell, hipMemcpyDeviceToHost, s), "D2H divu");
+    HCHK(hipMemcpyAsync(enew, denew.p, sizeof(double) * ncell, hipMemcpyDeviceToHost, s), "D2H enew");
+  }
   HCHK(hipStreamSynchronize(s), "sync");
 #undef HCHK
   if (bad) return fail(RAMSES_AMD_EINVAL, "level %d: %d of the 3^3 father cells of an oct do not exist (tree inconsistent)", ilevel, bad);
@@ -834,9 +848,11 @@ int ramses_amd_godunov_fine_amr_f90(const ramses_amd_hydro_params *p, int ilevel
                                     const int *igrid, const int *son, const int *nbor,
                                     const int *father, int64_t ngridmax, int64_t ncoarse,
                                     const double *uold, double *unew, const double *f_or_dummy, int has_f,
+                                    double *divu_or_dummy, double *enew_or_dummy, int has_pfix,
                                     double dx, double dt, int nvector, int interpol_var, int interpol_type) {
   return ramses_amd_godunov_fine_amr_host(p, ilevel, ngrid, igrid, son, nbor, father, ngridmax, ncoarse, uold, unew,
-                                          has_f ? f_or_dummy : nullptr, dx, dt, nvector, interpol_var, interpol_type);
+                                          has_f ? f_or_dummy : nullptr, has_pfix ? divu_or_dummy : nullptr,
+                                          has_pfix ? enew_or_dummy : nullptr, dx, dt, nvector, interpol_var, interpol_type);
 }
 
 // Fortran-friendly variant: f is always a valid array (ignored when has_f==0)

@@ -646,6 +646,21 @@ RA_DEV void scaled_interface_flux(const double (&qL)[NV], const double (&qR)[NV]
   }
 }
 
+// The same plus cmpflxm's two extra face quantities (hydro/umuscl.f90:843-850, scaled like
+// the fluxes in unsplit :136-163): tmp[0] = half*(uL+uR) normal velocity, tmp[1] = internal
+// energy flux -- the divu/enew updates of pressure_fix.  Strict arithmetic only.
+template <int RS, int NV, int DIR>
+RA_DEV void scaled_interface_flux_tmp(const double (&qL)[NV], const double (&qR)[NV],
+                                      const HydroConst &P, double dt, double dx, double rdx,
+                                      bool DXPOW2, double (&flux)[NV], double (&tmp)[2]) {
+  double un_, ef_;
+  interface_flux<RS, NV, DIR>(qL, qR, P, flux, un_, ef_);
+#pragma unroll
+  for (int n = 0; n < NV; n++) flux[n] = DXPOW2 ? flux[n] * dt * rdx : flux[n] * dt / dx;
+  tmp[0] = DXPOW2 ? un_ * dt * rdx : un_ * dt / dx;
+  tmp[1] = DXPOW2 ? ef_ * dt * rdx : ef_ * dt / dx;
+}
+
 // ---------------------------------------------------------------------------
 // cmpdt (hydro/godunov_utils.f90:5-120) for one cell, 3-D.
 // ---------------------------------------------------------------------------

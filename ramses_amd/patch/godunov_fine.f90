@@ -78,8 +78,8 @@ subroutine godunov_fine(ilevel)
   if(verbose)write(*,111)ilevel
 
   ! What the device path does not implement stops the run (no silent fallback)
-  if(pressure_fix.or.MC_tracer.or.momentum_feedback>0.or.strict_equilibrium>0)then
-     write(*,*)'ramses_amd: pressure_fix/MC_tracer/momentum_feedback/strict_equilibrium are not on the device'
+  if(MC_tracer.or.momentum_feedback>0.or.strict_equilibrium>0)then
+     write(*,*)'ramses_amd: MC_tracer/momentum_feedback/strict_equilibrium are not on the device'
      call ramses_amd_fatal('godunov_fine (unsupported option)')
   end if
 
@@ -101,14 +101,23 @@ subroutine godunov_fine(ilevel)
   if(ncpu>1.or.nboundary>0)amr_level=.true.
   ! artificial diffusion (cmpdivu + consup) is implemented in the tree-walking sweep only
   if(difmag>0.0d0)amr_level=.true.
+  ! so are the divu/enew updates of pressure_fix
+  if(pressure_fix)amr_level=.true.
 
   if(amr_level)then
-     if(poisson)then
+     ! f, divu, enew exist only with poisson resp. pressure_fix: uold stands in (never read)
+     if(poisson.and.pressure_fix)then
         rc=ramses_amd_godunov_fine_amr_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,son,nbor,father, &
-             & int(ngridmax,8),int(ncoarse,8),uold,unew,f,1,dx,dtnew(ilevel),nvector,interpol_var,interpol_type)
+             & int(ngridmax,8),int(ncoarse,8),uold,unew,f,1,divu,enew,1,dx,dtnew(ilevel),nvector,interpol_var,interpol_type)
+     else if(poisson)then
+        rc=ramses_amd_godunov_fine_amr_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,son,nbor,father, &
+             & int(ngridmax,8),int(ncoarse,8),uold,unew,f,1,uold,uold,0,dx,dtnew(ilevel),nvector,interpol_var,interpol_type)
+     else if(pressure_fix)then
+        rc=ramses_amd_godunov_fine_amr_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,son,nbor,father, &
+             & int(ngridmax,8),int(ncoarse,8),uold,unew,uold,0,divu,enew,1,dx,dtnew(ilevel),nvector,interpol_var,interpol_type)
      else
         rc=ramses_amd_godunov_fine_amr_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,son,nbor,father, &
-             & int(ngridmax,8),int(ncoarse,8),uold,unew,uold,0,dx,dtnew(ilevel),nvector,interpol_var,interpol_type)
+             & int(ngridmax,8),int(ncoarse,8),uold,unew,uold,0,uold,uold,0,dx,dtnew(ilevel),nvector,interpol_var,interpol_type)
      end if
   else if(ramses_amd_resident())then
      ! state already on the device (loaded by courant_fine or here); unew stays there

@@ -78,15 +78,15 @@ module ramses_amd_iface
 
      ! ---- AMR level: the reference's tree arrays by address ----
      function ramses_amd_godunov_fine_amr_f90(p, ilevel, ngrid, igrid, son, nbor, father, ngridmax, ncoarse, &
-          & uold, unew, f_or_dummy, has_f, dx, dt, nvector, interpol_var, interpol_type) &
-          & bind(C, name='ramses_amd_godunov_fine_amr_f90') result(rc)
+          & uold, unew, f_or_dummy, has_f, divu_or_dummy, enew_or_dummy, has_pfix, dx, dt, nvector, &
+          & interpol_var, interpol_type) bind(C, name='ramses_amd_godunov_fine_amr_f90') result(rc)
        import :: ramses_amd_hydro_params, c_int, c_int64_t, c_double
        type(ramses_amd_hydro_params), intent(in) :: p
        integer(c_int), value :: ilevel, ngrid
        integer(c_int) :: igrid(*), son(*), nbor(*), father(*)
        integer(c_int64_t), value :: ngridmax, ncoarse
-       real(c_double) :: uold(*), unew(*), f_or_dummy(*)
-       integer(c_int), value :: has_f
+       real(c_double) :: uold(*), unew(*), f_or_dummy(*), divu_or_dummy(*), enew_or_dummy(*)
+       integer(c_int), value :: has_f, has_pfix
        real(c_double), value :: dx, dt
        integer(c_int), value :: nvector, interpol_var, interpol_type
        integer(c_int) :: rc

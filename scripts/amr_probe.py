@@ -39,7 +39,7 @@ dt = 1e-6
 def run():
     check(lib().ramses_amd_godunov_fine_amr_device(C.byref(p), L, len(T["igrid"]), ptr(d_igrid), ptr(d_son), ptr(d_nbor),
                                                    ptr(d_father), T["ngridmax"], T["ncoarse"], ptr(d_uold), ptr(d_unew),
-                                                   None, dx, dt, 32, 0, 1, ptr(d_work), ptr(d_err),
+                                                   None, None, None, dx, dt, 32, 0, 1, ptr(d_work), ptr(d_err),
                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
 

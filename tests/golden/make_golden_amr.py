@@ -32,6 +32,8 @@ CASES = [
     # analytic point-mass gravity (gravity_type=2: no Poisson solve): the predictor of ctoprim
     # with f of existing cells and the father cell's f for interpolated ones
     ("g", 3, 5, "1,1,2,2", "hll", 7, 0, 1, 4, (7, 11)),
+    # pressure_fix: divu/enew updated with cmpflxm's normal-velocity and internal-energy fluxes
+    ("p", 3, 5, "1,1,2,2", "hllc", 1, 0, 2, 5, (7, 15)),
 ]
 GRAVITY = """&POISSON_PARAMS
 gravity_type=2
@@ -44,8 +46,8 @@ def read_dump(work, k):
     fi = os.path.join(work, "godunov_%04d_in.bin" % k)
     fo = os.path.join(work, "godunov_%04d_out.bin" % k)
     with open(fi, "rb") as fh:
-        hdr = np.fromfile(fh, np.int32, 10)
-        ilevel, ngrid, ngridmax, ncoarse, nvar, nvector, nlevelmax, ivar, itype, ipoisson = [int(x) for x in hdr]
+        hdr = np.fromfile(fh, np.int32, 11)
+        ilevel, ngrid, ngridmax, ncoarse, nvar, nvector, nlevelmax, ivar, itype, ipoisson, ipfix = [int(x) for x in hdr]
         dx, dt, gamma, smallr, smallc = np.fromfile(fh, np.float64, 5)
         igrid = np.fromfile(fh, np.int32, ngrid)
         ncell = ncoarse + 8 * ngridmax
@@ -55,15 +57,23 @@ def read_dump(work, k):
         uold = np.fromfile(fh, np.float64, ncell * nvar).reshape(nvar, ncell)
         unew = np.fromfile(fh, np.float64, ncell * nvar).reshape(nvar, ncell)
         f = np.fromfile(fh, np.float64, ncell * 3).reshape(3, ncell) if ipoisson else np.zeros((0, 0))
+        divu = np.fromfile(fh, np.float64, ncell) if ipfix else np.zeros(0)
+        enew = np.fromfile(fh, np.float64, ncell) if ipfix else np.zeros(0)
         assert fh.read() == b""
-    unew_out = np.fromfile(fo, np.float64).reshape(nvar, ncell)
+    with open(fo, "rb") as fh:
+        unew_out = np.fromfile(fh, np.float64, ncell * nvar).reshape(nvar, ncell)
+        divu_out = np.fromfile(fh, np.float64, ncell) if ipfix else np.zeros(0)
+        enew_out = np.fromfile(fh, np.float64, ncell) if ipfix else np.zeros(0)
+        assert fh.read() == b""
     return dict(meta=np.array([ilevel, ngrid, ngridmax, ncoarse, nvar, nvector, nlevelmax, ivar, itype], np.int64),
                 real=np.array([dx, dt, gamma, smallr, smallc]), igrid=igrid, son=son, nbor=nbor, father=father,
-                uold=uold, unew=unew, unew_out=unew_out, f=f)
+                uold=uold, unew=unew, unew_out=unew_out, f=f, divu=divu, enew=enew, divu_out=divu_out, enew_out=enew_out)
 
 
 def amr_namelist(lmin, lmax, nsub, riemann, slope, ivar, itype, nstep, foutput=1, tag=""):
     grav = tag == "g"
+    if tag == "p":
+        riemann = riemann + "'\npressure_fix=.true.\nbeta_fix=0.5\n!'"
     nml = rs.sedov3d_namelist(level=lmin, nstepmax=nstep, foutput=foutput, riemann=riemann, slope_type=slope,
                               extra=REFINE.format(ivar=ivar, itype=itype) + (GRAVITY if grav else ""), mem_factor=1.0,
                               poisson=grav)
