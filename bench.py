@@ -356,6 +356,24 @@ def main():
                          "kernel": "godunov_sweep_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL_UPDATE},
         }
+        if world == 1 and args.fast:
+            # the other build of the same kernel, for the record: strict arithmetic
+            # (bit-identical to the reference), a few launches after the timed region
+            lev.params.fast_math = 0
+            for _ in range(2):
+                lev.godunov_fine(dt)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(5):
+                lev.godunov_fine(dt)
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b) / 5
+            gbs = cells * BYTES_PER_CELL_UPDATE / (ms * 1e-3) / 1e9
+            out["strict_build"] = {"kernel_ms": ms, "cell_updates_per_s": cells / (ms * 1e-3), "achieved": gbs,
+                                   "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                   "note": "same kernel, -ffp-contract=off and the reference's operation order: bit-identical results"}
+            lev.params.fast_math = 1
         if world == 1 and args.vcycle_level > 0:
             del lev
             torch.cuda.empty_cache()
