@@ -77,6 +77,11 @@ def lib():
         L.ora_interpol_hydro.restype = None
         L.ora_upl.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
         L.ora_upl.restype = None
+        _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+        L.ora_godunov_fine_amr.argtypes = [C.POINTER(HydroParams), C.c_int, _ip, _ip, _ip, _ip, C.c_long, C.c_long,
+                                           _dp, _dp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                           C.c_int, C.c_int, C.c_int]
+        L.ora_godunov_fine_amr.restype = None
         for fn in (L.ora_mg_gauss_seidel, L.ora_mg_residual, L.ora_mg_restrict, L.ora_mg_interp_correct,
                    L.ora_gradient_phi_uniform):
             fn.restype = None
@@ -139,6 +144,18 @@ def courant_uniform(p, uold, dx, courant_factor, grav=None):
         gptr = grav.ctypes.data_as(C.c_void_p)
     return lib().ora_courant_uniform(C.byref(p), np.ascontiguousarray(uold), gptr,
                                      nx, ny, nz, dx, courant_factor)
+
+
+def godunov_fine_amr(p, igrid, son, nbor, father, ngridmax, ncoarse, uold, unew, dx, dt, nvector,
+                     interpol_var, interpol_type, f=None, divu=None, enew=None):
+    """godunov_fine(ilevel) on an AMR level, on the reference's tree arrays (1-based indices);
+    unew (and divu, enew when given) are updated in place."""
+    vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
+    lib().ora_godunov_fine_amr(C.byref(p), len(igrid), np.ascontiguousarray(igrid, np.int32),
+                               np.ascontiguousarray(son, np.int32), np.ascontiguousarray(nbor, np.int32),
+                               np.ascontiguousarray(father, np.int32), ngridmax, ncoarse,
+                               np.ascontiguousarray(uold), unew, vp(f), vp(divu), vp(enew), dx, dt, nvector,
+                               interpol_var, interpol_type)
 
 
 TWOPI_REF = 6.2831853   # amr/constants.f90:5 (the reference's truncated 2*pi)

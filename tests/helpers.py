@@ -46,7 +46,7 @@ def _morton_rank(no):
     return np.argsort(np.argsort(key.reshape(-1))).reshape(no, no, no)
 
 
-def uniform_tree(L, slack=7, order="scrambled"):
+def uniform_tree(L, slack=7, order="scrambled", refine_box=None):
     """RAMSES tree arrays (amr/amr_commons.f90:67-75) of a periodic nx=ny=nz=1 box
     whose levels 1..L are fully refined; octs are numbered level by level in a
     scrambled order (the reference's lists are not lexicographic either).
@@ -55,7 +55,11 @@ def uniform_tree(L, slack=7, order="scrambled"):
     rng = np.random.default_rng(L)
     ncoarse = 1
     counts = [8 ** (l - 1) for l in range(1, L + 1)]
-    ngridmax = sum(counts) + slack
+    nextra = 0
+    if refine_box is not None:
+        (x0, x1), (y0, y1), (z0, z1) = refine_box
+        nextra = (x1 - x0) * (y1 - y0) * (z1 - z0)
+    ngridmax = sum(counts) + nextra + slack
     ncell = ncoarse + 8 * ngridmax
     son = np.zeros(ncell, np.int32)
     nbor = np.zeros((6, ngridmax), np.int32)
@@ -103,5 +107,23 @@ def uniform_tree(L, slack=7, order="scrambled"):
         kz, ky, kx = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
         return vec[:, cell_of(L, kx, ky, kz) - 1]
 
-    return dict(son=son, nbor=nbor, father=father, igrid=igrid, ncoarse=ncoarse, ngridmax=ngridmax, ncell=ncell,
-                to_cells=to_cells, from_cells=from_cells)
+    out = dict(son=son, nbor=nbor, father=father, igrid=igrid, ncoarse=ncoarse, ngridmax=ngridmax, ncell=ncell,
+               to_cells=to_cells, from_cells=from_cells)
+    if refine_box is not None:
+        # level L+1 octs in every level-L cell of the (periodic) box: a partially refined level whose
+        # father cells all have their 3^3 neighbours (level L is fully refined)
+        (x0, x1), (y0, y1), (z0, z1) = refine_box
+        cz, cy, cx = np.meshgrid(np.arange(z0, z1) % n, np.arange(y0, y1) % n, np.arange(x0, x1) % n, indexing="ij")
+        cz, cy, cx = cz.reshape(-1), cy.reshape(-1), cx.reshape(-1)
+        idf = free[used:used + cx.size].astype(np.int32)
+        fcell = cell_of(L, cx, cy, cz)
+        father[idf - 1] = fcell
+        son[fcell - 1] = idf
+        for d in range(6):
+            axis, up = d >> 1, d & 1
+            c = [cx.copy(), cy.copy(), cz.copy()]
+            c[axis] = (c[axis] + (1 if up else -1)) % n
+            nbor[d, idf - 1] = cell_of(L, c[0], c[1], c[2])
+        out["igrid_fine"] = rng.permutation(idf).astype(np.int32)
+        out["fine_cells"] = lambda: np.concatenate([ncoarse + ind * ngridmax + idf for ind in range(8)])
+    return out
