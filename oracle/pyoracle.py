@@ -158,6 +158,21 @@ def godunov_fine_amr(p, igrid, son, nbor, father, ngridmax, ncoarse, uold, unew,
                                interpol_var, interpol_type)
 
 
+def cg_solve(igrid, son, nbor, ngridmax, ncoarse, phi, f, epsilon, itermax=10000):
+    """Iteration loop of phi_fine_cg on one level (serial): phi[ncell] and f[3, ncell] (r, p, Ap) are
+    updated in place from the state cmp_residual_cg left; returns (iterations, error, error_ini)."""
+    assert f.shape[0] == 3 and f.flags.c_contiguous and phi.flags.c_contiguous
+    err = (C.c_double * 2)()
+    L = lib()
+    L.ora_cg_solve.restype = C.c_int
+    L.ora_cg_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                               C.c_double, C.c_int, C.c_void_p]
+    ig, so, nb = (np.ascontiguousarray(a, np.int32) for a in (igrid, son, nbor))
+    it = L.ora_cg_solve(len(ig), ig.ctypes.data, so.ctypes.data, nb.ctypes.data, ngridmax, ncoarse, phi.ctypes.data,
+                        f.ctypes.data, epsilon, itermax, C.addressof(err))
+    return it, err[0], err[1]
+
+
 TWOPI_REF = 6.2831853   # amr/constants.f90:5 (the reference's truncated 2*pi)
 
 
