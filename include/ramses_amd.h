@@ -398,6 +398,24 @@ int ramses_amd_mgamr_restrict(int finelevel);
 int ramses_amd_mgamr_interpolate(int finelevel);
 int ramses_amd_mgamr_end(void);
 
+/* -------------------------------------------------------------------------
+ * phi_fine_cg(ilevel,icount) -- poisson/phi_fine_cg.f90:5-206: the iteration loop (:88-187)
+ * of the conjugate-gradient Poisson solver with cmp_Ap_cg (:344-447), on one AMR level in the
+ * reference's own arrays (host pointers): phi, f = (r, p, A p) as f(1:ncell,1:3), tree son/nbor,
+ * the level's oct list.  The caller has done the reference's pre-loop steps (initial guess,
+ * make_virtual_fine_dp, make_boundary_phi, cmp_residual_cg :52-85).  On return phi and f hold
+ * what the reference's loop leaves; *iter = iterations, err[0] = last rms residual
+ * (:186), err[1] = the first, err[2] = rhs_norm (:63-78, 0 if rho is NULL).
+ * fact = fourpi*dx^2/6 (:45), ncell_level = twotondim*numbtot(1,ilevel).  One rank (the dot
+ * products are not reduced over MPI).  ordered != 0: the dot products are summed in the
+ * reference's order (bit-identical, slow); 0: fixed parallel tree (deterministic, phi equal to
+ * ~1e-13 relative); < 0: taken from the environment (RAMSES_AMD_CG_ORDERED=1).
+ * ------------------------------------------------------------------------- */
+int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int *son, const int *nbor,
+                             int64_t ngridmax, int64_t ncoarse, double *phi, double *f, const double *rho_or_null,
+                             double rho_tot, double fact, double ncell_level, double epsilon, int itermax,
+                             int ordered, int *iter, double *err);
+
 /* ---------------------------------------------------------------------------
  * Device-resident level.  For a fully refined periodic
  * level of a single-rank hydro-only run the state stays on the GPU across

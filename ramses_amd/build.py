@@ -29,6 +29,7 @@ UNITS = [
     ("amr_ops.o", "amr_ops.hip", ["-ffp-contract=off"]),
     ("amr_sweep.o", "amr_sweep.hip", ["-ffp-contract=off"]),
     ("mg_amr.o", "mg_amr.hip", ["-ffp-contract=off"]),
+    ("cg_amr.o", "cg_amr.hip", ["-ffp-contract=off"]),
     ("capi.o", "capi.hip", ["-ffp-contract=off"]),
 ]
 

@@ -13,6 +13,7 @@
 #include "../../include/ramses_amd.h"
 #include "amr_args.hpp"
 #include "amr_sweep_args.hpp"
+#include "cg_amr_args.hpp"
 #include "mg_amr_args.hpp"
 #include "mg_args.hpp"
 #include "misc_args.hpp"
@@ -1299,6 +1300,101 @@ int ramses_amd_mgamr_end(void) {
   if (!M.sync) rc = mgamr_store_fine(M.h_phi, M.lev[M.ilevel].u1.as<double>());
   M.open = false;
   return rc;
+}
+
+// ---------------------------------------------------------------------------
+// Conjugate-gradient Poisson solver on one AMR level (phi_fine_cg,
+// poisson/phi_fine_cg.f90:88-187; kernels in cg_amr.hip).  The caller has run the
+// reference's pre-loop steps (initial guess, boundaries, cmp_residual_cg): phi and
+// f(:,1) = f(:,2) = r hold the state the loop starts from.  The loop is pipelined:
+// iteration k+1 is queued while r2 of iteration k travels to the host, which needs
+// it only to decide about iteration k+2 (the reference tests the error of the
+// previous iteration).
+// ---------------------------------------------------------------------------
+extern "C++" {
+namespace {
+struct CgCtx {
+  DevBuf son, nbor, igrid, nb, x, r, p, z, rho, scal, partial, prod;
+  double *pin = nullptr;      // pinned: r2 of each iteration (ring of 4), rhs norm
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+CgCtx g_cg;
+}  // namespace
+}  // extern "C++"
+
+int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int *son, const int *nbor,
+                             int64_t ngridmax, int64_t ncoarse, double *phi, double *f, const double *rho_or_null,
+                             double rho_tot, double fact, double ncell_level, double epsilon, int itermax,
+                             int ordered, int *iter_out, double *err_out) {
+  if (!igrid || !son || !nbor || !phi || !f || !iter_out || !err_out) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (ngrid <= 0 || ngridmax < ngrid || ncoarse < 1) return fail(RAMSES_AMD_EINVAL, "bad level sizes (ngrid=%d)", ngrid);
+  if (ilevel < 1 || ilevel > 30) return fail(RAMSES_AMD_EINVAL, "bad level %d", ilevel);
+  if (!(ncell_level > 0) || itermax < 1) return fail(RAMSES_AMD_EINVAL, "bad ncell_level/itermax");
+  CgCtx &G = g_cg;
+  hipStream_t s = nullptr;
+  if (ordered < 0) {   // the Fortran shim: RAMSES_AMD_CG_ORDERED=1 selects the reference's summation order
+    const char *e = getenv("RAMSES_AMD_CG_ORDERED");
+    ordered = e && e[0] == '1';
+  }
+  const long ncell = ncoarse + 8 * ngridmax;
+  const size_t vb = sizeof(double) * ncell;
+  HCHK(G.son.ensure(sizeof(int) * ncell), "hipMalloc son");
+  HCHK(G.nbor.ensure(sizeof(int) * 6 * ngridmax), "hipMalloc nbor");
+  HCHK(G.igrid.ensure(sizeof(int) * ngrid), "hipMalloc igrid");
+  HCHK(G.nb.ensure(sizeof(int) * 6 * (size_t)ngrid), "hipMalloc nb");
+  HCHK(G.x.ensure(vb), "hipMalloc x"); HCHK(G.r.ensure(vb), "hipMalloc r");
+  HCHK(G.p.ensure(vb), "hipMalloc p"); HCHK(G.z.ensure(vb), "hipMalloc z");
+  HCHK(G.scal.ensure(sizeof(double) * 8), "hipMalloc"); HCHK(G.partial.ensure(sizeof(double) * CG_MAX_BLOCKS), "hipMalloc");
+  if (ordered) HCHK(G.prod.ensure(sizeof(double) * 8 * (size_t)ngrid), "hipMalloc prod");
+  if (!G.pin) {
+    HCHK(hipHostMalloc(reinterpret_cast<void **>(&G.pin), sizeof(double) * 8, hipHostMallocDefault), "hipHostMalloc");
+    for (int k = 0; k < 4; k++) HCHK(hipEventCreateWithFlags(&G.ev[k], hipEventDisableTiming), "hipEventCreate");
+  }
+  HCHK(hipMemcpyAsync(G.son.p, son, sizeof(int) * ncell, hipMemcpyHostToDevice, s), "H2D son");
+  HCHK(hipMemcpyAsync(G.nbor.p, nbor, sizeof(int) * 6 * ngridmax, hipMemcpyHostToDevice, s), "H2D nbor");
+  HCHK(hipMemcpyAsync(G.igrid.p, igrid, sizeof(int) * ngrid, hipMemcpyHostToDevice, s), "H2D igrid");
+  HCHK(hipMemcpyAsync(G.x.p, phi, vb, hipMemcpyHostToDevice, s), "H2D phi");
+  HCHK(hipMemcpyAsync(G.r.p, f, vb, hipMemcpyHostToDevice, s), "H2D r");
+  HCHK(hipMemcpyAsync(G.p.p, f + ncell, vb, hipMemcpyHostToDevice, s), "H2D p");
+  HCHK(hipMemcpyAsync(G.z.p, f + 2 * ncell, vb, hipMemcpyHostToDevice, s), "H2D z");
+  HCHK(hipMemsetAsync(G.scal.p, 0, sizeof(double) * 8, s), "memset");
+  HCHK(cg_launch_setup(G.igrid.as<int>(), ngrid, G.son.as<int>(), G.nbor.as<int>(), ngridmax, G.nb.as<int>(), s), "cg setup");
+  CgLevel L;
+  L.ngrid = ngrid; L.igrid = G.igrid.as<int>(); L.nb = G.nb.as<int>(); L.ncoarse = ncoarse; L.ngridmax = ngridmax;
+  L.x = G.x.as<double>(); L.r = G.r.as<double>(); L.p = G.p.as<double>(); L.z = G.z.as<double>();
+  L.scal = G.scal.as<double>(); L.partial = G.partial.as<double>(); L.prod = ordered ? G.prod.as<double>() : nullptr;
+  double rhs_norm = 0.0;
+  if (rho_or_null) {
+    HCHK(G.rho.ensure(vb), "hipMalloc rho");
+    HCHK(hipMemcpyAsync(G.rho.p, rho_or_null, vb, hipMemcpyHostToDevice, s), "H2D rho");
+    HCHK(cg_launch_rhs_norm(L, G.rho.as<double>(), rho_tot, fact * fact, s), "cg rhs norm");
+    HCHK(hipMemcpyAsync(G.pin + 4, L.scal + CG_RHS, sizeof(double), hipMemcpyDeviceToHost, s), "D2H rhs");
+  }
+  // r2 of iteration k lives in pin[k & 3], signalled by ev[k & 3]
+  HCHK(cg_launch_dot_rr(L, s), "cg dot");
+  HCHK(hipMemcpyAsync(G.pin + 1, L.scal + CG_R2, sizeof(double), hipMemcpyDeviceToHost, s), "D2H r2");
+  HCHK(hipEventRecord(G.ev[1], s), "event");
+  int iter = 0;
+  double error = 1.0, error_ini = 1.0;
+  while (error > epsilon * error_ini && iter < itermax) {
+    iter++;
+    HCHK(cg_launch_iteration(L, iter, s), "cg iteration");
+    HCHK(hipMemcpyAsync(G.pin + ((iter + 1) & 3), L.scal + CG_R2, sizeof(double), hipMemcpyDeviceToHost, s), "D2H r2");
+    HCHK(hipEventRecord(G.ev[(iter + 1) & 3], s), "event");
+    HCHK(hipEventSynchronize(G.ev[iter & 3]), "event sync");
+    error = std::sqrt(G.pin[iter & 3] / ncell_level);     // :186
+    if (iter == 1) error_ini = error;
+  }
+  HCHK(hipMemcpyAsync(phi, G.x.p, vb, hipMemcpyDeviceToHost, s), "D2H phi");
+  HCHK(hipMemcpyAsync(f, G.r.p, vb, hipMemcpyDeviceToHost, s), "D2H r");
+  HCHK(hipMemcpyAsync(f + ncell, G.p.p, vb, hipMemcpyDeviceToHost, s), "D2H p");
+  HCHK(hipMemcpyAsync(f + 2 * ncell, G.z.p, vb, hipMemcpyDeviceToHost, s), "D2H z");
+  HCHK(hipStreamSynchronize(s), "sync");
+  if (rho_or_null) rhs_norm = std::sqrt(G.pin[4] / ncell_level);   // :78
+  *iter_out = iter;
+  err_out[0] = error; err_out[1] = error_ini; err_out[2] = rhs_norm;
+  g_host.res_valid = false;
+  return 0;
 }
 #undef HCHK
 

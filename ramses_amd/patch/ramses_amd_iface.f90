@@ -92,6 +92,19 @@ module ramses_amd_iface
        integer(c_int) :: rc
      end function ramses_amd_godunov_fine_amr_f90
 
+     ! ---- conjugate-gradient solver on an AMR level (include/ramses_amd.h) ----
+     function ramses_amd_cg_solve_host(ilevel, ngrid, igrid, son, nbor, ngridmax, ncoarse, phi, f, rho, rho_tot, &
+          & fact, ncell_level, epsilon, itermax, ordered, iter, err) bind(C, name='ramses_amd_cg_solve_host') result(rc)
+       import :: c_int, c_int64_t, c_double
+       integer(c_int), value :: ilevel, ngrid, itermax, ordered
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       real(c_double), value :: rho_tot, fact, ncell_level, epsilon
+       integer(c_int) :: igrid(*), son(*), nbor(*)
+       real(c_double) :: phi(*), f(*), rho(*), err(3)
+       integer(c_int) :: iter
+       integer(c_int) :: rc
+     end function ramses_amd_cg_solve_host
+
      ! ---- multigrid on AMR levels (include/ramses_amd.h) ----
      function ramses_amd_mgamr_begin(ilevel, ngridmax, ncoarse, son, nbor, father, lookup_mg, flag2, phi, f, &
           & ngrid, igrid) bind(C, name='ramses_amd_mgamr_begin') result(rc)

@@ -1,0 +1,146 @@
+"""Conjugate-gradient Poisson solver (phi_fine_cg) on the MI355X:
+kernel level against dumps of the UNMODIFIED reference (tests/golden/cg_ref.npz, made by
+tests/golden/make_golden_cg.py with oracle/dump_patch/phi_fine_cg.f90), against the C oracle on
+a synthetic partially refined tree, and end to end through the patched reference program."""
+import ctypes as C
+import importlib.util
+import os
+import re
+import shutil
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "cg_ref.npz")
+vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
+
+
+def _solve(gpu_lib, d, ordered, rho=None, rho_tot=0.0, fact=1.0):
+    it = C.c_int(0)
+    err = (C.c_double * 3)()
+    rc = gpu_lib.ramses_amd_cg_solve_host(d["ilevel"], d["ngrid"], vp(d["igrid"]), vp(d["son"]), vp(d["nbor"]), d["ngridmax"],
+                                          d["ncoarse"], vp(d["phi"]), vp(d["f"]), vp(rho), rho_tot, fact, 8.0 * d["ngrid"],
+                                          d["epsilon"], 10000, ordered, C.byref(it), err)
+    assert rc == 0, gpu_lib.ramses_amd_last_error()
+    return it.value, list(err)
+
+
+def _load(z, s):
+    from test_cg_oracle import load
+    d = load(z, s)
+    for k in ("igrid", "son", "nbor"):
+        d[k] = np.ascontiguousarray(d[k], np.int32)
+    return d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solve", [1, 2, 6])
+def test_cg_ordered_equals_reference_dump(gpu_lib, solve):
+    """Dot products summed in the reference's order: iteration count, phi and r/p/Ap bit for bit."""
+    z = np.load(GOLD)
+    d = _load(z, solve)
+    it, err = _solve(gpu_lib, d, ordered=1)
+    assert it == int(z["solves"][solve - 1][1])
+    assert np.array_equal(d["phi"], d["phi_out"]), np.abs(d["phi"] - d["phi_out"]).max()
+    lev = np.zeros(d["phi"].size, bool)
+    for ind in range(8):
+        lev[d["ncoarse"] + ind * d["ngridmax"] + d["igrid"] - 1] = True
+    assert np.array_equal(d["f"][:, lev], d["f_out"][:, lev])
+    assert np.array_equal(d["f"][:2, ~lev], z["s%d_f" % solve][:, ~lev])       # cells off the level untouched
+    assert abs(err[0] / err[1] - z["errors"][solve - 1][1]) <= 6e-4 * z["errors"][solve - 1][1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solve", [1, 2, 6])
+def test_cg_parallel_sums_agree_with_reference_dump(gpu_lib, solve):
+    """Default mode (fixed parallel reduction tree): same iteration count on these solves, phi equal
+    to 1e-12 of its range, and the result is reproducible run to run."""
+    z = np.load(GOLD)
+    d = _load(z, solve)
+    it, _ = _solve(gpu_lib, d, ordered=0)
+    assert it == int(z["solves"][solve - 1][1])
+    scale = np.abs(d["phi_out"]).max()
+    assert np.abs(d["phi"] - d["phi_out"]).max() <= 1e-12 * scale
+    d2 = _load(z, solve)
+    it2, _ = _solve(gpu_lib, d2, ordered=0)
+    assert it2 == it and np.array_equal(d2["phi"], d["phi"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ordered", [1, 0])
+def test_cg_on_a_synthetic_tree_equals_the_oracle(gpu_lib, oracle, ordered):
+    """Random right-hand side on a two-level synthetic tree (level 5 octs in a box crossing the
+    periodic boundary, zero outside the level): HIP against oracle/cg_oracle.c, incl. rhs_norm."""
+    from helpers import uniform_tree
+    T = uniform_tree(4, refine_box=((13, 20), (2, 9), (6, 12)))
+    rng = np.random.default_rng(5)
+    ncell = T["ncell"]
+    igrid = np.ascontiguousarray(T["igrid_fine"], np.int32)
+    lev = T["fine_cells"]() - 1
+    phi0 = np.zeros(ncell)
+    phi0[lev] = rng.normal(size=lev.size)
+    f0 = np.zeros((3, ncell))
+    f0[0, lev] = rng.normal(size=lev.size)
+    f0[1] = f0[0]
+    f0[1, ~np.isin(np.arange(ncell), lev)] = 0.0
+    rho = rng.random(ncell)
+    d = dict(ilevel=5, ngrid=len(igrid), ngridmax=T["ngridmax"], ncoarse=T["ncoarse"], igrid=igrid, son=T["son"], nbor=T["nbor"],
+             epsilon=1e-8, phi=phi0.copy(), f=f0.copy())
+    it, err = _solve(gpu_lib, d, ordered, rho=rho, rho_tot=0.5, fact=0.37)
+    phi, f = phi0.copy(), f0.copy()
+    it_o, e_o, e_ini_o = oracle.cg_solve(igrid, T["son"], T["nbor"], T["ngridmax"], T["ncoarse"], phi, f, 1e-8)
+    assert it_o > 20
+    rhs_o = np.float64(0.0)
+    for ind in range(8):          # the reference's summation order (:63-70)
+        for g in igrid:
+            dd = rho[T["ncoarse"] + ind * T["ngridmax"] + g - 1] - 0.5
+            rhs_o = rhs_o + (0.37 * 0.37) * dd * dd
+    rhs_o = np.sqrt(rhs_o / (8.0 * len(igrid)))
+    if ordered:
+        assert it == it_o and np.array_equal(d["phi"], phi) and np.array_equal(d["f"], f)
+        assert err[0] == e_o and err[1] == e_ini_o and err[2] == rhs_o
+    else:
+        assert abs(it - it_o) <= 1
+        assert np.abs(d["phi"] - phi).max() <= 1e-7 * np.abs(phi).max()     # both converged to epsilon = 1e-8
+        assert abs(err[2] - rhs_o) <= 1e-14 * rhs_o
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ordered", ["1", "0"])
+def test_patched_program_with_cg_levels_equals_reference(gpu_lib, ordered):
+    """The self-gravitating AMR run with cg_levelmin=4 (levels 4 and 5 solved by phi_fine_cg, level 3
+    by multigrid) through the patched reference program: ordered sums -> the reference's snapshot
+    bit for bit and the same iteration counts; parallel sums -> equal to rounding."""
+    patched = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch")
+    if not os.path.exists(patched):
+        pytest.skip("oracle/_ref/ramses3d_patch not built")
+    from oracle import ramses_snapshot as rs
+    spec = importlib.util.spec_from_file_location("mkcg", os.path.join(ROOT, "tests", "golden", "make_golden_cg.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    z = np.load(GOLD)
+    os.environ["RAMSES_AMD_CG_ORDERED"] = ordered
+    try:
+        work, out = rs.run_reference(mk.cg_namelist(), binary=patched)
+    finally:
+        os.environ.pop("RAMSES_AMD_CG_ORDERED", None)
+    try:
+        assert "phi_fine_cg" not in out or "MI355X" in out
+        solves = re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+) Error=\s*(\S+)[ \t]+(\S+)[ \t]*\n", out)
+        solves = np.array([[int(a), int(b)] for a, b, _, _ in solves])
+        snap = rs.load_leaf_cells(os.path.join(work, "output_00002"), with_grav=True)
+        order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+        assert np.array_equal(snap["level"][order], z["level"])
+        if ordered == "1":
+            assert np.array_equal(solves, z["solves"])
+            assert np.array_equal(snap["grav"][:, order], z["grav"]), np.abs(snap["grav"][:, order] - z["grav"]).max()
+            assert np.array_equal(snap["prim"][:, order], z["prim"])
+        else:
+            assert solves.shape == z["solves"].shape and np.abs(solves - z["solves"]).max() <= 1
+            assert np.abs(snap["grav"][:, order] - z["grav"]).max() <= 1e-9 * np.abs(z["grav"]).max()
+            assert np.abs(snap["prim"][:, order] - z["prim"]).max() <= 1e-11 * np.abs(z["prim"]).max()
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
