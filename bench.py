@@ -410,7 +410,8 @@ def main():
             if rank == 0:
                 out["vcycle"] = vc
         elif rank == 0:
-            note["note"] = "the distributed multigrid needs a cubic rank grid (1 or 8 GPUs per node)"
+            note["note"] = ("a periodic RAMSES box is a cube (nx=ny=nz=1; they are not namelist items of the reference), so a "
+                            "weak-scaling V-cycle at a fixed brick per GPU exists only on cubic rank grids: 1 and 8 GPUs")
             out["vcycle"] = note
     if rank == 0:
         print(json.dumps(out), flush=True)
