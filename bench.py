@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--mg-tune", type=int, default=-1,
                     help="fused smoother: 1 = 4 colour passes per launch, 12/16 = 2+2 passes on 12/16-row tiles (-1: library default)")
     ap.add_argument("--vcycle-deadline", type=int, default=180, help="N>1: seconds before the V-cycle leg is abandoned")
+    ap.add_argument("--deadline", type=int, default=900,
+                    help="N>1: seconds before the whole run is abandoned (a hung collective must not hang the node)")
     return ap.parse_args()
 
 
@@ -165,7 +167,7 @@ def vcycle_bench(level):
                          "frac": gbs / HBM_PEAK_GBS, "bytes_per_dof": BYTES_PER_DOF_VCYCLE}}
 
 
-def vcycle_bench_dist(level_local, pgrid, rank, world):
+def vcycle_bench_dist(level_local, pgrid, rank, world, transport=None):
     """The same measurement on p^3 GPUs (weak scaling: 2^level_local cells per
     direction per rank): distributed V-cycles with the 5-cell communication-
     avoiding halo and replicated coarse levels (ramses_amd/poisson_parallel.py).
@@ -176,7 +178,7 @@ def vcycle_bench_dist(level_local, pgrid, rank, world):
     from ramses_amd.poisson_parallel import PoissonDecomposition
     n = 2 ** level_local
     p = pgrid[0]
-    pd = PoissonDecomposition(pgrid, rank, n, boxlen=1.0, epsilon=1e-30)   # exactly MAXITER=10 V-cycles
+    pd = PoissonDecomposition(pgrid, rank, n, boxlen=1.0, epsilon=1e-30, transport=transport)   # exactly MAXITER=10 V-cycles
     N = n * p
     a, b = int(0.375 * N), int(0.625 * N)
     c = rank_coords(rank, pgrid)
@@ -189,12 +191,12 @@ def vcycle_bench_dist(level_local, pgrid, rank, world):
     rho_tot = 1.0 + 9.0 * ((b - a) / N) ** 3
     pd.multigrid_fine(rho_tot)                # warm-up
     pd.exchanges = 0
-    dist.barrier()
+    pd.tr.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     iters, err = pd.multigrid_fine(rho_tot)
     torch.cuda.synchronize()
-    dist.barrier()
+    pd.tr.barrier()
     t = time.perf_counter() - t0
     t = pd.tr.allreduce(t, "cuda", op="max")
     dof = float(N) ** 3 * iters / t
@@ -206,6 +208,37 @@ def vcycle_bench_dist(level_local, pgrid, rank, world):
             "replicated_levels_from": pd.lrep,
             "roofline": {"bound": "hbm", "achieved": gbs / world, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
                          "frac": gbs / world / HBM_PEAK_GBS, "bytes_per_dof": BYTES_PER_DOF_VCYCLE}}
+
+
+def pick_transport(rank, world, timeout):
+    """RCCL is the transport.  Before anything is measured every rank exercises it once (an
+    all-reduce and a ring send/recv of device tensors); the verdicts are combined over a gloo
+    group.  If RCCL does not work on this node the exchange falls back to host-staged gloo --
+    slower, still a valid whole-job number, and the JSON line says so."""
+    import torch
+    import torch.distributed as dist
+    from ramses_amd.transport import DistTransport
+    gloo = dist.new_group(backend="gloo", timeout=timeout)
+    ok, why = 1, ""
+    try:
+        tr = DistTransport()
+        t = torch.ones(4, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        recv = torch.zeros(1024, dtype=torch.float64, device="cuda")
+        send = torch.full((1024,), float(rank), dtype=torch.float64, device="cuda")
+        tr.sendrecv([(send, (rank + 1) % world)], [(recv, (rank - 1) % world)])
+        torch.cuda.synchronize()
+        if float(t[0].item()) != world or float(recv[0].item()) != (rank - 1) % world:
+            ok, why = 0, "wrong data"
+    except Exception as exc:     # noqa: BLE001
+        ok, why = 0, str(exc)[:160]
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=gloo)
+    if int(flag.item()) == 1:
+        return DistTransport(), None
+    if why:
+        sys.stderr.write("bench.py rank %d: RCCL self-test failed: %s\n" % (rank, why))
+    return DistTransport(group=gloo, staged=True), "gloo send/recv staged through the host (the RCCL self-test failed on this node)"
 
 
 def main():
@@ -224,13 +257,35 @@ def main():
     # RAMSES_AMD_DIST_BACKEND=gloo: smoke-test the multi-rank path with all ranks on
     # one GPU (tensors staged through the host); never a measurement
     backend = os.environ.get("RAMSES_AMD_DIST_BACKEND", "nccl")
+    # "nccl-shared": RCCL with several ranks on one GPU -- it must refuse, which exercises the fallback
     local_dev = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_dev)
+    transport, transport_note = None, None
     if world > 1:
+        import datetime
+        import threading
+
+        def abandon():
+            # a collective that never returns (RCCL bootstrap, a lost peer): say so and leave
+            sys.stderr.write("bench.py rank %d: no result after %d s, giving up\n" % (rank, args.deadline))
+            if rank == 0:
+                print(json.dumps({"metric": "cell-updates/s (Godunov sweep), uniform Sedov3D", "value": None,
+                                  "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                                  "error": "run abandoned after %d s (hung collective?)" % args.deadline}), flush=True)
+            os._exit(3)
+
+        watchdog = threading.Timer(args.deadline, abandon)
+        watchdog.daemon = True
+        watchdog.start()
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+            transport, transport_note = pick_transport(rank, world, datetime.timedelta(seconds=120))
+        elif backend == "nccl-shared":
+            dist.init_process_group("nccl")
+            transport, transport_note = pick_transport(rank, world, datetime.timedelta(seconds=120))
         else:
             dist.init_process_group(backend)
+            transport_note = "%s send/recv staged through the host (smoke-test mode, not a measurement)" % backend
 
     n = args.n
     pgrid = rank_grid(world)
@@ -253,7 +308,7 @@ def main():
         exchange = None
     else:
         from ramses_amd.parallel import BrickDecomposition
-        dec = BrickDecomposition(pgrid, rank, n, boxlen=0.5 * pgrid[0])
+        dec = BrickDecomposition(pgrid, rank, n, boxlen=0.5 * pgrid[0], transport=transport)
         lev = dec.make_level(params)
         dec.init_sedov(lev)
         exchange = dec
@@ -289,7 +344,7 @@ def main():
         for mode in (False, True):
             for _ in range(2):
                 step(mode)
-            dist.barrier()
+            exchange.transport.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(4):
@@ -304,7 +359,7 @@ def main():
     # ---- timed region --------------------------------------------------------
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if world > 1:
-        dist.barrier()
+        exchange.transport.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -320,7 +375,7 @@ def main():
                 exchange.make_virtual_fine_dp(lev)
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        exchange.transport.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
@@ -346,7 +401,8 @@ def main():
                                    % (n, pgrid[0], pgrid[1], pgrid[2], n * pgrid[0], n * pgrid[1], n * pgrid[2]),
                        "arithmetic": "fast (FMA contraction, <=1e-12 rel of strict)" if args.fast else "strict (bit-identical to the reference)",
                        "halo": "none (single rank, in-kernel periodic wrap)" if world == 1 else
-                               "RCCL send/recv of 2-cell face slabs, all nvar fused, " +
+                               ("RCCL send/recv" if transport_note is None else transport_note) +
+                               " of 2-cell face slabs, all nvar fused, " +
                                "one grouped exchange of all 26 neighbour regions (one message per peer), " +
                                ("overlapped with the interior sweep on a second stream" if overlap else "after the sweep") +
                                ("" if tune is None else " (auto-selected: serial %.3f ms/step, overlapped %.3f ms/step)"
@@ -403,7 +459,7 @@ def main():
             try:
                 del lev, exchange, dec
                 torch.cuda.empty_cache()
-                vc = vcycle_bench_dist(args.vcycle_level, pgrid, rank, world)
+                vc = vcycle_bench_dist(args.vcycle_level, pgrid, rank, world, transport)
             except Exception as exc:
                 vc = dict(note, error=str(exc)[:300])
             wd.cancel()

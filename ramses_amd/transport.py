@@ -23,10 +23,15 @@ class DistTransport:
     the multi-process paths be exercised where RCCL cannot run (CPU container,
     several ranks sharing one GPU)."""
 
-    def __init__(self):
+    def __init__(self, group=None, staged=None):
+        """group: a process group spanning all ranks (default: the world group); staged: force
+        the host-staged path (default: staged iff the group's backend is gloo)."""
+        self.group = group
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.staged = dist.is_initialized() and dist.get_backend() == "gloo"
+        if staged is None:
+            staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
+        self.staged = bool(staged)
 
     def sendrecv(self, sends, recvs):
         """sends/recvs: lists of (tensor, peer).  One grouped launch
@@ -36,20 +41,23 @@ class DistTransport:
         if self.staged and (sends + recvs)[0][0].is_cuda:
             hs = [(t.cpu(), p) for t, p in sends]
             hr = [(torch.empty(t.shape, dtype=t.dtype), p) for t, p in recvs]
-            ops = [dist.P2POp(dist.isend, t, p) for t, p in hs] + [dist.P2POp(dist.irecv, t, p) for t, p in hr]
+            g = self.group
+            ops = [dist.P2POp(dist.isend, t, p, g) for t, p in hs] + [dist.P2POp(dist.irecv, t, p, g) for t, p in hr]
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
             for (t, _), (h, _) in zip(recvs, hr):
                 t.copy_(h)
             return
-        ops = [dist.P2POp(dist.isend, t, p) for t, p in sends] + [dist.P2POp(dist.irecv, t, p) for t, p in recvs]
+        g = self.group
+        ops = [dist.P2POp(dist.isend, t, p, g) for t, p in sends] + [dist.P2POp(dist.irecv, t, p, g) for t, p in recvs]
         for w in dist.batch_isend_irecv(ops):
             w.wait()
 
     def allreduce(self, value, device, op="sum"):
         t = torch.tensor([value], dtype=torch.float64, device="cpu" if self.staged else device)
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MIN if op == "min" else (dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM))
+            dist.all_reduce(t, op=dist.ReduceOp.MIN if op == "min" else (dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM),
+                            group=self.group)
         return float(t.item())
 
     def allgather(self, t):
@@ -59,12 +67,12 @@ class DistTransport:
         src = t.contiguous().cpu() if self.staged else t.contiguous()
         # concatenated along dim 0 (the layout every backend accepts), viewed per rank
         out = torch.empty((self.world * src.shape[0],) + tuple(src.shape[1:]), dtype=t.dtype, device=src.device)
-        dist.all_gather_into_tensor(out, src)
+        dist.all_gather_into_tensor(out, src, group=self.group)
         return out.view((self.world,) + tuple(src.shape)).to(t.device)
 
     def barrier(self):
         if self.world > 1:
-            dist.barrier()
+            dist.barrier(group=self.group)
 
 
 class LocalWorld:
