@@ -1315,7 +1315,8 @@ extern "C++" {
 namespace {
 struct CgCtx {
   DevBuf son, nbor, igrid, nb, x, r, p, z, rho, scal, partial, prod;
-  double *pin = nullptr;      // pinned: r2 of each iteration (ring of 4), rhs norm
+  double *pin = nullptr;      // pinned, device-visible: r2 of each iteration (ring of 4, written by the kernels), rhs norm
+  double *pin_dev = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 CgCtx g_cg;
@@ -1347,7 +1348,8 @@ int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int 
   HCHK(G.scal.ensure(sizeof(double) * 8), "hipMalloc"); HCHK(G.partial.ensure(sizeof(double) * CG_MAX_BLOCKS), "hipMalloc");
   if (ordered) HCHK(G.prod.ensure(sizeof(double) * 8 * (size_t)ngrid), "hipMalloc prod");
   if (!G.pin) {
-    HCHK(hipHostMalloc(reinterpret_cast<void **>(&G.pin), sizeof(double) * 8, hipHostMallocDefault), "hipHostMalloc");
+    HCHK(hipHostMalloc(reinterpret_cast<void **>(&G.pin), sizeof(double) * 8, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
+    HCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&G.pin_dev), G.pin, 0), "hipHostGetDevicePointer");
     for (int k = 0; k < 4; k++) HCHK(hipEventCreateWithFlags(&G.ev[k], hipEventDisableTiming), "hipEventCreate");
   }
   HCHK(hipMemcpyAsync(G.son.p, son, sizeof(int) * ncell, hipMemcpyHostToDevice, s), "H2D son");
@@ -1362,6 +1364,7 @@ int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int 
   CgLevel L;
   L.ngrid = ngrid; L.igrid = G.igrid.as<int>(); L.nb = G.nb.as<int>(); L.ncoarse = ncoarse; L.ngridmax = ngridmax;
   L.x = G.x.as<double>(); L.r = G.r.as<double>(); L.p = G.p.as<double>(); L.z = G.z.as<double>();
+  L.host_r2 = G.pin_dev;
   L.scal = G.scal.as<double>(); L.partial = G.partial.as<double>(); L.prod = ordered ? G.prod.as<double>() : nullptr;
   double rhs_norm = 0.0;
   if (rho_or_null) {
@@ -1370,16 +1373,14 @@ int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int 
     HCHK(cg_launch_rhs_norm(L, G.rho.as<double>(), rho_tot, fact * fact, s), "cg rhs norm");
     HCHK(hipMemcpyAsync(G.pin + 4, L.scal + CG_RHS, sizeof(double), hipMemcpyDeviceToHost, s), "D2H rhs");
   }
-  // r2 of iteration k lives in pin[k & 3], signalled by ev[k & 3]
-  HCHK(cg_launch_dot_rr(L, s), "cg dot");
-  HCHK(hipMemcpyAsync(G.pin + 1, L.scal + CG_R2, sizeof(double), hipMemcpyDeviceToHost, s), "D2H r2");
+  // r2 of iteration k is stored into pin[k & 3] by the kernel that forms it, signalled by ev[k & 3]
+  HCHK(cg_launch_dot_rr(L, 1, s), "cg dot");
   HCHK(hipEventRecord(G.ev[1], s), "event");
   int iter = 0;
   double error = 1.0, error_ini = 1.0;
   while (error > epsilon * error_ini && iter < itermax) {
     iter++;
-    HCHK(cg_launch_iteration(L, iter, s), "cg iteration");
-    HCHK(hipMemcpyAsync(G.pin + ((iter + 1) & 3), L.scal + CG_R2, sizeof(double), hipMemcpyDeviceToHost, s), "D2H r2");
+    HCHK(cg_launch_iteration(L, iter, (iter + 1) & 3, s), "cg iteration");
     HCHK(hipEventRecord(G.ev[(iter + 1) & 3], s), "event");
     HCHK(hipEventSynchronize(G.ev[iter & 3]), "event sync");
     error = std::sqrt(G.pin[iter & 3] / ncell_level);     // :186

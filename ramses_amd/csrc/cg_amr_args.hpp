@@ -12,7 +12,9 @@ struct CgLevel {
   const int *nb;        // [6][ngrid] son(nbor(igrid,k)): neighbouring oct or 0
   long ncoarse, ngridmax;
   double *x, *r, *p, *z;
-  double *scal;         // device scalars: [0] r2, [1] r2 of the previous iteration, [2] pAp, [3] rhs norm^2
+  double *scal;         // device scalars: [0] r2, [1] r2 of the previous iteration, [2] pAp, [3] rhs norm^2,
+                        // [6] (as unsigned) count of finished blocks of the running reduction
+  double *host_r2;      // pinned ring of 4 (device-visible): r2 of iteration k goes to slot k & 3
   double *partial;      // [CG_MAX_BLOCKS] per-block partial sums
   double *prod;         // [8*ngrid] products in the reference's summation order (ordered mode) or nullptr
 };
@@ -22,9 +24,10 @@ enum { CG_R2 = 0, CG_R2_OLD = 1, CG_PAP = 2, CG_RHS = 3 };
 hipError_t cg_launch_setup(const int *igrid, int ngrid, const int *son, const int *nbor, long ngridmax, int *nb, hipStream_t s);
 // scal[CG_RHS] = sum fact2*(rho-rho_tot)^2 over the level
 hipError_t cg_launch_rhs_norm(const CgLevel &L, const double *rho, double rho_tot, double fact2, hipStream_t s);
-// scal[CG_R2] = r.r   (start of the first iteration)
-hipError_t cg_launch_dot_rr(const CgLevel &L, hipStream_t s);
+// scal[CG_R2] = r.r   (start of the first iteration), also stored to host_r2[slot]
+hipError_t cg_launch_dot_rr(const CgLevel &L, int slot, hipStream_t s);
 // one iteration (:96-183): p = r + beta p; z = A p; pAp; x += alpha p; r -= alpha z; r2 of the new r
-hipError_t cg_launch_iteration(const CgLevel &L, int iter, hipStream_t s);
+// (stored to host_r2[slot]).  Three launches (parallel sums) or five (ordered sums).
+hipError_t cg_launch_iteration(const CgLevel &L, int iter, int slot, hipStream_t s);
 
 }  // namespace ramses_amd
