@@ -394,24 +394,24 @@ int64_t ramses_amd_mg_workspace_doubles(int level) {
 #define MGCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipfail(e_, what); } while (0)
 
 int ramses_amd_mg_gauss_seidel(double *d_phi, const double *d_rhs, int n, double dx2, int redstep, void *stream) {
-  if (!d_phi || !d_rhs || n < 2 || (n & 1)) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  if (!d_phi || !d_rhs || n < 2 || (n & (n - 1))) return fail(RAMSES_AMD_EINVAL, "bad argument (n must be a power of two)");
   MGCHK(mg_launch_gs(d_phi, d_rhs, n, dx2, redstep ? 0 : 1, reinterpret_cast<hipStream_t>(stream)), "mg gs launch");
   return 0;
 }
 int ramses_amd_mg_residual(const double *d_phi, const double *d_rhs, double *d_res, int n, double dx,
                            double *d_work, double *d_norm2, void *stream) {
-  if (!d_phi || !d_rhs || !d_res || n < 2) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  if (!d_phi || !d_rhs || !d_res || n < 2 || (n & (n - 1))) return fail(RAMSES_AMD_EINVAL, "bad argument (n must be a power of two)");
   if (d_norm2 && !d_work) return fail(RAMSES_AMD_EINVAL, "norm needs a workspace of %d doubles", MG_MAX_PARTIALS);
   MGCHK(mg_launch_residual(d_phi, d_rhs, d_res, n, dx, d_work, d_norm2, reinterpret_cast<hipStream_t>(stream)), "mg residual launch");
   return 0;
 }
 int ramses_amd_mg_restrict(const double *d_res_f, double *d_rhs_c, double *d_u1_c, int nf, void *stream) {
-  if (!d_res_f || !d_rhs_c || !d_u1_c || nf < 2 || (nf & 1)) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  if (!d_res_f || !d_rhs_c || !d_u1_c || nf < 2 || (nf & (nf - 1))) return fail(RAMSES_AMD_EINVAL, "bad argument (nf must be a power of two)");
   MGCHK(mg_launch_restrict(d_res_f, d_rhs_c, d_u1_c, nf, reinterpret_cast<hipStream_t>(stream)), "mg restrict launch");
   return 0;
 }
 int ramses_amd_mg_interp_correct(double *d_phi_f, const double *d_corr_c, int nf, void *stream) {
-  if (!d_phi_f || !d_corr_c || nf < 2 || (nf & 1)) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  if (!d_phi_f || !d_corr_c || nf < 2 || (nf & (nf - 1))) return fail(RAMSES_AMD_EINVAL, "bad argument (nf must be a power of two)");
   MGCHK(mg_launch_interp(d_phi_f, d_corr_c, nf, reinterpret_cast<hipStream_t>(stream)), "mg interp launch");
   return 0;
 }
@@ -526,13 +526,13 @@ int ramses_amd_mg_rhs(const double *d_rho, double *d_f2, int64_t N, double fourp
   return 0;
 }
 int ramses_amd_mg_restrict_ghost(const double *d_res_f, double *d_rhs_c, int nf, int ngf, int ngc, void *stream) {
-  if (!d_res_f || !d_rhs_c || nf < 2 || (nf & 1) || ngf < 0 || ngc < 0) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  if (!d_res_f || !d_rhs_c || nf < 2 || (nf & (nf - 1)) || ngf < 0 || ngc < 0) return fail(RAMSES_AMD_EINVAL, "bad argument (nf must be a power of two)");
   MGCHK(mg_launch_restrict_ghost(d_res_f, d_rhs_c, nf, ngf, ngc, reinterpret_cast<hipStream_t>(stream)), "mg restrict launch");
   return 0;
 }
 int ramses_amd_mg_interp_correct_ghost(double *d_phi_f, int nf, int ngf, const double *d_corr_c, int ngc,
                                        int cglob, const int *coarse_origin, void *stream) {
-  if (!d_phi_f || !d_corr_c || nf < 2 || (nf & 1) || ngf < 0) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  if (!d_phi_f || !d_corr_c || nf < 2 || (nf & (nf - 1)) || ngf < 0) return fail(RAMSES_AMD_EINVAL, "bad argument (nf must be a power of two)");
   if (cglob == 0 && ngc < 1) return fail(RAMSES_AMD_EINVAL, "the local coarse brick needs >= 1 ghost layer");
   if (cglob != 0 && !coarse_origin) return fail(RAMSES_AMD_EINVAL, "replicated coarse level needs the origin of this rank's part");
   const int ox = coarse_origin ? coarse_origin[0] : 0, oy = coarse_origin ? coarse_origin[1] : 0, oz = coarse_origin ? coarse_origin[2] : 0;
@@ -540,7 +540,7 @@ int ramses_amd_mg_interp_correct_ghost(double *d_phi_f, int nf, int ngf, const d
   return 0;
 }
 int ramses_amd_gradient_phi_ghost(const double *d_phi, double *d_f, int n, int ng, double dx, void *stream) {
-  if (!d_phi || !d_f || n < 2 || ng < 2) return fail(RAMSES_AMD_EINVAL, "gradient_phi needs 2 ghost layers of phi");
+  if (!d_phi || !d_f || n < 2 || (n & (n - 1)) || ng < 2) return fail(RAMSES_AMD_EINVAL, "gradient_phi needs a power-of-two brick with 2 ghost layers of phi");
   const double a = 0.50 * 4.0 / 3.0 / dx;   // force_fine.f90:233-234
   const double b = 0.25 * 1.0 / 3.0 / dx;
   MGCHK(mg_launch_gradient_ghost(d_phi, d_f, n, ng, a, b, reinterpret_cast<hipStream_t>(stream)), "gradient_phi launch");

@@ -19,6 +19,16 @@ namespace ramses_amd {
 
 __device__ __forceinline__ int wrapi(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
 
+// cell index -> (i,j,k) of an n^3 box, n a power of two (every multigrid level is): shifts and
+// masks instead of 64-bit integer division, which costs more than the 7-point stencil itself
+__device__ __forceinline__ int ilog2(int n) { return 31 - __clz(n); }
+__device__ __forceinline__ void decode3(long c, int lg, int &i, int &j, int &k) {
+  const int mask = (1 << lg) - 1;
+  i = (int)(c & mask);
+  j = (int)((c >> lg) & mask);
+  k = (int)(c >> (2 * lg));
+}
+
 __device__ __forceinline__ double nb_sum6(const double *__restrict__ phi, int i, int j, int k, int n) {
   const long nn = (long)n * n;
   const long row = (long)j * n + (long)k * nn;
@@ -56,9 +66,10 @@ __global__ __launch_bounds__(256) void mg_gs_kernel(double *__restrict__ phi, co
   const int nh = n >> 1;
   const long total = (long)nh * n * n;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    const int ih = (int)(t % nh);
-    const int j = (int)((t / nh) % n);
-    const int k = (int)(t / ((long)nh * n));
+    const int lg = ilog2(n);
+    const int ih = (int)(t & (nh - 1));
+    const int j = (int)((t >> (lg - 1)) & (n - 1));
+    const int k = (int)(t >> (2 * lg - 1));
     const int i = 2 * ih + ((j + k + color) & 1);
     const double nb = nb_sum6(phi, i, j, k, n);
     const long c = (long)i + (long)n * (j + (long)n * k);
@@ -74,9 +85,8 @@ __global__ __launch_bounds__(256) void mg_residual_kernel(const double *__restri
   const long N = (long)n * n * n;
   double acc = 0.0;
   for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (long)gridDim.x * blockDim.x) {
-    const int i = (int)(c % n);
-    const int j = (int)((c / n) % n);
-    const int k = (int)(c / ((long)n * n));
+    int i, j, k;
+    decode3(c, ilog2(n), i, j, k);
     const double phi_c = phi[c];
     const double nb = nb_sum6(phi, i, j, k, n);
     const double r = -oneoverdx2 * (nb - 6.0 * phi_c) + rhs[c];
@@ -119,9 +129,8 @@ __global__ __launch_bounds__(256) void mg_restrict_kernel(const double *__restri
   const int nc = nf >> 1;
   const long Nc = (long)nc * nc * nc;
   for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < Nc; c += (long)gridDim.x * blockDim.x) {
-    const int I = (int)(c % nc);
-    const int J = (int)((c / nc) % nc);
-    const int K = (int)(c / ((long)nc * nc));
+    int I, J, K;
+    decode3(c, ilog2(nc), I, J, K);
     double acc = 0.0;
 #pragma unroll
     for (int ind = 0; ind < 8; ind++) {
@@ -141,9 +150,8 @@ __global__ __launch_bounds__(256) void mg_interp_kernel(double *__restrict__ phi
   const double a = 1.0 / 64.0, b = 3 * a, cc = 9 * a, d = 27 * a;
   const double bbb[8] = {a, b, b, cc, b, cc, cc, d};
   for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < Nf; c += (long)gridDim.x * blockDim.x) {
-    const int i = (int)(c % nf);
-    const int j = (int)((c / nf) % nf);
-    const int k = (int)(c / ((long)nf * nf));
+    int i, j, k;
+    decode3(c, ilog2(nf), i, j, k);
     const int I = i >> 1, J = j >> 1, K = k >> 1;
     const int sx = (i & 1) ? 1 : -1, sy = (j & 1) ? 1 : -1, sz = (k & 1) ? 1 : -1;
     double corr = 0.0;
@@ -163,9 +171,8 @@ __global__ __launch_bounds__(256) void mg_gradient_kernel(const double *__restri
                                                            int n, double a, double b) {
   const long N = (long)n * n * n;
   for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (long)gridDim.x * blockDim.x) {
-    const int i = (int)(c % n);
-    const int j = (int)((c / n) % n);
-    const int k = (int)(c / ((long)n * n));
+    int i, j, k;
+    decode3(c, ilog2(n), i, j, k);
     const long nn = (long)n * n;
     {
       const long row = (long)j * n + (long)k * nn;
@@ -202,9 +209,8 @@ __global__ __launch_bounds__(256) void mg_restrict_ghost_kernel(const double *__
   const long Nc = (long)nc * nc * nc;
   const int pf = nf + 2 * ngf, pc = nc + 2 * ngc;
   for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < Nc; c += (long)gridDim.x * blockDim.x) {
-    const int I = (int)(c % nc);
-    const int J = (int)((c / nc) % nc);
-    const int K = (int)(c / ((long)nc * nc));
+    int I, J, K;
+    decode3(c, ilog2(nc), I, J, K);
     double acc = 0.0;
 #pragma unroll
     for (int ind = 0; ind < 8; ind++) {
@@ -228,9 +234,8 @@ __global__ __launch_bounds__(256) void mg_interp_ghost_kernel(double *__restrict
   const double a = 1.0 / 64.0, b = 3 * a, cc = 9 * a, d = 27 * a;
   const double bbb[8] = {a, b, b, cc, b, cc, cc, d};
   for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < Nf; c += (long)gridDim.x * blockDim.x) {
-    const int i = (int)(c % nf);
-    const int j = (int)((c / nf) % nf);
-    const int k = (int)(c / ((long)nf * nf));
+    int i, j, k;
+    decode3(c, ilog2(nf), i, j, k);
     const int I = i >> 1, J = j >> 1, K = k >> 1;
     const int sx = (i & 1) ? 1 : -1, sy = (j & 1) ? 1 : -1, sz = (k & 1) ? 1 : -1;
     double corr = 0.0;
@@ -261,9 +266,8 @@ __global__ __launch_bounds__(256) void mg_gradient_ghost_kernel(const double *__
   const int p = n + 2 * ng;
   const long pp = (long)p * p;
   for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (long)gridDim.x * blockDim.x) {
-    const int i = (int)(c % n);
-    const int j = (int)((c / n) % n);
-    const int k = (int)(c / ((long)n * n));
+    int i, j, k;
+    decode3(c, ilog2(n), i, j, k);
     const long o = gidx(i, j, k, ng, p);
     f[c] = a * (phi[o - 1] - phi[o + 1]) - b * (phi[o - 2] - phi[o + 2]);
     f[c + N] = a * (phi[o - p] - phi[o + p]) - b * (phi[o - 2 * p] - phi[o + 2 * p]);
