@@ -434,7 +434,7 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
   // rhs of colour pass s on plane z is the value pass s-2 used on the same plane 4 steps
   // earlier (same cell: the pair offset depends on z only through its parity), so only
   // passes 1 and 2 load; later passes take it from a register FIFO
-  struct StepLoads { double ph[NROW]; double rv[2][NPAIR]; double rf[NROW]; };
+  struct StepLoads { double ph[NROW]; double rv[2][NPAIR]; };
   // which cell of the pair has colour c on plane z in row ly: lx = 2p + off
   auto pair_off = [&](int ly, int z, int color) { return ((x0 + y0 + ly + z) & 1) ^ color; };
   auto issue = [&](int m, StepLoads &L) {
@@ -450,18 +450,18 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
 #pragma unroll
       for (int j = 0; j < NPAIR; j++) L.rv[s - 1][j] = base[goffC[j][pair_off(lyC[j], z, (s & 1) ? 0 : 1)]];
     }
-    if (RESID) {
-      const double *__restrict__ base = rhs + (long)wrap1(m - 2 * P) * nn;
-#pragma unroll
-      for (int i = 0; i < NROW; i++) L.rf[i] = base[goffR[i]];
-    }
+    // (the residual of plane m-2P needs no load of its own: its red cells' rhs was loaded by pass 1
+    //  2P steps ago, its black cells' by pass 2 2P-2 steps ago -- both are still in the register FIFO)
   };
   // prefetch distance 2 steps: LDS capacity limits the CU to 6 wavefronts, so
   // registers are plentiful and memory-level parallelism has to come from here
   StepLoads cur, nxt, nx2;
-  double fifo[4][2][NPAIR];   // rhs values of passes 1,2 of the last 4 steps; [0] = 4 steps ago
+  // rhs values of passes 1,2 of the last FD steps; [FD-1] = previous step, [0] = FD steps ago.
+  // Passes 3,4 reuse the values of 4 steps ago; the fused residual those of 2P (red) and 2P-2 (black)
+  constexpr int FD = RESID ? 2 * P : 4;
+  double fifo[FD][2][NPAIR];
 #pragma unroll
-  for (int a = 0; a < 4; a++)
+  for (int a = 0; a < FD; a++)
 #pragma unroll
     for (int b = 0; b < 2; b++)
 #pragma unroll
@@ -506,33 +506,50 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
         nbv[s - 1][j] = nb;
       }
     }
+    // final stage.  Without the residual: row mapping (a), one phi per lane and row.  With it: pair
+    // mapping (b), the lane's (2p, 2p+1) cells of its row pairs, because that is where the rhs sits.
     double nbf[NROW], phf[NROW];
     bool onf[NROW];
+    double nbb[NPAIR][2], phb[NPAIR][2];
+    bool onb[NPAIR][2];
     const int zf = m - 2 * P;
     {
       const bool zin = (zf >= z0) && (zf <= z1 - 1);
       const double *pc = ring + slot(zf) * G::PLANE;
       const double *pm = ring + slot(zf - 1) * G::PLANE;
       const double *pp = ring + slot(zf + 1) * G::PLANE;
-      const bool xin = zin && (lane >= H) && (lane < G::LX - H) && (gxu < n);
+      if (!RESID) {
+        const bool xin = zin && (lane >= H) && (lane < G::LX - H) && (gxu < n);
 #pragma unroll
-      for (int i = 0; i < NROW; i++) {
-        const int ly = wv + NW * i;
-        onf[i] = xin && ly >= H && ly < G::LY - H && (y0 + ly) < n;
-        double nb = 0.0, ph = 0.0;
-        if (onf[i]) {
-          const int c = lofsR[i];
-          ph = pc[c];
-          if (RESID) {
-            nb = nb + pc[c - 1];
-            nb = nb + pc[c - G::LX];
-            nb = nb + pm[c];
-            nb = nb + pc[c + 1];
-            nb = nb + pc[c + G::LX];
-            nb = nb + pp[c];
+        for (int i = 0; i < NROW; i++) {
+          const int ly = wv + NW * i;
+          onf[i] = xin && ly >= H && ly < G::LY - H && (y0 + ly) < n;
+          phf[i] = onf[i] ? pc[lofsR[i]] : 0.0;
+          nbf[i] = 0.0;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NPAIR; j++) {
+          const int ly = lyC[j];
+          const bool yin = zin && ly >= H && ly < G::LY - H && (y0 + ly) < n;
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            const int lx = 2 * pr + e;
+            onb[j][e] = yin && lx >= H && lx < G::LX - H && (x0 + lx) < n;
+            double nb = 0.0, ph = 0.0;
+            if (onb[j][e]) {
+              const int c = ly * G::LX + lx;
+              ph = pc[c];
+              nb = nb + pc[c - 1];
+              nb = nb + pc[c - G::LX];
+              nb = nb + pm[c];
+              nb = nb + pc[c + 1];
+              nb = nb + pc[c + G::LX];
+              nb = nb + pp[c];
+            }
+            nbb[j][e] = nb; phb[j][e] = ph;
           }
         }
-        nbf[i] = nb; phf[i] = ph;
       }
     }
     // ---- update phase: colour passes write their cells -------------------------
@@ -542,22 +559,31 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
 #pragma unroll
       for (int j = 0; j < NPAIR; j++)
         if (on[s - 1][j]) {
-          const double r = s <= 2 ? cur.rv[(s - 1) & 1][j] : fifo[0][(s - 1) & 1][j];
+          const double r = s <= 2 ? cur.rv[(s - 1) & 1][j] : fifo[FD - 4][(s - 1) & 1][j];
           pc[cidx[s - 1][j]] = div6(nbv[s - 1][j] - dx2 * r);
         }
     }
     // ---- final stage: store phi (+ residual and its norm) of plane m-2P -------
     {
       const long zoff = (long)wrap1(zf) * nn;
+      if (!RESID) {
 #pragma unroll
-      for (int i = 0; i < NROW; i++) {
-        if (onf[i]) {
-          const long g = zoff + goffR[i];
-          phi_out[g] = phf[i];
-          if (RESID) {
-            const double r = -oneoverdx2 * (nbf[i] - 6.0 * phf[i]) + cur.rf[i];
-            if (res) res[g] = r;      // norm-only callers pass NULL: the residual never leaves the chip
-            acc = acc + r * r;
+        for (int i = 0; i < NROW; i++)
+          if (onf[i]) phi_out[zoff + goffR[i]] = phf[i];
+      } else {
+#pragma unroll
+        for (int j = 0; j < NPAIR; j++) {
+          const int ered = pair_off(lyC[j], zf, 0);       // which cell of the pair is red on this plane
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            if (onb[j][e]) {
+              const long g = zoff + goffC[j][e];
+              phi_out[g] = phb[j][e];
+              const double rr = (e == ered) ? fifo[0][0][j] : fifo[2][1][j];
+              const double r = -oneoverdx2 * (nbb[j][e] - 6.0 * phb[j][e]) + rr;
+              if (res) res[g] = r;      // norm-only callers pass NULL: the residual never leaves the chip
+              acc = acc + r * r;
+            }
           }
         }
       }
@@ -569,13 +595,14 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
       for (int i = 0; i < NROW; i++) pl[lofsR[i]] = cur.ph[i];
     }
     __syncthreads();
-    if (P > 2) {
+    if (P > 2 || RESID) {
 #pragma unroll
       for (int b = 0; b < 2; b++)
 #pragma unroll
         for (int j = 0; j < NPAIR; j++) {
-          fifo[0][b][j] = fifo[1][b][j]; fifo[1][b][j] = fifo[2][b][j];
-          fifo[2][b][j] = fifo[3][b][j]; fifo[3][b][j] = cur.rv[b][j];
+#pragma unroll
+          for (int a = 0; a + 1 < FD; a++) fifo[a][b][j] = fifo[a + 1][b][j];
+          fifo[FD - 1][b][j] = cur.rv[b][j];
         }
     }
     cur = nxt;
