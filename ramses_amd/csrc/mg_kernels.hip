@@ -143,26 +143,51 @@ __global__ __launch_bounds__(256) void mg_restrict_kernel(const double *__restri
 }
 
 // phi_f += sum_{8 of 27 parents} w*corr_c, weights (a,b,b,c,b,c,c,d)
+// One thread per COARSE cell: its 3^3 neighbourhood of corrections is loaded once (27 loads for 8
+// children instead of 8 per child) and each child adds its 8 terms in the reference's order
+// (interpolate_and_correct_fine, multigrid_fine_fine.f90:596-698: t = 0..7, bit 0/1/2 of t set =
+// the parent itself along x/y/z, clear = the neighbour on the child's side).
 __global__ __launch_bounds__(256) void mg_interp_kernel(double *__restrict__ phi_f,
                                                          const double *__restrict__ corr_c, int nf) {
   const int nc = nf >> 1;
-  const long Nf = (long)nf * nf * nf;
+  const int lgc = ilog2(nc);
+  const long Nc = (long)nc * nc * nc;
   const double a = 1.0 / 64.0, b = 3 * a, cc = 9 * a, d = 27 * a;
   const double bbb[8] = {a, b, b, cc, b, cc, cc, d};
-  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < Nf; c += (long)gridDim.x * blockDim.x) {
-    int i, j, k;
-    decode3(c, ilog2(nf), i, j, k);
-    const int I = i >> 1, J = j >> 1, K = k >> 1;
-    const int sx = (i & 1) ? 1 : -1, sy = (j & 1) ? 1 : -1, sz = (k & 1) ? 1 : -1;
-    double corr = 0.0;
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < Nc; c += (long)gridDim.x * blockDim.x) {
+    int I, J, K;
+    decode3(c, lgc, I, J, K);
+    int xi[3] = {wrapi(I - 1, nc), I, wrapi(I + 1, nc)};
+    long yo[3] = {(long)wrapi(J - 1, nc) * nc, (long)J * nc, (long)wrapi(J + 1, nc) * nc};
+    long zo[3] = {(long)wrapi(K - 1, nc) * nc * nc, (long)K * nc * nc, (long)wrapi(K + 1, nc) * nc * nc};
+    double v[3][3][3];
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-      const int pi = (t & 1) ? I : wrapi(I + sx, nc);
-      const int pj = (t & 2) ? J : wrapi(J + sy, nc);
-      const int pk = (t & 4) ? K : wrapi(K + sz, nc);
-      corr = corr + bbb[t] * corr_c[(long)pi + (long)nc * (pj + (long)nc * pk)];
-    }
-    phi_f[c] = phi_f[c] + corr;
+    for (int kz = 0; kz < 3; kz++)
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) v[kz][ky][kx] = corr_c[zo[kz] + yo[ky] + xi[kx]];
+#pragma unroll
+    for (int iz = 0; iz < 2; iz++)
+#pragma unroll
+      for (int iy = 0; iy < 2; iy++) {
+        const long row = (long)(2 * I) + (long)nf * ((2 * J + iy) + (long)nf * (2 * K + iz));
+        double out[2];
+#pragma unroll
+        for (int ix = 0; ix < 2; ix++) {
+          double corr = 0.0;
+#pragma unroll
+          for (int t = 0; t < 8; t++) {
+            const int kx = (t & 1) ? 1 : (ix ? 2 : 0);
+            const int ky = (t & 2) ? 1 : (iy ? 2 : 0);
+            const int kz = (t & 4) ? 1 : (iz ? 2 : 0);
+            corr = corr + bbb[t] * v[kz][ky][kx];
+          }
+          out[ix] = phi_f[row + ix] + corr;
+        }
+        phi_f[row] = out[0];
+        phi_f[row + 1] = out[1];
+      }
   }
 }
 
@@ -311,7 +336,8 @@ hipError_t mg_launch_restrict(const double *res_f, double *rhs_c, double *u1_c, 
   return hipGetLastError();
 }
 hipError_t mg_launch_interp(double *phi_f, const double *corr_c, int nf, hipStream_t s) {
-  hipLaunchKernelGGL(mg_interp_kernel, dim3(grid_for((long)nf * nf * nf, 8192)), dim3(256), 0, s, phi_f, corr_c, nf);
+  const int nc = nf >> 1;
+  hipLaunchKernelGGL(mg_interp_kernel, dim3(grid_for((long)nc * nc * nc, 8192)), dim3(256), 0, s, phi_f, corr_c, nf);
   return hipGetLastError();
 }
 hipError_t mg_launch_restrict_ghost(const double *res_f, double *rhs_c, int nf, int ngf, int ngc, hipStream_t s) {
