@@ -253,32 +253,52 @@ __global__ __launch_bounds__(256) void mg_restrict_ghost_kernel(const double *__
 __global__ __launch_bounds__(256) void mg_interp_ghost_kernel(double *__restrict__ phi_f, int nf, int ngf,
                                                                const double *__restrict__ corr_c, int ngc,
                                                                int cglob, int cox, int coy, int coz) {
+  // one thread per coarse cell, as mg_interp_kernel
   const int nc = nf >> 1;
-  const long Nf = (long)nf * nf * nf;
+  const int lgc = ilog2(nc);
+  const long Nc = (long)nc * nc * nc;
   const int pf = nf + 2 * ngf, pc = nc + 2 * ngc;
   const double a = 1.0 / 64.0, b = 3 * a, cc = 9 * a, d = 27 * a;
   const double bbb[8] = {a, b, b, cc, b, cc, cc, d};
-  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < Nf; c += (long)gridDim.x * blockDim.x) {
-    int i, j, k;
-    decode3(c, ilog2(nf), i, j, k);
-    const int I = i >> 1, J = j >> 1, K = k >> 1;
-    const int sx = (i & 1) ? 1 : -1, sy = (j & 1) ? 1 : -1, sz = (k & 1) ? 1 : -1;
-    double corr = 0.0;
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < Nc; c += (long)gridDim.x * blockDim.x) {
+    int I, J, K;
+    decode3(c, lgc, I, J, K);
+    double v[3][3][3];
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-      const int pi = (t & 1) ? I : I + sx;
-      const int pj = (t & 2) ? J : J + sy;
-      const int pk = (t & 4) ? K : K + sz;
-      double v;
-      if (cglob) {
-        v = corr_c[(long)wrapi(pi + cox, cglob) + (long)cglob * (wrapi(pj + coy, cglob) + (long)cglob * wrapi(pk + coz, cglob))];
-      } else {
-        v = corr_c[gidx(pi, pj, pk, ngc, pc)];
+    for (int kz = 0; kz < 3; kz++)
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+          const int pi = I - 1 + kx, pj = J - 1 + ky, pk = K - 1 + kz;
+          if (cglob) {
+            v[kz][ky][kx] = corr_c[(long)wrapi(pi + cox, cglob) +
+                                   (long)cglob * (wrapi(pj + coy, cglob) + (long)cglob * wrapi(pk + coz, cglob))];
+          } else {
+            v[kz][ky][kx] = corr_c[gidx(pi, pj, pk, ngc, pc)];
+          }
+        }
+#pragma unroll
+    for (int iz = 0; iz < 2; iz++)
+#pragma unroll
+      for (int iy = 0; iy < 2; iy++) {
+        const long row = gidx(2 * I, 2 * J + iy, 2 * K + iz, ngf, pf);
+        double out[2];
+#pragma unroll
+        for (int ix = 0; ix < 2; ix++) {
+          double corr = 0.0;
+#pragma unroll
+          for (int t = 0; t < 8; t++) {
+            const int kx = (t & 1) ? 1 : (ix ? 2 : 0);
+            const int ky = (t & 2) ? 1 : (iy ? 2 : 0);
+            const int kz = (t & 4) ? 1 : (iz ? 2 : 0);
+            corr = corr + bbb[t] * v[kz][ky][kx];
+          }
+          out[ix] = phi_f[row + ix] + corr;
+        }
+        phi_f[row] = out[0];
+        phi_f[row + 1] = out[1];
       }
-      corr = corr + bbb[t] * v;
-    }
-    const long g = gidx(i, j, k, ngf, pf);
-    phi_f[g] = phi_f[g] + corr;
   }
 }
 
@@ -347,7 +367,8 @@ hipError_t mg_launch_restrict_ghost(const double *res_f, double *rhs_c, int nf, 
 }
 hipError_t mg_launch_interp_ghost(double *phi_f, int nf, int ngf, const double *corr_c, int ngc, int cglob,
                                   int cox, int coy, int coz, hipStream_t s) {
-  hipLaunchKernelGGL(mg_interp_ghost_kernel, dim3(grid_for((long)nf * nf * nf, 8192)), dim3(256), 0, s, phi_f, nf,
+  const int nc = nf >> 1;
+  hipLaunchKernelGGL(mg_interp_ghost_kernel, dim3(grid_for((long)nc * nc * nc, 8192)), dim3(256), 0, s, phi_f, nf,
                      ngf, corr_c, ngc, cglob, cox, coy, coz);
   return hipGetLastError();
 }
