@@ -1051,6 +1051,35 @@ int ramses_amd_resident_sync_host_f90(double *uold) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Page-lock a host array of the caller for the staged paths (the Fortran module
+// arrays are allocated once with fixed ngridmax and never reallocated, so their
+// addresses are stable for the run): H2D/D2H of pinned memory runs at DMA speed
+// instead of through the pageable bounce buffers.  Not fatal if the driver
+// refuses (the copies then take the pageable path).  Opt-in (RAMSES_AMD_PIN=1):
+// at the sizes measured so far (128^3 uniform, 570 k-cell AMR run) the staged
+// calls gain 5-10 % and the one-time registration costs ~0.2 s.
+// ---------------------------------------------------------------------------
+int ramses_amd_host_register(void *p, int64_t bytes) {
+  struct Range { char *lo, *hi; };
+  static Range done[64];
+  static int ndone = 0;
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char *e = getenv("RAMSES_AMD_PIN");
+    enabled = e && e[0] == '1';
+  }
+  if (!enabled || !p || bytes <= 0) return 0;
+  char *lo = static_cast<char *>(p), *hi = lo + bytes;
+  for (int i = 0; i < ndone; i++)
+    if (lo >= done[i].lo && hi <= done[i].hi) return 0;
+  if (ndone >= 64) return 0;
+  hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) (void)hipGetLastError();   // pageable copies still work
+  done[ndone].lo = lo; done[ndone].hi = hi; ndone++;   // (also remembers refusals: asked once)
+  return 0;
+}
+
 // forget the resident level (the host array was modified behind our back)
 int ramses_amd_resident_invalidate(void) {
   HostCtx &H = g_host;

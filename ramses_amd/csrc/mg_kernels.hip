@@ -13,6 +13,8 @@
 // reference's octant sets (1,4,6,7)/(2,3,5,8).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "mg_args.hpp"
 
 namespace ramses_amd {
@@ -686,6 +688,7 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
   const int IX = 64 - 2 * H, IY = LY - 2 * H;
   const int ntx = (n + IX - 1) / IX, nty = (n + IY - 1) / IY;
   int zchunk = n >= 256 ? 128 : (n >= 128 ? 64 : n);
+  if (const char *e = getenv("RAMSES_AMD_MG_ZCHUNK")) { const int z = atoi(e); if (z >= 8 && n >= 256) zchunk = z; }   // tuning aid
   const int ntz = (n + zchunk - 1) / zchunk;
   const int blocks = ntx * nty * ntz;
   if (resid && blocks > MG_MAX_PARTIALS) return hipErrorInvalidValue;

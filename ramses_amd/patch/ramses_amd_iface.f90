@@ -92,6 +92,19 @@ module ramses_amd_iface
        integer(c_int) :: rc
      end function ramses_amd_godunov_fine_amr_f90
 
+     function ramses_amd_host_register_dp(p, bytes) bind(C, name='ramses_amd_host_register') result(rc)
+       import :: c_int, c_int64_t, c_double
+       real(c_double) :: p(*)
+       integer(c_int64_t), value :: bytes
+       integer(c_int) :: rc
+     end function ramses_amd_host_register_dp
+     function ramses_amd_host_register_int(p, bytes) bind(C, name='ramses_amd_host_register') result(rc)
+       import :: c_int, c_int64_t
+       integer(c_int) :: p(*)
+       integer(c_int64_t), value :: bytes
+       integer(c_int) :: rc
+     end function ramses_amd_host_register_int
+
      ! ---- conjugate-gradient solver on an AMR level (include/ramses_amd.h) ----
      function ramses_amd_cg_solve_host(ilevel, ngrid, igrid, son, nbor, ngridmax, ncoarse, phi, f, rho, rho_tot, &
           & fact, ncell_level, epsilon, itermax, ordered, iter, err) bind(C, name='ramses_amd_cg_solve_host') result(rc)
@@ -223,11 +236,38 @@ contains
           if (rc /= 0) call ramses_amd_fatal('ramses_amd_abi_check')
           rc = ramses_amd_set_device_auto(ramses_amd_world_rank())
           if (rc /= 0) call ramses_amd_fatal('ramses_amd_set_device_auto')
+          call ramses_amd_pin_arrays()
        end if
        ramses_amd_checked = .true.
     end if
     ramses_amd_enabled = ramses_amd_on
   end function ramses_amd_enabled
+
+  !---------------------------------------------------------------------------
+  ! Page-lock the module arrays the staged entry points copy from and to (allocated once,
+  ! hydro/init_hydro.f90:30-32, poisson/init_poisson.f90:24-28, amr/init_amr.f90:52-55,
+  ! 227-233): the copies then run at DMA speed.  Never fatal.
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_pin_arrays()
+    use amr_commons
+    use hydro_commons
+    use poisson_commons
+    integer :: rc
+    integer(c_int64_t) :: nc
+    nc = int(ncoarse, 8) + 8_8 * int(ngridmax, 8)
+    if (hydro) then
+       if (allocated(uold)) rc = ramses_amd_host_register_dp(uold, nc * int(size(uold, 2), 8) * 8_8)
+       if (allocated(unew)) rc = ramses_amd_host_register_dp(unew, nc * int(size(unew, 2), 8) * 8_8)
+    end if
+    if (poisson) then
+       if (allocated(phi)) rc = ramses_amd_host_register_dp(phi, nc * 8_8)
+       if (allocated(rho)) rc = ramses_amd_host_register_dp(rho, nc * 8_8)
+       if (allocated(f)) rc = ramses_amd_host_register_dp(f, nc * int(size(f, 2), 8) * 8_8)
+    end if
+    if (allocated(son)) rc = ramses_amd_host_register_int(son, nc * 4_8)
+    if (allocated(nbor)) rc = ramses_amd_host_register_int(nbor, int(ngridmax, 8) * int(size(nbor, 2), 8) * 4_8)
+    if (allocated(father)) rc = ramses_amd_host_register_int(father, int(ngridmax, 8) * 4_8)
+  end subroutine ramses_amd_pin_arrays
 
   !---------------------------------------------------------------------------
   ! First device routine of an AMR multigrid solve: hand the tree, the fine level and
