@@ -161,3 +161,71 @@ def test_solve_fused_equals_unfused(gpu_lib):
     gpu_lib.ramses_amd_mg_tune(1)
     assert outs[0][0] == outs[1][0]
     assert np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("level", [8, 9])
+def test_full_size_properties(gpu_lib, level):
+    """BASELINE sizes (256^3 = config C4, 512^3 = the bench's V-cycle), where no CPU oracle finishes
+    in seconds: size-independent properties of multigrid_fine + force_fine.
+      * homogeneity: every operation of the solve is linear and a factor 2 is exact in binary
+        floating point, so doubling rho and rho_tot doubles phi and f bit for bit and leaves the
+        iteration count and the relative error unchanged;
+      * the reported error is the one an independent evaluation gives with the per-operator
+        kernels (not the fused smoother): norm of the final residual over the norm of the residual
+        after the first pre-smoothing (multigrid_fine_commons.f90:197-215,267);
+      * the fused smoother and the one-kernel-per-colour path give the same phi bit for bit."""
+    import torch
+    from ramses_amd.poisson import PoissonLevel
+    n = 1 << level
+    g = torch.Generator(device="cuda").manual_seed(level)
+    rho = 1.0 + 0.5 * torch.rand((n, n, n), dtype=torch.float64, device="cuda", generator=g)
+    a, b = n // 8, n // 3
+    rho[a:a + n // 6, b:b + n // 4, n // 2:n // 2 + n // 5] += 20.0
+    rho[-(n // 10):, :n // 7, n // 3:n // 2] += 7.0          # straddles the periodic boundary
+    rho_tot = float(rho.mean())
+    eps = 1e-7
+    lev = PoissonLevel(level, boxlen=1.0, epsilon=eps)
+    lev.rho.copy_(rho)
+    it, err = lev.multigrid_fine(rho_tot)
+    lev.force_fine()
+    torch.cuda.synchronize()
+    assert 2 <= it <= 10 and err < eps
+    phi = lev.phi.clone()
+    f = lev.f.clone()
+    # independent residual: r = rhs - A phi with the per-operator kernel, rhs = fourpi*(rho-rho_tot)
+    L = gpu_lib
+    fourpi = 2.0 * 6.2831853 * 1.0                # 2*twopi*scale, the reference's truncated twopi
+    rhs = fourpi * (rho - rho_tot)
+    res = torch.empty_like(rho)
+    work = torch.zeros(8192, dtype=torch.float64, device="cuda")
+    nrm = torch.zeros(2, dtype=torch.float64, device="cuda")
+    dx = 1.0 / n
+    zero = torch.zeros_like(rho)
+    for _ in range(2):                            # ngs_fine = 2 sweeps, red then black
+        assert L.ramses_amd_mg_gauss_seidel(_p(zero), _p(rhs), n, dx * dx, 1, None) == 0
+        assert L.ramses_amd_mg_gauss_seidel(_p(zero), _p(rhs), n, dx * dx, 0, None) == 0
+    assert L.ramses_amd_mg_residual(_p(zero), _p(rhs), _p(res), n, dx, _p(work), _p(nrm), None) == 0
+    n0 = float(nrm[0].item())
+    assert L.ramses_amd_mg_residual(_p(phi), _p(rhs), _p(res), n, dx, _p(work), _p(nrm), None) == 0
+    n1 = float(nrm[0].item())
+    torch.cuda.synchronize()
+    assert abs(np.sqrt(n1 / n0) - err) <= 1e-6 * err
+    del res, zero, rhs
+    # homogeneity
+    lev.rho.copy_(2.0 * rho)
+    it2, err2 = lev.multigrid_fine(2.0 * rho_tot)
+    lev.force_fine()
+    torch.cuda.synchronize()
+    assert it2 == it and err2 == err
+    assert torch.equal(lev.phi, 2.0 * phi)
+    assert torch.equal(lev.f, 2.0 * f)
+    del f
+    # fused smoother == one kernel per colour pass
+    L.ramses_amd_mg_tune(0)
+    try:
+        lev.rho.copy_(rho)
+        it3, _ = lev.multigrid_fine(rho_tot)
+        torch.cuda.synchronize()
+    finally:
+        L.ramses_amd_mg_tune(1)
+    assert it3 == it and torch.equal(lev.phi, phi)
