@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--vcycle-level", type=int, default=9,
                     help="multigrid V-cycle measurement: 2^level cells per direction per GPU (0 = skip)")
     ap.add_argument("--mg-tune", type=int, default=-1,
-                    help="fused smoother: 1 = 4 colour passes per launch, 12/16 = 2+2 passes on 12/16-row tiles (-1: library default)")
+                    help="fused smoother: 1 = library default (2+2 colour passes on 32-row tiles), 4 = one 4-pass launch, "
+                         "12/16/24/32 = 2+2 passes on that many tile rows, 0 = one kernel per colour pass (-1: leave the default)")
     ap.add_argument("--vcycle-deadline", type=int, default=180, help="N>1: seconds before the V-cycle leg is abandoned")
     ap.add_argument("--deadline", type=int, default=900,
                     help="N>1: seconds before the whole run is abandoned (a hung collective must not hang the node)")

@@ -220,8 +220,9 @@ int ramses_amd_mg_interp_correct(double *d_phi_f, const double *d_corr_c, int nf
 int ramses_amd_mg_smooth_fused(const double *d_phi_in, double *d_phi_out,
                                const double *d_rhs, double *d_res, double *d_work,
                                double *d_norm2, int n, double dx, int npass, void *stream);
-/* 1 (default): levels with n>=64 use the fused smoother inside multigrid_fine;
- * 0: one kernel per colour pass.  Results do not depend on it. */
+/* How multigrid_fine smooths levels with n>=64.  1 (default): fused smoother, 2+2 colour passes per
+ * smoothing step on 32-row tiles; 12|16|24|32: the same on that many tile rows; 4: one launch of 4
+ * colour passes (24-row tiles); 0: one kernel per colour pass.  Results do not depend on it. */
 int ramses_amd_mg_tune(int fused);
 
 /* ---------------------------------------------------------------------------

@@ -419,10 +419,11 @@ int ramses_amd_mg_interp_correct(double *d_phi_f, const double *d_corr_c, int nf
 // fused: 0 one launch per colour pass, 1 the fused smoother with 4 colour passes per launch (24-row
 // tiles, one workgroup per CU), 12 / 16: two launches of 2 colour passes on 12- / 16-row tiles
 // (three / two workgroups per CU).  Results do not depend on it.
-static int g_mg_split_rows = 0;
+static int g_mg_split_rows = 32;   // default: 2+2 colour passes on 32-row tiles (measured fastest at 512^3)
 int ramses_amd_mg_tune(int fused) {
   g_mg_fused = fused ? 1 : 0;
-  g_mg_split_rows = (fused == 12 || fused == 16) ? fused : 0;
+  if (fused == 1) fused = 32;                       // the default
+  g_mg_split_rows = (fused == 12 || fused == 16 || fused == 24 || fused == 32) ? fused : 0;   // 4: one 4-pass launch
   mg_set_smooth_rows(g_mg_split_rows ? g_mg_split_rows : 24);
   return 0;
 }

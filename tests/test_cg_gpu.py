@@ -144,3 +144,35 @@ def test_patched_program_with_cg_levels_equals_reference(gpu_lib, ordered):
             assert np.abs(snap["prim"][:, order] - z["prim"]).max() <= 1e-11 * np.abs(z["prim"]).max()
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+@pytest.mark.gpu
+def test_cg_homogeneity_on_a_full_level(gpu_lib):
+    """A fully refined periodic level of 2.1 M cells (no CPU oracle run at this size): every
+    operation of the iteration is linear and a factor 2 is exact, so doubling r and p doubles phi
+    and r/p/Ap bit for bit with the same iteration count (alpha and beta are ratios)."""
+    from helpers import uniform_tree
+    L = 7
+    T = uniform_tree(L, order="morton")
+    ncell = T["ncell"]
+    igrid = np.ascontiguousarray(T["igrid"], np.int32)
+    rng = np.random.default_rng(9)
+    lev = np.concatenate([T["ncoarse"] + ind * T["ngridmax"] + igrid - 1 for ind in range(8)])
+    r0 = np.zeros(ncell)
+    r0[lev] = rng.normal(size=lev.size)
+    r0[lev] -= r0[lev].mean()
+    outs = []
+    for scale in (1.0, 2.0):
+        f = np.zeros((3, ncell))
+        f[0] = scale * r0
+        f[1] = scale * r0
+        d = dict(ilevel=L, ngrid=len(igrid), ngridmax=T["ngridmax"], ncoarse=T["ncoarse"], igrid=igrid,
+                 son=np.ascontiguousarray(T["son"], np.int32), nbor=np.ascontiguousarray(T["nbor"], np.int32),
+                 epsilon=1e-6, phi=np.zeros(ncell), f=f)
+        it, err = _solve(gpu_lib, d, ordered=0)
+        outs.append((it, err, d["phi"], d["f"]))
+    (it1, e1, phi1, f1), (it2, e2, phi2, f2) = outs
+    assert it1 == it2 and it1 > 30
+    assert e2[0] == 2.0 * e1[0] and e2[1] == 2.0 * e1[1]
+    assert np.array_equal(phi2, 2.0 * phi1) and np.array_equal(f2, 2.0 * f1)
+    assert np.abs(phi1[lev]).max() > 0 and e1[0] <= 1e-6 * e1[1]
