@@ -35,7 +35,9 @@ __device__ __forceinline__ long nbr_cell(const MgAmrLevel &L, const MgAmrTree &T
   const int g2 = T.son[nb - 1];
   if (g2 == 0) return -1;
   const int j = T.lookup[g2 - 1];
-  if (j <= 0) return -2;
+  // (membership is checked, not assumed: an oct outside the level -- a physical-boundary oct --
+  //  may carry a stale entry of an earlier solve)
+  if (j <= 0 || j > L.ngrid || L.igrid[j - 1] != g2) return -2;
   return (long)jnd * L.ngrid + (j - 1);
 }
 
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void restrict_kernel(MgAmrLevel F, MgAmrLevel 
     const int ind_c = (int)((fc - T.ncoarse - 1) / T.ngridmax);
     const int g_c = (int)(fc - T.ncoarse - (long)ind_c * T.ngridmax);
     const int j = T.lookup[g_c - 1];
-    if (j <= 0) continue;
+    if (j <= 0 || j > C.ngrid || C.igrid[j - 1] != g_c) continue;
     const long cc = (long)ind_c * C.ngrid + (j - 1);
     if (C.u4[cc] <= 0.0) continue;
     double acc = 0.0;
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void interp_kernel(MgAmrLevel F, MgAmrLevel C,
         const int ind_c = (int)((fc - T.ncoarse - 1) / T.ngridmax);
         const int g_c = (int)(fc - T.ncoarse - (long)ind_c * T.ngridmax);
         const int j = T.lookup[g_c - 1];
-        if (j <= 0) continue;
+        if (j <= 0 || j > C.ngrid || C.igrid[j - 1] != g_c) continue;
         corr = corr + bbb[av] * C.u1[(long)ind_c * C.ngrid + (j - 1)];
       }
     }

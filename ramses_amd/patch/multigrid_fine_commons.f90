@@ -43,12 +43,13 @@ subroutine multigrid_fine(ilevel,icount)
   ! An AMR level (it does not cover the box, or it is not levelmin): the reference's own
   ! driver and per-solve setup run on the host, the compute routines it calls (shadowed by
   ! multigrid_fine_fine.f90 / multigrid_fine_coarse.f90 of this directory) on the device
+  ! (a box with physical boundaries: the Dirichlet values enter through the masks and the
+  !  right-hand side the reference prepares, so every level takes this path)
   nx_loc=icoarse_max-icoarse_min+1
-  if(ilevel>levelmin.or.int(active(ilevel)%ngrid,8)*8_8/=(2_8**ilevel)**3*int(nx_loc,8)**3)then
-     if(ncpu>1.or.nboundary>0)then
-        write(*,*)'ramses_amd: device multigrid on AMR levels handles periodic single-rank runs;'
-        write(*,*)'            got ncpu=',ncpu,' nboundary=',nboundary
-        call ramses_amd_fatal('multigrid_fine (AMR level: several ranks / physical boundaries)')
+  if(ilevel>levelmin.or.nboundary>0.or.int(active(ilevel)%ngrid,8)*8_8/=(2_8**ilevel)**3*int(nx_loc,8)**3)then
+     if(ncpu>1)then
+        write(*,*)'ramses_amd: device multigrid on AMR levels handles single-rank runs; got ncpu=',ncpu
+        call ramses_amd_fatal('multigrid_fine (AMR level: several ranks)')
      end if
      ramses_amd_mg_active=.true.
      ramses_amd_mg_started=.false.

@@ -140,6 +140,12 @@ def walls_namelist():
     return nml.replace("levelmax=3", "levelmax=5").replace("ngridtot=", "ngridtot=20000 !")
 
 
+def walls_selfgrav_namelist():
+    """Self-gravity in a box with six reflexive walls: Dirichlet boundaries of phi enter the
+    multigrid through the masks and the right-hand side on EVERY level (levelmin included)."""
+    return selfgrav_namelist().replace("&POISSON_PARAMS", WALLS + "&POISSON_PARAMS").replace("ngridtot=6000 !", "ngridtot=20000 !")
+
+
 # two passive scalars (NVAR=7 builds): interpolation, sweep and coarse corrections of the scalars
 V7_INIT = SELFGRAV_INIT + """
 var_region(1,1)=0.1
@@ -284,6 +290,21 @@ def main():
         out["sg_grav"] = snap["grav"][:, order]
         print("selfgrav leaf cells", snap["level"].size, "levels", np.unique(snap["level"]), "solves", len(solves),
               "levels solved", sorted(set(int(a) for a, _, _ in solves)))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    # AMR + self-gravity inside six walls
+    work, log = rs.run_reference(walls_selfgrav_namelist())
+    try:
+        import re
+        solves = re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+) Error=\s*(\S+)", log)
+        out["wg_solves"] = np.array([[int(a), int(b)] for a, b, _ in solves])
+        snap = rs.load_leaf_cells(os.path.join(work, "output_00002"), with_grav=True)
+        order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+        out["wg_level"] = snap["level"][order].astype(np.int8)
+        out["wg_x"] = snap["x"][order]
+        out["wg_prim"] = snap["prim"][:, order]
+        out["wg_grav"] = snap["grav"][:, order]
+        print("walls+selfgrav leaf cells", snap["level"].size, "levels", np.unique(snap["level"]), "solves", len(solves))
     finally:
         shutil.rmtree(work, ignore_errors=True)
     # BASELINE config C5 at 1/8 linear size (sedov3d.nml + levelmin=6, levelmax=8 + the C5 refine

@@ -29,6 +29,15 @@ def cg_namelist(eps="1e-5"):
     return mka.selfgrav_namelist(eps).replace("epsilon=%s" % eps, "epsilon=%s\ncg_levelmin=4" % eps)
 
 
+def cg_walls_namelist(eps="1e-5"):
+    """The same run inside six reflexive walls: cmp_Ap_cg reads p in physical-boundary octs, which
+    exist in the tree but are not in the level's list (constants of the solve)."""
+    spec = importlib.util.spec_from_file_location("mka", os.path.join(ROOT, "tests", "golden", "make_golden_amr.py"))
+    mka = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mka)
+    return mka.walls_selfgrav_namelist().replace("epsilon=%s" % eps, "epsilon=%s\ncg_levelmin=4" % eps)
+
+
 def read(work, k):
     with open(os.path.join(work, "cg_%04d_in.bin" % k), "rb") as fh:
         ilevel, ngrid, ngridmax, ncoarse = [int(x) for x in np.fromfile(fh, np.int32, 4)]
@@ -68,6 +77,20 @@ def main():
         out["x"] = snap["x"][order]
         out["prim"] = snap["prim"][:, order]
         out["grav"] = snap["grav"][:, order]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    # end to end inside walls (no dumps)
+    os.environ.pop("RAMSES_DUMP_CG", None)
+    work, log = rs.run_reference(cg_walls_namelist())
+    try:
+        solves = re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+) Error=\s*(\S+)[ \t]+(\S+)[ \t]*\n", log)
+        print("CG solves inside walls (level, iterations)", [(a, b) for a, b, _, _ in solves])
+        out["w_solves"] = np.array([[int(a), int(b)] for a, b, _, _ in solves])
+        snap = rs.load_leaf_cells(os.path.join(work, "output_00002"), with_grav=True)
+        order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+        out["w_level"] = snap["level"][order].astype(np.int8)
+        out["w_prim"] = snap["prim"][:, order]
+        out["w_grav"] = snap["grav"][:, order]
     finally:
         shutil.rmtree(work, ignore_errors=True)
     out["dumped"] = np.array(SOLVES)

@@ -147,6 +147,35 @@ def test_patched_program_with_cg_levels_equals_reference(gpu_lib, ordered):
 
 
 @pytest.mark.gpu
+def test_patched_program_with_cg_levels_inside_walls_equals_reference(gpu_lib):
+    """The same run inside six reflexive walls (ordered sums): boundary octs are neighbours whose p
+    the solver reads but never updates, and level 3 = levelmin takes the AMR multigrid path."""
+    patched = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch")
+    if not os.path.exists(patched):
+        pytest.skip("oracle/_ref/ramses3d_patch not built")
+    from oracle import ramses_snapshot as rs
+    spec = importlib.util.spec_from_file_location("mkcg", os.path.join(ROOT, "tests", "golden", "make_golden_cg.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    z = np.load(GOLD)
+    os.environ["RAMSES_AMD_CG_ORDERED"] = "1"
+    try:
+        work, out = rs.run_reference(mk.cg_walls_namelist(), binary=patched)
+    finally:
+        os.environ.pop("RAMSES_AMD_CG_ORDERED", None)
+    try:
+        solves = re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+) Error=\s*(\S+)[ \t]+(\S+)[ \t]*\n", out)
+        assert np.array_equal(np.array([[int(a), int(b)] for a, b, _, _ in solves]), z["w_solves"])
+        snap = rs.load_leaf_cells(os.path.join(work, "output_00002"), with_grav=True)
+        order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+        assert np.array_equal(snap["level"][order], z["w_level"])
+        assert np.array_equal(snap["grav"][:, order], z["w_grav"]), np.abs(snap["grav"][:, order] - z["w_grav"]).max()
+        assert np.array_equal(snap["prim"][:, order], z["w_prim"])
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+@pytest.mark.gpu
 def test_cg_homogeneity_on_a_full_level(gpu_lib):
     """A fully refined periodic level of 2.1 M cells (no CPU oracle run at this size): every
     operation of the iteration is linear and a factor 2 is exact, so doubling r and p doubles phi
