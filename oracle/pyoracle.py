@@ -158,6 +158,30 @@ def godunov_fine_amr(p, igrid, son, nbor, father, ngridmax, ncoarse, uold, unew,
                                interpol_var, interpol_type)
 
 
+def gauss_seidel_mg_fine(ilevel, redstep, safe, igrid, son, nbor, flag2, ngridmax, ncoarse, phi, f):
+    """One colour of gauss_seidel_mg_fine on an AMR level; phi[ncell] updated in place, f = (3, ncell)."""
+    L = lib()
+    L.ora_gauss_seidel_mg_fine.restype = None
+    L.ora_gauss_seidel_mg_fine.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    ig, so, nb, fl = (np.ascontiguousarray(a, np.int32) for a in (igrid, son, nbor, flag2))
+    assert phi.flags.c_contiguous and f.flags.c_contiguous and f.shape[0] == 3
+    L.ora_gauss_seidel_mg_fine(ilevel, 1 if redstep else 0, 1 if safe else 0, len(ig), ig.ctypes.data, so.ctypes.data,
+                               nb.ctypes.data, fl.ctypes.data, ngridmax, ncoarse, phi.ctypes.data, f.ctypes.data)
+
+
+def cmp_residual_mg_fine(ilevel, igrid, son, nbor, flag2, ngridmax, ncoarse, phi, f):
+    """cmp_residual_mg_fine on an AMR level; f[0] (= f(:,1)) updated in place."""
+    L = lib()
+    L.ora_cmp_residual_mg_fine.restype = None
+    L.ora_cmp_residual_mg_fine.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                           C.c_int64, C.c_void_p, C.c_void_p]
+    ig, so, nb, fl = (np.ascontiguousarray(a, np.int32) for a in (igrid, son, nbor, flag2))
+    assert phi.flags.c_contiguous and f.flags.c_contiguous and f.shape[0] == 3
+    L.ora_cmp_residual_mg_fine(ilevel, len(ig), ig.ctypes.data, so.ctypes.data, nb.ctypes.data, fl.ctypes.data, ngridmax,
+                               ncoarse, phi.ctypes.data, f.ctypes.data)
+
+
 def cg_solve(igrid, son, nbor, ngridmax, ncoarse, phi, f, epsilon, itermax=10000):
     """Iteration loop of phi_fine_cg on one level (serial): phi[ncell] and f[3, ncell] (r, p, Ap) are
     updated in place from the state cmp_residual_cg left; returns (iterations, error, error_ini)."""
