@@ -79,7 +79,61 @@ def run_amr(tag, binary, env, lmin, lmax, nstep):
                       "octs_per_level": {k: v for k, v in last.items() if k >= lmin}, "timers_s": rows}), flush=True)
 
 
+GRAV_BLOB = """nregion=2
+region_type(1)='square'
+region_type(2)='square'
+x_center=0.5,0.4
+y_center=0.5,0.55
+z_center=0.5,0.6
+length_x=10.0,0.25
+length_y=10.0,0.25
+length_z=10.0,0.25
+exp_region=10.0,10.0
+d_region=1.0,10.0
+u_region=0.0,0.0
+v_region=0.0,0.0
+p_region=1.0,1.0"""
+
+
+def run_grav(tag, binary, env, level, nstep):
+    """BASELINE config C4 stand-in: uniform periodic level, hydro + self-gravity (multigrid_fine +
+    force_fine every step), 'square' over-density."""
+    nml = rs.sedov3d_namelist(level=level, nstepmax=nstep, foutput=1000, boxlen=1.0, poisson=True, init=GRAV_BLOB,
+                              extra="&POISSON_PARAMS\nepsilon=1d-6\n/\n")
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    t0 = time.time()
+    try:
+        work, out = rs.run_reference(nml, binary=binary, timeout=3000)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    wall = time.time() - t0
+    shutil.rmtree(work, ignore_errors=True)
+    rows = {}
+    for line in out.splitlines():
+        m = re.match(r"^\s*([0-9.]+)\s+([0-9.]+)\s+([a-zA-Z].*?)\s*$", line)
+        if m and "STEP" not in m.group(3):
+            rows[m.group(3)] = float(m.group(1))
+    solves = re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+) Error=\s*(\S+)", out)
+    print(json.dumps({"config": tag, "level": level, "steps": nstep, "wall_s": round(wall, 3),
+                      "vcycles": [int(b) for _, b, _ in solves], "timers_s": rows}), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "grav":
+        level, nstep = int(sys.argv[2]), int(sys.argv[3])
+        which = sys.argv[4] if len(sys.argv) > 4 else "all"
+        ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d")
+        pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch")
+        if which in ("all", "gpu"):
+            run_grav("patched (dense sweep + dense multigrid on the device, arrays staged per call)", pat, {"RAMSES_AMD": "1"}, level, nstep)
+        if which in ("all", "ref"):
+            run_grav("reference (1 core)", ref, {"RAMSES_AMD": "0"}, level, nstep)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "amr":
         lmin, lmax, nstep = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
         which = sys.argv[5] if len(sys.argv) > 5 else "all"
