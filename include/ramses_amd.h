@@ -429,6 +429,13 @@ int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int 
  * The first call loads the level from the host array `uold`; later calls
  * with the same (level, ngrid, array) reuse the device copy.
  * ------------------------------------------------------------------------- */
+/* force_fine(ilevel,icount) -- poisson/force_fine.f90:5-194 with gradient_phi :199-324 -- on the
+ * reference's own arrays (host pointers): f(1:ncell,1:3) of the level's cells from phi, for a fully
+ * refined periodic level of a single-rank run (gravity_type = 0).  The diagnostics of :158-190
+ * (epot_tot, rho_max) stay with the caller. */
+int ramses_amd_force_fine_f90(int ilevel, int ngrid, const int *igrid, const double *xg,
+                              int64_t ngridmax, int64_t ncoarse, int nx_loc, const double *phi, double *f);
+
 /* Page-lock a host array that the staged entry points (…_host/_f90) copy from and to.  The
  * reference allocates uold/unew (hydro/init_hydro.f90:30-32), phi/rho/f (poisson/init_poisson.f90:24-28)
  * and the tree (amr/init_amr.f90:52-55,227-233) once, with fixed ngridmax: their addresses are stable

@@ -925,6 +925,59 @@ int ramses_amd_multigrid_fine_f90(int ilevel, int ngrid, const int *igrid, const
   return 0;
 }
 
+// force_fine(ilevel,icount) on the reference's own arrays (fully refined periodic level of a
+// single-rank run, gravity_type = 0): f(:,1:3) = gradient_phi of phi (poisson/force_fine.f90:
+// 199-324, 5-point differences); the caller keeps the diagnostics of :158-190 (epot, rho_max).
+int ramses_amd_force_fine_f90(int ilevel, int ngrid, const int *igrid, const double *xg,
+                              int64_t ngridmax, int64_t ncoarse, int nx_loc, const double *phi, double *f) {
+  if (!igrid || !xg || !phi || !f) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (nx_loc != 1) return fail(RAMSES_AMD_EUNSUPPORTED, "device force_fine needs a periodic box with nx=ny=nz=1 (got nx_loc=%d)", nx_loc);
+  if (ilevel < 2 || ilevel > 11) return fail(RAMSES_AMD_EINVAL, "level out of range");
+  const int n = 1 << ilevel;
+  const long N = (long)n * n * n;
+  if ((long)ngrid * 8 != N)
+    return fail(RAMSES_AMD_EUNSUPPORTED, "level %d is not fully refined on this rank (ngrid=%d)", ilevel, ngrid);
+  const long ncell = ncoarse + 8 * ngridmax;
+  hipStream_t s = nullptr;
+  HostCtx &H = g_host;
+  static DevBuf phivec, fvec3, bphi, bf;
+#define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipfail(e_, what); } while (0)
+  HCHK(phivec.ensure(sizeof(double) * ncell), "hipMalloc");
+  HCHK(fvec3.ensure(sizeof(double) * 3 * ncell), "hipMalloc");
+  HCHK(bphi.ensure(sizeof(double) * N), "hipMalloc");
+  HCHK(bf.ensure(sizeof(double) * 3 * N), "hipMalloc");
+  HCHK(H.igrid.ensure(sizeof(int) * ngrid), "hipMalloc igrid");
+  HCHK(H.xg.ensure(sizeof(double) * 3 * ngridmax), "hipMalloc xg");
+  HCHK(H.octorg.ensure(sizeof(long) * ngrid), "hipMalloc octorg");
+  HCHK(H.flag.ensure(sizeof(int)), "hipMalloc flag");
+  HCHK(hipMemcpyAsync(phivec.p, phi, sizeof(double) * ncell, hipMemcpyHostToDevice, s), "H2D phi");
+  HCHK(hipMemcpyAsync(fvec3.p, f, sizeof(double) * 3 * ncell, hipMemcpyHostToDevice, s), "H2D f");   // cells off the level keep their values
+  HCHK(hipMemcpyAsync(H.igrid.p, igrid, sizeof(int) * ngrid, hipMemcpyHostToDevice, s), "H2D igrid");
+  HCHK(hipMemcpyAsync(H.xg.p, xg, sizeof(double) * 3 * ngridmax, hipMemcpyHostToDevice, s), "H2D xg");
+  HCHK(hipMemsetAsync(H.flag.p, 0, sizeof(int), s), "memset");
+  const double skip[3] = {0.0, 0.0, 0.0};
+  HCHK(launch_oct_origin(H.igrid.as<int>(), H.xg.as<double>(), ngridmax, ngrid, n, skip, H.octorg.as<long>(), H.flag.as<int>(), s), "oct origin launch");
+  int bad = 0;
+  HCHK(hipMemcpyAsync(&bad, H.flag.p, sizeof(int), hipMemcpyDeviceToHost, s), "D2H flag");
+  HCHK(hipStreamSynchronize(s), "sync");
+  if (bad) return fail(RAMSES_AMD_EINVAL, "%d octs of level %d do not sit on the level lattice", bad, ilevel);
+  g_host.res_valid = false;   // igrid/xg/octorg buffers are shared with the resident level
+  PackArgs A;
+  A.igrid = H.igrid.as<int>(); A.octorg = H.octorg.as<long>();
+  A.ngrid = ngrid; A.n = n; A.nvar = 1;
+  A.ncoarse = ncoarse; A.ngridmax = ngridmax; A.ncell = ncell; A.pitch_var = N;
+  A.brick = bphi.as<double>(); A.cellvec = phivec.as<double>();
+  HCHK(launch_oct_copy(A, true, s), "gather launch");
+  if (int rc = ramses_amd_gradient_phi_brick(ilevel, bphi.as<double>(), bf.as<double>(), s)) return rc;
+  A.nvar = 3;
+  A.brick = bf.as<double>(); A.cellvec = fvec3.as<double>();
+  HCHK(launch_oct_copy(A, false, s), "scatter launch");
+  HCHK(hipMemcpyAsync(f, fvec3.p, sizeof(double) * 3 * ncell, hipMemcpyDeviceToHost, s), "D2H f");
+  HCHK(hipStreamSynchronize(s), "sync");
+#undef HCHK
+  return 0;
+}
+
 // ---------------------------------------------------------------------------
 // Device-resident level: courant_fine, set_unew,
 // godunov_fine and set_uold of a fully refined periodic level without the

@@ -92,6 +92,15 @@ module ramses_amd_iface
        integer(c_int) :: rc
      end function ramses_amd_godunov_fine_amr_f90
 
+     function ramses_amd_force_fine_f90(ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, phi, f) &
+          & bind(C, name='ramses_amd_force_fine_f90') result(rc)
+       import :: c_int, c_int64_t, c_double
+       integer(c_int), value :: ilevel, ngrid, nx_loc
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       integer(c_int) :: igrid(*)
+       real(c_double) :: xg(*), phi(*), f(*)
+       integer(c_int) :: rc
+     end function ramses_amd_force_fine_f90
      function ramses_amd_host_register_dp(p, bytes) bind(C, name='ramses_amd_host_register') result(rc)
        import :: c_int, c_int64_t, c_double
        real(c_double) :: p(*)
