@@ -126,6 +126,19 @@ def _worker(rank, world, pgrid, n, port, ret):
         ok = ok and tr.allreduce(float(rank + 1), "cpu", op="min") == 1.0
         g = tr.allgather(torch.full((2, 3), float(rank)))
         ok = ok and g.shape == (world, 2, 3) and all(bool((g[r] == r).all()) for r in range(world))
+        # the same through an explicit second process group (what bench.py falls back to when the
+        # RCCL self-test fails: a gloo group next to the default one, host-staged tensors)
+        from ramses_amd.transport import DistTransport
+        tr2 = DistTransport(group=dist.new_group(backend="gloo"), staged=True)
+        dec2 = TorchMoverDecomposition(pgrid, rank, n, boxlen=1.0, ng=ng, transport=tr2)
+        lev2 = FakeLevel(n, ng, nvar)
+        lev2.uold[:, ng:ng + n, ng:ng + n, ng:ng + n] = torch.from_numpy(own.copy())
+        dec2.exchange_direct(lev2, lev2.uold, nvar)
+        ok = ok and np.array_equal(lev2.uold.numpy(), exp)
+        ok = ok and tr2.allreduce(float(rank + 1), "cpu", op="max") == float(world)
+        g2 = tr2.allgather(torch.full((3,), float(rank)))
+        ok = ok and g2.shape == (world, 3) and all(bool((g2[r] == r).all()) for r in range(world))
+        tr2.barrier()
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
