@@ -19,13 +19,12 @@ vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: 
 
 
 def _solve(gpu_lib, d, ordered, rho=None, rho_tot=0.0, fact=1.0):
-    it = C.c_int(0)
-    err = (C.c_double * 3)()
-    rc = gpu_lib.ramses_amd_cg_solve_host(d["ilevel"], d["ngrid"], vp(d["igrid"]), vp(d["son"]), vp(d["nbor"]), d["ngridmax"],
-                                          d["ncoarse"], vp(d["phi"]), vp(d["f"]), vp(rho), rho_tot, fact, 8.0 * d["ngrid"],
-                                          d["epsilon"], 10000, ordered, C.byref(it), err)
-    assert rc == 0, gpu_lib.ramses_amd_last_error()
-    return it.value, list(err)
+    """through the host mirror ramses_amd.amr.phi_fine_cg (the C ABI's ramses_amd_cg_solve_host)"""
+    from ramses_amd import amr
+    tree = amr.AmrTree(d["son"], d["nbor"], np.zeros(d["ngridmax"], np.int32), d["ngridmax"], d["ncoarse"])
+    it, e, e_ini, rhs = amr.phi_fine_cg(tree, d["ilevel"], d["igrid"], d["phi"], d["f"], d["epsilon"], ordered=bool(ordered),
+                                        rho=rho, rho_tot=rho_tot, fact=fact)
+    return it, [e, e_ini, rhs]
 
 
 def _load(z, s):
