@@ -429,6 +429,30 @@ int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int 
  * The first call loads the level from the host array `uold`; later calls
  * with the same (level, ngrid, array) reuse the device copy.
  * ------------------------------------------------------------------------- */
+/* ---------------------------------------------------------------------------
+ * Gravity on the device-resident level (first part): the acceleration f(:,1:3)
+ * sits next to the hydro state on the device (loaded from the host array on first use, rewritten by
+ * ramses_amd_force_fine_f90), and the routines of amr_step's gravity branch that touch uold run there:
+ *   ramses_amd_resident_synchro_f90        synchro_hydro_fine(ilevel,dteff,1)  hydro/synchro_hydro_fine.f90:5-136
+ *   ramses_amd_resident_courant_grav_f90   courant_fine with cmpdt's gravity term  hydro/courant_fine.f90:77-85
+ *   ramses_amd_resident_godunov_grav_f90   set_unew + godunov_fine with the predictor's source term
+ *   ramses_amd_resident_set_uold_grav_f90  add_gravity_source_terms + set_uold  hydro/godunov_fine.f90:135-289
+ *   ramses_amd_resident_sync_density_f90   uold(:,1) back to the host for rho_fine (pm/rho_fine.f90:666-800)
+ * ------------------------------------------------------------------------- */
+int ramses_amd_resident_synchro_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                    const int *igrid, const double *xg, int64_t ngridmax,
+                                    int64_t ncoarse, int nx_loc, const double *uold, const double *f, double dteff);
+int ramses_amd_resident_courant_grav_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                         const int *igrid, const double *xg, int64_t ngridmax,
+                                         int64_t ncoarse, int nx_loc, const double *uold, const double *f,
+                                         double dx, double dt_in, double *out4);
+int ramses_amd_resident_godunov_grav_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                         const int *igrid, const double *xg, int64_t ngridmax,
+                                         int64_t ncoarse, int nx_loc, const double *uold, const double *f,
+                                         double dx, double dt);
+int ramses_amd_resident_set_uold_grav_f90(const ramses_amd_hydro_params *p, int ilevel, double dt);
+int ramses_amd_resident_sync_density_f90(double *uold);
+
 /* force_fine(ilevel,icount) -- poisson/force_fine.f90:5-194 with gradient_phi :199-324 -- on the
  * reference's own arrays (host pointers): f(1:ncell,1:3) of the level's cells from phi, for a fully
  * refined periodic level of a single-rank run (gravity_type = 0).  The diagnostics of :158-190

@@ -97,6 +97,11 @@ SYMBOLS = [
     ("ramses_amd_mgamr_interpolate", _i, [_i]),
     ("ramses_amd_mgamr_end", _i, []),
     ("ramses_amd_host_register", _i, [_vp, _i64]),
+    ("ramses_amd_resident_synchro_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _d]),
+    ("ramses_amd_resident_courant_grav_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _d, _d, _vp]),
+    ("ramses_amd_resident_godunov_grav_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _d, _d]),
+    ("ramses_amd_resident_set_uold_grav_f90", _i, [_PP, _i, _d]),
+    ("ramses_amd_resident_sync_density_f90", _i, [_vp]),
     ("ramses_amd_force_fine_f90", _i, [_i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp]),
     ("ramses_amd_cg_solve_host", _i, [_i, _i, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _i, _i, _vp, _vp]),
     ("ramses_amd_resident_courant_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _d, _vp]),

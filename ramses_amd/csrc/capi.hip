@@ -650,6 +650,7 @@ struct HostCtx {
   // device-resident level (ramses_amd_resident_*): the level brick in bold is
   // the current hydro state; the host array is stale until synced
   bool res_valid = false, res_host_stale = false, res_new_ready = false;
+  bool res_grav_valid = false;   // bf holds the acceleration f(:,1:3) of the resident level
   int res_level = 0, res_ngrid = 0, res_nvar = 0;
   long res_ncell = 0, res_ncoarse = 0, res_ngridmax = 0;
   const double *res_host_uold = nullptr;
@@ -961,16 +962,27 @@ int ramses_amd_force_fine_f90(int ilevel, int ngrid, const int *igrid, const dou
   HCHK(hipMemcpyAsync(&bad, H.flag.p, sizeof(int), hipMemcpyDeviceToHost, s), "D2H flag");
   HCHK(hipStreamSynchronize(s), "sync");
   if (bad) return fail(RAMSES_AMD_EINVAL, "%d octs of level %d do not sit on the level lattice", bad, ilevel);
-  g_host.res_valid = false;   // igrid/xg/octorg buffers are shared with the resident level
+  // igrid/xg/octorg are shared with the resident level: the same level rewrites them with the
+  // same contents, anything else ends the residency
+  const bool resident = H.res_valid && H.res_level == ilevel && H.res_ngrid == ngrid && H.res_ncell == ncell;
+  if (!resident) H.res_valid = false;
+  double *d_f = bf.as<double>();
+  if (resident) {
+    // the acceleration of the resident level is rewritten in place (synchro_hydro_fine,
+    // courant_fine, godunov_fine and set_uold read it there)
+    HCHK(H.bf.ensure(sizeof(double) * 3 * N), "hipMalloc f brick");
+    d_f = H.bf.as<double>();
+  }
   PackArgs A;
   A.igrid = H.igrid.as<int>(); A.octorg = H.octorg.as<long>();
   A.ngrid = ngrid; A.n = n; A.nvar = 1;
   A.ncoarse = ncoarse; A.ngridmax = ngridmax; A.ncell = ncell; A.pitch_var = N;
   A.brick = bphi.as<double>(); A.cellvec = phivec.as<double>();
   HCHK(launch_oct_copy(A, true, s), "gather launch");
-  if (int rc = ramses_amd_gradient_phi_brick(ilevel, bphi.as<double>(), bf.as<double>(), s)) return rc;
+  if (int rc = ramses_amd_gradient_phi_brick(ilevel, bphi.as<double>(), d_f, s)) return rc;
+  if (resident) H.res_grav_valid = true;
   A.nvar = 3;
-  A.brick = bf.as<double>(); A.cellvec = fvec3.as<double>();
+  A.brick = d_f; A.cellvec = fvec3.as<double>();
   HCHK(launch_oct_copy(A, false, s), "scatter launch");
   HCHK(hipMemcpyAsync(f, fvec3.p, sizeof(double) * 3 * ncell, hipMemcpyDeviceToHost, s), "D2H f");
   HCHK(hipStreamSynchronize(s), "sync");
@@ -1030,7 +1042,7 @@ static int resident_ensure(const ramses_amd_hydro_params *p, int ilevel, int ngr
   A.ncoarse = ncoarse; A.ngridmax = ngridmax; A.ncell = ncell; A.pitch_var = N;
   A.brick = H.bold.as<double>(); A.cellvec = H.uold.as<double>();
   HCHK(launch_oct_copy(A, true, s), "gather launch");
-  H.res_valid = true; H.res_host_stale = false; H.res_new_ready = false;
+  H.res_valid = true; H.res_host_stale = false; H.res_new_ready = false; H.res_grav_valid = false;
   H.res_level = ilevel; H.res_ngrid = ngrid; H.res_nvar = nvar; H.res_ncell = ncell;
   H.res_ncoarse = ncoarse; H.res_ngridmax = ngridmax; H.res_host_uold = uold;
   return 0;
@@ -1103,6 +1115,115 @@ int ramses_amd_resident_sync_host_f90(double *uold) {
   HCHK(hipStreamSynchronize(s), "sync");
   H.res_host_stale = false;
   return 0;
+}
+
+// ---- gravity on the resident level (first part) -------------------------
+// The acceleration lives in bf next to the hydro state: loaded from the host array on first use,
+// rewritten by ramses_amd_force_fine_f90 every step.
+static int resident_ensure_grav(const double *f) {
+  HostCtx &H = g_host;
+  if (H.res_grav_valid) return 0;
+  if (!f) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  const int n = 1 << H.res_level;
+  const long N = (long)n * n * n;
+  hipStream_t s = nullptr;
+  HCHK(H.fvec.ensure(sizeof(double) * 3 * H.res_ncell), "hipMalloc f");
+  HCHK(H.bf.ensure(sizeof(double) * 3 * N), "hipMalloc f brick");
+  HCHK(hipMemcpyAsync(H.fvec.p, f, sizeof(double) * 3 * H.res_ncell, hipMemcpyHostToDevice, s), "H2D f");
+  PackArgs G;
+  G.igrid = H.igrid.as<int>(); G.octorg = H.octorg.as<long>();
+  G.ngrid = H.res_ngrid; G.n = n; G.nvar = 3;
+  G.ncoarse = H.res_ncoarse; G.ngridmax = H.res_ngridmax; G.ncell = H.res_ncell; G.pitch_var = N;
+  G.brick = H.bf.as<double>(); G.cellvec = H.fvec.as<double>();
+  HCHK(launch_oct_copy(G, true, s), "gather launch");
+  H.res_grav_valid = true;
+  return 0;
+}
+
+// synchro_hydro_fine(ilevel,dteff,1) (hydro/synchro_hydro_fine.f90:5-136) on the resident level
+int ramses_amd_resident_synchro_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                    const int *igrid, const double *xg, int64_t ngridmax,
+                                    int64_t ncoarse, int nx_loc, const double *uold, const double *f, double dteff) {
+  if (int rc = resident_ensure(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, uold)) return rc;
+  if (int rc = resident_ensure_grav(f)) return rc;
+  HostCtx &H = g_host;
+  const int n = 1 << ilevel;
+  const long N = (long)n * n * n;
+  if (H.res_new_ready) return fail(RAMSES_AMD_EINVAL, "synchro_hydro_fine between godunov_fine and set_uold");
+  hipError_t e = launch_synchro_hydro(H.bold.as<double>(), H.bf.as<double>(), N, dteff, p->smallr, nullptr);
+  if (e != hipSuccess) return hipfail(e, "synchro_hydro launch");
+  H.res_host_stale = true;
+  return 0;
+}
+
+// courant_fine with the gravity term of cmpdt (hydro/courant_fine.f90:77-85)
+int ramses_amd_resident_courant_grav_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                         const int *igrid, const double *xg, int64_t ngridmax,
+                                         int64_t ncoarse, int nx_loc, const double *uold, const double *f,
+                                         double dx, double dt_in, double *out4) {
+  if (!out4) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (int rc = resident_ensure(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, uold)) return rc;
+  if (int rc = resident_ensure_grav(f)) return rc;
+  HostCtx &H = g_host;
+  const int n = 1 << ilevel;
+  hipStream_t s = nullptr;
+  ramses_amd_brick b;
+  ramses_amd_brick_dense(&b, n, n, n, 0);
+  if (int rc = ramses_amd_courant_init(p, dx, H.red.as<double>(), s)) return rc;
+  if (int rc = ramses_amd_courant_brick(p, &b, H.bold.as<double>(), H.bf.as<double>(), dx, H.red.as<double>(), s)) return rc;
+  HCHK(hipMemcpyAsync(out4, H.red.p, sizeof(double) * 4, hipMemcpyDeviceToHost, s), "D2H courant");
+  HCHK(hipStreamSynchronize(s), "sync");
+  if (dt_in < out4[0]) out4[0] = dt_in;
+  return 0;
+}
+
+// set_unew + godunov_fine with the gravity predictor (godfine1 :637-647, ctoprim)
+int ramses_amd_resident_godunov_grav_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                         const int *igrid, const double *xg, int64_t ngridmax,
+                                         int64_t ncoarse, int nx_loc, const double *uold, const double *f,
+                                         double dx, double dt) {
+  if (int rc = resident_ensure(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, uold)) return rc;
+  if (int rc = resident_ensure_grav(f)) return rc;
+  HostCtx &H = g_host;
+  const int n = 1 << ilevel;
+  ramses_amd_brick b;
+  ramses_amd_brick_dense(&b, n, n, n, 0);
+  if (int rc = ramses_amd_godunov_brick(p, &b, H.bold.as<double>(), H.bf.as<double>(), H.bnew.as<double>(), dx, dt, nullptr)) return rc;
+  H.res_new_ready = true;
+  return 0;
+}
+
+// set_uold with add_gravity_source_terms (hydro/godunov_fine.f90:160-162,237-289) before the swap
+int ramses_amd_resident_set_uold_grav_f90(const ramses_amd_hydro_params *p, int ilevel, double dt) {
+  HostCtx &H = g_host;
+  if (!p) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (!H.res_valid || H.res_level != ilevel) return fail(RAMSES_AMD_EINVAL, "set_uold: level %d is not resident", ilevel);
+  if (!H.res_new_ready) return fail(RAMSES_AMD_EINVAL, "set_uold: no godunov_fine result pending on level %d", ilevel);
+  if (!H.res_grav_valid) return fail(RAMSES_AMD_EINVAL, "set_uold: no acceleration on the device for level %d", ilevel);
+  const int n = 1 << ilevel;
+  const long N = (long)n * n * n;
+  hipError_t e = launch_add_gravity_source(H.bnew.as<double>(), H.bold.as<double>(), H.bf.as<double>(), N, dt, p->smallr, nullptr);
+  if (e != hipSuccess) return hipfail(e, "add_gravity_source launch");
+  return ramses_amd_resident_set_uold_f90(ilevel);
+}
+
+// the density of the resident level back into uold(:,1) (rho_fine reads nothing else of uold)
+int ramses_amd_resident_sync_density_f90(double *uold) {
+  HostCtx &H = g_host;
+  if (!H.res_valid || !H.res_host_stale) return 0;
+  if (uold != H.res_host_uold) return fail(RAMSES_AMD_EINVAL, "sync_density: not the array the level was loaded from");
+  const int n = 1 << H.res_level;
+  const long N = (long)n * n * n;
+  hipStream_t s = nullptr;
+  PackArgs A;
+  A.igrid = H.igrid.as<int>(); A.octorg = H.octorg.as<long>();
+  A.ngrid = H.res_ngrid; A.n = n; A.nvar = 1;
+  A.ncoarse = H.res_ncoarse; A.ngridmax = H.res_ngridmax; A.ncell = H.res_ncell; A.pitch_var = N;
+  A.brick = H.bold.as<double>(); A.cellvec = H.uold.as<double>();
+  HCHK(launch_oct_copy(A, false, s), "scatter launch");
+  HCHK(hipMemcpyAsync(uold, H.uold.p, sizeof(double) * H.res_ncell, hipMemcpyDeviceToHost, s), "D2H density");
+  HCHK(hipStreamSynchronize(s), "sync");
+  return 0;   // the other variables of the host array stay stale
 }
 
 // ---------------------------------------------------------------------------

@@ -249,4 +249,68 @@ hipError_t launch_boundary(const BoundaryArgs &A, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Gravity source terms on the device-resident level (NDIM = 3; variables rho, rho*u, rho*v,
+// rho*w, E at u[0..4][N], passive scalars untouched).  Operation order is the reference's
+// (this unit is compiled with -ffp-contract=off).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void synchro_hydro_kernel(double *__restrict__ u, const double *__restrict__ f, long N,
+                                                             double dteff, double smallr) {
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (long)gridDim.x * blockDim.x) {
+    const double d = fmax(u[c], smallr);
+    double m[3] = {u[N + c], u[2 * N + c], u[3 * N + c]};
+    // remove the kinetic energy (:65-73)
+    double pp = u[4 * N + c];
+#pragma unroll
+    for (int k = 0; k < 3; k++) pp = pp - 0.5 * (m[k] * m[k]) / d;
+    // momentum kick (:76-100)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      m[k] = m[k] + d * f[(long)k * N + c] * dteff;
+      u[(long)(k + 1) * N + c] = m[k];
+    }
+    // put the kinetic energy of the new momenta back (:103-113)
+#pragma unroll
+    for (int k = 0; k < 3; k++) pp = pp + 0.5 * (m[k] * m[k]) / d;
+    u[4 * N + c] = pp;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_gravity_source_kernel(double *__restrict__ un, const double *__restrict__ uo,
+                                                                  const double *__restrict__ f, long N, double dt, double smallr) {
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (long)gridDim.x * blockDim.x) {
+    const double d = fmax(un[c], smallr);
+    double u = un[N + c] / d, v = un[2 * N + c] / d, w = un[3 * N + c] / d;
+    double e_kin = 0.5 * d * (u * u + v * v + w * w);
+    const double e_prim = un[4 * N + c] - e_kin;
+    const double d_old = fmax(uo[c], smallr);
+    const double req = 0.0;                                  // strict_equilibrium = 0
+    const double fact = (d_old - req) / d * 0.5 * dt;
+    u = u + f[c] * fact;
+    un[N + c] = d * u;
+    v = v + f[N + c] * fact;
+    un[2 * N + c] = d * v;
+    w = w + f[2 * N + c] * fact;
+    un[3 * N + c] = d * w;
+    e_kin = 0.5 * d * (u * u + v * v + w * w);
+    un[4 * N + c] = e_prim + e_kin;
+  }
+}
+
+static inline int misc_grid(long work) {
+  long g = (work + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 8192) g = 8192;
+  return (int)g;
+}
+hipError_t launch_synchro_hydro(double *u, const double *f, long N, double dteff, double smallr, hipStream_t s) {
+  hipLaunchKernelGGL(synchro_hydro_kernel, dim3(misc_grid(N)), dim3(256), 0, s, u, f, N, dteff, smallr);
+  return hipGetLastError();
+}
+hipError_t launch_add_gravity_source(double *unew, const double *uold, const double *f, long N, double dt, double smallr,
+                                     hipStream_t s) {
+  hipLaunchKernelGGL(add_gravity_source_kernel, dim3(misc_grid(N)), dim3(256), 0, s, unew, uold, f, N, dt, smallr);
+  return hipGetLastError();
+}
+
 }  // namespace ramses_amd

@@ -54,4 +54,13 @@ struct BoundaryArgs {
 };
 hipError_t launch_boundary(const BoundaryArgs &A, hipStream_t s);
 
+// gravity source terms on a dense level brick u[nvar][N] with the acceleration f[3][N]
+// synchydrofine1 (hydro/synchro_hydro_fine.f90:45-136, which_force = 1): momentum kick by dteff,
+// total energy carried along through the internal energy
+hipError_t launch_synchro_hydro(double *u, const double *f, long N, double dteff, double smallr, hipStream_t s);
+// add_gravity_source_terms (hydro/godunov_fine.f90:237-289): half a time step on unew, the density
+// ratio taken against uold
+hipError_t launch_add_gravity_source(double *unew, const double *uold, const double *f, long N, double dt, double smallr,
+                                     hipStream_t s);
+
 }  // namespace ramses_amd

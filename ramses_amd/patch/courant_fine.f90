@@ -15,6 +15,7 @@
 subroutine courant_fine(ilevel)
   use amr_commons
   use hydro_commons
+  use poisson_commons
   use ramses_amd_iface
   implicit none
   integer::ilevel
@@ -35,8 +36,14 @@ subroutine courant_fine(ilevel)
   scale=boxlen/dble(nx_loc)
   dx=0.5D0**ilevel*scale
 
-  rc=ramses_amd_resident_courant_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
-       & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,dx,dtnew(ilevel),out4)
+  if(poisson)then
+     ! cmpdt with the gravity term (hydro/courant_fine.f90:77-85)
+     rc=ramses_amd_resident_courant_grav_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+          & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,f,dx,dtnew(ilevel),out4)
+  else
+     rc=ramses_amd_resident_courant_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+          & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,dx,dtnew(ilevel),out4)
+  end if
   if(rc/=0)call ramses_amd_fatal('courant_fine')
 
   ! same bookkeeping as hydro/courant_fine.f90:150-156 (single rank)

@@ -41,9 +41,16 @@ subroutine set_uold(ilevel)
   implicit none
   integer::ilevel
   integer::rc
+  type(ramses_amd_hydro_params)::p
   if(numbtot(1,ilevel)==0)return
   if(ramses_amd_resident())then
-     rc=ramses_amd_resident_set_uold_f90(ilevel)
+     if(poisson)then
+        ! add_gravity_source_terms (:160-162,237-289) on the new state, then the swap
+        call ramses_amd_fill_hydro_params(p)
+        rc=ramses_amd_resident_set_uold_grav_f90(p,ilevel,dtnew(ilevel))
+     else
+        rc=ramses_amd_resident_set_uold_f90(ilevel)
+     end if
      if(rc/=0)call ramses_amd_fatal('set_uold')
      return
   end if
@@ -121,8 +128,13 @@ subroutine godunov_fine(ilevel)
      end if
   else if(ramses_amd_resident())then
      ! state already on the device (loaded by courant_fine or here); unew stays there
-     rc=ramses_amd_resident_godunov_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
-          & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,dx,dtnew(ilevel))
+     if(poisson)then
+        rc=ramses_amd_resident_godunov_grav_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+             & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,f,dx,dtnew(ilevel))
+     else
+        rc=ramses_amd_resident_godunov_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+             & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,dx,dtnew(ilevel))
+     end if
   else if(poisson)then
      has_f=1
      rc=ramses_amd_godunov_fine_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &

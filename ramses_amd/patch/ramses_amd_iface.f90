@@ -214,6 +214,60 @@ module ramses_amd_iface
        real(c_double) :: uold(*)
        integer(c_int) :: rc
      end function ramses_amd_resident_sync_host_f90
+     ! ---- gravity on the resident level ----
+     function ramses_amd_resident_synchro_f90(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, &
+          & uold, f, dteff) bind(C, name='ramses_amd_resident_synchro_f90') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_int64_t, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ilevel, ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: xg(*)
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       integer(c_int), value :: nx_loc
+       real(c_double) :: uold(*), f(*)
+       real(c_double), value :: dteff
+       integer(c_int) :: rc
+     end function ramses_amd_resident_synchro_f90
+     function ramses_amd_resident_courant_grav_f90(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, &
+          & uold, f, dx, dt_in, out4) bind(C, name='ramses_amd_resident_courant_grav_f90') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_int64_t, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ilevel, ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: xg(*)
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       integer(c_int), value :: nx_loc
+       real(c_double) :: uold(*), f(*)
+       real(c_double), value :: dx, dt_in
+       real(c_double) :: out4(4)
+       integer(c_int) :: rc
+     end function ramses_amd_resident_courant_grav_f90
+     function ramses_amd_resident_godunov_grav_f90(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, &
+          & uold, f, dx, dt) bind(C, name='ramses_amd_resident_godunov_grav_f90') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_int64_t, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ilevel, ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: xg(*)
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       integer(c_int), value :: nx_loc
+       real(c_double) :: uold(*), f(*)
+       real(c_double), value :: dx, dt
+       integer(c_int) :: rc
+     end function ramses_amd_resident_godunov_grav_f90
+     function ramses_amd_resident_set_uold_grav_f90(p, ilevel, dt) &
+          & bind(C, name='ramses_amd_resident_set_uold_grav_f90') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ilevel
+       real(c_double), value :: dt
+       integer(c_int) :: rc
+     end function ramses_amd_resident_set_uold_grav_f90
+     function ramses_amd_resident_sync_density_f90(uold) bind(C, name='ramses_amd_resident_sync_density_f90') result(rc)
+       import :: c_int, c_double
+       real(c_double) :: uold(*)
+       integer(c_int) :: rc
+     end function ramses_amd_resident_sync_density_f90
   end interface
 
   logical, save :: ramses_amd_checked = .false.
@@ -338,6 +392,7 @@ contains
   logical function ramses_amd_resident()
     use amr_commons
     use hydro_parameters
+    use poisson_parameters, only: gravity_type
     character(len=16) :: val
     integer :: stat
     if (.not. ramses_amd_res_checked) then
@@ -347,7 +402,17 @@ contains
           if (trim(val) == '0') ramses_amd_res_on = .false.
        end if
        if (ncpu > 1 .or. levelmin /= nlevelmax .or. nboundary > 0) ramses_amd_res_on = .false.
-       if (.not. hydro .or. poisson .or. pic .or. rt .or. cooling .or. star .or. sink .or. stellar) ramses_amd_res_on = .false.
+       if (.not. hydro .or. pic .or. rt .or. cooling .or. star .or. sink .or. stellar) ramses_amd_res_on = .false.
+       ! with self-gravity the level stays resident too (synchro_hydro_fine, the gravity terms of
+       ! courant_fine / godunov_fine / set_uold and force_fine run on the device, rho_fine gets the
+       ! density back); RAMSES_AMD_RESIDENT_GRAV=0 keeps such runs on the staging path
+       if (poisson) then
+          call get_environment_variable('RAMSES_AMD_RESIDENT_GRAV', val, status=stat)
+          if (stat == 0) then
+             if (trim(val) == '0') ramses_amd_res_on = .false.
+          end if
+          if (gravity_type > 0 .or. cosmo) ramses_amd_res_on = .false.
+       end if
        if (tracer .or. MC_tracer .or. clumpfind .or. lightcone .or. movie .or. aton) ramses_amd_res_on = .false.
        if (static .or. static_gas .or. neq_chem .or. barotropic_eos .or. isothermal .or. metal) ramses_amd_res_on = .false.
        if (difmag > 0.0d0) ramses_amd_res_on = .false.

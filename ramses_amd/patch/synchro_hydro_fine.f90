@@ -1,0 +1,46 @@
+!==============================================================================
+! synchro_hydro_fine.f90 of the ramses_amd patch directory.
+!
+! Shadows hydro/synchro_hydro_fine.f90 (synchro_hydro_fine -> *_reference by
+! #define + #include; synchydrofine1 stays the reference's).  While the level is
+! device-resident (ramses_amd_iface: ramses_amd_resident) the gravity kick of the
+! momenta and the energy runs on the resident brick; otherwise the reference.
+!==============================================================================
+#define synchro_hydro_fine synchro_hydro_fine_reference
+#include "hydro/synchro_hydro_fine.f90"
+#undef synchro_hydro_fine
+
+subroutine synchro_hydro_fine(ilevel,dteff,which_force)
+  use amr_commons
+  use hydro_commons
+  use poisson_commons
+  use ramses_amd_iface
+  implicit none
+  integer::ilevel
+  real(dp)::dteff
+  integer::which_force !gravity=1, turbulence=2
+  !--------------------------------------------------------------------------
+  ! Same contract as the reference (hydro/synchro_hydro_fine.f90:5-40): uold of
+  ! the level's cells receives rho*f*dteff on the momenta, the total energy
+  ! follows (internal energy unchanged).
+  !--------------------------------------------------------------------------
+  type(ramses_amd_hydro_params)::p
+  integer::rc,nx_loc
+
+  if(.not.poisson)return
+  if(numbtot(1,ilevel)==0)return
+  if(which_force/=1.or..not.ramses_amd_resident())then
+     call synchro_hydro_fine_reference(ilevel,dteff,which_force)
+     return
+  end if
+  if(verbose)write(*,111)ilevel
+
+  call ramses_amd_fill_hydro_params(p)
+  nx_loc=icoarse_max-icoarse_min+1
+  rc=ramses_amd_resident_synchro_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+       & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,f,dteff)
+  if(rc/=0)call ramses_amd_fatal('synchro_hydro_fine')
+
+111 format('   Entering synchro_hydro_fine (MI355X) for level',i2)
+
+end subroutine synchro_hydro_fine

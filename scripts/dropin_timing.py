@@ -130,7 +130,8 @@ if __name__ == "__main__":
         ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d")
         pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch")
         if which in ("all", "gpu"):
-            run_grav("patched (dense sweep + dense multigrid on the device, arrays staged per call)", pat, {"RAMSES_AMD": "1"}, level, nstep)
+            run_grav("patched, level and acceleration resident on the GPU", pat, {"RAMSES_AMD": "1", "RAMSES_AMD_RESIDENT_GRAV": "1"}, level, nstep)
+            run_grav("patched, arrays staged per call", pat, {"RAMSES_AMD": "1", "RAMSES_AMD_RESIDENT_GRAV": "0"}, level, nstep)
         if which in ("all", "ref"):
             run_grav("reference (1 core)", ref, {"RAMSES_AMD": "0"}, level, nstep)
         sys.exit(0)

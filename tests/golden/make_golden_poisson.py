@@ -64,6 +64,18 @@ def main():
                                           float(m.group(2)), float(m.group(3))])
         print(key, "iters", m.group(2), "err", m.group(3), "rho_tot", snap["info"]["rho_tot"])
         shutil.rmtree(work)
+    # three coarse steps of the last case (the gravity branch of amr_step three times over:
+    # synchro_hydro_fine with the old and the new force, courant_fine/godunov_fine/set_uold with gravity)
+    key, level, boxlen, eps, blob = CASES[-1]
+    nml = rs.sedov3d_namelist(level=level, nstepmax=4, foutput=3, boxlen=boxlen, poisson=True,
+                              init=BLOB.format(**blob), extra="&POISSON_PARAMS\nepsilon=%s\n/\n" % eps)
+    work, out = rs.run_reference(nml, binary=binary)
+    snap = rs.load_uniform_level(os.path.join(work, "output_00002"), level, with_grav=True)
+    arrays[key + "_s3_grav"] = snap["grav"]
+    arrays[key + "_s3_prim"] = snap["prim"]
+    arrays[key + "_s3_iters"] = np.array([int(b) for _, b, _ in re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+) Error=\s*(\S+)", out)])
+    print(key, "3 steps: V-cycles per solve", arrays[key + "_s3_iters"])
+    shutil.rmtree(work)
     np.savez_compressed(os.path.join(OUT, "poisson_ref_runs.npz"), **arrays)
 
 

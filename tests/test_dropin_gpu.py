@@ -192,3 +192,43 @@ def test_patched_program_self_gravity_reproduces_goldens(gpu_lib, case):
         assert np.array_equal(snap["prim"], z[key + "_prim2"])
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+@pytest.mark.parametrize("resident_grav", ["0", "1"])
+def test_patched_program_self_gravity_three_steps(gpu_lib, resident_grav):
+    """Three coarse steps of hydro + self-gravity on a uniform 32^3 level through the patched
+    reference program: the gravity branch of amr_step three times over (synchro_hydro_fine with the
+    old and the new force, multigrid_fine, force_fine, courant_fine / godunov_fine / set_uold with
+    gravity).  resident_grav = 0: arrays staged around every device call; 1
+    (RAMSES_AMD_RESIDENT_GRAV=1): the level and its acceleration stay on the GPU, rho_fine gets
+    the density back.  Either way the snapshot equals the untouched reference bit for bit."""
+    if not os.path.exists(PATCHED):
+        pytest.skip("oracle/_ref/ramses3d_patch not built")
+    import importlib.util
+    import re
+    from oracle import ramses_snapshot as rs
+    spec = importlib.util.spec_from_file_location("mkp", os.path.join(ROOT, "tests", "golden", "make_golden_poisson.py"))
+    mkp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mkp)
+    key, level, boxlen, eps, blob = mkp.CASES[-1]
+    z = np.load(os.path.join(ROOT, "tests", "golden", "poisson_ref_runs.npz"))
+    nml = rs.sedov3d_namelist(level=level, nstepmax=4, foutput=3, boxlen=boxlen, poisson=True,
+                              init=mkp.BLOB.format(**blob), extra="&POISSON_PARAMS\nepsilon=%s\n/\n" % eps)
+    os.environ["RAMSES_AMD"] = "1"
+    os.environ["RAMSES_AMD_RESIDENT_GRAV"] = resident_grav
+    try:
+        work, out = rs.run_reference(nml, binary=PATCHED)
+    finally:
+        os.environ.pop("RAMSES_AMD_RESIDENT_GRAV", None)
+    try:
+        assert ("stays resident on the GPU" in out) == (resident_grav == "1")
+        iters = np.array([int(b) for _, b, _ in re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+) Error=\s*(\S+)", out)])
+        assert np.array_equal(iters, z[key + "_s3_iters"])
+        snap = rs.load_uniform_level(os.path.join(work, "output_00002"), level, with_grav=True)
+        gold = z[key + "_s3_grav"]
+        gold = gold[1:] if gold.shape[0] == 5 else gold          # the golden run also wrote rho (its own -DOUTPUT_PARTICLE_DENSITY)
+        got = snap["grav"][1:] if snap["grav"].shape[0] == 5 else snap["grav"]
+        assert np.array_equal(got, gold), np.abs(got - gold).max()                      # phi, f(1:3)
+        assert np.array_equal(snap["prim"], z[key + "_s3_prim"]), np.abs(snap["prim"] - z[key + "_s3_prim"]).max()
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
