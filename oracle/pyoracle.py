@@ -182,6 +182,25 @@ def cmp_residual_mg_fine(ilevel, igrid, son, nbor, flag2, ngridmax, ncoarse, phi
                                ncoarse, phi.ctypes.data, f.ctypes.data)
 
 
+def synchro_hydro(u, f, dteff, smallr=1e-10):
+    """synchro_hydro_fine(ilevel,dteff,1) on a dense brick u[nvar,...] with f[3,...]: in place."""
+    assert u.flags.c_contiguous and f.flags.c_contiguous and u.dtype == np.float64 and f.dtype == np.float64
+    L = lib()
+    L.ora_synchro_hydro.restype = None
+    L.ora_synchro_hydro.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double]
+    L.ora_synchro_hydro(u.ctypes.data, f.ctypes.data, u[0].size, dteff, smallr)
+
+
+def add_gravity_source(unew, uold, f, dt, smallr=1e-10):
+    """add_gravity_source_terms on dense bricks: unew updated in place."""
+    for a in (unew, uold, f):
+        assert a.flags.c_contiguous and a.dtype == np.float64
+    L = lib()
+    L.ora_add_gravity_source.restype = None
+    L.ora_add_gravity_source.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double]
+    L.ora_add_gravity_source(unew.ctypes.data, uold.ctypes.data, f.ctypes.data, unew[0].size, dt, smallr)
+
+
 def cg_solve(igrid, son, nbor, ngridmax, ncoarse, phi, f, epsilon, itermax=10000):
     """Iteration loop of phi_fine_cg on one level (serial): phi[ncell] and f[3, ncell] (r, p, Ap) are
     updated in place from the state cmp_residual_cg left; returns (iterations, error, error_ini)."""

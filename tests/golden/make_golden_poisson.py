@@ -67,13 +67,20 @@ def main():
     # three coarse steps of the last case (the gravity branch of amr_step three times over:
     # synchro_hydro_fine with the old and the new force, courant_fine/godunov_fine/set_uold with gravity)
     key, level, boxlen, eps, blob = CASES[-1]
-    nml = rs.sedov3d_namelist(level=level, nstepmax=4, foutput=3, boxlen=boxlen, poisson=True,
+    nml = rs.sedov3d_namelist(level=level, nstepmax=4, foutput=1, boxlen=boxlen, poisson=True,
                               init=BLOB.format(**blob), extra="&POISSON_PARAMS\nepsilon=%s\n/\n" % eps)
     work, out = rs.run_reference(nml, binary=binary)
-    snap = rs.load_uniform_level(os.path.join(work, "output_00002"), level, with_grav=True)
+    snap = rs.load_uniform_level(os.path.join(work, "output_00004"), level, with_grav=True)   # after 3 steps
     arrays[key + "_s3_grav"] = snap["grav"]
     arrays[key + "_s3_prim"] = snap["prim"]
     arrays[key + "_s3_iters"] = np.array([int(b) for _, b, _ in re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+) Error=\s*(\S+)", out)])
+    # the multigrid source of each of the three steps: rho_fine's hydro deposit (multipole_fine +
+    # cic_from_multipole, pm/rho_fine.f90:666-891) is NOT the cell density bit for bit -- the mass of
+    # a cell is CIC-deposited at its centre of mass (m*x)/m -- and it stays the reference's host code
+    steps = [rs.load_uniform_level(os.path.join(work, "output_%05d" % k), level, with_grav=True) for k in (2, 3, 4)]
+    arrays[key + "_s3_rho"] = np.stack([sn["grav"][0] for sn in steps])
+    # rho_tot is recomputed by rho_fine every step from the summed multipole (:90-100): last bits move
+    arrays[key + "_s3_rho_tot"] = np.array([sn["info"]["rho_tot"] for sn in steps])
     print(key, "3 steps: V-cycles per solve", arrays[key + "_s3_iters"])
     shutil.rmtree(work)
     np.savez_compressed(os.path.join(OUT, "poisson_ref_runs.npz"), **arrays)
