@@ -1,0 +1,145 @@
+/* oracle/rho_fine_oracle.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * CPU restatement of rho_fine's hydro deposit on one level of a periodic nx=ny=nz=1 box (3-D, no
+ * particles, every cell of the level a leaf), in the reference's loop order:
+ *   rho_fine              pm/rho_fine.f90:5-240     (multipole reset, level loop, rho_tot :176-183)
+ *   multipole_fine        :666-800                  (mass and mass*position of every leaf cell into
+ *                                                    unew(:,1:4), the reference's scratch)
+ *   cic_from_multipole    :805-870, cic_cell :875-1130  (the mass of a cell is CIC-deposited at its
+ *                                                    centre of mass (m*x)/m: not the cell density bit
+ *                                                    for bit once rounding moves that point)
+ *   get3cubefather        amr/nbors_utils.f90:5-194 (as x,y,z steps through son(nbor))
+ * Pinned by tests/test_rho_fine_oracle.py against dumps of the unmodified reference
+ * (oracle/dump_patch/rho_fine.f90 -> tests/golden/rho_fine_ref.npz).
+ *
+ * Arrays are the reference's: cell = ncoarse + ind*ngridmax + igrid (1-based igrid, ind 0..7),
+ * xg = (3, ngridmax), nbor = (6, ngridmax), unew = (4, ncell) scratch. */
+#include <stdint.h>
+#include <stdlib.h>
+
+static double dmax(double a, double b) { return a > b ? a : b; }
+
+typedef struct {
+  const int *son, *nbor;
+  int64_t ncoarse, ngridmax;
+} tree_t;
+
+/* same-level neighbour of cell c (1-based) in direction dir (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z); 0 if the
+ * neighbouring oct does not exist */
+static int64_t nbor_cell(const tree_t *T, int64_t c, int dir) {
+  const int pos = (int)((c - T->ncoarse - 1) / T->ngridmax);
+  const int64_t g = c - T->ncoarse - (int64_t)pos * T->ngridmax;
+  const int axis = dir >> 1, up = dir & 1;
+  const int bit = (pos >> axis) & 1;
+  if (bit != up) return c + (up ? 1 : -1) * ((int64_t)(1 << axis) * T->ngridmax);
+  const int nb = T->nbor[(int64_t)dir * T->ngridmax + g - 1];
+  const int g2 = T->son[nb - 1];
+  if (g2 == 0) return 0;
+  return T->ncoarse + (int64_t)(pos ^ (1 << axis)) * T->ngridmax + g2;
+}
+
+void ora_rho_fine_hydro(int ilevel, int levelmin, int nvector, int ngrid_tot, const int *igrid, const double *xg,
+                        const int *son, const int *nbor, const int *father, int64_t ngridmax, int64_t ncoarse,
+                        double boxlen, double smallr, const double *dens, double *unew, double *rho,
+                        double *multipole, double *rho_tot) {
+  const int64_t ncell = ncoarse + 8 * ngridmax;
+  tree_t T = {son, nbor, ncoarse, ngridmax};
+  double dx = 1.0;
+  for (int l = 0; l < ilevel; l++) dx *= 0.5;
+  const double scale = boxlen;                 /* nx_loc = 1, skip_loc = 0 */
+  const double dx_loc = dx * scale;
+  const double vol_loc = dx_loc * dx_loc * dx_loc;
+  double xc[8][3];
+  for (int ind = 0; ind < 8; ind++) {
+    const int iz = ind / 4, iy = (ind - 4 * iz) / 2, ix = ind - 2 * iy - 4 * iz;
+    xc[ind][0] = ((double)ix - 0.5) * dx;
+    xc[ind][1] = ((double)iy - 0.5) * dx;
+    xc[ind][2] = ((double)iz - 0.5) * dx;
+  }
+  if (ilevel == levelmin) for (int d = 0; d < 4; d++) multipole[d] = 0.0;   /* rho_fine :28 */
+
+  /* ---- multipole_fine ---- */
+  for (int ind = 0; ind < 8; ind++)
+    for (int i = 0; i < ngrid_tot; i++)
+      for (int d = 0; d < 4; d++) unew[(int64_t)d * ncell + ncoarse + (int64_t)ind * ngridmax + igrid[i] - 1] = 0.0;
+  for (int i0 = 0; i0 < ngrid_tot; i0 += nvector) {
+    const int ngrid = ngrid_tot - i0 < nvector ? ngrid_tot - i0 : nvector;
+    for (int ind = 0; ind < 8; ind++) {
+      for (int i = 0; i < ngrid; i++) {
+        const int g = igrid[i0 + i];
+        const int64_t c = ncoarse + (int64_t)ind * ngridmax + g - 1;
+        if (son[c] != 0) continue;             /* split cells: not on a fully refined finest level */
+        const double mm = dmax(dens[c], smallr) * vol_loc;
+        unew[c] = unew[c] + mm;
+      }
+      for (int d = 0; d < 3; d++)
+        for (int i = 0; i < ngrid; i++) {
+          const int g = igrid[i0 + i];
+          const int64_t c = ncoarse + (int64_t)ind * ngridmax + g - 1;
+          if (son[c] != 0) continue;
+          const double xx = (xg[(int64_t)d * ngridmax + g - 1] + xc[ind][d] - 0.0) * scale;
+          const double mm = dmax(dens[c], smallr) * vol_loc;
+          unew[(int64_t)(d + 1) * ncell + c] = unew[(int64_t)(d + 1) * ncell + c] + mm * xx;
+        }
+    }
+  }
+
+  /* ---- cic_from_multipole ---- */
+  for (int ind = 0; ind < 8; ind++)
+    for (int i = 0; i < ngrid_tot; i++) rho[ncoarse + (int64_t)ind * ngridmax + igrid[i] - 1] = 0.0;
+  int64_t *fc27 = (int64_t *)malloc(sizeof(int64_t) * 27 * (size_t)nvector);
+  for (int i0 = 0; i0 < ngrid_tot; i0 += nvector) {
+    const int np = ngrid_tot - i0 < nvector ? ngrid_tot - i0 : nvector;
+    /* get3cubefather: the 3^3 father cells around the father cell of every oct, x fastest */
+    for (int j = 0; j < np; j++) {
+      const int64_t f0 = father[igrid[i0 + j] - 1];
+      for (int t = 0; t < 27; t++) {
+        const int d3[3] = {t % 3 - 1, (t / 3) % 3 - 1, t / 9 - 1};
+        int64_t c = f0;
+        for (int axis = 0; axis < 3 && c > 0; axis++)
+          if (d3[axis] != 0) c = nbor_cell(&T, c, 2 * axis + (d3[axis] > 0 ? 1 : 0));
+        fc27[(size_t)j * 27 + t] = c;
+      }
+    }
+    for (int ind_son = 0; ind_son < 8; ind_son++) {
+      const int64_t iskip_son = ncoarse + (int64_t)ind_son * ngridmax;
+      if (ilevel == levelmin)
+        for (int d = 0; d < 4; d++)
+          for (int j = 0; j < np; j++) multipole[d] = multipole[d] + unew[(int64_t)d * ncell + iskip_son + igrid[i0 + j] - 1];
+      /* the eight targets of every source cell are accumulated target by target, cell by cell */
+      for (int ind = 0; ind < 8; ind++) {
+        for (int j = 0; j < np; j++) {
+          const int g = igrid[i0 + j];
+          const int64_t cs = iskip_son + g - 1;
+          double dd[3], dg[3];
+          int ig[3], id[3];
+          for (int d = 0; d < 3; d++) {
+            double x = unew[(int64_t)(d + 1) * ncell + cs] / unew[cs];       /* centre of mass */
+            x = x / scale + 0.0;
+            x = x - (xg[(int64_t)d * ngridmax + g - 1] - 3.0 * dx);
+            x = x / dx;
+            dd[d] = x + 0.5;
+            id[d] = (int)dd[d];
+            dd[d] = dd[d] - id[d];
+            dg[d] = 1.0 - dd[d];
+            ig[d] = id[d] - 1;
+          }
+          const int bx = ind & 1, by = (ind >> 1) & 1, bz = (ind >> 2) & 1;
+          const double vol = (bx ? dd[0] : dg[0]) * (by ? dd[1] : dg[1]) * (bz ? dd[2] : dg[2]);
+          const int kx = bx ? id[0] : ig[0], ky = by ? id[1] : ig[1], kz = bz ? id[2] : ig[2];
+          const int kg = (kx / 2) + 3 * (ky / 2) + 9 * (kz / 2);
+          const int64_t fcell = fc27[(size_t)j * 27 + kg];
+          const int gt = fcell > 0 ? son[fcell - 1] : 0;
+          const int icell = (kx - 2 * (kx / 2)) + 2 * (ky - 2 * (ky / 2)) + 4 * (kz - 2 * (kz / 2));
+          const double vol2 = unew[cs] * vol / vol_loc;
+          if (gt > 0) {
+            const int64_t ct = ncoarse + (int64_t)icell * ngridmax + gt - 1;
+            rho[ct] = rho[ct] + vol2;
+          }
+        }
+      }
+    }
+  }
+  free(fc27);
+  *rho_tot = multipole[0] / (scale * scale * scale);                           /* :179 */
+}

@@ -95,3 +95,45 @@ def test_three_coarse_steps_with_self_gravity_equal_the_reference_run(oracle):
     assert np.array_equal(phi, g[0])
     assert np.array_equal(f, g[1:4])
     assert np.array_equal(rs.cons_to_prim(u, GAMMA, SMALLR), z[key + "_s3_prim"])
+
+
+def test_three_coarse_steps_with_the_deposit_oracle_equal_the_reference_run(oracle):
+    """The same three steps with NOTHING taken from the reference run but the initial state and the
+    tree (oct list, xg, son/nbor/father of tests/golden/rho_fine_ref.npz, the same 32^3 run): the
+    multigrid source and rho_tot come from oracle/rho_fine_oracle.c (multipole_fine +
+    cic_from_multipole restated, pinned on dumps of the reference in tests/test_rho_fine_oracle.py)."""
+    sys.path.insert(0, ROOT)
+    from oracle import ramses_snapshot as rs
+    z = np.load(GOLD)
+    t = np.load(os.path.join(ROOT, "tests", "golden", "rho_fine_ref.npz"))
+    key = "l5_b1_e6"
+    _, boxlen, eps, _, _ = [float(x) for x in z[key + "_meta"]]
+    k = "c%d_" % int(t["calls"][0])
+    ilevel, _, ngrid, ngridmax, ncoarse, levelmin, nvector = [int(x) for x in t[k + "meta"]]
+    n = 1 << ilevel
+    igrid, xg = t[k + "igrid"], t[k + "xg"]
+    # cell vector <-> brick: centre of cell (ind, oct) = xg + (bit - 1/2) dx, in units of the box
+    cells, bi = [], []
+    for ind in range(8):
+        cells.append(ncoarse + ind * ngridmax + igrid - 1)
+        bi.append([np.floor((xg[d, igrid - 1] + (((ind >> d) & 1) - 0.5) / n) * n).astype(int) for d in range(3)])
+    cells = np.concatenate(cells)
+    ix, iy, iz = (np.concatenate([b[d] for b in bi]) for d in range(3))
+    assert cells.size == n ** 3 and len(set(zip(ix, iy, iz))) == n ** 3
+    p = oracle.make_params(gamma=GAMMA, smallr=SMALLR, smallc=SMALLC)
+    u = initial_state(np.ascontiguousarray(z[key + "_rho"]))
+    f = np.zeros((3,) + u[0].shape)
+    dt, safe = 0.0, False
+    for s in range(3):
+        dens = np.zeros(ncoarse + 8 * ngridmax)
+        dens[cells] = u[0][iz, iy, ix]
+        rho_v, _, rho_tot = oracle.rho_fine_hydro(ilevel, levelmin, nvector, igrid, xg, t[k + "son"], t[k + "nbor"], t[k + "father"],
+                                                  ngridmax, ncoarse, boxlen, SMALLR, dens)
+        rho = np.zeros_like(u[0])
+        rho[iz, iy, ix] = rho_v[cells]
+        assert np.array_equal(rho, z[key + "_s3_rho"][s]) and rho_tot == float(z[key + "_s3_rho_tot"][s])
+        u, f, phi, dt, it, safe = step(oracle, p, u, f, dt, rho_tot, boxlen, eps, safe, rho=rho)
+    g = z[key + "_s3_grav"]
+    g = g[1:] if g.shape[0] == 5 else g
+    assert np.array_equal(phi, g[0]) and np.array_equal(f, g[1:4])
+    assert np.array_equal(rs.cons_to_prim(u, GAMMA, SMALLR), z[key + "_s3_prim"])
