@@ -222,6 +222,30 @@ def rho_fine_hydro(ilevel, levelmin, nvector, igrid, xg, son, nbor, father, ngri
     return rho, mp, rt.value
 
 
+def rho_deposit_gather(ilevel, levelmin, nvector, igrid, xg, son, nbor, father, ngridmax, ncoarse, boxlen, smallr, dens):
+    """The same deposit formulated as a gather with order tags (ora_rho_deposit_gather): returns rho[ncell]."""
+    ncell = ncoarse + 8 * ngridmax
+    ig, so, nb, fa = (np.ascontiguousarray(a, np.int32) for a in (igrid, son, nbor, father))
+    xg = np.ascontiguousarray(xg, np.float64)
+    dens = np.ascontiguousarray(dens, np.float64)
+    unew = np.zeros((4, ncell))
+    rho = np.zeros(ncell)
+    mp = np.zeros(4)
+    rt = C.c_double()
+    L = lib()
+    rho_fine_hydro(ilevel, levelmin, nvector, igrid, xg, son, nbor, father, ngridmax, ncoarse, boxlen, smallr, dens)  # argtypes
+    L.ora_rho_fine_hydro(ilevel, levelmin, nvector, len(ig), ig.ctypes.data, xg.ctypes.data, so.ctypes.data, nb.ctypes.data,
+                         fa.ctypes.data, ngridmax, ncoarse, boxlen, smallr, dens.ctypes.data, unew.ctypes.data,
+                         rho.ctypes.data, mp.ctypes.data, C.addressof(rt))                                       # multipoles
+    out = np.zeros(ncell)
+    L.ora_rho_deposit_gather.restype = None
+    L.ora_rho_deposit_gather.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int64, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]
+    L.ora_rho_deposit_gather(ilevel, nvector, len(ig), ig.ctypes.data, xg.ctypes.data, so.ctypes.data, nb.ctypes.data,
+                             fa.ctypes.data, ngridmax, ncoarse, boxlen, unew.ctypes.data, out.ctypes.data)
+    return out
+
+
 def cg_solve(igrid, son, nbor, ngridmax, ncoarse, phi, f, epsilon, itermax=10000):
     """Iteration loop of phi_fine_cg on one level (serial): phi[ncell] and f[3, ncell] (r, p, Ap) are
     updated in place from the state cmp_residual_cg left; returns (iterations, error, error_ini)."""

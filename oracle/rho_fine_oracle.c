@@ -143,3 +143,83 @@ void ora_rho_fine_hydro(int ilevel, int levelmin, int nvector, int ngrid_tot, co
   free(fc27);
   *rho_tot = multipole[0] / (scale * scale * scale);                           /* :179 */
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * The same deposit as a GATHER (the shape a device kernel needs: one thread per target cell, no
+ * atomics): every contribution is tagged with the position it has in the reference's loop nest
+ * (batch of nvector octs, ind_son, CIC corner, oct in batch); a target sorts what it receives by
+ * that tag and adds it in order.  The sources are visited in REVERSE here on purpose: the result
+ * must not depend on the order in which the contributions are produced.  tests/test_rho_fine_oracle.py
+ * checks it against ora_rho_fine_hydro and the reference's dumps, bit for bit.
+ * unew must hold the multipoles (call ora_rho_fine_hydro first); rho_out receives the deposit. */
+typedef struct { int64_t key; double val; } contrib_t;
+
+static int cmp_contrib(const void *a, const void *b) {
+  const int64_t ka = ((const contrib_t *)a)->key, kb = ((const contrib_t *)b)->key;
+  return ka < kb ? -1 : (ka > kb ? 1 : 0);
+}
+
+void ora_rho_deposit_gather(int ilevel, int nvector, int ngrid_tot, const int *igrid, const double *xg, const int *son,
+                            const int *nbor, const int *father, int64_t ngridmax, int64_t ncoarse, double boxlen,
+                            const double *unew, double *rho_out) {
+  const int64_t ncell = ncoarse + 8 * ngridmax;
+  tree_t T = {son, nbor, ncoarse, ngridmax};
+  double dx = 1.0;
+  for (int l = 0; l < ilevel; l++) dx *= 0.5;
+  const double scale = boxlen, dx_loc = dx * scale, vol_loc = dx_loc * dx_loc * dx_loc;
+  enum { CAP = 64 };
+  contrib_t *box = (contrib_t *)malloc(sizeof(contrib_t) * CAP * (size_t)ncell);
+  int *cnt = (int *)calloc((size_t)ncell, sizeof(int));
+  for (int i = ngrid_tot - 1; i >= 0; i--) {                 /* sources in reverse list order */
+    const int g = igrid[i];
+    const int64_t batch = i / nvector, j = i % nvector;
+    int64_t fc27[27];
+    const int64_t f0 = father[g - 1];
+    for (int t = 0; t < 27; t++) {
+      const int d3[3] = {t % 3 - 1, (t / 3) % 3 - 1, t / 9 - 1};
+      int64_t c = f0;
+      for (int axis = 0; axis < 3 && c > 0; axis++)
+        if (d3[axis] != 0) c = nbor_cell(&T, c, 2 * axis + (d3[axis] > 0 ? 1 : 0));
+      fc27[t] = c;
+    }
+    for (int ind_son = 7; ind_son >= 0; ind_son--) {
+      const int64_t cs = ncoarse + (int64_t)ind_son * ngridmax + g - 1;
+      double dd[3], dg[3];
+      int ig[3], id[3];
+      for (int d = 0; d < 3; d++) {
+        double x = unew[(int64_t)(d + 1) * ncell + cs] / unew[cs];
+        x = x / scale + 0.0;
+        x = x - (xg[(int64_t)d * ngridmax + g - 1] - 3.0 * dx);
+        x = x / dx;
+        dd[d] = x + 0.5;
+        id[d] = (int)dd[d];
+        dd[d] = dd[d] - id[d];
+        dg[d] = 1.0 - dd[d];
+        ig[d] = id[d] - 1;
+      }
+      for (int ind = 7; ind >= 0; ind--) {
+        const int bx = ind & 1, by = (ind >> 1) & 1, bz = (ind >> 2) & 1;
+        const double vol = (bx ? dd[0] : dg[0]) * (by ? dd[1] : dg[1]) * (bz ? dd[2] : dg[2]);
+        const int kx = bx ? id[0] : ig[0], ky = by ? id[1] : ig[1], kz = bz ? id[2] : ig[2];
+        const int64_t fcell = fc27[(kx / 2) + 3 * (ky / 2) + 9 * (kz / 2)];
+        const int gt = fcell > 0 ? son[fcell - 1] : 0;
+        if (gt <= 0) continue;
+        const int icell = (kx - 2 * (kx / 2)) + 2 * (ky - 2 * (ky / 2)) + 4 * (kz - 2 * (kz / 2));
+        const int64_t ct = ncoarse + (int64_t)icell * ngridmax + gt - 1;
+        contrib_t *b = box + (size_t)ct * CAP + cnt[ct]++;
+        b->key = ((batch * 8 + ind_son) * 8 + ind) * nvector + j;
+        b->val = unew[cs] * vol / vol_loc;
+      }
+    }
+  }
+  for (int ind = 0; ind < 8; ind++)
+    for (int i = 0; i < ngrid_tot; i++) {
+      const int64_t ct = ncoarse + (int64_t)ind * ngridmax + igrid[i] - 1;
+      qsort(box + (size_t)ct * CAP, (size_t)cnt[ct], sizeof(contrib_t), cmp_contrib);
+      double r = 0.0;
+      for (int k = 0; k < cnt[ct]; k++) r = r + box[(size_t)ct * CAP + k].val;
+      rho_out[ct] = r;
+    }
+  free(box);
+  free(cnt);
+}

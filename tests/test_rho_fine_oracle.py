@@ -27,3 +27,20 @@ def test_rho_fine_oracle_equals_reference_dump(oracle, which):
     assert np.array_equal(rho[lev], z[k + "rho"][lev]), np.abs(rho[lev] - z[k + "rho"][lev]).max()
     assert np.array_equal(mp, z[k + "multipole"])
     assert rho_tot == float(z[k + "rho_tot"][0])
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_gather_formulation_of_the_deposit_equals_the_sequential_one(oracle, which):
+    """The deposit as a gather with order tags (one target cell at a time, contributions produced in
+    reverse order, sorted by their position in the reference's loop nest, then added): the shape a
+    device kernel needs.  Same rho as the reference's sequential accumulation, bit for bit."""
+    z = np.load(GOLD)
+    k = "c%d_" % int(z["calls"][which])
+    ilevel, icount, ngrid, ngridmax, ncoarse, levelmin, nvector = [int(x) for x in z[k + "meta"]]
+    boxlen, smallr = [float(x) for x in z[k + "real"]]
+    rho = oracle.rho_deposit_gather(ilevel, levelmin, nvector, z[k + "igrid"], z[k + "xg"], z[k + "son"], z[k + "nbor"],
+                                    z[k + "father"], ngridmax, ncoarse, boxlen, smallr, z[k + "dens"])
+    lev = np.zeros(rho.size, bool)
+    for ind in range(8):
+        lev[ncoarse + ind * ngridmax + z[k + "igrid"] - 1] = True
+    assert np.array_equal(rho[lev], z[k + "rho"][lev]), np.abs(rho[lev] - z[k + "rho"][lev]).max()
