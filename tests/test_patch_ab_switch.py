@@ -1,0 +1,76 @@
+"""RAMSES_AMD=0: the patched reference program (oracle/_ref/ramses3d_patch = the reference built with
+ramses_amd/patch as its PATCH= directory) must run the untouched reference routines behind every
+shim (godunov_fine, set_unew/set_uold, courant_fine, synchro_hydro_fine, rho_fine, multigrid_fine and
+its compute routines, phi_fine_cg, force_fine, backup_hydro) -- the A/B switch of INTEGRATION.md.
+No GPU is touched, so this runs in the CPU suite: snapshots must equal the reference's goldens."""
+import importlib.util
+import os
+import re
+import shutil
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATCHED = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch")
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _run(nml):
+    sys.path.insert(0, ROOT)
+    from oracle import ramses_snapshot as rs
+    old = os.environ.get("RAMSES_AMD")
+    os.environ["RAMSES_AMD"] = "0"
+    try:
+        return rs, rs.run_reference(nml, binary=PATCHED)
+    finally:
+        if old is None:
+            os.environ.pop("RAMSES_AMD", None)
+        else:
+            os.environ["RAMSES_AMD"] = old
+
+
+@pytest.mark.skipif(not os.path.exists(PATCHED), reason="oracle/_ref/ramses3d_patch not built")
+def test_uniform_self_gravity_three_steps_through_the_reference_routines():
+    mkp = _load(os.path.join(ROOT, "tests", "golden", "make_golden_poisson.py"), "mkp")
+    key, level, boxlen, eps, blob = mkp.CASES[-1]
+    z = np.load(os.path.join(ROOT, "tests", "golden", "poisson_ref_runs.npz"))
+    sys.path.insert(0, ROOT)
+    from oracle import ramses_snapshot as rs0
+    nml = rs0.sedov3d_namelist(level=level, nstepmax=4, foutput=3, boxlen=boxlen, poisson=True,
+                               init=mkp.BLOB.format(**blob), extra="&POISSON_PARAMS\nepsilon=%s\n/\n" % eps)
+    rs, (work, out) = _run(nml)
+    try:
+        assert "MI355X" not in out and "resident on the GPU" not in out
+        snap = rs.load_uniform_level(os.path.join(work, "output_00002"), level, with_grav=True)
+        gold = z[key + "_s3_grav"]
+        gold = gold[1:] if gold.shape[0] == 5 else gold
+        got = snap["grav"][1:] if snap["grav"].shape[0] == 5 else snap["grav"]
+        assert np.array_equal(got, gold)
+        assert np.array_equal(snap["prim"], z[key + "_s3_prim"])
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+@pytest.mark.skipif(not os.path.exists(PATCHED), reason="oracle/_ref/ramses3d_patch not built")
+def test_amr_self_gravity_with_cg_levels_through_the_reference_routines():
+    mk = _load(os.path.join(ROOT, "tests", "golden", "make_golden_cg.py"), "mkcg")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "cg_ref.npz"))
+    rs, (work, out) = _run(mk.cg_namelist())
+    try:
+        solves = re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+) Error=\s*(\S+)[ \t]+(\S+)[ \t]*\n", out)
+        assert np.array_equal(np.array([[int(a), int(b)] for a, b, _, _ in solves]), z["solves"])
+        snap = rs.load_leaf_cells(os.path.join(work, "output_00002"), with_grav=True)
+        order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+        assert np.array_equal(snap["level"][order], z["level"])
+        assert np.array_equal(snap["grav"][:, order], z["grav"])
+        assert np.array_equal(snap["prim"][:, order], z["prim"])
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
