@@ -74,3 +74,34 @@ def test_amr_self_gravity_with_cg_levels_through_the_reference_routines():
         assert np.array_equal(snap["prim"][:, order], z["prim"])
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+MPI_PATCHED = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi_patch")
+
+
+@pytest.mark.skipif(not (os.path.exists(MPI_PATCHED) and os.path.exists("/opt/conda/bin/mpiexec")),
+                    reason="oracle/_ref/ramses3d_mpi_patch or mpiexec not available")
+def test_mpi_build_through_the_reference_routines():
+    """The MPI build of the patched program on two ranks with RAMSES_AMD=0 (AMR run): the snapshot of
+    the unmodified MPI reference."""
+    mka = _load(os.path.join(ROOT, "tests", "golden", "make_golden_amr.py"), "mka")
+    tag, nproc, nml, nstep = [c for c in mka.MPI_CASES() if c[1] == 2][0]
+    z = np.load(os.path.join(ROOT, "tests", "golden", "amr_godunov_ref.npz"))
+    sys.path.insert(0, ROOT)
+    from oracle import ramses_snapshot as rs
+    old = os.environ.get("RAMSES_AMD")
+    os.environ["RAMSES_AMD"] = "0"
+    try:
+        work, out = rs.run_reference(nml, nproc=nproc, binary=MPI_PATCHED)
+    finally:
+        if old is None:
+            os.environ.pop("RAMSES_AMD", None)
+        else:
+            os.environ["RAMSES_AMD"] = old
+    try:
+        snap = rs.load_leaf_cells(os.path.join(work, "output_%05d" % (nstep + 1)))
+        order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+        assert np.array_equal(snap["level"][order], z[tag + "_level"])
+        assert np.array_equal(snap["prim"][:, order], z[tag + "_prim"])
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
