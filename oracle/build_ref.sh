@@ -174,6 +174,8 @@ case "$cmd" in
        if [ -d /opt/conda/include ] && [ -f /opt/conda/lib/libmpifort.so ]; then build_ramses 3 mpi; fi
        if [ -f "$HERE/../ramses_amd/lib/libramses_amd.so" ]; then
          build_ramses 3 serial "$HERE/../ramses_amd/patch"
+         build_ramses 1 serial "$HERE/../ramses_amd/patch"     # the shims compile for NDIM=1,2 (A/B tests with RAMSES_AMD=0)
+         build_ramses 2 serial "$HERE/../ramses_amd/patch"
          if [ -d /opt/conda/include ] && [ -f /opt/conda/lib/libmpifort.so ]; then
            build_ramses 3 mpi "$HERE/../ramses_amd/patch"
          fi

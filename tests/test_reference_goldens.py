@@ -44,14 +44,28 @@ def _checksums(data, threshold=2.0e-14, min_variance=1.0e-14):
 CASES = [("sod-tube", 1, 3.0e-13), ("implosion", 2, 3.0e-13), ("barotrop", 1, 2.0e-12)]
 
 
+@pytest.mark.parametrize("variant", ["", "_patch"])
 @pytest.mark.parametrize("name,ndim,tol", CASES)
-def test_reference_golden(name, ndim, tol):
-    binary = os.path.join(ROOT, "oracle", "_ref", "ramses%dd" % ndim)
+def test_reference_golden(name, ndim, tol, variant):
+    """variant "_patch": the same reference built with ramses_amd/patch as its PATCH= directory and run
+    with RAMSES_AMD=0 (the shims compile for NDIM=1 and 2 and hand every call to the reference's routine)."""
+    if variant and name == "implosion" and os.environ.get("RAMSES_AMD_LONG_TESTS") != "1":
+        pytest.skip("50 s; the 2-D shims are exercised by the build, the 1-D ones by sod-tube and barotrop (RAMSES_AMD_LONG_TESTS=1 runs it)")
+    binary = os.path.join(ROOT, "oracle", "_ref", "ramses%dd%s" % (ndim, variant))
     case = os.path.join(REF, "tests", "hydro", name)
     if not (os.path.exists(binary) and os.path.isdir(case)):
-        pytest.skip("needs the reference tree and oracle/_ref/ramses%dd (oracle/build_ref.sh ramses %d serial)" % (ndim, ndim))
+        pytest.skip("needs the reference tree and oracle/_ref/ramses%dd%s (oracle/build_ref.sh ramses %d serial [PATCHDIR])"
+                    % (ndim, variant, ndim))
     from oracle import ramses_snapshot as rs
-    work, out = rs.run_reference(open(os.path.join(case, name + ".nml")).read(), ndim=ndim, binary=binary)
+    old = os.environ.get("RAMSES_AMD")
+    os.environ["RAMSES_AMD"] = "0"
+    try:
+        work, out = rs.run_reference(open(os.path.join(case, name + ".nml")).read(), ndim=ndim, binary=binary)
+    finally:
+        if old is None:
+            os.environ.pop("RAMSES_AMD", None)
+        else:
+            os.environ["RAMSES_AMD"] = old
     try:
         outs = sorted(d for d in os.listdir(work) if d.startswith("output_"))
         leaf = rs.load_leaf_cells(os.path.join(work, outs[-1]))
