@@ -437,7 +437,7 @@ int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int 
  *   ramses_amd_resident_courant_grav_f90   courant_fine with cmpdt's gravity term  hydro/courant_fine.f90:77-85
  *   ramses_amd_resident_godunov_grav_f90   set_unew + godunov_fine with the predictor's source term
  *   ramses_amd_resident_set_uold_grav_f90  add_gravity_source_terms + set_uold  hydro/godunov_fine.f90:135-289
- *   ramses_amd_resident_sync_density_f90   uold(:,1) back to the host for rho_fine (pm/rho_fine.f90:666-800)
+ *   ramses_amd_resident_sync_density_f90   uold(:,1) back to the host for rho_fine (pm/rho_fine.f90:666-820)
  * ------------------------------------------------------------------------- */
 int ramses_amd_resident_synchro_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
                                     const int *igrid, const double *xg, int64_t ngridmax,

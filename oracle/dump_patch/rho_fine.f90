@@ -1,7 +1,7 @@
 !==============================================================================
 ! oracle/dump_patch/rho_fine.f90 -- TEST INFRASTRUCTURE ONLY.
 !
-! Wraps the UNMODIFIED rho_fine of the reference (pm/rho_fine.f90:5-240) and
+! Wraps the UNMODIFIED rho_fine of the reference (pm/rho_fine.f90:5-226) and
 ! dumps, for chosen calls, the tree, the oct list, the hydro density it reads and
 ! the rho / multipole / rho_tot it leaves (kernel-level goldens of the hydro
 ! deposit: multipole_fine + cic_from_multipole / cic_cell).

@@ -2,10 +2,10 @@
  *
  * CPU restatement of rho_fine's hydro deposit on one level of a periodic nx=ny=nz=1 box (3-D, no
  * particles, every cell of the level a leaf), in the reference's loop order:
- *   rho_fine              pm/rho_fine.f90:5-240     (multipole reset, level loop, rho_tot :176-183)
- *   multipole_fine        :666-800                  (mass and mass*position of every leaf cell into
+ *   rho_fine              pm/rho_fine.f90:5-226     (multipole reset, level loop, rho_tot :176-183)
+ *   multipole_fine        :666-820                  (mass and mass*position of every leaf cell into
  *                                                    unew(:,1:4), the reference's scratch)
- *   cic_from_multipole    :805-870, cic_cell :875-1130  (the mass of a cell is CIC-deposited at its
+ *   cic_from_multipole    :825-891, cic_cell :896-1142  (the mass of a cell is CIC-deposited at its
  *                                                    centre of mass (m*x)/m: not the cell density bit
  *                                                    for bit once rounding moves that point)
  *   get3cubefather        amr/nbors_utils.f90:5-194 (as x,y,z steps through son(nbor))

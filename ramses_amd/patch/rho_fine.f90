@@ -3,7 +3,7 @@
 !
 ! Shadows pm/rho_fine.f90 (rho_fine -> rho_fine_reference by #define + #include;
 ! multipole_fine, cic_from_multipole, ... stay the reference's).  rho_fine's hydro
-! deposit reads the density uold(:,1) (multipole_fine, pm/rho_fine.f90:666-800):
+! deposit reads the density uold(:,1) (multipole_fine, pm/rho_fine.f90:666-820):
 ! while the level is device-resident the new rho_fine first brings that one
 ! variable back to the host array, then runs the untouched reference routine.
 !==============================================================================
