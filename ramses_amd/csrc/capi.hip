@@ -659,6 +659,17 @@ HostCtx g_host;
 }  // namespace
 }  // extern "C++"
 
+// The staged entry points reuse the staging buffers of the resident level.  If that level holds
+// the only current copy of the hydro state, dropping it would silently lose a step: refuse, as
+// ramses_amd_resident_invalidate does (the caller syncs the host array first).
+static int resident_release(const char *who) {
+  HostCtx &H = g_host;
+  if (H.res_valid && H.res_host_stale)
+    return fail(RAMSES_AMD_EINVAL, "%s: level %d is resident on the device and the host array is stale; call ramses_amd_resident_sync_host_f90 first", who, H.res_level);
+  H.res_valid = false;
+  return 0;
+}
+
 int ramses_amd_godunov_fine_host(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
                                  const int *igrid, const double *xg, int64_t ngridmax,
                                  int64_t ncoarse, int nx_loc, const double *uold, double *unew,
@@ -675,6 +686,7 @@ int ramses_amd_godunov_fine_host(const ramses_amd_hydro_params *p, int ilevel, i
                 ilevel, ngrid, ncells_level / 8);
   const long ncell = ncoarse + 8 * ngridmax;
   const int nvar = p->nvar;
+  if (int rc = resident_release("godunov_fine (staged brick sweep)")) return rc;   // the bricks are reused
   hipStream_t s = nullptr;
   HostCtx &H = g_host;
 #define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipfail(e_, what); } while (0)
@@ -793,6 +805,7 @@ int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ileve
   if ((divu == nullptr) != (enew == nullptr)) return fail(RAMSES_AMD_EINVAL, "pressure_fix needs both divu and enew");
   if (int rc = amr_check(p, ilevel, nvector, interpol_var, interpol_type)) return rc;
   if (ngrid <= 0) return 0;
+  if (int rc = resident_release("godunov_fine (tree-walking sweep)")) return rc;   // the staging buffers are reused
   const long ncell = ncoarse + 8 * ngridmax;
   hipStream_t s = nullptr;
   HostCtx &H = g_host;
@@ -820,7 +833,6 @@ int ramses_amd_godunov_fine_amr_host(const ramses_amd_hydro_params *p, int ileve
     HCHK(hipMemcpyAsync(H.fvec.p, f, sizeof(double) * 3 * ncell, hipMemcpyHostToDevice, s), "H2D f");
     d_grav = H.fvec.as<double>();
   }
-  g_host.res_valid = false;   // the staging buffers are reused
   double *d_divu = nullptr, *d_enew = nullptr;
   if (divu) {
     HCHK(ddivu.ensure(sizeof(double) * ncell), "hipMalloc divu");
@@ -883,6 +895,9 @@ int ramses_amd_multigrid_fine_f90(int ilevel, int ngrid, const int *igrid, const
   const long ncell = ncoarse + 8 * ngridmax;
   hipStream_t s = nullptr;
   HostCtx &H = g_host;
+  // igrid/xg/octorg are shared with the resident level: the same level rewrites them with the same contents
+  if (H.res_valid && !(H.res_level == ilevel && H.res_ngrid == ngrid && H.res_ncell == ncell))
+    if (int rc = resident_release("multigrid_fine")) return rc;
   static DevBuf rhovec, phivec, brho, bphi, bf1, bf2, work;
 #define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipfail(e_, what); } while (0)
   const int64_t nwork = ramses_amd_mg_workspace_doubles(ilevel);
@@ -965,7 +980,7 @@ int ramses_amd_force_fine_f90(int ilevel, int ngrid, const int *igrid, const dou
   // igrid/xg/octorg are shared with the resident level: the same level rewrites them with the
   // same contents, anything else ends the residency
   const bool resident = H.res_valid && H.res_level == ilevel && H.res_ngrid == ngrid && H.res_ncell == ncell;
-  if (!resident) H.res_valid = false;
+  if (!resident) if (int rc = resident_release("force_fine")) return rc;
   double *d_f = bf.as<double>();
   if (resident) {
     // the acceleration of the resident level is rewritten in place (synchro_hydro_fine,
@@ -1373,6 +1388,7 @@ int ramses_amd_mgamr_begin(int ilevel, int64_t ngridmax, int64_t ncoarse, const 
                            int ngrid, const int *igrid) {
   if (!son || !nbor || !father || !lookup_mg || !flag2 || !phi || !f || (!igrid && ngrid > 0)) return fail(RAMSES_AMD_EINVAL, "NULL argument");
   if (ilevel < 2 || ilevel > 30) return fail(RAMSES_AMD_EUNSUPPORTED, "AMR multigrid on the device needs 2 <= ilevel <= 30 (got %d)", ilevel);
+  if (int rc = resident_release("multigrid_fine (AMR level)")) return rc;
   MgAmrCtx &M = g_mg;
   hipStream_t s = nullptr;
   const char *e = getenv("RAMSES_AMD_MG_SYNC");
@@ -1402,7 +1418,6 @@ int ramses_amd_mgamr_begin(int ilevel, int64_t ngridmax, int64_t ncoarse, const 
     HCHK(mgamr_launch_lookup(D.igrid.as<int>(), ngrid, M.lookup.as<int>(), s), "lookup");
   }
   if (int rc = mgamr_load_fine(false)) return rc;
-  g_host.res_valid = false;
   return 0;
 }
 
@@ -1535,6 +1550,7 @@ int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int 
   if (ngrid <= 0 || ngridmax < ngrid || ncoarse < 1) return fail(RAMSES_AMD_EINVAL, "bad level sizes (ngrid=%d)", ngrid);
   if (ilevel < 1 || ilevel > 30) return fail(RAMSES_AMD_EINVAL, "bad level %d", ilevel);
   if (!(ncell_level > 0) || itermax < 1) return fail(RAMSES_AMD_EINVAL, "bad ncell_level/itermax");
+  if (int rc = resident_release("phi_fine_cg")) return rc;
   CgCtx &G = g_cg;
   hipStream_t s = nullptr;
   if (ordered < 0) {   // the Fortran shim: RAMSES_AMD_CG_ORDERED=1 selects the reference's summation order
@@ -1598,7 +1614,6 @@ int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int 
   if (rho_or_null) rhs_norm = std::sqrt(G.pin[4] / ncell_level);   // :78
   *iter_out = iter;
   err_out[0] = error; err_out[1] = error_ini; err_out[2] = rhs_norm;
-  g_host.res_valid = false;
   return 0;
 }
 #undef HCHK

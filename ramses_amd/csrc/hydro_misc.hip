@@ -297,6 +297,55 @@ __global__ __launch_bounds__(256) void add_gravity_source_kernel(double *__restr
   }
 }
 
+// ---------------------------------------------------------------------------
+// Diagnostics of force_fine (poisson/force_fine.f90:158-190) on a level brick: the potential
+// energy  sum over leaf cells and directions of fact*f**2  and the maximum of |rho|.  The
+// maximum is exact; the sum is a fixed two-stage tree (deterministic; differs from the
+// reference's serial loop by rounding only -- epot_tot feeds the energy-conservation print).
+// leaf == nullptr: every cell is a leaf.
+// ---------------------------------------------------------------------------
+constexpr int DIAG_BLOCKS = 512;
+__global__ __launch_bounds__(256) void force_diag_kernel(const double *__restrict__ f, const double *__restrict__ rho,
+                                                          const int *__restrict__ leaf, long N, double fact,
+                                                          double *__restrict__ partial) {
+  double e = 0.0, rmax = 0.0;
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (long)gridDim.x * blockDim.x) {
+    if (!leaf || leaf[c]) {
+#pragma unroll
+      for (int d = 0; d < 3; d++) { const double v = f[(long)d * N + c]; e = e + fact * (v * v); }
+    }
+    rmax = __builtin_fmax(rmax, __builtin_fabs(rho[c]));
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  e = wave_sum(e);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) rmax = __builtin_fmax(rmax, __shfl_down(rmax, off, 64));
+  __shared__ double red[4][2];
+  if (lane == 0) { red[wave][0] = e; red[wave][1] = rmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double es = red[0][0], rm = red[0][1];
+    for (int w = 1; w < 4; w++) { es += red[w][0]; rm = __builtin_fmax(rm, red[w][1]); }
+    partial[2 * blockIdx.x] = es;
+    partial[2 * blockIdx.x + 1] = rm;
+  }
+}
+__global__ void force_diag_final_kernel(const double *__restrict__ partial, int nblocks, double *__restrict__ out) {
+  double es = 0.0, rm = 0.0;
+  for (int b = 0; b < nblocks; b++) { es += partial[2 * b]; rm = __builtin_fmax(rm, partial[2 * b + 1]); }
+  out[0] = es; out[1] = rm;
+}
+// partial: 2*DIAG_BLOCKS doubles of scratch; out: {epot, rho_max}
+hipError_t launch_force_diag(const double *f, const double *rho, const int *leaf, long N, double fact, double *partial,
+                             double *out, hipStream_t s) {
+  long g = (N + 255) / 256;
+  if (g > DIAG_BLOCKS) g = DIAG_BLOCKS;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(force_diag_kernel, dim3((int)g), dim3(256), 0, s, f, rho, leaf, N, fact, partial);
+  hipLaunchKernelGGL(force_diag_final_kernel, dim3(1), dim3(1), 0, s, partial, (int)g, out);
+  return hipGetLastError();
+}
+
 static inline int misc_grid(long work) {
   long g = (work + 255) / 256;
   if (g < 1) g = 1;

@@ -35,6 +35,10 @@ namespace ramses_amd {
 #define SWEEP_NS strictmode
 #endif
 
+#ifndef RAMSES_AMD_SWEEP_BARRIERS
+#define RAMSES_AMD_SWEEP_BARRIERS 1   // 1: merged, double-buffered y exchange (one barrier per plane); 2: the older loop
+#endif
+
 namespace SWEEP_NS {
 
 constexpr int BX = 64;   // lanes along x = one wavefront
@@ -223,6 +227,166 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   const int txm = max(tx - 1, 0), txp = min(tx + 1, BX - 1);
   const int tym = max(ty - 1, 0), typ = min(ty + 1, BY - 1);
 
+#if RAMSES_AMD_SWEEP_BARRIERS == 1
+  // ---- ONE barrier per plane --------------------------------------------------------------
+  // The +y traced state and the y flux share ONE LDS slot per row, double-buffered by plane
+  // parity: slot M[c&1][ty] is written by row ty with its +y state before the barrier of
+  // iteration c, read after it by row ty+1, which then overwrites it with the flux through
+  // that face; row ty picks the flux up after the NEXT barrier, when it finishes plane c-1
+  // -> c.  Nobody else touches the slot, so the second barrier of the two-barrier loop (and
+  // the lock-step of the heavy waves it enforced) is gone.  Same operations in the same
+  // order per cell: ((u + (fx- - fx+)) + (fy- - fy+)) + (fz- - fz+).
+  Plane<BY, NV> *mring = smy;            // [2]: smy and fyb of the two-barrier loop, merged
+  double partx[NV];                      // u + x flux difference of plane c-1
+  double fyown[NV];                      // y flux through the -y face of plane c-1 (this row's own)
+  double rnew = 0.0, snew[NV > 5 ? NV - 5 : 1];
+#pragma unroll
+  for (int n = 0; n < NV; n++) { partx[n] = 0.0; fyown[n] = 0.0; }
+
+  for (int c = z0 - 1; c <= z1; c++) {
+    Plane<BY, NV> &M = mring[c & 1];
+    Plane<BY, NV> &Mprev = mring[(c & 1) ^ 1];
+    // ---- phase A: plane c+1 arrives; trace plane c; x and z fluxes ------------------
+    double qc[NV];
+    ctoprim_cell<NV, GRAV>(upre, gpre, dtxhalf, P, qc);
+#pragma unroll
+    for (int n = 0; n < NV; n++) qring[sc].v[n][ty][tx] = qc[n];
+    double ucur[NV];
+    { const int pn = min(c + 2, z1 + 1); load_u(pn, upre); load_g(pn, gpre); }
+    if (r_fxz) load_u(c, ucur);
+
+    double qpy[NV], dz[NV], px[NV];
+    if (ST == 3) __syncthreads();  // the 27-point slope reads the neighbours' plane c+1 just written
+    if constexpr (r_trace) {
+      const Plane<BY, NV> &qs = qring[sb];
+      const Plane<BY, NV> &qprev = qring[sa];
+      double qb[NV], dq[3][NV];
+      if (ST == 3) {
+        const Plane<BY, NV> &qnext = qring[sc];
+        const int xs[3] = {txm, tx, txp}, ys[3] = {tym, ty, typ};
+#pragma unroll
+        for (int n = 0; n < NV; n++) {
+          double nb[27], d3[3];
+#pragma unroll
+          for (int dj = 0; dj < 3; dj++)
+#pragma unroll
+            for (int di = 0; di < 3; di++) {
+              nb[di + 3 * dj] = qprev.v[n][ys[dj]][xs[di]];
+              nb[di + 3 * dj + 9] = qs.v[n][ys[dj]][xs[di]];
+              nb[di + 3 * dj + 18] = qnext.v[n][ys[dj]][xs[di]];
+            }
+          qb[n] = nb[13];
+          slope3_var(nb, d3);
+          dq[0][n] = d3[0]; dq[1][n] = d3[1]; dq[2][n] = d3[2];
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < NV; n++) {
+          qb[n] = qs.v[n][ty][tx];
+          dq[0][n] = slope1<ST>(qs.v[n][ty][txm], qb[n], qs.v[n][ty][txp], P);
+          dq[1][n] = slope1<ST>(qs.v[n][tym][tx], qb[n], qs.v[n][typ][tx], P);
+          dq[2][n] = slope1<ST>(qprev.v[n][ty][tx], qb[n], qc[n], P);
+        }
+      }
+      double qm[3][NV], qp[3][NV];
+      if (SCHEME == 0) {
+        trace3d_cell<NV>(qb, dq, dtdx, dtdx, dtdx, P, qm, qp);
+      } else {
+        const double cc = ctoprim_sound(qb[0], qb[4], P);
+        tracexyz_cell<NV>(qb, dq, cc, dtdx, dtdx, dtdx, P, qm, qp);
+      }
+      if constexpr (ROLE == ROLE_HIGH && OFFLOAD_HI) {
+        // nobody reads this row's +y state; its slot carries the -y state to row BY-1
+#pragma unroll
+        for (int n = 0; n < NV; n++) M.v[n][ty][tx] = qp[1][n];
+      } else {
+#pragma unroll
+        for (int n = 0; n < NV; n++) M.v[n][ty][tx] = qm[1][n];
+      }
+#pragma unroll
+      for (int n = 0; n < NV; n++) qpy[n] = qp[1][n];
+      if constexpr (r_fxz) {
+        double qL[NV], fx[NV], fz[NV];
+#pragma unroll
+        for (int n = 0; n < NV; n++) qL[n] = wave_shr1(qm[0][n]);  // +x state of column tx-1
+        scaled_interface_flux<RS, NV, 0>(qL, qp[0], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fx);
+        // z flux through the face between planes c-1 and c
+        scaled_interface_flux<RS, NV, 2>(qmz, qp[2], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fz);
+#pragma unroll
+        for (int n = 0; n < NV; n++) {
+          qmz[n] = qm[2][n];
+          dz[n] = fzlo[n] - fz[n];          // z flux difference of plane c-1
+          fzlo[n] = fz[n];
+          const double fxhi = wave_shl1(fx[n]);   // -x face flux of column tx+1
+          px[n] = ucur[n] + (fx[n] - fxhi);       // consumes the re-read state before the barrier
+        }
+        if (NV > 5) {
+          rnew = ucur[0];
+#pragma unroll
+          for (int n = 5; n < NV; n++) snew[n - 5] = ucur[n];
+        }
+      }
+    }
+    __syncthreads();  // the one barrier: +y states of plane c and y fluxes of plane c-1 visible
+
+    // ---- phase B: y flux of plane c; finish plane c-1 --------------------------------
+    double fy[NV];
+    if constexpr (ROLE == ROLE_FULL || (ROLE == ROLE_HIGH && !OFFLOAD_HI)) {
+      double qL[NV];
+#pragma unroll
+      for (int n = 0; n < NV; n++) qL[n] = M.v[n][tym][tx];
+      scaled_interface_flux<RS, NV, 1>(qL, qpy, P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fy);
+      // the flux through this row's -y face is the +y face flux of row ty-1: into ITS slot
+#pragma unroll
+      for (int n = 0; n < NV; n++) M.v[n][tym][tx] = fy[n];
+    }
+    if constexpr (ROLE == ROLE_HALO_HI && OFFLOAD_HI) {
+      // y flux between rows BY-3 and BY-2, read by row BY-3 when it finishes the plane
+      double qL[NV], qR[NV];
+#pragma unroll
+      for (int n = 0; n < NV; n++) { qL[n] = M.v[n][BY - 3][tx]; qR[n] = M.v[n][BY - 2][tx]; }
+      scaled_interface_flux<RS, NV, 1>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fy);
+#pragma unroll
+      for (int n = 0; n < NV; n++) M.v[n][BY - 3][tx] = fy[n];
+    }
+    if constexpr (r_fxz) {
+      // plane c-1: its x part and own -y flux were kept in registers, the +y face flux was left
+      // in this row's slot of the other buffer by row ty+1 before this iteration's barrier.
+      // (The first two iterations of a chunk produce values from the not yet primed pipeline;
+      // they are computed and dropped by the store's range check.)
+      double un[NV];
+#pragma unroll
+      for (int n = 0; n < NV; n++) {
+        const double part = partx[n] + (fyown[n] - Mprev.v[n][ty][tx]);
+        un[n] = part + dz[n];
+      }
+      if (NV > 5) {
+        // set_uold's passive-scalar fix near the density floor
+        // (hydro/godunov_fine.f90:176-190), fused: the kernel's output is the new uold
+        if (rold < P.smallr && un[0] > rold) {
+#pragma unroll
+          for (int n = 5; n < NV; n++) un[n] = sold[n - 5] * dmaxd(un[0], P.smallr) / P.smallr;
+        } else if (un[0] < P.smallr && rold > un[0]) {
+#pragma unroll
+          for (int n = 5; n < NV; n++) un[n] = sold[n - 5] * P.smallr / dmaxd(rold, P.smallr);
+        }
+        rold = rnew;
+#pragma unroll
+        for (int n = 5; n < NV; n++) sold[n - 5] = snew[n - 5];
+      }
+#pragma unroll
+      for (int n = 0; n < NV; n++) { partx[n] = px[n]; fyown[n] = fy[n]; }
+      {
+        const unsigned pb = plane_off(c - 1);
+        const unsigned so = (c >= z0 + 1) ? colb_upd : BUF_OOB;
+#pragma unroll
+        for (int n = 0; n < NV; n++) plane_store(unew + (long)n * A.pitch_var, pb, so, un[n]);
+      }
+    }
+    // rotate the ring
+    const int t = sa; sa = sb; sb = sc; sc = t;
+  }
+#else
   for (int c = z0 - 1; c <= z1; c++) {
     // ---- plane c+1 arrives: primitives into ring slot sc ---------------------
     double qc[NV];
@@ -365,6 +529,7 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     // rotate the ring
     const int t = sa; sa = sb; sb = sc; sc = t;
   }
+#endif
 }
 
 template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV>

@@ -63,4 +63,10 @@ hipError_t launch_synchro_hydro(double *u, const double *f, long N, double dteff
 hipError_t launch_add_gravity_source(double *unew, const double *uold, const double *f, long N, double dt, double smallr,
                                      hipStream_t s);
 
+// force_fine's diagnostics (poisson/force_fine.f90:158-190) on a level brick: out = {sum fact*f^2 over leaf
+// cells, max |rho|}; partial = FORCE_DIAG_SCRATCH doubles; leaf[N] (0/1) or nullptr = every cell is a leaf
+constexpr int FORCE_DIAG_SCRATCH = 1024;
+hipError_t launch_force_diag(const double *f, const double *rho, const int *leaf, long N, double fact, double *partial,
+                             double *out, hipStream_t s);
+
 }  // namespace ramses_amd

@@ -106,6 +106,8 @@ subroutine godunov_fine(ilevel)
   ! several MPI ranks (each sweeps its own active octs; ghost octs of the other ranks are
   ! ordinary neighbours in the tree) and physical boundary octs: the tree-walking sweep
   if(ncpu>1.or.nboundary>0)amr_level=.true.
+  ! the dense brick entry points cover a box with nx=ny=nz=1; other coarse grids walk the tree
+  if(nx_loc/=1.or.jcoarse_max/=jcoarse_min.or.kcoarse_max/=kcoarse_min)amr_level=.true.
   ! artificial diffusion (cmpdivu + consup) is implemented in the tree-walking sweep only
   if(difmag>0.0d0)amr_level=.true.
   ! so are the divu/enew updates of pressure_fix

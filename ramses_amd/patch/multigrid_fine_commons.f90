@@ -39,6 +39,7 @@ subroutine multigrid_fine(ilevel,icount)
      return
   end if
   if(verbose) print '(A,I2)','Entering fine multigrid (MI355X) at level ',ilevel
+  call ramses_amd_need_ndim3('multigrid_fine')
 
   ! An AMR level (it does not cover the box, or it is not levelmin): the reference's own
   ! driver and per-solve setup run on the host, the compute routines it calls (shadowed by
@@ -46,7 +47,8 @@ subroutine multigrid_fine(ilevel,icount)
   ! (a box with physical boundaries: the Dirichlet values enter through the masks and the
   !  right-hand side the reference prepares, so every level takes this path)
   nx_loc=icoarse_max-icoarse_min+1
-  if(ilevel>levelmin.or.nboundary>0.or.int(active(ilevel)%ngrid,8)*8_8/=(2_8**ilevel)**3*int(nx_loc,8)**3)then
+  if(ilevel>levelmin.or.nboundary>0.or.nx_loc/=1.or.jcoarse_max/=jcoarse_min.or.kcoarse_max/=kcoarse_min &
+       & .or.int(active(ilevel)%ngrid,8)*8_8/=(2_8**ilevel)**3*int(nx_loc,8)**3)then
      if(ncpu>1)then
         write(*,*)'ramses_amd: device multigrid on AMR levels handles single-rank runs; got ncpu=',ncpu
         call ramses_amd_fatal('multigrid_fine (AMR level: several ranks)')

@@ -40,6 +40,7 @@ subroutine phi_fine_cg(ilevel,icount)
      return
   end if
   if(verbose)write(*,111)ilevel
+  call ramses_amd_need_ndim3('phi_fine_cg')
 
   ! What the device path does not implement stops the run (no silent fallback)
   if(ncpu>1)then

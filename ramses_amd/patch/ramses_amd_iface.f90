@@ -299,12 +299,44 @@ contains
           if (rc /= 0) call ramses_amd_fatal('ramses_amd_abi_check')
           rc = ramses_amd_set_device_auto(ramses_amd_world_rank())
           if (rc /= 0) call ramses_amd_fatal('ramses_amd_set_device_auto')
+          call ramses_amd_check_build()
           call ramses_amd_pin_arrays()
        end if
        ramses_amd_checked = .true.
     end if
     ramses_amd_enabled = ramses_amd_on
   end function ramses_amd_enabled
+
+  !---------------------------------------------------------------------------
+  ! What the build must look like for the device hydro path: NENER=0.  With non-thermal
+  ! energies the reference folds them into the pressure in ctoprim, cmpdt, the Riemann
+  ! solvers and set_uold (hydro/godunov_fine.f90:83,166,214; hydro/umuscl.f90;
+  ! hydro/godunov_utils.f90:40-79); the device kernels would treat variables 6.. as
+  ! passive scalars.  Stop instead (RAMSES_AMD=0 runs the reference path).
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_check_build()
+    use amr_commons, only: hydro
+    use hydro_parameters, only: nener
+    if (hydro .and. nener > 0) then
+       write(*,*) 'ramses_amd: this binary was built with NENER=', nener, &
+            & ' (non-thermal energies); the device hydro path implements NENER=0 only'
+       call ramses_amd_fatal('build check (NENER>0)')
+    end if
+  end subroutine ramses_amd_check_build
+
+  !---------------------------------------------------------------------------
+  ! The Poisson entry points of the C ABI hard-code the 3-D tree layout
+  ! (ncell = ncoarse+8*ngridmax, nbor(1:ngridmax,1:6)): a NDIM=1/2 build must
+  ! take the reference routines with RAMSES_AMD=0.
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_need_ndim3(where)
+    use amr_parameters, only: ndim
+    character(len=*), intent(in) :: where
+    if (ndim /= 3) then
+       write(*,*) 'ramses_amd: ', where, ' on the device needs an NDIM=3 build (this one has NDIM=', ndim, ')'
+       call ramses_amd_fatal(where)
+    end if
+  end subroutine ramses_amd_need_ndim3
 
   !---------------------------------------------------------------------------
   ! Page-lock the module arrays the staged entry points copy from and to (allocated once,
@@ -317,7 +349,7 @@ contains
     use poisson_commons
     integer :: rc
     integer(c_int64_t) :: nc
-    nc = int(ncoarse, 8) + 8_8 * int(ngridmax, 8)
+    nc = int(ncoarse, 8) + int(twotondim, 8) * int(ngridmax, 8)
     if (hydro) then
        if (allocated(uold)) rc = ramses_amd_host_register_dp(uold, nc * int(size(uold, 2), 8) * 8_8)
        if (allocated(unew)) rc = ramses_amd_host_register_dp(unew, nc * int(size(unew, 2), 8) * 8_8)
@@ -393,6 +425,9 @@ contains
     use amr_commons
     use hydro_parameters
     use poisson_parameters, only: gravity_type
+#if USE_TURB==1
+    use turb_commons, only: turb
+#endif
     character(len=16) :: val
     integer :: stat
     if (.not. ramses_amd_res_checked) then
@@ -419,6 +454,13 @@ contains
        if (pressure_fix .or. T2_star > 0.0d0 .or. momentum_feedback > 0 .or. strict_equilibrium > 0) &
             & ramses_amd_res_on = .false.
        if (ndim /= 3) ramses_amd_res_on = .false.
+       ! the dense brick entry points cover a box with nx=ny=nz=1
+       if (icoarse_max - icoarse_min /= 0 .or. jcoarse_max - jcoarse_min /= 0 .or. kcoarse_max - kcoarse_min /= 0) &
+            & ramses_amd_res_on = .false.
+#if USE_TURB==1
+       ! the turbulent forcing (calc_turb_forcing / synchro_hydro_fine(...,2)) is host code on uold
+       if (turb) ramses_amd_res_on = .false.
+#endif
        ramses_amd_res_checked = .true.
        if (ramses_amd_res_on .and. myid == 1) &
             & write(*,*) 'ramses_amd: hydro state of level ', levelmin, ' stays resident on the GPU'

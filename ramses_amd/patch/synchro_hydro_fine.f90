@@ -14,6 +14,9 @@ subroutine synchro_hydro_fine(ilevel,dteff,which_force)
   use amr_commons
   use hydro_commons
   use poisson_commons
+#if USE_TURB==1
+  use turb_commons
+#endif
   use ramses_amd_iface
   implicit none
   integer::ilevel
@@ -27,9 +30,15 @@ subroutine synchro_hydro_fine(ilevel,dteff,which_force)
   type(ramses_amd_hydro_params)::p
   integer::rc,nx_loc
 
+  ! the reference's own early returns (hydro/synchro_hydro_fine.f90:21-26): a USE_TURB=1 build
+  ! also enters for the turbulent forcing (which_force=2) without self-gravity
+#if USE_TURB==1
+  if(.not.(poisson.or.turb))return
+#else
   if(.not.poisson)return
   if(numbtot(1,ilevel)==0)return
-  if(which_force/=1.or..not.ramses_amd_resident())then
+#endif
+  if(which_force/=1.or..not.poisson.or..not.ramses_amd_resident())then
      call synchro_hydro_fine_reference(ilevel,dteff,which_force)
      return
   end if

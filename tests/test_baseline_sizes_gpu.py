@@ -1,0 +1,148 @@
+"""GPU tests at the sizes BASELINE.json quotes.
+
+1. The fast-arithmetic build of the sweep (FMA contraction, rcp/rsq + Newton, fused LLF)
+   against the strict build (bit-identical to the reference): >= 20 steps of sedov3d.nml at
+   64^3 and 128^3, both paths stepping on their own CFL dt like a namelist run, relative
+   L-infinity on rho, rho*u, rho*v, rho*w and E checked at EVERY step against north_star's
+   1e-12.  This is what certifies (or refuses) `config.arithmetic` of the bench line.
+2. Live A/B of the two reference builds on the GPU box: oracle/_ref/ramses3d_mpi (untouched
+   reference, MPI on the host cores) vs oracle/_ref/ramses3d_patch (the same program with
+   ramses_amd/patch, level resident on the GPU) on sedov3d.nml as shipped (nstepmax=10) at
+   128^3 and 256^3 (config C2): the assembled level must be equal bit for bit.
+3. Config C4 stand-in at 128^3 (hydro + self-gravity, three coarse steps) and config C5 at
+   levels 7-9 through the patched program against checksums of the serial reference
+   (tests/golden/baseline_sizes.json, made by tests/golden/make_golden_baseline.py).
+"""
+import importlib.util
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_MPI = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi")
+PATCHED = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch")
+GOLD = os.path.join(ROOT, "tests", "golden", "baseline_sizes.json")
+TOL = 1e-12     # north_star: "results within 1e-12 relative L-infinity of the F90 reference"
+
+
+def _mkb():
+    spec = importlib.util.spec_from_file_location("mkb", os.path.join(ROOT, "tests", "golden", "make_golden_baseline.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _rel_linf_per_var(a, b):
+    """max |a-b| / max |b| for every variable; the three momenta share one scale (|rho v| of the blast)"""
+    out = []
+    mom_scale = max(np.abs(b[1:4]).max(), 1e-300)
+    for n in range(a.shape[0]):
+        scale = mom_scale if 1 <= n <= 3 else max(np.abs(b[n]).max(), 1e-300)
+        out.append(np.abs(a[n] - b[n]).max() / scale)
+    return np.array(out)
+
+
+@pytest.mark.parametrize("n,nsteps", [(64, 24), (128, 24)])
+def test_fast_build_multistep_within_tolerance(gpu_lib, n, nsteps):
+    import ramses_amd
+    from ramses_amd import ic
+    from ramses_amd.hydro import HydroLevel
+    u, dx = ic.sedov3d(n)
+    strict = HydroLevel(n, n, n, dx, params=ramses_amd.make_params(courant_factor=0.8, fast_math=0))
+    fast = HydroLevel(n, n, n, dx, params=ramses_amd.make_params(courant_factor=0.8, fast_math=1))
+    strict.upload(u)
+    fast.upload(u)
+    worst = np.zeros(5)
+    for step in range(nsteps):
+        dts = strict.courant_fine()[0]
+        dtf = fast.courant_fine()[0]
+        assert abs(dtf - dts) <= TOL * dts, (step, dts, dtf)
+        strict.step(dts)
+        fast.step(dtf)
+        err = _rel_linf_per_var(fast.download(), strict.download())
+        worst = np.maximum(worst, err)
+        assert (err <= TOL).all(), "step %d: rel-Linf (rho, mx, my, mz, E) = %s" % (step + 1, err)
+    print("fast vs strict, %d^3, %d steps: worst rel-Linf per variable %s" % (n, nsteps, worst))
+
+
+def _nproc():
+    n = os.cpu_count() or 1
+    p = 1
+    while p * 2 <= min(n, 32):
+        p *= 2
+    return p
+
+
+@pytest.mark.parametrize("level", [7, 8])
+def test_live_reference_ab_c2(gpu_lib, level):
+    """sedov3d.nml as shipped (LLF + minmod, nstepmax=10) at 128^3 / 256^3: the untouched reference
+    under MPI on the host cores vs the patched program with the level resident on the GPU."""
+    if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED)):
+        pytest.skip("oracle/_ref/ramses3d_mpi / ramses3d_patch not built")
+    from oracle import ramses_snapshot as rs
+    nproc = _nproc()
+    nml = rs.sedov3d_namelist(level=level, nstepmax=10, foutput=10, mem_factor=1.3)
+    os.environ["RAMSES_AMD"] = "1"
+    workp, outp = rs.run_reference(nml, binary=PATCHED)
+    try:
+        assert "stays resident on the GPU" in outp
+        got = rs.load_uniform_level(os.path.join(workp, "output_00002"), level)
+    finally:
+        shutil.rmtree(workp, ignore_errors=True)
+    nml_mpi = rs.sedov3d_namelist(level=level, nstepmax=10, foutput=10, mem_factor=3.0 if nproc > 1 else 1.3)
+    workr, outr = rs.run_reference(nml_mpi, binary=REF_MPI, nproc=nproc)
+    try:
+        ref = rs.load_uniform_level(os.path.join(workr, "output_00002"), level)
+    finally:
+        shutil.rmtree(workr, ignore_errors=True)
+    assert got["info"]["t"] == ref["info"]["t"]
+    assert np.array_equal(got["prim"], ref["prim"]), np.abs(got["prim"] - ref["prim"]).max()
+
+
+def test_c4_standin_128_checksum(gpu_lib):
+    """config C4 stand-in at 128^3: three coarse steps of hydro + self-gravity through the patched
+    program (level resident: multigrid_fine, force_fine, rho_fine, synchro_hydro_fine, the gravity terms of
+    courant_fine / godunov_fine / set_uold) == the serial reference, by checksum of (prim, phi, f)."""
+    if not os.path.exists(PATCHED) or not os.path.exists(GOLD):
+        pytest.skip("patched program or golden checksums missing")
+    gold = json.load(open(GOLD)).get("c4_128")
+    if gold is None:
+        pytest.skip("no c4_128 checksum")
+    from oracle import ramses_snapshot as rs
+    mkb = _mkb()
+    os.environ["RAMSES_AMD"] = "1"
+    work, out = rs.run_reference(mkb.c4_namelist(), binary=PATCHED)
+    try:
+        assert "stays resident on the GPU" in out
+        assert mkb.solves(out) == gold["solves"]
+        snap = rs.load_uniform_level(os.path.join(work, "output_00002"), 7, with_grav=True)
+        assert snap["info"]["t"] == gold["t"]
+        assert snap["info"]["rho_tot"] == gold["rho_tot"]
+        assert mkb.digest_uniform(snap) == gold["sha256"]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def test_c5_levels_7_9_checksum(gpu_lib):
+    """config C5 at levels 7-9 (8 coarse steps, ~2.3 M leaf cells): the tree-walking sweep on every
+    level, with sub-cycling and regridding, == the serial reference by checksum of the sorted leaf data."""
+    if not os.path.exists(PATCHED) or not os.path.exists(GOLD):
+        pytest.skip("patched program or golden checksums missing")
+    gold = json.load(open(GOLD)).get("c5_79")
+    if gold is None:
+        pytest.skip("no c5_79 checksum")
+    from oracle import ramses_snapshot as rs
+    mkb = _mkb()
+    os.environ["RAMSES_AMD"] = "1"
+    work, out = rs.run_reference(mkb.c5_namelist(), binary=PATCHED)
+    try:
+        snap = rs.load_leaf_cells(os.path.join(work, "output_00002"))
+        assert [int((snap["level"] == l).sum()) for l in (7, 8, 9)] == gold["ncell"]
+        assert snap["info"]["t"] == gold["t"]
+        assert mkb.digest_leaves(snap) == gold["sha256"]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
