@@ -240,6 +240,30 @@ def pick_transport(rank, world, timeout):
     flag = torch.tensor([ok], dtype=torch.int32)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=gloo)
     if int(flag.item()) == 1:
+        # RCCL works on this node: move the neighbour exchange behind the C ABI (the library's own RCCL
+        # communicator, the entry the Fortran drop-in uses), with the same self-test; torch's RCCL
+        # send/recv remains the fallback
+        ok2, why2, tr2 = 1, "", None
+        if os.environ.get("RAMSES_AMD_BENCH_TRANSPORT", "capi") == "capi":
+            try:
+                from ramses_amd.transport import RcclTransport
+                tr2 = RcclTransport()
+                recv = torch.zeros(1024, dtype=torch.float64, device="cuda")
+                send = torch.full((1024,), float(rank), dtype=torch.float64, device="cuda")
+                tr2.sendrecv([(send, (rank + 1) % world)], [(recv, (rank - 1) % world)])
+                torch.cuda.synchronize()
+                if float(recv[0].item()) != (rank - 1) % world:
+                    ok2, why2 = 0, "wrong data"
+            except Exception as exc:     # noqa: BLE001
+                ok2, why2 = 0, str(exc)[:160]
+        else:
+            ok2, why2 = 0, "disabled by RAMSES_AMD_BENCH_TRANSPORT"
+        flag2 = torch.tensor([ok2], dtype=torch.int32)
+        dist.all_reduce(flag2, op=dist.ReduceOp.MIN, group=gloo)
+        if int(flag2.item()) == 1:
+            return tr2, "RCCL send/recv behind the C ABI (ramses_amd_rccl_sendrecv, the library's own communicator)"
+        if why2:
+            sys.stderr.write("bench.py rank %d: C-ABI RCCL transport not used: %s\n" % (rank, why2))
         return DistTransport(), None
     if why:
         sys.stderr.write("bench.py rank %d: RCCL self-test failed: %s\n" % (rank, why))
@@ -406,7 +430,7 @@ def main():
                                    % (n, pgrid[0], pgrid[1], pgrid[2], n * pgrid[0], n * pgrid[1], n * pgrid[2]),
                        "arithmetic": "fast (FMA contraction, <=1e-12 rel of strict)" if args.fast else "strict (bit-identical to the reference)",
                        "halo": "none (single rank, in-kernel periodic wrap)" if world == 1 else
-                               ("RCCL send/recv" if transport_note is None else transport_note) +
+                               ("RCCL send/recv (torch.distributed)" if transport_note is None else transport_note) +
                                " of 2-cell face slabs, all nvar fused, " +
                                "one grouped exchange of all 26 neighbour regions (one message per peer), " +
                                ("overlapped with the interior sweep on a second stream" if overlap else "after the sweep") +

@@ -480,6 +480,78 @@ int ramses_amd_resident_set_uold_f90(int ilevel);
 int ramses_amd_resident_sync_host_f90(double *uold);
 int ramses_amd_resident_invalidate(void);
 
+/* ---------------------------------------------------------------------------
+ * MPI: one rank per GPU.  The virtual-boundary exchange on the device.
+ *
+ * Transport: neighbour send/recv over xGMI with RCCL.  librccl.so is loaded on first use; the
+ * communicator is bootstrapped by the caller's own launcher: rank 0 calls ramses_amd_rccl_unique_id,
+ * broadcasts the 128 bytes (the Fortran shim: MPI_BCAST; the Python mirror: torch.distributed), every
+ * rank calls ramses_amd_rccl_init after selecting its device (ramses_amd_set_device_auto).
+ * ramses_amd_rccl_exchange: ONE grouped ncclSend/ncclRecv, message i to/from rank peer[i], offsets and
+ * counts in doubles into device buffers (replaces the MPI_ISEND/MPI_IRECV rounds of make_virtual_fine_dp,
+ * amr/virtual_boundaries.f90:373-528, with all nvar fields fused).  ramses_amd_rccl_allreduce: in-place
+ * reduction of n device doubles, op 0 sum / 1 min / 2 max (courant_fine's MPI_ALLREDUCE,
+ * hydro/courant_fine.f90:133-140; multigrid norms; CG dot products).
+ * ------------------------------------------------------------------------- */
+#define RAMSES_AMD_RCCL_ID_BYTES 128
+/* equal for two processes exactly when they drive the same GPU of the same host (RCCL refuses that) */
+int ramses_amd_device_uid(int64_t *uid);
+int ramses_amd_rccl_unique_id(char *id128);
+int ramses_amd_rccl_init(const char *id128, int nranks, int rank);
+int ramses_amd_rccl_ready(void);
+int ramses_amd_rccl_finalize(void);
+int ramses_amd_rccl_exchange(int npeer, const int *peer, const double *d_send, const int64_t *send_off,
+                             const int64_t *send_cnt, double *d_recv, const int64_t *recv_off,
+                             const int64_t *recv_cnt, void *stream);
+/* one pointer per message: send i to send_peer[i], receive i from recv_peer[i] (per peer in posting order) */
+int ramses_amd_rccl_sendrecv(int nsend, const double *const *send_ptr, const int64_t *send_cnt, const int *send_peer,
+                             int nrecv, double *const *recv_ptr, const int64_t *recv_cnt, const int *recv_peer, void *stream);
+int ramses_amd_rccl_allreduce(double *d_buf, int n, int op, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Device image of the reference's communicators (type communicator, amr/amr_commons.f90:108-119;
+ * emission(:,l) / reception(:,l) built by build_comm, amr/virtual_boundaries.f90:1286-1648) for one
+ * rank's share of a fully refined periodic level: a box of octs, stored as a brick with a one-oct
+ * ghost layer.  Lists are passed concatenated over icpu = 1..ncpu: em_ngrid[ncpu] / rc_ngrid[ncpu] =
+ * emission(icpu,l)%ngrid / reception(icpu,l)%ngrid, em_igrid / rc_igrid = the %igrid arrays one after
+ * the other (1-based oct slots).
+ * ramses_amd_halo_plan: host-side only (no device needed): the box {olo[3], odim[3] in octs, self_axes
+ *   (bit d: direction d spans the whole box: periodic self-copy instead of a peer), number of ghost
+ *   positions} and the brick offsets of every list entry.  Fails when the rank's octs do not fill a box
+ *   or the reception lists do not cover the one-oct shell around it.
+ * ------------------------------------------------------------------------- */
+int ramses_amd_halo_plan(int ilevel, int ngrid, const int *igrid, const double *xg, int64_t ngridmax, int ncpu,
+                         const int *em_ngrid, const int *em_igrid, const int *rc_ngrid, const int *rc_igrid,
+                         int *out_box, int64_t *act_org, int64_t *em_org, int *rc_src, int64_t *rc_org, int64_t rc_cap);
+
+/* Device-resident level under MPI (hydro): the routines of amr_step that touch uold/unew of the level,
+ *   ramses_amd_mpires_setup         load (active + ghost octs) from the host arrays uold/unew(1:ncell,1:nvar)
+ *   ramses_amd_mpires_courant       courant_fine: out4 = local {dt, mass, sum E vol, eint}; the caller reduces over ranks
+ *   ramses_amd_mpires_godunov       set_unew + godunov_fine           hydro/godunov_fine.f90:5-130
+ *   ramses_amd_mpires_reverse_unew  make_virtual_reverse_dp(unew(1,1:nvar),l)   amr/virtual_boundaries.f90:693-983
+ *   ramses_amd_mpires_set_uold      set_uold (buffer swap)            hydro/godunov_fine.f90:135-232
+ *   ramses_amd_mpires_halo_forward  make_virtual_fine_dp(uold(1,1:nvar),l) over RCCL   :373-528
+ *   ramses_amd_mpires_halo_stage_out / _stage_in   the same with the caller's MPI as transport (pinned host buffers)
+ *   ramses_amd_mpires_which         +ivar / -ivar when xx is uold(1,ivar) / unew(1,ivar) of the level, else 0
+ *   ramses_amd_mpires_sync_host     host array refreshed on demand (backup_hydro)
+ * ------------------------------------------------------------------------- */
+int ramses_amd_mpires_setup(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, const double *xg,
+                            int64_t ngridmax, int64_t ncoarse, int nx_loc, const double *uold, const double *unew,
+                            int ncpu, int myid, const int *em_ngrid, const int *em_igrid, const int *rc_ngrid,
+                            const int *rc_igrid);
+int ramses_amd_mpires_active(void);
+int ramses_amd_mpires_which(const double *xx);
+int ramses_amd_mpires_courant(const ramses_amd_hydro_params *p, double dx, double dt_in, double *out4);
+int ramses_amd_mpires_godunov(const ramses_amd_hydro_params *p, double dx, double dt);
+int ramses_amd_mpires_reverse_unew(void);
+int ramses_amd_mpires_set_uold(void);
+int ramses_amd_mpires_halo_forward(void);
+int ramses_amd_mpires_halo_stage_out(double **h_send, const int64_t **send_off, double **h_recv, const int64_t **recv_off);
+int ramses_amd_mpires_halo_stage_out_f90(int64_t *h_send_addr, int64_t *h_recv_addr, int64_t *send_off, int64_t *recv_off, int ncpu);
+int ramses_amd_mpires_halo_stage_in(void);
+int ramses_amd_mpires_sync_host(double *uold);
+int ramses_amd_mpires_invalidate(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,29 @@ SYMBOLS = [
     ("ramses_amd_resident_set_uold_f90", _i, [_i]),
     ("ramses_amd_resident_sync_host_f90", _i, [_vp]),
     ("ramses_amd_resident_invalidate", _i, []),
+    # MPI: one rank per GPU
+    ("ramses_amd_device_uid", _i, [_vp]),
+    ("ramses_amd_rccl_unique_id", _i, [_vp]),
+    ("ramses_amd_rccl_init", _i, [_vp, _i, _i]),
+    ("ramses_amd_rccl_ready", _i, []),
+    ("ramses_amd_rccl_finalize", _i, []),
+    ("ramses_amd_rccl_exchange", _i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("ramses_amd_rccl_sendrecv", _i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    ("ramses_amd_rccl_allreduce", _i, [_vp, _i, _i, _vp]),
+    ("ramses_amd_halo_plan", _i, [_i, _i, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+    ("ramses_amd_mpires_setup", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    ("ramses_amd_mpires_active", _i, []),
+    ("ramses_amd_mpires_which", _i, [_vp]),
+    ("ramses_amd_mpires_courant", _i, [_PP, _d, _d, _vp]),
+    ("ramses_amd_mpires_godunov", _i, [_PP, _d, _d]),
+    ("ramses_amd_mpires_reverse_unew", _i, []),
+    ("ramses_amd_mpires_set_uold", _i, []),
+    ("ramses_amd_mpires_halo_forward", _i, []),
+    ("ramses_amd_mpires_halo_stage_out", _i, [_vp, _vp, _vp, _vp]),
+    ("ramses_amd_mpires_halo_stage_out_f90", _i, [_vp, _vp, _vp, _vp, _i]),
+    ("ramses_amd_mpires_halo_stage_in", _i, []),
+    ("ramses_amd_mpires_sync_host", _i, [_vp]),
+    ("ramses_amd_mpires_invalidate", _i, []),
 ]
 
 

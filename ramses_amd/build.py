@@ -31,6 +31,7 @@ UNITS = [
     ("mg_amr.o", "mg_amr.hip", ["-ffp-contract=off"]),
     ("cg_amr.o", "cg_amr.hip", ["-ffp-contract=off"]),
     ("capi.o", "capi.hip", ["-ffp-contract=off"]),
+    ("capi_mpi.o", "capi_mpi.hip", ["-ffp-contract=off"]),
 ]
 
 
@@ -84,7 +85,7 @@ def build(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 2)) as ex:
             list(ex.map(run, jobs))
     if jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

@@ -77,6 +77,8 @@ static int check_brick(const ramses_amd_brick *b) {
 extern "C" {
 
 const char *ramses_amd_last_error(void) { return g_err; }
+// for the other translation units of the library (capi_mpi.hip)
+int ramses_amd_set_error(int code, const char *msg) { return fail(code, "%s", msg ? msg : ""); }
 
 int ramses_amd_abi_check(size_t sizeof_hydro_params, size_t sizeof_brick) {
   if (sizeof_hydro_params != sizeof(ramses_amd_hydro_params) || sizeof_brick != sizeof(ramses_amd_brick))

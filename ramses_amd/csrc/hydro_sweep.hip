@@ -38,6 +38,15 @@ namespace ramses_amd {
 #ifndef RAMSES_AMD_SWEEP_BARRIERS
 #define RAMSES_AMD_SWEEP_BARRIERS 1   // 1: merged, double-buffered y exchange (one barrier per plane); 2: the older loop
 #endif
+#ifndef RAMSES_AMD_SWEEP_CLAMP
+#define RAMSES_AMD_SWEEP_CLAMP 0
+#endif
+#ifndef RAMSES_AMD_SWEEP_LATE_UCUR
+#define RAMSES_AMD_SWEEP_LATE_UCUR 0
+#endif
+#ifndef RAMSES_AMD_SWEEP_PREFETCH
+#define RAMSES_AMD_SWEEP_PREFETCH 0   // where plane c+2 is requested: 0 start of the iteration, 1 before the barrier, 2 after it
+#endif
 
 namespace SWEEP_NS {
 
@@ -224,8 +233,18 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
   __syncthreads();
 
+  // Neighbour columns by constant offsets from the thread's own LDS address (one address register,
+  // immediate offsets).  Lanes 0 and 63 and a tile's first and last row then read a neighbouring row,
+  // variable or nothing at all (out-of-range LDS reads return 0): whatever they compute from it stays in
+  // the two halo columns / rows, which are never stored (rows 0 and BY-1 take no slopes, lanes 0, 1, 62, 63
+  // own no cell, and the x flux an owned cell uses reaches two lanes at most).
+#if RAMSES_AMD_SWEEP_CLAMP
   const int txm = max(tx - 1, 0), txp = min(tx + 1, BX - 1);
   const int tym = max(ty - 1, 0), typ = min(ty + 1, BY - 1);
+#else
+  const int txm = tx - 1, txp = tx + 1;
+  const int tym = ty - 1, typ = ty + 1;
+#endif
 
 #if RAMSES_AMD_SWEEP_BARRIERS == 1
   // ---- ONE barrier per plane --------------------------------------------------------------
@@ -238,7 +257,8 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   // order per cell: ((u + (fx- - fx+)) + (fy- - fy+)) + (fz- - fz+).
   Plane<BY, NV> *mring = smy;            // [2]: smy and fyb of the two-barrier loop, merged
   double partx[NV];                      // u + x flux difference of plane c-1
-  double fyown[NV];                      // y flux through the -y face of plane c-1 (this row's own)
+  double fyown[NV];                      // y flux through the -y face of plane c-1 (computed by this row; its copy
+                                         // in slot ty-1 belongs to row ty-1, which reuses the slot without a barrier)
   double rnew = 0.0, snew[NV > 5 ? NV - 5 : 1];
 #pragma unroll
   for (int n = 0; n < NV; n++) { partx[n] = 0.0; fyown[n] = 0.0; }
@@ -252,8 +272,12 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #pragma unroll
     for (int n = 0; n < NV; n++) qring[sc].v[n][ty][tx] = qc[n];
     double ucur[NV];
+#if RAMSES_AMD_SWEEP_PREFETCH == 0
     { const int pn = min(c + 2, z1 + 1); load_u(pn, upre); load_g(pn, gpre); }
+#endif
+#if !RAMSES_AMD_SWEEP_LATE_UCUR
     if (r_fxz) load_u(c, ucur);
+#endif
 
     double qpy[NV], dz[NV], px[NV];
     if (ST == 3) __syncthreads();  // the 27-point slope reads the neighbours' plane c+1 just written
@@ -307,6 +331,13 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
       for (int n = 0; n < NV; n++) qpy[n] = qp[1][n];
       if constexpr (r_fxz) {
         double qL[NV], fx[NV], fz[NV];
+#if RAMSES_AMD_SWEEP_LATE_UCUR
+        // the conserved state of plane c (an L2 hit) is requested only now, behind the register
+        // peak of the tracing, and arrives while the two fluxes are computed
+        __builtin_amdgcn_sched_barrier(0);
+        load_u(c, ucur);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int n = 0; n < NV; n++) qL[n] = wave_shr1(qm[0][n]);  // +x state of column tx-1
         scaled_interface_flux<RS, NV, 0>(qL, qp[0], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fx);
@@ -327,7 +358,16 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
         }
       }
     }
+#if RAMSES_AMD_SWEEP_PREFETCH == 1
+    // prefetch plane c+2 after the register peak of the trace and flux phase (still ~1 us ahead of its use)
+    __builtin_amdgcn_sched_barrier(0);
+    { const int pn = min(c + 2, z1 + 1); load_u(pn, upre); load_g(pn, gpre); }
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     __syncthreads();  // the one barrier: +y states of plane c and y fluxes of plane c-1 visible
+#if RAMSES_AMD_SWEEP_PREFETCH == 2
+    { const int pn = min(c + 2, z1 + 1); load_u(pn, upre); load_g(pn, gpre); }
+#endif
 
     // ---- phase B: y flux of plane c; finish plane c-1 --------------------------------
     double fy[NV];

@@ -44,13 +44,14 @@ __global__ __launch_bounds__(256) void oct_origin_kernel(const int *__restrict__
 template <bool GATHER>
 __global__ __launch_bounds__(256) void oct_copy_kernel(PackArgs A) {
   const long total = (long)A.ngrid * 8;
+  const long py = A.pitch_y ? A.pitch_y : (long)A.n, pz = A.pitch_z ? A.pitch_z : (long)A.n * A.n;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     // consecutive threads walk consecutive octs of one octant: the cell-vector
     // side is then contiguous whenever the oct list is (it is after defrag)
     const int ind = (int)(t / A.ngrid);
     const int g = (int)(t % A.ngrid);
     const long icell = A.ncoarse + (long)ind * A.ngridmax + (A.igrid[g] - 1);  // 0-based
-    const long b = A.octorg[g] + (ind & 1) + (long)A.n * (((ind >> 1) & 1) + (long)A.n * ((ind >> 2) & 1));
+    const long b = A.octorg[g] + (ind & 1) + py * ((ind >> 1) & 1) + pz * ((ind >> 2) & 1);
     for (int v = 0; v < A.nvar; v++) {
       if (GATHER) A.brick[b + (long)v * A.pitch_var] = A.cellvec[icell + (long)v * A.ncell];
       else A.cellvec[icell + (long)v * A.ncell] = A.brick[b + (long)v * A.pitch_var];

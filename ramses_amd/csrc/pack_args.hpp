@@ -11,6 +11,7 @@ struct PackArgs {
   const long *octorg;     // brick index of each oct's (0,0,0) cell
   int ngrid, n, nvar;
   long ncoarse, ngridmax, ncell, pitch_var;
+  long pitch_y = 0, pitch_z = 0;   // 0: dense n^3 brick (pitch_y = n, pitch_z = n*n)
 };
 
 hipError_t launch_oct_origin(const int *igrid, const double *xg, long ngridmax, int ngrid, int n,

@@ -16,6 +16,7 @@ subroutine courant_fine(ilevel)
   use amr_commons
   use hydro_commons
   use poisson_commons
+  use mpi_mod
   use ramses_amd_iface
   implicit none
   integer::ilevel
@@ -23,8 +24,35 @@ subroutine courant_fine(ilevel)
   integer::rc,nx_loc
   real(dp)::scale,dx
   real(kind=8),dimension(4)::out4
+#ifndef WITHOUTMPI
+  integer::info
+  real(kind=8),dimension(3)::comm_buffin,comm_buffout
+  real(kind=8)::dt_all
+#endif
 
   if(numbtot(1,ilevel)==0)return
+#ifndef WITHOUTMPI
+  if(ramses_amd_mpi_resident())then
+     ! one brick per rank on its GPU: local reduction on the device, then the reference's own
+     ! reductions over the ranks (hydro/courant_fine.f90:133-140)
+     if(verbose)write(*,111)ilevel
+     call ramses_amd_mpires_ensure()
+     call ramses_amd_fill_hydro_params(p)
+     nx_loc=icoarse_max-icoarse_min+1
+     scale=boxlen/dble(nx_loc)
+     dx=0.5D0**ilevel*scale
+     rc=ramses_amd_mpires_courant(p,dx,dtnew(ilevel),out4)
+     if(rc/=0)call ramses_amd_fatal('courant_fine')
+     comm_buffin(1:3)=out4(2:4)
+     call MPI_ALLREDUCE(comm_buffin,comm_buffout,3,MPI_DOUBLE_PRECISION,MPI_SUM,MPI_COMM_WORLD,info)
+     call MPI_ALLREDUCE(out4(1),dt_all,1,MPI_DOUBLE_PRECISION,MPI_MIN,MPI_COMM_WORLD,info)
+     mass_tot=mass_tot+comm_buffout(1)
+     ekin_tot=ekin_tot+comm_buffout(2)
+     eint_tot=eint_tot+comm_buffout(3)
+     dtnew(ilevel)=MIN(dtnew(ilevel),dt_all)
+     return
+  end if
+#endif
   if(.not.ramses_amd_resident())then
      call courant_fine_reference(ilevel)
      return

@@ -32,6 +32,7 @@ subroutine set_unew(ilevel)
   integer::ilevel
   if(numbtot(1,ilevel)==0)return
   if(ramses_amd_resident())return
+  if(ramses_amd_mpi_resident())return
   call set_unew_reference(ilevel)
 end subroutine set_unew
 
@@ -51,6 +52,11 @@ subroutine set_uold(ilevel)
      else
         rc=ramses_amd_resident_set_uold_f90(ilevel)
      end if
+     if(rc/=0)call ramses_amd_fatal('set_uold')
+     return
+  end if
+  if(ramses_amd_mpi_resident())then
+     rc=ramses_amd_mpires_set_uold()
      if(rc/=0)call ramses_amd_fatal('set_uold')
      return
   end if
@@ -94,6 +100,17 @@ subroutine godunov_fine(ilevel)
   nx_loc=icoarse_max-icoarse_min+1
   scale=boxlen/dble(nx_loc)
   dx=0.5d0**ilevel*scale
+
+#ifndef WITHOUTMPI
+  ! MPI, one rank per GPU: the dense sweep on the rank's resident brick (ghost layer kept current
+  ! by the device halo exchange, virtual_boundaries.f90 of this directory)
+  if(ramses_amd_mpi_resident())then
+     call ramses_amd_mpires_ensure()
+     rc=ramses_amd_mpires_godunov(p,dx,dtnew(ilevel))
+     if(rc/=0)call ramses_amd_fatal('godunov_fine')
+     return
+  end if
+#endif
 
   ! A level with refined cells, or one that does not cover the box, takes the AMR
   ! sweep (one wavefront per oct on the tree arrays); a fully refined level without

@@ -21,6 +21,10 @@ subroutine backup_hydro(filename, filename_desc)
   if(ramses_amd_enabled())then
      rc=ramses_amd_resident_sync_host_f90(uold)
      if(rc/=0)call ramses_amd_fatal('backup_hydro (sync of the resident level)')
+     if(ramses_amd_mpi_on)then
+        rc=ramses_amd_mpires_sync_host(uold)
+        if(rc/=0)call ramses_amd_fatal('backup_hydro (sync of the resident bricks)')
+     end if
   end if
   call backup_hydro_reference(filename, filename_desc)
 end subroutine backup_hydro

@@ -268,6 +268,100 @@ module ramses_amd_iface
        real(c_double) :: uold(*)
        integer(c_int) :: rc
      end function ramses_amd_resident_sync_density_f90
+     ! ---- MPI: one rank per GPU (include/ramses_amd.h) ----
+     function ramses_amd_device_uid(uid) bind(C, name='ramses_amd_device_uid') result(rc)
+       import :: c_int, c_int64_t
+       integer(c_int64_t) :: uid
+       integer(c_int) :: rc
+     end function ramses_amd_device_uid
+     function ramses_amd_rccl_unique_id(id) bind(C, name='ramses_amd_rccl_unique_id') result(rc)
+       import :: c_int, c_char
+       character(kind=c_char) :: id(128)
+       integer(c_int) :: rc
+     end function ramses_amd_rccl_unique_id
+     function ramses_amd_rccl_init(id, nranks, rank) bind(C, name='ramses_amd_rccl_init') result(rc)
+       import :: c_int, c_char
+       character(kind=c_char) :: id(128)
+       integer(c_int), value :: nranks, rank
+       integer(c_int) :: rc
+     end function ramses_amd_rccl_init
+     function ramses_amd_rccl_finalize() bind(C, name='ramses_amd_rccl_finalize') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function ramses_amd_rccl_finalize
+     function ramses_amd_halo_plan(ilevel, ngrid, igrid, xg, ngridmax, ncpu, em_ngrid, em_igrid, rc_ngrid, rc_igrid, &
+          & out_box, act_org, em_org, rc_src, rc_org, rc_cap) bind(C, name='ramses_amd_halo_plan') result(rc)
+       import :: c_int, c_int64_t, c_double, c_ptr
+       integer(c_int), value :: ilevel, ngrid, ncpu
+       integer(c_int64_t), value :: ngridmax, rc_cap
+       integer(c_int) :: igrid(*), em_ngrid(*), em_igrid(*), rc_ngrid(*), rc_igrid(*), out_box(8)
+       real(c_double) :: xg(*)
+       type(c_ptr), value :: act_org, em_org, rc_src, rc_org
+       integer(c_int) :: rc
+     end function ramses_amd_halo_plan
+     function ramses_amd_mpires_setup(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, uold, unew, ncpu, myid, &
+          & em_ngrid, em_igrid, rc_ngrid, rc_igrid) bind(C, name='ramses_amd_mpires_setup') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_int64_t, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ilevel, ngrid, nx_loc, ncpu, myid
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       integer(c_int) :: igrid(*), em_ngrid(*), em_igrid(*), rc_ngrid(*), rc_igrid(*)
+       real(c_double) :: xg(*), uold(*), unew(*)
+       integer(c_int) :: rc
+     end function ramses_amd_mpires_setup
+     function ramses_amd_mpires_active() bind(C, name='ramses_amd_mpires_active') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function ramses_amd_mpires_active
+     function ramses_amd_mpires_which(xx) bind(C, name='ramses_amd_mpires_which') result(k)
+       import :: c_int, c_double
+       real(c_double) :: xx(*)
+       integer(c_int) :: k
+     end function ramses_amd_mpires_which
+     function ramses_amd_mpires_courant(p, dx, dt_in, out4) bind(C, name='ramses_amd_mpires_courant') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       real(c_double), value :: dx, dt_in
+       real(c_double) :: out4(4)
+       integer(c_int) :: rc
+     end function ramses_amd_mpires_courant
+     function ramses_amd_mpires_godunov(p, dx, dt) bind(C, name='ramses_amd_mpires_godunov') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       real(c_double), value :: dx, dt
+       integer(c_int) :: rc
+     end function ramses_amd_mpires_godunov
+     function ramses_amd_mpires_reverse_unew() bind(C, name='ramses_amd_mpires_reverse_unew') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function ramses_amd_mpires_reverse_unew
+     function ramses_amd_mpires_set_uold() bind(C, name='ramses_amd_mpires_set_uold') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function ramses_amd_mpires_set_uold
+     function ramses_amd_mpires_halo_forward() bind(C, name='ramses_amd_mpires_halo_forward') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function ramses_amd_mpires_halo_forward
+     function ramses_amd_mpires_halo_stage_out(h_send, send_off, h_recv, recv_off) &
+          & bind(C, name='ramses_amd_mpires_halo_stage_out') result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr) :: h_send, send_off, h_recv, recv_off
+       integer(c_int) :: rc
+     end function ramses_amd_mpires_halo_stage_out
+     function ramses_amd_mpires_halo_stage_in() bind(C, name='ramses_amd_mpires_halo_stage_in') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function ramses_amd_mpires_halo_stage_in
+     function ramses_amd_mpires_sync_host(uold) bind(C, name='ramses_amd_mpires_sync_host') result(rc)
+       import :: c_int, c_double
+       real(c_double) :: uold(*)
+       integer(c_int) :: rc
+     end function ramses_amd_mpires_sync_host
+     function ramses_amd_mpires_invalidate() bind(C, name='ramses_amd_mpires_invalidate') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function ramses_amd_mpires_invalidate
   end interface
 
   logical, save :: ramses_amd_checked = .false.
@@ -279,6 +373,11 @@ module ramses_amd_iface
   integer, save :: ramses_amd_mg_level = 0
   logical, save :: ramses_amd_res_checked = .false.
   logical, save :: ramses_amd_res_on = .false.
+  ! MPI: the rank's share of the level stays on its GPU (ramses_amd_mpi_resident); the halo exchange
+  ! goes over RCCL (ramses_amd_halo_rccl) or, failing that, through the program's own MPI on pinned buffers
+  logical, save :: ramses_amd_mpi_checked = .false.
+  logical, save :: ramses_amd_mpi_on = .false.
+  logical, save :: ramses_amd_halo_rccl = .false.
 
 contains
 
@@ -467,6 +566,233 @@ contains
     end if
     ramses_amd_resident = ramses_amd_res_on
   end function ramses_amd_resident
+
+  !---------------------------------------------------------------------------
+  ! Device residency under MPI (one rank per GPU): a hydro-only periodic run on one fully refined
+  ! level whose Hilbert domains are boxes (2^k ranks).  Every rank keeps its box as a brick with a
+  ! one-oct ghost layer; courant_fine, set_unew, godunov_fine, set_uold and the two halo routines
+  ! of amr_step (make_virtual_reverse_dp on unew, make_virtual_fine_dp on uold) run on the device
+  ! (shims godunov_fine.f90, courant_fine.f90, virtual_boundaries.f90).  Decided once, by all ranks
+  ! together, the first time the level is stepped (the communicators exist by then).
+  ! RAMSES_AMD_RESIDENT=0 keeps the run on the tree-walking sweep + host MPI.
+  !---------------------------------------------------------------------------
+  logical function ramses_amd_mpi_resident()
+    use amr_commons
+    use hydro_parameters
+    use mpi_mod
+#if USE_TURB==1
+    use turb_commons, only: turb
+#endif
+    character(len=16) :: val
+    integer :: stat, ok, okall, info
+    if (.not. ramses_amd_mpi_checked) then
+       ramses_amd_mpi_checked = .true.
+       ramses_amd_mpi_on = ramses_amd_enabled() .and. ncpu > 1
+#ifdef WITHOUTMPI
+       ramses_amd_mpi_on = .false.
+#endif
+#ifdef LIGHT_MPI_COMM
+       ramses_amd_mpi_on = .false.     ! the condensed communicators of LIGHT_MPI_COMM are not mirrored
+#endif
+       call get_environment_variable('RAMSES_AMD_RESIDENT', val, status=stat)
+       if (stat == 0) then
+          if (trim(val) == '0') ramses_amd_mpi_on = .false.
+       end if
+       if (levelmin /= nlevelmax .or. nboundary > 0 .or. nremap > 0) ramses_amd_mpi_on = .false.
+       if (.not. hydro .or. poisson .or. pic .or. rt .or. cooling .or. star .or. sink .or. stellar) ramses_amd_mpi_on = .false.
+       if (tracer .or. MC_tracer .or. clumpfind .or. lightcone .or. movie .or. aton) ramses_amd_mpi_on = .false.
+       if (static .or. static_gas .or. neq_chem .or. barotropic_eos .or. isothermal .or. metal) ramses_amd_mpi_on = .false.
+       if (difmag > 0.0d0 .or. pressure_fix .or. T2_star > 0.0d0 .or. momentum_feedback > 0 .or. strict_equilibrium > 0) &
+            & ramses_amd_mpi_on = .false.
+       if (ndim /= 3) ramses_amd_mpi_on = .false.
+       if (icoarse_max - icoarse_min /= 0 .or. jcoarse_max - jcoarse_min /= 0 .or. kcoarse_max - kcoarse_min /= 0) &
+            & ramses_amd_mpi_on = .false.
+#if USE_TURB==1
+       if (turb) ramses_amd_mpi_on = .false.
+#endif
+#ifndef WITHOUTMPI
+       if (ramses_amd_mpi_on) then
+          ! every rank's octs must fill a box and its reception lists the shell around it
+          ok = 0
+          if (ramses_amd_mpi_plan_ok()) ok = 1
+          call MPI_ALLREDUCE(ok, okall, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, info)
+          if (okall == 0) then
+             ramses_amd_mpi_on = .false.
+             if (myid == 1) write(*,*) 'ramses_amd: the rank domains of level ', levelmin, &
+                  & ' are not boxes: tree-walking sweep + host MPI halo'
+          end if
+       end if
+       if (ramses_amd_mpi_on) then
+          call ramses_amd_halo_init()
+          if (myid == 1) write(*,*) 'ramses_amd: hydro state of level ', levelmin, &
+               & ' stays resident on the GPUs (one brick per rank)'
+       end if
+#endif
+    end if
+    ramses_amd_mpi_resident = ramses_amd_mpi_on
+  end function ramses_amd_mpi_resident
+
+#ifndef WITHOUTMPI
+  !---------------------------------------------------------------------------
+  ! Concatenated emission / reception oct lists of one level (amr/amr_commons.f90:170-179)
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_comm_lists(ilevel, em_n, em_ig, rc_n, rc_ig)
+    use amr_commons
+    integer, intent(in) :: ilevel
+    integer, allocatable, intent(out) :: em_n(:), em_ig(:), rc_n(:), rc_ig(:)
+    integer :: icpu, nem, nrc, i
+    allocate(em_n(ncpu), rc_n(ncpu))
+    nem = 0; nrc = 0
+    do icpu = 1, ncpu
+       em_n(icpu) = emission(icpu, ilevel)%ngrid
+       rc_n(icpu) = reception(icpu, ilevel)%ngrid
+       nem = nem + em_n(icpu); nrc = nrc + rc_n(icpu)
+    end do
+    allocate(em_ig(max(nem, 1)), rc_ig(max(nrc, 1)))
+    nem = 0; nrc = 0
+    do icpu = 1, ncpu
+       do i = 1, em_n(icpu)
+          em_ig(nem + i) = emission(icpu, ilevel)%igrid(i)
+       end do
+       do i = 1, rc_n(icpu)
+          rc_ig(nrc + i) = reception(icpu, ilevel)%igrid(i)
+       end do
+       nem = nem + em_n(icpu); nrc = nrc + rc_n(icpu)
+    end do
+  end subroutine ramses_amd_comm_lists
+
+  logical function ramses_amd_mpi_plan_ok()
+    use amr_commons
+    integer, allocatable :: em_n(:), em_ig(:), rc_n(:), rc_ig(:)
+    integer :: rc, box(8)
+    if (active(levelmin)%ngrid == 0) then
+       ramses_amd_mpi_plan_ok = .false.
+       return
+    end if
+    call ramses_amd_comm_lists(levelmin, em_n, em_ig, rc_n, rc_ig)
+    rc = ramses_amd_halo_plan(levelmin, active(levelmin)%ngrid, active(levelmin)%igrid, xg, int(ngridmax, 8), ncpu, &
+         & em_n, em_ig, rc_n, rc_ig, box, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, 0_8)
+    ramses_amd_mpi_plan_ok = (rc == 0)
+  end function ramses_amd_mpi_plan_ok
+
+  !---------------------------------------------------------------------------
+  ! Load the level onto the device if it is not there (first step, or after build_comm)
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_mpires_ensure()
+    use amr_commons
+    use hydro_commons
+    integer, allocatable :: em_n(:), em_ig(:), rc_n(:), rc_ig(:)
+    type(ramses_amd_hydro_params) :: p
+    integer :: rc, nx_loc
+    if (ramses_amd_mpires_active() /= 0) return
+    call ramses_amd_fill_hydro_params(p)
+    nx_loc = icoarse_max - icoarse_min + 1
+    call ramses_amd_comm_lists(levelmin, em_n, em_ig, rc_n, rc_ig)
+    rc = ramses_amd_mpires_setup(p, levelmin, active(levelmin)%ngrid, active(levelmin)%igrid, xg, int(ngridmax, 8), &
+         & int(ncoarse, 8), nx_loc, uold, unew, ncpu, myid, em_n, em_ig, rc_n, rc_ig)
+    if (rc /= 0) call ramses_amd_fatal('device-resident level under MPI (setup)')
+  end subroutine ramses_amd_mpires_ensure
+
+  !---------------------------------------------------------------------------
+  ! Transport of the halo exchange.  RAMSES_AMD_HALO = rccl | host | auto (default): RCCL neighbour
+  ! send/recv over xGMI when every rank has its own GPU; several ranks on one GPU (RCCL refuses that)
+  ! or RAMSES_AMD_HALO=host: the program's own MPI on pinned host buffers, and the run says so.
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_halo_init()
+    use amr_commons
+    use mpi_mod
+    character(len=16) :: val
+    character(kind=c_char) :: id(128)
+    integer :: stat, info, rc, rcmax, i, j
+    integer(c_int64_t) :: uid
+    integer(c_int64_t), allocatable :: alluid(:)
+    logical :: dup
+    val = 'auto'
+    call get_environment_variable('RAMSES_AMD_HALO', val, status=stat)
+    if (stat /= 0) val = 'auto'
+    ramses_amd_halo_rccl = .false.
+    if (trim(val) == 'host') then
+       if (myid == 1) write(*,*) 'ramses_amd: halo exchange staged through host MPI (RAMSES_AMD_HALO=host)'
+       return
+    end if
+    allocate(alluid(ncpu))
+    rc = ramses_amd_device_uid(uid)
+    if (rc /= 0) call ramses_amd_fatal('halo transport (device id)')
+    call MPI_ALLGATHER(uid, 1, MPI_INTEGER8, alluid, 1, MPI_INTEGER8, MPI_COMM_WORLD, info)
+    dup = .false.
+    do i = 1, ncpu
+       do j = i + 1, ncpu
+          if (alluid(i) == alluid(j)) dup = .true.
+       end do
+    end do
+    if (dup .and. trim(val) /= 'rccl') then
+       if (myid == 1) write(*,*) 'ramses_amd: several ranks share a GPU: halo exchange staged through host MPI (not RCCL)'
+       return
+    end if
+    id = c_null_char
+    rc = 0
+    if (myid == 1) rc = ramses_amd_rccl_unique_id(id)
+    call MPI_BCAST(rc, 1, MPI_INTEGER, 0, MPI_COMM_WORLD, info)
+    if (rc == 0) then
+       call MPI_BCAST(id, 128, MPI_CHARACTER, 0, MPI_COMM_WORLD, info)
+       rc = ramses_amd_rccl_init(id, ncpu, myid - 1)
+    end if
+    call MPI_ALLREDUCE(rc, rcmax, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, info)   ! error codes are negative
+    if (rcmax /= 0) then
+       if (trim(val) == 'rccl') call ramses_amd_fatal('halo transport (RCCL requested with RAMSES_AMD_HALO=rccl)')
+       rc = ramses_amd_rccl_finalize()
+       if (myid == 1) write(*,*) 'ramses_amd: RCCL could not be brought up: halo exchange staged through host MPI'
+       return
+    end if
+    ramses_amd_halo_rccl = .true.
+    if (myid == 1) write(*,*) 'ramses_amd: halo exchange over RCCL, ', ncpu, ' ranks'
+  end subroutine ramses_amd_halo_init
+
+  !---------------------------------------------------------------------------
+  ! make_virtual_fine_dp(uold(1,1:nvar),levelmin) on the resident bricks: all nvar fields in ONE
+  ! exchange (reference: nvar rounds, amr/amr_step.f90:497-508; pack/unpack amr/virtual_boundaries.f90:454-506)
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_halo_forward()
+    use amr_commons
+    use mpi_mod
+    integer :: rc, icpu, info, nreq, cnt
+    type(c_ptr) :: hs, hr, so, ro
+    real(c_double), pointer :: sbuf(:), rbuf(:)
+    integer(c_int64_t), pointer :: soff(:), roff(:)
+    integer, dimension(2*ncpu) :: req
+    integer, dimension(MPI_STATUS_SIZE, 2*ncpu) :: statuses
+    integer, parameter :: tag = 131
+    if (ramses_amd_halo_rccl) then
+       rc = ramses_amd_mpires_halo_forward()
+       if (rc /= 0) call ramses_amd_fatal('make_virtual_fine_dp (RCCL exchange)')
+       return
+    end if
+    rc = ramses_amd_mpires_halo_stage_out(hs, so, hr, ro)
+    if (rc /= 0) call ramses_amd_fatal('make_virtual_fine_dp (pack)')
+    call c_f_pointer(so, soff, [ncpu + 1])
+    call c_f_pointer(ro, roff, [ncpu + 1])
+    call c_f_pointer(hs, sbuf, [max(soff(ncpu + 1), 1_8)])
+    call c_f_pointer(hr, rbuf, [max(roff(ncpu + 1), 1_8)])
+    nreq = 0
+    do icpu = 1, ncpu
+       cnt = int(roff(icpu + 1) - roff(icpu))
+       if (cnt > 0) then
+          nreq = nreq + 1
+          call MPI_IRECV(rbuf(roff(icpu) + 1), cnt, MPI_DOUBLE_PRECISION, icpu - 1, tag, MPI_COMM_WORLD, req(nreq), info)
+       end if
+    end do
+    do icpu = 1, ncpu
+       cnt = int(soff(icpu + 1) - soff(icpu))
+       if (cnt > 0) then
+          nreq = nreq + 1
+          call MPI_ISEND(sbuf(soff(icpu) + 1), cnt, MPI_DOUBLE_PRECISION, icpu - 1, tag, MPI_COMM_WORLD, req(nreq), info)
+       end if
+    end do
+    call MPI_WAITALL(nreq, req, statuses, info)
+    rc = ramses_amd_mpires_halo_stage_in()
+    if (rc /= 0) call ramses_amd_fatal('make_virtual_fine_dp (unpack)')
+  end subroutine ramses_amd_halo_forward
+#endif
 
   !---------------------------------------------------------------------------
   ! The reference has no error returns on this path: print and clean_stop

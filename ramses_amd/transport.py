@@ -75,6 +75,45 @@ class DistTransport:
             dist.barrier(group=self.group)
 
 
+class RcclTransport(DistTransport):
+    """Neighbour send/recv through the C ABI of libramses_amd.so (ramses_amd_rccl_sendrecv: one grouped
+    ncclSend/ncclRecv on the current HIP stream) -- the same entry the Fortran shim
+    ramses_amd/patch/virtual_boundaries.f90 reaches through ramses_amd_mpires_halo_forward.  The 128-byte
+    unique id travels over the torch.distributed group that launched the ranks; the scalar reductions,
+    the coarse-level all-gather and the barrier stay with torch.distributed."""
+
+    def __init__(self, group=None):
+        super().__init__(group=group, staged=False)
+        import ctypes as C
+        from ._capi import check, lib
+        self._C, self._check, self._lib = C, check, lib()
+        idt = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (C.c_char * 128)()
+            check(self._lib.ramses_amd_rccl_unique_id(buf))
+            idt = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+        dev = idt.cuda() if dist.get_backend(group) == "nccl" else idt
+        dist.broadcast(dev, src=0, group=group)
+        raw = bytes(dev.cpu().numpy().tobytes())
+        check(self._lib.ramses_amd_rccl_init(C.c_char_p(raw), self.world, self.rank))
+
+    def sendrecv(self, sends, recvs):
+        if not sends and not recvs:
+            return
+        C = self._C
+        for t, _ in sends + recvs:
+            assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+        ns, nr = len(sends), len(recvs)
+        sp = (C.c_void_p * max(ns, 1))(*[t.data_ptr() for t, _ in sends])
+        sc = (C.c_int64 * max(ns, 1))(*[t.numel() for t, _ in sends])
+        sq = (C.c_int * max(ns, 1))(*[p for _, p in sends])
+        rp = (C.c_void_p * max(nr, 1))(*[t.data_ptr() for t, _ in recvs])
+        rc = (C.c_int64 * max(nr, 1))(*[t.numel() for t, _ in recvs])
+        rq = (C.c_int * max(nr, 1))(*[p for _, p in recvs])
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._check(self._lib.ramses_amd_rccl_sendrecv(ns, sp, sc, sq, nr, rp, rc, rq, stream))
+
+
 class LocalWorld:
     """world virtual ranks in this process: run(fn) calls fn(transport) on one
     thread per rank and returns the list of results (re-raises the first error)."""
