@@ -455,10 +455,34 @@ int ramses_amd_resident_sync_density_f90(double *uold);
 
 /* force_fine(ilevel,icount) -- poisson/force_fine.f90:5-194 with gradient_phi :199-324 -- on the
  * reference's own arrays (host pointers): f(1:ncell,1:3) of the level's cells from phi, for a fully
- * refined periodic level of a single-rank run (gravity_type = 0).  The diagnostics of :158-190
- * (epot_tot, rho_max) stay with the caller. */
+ * refined periodic level of a single-rank run (gravity_type = 0).  The diagnostics of :158-190 are
+ * reduced on the device: diag2 = {sum over leaf cells and directions of fact*f**2 (the level's
+ * contribution to epot_tot), max |rho| (rho_max(ilevel))}; rho = rho(1:ncell), son_or_dummy = son(1:ncell)
+ * read when has_son != 0 (a finer level exists: only cells with son == 0 count), fact =
+ * -dx_loc**ndim/fourpi/2.  The maximum is exact; the sum is a fixed reduction tree (deterministic,
+ * equal to the reference's serial loop up to rounding -- it feeds the energy-conservation print only). */
 int ramses_amd_force_fine_f90(int ilevel, int ngrid, const int *igrid, const double *xg,
-                              int64_t ngridmax, int64_t ncoarse, int nx_loc, const double *phi, double *f);
+                              int64_t ngridmax, int64_t ncoarse, int nx_loc, const double *phi, double *f,
+                              const double *rho, const int *son_or_dummy, int has_son, double fact, double *diag2);
+
+/* The Poisson branch of amr_step on the device-resident level: no host array is
+ * touched between rho_fine and force_fine; phi, f and rho reach the host on demand (backup_poisson).
+ *   ramses_amd_resident_rho_fine_f90     rho_fine's hydro deposit (pm/rho_fine.f90: multipole_fine :666-820,
+ *       cic_from_multipole :825-891, cic_cell :896-1142): every cell's mass max(rho,smallr)*vol is CIC-deposited
+ *       at its centre of mass (m*x)/m, a target cell adds what it receives in the order of the reference's
+ *       loop nest (batch of nvector octs, ind_son, CIC corner, oct in batch); multipole4 = multipole(1:4),
+ *       strictly sequential sums in list order (rho_tot = multipole(1)/scale**ndim, :179).  Bit-identical.
+ *   ramses_amd_resident_multigrid_f90    multigrid_fine on that deposit (poisson/multigrid_fine_commons.f90:25-296)
+ *   ramses_amd_resident_force_fine_f90   force_fine into the resident acceleration + the diagnostics (see above)
+ *   ramses_amd_resident_sync_poisson_f90 phi(1:ncell), f(1:ncell,1:3), rho(1:ncell) of the level back to the host */
+int ramses_amd_resident_rho_fine_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                     const int *igrid, const double *xg, int64_t ngridmax,
+                                     int64_t ncoarse, int nx_loc, const double *uold, double boxlen,
+                                     int nvector, double *multipole4);
+int ramses_amd_resident_multigrid_f90(int ilevel, double rho_tot, double fourpi, double epsilon, int *safe_mode,
+                                      int *iters, double *err);
+int ramses_amd_resident_force_fine_f90(int ilevel, double fact, double *diag2);
+int ramses_amd_resident_sync_poisson_f90(double *phi, double *f, double *rho);
 
 /* Page-lock a host array that the staged entry points (…_host/_f90) copy from and to.  The
  * reference allocates uold/unew (hydro/init_hydro.f90:30-32), phi/rho/f (poisson/init_poisson.f90:24-28)

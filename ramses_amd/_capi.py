@@ -102,7 +102,11 @@ SYMBOLS = [
     ("ramses_amd_resident_godunov_grav_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _d, _d]),
     ("ramses_amd_resident_set_uold_grav_f90", _i, [_PP, _i, _d]),
     ("ramses_amd_resident_sync_density_f90", _i, [_vp]),
-    ("ramses_amd_force_fine_f90", _i, [_i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp]),
+    ("ramses_amd_force_fine_f90", _i, [_i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _i, _d, _vp]),
+    ("ramses_amd_resident_rho_fine_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _i, _vp]),
+    ("ramses_amd_resident_multigrid_f90", _i, [_i, _d, _d, _d, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    ("ramses_amd_resident_force_fine_f90", _i, [_i, _d, _vp]),
+    ("ramses_amd_resident_sync_poisson_f90", _i, [_vp, _vp, _vp]),
     ("ramses_amd_cg_solve_host", _i, [_i, _i, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _i, _i, _vp, _vp]),
     ("ramses_amd_resident_courant_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _d, _vp]),
     ("ramses_amd_resident_godunov_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _d]),

@@ -30,6 +30,7 @@ UNITS = [
     ("amr_sweep.o", "amr_sweep.hip", ["-ffp-contract=off"]),
     ("mg_amr.o", "mg_amr.hip", ["-ffp-contract=off"]),
     ("cg_amr.o", "cg_amr.hip", ["-ffp-contract=off"]),
+    ("rho_fine.o", "rho_fine.hip", ["-ffp-contract=off"]),
     ("capi.o", "capi.hip", ["-ffp-contract=off"]),
     ("capi_mpi.o", "capi_mpi.hip", ["-ffp-contract=off"]),
 ]

@@ -18,6 +18,7 @@
 #include "mg_args.hpp"
 #include "misc_args.hpp"
 #include "pack_args.hpp"
+#include "rho_args.hpp"
 #include "sweep_args.hpp"
 
 using namespace ramses_amd;
@@ -649,6 +650,11 @@ struct DevBuf {
 };
 struct HostCtx {
   DevBuf uold, unew, fvec, igrid, xg, octorg, bold, bnew, bf, flag, red;
+  // Poisson fields of the resident level (rho_fine -> multigrid_fine -> force_fine without PCIe):
+  // rho, phi bricks, the multigrid work arrays, the oct-position -> list-index table of rho_fine
+  DevBuf brho, bphi, bf1, bf2, mgwork, octidx, diag, cellvec1;
+  bool res_rho_valid = false, res_phi_valid = false;      // brho / bphi hold the level's current rho / phi
+  bool res_pois_host_stale = false;                       // the host arrays phi, f (and rho) are behind the device
   // device-resident level (ramses_amd_resident_*): the level brick in bold is
   // the current hydro state; the host array is stale until synced
   bool res_valid = false, res_host_stale = false, res_new_ready = false;
@@ -947,8 +953,9 @@ int ramses_amd_multigrid_fine_f90(int ilevel, int ngrid, const int *igrid, const
 // single-rank run, gravity_type = 0): f(:,1:3) = gradient_phi of phi (poisson/force_fine.f90:
 // 199-324, 5-point differences); the caller keeps the diagnostics of :158-190 (epot, rho_max).
 int ramses_amd_force_fine_f90(int ilevel, int ngrid, const int *igrid, const double *xg,
-                              int64_t ngridmax, int64_t ncoarse, int nx_loc, const double *phi, double *f) {
-  if (!igrid || !xg || !phi || !f) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+                              int64_t ngridmax, int64_t ncoarse, int nx_loc, const double *phi, double *f,
+                              const double *rho, const int *son_or_dummy, int has_son, double fact, double *diag2) {
+  if (!igrid || !xg || !phi || !f || !rho || !diag2 || (has_son && !son_or_dummy)) return fail(RAMSES_AMD_EINVAL, "NULL argument");
   if (nx_loc != 1) return fail(RAMSES_AMD_EUNSUPPORTED, "device force_fine needs a periodic box with nx=ny=nz=1 (got nx_loc=%d)", nx_loc);
   if (ilevel < 2 || ilevel > 11) return fail(RAMSES_AMD_EINVAL, "level out of range");
   const int n = 1 << ilevel;
@@ -1002,6 +1009,29 @@ int ramses_amd_force_fine_f90(int ilevel, int ngrid, const int *igrid, const dou
   A.brick = d_f; A.cellvec = fvec3.as<double>();
   HCHK(launch_oct_copy(A, false, s), "scatter launch");
   HCHK(hipMemcpyAsync(f, fvec3.p, sizeof(double) * 3 * ncell, hipMemcpyDeviceToHost, s), "D2H f");
+  // diagnostics (:158-190): potential energy of the leaf cells and maximum density, reduced on the device
+  {
+    static DevBuf rhovec, brho, sonvec, bleaf;
+    HCHK(rhovec.ensure(sizeof(double) * ncell), "hipMalloc");
+    HCHK(brho.ensure(sizeof(double) * N), "hipMalloc");
+    HCHK(H.diag.ensure(sizeof(double) * (FORCE_DIAG_SCRATCH + 2)), "hipMalloc");
+    HCHK(hipMemcpyAsync(rhovec.p, rho, sizeof(double) * ncell, hipMemcpyHostToDevice, s), "H2D rho");
+    A.nvar = 1; A.brick = brho.as<double>(); A.cellvec = rhovec.as<double>();
+    HCHK(launch_oct_copy(A, true, s), "gather launch");
+    const int *d_leaf = nullptr;
+    if (has_son) {
+      // son(icell) == 0 marks a leaf: gathered as 8-byte words through the same kernel (son viewed as doubles would
+      // need pairs of cells), so a small dedicated pass: leaf[b] = (son[icell] == 0)
+      HCHK(sonvec.ensure(sizeof(int) * ncell), "hipMalloc");
+      HCHK(bleaf.ensure(sizeof(int) * N), "hipMalloc");
+      HCHK(hipMemcpyAsync(sonvec.p, son_or_dummy, sizeof(int) * ncell, hipMemcpyHostToDevice, s), "H2D son");
+      HCHK(launch_oct_leaf(A, sonvec.as<int>(), bleaf.as<int>(), s), "leaf launch");
+      d_leaf = bleaf.as<int>();
+    }
+    double *scratch = H.diag.as<double>();
+    HCHK(launch_force_diag(d_f, brho.as<double>(), d_leaf, N, fact, scratch, scratch + FORCE_DIAG_SCRATCH, s), "force diagnostics launch");
+    HCHK(hipMemcpyAsync(diag2, scratch + FORCE_DIAG_SCRATCH, sizeof(double) * 2, hipMemcpyDeviceToHost, s), "D2H diag");
+  }
   HCHK(hipStreamSynchronize(s), "sync");
 #undef HCHK
   return 0;
@@ -1060,6 +1090,7 @@ static int resident_ensure(const ramses_amd_hydro_params *p, int ilevel, int ngr
   A.brick = H.bold.as<double>(); A.cellvec = H.uold.as<double>();
   HCHK(launch_oct_copy(A, true, s), "gather launch");
   H.res_valid = true; H.res_host_stale = false; H.res_new_ready = false; H.res_grav_valid = false;
+  H.res_rho_valid = false; H.res_phi_valid = false; H.res_pois_host_stale = false;
   H.res_level = ilevel; H.res_ngrid = ngrid; H.res_nvar = nvar; H.res_ncell = ncell;
   H.res_ncoarse = ncoarse; H.res_ngridmax = ngridmax; H.res_host_uold = uold;
   return 0;
@@ -1241,6 +1272,123 @@ int ramses_amd_resident_sync_density_f90(double *uold) {
   HCHK(hipMemcpyAsync(uold, H.uold.p, sizeof(double) * H.res_ncell, hipMemcpyDeviceToHost, s), "D2H density");
   HCHK(hipStreamSynchronize(s), "sync");
   return 0;   // the other variables of the host array stay stale
+}
+
+// ---- the Poisson branch of amr_step on the resident level (second part) ----------
+// rho_fine's hydro deposit, multigrid_fine and force_fine read and write device bricks only; the host
+// arrays rho, phi, f are refreshed on demand (backup_poisson shim -> ramses_amd_resident_sync_poisson_f90).
+
+// rho_fine (pm/rho_fine.f90:5-226) for a hydro-only source on the resident level: rho = CIC deposit of the cell
+// masses at their centres of mass (multipole_fine + cic_from_multipole), multipole(1:4) summed in the
+// reference's order.  The caller sets rho_tot = multipole(1)/scale**ndim (:179).
+int ramses_amd_resident_rho_fine_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
+                                     const int *igrid, const double *xg, int64_t ngridmax,
+                                     int64_t ncoarse, int nx_loc, const double *uold, double boxlen,
+                                     int nvector, double *multipole4) {
+  if (!multipole4) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (nvector < 1) return fail(RAMSES_AMD_EINVAL, "nvector must be >= 1");
+  if (int rc = resident_ensure(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, uold)) return rc;
+  HostCtx &H = g_host;
+  if (H.res_new_ready) return fail(RAMSES_AMD_EINVAL, "rho_fine between godunov_fine and set_uold");
+  const int n = 1 << ilevel;
+  const long N = (long)n * n * n;
+  hipStream_t s = nullptr;
+  HCHK(H.brho.ensure(sizeof(double) * N), "hipMalloc rho brick");
+  HCHK(H.octidx.ensure(sizeof(int) * (size_t)(N / 8)), "hipMalloc oct index");
+  HCHK(H.diag.ensure(sizeof(double) * (FORCE_DIAG_SCRATCH + 8)), "hipMalloc");
+  HCHK(launch_oct_index(H.octorg.as<long>(), ngrid, n, H.octidx.as<int>(), s), "oct index launch");
+  RhoArgs A;
+  A.dens = H.bold.as<double>();          // variable 1 of the resident state
+  A.rho = H.brho.as<double>();
+  A.octorg = H.octorg.as<long>(); A.octidx = H.octidx.as<int>();
+  A.n = n; A.ngrid = ngrid; A.nvector = nvector;
+  A.dx = std::ldexp(1.0, -ilevel);
+  A.scale = boxlen / (double)nx_loc;
+  const double dx_loc = A.dx * A.scale;
+  A.vol_loc = dx_loc * dx_loc * dx_loc;
+  A.smallr = p->smallr;
+  HCHK(launch_rho_deposit(A, s), "rho deposit launch");
+  double *d_mp = H.diag.as<double>() + FORCE_DIAG_SCRATCH + 2;
+  HCHK(launch_multipole(A, d_mp, s), "multipole launch");
+  HCHK(hipMemcpyAsync(multipole4, d_mp, sizeof(double) * 4, hipMemcpyDeviceToHost, s), "D2H multipole");
+  HCHK(hipStreamSynchronize(s), "sync");
+  H.res_rho_valid = true;
+  H.res_pois_host_stale = true;
+  return 0;
+}
+
+// multigrid_fine(ilevel,icount) on the resident level: source = the deposit left by ramses_amd_resident_rho_fine_f90
+int ramses_amd_resident_multigrid_f90(int ilevel, double rho_tot, double fourpi, double epsilon, int *safe_mode,
+                                      int *iters, double *err) {
+  HostCtx &H = g_host;
+  if (!safe_mode) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (!H.res_valid || H.res_level != ilevel) return fail(RAMSES_AMD_EINVAL, "multigrid_fine: level %d is not resident", ilevel);
+  if (!H.res_rho_valid) return fail(RAMSES_AMD_EINVAL, "multigrid_fine: no density deposit on the device (rho_fine)");
+  const int n = 1 << ilevel;
+  const long N = (long)n * n * n;
+  hipStream_t s = nullptr;
+  const int64_t nwork = ramses_amd_mg_workspace_doubles(ilevel);
+  if (nwork < 0) return (int)nwork;
+  HCHK(H.bphi.ensure(sizeof(double) * N), "hipMalloc"); HCHK(H.bf1.ensure(sizeof(double) * N), "hipMalloc");
+  HCHK(H.bf2.ensure(sizeof(double) * N), "hipMalloc"); HCHK(H.mgwork.ensure(sizeof(double) * nwork), "hipMalloc");
+  HCHK(hipMemsetAsync(H.bphi.p, 0, sizeof(double) * N, s), "memset phi");   // make_multipole_phi, periodic: phi = 0
+  if (int rc = ramses_amd_multigrid_fine_brick(ilevel, H.brho.as<double>(), rho_tot, fourpi, epsilon, safe_mode,
+                                               H.bphi.as<double>(), H.bf1.as<double>(), H.bf2.as<double>(),
+                                               H.mgwork.as<double>(), iters, err, s)) return rc;
+  H.res_phi_valid = true;
+  H.res_pois_host_stale = true;
+  return 0;
+}
+
+// force_fine(ilevel,icount) on the resident level: f = gradient_phi(phi) into the acceleration brick the hydro
+// routines read; diag2 = {sum over cells and directions of fact*f**2, max |rho|} (poisson/force_fine.f90:158-190)
+int ramses_amd_resident_force_fine_f90(int ilevel, double fact, double *diag2) {
+  HostCtx &H = g_host;
+  if (!diag2) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (!H.res_valid || H.res_level != ilevel) return fail(RAMSES_AMD_EINVAL, "force_fine: level %d is not resident", ilevel);
+  if (!H.res_phi_valid || !H.res_rho_valid) return fail(RAMSES_AMD_EINVAL, "force_fine: no potential on the device (multigrid_fine)");
+  const int n = 1 << ilevel;
+  const long N = (long)n * n * n;
+  hipStream_t s = nullptr;
+  HCHK(H.bf.ensure(sizeof(double) * 3 * N), "hipMalloc f brick");
+  HCHK(H.diag.ensure(sizeof(double) * (FORCE_DIAG_SCRATCH + 8)), "hipMalloc");
+  if (int rc = ramses_amd_gradient_phi_brick(ilevel, H.bphi.as<double>(), H.bf.as<double>(), s)) return rc;
+  H.res_grav_valid = true;
+  double *scratch = H.diag.as<double>();
+  HCHK(launch_force_diag(H.bf.as<double>(), H.brho.as<double>(), nullptr, N, fact, scratch, scratch + FORCE_DIAG_SCRATCH, s), "force diagnostics launch");
+  HCHK(hipMemcpyAsync(diag2, scratch + FORCE_DIAG_SCRATCH, sizeof(double) * 2, hipMemcpyDeviceToHost, s), "D2H diag");
+  HCHK(hipStreamSynchronize(s), "sync");
+  H.res_pois_host_stale = true;
+  return 0;
+}
+
+// phi, f(1:ncell,1:3) and rho of the resident level back into the host arrays (backup_poisson)
+int ramses_amd_resident_sync_poisson_f90(double *phi, double *f, double *rho) {
+  HostCtx &H = g_host;
+  if (!H.res_valid || !H.res_pois_host_stale) return 0;
+  if (!phi || !f || !rho) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  const int n = 1 << H.res_level;
+  const long N = (long)n * n * n;
+  const long ncell = H.res_ncell;
+  hipStream_t s = nullptr;
+  HCHK(H.cellvec1.ensure(sizeof(double) * 3 * ncell), "hipMalloc");
+  PackArgs A;
+  A.igrid = H.igrid.as<int>(); A.octorg = H.octorg.as<long>();
+  A.ngrid = H.res_ngrid; A.n = n;
+  A.ncoarse = H.res_ncoarse; A.ngridmax = H.res_ngridmax; A.ncell = ncell; A.pitch_var = N;
+  struct { bool ok; double *host; double *brick; int nvar; } col[3] = {
+      {H.res_phi_valid, phi, H.bphi.as<double>(), 1}, {H.res_grav_valid, f, H.bf.as<double>(), 3}, {H.res_rho_valid, rho, H.brho.as<double>(), 1}};
+  for (auto &c : col) {
+    if (!c.ok) continue;
+    // cells of other levels keep their host values: scatter into a device copy of the host vector
+    HCHK(hipMemcpyAsync(H.cellvec1.p, c.host, sizeof(double) * c.nvar * ncell, hipMemcpyHostToDevice, s), "H2D");
+    A.nvar = c.nvar; A.brick = c.brick; A.cellvec = H.cellvec1.as<double>();
+    HCHK(launch_oct_copy(A, false, s), "scatter launch");
+    HCHK(hipMemcpyAsync(c.host, H.cellvec1.p, sizeof(double) * c.nvar * ncell, hipMemcpyDeviceToHost, s), "D2H");
+    HCHK(hipStreamSynchronize(s), "sync");
+  }
+  H.res_pois_host_stale = false;
+  return 0;
 }
 
 // ---------------------------------------------------------------------------

@@ -51,8 +51,10 @@ RA_DEV double rcp_fast(double x) {
   double r = __builtin_amdgcn_rcp(x);
   double e = __builtin_fma(-x, r, 1.0);
   r = __builtin_fma(r, e, r);
+#if !RAMSES_AMD_RCP_ONE_STEP
   e = __builtin_fma(-x, r, 1.0);
   r = __builtin_fma(r, e, r);
+#endif
   return r;
 }
 RA_DEV double ddiv(double a, double b) { return a * rcp_fast(b); }

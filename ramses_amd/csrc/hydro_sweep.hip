@@ -88,11 +88,14 @@ enum { ROLE_HALO = 0, ROLE_LOW = 1, ROLE_HIGH = 2, ROLE_FULL = 3, ROLE_HALO_HI =
 // strict build (long division/sqrt sequences: VALU-throughput bound, measured
 // 6.25 -> 5.86 ms at 512^3) and costs in the fast build (latency bound: the
 // extra LDS round trip lengthens the short y-flux phase, 3.66 -> 3.75 ms).
+#ifndef RAMSES_AMD_SWEEP_OFFLOAD_HI
 #ifdef RAMSES_AMD_FAST
-constexpr bool OFFLOAD_HI = false;
+#define RAMSES_AMD_SWEEP_OFFLOAD_HI 0
 #else
-constexpr bool OFFLOAD_HI = true;
+#define RAMSES_AMD_SWEEP_OFFLOAD_HI 1
 #endif
+#endif
+constexpr bool OFFLOAD_HI = RAMSES_AMD_SWEEP_OFFLOAD_HI != 0;
 
 // Raw buffer access: one scalar resource descriptor per variable (base of the
 // variable's brick), a wave-uniform byte offset of the plane (soffset) and one

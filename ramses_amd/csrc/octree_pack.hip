@@ -59,6 +59,26 @@ __global__ __launch_bounds__(256) void oct_copy_kernel(PackArgs A) {
   }
 }
 
+// leaf[b] = (son(icell) == 0) on the level brick (A.n, A.octorg, A.igrid as for the copies)
+__global__ __launch_bounds__(256) void oct_leaf_kernel(PackArgs A, const int *__restrict__ son, int *__restrict__ leaf) {
+  const long total = (long)A.ngrid * 8;
+  const long py = A.pitch_y ? A.pitch_y : (long)A.n, pz = A.pitch_z ? A.pitch_z : (long)A.n * A.n;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ind = (int)(t / A.ngrid);
+    const int g = (int)(t % A.ngrid);
+    const long icell = A.ncoarse + (long)ind * A.ngridmax + (A.igrid[g] - 1);
+    const long b = A.octorg[g] + (ind & 1) + py * ((ind >> 1) & 1) + pz * ((ind >> 2) & 1);
+    leaf[b] = son[icell] == 0 ? 1 : 0;
+  }
+}
+hipError_t launch_oct_leaf(const PackArgs &A, const int *son, int *leaf, hipStream_t s) {
+  long grid = ((long)A.ngrid * 8 + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(oct_leaf_kernel, dim3((int)grid), dim3(256), 0, s, A, son, leaf);
+  return hipGetLastError();
+}
+
 hipError_t launch_oct_origin(const int *igrid, const double *xg, long ngridmax, int ngrid, int n,
                              const double skip[3], long *octorg, int *bad, hipStream_t s) {
   hipLaunchKernelGGL(oct_origin_kernel, dim3((ngrid + 255) / 256), dim3(256), 0, s, igrid, xg, ngridmax, ngrid, n,

@@ -17,5 +17,6 @@ struct PackArgs {
 hipError_t launch_oct_origin(const int *igrid, const double *xg, long ngridmax, int ngrid, int n,
                              const double skip[3], long *octorg, int *bad, hipStream_t s);
 hipError_t launch_oct_copy(const PackArgs &A, bool gather, hipStream_t s);
+hipError_t launch_oct_leaf(const PackArgs &A, const int *son, int *leaf, hipStream_t s);
 
 }  // namespace ramses_amd

@@ -79,8 +79,13 @@ subroutine multigrid_fine(ilevel,icount)
 
   isafe=0
   if(safe_mode(ilevel))isafe=1
-  rc=ramses_amd_multigrid_fine_f90(ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
-       & int(ngridmax,8),int(ncoarse,8),nx_loc,rho,phi,rho_tot,fourpi,epsilon,isafe,iters,err)
+  if(ramses_amd_pois_dev)then
+     ! the source is already on the device (rho_fine shim), phi stays there for force_fine
+     rc=ramses_amd_resident_multigrid_f90(ilevel,rho_tot,fourpi,epsilon,isafe,iters,err)
+  else
+     rc=ramses_amd_multigrid_fine_f90(ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+          & int(ngridmax,8),int(ncoarse,8),nx_loc,rho,phi,rho_tot,fourpi,epsilon,isafe,iters,err)
+  end if
   if(rc/=0)call ramses_amd_fatal('multigrid_fine')
   safe_mode(ilevel)=(isafe/=0)
 

@@ -92,15 +92,50 @@ module ramses_amd_iface
        integer(c_int) :: rc
      end function ramses_amd_godunov_fine_amr_f90
 
-     function ramses_amd_force_fine_f90(ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, phi, f) &
-          & bind(C, name='ramses_amd_force_fine_f90') result(rc)
+     function ramses_amd_force_fine_f90(ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, phi, f, &
+          & rho, son, has_son, fact, diag2) bind(C, name='ramses_amd_force_fine_f90') result(rc)
        import :: c_int, c_int64_t, c_double
-       integer(c_int), value :: ilevel, ngrid, nx_loc
+       integer(c_int), value :: ilevel, ngrid, nx_loc, has_son
        integer(c_int64_t), value :: ngridmax, ncoarse
-       integer(c_int) :: igrid(*)
-       real(c_double) :: xg(*), phi(*), f(*)
+       integer(c_int) :: igrid(*), son(*)
+       real(c_double) :: xg(*), phi(*), f(*), rho(*), diag2(2)
+       real(c_double), value :: fact
        integer(c_int) :: rc
      end function ramses_amd_force_fine_f90
+     ! ---- Poisson branch on the resident level ----
+     function ramses_amd_resident_rho_fine_f90(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, uold, boxlen, &
+          & nvector, multipole4) bind(C, name='ramses_amd_resident_rho_fine_f90') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_int64_t, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ilevel, ngrid, nx_loc, nvector
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       integer(c_int) :: igrid(*)
+       real(c_double) :: xg(*), uold(*), multipole4(4)
+       real(c_double), value :: boxlen
+       integer(c_int) :: rc
+     end function ramses_amd_resident_rho_fine_f90
+     function ramses_amd_resident_multigrid_f90(ilevel, rho_tot, fourpi, epsilon, safe_mode, iters, err) &
+          & bind(C, name='ramses_amd_resident_multigrid_f90') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: ilevel
+       real(c_double), value :: rho_tot, fourpi, epsilon
+       integer(c_int) :: safe_mode, iters
+       real(c_double) :: err
+       integer(c_int) :: rc
+     end function ramses_amd_resident_multigrid_f90
+     function ramses_amd_resident_force_fine_f90(ilevel, fact, diag2) &
+          & bind(C, name='ramses_amd_resident_force_fine_f90') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: ilevel
+       real(c_double), value :: fact
+       real(c_double) :: diag2(2)
+       integer(c_int) :: rc
+     end function ramses_amd_resident_force_fine_f90
+     function ramses_amd_resident_sync_poisson_f90(phi, f, rho) bind(C, name='ramses_amd_resident_sync_poisson_f90') result(rc)
+       import :: c_int, c_double
+       real(c_double) :: phi(*), f(*), rho(*)
+       integer(c_int) :: rc
+     end function ramses_amd_resident_sync_poisson_f90
      function ramses_amd_host_register_dp(p, bytes) bind(C, name='ramses_amd_host_register') result(rc)
        import :: c_int, c_int64_t, c_double
        real(c_double) :: p(*)
@@ -373,6 +408,8 @@ module ramses_amd_iface
   integer, save :: ramses_amd_mg_level = 0
   logical, save :: ramses_amd_res_checked = .false.
   logical, save :: ramses_amd_res_on = .false.
+  ! the Poisson fields of the resident level are on the device (rho_fine's deposit ran there this step)
+  logical, save :: ramses_amd_pois_dev = .false.
   ! MPI: the rank's share of the level stays on its GPU (ramses_amd_mpi_resident); the halo exchange
   ! goes over RCCL (ramses_amd_halo_rccl) or, failing that, through the program's own MPI on pinned buffers
   logical, save :: ramses_amd_mpi_checked = .false.

@@ -14,15 +14,54 @@
 subroutine rho_fine(ilevel,icount)
   use amr_commons
   use hydro_commons
+  use poisson_commons
   use ramses_amd_iface
   implicit none
   integer::ilevel,icount
-  integer::rc
+  !--------------------------------------------------------------------------
+  ! Same contract as the reference (pm/rho_fine.f90:5-226).  On the device-resident level of a
+  ! hydro + self-gravity run without particles the source of the Poisson equation is the hydro
+  ! deposit alone: it is computed on the GPU from the resident density (every cell's mass CIC-
+  ! deposited at its centre of mass, contributions added in the reference's order; multipole(1:4)
+  ! by strictly sequential sums) and stays there for multigrid_fine / force_fine.  The other duties
+  ! of rho_fine in that configuration are no-ops (no particles, no reception / boundary cells,
+  ! m_refine < 0, cic_levelmax = 0); its reset of phi is subsumed by multigrid_fine's first guess.
+  ! RAMSES_AMD_RESIDENT_RHO=0 keeps the reference's host loops (the density is synced back first).
+  !--------------------------------------------------------------------------
+  integer::rc,nx_loc,stat
+  real(dp)::scale
+  real(kind=8),dimension(4)::mp4
+  type(ramses_amd_hydro_params)::p
+  character(len=16)::val
+  logical,save::first=.true.,rho_dev=.true.
+  ramses_amd_pois_dev=.false.
   if(poisson.and.hydro)then
      if(ramses_amd_resident())then
+        if(first)then
+           call get_environment_variable('RAMSES_AMD_RESIDENT_RHO',val,status=stat)
+           if(stat==0)then
+              if(trim(val)=='0')rho_dev=.false.
+           end if
+           first=.false.
+        end if
+        if(rho_dev.and.numbtot(1,ilevel)>0.and.ilevel==levelmin.and.m_refine(ilevel)<0.0d0.and.cic_levelmax==0 &
+             & .and.nboundary==0)then
+           if(verbose)write(*,111)ilevel
+           call ramses_amd_fill_hydro_params(p)
+           nx_loc=icoarse_max-icoarse_min+1
+           scale=boxlen/dble(nx_loc)
+           rc=ramses_amd_resident_rho_fine_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+                & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,boxlen,nvector,mp4)
+           if(rc/=0)call ramses_amd_fatal('rho_fine')
+           multipole(1:ndim+1)=mp4(1:ndim+1)
+           rho_tot=multipole(1)/scale**ndim
+           ramses_amd_pois_dev=.true.
+           return
+        end if
         rc=ramses_amd_resident_sync_density_f90(uold)
         if(rc/=0)call ramses_amd_fatal('rho_fine (density of the resident level)')
      end if
   end if
   call rho_fine_reference(ilevel,icount)
+111 format('   Entering rho_fine (MI355X) for level ',I2)
 end subroutine rho_fine

@@ -1,0 +1,55 @@
+"""rho_fine's hydro deposit on the device (ramses_amd/csrc/rho_fine.hip through
+ramses_amd_resident_rho_fine_f90) against dumps of the UNMODIFIED reference
+(tests/golden/rho_fine_ref.npz, made by tests/golden/make_golden_rho.py from a self-gravity run in
+which the gas moves, so the deposit is not the cell density bit for bit): rho of every cell of the
+level and the four multipole sums (hence rho_tot), bit for bit."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "rho_fine_ref.npz")
+
+
+@pytest.mark.parametrize("which", [0, 1])
+@pytest.mark.parametrize("nvector", [32, 7])
+def test_device_deposit_equals_reference_dump(gpu_lib, oracle, which, nvector):
+    import ramses_amd
+    z = np.load(GOLD)
+    k = "c%d_" % int(z["calls"][which])
+    ilevel, icount, ngrid, ngridmax, ncoarse, levelmin, nvec_ref = [int(x) for x in z[k + "meta"]]
+    boxlen, smallr = [float(x) for x in z[k + "real"]]
+    igrid = np.ascontiguousarray(z[k + "igrid"])
+    xg = np.ascontiguousarray(z[k + "xg"])
+    ncell = ncoarse + 8 * ngridmax
+    rng = np.random.default_rng(1)
+    uold = rng.uniform(0.5, 1.5, (5, ncell))
+    uold[0] = z[k + "dens"]
+    if nvector == nvec_ref:
+        want_rho, want_mp = z[k + "rho"], z[k + "multipole"]
+    else:
+        # another NVECTOR changes the order of the sums: the oracle (pinned on the dumps at the reference's own
+        # NVECTOR) gives the expected values
+        want_rho, want_mp, _ = oracle.rho_fine_hydro(ilevel, levelmin, nvector, igrid, xg, z[k + "son"], z[k + "nbor"],
+                                                     z[k + "father"], ngridmax, ncoarse, boxlen, smallr, z[k + "dens"])
+    p = ramses_amd.make_params(smallr=smallr)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert gpu_lib.ramses_amd_resident_invalidate() == 0
+    mp = np.zeros(4)
+    rc = gpu_lib.ramses_amd_resident_rho_fine_f90(C.byref(p), ilevel, ngrid, vp(igrid), vp(xg), ngridmax, ncoarse, 1,
+                                                  vp(uold), boxlen, nvector, vp(mp))
+    assert rc == 0, gpu_lib.ramses_amd_last_error()
+    assert np.array_equal(mp, want_mp), (mp, want_mp)
+    phi = np.zeros(ncell)
+    f = np.zeros((3, ncell))
+    rho = np.full(ncell, -7.0)
+    assert gpu_lib.ramses_amd_resident_sync_poisson_f90(vp(phi), vp(f), vp(rho)) == 0
+    lev = np.zeros(ncell, bool)
+    for ind in range(8):
+        lev[ncoarse + ind * ngridmax + igrid - 1] = True
+    assert np.array_equal(rho[lev], want_rho[lev]), np.abs(rho[lev] - want_rho[lev]).max()
+    assert (rho[~lev] == -7.0).all()            # cells of other levels are untouched
+    assert (want_rho[lev] != z[k + "dens"][lev]).any()
+    assert gpu_lib.ramses_amd_resident_invalidate() == 0
