@@ -22,7 +22,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-fast-mat
 # (object name, source, extra flags)
 UNITS = [
     ("hydro_sweep_strict.o", "hydro_sweep.hip", ["-ffp-contract=off"]),
-    ("hydro_sweep_fast.o", "hydro_sweep.hip", ["-ffp-contract=fast", "-DRAMSES_AMD_FAST=1"]),
+    ("hydro_sweep_fast.o", "hydro_sweep.hip", ["-ffp-contract=off", "-DRAMSES_AMD_FAST=1"]),
     ("hydro_misc.o", "hydro_misc.hip", ["-ffp-contract=off"]),
     ("mg_kernels.o", "mg_kernels.hip", ["-ffp-contract=off"]),
     ("octree_pack.o", "octree_pack.hip", ["-ffp-contract=off"]),

@@ -47,6 +47,9 @@ RA_DEV double fsignd(double a, double b) { return __builtin_copysign(a, b); }
 // their ratios); held to <=1e-12 relative L-infinity of the strict result.
 // ---------------------------------------------------------------------------
 #ifdef RAMSES_AMD_FAST
+#ifndef RAMSES_AMD_RCP_ONE_STEP
+#define RAMSES_AMD_RCP_ONE_STEP 1   // one Newton step after v_rcp_f64 (~2^-50): fast vs strict stays at ~2e-15 over 24 Sedov steps
+#endif
 RA_DEV double rcp_fast(double x) {
   double r = __builtin_amdgcn_rcp(x);
   double e = __builtin_fma(-x, r, 1.0);
@@ -88,16 +91,31 @@ RA_DEV void ctoprim_cell(const double (&u)[NV], const double (&g)[3],
   const double vx = u[1] * oneoverrho;
   const double vy = u[2] * oneoverrho;
   const double vz = u[3] * oneoverrho;
+#ifdef RAMSES_AMD_FAST
+  // every fused multiply-add of the fast build is written out (the unit is compiled with
+  // -ffp-contract=off): each cell gets the same arithmetic whichever row role or tile computes it
+  double k2 = vx * vx;
+  k2 = __builtin_fma(vy, vy, k2);
+  k2 = __builtin_fma(vz, vz, k2);
+  const double eint = dmaxd(__builtin_fma(u[4], oneoverrho, -0.5 * k2), P.smalle);
+#else
   double eken = 0.5 * vx * vx;
   eken = eken + 0.5 * vy * vy;
   eken = eken + 0.5 * vz * vz;
   const double eint = dmaxd(u[4] * oneoverrho - eken, P.smalle);
+#endif
   q[0] = rho;
   q[4] = P.gm1 * rho * eint;
   if (GRAV) {
+#ifdef RAMSES_AMD_FAST
+    q[1] = __builtin_fma(g[0], dtxhalf, vx);
+    q[2] = __builtin_fma(g[1], dtxhalf, vy);
+    q[3] = __builtin_fma(g[2], dtxhalf, vz);
+#else
     q[1] = vx + g[0] * dtxhalf;
     q[2] = vy + g[1] * dtxhalf;
     q[3] = vz + g[2] * dtxhalf;
+#endif
   } else {
     // gravin is identically zero when poisson=.false.; v + 0*dt == v
     q[1] = vx; q[2] = vy; q[3] = vz;
@@ -191,14 +209,23 @@ RA_DEV void trace3d_cell(const double (&q)[NV], const double (&dq)[3][NV],
   const double dry = dq[1][0], duy = dq[1][1], dvy = dq[1][2], dwy = dq[1][3], dpy = dq[1][4];
   const double drz = dq[2][0], duz = dq[2][1], dvz = dq[2][2], dwz = dq[2][3], dpz = dq[2][4];
   const double div = dux + dvy + dwz;
+#ifdef RAMSES_AMD_FAST
+  // s = -(u dq/dx + v dq/dy + w dq/dz + source) as explicit FMA chains
+  const double rinv = rcp_fast(r);
+  auto adv = [&](double ax, double ay, double az, double c0, double c1) {
+    double t = u * ax;
+    t = __builtin_fma(v, ay, t);
+    t = __builtin_fma(w, az, t);
+    return -__builtin_fma(c0, c1, t);
+  };
+  const double sr0 = adv(drx, dry, drz, div, r);
+  const double sp0 = adv(dpx, dpy, dpz, div * P.gamma, p);
+  const double su0 = adv(dux, duy, duz, dpx, rinv);
+  const double sv0 = adv(dvx, dvy, dvz, dpy, rinv);
+  const double sw0 = adv(dwx, dwy, dwz, dpz, rinv);
+#else
   const double sr0 = -u * drx - v * dry - w * drz - (div)*r;
   const double sp0 = -u * dpx - v * dpy - w * dpz - (div)*P.gamma * p;
-#ifdef RAMSES_AMD_FAST
-  const double rinv = rcp_fast(r);
-  const double su0 = -u * dux - v * duy - w * duz - (dpx)*rinv;
-  const double sv0 = -u * dvx - v * dvy - w * dvz - (dpy)*rinv;
-  const double sw0 = -u * dwx - v * dwy - w * dwz - (dpz)*rinv;
-#else
   const double su0 = -u * dux - v * duy - w * duz - (dpx) / r;
   const double sv0 = -u * dvx - v * dvy - w * dvz - (dpy) / r;
   const double sw0 = -u * dwx - v * dwy - w * dwz - (dpz) / r;
@@ -207,6 +234,16 @@ RA_DEV void trace3d_cell(const double (&q)[NV], const double (&dq)[3][NV],
   const double dtd[3] = {dtdx, dtdy, dtdz};
 #pragma unroll
   for (int d = 0; d < 3; d++) {
+#ifdef RAMSES_AMD_FAST
+    // q + s0*dt/(2dx) once, then one FMA per face state (the strict build keeps (q -+ dq/2) + s0*dt/(2dx))
+    const double hdt = 0.5 * dtd[d];
+#pragma unroll
+    for (int n = 0; n < 5; n++) {
+      const double base = __builtin_fma(s0[n], hdt, q[n]);
+      qp[d][n] = __builtin_fma(-0.5, dq[d][n], base);
+      qm[d][n] = __builtin_fma(0.5, dq[d][n], base);
+    }
+#else
 #pragma unroll
     for (int n = 0; n < 5; n++) {
       const double hd = 0.5 * dq[d][n];
@@ -214,6 +251,7 @@ RA_DEV void trace3d_cell(const double (&q)[NV], const double (&dq)[3][NV],
       qp[d][n] = q[n] - hd + st;
       qm[d][n] = q[n] + hd + st;
     }
+#endif
     if (qp[d][0] < P.smallr) qp[d][0] = r;
     if (qm[d][0] < P.smallr) qm[d][0] = r;
   }
@@ -617,12 +655,13 @@ RA_DEV void llf_flux_fast(const double (&qL)[5], const double (&qR)[5],
   const double t2L = qL[0] * qL[lt2], t2R = qR[0] * qR[lt2];
   // physical fluxes
   const double fnL = __builtin_fma(ul, mL, qL[4]), fnR = __builtin_fma(ur, mR, qR[4]);
-  const double feL = ul * (eL + qL[4]), feR = ur * (eR + qR[4]);
+  const double feR = ur * (eR + qR[4]);
+  const double fesum = __builtin_fma(ul, eL + qL[4], feR);
   flux[0] = __builtin_fma(hc, qL[0] - qR[0], hs * (mL + mR));
   flux[ln] = __builtin_fma(hc, mL - mR, hs * (fnL + fnR));
   flux[lt1] = __builtin_fma(hc, t1L - t1R, hs * __builtin_fma(ul, t1L, ur * t1R));
   flux[lt2] = __builtin_fma(hc, t2L - t2R, hs * __builtin_fma(ul, t2L, ur * t2R));
-  flux[4] = __builtin_fma(hc, eL - eR, hs * (feL + feR));
+  flux[4] = __builtin_fma(hc, eL - eR, hs * fesum);
 }
 #endif
 

@@ -45,7 +45,7 @@ namespace ramses_amd {
 #define RAMSES_AMD_SWEEP_LATE_UCUR 0
 #endif
 #ifndef RAMSES_AMD_SWEEP_PREFETCH
-#define RAMSES_AMD_SWEEP_PREFETCH 0   // where plane c+2 is requested: 0 start of the iteration, 1 before the barrier, 2 after it
+#define RAMSES_AMD_SWEEP_PREFETCH 1   // where plane c+2 is requested: 0 start of the iteration, 1 before the barrier (measured best), 2 after it
 #endif
 
 namespace SWEEP_NS {
@@ -84,16 +84,10 @@ __device__ __forceinline__ double wave_shl1(double v) {
 //   ROLE_HALO_HI : row BY-1     primitives, and the y flux through the -y face of row BY-2
 //                               (its wave has nothing else to do: evens out the SIMDs)
 enum { ROLE_HALO = 0, ROLE_LOW = 1, ROLE_HIGH = 2, ROLE_FULL = 3, ROLE_HALO_HI = 4 };
-// Handing row BY-2's y flux to the otherwise idle wave of row BY-1 pays in the
-// strict build (long division/sqrt sequences: VALU-throughput bound, measured
-// 6.25 -> 5.86 ms at 512^3) and costs in the fast build (latency bound: the
-// extra LDS round trip lengthens the short y-flux phase, 3.66 -> 3.75 ms).
+// Handing row BY-2's y flux to the otherwise idle wave of row BY-1 paid in the strict build of the
+// two-barrier loop (6.25 -> 5.86 ms at 512^3) and cost in the fast one (3.66 -> 3.75 ms).
 #ifndef RAMSES_AMD_SWEEP_OFFLOAD_HI
-#ifdef RAMSES_AMD_FAST
-#define RAMSES_AMD_SWEEP_OFFLOAD_HI 0
-#else
-#define RAMSES_AMD_SWEEP_OFFLOAD_HI 1
-#endif
+#define RAMSES_AMD_SWEEP_OFFLOAD_HI 0   // with one barrier per plane the hand-off no longer pays in either build (measured)
 #endif
 constexpr bool OFFLOAD_HI = RAMSES_AMD_SWEEP_OFFLOAD_HI != 0;
 

@@ -26,7 +26,7 @@ def main():
         tag, _, flags = spec.partition("=")
         extra = [f for f in flags.split(",") if f]
         objs = []
-        for mode, mflags in (("strict", ["-ffp-contract=off"]), ("fast", ["-ffp-contract=fast", "-DRAMSES_AMD_FAST=1"])):
+        for mode, mflags in (("strict", ["-ffp-contract=off"]), ("fast", ["-ffp-contract=off", "-DRAMSES_AMD_FAST=1"])):
             o = os.path.join(objdir, "sweep_%s_%s.o" % (tag, mode))
             objs.append(o)
             jobs.append([hipcc] + B.COMMON + mflags + extra + ["-c", src, "-o", o])

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../ramses_amd/csrc"
 i=0
 for knobs in "$@"; do
   for mode in fast strict; do
-    if [ $mode = fast ]; then F="-ffp-contract=fast -DRAMSES_AMD_FAST=1"; else F="-ffp-contract=off"; fi
+    if [ $mode = fast ]; then F="-ffp-contract=off -DRAMSES_AMD_FAST=1"; else F="-ffp-contract=off"; fi
     ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -I ../../include $F $knobs -c hydro_sweep.hip \
         -o /tmp/sweepregs_${i}_$mode.o -Rpass-analysis=kernel-resource-usage 2> /tmp/sweepregs_${i}_$mode.log ) &
   done
