@@ -24,6 +24,8 @@
 // unrefined levels.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "amr_core.hpp"
 #include "amr_sweep_args.hpp"
 #include "hydro_core.hpp"
@@ -359,6 +361,287 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
   }
 }
 
+
+// ===========================================================================
+// Grouped variant: one WORKGROUP per father oct.  The (up to) eight son octs of one level-(l-1) oct
+// are updated together from ONE 8^3 stencil (the 4^3 father cells around the father oct): 512
+// gathered / interpolated cells, 6^3 traces and 240 interface fluxes for 64 cells, where eight
+// single-oct waves gather 8 x 216 cells, trace 8 x 64 and solve 8 x 36 interfaces.  Every cell,
+// slope, traced state and flux is the same function of the same stencil values as in the
+// single-oct kernel (and in the reference), so the results are bit-identical; octs of the group
+// that are not in the call's list (posof < 0) are left alone.  Options this variant does not
+// carry (difmag, pressure_fix) take the single-oct kernel.
+// ===========================================================================
+constexpr int GRP_THREADS = 256;
+#ifndef RAMSES_AMD_GRP_MINWAVES
+#define RAMSES_AMD_GRP_MINWAVES 4   // workgroups per CU the register allocation must allow (256 threads: waves per SIMD)
+#endif
+
+template <int NV>
+struct GrpFaces {
+  double qm[3][80][NV];   // traced state on the +d face of the low cell of face (a = 0..4, 4x4 transverse)
+  double qp[3][80][NV];   // traced state on the -d face of the high cell
+  double fl[3][80][NV];   // flux through the face
+};
+template <int NV>
+struct GrpLds {
+  union {
+    double u[512][NV];     // primitive variables of the 8^3 stencil (until the traces are done)
+    GrpFaces<NV> f;
+  };
+  int fc[64];              // the 4^3 father cells (1-based cell index, 0: not there)
+  int ex[64];              // their son oct (0: not refined)
+  int io[8];               // position of each son of the father oct in the call's list (-1: not active)
+  unsigned char ok[512];   // cell is refined
+};
+__device__ __forceinline__ int gsidx(int i, int j, int k) { return i + 8 * (j + 8 * k); }
+__device__ __forceinline__ int gface(int a, int b, int c) { return a * 16 + b + 4 * c; }
+
+template <int ST, int RS, bool GRAV, int NV, int SCHEME>
+__global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_group_kernel(AmrSweepArgs A, const int *__restrict__ groups,
+                                                                 const int *__restrict__ posof) {
+  __shared__ GrpLds<NV> L;
+  const int t = threadIdx.x;
+  const HydroConst &P = A.P;
+  const int gF = groups[blockIdx.x];          // the father oct (level l-1)
+  const long ncell = A.ncell;
+
+  // ---- (A) the 4^3 father cells around the father oct --------------------------------
+  if (t < 64) {
+    const int i = t & 3, j = (t >> 2) & 3, k = t >> 4;
+    const int bi = i == 0 ? 0 : (i == 3 ? 1 : i - 1), bj = j == 0 ? 0 : (j == 3 ? 1 : j - 1), bk = k == 0 ? 0 : (k == 3 ? 1 : k - 1);
+    int c = (int)(A.ncoarse + (long)(bi + 2 * bj + 4 * bk) * A.ngridmax + gF);
+    const int step[3] = {i == 0 ? -1 : (i == 3 ? 1 : 0), j == 0 ? -1 : (j == 3 ? 1 : 0), k == 0 ? -1 : (k == 3 ? 1 : 0)};
+#pragma unroll
+    for (int axis = 0; axis < 3; axis++) {
+      if (step[axis] != 0 && c > 0) {
+        c = nbor_cell(c, 2 * axis + (step[axis] > 0 ? 1 : 0), A);
+        if (c < 0) c = 0;                      // no oct there: only octs that do not exist would need it
+      }
+    }
+    L.fc[t] = c;
+    L.ex[t] = c > 0 ? A.son[c - 1] : 0;
+  }
+  __syncthreads();
+  if (t < 8) {
+    const int f = (1 + (t & 1)) + 4 * ((1 + ((t >> 1) & 1)) + 4 * (1 + (t >> 2)));
+    const int og = L.ex[f];
+    L.io[t] = og > 0 ? posof[og - 1] : -1;
+  }
+
+  // ---- (B)+(C) gather the 8^3 stencil, convert to primitive variables ------------------
+  const double dtxhalf = A.dt * 0.5;
+  for (int e = t; e < 512; e += GRP_THREADS) {
+    const int ind = e >> 6, f = e & 63;        // lanes run over the father cells first (sibling octs are contiguous)
+    const int og = L.ex[f];
+    if (og > 0) {
+      const int i3 = 2 * (f & 3) + (ind & 1), j3 = 2 * ((f >> 2) & 3) + ((ind >> 1) & 1), k3 = 2 * (f >> 4) + (ind >> 2);
+      const long cell = A.ncoarse + (long)ind * A.ngridmax + og;   // 1-based
+      const int s = gsidx(i3, j3, k3);
+      double u[NV], q[NV], gz[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int v = 0; v < NV; v++) u[v] = A.uold[(long)v * ncell + cell - 1];
+      if (GRAV) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) gz[d] = A.grav[(long)d * ncell + cell - 1];
+      }
+      ctoprim_cell<NV, GRAV>(u, gz, dtxhalf, P, q);
+#pragma unroll
+      for (int v = 0; v < NV; v++) L.u[s][v] = q[v];
+      L.ok[s] = A.son[cell - 1] > 0;
+    }
+  }
+  if (t < 64 && L.ex[t] == 0) {
+    const int c0 = L.fc[t];
+    const int i0 = 2 * (t & 3), j0 = 2 * ((t >> 2) & 3), k0 = 2 * (t >> 4);
+    if (c0 > 0) {
+      // missing oct: interpolate the father cell with its 2*ndim neighbours
+      double u1[7][NV], u2[8][NV];
+#pragma unroll
+      for (int j = 0; j < 7; j++) {
+        int c = c0;
+        if (j > 0) {
+          c = nbor_cell(c0, j - 1, A);
+          if (c < 0) c = -c;
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++) u1[j][v] = A.uold[(long)v * ncell + c - 1];
+      }
+      interpol_hydro_cell<NV>(u1, u2, A.interpol_var, A.interpol_type, P.smallr);
+      double gz[3] = {0.0, 0.0, 0.0};
+      if (GRAV) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) gz[d] = A.grav[(long)d * ncell + c0 - 1];
+      }
+#pragma unroll
+      for (int ind = 0; ind < 8; ind++) {
+        const int s = gsidx(i0 + (ind & 1), j0 + ((ind >> 1) & 1), k0 + (ind >> 2));
+        double q[NV];
+        ctoprim_cell<NV, GRAV>(u2[ind], gz, dtxhalf, P, q);
+#pragma unroll
+        for (int v = 0; v < NV; v++) L.u[s][v] = q[v];
+        L.ok[s] = 0;
+      }
+    } else {
+      // no father cell: nothing that is stored depends on these cells; keep them finite
+#pragma unroll
+      for (int ind = 0; ind < 8; ind++) {
+        const int s = gsidx(i0 + (ind & 1), j0 + ((ind >> 1) & 1), k0 + (ind >> 2));
+#pragma unroll
+        for (int v = 0; v < NV; v++) L.u[s][v] = 1.0;
+        L.ok[s] = 0;
+      }
+    }
+  }
+  __syncthreads();
+
+  // a father cell that an active son needs and that does not exist: the tree breaks the refinement rules
+  if (t < 64 && L.fc[t] == 0) {
+    const int i = t & 3, j = (t >> 2) & 3, k = t >> 4;
+    for (int so = 0; so < 8; so++) {
+      const int dxs = i - (1 + (so & 1)), dys = j - (1 + ((so >> 1) & 1)), dzs = k - (1 + (so >> 2));
+      if (L.io[so] >= 0 && dxs >= -1 && dxs <= 1 && dys >= -1 && dys <= 1 && dzs >= -1 && dzs <= 1) atomicAdd(A.err, 1);
+    }
+  }
+
+  // ---- (D) slopes + trace of the inner 6^3 cells -----------------------------------------
+  const double dtdx = A.dt / A.dx;
+  double qm[3][NV], qp[3][NV];
+  const bool tracer = t < 216;
+  const int ti = t % 6, tj = (t / 6) % 6, tk = t / 36;
+  if (tracer) {
+    const int s = gsidx(ti + 1, tj + 1, tk + 1);
+    double qb[NV], dq[3][NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      qb[v] = L.u[s][v];
+      if constexpr (ST == 3) {
+        double nb[27], d3[3];
+#pragma unroll
+        for (int n = 0; n < 27; n++) nb[n] = L.u[s + (n % 3 - 1) + 8 * ((n / 3) % 3 - 1) + 64 * (n / 9 - 1)][v];
+        slope3_var(nb, d3);
+        dq[0][v] = d3[0]; dq[1][v] = d3[1]; dq[2][v] = d3[2];
+      } else {
+        dq[0][v] = slope1<ST>(L.u[s - 1][v], qb[v], L.u[s + 1][v], P);
+        dq[1][v] = slope1<ST>(L.u[s - 8][v], qb[v], L.u[s + 8][v], P);
+        dq[2][v] = slope1<ST>(L.u[s - 64][v], qb[v], L.u[s + 64][v], P);
+      }
+    }
+    if constexpr (SCHEME == 0) {
+      trace3d_cell<NV>(qb, dq, dtdx, dtdx, dtdx, P, qm, qp);
+    } else {
+      const double cs = ctoprim_sound(qb[0], qb[4], P);
+      tracexyz_cell<NV>(qb, dq, cs, dtdx, dtdx, dtdx, P, qm, qp);
+    }
+  }
+  __syncthreads();            // every thread has read its stencil values: the memory is reused below
+  if (tracer) {
+    const int tc[3] = {ti, tj, tk};
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const int t0 = d == 0 ? 1 : 0, t1 = d == 2 ? 1 : 2;     // transverse axes, increasing
+      const int a = tc[d], b = tc[t0] - 1, c = tc[t1] - 1;
+      if (b >= 0 && b < 4 && c >= 0 && c < 4) {
+        if (a <= 4) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) L.f.qm[d][gface(a, b, c)][v] = qm[d][v];
+        }
+        if (a >= 1) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) L.f.qp[d][gface(a - 1, b, c)][v] = qp[d][v];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- (E) the 240 interface fluxes, zeroed at refined interfaces ---------------------------
+  if (t < 240) {
+    const int d = t / 80, r = t % 80, a = r >> 4, b = r & 3, c = (r >> 2) & 3;
+    double qL[NV], qR[NV], fx[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) { qL[v] = L.f.qm[d][r][v]; qR[v] = L.f.qp[d][r][v]; }
+    const bool pow2 = A.pow2 != 0;
+    if (d == 0) scaled_interface_flux<RS, NV, 0>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
+    else if (d == 1) scaled_interface_flux<RS, NV, 1>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
+    else scaled_interface_flux<RS, NV, 2>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
+    const int t0 = d == 0 ? 1 : 0, t1 = d == 2 ? 1 : 2;
+    int cl[3];
+    cl[d] = a + 1; cl[t0] = b + 2; cl[t1] = c + 2;            // stencil coordinates of the low cell of the face
+    const int sl = gsidx(cl[0], cl[1], cl[2]);
+    const int stride = d == 0 ? 1 : (d == 1 ? 8 : 64);
+    const bool zero = L.ok[sl] || L.ok[sl + stride];
+#pragma unroll
+    for (int v = 0; v < NV; v++) L.f.fl[d][r][v] = zero ? 0.0 : fx[v];
+  }
+  __syncthreads();
+
+  // ---- (F) conservative update of the cells of the active sons -------------------------------
+  if (t < 64) {
+    const int x = t & 3, y = (t >> 2) & 3, z = t >> 4;
+    const int so = (x >> 1) + 2 * (y >> 1) + 4 * (z >> 1);
+    if (L.io[so] >= 0) {
+      const int og = L.ex[(1 + (x >> 1)) + 4 * ((1 + (y >> 1)) + 4 * (1 + (z >> 1)))];
+      const int ind = (x & 1) + 2 * (y & 1) + 4 * (z & 1);
+      const long cell = A.ncoarse + (long)ind * A.ngridmax + og;
+      const int ic[3] = {x, y, z};
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        double un = A.unew[(long)v * ncell + cell - 1];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          const int t0 = d == 0 ? 1 : 0, t1 = d == 2 ? 1 : 2;
+          const int a = ic[d], b = ic[t0], c = ic[t1];
+          un = un + (L.f.fl[d][gface(a, b, c)][v] - L.f.fl[d][gface(a + 1, b, c)][v]);
+        }
+        A.unew[(long)v * ncell + cell - 1] = un;
+      }
+    }
+  }
+  // ---- (G) fluxes owed to coarse neighbour cells (same records as the single-oct kernel) --------
+  if (t >= 64 && t < 64 + 48) {
+    const int e = t - 64, so = e / 6, f = e % 6, d = f >> 1, side = f & 1;
+    const int io = L.io[so];
+    if (io >= 0) {
+      const int sc[3] = {so & 1, (so >> 1) & 1, so >> 2};
+      const int og = L.ex[(1 + sc[0]) + 4 * ((1 + sc[1]) + 4 * (1 + sc[2]))];
+      const int nb = A.nbor[(long)f * A.ngridmax + og - 1];
+      const bool coarse = A.son[nb - 1] == 0;
+      A.corr_tgt[(long)io * 6 + f] = coarse ? nb : 0;
+      if (coarse) {
+        const int t0 = d == 0 ? 1 : 0, t1 = d == 2 ? 1 : 2;
+        const int a = 2 * sc[d] + (side ? 2 : 0);
+        constexpr int CV = NV + 2;
+        double *dst = A.corr + ((long)io * 6 + f) * 4 * CV;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int fi = gface(a, 2 * sc[t0] + (q & 1), 2 * sc[t1] + (q >> 1));
+#pragma unroll
+          for (int v = 0; v < NV; v++) dst[q * CV + v] = L.f.fl[d][fi][v];
+          dst[q * CV + NV] = 0.0;
+          dst[q * CV + NV + 1] = 0.0;
+        }
+      }
+    }
+  }
+}
+
+// groups[] = the father octs that have at least one son in the call's list, each once: the son at the lowest
+// octant position enters it
+__global__ void amr_group_build_kernel(AmrSweepArgs A, const int *posof, int *groups, int *count) {
+  const int io = blockIdx.x * blockDim.x + threadIdx.x;
+  if (io >= A.ngrid) return;
+  const int g = A.igrid[io];
+  const int c = A.father[g - 1];
+  int pos, gF;
+  cell_split(c, A.ncoarse, A.ngridmax, pos, gF);
+  for (int p = 0; p < pos; p++) {
+    const int s = A.son[A.ncoarse + (long)p * A.ngridmax + gF - 1];
+    if (s > 0 && posof[s - 1] >= 0) return;
+  }
+  groups[atomicAdd(count, 1)] = gF;
+}
+
 // posof[oct-1] = position (0-based) of the oct in the active list
 __global__ void amr_posof_kernel(const int *igrid, int ngrid, int *posof) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -430,7 +713,22 @@ __global__ __launch_bounds__(256) void amr_coarse_update_kernel(AmrSweepArgs A, 
 }
 
 template <int ST, int RS, int NV>
-static hipError_t launch3(const AmrSweepArgs &A, hipStream_t s) {
+static hipError_t launch3(const AmrSweepArgs &A, const int *groups, int ngroups, const int *posof, hipStream_t s) {
+  if (ngroups > 0) {
+    const dim3 grid(ngroups), block(GRP_THREADS);
+    if (A.scheme == 1) {
+      if constexpr (NV == 5) {
+        if (A.grav) hipLaunchKernelGGL((amr_group_kernel<ST, RS, true, NV, 1>), grid, block, 0, s, A, groups, posof);
+        else hipLaunchKernelGGL((amr_group_kernel<ST, RS, false, NV, 1>), grid, block, 0, s, A, groups, posof);
+        return hipGetLastError();
+      } else {
+        return hipErrorInvalidValue;
+      }
+    }
+    if (A.grav) hipLaunchKernelGGL((amr_group_kernel<ST, RS, true, NV, 0>), grid, block, 0, s, A, groups, posof);
+    else hipLaunchKernelGGL((amr_group_kernel<ST, RS, false, NV, 0>), grid, block, 0, s, A, groups, posof);
+    return hipGetLastError();
+  }
   const int blocks = (A.ngrid + OCTS_PER_BLOCK - 1) / OCTS_PER_BLOCK;
   const dim3 grid(blocks), block(64 * OCTS_PER_BLOCK);
   if (A.scheme == 1) {
@@ -448,23 +746,23 @@ static hipError_t launch3(const AmrSweepArgs &A, hipStream_t s) {
   return hipGetLastError();
 }
 template <int ST, int RS>
-static hipError_t launch2(const AmrSweepArgs &A, hipStream_t s) {
+static hipError_t launch2(const AmrSweepArgs &A, const int *groups, int ngroups, const int *posof, hipStream_t s) {
   switch (A.nvar) {
-    case 5: return launch3<ST, RS, 5>(A, s);
-    case 6: return launch3<ST, RS, 6>(A, s);
-    case 7: return launch3<ST, RS, 7>(A, s);
+    case 5: return launch3<ST, RS, 5>(A, groups, ngroups, posof, s);
+    case 6: return launch3<ST, RS, 6>(A, groups, ngroups, posof, s);
+    case 7: return launch3<ST, RS, 7>(A, groups, ngroups, posof, s);
   }
   return hipErrorInvalidValue;
 }
 
 template <int ST>
-static hipError_t launch1(const AmrSweepArgs &A, int rs, hipStream_t s) {
+static hipError_t launch1(const AmrSweepArgs &A, int rs, const int *groups, int ngroups, const int *posof, hipStream_t s) {
   switch (rs) {
-    case RIEMANN_LLF: return launch2<ST, RIEMANN_LLF>(A, s);
-    case RIEMANN_HLLC: return launch2<ST, RIEMANN_HLLC>(A, s);
-    case RIEMANN_HLL: return launch2<ST, RIEMANN_HLL>(A, s);
-    case RIEMANN_ACOUSTIC: return launch2<ST, RIEMANN_ACOUSTIC>(A, s);
-    case RIEMANN_EXACT: return launch2<ST, RIEMANN_EXACT>(A, s);
+    case RIEMANN_LLF: return launch2<ST, RIEMANN_LLF>(A, groups, ngroups, posof, s);
+    case RIEMANN_HLLC: return launch2<ST, RIEMANN_HLLC>(A, groups, ngroups, posof, s);
+    case RIEMANN_HLL: return launch2<ST, RIEMANN_HLL>(A, groups, ngroups, posof, s);
+    case RIEMANN_ACOUSTIC: return launch2<ST, RIEMANN_ACOUSTIC>(A, groups, ngroups, posof, s);
+    case RIEMANN_EXACT: return launch2<ST, RIEMANN_EXACT>(A, groups, ngroups, posof, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -479,13 +777,31 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A, int slope_type, int riemann
   e = hipMemsetAsync(posof, 0xff, sizeof(int) * A.ngridmax, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(amr_posof_kernel, dim3((A.ngrid + 255) / 256), dim3(256), 0, s, A.igrid, A.ngrid, posof);
+  // One workgroup per father oct (its sons share one stencil) unless an option only the single-oct kernel
+  // carries is on; RAMSES_AMD_AMR_GROUP=0 forces the single-oct kernel (A/B).
+  int *groups = posof + A.ngridmax, *count = groups + A.ngrid;     // workspace tail (ramses_amd_godunov_fine_amr_workspace)
+  int ngroups = 0;
+  static int use_groups = -1;
+  if (use_groups < 0) {
+    const char *env = getenv("RAMSES_AMD_AMR_GROUP");
+    use_groups = !(env && env[0] == '0');
+  }
+  if (use_groups && !(A.difmag > 0.0) && A.divu == nullptr) {
+    e = hipMemsetAsync(count, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(amr_group_build_kernel, dim3((A.ngrid + 255) / 256), dim3(256), 0, s, A, posof, groups, count);
+    e = hipMemcpyAsync(&ngroups, count, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+  }
   switch (slope_type) {
-    case 0: e = launch1<0>(A, riemann, s); break;
-    case 1: e = launch1<1>(A, riemann, s); break;
-    case 2: e = launch1<2>(A, riemann, s); break;
-    case 3: e = launch1<3>(A, riemann, s); break;
-    case 7: e = launch1<7>(A, riemann, s); break;
-    case 8: e = launch1<8>(A, riemann, s); break;
+    case 0: e = launch1<0>(A, riemann, groups, ngroups, posof, s); break;
+    case 1: e = launch1<1>(A, riemann, groups, ngroups, posof, s); break;
+    case 2: e = launch1<2>(A, riemann, groups, ngroups, posof, s); break;
+    case 3: e = launch1<3>(A, riemann, groups, ngroups, posof, s); break;
+    case 7: e = launch1<7>(A, riemann, groups, ngroups, posof, s); break;
+    case 8: e = launch1<8>(A, riemann, groups, ngroups, posof, s); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;

@@ -755,7 +755,9 @@ int ramses_amd_godunov_fine_host(const ramses_amd_hydro_params *p, int ilevel, i
 // workspace of the device entry point, in bytes
 int64_t ramses_amd_godunov_fine_amr_workspace(int ngrid, int64_t ngridmax) {
   if (ngrid < 0 || ngridmax < 1) return fail(RAMSES_AMD_EINVAL, "bad argument");
-  return (int64_t)(sizeof(double) * (size_t)ngrid * 6 * 4 * 9 + sizeof(int) * (size_t)ngrid * 6 + sizeof(int) * (size_t)ngridmax + 64);
+  // coarse-correction records, their targets, oct -> list position, the father-oct groups and their counter
+  return (int64_t)(sizeof(double) * (size_t)ngrid * 6 * 4 * 9 + sizeof(int) * (size_t)ngrid * 6 + sizeof(int) * (size_t)ngridmax +
+                   sizeof(int) * ((size_t)ngrid + 16) + 64);
 }
 
 static int amr_check(const ramses_amd_hydro_params *p, int ilevel, int nvector, int interpol_var, int interpol_type) {
