@@ -285,6 +285,12 @@ struct MpiRes {
   std::vector<int64_t> send_off, send_cnt, recv_off, recv_cnt;   // per entry of peers, in doubles
   std::vector<int64_t> f_send_off, f_recv_off;  // [ncpu+1] for the Fortran shim (host-staged transport)
   long nexchanges = 0;
+  // overlap: the shell sweep produces every cell the peers receive; the exchange of the NEW state then runs on a
+  // second stream behind the interior sweep (the reference runs them back to back, amr/amr_step.f90:388-510)
+  hipStream_t s_comp = nullptr, s_comm = nullptr;
+  hipEvent_t ev_shell = nullptr, ev_comm = nullptr;
+  bool overlap = false;         // configured (RAMSES_AMD_OVERLAP != 0 and every emission oct lies in the boundary layer)
+  int prefetched = 0;           // 0 no; 1 packed and staged to the host buffer; 2 exchanged and unpacked (RCCL)
 };
 MpiRes g_mr;
 
@@ -426,6 +432,27 @@ int ramses_amd_mpires_setup(const ramses_amd_hydro_params *p, int ilevel, int ng
   HCHK(launch_oct_copy(A, true, s), "gather launch");
   if (int rc = self_fill(M, M.bold.as<double>(), s)) return rc;
   HCHK(hipStreamSynchronize(s), "sync");
+  if (!M.s_comp) {
+    HCHK(hipStreamCreateWithFlags(&M.s_comp, hipStreamNonBlocking), "hipStreamCreate");
+    HCHK(hipStreamCreateWithFlags(&M.s_comm, hipStreamNonBlocking), "hipStreamCreate");
+    HCHK(hipEventCreateWithFlags(&M.ev_shell, hipEventDisableTiming), "hipEventCreate");
+    HCHK(hipEventCreateWithFlags(&M.ev_comm, hipEventDisableTiming), "hipEventCreate");
+  }
+  {
+    const char *e = getenv("RAMSES_AMD_OVERLAP");
+    M.overlap = !(e && e[0] == '0');
+    // every emission oct must be produced by the shell launch: within one oct of a face shared with a peer
+    for (int m = 0; m < nem && M.overlap; m++) {
+      bool edge = false;
+      for (int d = 0; d < 3; d++) {
+        if (P.self_axes >> d & 1) continue;
+        const int r = oct_coord(xg, ngridmax, em_igrid[m], d, P.no) - P.olo[d];
+        if (r == 0 || r == P.odim[d] - 1) edge = true;
+      }
+      if (!edge) M.overlap = false;
+    }
+  }
+  M.prefetched = 0;
   M.valid = true; M.host_stale = false; M.new_ready = false; M.nexchanges = 0;
   return 0;
 }
@@ -449,7 +476,7 @@ int ramses_amd_mpires_courant(const ramses_amd_hydro_params *p, double dx, doubl
   NEED_VALID("courant_fine");
   if (!p || !out4) return failf(RAMSES_AMD_EINVAL, "NULL argument");
   MpiRes &M = g_mr;
-  hipStream_t s = nullptr;
+  hipStream_t s = M.s_comp;
   if (int rc = ramses_amd_courant_init(p, dx, M.red.as<double>(), s)) return rc;
   if (int rc = ramses_amd_courant_brick(p, &M.brick, M.bold.as<double>(), nullptr, dx, M.red.as<double>(), s)) return rc;
   HCHK(hipMemcpyAsync(out4, M.red.p, sizeof(double) * 4, hipMemcpyDeviceToHost, s), "D2H courant");
@@ -458,11 +485,44 @@ int ramses_amd_mpires_courant(const ramses_amd_hydro_params *p, double dx, doubl
   return 0;
 }
 
-// set_unew + godunov_fine: bold (ghosts current) -> bnew interior
+// set_unew + godunov_fine: bold (ghosts current) -> bnew interior.  With the overlap on, the launch is split:
+// shell (every cell within one oct of a face) on the compute stream; then, on the communication stream, the
+// + 0.0 of the reverse exchange, the pack of the NEW state and its way to the peers (RCCL: the whole exchange
+// and the unpack into the ghost layer of bnew; host transport: the copy into the pinned send buffer) run while
+// the compute stream sweeps the interior.  Same values as the serial order.
 int ramses_amd_mpires_godunov(const ramses_amd_hydro_params *p, double dx, double dt) {
   NEED_VALID("godunov_fine");
   MpiRes &M = g_mr;
-  if (int rc = ramses_amd_godunov_brick(p, &M.brick, M.bold.as<double>(), nullptr, M.bnew.as<double>(), dx, dt, nullptr)) return rc;
+  M.prefetched = 0;
+  if (!M.overlap) {
+    if (int rc = ramses_amd_godunov_brick(p, &M.brick, M.bold.as<double>(), nullptr, M.bnew.as<double>(), dx, dt, M.s_comp)) return rc;
+    M.new_ready = true;
+    return 0;
+  }
+  if (int rc = ramses_amd_godunov_brick_shell(p, &M.brick, M.bold.as<double>(), nullptr, M.bnew.as<double>(), dx, dt, M.s_comp)) return rc;
+  HCHK(hipEventRecord(M.ev_shell, M.s_comp), "event record");
+  HCHK(hipStreamWaitEvent(M.s_comm, M.ev_shell, 0), "stream wait");
+  {
+    hipStream_t s = M.s_comm;
+    const int nem = M.plan.em_first[M.ncpu];
+    OctListArgs Z = list_args(M, M.bnew.as<double>(), nullptr, M.em_org.as<int64_t>(), nullptr, nem);
+    HCHK(launch_oct_list(Z, OL_ADDZERO, s), "reverse launch");
+    OctListArgs A = list_args(M, M.bnew.as<double>(), M.sendbuf.as<double>(), M.em_org.as<int64_t>(), nullptr, nem);
+    HCHK(launch_oct_list(A, OL_PACK, s), "halo pack launch");
+    if (ramses_amd_rccl_ready()) {
+      if (int rc = ramses_amd_rccl_exchange((int)M.peers.size(), M.peers.data(), M.sendbuf.as<double>(), M.send_off.data(), M.send_cnt.data(),
+                                            M.recvbuf.as<double>(), M.recv_off.data(), M.recv_cnt.data(), s)) return rc;
+      OctListArgs B = list_args(M, M.bnew.as<double>(), M.recvbuf.as<double>(), M.rc_org.as<int64_t>(), M.rc_src.as<int>(), (int)M.plan.rc_src.size());
+      HCHK(launch_oct_list(B, OL_UNPACK, s), "halo unpack launch");
+      if (int rc = self_fill(M, M.bnew.as<double>(), s)) return rc;
+      M.prefetched = 2;
+    } else {
+      if (nem) HCHK(hipMemcpyAsync(M.h_send.p, M.sendbuf.p, sizeof(double) * 8 * M.nvar * (size_t)nem, hipMemcpyDeviceToHost, s), "D2H halo");
+      M.prefetched = 1;
+    }
+    HCHK(hipEventRecord(M.ev_comm, s), "event record");
+  }
+  if (int rc = ramses_amd_godunov_brick_interior(p, &M.brick, M.bold.as<double>(), nullptr, M.bnew.as<double>(), dx, dt, M.s_comp)) return rc;
   M.new_ready = true;
   return 0;
 }
@@ -474,8 +534,9 @@ int ramses_amd_mpires_reverse_unew(void) {
   NEED_VALID("make_virtual_reverse_dp");
   MpiRes &M = g_mr;
   if (!M.new_ready) return failf(RAMSES_AMD_EINVAL, "make_virtual_reverse_dp(unew): no godunov_fine result pending");
+  if (M.prefetched) return 0;     // done on the communication stream before the pack (ramses_amd_mpires_godunov)
   OctListArgs A = list_args(M, M.bnew.as<double>(), nullptr, M.em_org.as<int64_t>(), nullptr, M.plan.em_first[M.ncpu]);
-  HCHK(launch_oct_list(A, OL_ADDZERO, nullptr), "reverse launch");
+  HCHK(launch_oct_list(A, OL_ADDZERO, M.s_comp), "reverse launch");
   return 0;
 }
 
@@ -492,7 +553,14 @@ int ramses_amd_mpires_set_uold(void) {
 int ramses_amd_mpires_halo_forward(void) {
   NEED_VALID("make_virtual_fine_dp");
   MpiRes &M = g_mr;
-  hipStream_t s = nullptr;
+  hipStream_t s = M.s_comp;
+  if (M.prefetched == 2 && !M.new_ready) {
+    // the exchange of this state ran behind the interior sweep: the compute stream only has to wait for it
+    HCHK(hipStreamWaitEvent(s, M.ev_comm, 0), "stream wait");
+    M.prefetched = 0;
+    M.nexchanges++;
+    return 0;
+  }
   OctListArgs A = list_args(M, M.bold.as<double>(), M.sendbuf.as<double>(), M.em_org.as<int64_t>(), nullptr, M.plan.em_first[M.ncpu]);
   HCHK(launch_oct_list(A, OL_PACK, s), "halo pack launch");
   if (int rc = ramses_amd_rccl_exchange((int)M.peers.size(), M.peers.data(), M.sendbuf.as<double>(), M.send_off.data(), M.send_cnt.data(),
@@ -511,12 +579,18 @@ int ramses_amd_mpires_halo_stage_out(double **h_send, const int64_t **send_off, 
   NEED_VALID("make_virtual_fine_dp");
   if (!h_send || !send_off || !h_recv || !recv_off) return failf(RAMSES_AMD_EINVAL, "NULL argument");
   MpiRes &M = g_mr;
-  hipStream_t s = nullptr;
+  hipStream_t s = M.s_comp;
   const int nem = M.plan.em_first[M.ncpu];
-  OctListArgs A = list_args(M, M.bold.as<double>(), M.sendbuf.as<double>(), M.em_org.as<int64_t>(), nullptr, nem);
-  HCHK(launch_oct_list(A, OL_PACK, s), "halo pack launch");
-  if (nem) HCHK(hipMemcpyAsync(M.h_send.p, M.sendbuf.p, sizeof(double) * 8 * M.nvar * (size_t)nem, hipMemcpyDeviceToHost, s), "D2H halo");
-  HCHK(hipStreamSynchronize(s), "sync");
+  if (M.prefetched == 1 && !M.new_ready) {
+    // packed and copied to the pinned buffer behind the interior sweep
+    HCHK(hipEventSynchronize(M.ev_comm), "event sync");
+    M.prefetched = 0;
+  } else {
+    OctListArgs A = list_args(M, M.bold.as<double>(), M.sendbuf.as<double>(), M.em_org.as<int64_t>(), nullptr, nem);
+    HCHK(launch_oct_list(A, OL_PACK, s), "halo pack launch");
+    if (nem) HCHK(hipMemcpyAsync(M.h_send.p, M.sendbuf.p, sizeof(double) * 8 * M.nvar * (size_t)nem, hipMemcpyDeviceToHost, s), "D2H halo");
+    HCHK(hipStreamSynchronize(s), "sync");
+  }
   *h_send = M.h_send.as<double>(); *h_recv = M.h_recv.as<double>();
   *send_off = M.f_send_off.data(); *recv_off = M.f_recv_off.data();
   return 0;
@@ -524,7 +598,7 @@ int ramses_amd_mpires_halo_stage_out(double **h_send, const int64_t **send_off, 
 int ramses_amd_mpires_halo_stage_in(void) {
   NEED_VALID("make_virtual_fine_dp");
   MpiRes &M = g_mr;
-  hipStream_t s = nullptr;
+  hipStream_t s = M.s_comp;
   const int nrcm = M.plan.rc_first[M.ncpu];
   if (nrcm) HCHK(hipMemcpyAsync(M.recvbuf.p, M.h_recv.p, sizeof(double) * 8 * M.nvar * (size_t)nrcm, hipMemcpyHostToDevice, s), "H2D halo");
   OctListArgs B = list_args(M, M.bold.as<double>(), M.recvbuf.as<double>(), M.rc_org.as<int64_t>(), M.rc_src.as<int>(), (int)M.plan.rc_src.size());
@@ -550,7 +624,8 @@ int ramses_amd_mpires_sync_host(double *uold) {
   MpiRes &M = g_mr;
   if (!M.valid || !M.host_stale) return 0;
   if (uold != M.h_uold) return failf(RAMSES_AMD_EINVAL, "sync_host: not the array the level was loaded from");
-  hipStream_t s = nullptr;
+  hipStream_t s = M.s_comp;
+  HCHK(hipStreamSynchronize(M.s_comm), "sync");
   PackArgs A;
   A.igrid = M.load_igrid.as<int>(); A.octorg = reinterpret_cast<const long *>(M.load_org.p);
   A.ngrid = M.ngrid + (int)M.plan.rc_src.size();   // the ghost octs too: the host's reception cells stay what an exchange would leave

@@ -32,14 +32,17 @@ def _run(nml, binary, nproc, env):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("nproc,level,riemann,slope", [(2, 5, "llf", 1), (4, 5, "hllc", 2), (8, 6, "llf", 1), (2, 2, "llf", 1)])
-def test_mpi_resident_bricks_equal_mpi_reference(gpu_lib, nproc, level, riemann, slope):
+@pytest.mark.parametrize("nproc,level,riemann,slope,overlap", [(2, 5, "llf", 1, "1"), (4, 5, "hllc", 2, "1"), (8, 6, "llf", 1, "1"),
+                                                               (2, 2, "llf", 1, "1"), (4, 6, "llf", 1, "0"), (8, 7, "llf", 1, "1")])
+def test_mpi_resident_bricks_equal_mpi_reference(gpu_lib, nproc, level, riemann, slope, overlap):
+    """overlap = 1 (default): shell sweep, then the pack / exchange of the new state on a second stream behind the
+    interior sweep; 0: sweep, then exchange.  Same snapshots."""
     if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED_MPI)):
         pytest.skip("oracle/_ref/ramses3d_mpi[_patch] not built")
     from oracle import ramses_snapshot as rs
     nstep = 6
     nml = rs.sedov3d_namelist(level=level, nstepmax=nstep, foutput=nstep, riemann=riemann, slope_type=slope, mem_factor=6.0)
-    workp, outp = _run(nml, PATCHED_MPI, nproc, {"RAMSES_AMD": "1"})
+    workp, outp = _run(nml, PATCHED_MPI, nproc, {"RAMSES_AMD": "1", "RAMSES_AMD_OVERLAP": overlap})
     try:
         assert "stays resident on the GPUs" in outp, outp[-2000:]
         assert ("halo exchange over RCCL" in outp) or ("staged through host MPI" in outp)
