@@ -83,8 +83,9 @@ def _cpu_baseline_port(n_ref=48, steps=1):
 def cpu_baseline():
     """The reference itself (oracle/_ref/ramses3d[_mpi], the unmodified F90
     program built by oracle/build_ref.sh) on the host cores of this box, on a
-    bounded sample of the same workload: sedov3d.nml at 128^3 (MPI) or 64^3
-    (serial); the rate comes from its own 'hydro - godunov' timer row."""
+    bounded sample of the same workload: sedov3d.nml at 256^3 (config C2, MPI on up
+    to 64 cores; 128^3 below 16 cores) or 64^3 (serial); the rate comes from its own
+    'hydro - godunov' timer row."""
     import re
     import shutil
     ref = os.path.join(ROOT, "oracle", "_ref")
@@ -100,9 +101,9 @@ def cpu_baseline():
             pass
         if os.path.exists(mpi_bin) and os.path.exists(mpiexec) and ncores >= 2:
             P = 1
-            while P * 2 <= min(ncores, 32):
+            while P * 2 <= min(ncores, 64):
                 P *= 2
-            level, nstep, binary = 7, 10, mpi_bin
+            level, nstep, binary = (8 if P >= 16 else 7), 10, mpi_bin
         elif os.path.exists(ser_bin):
             P, level, nstep, binary = 1, 6, 8, ser_bin
         else:
@@ -129,9 +130,11 @@ def cpu_baseline():
 def pmc_traffic(n, world, args):
     """HBM bytes per sweep launch from the rocprofv3 PMC passes (FETCH_SIZE with the
     gfx950 calibration + WRITE_SIZE), measured by scripts/profile_gpu.sh on this
-    same command and committed under profiles/; null when no matching profile."""
-    path = os.path.join(ROOT, "profiles", "r01_sweep_traffic.json")
+    same command with the current kernel and committed under profiles/ (the newest
+    r*_sweep_traffic.json); null when no matching profile."""
+    import glob
     try:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sweep_traffic.json")))[-1]
         t = json.load(open(path))
         if t["n"] == n and world == 1 and args.fast == 1 and not args.tile_rows and not args.zchunk:
             return t["traffic_bytes_per_launch"]
@@ -428,7 +431,8 @@ def main():
             "config": {"workload": "sedov3d.nml uniform %d^3 per GPU (%dx%dx%d ranks, global %dx%dx%d), "
                                    "hydro-only Godunov sweep, LLF + minmod, muscl"
                                    % (n, pgrid[0], pgrid[1], pgrid[2], n * pgrid[0], n * pgrid[1], n * pgrid[2]),
-                       "arithmetic": "fast (FMA contraction, <=1e-12 rel of strict)" if args.fast else "strict (bit-identical to the reference)",
+                       "arithmetic": "fast (explicit FMAs, rcp/rsq + Newton; rel-Linf of strict <= 2e-15 over 24 Sedov steps at 64^3 and 128^3, "
+                                     "bound 1e-12: tests/test_baseline_sizes_gpu.py::test_fast_build_multistep_within_tolerance)" if args.fast else "strict (bit-identical to the reference)",
                        "halo": "none (single rank, in-kernel periodic wrap)" if world == 1 else
                                ("RCCL send/recv (torch.distributed)" if transport_note is None else transport_note) +
                                " of 2-cell face slabs, all nvar fused, " +

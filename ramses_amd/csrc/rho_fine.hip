@@ -11,8 +11,8 @@
 //     tags each with its position in that loop nest, and adds them in tag order (the order-tagged
 //     gather validated on the CPU by oracle/rho_fine_oracle.c: ora_rho_deposit_gather);
 //   * multipole(1:4) (rho_tot = multipole(1)/scale^3 enters the right-hand side of the Poisson solve):
-//     strictly sequential sums over all cells in list order -- one lane adds, the other threads of
-//     the workgroup stream the operands into LDS ahead of it (one workgroup per component).
+//     strictly sequential sums over all cells in list order, reproduced bit for bit by a parallel scan
+//     of parity functions (see multipole_kernel; one workgroup per component).
 // This unit is compiled with -ffp-contract=off: IEEE operations in the reference's order.
 #include <hip/hip_runtime.h>
 
@@ -112,13 +112,38 @@ __global__ __launch_bounds__(DEP_THREADS) void rho_deposit_kernel(RhoArgs A) {
   A.rho[t] = r;
 }
 
-// multipole(d), d = 0..3: sequential sum over the cells in the order (batch of nvector octs, ind_son, oct in
-// the batch) of cic_from_multipole (:858-866).  One workgroup per component; thread 0 adds, threads 1.. stage
-// the next chunk of operands in LDS.
-constexpr int MP_THREADS = 256;
-constexpr int MP_CHUNK = 2040;     // 8 operands per staging thread
+// multipole(d), d = 0..3: the SEQUENTIAL sum  s <- fl(s + a_i)  over the cells in the order (batch of nvector
+// octs, ind_son, oct in the batch) of cic_from_multipole (:858-866), reproduced bit for bit by a parallel scan.
+//
+// While the running sum stays inside one binade [2^E, 2^(E+1)) its spacing is u = 2^(E-52), and adding a
+// positive a_i is an INTEGER operation on S = s/u: S <- S + n_i + (rem_i > u/2) + (rem_i == u/2 and S + n_i odd),
+// with n_i = floor(a_i/u) and rem_i the part of a_i below u (round to nearest, ties to even).  The increment
+// depends on what came before only through the parity of S, so a run of elements is a function
+// parity -> (increment for parity 0, increment for parity 1), and these functions compose associatively: a
+// workgroup scans them like a prefix sum.  Elements that could leave the binade (checked with a margin of one
+// unit per element) end the scan: the thread that owns them adds its elements with real floating-point adds,
+// the exponent is re-read and the scan restarts behind them.  The sum crosses ~log2(N) binades in all.
+// One workgroup per component; all additions are either exact integer sums or IEEE adds in the original order.
+constexpr int MP_THREADS = 1024;
+constexpr int MP_K = 8;                 // consecutive elements per thread and chunk
+struct ParFn { long t0, t1; };          // increment of S for incoming parity 0 / 1
+__device__ __forceinline__ ParFn par_compose(const ParFn &f, const ParFn &g) {   // f first, then g
+  ParFn r;
+  r.t0 = f.t0 + ((f.t0 & 1) ? g.t1 : g.t0);
+  r.t1 = f.t1 + (((1 + f.t1) & 1) ? g.t1 : g.t0);
+  // saturate (elements that leave the binade carry 2^53): anything beyond 2^53 only has to stay beyond it
+  const long cap = 1L << 60;
+  r.t0 = r.t0 < cap ? r.t0 : cap;
+  r.t1 = r.t1 < cap ? r.t1 : cap;
+  return r;
+}
+constexpr long MP_POISON = 1L << 53;
+
 __global__ __launch_bounds__(MP_THREADS) void multipole_kernel(RhoArgs A, double *__restrict__ out) {
-  __shared__ double buf[2][MP_CHUNK];
+  __shared__ ParFn wavefn[MP_THREADS / 64];
+  __shared__ double sh_s;
+  __shared__ long sh_next;
+  __shared__ int sh_cross;
   const int comp = blockIdx.x;       // 0: mass, 1..3: mass * position
   const int n = A.n;
   const long ncells = (long)A.ngrid * 8;
@@ -145,36 +170,105 @@ __global__ __launch_bounds__(MP_THREADS) void multipole_kernel(RhoArgs A, double
     const double xx = (xg + xc - 0.0) * A.scale;
     return mm * xx;
   };
-  const long nchunk = (ncells + MP_CHUNK - 1) / MP_CHUNK;
-  // first chunk: staged by everybody but thread 0 as well (uniform code)
-  auto stage = [&](long k) {
-    if (threadIdx.x == 0) return;
-    const long base = k * MP_CHUNK;
-    for (int e = threadIdx.x - 1; e < MP_CHUNK; e += MP_THREADS - 1) {
-      const long p = base + e;
-      buf[k & 1][e] = p < ncells ? operand(p) : 0.0;
-    }
-  };
-  stage(0);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) {
+    // the first elements cross a binade at almost every addition: plain sequential adds
+    double s = 0.0;
+    const long m = ncells < 64 ? ncells : 64;
+    for (long p = 0; p < m; p++) s = s + operand(p);
+    sh_s = s;
+    sh_next = m;
+  }
   __syncthreads();
-  double s = 0.0;
-  for (long k = 0; k < nchunk; k++) {
-    if (threadIdx.x == 0) {
-      const long left = ncells - k * MP_CHUNK;
-      const int m = left < MP_CHUNK ? (int)left : MP_CHUNK;
-      const double *b = buf[k & 1];
-      int e = 0;
-      for (; e + 8 <= m; e += 8) {
-        const double a0 = b[e], a1 = b[e + 1], a2 = b[e + 2], a3 = b[e + 3], a4 = b[e + 4], a5 = b[e + 5], a6 = b[e + 6], a7 = b[e + 7];
-        s = s + a0; s = s + a1; s = s + a2; s = s + a3; s = s + a4; s = s + a5; s = s + a6; s = s + a7;
+  while (true) {
+    const long i0 = sh_next;
+    if (i0 >= ncells) break;
+    const double s = sh_s;
+    const long sbits = __double_as_longlong(s);
+    const int sexp = (int)((sbits >> 52) & 0x7ff);
+    // (s is a positive normal number here: sums of positive normal operands)
+    const long S = (sbits & 0xfffffffffffffL) | (1L << 52);
+    const int qu = sexp - 1075;                       // s = S * 2^qu
+    // ---- this thread's MP_K elements as one parity function (+ an upper bound of their increments) ----
+    double a[MP_K];
+    const long base = i0 + (long)tid * MP_K;
+#pragma unroll
+    for (int e = 0; e < MP_K; e++) a[e] = (base + e) < ncells ? operand(base + e) : 0.0;
+    ParFn f = {0, 0};
+    long ub = 0;
+#pragma unroll
+    for (int e = 0; e < MP_K; e++) {
+      const long ab = __double_as_longlong(a[e]);
+      const int aexp = (int)((ab >> 52) & 0x7ff);
+      const long m = aexp ? ((ab & 0xfffffffffffffL) | (1L << 52)) : (ab & 0xfffffffffffffL);
+      const int q = (aexp ? aexp : 1) - 1075;         // a = m * 2^q
+      const int k = qu - q;                           // a / u = m / 2^k
+      long nint, inc_gt;
+      int tie;
+      if (m == 0) { nint = 0; inc_gt = 0; tie = 0; }
+      else if (k <= 0) { nint = MP_POISON; inc_gt = 0; tie = 0; }       // a >= 2^E: leaves the binade
+      else if (k >= 64) { nint = 0; inc_gt = 0; tie = 0; }
+      else {
+        nint = m >> k;
+        const long rem = m & ((1L << k) - 1), half = 1L << (k - 1);
+        inc_gt = rem > half ? 1 : 0;
+        tie = rem == half ? 1 : 0;
       }
-      for (; e < m; e++) s = s + b[e];
-    } else if (k + 1 < nchunk) {
-      stage(k + 1);
+      const long bsum = nint + inc_gt;
+      ParFn g;
+      g.t0 = bsum + (tie ? (nint & 1) : 0);           // incoming parity 0: S + n odd  <=>  n odd
+      g.t1 = bsum + (tie ? ((nint + 1) & 1) : 0);
+      f = par_compose(f, g);
+      ub += nint + 1;
+      if (ub > MP_POISON) ub = MP_POISON;
+    }
+    // ---- inclusive scan of the functions over the workgroup (wave shuffles, then the 16 wave totals) ----
+    ParFn inc = f;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      ParFn o;
+      o.t0 = __shfl_up(inc.t0, off, 64);
+      o.t1 = __shfl_up(inc.t1, off, 64);
+      if (lane >= off) inc = par_compose(o, inc);
+    }
+    if (lane == 63) wavefn[wv] = inc;
+    __syncthreads();
+    ParFn pre = {0, 0};                                // everything before this thread's wave
+    for (int w = 0; w < wv; w++) pre = par_compose(pre, wavefn[w]);
+    ParFn excl;                                        // everything before this thread
+    {
+      ParFn o;
+      o.t0 = __shfl_up(inc.t0, 1, 64);
+      o.t1 = __shfl_up(inc.t1, 1, 64);
+      if (lane == 0) { o.t0 = 0; o.t1 = 0; }
+      excl = par_compose(pre, o);
+    }
+    const int p0 = (int)(S & 1);
+    const long S_t = S + (p0 ? excl.t1 : excl.t0);     // S on entry of this thread's elements
+    const bool unsafe = (ub >= MP_POISON) || (S_t + ub >= MP_POISON) || (S_t >= MP_POISON);
+    if (tid == 0) sh_cross = MP_THREADS;
+    __syncthreads();
+    if (unsafe) atomicMin(&sh_cross, tid);
+    __syncthreads();
+    const int tc = sh_cross;
+    if (tc == MP_THREADS) {
+      if (tid == MP_THREADS - 1) {
+        const ParFn tot = par_compose(excl, f);
+        const long S_end = S + (p0 ? tot.t1 : tot.t0);
+        sh_s = __builtin_ldexp((double)S_end, qu);
+        sh_next = i0 + (long)MP_THREADS * MP_K;
+      }
+    } else if (tid == tc) {
+      // everything before this thread stayed inside the binade; its own elements are added one by one
+      double sc = __builtin_ldexp((double)S_t, qu);
+#pragma unroll
+      for (int e = 0; e < MP_K; e++) sc = sc + a[e];
+      sh_s = sc;
+      sh_next = base + MP_K;
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[comp] = s;
+  if (tid == 0) out[comp] = sh_s;
 }
 
 hipError_t launch_oct_index(const long *octorg, int ngrid, int n, int *octidx, hipStream_t s) {

@@ -123,7 +123,48 @@ def run_grav(tag, binary, env, level, nstep):
                       "vcycles": [int(b) for _, b, _ in solves], "timers_s": rows}), flush=True)
 
 
+def run_mpi(tag, binary, env, level, nstep, nproc):
+    """sedov3d.nml on nproc MPI ranks (one brick per rank): the MAX column of the reference's MPI timer table"""
+    nml = rs.sedov3d_namelist(level=level, nstepmax=nstep, foutput=1000, mem_factor=4.0)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    t0 = time.time()
+    try:
+        work, out = rs.run_reference(nml, binary=binary, nproc=nproc, timeout=3000)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    wall = time.time() - t0
+    shutil.rmtree(work, ignore_errors=True)
+    rows = {}
+    for line in out.splitlines():
+        m = re.match(r"^\s*([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+\S+\s+([0-9.]+)\s+(\d+)\s+(\d+)\s+([a-zA-Z].*?)\s*$", line)
+        if m:
+            rows[m.group(8)] = float(m.group(3))
+        m = re.match(r"^\s*([0-9.]+)\s+100\.0\s+TOTAL", line)
+        if m:
+            rows["TOTAL"] = float(m.group(1))
+    note = [l.strip() for l in out.splitlines() if "ramses_amd:" in l]
+    print(json.dumps({"config": tag, "level": level, "steps": nstep, "ranks": nproc, "wall_s": round(wall, 3),
+                      "timers_max_s": rows, "notes": note[:4]}), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "mpi":
+        level, nstep, nproc = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+        which = sys.argv[5] if len(sys.argv) > 5 else "all"
+        ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi")
+        pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi_patch")
+        if which in ("all", "gpu"):
+            run_mpi("patched, one brick per rank resident on the GPU, exchange behind the interior sweep", pat, {"RAMSES_AMD": "1"}, level, nstep, nproc)
+            run_mpi("patched, resident bricks, exchange after the sweep", pat, {"RAMSES_AMD": "1", "RAMSES_AMD_OVERLAP": "0"}, level, nstep, nproc)
+            run_mpi("patched, tree-walking sweep + the reference's host MPI halo (round 1 path)", pat, {"RAMSES_AMD": "1", "RAMSES_AMD_RESIDENT": "0"}, level, nstep, nproc)
+        if which in ("all", "ref"):
+            run_mpi("reference (MPI)", ref, {"RAMSES_AMD": "0"}, level, nstep, nproc)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "grav":
         level, nstep = int(sys.argv[2]), int(sys.argv[3])
         which = sys.argv[4] if len(sys.argv) > 4 else "all"

@@ -53,3 +53,58 @@ def test_device_deposit_equals_reference_dump(gpu_lib, oracle, which, nvector):
     assert (rho[~lev] == -7.0).all()            # cells of other levels are untouched
     assert (want_rho[lev] != z[k + "dens"][lev]).any()
     assert gpu_lib.ramses_amd_resident_invalidate() == 0
+
+
+@pytest.mark.parametrize("level,nvector", [(6, 32), (6, 5), (7, 32)])
+def test_multipole_scan_equals_the_sequential_sum(gpu_lib, level, nvector):
+    """multipole(1:4) are strictly sequential floating-point sums over all cells (cic_from_multipole,
+    pm/rho_fine.f90:858-866); the device reproduces them with a scan of parity functions.  Compared with the
+    sequential sums (numpy cumsum = left-to-right accumulation) on densities chosen to stress it: many decades,
+    exact powers of two and small dyadic multiples (ties in the rounding), zeros below smallr."""
+    import ramses_amd
+    n, no = 2 ** level, 2 ** (level - 1)
+    ngrid = no ** 3
+    ngridmax, ncoarse = ngrid + 3, 1
+    ncell = ncoarse + 8 * ngridmax
+    rng = np.random.default_rng(level * 100 + nvector)
+    perm = rng.permutation(ngrid)                       # list order != position order
+    oz, oy, ox = np.unravel_index(perm, (no, no, no))
+    igrid = np.arange(1, ngrid + 1, dtype=np.int32)
+    xg = np.zeros((3, ngridmax))
+    for d, o in enumerate((ox, oy, oz)):
+        xg[d, :ngrid] = (o + 0.5) / no
+    dens = np.zeros(ncell)
+    kind = rng.integers(0, 4, ncell)
+    dens[kind == 0] = 10.0 ** rng.uniform(-8, 6, (kind == 0).sum())
+    dens[kind == 1] = 2.0 ** rng.integers(-30, 20, (kind == 1).sum())
+    dens[kind == 2] = rng.integers(1, 64, (kind == 2).sum()) * 2.0 ** rng.integers(-40, 0, (kind == 2).sum())
+    dens[kind == 3] = 0.0
+    uold = np.zeros((5, ncell))
+    uold[0] = dens
+    boxlen, smallr = 1.0, 1e-10
+    p = ramses_amd.make_params(smallr=smallr)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert gpu_lib.ramses_amd_resident_invalidate() == 0
+    mp = np.zeros(4)
+    rc = gpu_lib.ramses_amd_resident_rho_fine_f90(C.byref(p), level, ngrid, vp(igrid), vp(xg), ngridmax, ncoarse, 1,
+                                                  vp(uold), boxlen, nvector, vp(mp))
+    assert rc == 0, gpu_lib.ramses_amd_last_error()
+    assert gpu_lib.ramses_amd_resident_invalidate() == 0
+    # the reference's order: batches of nvector octs, ind_son, oct in the batch
+    dx = 0.5 ** level
+    vol_loc = (dx * boxlen) ** 3
+    want = np.zeros(4)
+    chunks = [[], [], [], []]
+    for b0 in range(0, ngrid, nvector):
+        g = igrid[b0:b0 + nvector]
+        for ind in range(8):
+            cells = ncoarse + ind * ngridmax + g - 1
+            mm = np.maximum(dens[cells], smallr) * vol_loc
+            chunks[0].append(mm)
+            for d in range(3):
+                xc = (((ind >> d) & 1) - 0.5) * dx
+                xx = (xg[d, g - 1] + xc - 0.0) * boxlen
+                chunks[d + 1].append(mm * xx)
+    for c in range(4):
+        want[c] = np.cumsum(np.concatenate(chunks[c]))[-1]
+    assert np.array_equal(mp, want), (mp, want, mp - want)
