@@ -576,6 +576,39 @@ int ramses_amd_mpires_halo_stage_in(void);
 int ramses_amd_mpires_sync_host(double *uold);
 int ramses_amd_mpires_invalidate(void);
 
+/* ---------------------------------------------------------------------------
+ * Residency for AMR runs (single rank, hydro).  The reference's own cell vectors
+ * uold/unew(1:ncell,1:nvar) and tree arrays stay on the device between the routines of amr_step:
+ *   ramses_amd_amrres_load         uold + son(1:ncell), nbor(1:ngridmax,1:6), father(1:ngridmax)
+ *   ramses_amd_amrres_tree         the tree again (after refine_fine)
+ *   ramses_amd_amrres_sync_level / _load_level   uold of one level's cells to / from the host array
+ *                                  (igrid = active(l)%igrid): before refine_fine reads levels, after it rebuilt them
+ *   ramses_amd_amrres_sync_all     the whole uold back (backup_hydro)
+ *   ramses_amd_amrres_set_unew     set_unew      hydro/godunov_fine.f90:40-130
+ *   ramses_amd_amrres_godunov      godunov_fine  hydro/godunov_fine.f90:5-35,486-911 (the tree-walking sweep)
+ *   ramses_amd_amrres_set_uold     set_uold      hydro/godunov_fine.f90:135-232 (incl. the passive-scalar fix :176-190)
+ *   ramses_amd_amrres_upload_fine  upload_fine / upl  hydro/interpol_hydro.f90:5-263
+ *   ramses_amd_amrres_courant      courant_fine  hydro/courant_fine.f90:1-159 (leaf cells; out4 as ramses_amd_resident_courant_f90)
+ *   ramses_amd_amrres_hydro_flag   hydro_flag's gradient criteria (hydro/hydro_flag.f90:84-140, hydro_refine
+ *                                  hydro/godunov_utils.f90:125-263): ok[(ind-1)*ngrid+i] = 1 where a cell asks for refinement
+ * ------------------------------------------------------------------------- */
+int ramses_amd_amrres_active(void);
+int ramses_amd_amrres_load(int nvar, int64_t ngridmax, int64_t ncoarse, const double *uold, const int *son, const int *nbor,
+                           const int *father);
+int ramses_amd_amrres_tree(const int *son, const int *nbor, const int *father);
+int ramses_amd_amrres_invalidate(void);
+int ramses_amd_amrres_sync_level(int ngrid, const int *igrid, double *uold);
+int ramses_amd_amrres_load_level(int ngrid, const int *igrid, const double *uold);
+int ramses_amd_amrres_sync_all(double *uold);
+int ramses_amd_amrres_set_unew(int ngrid, const int *igrid);
+int ramses_amd_amrres_set_uold(const ramses_amd_hydro_params *p, int ngrid, const int *igrid);
+int ramses_amd_amrres_upload_fine(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, int interpol_var);
+int ramses_amd_amrres_courant(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double dx, double dt_in, double *out4);
+int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double err_grad_d, double err_grad_p,
+                                 double err_grad_u, double floor_d, double floor_p, double floor_u, int *ok);
+int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, double dx, double dt,
+                              int nvector, int interpol_var, int interpol_type);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,6 +136,20 @@ SYMBOLS = [
     ("ramses_amd_mpires_halo_stage_in", _i, []),
     ("ramses_amd_mpires_sync_host", _i, [_vp]),
     ("ramses_amd_mpires_invalidate", _i, []),
+    # residency for AMR runs
+    ("ramses_amd_amrres_active", _i, []),
+    ("ramses_amd_amrres_load", _i, [_i, _i64, _i64, _vp, _vp, _vp, _vp]),
+    ("ramses_amd_amrres_tree", _i, [_vp, _vp, _vp]),
+    ("ramses_amd_amrres_invalidate", _i, []),
+    ("ramses_amd_amrres_sync_level", _i, [_i, _vp, _vp]),
+    ("ramses_amd_amrres_load_level", _i, [_i, _vp, _vp]),
+    ("ramses_amd_amrres_sync_all", _i, [_vp]),
+    ("ramses_amd_amrres_set_unew", _i, [_i, _vp]),
+    ("ramses_amd_amrres_set_uold", _i, [_PP, _i, _vp]),
+    ("ramses_amd_amrres_upload_fine", _i, [_PP, _i, _vp, _i]),
+    ("ramses_amd_amrres_courant", _i, [_PP, _i, _vp, _d, _d, _vp]),
+    ("ramses_amd_amrres_hydro_flag", _i, [_PP, _i, _vp, _d, _d, _d, _d, _d, _d, _vp]),
+    ("ramses_amd_amrres_godunov", _i, [_PP, _i, _i, _vp, _d, _d, _i, _i, _i]),
 ]
 
 

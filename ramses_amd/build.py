@@ -33,6 +33,7 @@ UNITS = [
     ("rho_fine.o", "rho_fine.hip", ["-ffp-contract=off"]),
     ("capi.o", "capi.hip", ["-ffp-contract=off"]),
     ("capi_mpi.o", "capi_mpi.hip", ["-ffp-contract=off"]),
+    ("capi_amr.o", "capi_amr.hip", ["-ffp-contract=off"]),
 ]
 
 

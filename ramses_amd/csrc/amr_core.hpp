@@ -122,4 +122,35 @@ __device__ __forceinline__ void interpol_hydro_cell(double (&u1)[7][NV], double 
   }
 }
 
+// upl (hydro/interpol_hydro.f90:73-263): a split cell = mean of its 8 children ch[ind][v], ind-1 = ix+2*iy+4*iz;
+// density floored before averaging; with interpol_var 1|2 the internal energy is averaged instead of the total one.
+template <int NV>
+__device__ __forceinline__ void upl_cell(const double (&ch)[8][NV], int interpol_var, double smallr, double (&pa)[NV]) {
+  double getx = 0.0;
+#pragma unroll
+  for (int ind = 0; ind < 8; ind++) getx = getx + dmx(ch[ind][0], smallr);
+  pa[0] = getx / 8.0;
+#pragma unroll
+  for (int v = 1; v < NV; v++) {
+    getx = 0.0;
+#pragma unroll
+    for (int ind = 0; ind < 8; ind++) getx = getx + ch[ind][v];
+    pa[v] = getx / 8.0;
+  }
+  if (interpol_var == 1 || interpol_var == 2) {
+    getx = 0.0;
+#pragma unroll
+    for (int ind = 0; ind < 8; ind++) {
+      double ekin = 0.0;
+#pragma unroll
+      for (int d = 0; d < 3; d++) ekin = ekin + 0.5 * (ch[ind][1 + d] * ch[ind][1 + d]) / dmx(ch[ind][0], smallr);
+      getx = getx + ch[ind][4] - ekin - 0.0;
+    }
+    double ekin = 0.0;
+#pragma unroll
+    for (int d = 0; d < 3; d++) ekin = ekin + 0.5 * (pa[1 + d] * pa[1 + d]) / dmx(pa[0], smallr);
+    pa[4] = getx / 8.0 + ekin + 0.0;
+  }
+}
+
 }  // namespace ramses_amd

@@ -1,0 +1,475 @@
+// capi_amr.hip -- residency for AMR runs: the reference's own cell vectors
+// uold/unew(1:ncell,1:nvar) and tree arrays (son, nbor, father) stay on the device between the routines of
+// amr_step that touch the hydro state, instead of crossing PCIe around every call:
+//   set_unew      hydro/godunov_fine.f90:40-130        lvl_copy_kernel
+//   godunov_fine  hydro/godunov_fine.f90:5-35,486-911  the tree-walking sweep (amr_sweep.hip) on the resident arrays
+//   set_uold      hydro/godunov_fine.f90:135-232       lvl_set_uold_kernel (incl. the passive-scalar floor fix :176-190)
+//   upload_fine   hydro/interpol_hydro.f90:5-263       lvl_upload_kernel (upl: restriction, interpol_var 0/1/2)
+//   courant_fine  hydro/courant_fine.f90:1-159         lvl_courant_kernel (cmpdt on the leaf cells)
+//   hydro_flag    hydro/hydro_flag.f90:1-178 + hydro_refine hydro/godunov_utils.f90:125-263   lvl_flag_kernel
+// The mesh itself stays the reference's host code: before refine_fine rebuilds levels the shim brings the
+// levels it reads back to the host (sync_level), and afterwards the tree and the rebuilt levels are sent
+// again (tree, load_level) -- the other levels never leave the device.  Single rank, NDIM=3, hydro only.
+// Compiled with -ffp-contract=off: the reference's operation order.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/ramses_amd.h"
+#include "amr_core.hpp"
+#include "hydro_core.hpp"
+
+using namespace ramses_amd;
+
+extern "C" int ramses_amd_set_error(int code, const char *msg);
+static int failf(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return ramses_amd_set_error(code, buf);
+}
+#define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return failf(RAMSES_AMD_EHIP, "%s: %s", what, hipGetErrorString(e_)); } while (0)
+
+namespace {
+
+struct LvlArgs {
+  double *uold, *unew;
+  const int *son, *nbor;
+  const int *igrid;
+  int ngrid, nvar;
+  long ncell, ncoarse, ngridmax;
+};
+
+// dst(cells of the level's octs, 1:nvar) = src(...)
+__global__ __launch_bounds__(256) void lvl_copy_kernel(LvlArgs A, double *__restrict__ dst, const double *__restrict__ src) {
+  const long total = (long)A.ngrid * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ind = (int)(t / A.ngrid), i = (int)(t % A.ngrid);
+    const long c = A.ncoarse + (long)ind * A.ngridmax + A.igrid[i] - 1;
+    for (int v = 0; v < A.nvar; v++) dst[c + (long)v * A.ncell] = src[c + (long)v * A.ncell];
+  }
+}
+
+// set_uold: the passive-scalar fix near the density floor (:176-190), then uold = unew
+__global__ __launch_bounds__(256) void lvl_set_uold_kernel(LvlArgs A, double smallr) {
+  const long total = (long)A.ngrid * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ind = (int)(t / A.ngrid), i = (int)(t % A.ngrid);
+    const long c = A.ncoarse + (long)ind * A.ngridmax + A.igrid[i] - 1;
+    if (A.nvar > 5) {
+      const double ro = A.uold[c], rn = A.unew[c];
+      if (ro < smallr && rn > ro) {
+        for (int v = 5; v < A.nvar; v++) A.unew[c + (long)v * A.ncell] = A.uold[c + (long)v * A.ncell] * __builtin_fmax(rn, smallr) / smallr;
+      } else if (rn < smallr && ro > rn) {
+        for (int v = 5; v < A.nvar; v++) A.unew[c + (long)v * A.ncell] = A.uold[c + (long)v * A.ncell] * smallr / __builtin_fmax(ro, smallr);
+      }
+    }
+    for (int v = 0; v < A.nvar; v++) A.uold[c + (long)v * A.ncell] = A.unew[c + (long)v * A.ncell];
+  }
+}
+
+// upload_fine / upl: every split cell of the level = mean of its 8 children (density floored; internal-energy
+// averaging with interpol_var 1|2)
+template <int NV>
+__global__ __launch_bounds__(256) void lvl_upload_kernel(LvlArgs A, int interpol_var, double smallr) {
+  const long total = (long)A.ngrid * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ind = (int)(t / A.ngrid), i = (int)(t % A.ngrid);
+    const long c = A.ncoarse + (long)ind * A.ngridmax + A.igrid[i] - 1;
+    const int gs = A.son[c];
+    if (gs <= 0) continue;
+    double ch[8][NV];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const long cs = A.ncoarse + (long)k * A.ngridmax + gs - 1;
+#pragma unroll
+      for (int v = 0; v < NV; v++) ch[k][v] = A.uold[cs + (long)v * A.ncell];
+    }
+    double pa[NV];
+    upl_cell<NV>(ch, interpol_var, smallr, pa);
+#pragma unroll
+    for (int v = 0; v < NV; v++) A.uold[c + (long)v * A.ncell] = pa[v];
+  }
+}
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wmin(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = __builtin_fmin(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+// courant_fine: cmpdt over the leaf cells of the level (dt exact: a minimum), mass / energy sums (diagnostics)
+__global__ __launch_bounds__(256) void lvl_courant_kernel(LvlArgs A, HydroConst P, double dx, double vol, double courant_factor,
+                                                          double dt_init, double *__restrict__ out) {
+  double dtmin = dt_init, mass = 0.0, etot = 0.0, eint = 0.0;
+  const long total = (long)A.ngrid * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ind = (int)(t / A.ngrid), i = (int)(t % A.ngrid);
+    const long c = A.ncoarse + (long)ind * A.ngridmax + A.igrid[i] - 1;
+    if (A.son[c] != 0) continue;
+    double u[5], g[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int v = 0; v < 5; v++) u[v] = A.uold[c + (long)v * A.ncell];
+    dtmin = __builtin_fmin(dtmin, cmpdt_cell<5, false>(u, g, dx, courant_factor, P, 3.0));
+    mass += u[0] * vol;
+    etot += u[4] * vol;
+    double ei = u[4] * vol;
+    const double rho = __builtin_fmax(u[0], P.smallr);
+    ei -= 0.5 * (u[1] * u[1]) / rho * vol;
+    ei -= 0.5 * (u[2] * u[2]) / rho * vol;
+    ei -= 0.5 * (u[3] * u[3]) / rho * vol;
+    eint += ei;
+  }
+  dtmin = wmin(dtmin); mass = wsum(mass); etot = wsum(etot); eint = wsum(eint);
+  __shared__ double red[4][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave][0] = dtmin; red[wave][1] = mass; red[wave][2] = etot; red[wave][3] = eint; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double d = red[0][0], m = red[0][1], e = red[0][2], ei = red[0][3];
+    for (int w = 1; w < 4; w++) { d = __builtin_fmin(d, red[w][0]); m += red[w][1]; e += red[w][2]; ei += red[w][3]; }
+    atomicMin(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(d));
+    atomicAdd(out + 1, m); atomicAdd(out + 2, e); atomicAdd(out + 3, ei);
+  }
+}
+__global__ void lvl_courant_init_kernel(double *out, double dt_init) { out[0] = dt_init; out[1] = out[2] = out[3] = 0.0; }
+
+// hydro_flag's gradient criteria (hydro_refine): ok[ind*ngrid+i] = 1 when the cell is to be refined
+struct FlagCrit { double err_grad_d, err_grad_p, err_grad_u, floor_d, floor_p, floor_u, gamma, smallr; };
+__device__ __forceinline__ void refine_prim(const LvlArgs &A, long c, const FlagCrit &F, double (&q)[5]) {
+  // conservative -> (rho, u, v, w, P) as hydro_refine does (:150-190)
+  double u[5];
+#pragma unroll
+  for (int v = 0; v < 5; v++) u[v] = A.uold[c + (long)v * A.ncell];
+  q[0] = __builtin_fmax(u[0], F.smallr);
+  double ek = 0.0;
+#pragma unroll
+  for (int d = 0; d < 3; d++) { q[1 + d] = u[1 + d] / q[0]; }
+#pragma unroll
+  for (int d = 0; d < 3; d++) ek = ek + 0.5 * q[0] * (q[1 + d] * q[1 + d]);
+  q[4] = (F.gamma - 1.0) * (u[4] - ek);
+}
+__global__ __launch_bounds__(256) void lvl_flag_kernel(LvlArgs A, FlagCrit F, int *__restrict__ ok) {
+  const long total = (long)A.ngrid * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ind = (int)(t / A.ngrid), i = (int)(t % A.ngrid);
+    const int g = A.igrid[i];
+    const long c = A.ncoarse + (long)ind * A.ngridmax + g - 1;
+    double qm[5];
+    refine_prim(A, c, F, qm);
+    bool flag = false;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      // neighbour cells in direction d (getnborcells); a missing one is replaced by the neighbouring father cell
+      long cn[2];
+#pragma unroll
+      for (int side = 0; side < 2; side++) {
+        const int bit = (ind >> d) & 1;
+        if (bit != side) {
+          cn[side] = c + (side ? 1 : -1) * ((long)(1 << d) * A.ngridmax);
+        } else {
+          const int nb = A.nbor[(long)(2 * d + side) * A.ngridmax + g - 1];
+          const int g2 = A.son[nb - 1];
+          cn[side] = g2 > 0 ? A.ncoarse + (long)(ind ^ (1 << d)) * A.ngridmax + g2 - 1 : (long)nb - 1;
+        }
+      }
+      double qg[5], qd[5];
+      refine_prim(A, cn[0], F, qg);
+      refine_prim(A, cn[1], F, qd);
+      if (F.err_grad_d >= 0.0) {
+        const double e = 2.0 * __builtin_fmax(__builtin_fabs((qd[0] - qm[0]) / (qd[0] + qm[0] + F.floor_d)),
+                                              __builtin_fabs((qm[0] - qg[0]) / (qm[0] + qg[0] + F.floor_d)));
+        flag = flag || e > F.err_grad_d;
+      }
+      if (F.err_grad_p >= 0.0) {
+        const double e = 2.0 * __builtin_fmax(__builtin_fabs((qd[4] - qm[4]) / (qd[4] + qm[4] + F.floor_p)),
+                                              __builtin_fabs((qm[4] - qg[4]) / (qm[4] + qg[4] + F.floor_p)));
+        flag = flag || e > F.err_grad_p;
+      }
+      if (F.err_grad_u >= 0.0) {
+        const double cg = __builtin_sqrt(__builtin_fmax(F.gamma * qg[4] / qg[0], F.floor_u * F.floor_u));
+        const double cm = __builtin_sqrt(__builtin_fmax(F.gamma * qm[4] / qm[0], F.floor_u * F.floor_u));
+        const double cd = __builtin_sqrt(__builtin_fmax(F.gamma * qd[4] / qd[0], F.floor_u * F.floor_u));
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const double vg = qg[1 + k], vm = qm[1 + k], vd = qd[1 + k];
+          const double e = 2.0 * __builtin_fmax(__builtin_fabs((vd - vm) / (cd + cm + __builtin_fabs(vd) + __builtin_fabs(vm) + F.floor_u)),
+                                                __builtin_fabs((vm - vg) / (cm + cg + __builtin_fabs(vm) + __builtin_fabs(vg) + F.floor_u)));
+          flag = flag || e > F.err_grad_u;
+        }
+      }
+    }
+    ok[t] = flag ? 1 : 0;
+  }
+}
+
+// compact buffer buf[v][ind*ngrid+i] <-> cell vector (sync_level / load_level)
+template <bool GATHER>
+__global__ __launch_bounds__(256) void lvl_pack_kernel(LvlArgs A, double *__restrict__ buf) {
+  const long total = (long)A.ngrid * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ind = (int)(t / A.ngrid), i = (int)(t % A.ngrid);
+    const long c = A.ncoarse + (long)ind * A.ngridmax + A.igrid[i] - 1;
+    for (int v = 0; v < A.nvar; v++) {
+      if (GATHER) buf[(long)v * total + t] = A.uold[c + (long)v * A.ncell];
+      else A.uold[c + (long)v * A.ncell] = buf[(long)v * total + t];
+    }
+  }
+}
+
+struct Buf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap && p) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    if (bytes == 0) bytes = 8;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+struct AmrRes {
+  bool valid = false;
+  int nvar = 0;
+  long ncell = 0, ncoarse = 0, ngridmax = 0;
+  const double *h_uold = nullptr;
+  Buf uold, unew, son, nbor, father, igrid, work, err, red, okbuf, pack;
+  std::vector<double> hpack;
+};
+AmrRes g_ar;
+
+inline int grid_for(long n) {
+  long g = (n + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 8192) g = 8192;
+  return (int)g;
+}
+
+int set_level(AmrRes &R, int ngrid, const int *igrid, LvlArgs &A) {
+  if (!R.valid) return failf(RAMSES_AMD_EINVAL, "no resident AMR state (ramses_amd_amrres_load)");
+  if (ngrid < 0 || (ngrid > 0 && !igrid)) return failf(RAMSES_AMD_EINVAL, "bad oct list");
+  HCHK(R.igrid.ensure(sizeof(int) * (size_t)(ngrid > 0 ? ngrid : 1)), "hipMalloc igrid");
+  if (ngrid > 0) HCHK(hipMemcpyAsync(R.igrid.p, igrid, sizeof(int) * (size_t)ngrid, hipMemcpyHostToDevice, nullptr), "H2D igrid");
+  A.uold = R.uold.as<double>(); A.unew = R.unew.as<double>();
+  A.son = R.son.as<int>(); A.nbor = R.nbor.as<int>(); A.igrid = R.igrid.as<int>();
+  A.ngrid = ngrid; A.nvar = R.nvar; A.ncell = R.ncell; A.ncoarse = R.ncoarse; A.ngridmax = R.ngridmax;
+  return 0;
+}
+}  // namespace
+
+static HydroConst make_const_amr(const ramses_amd_hydro_params *p) {
+  HydroConst P;
+  P.gamma = p->gamma; P.smallr = p->smallr; P.smallc = p->smallc;
+  P.smallc2 = p->smallc * p->smallc;
+  P.smallp = P.smallc2 / p->gamma;
+  P.smalle = P.smallc2 / p->gamma / (p->gamma - 1.0);
+  P.entho = 1.0 / (p->gamma - 1.0);
+  P.gm1 = p->gamma - 1.0;
+  P.gamma6 = (p->gamma + 1.0) / (2.0 * p->gamma);
+  P.smallpp = p->smallr * P.smallp;
+  P.oneovergamma = 1.0 / p->gamma;
+  P.slope_theta = p->slope_theta;
+  P.niter_riemann = p->niter_riemann;
+  return P;
+}
+
+extern "C" {
+
+int ramses_amd_amrres_active(void) { return g_ar.valid ? 1 : 0; }
+
+// the tree arrays again (after refine_fine): son(1:ncell), nbor(1:ngridmax,1:6), father(1:ngridmax)
+int ramses_amd_amrres_tree(const int *son, const int *nbor, const int *father) {
+  AmrRes &R = g_ar;
+  if (!R.valid) return failf(RAMSES_AMD_EINVAL, "no resident AMR state");
+  if (!son || !nbor || !father) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  HCHK(hipMemcpyAsync(R.son.p, son, sizeof(int) * (size_t)R.ncell, hipMemcpyHostToDevice, nullptr), "H2D son");
+  HCHK(hipMemcpyAsync(R.nbor.p, nbor, sizeof(int) * 6 * (size_t)R.ngridmax, hipMemcpyHostToDevice, nullptr), "H2D nbor");
+  HCHK(hipMemcpyAsync(R.father.p, father, sizeof(int) * (size_t)R.ngridmax, hipMemcpyHostToDevice, nullptr), "H2D father");
+  HCHK(hipStreamSynchronize(nullptr), "sync");
+  return 0;
+}
+
+// everything: the hydro state uold(1:ncell,1:nvar) and the tree
+int ramses_amd_amrres_load(int nvar, int64_t ngridmax, int64_t ncoarse, const double *uold, const int *son, const int *nbor,
+                           const int *father) {
+  if (!uold || !son || !nbor || !father) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  if (nvar < 5 || nvar > 7 || ngridmax < 1 || ncoarse < 1) return failf(RAMSES_AMD_EUNSUPPORTED, "AMR residency implements NVAR=5..7");
+  AmrRes &R = g_ar;
+  R.valid = false;
+  R.nvar = nvar; R.ngridmax = ngridmax; R.ncoarse = ncoarse; R.ncell = ncoarse + 8 * ngridmax;
+  R.h_uold = uold;
+  const size_t vb = sizeof(double) * (size_t)nvar * (size_t)R.ncell;
+  HCHK(R.uold.ensure(vb), "hipMalloc uold"); HCHK(R.unew.ensure(vb), "hipMalloc unew");
+  HCHK(R.son.ensure(sizeof(int) * (size_t)R.ncell), "hipMalloc son");
+  HCHK(R.nbor.ensure(sizeof(int) * 6 * (size_t)ngridmax), "hipMalloc nbor");
+  HCHK(R.father.ensure(sizeof(int) * (size_t)ngridmax), "hipMalloc father");
+  HCHK(R.err.ensure(sizeof(int)), "hipMalloc"); HCHK(R.red.ensure(sizeof(double) * 4), "hipMalloc");
+  HCHK(hipMemcpyAsync(R.uold.p, uold, vb, hipMemcpyHostToDevice, nullptr), "H2D uold");
+  HCHK(hipMemsetAsync(R.unew.p, 0, vb, nullptr), "memset unew");
+  R.valid = true;
+  return ramses_amd_amrres_tree(son, nbor, father);
+}
+
+int ramses_amd_amrres_invalidate(void) { g_ar.valid = false; return 0; }
+
+// uold of one level's cells back into the host array (before refine_fine reads it)
+int ramses_amd_amrres_sync_level(int ngrid, const int *igrid, double *uold) {
+  AmrRes &R = g_ar;
+  LvlArgs A;
+  if (int rc = set_level(R, ngrid, igrid, A)) return rc;
+  if (uold != R.h_uold) return failf(RAMSES_AMD_EINVAL, "sync_level: not the array the state was loaded from");
+  if (ngrid == 0) return 0;
+  const size_t n = (size_t)ngrid * 8 * R.nvar;
+  HCHK(R.pack.ensure(sizeof(double) * n), "hipMalloc");
+  hipLaunchKernelGGL(lvl_pack_kernel<true>, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, A, R.pack.as<double>());
+  HCHK(hipGetLastError(), "pack launch");
+  R.hpack.resize(n);
+  HCHK(hipMemcpy(R.hpack.data(), R.pack.p, sizeof(double) * n, hipMemcpyDeviceToHost), "D2H level");
+  const long tot = (long)ngrid * 8;
+  for (int v = 0; v < R.nvar; v++)
+    for (int ind = 0; ind < 8; ind++) {
+      double *dst = uold + (size_t)v * R.ncell + R.ncoarse + (size_t)ind * R.ngridmax - 1;
+      const double *src = R.hpack.data() + (size_t)v * tot + (size_t)ind * ngrid;
+      for (int i = 0; i < ngrid; i++) dst[igrid[i]] = src[i];
+    }
+  return 0;
+}
+
+// uold of one level's cells from the host array (after refine_fine rebuilt the level)
+int ramses_amd_amrres_load_level(int ngrid, const int *igrid, const double *uold) {
+  AmrRes &R = g_ar;
+  LvlArgs A;
+  if (int rc = set_level(R, ngrid, igrid, A)) return rc;
+  if (ngrid == 0) return 0;
+  const size_t n = (size_t)ngrid * 8 * R.nvar;
+  const long tot = (long)ngrid * 8;
+  R.hpack.resize(n);
+  for (int v = 0; v < R.nvar; v++)
+    for (int ind = 0; ind < 8; ind++) {
+      const double *src = uold + (size_t)v * R.ncell + R.ncoarse + (size_t)ind * R.ngridmax - 1;
+      double *dst = R.hpack.data() + (size_t)v * tot + (size_t)ind * ngrid;
+      for (int i = 0; i < ngrid; i++) dst[i] = src[igrid[i]];
+    }
+  HCHK(R.pack.ensure(sizeof(double) * n), "hipMalloc");
+  HCHK(hipMemcpy(R.pack.p, R.hpack.data(), sizeof(double) * n, hipMemcpyHostToDevice), "H2D level");
+  hipLaunchKernelGGL(lvl_pack_kernel<false>, dim3(grid_for(tot)), dim3(256), 0, nullptr, A, R.pack.as<double>());
+  HCHK(hipGetLastError(), "unpack launch");
+  HCHK(hipStreamSynchronize(nullptr), "sync");
+  return 0;
+}
+
+// the whole hydro state back (backup_hydro)
+int ramses_amd_amrres_sync_all(double *uold) {
+  AmrRes &R = g_ar;
+  if (!R.valid) return 0;
+  if (uold != R.h_uold) return failf(RAMSES_AMD_EINVAL, "sync_all: not the array the state was loaded from");
+  HCHK(hipMemcpy(uold, R.uold.p, sizeof(double) * (size_t)R.nvar * (size_t)R.ncell, hipMemcpyDeviceToHost), "D2H uold");
+  return 0;
+}
+
+int ramses_amd_amrres_set_unew(int ngrid, const int *igrid) {
+  LvlArgs A;
+  if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
+  if (ngrid == 0) return 0;
+  hipLaunchKernelGGL(lvl_copy_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, A, A.unew, A.uold);
+  HCHK(hipGetLastError(), "set_unew launch");
+  return 0;
+}
+
+int ramses_amd_amrres_set_uold(const ramses_amd_hydro_params *p, int ngrid, const int *igrid) {
+  if (!p) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  LvlArgs A;
+  if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
+  if (ngrid == 0) return 0;
+  hipLaunchKernelGGL(lvl_set_uold_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, A, p->smallr);
+  HCHK(hipGetLastError(), "set_uold launch");
+  return 0;
+}
+
+int ramses_amd_amrres_upload_fine(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, int interpol_var) {
+  if (!p) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  if (interpol_var < 0 || interpol_var > 2) return failf(RAMSES_AMD_EINVAL, "interpol_var must be 0, 1 or 2");
+  LvlArgs A;
+  if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
+  if (ngrid == 0) return 0;
+  const dim3 g(grid_for((long)ngrid * 8)), b(256);
+  switch (A.nvar) {
+    case 5: hipLaunchKernelGGL(lvl_upload_kernel<5>, g, b, 0, nullptr, A, interpol_var, p->smallr); break;
+    case 6: hipLaunchKernelGGL(lvl_upload_kernel<6>, g, b, 0, nullptr, A, interpol_var, p->smallr); break;
+    default: hipLaunchKernelGGL(lvl_upload_kernel<7>, g, b, 0, nullptr, A, interpol_var, p->smallr); break;
+  }
+  HCHK(hipGetLastError(), "upload_fine launch");
+  return 0;
+}
+
+// out4 = {dt_loc (min with dt_in), mass_loc, sum(E*vol), eint_loc} over the leaf cells of the level
+int ramses_amd_amrres_courant(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double dx, double dt_in, double *out4) {
+  if (!p || !out4) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  LvlArgs A;
+  if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
+  AmrRes &R = g_ar;
+  const double dt0 = p->courant_factor * dx / p->smallc;
+  hipLaunchKernelGGL(lvl_courant_init_kernel, dim3(1), dim3(1), 0, nullptr, R.red.as<double>(), dt0);
+  if (ngrid > 0) {
+    int g = grid_for((long)ngrid * 8);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(lvl_courant_kernel, dim3(g), dim3(256), 0, nullptr, A, make_const_amr(p), dx, dx * dx * dx, p->courant_factor, dt0, R.red.as<double>());
+  }
+  HCHK(hipGetLastError(), "courant launch");
+  HCHK(hipMemcpy(out4, R.red.p, sizeof(double) * 4, hipMemcpyDeviceToHost), "D2H courant");
+  if (dt_in < out4[0]) out4[0] = dt_in;
+  return 0;
+}
+
+// hydro_flag's gradient criteria: ok[(ind-1)*ngrid + i] (host) = 1 where hydro_refine asks for refinement
+int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double err_grad_d, double err_grad_p,
+                                 double err_grad_u, double floor_d, double floor_p, double floor_u, int *ok) {
+  if (!p || !ok) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  LvlArgs A;
+  if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
+  if (ngrid == 0) return 0;
+  if (A.nvar < 5) return failf(RAMSES_AMD_EUNSUPPORTED, "NVAR");
+  AmrRes &R = g_ar;
+  HCHK(R.okbuf.ensure(sizeof(int) * 8 * (size_t)ngrid), "hipMalloc");
+  FlagCrit F = {err_grad_d, err_grad_p, err_grad_u, floor_d, floor_p, floor_u, p->gamma, p->smallr};
+  hipLaunchKernelGGL(lvl_flag_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, A, F, R.okbuf.as<int>());
+  HCHK(hipGetLastError(), "hydro_flag launch");
+  HCHK(hipMemcpy(ok, R.okbuf.p, sizeof(int) * 8 * (size_t)ngrid, hipMemcpyDeviceToHost), "D2H flags");
+  return 0;
+}
+
+// godunov_fine(ilevel) on the resident arrays
+int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, double dx, double dt,
+                              int nvector, int interpol_var, int interpol_type) {
+  if (!p) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  LvlArgs A;
+  if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
+  if (ngrid == 0) return 0;
+  AmrRes &R = g_ar;
+  const int64_t nw = ramses_amd_godunov_fine_amr_workspace(ngrid, R.ngridmax);
+  if (nw < 0) return (int)nw;
+  HCHK(R.work.ensure((size_t)nw), "hipMalloc work");
+  HCHK(hipMemsetAsync(R.err.p, 0, sizeof(int), nullptr), "memset");
+  if (int rc = ramses_amd_godunov_fine_amr_device(p, ilevel, ngrid, R.igrid.as<int>(), R.son.as<int>(), R.nbor.as<int>(), R.father.as<int>(),
+                                                  R.ngridmax, R.ncoarse, R.uold.as<double>(), R.unew.as<double>(), nullptr, nullptr, nullptr,
+                                                  dx, dt, nvector, interpol_var, interpol_type, R.work.p, R.err.as<int>(), nullptr)) return rc;
+  int bad = 0;
+  HCHK(hipMemcpy(&bad, R.err.p, sizeof(int), hipMemcpyDeviceToHost), "D2H flag");
+  if (bad) return failf(RAMSES_AMD_EINVAL, "level %d: %d father cells needed by an oct do not exist (tree inconsistent)", ilevel, bad);
+  return 0;
+}
+
+}  // extern "C"

@@ -53,6 +53,24 @@ subroutine courant_fine(ilevel)
      return
   end if
 #endif
+  if(ramses_amd_amr_config())then
+     ! AMR run: the first courant_fine of the time loop arms the residency (the mesh construction before it ran
+     ! on the host arrays); from here on uold lives on the device
+     ramses_amd_amr_armed=.true.
+     if(verbose)write(*,111)ilevel
+     call ramses_amd_amr_ensure()
+     call ramses_amd_fill_hydro_params(p)
+     nx_loc=icoarse_max-icoarse_min+1
+     scale=boxlen/dble(nx_loc)
+     dx=0.5D0**ilevel*scale
+     rc=ramses_amd_amrres_courant(p,active(ilevel)%ngrid,active(ilevel)%igrid,dx,dtnew(ilevel),out4)
+     if(rc/=0)call ramses_amd_fatal('courant_fine')
+     mass_tot=mass_tot+out4(2)
+     ekin_tot=ekin_tot+out4(3)
+     eint_tot=eint_tot+out4(4)
+     dtnew(ilevel)=MIN(dtnew(ilevel),out4(1))
+     return
+  end if
   if(.not.ramses_amd_resident())then
      call courant_fine_reference(ilevel)
      return

@@ -30,9 +30,16 @@ subroutine set_unew(ilevel)
   use ramses_amd_iface
   implicit none
   integer::ilevel
+  integer::rc
   if(numbtot(1,ilevel)==0)return
   if(ramses_amd_resident())return
   if(ramses_amd_mpi_resident())return
+  if(ramses_amd_amr_resident())then
+     call ramses_amd_amr_ensure()
+     rc=ramses_amd_amrres_set_unew(active(ilevel)%ngrid,active(ilevel)%igrid)
+     if(rc/=0)call ramses_amd_fatal('set_unew')
+     return
+  end if
   call set_unew_reference(ilevel)
 end subroutine set_unew
 
@@ -57,6 +64,13 @@ subroutine set_uold(ilevel)
   end if
   if(ramses_amd_mpi_resident())then
      rc=ramses_amd_mpires_set_uold()
+     if(rc/=0)call ramses_amd_fatal('set_uold')
+     return
+  end if
+  if(ramses_amd_amr_resident())then
+     call ramses_amd_amr_ensure()
+     call ramses_amd_fill_hydro_params(p)
+     rc=ramses_amd_amrres_set_uold(p,active(ilevel)%ngrid,active(ilevel)%igrid)
      if(rc/=0)call ramses_amd_fatal('set_uold')
      return
   end if
@@ -111,6 +125,15 @@ subroutine godunov_fine(ilevel)
      return
   end if
 #endif
+
+  ! AMR run with the state and the tree resident on the device: the tree-walking sweep in place
+  if(ramses_amd_amr_resident())then
+     call ramses_amd_amr_ensure()
+     rc=ramses_amd_amrres_godunov(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,dx,dtnew(ilevel), &
+          & nvector,interpol_var,interpol_type)
+     if(rc/=0)call ramses_amd_fatal('godunov_fine')
+     return
+  end if
 
   ! A level with refined cells, or one that does not cover the box, takes the AMR
   ! sweep (one wavefront per oct on the tree arrays); a fully refined level without

@@ -21,6 +21,13 @@ subroutine backup_hydro(filename, filename_desc)
   if(ramses_amd_enabled())then
      rc=ramses_amd_resident_sync_host_f90(uold)
      if(rc/=0)call ramses_amd_fatal('backup_hydro (sync of the resident level)')
+     if(ramses_amd_amr_resident())then
+        if(ramses_amd_amrres_active()/=0)then
+           call ramses_amd_amr_ensure()          ! (levels rebuilt on the host since the last device routine go first)
+           rc=ramses_amd_amrres_sync_all(uold)
+           if(rc/=0)call ramses_amd_fatal('backup_hydro (sync of the resident AMR state)')
+        end if
+     end if
      if(ramses_amd_mpi_on)then
         rc=ramses_amd_mpires_sync_host(uold)
         if(rc/=0)call ramses_amd_fatal('backup_hydro (sync of the resident bricks)')

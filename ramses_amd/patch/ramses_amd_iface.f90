@@ -397,6 +397,92 @@ module ramses_amd_iface
        import :: c_int
        integer(c_int) :: rc
      end function ramses_amd_mpires_invalidate
+
+     ! ---- residency for AMR runs (include/ramses_amd.h) ----
+     function ramses_amd_amrres_active() bind(C, name='ramses_amd_amrres_active') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_active
+     function ramses_amd_amrres_load(nvar, ngridmax, ncoarse, uold, son, nbor, father) &
+          & bind(C, name='ramses_amd_amrres_load') result(rc)
+       import :: c_int, c_int64_t, c_double
+       integer(c_int), value :: nvar
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       real(c_double) :: uold(*)
+       integer(c_int) :: son(*), nbor(*), father(*)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_load
+     function ramses_amd_amrres_tree(son, nbor, father) bind(C, name='ramses_amd_amrres_tree') result(rc)
+       import :: c_int
+       integer(c_int) :: son(*), nbor(*), father(*)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_tree
+     function ramses_amd_amrres_sync_level(ngrid, igrid, uold) bind(C, name='ramses_amd_amrres_sync_level') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: uold(*)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_sync_level
+     function ramses_amd_amrres_load_level(ngrid, igrid, uold) bind(C, name='ramses_amd_amrres_load_level') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: uold(*)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_load_level
+     function ramses_amd_amrres_sync_all(uold) bind(C, name='ramses_amd_amrres_sync_all') result(rc)
+       import :: c_int, c_double
+       real(c_double) :: uold(*)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_sync_all
+     function ramses_amd_amrres_set_unew(ngrid, igrid) bind(C, name='ramses_amd_amrres_set_unew') result(rc)
+       import :: c_int
+       integer(c_int), value :: ngrid
+       integer(c_int) :: igrid(*)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_set_unew
+     function ramses_amd_amrres_set_uold(p, ngrid, igrid) bind(C, name='ramses_amd_amrres_set_uold') result(rc)
+       import :: ramses_amd_hydro_params, c_int
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ngrid
+       integer(c_int) :: igrid(*)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_set_uold
+     function ramses_amd_amrres_upload_fine(p, ngrid, igrid, interpol_var) bind(C, name='ramses_amd_amrres_upload_fine') result(rc)
+       import :: ramses_amd_hydro_params, c_int
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ngrid, interpol_var
+       integer(c_int) :: igrid(*)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_upload_fine
+     function ramses_amd_amrres_courant(p, ngrid, igrid, dx, dt_in, out4) bind(C, name='ramses_amd_amrres_courant') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double), value :: dx, dt_in
+       real(c_double) :: out4(4)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_courant
+     function ramses_amd_amrres_hydro_flag(p, ngrid, igrid, egd, egp, egu, fld, flp, flu, ok) &
+          & bind(C, name='ramses_amd_amrres_hydro_flag') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ngrid
+       integer(c_int) :: igrid(*), ok(*)
+       real(c_double), value :: egd, egp, egu, fld, flp, flu
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_hydro_flag
+     function ramses_amd_amrres_godunov(p, ilevel, ngrid, igrid, dx, dt, nvector, interpol_var, interpol_type) &
+          & bind(C, name='ramses_amd_amrres_godunov') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ilevel, ngrid, nvector, interpol_var, interpol_type
+       integer(c_int) :: igrid(*)
+       real(c_double), value :: dx, dt
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_godunov
   end interface
 
   logical, save :: ramses_amd_checked = .false.
@@ -415,6 +501,14 @@ module ramses_amd_iface
   logical, save :: ramses_amd_mpi_checked = .false.
   logical, save :: ramses_amd_mpi_on = .false.
   logical, save :: ramses_amd_halo_rccl = .false.
+  ! AMR runs: uold/unew and the tree stay on the device between the hydro routines of amr_step
+  ! (ramses_amd_amr_resident); armed by the first courant_fine of the time loop, so that the
+  ! initial mesh construction (init_refine_2, init_flow_fine) runs on the host arrays as ever
+  logical, save :: ramses_amd_amr_checked = .false.
+  logical, save :: ramses_amd_amr_ok = .false.
+  logical, save :: ramses_amd_amr_armed = .false.
+  integer, save :: ramses_amd_amr_reload_from = 1000   ! levels >= this were rebuilt on the host and await their reload
+  integer, save :: ramses_amd_amr_host_from = 1000     ! levels >= this are current on the host (synced or rebuilt) since the last device routine
 
 contains
 
@@ -830,6 +924,102 @@ contains
     if (rc /= 0) call ramses_amd_fatal('make_virtual_fine_dp (unpack)')
   end subroutine ramses_amd_halo_forward
 #endif
+
+  !---------------------------------------------------------------------------
+  ! Residency for AMR runs (single rank, hydro only): does the configuration allow it?
+  ! RAMSES_AMD_RESIDENT_AMR=0 keeps the staging path (arrays copied around every call).
+  !---------------------------------------------------------------------------
+  logical function ramses_amd_amr_config()
+    use amr_commons
+    use hydro_parameters
+#if USE_TURB==1
+    use turb_commons, only: turb
+#endif
+    character(len=16) :: val
+    integer :: stat, l
+    if (.not. ramses_amd_amr_checked) then
+       ramses_amd_amr_checked = .true.
+       ramses_amd_amr_ok = ramses_amd_enabled()
+       call get_environment_variable('RAMSES_AMD_RESIDENT_AMR', val, status=stat)
+       if (stat == 0) then
+          if (trim(val) == '0') ramses_amd_amr_ok = .false.
+       end if
+       if (ncpu > 1 .or. levelmin >= nlevelmax .or. nboundary > 0 .or. nremap > 0) ramses_amd_amr_ok = .false.
+       if (.not. hydro .or. poisson .or. pic .or. rt .or. cooling .or. star .or. sink .or. stellar) ramses_amd_amr_ok = .false.
+       if (tracer .or. MC_tracer .or. clumpfind .or. lightcone .or. movie .or. aton) ramses_amd_amr_ok = .false.
+       if (static .or. static_gas .or. neq_chem .or. barotropic_eos .or. isothermal .or. metal) ramses_amd_amr_ok = .false.
+       if (pressure_fix .or. T2_star > 0.0d0 .or. momentum_feedback > 0 .or. strict_equilibrium > 0) ramses_amd_amr_ok = .false.
+       if (ndim /= 3 .or. levelmin < 3) ramses_amd_amr_ok = .false.
+       if (icoarse_max - icoarse_min /= 0 .or. jcoarse_max - jcoarse_min /= 0 .or. kcoarse_max - kcoarse_min /= 0) &
+            & ramses_amd_amr_ok = .false.
+       do l = 1, nlevelmax
+          if (jeans_refine(l) > -1.0d0) ramses_amd_amr_ok = .false.     ! jeans_length_refine reads uold on the host
+       end do
+#if USE_TURB==1
+       if (turb) ramses_amd_amr_ok = .false.
+#endif
+       if (ramses_amd_amr_ok .and. myid == 1) &
+            & write(*,*) 'ramses_amd: hydro state and tree of the AMR levels stay resident on the GPU'
+    end if
+    ramses_amd_amr_config = ramses_amd_amr_ok
+  end function ramses_amd_amr_config
+
+  logical function ramses_amd_amr_resident()
+    ramses_amd_amr_resident = .false.
+    if (ramses_amd_amr_armed) ramses_amd_amr_resident = ramses_amd_amr_config()
+  end function ramses_amd_amr_resident
+
+  !---------------------------------------------------------------------------
+  ! Before a device routine: load everything (first use), or send what refine_fine rebuilt on the
+  ! host since the last device routine (the tree and the levels >= ramses_amd_amr_reload_from)
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_amr_ensure()
+    use amr_commons
+    use hydro_commons
+    integer :: rc, l
+    if (ramses_amd_amrres_active() == 0) then
+       rc = ramses_amd_amrres_load(nvar, int(ngridmax, 8), int(ncoarse, 8), uold, son, nbor, father)
+       if (rc /= 0) call ramses_amd_fatal('AMR residency (load)')
+       ramses_amd_amr_reload_from = 1000
+       ramses_amd_amr_host_from = 1000
+       return
+    end if
+    ramses_amd_amr_host_from = 1000        ! a device routine follows: the host copies go stale
+    if (ramses_amd_amr_reload_from <= nlevelmax) then
+       rc = ramses_amd_amrres_tree(son, nbor, father)
+       if (rc /= 0) call ramses_amd_fatal('AMR residency (tree)')
+       do l = ramses_amd_amr_reload_from, nlevelmax
+          if (numbtot(1, l) > 0) then
+             rc = ramses_amd_amrres_load_level(active(l)%ngrid, active(l)%igrid, uold)
+             if (rc /= 0) call ramses_amd_fatal('AMR residency (level reload)')
+          end if
+       end do
+       ramses_amd_amr_reload_from = 1000
+    end if
+  end subroutine ramses_amd_amr_ensure
+
+  !---------------------------------------------------------------------------
+  ! refine_fine(ilevel) is about to read uold of levels ilevel-1 .. (interpol_hydro of new octs,
+  ! getnborfather's coarser fallback) and to rebuild levels ilevel+1 ..: bring the device's levels
+  ! back first, remember from which level the host is ahead.
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_amr_refine_hook(ilevel)
+    use amr_commons
+    use hydro_commons
+    integer, intent(in) :: ilevel
+    integer :: rc, l
+    if (.not. ramses_amd_amr_resident()) return
+    if (ramses_amd_amrres_active() == 0) return
+    if (ilevel < levelmin) return      ! fully refined coarse levels: nothing is created, no hydro data is read
+    do l = max(ilevel - 1, levelmin), min(nlevelmax, ramses_amd_amr_host_from - 1)
+       if (numbtot(1, l) > 0) then
+          rc = ramses_amd_amrres_sync_level(active(l)%ngrid, active(l)%igrid, uold)
+          if (rc /= 0) call ramses_amd_fatal('AMR residency (level sync before refine_fine)')
+       end if
+    end do
+    ramses_amd_amr_host_from = min(ramses_amd_amr_host_from, max(ilevel - 1, levelmin))
+    ramses_amd_amr_reload_from = min(ramses_amd_amr_reload_from, ilevel + 1)      ! refine_fine(ilevel) rebuilds level ilevel+1
+  end subroutine ramses_amd_amr_refine_hook
 
   !---------------------------------------------------------------------------
   ! The reference has no error returns on this path: print and clean_stop

@@ -165,6 +165,50 @@ if __name__ == "__main__":
         if which in ("all", "ref"):
             run_mpi("reference (MPI)", ref, {"RAMSES_AMD": "0"}, level, nstep, nproc)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "c5":
+        # BASELINE config C5 (sedov3d.nml, AMR, hydro only) at levels lmin..lmax, nstep coarse steps
+        lmin, lmax, nstep = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+        which = sys.argv[5] if len(sys.argv) > 5 else "all"
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("mkb", os.path.join(ROOT, "tests", "golden", "make_golden_baseline.py"))
+        mkb = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mkb)
+        ngt = {7: 900000, 8: 4000000}.get(lmin, 300000)
+        nml = mkb.c5_namelist(lmin, lmax, nstep, ngt).replace("foutput=%d" % nstep, "foutput=1000")
+
+        def run_c5(tag, binary, env):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            t0 = time.time()
+            try:
+                work, out = rs.run_reference(nml, binary=binary, timeout=3000)
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            wall = time.time() - t0
+            shutil.rmtree(work, ignore_errors=True)
+            rows = {}
+            for line in out.splitlines():
+                m = re.match(r"^\s*([0-9.]+)\s+([0-9.]+)\s+([a-zA-Z].*?)\s*$", line)
+                if m and "STEP" not in m.group(3):
+                    rows[m.group(3)] = float(m.group(1))
+            last = {}
+            for l, g in re.findall(r"Level\s+(\d+) has\s+(\d+) grids", out):
+                last[int(l)] = int(g)
+            print(json.dumps({"config": tag, "levels": [lmin, lmax], "steps": nstep, "wall_s": round(wall, 3),
+                              "octs_per_level": {k: v for k, v in last.items() if k >= lmin}, "timers_s": rows}), flush=True)
+
+        ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d")
+        pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch")
+        if which in ("all", "gpu"):
+            run_c5("patched, state and tree resident on the GPU", pat, {"RAMSES_AMD": "1"})
+            run_c5("patched, arrays staged around every godunov_fine (round 1 path)", pat, {"RAMSES_AMD": "1", "RAMSES_AMD_RESIDENT_AMR": "0"})
+        if which in ("all", "ref"):
+            run_c5("reference (1 core)", ref, {"RAMSES_AMD": "0"})
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "grav":
         level, nstep = int(sys.argv[2]), int(sys.argv[3])
         which = sys.argv[4] if len(sys.argv) > 4 else "all"

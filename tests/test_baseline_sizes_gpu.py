@@ -127,9 +127,13 @@ def test_c4_standin_128_checksum(gpu_lib):
         shutil.rmtree(work, ignore_errors=True)
 
 
-def test_c5_levels_7_9_checksum(gpu_lib):
-    """config C5 at levels 7-9 (8 coarse steps, ~2.3 M leaf cells): the tree-walking sweep on every
-    level, with sub-cycling and regridding, == the serial reference by checksum of the sorted leaf data."""
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_c5_levels_7_9_checksum(gpu_lib, resident):
+    """config C5 at levels 7-9 (8 coarse steps, ~2.1 M leaf cells): the tree-walking sweep on every
+    level, with sub-cycling and regridding, == the serial reference by checksum of the sorted leaf data.
+    resident = 1 (default): uold/unew and the tree stay on the device across set_unew / godunov_fine /
+    set_uold / upload_fine / courant_fine / hydro_flag, levels travel only around refine_fine;
+    0 (RAMSES_AMD_RESIDENT_AMR=0): the arrays are staged around every godunov_fine, the rest is host code."""
     if not os.path.exists(PATCHED) or not os.path.exists(GOLD):
         pytest.skip("patched program or golden checksums missing")
     gold = json.load(open(GOLD)).get("c5_79")
@@ -138,8 +142,13 @@ def test_c5_levels_7_9_checksum(gpu_lib):
     from oracle import ramses_snapshot as rs
     mkb = _mkb()
     os.environ["RAMSES_AMD"] = "1"
-    work, out = rs.run_reference(mkb.c5_namelist(), binary=PATCHED)
+    os.environ["RAMSES_AMD_RESIDENT_AMR"] = resident
     try:
+        work, out = rs.run_reference(mkb.c5_namelist(), binary=PATCHED)
+    finally:
+        os.environ.pop("RAMSES_AMD_RESIDENT_AMR", None)
+    try:
+        assert ("AMR levels stay resident on the GPU" in out) == (resident == "1")
         snap = rs.load_leaf_cells(os.path.join(work, "output_00002"))
         assert [int((snap["level"] == l).sum()) for l in (7, 8, 9)] == gold["ncell"]
         assert snap["info"]["t"] == gold["t"]
