@@ -399,6 +399,30 @@ int ramses_amd_mgamr_restrict(int finelevel);
 int ramses_amd_mgamr_interpolate(int finelevel);
 int ramses_amd_mgamr_end(void);
 
+/* ---------------------------------------------------------------------------
+ * multigrid_fine(ilevel,icount) on an AMR level of a periodic single-rank run, driver AND per-solve
+ * setup on the device (csrc/pois_amr.hip): make_initial_phi + interpol_phi (poisson/phi_fine_cg.f90:452-521,
+ * poisson/interpol_phi.f90:1-81), make_fine_mask, make_fine_bc_rhs (poisson/multigrid_fine_commons.f90:982-1159),
+ * build_parent_comms_mg (:400-894), restrict_mask_fine/coarse_reverse (multigrid_fine_fine.f90:88-141,
+ * multigrid_fine_coarse.f90:105-160), set_scan_flag_fine/_coarse (:705-771, :892-985), the iteration loop
+ * (:176-282) and recursive_multigrid_coarse (:307-390).
+ *   poisamr_tree       son(1:ncell), nbor(1:ngridmax,1:6), father(1:ngridmax); copied only when `epoch` (a counter the
+ *                      caller advances whenever the tree may have changed) differs from the cached one
+ *   poisamr_multigrid  igrid = active(ilevel)%igrid, igrid_c = active(ilevel-1)%igrid; phi, phi_old, rho = the
+ *                      reference's cell vectors (host).  Read: rho on the level, phi and phi_old on the level above
+ *                      (interp=1: first guess and boundary values interpolated, tfrac = dtnew(l)/dtold(l-1)*(icount-1));
+ *                      written: phi on the level.  flag2 = the reference's work array flag2(1:ncell) (its element 1, not
+ *                      0): read and updated on the level's cells the way set_scan_flag_fine does (the stale-flag
+ *                      behaviour of :763-768 decides which cells take the scanning branch), flag2(1:n) receives the
+ *                      coarse oct lists as in build_parent_comms_mg.  safe_mode in/out; iters/err = what the reference prints.
+ * ------------------------------------------------------------------------- */
+int ramses_amd_poisamr_tree(int epoch, int64_t ngridmax, int64_t ncoarse, const int *son, const int *nbor, const int *father);
+int ramses_amd_poisamr_multigrid(int ilevel, int ngrid, const int *igrid, int ngrid_c, const int *igrid_c, double *phi,
+                                 const double *phi_old, const double *rho, int *flag2, double rho_tot, double fourpi,
+                                 double tfrac, int interp, double epsilon, int ngs_fine, int ngs_coarse,
+                                 int ncycles_coarse_safe, int *safe_mode, int *iters, double *err);
+int ramses_amd_poisamr_levelmin_mg(void);
+
 /* -------------------------------------------------------------------------
  * phi_fine_cg(ilevel,icount) -- poisson/phi_fine_cg.f90:5-206: the iteration loop (:88-187)
  * of the conjugate-gradient Poisson solver with cmp_Ap_cg (:344-447), on one AMR level in the

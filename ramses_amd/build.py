@@ -34,6 +34,7 @@ UNITS = [
     ("capi.o", "capi.hip", ["-ffp-contract=off"]),
     ("capi_mpi.o", "capi_mpi.hip", ["-ffp-contract=off"]),
     ("capi_amr.o", "capi_amr.hip", ["-ffp-contract=off"]),
+    ("pois_amr.o", "pois_amr.hip", ["-ffp-contract=off"]),
 ]
 
 

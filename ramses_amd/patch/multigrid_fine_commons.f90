@@ -27,8 +27,8 @@ subroutine multigrid_fine(ilevel,icount)
   ! of the level.  f(:,1:3) is scratch in the reference (force_fine overwrites
   ! it next) and is left untouched here.
   !--------------------------------------------------------------------------
-  integer::rc,nx_loc,isafe,iters
-  real(dp)::scale,fourpi
+  integer::rc,nx_loc,isafe,iters,interp
+  real(dp)::scale,fourpi,tfrac
   real(kind=8)::err
 
   if(gravity_type>0)return
@@ -52,6 +52,38 @@ subroutine multigrid_fine(ilevel,icount)
      if(ncpu>1)then
         write(*,*)'ramses_amd: device multigrid on AMR levels handles single-rank runs; got ncpu=',ncpu
         call ramses_amd_fatal('multigrid_fine (AMR level: several ranks)')
+     end if
+     ! periodic box of one coarse cell: driver and per-solve setup on the device too (csrc/pois_amr.hip); only
+     ! rho of the level and phi, phi_old of the level above travel in, phi of the level out
+     ! (RAMSES_AMD_MG_DRIVER=host: the reference's driver and setup with the device operators, as with walls)
+     if(nboundary==0.and.ncoarse==1.and.ilevel>1.and.ramses_amd_mg_device_driver())then
+        if(nremap>0)ramses_amd_tree_epoch=ramses_amd_tree_epoch+1     ! (defrag may renumber the octs)
+        rc=ramses_amd_poisamr_tree(ramses_amd_tree_epoch,int(ngridmax,8),int(ncoarse,8),son,nbor,father)
+        if(rc/=0)call ramses_amd_fatal('multigrid_fine (AMR level, tree)')
+        scale=boxlen/dble(nx_loc)
+        fourpi=2*twopi*scale
+        if(cosmo)fourpi=1.5D0*omega_m*aexp*scale
+        interp=0
+        tfrac=0.0d0
+        if(ilevel>levelmin)then
+           interp=1
+           if(icount/=1.and.icount/=2)then
+              write(*,*)'icount has bad value'
+              call clean_stop
+           end if
+           if(dtold(ilevel-1)>0)tfrac=1d0*dtnew(ilevel)/dtold(ilevel-1)*(icount-1)
+        end if
+        isafe=0
+        if(safe_mode(ilevel))isafe=1
+        rc=ramses_amd_poisamr_multigrid(ilevel,active(ilevel)%ngrid,active(ilevel)%igrid, &
+             & active(ilevel-1)%ngrid,active(ilevel-1)%igrid,phi,phi_old,rho,flag2(1),rho_tot,fourpi,tfrac,interp, &
+             & epsilon,ngs_fine,ngs_coarse,ncycles_coarse_safe,isafe,iters,err)
+        if(rc/=0)call ramses_amd_fatal('multigrid_fine (AMR level)')
+        safe_mode(ilevel)=(isafe/=0)
+        if(myid==1) print '(A,I5,A,I5,A,1pE10.3)','   ==> Level=',ilevel, ' Step=', &
+             iters,' Error=',err
+        if(myid==1 .and. iters==10) print *,'WARN: Fine multigrid Poisson failed to converge...'
+        return
      end if
      ramses_amd_mg_active=.true.
      ramses_amd_mg_started=.false.
@@ -94,3 +126,4 @@ subroutine multigrid_fine(ilevel,icount)
   if(myid==1 .and. iters==10) print *,'WARN: Fine multigrid Poisson failed to converge...'
 
 end subroutine multigrid_fine
+

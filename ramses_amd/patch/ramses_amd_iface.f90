@@ -210,6 +210,26 @@ module ramses_amd_iface
        import :: c_int
        integer(c_int) :: rc
      end function ramses_amd_mgamr_end
+     function ramses_amd_poisamr_tree(epoch, ngridmax, ncoarse, son, nbor, father) &
+          & bind(C, name='ramses_amd_poisamr_tree') result(rc)
+       import :: c_int, c_int64_t
+       integer(c_int), value :: epoch
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       integer(c_int) :: son(*), nbor(*), father(*)
+       integer(c_int) :: rc
+     end function ramses_amd_poisamr_tree
+     function ramses_amd_poisamr_multigrid(ilevel, ngrid, igrid, ngrid_c, igrid_c, phi, phi_old, rho, flag2, rho_tot, fourpi, &
+          & tfrac, interp, epsilon, ngs_fine, ngs_coarse, ncycles_coarse_safe, safe_mode, iters, err) &
+          & bind(C, name='ramses_amd_poisamr_multigrid') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: ilevel, ngrid, ngrid_c, interp, ngs_fine, ngs_coarse, ncycles_coarse_safe
+       integer(c_int) :: igrid(*), igrid_c(*), flag2(*)
+       real(c_double) :: phi(*), phi_old(*), rho(*)
+       real(c_double), value :: rho_tot, fourpi, tfrac, epsilon
+       integer(c_int) :: safe_mode, iters
+       real(c_double) :: err
+       integer(c_int) :: rc
+     end function ramses_amd_poisamr_multigrid
 
      ! ---- device-resident level (include/ramses_amd.h) ----
      function ramses_amd_resident_courant_f90(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, &
@@ -509,6 +529,9 @@ module ramses_amd_iface
   logical, save :: ramses_amd_amr_armed = .false.
   integer, save :: ramses_amd_amr_reload_from = 1000   ! levels >= this were rebuilt on the host and await their reload
   integer, save :: ramses_amd_amr_host_from = 1000     ! levels >= this are current on the host (synced or rebuilt) since the last device routine
+  ! advanced whenever the reference may have changed the tree (refine_fine); the device copies of son/nbor/father
+  ! are re-sent when their epoch is behind
+  integer, save :: ramses_amd_tree_epoch = 0
 
 contains
 
@@ -636,6 +659,21 @@ contains
     end if
     ramses_amd_mg_on_device = ramses_amd_mg_active .and. iand(mask, ibit) == 0
   end function ramses_amd_mg_on_device
+
+  ! AMR multigrid: driver and per-solve setup on the device (default) or the reference's (RAMSES_AMD_MG_DRIVER=host)
+  logical function ramses_amd_mg_device_driver()
+    character(len=16) :: val
+    integer :: stat
+    integer, save :: state = -1
+    if (state < 0) then
+       state = 1
+       call get_environment_variable('RAMSES_AMD_MG_DRIVER', val, status=stat)
+       if (stat == 0) then
+          if (trim(val) == 'host') state = 0
+       end if
+    end if
+    ramses_amd_mg_device_driver = state == 1
+  end function ramses_amd_mg_device_driver
 
   integer function ramses_amd_world_rank()
     use amr_commons, only: myid
@@ -1008,6 +1046,7 @@ contains
     use hydro_commons
     integer, intent(in) :: ilevel
     integer :: rc, l
+    ramses_amd_tree_epoch = ramses_amd_tree_epoch + 1
     if (.not. ramses_amd_amr_resident()) return
     if (ramses_amd_amrres_active() == 0) return
     if (ilevel < levelmin) return      ! fully refined coarse levels: nothing is created, no hydro data is read
