@@ -422,6 +422,18 @@ int ramses_amd_poisamr_multigrid(int ilevel, int ngrid, const int *igrid, int ng
                                  double tfrac, int interp, double epsilon, int ngs_fine, int ngs_coarse,
                                  int ncycles_coarse_safe, int *safe_mode, int *iters, double *err);
 int ramses_amd_poisamr_levelmin_mg(void);
+/* force_fine(ilevel) on an AMR level of the same kind of run (poisson/force_fine.f90:5-194, gradient_phi :199-324 with
+ * interpol_phi at the level's edge): f(1:ncell,1:3) written on the level's cells; diag[0] = the level's term of epot_tot,
+ * diag[1] = rho_max(ilevel).  fresh=1: poisamr_multigrid has just solved this level (phi, rho and the level above are still
+ * on the device), else they are read from the host vectors. */
+int ramses_amd_poisamr_force(int ilevel, int ngrid, const int *igrid, int ngrid_c, const int *igrid_c, const double *phi,
+                             const double *phi_old, const double *rho, double *f, double tfrac, int interp, int fresh,
+                             double fact, double *diag);
+/* create the HIP context and load the device code of every kernel now (one-time ~0.2 s, otherwise paid by the
+ * first call of each kernel family inside the reference's timed loop) */
+int ramses_amd_warmup(void);
+/* RAMSES_AMD_PROFILE=1: accumulate wall time per shadowed routine and level (printed at exit) */
+int ramses_amd_prof_add(const char *name, int level, double seconds);
 
 /* -------------------------------------------------------------------------
  * phi_fine_cg(ilevel,icount) -- poisson/phi_fine_cg.f90:5-206: the iteration loop (:88-187)

@@ -99,6 +99,9 @@ SYMBOLS = [
     ("ramses_amd_poisamr_tree", _i, [_i, _i64, _i64, _vp, _vp, _vp]),
     ("ramses_amd_poisamr_multigrid", _i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i, _d, _i, _i, _i, _vp, _vp, _vp]),
     ("ramses_amd_poisamr_levelmin_mg", _i, []),
+    ("ramses_amd_poisamr_force", _i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _d, _vp]),
+    ("ramses_amd_prof_add", _i, [C.c_char_p, _i, _d]),
+    ("ramses_amd_warmup", _i, []),
     ("ramses_amd_host_register", _i, [_vp, _i64]),
     ("ramses_amd_resident_synchro_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _d]),
     ("ramses_amd_resident_courant_grav_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _d, _d, _vp]),

@@ -104,3 +104,6 @@ hipError_t launch_amr_op(const AmrOpArgs &A, bool prolong, hipStream_t s) {
 }
 
 }  // namespace ramses_amd
+
+#include "warm.hpp"
+RAMSES_AMD_TU_WARM(amr_ops)

@@ -811,3 +811,6 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A, int slope_type, int riemann
 }
 
 }  // namespace ramses_amd
+
+#include "warm.hpp"
+RAMSES_AMD_TU_WARM(amr_sweep)

@@ -473,3 +473,6 @@ int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int 
 }
 
 }  // extern "C"
+
+#include "warm.hpp"
+RAMSES_AMD_TU_WARM(capi_amr)

@@ -648,3 +648,6 @@ int ramses_amd_mpires_invalidate(void) {
 }
 
 }  // extern "C"
+
+#include "warm.hpp"
+RAMSES_AMD_TU_WARM(capi_mpi)

@@ -301,3 +301,6 @@ hipError_t cg_launch_iteration(const CgLevel &L, int iter, int slot, hipStream_t
 }
 
 }  // namespace ramses_amd
+
+#include "warm.hpp"
+RAMSES_AMD_TU_WARM(cg_amr)

@@ -363,3 +363,6 @@ hipError_t launch_add_gravity_source(double *unew, const double *uold, const dou
 }
 
 }  // namespace ramses_amd
+
+#include "warm.hpp"
+RAMSES_AMD_TU_WARM(hydro_misc)

@@ -689,3 +689,10 @@ hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int b
 
 }  // namespace SWEEP_NS
 }  // namespace ramses_amd
+
+#include "warm.hpp"
+#if RAMSES_AMD_FAST
+RAMSES_AMD_TU_WARM(hydro_sweep_fast)
+#else
+RAMSES_AMD_TU_WARM(hydro_sweep_strict)
+#endif

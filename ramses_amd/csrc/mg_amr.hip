@@ -315,3 +315,6 @@ hipError_t mgamr_launch_lookup(const int *igrid, int ngrid, int *lookup, hipStre
 }
 
 }  // namespace ramses_amd
+
+#include "warm.hpp"
+RAMSES_AMD_TU_WARM(mg_amr)

@@ -718,3 +718,6 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
 }
 
 }  // namespace ramses_amd
+
+#include "warm.hpp"
+RAMSES_AMD_TU_WARM(mg_kernels)

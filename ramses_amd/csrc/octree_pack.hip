@@ -97,3 +97,6 @@ hipError_t launch_oct_copy(const PackArgs &A, bool gather, hipStream_t s) {
 }
 
 }  // namespace ramses_amd
+
+#include "warm.hpp"
+RAMSES_AMD_TU_WARM(octree_pack)

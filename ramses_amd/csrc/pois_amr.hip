@@ -26,10 +26,12 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../include/ramses_amd.h"
 #include "mg_amr_args.hpp"
+#include "misc_args.hpp"
 
 using namespace ramses_amd;
 
@@ -276,6 +278,55 @@ __global__ __launch_bounds__(256) void scan_flag_kernel(MgAmrLevel L, MgAmrTree 
   }
 }
 
+// gradient_phi (poisson/force_fine.f90:199-324): f_d = a (phi(-1) - phi(+1)) - b (phi(-2) - phi(+2)); a value in a
+// neighbouring oct that does not exist is interpolated from the level above (interpol_phi of the neighbouring
+// father cell).  out = packed [3][8*ngrid]; leaf[c] = 1 where the cell is not refined (for the diagnostics)
+struct ForceArgs {
+  MgAmrLevel L;
+  MgAmrTree T;
+  const double *phi, *phi_old;     // AMR cell vectors: phi of the level (and of the level above, with phi_old, if interp)
+  double tfrac, a, b;
+  int interp;
+  double *out;
+  int *leaf;
+};
+__device__ __forceinline__ double force_phi_at(const ForceArgs &A, int g_nb, int nb_father, int octant) {
+  if (g_nb > 0) return A.phi[A.T.ncoarse + (long)octant * A.T.ngridmax + g_nb - 1];
+  return interpol_phi_child(nb_father, octant, A.phi, A.phi_old, A.tfrac, A.T);
+}
+__global__ __launch_bounds__(256) void force_kernel(ForceArgs A) {
+  const long total = 8L * A.L.ngrid;
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(c % A.L.ngrid), ind = (int)(c / A.L.ngrid);
+    const int g = A.L.igrid[i];
+    A.leaf[c] = A.T.son[A.T.ncoarse + (long)ind * A.T.ngridmax + g - 1] == 0;
+#pragma unroll 1
+    for (int d = 0; d < 3; d++) {
+      const int nbl = A.T.nbor[(long)(2 * d) * A.T.ngridmax + g - 1], nbr = A.T.nbor[(long)(2 * d + 1) * A.T.ngridmax + g - 1];
+      const int gl = A.T.son[nbl - 1], gr = A.T.son[nbr - 1];
+      const int bit = (ind >> d) & 1, jnd = ind ^ (1 << d);
+      const double phi1 = bit ? A.phi[A.T.ncoarse + (long)jnd * A.T.ngridmax + g - 1] : force_phi_at(A, gl, nbl, jnd);
+      const double phi2 = bit ? force_phi_at(A, gr, nbr, jnd) : A.phi[A.T.ncoarse + (long)jnd * A.T.ngridmax + g - 1];
+      const double phi3 = force_phi_at(A, gl, nbl, ind);
+      const double phi4 = force_phi_at(A, gr, nbr, ind);
+      A.out[(long)d * total + c] = A.a * (phi1 - phi2) - A.b * (phi3 - phi4);
+    }
+  }
+}
+// packed level values of 3 components -> AMR cell vectors f(1:ncell,1:3) on the device
+__global__ void vec3_scatter_kernel(double *vec, const double *in, const int *igrid, int ngrid, long ncoarse, long ngridmax, long ncell) {
+  const long total = 8L * ngrid;
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x) {
+    const long cell = ncoarse + (long)(c / ngrid) * ngridmax + igrid[c % ngrid] - 1;
+    for (int d = 0; d < 3; d++) vec[(long)d * ncell + cell] = in[(long)d * total + c];
+  }
+}
+__global__ void vec_gather_kernel(const double *vec, double *out, const int *igrid, int ngrid, long ncoarse, long ngridmax) {
+  const long total = 8L * ngrid;
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x)
+    out[c] = vec[ncoarse + (long)(c / ngrid) * ngridmax + igrid[c % ngrid] - 1];
+}
+
 // cell vector (AMR layout, device) <- packed level values (ind*ngrid + i) and back
 __global__ void vec_scatter_kernel(double *vec, const double *in, const int *igrid, int ngrid, long ncoarse, long ngridmax) {
   const long total = 8L * ngrid;
@@ -318,7 +369,12 @@ struct PoisAmr {
   long ncoarse = 0, ngridmax = 0, ncell = 0;
   Buf son, nbor, father, lookup;
   // the reference's cell vectors (AMR layout)
-  Buf phi, phi_old, rho;
+  Buf phi, phi_old, rho, f;
+  // what the device copies hold: phi and rho of level `have_level` (ngrid `have_ngrid`), and, if have_above, phi and
+  // phi_old of the level above it -- left there by the last multigrid solve for force_fine
+  int have_level = 0, have_ngrid = 0, have_epoch = -1;
+  bool have_above = false;
+  Buf fpack, leaf, diag;
   Buf igrid_c;                      // octs of the level above (whose phi feeds the interpolation)
   Level lev[32];
   Buf count, any, partial, norm, pack;
@@ -582,9 +638,117 @@ int ramses_amd_poisamr_multigrid(int ilevel, int ngrid, const int *igrid, int ng
     const double *src = hs + (size_t)ind * ngrid;
     for (int i = 0; i < ngrid; i++) dst[igrid[i]] = src[i];
   }
+  P.have_level = ilevel; P.have_ngrid = ngrid; P.have_epoch = P.epoch; P.have_above = interp != 0;
+  return 0;
+}
+
+// force_fine(ilevel) on an AMR level of a periodic single-rank run (poisson/force_fine.f90:5-194 with gravity_type = 0):
+// f(:,1:3) of the level's cells from phi (gradient_phi, values beyond the level's edge interpolated from the level above),
+// diag[0] = the level's term of epot_tot (fact * sum f^2 over leaf cells), diag[1] = rho_max(ilevel).
+//   fresh = 1: ramses_amd_poisamr_multigrid has just solved this level -- phi, rho of the level and phi, phi_old of the
+//   level above are still on the device; otherwise they are read from the host vectors.  f = f(1:ncell,1:3) (host), written
+//   on the level's cells.
+int ramses_amd_poisamr_force(int ilevel, int ngrid, const int *igrid, int ngrid_c, const int *igrid_c, const double *phi,
+                             const double *phi_old, const double *rho, double *f, double tfrac, int interp, int fresh, double fact,
+                             double *diag) {
+  PoisAmr &P = g_pa;
+  if (!P.tree_valid) return failf(RAMSES_AMD_EINVAL, "poisamr_force: no tree (ramses_amd_poisamr_tree)");
+  if (!igrid || !phi || !phi_old || !rho || !f || !diag) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  if (ilevel < 2 || ilevel > 30 || ngrid < 1 || ngrid > P.ngridmax) return failf(RAMSES_AMD_EINVAL, "bad level %d / ngrid %d", ilevel, ngrid);
+  if (interp && (!igrid_c || ngrid_c < 1)) return failf(RAMSES_AMD_EINVAL, "the level above is empty");
+  hipStream_t s = nullptr;
+  const long ncoarse = P.ncoarse, ngridmax = P.ngridmax;
+  const long nf = 8L * ngrid, nc = interp ? 8L * ngrid_c : 0;
+  const size_t vb = sizeof(double) * (size_t)P.ncell;
+  HCHK(P.phi.ensure(vb), "hipMalloc phi"); HCHK(P.phi_old.ensure(vb), "hipMalloc phi_old"); HCHK(P.rho.ensure(vb), "hipMalloc rho");
+  HCHK(P.f.ensure(3 * vb), "hipMalloc f");
+  HCHK(P.fpack.ensure(sizeof(double) * 3 * (size_t)nf), "hipMalloc"); HCHK(P.leaf.ensure(sizeof(int) * (size_t)nf), "hipMalloc");
+  HCHK(P.diag.ensure(sizeof(double) * (2 * 512 + 2)), "hipMalloc"); HCHK(P.pack.ensure(sizeof(double) * (size_t)(2 * nf + 2 * nc)), "hipMalloc pack");
+  HCHK(P.stage.ensure(sizeof(double) * (size_t)(3 * nf + 2 * nc)), "hipHostMalloc");
+  Level &F = P.lev[ilevel];
+  const bool have = fresh && P.have_level == ilevel && P.have_ngrid == ngrid && P.have_epoch == P.epoch && (!interp || P.have_above);
+  double *hs = P.stage.as<double>();
+  if (!have) {
+    F.ngrid = ngrid;
+    HCHK(F.igrid.ensure(sizeof(int) * (size_t)ngrid), "hipMalloc igrid");
+    HCHK(hipMemcpyAsync(F.igrid.p, igrid, sizeof(int) * (size_t)ngrid, hipMemcpyHostToDevice, s), "H2D igrid");
+    for (int ind = 0; ind < 8; ind++) {
+      const double *s1 = phi + ncoarse + (size_t)ind * ngridmax - 1, *s2 = rho + ncoarse + (size_t)ind * ngridmax - 1;
+      double *d1 = hs + (size_t)ind * ngrid, *d2 = hs + nf + (size_t)ind * ngrid;
+      for (int i = 0; i < ngrid; i++) { d1[i] = s1[igrid[i]]; d2[i] = s2[igrid[i]]; }
+    }
+    if (interp)
+      for (int ind = 0; ind < 8; ind++) {
+        const double *s1 = phi + ncoarse + (size_t)ind * ngridmax - 1, *s2 = phi_old + ncoarse + (size_t)ind * ngridmax - 1;
+        double *d1 = hs + 2 * nf + (size_t)ind * ngrid_c, *d2 = hs + 2 * nf + nc + (size_t)ind * ngrid_c;
+        for (int i = 0; i < ngrid_c; i++) { d1[i] = s1[igrid_c[i]]; d2[i] = s2[igrid_c[i]]; }
+      }
+    HCHK(hipMemcpyAsync(P.pack.p, hs, sizeof(double) * (size_t)(2 * nf + 2 * nc), hipMemcpyHostToDevice, s), "H2D level data");
+    hipLaunchKernelGGL(vec_scatter_kernel, dim3(grid_for(nf)), dim3(256), 0, s, P.phi.as<double>(), P.pack.as<double>(), F.igrid.as<int>(), ngrid, ncoarse, ngridmax);
+    hipLaunchKernelGGL(vec_scatter_kernel, dim3(grid_for(nf)), dim3(256), 0, s, P.rho.as<double>(), P.pack.as<double>() + nf, F.igrid.as<int>(), ngrid, ncoarse, ngridmax);
+    if (interp) {
+      HCHK(P.igrid_c.ensure(sizeof(int) * (size_t)ngrid_c), "hipMalloc igrid_c");
+      HCHK(hipMemcpyAsync(P.igrid_c.p, igrid_c, sizeof(int) * (size_t)ngrid_c, hipMemcpyHostToDevice, s), "H2D igrid_c");
+      hipLaunchKernelGGL(vec_scatter_kernel, dim3(grid_for(nc)), dim3(256), 0, s, P.phi.as<double>(), P.pack.as<double>() + 2 * nf, P.igrid_c.as<int>(), ngrid_c, ncoarse, ngridmax);
+      hipLaunchKernelGGL(vec_scatter_kernel, dim3(grid_for(nc)), dim3(256), 0, s, P.phi_old.as<double>(), P.pack.as<double>() + 2 * nf + nc, P.igrid_c.as<int>(), ngrid_c, ncoarse, ngridmax);
+    }
+    HCHK(hipGetLastError(), "scatter launch");
+    HCHK(hipStreamSynchronize(s), "sync");     // the staging area is reused below
+  }
+  P.have_level = 0;
+  ForceArgs A;
+  A.L = F.view(); A.L.ngrid = ngrid; A.T = P.tree();
+  A.phi = P.phi.as<double>(); A.phi_old = P.phi_old.as<double>();
+  A.tfrac = tfrac; A.interp = interp ? 1 : 0;
+  const double dx = std::ldexp(1.0, -ilevel);
+  A.a = 0.50 * 4.0 / 3.0 / dx;
+  A.b = 0.25 * 1.0 / 3.0 / dx;
+  A.out = P.fpack.as<double>(); A.leaf = P.leaf.as<int>();
+  hipLaunchKernelGGL(force_kernel, dim3(grid_for(nf)), dim3(256), 0, s, A);
+  HCHK(hipGetLastError(), "force launch");
+  // diagnostics over the level's cells (rho packed from the device vector)
+  hipLaunchKernelGGL(vec_gather_kernel, dim3(grid_for(nf)), dim3(256), 0, s, P.rho.as<double>(), P.pack.as<double>(), F.igrid.as<int>(), ngrid, ncoarse, ngridmax);
+  HCHK(launch_force_diag(P.fpack.as<double>(), P.pack.as<double>(), P.leaf.as<int>(), nf, fact, P.diag.as<double>() + 2, P.diag.as<double>(), s), "diag launch");
+  hipLaunchKernelGGL(vec3_scatter_kernel, dim3(grid_for(nf)), dim3(256), 0, s, P.f.as<double>(), P.fpack.as<double>(), F.igrid.as<int>(), ngrid, ncoarse, ngridmax, P.ncell);
+  HCHK(hipMemcpyAsync(hs, P.fpack.p, sizeof(double) * 3 * (size_t)nf, hipMemcpyDeviceToHost, s), "D2H f");
+  HCHK(hipMemcpyAsync(diag, P.diag.p, sizeof(double) * 2, hipMemcpyDeviceToHost, s), "D2H diag");
+  HCHK(hipStreamSynchronize(s), "sync");
+  for (int d = 0; d < 3; d++)
+    for (int ind = 0; ind < 8; ind++) {
+      double *dst = f + (size_t)d * P.ncell + ncoarse + (size_t)ind * ngridmax - 1;
+      const double *src = hs + (size_t)d * nf + (size_t)ind * ngrid;
+      for (int i = 0; i < ngrid; i++) dst[igrid[i]] = src[i];
+    }
   return 0;
 }
 
 int ramses_amd_poisamr_levelmin_mg(void) { return g_pa.levelmin_mg; }
 
+// RAMSES_AMD_PROFILE=1: wall time per shadowed routine and level, accumulated by the Fortran shims
+// (ramses_amd_iface: ramses_amd_tic / ramses_amd_toc) and printed when the program ends
+int ramses_amd_prof_add(const char *name, int level, double seconds) {
+  struct Row { char name[48]; int level; double t, tmax; long n; };
+  static Row rows[256];
+  static int nrows = 0, state = -1;
+  if (state < 0) {
+    state = getenv("RAMSES_AMD_PROFILE") != nullptr;
+    if (state) atexit([] {
+      const char *e = getenv("RAMSES_AMD_PROFILE");          // "1": stderr, anything else: a file to append to
+      FILE *fo = (e && e[0] && strcmp(e, "1") != 0) ? fopen(e, "a") : stderr;
+      if (!fo) fo = stderr;
+      fprintf(fo, "ramses_amd profile (wall seconds inside the shadowed routines)\n");
+      for (int i = 0; i < nrows; i++) fprintf(fo, "  %-32s level %2d  calls %6ld  %10.4f s  (longest call %.4f s)\n", rows[i].name, rows[i].level, rows[i].n, rows[i].t, rows[i].tmax);
+      if (fo != stderr) fclose(fo);
+    });
+  }
+  if (!state || !name) return 0;
+  for (int i = 0; i < nrows; i++)
+    if (rows[i].level == level && strncmp(rows[i].name, name, 47) == 0) { rows[i].t += seconds; rows[i].n++; if (seconds > rows[i].tmax) rows[i].tmax = seconds; return 0; }
+  if (nrows < 256) { strncpy(rows[nrows].name, name, 47); rows[nrows].name[47] = 0; rows[nrows].level = level; rows[nrows].t = rows[nrows].tmax = seconds; rows[nrows].n = 1; nrows++; }
+  return 0;
+}
+
 }  // extern "C"
+
+#include "warm.hpp"
+RAMSES_AMD_TU_WARM(pois_amr)

@@ -286,3 +286,6 @@ hipError_t launch_multipole(const RhoArgs &A, double *out4, hipStream_t s) {
 }
 
 }  // namespace ramses_amd
+
+#include "warm.hpp"
+RAMSES_AMD_TU_WARM(rho_fine)

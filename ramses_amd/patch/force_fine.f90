@@ -11,7 +11,7 @@
 #include "poisson/force_fine.f90"
 #undef force_fine
 
-subroutine force_fine(ilevel,icount)
+subroutine force_fine_amd(ilevel,icount)
   use amr_commons
   use pm_commons
   use poisson_commons
@@ -27,12 +27,43 @@ subroutine force_fine(ilevel,icount)
   ! box, level fully refined (every neighbour exists: no interpol_phi), no sink
   ! particles; anything else is the reference's routine.
   !--------------------------------------------------------------------------
-  integer::rc,nx_loc,has_son
-  real(dp)::dx,dx_loc,scale,fact,fourpi
+  integer::rc,nx_loc,has_son,fresh
+  real(dp)::dx,dx_loc,scale,fact,fourpi,tfrac
   real(kind=8),dimension(2)::diag
 
   if(numbtot(1,ilevel)==0)return
   nx_loc=(icoarse_max-icoarse_min+1)
+  fresh=0
+  if(ramses_amd_pois_amr_level==ilevel)fresh=1
+  ramses_amd_pois_amr_level=0
+  ! an AMR level (not the whole box) of a periodic single-rank run: gradient_phi with interpol_phi at the level's
+  ! edge on the device (csrc/pois_amr.hip), reusing what the multigrid driver left there
+  if(ramses_amd_enabled().and.gravity_type==0.and.ncpu==1.and.nboundary==0.and..not.sink.and.ndim==3.and.ilevel>levelmin &
+       & .and.ncoarse==1.and.ramses_amd_mg_device_driver() &
+       & .and.int(active(ilevel)%ngrid,8)*8_8/=(2_8**ilevel)**3*int(nx_loc,8)**3)then
+     if(verbose)write(*,111)ilevel
+     if(nremap>0)ramses_amd_tree_epoch=ramses_amd_tree_epoch+1
+     rc=ramses_amd_poisamr_tree(ramses_amd_tree_epoch,int(ngridmax,8),int(ncoarse,8),son,nbor,father)
+     if(rc/=0)call ramses_amd_fatal('force_fine (AMR level, tree)')
+     dx=0.5D0**ilevel
+     scale=boxlen/dble(nx_loc)
+     dx_loc=dx*scale
+     fourpi=2*twopi
+     if(cosmo)fourpi=1.5D0*omega_m*aexp
+     fact=-dx_loc**ndim/fourpi/2.0D0
+     if(icount/=1.and.icount/=2)then
+        write(*,*)'icount has bad value'
+        call clean_stop
+     end if
+     tfrac=0.0d0
+     if(dtold(ilevel-1)>0)tfrac=1d0*dtnew(ilevel)/dtold(ilevel-1)*(icount-1)
+     rc=ramses_amd_poisamr_force(ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,active(ilevel-1)%ngrid, &
+          & active(ilevel-1)%igrid,phi,phi_old,rho,f,tfrac,1,fresh,fact,diag)
+     if(rc/=0)call ramses_amd_fatal('force_fine (AMR level)')
+     epot_tot=epot_tot+diag(1)
+     rho_max(ilevel)=diag(2)
+     return
+  end if
   if(.not.ramses_amd_enabled().or.gravity_type>0.or.ncpu>1.or.nboundary>0.or.sink.or.ndim/=3.or.ilevel<2 &
        & .or.nx_loc/=1.or.int(active(ilevel)%ngrid,8)*8_8/=(2_8**ilevel)**3*int(nx_loc,8)**3)then
      call force_fine_reference(ilevel,icount)
@@ -68,4 +99,14 @@ subroutine force_fine(ilevel,icount)
 
 111 format('   Entering force_fine (MI355X) for level ',I2)
 
+end subroutine force_fine_amd
+
+subroutine force_fine(ilevel,icount)
+  use ramses_amd_iface
+  implicit none
+  integer::ilevel,icount
+  integer(8)::t0
+  call ramses_amd_tic(t0)
+  call force_fine_amd(ilevel,icount)
+  call ramses_amd_toc('force_fine',ilevel,t0)
 end subroutine force_fine

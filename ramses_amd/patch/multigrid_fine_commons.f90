@@ -13,7 +13,7 @@
 #include "poisson/multigrid_fine_commons.f90"
 #undef multigrid_fine
 
-subroutine multigrid_fine(ilevel,icount)
+subroutine multigrid_fine_amd(ilevel,icount)
   use amr_commons
   use poisson_commons
   use poisson_parameters
@@ -80,6 +80,7 @@ subroutine multigrid_fine(ilevel,icount)
              & epsilon,ngs_fine,ngs_coarse,ncycles_coarse_safe,isafe,iters,err)
         if(rc/=0)call ramses_amd_fatal('multigrid_fine (AMR level)')
         safe_mode(ilevel)=(isafe/=0)
+        ramses_amd_pois_amr_level=ilevel
         if(myid==1) print '(A,I5,A,I5,A,1pE10.3)','   ==> Level=',ilevel, ' Step=', &
              iters,' Error=',err
         if(myid==1 .and. iters==10) print *,'WARN: Fine multigrid Poisson failed to converge...'
@@ -125,5 +126,15 @@ subroutine multigrid_fine(ilevel,icount)
        iters,' Error=',err
   if(myid==1 .and. iters==10) print *,'WARN: Fine multigrid Poisson failed to converge...'
 
-end subroutine multigrid_fine
+end subroutine multigrid_fine_amd
 
+
+subroutine multigrid_fine(ilevel,icount)
+  use ramses_amd_iface
+  implicit none
+  integer::ilevel,icount
+  integer(8)::t0
+  call ramses_amd_tic(t0)
+  call multigrid_fine_amd(ilevel,icount)
+  call ramses_amd_toc('multigrid_fine',ilevel,t0)
+end subroutine multigrid_fine

@@ -218,6 +218,26 @@ module ramses_amd_iface
        integer(c_int) :: son(*), nbor(*), father(*)
        integer(c_int) :: rc
      end function ramses_amd_poisamr_tree
+     function ramses_amd_warmup() bind(C, name='ramses_amd_warmup') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function ramses_amd_warmup
+     function ramses_amd_poisamr_force(ilevel, ngrid, igrid, ngrid_c, igrid_c, phi, phi_old, rho, f, tfrac, interp, fresh, &
+          & fact, diag) bind(C, name='ramses_amd_poisamr_force') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: ilevel, ngrid, ngrid_c, interp, fresh
+       integer(c_int) :: igrid(*), igrid_c(*)
+       real(c_double) :: phi(*), phi_old(*), rho(*), f(*), diag(2)
+       real(c_double), value :: tfrac, fact
+       integer(c_int) :: rc
+     end function ramses_amd_poisamr_force
+     function ramses_amd_prof_add(name, level, seconds) bind(C, name='ramses_amd_prof_add') result(rc)
+       import :: c_int, c_double, c_char
+       character(kind=c_char) :: name(*)
+       integer(c_int), value :: level
+       real(c_double), value :: seconds
+       integer(c_int) :: rc
+     end function ramses_amd_prof_add
      function ramses_amd_poisamr_multigrid(ilevel, ngrid, igrid, ngrid_c, igrid_c, phi, phi_old, rho, flag2, rho_tot, fourpi, &
           & tfrac, interp, epsilon, ngs_fine, ngs_coarse, ncycles_coarse_safe, safe_mode, iters, err) &
           & bind(C, name='ramses_amd_poisamr_multigrid') result(rc)
@@ -532,6 +552,8 @@ module ramses_amd_iface
   ! advanced whenever the reference may have changed the tree (refine_fine); the device copies of son/nbor/father
   ! are re-sent when their epoch is behind
   integer, save :: ramses_amd_tree_epoch = 0
+  ! the AMR level whose potential the device multigrid driver has just left on the device (0: none)
+  integer, save :: ramses_amd_pois_amr_level = 0
 
 contains
 
@@ -554,6 +576,8 @@ contains
           if (rc /= 0) call ramses_amd_fatal('ramses_amd_set_device_auto')
           call ramses_amd_check_build()
           call ramses_amd_pin_arrays()
+          rc = ramses_amd_warmup()
+          if (rc /= 0) call ramses_amd_fatal('ramses_amd_warmup')
        end if
        ramses_amd_checked = .true.
     end if
@@ -659,6 +683,21 @@ contains
     end if
     ramses_amd_mg_on_device = ramses_amd_mg_active .and. iand(mask, ibit) == 0
   end function ramses_amd_mg_on_device
+
+  ! RAMSES_AMD_PROFILE=1: wall time per shadowed routine and level (table printed when the program ends)
+  subroutine ramses_amd_tic(t0)
+    integer(8), intent(out) :: t0
+    call system_clock(t0)
+  end subroutine ramses_amd_tic
+  subroutine ramses_amd_toc(name, level, t0)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: level
+    integer(8), intent(in) :: t0
+    integer(8) :: t1, rate
+    integer :: rc
+    call system_clock(t1, rate)
+    rc = ramses_amd_prof_add(trim(name)//c_null_char, level, dble(t1 - t0) / dble(rate))
+  end subroutine ramses_amd_toc
 
   ! AMR multigrid: driver and per-solve setup on the device (default) or the reference's (RAMSES_AMD_MG_DRIVER=host)
   logical function ramses_amd_mg_device_driver()

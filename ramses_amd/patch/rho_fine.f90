@@ -11,7 +11,7 @@
 #include "pm/rho_fine.f90"
 #undef rho_fine
 
-subroutine rho_fine(ilevel,icount)
+subroutine rho_fine_amd(ilevel,icount)
   use amr_commons
   use hydro_commons
   use poisson_commons
@@ -35,6 +35,7 @@ subroutine rho_fine(ilevel,icount)
   character(len=16)::val
   logical,save::first=.true.,rho_dev=.true.
   ramses_amd_pois_dev=.false.
+  ramses_amd_pois_amr_level=0
   if(poisson.and.hydro)then
      if(ramses_amd_resident())then
         if(first)then
@@ -64,4 +65,14 @@ subroutine rho_fine(ilevel,icount)
   end if
   call rho_fine_reference(ilevel,icount)
 111 format('   Entering rho_fine (MI355X) for level ',I2)
+end subroutine rho_fine_amd
+
+subroutine rho_fine(ilevel,icount)
+  use ramses_amd_iface
+  implicit none
+  integer::ilevel,icount
+  integer(8)::t0
+  call ramses_amd_tic(t0)
+  call rho_fine_amd(ilevel,icount)
+  call ramses_amd_toc('rho_fine',ilevel,t0)
 end subroutine rho_fine

@@ -10,7 +10,7 @@
 #include "hydro/synchro_hydro_fine.f90"
 #undef synchro_hydro_fine
 
-subroutine synchro_hydro_fine(ilevel,dteff,which_force)
+subroutine synchro_hydro_fine_amd(ilevel,dteff,which_force)
   use amr_commons
   use hydro_commons
   use poisson_commons
@@ -52,4 +52,16 @@ subroutine synchro_hydro_fine(ilevel,dteff,which_force)
 
 111 format('   Entering synchro_hydro_fine (MI355X) for level',i2)
 
+end subroutine synchro_hydro_fine_amd
+
+subroutine synchro_hydro_fine(ilevel,dteff,which_force)
+  use amr_parameters, only: dp
+  use ramses_amd_iface
+  implicit none
+  integer::ilevel,which_force
+  real(dp)::dteff
+  integer(8)::t0
+  call ramses_amd_tic(t0)
+  call synchro_hydro_fine_amd(ilevel,dteff,which_force)
+  call ramses_amd_toc('synchro_hydro_fine',ilevel,t0)
 end subroutine synchro_hydro_fine
