@@ -640,6 +640,16 @@ int ramses_amd_amrres_set_unew(int ngrid, const int *igrid);
 int ramses_amd_amrres_set_uold(const ramses_amd_hydro_params *p, int ngrid, const int *igrid);
 int ramses_amd_amrres_upload_fine(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, int interpol_var);
 int ramses_amd_amrres_courant(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double dx, double dt_in, double *out4);
+/* with self-gravity: the acceleration f(1:ncell,1:3) stays the host array's (force_fine writes it there); the device copy
+ * is refreshed per level (load_f: after force_fine(ilevel), after a regrid) and feeds synchro_hydro_fine
+ * (hydro/synchro_hydro_fine.f90:5-136), cmpdt's gravity term, the sweep's gravity predictor and add_gravity_source_terms
+ * (hydro/godunov_fine.f90:237-289, set_uold_grav).  sync_density: uold(:,1) of one level back to the host for rho_fine's
+ * multipole_fine (pm/rho_fine.f90:666-770), which reads nothing else of the hydro state. */
+int ramses_amd_amrres_load_f(int ngrid, const int *igrid, const double *f);
+int ramses_amd_amrres_has_gravity(void);
+int ramses_amd_amrres_sync_density(int ngrid, const int *igrid, double *uold);
+int ramses_amd_amrres_synchro(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double dteff);
+int ramses_amd_amrres_set_uold_grav(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double dt);
 int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double err_grad_d, double err_grad_p,
                                  double err_grad_u, double floor_d, double floor_p, double floor_u, int *ok);
 int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, double dx, double dt,

@@ -154,6 +154,11 @@ SYMBOLS = [
     ("ramses_amd_amrres_set_uold", _i, [_PP, _i, _vp]),
     ("ramses_amd_amrres_upload_fine", _i, [_PP, _i, _vp, _i]),
     ("ramses_amd_amrres_courant", _i, [_PP, _i, _vp, _d, _d, _vp]),
+    ("ramses_amd_amrres_load_f", _i, [_i, _vp, _vp]),
+    ("ramses_amd_amrres_has_gravity", _i, []),
+    ("ramses_amd_amrres_sync_density", _i, [_i, _vp, _vp]),
+    ("ramses_amd_amrres_synchro", _i, [_PP, _i, _vp, _d]),
+    ("ramses_amd_amrres_set_uold_grav", _i, [_PP, _i, _vp, _d]),
     ("ramses_amd_amrres_hydro_flag", _i, [_PP, _i, _vp, _d, _d, _d, _d, _d, _d, _vp]),
     ("ramses_amd_amrres_godunov", _i, [_PP, _i, _i, _vp, _d, _d, _i, _i, _i]),
 ]

@@ -109,8 +109,9 @@ __device__ __forceinline__ double wmin(double v) {
 }
 
 // courant_fine: cmpdt over the leaf cells of the level (dt exact: a minimum), mass / energy sums (diagnostics)
-__global__ __launch_bounds__(256) void lvl_courant_kernel(LvlArgs A, HydroConst P, double dx, double vol, double courant_factor,
-                                                          double dt_init, double *__restrict__ out) {
+template <bool GRAV>
+__global__ __launch_bounds__(256) void lvl_courant_kernel(LvlArgs A, const double *__restrict__ f, HydroConst P, double dx, double vol,
+                                                          double courant_factor, double dt_init, double *__restrict__ out) {
   double dtmin = dt_init, mass = 0.0, etot = 0.0, eint = 0.0;
   const long total = (long)A.ngrid * 8;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
@@ -120,7 +121,11 @@ __global__ __launch_bounds__(256) void lvl_courant_kernel(LvlArgs A, HydroConst 
     double u[5], g[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int v = 0; v < 5; v++) u[v] = A.uold[c + (long)v * A.ncell];
-    dtmin = __builtin_fmin(dtmin, cmpdt_cell<5, false>(u, g, dx, courant_factor, P, 3.0));
+    if (GRAV) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) g[k] = f[c + (long)k * A.ncell];
+    }
+    dtmin = __builtin_fmin(dtmin, cmpdt_cell<5, GRAV>(u, g, dx, courant_factor, P, 3.0));
     mass += u[0] * vol;
     etot += u[4] * vol;
     double ei = u[4] * vol;
@@ -227,6 +232,68 @@ __global__ __launch_bounds__(256) void lvl_pack_kernel(LvlArgs A, double *__rest
   }
 }
 
+
+// synchro_hydro_fine (hydro/synchro_hydro_fine.f90:5-136): momentum kick d*f*dteff with the kinetic energy taken out of
+// and put back into the total energy, on the level's cells
+__global__ __launch_bounds__(256) void lvl_synchro_kernel(LvlArgs A, const double *__restrict__ f, double dteff, double smallr) {
+  const long total = (long)A.ngrid * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ind = (int)(t / A.ngrid), i = (int)(t % A.ngrid);
+    const long c = A.ncoarse + (long)ind * A.ngridmax + A.igrid[i] - 1;
+    const double d = __builtin_fmax(A.uold[c], smallr);
+    double m[3] = {A.uold[c + A.ncell], A.uold[c + 2 * A.ncell], A.uold[c + 3 * A.ncell]};
+    double pp = A.uold[c + 4 * A.ncell];
+#pragma unroll
+    for (int k = 0; k < 3; k++) pp = pp - 0.5 * (m[k] * m[k]) / d;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      m[k] = m[k] + d * f[c + (long)k * A.ncell] * dteff;
+      A.uold[c + (long)(k + 1) * A.ncell] = m[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) pp = pp + 0.5 * (m[k] * m[k]) / d;
+    A.uold[c + 4 * A.ncell] = pp;
+  }
+}
+
+// add_gravity_source_terms (hydro/godunov_fine.f90:237-289) on unew of the level's cells (strict_equilibrium = 0)
+__global__ __launch_bounds__(256) void lvl_gravity_source_kernel(LvlArgs A, const double *__restrict__ f, double dt, double smallr) {
+  const long total = (long)A.ngrid * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ind = (int)(t / A.ngrid), i = (int)(t % A.ngrid);
+    const long c = A.ncoarse + (long)ind * A.ngridmax + A.igrid[i] - 1;
+    const long N = A.ncell;
+    const double d = __builtin_fmax(A.unew[c], smallr);
+    double u = A.unew[c + N] / d, v = A.unew[c + 2 * N] / d, w = A.unew[c + 3 * N] / d;
+    double e_kin = 0.5 * d * (u * u + v * v + w * w);
+    const double e_prim = A.unew[c + 4 * N] - e_kin;
+    const double d_old = __builtin_fmax(A.uold[c], smallr);
+    const double req = 0.0;
+    const double fact = (d_old - req) / d * 0.5 * dt;
+    u = u + f[c] * fact;
+    A.unew[c + N] = d * u;
+    v = v + f[c + N] * fact;
+    A.unew[c + 2 * N] = d * v;
+    w = w + f[c + 2 * N] * fact;
+    A.unew[c + 3 * N] = d * w;
+    e_kin = 0.5 * d * (u * u + v * v + w * w);
+    A.unew[c + 4 * N] = e_prim + e_kin;
+  }
+}
+
+// one variable (or ncomp of them, stride ncell) of the level's cells <-> packed [ncomp][8*ngrid]
+template <bool GATHER>
+__global__ void lvl_pack_comp_kernel(double *vec, double *buf, const int *igrid, int ngrid, int ncomp, long ncell, long ncoarse, long ngridmax) {
+  const long total = (long)ngrid * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long c = ncoarse + (long)(t / ngrid) * ngridmax + igrid[t % ngrid] - 1;
+    for (int k = 0; k < ncomp; k++) {
+      if (GATHER) buf[(long)k * total + t] = vec[c + (long)k * ncell];
+      else vec[c + (long)k * ncell] = buf[(long)k * total + t];
+    }
+  }
+}
+
 struct Buf {
   void *p = nullptr;
   size_t cap = 0;
@@ -247,6 +314,8 @@ struct AmrRes {
   long ncell = 0, ncoarse = 0, ngridmax = 0;
   const double *h_uold = nullptr;
   Buf uold, unew, son, nbor, father, igrid, work, err, red, okbuf, pack;
+  Buf f;                 // f(1:ncell,1:3), a copy of the host array refreshed after force_fine and after regrids
+  bool grav = false;
   std::vector<double> hpack;
 };
 AmrRes g_ar;
@@ -308,7 +377,7 @@ int ramses_amd_amrres_load(int nvar, int64_t ngridmax, int64_t ncoarse, const do
   if (!uold || !son || !nbor || !father) return failf(RAMSES_AMD_EINVAL, "NULL argument");
   if (nvar < 5 || nvar > 7 || ngridmax < 1 || ncoarse < 1) return failf(RAMSES_AMD_EUNSUPPORTED, "AMR residency implements NVAR=5..7");
   AmrRes &R = g_ar;
-  R.valid = false;
+  R.valid = false; R.grav = false;
   R.nvar = nvar; R.ngridmax = ngridmax; R.ncoarse = ncoarse; R.ncell = ncoarse + 8 * ngridmax;
   R.h_uold = uold;
   const size_t vb = sizeof(double) * (size_t)nvar * (size_t)R.ncell;
@@ -426,7 +495,8 @@ int ramses_amd_amrres_courant(const ramses_amd_hydro_params *p, int ngrid, const
   if (ngrid > 0) {
     int g = grid_for((long)ngrid * 8);
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(lvl_courant_kernel, dim3(g), dim3(256), 0, nullptr, A, make_const_amr(p), dx, dx * dx * dx, p->courant_factor, dt0, R.red.as<double>());
+    if (R.grav) hipLaunchKernelGGL(lvl_courant_kernel<true>, dim3(g), dim3(256), 0, nullptr, A, R.f.as<double>(), make_const_amr(p), dx, dx * dx * dx, p->courant_factor, dt0, R.red.as<double>());
+    else hipLaunchKernelGGL(lvl_courant_kernel<false>, dim3(g), dim3(256), 0, nullptr, A, (const double *)nullptr, make_const_amr(p), dx, dx * dx * dx, p->courant_factor, dt0, R.red.as<double>());
   }
   HCHK(hipGetLastError(), "courant launch");
   HCHK(hipMemcpy(out4, R.red.p, sizeof(double) * 4, hipMemcpyDeviceToHost), "D2H courant");
@@ -464,11 +534,91 @@ int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int 
   HCHK(R.work.ensure((size_t)nw), "hipMalloc work");
   HCHK(hipMemsetAsync(R.err.p, 0, sizeof(int), nullptr), "memset");
   if (int rc = ramses_amd_godunov_fine_amr_device(p, ilevel, ngrid, R.igrid.as<int>(), R.son.as<int>(), R.nbor.as<int>(), R.father.as<int>(),
-                                                  R.ngridmax, R.ncoarse, R.uold.as<double>(), R.unew.as<double>(), nullptr, nullptr, nullptr,
+                                                  R.ngridmax, R.ncoarse, R.uold.as<double>(), R.unew.as<double>(), R.grav ? R.f.as<double>() : nullptr, nullptr, nullptr,
                                                   dx, dt, nvector, interpol_var, interpol_type, R.work.p, R.err.as<int>(), nullptr)) return rc;
   int bad = 0;
   HCHK(hipMemcpy(&bad, R.err.p, sizeof(int), hipMemcpyDeviceToHost), "D2H flag");
   if (bad) return failf(RAMSES_AMD_EINVAL, "level %d: %d father cells needed by an oct do not exist (tree inconsistent)", ilevel, bad);
+  return 0;
+}
+
+
+// ---- self-gravity: the acceleration f(1:ncell,1:3) is computed by force_fine into the host array (and stays authoritative
+// there); the device keeps a copy for synchro_hydro_fine, the gravity terms of courant_fine / godunov_fine / set_uold
+
+// f of one level's cells from the host array (after force_fine(ilevel), after a regrid)
+int ramses_amd_amrres_load_f(int ngrid, const int *igrid, const double *f) {
+  AmrRes &R = g_ar;
+  LvlArgs A;
+  if (!f) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  if (int rc = set_level(R, ngrid, igrid, A)) return rc;
+  if (!R.grav) {
+    HCHK(R.f.ensure(sizeof(double) * 3 * (size_t)R.ncell), "hipMalloc f");
+    HCHK(hipMemsetAsync(R.f.p, 0, sizeof(double) * 3 * (size_t)R.ncell, nullptr), "memset f");
+    R.grav = true;
+  }
+  if (ngrid == 0) return 0;
+  const long tot = (long)ngrid * 8;
+  R.hpack.resize((size_t)tot * 3);
+  for (int k = 0; k < 3; k++)
+    for (int ind = 0; ind < 8; ind++) {
+      const double *src = f + (size_t)k * R.ncell + R.ncoarse + (size_t)ind * R.ngridmax - 1;
+      double *dst = R.hpack.data() + (size_t)k * tot + (size_t)ind * ngrid;
+      for (int i = 0; i < ngrid; i++) dst[i] = src[igrid[i]];
+    }
+  HCHK(R.pack.ensure(sizeof(double) * (size_t)tot * 3), "hipMalloc");
+  HCHK(hipMemcpy(R.pack.p, R.hpack.data(), sizeof(double) * (size_t)tot * 3, hipMemcpyHostToDevice), "H2D f");
+  hipLaunchKernelGGL(lvl_pack_comp_kernel<false>, dim3(grid_for(tot)), dim3(256), 0, nullptr, R.f.as<double>(), R.pack.as<double>(), R.igrid.as<int>(), ngrid, 3,
+                     R.ncell, R.ncoarse, R.ngridmax);
+  HCHK(hipGetLastError(), "f unpack launch");
+  HCHK(hipStreamSynchronize(nullptr), "sync");
+  return 0;
+}
+int ramses_amd_amrres_has_gravity(void) { return g_ar.valid && g_ar.grav ? 1 : 0; }
+
+// the density uold(:,1) of one level's cells back into the host array (rho_fine's multipole_fine reads nothing else)
+int ramses_amd_amrres_sync_density(int ngrid, const int *igrid, double *uold) {
+  AmrRes &R = g_ar;
+  LvlArgs A;
+  if (int rc = set_level(R, ngrid, igrid, A)) return rc;
+  if (uold != R.h_uold) return failf(RAMSES_AMD_EINVAL, "sync_density: not the array the state was loaded from");
+  if (ngrid == 0) return 0;
+  const long tot = (long)ngrid * 8;
+  HCHK(R.pack.ensure(sizeof(double) * (size_t)tot), "hipMalloc");
+  hipLaunchKernelGGL(lvl_pack_comp_kernel<true>, dim3(grid_for(tot)), dim3(256), 0, nullptr, R.uold.as<double>(), R.pack.as<double>(), R.igrid.as<int>(), ngrid, 1,
+                     R.ncell, R.ncoarse, R.ngridmax);
+  HCHK(hipGetLastError(), "density pack launch");
+  R.hpack.resize((size_t)tot);
+  HCHK(hipMemcpy(R.hpack.data(), R.pack.p, sizeof(double) * (size_t)tot, hipMemcpyDeviceToHost), "D2H density");
+  for (int ind = 0; ind < 8; ind++) {
+    double *dst = uold + R.ncoarse + (size_t)ind * R.ngridmax - 1;
+    const double *src = R.hpack.data() + (size_t)ind * ngrid;
+    for (int i = 0; i < ngrid; i++) dst[igrid[i]] = src[i];
+  }
+  return 0;
+}
+
+int ramses_amd_amrres_synchro(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double dteff) {
+  if (!p) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  LvlArgs A;
+  if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
+  if (!g_ar.grav) return failf(RAMSES_AMD_EINVAL, "synchro_hydro_fine: no acceleration on the device (ramses_amd_amrres_load_f)");
+  if (ngrid == 0) return 0;
+  hipLaunchKernelGGL(lvl_synchro_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, A, g_ar.f.as<double>(), dteff, p->smallr);
+  HCHK(hipGetLastError(), "synchro launch");
+  return 0;
+}
+
+// set_uold with poisson: add_gravity_source_terms on unew, then the scalar fix and uold = unew
+int ramses_amd_amrres_set_uold_grav(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double dt) {
+  if (!p) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  LvlArgs A;
+  if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
+  if (!g_ar.grav) return failf(RAMSES_AMD_EINVAL, "set_uold: no acceleration on the device (ramses_amd_amrres_load_f)");
+  if (ngrid == 0) return 0;
+  hipLaunchKernelGGL(lvl_gravity_source_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, A, g_ar.f.as<double>(), dt, p->smallr);
+  hipLaunchKernelGGL(lvl_set_uold_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, A, p->smallr);
+  HCHK(hipGetLastError(), "set_uold launch");
   return 0;
 }
 

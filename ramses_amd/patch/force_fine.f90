@@ -102,11 +102,16 @@ subroutine force_fine_amd(ilevel,icount)
 end subroutine force_fine_amd
 
 subroutine force_fine(ilevel,icount)
+  use amr_commons, only: numbtot
   use ramses_amd_iface
   implicit none
   integer::ilevel,icount
   integer(8)::t0
   call ramses_amd_tic(t0)
   call force_fine_amd(ilevel,icount)
+  ! AMR run with the hydro state on the device: its copy of the acceleration follows
+  if(ramses_amd_amr_resident())then
+     if(ramses_amd_amrres_active()/=0.and.numbtot(1,ilevel)>0)call ramses_amd_amr_load_f(ilevel)
+  end if
   call ramses_amd_toc('force_fine',ilevel,t0)
 end subroutine force_fine

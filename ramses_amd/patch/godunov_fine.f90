@@ -70,7 +70,11 @@ subroutine set_uold(ilevel)
   if(ramses_amd_amr_resident())then
      call ramses_amd_amr_ensure()
      call ramses_amd_fill_hydro_params(p)
-     rc=ramses_amd_amrres_set_uold(p,active(ilevel)%ngrid,active(ilevel)%igrid)
+     if(poisson)then
+        rc=ramses_amd_amrres_set_uold_grav(p,active(ilevel)%ngrid,active(ilevel)%igrid,dtnew(ilevel))
+     else
+        rc=ramses_amd_amrres_set_uold(p,active(ilevel)%ngrid,active(ilevel)%igrid)
+     end if
      if(rc/=0)call ramses_amd_fatal('set_uold')
      return
   end if

@@ -496,6 +496,36 @@ module ramses_amd_iface
        integer(c_int) :: igrid(*)
        integer(c_int) :: rc
      end function ramses_amd_amrres_upload_fine
+     function ramses_amd_amrres_load_f(ngrid, igrid, f) bind(C, name='ramses_amd_amrres_load_f') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: f(*)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_load_f
+     function ramses_amd_amrres_sync_density(ngrid, igrid, uold) bind(C, name='ramses_amd_amrres_sync_density') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: uold(*)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_sync_density
+     function ramses_amd_amrres_synchro(p, ngrid, igrid, dteff) bind(C, name='ramses_amd_amrres_synchro') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double), value :: dteff
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_synchro
+     function ramses_amd_amrres_set_uold_grav(p, ngrid, igrid, dt) bind(C, name='ramses_amd_amrres_set_uold_grav') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double), value :: dt
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_set_uold_grav
      function ramses_amd_amrres_courant(p, ngrid, igrid, dx, dt_in, out4) bind(C, name='ramses_amd_amrres_courant') result(rc)
        import :: ramses_amd_hydro_params, c_int, c_double
        type(ramses_amd_hydro_params), intent(in) :: p
@@ -1009,6 +1039,7 @@ contains
   logical function ramses_amd_amr_config()
     use amr_commons
     use hydro_parameters
+    use poisson_parameters, only: gravity_type
 #if USE_TURB==1
     use turb_commons, only: turb
 #endif
@@ -1022,7 +1053,19 @@ contains
           if (trim(val) == '0') ramses_amd_amr_ok = .false.
        end if
        if (ncpu > 1 .or. levelmin >= nlevelmax .or. nboundary > 0 .or. nremap > 0) ramses_amd_amr_ok = .false.
-       if (.not. hydro .or. poisson .or. pic .or. rt .or. cooling .or. star .or. sink .or. stellar) ramses_amd_amr_ok = .false.
+       if (.not. hydro .or. pic .or. rt .or. cooling .or. star .or. sink .or. stellar) ramses_amd_amr_ok = .false.
+       ! with self-gravity too (the acceleration is mirrored on the device, rho_fine gets the density back);
+       ! RAMSES_AMD_RESIDENT_GRAV=0 keeps such runs on the staging path
+       if (poisson) then
+          call get_environment_variable('RAMSES_AMD_RESIDENT_GRAV', val, status=stat)
+          if (stat == 0) then
+             if (trim(val) == '0') ramses_amd_amr_ok = .false.
+          end if
+          if (gravity_type > 0 .or. cosmo) ramses_amd_amr_ok = .false.
+          do l = 1, nlevelmax
+             if (m_refine(l) > -1.0d0) ramses_amd_amr_ok = .false.    ! rho_fine's quasi-Lagrangian map reads uold on the host
+          end do
+       end if
        if (tracer .or. MC_tracer .or. clumpfind .or. lightcone .or. movie .or. aton) ramses_amd_amr_ok = .false.
        if (static .or. static_gas .or. neq_chem .or. barotropic_eos .or. isothermal .or. metal) ramses_amd_amr_ok = .false.
        if (pressure_fix .or. T2_star > 0.0d0 .or. momentum_feedback > 0 .or. strict_equilibrium > 0) ramses_amd_amr_ok = .false.
@@ -1053,10 +1096,16 @@ contains
   subroutine ramses_amd_amr_ensure()
     use amr_commons
     use hydro_commons
+    use poisson_commons, only: f
     integer :: rc, l
     if (ramses_amd_amrres_active() == 0) then
        rc = ramses_amd_amrres_load(nvar, int(ngridmax, 8), int(ncoarse, 8), uold, son, nbor, father)
        if (rc /= 0) call ramses_amd_fatal('AMR residency (load)')
+       if (poisson) then
+          do l = levelmin, nlevelmax
+             if (numbtot(1, l) > 0) call ramses_amd_amr_load_f(l)
+          end do
+       end if
        ramses_amd_amr_reload_from = 1000
        ramses_amd_amr_host_from = 1000
        return
@@ -1069,11 +1118,22 @@ contains
           if (numbtot(1, l) > 0) then
              rc = ramses_amd_amrres_load_level(active(l)%ngrid, active(l)%igrid, uold)
              if (rc /= 0) call ramses_amd_fatal('AMR residency (level reload)')
+             if (poisson) call ramses_amd_amr_load_f(l)
           end if
        end do
        ramses_amd_amr_reload_from = 1000
     end if
   end subroutine ramses_amd_amr_ensure
+
+  ! the acceleration of one level from the host array f (force_fine has just written it, or the level was rebuilt)
+  subroutine ramses_amd_amr_load_f(ilevel)
+    use amr_commons
+    use poisson_commons
+    integer, intent(in) :: ilevel
+    integer :: rc
+    rc = ramses_amd_amrres_load_f(active(ilevel)%ngrid, active(ilevel)%igrid, f)
+    if (rc /= 0) call ramses_amd_fatal('AMR residency (acceleration)')
+  end subroutine ramses_amd_amr_load_f
 
   !---------------------------------------------------------------------------
   ! refine_fine(ilevel) is about to read uold of levels ilevel-1 .. (interpol_hydro of new octs,

@@ -68,11 +68,25 @@ subroutine rho_fine_amd(ilevel,icount)
 end subroutine rho_fine_amd
 
 subroutine rho_fine(ilevel,icount)
+  use amr_commons
+  use hydro_commons, only: uold
   use ramses_amd_iface
   implicit none
-  integer::ilevel,icount
+  integer::ilevel,icount,l,rc
   integer(8)::t0
   call ramses_amd_tic(t0)
+  ! AMR run with the hydro state on the device: multipole_fine (pm/rho_fine.f90:666-770) reads the density of the
+  ! levels it visits (:45-47) from the host array -- bring it back (nothing else of uold is read)
+  if(ramses_amd_amr_resident())then
+     if(ramses_amd_amrres_active()/=0.and.(ilevel==levelmin.or.icount>1))then
+        do l=nlevelmax,ilevel,-1
+           if(numbtot(1,l)>0.and.l<ramses_amd_amr_host_from)then
+              rc=ramses_amd_amrres_sync_density(active(l)%ngrid,active(l)%igrid,uold)
+              if(rc/=0)call ramses_amd_fatal('rho_fine (density back to the host)')
+           end if
+        end do
+     end if
+  end if
   call rho_fine_amd(ilevel,icount)
   call ramses_amd_toc('rho_fine',ilevel,t0)
 end subroutine rho_fine

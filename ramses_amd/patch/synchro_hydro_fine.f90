@@ -38,6 +38,14 @@ subroutine synchro_hydro_fine_amd(ilevel,dteff,which_force)
   if(.not.poisson)return
   if(numbtot(1,ilevel)==0)return
 #endif
+  if(which_force==1.and.poisson.and.ramses_amd_amr_resident())then
+     ! AMR run with the state on the device: the kick on the resident arrays (the acceleration was mirrored by force_fine)
+     call ramses_amd_amr_ensure()
+     call ramses_amd_fill_hydro_params(p)
+     rc=ramses_amd_amrres_synchro(p,active(ilevel)%ngrid,active(ilevel)%igrid,dteff)
+     if(rc/=0)call ramses_amd_fatal('synchro_hydro_fine')
+     return
+  end if
   if(which_force/=1.or..not.poisson.or..not.ramses_amd_resident())then
      call synchro_hydro_fine_reference(ilevel,dteff,which_force)
      return

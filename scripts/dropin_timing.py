@@ -47,12 +47,10 @@ def run(tag, binary, level, nstep, env):
 def run_amr(tag, binary, env, lmin, lmax, nstep):
     """AMR + self-gravity (the blob + blast setup of tests/golden/make_golden_amr.py at higher levels)"""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("mka", os.path.join(ROOT, "tests", "golden", "make_golden_amr.py"))
-    mka = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mka)
-    nml = mka.selfgrav_namelist().replace("levelmin=3", "levelmin=%d" % lmin).replace("levelmax=5", "levelmax=%d" % lmax)
-    nml = nml.replace("nstepmax=%d" % mka.SELFGRAV_NSTEP, "nstepmax=%d" % nstep).replace("ngridtot=6000 !", "ngridtot=600000 !")
-    nml = nml.replace("foutput=%d" % mka.SELFGRAV_NSTEP, "foutput=1000")
+    spec = importlib.util.spec_from_file_location("mkb", os.path.join(ROOT, "tests", "golden", "make_golden_baseline.py"))
+    mkb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mkb)
+    nml = mkb.amr_grav_namelist(lmin, lmax, nstep, foutput=1000)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     t0 = time.time()
@@ -226,7 +224,12 @@ if __name__ == "__main__":
         ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d")
         pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch")
         if which in ("all", "gpu"):
-            run_amr("patched (AMR sweep + AMR multigrid on the device, arrays staged per call)", pat, {"RAMSES_AMD": "1"}, lmin, lmax, nstep)
+            run_amr("patched: hydro state, tree and acceleration resident; multigrid driver + setup and force_fine of the AMR levels on the device",
+                    pat, {"RAMSES_AMD": "1"}, lmin, lmax, nstep)
+            run_amr("patched, hydro arrays staged per call (RAMSES_AMD_RESIDENT_GRAV=0), device multigrid driver", pat,
+                    {"RAMSES_AMD": "1", "RAMSES_AMD_RESIDENT_GRAV": "0"}, lmin, lmax, nstep)
+            run_amr("patched, staged + the reference's multigrid driver / setup / force_fine with device operators (round 1 path)", pat,
+                    {"RAMSES_AMD": "1", "RAMSES_AMD_RESIDENT_GRAV": "0", "RAMSES_AMD_MG_DRIVER": "host"}, lmin, lmax, nstep)
         if which in ("all", "ref"):
             run_amr("reference (1 core)", ref, {"RAMSES_AMD": "0"}, lmin, lmax, nstep)
         sys.exit(0)

@@ -15,7 +15,9 @@ CPU) and the GPU tests compare the patched program with them; the uniform hydro-
 configurations C2 (128^3, 256^3) are cheap with the MPI reference and are A/B-ed live on
 the GPU box instead (tests/test_baseline_sizes_gpu.py).
 
-Run:  python tests/golden/make_golden_baseline.py [c4_128] [c5_79]
+  amr_grav_68  AMR levels 6-8 with self-gravity (blob + blast), 3 coarse steps: sha256 of the sorted leaf data
+           (level, x, prim, phi, f), cells per level, V-cycle counts
+Run:  python tests/golden/make_golden_baseline.py [c4_128] [c5_79] [amr_grav_68]
 Writes tests/golden/baseline_sizes.json (merged with what is there).
 """
 import hashlib
@@ -67,6 +69,31 @@ def c5_namelist(lmin=7, lmax=9, nstep=8, ngridtot=900000):
     return nml.replace("levelmax=%d" % lmin, "levelmax=%d" % lmax).replace("ngridtot=", "ngridtot=%d !" % ngridtot)
 
 
+def amr_grav_namelist(lmin=6, lmax=8, nstep=3, foutput=None):
+    """AMR + self-gravity: the blob + blast setup of tests/golden/make_golden_amr.py (levels 3-5) moved to
+    levels lmin..lmax -- every level takes multigrid_fine, force_fine, rho_fine, synchro_hydro_fine and the
+    gravity terms of courant_fine / godunov_fine / set_uold, with regridding every coarse step"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mka", os.path.join(os.path.dirname(os.path.abspath(__file__)), "make_golden_amr.py"))
+    mka = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mka)
+    nml = mka.selfgrav_namelist().replace("levelmin=3", "levelmin=%d" % lmin).replace("levelmax=5", "levelmax=%d" % lmax)
+    nml = nml.replace("nstepmax=%d" % mka.SELFGRAV_NSTEP, "nstepmax=%d" % nstep).replace("ngridtot=6000 !", "ngridtot=600000 !")
+    return nml.replace("foutput=%d" % mka.SELFGRAV_NSTEP, "foutput=%d" % (nstep if foutput is None else foutput))
+
+
+def digest_leaves_grav(snap):
+    order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(snap["level"][order].astype(np.int8)).tobytes())
+    h.update(np.ascontiguousarray(snap["x"][order]).tobytes())
+    h.update(np.ascontiguousarray(snap["prim"][:, order]).tobytes())
+    g = snap["grav"]
+    g = g[1:] if g.shape[0] == 5 else g
+    h.update(np.ascontiguousarray(g[:, order]).tobytes())
+    return h.hexdigest()
+
+
 def digest_uniform(snap):
     h = hashlib.sha256()
     h.update(np.ascontiguousarray(snap["prim"]).tobytes())
@@ -91,7 +118,7 @@ def solves(log):
 
 
 def main():
-    todo = sys.argv[1:] or ["c4_128", "c5_79"]
+    todo = sys.argv[1:] or ["c4_128", "c5_79", "amr_grav_68"]
     out = json.load(open(PATH)) if os.path.exists(PATH) else {}
     if "c4_128" in todo:
         work, log = rs.run_reference(c4_namelist())
@@ -109,6 +136,15 @@ def main():
             out["c5_79"] = dict(sha256=digest_leaves(snap), ncell=[int((snap["level"] == l).sum()) for l in (7, 8, 9)],
                                 t=snap["info"]["t"])
             print("c5_79", out["c5_79"])
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    if "amr_grav_68" in todo:
+        work, log = rs.run_reference(amr_grav_namelist())
+        try:
+            snap = rs.load_leaf_cells(os.path.join(work, "output_00002"), with_grav=True)
+            out["amr_grav_68"] = dict(sha256=digest_leaves_grav(snap), ncell=[int((snap["level"] == l).sum()) for l in (6, 7, 8)],
+                                      solves=solves(log), t=snap["info"]["t"])
+            print("amr_grav_68", out["amr_grav_68"])
         finally:
             shutil.rmtree(work, ignore_errors=True)
     with open(PATH, "w") as fh:

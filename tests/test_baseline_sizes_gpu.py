@@ -9,9 +9,10 @@
    reference, MPI on the host cores) vs oracle/_ref/ramses3d_patch (the same program with
    ramses_amd/patch, level resident on the GPU) on sedov3d.nml as shipped (nstepmax=10) at
    128^3 and 256^3 (config C2): the assembled level must be equal bit for bit.
-3. Config C4 stand-in at 128^3 (hydro + self-gravity, three coarse steps) and config C5 at
-   levels 7-9 through the patched program against checksums of the serial reference
-   (tests/golden/baseline_sizes.json, made by tests/golden/make_golden_baseline.py).
+3. Config C4 stand-in at 128^3 (hydro + self-gravity, three coarse steps), config C5 at
+   levels 7-9 and an AMR + self-gravity run at levels 6-8 through the patched program against
+   checksums of the serial reference (tests/golden/baseline_sizes.json, made by
+   tests/golden/make_golden_baseline.py).
 """
 import importlib.util
 import json
@@ -153,5 +154,42 @@ def test_c5_levels_7_9_checksum(gpu_lib, resident):
         assert [int((snap["level"] == l).sum()) for l in (7, 8, 9)] == gold["ncell"]
         assert snap["info"]["t"] == gold["t"]
         assert mkb.digest_leaves(snap) == gold["sha256"]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+@pytest.mark.parametrize("mode", ["resident", "staged", "host-driver"])
+def test_amr_self_gravity_levels_6_8_checksum(gpu_lib, mode):
+    """AMR + self-gravity at levels 6-8 (0.53 M leaf cells, 3 coarse steps with regridding) through the patched
+    program == the serial reference by checksum of the sorted leaf data (level, x, prim, phi, f) and V-cycle counts.
+    resident (default): uold/unew, the tree and a copy of f stay on the device; multigrid_fine (driver and per-solve
+    setup) and force_fine of the partially refined levels are device code, rho_fine gets the density back.
+    staged (RAMSES_AMD_RESIDENT_GRAV=0): same solvers, the hydro arrays cross PCIe around every call.
+    host-driver (+ RAMSES_AMD_MG_DRIVER=host): the reference's multigrid driver and force_fine with the device operators."""
+    if not os.path.exists(PATCHED) or not os.path.exists(GOLD):
+        pytest.skip("patched program or golden checksums missing")
+    gold = json.load(open(GOLD)).get("amr_grav_68")
+    if gold is None:
+        pytest.skip("no amr_grav_68 checksum")
+    from oracle import ramses_snapshot as rs
+    mkb = _mkb()
+    env = {"RAMSES_AMD": "1"}
+    if mode != "resident":
+        env["RAMSES_AMD_RESIDENT_GRAV"] = "0"
+    if mode == "host-driver":
+        env["RAMSES_AMD_MG_DRIVER"] = "host"
+    os.environ.update(env)
+    try:
+        work, out = rs.run_reference(mkb.amr_grav_namelist(), binary=PATCHED)
+    finally:
+        for k in ("RAMSES_AMD_RESIDENT_GRAV", "RAMSES_AMD_MG_DRIVER"):
+            os.environ.pop(k, None)
+    try:
+        assert ("AMR levels stay resident on the GPU" in out) == (mode == "resident")
+        assert mkb.solves(out) == gold["solves"]
+        snap = rs.load_leaf_cells(os.path.join(work, "output_00002"), with_grav=True)
+        assert [int((snap["level"] == l).sum()) for l in (6, 7, 8)] == gold["ncell"]
+        assert snap["info"]["t"] == gold["t"]
+        assert mkb.digest_leaves_grav(snap) == gold["sha256"]
     finally:
         shutil.rmtree(work, ignore_errors=True)
