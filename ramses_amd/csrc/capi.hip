@@ -387,7 +387,19 @@ static size_t mg_hier_size(int level) {
   for (int m = 1; m < level; m++) off += 4 * mg_level_cells(m);
   return off;
 }
-static const int MG_FUSED_MIN_N = 64;           // levels with n >= 64 use the fused time-skewed smoother
+// levels with n >= MG_FUSED_MIN_N use the fused time-skewed smoother: a launch of it costs ~120 us whatever the level
+// (its planes are marched one barrier at a time), which only pays from 256^3 up; below, the per-colour kernels on
+// cache-resident levels are faster (profiles/r02_vcycle_levels.txt).  RAMSES_AMD_MG_FUSED_MIN=<n> overrides (A/B, >= 64).
+static int mg_fused_min_n() {
+  static int v = -1;
+  if (v < 0) {
+    v = 256;
+    const char *e = getenv("RAMSES_AMD_MG_FUSED_MIN");
+    if (e && atoi(e) >= 64) v = atoi(e);
+  }
+  return v;
+}
+#define MG_FUSED_MIN_N mg_fused_min_n()
 
 int64_t ramses_amd_mg_workspace_doubles(int level) {
   if (level < 1 || level > 11) return fail(RAMSES_AMD_EINVAL, "multigrid level must be in [1,11] (got %d)", level);
