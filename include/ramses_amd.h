@@ -650,6 +650,13 @@ int ramses_amd_amrres_has_gravity(void);
 int ramses_amd_amrres_sync_density(int ngrid, const int *igrid, double *uold);
 int ramses_amd_amrres_synchro(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double dteff);
 int ramses_amd_amrres_set_uold_grav(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double dt);
+/* pressure_fix (hydro/godunov_fine.f90:66-83 set_unew's divu = 0 / enew = e_int, :294-481 add_pdv_source_terms, :203-227 the
+ * energy switch of set_uold): divu and enew are device vectors (scratch of one hydro step; the sweep adds its divergence
+ * and internal-energy fluxes to them, level and coarser level); dx_loc = 0.5**ilevel * boxlen/nx_loc */
+int ramses_amd_amrres_enable_pfix(void);
+int ramses_amd_amrres_set_unew_pfix(const ramses_amd_hydro_params *p, int ngrid, const int *igrid);
+int ramses_amd_amrres_set_uold_pfix(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double dt, double dx_loc,
+                                    double beta_fix, double hexp);
 int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double err_grad_d, double err_grad_p,
                                  double err_grad_u, double floor_d, double floor_p, double floor_u, int *ok);
 int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, double dx, double dt,

@@ -159,6 +159,9 @@ SYMBOLS = [
     ("ramses_amd_amrres_sync_density", _i, [_i, _vp, _vp]),
     ("ramses_amd_amrres_synchro", _i, [_PP, _i, _vp, _d]),
     ("ramses_amd_amrres_set_uold_grav", _i, [_PP, _i, _vp, _d]),
+    ("ramses_amd_amrres_enable_pfix", _i, []),
+    ("ramses_amd_amrres_set_unew_pfix", _i, [_PP, _i, _vp]),
+    ("ramses_amd_amrres_set_uold_pfix", _i, [_PP, _i, _vp, _d, _d, _d, _d]),
     ("ramses_amd_amrres_hydro_flag", _i, [_PP, _i, _vp, _d, _d, _d, _d, _d, _d, _vp]),
     ("ramses_amd_amrres_godunov", _i, [_PP, _i, _i, _vp, _d, _d, _i, _i, _i]),
 ]

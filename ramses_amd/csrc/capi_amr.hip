@@ -294,6 +294,74 @@ __global__ void lvl_pack_comp_kernel(double *vec, double *buf, const int *igrid,
   }
 }
 
+// ---- pressure_fix (hydro/godunov_fine.f90:66-83, 203-227, 294-481) -------------------------------------------------------
+// set_unew: divu = 0, enew = internal energy of uold
+__global__ __launch_bounds__(256) void lvl_pfix_init_kernel(LvlArgs A, double *__restrict__ divu, double *__restrict__ enew, double smallr) {
+  const long total = (long)A.ngrid * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long c = A.ncoarse + (long)(t / A.ngrid) * A.ngridmax + A.igrid[t % A.ngrid] - 1;
+    const long N = A.ncell;
+    const double d = __builtin_fmax(A.uold[c], smallr);
+    const double u = A.uold[c + N] / d, v = A.uold[c + 2 * N] / d, w = A.uold[c + 3 * N] / d;
+    divu[c] = 0.0;
+    enew[c] = A.uold[c + 4 * N] - 0.5 * d * (u * u + v * v + w * w);
+  }
+}
+// add_pdv_source_terms: enew -= (gamma-1) e_old div(u) dt, div(u) from the normal velocities of the two neighbours per
+// direction (a neighbour oct that does not exist: the father's neighbour cell at 1.5 dx)
+__global__ __launch_bounds__(256) void lvl_pdv_kernel(LvlArgs A, double *__restrict__ enew, double dx_loc, double dt, double gamma, double smallr) {
+  const long total = (long)A.ngrid * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ind = (int)(t / A.ngrid), i = (int)(t % A.ngrid);
+    const int g = A.igrid[i];
+    const long N = A.ncell;
+    const long c = A.ncoarse + (long)ind * A.ngridmax + g - 1;
+    double divu_loc = 0.0;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const int bit = (ind >> d) & 1, jnd = ind ^ (1 << d);
+      double vel[2], dxs[2];
+#pragma unroll
+      for (int side = 0; side < 2; side++) {
+        long cn;
+        dxs[side] = dx_loc;
+        if (bit != side) {
+          cn = A.ncoarse + (long)jnd * A.ngridmax + g - 1;             // inside the oct
+        } else {
+          const int nb = A.nbor[(long)(2 * d + side) * A.ngridmax + g - 1];
+          const int g2 = A.son[nb - 1];
+          if (g2 > 0) cn = A.ncoarse + (long)jnd * A.ngridmax + g2 - 1;
+          else { cn = nb - 1; dxs[side] = dx_loc * 1.5; }
+        }
+        vel[side] = A.uold[cn + (long)(d + 1) * N] / __builtin_fmax(A.uold[cn], smallr);
+      }
+      divu_loc = divu_loc + (vel[1] - vel[0]) / (dxs[0] + dxs[1]);
+    }
+    const double dd = __builtin_fmax(A.uold[c], smallr);
+    const double u = A.uold[c + N] / dd, v = A.uold[c + 2 * N] / dd, w = A.uold[c + 3 * N] / dd;
+    const double eold = A.uold[c + 4 * N] - 0.5 * dd * (u * u + v * v + w * w);
+    enew[c] = enew[c] - (gamma - 1.0) * eold * divu_loc * dt;
+  }
+}
+// set_uold's energy switch, after uold = unew
+__global__ __launch_bounds__(256) void lvl_pfix_switch_kernel(LvlArgs A, const double *__restrict__ divu, const double *__restrict__ enew, double dx_loc,
+                                                              double dt, double beta_fix, double hexp, double smallr) {
+  const long total = (long)A.ngrid * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long c = A.ncoarse + (long)(t / A.ngrid) * A.ngridmax + A.igrid[t % A.ngrid] - 1;
+    const long N = A.ncell;
+    const double d = __builtin_fmax(A.uold[c], smallr);
+    const double u = A.uold[c + N] / d, v = A.uold[c + 2 * N] / d, w = A.uold[c + 3 * N] / d;
+    const double e_kin = 0.5 * d * (u * u + v * v + w * w);
+    const double e_cons = A.uold[c + 4 * N] - e_kin;
+    const double e_prim = enew[c];
+    const double div = __builtin_fabs(divu[c]) * dx_loc / dt;
+    const double m = __builtin_fmax(div, 3.0 * hexp * dx_loc);
+    const double e_trunc = beta_fix * d * (m * m);
+    if (e_cons < e_trunc) A.uold[c + 4 * N] = e_prim + e_kin;
+  }
+}
+
 struct Buf {
   void *p = nullptr;
   size_t cap = 0;
@@ -316,6 +384,8 @@ struct AmrRes {
   Buf uold, unew, son, nbor, father, igrid, work, err, red, okbuf, pack;
   Buf f;                 // f(1:ncell,1:3), a copy of the host array refreshed after force_fine and after regrids
   bool grav = false;
+  Buf divu, enew;        // pressure_fix: the reference's divu / enew work vectors (device only: scratch of one step)
+  bool pfix = false;
   std::vector<double> hpack;
 };
 AmrRes g_ar;
@@ -377,7 +447,7 @@ int ramses_amd_amrres_load(int nvar, int64_t ngridmax, int64_t ncoarse, const do
   if (!uold || !son || !nbor || !father) return failf(RAMSES_AMD_EINVAL, "NULL argument");
   if (nvar < 5 || nvar > 7 || ngridmax < 1 || ncoarse < 1) return failf(RAMSES_AMD_EUNSUPPORTED, "AMR residency implements NVAR=5..7");
   AmrRes &R = g_ar;
-  R.valid = false; R.grav = false;
+  R.valid = false; R.grav = false; R.pfix = false;
   R.nvar = nvar; R.ngridmax = ngridmax; R.ncoarse = ncoarse; R.ncell = ncoarse + 8 * ngridmax;
   R.h_uold = uold;
   const size_t vb = sizeof(double) * (size_t)nvar * (size_t)R.ncell;
@@ -534,7 +604,7 @@ int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int 
   HCHK(R.work.ensure((size_t)nw), "hipMalloc work");
   HCHK(hipMemsetAsync(R.err.p, 0, sizeof(int), nullptr), "memset");
   if (int rc = ramses_amd_godunov_fine_amr_device(p, ilevel, ngrid, R.igrid.as<int>(), R.son.as<int>(), R.nbor.as<int>(), R.father.as<int>(),
-                                                  R.ngridmax, R.ncoarse, R.uold.as<double>(), R.unew.as<double>(), R.grav ? R.f.as<double>() : nullptr, nullptr, nullptr,
+                                                  R.ngridmax, R.ncoarse, R.uold.as<double>(), R.unew.as<double>(), R.grav ? R.f.as<double>() : nullptr, R.pfix ? R.divu.as<double>() : nullptr, R.pfix ? R.enew.as<double>() : nullptr,
                                                   dx, dt, nvector, interpol_var, interpol_type, R.work.p, R.err.as<int>(), nullptr)) return rc;
   int bad = 0;
   HCHK(hipMemcpy(&bad, R.err.p, sizeof(int), hipMemcpyDeviceToHost), "D2H flag");
@@ -618,6 +688,48 @@ int ramses_amd_amrres_set_uold_grav(const ramses_amd_hydro_params *p, int ngrid,
   if (ngrid == 0) return 0;
   hipLaunchKernelGGL(lvl_gravity_source_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, A, g_ar.f.as<double>(), dt, p->smallr);
   hipLaunchKernelGGL(lvl_set_uold_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, A, p->smallr);
+  HCHK(hipGetLastError(), "set_uold launch");
+  return 0;
+}
+
+
+// ---- pressure_fix: divu / enew live on the device only (they are scratch of one hydro step)
+int ramses_amd_amrres_enable_pfix(void) {
+  AmrRes &R = g_ar;
+  if (!R.valid) return failf(RAMSES_AMD_EINVAL, "no resident AMR state");
+  if (R.pfix) return 0;
+  HCHK(R.divu.ensure(sizeof(double) * (size_t)R.ncell), "hipMalloc divu"); HCHK(R.enew.ensure(sizeof(double) * (size_t)R.ncell), "hipMalloc enew");
+  HCHK(hipMemsetAsync(R.divu.p, 0, sizeof(double) * (size_t)R.ncell, nullptr), "memset"); HCHK(hipMemsetAsync(R.enew.p, 0, sizeof(double) * (size_t)R.ncell, nullptr), "memset");
+  R.pfix = true;
+  return 0;
+}
+// set_unew with pressure_fix: unew = uold, divu = 0, enew = internal energy
+int ramses_amd_amrres_set_unew_pfix(const ramses_amd_hydro_params *p, int ngrid, const int *igrid) {
+  if (!p) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  LvlArgs A;
+  if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
+  if (!g_ar.pfix) return failf(RAMSES_AMD_EINVAL, "set_unew: pressure_fix not enabled (ramses_amd_amrres_enable_pfix)");
+  if (ngrid == 0) return 0;
+  const dim3 g(grid_for((long)ngrid * 8)), b(256);
+  hipLaunchKernelGGL(lvl_copy_kernel, g, b, 0, nullptr, A, A.unew, A.uold);
+  hipLaunchKernelGGL(lvl_pfix_init_kernel, g, b, 0, nullptr, A, g_ar.divu.as<double>(), g_ar.enew.as<double>(), p->smallr);
+  HCHK(hipGetLastError(), "set_unew launch");
+  return 0;
+}
+// set_uold with pressure_fix: (add_gravity_source_terms,) add_pdv_source_terms, the scalar fix and uold = unew, the energy switch
+int ramses_amd_amrres_set_uold_pfix(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double dt, double dx_loc, double beta_fix,
+                                    double hexp) {
+  if (!p) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  LvlArgs A;
+  if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
+  AmrRes &R = g_ar;
+  if (!R.pfix) return failf(RAMSES_AMD_EINVAL, "set_uold: pressure_fix not enabled (ramses_amd_amrres_enable_pfix)");
+  if (ngrid == 0) return 0;
+  const dim3 g(grid_for((long)ngrid * 8)), b(256);
+  if (R.grav) hipLaunchKernelGGL(lvl_gravity_source_kernel, g, b, 0, nullptr, A, R.f.as<double>(), dt, p->smallr);
+  hipLaunchKernelGGL(lvl_pdv_kernel, g, b, 0, nullptr, A, R.enew.as<double>(), dx_loc, dt, p->gamma, p->smallr);
+  hipLaunchKernelGGL(lvl_set_uold_kernel, g, b, 0, nullptr, A, p->smallr);
+  hipLaunchKernelGGL(lvl_pfix_switch_kernel, g, b, 0, nullptr, A, R.divu.as<double>(), R.enew.as<double>(), dx_loc, dt, beta_fix, hexp, p->smallr);
   HCHK(hipGetLastError(), "set_uold launch");
   return 0;
 }

@@ -31,12 +31,18 @@ subroutine set_unew(ilevel)
   implicit none
   integer::ilevel
   integer::rc
+  type(ramses_amd_hydro_params)::p
   if(numbtot(1,ilevel)==0)return
   if(ramses_amd_resident())return
   if(ramses_amd_mpi_resident())return
   if(ramses_amd_amr_resident())then
      call ramses_amd_amr_ensure()
-     rc=ramses_amd_amrres_set_unew(active(ilevel)%ngrid,active(ilevel)%igrid)
+     if(pressure_fix)then
+        call ramses_amd_fill_hydro_params(p)
+        rc=ramses_amd_amrres_set_unew_pfix(p,active(ilevel)%ngrid,active(ilevel)%igrid)
+     else
+        rc=ramses_amd_amrres_set_unew(active(ilevel)%ngrid,active(ilevel)%igrid)
+     end if
      if(rc/=0)call ramses_amd_fatal('set_unew')
      return
   end if
@@ -70,7 +76,11 @@ subroutine set_uold(ilevel)
   if(ramses_amd_amr_resident())then
      call ramses_amd_amr_ensure()
      call ramses_amd_fill_hydro_params(p)
-     if(poisson)then
+     if(pressure_fix)then
+        ! (+ add_gravity_source_terms with poisson), add_pdv_source_terms, uold = unew, the energy switch
+        rc=ramses_amd_amrres_set_uold_pfix(p,active(ilevel)%ngrid,active(ilevel)%igrid,dtnew(ilevel), &
+             & 0.5d0**ilevel*boxlen/dble(icoarse_max-icoarse_min+1),beta_fix,hexp)
+     else if(poisson)then
         rc=ramses_amd_amrres_set_uold_grav(p,active(ilevel)%ngrid,active(ilevel)%igrid,dtnew(ilevel))
      else
         rc=ramses_amd_amrres_set_uold(p,active(ilevel)%ngrid,active(ilevel)%igrid)

@@ -526,6 +526,26 @@ module ramses_amd_iface
        real(c_double), value :: dt
        integer(c_int) :: rc
      end function ramses_amd_amrres_set_uold_grav
+     function ramses_amd_amrres_enable_pfix() bind(C, name='ramses_amd_amrres_enable_pfix') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_enable_pfix
+     function ramses_amd_amrres_set_unew_pfix(p, ngrid, igrid) bind(C, name='ramses_amd_amrres_set_unew_pfix') result(rc)
+       import :: ramses_amd_hydro_params, c_int
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ngrid
+       integer(c_int) :: igrid(*)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_set_unew_pfix
+     function ramses_amd_amrres_set_uold_pfix(p, ngrid, igrid, dt, dx_loc, beta_fix, hexp) &
+          & bind(C, name='ramses_amd_amrres_set_uold_pfix') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double), value :: dt, dx_loc, beta_fix, hexp
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_set_uold_pfix
      function ramses_amd_amrres_courant(p, ngrid, igrid, dx, dt_in, out4) bind(C, name='ramses_amd_amrres_courant') result(rc)
        import :: ramses_amd_hydro_params, c_int, c_double
        type(ramses_amd_hydro_params), intent(in) :: p
@@ -1068,7 +1088,7 @@ contains
        end if
        if (tracer .or. MC_tracer .or. clumpfind .or. lightcone .or. movie .or. aton) ramses_amd_amr_ok = .false.
        if (static .or. static_gas .or. neq_chem .or. barotropic_eos .or. isothermal .or. metal) ramses_amd_amr_ok = .false.
-       if (pressure_fix .or. T2_star > 0.0d0 .or. momentum_feedback > 0 .or. strict_equilibrium > 0) ramses_amd_amr_ok = .false.
+       if (T2_star > 0.0d0 .or. momentum_feedback > 0 .or. strict_equilibrium > 0) ramses_amd_amr_ok = .false.
        if (ndim /= 3 .or. levelmin < 3) ramses_amd_amr_ok = .false.
        if (icoarse_max - icoarse_min /= 0 .or. jcoarse_max - jcoarse_min /= 0 .or. kcoarse_max - kcoarse_min /= 0) &
             & ramses_amd_amr_ok = .false.
@@ -1101,6 +1121,10 @@ contains
     if (ramses_amd_amrres_active() == 0) then
        rc = ramses_amd_amrres_load(nvar, int(ngridmax, 8), int(ncoarse, 8), uold, son, nbor, father)
        if (rc /= 0) call ramses_amd_fatal('AMR residency (load)')
+       if (pressure_fix) then
+          rc = ramses_amd_amrres_enable_pfix()
+          if (rc /= 0) call ramses_amd_fatal('AMR residency (pressure_fix)')
+       end if
        if (poisson) then
           do l = levelmin, nlevelmax
              if (numbtot(1, l) > 0) call ramses_amd_amr_load_f(l)
