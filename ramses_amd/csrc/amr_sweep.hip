@@ -392,6 +392,7 @@ struct GrpLds {
   int fc[64];              // the 4^3 father cells (1-based cell index, 0: not there)
   int ex[64];              // their son oct (0: not refined)
   int io[8];               // position of each son of the father oct in the call's list (-1: not active)
+  int px[64];              // position of the son oct of each father cell in the call's list (-1: none / not in the list)
   unsigned char ok[512];   // cell is refined
 };
 __device__ __forceinline__ int gsidx(int i, int j, int k) { return i + 8 * (j + 8 * k); }
@@ -420,7 +421,9 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
       }
     }
     L.fc[t] = c;
-    L.ex[t] = c > 0 ? A.son[c - 1] : 0;
+    const int og_t = c > 0 ? A.son[c - 1] : 0;
+    L.ex[t] = og_t;
+    L.px[t] = og_t > 0 ? posof[og_t - 1] : -1;
   }
   __syncthreads();
   if (t < 8) {
@@ -431,24 +434,41 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
 
   // ---- (B)+(C) gather the 8^3 stencil, convert to primitive variables ------------------
   const double dtxhalf = A.dt * 0.5;
+  const bool packed = A.packed != nullptr;
   for (int e = t; e < 512; e += GRP_THREADS) {
-    const int ind = e >> 6, f = e & 63;        // lanes run over the father cells first (sibling octs are contiguous)
+    // cell vectors: lanes run over the father cells first (the same octant of sibling octs is contiguous);
+    // packed records: over the octants first (the 8 values of a variable are 64 contiguous bytes, sibling octs follow)
+    const int ind = packed ? (e & 7) : (e >> 6), f = packed ? (e >> 3) : (e & 63);
     const int og = L.ex[f];
     if (og > 0) {
       const int i3 = 2 * (f & 3) + (ind & 1), j3 = 2 * ((f >> 2) & 3) + ((ind >> 1) & 1), k3 = 2 * (f >> 4) + (ind >> 2);
-      const long cell = A.ncoarse + (long)ind * A.ngridmax + og;   // 1-based
       const int s = gsidx(i3, j3, k3);
       double u[NV], q[NV], gz[3] = {0.0, 0.0, 0.0};
+      bool refined;
+      const int px = L.px[f];
+      if (packed && px >= 0) {
+        const double *__restrict__ r = A.packed + (long)px * A.rec;
 #pragma unroll
-      for (int v = 0; v < NV; v++) u[v] = A.uold[(long)v * ncell + cell - 1];
-      if (GRAV) {
+        for (int v = 0; v < NV; v++) u[v] = r[v * 8 + ind];
+        if (GRAV) {
 #pragma unroll
-        for (int d = 0; d < 3; d++) gz[d] = A.grav[(long)d * ncell + cell - 1];
+          for (int d = 0; d < 3; d++) gz[d] = r[(NV + d) * 8 + ind];
+        }
+        refined = reinterpret_cast<const int *>(r + 8 * (NV + (GRAV ? 3 : 0)))[ind] != 0;
+      } else {
+        const long cell = A.ncoarse + (long)ind * A.ngridmax + og;   // 1-based
+#pragma unroll
+        for (int v = 0; v < NV; v++) u[v] = A.uold[(long)v * ncell + cell - 1];
+        if (GRAV) {
+#pragma unroll
+          for (int d = 0; d < 3; d++) gz[d] = A.grav[(long)d * ncell + cell - 1];
+        }
+        refined = A.son[cell - 1] > 0;
       }
       ctoprim_cell<NV, GRAV>(u, gz, dtxhalf, P, q);
 #pragma unroll
       for (int v = 0; v < NV; v++) L.u[s][v] = q[v];
-      L.ok[s] = A.son[cell - 1] > 0;
+      L.ok[s] = refined;
     }
   }
   if (t < 64 && L.ex[t] == 0) {
@@ -626,6 +646,38 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
   }
 }
 
+// The octs of the call's list repacked as contiguous records, record i = oct igrid[i]:
+//   [8 x uold(:,1)] ... [8 x uold(:,nvar)] [8 x f(:,1..3) with gravity] [8 ints: cell is refined], padded to 128 bytes.
+// The grouped kernel then reads a father cell's son oct as one 3-5 line burst instead of 8 x nvar eight-byte gathers at
+// stride ngridmax (profiles/r02_amr_sweep_pmc.txt: those gathers moved 24x the algorithmic traffic).  32 octs per
+// workgroup: cell-vector reads run over consecutive octs, the records leave through LDS in record order.
+constexpr int PACK_OCTS = 32;
+__global__ __launch_bounds__(256) void amr_pack_kernel(AmrSweepArgs A, double *__restrict__ out, int rec, int nvt) {
+  __shared__ double tile[PACK_OCTS][AMR_PACK_REC_MAX + 1];
+  const int base = blockIdx.x * PACK_OCTS;
+  const int n = min(PACK_OCTS, A.ngrid - base);
+  const int nval = 8 * nvt;                               // doubles of data per record
+  for (int e = threadIdx.x; e < PACK_OCTS * (nval + 8); e += 256) {
+    const int o = e % PACK_OCTS, k = e / PACK_OCTS;       // consecutive lanes: consecutive octs
+    if (o >= n) continue;
+    const int g = A.igrid[base + o];
+    if (k < nval) {
+      const int v = k >> 3, ind = k & 7;
+      const long cell = A.ncoarse + (long)ind * A.ngridmax + g - 1;
+      tile[o][k] = v < A.nvar ? A.uold[(long)v * A.ncell + cell] : A.grav[(long)(v - A.nvar) * A.ncell + cell];
+    } else {
+      const int ind = k - nval;
+      const long cell = A.ncoarse + (long)ind * A.ngridmax + g - 1;
+      reinterpret_cast<int *>(&tile[o][nval])[ind] = A.son[cell] > 0 ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n * rec; e += 256) {
+    const int o = e / rec, k = e % rec;
+    out[(long)(base + o) * rec + k] = k < nval + 4 ? tile[o][k] : 0.0;
+  }
+}
+
 // groups[] = the father octs that have at least one son in the call's list, each once: the son at the lowest
 // octant position enters it
 __global__ void amr_group_build_kernel(AmrSweepArgs A, const int *posof, int *groups, int *count) {
@@ -769,9 +821,11 @@ static hipError_t launch1(const AmrSweepArgs &A, int rs, const int *groups, int 
 
 }  // namespace amrsweep
 
-hipError_t launch_amr_godunov(const AmrSweepArgs &A, int slope_type, int riemann, int *posof, int nvector,
-                              hipStream_t s) {
+hipError_t launch_amr_godunov(const AmrSweepArgs &A_in, int slope_type, int riemann, int *posof, int nvector,
+                              hipStream_t s, double *pack_area) {
   using namespace amrsweep;
+  AmrSweepArgs A = A_in;
+  A.packed = nullptr; A.rec = 0;
   if (A.ngrid <= 0) return hipSuccess;
   hipError_t e;
   e = hipMemsetAsync(posof, 0xff, sizeof(int) * A.ngridmax, s);
@@ -794,6 +848,18 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A, int slope_type, int riemann
     if (e != hipSuccess) return e;
     e = hipStreamSynchronize(s);
     if (e != hipSuccess) return e;
+    // the grouped kernel reads the level from packed oct records (RAMSES_AMD_AMR_PACK=0: straight from the cell vectors)
+    static int use_pack = -1;
+    if (use_pack < 0) {
+      const char *env = getenv("RAMSES_AMD_AMR_PACK");
+      use_pack = !(env && env[0] == '0');
+    }
+    if (use_pack && pack_area && ngroups > 0) {
+      const int nvt = A.nvar + (A.grav ? 3 : 0);
+      const int rec = amr_pack_rec(A.nvar, A.grav != nullptr);
+      hipLaunchKernelGGL(amr_pack_kernel, dim3((A.ngrid + PACK_OCTS - 1) / PACK_OCTS), dim3(256), 0, s, A, pack_area, rec, nvt);
+      A.packed = pack_area; A.rec = rec;
+    }
   }
   switch (slope_type) {
     case 0: e = launch1<0>(A, riemann, groups, ngroups, posof, s); break;

@@ -24,10 +24,16 @@ struct AmrSweepArgs {
   double *corr;         // [ngrid][6][4][nvar+2] fluxes (+ the two pressure_fix quantities) owed to coarse neighbour cells
   int *corr_tgt;        // [ngrid][6] the coarse cell (1-based) or 0
   int *err;             // tree inconsistencies found
+  // grouped kernel: the level's octs repacked as contiguous records (see amr_pack_kernel), or null
+  const double *packed;
+  int rec;              // doubles per record
   HydroConst P;
 };
 
 hipError_t launch_amr_godunov(const AmrSweepArgs &A, int slope_type, int riemann, int *posof, int nvector,
-                              hipStream_t s);
+                              hipStream_t s, double *pack_area = nullptr);
+// doubles per packed oct record for nvar variables (+3 with gravity): 8 values per variable, 8 refinement flags, padded to 128 bytes
+inline int amr_pack_rec(int nvar, bool grav) { return ((8 * (nvar + (grav ? 3 : 0)) + 4) + 15) / 16 * 16; }
+constexpr int AMR_PACK_REC_MAX = 96;   // nvar = 7 with gravity
 
 }  // namespace ramses_amd

@@ -765,11 +765,17 @@ int ramses_amd_godunov_fine_host(const ramses_amd_hydro_params *p, int ilevel, i
 // unew that already holds the finer level's corrections, corrections owed to
 // the coarser level).  Works directly on the reference's tree arrays.
 // workspace of the device entry point, in bytes
+// (coarse-correction records, their targets, oct -> list position, the father-oct groups and their counter; then, 128-byte
+//  aligned, the packed oct records of the grouped kernel)
+static size_t amr_ws_pack_offset(int ngrid, int64_t ngridmax) {
+  const size_t head = sizeof(double) * (size_t)ngrid * 6 * 4 * 9 + sizeof(int) * (size_t)ngrid * 6 + sizeof(int) * (size_t)ngridmax +
+                      sizeof(int) * ((size_t)ngrid + 16) + 64;
+  return (head + 127) / 128 * 128;
+}
 int64_t ramses_amd_godunov_fine_amr_workspace(int ngrid, int64_t ngridmax) {
   if (ngrid < 0 || ngridmax < 1) return fail(RAMSES_AMD_EINVAL, "bad argument");
   // coarse-correction records, their targets, oct -> list position, the father-oct groups and their counter
-  return (int64_t)(sizeof(double) * (size_t)ngrid * 6 * 4 * 9 + sizeof(int) * (size_t)ngrid * 6 + sizeof(int) * (size_t)ngridmax +
-                   sizeof(int) * ((size_t)ngrid + 16) + 64);
+  return (int64_t)(amr_ws_pack_offset(ngrid, ngridmax) + sizeof(double) * (size_t)AMR_PACK_REC_MAX * (size_t)ngrid);
 }
 
 static int amr_check(const ramses_amd_hydro_params *p, int ilevel, int nvector, int interpol_var, int interpol_type) {
@@ -812,7 +818,8 @@ int ramses_amd_godunov_fine_amr_device(const ramses_amd_hydro_params *p, int ile
   int *posof = reinterpret_cast<int *>(w);
   A.err = d_err;
   A.P = make_const(p);
-  hipError_t e = launch_amr_godunov(A, p->slope_type, p->riemann, posof, nvector, reinterpret_cast<hipStream_t>(stream));
+  double *pack_area = reinterpret_cast<double *>(reinterpret_cast<char *>(d_work) + amr_ws_pack_offset(ngrid, ngridmax));
+  hipError_t e = launch_amr_godunov(A, p->slope_type, p->riemann, posof, nvector, reinterpret_cast<hipStream_t>(stream), pack_area);
   if (e != hipSuccess) return hipfail(e, "AMR godunov launch");
   return 0;
 }
