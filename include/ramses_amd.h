@@ -392,6 +392,16 @@ int ramses_amd_mgamr_begin(int ilevel, int64_t ngridmax, int64_t ncoarse, const 
                            const int *father, const int *lookup_mg, const int *flag2, double *phi, double *f,
                            int ngrid, const int *igrid);
 int ramses_amd_mgamr_add_level(int level, int ngrid, const int *igrid, double *u, const int *fscan);
+/* MPI: a level is the calling rank's own octs followed by the reception octs of the other ranks (active_mg(icpu,l) for
+ * icpu /= myid, whose values the reference's make_virtual_mg_dp / make_reverse_mg_dp keep current on the host): level_begin
+ * announces the total, level_block passes one rank buffer (igrid, u(1:8*ngrid,1:4), f(1:8*ngrid,1)) -- the caller's own
+ * first; only that one is updated, the restriction also adds into the others.  fine_active: the list given to begin() holds
+ * nact active octs followed by the level's reception octs.  Several ranks imply RAMSES_AMD_MG_SYNC=1 semantics (every
+ * routine exchanges its arrays with the host, where the reference's halo routines work). */
+int ramses_amd_mgamr_level_begin(int level, int ngrid_total);
+int ramses_amd_mgamr_level_block(int level, int ngrid, const int *igrid, double *u, const int *fscan);
+int ramses_amd_mgamr_fine_active(int nact);
+int ramses_amd_mgamr_force_sync(int on);
 int ramses_amd_mgamr_gauss_seidel(int level, int redstep, int safe);
 int ramses_amd_mgamr_residual(int level);
 int ramses_amd_mgamr_norm2(int level, double *norm2);

@@ -90,6 +90,10 @@ SYMBOLS = [
     ("ramses_amd_mg_coarse_solve_dense", _i, [_i, _vp, _vp, _vp, _i, _vp]),
     ("ramses_amd_mgamr_begin", _i, [_i, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     ("ramses_amd_mgamr_add_level", _i, [_i, _i, _vp, _vp, _vp]),
+    ("ramses_amd_mgamr_level_begin", _i, [_i, _i]),
+    ("ramses_amd_mgamr_level_block", _i, [_i, _i, _vp, _vp, _vp]),
+    ("ramses_amd_mgamr_fine_active", _i, [_i]),
+    ("ramses_amd_mgamr_force_sync", _i, [_i]),
     ("ramses_amd_mgamr_gauss_seidel", _i, [_i, _i, _i]),
     ("ramses_amd_mgamr_residual", _i, [_i]),
     ("ramses_amd_mgamr_norm2", _i, [_i, _vp]),

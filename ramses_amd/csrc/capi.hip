@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../../include/ramses_amd.h"
 #include "amr_args.hpp"
@@ -1465,15 +1466,20 @@ int ramses_amd_resident_invalidate(void) {
 // ---------------------------------------------------------------------------
 extern "C++" {
 namespace {
+// a multigrid level = the rank's own octs (block 0) followed, under MPI, by the reception octs of the other ranks
+// (active_mg(icpu,l) for icpu /= myid): one layout of ngrid = sum of the blocks' octs, of which the first nact are updated
+struct MgAmrBlock {
+  int ngrid, off;             // octs, position of the first one in the level's layout
+  double *h_u;                // the block's host array u(1:ngrid*8, 1:4)
+  const int *h_f;             // f(1:ngrid*8, 1)
+};
 struct MgAmrDev {
-  int level = 0, ngrid = 0;
+  int level = 0, ngrid = 0, nact = 0, filled = 0;
   DevBuf igrid, u1, u2, u3, u4, scan;
-  // host arrays (coarse levels: only valid during add_level / sync mode)
-  double *h_u = nullptr;      // u(1:ngrid*8, 1:4)
-  const int *h_f = nullptr;   // f(1:ngrid*8, 1)
+  std::vector<MgAmrBlock> blocks;   // (coarse levels; host arrays only valid during the solve)
   MgAmrLevel view() {
     MgAmrLevel L;
-    L.ngrid = ngrid; L.igrid = igrid.as<int>();
+    L.ngrid = ngrid; L.nact = nact; L.igrid = igrid.as<int>();
     L.u1 = u1.as<double>(); L.u2 = u2.as<double>(); L.u3 = u3.as<double>(); L.u4 = u4.as<double>();
     L.scan = scan.as<int>();
     return L;
@@ -1496,6 +1502,7 @@ struct MgAmrCtx {
   }
 };
 MgAmrCtx g_mg;
+bool g_mg_force_sync = false;     // several MPI ranks: every routine exchanges its arrays with the host
 }  // namespace
 }  // extern "C++"
 
@@ -1525,29 +1532,39 @@ static int mgamr_store_fine(double *h_vec, const double *d_col) {
   MgAmrDev &D = M.lev[M.ilevel];
   hipStream_t s = nullptr;
   HCHK(hipMemcpyAsync(M.vec.p, h_vec, sizeof(double) * M.ncell, hipMemcpyHostToDevice, s), "H2D");
-  HCHK(mgamr_launch_scatter(M.vec.as<double>(), d_col, D.igrid.as<int>(), D.ngrid, M.ncoarse, M.ngridmax, s), "scatter");
+  HCHK(mgamr_launch_scatter(M.vec.as<double>(), d_col, D.igrid.as<int>(), D.nact, D.ngrid, M.ncoarse, M.ngridmax, s), "scatter");
   HCHK(hipMemcpyAsync(h_vec, M.vec.p, sizeof(double) * M.ncell, hipMemcpyDeviceToHost, s), "D2H");
   HCHK(hipStreamSynchronize(s), "sync");
   return 0;
 }
-static int mgamr_load_coarse(MgAmrDev &D, bool all) {
+// one component (8*ngrid_b values, octant-major) of every block between the blocks' host arrays and the level's layout
+static int mgamr_copy_comp(MgAmrDev &D, DevBuf &dev, int k, bool to_device, bool mine_only) {   // k = 1..4
   hipStream_t s = nullptr;
-  const size_t n = sizeof(double) * 8 * (size_t)D.ngrid;
-  if (D.ngrid == 0) return 0;
-  if (all) {
-    HCHK(hipMemcpyAsync(D.u1.p, D.h_u, n, hipMemcpyHostToDevice, s), "H2D u1");
-    HCHK(hipMemcpyAsync(D.u2.p, D.h_u + 8L * D.ngrid, n, hipMemcpyHostToDevice, s), "H2D u2");
-    HCHK(hipMemcpyAsync(D.u3.p, D.h_u + 16L * D.ngrid, n, hipMemcpyHostToDevice, s), "H2D u3");
+  for (size_t b = 0; b < D.blocks.size(); b++) {
+    const MgAmrBlock &B = D.blocks[b];
+    if (B.ngrid == 0 || (mine_only && b > 0)) continue;
+    double *host = B.h_u + (size_t)(k - 1) * 8 * B.ngrid;
+    double *devp = dev.as<double>() + B.off;
+    if (to_device) HCHK(hipMemcpy2DAsync(devp, sizeof(double) * D.ngrid, host, sizeof(double) * B.ngrid, sizeof(double) * B.ngrid, 8, hipMemcpyHostToDevice, s), "H2D level");
+    else HCHK(hipMemcpy2DAsync(host, sizeof(double) * B.ngrid, devp, sizeof(double) * D.ngrid, sizeof(double) * B.ngrid, 8, hipMemcpyDeviceToHost, s), "D2H level");
   }
-  HCHK(hipMemcpyAsync(D.u4.p, D.h_u + 24L * D.ngrid, n, hipMemcpyHostToDevice, s), "H2D u4");
   return 0;
 }
-static int mgamr_store_coarse(MgAmrDev &D, int k) {   // k = 1..3
-  hipStream_t s = nullptr;
+static int mgamr_load_coarse(MgAmrDev &D, bool all) {
+  if (D.ngrid == 0) return 0;
+  if (all) {
+    if (int rc = mgamr_copy_comp(D, D.u1, 1, true, false)) return rc;
+    if (int rc = mgamr_copy_comp(D, D.u2, 2, true, false)) return rc;
+    if (int rc = mgamr_copy_comp(D, D.u3, 3, true, false)) return rc;
+  }
+  return mgamr_copy_comp(D, D.u4, 4, true, false);
+}
+// k = 1..3; all_blocks: the reception blocks too (the restriction adds into cells other ranks own)
+static int mgamr_store_coarse(MgAmrDev &D, int k, bool all_blocks = false) {
   if (D.ngrid == 0) return 0;
   DevBuf *b[3] = {&D.u1, &D.u2, &D.u3};
-  HCHK(hipMemcpyAsync(D.h_u + (long)(k - 1) * 8 * D.ngrid, b[k - 1]->p, sizeof(double) * 8 * (size_t)D.ngrid, hipMemcpyDeviceToHost, s), "D2H");
-  HCHK(hipStreamSynchronize(s), "sync");
+  if (int rc = mgamr_copy_comp(D, *b[k - 1], k, false, !all_blocks)) return rc;
+  HCHK(hipStreamSynchronize(nullptr), "sync");
   return 0;
 }
 __global__ void mgamr_scan_bit_kernel(const int *f, int *scan, long n) {
@@ -1563,10 +1580,10 @@ int ramses_amd_mgamr_begin(int ilevel, int64_t ngridmax, int64_t ncoarse, const 
   MgAmrCtx &M = g_mg;
   hipStream_t s = nullptr;
   const char *e = getenv("RAMSES_AMD_MG_SYNC");
-  M.sync = e && e[0] == '1';
+  M.sync = (e && e[0] == '1') || g_mg_force_sync;
   M.open = true; M.ilevel = ilevel; M.ncoarse = ncoarse; M.ngridmax = ngridmax; M.ncell = ncoarse + 8 * ngridmax;
   M.h_phi = phi; M.h_f = f; M.h_flag2 = flag2;
-  for (int l = 0; l < 32; l++) { M.lev[l].ngrid = 0; M.lev[l].level = l; M.lev[l].h_u = nullptr; M.lev[l].h_f = nullptr; }
+  for (int l = 0; l < 32; l++) { M.lev[l].ngrid = 0; M.lev[l].nact = 0; M.lev[l].filled = 0; M.lev[l].level = l; M.lev[l].blocks.clear(); }
   HCHK(M.son.ensure(sizeof(int) * M.ncell), "hipMalloc son");
   HCHK(M.nbor.ensure(sizeof(int) * 6 * ngridmax), "hipMalloc nbor");
   HCHK(M.father.ensure(sizeof(int) * ngridmax), "hipMalloc father");
@@ -1576,9 +1593,12 @@ int ramses_amd_mgamr_begin(int ilevel, int64_t ngridmax, int64_t ncoarse, const 
   HCHK(hipMemcpyAsync(M.son.p, son, sizeof(int) * M.ncell, hipMemcpyHostToDevice, s), "H2D son");
   HCHK(hipMemcpyAsync(M.nbor.p, nbor, sizeof(int) * 6 * ngridmax, hipMemcpyHostToDevice, s), "H2D nbor");
   HCHK(hipMemcpyAsync(M.father.p, father, sizeof(int) * ngridmax, hipMemcpyHostToDevice, s), "H2D father");
-  HCHK(hipMemcpyAsync(M.lookup.p, lookup_mg, sizeof(int) * ngridmax, hipMemcpyHostToDevice, s), "H2D lookup");
+  // (the oct -> position table is built here from the levels' lists: under MPI the reference's lookup_mg counts inside each
+  //  rank's buffer, the device layout is the concatenation of the buffers)
+  (void)lookup_mg;
+  HCHK(hipMemsetAsync(M.lookup.p, 0, sizeof(int) * ngridmax, s), "memset lookup");
   MgAmrDev &D = M.lev[ilevel];
-  D.ngrid = ngrid;
+  D.ngrid = ngrid; D.nact = ngrid; D.blocks.clear();
   const size_t n = sizeof(double) * 8 * (size_t)(ngrid > 0 ? ngrid : 1);
   HCHK(D.igrid.ensure(sizeof(int) * (size_t)(ngrid > 0 ? ngrid : 1)), "hipMalloc");
   HCHK(D.u1.ensure(n), "hipMalloc"); HCHK(D.u2.ensure(n), "hipMalloc"); HCHK(D.u3.ensure(n), "hipMalloc"); HCHK(D.u4.ensure(n), "hipMalloc");
@@ -1592,27 +1612,65 @@ int ramses_amd_mgamr_begin(int ilevel, int64_t ngridmax, int64_t ncoarse, const 
   return 0;
 }
 
-int ramses_amd_mgamr_add_level(int level, int ngrid, const int *igrid, double *u, const int *fscan) {
+// a multigrid level in blocks: level_begin(total octs), then level_block() per rank buffer with octs -- the calling rank's
+// own first --, the last block completes the level (lists, masks, scan flags and the other arrays go to the device)
+int ramses_amd_mgamr_level_begin(int level, int ngrid_total) {
   MgAmrCtx &M = g_mg;
-  if (!M.open) return fail(RAMSES_AMD_EINVAL, "mgamr_add_level outside begin/end");
+  if (!M.open) return fail(RAMSES_AMD_EINVAL, "mgamr_level_begin outside begin/end");
   if (level < 1 || level >= M.ilevel) return fail(RAMSES_AMD_EINVAL, "multigrid level %d out of range", level);
-  if (ngrid > 0 && (!igrid || !u || !fscan)) return fail(RAMSES_AMD_EINVAL, "NULL argument");
-  hipStream_t s = nullptr;
+  if (ngrid_total < 0) return fail(RAMSES_AMD_EINVAL, "bad oct count");
   MgAmrDev &D = M.lev[level];
-  D.ngrid = ngrid; D.h_u = u; D.h_f = fscan;
-  const size_t nn = 8 * (size_t)(ngrid > 0 ? ngrid : 1);
-  HCHK(D.igrid.ensure(sizeof(int) * (size_t)(ngrid > 0 ? ngrid : 1)), "hipMalloc");
+  D.ngrid = ngrid_total; D.nact = 0; D.filled = 0; D.blocks.clear();
+  const size_t nn = 8 * (size_t)(ngrid_total > 0 ? ngrid_total : 1);
+  HCHK(D.igrid.ensure(sizeof(int) * (size_t)(ngrid_total > 0 ? ngrid_total : 1)), "hipMalloc");
   HCHK(D.u1.ensure(sizeof(double) * nn), "hipMalloc"); HCHK(D.u2.ensure(sizeof(double) * nn), "hipMalloc");
   HCHK(D.u3.ensure(sizeof(double) * nn), "hipMalloc"); HCHK(D.u4.ensure(sizeof(double) * nn), "hipMalloc");
   HCHK(D.scan.ensure(sizeof(int) * nn), "hipMalloc");
-  if (ngrid == 0) return 0;
-  HCHK(hipMemcpyAsync(D.igrid.p, igrid, sizeof(int) * ngrid, hipMemcpyHostToDevice, s), "H2D igrid");
-  HCHK(M.ivec.ensure(sizeof(int) * nn > sizeof(int) * M.ncell ? sizeof(int) * nn : sizeof(int) * M.ncell), "hipMalloc");
-  HCHK(hipMemcpyAsync(M.ivec.p, fscan, sizeof(int) * nn, hipMemcpyHostToDevice, s), "H2D scan");
-  hipLaunchKernelGGL(mgamr_scan_bit_kernel, dim3(64), dim3(256), 0, s, M.ivec.as<int>(), D.scan.as<int>(), (long)nn);
-  HCHK(hipGetLastError(), "scan launch");
-  if (int rc = mgamr_load_coarse(D, true)) return rc;
+  return 0;
+}
+int ramses_amd_mgamr_level_block(int level, int ngrid, const int *igrid, double *u, const int *fscan) {
+  MgAmrCtx &M = g_mg;
+  if (!M.open) return fail(RAMSES_AMD_EINVAL, "mgamr_level_block outside begin/end");
+  if (level < 1 || level >= M.ilevel) return fail(RAMSES_AMD_EINVAL, "multigrid level %d out of range", level);
+  if (ngrid < 0 || (ngrid > 0 && (!igrid || !u || !fscan))) return fail(RAMSES_AMD_EINVAL, "bad block");
+  hipStream_t s = nullptr;
+  MgAmrDev &D = M.lev[level];
+  if (D.filled + ngrid > D.ngrid) return fail(RAMSES_AMD_EINVAL, "level %d: blocks exceed the announced %d octs", level, D.ngrid);
+  MgAmrBlock B = {ngrid, D.filled, u, fscan};
+  if (D.blocks.empty()) D.nact = ngrid;          // the first block is the caller's own
+  D.blocks.push_back(B);
+  if (ngrid > 0) {
+    HCHK(hipMemcpyAsync(D.igrid.as<int>() + B.off, igrid, sizeof(int) * ngrid, hipMemcpyHostToDevice, s), "H2D igrid");
+    const size_t nn = 8 * (size_t)D.ngrid;
+    HCHK(M.ivec.ensure(sizeof(int) * nn > sizeof(int) * M.ncell ? sizeof(int) * nn : sizeof(int) * M.ncell), "hipMalloc");
+    HCHK(hipMemcpy2DAsync(M.ivec.as<int>() + B.off, sizeof(int) * D.ngrid, fscan, sizeof(int) * ngrid, sizeof(int) * ngrid, 8, hipMemcpyHostToDevice, s), "H2D scan");
+  }
+  D.filled += ngrid;
+  if (D.filled < D.ngrid) { HCHK(hipStreamSynchronize(s), "sync"); return 0; }
+  // complete: positions, scan bits, arrays
+  if (D.ngrid > 0) {
+    HCHK(mgamr_launch_lookup(D.igrid.as<int>(), D.ngrid, M.lookup.as<int>(), s), "lookup");
+    hipLaunchKernelGGL(mgamr_scan_bit_kernel, dim3(64), dim3(256), 0, s, M.ivec.as<int>(), D.scan.as<int>(), (long)(8 * (size_t)D.ngrid));
+    HCHK(hipGetLastError(), "scan launch");
+    if (int rc = mgamr_load_coarse(D, true)) return rc;
+  }
   HCHK(hipStreamSynchronize(s), "sync");   // host buffers of the caller may be temporaries
+  return 0;
+}
+int ramses_amd_mgamr_force_sync(int on) { g_mg_force_sync = on != 0; return 0; }
+// single rank: the level is one block
+int ramses_amd_mgamr_add_level(int level, int ngrid, const int *igrid, double *u, const int *fscan) {
+  if (ngrid > 0 && (!igrid || !u || !fscan)) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (int rc = ramses_amd_mgamr_level_begin(level, ngrid)) return rc;
+  return ramses_amd_mgamr_level_block(level, ngrid, igrid, u, fscan);
+}
+// the fine level's list passed to begin() holds nact active octs followed by reception octs (MPI): only the former are updated
+int ramses_amd_mgamr_fine_active(int nact) {
+  MgAmrCtx &M = g_mg;
+  if (!M.open) return fail(RAMSES_AMD_EINVAL, "mgamr_fine_active outside begin/end");
+  MgAmrDev &D = M.lev[M.ilevel];
+  if (nact < 0 || nact > D.ngrid) return fail(RAMSES_AMD_EINVAL, "bad active count %d of %d", nact, D.ngrid);
+  D.nact = nact;
   return 0;
 }
 
@@ -1667,7 +1725,7 @@ int ramses_amd_mgamr_restrict(int finelevel) {
   if (g_mg.sync) if (int rc = mgamr_load_coarse(*C, true)) return rc;
   HCHK(mgamr_launch_restrict(F->view(), C->view(), g_mg.tree(), nullptr), "restrict launch");
   if (g_mg.sync) {
-    if (int rc = mgamr_store_coarse(*C, 2)) return rc;
+    if (int rc = mgamr_store_coarse(*C, 2, true)) return rc;
     // the correction is reset by the reference's driver itself; do not touch the host copy
   }
   return 0;

@@ -43,10 +43,10 @@ __device__ __forceinline__ long nbr_cell(const MgAmrLevel &L, const MgAmrTree &T
 
 // one colour of red-black Gauss-Seidel.  color 0: octants 1,4,6,7 (red), 1: 2,3,5,8 (black)
 __global__ __launch_bounds__(256) void gs_kernel(MgAmrLevel L, MgAmrTree T, int color, int safe, double dx2) {
-  const long total = 4L * L.ngrid;
+  const long total = 4L * L.nact;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    const int i = (int)(t % L.ngrid);
-    const int k = (int)(t / L.ngrid);
+    const int i = (int)(t % L.nact);
+    const int k = (int)(t / L.nact);
     const int red[4] = {0, 3, 5, 6}, black[4] = {1, 2, 4, 7};
     const int ind = color ? black[k] : red[k];
     const long c = (long)ind * L.ngrid + i;
@@ -83,10 +83,11 @@ __global__ __launch_bounds__(256) void gs_kernel(MgAmrLevel L, MgAmrTree T, int 
 
 // u3 = -(sum_nb - 6 phi)/dx^2 + rhs, masked cells 0
 __global__ __launch_bounds__(256) void residual_kernel(MgAmrLevel L, MgAmrTree T, double oneoverdx2) {
-  const long total = 8L * L.ngrid;
-  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x) {
-    const int i = (int)(c % L.ngrid);
-    const int ind = (int)(c / L.ngrid);
+  const long total = 8L * L.nact;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(t % L.nact);
+    const int ind = (int)(t / L.nact);
+    const long c = (long)ind * L.ngrid + i;
     const double phi_c = L.u1[c];
     double nb_sum = 0.0;
     if (L.scan[c] == 0) {
@@ -118,10 +119,12 @@ __global__ __launch_bounds__(256) void residual_kernel(MgAmrLevel L, MgAmrTree T
 
 // partial sums of u3^2 over unmasked cells (fixed-order tree per block)
 __global__ __launch_bounds__(256) void norm_kernel(MgAmrLevel L, double *partial) {
-  const long total = 8L * L.ngrid;
+  const long total = 8L * L.nact;
   double acc = 0.0;
-  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x)
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long c = (long)(t / L.nact) * L.ngrid + (t % L.nact);
     if (L.u4[c] > 0.0) acc = acc + L.u3[c] * L.u3[c];
+  }
   __shared__ double sm[256];
   sm[threadIdx.x] = acc;
   __syncthreads();
@@ -148,7 +151,7 @@ __global__ void norm_final_kernel(const double *partial, int m, double scale, do
 // the 8 children of a coarse cell are added in octant order, as the reference's loop does);
 // the coarse rhs and correction were zeroed by the launcher
 __global__ __launch_bounds__(256) void restrict_kernel(MgAmrLevel F, MgAmrLevel C, MgAmrTree T) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < F.ngrid; i += gridDim.x * blockDim.x) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < F.nact; i += gridDim.x * blockDim.x) {
     const int g = F.igrid[i];
     const int fc = T.father[g - 1];                    // father cell (1-based), a cell of an oct of level C
     const int ind_c = (int)((fc - T.ncoarse - 1) / T.ngridmax);
@@ -184,16 +187,17 @@ __device__ __forceinline__ int amr_nbor_cell(int c, int dir, const MgAmrTree &T)
 // phi_F += trilinear interpolation of the correction of level C (8 of the 27 father cells
 // around the oct, weights 1,3,3,9,3,9,9,27 /64 in the reference's order)
 __global__ __launch_bounds__(256) void interp_kernel(MgAmrLevel F, MgAmrLevel C, MgAmrTree T) {
-  const long total = 8L * F.ngrid;
+  const long total = 8L * F.nact;
   const double a = 1.0 / 64.0, b = 3 * a, cc = 9 * a, d = 27 * a;
   const double bbb[8] = {a, b, b, cc, b, cc, cc, d};
   // ccc(ind_average, ind_f): which of the 27 father cells (1-based, x fastest)
   const int ccc[8][8] = {{1, 2, 4, 5, 10, 11, 13, 14},   {3, 2, 6, 5, 12, 11, 15, 14},  {7, 8, 4, 5, 16, 17, 13, 14},
                          {9, 8, 6, 5, 18, 17, 15, 14},   {19, 20, 22, 23, 10, 11, 13, 14}, {21, 20, 24, 23, 12, 11, 15, 14},
                          {25, 26, 22, 23, 16, 17, 13, 14}, {27, 26, 24, 23, 18, 17, 15, 14}};
-  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x) {
-    const int i = (int)(c % F.ngrid);
-    const int ind_f = (int)(c / F.ngrid);
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(t % F.nact);
+    const int ind_f = (int)(t / F.nact);
+    const long c = (long)ind_f * F.ngrid + i;
     double corr = 0.0;
     if (F.u4[c] > 0.0) {
       const int g = F.igrid[i];
@@ -226,11 +230,12 @@ __global__ void gather_kernel(const double *vec, double *out, const int *igrid, 
     out[c] = vec[ncoarse + (long)ind * ngridmax + igrid[i] - 1];
   }
 }
-__global__ void scatter_kernel(double *vec, const double *in, const int *igrid, int ngrid, long ncoarse, long ngridmax) {
-  const long total = 8L * ngrid;
-  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x) {
-    const int i = (int)(c % ngrid), ind = (int)(c / ngrid);
-    vec[ncoarse + (long)ind * ngridmax + igrid[i] - 1] = in[c];
+// (only the first nact octs of a layout of ngrid octs are written back)
+__global__ void scatter_kernel(double *vec, const double *in, const int *igrid, int nact, int ngrid, long ncoarse, long ngridmax) {
+  const long total = 8L * nact;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(t % nact), ind = (int)(t / nact);
+    vec[ncoarse + (long)ind * ngridmax + igrid[i] - 1] = in[(long)ind * ngrid + i];
   }
 }
 // scan flag of the fine level: flag2(cell)/ngridmax
@@ -260,16 +265,16 @@ using namespace mgamr;
 
 hipError_t mgamr_launch_gs(const MgAmrLevel &L, const MgAmrTree &T, int color, int safe, double dx2, hipStream_t s) {
   if (L.ngrid <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gs_kernel, dim3(grid_for(4L * L.ngrid)), dim3(256), 0, s, L, T, color, safe, dx2);
+  hipLaunchKernelGGL(gs_kernel, dim3(grid_for(4L * L.nact)), dim3(256), 0, s, L, T, color, safe, dx2);
   return hipGetLastError();
 }
 hipError_t mgamr_launch_residual(const MgAmrLevel &L, const MgAmrTree &T, double oneoverdx2, hipStream_t s) {
   if (L.ngrid <= 0) return hipSuccess;
-  hipLaunchKernelGGL(residual_kernel, dim3(grid_for(8L * L.ngrid)), dim3(256), 0, s, L, T, oneoverdx2);
+  hipLaunchKernelGGL(residual_kernel, dim3(grid_for(8L * L.nact)), dim3(256), 0, s, L, T, oneoverdx2);
   return hipGetLastError();
 }
 hipError_t mgamr_launch_norm(const MgAmrLevel &L, double scale, double *partial, double *out, hipStream_t s) {
-  const int blocks = L.ngrid > 0 ? grid_for(8L * L.ngrid, 1024) : 1;
+  const int blocks = L.ngrid > 0 ? grid_for(8L * L.nact, 1024) : 1;
   if (L.ngrid > 0) hipLaunchKernelGGL(norm_kernel, dim3(blocks), dim3(256), 0, s, L, partial);
   else hipMemsetAsync(partial, 0, sizeof(double), s);
   hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, s, partial, blocks, scale, out);
@@ -281,12 +286,12 @@ hipError_t mgamr_launch_restrict(const MgAmrLevel &F, const MgAmrLevel &C, const
     hipMemsetAsync(C.u1, 0, sizeof(double) * 8 * C.ngrid, s);
   }
   if (F.ngrid <= 0 || C.ngrid <= 0) return hipGetLastError();
-  hipLaunchKernelGGL(restrict_kernel, dim3(grid_for(F.ngrid)), dim3(256), 0, s, F, C, T);
+  hipLaunchKernelGGL(restrict_kernel, dim3(grid_for(F.nact)), dim3(256), 0, s, F, C, T);
   return hipGetLastError();
 }
 hipError_t mgamr_launch_interp(const MgAmrLevel &F, const MgAmrLevel &C, const MgAmrTree &T, hipStream_t s) {
   if (F.ngrid <= 0) return hipSuccess;
-  hipLaunchKernelGGL(interp_kernel, dim3(grid_for(8L * F.ngrid)), dim3(256), 0, s, F, C, T);
+  hipLaunchKernelGGL(interp_kernel, dim3(grid_for(8L * F.nact)), dim3(256), 0, s, F, C, T);
   return hipGetLastError();
 }
 hipError_t mgamr_launch_gather(const double *vec, double *out, const int *igrid, int ngrid, long ncoarse, long ngridmax,
@@ -295,10 +300,10 @@ hipError_t mgamr_launch_gather(const double *vec, double *out, const int *igrid,
   hipLaunchKernelGGL(gather_kernel, dim3(grid_for(8L * ngrid)), dim3(256), 0, s, vec, out, igrid, ngrid, ncoarse, ngridmax);
   return hipGetLastError();
 }
-hipError_t mgamr_launch_scatter(double *vec, const double *in, const int *igrid, int ngrid, long ncoarse, long ngridmax,
+hipError_t mgamr_launch_scatter(double *vec, const double *in, const int *igrid, int nact, int ngrid, long ncoarse, long ngridmax,
                                 hipStream_t s) {
-  if (ngrid <= 0) return hipSuccess;
-  hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(8L * ngrid)), dim3(256), 0, s, vec, in, igrid, ngrid, ncoarse, ngridmax);
+  if (nact <= 0) return hipSuccess;
+  hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(8L * nact)), dim3(256), 0, s, vec, in, igrid, nact, ngrid, ncoarse, ngridmax);
   return hipGetLastError();
 }
 hipError_t mgamr_launch_gather_scan(const int *flag2, int *out, const int *igrid, int ngrid, long ncoarse, long ngridmax,

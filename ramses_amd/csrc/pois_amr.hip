@@ -346,7 +346,7 @@ struct Level {
   Buf igrid, u1, u2, u3, u4, scan;
   MgAmrLevel view() {
     MgAmrLevel L;
-    L.ngrid = ngrid; L.igrid = igrid.as<int>();
+    L.ngrid = ngrid; L.nact = ngrid; L.igrid = igrid.as<int>();
     L.u1 = u1.as<double>(); L.u2 = u2.as<double>(); L.u3 = u3.as<double>(); L.u4 = u4.as<double>();
     L.scan = scan.as<int>();
     return L;

@@ -47,16 +47,14 @@ subroutine multigrid_fine_amd(ilevel,icount)
   ! (a box with physical boundaries: the Dirichlet values enter through the masks and the
   !  right-hand side the reference prepares, so every level takes this path)
   nx_loc=icoarse_max-icoarse_min+1
-  if(ilevel>levelmin.or.nboundary>0.or.nx_loc/=1.or.jcoarse_max/=jcoarse_min.or.kcoarse_max/=kcoarse_min &
+  ! (several MPI ranks: every level takes this path too -- the reference's driver with its halo exchanges on the host,
+  !  each compute routine on the rank's GPU over its own octs and the reception octs of its neighbours)
+  if(ilevel>levelmin.or.nboundary>0.or.ncpu>1.or.nx_loc/=1.or.jcoarse_max/=jcoarse_min.or.kcoarse_max/=kcoarse_min &
        & .or.int(active(ilevel)%ngrid,8)*8_8/=(2_8**ilevel)**3*int(nx_loc,8)**3)then
-     if(ncpu>1)then
-        write(*,*)'ramses_amd: device multigrid on AMR levels handles single-rank runs; got ncpu=',ncpu
-        call ramses_amd_fatal('multigrid_fine (AMR level: several ranks)')
-     end if
      ! periodic box of one coarse cell: driver and per-solve setup on the device too (csrc/pois_amr.hip); only
      ! rho of the level and phi, phi_old of the level above travel in, phi of the level out
      ! (RAMSES_AMD_MG_DRIVER=host: the reference's driver and setup with the device operators, as with walls)
-     if(nboundary==0.and.ncoarse==1.and.ilevel>1.and.ramses_amd_mg_device_driver())then
+     if(nboundary==0.and.ncpu==1.and.ncoarse==1.and.ilevel>1.and.ramses_amd_mg_device_driver())then
         if(nremap>0)ramses_amd_tree_epoch=ramses_amd_tree_epoch+1     ! (defrag may renumber the octs)
         rc=ramses_amd_poisamr_tree(ramses_amd_tree_epoch,int(ngridmax,8),int(ncoarse,8),son,nbor,father)
         if(rc/=0)call ramses_amd_fatal('multigrid_fine (AMR level, tree)')

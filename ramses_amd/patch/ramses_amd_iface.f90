@@ -206,6 +206,28 @@ module ramses_amd_iface
        integer(c_int), value :: finelevel
        integer(c_int) :: rc
      end function ramses_amd_mgamr_interpolate
+     function ramses_amd_mgamr_level_begin(level, ngrid_total) bind(C, name='ramses_amd_mgamr_level_begin') result(rc)
+       import :: c_int
+       integer(c_int), value :: level, ngrid_total
+       integer(c_int) :: rc
+     end function ramses_amd_mgamr_level_begin
+     function ramses_amd_mgamr_level_block(level, ngrid, igrid, u, fscan) bind(C, name='ramses_amd_mgamr_level_block') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: level, ngrid
+       integer(c_int) :: igrid(*), fscan(*)
+       real(c_double) :: u(*)
+       integer(c_int) :: rc
+     end function ramses_amd_mgamr_level_block
+     function ramses_amd_mgamr_fine_active(nact) bind(C, name='ramses_amd_mgamr_fine_active') result(rc)
+       import :: c_int
+       integer(c_int), value :: nact
+       integer(c_int) :: rc
+     end function ramses_amd_mgamr_fine_active
+     function ramses_amd_mgamr_force_sync(on) bind(C, name='ramses_amd_mgamr_force_sync') result(rc)
+       import :: c_int
+       integer(c_int), value :: on
+       integer(c_int) :: rc
+     end function ramses_amd_mgamr_force_sync
      function ramses_amd_mgamr_end() bind(C, name='ramses_amd_mgamr_end') result(rc)
        import :: c_int
        integer(c_int) :: rc
@@ -604,6 +626,7 @@ module ramses_amd_iface
   integer, save :: ramses_amd_tree_epoch = 0
   ! the AMR level whose potential the device multigrid driver has just left on the device (0: none)
   integer, save :: ramses_amd_pois_amr_level = 0
+  logical, save :: ramses_amd_mg_mpi_said = .false.
 
 contains
 
@@ -698,19 +721,73 @@ contains
   subroutine ramses_amd_mg_ensure()
     use amr_commons
     use poisson_commons
-    integer :: rc, l, ilevel
+    integer :: rc, l, ilevel, icpu, ntot, n, i
+    integer, allocatable :: list(:)
     if (ramses_amd_mg_started) return
     ilevel = ramses_amd_mg_level
-    rc = ramses_amd_mgamr_begin(ilevel, int(ngridmax, 8), int(ncoarse, 8), son, nbor, father, lookup_mg, flag2(1), &   ! flag2 is (0:ncell)
-         & phi, f, active(ilevel)%ngrid, active(ilevel)%igrid)
-    if (rc /= 0) call ramses_amd_fatal('multigrid_fine (AMR level, begin)')
-    do l = 1, ilevel - 1
-       if (active_mg(myid, l)%ngrid > 0) then
-          rc = ramses_amd_mgamr_add_level(l, active_mg(myid, l)%ngrid, active_mg(myid, l)%igrid, &
-               & active_mg(myid, l)%u, active_mg(myid, l)%f)
-          if (rc /= 0) call ramses_amd_fatal('multigrid_fine (AMR level, add_level)')
+    if (ncpu == 1) then
+       rc = ramses_amd_mgamr_begin(ilevel, int(ngridmax, 8), int(ncoarse, 8), son, nbor, father, lookup_mg, flag2(1), &   ! flag2 is (0:ncell)
+            & phi, f, active(ilevel)%ngrid, active(ilevel)%igrid)
+       if (rc /= 0) call ramses_amd_fatal('multigrid_fine (AMR level, begin)')
+       do l = 1, ilevel - 1
+          if (active_mg(myid, l)%ngrid > 0) then
+             rc = ramses_amd_mgamr_add_level(l, active_mg(myid, l)%ngrid, active_mg(myid, l)%igrid, &
+                  & active_mg(myid, l)%u, active_mg(myid, l)%f)
+             if (rc /= 0) call ramses_amd_fatal('multigrid_fine (AMR level, add_level)')
+          end if
+       end do
+    else
+       ! several ranks: the level's reception octs follow the active ones (their phi, mask and residual are kept current in
+       ! the host cell vectors by the reference's make_virtual_fine_dp); every multigrid level is this rank's buffer
+       ! followed by its reception buffers active_mg(icpu,l); every device routine exchanges its arrays with the host
+       rc = ramses_amd_mgamr_force_sync(1)
+       if (.not. ramses_amd_mg_mpi_said .and. myid == 1) then
+          write(*,*) 'ramses_amd: multigrid under MPI: compute routines on the GPUs (own + reception octs), halo exchanges on the host'
+          ramses_amd_mg_mpi_said = .true.
        end if
-    end do
+       ntot = active(ilevel)%ngrid
+       do icpu = 1, ncpu
+          ntot = ntot + reception(icpu, ilevel)%ngrid
+       end do
+       allocate(list(1:max(ntot, 1)))
+       n = active(ilevel)%ngrid
+       list(1:n) = active(ilevel)%igrid(1:n)
+       do icpu = 1, ncpu
+          do i = 1, reception(icpu, ilevel)%ngrid
+             list(n + i) = reception(icpu, ilevel)%igrid(i)
+          end do
+          n = n + reception(icpu, ilevel)%ngrid
+       end do
+       rc = ramses_amd_mgamr_begin(ilevel, int(ngridmax, 8), int(ncoarse, 8), son, nbor, father, lookup_mg, flag2(1), &
+            & phi, f, ntot, list)
+       if (rc /= 0) call ramses_amd_fatal('multigrid_fine (AMR level, begin)')
+       rc = ramses_amd_mgamr_fine_active(active(ilevel)%ngrid)
+       if (rc /= 0) call ramses_amd_fatal('multigrid_fine (AMR level, fine_active)')
+       deallocate(list)
+       do l = 1, ilevel - 1
+          ntot = 0
+          do icpu = 1, ncpu
+             ntot = ntot + active_mg(icpu, l)%ngrid
+          end do
+          if (ntot == 0) cycle
+          rc = ramses_amd_mgamr_level_begin(l, ntot)
+          if (rc /= 0) call ramses_amd_fatal('multigrid_fine (AMR level, level_begin)')
+          ! this rank's own buffer first (possibly empty), then the others in rank order
+          if (active_mg(myid, l)%ngrid > 0) then
+             rc = ramses_amd_mgamr_level_block(l, active_mg(myid, l)%ngrid, active_mg(myid, l)%igrid, &
+                  & active_mg(myid, l)%u, active_mg(myid, l)%f)
+          else
+             rc = ramses_amd_mgamr_level_block(l, 0, active(ilevel)%igrid, phi, flag2(1))      ! (arrays unused)
+          end if
+          if (rc /= 0) call ramses_amd_fatal('multigrid_fine (AMR level, level_block)')
+          do icpu = 1, ncpu
+             if (icpu == myid .or. active_mg(icpu, l)%ngrid == 0) cycle
+             rc = ramses_amd_mgamr_level_block(l, active_mg(icpu, l)%ngrid, active_mg(icpu, l)%igrid, &
+                  & active_mg(icpu, l)%u, active_mg(icpu, l)%f)
+             if (rc /= 0) call ramses_amd_fatal('multigrid_fine (AMR level, level_block)')
+          end do
+       end do
+    end if
     ramses_amd_mg_started = .true.
   end subroutine ramses_amd_mg_ensure
 

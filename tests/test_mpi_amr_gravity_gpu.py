@@ -1,0 +1,73 @@
+"""GPU test of the AMR multigrid under MPI: the patched MPI program
+(oracle/_ref/ramses3d_mpi_patch) on 2 and 4 ranks runs hydro + self-gravity on AMR levels 3-5.  Every level
+(levelmin included) takes the reference's own multigrid driver with its halo exchanges on the host
+(make_virtual_fine_dp, make_virtual_mg_dp, make_reverse_mg_dp, the MPI_ALLREDUCE of the norms) and every
+compute routine -- Gauss-Seidel fine / coarse with the masked branch, residual, norm, restriction,
+prolongation -- on the rank's GPU, over the rank's own octs followed by the reception octs of its neighbours
+(csrc/capi.hip: ramses_amd_mgamr_level_begin / _level_block / _fine_active; the arrays cross PCIe around
+every routine, which is what keeps the reference's host halo code usable).  phi, f, the hydro state of every
+leaf cell and the V-cycle counts must equal the untouched MPI reference (oracle/_ref/ramses3d_mpi, same rank
+count) bit for bit."""
+import importlib.util
+import os
+import re
+import shutil
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_MPI = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi")
+PATCHED_MPI = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi_patch")
+
+
+def _mka():
+    spec = importlib.util.spec_from_file_location("mka", os.path.join(ROOT, "tests", "golden", "make_golden_amr.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _run(nml, binary, nproc, env):
+    from oracle import ramses_snapshot as rs
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return rs.run_reference(nml, binary=binary, nproc=nproc)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _sorted(snap):
+    order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+    return snap["level"][order], snap["x"][order], snap["prim"][:, order], snap["grav"][:, order]
+
+
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_amr_multigrid_under_mpi_equals_the_mpi_reference(gpu_lib, nproc):
+    if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED_MPI)):
+        pytest.skip("oracle/_ref/ramses3d_mpi[_patch] not built")
+    from oracle import ramses_snapshot as rs
+    nml = _mka().selfgrav_namelist().replace("ngridtot=6000 !", "ngridtot=60000 !")
+    workp, outp = _run(nml, PATCHED_MPI, nproc, {"RAMSES_AMD": "1"})
+    try:
+        assert "multigrid under MPI: compute routines on the GPUs" in outp, outp[-1500:]
+        sol_p = re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+)", outp)
+        got = _sorted(rs.load_leaf_cells(os.path.join(workp, "output_00002"), with_grav=True))
+    finally:
+        shutil.rmtree(workp, ignore_errors=True)
+    workr, outr = _run(nml, REF_MPI, nproc, {})
+    try:
+        sol_r = re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+)", outr)
+        ref = _sorted(rs.load_leaf_cells(os.path.join(workr, "output_00002"), with_grav=True))
+    finally:
+        shutil.rmtree(workr, ignore_errors=True)
+    assert sol_p == sol_r
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert np.array_equal(got[3], ref[3]), np.abs(got[3] - ref[3]).max()     # phi, f
+    assert np.array_equal(got[2], ref[2]), np.abs(got[2] - ref[2]).max()     # hydro state
