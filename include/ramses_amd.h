@@ -623,7 +623,7 @@ int ramses_amd_mpires_sync_host(double *uold);
 int ramses_amd_mpires_invalidate(void);
 
 /* ---------------------------------------------------------------------------
- * Residency for AMR runs (single rank, hydro).  The reference's own cell vectors
+ * Residency for AMR runs (hydro, with self-gravity on one rank).  The reference's own cell vectors
  * uold/unew(1:ncell,1:nvar) and tree arrays stay on the device between the routines of amr_step:
  *   ramses_amd_amrres_load         uold + son(1:ncell), nbor(1:ngridmax,1:6), father(1:ngridmax)
  *   ramses_amd_amrres_tree         the tree again (after refine_fine)
@@ -671,6 +671,27 @@ int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, co
                                  double err_grad_u, double floor_d, double floor_p, double floor_u, int *ok);
 int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, double dx, double dt,
                               int nvector, int interpol_var, int interpol_type);
+/* Several MPI ranks (one per GPU): the virtual-boundary exchanges of amr_step on the resident cell vectors.
+ *   make_virtual_fine_dp(uold(1,ivar),ilevel)     amr/virtual_boundaries.f90:373-528, callers amr/amr_step.f90:61,287,505
+ *   make_virtual_reverse_dp(unew(1,ivar),ilevel)  amr/virtual_boundaries.f90:693-983, caller amr/amr_step.f90:397
+ *   (and enew / divu with pressure_fix, amr/amr_step.f90:417-418); set_unew's zeroing of the virtual octs
+ *   hydro/godunov_fine.f90:92-122.
+ * comm_set hands over the communicators build_comm left for a level (emission(icpu,l)%igrid / reception(icpu,l)%igrid,
+ * concatenated in icpu order; epoch = the shim's count of build_comm calls, comm_epoch returns the one on the device, -1 if
+ * none).  dir 0: forward on uold; 1: reverse on unew; 2 / 3: reverse on enew / divu.  All nvar variables travel in one
+ * message per peer (reference: one round per variable); the reverse exchange accumulates peer by peer in icpu order, as the
+ * reference does.  Transport: ramses_amd_amrres_halo_rccl (one grouped ncclSend/ncclRecv, myid 1-based) or, with several
+ * ranks on one GPU, the caller's own MPI between halo_stage_out (pack; pinned host buffers, addresses as integers, offsets
+ * [ncpu+1] in doubles) and halo_stage_in (unpack / accumulate).
+ * ramses_amd_which_column: which column (1..ncol, 0 = none) of a host array base(1:ncell,1:ncol) an anonymous xx is. */
+int ramses_amd_which_column(const double *xx, const double *base, int64_t ncell, int ncol);
+int ramses_amd_amrres_comm_epoch(int ilevel);
+int ramses_amd_amrres_comm_set(int ilevel, int epoch, int ncpu, const int *em_n, const int *em_ig, const int *rc_n, const int *rc_ig);
+int ramses_amd_amrres_zero_unew_virtual(int ilevel);
+int ramses_amd_amrres_halo_rccl(int ilevel, int dir, int myid);
+int ramses_amd_amrres_halo_stage_out(int ilevel, int dir, int ncpu, int64_t *h_send_addr, int64_t *h_recv_addr, int64_t *send_off,
+                                     int64_t *recv_off);
+int ramses_amd_amrres_halo_stage_in(int ilevel, int dir);
 
 #ifdef __cplusplus
 }

@@ -168,6 +168,14 @@ SYMBOLS = [
     ("ramses_amd_amrres_set_uold_pfix", _i, [_PP, _i, _vp, _d, _d, _d, _d]),
     ("ramses_amd_amrres_hydro_flag", _i, [_PP, _i, _vp, _d, _d, _d, _d, _d, _d, _vp]),
     ("ramses_amd_amrres_godunov", _i, [_PP, _i, _i, _vp, _d, _d, _i, _i, _i]),
+    # AMR residency under MPI: the virtual-boundary exchanges on the resident cell vectors
+    ("ramses_amd_which_column", _i, [_vp, _vp, _i64, _i]),
+    ("ramses_amd_amrres_comm_epoch", _i, [_i]),
+    ("ramses_amd_amrres_comm_set", _i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    ("ramses_amd_amrres_zero_unew_virtual", _i, [_i]),
+    ("ramses_amd_amrres_halo_rccl", _i, [_i, _i, _i]),
+    ("ramses_amd_amrres_halo_stage_out", _i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    ("ramses_amd_amrres_halo_stage_in", _i, [_i, _i]),
 ]
 
 

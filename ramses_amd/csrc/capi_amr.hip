@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstddef>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -294,6 +296,23 @@ __global__ void lvl_pack_comp_kernel(double *vec, double *buf, const int *igrid,
   }
 }
 
+// make_virtual_reverse_dp's scatter (amr/virtual_boundaries.f90:857-867): vec(emission cells) += what the peer's virtual cells held
+__global__ void lvl_acc_comp_kernel(double *vec, const double *buf, const int *igrid, int ngrid, int ncomp, long ncell, long ncoarse, long ngridmax) {
+  const long total = (long)ngrid * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long c = ncoarse + (long)(t / ngrid) * ngridmax + igrid[t % ngrid] - 1;
+    for (int k = 0; k < ncomp; k++) vec[c + (long)k * ncell] = vec[c + (long)k * ncell] + buf[(long)k * total + t];
+  }
+}
+// set_unew's loop over the virtual octs (hydro/godunov_fine.f90:92-122): vec(cells of the octs, 1:ncomp) = 0
+__global__ void lvl_zero_comp_kernel(double *vec, const int *igrid, int ngrid, int ncomp, long ncell, long ncoarse, long ngridmax) {
+  const long total = (long)ngrid * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long c = ncoarse + (long)(t / ngrid) * ngridmax + igrid[t % ngrid] - 1;
+    for (int k = 0; k < ncomp; k++) vec[c + (long)k * ncell] = 0.0;
+  }
+}
+
 // ---- pressure_fix (hydro/godunov_fine.f90:66-83, 203-227, 294-481) -------------------------------------------------------
 // set_unew: divu = 0, enew = internal energy of uold
 __global__ __launch_bounds__(256) void lvl_pfix_init_kernel(LvlArgs A, double *__restrict__ divu, double *__restrict__ enew, double smallr) {
@@ -376,7 +395,33 @@ struct Buf {
   template <class T> T *as() { return reinterpret_cast<T *>(p); }
 };
 
+struct PinBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap && p) return hipSuccess;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    if (bytes == 0) bytes = 8;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+// MPI: the communicators of one level as build_comm left them (amr/amr_commons.f90:170-179, emission(icpu,l)%igrid and
+// reception(icpu,l)%igrid concatenated in icpu order)
+struct CommLevel {
+  int epoch = -1, ncpu = 0;
+  std::vector<int> em_first, rc_first;        // [ncpu+1] positions in the concatenated lists
+  Buf em_ig, rc_ig;
+};
+
 struct AmrRes {
+  std::vector<CommLevel> comm;                 // by level
+  Buf sendbuf, recvbuf;
+  PinBuf h_send, h_recv;
+  std::vector<int64_t> f_send_off, f_recv_off; // [ncpu+1], doubles, of the exchange that is under way
   bool valid = false;
   int nvar = 0;
   long ncell = 0, ncoarse = 0, ngridmax = 0;
@@ -732,6 +777,178 @@ int ramses_amd_amrres_set_uold_pfix(const ramses_amd_hydro_params *p, int ngrid,
   hipLaunchKernelGGL(lvl_pfix_switch_kernel, g, b, 0, nullptr, A, R.divu.as<double>(), R.enew.as<double>(), dx_loc, dt, beta_fix, hexp, p->smallr);
   HCHK(hipGetLastError(), "set_uold launch");
   return 0;
+}
+
+
+// ---- several MPI ranks: the virtual-boundary exchanges of amr_step on the resident cell vectors ----------------------------
+// (amr/virtual_boundaries.f90:373-528 make_virtual_fine_dp, :693-983 make_virtual_reverse_dp; callers amr/amr_step.f90:61,
+// 287,397,417-418,505).  The device holds the reference's own layout, so the reference's own communicators -- oct lists per
+// peer -- address it directly.  A message is what the reference sends, all variables at once: for the octs i = 1..n of the
+// list, buf[(v*8 + ind)*n + i] = vec(ncoarse + ind*ngridmax + igrid(i), v).
+
+// which column of a host array is xx?  1..ncol, or 0
+int ramses_amd_which_column(const double *xx, const double *base, int64_t ncell, int ncol) {
+  if (!xx || !base || ncell < 1 || ncol < 1) return 0;
+  const ptrdiff_t off = xx - base;
+  if (off < 0 || off % ncell != 0 || off / ncell >= ncol) return 0;
+  return (int)(off / ncell) + 1;
+}
+
+int ramses_amd_amrres_comm_epoch(int ilevel) {
+  AmrRes &R = g_ar;
+  if (ilevel < 0 || (size_t)ilevel >= R.comm.size()) return -1;
+  return R.comm[ilevel].epoch;
+}
+
+// the communicators of a level after build_comm: em_n / rc_n [ncpu] octs per peer, em_ig / rc_ig the concatenated lists
+int ramses_amd_amrres_comm_set(int ilevel, int epoch, int ncpu, const int *em_n, const int *em_ig, const int *rc_n, const int *rc_ig) {
+  AmrRes &R = g_ar;
+  if (ilevel < 1 || ilevel > 64 || ncpu < 1 || !em_n || !rc_n || epoch < 0) return failf(RAMSES_AMD_EINVAL, "comm_set: bad argument");
+  if ((size_t)ilevel >= R.comm.size()) R.comm.resize((size_t)ilevel + 1);
+  CommLevel &L = R.comm[ilevel];
+  L.epoch = -1;
+  L.ncpu = ncpu;
+  L.em_first.assign((size_t)ncpu + 1, 0); L.rc_first.assign((size_t)ncpu + 1, 0);
+  for (int c = 0; c < ncpu; c++) {
+    if (em_n[c] < 0 || rc_n[c] < 0) return failf(RAMSES_AMD_EINVAL, "comm_set: negative list length");
+    L.em_first[c + 1] = L.em_first[c] + em_n[c];
+    L.rc_first[c + 1] = L.rc_first[c] + rc_n[c];
+  }
+  const int nem = L.em_first[ncpu], nrc = L.rc_first[ncpu];
+  if ((nem > 0 && !em_ig) || (nrc > 0 && !rc_ig)) return failf(RAMSES_AMD_EINVAL, "comm_set: NULL list");
+  HCHK(L.em_ig.ensure(sizeof(int) * (size_t)(nem > 0 ? nem : 1)), "hipMalloc"); HCHK(L.rc_ig.ensure(sizeof(int) * (size_t)(nrc > 0 ? nrc : 1)), "hipMalloc");
+  if (nem > 0) HCHK(hipMemcpy(L.em_ig.p, em_ig, sizeof(int) * (size_t)nem, hipMemcpyHostToDevice), "H2D emission list");
+  if (nrc > 0) HCHK(hipMemcpy(L.rc_ig.p, rc_ig, sizeof(int) * (size_t)nrc, hipMemcpyHostToDevice), "H2D reception list");
+  L.epoch = epoch;
+  return 0;
+}
+
+namespace {
+int comm_of(AmrRes &R, int ilevel, CommLevel *&L) {
+  if (!R.valid) return failf(RAMSES_AMD_EINVAL, "no resident AMR state (ramses_amd_amrres_load)");
+  if (ilevel < 1 || (size_t)ilevel >= R.comm.size() || R.comm[ilevel].epoch < 0)
+    return failf(RAMSES_AMD_EINVAL, "level %d: no communicators on the device (ramses_amd_amrres_comm_set)", ilevel);
+  L = &R.comm[ilevel];
+  return 0;
+}
+// dir 0: make_virtual_fine_dp on uold(:,1:nvar); 1: make_virtual_reverse_dp on unew(:,1:nvar); 2 / 3: the same on enew / divu
+struct HaloSpec { double *vec; int ncomp; bool reverse; };
+int halo_spec(AmrRes &R, int dir, HaloSpec &S) {
+  switch (dir) {
+    case 0: S = {R.uold.as<double>(), R.nvar, false}; return 0;
+    case 1: S = {R.unew.as<double>(), R.nvar, true}; return 0;
+    case 2: case 3:
+      if (!R.pfix) return failf(RAMSES_AMD_EINVAL, "halo on enew/divu: pressure_fix is not enabled");
+      S = {dir == 2 ? R.enew.as<double>() : R.divu.as<double>(), 1, true}; return 0;
+  }
+  return failf(RAMSES_AMD_EINVAL, "halo: bad direction %d", dir);
+}
+// gather every peer's message into sendbuf; fills the [ncpu+1] offset tables (in doubles)
+int halo_pack(AmrRes &R, CommLevel &L, const HaloSpec &S) {
+  const std::vector<int> &sf = S.reverse ? L.rc_first : L.em_first, &rf = S.reverse ? L.em_first : L.rc_first;
+  const int *sig = S.reverse ? L.rc_ig.as<int>() : L.em_ig.as<int>();
+  const size_t per = (size_t)8 * S.ncomp;
+  R.f_send_off.assign((size_t)L.ncpu + 1, 0); R.f_recv_off.assign((size_t)L.ncpu + 1, 0);
+  for (int c = 0; c <= L.ncpu; c++) { R.f_send_off[c] = (int64_t)(per * sf[c]); R.f_recv_off[c] = (int64_t)(per * rf[c]); }
+  HCHK(R.sendbuf.ensure(sizeof(double) * per * (size_t)(sf[L.ncpu] > 0 ? sf[L.ncpu] : 1)), "hipMalloc sendbuf");
+  HCHK(R.recvbuf.ensure(sizeof(double) * per * (size_t)(rf[L.ncpu] > 0 ? rf[L.ncpu] : 1)), "hipMalloc recvbuf");
+  for (int c = 0; c < L.ncpu; c++) {
+    const int n = sf[c + 1] - sf[c];
+    if (n <= 0) continue;
+    hipLaunchKernelGGL(lvl_pack_comp_kernel<true>, dim3(grid_for((long)n * 8)), dim3(256), 0, nullptr, S.vec, R.sendbuf.as<double>() + per * sf[c],
+                       sig + sf[c], n, S.ncomp, R.ncell, R.ncoarse, R.ngridmax);
+  }
+  HCHK(hipGetLastError(), "halo pack launch");
+  return 0;
+}
+// scatter (forward) or accumulate in icpu order (reverse) what arrived in recvbuf
+int halo_unpack(AmrRes &R, CommLevel &L, const HaloSpec &S) {
+  const std::vector<int> &rf = S.reverse ? L.em_first : L.rc_first;
+  const int *rig = S.reverse ? L.em_ig.as<int>() : L.rc_ig.as<int>();
+  const size_t per = (size_t)8 * S.ncomp;
+  for (int c = 0; c < L.ncpu; c++) {
+    const int n = rf[c + 1] - rf[c];
+    if (n <= 0) continue;
+    if (S.reverse) hipLaunchKernelGGL(lvl_acc_comp_kernel, dim3(grid_for((long)n * 8)), dim3(256), 0, nullptr, S.vec, R.recvbuf.as<double>() + per * rf[c],
+                                      rig + rf[c], n, S.ncomp, R.ncell, R.ncoarse, R.ngridmax);
+    else hipLaunchKernelGGL(lvl_pack_comp_kernel<false>, dim3(grid_for((long)n * 8)), dim3(256), 0, nullptr, S.vec, R.recvbuf.as<double>() + per * rf[c],
+                            rig + rf[c], n, S.ncomp, R.ncell, R.ncoarse, R.ngridmax);
+  }
+  HCHK(hipGetLastError(), "halo unpack launch");
+  return 0;
+}
+}  // namespace
+
+// set_unew's second loop: unew (and divu, enew with pressure_fix) of the virtual octs = 0
+int ramses_amd_amrres_zero_unew_virtual(int ilevel) {
+  AmrRes &R = g_ar;
+  CommLevel *L;
+  if (int rc = comm_of(R, ilevel, L)) return rc;
+  const int n = L->rc_first[L->ncpu];
+  if (n <= 0) return 0;
+  const dim3 g(grid_for((long)n * 8)), b(256);
+  hipLaunchKernelGGL(lvl_zero_comp_kernel, g, b, 0, nullptr, R.unew.as<double>(), L->rc_ig.as<int>(), n, R.nvar, R.ncell, R.ncoarse, R.ngridmax);
+  if (R.pfix) {
+    hipLaunchKernelGGL(lvl_zero_comp_kernel, g, b, 0, nullptr, R.divu.as<double>(), L->rc_ig.as<int>(), n, 1, R.ncell, R.ncoarse, R.ngridmax);
+    hipLaunchKernelGGL(lvl_zero_comp_kernel, g, b, 0, nullptr, R.enew.as<double>(), L->rc_ig.as<int>(), n, 1, R.ncell, R.ncoarse, R.ngridmax);
+  }
+  HCHK(hipGetLastError(), "set_unew (virtual octs) launch");
+  return 0;
+}
+
+// One exchange over RCCL: pack, one grouped send/recv (a message per peer), unpack / accumulate; asynchronous
+extern "C" int ramses_amd_rccl_exchange(int npeer, const int *peer, const double *d_send, const int64_t *send_off, const int64_t *send_cnt,
+                                        double *d_recv, const int64_t *recv_off, const int64_t *recv_cnt, void *stream);
+int ramses_amd_amrres_halo_rccl(int ilevel, int dir, int myid) {
+  AmrRes &R = g_ar;
+  CommLevel *L;
+  HaloSpec S;
+  if (int rc = comm_of(R, ilevel, L)) return rc;
+  if (int rc = halo_spec(R, dir, S)) return rc;
+  if (int rc = halo_pack(R, *L, S)) return rc;
+  std::vector<int> peer;
+  std::vector<int64_t> so, sc, ro, rcn;
+  for (int c = 0; c < L->ncpu; c++) {
+    const int64_t ns = R.f_send_off[c + 1] - R.f_send_off[c], nr = R.f_recv_off[c + 1] - R.f_recv_off[c];
+    if (ns == 0 && nr == 0) continue;
+    if (c == myid - 1) return failf(RAMSES_AMD_EINVAL, "level %d: a communicator of the rank with itself", ilevel);
+    peer.push_back(c); so.push_back(R.f_send_off[c]); sc.push_back(ns); ro.push_back(R.f_recv_off[c]); rcn.push_back(nr);
+  }
+  if (int rc = ramses_amd_rccl_exchange((int)peer.size(), peer.data(), R.sendbuf.as<double>(), so.data(), sc.data(), R.recvbuf.as<double>(),
+                                        ro.data(), rcn.data(), nullptr)) return rc;
+  return halo_unpack(R, *L, S);
+}
+
+// The same with the caller's own MPI as transport (several ranks on one GPU, or no RCCL): stage_out packs on the device and
+// hands pinned host buffers over -- the message for peer icpu at h_send + send_off[icpu-1], send_off[icpu]-send_off[icpu-1]
+// doubles, likewise h_recv / recv_off -- stage_in applies what arrived.  Addresses as integers for c_f_pointer.
+int ramses_amd_amrres_halo_stage_out(int ilevel, int dir, int ncpu, int64_t *h_send_addr, int64_t *h_recv_addr, int64_t *send_off, int64_t *recv_off) {
+  AmrRes &R = g_ar;
+  CommLevel *L;
+  HaloSpec S;
+  if (!h_send_addr || !h_recv_addr || !send_off || !recv_off) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  if (int rc = comm_of(R, ilevel, L)) return rc;
+  if (ncpu != L->ncpu) return failf(RAMSES_AMD_EINVAL, "ncpu mismatch");
+  if (int rc = halo_spec(R, dir, S)) return rc;
+  if (int rc = halo_pack(R, *L, S)) return rc;
+  const size_t ns = (size_t)R.f_send_off[ncpu], nr = (size_t)R.f_recv_off[ncpu];
+  HCHK(R.h_send.ensure(sizeof(double) * (ns > 0 ? ns : 1)), "hipHostMalloc"); HCHK(R.h_recv.ensure(sizeof(double) * (nr > 0 ? nr : 1)), "hipHostMalloc");
+  if (ns > 0) HCHK(hipMemcpyAsync(R.h_send.p, R.sendbuf.p, sizeof(double) * ns, hipMemcpyDeviceToHost, nullptr), "D2H halo");
+  HCHK(hipStreamSynchronize(nullptr), "sync");
+  *h_send_addr = (int64_t)(intptr_t)R.h_send.p; *h_recv_addr = (int64_t)(intptr_t)R.h_recv.p;
+  for (int c = 0; c <= ncpu; c++) { send_off[c] = R.f_send_off[c]; recv_off[c] = R.f_recv_off[c]; }
+  return 0;
+}
+int ramses_amd_amrres_halo_stage_in(int ilevel, int dir) {
+  AmrRes &R = g_ar;
+  CommLevel *L;
+  HaloSpec S;
+  if (int rc = comm_of(R, ilevel, L)) return rc;
+  if (int rc = halo_spec(R, dir, S)) return rc;
+  if (R.f_recv_off.size() != (size_t)L->ncpu + 1) return failf(RAMSES_AMD_EINVAL, "halo stage_in without stage_out");
+  const size_t nr = (size_t)R.f_recv_off[L->ncpu];
+  if (nr > 0) HCHK(hipMemcpyAsync(R.recvbuf.p, R.h_recv.p, sizeof(double) * nr, hipMemcpyHostToDevice, nullptr), "H2D halo");
+  return halo_unpack(R, *L, S);
 }
 
 }  // extern "C"

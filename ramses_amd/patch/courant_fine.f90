@@ -65,6 +65,21 @@ subroutine courant_fine(ilevel)
      dx=0.5D0**ilevel*scale
      rc=ramses_amd_amrres_courant(p,active(ilevel)%ngrid,active(ilevel)%igrid,dx,dtnew(ilevel),out4)
      if(rc/=0)call ramses_amd_fatal('courant_fine')
+#ifndef WITHOUTMPI
+     if(ncpu>1)then
+        ! several ranks: the reference's own reductions (hydro/courant_fine.f90:133-140); the first call also
+        ! chooses the transport of the virtual-boundary exchanges (every rank is here together)
+        if(.not.ramses_amd_amr_halo_ready)then
+           call ramses_amd_halo_init()
+           ramses_amd_amr_halo_ready=.true.
+        end if
+        comm_buffin(1:3)=out4(2:4)
+        call MPI_ALLREDUCE(comm_buffin,comm_buffout,3,MPI_DOUBLE_PRECISION,MPI_SUM,MPI_COMM_WORLD,info)
+        call MPI_ALLREDUCE(out4(1),dt_all,1,MPI_DOUBLE_PRECISION,MPI_MIN,MPI_COMM_WORLD,info)
+        out4(2:4)=comm_buffout(1:3)
+        out4(1)=dt_all
+     end if
+#endif
      mass_tot=mass_tot+out4(2)
      ekin_tot=ekin_tot+out4(3)
      eint_tot=eint_tot+out4(4)

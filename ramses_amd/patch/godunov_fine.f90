@@ -44,6 +44,15 @@ subroutine set_unew(ilevel)
         rc=ramses_amd_amrres_set_unew(active(ilevel)%ngrid,active(ilevel)%igrid)
      end if
      if(rc/=0)call ramses_amd_fatal('set_unew')
+#ifndef WITHOUTMPI
+     if(ncpu>1)then
+        ! unew = 0 on the virtual octs (hydro/godunov_fine.f90:92-122): they collect the corrections the finer
+        ! level owes to cells of other ranks, which make_virtual_reverse_dp then sends home
+        call ramses_amd_amr_comm_ensure(ilevel)
+        rc=ramses_amd_amrres_zero_unew_virtual(ilevel)
+        if(rc/=0)call ramses_amd_fatal('set_unew (virtual octs)')
+     end if
+#endif
      return
   end if
   call set_unew_reference(ilevel)

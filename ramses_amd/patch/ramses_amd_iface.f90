@@ -586,6 +586,49 @@ module ramses_amd_iface
        real(c_double), value :: egd, egp, egu, fld, flp, flu
        integer(c_int) :: rc
      end function ramses_amd_amrres_hydro_flag
+     ! ---- AMR residency under MPI: the virtual-boundary exchanges on the resident cell vectors ----
+     function ramses_amd_which_column(xx, base, ncell, ncol) bind(C, name='ramses_amd_which_column') result(k)
+       import :: c_int, c_int64_t, c_double
+       real(c_double) :: xx(*), base(*)
+       integer(c_int64_t), value :: ncell
+       integer(c_int), value :: ncol
+       integer(c_int) :: k
+     end function ramses_amd_which_column
+     function ramses_amd_amrres_comm_epoch(ilevel) bind(C, name='ramses_amd_amrres_comm_epoch') result(e)
+       import :: c_int
+       integer(c_int), value :: ilevel
+       integer(c_int) :: e
+     end function ramses_amd_amrres_comm_epoch
+     function ramses_amd_amrres_comm_set(ilevel, epoch, ncpu, em_n, em_ig, rc_n, rc_ig) &
+          & bind(C, name='ramses_amd_amrres_comm_set') result(rc)
+       import :: c_int
+       integer(c_int), value :: ilevel, epoch, ncpu
+       integer(c_int) :: em_n(*), em_ig(*), rc_n(*), rc_ig(*)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_comm_set
+     function ramses_amd_amrres_zero_unew_virtual(ilevel) bind(C, name='ramses_amd_amrres_zero_unew_virtual') result(rc)
+       import :: c_int
+       integer(c_int), value :: ilevel
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_zero_unew_virtual
+     function ramses_amd_amrres_halo_rccl(ilevel, dir, myid) bind(C, name='ramses_amd_amrres_halo_rccl') result(rc)
+       import :: c_int
+       integer(c_int), value :: ilevel, dir, myid
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_halo_rccl
+     function ramses_amd_amrres_halo_stage_out(ilevel, dir, ncpu, h_send_addr, h_recv_addr, send_off, recv_off) &
+          & bind(C, name='ramses_amd_amrres_halo_stage_out') result(rc)
+       import :: c_int, c_int64_t, c_ptr
+       integer(c_int), value :: ilevel, dir, ncpu
+       type(c_ptr) :: h_send_addr, h_recv_addr        ! int64_t* on the C side: the addresses of the pinned buffers
+       integer(c_int64_t) :: send_off(*), recv_off(*)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_halo_stage_out
+     function ramses_amd_amrres_halo_stage_in(ilevel, dir) bind(C, name='ramses_amd_amrres_halo_stage_in') result(rc)
+       import :: c_int
+       integer(c_int), value :: ilevel, dir
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_halo_stage_in
      function ramses_amd_amrres_godunov(p, ilevel, ngrid, igrid, dx, dt, nvector, interpol_var, interpol_type) &
           & bind(C, name='ramses_amd_amrres_godunov') result(rc)
        import :: ramses_amd_hydro_params, c_int, c_double
@@ -624,6 +667,10 @@ module ramses_amd_iface
   ! advanced whenever the reference may have changed the tree (refine_fine); the device copies of son/nbor/father
   ! are re-sent when their epoch is behind
   integer, save :: ramses_amd_tree_epoch = 0
+  ! AMR residency with several MPI ranks: count of build_comm calls per level (the device copy of a level's
+  ! communicators is re-sent when its epoch is behind); the transport has been chosen (ramses_amd_halo_init)
+  integer, save :: ramses_amd_comm_epoch(1:64) = 1
+  logical, save :: ramses_amd_amr_halo_ready = .false.
   ! the AMR level whose potential the device multigrid driver has just left on the device (0: none)
   integer, save :: ramses_amd_pois_amr_level = 0
   logical, save :: ramses_amd_mg_mpi_said = .false.
@@ -1149,7 +1196,24 @@ contains
        if (stat == 0) then
           if (trim(val) == '0') ramses_amd_amr_ok = .false.
        end if
-       if (ncpu > 1 .or. levelmin >= nlevelmax .or. nboundary > 0 .or. nremap > 0) ramses_amd_amr_ok = .false.
+       if (levelmin >= nlevelmax .or. nboundary > 0 .or. nremap > 0) ramses_amd_amr_ok = .false.
+       if (ncpu > 1) then
+          ! several ranks: the virtual-boundary exchanges of the hydro state run on the device too
+          ! (virtual_boundaries.f90 of this directory); RAMSES_AMD_RESIDENT_AMR_MPI=0 keeps such runs staged.
+          ! With self-gravity the Poisson solve itself stays the MPI path of multigrid_fine_commons.f90 (host arrays
+          ! phi, rho, f); the device mirror of f then covers the virtual octs too.  Not yet with pressure_fix.
+          call get_environment_variable('RAMSES_AMD_RESIDENT_AMR_MPI', val, status=stat)
+          if (stat == 0) then
+             if (trim(val) == '0') ramses_amd_amr_ok = .false.
+          end if
+          if (pressure_fix .or. nlevelmax > 64) ramses_amd_amr_ok = .false.
+#ifdef WITHOUTMPI
+          ramses_amd_amr_ok = .false.
+#endif
+#ifdef LIGHT_MPI_COMM
+          ramses_amd_amr_ok = .false.     ! the condensed communicators of LIGHT_MPI_COMM are not mirrored
+#endif
+       end if
        if (.not. hydro .or. pic .or. rt .or. cooling .or. star .or. sink .or. stellar) ramses_amd_amr_ok = .false.
        ! with self-gravity too (the acceleration is mirrored on the device, rho_fine gets the density back);
        ! RAMSES_AMD_RESIDENT_GRAV=0 keeps such runs on the staging path
@@ -1194,7 +1258,8 @@ contains
     use amr_commons
     use hydro_commons
     use poisson_commons, only: f
-    integer :: rc, l
+    integer :: rc, l, nl
+    integer, allocatable :: list(:)
     if (ramses_amd_amrres_active() == 0) then
        rc = ramses_amd_amrres_load(nvar, int(ngridmax, 8), int(ncoarse, 8), uold, son, nbor, father)
        if (rc /= 0) call ramses_amd_fatal('AMR residency (load)')
@@ -1217,7 +1282,14 @@ contains
        if (rc /= 0) call ramses_amd_fatal('AMR residency (tree)')
        do l = ramses_amd_amr_reload_from, nlevelmax
           if (numbtot(1, l) > 0) then
-             rc = ramses_amd_amrres_load_level(active(l)%ngrid, active(l)%igrid, uold)
+             if (ncpu > 1) then
+                ! the virtual octs too: the host has just exchanged them itself (amr/amr_step.f90:49-62)
+                call ramses_amd_amr_level_octs(l, nl, list)
+                rc = ramses_amd_amrres_load_level(nl, list, uold)
+                deallocate(list)
+             else
+                rc = ramses_amd_amrres_load_level(active(l)%ngrid, active(l)%igrid, uold)
+             end if
              if (rc /= 0) call ramses_amd_fatal('AMR residency (level reload)')
              if (poisson) call ramses_amd_amr_load_f(l)
           end if
@@ -1231,8 +1303,17 @@ contains
     use amr_commons
     use poisson_commons
     integer, intent(in) :: ilevel
-    integer :: rc
-    rc = ramses_amd_amrres_load_f(active(ilevel)%ngrid, active(ilevel)%igrid, f)
+    integer :: rc, nl
+    integer, allocatable :: list(:)
+    if (ncpu > 1) then
+       ! the virtual octs too (force_fine has exchanged f itself, poisson/force_fine.f90:107,137): the sweep's
+       ! gravity predictor reads f of every stencil cell
+       call ramses_amd_amr_level_octs(ilevel, nl, list)
+       rc = ramses_amd_amrres_load_f(nl, list, f)
+       deallocate(list)
+    else
+       rc = ramses_amd_amrres_load_f(active(ilevel)%ngrid, active(ilevel)%igrid, f)
+    end if
     if (rc /= 0) call ramses_amd_fatal('AMR residency (acceleration)')
   end subroutine ramses_amd_amr_load_f
 
@@ -1245,20 +1326,118 @@ contains
     use amr_commons
     use hydro_commons
     integer, intent(in) :: ilevel
-    integer :: rc, l
+    integer :: rc, l, nl
+    integer, allocatable :: list(:)
     ramses_amd_tree_epoch = ramses_amd_tree_epoch + 1
     if (.not. ramses_amd_amr_resident()) return
     if (ramses_amd_amrres_active() == 0) return
     if (ilevel < levelmin) return      ! fully refined coarse levels: nothing is created, no hydro data is read
     do l = max(ilevel - 1, levelmin), min(nlevelmax, ramses_amd_amr_host_from - 1)
        if (numbtot(1, l) > 0) then
-          rc = ramses_amd_amrres_sync_level(active(l)%ngrid, active(l)%igrid, uold)
+          if (ncpu > 1) then
+             ! the virtual octs too: refine_fine interpolates the new virtual octs from them
+             call ramses_amd_amr_level_octs(l, nl, list)
+             rc = ramses_amd_amrres_sync_level(nl, list, uold)
+             deallocate(list)
+          else
+             rc = ramses_amd_amrres_sync_level(active(l)%ngrid, active(l)%igrid, uold)
+          end if
           if (rc /= 0) call ramses_amd_fatal('AMR residency (level sync before refine_fine)')
        end if
     end do
     ramses_amd_amr_host_from = min(ramses_amd_amr_host_from, max(ilevel - 1, levelmin))
     ramses_amd_amr_reload_from = min(ramses_amd_amr_reload_from, ilevel + 1)      ! refine_fine(ilevel) rebuilds level ilevel+1
   end subroutine ramses_amd_amr_refine_hook
+
+  !---------------------------------------------------------------------------
+  ! AMR residency with several MPI ranks.  The octs of a level whose cells a rank holds: its own
+  ! (active) followed by the virtual ones (reception lists of every peer).
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_amr_level_octs(ilevel, n, list)
+    use amr_commons
+    integer, intent(in) :: ilevel
+    integer, intent(out) :: n
+    integer, allocatable, intent(out) :: list(:)
+    integer :: icpu, i
+    n = active(ilevel)%ngrid
+    do icpu = 1, ncpu
+       n = n + reception(icpu, ilevel)%ngrid
+    end do
+    allocate(list(max(n, 1)))
+    do i = 1, active(ilevel)%ngrid
+       list(i) = active(ilevel)%igrid(i)
+    end do
+    n = active(ilevel)%ngrid
+    do icpu = 1, ncpu
+       do i = 1, reception(icpu, ilevel)%ngrid
+          list(n + i) = reception(icpu, ilevel)%igrid(i)
+       end do
+       n = n + reception(icpu, ilevel)%ngrid
+    end do
+  end subroutine ramses_amd_amr_level_octs
+
+#ifndef WITHOUTMPI
+  !---------------------------------------------------------------------------
+  ! The communicators of a level on the device, re-sent after build_comm rebuilt them
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_amr_comm_ensure(ilevel)
+    use amr_commons
+    integer, intent(in) :: ilevel
+    integer, allocatable :: em_n(:), em_ig(:), rc_n(:), rc_ig(:)
+    integer :: rc
+    if (ramses_amd_amrres_comm_epoch(ilevel) == ramses_amd_comm_epoch(ilevel)) return
+    call ramses_amd_comm_lists(ilevel, em_n, em_ig, rc_n, rc_ig)
+    rc = ramses_amd_amrres_comm_set(ilevel, ramses_amd_comm_epoch(ilevel), ncpu, em_n, em_ig, rc_n, rc_ig)
+    if (rc /= 0) call ramses_amd_fatal('AMR residency (communicators)')
+  end subroutine ramses_amd_amr_comm_ensure
+
+  !---------------------------------------------------------------------------
+  ! One virtual-boundary exchange on the resident cell vectors.  dir 0: make_virtual_fine_dp on
+  ! uold(1,1:nvar) (amr/virtual_boundaries.f90:373-528); 1: make_virtual_reverse_dp on unew(1,1:nvar)
+  ! (:693-983).  All nvar variables in one message per peer; RCCL, or the program's own MPI on pinned
+  ! host buffers when ranks share a GPU.
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_amr_halo(ilevel, dir)
+    use amr_commons
+    use mpi_mod
+    integer, intent(in) :: ilevel, dir
+    integer :: rc, icpu, info, nreq, cnt
+    type(c_ptr) :: hs, hr
+    real(c_double), pointer :: sbuf(:), rbuf(:)
+    integer(c_int64_t), dimension(ncpu + 1) :: soff, roff
+    integer, dimension(2*ncpu) :: req
+    integer, dimension(MPI_STATUS_SIZE, 2*ncpu) :: statuses
+    integer, parameter :: tag = 137
+    call ramses_amd_amr_comm_ensure(ilevel)
+    if (ramses_amd_halo_rccl) then
+       rc = ramses_amd_amrres_halo_rccl(ilevel, dir, myid)
+       if (rc /= 0) call ramses_amd_fatal('virtual boundaries of an AMR level (RCCL exchange)')
+       return
+    end if
+    rc = ramses_amd_amrres_halo_stage_out(ilevel, dir, ncpu, hs, hr, soff, roff)
+    if (rc /= 0) call ramses_amd_fatal('virtual boundaries of an AMR level (pack)')
+    call c_f_pointer(hs, sbuf, [max(soff(ncpu + 1), 1_8)])
+    call c_f_pointer(hr, rbuf, [max(roff(ncpu + 1), 1_8)])
+    nreq = 0
+    do icpu = 1, ncpu
+       cnt = int(roff(icpu + 1) - roff(icpu))
+       if (cnt > 0) then
+          nreq = nreq + 1
+          call MPI_IRECV(rbuf(roff(icpu) + 1), cnt, MPI_DOUBLE_PRECISION, icpu - 1, tag, MPI_COMM_WORLD, req(nreq), info)
+       end if
+    end do
+    do icpu = 1, ncpu
+       cnt = int(soff(icpu + 1) - soff(icpu))
+       if (cnt > 0) then
+          nreq = nreq + 1
+          call MPI_ISEND(sbuf(soff(icpu) + 1), cnt, MPI_DOUBLE_PRECISION, icpu - 1, tag, MPI_COMM_WORLD, req(nreq), info)
+       end if
+    end do
+    call MPI_WAITALL(nreq, req, statuses, info)
+    rc = ramses_amd_amrres_halo_stage_in(ilevel, dir)
+    if (rc /= 0) call ramses_amd_fatal('virtual boundaries of an AMR level (unpack)')
+  end subroutine ramses_amd_amr_halo
+#endif
 
   !---------------------------------------------------------------------------
   ! The reference has no error returns on this path: print and clean_stop

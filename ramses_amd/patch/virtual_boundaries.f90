@@ -18,6 +18,16 @@
 ! unpack), the calls for ivar>1 have nothing left to do.  Every other array
 ! (flag1, cpu_map, phi, rho, f, ... and uold/unew of other levels) takes the
 ! reference's host MPI path.
+!
+! AMR runs with several ranks whose hydro state is device-resident
+! (ramses_amd_iface: ramses_amd_amr_resident): the same two calls, on ANY level,
+! and the forward call after a regrid (amr/amr_step.f90:49-62), run on the
+! reference's own cell vectors on the device, addressed by the reference's own
+! communicators (emission / reception oct lists; ramses_amd_amr_halo).  The
+! reverse exchange accumulates peer by peer in icpu order like the reference
+! (:857-867).  A level the host has just rebuilt (refine_fine; it is re-sent to
+! the device before the next device routine) takes the reference's path; a level
+! current on both sides takes both, so that both stay current.
 !==============================================================================
 #define make_virtual_fine_dp make_virtual_fine_dp_reference
 #define make_virtual_reverse_dp make_virtual_reverse_dp_reference
@@ -29,6 +39,7 @@
 
 subroutine make_virtual_fine_dp(xx,ilevel)
   use amr_commons
+  use hydro_commons
   use ramses_amd_iface
   implicit none
   integer::ilevel
@@ -48,12 +59,27 @@ subroutine make_virtual_fine_dp(xx,ilevel)
         end if
      end if
   end if
+  if(ncpu>1.and.numbtot(1,ilevel)>0)then
+     if(ramses_amd_amr_resident())then
+        if(ramses_amd_amrres_active()/=0)then
+           ! (a column of the HOST unew is rho_fine's multipole scratch, pm/rho_fine.f90:815: the reference's path)
+           k=ramses_amd_which_column(xx,uold,int(ncoarse,8)+int(twotondim,8)*int(ngridmax,8),nvar)
+           if(k/=0.and.ilevel<ramses_amd_amr_reload_from)then
+              ! the device holds the level: all nvar variables in one exchange, with the call for ivar=1
+              if(k==1)call ramses_amd_amr_halo(ilevel,0)
+              ! the host copy is current as well (synced for refine_fine): keep it so with the reference's exchange
+              if(ilevel<ramses_amd_amr_host_from)return
+           end if
+        end if
+     end if
+  end if
 #endif
   call make_virtual_fine_dp_reference(xx,ilevel)
 end subroutine make_virtual_fine_dp
 
 subroutine make_virtual_reverse_dp(xx,ilevel)
   use amr_commons
+  use hydro_commons
   use ramses_amd_iface
   implicit none
   integer::ilevel
@@ -77,6 +103,24 @@ subroutine make_virtual_reverse_dp(xx,ilevel)
         end if
      end if
   end if
+  if(ncpu>1.and.numbtot(1,ilevel)>0)then
+     if(ramses_amd_amr_resident())then
+        if(ramses_amd_amrres_active()/=0)then
+           if(ramses_amd_which_column(xx,uold,int(ncoarse,8)+int(twotondim,8)*int(ngridmax,8),nvar)/=0)then
+              write(*,*)'ramses_amd: make_virtual_reverse_dp on uold of a device-resident AMR level'
+              call ramses_amd_fatal('make_virtual_reverse_dp (uold)')
+           end if
+           k=ramses_amd_which_column(xx,unew,int(ncoarse,8)+int(twotondim,8)*int(ngridmax,8),nvar)
+           if(k/=0)then
+              ! unew exists on the device only (set_unew and the sweep ran there): the corrections collected in the
+              ! virtual octs go home, all nvar variables with the call for ivar=1
+              if(ilevel>=ramses_amd_amr_reload_from)call ramses_amd_fatal('make_virtual_reverse_dp (level awaiting its reload)')
+              if(k==1)call ramses_amd_amr_halo(ilevel,1)
+              return
+           end if
+        end if
+     end if
+  end if
 #endif
   call make_virtual_reverse_dp_reference(xx,ilevel)
 end subroutine make_virtual_reverse_dp
@@ -95,6 +139,8 @@ subroutine build_comm(ilevel)
   !--------------------------------------------------------------------------
 #ifndef WITHOUTMPI
   integer::rc
+  ! AMR residency: the device copy of this level's communicators is stale from here on
+  if(ilevel>=1.and.ilevel<=64)ramses_amd_comm_epoch(ilevel)=ramses_amd_comm_epoch(ilevel)+1
   if(ramses_amd_mpi_on.and.ilevel==levelmin)then
      if(ramses_amd_mpires_active()/=0)then
         rc=ramses_amd_mpires_sync_host(uold)

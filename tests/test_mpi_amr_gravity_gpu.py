@@ -48,14 +48,18 @@ def _sorted(snap):
     return snap["level"][order], snap["x"][order], snap["prim"][:, order], snap["grav"][:, order]
 
 
-@pytest.mark.parametrize("nproc", [2, 4])
-def test_amr_multigrid_under_mpi_equals_the_mpi_reference(gpu_lib, nproc):
+@pytest.mark.parametrize("nproc,resident", [(2, "1"), (4, "1"), (2, "0")])
+def test_amr_multigrid_under_mpi_equals_the_mpi_reference(gpu_lib, nproc, resident):
+    """resident=1 (default): the hydro state and the tree stay on every rank's GPU as well (virtual-boundary
+    exchanges of uold / unew on the device, the acceleration mirrored incl. the virtual octs, density back for
+    rho_fine); resident=0 (RAMSES_AMD_RESIDENT_AMR_MPI=0): hydro arrays staged around every call."""
     if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED_MPI)):
         pytest.skip("oracle/_ref/ramses3d_mpi[_patch] not built")
     from oracle import ramses_snapshot as rs
     nml = _mka().selfgrav_namelist().replace("ngridtot=6000 !", "ngridtot=60000 !")
-    workp, outp = _run(nml, PATCHED_MPI, nproc, {"RAMSES_AMD": "1"})
+    workp, outp = _run(nml, PATCHED_MPI, nproc, {"RAMSES_AMD": "1", "RAMSES_AMD_RESIDENT_AMR_MPI": resident})
     try:
+        assert ("AMR levels stay resident on the GPU" in outp) == (resident == "1"), outp[-1500:]
         assert "multigrid under MPI: compute routines on the GPUs" in outp, outp[-1500:]
         sol_p = re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+)", outp)
         got = _sorted(rs.load_leaf_cells(os.path.join(workp, "output_00002"), with_grav=True))
