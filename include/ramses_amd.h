@@ -453,8 +453,8 @@ int ramses_amd_prof_add(const char *name, int level, double seconds);
  * make_virtual_fine_dp, make_boundary_phi, cmp_residual_cg :52-85).  On return phi and f hold
  * what the reference's loop leaves; *iter = iterations, err[0] = last rms residual
  * (:186), err[1] = the first, err[2] = rhs_norm (:63-78, 0 if rho is NULL).
- * fact = fourpi*dx^2/6 (:45), ncell_level = twotondim*numbtot(1,ilevel).  One rank (the dot
- * products are not reduced over MPI).  ordered != 0: the dot products are summed in the
+ * fact = fourpi*dx^2/6 (:45), ncell_level = twotondim*numbtot(1,ilevel).  One rank (several: the
+ * ramses_amd_cgmpi_* routines below).  ordered != 0: the dot products are summed in the
  * reference's order (bit-identical, slow); 0: fixed parallel tree (deterministic, phi equal to
  * ~1e-13 relative); < 0: taken from the environment (RAMSES_AMD_CG_ORDERED=1).
  * ------------------------------------------------------------------------- */
@@ -462,6 +462,22 @@ int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int 
                              int64_t ngridmax, int64_t ncoarse, double *phi, double *f, const double *rho_or_null,
                              double rho_tot, double fact, double ncell_level, double epsilon, int itermax,
                              int ordered, int *iter, double *err);
+/* The same loop with several MPI ranks (the two MPI_ALLREDUCEs per iteration poisson/phi_fine_cg.f90:108,154 and the halo
+ * exchange of p :134 stay with the caller): cgmpi_begin uploads the state (arguments as above; ngrid may be 0) and returns
+ * out2 = {local rhs norm^2, local r.r}; cgmpi_step runs one routine of the loop body on the rank's octs -- 0: p = r + beta p,
+ * 1: z = A p and the local p.z, 2: x += alpha p, r -= alpha z and the local r.r -- with alpha, beta formed on the device from
+ * the device scalars (slot 0 r.r, 1 r.r of the previous iteration, 2 p.z), which the caller reads (cgmpi_get), reduces over the
+ * ranks and writes back (cgmpi_set).  cgmpi_p_cells moves the cells of the listed octs of p between the device and the host
+ * array f(:,2) (emission octs out before, reception octs in after the reference's make_virtual_fine_dp(f(1,2),ilevel)).
+ * cgmpi_end brings phi and f back. */
+int ramses_amd_cgmpi_begin(int ilevel, int ngrid, const int *igrid, const int *son, const int *nbor, int64_t ngridmax, int64_t ncoarse,
+                           const double *phi, double *f, const double *rho_or_null, double rho_tot, double fact, int ordered,
+                           double *out2);
+int ramses_amd_cgmpi_get(int slot, double *val);
+int ramses_amd_cgmpi_set(int slot, double val);
+int ramses_amd_cgmpi_step(int step, int iter);
+int ramses_amd_cgmpi_p_cells(int n, const int *igrid, int to_host);
+int ramses_amd_cgmpi_end(double *phi, double *f);
 
 /* ---------------------------------------------------------------------------
  * Device-resident level.  For a fully refined periodic

@@ -118,6 +118,12 @@ SYMBOLS = [
     ("ramses_amd_resident_force_fine_f90", _i, [_i, _d, _vp]),
     ("ramses_amd_resident_sync_poisson_f90", _i, [_vp, _vp, _vp]),
     ("ramses_amd_cg_solve_host", _i, [_i, _i, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _i, _i, _vp, _vp]),
+    ("ramses_amd_cgmpi_begin", _i, [_i, _i, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _d, _d, _i, _vp]),
+    ("ramses_amd_cgmpi_get", _i, [_i, _vp]),
+    ("ramses_amd_cgmpi_set", _i, [_i, _d]),
+    ("ramses_amd_cgmpi_step", _i, [_i, _i]),
+    ("ramses_amd_cgmpi_p_cells", _i, [_i, _vp, _i]),
+    ("ramses_amd_cgmpi_end", _i, [_vp, _vp]),
     ("ramses_amd_resident_courant_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _d, _vp]),
     ("ramses_amd_resident_godunov_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _d]),
     ("ramses_amd_resident_set_uold_f90", _i, [_i]),

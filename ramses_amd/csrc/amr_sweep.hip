@@ -389,18 +389,52 @@ struct GrpLds {
     double u[512][NV];     // primitive variables of the 8^3 stencil (until the traces are done)
     GrpFaces<NV> f;
   };
-  int fc[64];              // the 4^3 father cells (1-based cell index, 0: not there)
-  int ex[64];              // their son oct (0: not refined)
+  // tab[0..63]    fc: the 4^3 father cells (1-based cell index, 0: not there)
+  // tab[64..127]  ex: their son oct (0: not refined)
+  // tab[128..191] px: position of the son oct of each father cell in the call's list (-1: none / not in the list)
+  int tab[192];
   int io[8];               // position of each son of the father oct in the call's list (-1: not active)
-  int px[64];              // position of the son oct of each father cell in the call's list (-1: none / not in the list)
   unsigned char ok[512];   // cell is refined
 };
 __device__ __forceinline__ int gsidx(int i, int j, int k) { return i + 8 * (j + 8 * k); }
 __device__ __forceinline__ int gface(int a, int b, int c) { return a * 16 + b + 4 * c; }
 
+// father cell t (of the 4^3 around father oct gF): x, then y, then z steps through son(nbor(...)), the arithmetic
+// of getnborfather; 0 when an oct on that path does not exist
+__device__ __forceinline__ int group_father_cell(const AmrSweepArgs &A, int gF, int t) {
+  const int i = t & 3, j = (t >> 2) & 3, k = t >> 4;
+  const int bi = i == 0 ? 0 : (i == 3 ? 1 : i - 1), bj = j == 0 ? 0 : (j == 3 ? 1 : j - 1), bk = k == 0 ? 0 : (k == 3 ? 1 : k - 1);
+  int c = (int)(A.ncoarse + (long)(bi + 2 * bj + 4 * bk) * A.ngridmax + gF);
+  const int step[3] = {i == 0 ? -1 : (i == 3 ? 1 : 0), j == 0 ? -1 : (j == 3 ? 1 : 0), k == 0 ? -1 : (k == 3 ? 1 : 0)};
+#pragma unroll
+  for (int axis = 0; axis < 3; axis++) {
+    if (step[axis] != 0 && c > 0) {
+      c = nbor_cell(c, 2 * axis + (step[axis] > 0 ? 1 : 0), A);
+      if (c < 0) c = 0;                      // no oct there: only octs that do not exist would need it
+    }
+  }
+  return c;
+}
+
+// The walk of every group in a pass of its own (one thread per father cell, nothing but dependent loads: the
+// latency hides behind thousands of waves here, not behind the four groups a CU holds in the sweep kernel):
+// walk[g*192 + t] = father cell, [+64] its son oct, [+128] the son's position in the call's list
+__global__ __launch_bounds__(256) void amr_group_walk_kernel(AmrSweepArgs A, const int *__restrict__ groups, int ngroups,
+                                                             const int *__restrict__ posof, int *__restrict__ walk) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)ngroups * 64) return;
+  const int g = (int)(e >> 6), t = (int)(e & 63);
+  const int c = group_father_cell(A, groups[g], t);
+  const int og = c > 0 ? A.son[c - 1] : 0;
+  int *w = walk + (long)g * 192;
+  w[t] = c;
+  w[64 + t] = og;
+  w[128 + t] = og > 0 ? posof[og - 1] : -1;
+}
+
 template <int ST, int RS, bool GRAV, int NV, int SCHEME>
 __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_group_kernel(AmrSweepArgs A, const int *__restrict__ groups,
-                                                                 const int *__restrict__ posof) {
+                                                                 const int *__restrict__ posof, const int *__restrict__ walk) {
   __shared__ GrpLds<NV> L;
   const int t = threadIdx.x;
   const HydroConst &P = A.P;
@@ -408,29 +442,18 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
   const long ncell = A.ncell;
 
   // ---- (A) the 4^3 father cells around the father oct --------------------------------
-  if (t < 64) {
-    const int i = t & 3, j = (t >> 2) & 3, k = t >> 4;
-    const int bi = i == 0 ? 0 : (i == 3 ? 1 : i - 1), bj = j == 0 ? 0 : (j == 3 ? 1 : j - 1), bk = k == 0 ? 0 : (k == 3 ? 1 : k - 1);
-    int c = (int)(A.ncoarse + (long)(bi + 2 * bj + 4 * bk) * A.ngridmax + gF);
-    const int step[3] = {i == 0 ? -1 : (i == 3 ? 1 : 0), j == 0 ? -1 : (j == 3 ? 1 : 0), k == 0 ? -1 : (k == 3 ? 1 : 0)};
-#pragma unroll
-    for (int axis = 0; axis < 3; axis++) {
-      if (step[axis] != 0 && c > 0) {
-        c = nbor_cell(c, 2 * axis + (step[axis] > 0 ? 1 : 0), A);
-        if (c < 0) c = 0;                      // no oct there: only octs that do not exist would need it
-      }
-    }
-    L.fc[t] = c;
+  if (walk) {
+    // the pre-pass has walked: one coalesced 768-byte read (fc, ex, px are contiguous)
+    if (t < 192) L.tab[t] = walk[(long)blockIdx.x * 192 + t];
+  } else if (t < 64) {
+    const int c = group_father_cell(A, gF, t);
+    L.tab[t] = c;
     const int og_t = c > 0 ? A.son[c - 1] : 0;
-    L.ex[t] = og_t;
-    L.px[t] = og_t > 0 ? posof[og_t - 1] : -1;
+    L.tab[64 + t] = og_t;
+    L.tab[128 + t] = og_t > 0 ? posof[og_t - 1] : -1;
   }
   __syncthreads();
-  if (t < 8) {
-    const int f = (1 + (t & 1)) + 4 * ((1 + ((t >> 1) & 1)) + 4 * (1 + (t >> 2)));
-    const int og = L.ex[f];
-    L.io[t] = og > 0 ? posof[og - 1] : -1;
-  }
+  if (t < 8) L.io[t] = L.tab[128 + (1 + (t & 1)) + 4 * ((1 + ((t >> 1) & 1)) + 4 * (1 + (t >> 2)))];
 
   // ---- (B)+(C) gather the 8^3 stencil, convert to primitive variables ------------------
   const double dtxhalf = A.dt * 0.5;
@@ -439,13 +462,13 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
     // cell vectors: lanes run over the father cells first (the same octant of sibling octs is contiguous);
     // packed records: over the octants first (the 8 values of a variable are 64 contiguous bytes, sibling octs follow)
     const int ind = packed ? (e & 7) : (e >> 6), f = packed ? (e >> 3) : (e & 63);
-    const int og = L.ex[f];
+    const int og = L.tab[64 + f];
     if (og > 0) {
       const int i3 = 2 * (f & 3) + (ind & 1), j3 = 2 * ((f >> 2) & 3) + ((ind >> 1) & 1), k3 = 2 * (f >> 4) + (ind >> 2);
       const int s = gsidx(i3, j3, k3);
       double u[NV], q[NV], gz[3] = {0.0, 0.0, 0.0};
       bool refined;
-      const int px = L.px[f];
+      const int px = L.tab[128 + f];
       if (packed && px >= 0) {
         const double *__restrict__ r = A.packed + (long)px * A.rec;
 #pragma unroll
@@ -471,8 +494,8 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
       L.ok[s] = refined;
     }
   }
-  if (t < 64 && L.ex[t] == 0) {
-    const int c0 = L.fc[t];
+  if (t < 64 && L.tab[64 + t] == 0) {
+    const int c0 = L.tab[t];
     const int i0 = 2 * (t & 3), j0 = 2 * ((t >> 2) & 3), k0 = 2 * (t >> 4);
     if (c0 > 0) {
       // missing oct: interpolate the father cell with its 2*ndim neighbours
@@ -516,7 +539,7 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
   __syncthreads();
 
   // a father cell that an active son needs and that does not exist: the tree breaks the refinement rules
-  if (t < 64 && L.fc[t] == 0) {
+  if (t < 64 && L.tab[t] == 0) {
     const int i = t & 3, j = (t >> 2) & 3, k = t >> 4;
     for (int so = 0; so < 8; so++) {
       const int dxs = i - (1 + (so & 1)), dys = j - (1 + ((so >> 1) & 1)), dzs = k - (1 + (so >> 2));
@@ -601,7 +624,7 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
     const int x = t & 3, y = (t >> 2) & 3, z = t >> 4;
     const int so = (x >> 1) + 2 * (y >> 1) + 4 * (z >> 1);
     if (L.io[so] >= 0) {
-      const int og = L.ex[(1 + (x >> 1)) + 4 * ((1 + (y >> 1)) + 4 * (1 + (z >> 1)))];
+      const int og = L.tab[64 + (1 + (x >> 1)) + 4 * ((1 + (y >> 1)) + 4 * (1 + (z >> 1)))];
       const int ind = (x & 1) + 2 * (y & 1) + 4 * (z & 1);
       const long cell = A.ncoarse + (long)ind * A.ngridmax + og;
       const int ic[3] = {x, y, z};
@@ -624,7 +647,7 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
     const int io = L.io[so];
     if (io >= 0) {
       const int sc[3] = {so & 1, (so >> 1) & 1, so >> 2};
-      const int og = L.ex[(1 + sc[0]) + 4 * ((1 + sc[1]) + 4 * (1 + sc[2]))];
+      const int og = L.tab[64 + (1 + sc[0]) + 4 * ((1 + sc[1]) + 4 * (1 + sc[2]))];
       const int nb = A.nbor[(long)f * A.ngridmax + og - 1];
       const bool coarse = A.son[nb - 1] == 0;
       A.corr_tgt[(long)io * 6 + f] = coarse ? nb : 0;
@@ -765,20 +788,20 @@ __global__ __launch_bounds__(256) void amr_coarse_update_kernel(AmrSweepArgs A, 
 }
 
 template <int ST, int RS, int NV>
-static hipError_t launch3(const AmrSweepArgs &A, const int *groups, int ngroups, const int *posof, hipStream_t s) {
+static hipError_t launch3(const AmrSweepArgs &A, const int *groups, int ngroups, const int *posof, const int *walk, hipStream_t s) {
   if (ngroups > 0) {
     const dim3 grid(ngroups), block(GRP_THREADS);
     if (A.scheme == 1) {
       if constexpr (NV == 5) {
-        if (A.grav) hipLaunchKernelGGL((amr_group_kernel<ST, RS, true, NV, 1>), grid, block, 0, s, A, groups, posof);
-        else hipLaunchKernelGGL((amr_group_kernel<ST, RS, false, NV, 1>), grid, block, 0, s, A, groups, posof);
+        if (A.grav) hipLaunchKernelGGL((amr_group_kernel<ST, RS, true, NV, 1>), grid, block, 0, s, A, groups, posof, walk);
+        else hipLaunchKernelGGL((amr_group_kernel<ST, RS, false, NV, 1>), grid, block, 0, s, A, groups, posof, walk);
         return hipGetLastError();
       } else {
         return hipErrorInvalidValue;
       }
     }
-    if (A.grav) hipLaunchKernelGGL((amr_group_kernel<ST, RS, true, NV, 0>), grid, block, 0, s, A, groups, posof);
-    else hipLaunchKernelGGL((amr_group_kernel<ST, RS, false, NV, 0>), grid, block, 0, s, A, groups, posof);
+    if (A.grav) hipLaunchKernelGGL((amr_group_kernel<ST, RS, true, NV, 0>), grid, block, 0, s, A, groups, posof, walk);
+    else hipLaunchKernelGGL((amr_group_kernel<ST, RS, false, NV, 0>), grid, block, 0, s, A, groups, posof, walk);
     return hipGetLastError();
   }
   const int blocks = (A.ngrid + OCTS_PER_BLOCK - 1) / OCTS_PER_BLOCK;
@@ -798,23 +821,23 @@ static hipError_t launch3(const AmrSweepArgs &A, const int *groups, int ngroups,
   return hipGetLastError();
 }
 template <int ST, int RS>
-static hipError_t launch2(const AmrSweepArgs &A, const int *groups, int ngroups, const int *posof, hipStream_t s) {
+static hipError_t launch2(const AmrSweepArgs &A, const int *groups, int ngroups, const int *posof, const int *walk, hipStream_t s) {
   switch (A.nvar) {
-    case 5: return launch3<ST, RS, 5>(A, groups, ngroups, posof, s);
-    case 6: return launch3<ST, RS, 6>(A, groups, ngroups, posof, s);
-    case 7: return launch3<ST, RS, 7>(A, groups, ngroups, posof, s);
+    case 5: return launch3<ST, RS, 5>(A, groups, ngroups, posof, walk, s);
+    case 6: return launch3<ST, RS, 6>(A, groups, ngroups, posof, walk, s);
+    case 7: return launch3<ST, RS, 7>(A, groups, ngroups, posof, walk, s);
   }
   return hipErrorInvalidValue;
 }
 
 template <int ST>
-static hipError_t launch1(const AmrSweepArgs &A, int rs, const int *groups, int ngroups, const int *posof, hipStream_t s) {
+static hipError_t launch1(const AmrSweepArgs &A, int rs, const int *groups, int ngroups, const int *posof, const int *walk, hipStream_t s) {
   switch (rs) {
-    case RIEMANN_LLF: return launch2<ST, RIEMANN_LLF>(A, groups, ngroups, posof, s);
-    case RIEMANN_HLLC: return launch2<ST, RIEMANN_HLLC>(A, groups, ngroups, posof, s);
-    case RIEMANN_HLL: return launch2<ST, RIEMANN_HLL>(A, groups, ngroups, posof, s);
-    case RIEMANN_ACOUSTIC: return launch2<ST, RIEMANN_ACOUSTIC>(A, groups, ngroups, posof, s);
-    case RIEMANN_EXACT: return launch2<ST, RIEMANN_EXACT>(A, groups, ngroups, posof, s);
+    case RIEMANN_LLF: return launch2<ST, RIEMANN_LLF>(A, groups, ngroups, posof, walk, s);
+    case RIEMANN_HLLC: return launch2<ST, RIEMANN_HLLC>(A, groups, ngroups, posof, walk, s);
+    case RIEMANN_HLL: return launch2<ST, RIEMANN_HLL>(A, groups, ngroups, posof, walk, s);
+    case RIEMANN_ACOUSTIC: return launch2<ST, RIEMANN_ACOUSTIC>(A, groups, ngroups, posof, walk, s);
+    case RIEMANN_EXACT: return launch2<ST, RIEMANN_EXACT>(A, groups, ngroups, posof, walk, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -835,6 +858,7 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A_in, int slope_type, int riem
   // carries is on; RAMSES_AMD_AMR_GROUP=0 forces the single-oct kernel (A/B).
   int *groups = posof + A.ngridmax, *count = groups + A.ngrid;     // workspace tail (ramses_amd_godunov_fine_amr_workspace)
   int ngroups = 0;
+  const int *walk = nullptr;
   static int use_groups = -1;
   if (use_groups < 0) {
     const char *env = getenv("RAMSES_AMD_AMR_GROUP");
@@ -854,6 +878,26 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A_in, int slope_type, int riem
       const char *env = getenv("RAMSES_AMD_AMR_PACK");
       use_pack = !(env && env[0] == '0');
     }
+    // the father-cell walk of all groups in a pass of its own (RAMSES_AMD_AMR_WALK=0: inside the sweep kernel, A/B)
+    static int use_walk = -1;
+    if (use_walk < 0) {
+      const char *env = getenv("RAMSES_AMD_AMR_WALK");
+      use_walk = !(env && env[0] == '0');
+    }
+    if (use_walk && ngroups > 0) {
+      static int *walk_buf = nullptr;         // grow-only scratch of the library (768 bytes per father oct)
+      static size_t walk_cap = 0;
+      const size_t need = sizeof(int) * 192 * (size_t)ngroups;
+      if (need > walk_cap) {
+        if (walk_buf) { (void)hipFree(walk_buf); walk_buf = nullptr; walk_cap = 0; }
+        e = hipMalloc(reinterpret_cast<void **>(&walk_buf), need + need / 4);
+        if (e != hipSuccess) return e;
+        walk_cap = need + need / 4;
+      }
+      const long nthr = (long)ngroups * 64;
+      hipLaunchKernelGGL(amr_group_walk_kernel, dim3((int)((nthr + 255) / 256)), dim3(256), 0, s, A, groups, ngroups, posof, walk_buf);
+      walk = walk_buf;
+    }
     if (use_pack && pack_area && ngroups > 0) {
       const int nvt = A.nvar + (A.grav ? 3 : 0);
       const int rec = amr_pack_rec(A.nvar, A.grav != nullptr);
@@ -862,12 +906,12 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A_in, int slope_type, int riem
     }
   }
   switch (slope_type) {
-    case 0: e = launch1<0>(A, riemann, groups, ngroups, posof, s); break;
-    case 1: e = launch1<1>(A, riemann, groups, ngroups, posof, s); break;
-    case 2: e = launch1<2>(A, riemann, groups, ngroups, posof, s); break;
-    case 3: e = launch1<3>(A, riemann, groups, ngroups, posof, s); break;
-    case 7: e = launch1<7>(A, riemann, groups, ngroups, posof, s); break;
-    case 8: e = launch1<8>(A, riemann, groups, ngroups, posof, s); break;
+    case 0: e = launch1<0>(A, riemann, groups, ngroups, posof, walk, s); break;
+    case 1: e = launch1<1>(A, riemann, groups, ngroups, posof, walk, s); break;
+    case 2: e = launch1<2>(A, riemann, groups, ngroups, posof, walk, s); break;
+    case 3: e = launch1<3>(A, riemann, groups, ngroups, posof, walk, s); break;
+    case 7: e = launch1<7>(A, riemann, groups, ngroups, posof, walk, s); break;
+    case 8: e = launch1<8>(A, riemann, groups, ngroups, posof, walk, s); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;

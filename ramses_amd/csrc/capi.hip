@@ -1845,6 +1845,167 @@ int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int 
   err_out[0] = error; err_out[1] = error_ini; err_out[2] = rhs_norm;
   return 0;
 }
+
+// ---------------------------------------------------------------------------
+// The same solver with several MPI ranks: the reference's loop stays in the caller (the Fortran shim), which owns
+// the two MPI_ALLREDUCEs per iteration (poisson/phi_fine_cg.f90:108,154) and the halo exchange of p (:134); every
+// loop body is a device routine on the rank's octs.  Local sums land in the device scalars; the caller reads them
+// (cgmpi_get), reduces them over the ranks and writes the global value back (cgmpi_set) before the next routine
+// uses it -- alpha and beta are formed on the device from those scalars as in the single-rank loop.  The virtual
+// cells of p travel through the host array f(:,2) around the reference's own make_virtual_fine_dp.
+// ---------------------------------------------------------------------------
+extern "C++" {
+namespace {
+struct CgMpi {
+  bool open = false;
+  CgLevel L;
+  long ncell = 0;
+  double *h_f = nullptr;
+  DevBuf list, pack;
+  std::vector<double> hpack;
+};
+CgMpi g_cgm;
+
+__global__ void cg_cells_kernel(double *vec, double *buf, const int *igrid, int n, long ncoarse, long ngridmax, int gather) {
+  const long total = (long)n * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long c = ncoarse + (t / n) * ngridmax + igrid[t % n] - 1;
+    if (gather) buf[t] = vec[c]; else vec[c] = buf[t];
+  }
+}
+}  // namespace
+}  // extern "C++"
+
+// upload the state the loop starts from (as ramses_amd_cg_solve_host); out2 = {local rhs norm^2 (0 without rho), local r.r}
+int ramses_amd_cgmpi_begin(int ilevel, int ngrid, const int *igrid, const int *son, const int *nbor, int64_t ngridmax, int64_t ncoarse,
+                           const double *phi, double *f, const double *rho_or_null, double rho_tot, double fact, int ordered,
+                           double *out2) {
+  if (!son || !nbor || !phi || !f || !out2 || (ngrid > 0 && !igrid)) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (ngrid < 0 || ngridmax < ngrid || ncoarse < 1) return fail(RAMSES_AMD_EINVAL, "bad level sizes (ngrid=%d)", ngrid);
+  if (ilevel < 1 || ilevel > 30) return fail(RAMSES_AMD_EINVAL, "bad level %d", ilevel);
+  if (int rc = resident_release("phi_fine_cg")) return rc;
+  CgCtx &G = g_cg;
+  CgMpi &M = g_cgm;
+  hipStream_t s = nullptr;
+  if (ordered < 0) {
+    const char *e = getenv("RAMSES_AMD_CG_ORDERED");
+    ordered = e && e[0] == '1';
+  }
+  const long ncell = ncoarse + 8 * ngridmax;
+  const size_t vb = sizeof(double) * ncell;
+  const int ng1 = ngrid > 0 ? ngrid : 1;
+  HCHK(G.son.ensure(sizeof(int) * ncell), "hipMalloc son");
+  HCHK(G.nbor.ensure(sizeof(int) * 6 * ngridmax), "hipMalloc nbor");
+  HCHK(G.igrid.ensure(sizeof(int) * ng1), "hipMalloc igrid");
+  HCHK(G.nb.ensure(sizeof(int) * 6 * (size_t)ng1), "hipMalloc nb");
+  HCHK(G.x.ensure(vb), "hipMalloc x"); HCHK(G.r.ensure(vb), "hipMalloc r");
+  HCHK(G.p.ensure(vb), "hipMalloc p"); HCHK(G.z.ensure(vb), "hipMalloc z");
+  HCHK(G.scal.ensure(sizeof(double) * 8), "hipMalloc"); HCHK(G.partial.ensure(sizeof(double) * CG_MAX_BLOCKS), "hipMalloc");
+  if (ordered) HCHK(G.prod.ensure(sizeof(double) * 8 * (size_t)ng1), "hipMalloc prod");
+  if (!G.pin) {
+    HCHK(hipHostMalloc(reinterpret_cast<void **>(&G.pin), sizeof(double) * 8, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
+    HCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&G.pin_dev), G.pin, 0), "hipHostGetDevicePointer");
+    for (int k = 0; k < 4; k++) HCHK(hipEventCreateWithFlags(&G.ev[k], hipEventDisableTiming), "hipEventCreate");
+  }
+  HCHK(hipMemcpyAsync(G.son.p, son, sizeof(int) * ncell, hipMemcpyHostToDevice, s), "H2D son");
+  HCHK(hipMemcpyAsync(G.nbor.p, nbor, sizeof(int) * 6 * ngridmax, hipMemcpyHostToDevice, s), "H2D nbor");
+  if (ngrid > 0) HCHK(hipMemcpyAsync(G.igrid.p, igrid, sizeof(int) * ngrid, hipMemcpyHostToDevice, s), "H2D igrid");
+  HCHK(hipMemcpyAsync(G.x.p, phi, vb, hipMemcpyHostToDevice, s), "H2D phi");
+  HCHK(hipMemcpyAsync(G.r.p, f, vb, hipMemcpyHostToDevice, s), "H2D r");
+  HCHK(hipMemcpyAsync(G.p.p, f + ncell, vb, hipMemcpyHostToDevice, s), "H2D p");
+  HCHK(hipMemcpyAsync(G.z.p, f + 2 * ncell, vb, hipMemcpyHostToDevice, s), "H2D z");
+  HCHK(hipMemsetAsync(G.scal.p, 0, sizeof(double) * 8, s), "memset");
+  HCHK(cg_launch_setup(G.igrid.as<int>(), ngrid, G.son.as<int>(), G.nbor.as<int>(), ngridmax, G.nb.as<int>(), s), "cg setup");
+  CgLevel &L = M.L;
+  L.ngrid = ngrid; L.igrid = G.igrid.as<int>(); L.nb = G.nb.as<int>(); L.ncoarse = ncoarse; L.ngridmax = ngridmax;
+  L.x = G.x.as<double>(); L.r = G.r.as<double>(); L.p = G.p.as<double>(); L.z = G.z.as<double>();
+  L.host_r2 = G.pin_dev;
+  L.scal = G.scal.as<double>(); L.partial = G.partial.as<double>(); L.prod = ordered ? G.prod.as<double>() : nullptr;
+  M.ncell = ncell; M.h_f = f;
+  out2[0] = 0.0; out2[1] = 0.0;
+  if (rho_or_null) {
+    HCHK(G.rho.ensure(vb), "hipMalloc rho");
+    HCHK(hipMemcpyAsync(G.rho.p, rho_or_null, vb, hipMemcpyHostToDevice, s), "H2D rho");
+    HCHK(cg_launch_rhs_norm(L, G.rho.as<double>(), rho_tot, fact * fact, s), "cg rhs norm");
+    HCHK(hipMemcpyAsync(&out2[0], L.scal + CG_RHS, sizeof(double), hipMemcpyDeviceToHost, s), "D2H rhs");
+  }
+  HCHK(cg_launch_dot_rr(L, 1, s), "cg dot");
+  HCHK(hipMemcpyAsync(&out2[1], L.scal + CG_R2, sizeof(double), hipMemcpyDeviceToHost, s), "D2H r2");
+  HCHK(hipStreamSynchronize(s), "sync");
+  M.open = true;
+  return 0;
+}
+#define CGM_OPEN(what) do { if (!g_cgm.open) return fail(RAMSES_AMD_EINVAL, "%s: no CG solve is open (ramses_amd_cgmpi_begin)", what); } while (0)
+// device scalars: slot 0 r.r, 1 r.r of the previous iteration, 2 p.Ap
+int ramses_amd_cgmpi_get(int slot, double *val) {
+  CGM_OPEN("cgmpi_get");
+  if (slot < 0 || slot > 3 || !val) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  HCHK(hipMemcpy(val, g_cgm.L.scal + slot, sizeof(double), hipMemcpyDeviceToHost), "D2H scalar");
+  return 0;
+}
+int ramses_amd_cgmpi_set(int slot, double val) {
+  CGM_OPEN("cgmpi_set");
+  if (slot < 0 || slot > 3) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  HCHK(hipMemcpy(g_cgm.L.scal + slot, &val, sizeof(double), hipMemcpyHostToDevice), "H2D scalar");
+  return 0;
+}
+// step 0: p = r + beta p (:116-133); 1: z = A p and the local p.z (:139-153); 2: x += alpha p, r -= alpha z and the local r.r
+// of the next iteration (:160-183, :98-105)
+int ramses_amd_cgmpi_step(int step, int iter) {
+  CGM_OPEN("cgmpi_step");
+  hipError_t e;
+  switch (step) {
+    case 0: e = cg_launch_update_p(g_cgm.L, iter, nullptr); break;
+    case 1: e = cg_launch_ap(g_cgm.L, nullptr); break;
+    case 2: e = cg_launch_update_xr(g_cgm.L, nullptr); break;
+    default: return fail(RAMSES_AMD_EINVAL, "bad step %d", step);
+  }
+  HCHK(e, "cg step");
+  return 0;
+}
+// cells of the listed octs of p: device -> host array f(:,2) (to_host != 0: the emission octs before the exchange) or
+// host -> device (the reception octs after it)
+int ramses_amd_cgmpi_p_cells(int n, const int *igrid, int to_host) {
+  CGM_OPEN("cgmpi_p_cells");
+  CgMpi &M = g_cgm;
+  if (n < 0 || (n > 0 && !igrid)) return fail(RAMSES_AMD_EINVAL, "bad oct list");
+  if (n == 0) return 0;
+  const long tot = (long)n * 8;
+  double *hp = M.h_f + M.ncell;      // f(:,2)
+  HCHK(M.list.ensure(sizeof(int) * (size_t)n), "hipMalloc"); HCHK(M.pack.ensure(sizeof(double) * (size_t)tot), "hipMalloc");
+  HCHK(hipMemcpy(M.list.p, igrid, sizeof(int) * (size_t)n, hipMemcpyHostToDevice), "H2D list");
+  M.hpack.resize((size_t)tot);
+  int nb = (int)((tot + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  if (to_host) {
+    hipLaunchKernelGGL(cg_cells_kernel, dim3(nb), dim3(256), 0, nullptr, M.L.p, M.pack.as<double>(), M.list.as<int>(), n, M.L.ncoarse, M.L.ngridmax, 1);
+    HCHK(hipGetLastError(), "gather launch");
+    HCHK(hipMemcpy(M.hpack.data(), M.pack.p, sizeof(double) * (size_t)tot, hipMemcpyDeviceToHost), "D2H p");
+    for (int ind = 0; ind < 8; ind++)
+      for (int i = 0; i < n; i++) hp[M.L.ncoarse + (long)ind * M.L.ngridmax + igrid[i] - 1] = M.hpack[(size_t)ind * n + i];
+  } else {
+    for (int ind = 0; ind < 8; ind++)
+      for (int i = 0; i < n; i++) M.hpack[(size_t)ind * n + i] = hp[M.L.ncoarse + (long)ind * M.L.ngridmax + igrid[i] - 1];
+    HCHK(hipMemcpy(M.pack.p, M.hpack.data(), sizeof(double) * (size_t)tot, hipMemcpyHostToDevice), "H2D p");
+    hipLaunchKernelGGL(cg_cells_kernel, dim3(nb), dim3(256), 0, nullptr, M.L.p, M.pack.as<double>(), M.list.as<int>(), n, M.L.ncoarse, M.L.ngridmax, 0);
+    HCHK(hipGetLastError(), "scatter launch");
+  }
+  return 0;
+}
+// phi and f = (r, p, A p) back into the host arrays (what the reference's loop leaves)
+int ramses_amd_cgmpi_end(double *phi, double *f) {
+  CGM_OPEN("cgmpi_end");
+  if (!phi || !f) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  CgCtx &G = g_cg;
+  const size_t vb = sizeof(double) * g_cgm.ncell;
+  HCHK(hipMemcpy(phi, G.x.p, vb, hipMemcpyDeviceToHost), "D2H phi");
+  HCHK(hipMemcpy(f, G.r.p, vb, hipMemcpyDeviceToHost), "D2H r");
+  HCHK(hipMemcpy(f + g_cgm.ncell, G.p.p, vb, hipMemcpyDeviceToHost), "D2H p");
+  HCHK(hipMemcpy(f + 2 * g_cgm.ncell, G.z.p, vb, hipMemcpyDeviceToHost), "D2H z");
+  g_cgm.open = false;
+  return 0;
+}
+#undef CGM_OPEN
 #undef HCHK
 
 // ---------------------------------------------------------------------------

@@ -300,6 +300,32 @@ hipError_t cg_launch_iteration(const CgLevel &L, int iter, int slot, hipStream_t
   return hipGetLastError();
 }
 
+// the three routines of an iteration one by one (several MPI ranks: a reduction over the ranks sits between them)
+hipError_t cg_launch_update_p(const CgLevel &L, int iter, hipStream_t s) {
+  hipLaunchKernelGGL(update_p_kernel, dim3(blocks_for(L.ngrid)), dim3(TPB), 0, s, L, iter);
+  return hipGetLastError();
+}
+hipError_t cg_launch_ap(const CgLevel &L, hipStream_t s) {
+  const int nb = blocks_for(L.ngrid);
+  if (L.prod) {
+    hipLaunchKernelGGL(ap_kernel<false>, dim3(nb), dim3(TPB), 0, s, L);
+    launch_final(L, nb, CG_PAP, -1, s);
+  } else {
+    hipLaunchKernelGGL(ap_kernel<true>, dim3(nb), dim3(TPB), 0, s, L);
+  }
+  return hipGetLastError();
+}
+hipError_t cg_launch_update_xr(const CgLevel &L, hipStream_t s) {
+  const int nb = blocks_for(L.ngrid);
+  if (L.prod) {
+    hipLaunchKernelGGL(update_xr_kernel<false>, dim3(nb), dim3(TPB), 0, s, L, -1);
+    launch_final(L, nb, CG_R2, -1, s);
+  } else {
+    hipLaunchKernelGGL(update_xr_kernel<true>, dim3(nb), dim3(TPB), 0, s, L, -1);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace ramses_amd
 
 #include "warm.hpp"

@@ -29,5 +29,9 @@ hipError_t cg_launch_dot_rr(const CgLevel &L, int slot, hipStream_t s);
 // one iteration (:96-183): p = r + beta p; z = A p; pAp; x += alpha p; r -= alpha z; r2 of the new r
 // (stored to host_r2[slot]).  Three launches (parallel sums) or five (ordered sums).
 hipError_t cg_launch_iteration(const CgLevel &L, int iter, int slot, hipStream_t s);
+// its three routines one by one (several MPI ranks: the caller reduces scal[CG_PAP] / scal[CG_R2] over the ranks in between)
+hipError_t cg_launch_update_p(const CgLevel &L, int iter, hipStream_t s);
+hipError_t cg_launch_ap(const CgLevel &L, hipStream_t s);
+hipError_t cg_launch_update_xr(const CgLevel &L, hipStream_t s);
 
 }  // namespace ramses_amd

@@ -161,6 +161,45 @@ module ramses_amd_iface
        integer(c_int) :: iter
        integer(c_int) :: rc
      end function ramses_amd_cg_solve_host
+     ! the same loop with several MPI ranks, one routine at a time (the shim owns the MPI_ALLREDUCEs and the halo of p)
+     function ramses_amd_cgmpi_begin(ilevel, ngrid, igrid, son, nbor, ngridmax, ncoarse, phi, f, rho, rho_tot, fact, ordered, &
+          & out2) bind(C, name='ramses_amd_cgmpi_begin') result(rc)
+       import :: c_int, c_int64_t, c_double
+       integer(c_int), value :: ilevel, ngrid, ordered
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       real(c_double), value :: rho_tot, fact
+       integer(c_int) :: igrid(*), son(*), nbor(*)
+       real(c_double) :: phi(*), f(*), rho(*), out2(2)
+       integer(c_int) :: rc
+     end function ramses_amd_cgmpi_begin
+     function ramses_amd_cgmpi_get(slot, val) bind(C, name='ramses_amd_cgmpi_get') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: slot
+       real(c_double) :: val
+       integer(c_int) :: rc
+     end function ramses_amd_cgmpi_get
+     function ramses_amd_cgmpi_set(slot, val) bind(C, name='ramses_amd_cgmpi_set') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: slot
+       real(c_double), value :: val
+       integer(c_int) :: rc
+     end function ramses_amd_cgmpi_set
+     function ramses_amd_cgmpi_step(step, iter) bind(C, name='ramses_amd_cgmpi_step') result(rc)
+       import :: c_int
+       integer(c_int), value :: step, iter
+       integer(c_int) :: rc
+     end function ramses_amd_cgmpi_step
+     function ramses_amd_cgmpi_p_cells(n, igrid, to_host) bind(C, name='ramses_amd_cgmpi_p_cells') result(rc)
+       import :: c_int
+       integer(c_int), value :: n, to_host
+       integer(c_int) :: igrid(*)
+       integer(c_int) :: rc
+     end function ramses_amd_cgmpi_p_cells
+     function ramses_amd_cgmpi_end(phi, f) bind(C, name='ramses_amd_cgmpi_end') result(rc)
+       import :: c_int, c_double
+       real(c_double) :: phi(*), f(*)
+       integer(c_int) :: rc
+     end function ramses_amd_cgmpi_end
 
      ! ---- multigrid on AMR levels (include/ramses_amd.h) ----
      function ramses_amd_mgamr_begin(ilevel, ngridmax, ncoarse, son, nbor, father, lookup_mg, flag2, phi, f, &
@@ -1201,12 +1240,12 @@ contains
           ! several ranks: the virtual-boundary exchanges of the hydro state run on the device too
           ! (virtual_boundaries.f90 of this directory); RAMSES_AMD_RESIDENT_AMR_MPI=0 keeps such runs staged.
           ! With self-gravity the Poisson solve itself stays the MPI path of multigrid_fine_commons.f90 (host arrays
-          ! phi, rho, f); the device mirror of f then covers the virtual octs too.  Not yet with pressure_fix.
+          ! phi, rho, f); the device mirror of f then covers the virtual octs too.
           call get_environment_variable('RAMSES_AMD_RESIDENT_AMR_MPI', val, status=stat)
           if (stat == 0) then
              if (trim(val) == '0') ramses_amd_amr_ok = .false.
           end if
-          if (pressure_fix .or. nlevelmax > 64) ramses_amd_amr_ok = .false.
+          if (nlevelmax > 64) ramses_amd_amr_ok = .false.
 #ifdef WITHOUTMPI
           ramses_amd_amr_ok = .false.
 #endif

@@ -118,6 +118,17 @@ subroutine make_virtual_reverse_dp(xx,ilevel)
               if(k==1)call ramses_amd_amr_halo(ilevel,1)
               return
            end if
+           if(pressure_fix)then
+              ! enew / divu are device vectors there (scratch of one hydro step, amr/amr_step.f90:417-418)
+              if(ramses_amd_which_column(xx,enew,int(ncoarse,8)+int(twotondim,8)*int(ngridmax,8),1)==1)then
+                 call ramses_amd_amr_halo(ilevel,2)
+                 return
+              end if
+              if(ramses_amd_which_column(xx,divu,int(ncoarse,8)+int(twotondim,8)*int(ngridmax,8),1)==1)then
+                 call ramses_amd_amr_halo(ilevel,3)
+                 return
+              end if
+           end if
         end if
      end if
   end if

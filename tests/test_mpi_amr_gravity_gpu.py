@@ -75,3 +75,43 @@ def test_amr_multigrid_under_mpi_equals_the_mpi_reference(gpu_lib, nproc, reside
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
     assert np.array_equal(got[3], ref[3]), np.abs(got[3] - ref[3]).max()     # phi, f
     assert np.array_equal(got[2], ref[2]), np.abs(got[2] - ref[2]).max()     # hydro state
+
+
+@pytest.mark.parametrize("nproc,ordered", [(2, "1"), (4, "1"), (2, "0")])
+def test_cg_levels_under_mpi_equal_the_mpi_reference(gpu_lib, nproc, ordered):
+    """phi_fine_cg under MPI: cg_levelmin=4, so levels 4 and 5 of the self-gravitating AMR run
+    are solved by the conjugate-gradient loop -- every loop body on the rank's GPU (ramses_amd_cgmpi_*), the two
+    MPI_ALLREDUCEs per iteration (poisson/phi_fine_cg.f90:108,154) and the halo of p (:134) in the shim.  Ordered
+    local sums: iteration counts, phi, f and the hydro state equal the MPI reference bit for bit; parallel sums:
+    equal to rounding with the same iteration counts (+-1)."""
+    if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED_MPI)):
+        pytest.skip("oracle/_ref/ramses3d_mpi[_patch] not built")
+    from oracle import ramses_snapshot as rs
+    spec = importlib.util.spec_from_file_location("mkcg", os.path.join(ROOT, "tests", "golden", "make_golden_cg.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    nml = mk.cg_namelist().replace("ngridtot=6000 !", "ngridtot=60000 !")
+    pat = r"==> Level=\s*(\d+) Step=\s*(\d+)"
+    workp, outp = _run(nml, PATCHED_MPI, nproc, {"RAMSES_AMD": "1", "RAMSES_AMD_CG_ORDERED": ordered})
+    try:
+        assert "Entering phi_fine_cg" not in outp or "MI355X" in outp
+        sol_p = np.array([[int(a), int(b)] for a, b in re.findall(pat, outp)])
+        got = _sorted(rs.load_leaf_cells(os.path.join(workp, "output_00002"), with_grav=True))
+    finally:
+        shutil.rmtree(workp, ignore_errors=True)
+    workr, outr = _run(nml, REF_MPI, nproc, {})
+    try:
+        sol_r = np.array([[int(a), int(b)] for a, b in re.findall(pat, outr)])
+        ref = _sorted(rs.load_leaf_cells(os.path.join(workr, "output_00002"), with_grav=True))
+    finally:
+        shutil.rmtree(workr, ignore_errors=True)
+    assert len(sol_r) > 0 and {4, 5} <= set(int(l) for l in sol_r[:, 0])
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    if ordered == "1":
+        assert np.array_equal(sol_p, sol_r)
+        assert np.array_equal(got[3], ref[3]), np.abs(got[3] - ref[3]).max()     # phi, f
+        assert np.array_equal(got[2], ref[2]), np.abs(got[2] - ref[2]).max()     # hydro state
+    else:
+        assert sol_p.shape == sol_r.shape and np.abs(sol_p - sol_r).max() <= 1
+        assert np.abs(got[3] - ref[3]).max() <= 1e-9 * np.abs(ref[3]).max()
+        assert np.abs(got[2] - ref[2]).max() <= 1e-11 * np.abs(ref[2]).max()

@@ -46,10 +46,12 @@ def _mka():
     return mka
 
 
-def _namelist(lmin, lmax, nsub, riemann, slope, nstep, init=None):
+def _namelist(lmin, lmax, nsub, riemann, slope, nstep, init=None, pfix=False):
     from oracle import ramses_snapshot as rs
     mka = _mka()
     kw = {} if init is None else {"init": init}
+    if pfix:      # pressure_fix: divu / enew travel through make_virtual_reverse_dp as well (amr/amr_step.f90:417-418)
+        riemann = riemann + "'\npressure_fix=.true.\nbeta_fix=0.5\n!'"
     nml = rs.sedov3d_namelist(level=lmin, nstepmax=nstep, foutput=nstep, riemann=riemann, slope_type=slope,
                               extra=mka.REFINE.format(ivar=0, itype=2), mem_factor=1.0, **kw)
     nml = nml.replace("levelmax=%d" % lmin, "levelmax=%d" % lmax).replace("nsubcycle=10*1", "nsubcycle=" + nsub)
@@ -77,15 +79,16 @@ def _leaves(work, k):
     return snap["level"][order], snap["x"][order], snap["prim"][:, order], snap["info"]["t"]
 
 
-@pytest.mark.parametrize("nproc,lmin,lmax,nsub,riemann,slope,nstep,init", [
-    (2, 3, 5, "1,1,2,2", "llf", 1, 6, None),
-    (4, 4, 6, "1,1,2,2", "hllc", 2, 5, OFF_CENTRE),
-    (2, 5, 7, "10*2", "llf", 1, 4, OFF_CENTRE),
+@pytest.mark.parametrize("nproc,lmin,lmax,nsub,riemann,slope,nstep,init,pfix", [
+    (2, 3, 5, "1,1,2,2", "llf", 1, 6, None, False),
+    (4, 4, 6, "1,1,2,2", "hllc", 2, 5, OFF_CENTRE, False),
+    (2, 5, 7, "10*2", "llf", 1, 4, OFF_CENTRE, False),
+    (2, 3, 5, "1,1,2,2", "hllc", 1, 5, None, True),
 ])
-def test_amr_resident_under_mpi_equals_mpi_reference(gpu_lib, nproc, lmin, lmax, nsub, riemann, slope, nstep, init):
+def test_amr_resident_under_mpi_equals_mpi_reference(gpu_lib, nproc, lmin, lmax, nsub, riemann, slope, nstep, init, pfix):
     if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED_MPI)):
         pytest.skip("oracle/_ref/ramses3d_mpi[_patch] not built")
-    nml = _namelist(lmin, lmax, nsub, riemann, slope, nstep, init)
+    nml = _namelist(lmin, lmax, nsub, riemann, slope, nstep, init, pfix)
     workp, outp = _run(nml, PATCHED_MPI, nproc, {"RAMSES_AMD": "1"})
     try:
         assert "AMR levels stay resident on the GPU" in outp, outp[-3000:]
