@@ -63,7 +63,7 @@ subroutine courant_fine(ilevel)
      nx_loc=icoarse_max-icoarse_min+1
      scale=boxlen/dble(nx_loc)
      dx=0.5D0**ilevel*scale
-     rc=ramses_amd_amrres_courant(p,active(ilevel)%ngrid,active(ilevel)%igrid,dx,dtnew(ilevel),out4)
+     rc=ramses_amd_amrres_courant(p,active(ilevel)%ngrid,ramses_amd_octs(ilevel),dx,dtnew(ilevel),out4)
      if(rc/=0)call ramses_amd_fatal('courant_fine')
 #ifndef WITHOUTMPI
      if(ncpu>1)then
@@ -99,10 +99,10 @@ subroutine courant_fine(ilevel)
 
   if(poisson)then
      ! cmpdt with the gravity term (hydro/courant_fine.f90:77-85)
-     rc=ramses_amd_resident_courant_grav_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+     rc=ramses_amd_resident_courant_grav_f90(p,ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),xg, &
           & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,f,dx,dtnew(ilevel),out4)
   else
-     rc=ramses_amd_resident_courant_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+     rc=ramses_amd_resident_courant_f90(p,ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),xg, &
           & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,dx,dtnew(ilevel),out4)
   end if
   if(rc/=0)call ramses_amd_fatal('courant_fine')

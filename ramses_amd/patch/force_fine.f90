@@ -57,8 +57,8 @@ subroutine force_fine_amd(ilevel,icount)
      end if
      tfrac=0.0d0
      if(dtold(ilevel-1)>0)tfrac=1d0*dtnew(ilevel)/dtold(ilevel-1)*(icount-1)
-     rc=ramses_amd_poisamr_force(ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,active(ilevel-1)%ngrid, &
-          & active(ilevel-1)%igrid,phi,phi_old,rho,f,tfrac,1,fresh,fact,diag)
+     rc=ramses_amd_poisamr_force(ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),active(ilevel-1)%ngrid, &
+          & ramses_amd_octs(ilevel-1),phi,phi_old,rho,f,tfrac,1,fresh,fact,diag)
      if(rc/=0)call ramses_amd_fatal('force_fine (AMR level)')
      epot_tot=epot_tot+diag(1)
      rho_max(ilevel)=diag(2)
@@ -88,7 +88,7 @@ subroutine force_fine_amd(ilevel,icount)
      if(ilevel<nlevelmax)then
         if(numbtot(1,ilevel+1)>0)has_son=1
      end if
-     rc=ramses_amd_force_fine_f90(ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+     rc=ramses_amd_force_fine_f90(ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),xg, &
           & int(ngridmax,8),int(ncoarse,8),nx_loc,phi,f,rho,son,has_son,fact,diag)
   end if
   if(rc/=0)call ramses_amd_fatal('force_fine')

@@ -39,9 +39,9 @@ subroutine set_unew(ilevel)
      call ramses_amd_amr_ensure()
      if(pressure_fix)then
         call ramses_amd_fill_hydro_params(p)
-        rc=ramses_amd_amrres_set_unew_pfix(p,active(ilevel)%ngrid,active(ilevel)%igrid)
+        rc=ramses_amd_amrres_set_unew_pfix(p,active(ilevel)%ngrid,ramses_amd_octs(ilevel))
      else
-        rc=ramses_amd_amrres_set_unew(active(ilevel)%ngrid,active(ilevel)%igrid)
+        rc=ramses_amd_amrres_set_unew(active(ilevel)%ngrid,ramses_amd_octs(ilevel))
      end if
      if(rc/=0)call ramses_amd_fatal('set_unew')
 #ifndef WITHOUTMPI
@@ -87,12 +87,12 @@ subroutine set_uold(ilevel)
      call ramses_amd_fill_hydro_params(p)
      if(pressure_fix)then
         ! (+ add_gravity_source_terms with poisson), add_pdv_source_terms, uold = unew, the energy switch
-        rc=ramses_amd_amrres_set_uold_pfix(p,active(ilevel)%ngrid,active(ilevel)%igrid,dtnew(ilevel), &
+        rc=ramses_amd_amrres_set_uold_pfix(p,active(ilevel)%ngrid,ramses_amd_octs(ilevel),dtnew(ilevel), &
              & 0.5d0**ilevel*boxlen/dble(icoarse_max-icoarse_min+1),beta_fix,hexp)
      else if(poisson)then
-        rc=ramses_amd_amrres_set_uold_grav(p,active(ilevel)%ngrid,active(ilevel)%igrid,dtnew(ilevel))
+        rc=ramses_amd_amrres_set_uold_grav(p,active(ilevel)%ngrid,ramses_amd_octs(ilevel),dtnew(ilevel))
      else
-        rc=ramses_amd_amrres_set_uold(p,active(ilevel)%ngrid,active(ilevel)%igrid)
+        rc=ramses_amd_amrres_set_uold(p,active(ilevel)%ngrid,ramses_amd_octs(ilevel))
      end if
      if(rc/=0)call ramses_amd_fatal('set_uold')
      return
@@ -152,7 +152,7 @@ subroutine godunov_fine(ilevel)
   ! AMR run with the state and the tree resident on the device: the tree-walking sweep in place
   if(ramses_amd_amr_resident())then
      call ramses_amd_amr_ensure()
-     rc=ramses_amd_amrres_godunov(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,dx,dtnew(ilevel), &
+     rc=ramses_amd_amrres_godunov(p,ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),dx,dtnew(ilevel), &
           & nvector,interpol_var,interpol_type)
      if(rc/=0)call ramses_amd_fatal('godunov_fine')
      return
@@ -179,34 +179,34 @@ subroutine godunov_fine(ilevel)
   if(amr_level)then
      ! f, divu, enew exist only with poisson resp. pressure_fix: uold stands in (never read)
      if(poisson.and.pressure_fix)then
-        rc=ramses_amd_godunov_fine_amr_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,son,nbor,father, &
+        rc=ramses_amd_godunov_fine_amr_f90(p,ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),son,nbor,father, &
              & int(ngridmax,8),int(ncoarse,8),uold,unew,f,1,divu,enew,1,dx,dtnew(ilevel),nvector,interpol_var,interpol_type)
      else if(poisson)then
-        rc=ramses_amd_godunov_fine_amr_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,son,nbor,father, &
+        rc=ramses_amd_godunov_fine_amr_f90(p,ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),son,nbor,father, &
              & int(ngridmax,8),int(ncoarse,8),uold,unew,f,1,uold,uold,0,dx,dtnew(ilevel),nvector,interpol_var,interpol_type)
      else if(pressure_fix)then
-        rc=ramses_amd_godunov_fine_amr_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,son,nbor,father, &
+        rc=ramses_amd_godunov_fine_amr_f90(p,ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),son,nbor,father, &
              & int(ngridmax,8),int(ncoarse,8),uold,unew,uold,0,divu,enew,1,dx,dtnew(ilevel),nvector,interpol_var,interpol_type)
      else
-        rc=ramses_amd_godunov_fine_amr_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,son,nbor,father, &
+        rc=ramses_amd_godunov_fine_amr_f90(p,ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),son,nbor,father, &
              & int(ngridmax,8),int(ncoarse,8),uold,unew,uold,0,uold,uold,0,dx,dtnew(ilevel),nvector,interpol_var,interpol_type)
      end if
   else if(ramses_amd_resident())then
      ! state already on the device (loaded by courant_fine or here); unew stays there
      if(poisson)then
-        rc=ramses_amd_resident_godunov_grav_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+        rc=ramses_amd_resident_godunov_grav_f90(p,ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),xg, &
              & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,f,dx,dtnew(ilevel))
      else
-        rc=ramses_amd_resident_godunov_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+        rc=ramses_amd_resident_godunov_f90(p,ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),xg, &
              & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,dx,dtnew(ilevel))
      end if
   else if(poisson)then
      has_f=1
-     rc=ramses_amd_godunov_fine_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+     rc=ramses_amd_godunov_fine_f90(p,ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),xg, &
           & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,unew,f,has_f,dx,dtnew(ilevel))
   else
      has_f=0
-     rc=ramses_amd_godunov_fine_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+     rc=ramses_amd_godunov_fine_f90(p,ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),xg, &
           & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,unew,uold,has_f,dx,dtnew(ilevel))
   end if
   if(rc/=0)call ramses_amd_fatal('godunov_fine')

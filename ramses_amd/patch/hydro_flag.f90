@@ -42,7 +42,7 @@ subroutine hydro_flag(ilevel)
   call ramses_amd_fill_hydro_params(p)
   ncache=active(ilevel)%ngrid
   allocate(okdev(1:twotondim*ncache))
-  rc=ramses_amd_amrres_hydro_flag(p,ncache,active(ilevel)%igrid,dble(err_grad_d),dble(err_grad_p),dble(err_grad_u), &
+  rc=ramses_amd_amrres_hydro_flag(p,ncache,ramses_amd_octs(ilevel),dble(err_grad_d),dble(err_grad_p),dble(err_grad_u), &
        & dble(floor_d),dble(floor_p),dble(floor_u),okdev)
   if(rc/=0)call ramses_amd_fatal('hydro_flag')
 

@@ -28,7 +28,7 @@ subroutine upload_fine(ilevel)
   if(verbose)write(*,111)ilevel
   call ramses_amd_amr_ensure()
   call ramses_amd_fill_hydro_params(p)
-  rc=ramses_amd_amrres_upload_fine(p,active(ilevel)%ngrid,active(ilevel)%igrid,interpol_var)
+  rc=ramses_amd_amrres_upload_fine(p,active(ilevel)%ngrid,ramses_amd_octs(ilevel),interpol_var)
   if(rc/=0)call ramses_amd_fatal('upload_fine')
 111 format('   Entering upload_fine (MI355X) for level',i2)
 end subroutine upload_fine

@@ -73,8 +73,8 @@ subroutine multigrid_fine_amd(ilevel,icount)
         end if
         isafe=0
         if(safe_mode(ilevel))isafe=1
-        rc=ramses_amd_poisamr_multigrid(ilevel,active(ilevel)%ngrid,active(ilevel)%igrid, &
-             & active(ilevel-1)%ngrid,active(ilevel-1)%igrid,phi,phi_old,rho,flag2(1),rho_tot,fourpi,tfrac,interp, &
+        rc=ramses_amd_poisamr_multigrid(ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel), &
+             & active(ilevel-1)%ngrid,ramses_amd_octs(ilevel-1),phi,phi_old,rho,flag2(1),rho_tot,fourpi,tfrac,interp, &
              & epsilon,ngs_fine,ngs_coarse,ncycles_coarse_safe,isafe,iters,err)
         if(rc/=0)call ramses_amd_fatal('multigrid_fine (AMR level)')
         safe_mode(ilevel)=(isafe/=0)
@@ -114,7 +114,7 @@ subroutine multigrid_fine_amd(ilevel,icount)
      ! the source is already on the device (rho_fine shim), phi stays there for force_fine
      rc=ramses_amd_resident_multigrid_f90(ilevel,rho_tot,fourpi,epsilon,isafe,iters,err)
   else
-     rc=ramses_amd_multigrid_fine_f90(ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+     rc=ramses_amd_multigrid_fine_f90(ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),xg, &
           & int(ngridmax,8),int(ncoarse,8),nx_loc,rho,phi,rho_tot,fourpi,epsilon,isafe,iters,err)
   end if
   if(rc/=0)call ramses_amd_fatal('multigrid_fine')

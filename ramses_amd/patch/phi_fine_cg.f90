@@ -72,7 +72,7 @@ subroutine phi_fine_cg(ilevel,icount)
      return
   end if
 #endif
-  rc=ramses_amd_cg_solve_host(ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,son,nbor,int(ngridmax,8),int(ncoarse,8), &
+  rc=ramses_amd_cg_solve_host(ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),son,nbor,int(ngridmax,8),int(ncoarse,8), &
        & phi,f,rho,rho_tot,fact,dble(twotondim)*dble(numbtot(1,ilevel)),epsilon,itermax,-1,iter,err)
   if(rc/=0)call ramses_amd_fatal('phi_fine_cg')
 
@@ -113,7 +113,7 @@ subroutine phi_fine_cg_mpi(ilevel,fact,itermax,iter,err)
 
   call ramses_amd_comm_lists(ilevel,em_n,em_ig,rc_n,rc_ig)
   nem=sum(em_n); nrc=sum(rc_n)
-  rc=ramses_amd_cgmpi_begin(ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,son,nbor,int(ngridmax,8),int(ncoarse,8), &
+  rc=ramses_amd_cgmpi_begin(ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),son,nbor,int(ngridmax,8),int(ncoarse,8), &
        & phi,f,rho,rho_tot,fact,-1,out2)
   if(rc/=0)call ramses_amd_fatal('phi_fine_cg (begin)')
   call MPI_ALLREDUCE(out2,out2_all,2,MPI_DOUBLE_PRECISION,MPI_SUM,MPI_COMM_WORLD,info)

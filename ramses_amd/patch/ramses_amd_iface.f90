@@ -679,6 +679,8 @@ module ramses_amd_iface
      end function ramses_amd_amrres_godunov
   end interface
 
+  ! stands in for active(l)%igrid where a rank holds no oct of a level (see ramses_amd_octs)
+  integer, target, save :: ramses_amd_no_octs(1) = 0
   logical, save :: ramses_amd_checked = .false.
   logical, save :: ramses_amd_on = .true.
   ! AMR multigrid: the reference driver is running with the device routines (set by the
@@ -715,6 +717,23 @@ module ramses_amd_iface
   logical, save :: ramses_amd_mg_mpi_said = .false.
 
 contains
+
+  !---------------------------------------------------------------------------
+  ! The oct list of a level as an actual argument.  active(l)%igrid is a POINTER component that the reference
+  ! allocates only while active(l)%ngrid > 0 (amr/virtual_boundaries.f90 build_comm; amr/init_amr.f90 leaves it
+  ! undefined): with several ranks a rank may hold no oct of a level that exists, and handing the undefined
+  ! pointer to an assumed-size dummy makes the compiler inspect a garbage descriptor (contiguity check / copy-in).
+  !---------------------------------------------------------------------------
+  function ramses_amd_octs(ilevel) result(p)
+    use amr_commons, only: active
+    integer, intent(in) :: ilevel
+    integer, pointer :: p(:)
+    if (active(ilevel)%ngrid > 0) then
+       p => active(ilevel)%igrid
+    else
+       p => ramses_amd_no_octs
+    end if
+  end function ramses_amd_octs
 
   !---------------------------------------------------------------------------
   ! Run-time A/B switch: RAMSES_AMD=0 in the environment selects the untouched
@@ -813,7 +832,7 @@ contains
     ilevel = ramses_amd_mg_level
     if (ncpu == 1) then
        rc = ramses_amd_mgamr_begin(ilevel, int(ngridmax, 8), int(ncoarse, 8), son, nbor, father, lookup_mg, flag2(1), &   ! flag2 is (0:ncell)
-            & phi, f, active(ilevel)%ngrid, active(ilevel)%igrid)
+            & phi, f, active(ilevel)%ngrid, ramses_amd_octs(ilevel))
        if (rc /= 0) call ramses_amd_fatal('multigrid_fine (AMR level, begin)')
        do l = 1, ilevel - 1
           if (active_mg(myid, l)%ngrid > 0) then
@@ -837,7 +856,9 @@ contains
        end do
        allocate(list(1:max(ntot, 1)))
        n = active(ilevel)%ngrid
-       list(1:n) = active(ilevel)%igrid(1:n)
+       do i = 1, n
+          list(i) = active(ilevel)%igrid(i)
+       end do
        do icpu = 1, ncpu
           do i = 1, reception(icpu, ilevel)%ngrid
              list(n + i) = reception(icpu, ilevel)%igrid(i)
@@ -863,7 +884,7 @@ contains
              rc = ramses_amd_mgamr_level_block(l, active_mg(myid, l)%ngrid, active_mg(myid, l)%igrid, &
                   & active_mg(myid, l)%u, active_mg(myid, l)%f)
           else
-             rc = ramses_amd_mgamr_level_block(l, 0, active(ilevel)%igrid, phi, flag2(1))      ! (arrays unused)
+             rc = ramses_amd_mgamr_level_block(l, 0, ramses_amd_octs(ilevel), phi, flag2(1))      ! (arrays unused)
           end if
           if (rc /= 0) call ramses_amd_fatal('multigrid_fine (AMR level, level_block)')
           do icpu = 1, ncpu
@@ -1091,7 +1112,7 @@ contains
        return
     end if
     call ramses_amd_comm_lists(levelmin, em_n, em_ig, rc_n, rc_ig)
-    rc = ramses_amd_halo_plan(levelmin, active(levelmin)%ngrid, active(levelmin)%igrid, xg, int(ngridmax, 8), ncpu, &
+    rc = ramses_amd_halo_plan(levelmin, active(levelmin)%ngrid, ramses_amd_octs(levelmin), xg, int(ngridmax, 8), ncpu, &
          & em_n, em_ig, rc_n, rc_ig, box, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, 0_8)
     ramses_amd_mpi_plan_ok = (rc == 0)
   end function ramses_amd_mpi_plan_ok
@@ -1109,7 +1130,7 @@ contains
     call ramses_amd_fill_hydro_params(p)
     nx_loc = icoarse_max - icoarse_min + 1
     call ramses_amd_comm_lists(levelmin, em_n, em_ig, rc_n, rc_ig)
-    rc = ramses_amd_mpires_setup(p, levelmin, active(levelmin)%ngrid, active(levelmin)%igrid, xg, int(ngridmax, 8), &
+    rc = ramses_amd_mpires_setup(p, levelmin, active(levelmin)%ngrid, ramses_amd_octs(levelmin), xg, int(ngridmax, 8), &
          & int(ncoarse, 8), nx_loc, uold, unew, ncpu, myid, em_n, em_ig, rc_n, rc_ig)
     if (rc /= 0) call ramses_amd_fatal('device-resident level under MPI (setup)')
   end subroutine ramses_amd_mpires_ensure
@@ -1327,7 +1348,7 @@ contains
                 rc = ramses_amd_amrres_load_level(nl, list, uold)
                 deallocate(list)
              else
-                rc = ramses_amd_amrres_load_level(active(l)%ngrid, active(l)%igrid, uold)
+                rc = ramses_amd_amrres_load_level(active(l)%ngrid, ramses_amd_octs(l), uold)
              end if
              if (rc /= 0) call ramses_amd_fatal('AMR residency (level reload)')
              if (poisson) call ramses_amd_amr_load_f(l)
@@ -1351,7 +1372,7 @@ contains
        rc = ramses_amd_amrres_load_f(nl, list, f)
        deallocate(list)
     else
-       rc = ramses_amd_amrres_load_f(active(ilevel)%ngrid, active(ilevel)%igrid, f)
+       rc = ramses_amd_amrres_load_f(active(ilevel)%ngrid, ramses_amd_octs(ilevel), f)
     end if
     if (rc /= 0) call ramses_amd_fatal('AMR residency (acceleration)')
   end subroutine ramses_amd_amr_load_f
@@ -1379,7 +1400,7 @@ contains
              rc = ramses_amd_amrres_sync_level(nl, list, uold)
              deallocate(list)
           else
-             rc = ramses_amd_amrres_sync_level(active(l)%ngrid, active(l)%igrid, uold)
+             rc = ramses_amd_amrres_sync_level(active(l)%ngrid, ramses_amd_octs(l), uold)
           end if
           if (rc /= 0) call ramses_amd_fatal('AMR residency (level sync before refine_fine)')
        end if

@@ -51,7 +51,7 @@ subroutine rho_fine_amd(ilevel,icount)
            call ramses_amd_fill_hydro_params(p)
            nx_loc=icoarse_max-icoarse_min+1
            scale=boxlen/dble(nx_loc)
-           rc=ramses_amd_resident_rho_fine_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+           rc=ramses_amd_resident_rho_fine_f90(p,ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),xg, &
                 & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,boxlen,nvector,mp4)
            if(rc/=0)call ramses_amd_fatal('rho_fine')
            multipole(1:ndim+1)=mp4(1:ndim+1)
@@ -81,7 +81,7 @@ subroutine rho_fine(ilevel,icount)
      if(ramses_amd_amrres_active()/=0.and.(ilevel==levelmin.or.icount>1))then
         do l=nlevelmax,ilevel,-1
            if(numbtot(1,l)>0.and.l<ramses_amd_amr_host_from)then
-              rc=ramses_amd_amrres_sync_density(active(l)%ngrid,active(l)%igrid,uold)
+              rc=ramses_amd_amrres_sync_density(active(l)%ngrid,ramses_amd_octs(l),uold)
               if(rc/=0)call ramses_amd_fatal('rho_fine (density back to the host)')
            end if
         end do

@@ -42,7 +42,7 @@ subroutine synchro_hydro_fine_amd(ilevel,dteff,which_force)
      ! AMR run with the state on the device: the kick on the resident arrays (the acceleration was mirrored by force_fine)
      call ramses_amd_amr_ensure()
      call ramses_amd_fill_hydro_params(p)
-     rc=ramses_amd_amrres_synchro(p,active(ilevel)%ngrid,active(ilevel)%igrid,dteff)
+     rc=ramses_amd_amrres_synchro(p,active(ilevel)%ngrid,ramses_amd_octs(ilevel),dteff)
      if(rc/=0)call ramses_amd_fatal('synchro_hydro_fine')
      return
   end if
@@ -54,7 +54,7 @@ subroutine synchro_hydro_fine_amd(ilevel,dteff,which_force)
 
   call ramses_amd_fill_hydro_params(p)
   nx_loc=icoarse_max-icoarse_min+1
-  rc=ramses_amd_resident_synchro_f90(p,ilevel,active(ilevel)%ngrid,active(ilevel)%igrid,xg, &
+  rc=ramses_amd_resident_synchro_f90(p,ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),xg, &
        & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,f,dteff)
   if(rc/=0)call ramses_amd_fatal('synchro_hydro_fine')
 
