@@ -374,19 +374,42 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
 // ===========================================================================
 constexpr int GRP_THREADS = 256;
 #ifndef RAMSES_AMD_GRP_MINWAVES
-#define RAMSES_AMD_GRP_MINWAVES 4   // workgroups per CU the register allocation must allow (256 threads: waves per SIMD)
+// workgroups per CU the register allocation must allow (256 threads: waves per SIMD).  The kernel is latency-bound: measured
+// on the 256^3 tree (profiles/r02_amr_probe_walk.txt) 3 groups (148 VGPRs, no spills) 4.46 ms, 4 (128 VGPRs, 13 spilled)
+// 3.44 ms, 5 (96 VGPRs, 144 spilled to scratch) 3.08 ms, 6 3.37 ms, 7 3.10 ms per sweep
+#define RAMSES_AMD_GRP_MINWAVES 5
 #endif
 
+// LDS layout of the stencil and the face arrays: variable-major (RAMSES_AMD_GRP_SOA=1, the default: consecutive lanes
+// touch consecutive doubles of one variable) or cell-major (0: the NV values of a cell together, 40-byte stride)
+#ifndef RAMSES_AMD_GRP_SOA
+#define RAMSES_AMD_GRP_SOA 1
+#endif
 template <int NV>
 struct GrpFaces {
-  double qm[3][80][NV];   // traced state on the +d face of the low cell of face (a = 0..4, 4x4 transverse)
-  double qp[3][80][NV];   // traced state on the -d face of the high cell
-  double fl[3][80][NV];   // flux through the face
+#if RAMSES_AMD_GRP_SOA
+  double qm[3][NV][80];   // traced state on the +d face of the low cell of face (a = 0..4, 4x4 transverse); then the flux
+  double qp[3][NV][80];   // traced state on the -d face of the high cell
+#else
+  double qm[3][80][NV];
+  double qp[3][80][NV];
+#endif
 };
+#if RAMSES_AMD_GRP_SOA
+#define GU(s, v) u[v][s]
+#define GF(arr, d, r, v) f.arr[d][v][r]
+#else
+#define GU(s, v) u[s][v]
+#define GF(arr, d, r, v) f.arr[d][r][v]
+#endif
 template <int NV>
 struct GrpLds {
   union {
-    double u[512][NV];     // primitive variables of the 8^3 stencil (until the traces are done)
+#if RAMSES_AMD_GRP_SOA
+    double u[NV][512];     // primitive variables of the 8^3 stencil (until the traces are done)
+#else
+    double u[512][NV];
+#endif
     GrpFaces<NV> f;
   };
   // tab[0..63]    fc: the 4^3 father cells (1-based cell index, 0: not there)
@@ -490,7 +513,7 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
       }
       ctoprim_cell<NV, GRAV>(u, gz, dtxhalf, P, q);
 #pragma unroll
-      for (int v = 0; v < NV; v++) L.u[s][v] = q[v];
+      for (int v = 0; v < NV; v++) L.GU(s, v) = q[v];
       L.ok[s] = refined;
     }
   }
@@ -522,7 +545,7 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
         double q[NV];
         ctoprim_cell<NV, GRAV>(u2[ind], gz, dtxhalf, P, q);
 #pragma unroll
-        for (int v = 0; v < NV; v++) L.u[s][v] = q[v];
+        for (int v = 0; v < NV; v++) L.GU(s, v) = q[v];
         L.ok[s] = 0;
       }
     } else {
@@ -531,7 +554,7 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
       for (int ind = 0; ind < 8; ind++) {
         const int s = gsidx(i0 + (ind & 1), j0 + ((ind >> 1) & 1), k0 + (ind >> 2));
 #pragma unroll
-        for (int v = 0; v < NV; v++) L.u[s][v] = 1.0;
+        for (int v = 0; v < NV; v++) L.GU(s, v) = 1.0;
         L.ok[s] = 0;
       }
     }
@@ -557,17 +580,17 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
     double qb[NV], dq[3][NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) {
-      qb[v] = L.u[s][v];
+      qb[v] = L.GU(s, v);
       if constexpr (ST == 3) {
         double nb[27], d3[3];
 #pragma unroll
-        for (int n = 0; n < 27; n++) nb[n] = L.u[s + (n % 3 - 1) + 8 * ((n / 3) % 3 - 1) + 64 * (n / 9 - 1)][v];
+        for (int n = 0; n < 27; n++) nb[n] = L.GU(s + (n % 3 - 1) + 8 * ((n / 3) % 3 - 1) + 64 * (n / 9 - 1), v);
         slope3_var(nb, d3);
         dq[0][v] = d3[0]; dq[1][v] = d3[1]; dq[2][v] = d3[2];
       } else {
-        dq[0][v] = slope1<ST>(L.u[s - 1][v], qb[v], L.u[s + 1][v], P);
-        dq[1][v] = slope1<ST>(L.u[s - 8][v], qb[v], L.u[s + 8][v], P);
-        dq[2][v] = slope1<ST>(L.u[s - 64][v], qb[v], L.u[s + 64][v], P);
+        dq[0][v] = slope1<ST>(L.GU(s - 1, v), qb[v], L.GU(s + 1, v), P);
+        dq[1][v] = slope1<ST>(L.GU(s - 8, v), qb[v], L.GU(s + 8, v), P);
+        dq[2][v] = slope1<ST>(L.GU(s - 64, v), qb[v], L.GU(s + 64, v), P);
       }
     }
     if constexpr (SCHEME == 0) {
@@ -587,11 +610,11 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
       if (b >= 0 && b < 4 && c >= 0 && c < 4) {
         if (a <= 4) {
 #pragma unroll
-          for (int v = 0; v < NV; v++) L.f.qm[d][gface(a, b, c)][v] = qm[d][v];
+          for (int v = 0; v < NV; v++) L.GF(qm, d, gface(a, b, c), v) = qm[d][v];
         }
         if (a >= 1) {
 #pragma unroll
-          for (int v = 0; v < NV; v++) L.f.qp[d][gface(a - 1, b, c)][v] = qp[d][v];
+          for (int v = 0; v < NV; v++) L.GF(qp, d, gface(a - 1, b, c), v) = qp[d][v];
         }
       }
     }
@@ -603,7 +626,7 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
     const int d = t / 80, r = t % 80, a = r >> 4, b = r & 3, c = (r >> 2) & 3;
     double qL[NV], qR[NV], fx[NV];
 #pragma unroll
-    for (int v = 0; v < NV; v++) { qL[v] = L.f.qm[d][r][v]; qR[v] = L.f.qp[d][r][v]; }
+    for (int v = 0; v < NV; v++) { qL[v] = L.GF(qm, d, r, v); qR[v] = L.GF(qp, d, r, v); }
     const bool pow2 = A.pow2 != 0;
     if (d == 0) scaled_interface_flux<RS, NV, 0>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
     else if (d == 1) scaled_interface_flux<RS, NV, 1>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
@@ -615,7 +638,7 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
     const int stride = d == 0 ? 1 : (d == 1 ? 8 : 64);
     const bool zero = L.ok[sl] || L.ok[sl + stride];
 #pragma unroll
-    for (int v = 0; v < NV; v++) L.f.fl[d][r][v] = zero ? 0.0 : fx[v];
+    for (int v = 0; v < NV; v++) L.GF(qm, d, r, v) = zero ? 0.0 : fx[v];
   }
   __syncthreads();
 
@@ -635,7 +658,7 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
         for (int d = 0; d < 3; d++) {
           const int t0 = d == 0 ? 1 : 0, t1 = d == 2 ? 1 : 2;
           const int a = ic[d], b = ic[t0], c = ic[t1];
-          un = un + (L.f.fl[d][gface(a, b, c)][v] - L.f.fl[d][gface(a + 1, b, c)][v]);
+          un = un + (L.GF(qm, d, gface(a, b, c), v) - L.GF(qm, d, gface(a + 1, b, c), v));
         }
         A.unew[(long)v * ncell + cell - 1] = un;
       }
@@ -660,7 +683,7 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
         for (int q = 0; q < 4; q++) {
           const int fi = gface(a, 2 * sc[t0] + (q & 1), 2 * sc[t1] + (q >> 1));
 #pragma unroll
-          for (int v = 0; v < NV; v++) dst[q * CV + v] = L.f.fl[d][fi][v];
+          for (int v = 0; v < NV; v++) dst[q * CV + v] = L.GF(qm, d, fi, v);
           dst[q * CV + NV] = 0.0;
           dst[q * CV + NV + 1] = 0.0;
         }
@@ -668,6 +691,9 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
     }
   }
 }
+
+#undef GU
+#undef GF
 
 // The octs of the call's list repacked as contiguous records, record i = oct igrid[i]:
 //   [8 x uold(:,1)] ... [8 x uold(:,nvar)] [8 x f(:,1..3) with gravity] [8 ints: cell is refined], padded to 128 bytes.
@@ -703,18 +729,37 @@ __global__ __launch_bounds__(256) void amr_pack_kernel(AmrSweepArgs A, double *_
 
 // groups[] = the father octs that have at least one son in the call's list, each once: the son at the lowest
 // octant position enters it
-__global__ void amr_group_build_kernel(AmrSweepArgs A, const int *posof, int *groups, int *count) {
+__global__ __launch_bounds__(1024) void amr_group_build_kernel(AmrSweepArgs A, const int *posof, int *groups, int *count) {
   const int io = blockIdx.x * blockDim.x + threadIdx.x;
-  if (io >= A.ngrid) return;
-  const int g = A.igrid[io];
-  const int c = A.father[g - 1];
-  int pos, gF;
-  cell_split(c, A.ncoarse, A.ngridmax, pos, gF);
-  for (int p = 0; p < pos; p++) {
-    const int s = A.son[A.ncoarse + (long)p * A.ngridmax + gF - 1];
-    if (s > 0 && posof[s - 1] >= 0) return;
+  bool lead = false;
+  int gF = 0;
+  if (io < A.ngrid) {
+    const int g = A.igrid[io];
+    const int c = A.father[g - 1];
+    int pos;
+    cell_split(c, A.ncoarse, A.ngridmax, pos, gF);
+    lead = true;
+    for (int p = 0; p < pos; p++) {
+      const int s = A.son[A.ncoarse + (long)p * A.ngridmax + gF - 1];
+      if (s > 0 && posof[s - 1] >= 0) { lead = false; break; }
+    }
   }
-  groups[atomicAdd(count, 1)] = gF;
+  // one atomic per 1024-thread workgroup (atomics on one address cost ~11 ns each on the 256^3 tree, whether 262144
+  // single ones or 32768 per wavefront); the groups of a workgroup keep the order of the list, which keeps
+  // neighbouring father octs together
+  __shared__ int wcount[16], wbase[16];
+  const unsigned long long m = __ballot(lead);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (blockDim.x + 63) >> 6;
+  if (lane == 0) wcount[wave] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < nwave; w++) { wbase[w] = tot; tot += wcount[w]; }
+    const int base = tot > 0 ? atomicAdd(count, tot) : 0;
+    for (int w = 0; w < nwave; w++) wbase[w] += base;
+  }
+  __syncthreads();
+  if (lead) groups[wbase[wave] + __popcll(m & ((1ull << lane) - 1ull))] = gF;
 }
 
 // posof[oct-1] = position (0-based) of the oct in the active list
@@ -824,8 +869,10 @@ template <int ST, int RS>
 static hipError_t launch2(const AmrSweepArgs &A, const int *groups, int ngroups, const int *posof, const int *walk, hipStream_t s) {
   switch (A.nvar) {
     case 5: return launch3<ST, RS, 5>(A, groups, ngroups, posof, walk, s);
+#ifndef RAMSES_AMD_AMR_DEV
     case 6: return launch3<ST, RS, 6>(A, groups, ngroups, posof, walk, s);
     case 7: return launch3<ST, RS, 7>(A, groups, ngroups, posof, walk, s);
+#endif
   }
   return hipErrorInvalidValue;
 }
@@ -834,10 +881,12 @@ template <int ST>
 static hipError_t launch1(const AmrSweepArgs &A, int rs, const int *groups, int ngroups, const int *posof, const int *walk, hipStream_t s) {
   switch (rs) {
     case RIEMANN_LLF: return launch2<ST, RIEMANN_LLF>(A, groups, ngroups, posof, walk, s);
+#ifndef RAMSES_AMD_AMR_DEV     // development build (kernel tuning with scripts/amr_probe.py): minmod + LLF + NVAR=5 only
     case RIEMANN_HLLC: return launch2<ST, RIEMANN_HLLC>(A, groups, ngroups, posof, walk, s);
     case RIEMANN_HLL: return launch2<ST, RIEMANN_HLL>(A, groups, ngroups, posof, walk, s);
     case RIEMANN_ACOUSTIC: return launch2<ST, RIEMANN_ACOUSTIC>(A, groups, ngroups, posof, walk, s);
     case RIEMANN_EXACT: return launch2<ST, RIEMANN_EXACT>(A, groups, ngroups, posof, walk, s);
+#endif
     default: return hipErrorInvalidValue;
   }
 }
@@ -867,7 +916,7 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A_in, int slope_type, int riem
   if (use_groups && !(A.difmag > 0.0) && A.divu == nullptr) {
     e = hipMemsetAsync(count, 0, sizeof(int), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(amr_group_build_kernel, dim3((A.ngrid + 255) / 256), dim3(256), 0, s, A, posof, groups, count);
+    hipLaunchKernelGGL(amr_group_build_kernel, dim3((A.ngrid + 1023) / 1024), dim3(1024), 0, s, A, posof, groups, count);
     e = hipMemcpyAsync(&ngroups, count, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) return e;
     e = hipStreamSynchronize(s);
@@ -906,12 +955,14 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A_in, int slope_type, int riem
     }
   }
   switch (slope_type) {
-    case 0: e = launch1<0>(A, riemann, groups, ngroups, posof, walk, s); break;
     case 1: e = launch1<1>(A, riemann, groups, ngroups, posof, walk, s); break;
+#ifndef RAMSES_AMD_AMR_DEV
+    case 0: e = launch1<0>(A, riemann, groups, ngroups, posof, walk, s); break;
     case 2: e = launch1<2>(A, riemann, groups, ngroups, posof, walk, s); break;
     case 3: e = launch1<3>(A, riemann, groups, ngroups, posof, walk, s); break;
     case 7: e = launch1<7>(A, riemann, groups, ngroups, posof, walk, s); break;
     case 8: e = launch1<8>(A, riemann, groups, ngroups, posof, walk, s); break;
+#endif
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
