@@ -39,6 +39,8 @@ def parse():
                     help="N>1: hide the halo exchange behind the interior sweep (auto: measure both, keep the faster)")
     ap.add_argument("--vcycle-level", type=int, default=9,
                     help="multigrid V-cycle measurement: 2^level cells per direction per GPU (0 = skip)")
+    ap.add_argument("--amr-level", type=int, default=8,
+                    help="tree-walking (AMR) sweep measurement on a fully refined synthetic 2^level^3 tree (0 = skip)")
     ap.add_argument("--mg-tune", type=int, default=-1,
                     help="fused smoother: 1 = library default (2+2 colour passes on 32-row tiles), 4 = one 4-pass launch, "
                          "12/16/24/32 = 2+2 passes on that many tile rows, 0 = one kernel per colour pass (-1: leave the default)")
@@ -212,6 +214,57 @@ def vcycle_bench_dist(level_local, pgrid, rank, world, transport=None):
             "replicated_levels_from": pd.lrep,
             "roofline": {"bound": "hbm", "achieved": gbs / world, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
                          "frac": gbs / world / HBM_PEAK_GBS, "bytes_per_dof": BYTES_PER_DOF_VCYCLE}}
+
+
+BYTES_PER_CELL_UPDATE_AMR = 84   # 80 B + 4 B of `son` per cell on AMR levels
+
+
+def amr_sweep_bench(level=8, steps=5):
+    """The other sweep kernel of the path, for the record: godunov_fine of an AMR level through the tree-walking sweep
+    (csrc/amr_sweep.hip: the level's octs in the reference's own cell vectors and tree arrays son/nbor/father) on a
+    synthetic fully refined 2^level^3 tree whose octs are numbered along a Z-order curve (what refine_fine produces);
+    strict arithmetic.  One call = group build + father-cell walk + oct-record pack + sweep + coarse corrections."""
+    import numpy as np
+    import torch
+    import ramses_amd
+    from ramses_amd import ic
+    from ramses_amd._capi import check, lib
+    n = 2 ** level
+    T = ic.uniform_tree(level, order="morton")
+    u, dx = ic.sedov3d(n)
+    uold = np.zeros((5, T["ncell"]))
+    T["to_cells"](u, uold)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    d_uold, d_unew = dev(uold), dev(uold)
+    d_son, d_nbor, d_father, d_igrid = dev(T["son"]), dev(T["nbor"]), dev(T["father"]), dev(T["igrid"])
+    nw = lib().ramses_amd_godunov_fine_amr_workspace(len(T["igrid"]), T["ngridmax"])
+    d_work = torch.zeros(int(nw), dtype=torch.uint8, device="cuda")
+    d_err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    p = ramses_amd.make_params(courant_factor=0.8)
+    ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+    def run():
+        check(lib().ramses_amd_godunov_fine_amr_device(C.byref(p), level, len(T["igrid"]), ptr(d_igrid), ptr(d_son), ptr(d_nbor),
+                                                       ptr(d_father), T["ngridmax"], T["ncoarse"], ptr(d_uold), ptr(d_unew),
+                                                       None, None, None, dx, 1e-6, 32, 0, 1, ptr(d_work), ptr(d_err),
+                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps):
+        run()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / steps
+    gbs = n ** 3 * BYTES_PER_CELL_UPDATE_AMR / (ms * 1e-3) / 1e9
+    return {"metric": "cell-updates/s (godunov_fine of an AMR level, tree-walking sweep)", "value": n ** 3 / (ms * 1e-3),
+            "unit": "cell-updates/s", "ms_per_sweep": ms, "arithmetic": "strict (bit-identical to the reference)",
+            "workload": "fully refined synthetic %d^3 tree in the reference's cell-vector layout, Z-order oct numbering" % n,
+            "tree_errors": int(d_err.item()),
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "bytes_per_cell": BYTES_PER_CELL_UPDATE_AMR}}
 
 
 def pick_transport(rank, world, timeout):
@@ -467,6 +520,12 @@ def main():
             del lev
             torch.cuda.empty_cache()
             out["vcycle"] = vcycle_bench(args.vcycle_level)
+        if world == 1 and args.amr_level > 0:
+            try:
+                torch.cuda.empty_cache()
+                out["amr_sweep"] = amr_sweep_bench(args.amr_level)
+            except Exception as exc:     # noqa: BLE001  (an extra line, never a reason to lose the headline)
+                out["amr_sweep"] = {"value": None, "error": str(exc)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()     # rank 0 at N=1 only
     else:

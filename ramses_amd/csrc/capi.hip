@@ -484,6 +484,25 @@ static hipError_t mg_coarse_cycle(double *w, int level, int l, int safe, hipStre
   const double dx = std::ldexp(1.0, -l), dx2 = dx * dx;
   double *u1 = w + mg_hier_offset(level, l, 0), *u2 = w + mg_hier_offset(level, l, 1), *u3 = w + mg_hier_offset(level, l, 2);
   hipError_t e;
+  // the coarsest levels: the whole rest of the V-cycle (down to level 1 and back up) in one launch of one workgroup
+  // (RAMSES_AMD_MG_TAIL=<top level of the tail>, 0: one launch per colour pass everywhere; same bits)
+  static int use_tail = -1;
+  if (use_tail < 0) {
+    const char *env = getenv("RAMSES_AMD_MG_TAIL");
+    use_tail = env ? atoi(env) : 4;
+    if (use_tail > MG_TAIL_LTOP) use_tail = MG_TAIL_LTOP;
+  }
+  if (l <= use_tail && l >= 2) {
+    MgTailArgs T;
+    T.w = w; T.ltop = l;
+    for (int k = 1; k <= l; k++) {
+      for (int a = 0; a < 3; a++) T.off[k][a] = (long)mg_hier_offset(level, k, a);
+      const double dxk = std::ldexp(1.0, -k);
+      T.dx2[k] = dxk * dxk;
+      T.oneoverdx2[k] = 1.0 / (dxk * dxk);
+    }
+    return mg_launch_coarse_tail(T, s);
+  }
   if (l <= 1) {
     for (int i = 0; i < 2 * ngs_coarse; i++) {
       if ((e = mg_launch_gs(u1, u2, n, dx2, 0, s)) != hipSuccess) return e;

@@ -6,6 +6,17 @@ namespace ramses_amd {
 
 constexpr int MG_MAX_PARTIALS = 4096;
 
+// levels ltop .. 1 of a dense periodic hierarchy for the single-workgroup coarse tail: w + off[l][0..2] = correction,
+// right-hand side, residual of level l (2^l cells per direction)
+constexpr int MG_TAIL_LTOP = 5;
+struct MgTailArgs {
+  double *w;
+  int ltop;
+  long off[MG_TAIL_LTOP + 1][3];
+  double dx2[MG_TAIL_LTOP + 1], oneoverdx2[MG_TAIL_LTOP + 1];
+};
+hipError_t mg_launch_coarse_tail(const MgTailArgs &T, hipStream_t s);
+
 hipError_t mg_launch_rhs(const double *rho, double *f2, long N, double fourpi, double rho_tot, hipStream_t s);
 hipError_t mg_launch_gs(double *phi, const double *rhs, int n, double dx2, int color, hipStream_t s);
 int mg_residual_blocks(int n);

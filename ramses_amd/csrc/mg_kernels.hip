@@ -63,11 +63,11 @@ __global__ __launch_bounds__(256) void mg_rhs_kernel(const double *__restrict__ 
 }
 
 // one colour of red-black Gauss-Seidel (gauss_seidel_mg_fine/_coarse fast path)
-__global__ __launch_bounds__(256) void mg_gs_kernel(double *__restrict__ phi, const double *__restrict__ rhs,
-                                                     int n, double dx2, int color) {
+__device__ __forceinline__ void mg_gs_body(double *__restrict__ phi, const double *__restrict__ rhs, int n, double dx2,
+                                           int color, long first, long stride) {
   const int nh = n >> 1;
   const long total = (long)nh * n * n;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+  for (long t = first; t < total; t += stride) {
     const int lg = ilog2(n);
     const int ih = (int)(t & (nh - 1));
     const int j = (int)((t >> (lg - 1)) & (n - 1));
@@ -77,6 +77,10 @@ __global__ __launch_bounds__(256) void mg_gs_kernel(double *__restrict__ phi, co
     const long c = (long)i + (long)n * (j + (long)n * k);
     phi[c] = div6(nb - dx2 * rhs[c]);
   }
+}
+__global__ __launch_bounds__(256) void mg_gs_kernel(double *__restrict__ phi, const double *__restrict__ rhs,
+                                                     int n, double dx2, int color) {
+  mg_gs_body(phi, rhs, n, dx2, color, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 // res = -(nb - 6 phi)/dx^2 + rhs ; optional per-block partial sums of res^2
@@ -125,12 +129,11 @@ __global__ void mg_sum_partials_kernel(const double *__restrict__ partial, int m
 
 // coarse rhs = sum over the 8 children (octant order) of res/8 ; coarse
 // correction reset to zero in the same pass (multigrid_fine_commons.f90:217-238)
-__global__ __launch_bounds__(256) void mg_restrict_kernel(const double *__restrict__ res_f,
-                                                           double *__restrict__ rhs_c,
-                                                           double *__restrict__ u1_c, int nf) {
+__device__ __forceinline__ void mg_restrict_body(const double *__restrict__ res_f, double *__restrict__ rhs_c,
+                                                 double *__restrict__ u1_c, int nf, long first, long stride) {
   const int nc = nf >> 1;
   const long Nc = (long)nc * nc * nc;
-  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < Nc; c += (long)gridDim.x * blockDim.x) {
+  for (long c = first; c < Nc; c += stride) {
     int I, J, K;
     decode3(c, ilog2(nc), I, J, K);
     double acc = 0.0;
@@ -143,20 +146,25 @@ __global__ __launch_bounds__(256) void mg_restrict_kernel(const double *__restri
     u1_c[c] = 0.0;
   }
 }
+__global__ __launch_bounds__(256) void mg_restrict_kernel(const double *__restrict__ res_f,
+                                                           double *__restrict__ rhs_c,
+                                                           double *__restrict__ u1_c, int nf) {
+  mg_restrict_body(res_f, rhs_c, u1_c, nf, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
 
 // phi_f += sum_{8 of 27 parents} w*corr_c, weights (a,b,b,c,b,c,c,d)
 // One thread per COARSE cell: its 3^3 neighbourhood of corrections is loaded once (27 loads for 8
 // children instead of 8 per child) and each child adds its 8 terms in the reference's order
 // (interpolate_and_correct_fine, multigrid_fine_fine.f90:596-698: t = 0..7, bit 0/1/2 of t set =
 // the parent itself along x/y/z, clear = the neighbour on the child's side).
-__global__ __launch_bounds__(256) void mg_interp_kernel(double *__restrict__ phi_f,
-                                                         const double *__restrict__ corr_c, int nf) {
+__device__ __forceinline__ void mg_interp_body(double *__restrict__ phi_f, const double *__restrict__ corr_c, int nf,
+                                               long first, long stride) {
   const int nc = nf >> 1;
   const int lgc = ilog2(nc);
   const long Nc = (long)nc * nc * nc;
   const double a = 1.0 / 64.0, b = 3 * a, cc = 9 * a, d = 27 * a;
   const double bbb[8] = {a, b, b, cc, b, cc, cc, d};
-  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < Nc; c += (long)gridDim.x * blockDim.x) {
+  for (long c = first; c < Nc; c += stride) {
     int I, J, K;
     decode3(c, lgc, I, J, K);
     int xi[3] = {wrapi(I - 1, nc), I, wrapi(I + 1, nc)};
@@ -190,6 +198,58 @@ __global__ __launch_bounds__(256) void mg_interp_kernel(double *__restrict__ phi
         phi_f[row] = out[0];
         phi_f[row + 1] = out[1];
       }
+  }
+}
+__global__ __launch_bounds__(256) void mg_interp_kernel(double *__restrict__ phi_f,
+                                                         const double *__restrict__ corr_c, int nf) {
+  mg_interp_body(phi_f, corr_c, nf, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+// residual without the norm (the coarse levels' form): res = -(nb - 6 phi)/dx^2 + rhs
+__device__ __forceinline__ void mg_residual_body(const double *__restrict__ phi, const double *__restrict__ rhs,
+                                                 double *__restrict__ res, int n, double oneoverdx2, long first, long stride) {
+  const long N = (long)n * n * n;
+  for (long c = first; c < N; c += stride) {
+    int i, j, k;
+    decode3(c, ilog2(n), i, j, k);
+    const double phi_c = phi[c];
+    const double nb = nb_sum6(phi, i, j, k, n);
+    res[c] = -oneoverdx2 * (nb - 6.0 * phi_c) + rhs[c];
+  }
+}
+
+// recursive_multigrid_coarse (multigrid_fine_commons.f90:307-390) from level T.ltop down to level 1 and back up in ONE
+// launch of ONE workgroup: at <= 32^3 a colour pass is a 4.6 us launch of a kernel that runs for well under a microsecond
+// (profiles/r02_vcycle_levels.txt: ~80 launches = 0.41 ms of a 5.8 ms V-cycle at 512^3).  The same per-cell routines in the
+// same order as the per-kernel schedule (every pass is order-independent inside: one colour, or one output per cell), a
+// workgroup barrier where that schedule has a kernel boundary: bit-identical.
+__global__ __launch_bounds__(1024) void mg_coarse_tail_kernel(MgTailArgs T) {
+  const long t = threadIdx.x, nt = blockDim.x;
+  for (int l = T.ltop; l >= 2; l--) {
+    const int n = 1 << l;
+    double *u1 = T.w + T.off[l][0], *u2 = T.w + T.off[l][1], *u3 = T.w + T.off[l][2];
+    for (int i = 0; i < 2; i++) {
+      mg_gs_body(u1, u2, n, T.dx2[l], 0, t, nt); __syncthreads();
+      mg_gs_body(u1, u2, n, T.dx2[l], 1, t, nt); __syncthreads();
+    }
+    mg_residual_body(u1, u2, u3, n, T.oneoverdx2[l], t, nt); __syncthreads();
+    mg_restrict_body(u3, T.w + T.off[l - 1][1], T.w + T.off[l - 1][0], n, t, nt); __syncthreads();
+  }
+  {
+    double *u1 = T.w + T.off[1][0], *u2 = T.w + T.off[1][1];
+    for (int i = 0; i < 4; i++) {
+      mg_gs_body(u1, u2, 2, T.dx2[1], 0, t, nt); __syncthreads();
+      mg_gs_body(u1, u2, 2, T.dx2[1], 1, t, nt); __syncthreads();
+    }
+  }
+  for (int l = 2; l <= T.ltop; l++) {
+    const int n = 1 << l;
+    double *u1 = T.w + T.off[l][0], *u2 = T.w + T.off[l][1];
+    mg_interp_body(u1, T.w + T.off[l - 1][0], n, t, nt); __syncthreads();
+    for (int i = 0; i < 2; i++) {
+      mg_gs_body(u1, u2, n, T.dx2[l], 0, t, nt); __syncthreads();
+      mg_gs_body(u1, u2, n, T.dx2[l], 1, t, nt); __syncthreads();
+    }
   }
 }
 
@@ -360,6 +420,10 @@ hipError_t mg_launch_restrict(const double *res_f, double *rhs_c, double *u1_c, 
 hipError_t mg_launch_interp(double *phi_f, const double *corr_c, int nf, hipStream_t s) {
   const int nc = nf >> 1;
   hipLaunchKernelGGL(mg_interp_kernel, dim3(grid_for((long)nc * nc * nc, 8192)), dim3(256), 0, s, phi_f, corr_c, nf);
+  return hipGetLastError();
+}
+hipError_t mg_launch_coarse_tail(const MgTailArgs &T, hipStream_t s) {
+  hipLaunchKernelGGL(mg_coarse_tail_kernel, dim3(1), dim3(1024), 0, s, T);
   return hipGetLastError();
 }
 hipError_t mg_launch_restrict_ghost(const double *res_f, double *rhs_c, int nf, int ngf, int ngc, hipStream_t s) {

@@ -12,10 +12,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ramses_amd  # noqa: E402
-from helpers import uniform_tree  # noqa: E402
 from ramses_amd import ic  # noqa: E402
+from ramses_amd.ic import uniform_tree  # noqa: E402
 from ramses_amd._capi import check, lib  # noqa: E402
 
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 7
