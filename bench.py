@@ -231,11 +231,14 @@ def amr_sweep_bench(level=8, steps=5):
     from ramses_amd._capi import check, lib
     n = 2 ** level
     T = ic.uniform_tree(level, order="morton")
-    u, dx = ic.sedov3d(n)
-    uold = np.zeros((5, T["ncell"]))
-    T["to_cells"](u, uold)
+    dx = 0.5 / n
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
-    d_uold, d_unew = dev(uold), dev(uold)
+    # sedov3d.nml's state built on the device in the tree's cell vectors: rho = 1, P = 1e-5, the blast energy in one cell
+    d_uold = torch.zeros((5, T["ncell"]), dtype=torch.float64, device="cuda")
+    d_uold[0].fill_(1.0)
+    d_uold[4].fill_(1e-5 / 0.4)
+    d_uold[4, T["ncoarse"] + int(T["igrid"][0]) - 1] = (1e-5 + 0.4 * 0.125 / dx ** 3) / 0.4
+    d_unew = d_uold.clone()
     d_son, d_nbor, d_father, d_igrid = dev(T["son"]), dev(T["nbor"]), dev(T["father"]), dev(T["igrid"])
     nw = lib().ramses_amd_godunov_fine_amr_workspace(len(T["igrid"]), T["ngridmax"])
     d_work = torch.zeros(int(nw), dtype=torch.uint8, device="cuda")

@@ -161,8 +161,17 @@ static int godunov_brick_region(const ramses_amd_hydro_params *p, const ramses_a
   if (p->nvar != 5 && p->scheme != RAMSES_AMD_SCHEME_MUSCL) return fail(RAMSES_AMD_EUNSUPPORTED, "passive scalars with scheme='plmde' are not on the device yet");
   if (p->scheme != RAMSES_AMD_SCHEME_MUSCL && p->scheme != RAMSES_AMD_SCHEME_PLMDE) return fail(RAMSES_AMD_EINVAL, "unknown scheme %d", p->scheme);
   if (p->difmag > 0.0) return fail(RAMSES_AMD_EUNSUPPORTED, "difmag>0 is not implemented on the device yet");
-  if (!(p->slope_type == 0 || p->slope_type == 1 || p->slope_type == 2 || p->slope_type == 3 || p->slope_type == 7 || p->slope_type == 8))
-    return fail(RAMSES_AMD_EUNSUPPORTED, "slope_type=%d is not a 3-D slope type of the reference (0,1,2,3,7,8 are)", p->slope_type);
+  // slope types: 0,1,2,3,7,8 in every build of the reference; 4,5,6 (superbee, ultrabee, central) exist in its NDIM=1
+  // branch only (hydro/umuscl.f90:1030-1090), where type 3 means type 2 (MIN(slope_type,2), :1014-1023)
+  int slope_type = p->slope_type;
+  if (p->ndim == 1 && slope_type == 3) slope_type = 2;
+  const bool st1d = slope_type == 4 || slope_type == 5 || slope_type == 6;
+  if (st1d && p->ndim != 1)
+    return fail(RAMSES_AMD_EUNSUPPORTED, "slope_type=%d exists in NDIM=1 runs of the reference only (0,1,2,3,7,8 in 2-D/3-D)", slope_type);
+  if (st1d && (p->nvar != 5 || p->scheme != RAMSES_AMD_SCHEME_MUSCL || d_grav))
+    return fail(RAMSES_AMD_EUNSUPPORTED, "slope_type=%d: hydro variables only, scheme='muscl', no gravity", slope_type);
+  if (!(slope_type == 0 || slope_type == 1 || slope_type == 2 || slope_type == 3 || slope_type == 7 || slope_type == 8 || st1d))
+    return fail(RAMSES_AMD_EUNSUPPORTED, "slope_type=%d is not a slope type of the reference", slope_type);
   if (p->riemann < 0 || p->riemann > 4) return fail(RAMSES_AMD_EINVAL, "unknown Riemann solver %d", p->riemann);
   if (!(dx > 0.0) || !(dt >= 0.0)) return fail(RAMSES_AMD_EINVAL, "dx must be >0 and dt >=0");
 
@@ -178,8 +187,8 @@ static int godunov_brick_region(const ramses_amd_hydro_params *p, const ramses_a
   for (int region = region_first; region <= region_last; region++) {
     A.region = region;
     hipError_t e = p->fast_math
-                       ? fastmode::launch_godunov_sweep(A, p->slope_type, p->riemann, g_tile_rows, p->scheme, p->nvar, d_grav != nullptr, s)
-                       : strictmode::launch_godunov_sweep(A, p->slope_type, p->riemann, g_tile_rows, p->scheme, p->nvar, d_grav != nullptr, s);
+                       ? fastmode::launch_godunov_sweep(A, slope_type, p->riemann, g_tile_rows, p->scheme, p->nvar, d_grav != nullptr, s)
+                       : strictmode::launch_godunov_sweep(A, slope_type, p->riemann, g_tile_rows, p->scheme, p->nvar, d_grav != nullptr, s);
     if (e != hipSuccess) return hipfail(e, "godunov sweep launch");
   }
   return 0;

@@ -172,6 +172,44 @@ RA_DEV double slope1(double qm1, double q0, double qp1, const HydroConst &P) {
   return 0.0;
 }
 
+// The slope types only an NDIM=1 build of the reference has (hydro/umuscl.f90:1030-1090: 4 superbee, 5 ultrabee,
+// 6 "unstable" central difference).  dcen = q(u)*dt/dx of the cell along the direction ((u*dt)/dx, the reference's
+// order), n = variable index: types 5 and 6 limit the density only, every other slope is zero.  Strict arithmetic
+// (the reference's divisions) in both builds.
+template <int ST>
+RA_DEV double slope1_1d(double qm1, double q0, double qp1, double dcen, int n) {
+  if (ST == 4) {
+    const double dlft = 2.0 / (1.0 + dcen) * (q0 - qm1);
+    const double drgt = 2.0 / (1.0 - dcen) * (qp1 - q0);
+    const double dsgn = fsignd(1.0, dlft);
+    double dlim = dmind(__builtin_fabs(dlft), __builtin_fabs(drgt));
+    if ((dlft * drgt) <= 0.0) dlim = 0.0;
+    return dsgn * dlim;
+  }
+  if (ST == 5) {
+    if (n != 0) return 0.0;
+    double dlft, drgt;
+    if (dcen >= 0) {
+      dlft = 2.0 / (0.0 + dcen + 1e-10) * (q0 - qm1);
+      drgt = 2.0 / (1.0 - dcen) * (qp1 - q0);
+    } else {
+      dlft = 2.0 / (1.0 + dcen) * (q0 - qm1);
+      drgt = 2.0 / (0.0 - dcen + 1e-10) * (qp1 - q0);
+    }
+    const double dsgn = fsignd(1.0, dlft);
+    double dlim = dmind(__builtin_fabs(dlft), __builtin_fabs(drgt));
+    if ((dlft * drgt) <= 0.0) dlim = 0.0;
+    return dsgn * dlim;
+  }
+  if (ST == 6) {
+    if (n != 0) return 0.0;
+    const double dlft = q0 - qm1;
+    const double drgt = qp1 - q0;
+    return 0.5 * (dlft + drgt);
+  }
+  return 0.0;
+}
+
 // positivity-preserving unsplit slope (slope_type=3, umuscl.f90:1326-1386):
 // nb[27] = the 3x3x3 neighbourhood of one variable, index (di+1)+3*(dj+1)+9*(dk+1)
 RA_DEV void slope3_var(const double (&nb)[27], double (&d)[3]) {

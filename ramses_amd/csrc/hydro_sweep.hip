@@ -300,6 +300,17 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
           slope3_var(nb, d3);
           dq[0][n] = d3[0]; dq[1][n] = d3[1]; dq[2][n] = d3[2];
         }
+      } else if (ST == 4 || ST == 5 || ST == 6) {
+        // the NDIM=1 slope types (embedded 1-D problems: ny = nz = 1, the transverse differences vanish)
+#pragma unroll
+        for (int n = 0; n < NV; n++) qb[n] = qs.v[n][ty][tx];
+        const double dc0 = qb[1] * A.dt / A.dx, dc1 = qb[2] * A.dt / A.dx, dc2 = qb[3] * A.dt / A.dx;
+#pragma unroll
+        for (int n = 0; n < NV; n++) {
+          dq[0][n] = slope1_1d<ST>(qs.v[n][ty][txm], qb[n], qs.v[n][ty][txp], dc0, n);
+          dq[1][n] = slope1_1d<ST>(qs.v[n][tym][tx], qb[n], qs.v[n][typ][tx], dc1, n);
+          dq[2][n] = slope1_1d<ST>(qprev.v[n][ty][tx], qb[n], qc[n], dc2, n);
+        }
       } else {
 #pragma unroll
         for (int n = 0; n < NV; n++) {
@@ -465,6 +476,17 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
           slope3_var(nb, d3);
           dq[0][n] = d3[0]; dq[1][n] = d3[1]; dq[2][n] = d3[2];
         }
+      } else if (ST == 4 || ST == 5 || ST == 6) {
+        // the NDIM=1 slope types (embedded 1-D problems: ny = nz = 1, the transverse differences vanish)
+#pragma unroll
+        for (int n = 0; n < NV; n++) qb[n] = qs.v[n][ty][tx];
+        const double dc0 = qb[1] * A.dt / A.dx, dc1 = qb[2] * A.dt / A.dx, dc2 = qb[3] * A.dt / A.dx;
+#pragma unroll
+        for (int n = 0; n < NV; n++) {
+          dq[0][n] = slope1_1d<ST>(qs.v[n][ty][txm], qb[n], qs.v[n][ty][txp], dc0, n);
+          dq[1][n] = slope1_1d<ST>(qs.v[n][tym][tx], qb[n], qs.v[n][typ][tx], dc1, n);
+          dq[2][n] = slope1_1d<ST>(qprev.v[n][ty][tx], qb[n], qc[n], dc2, n);
+        }
       } else {
 #pragma unroll
         for (int n = 0; n < NV; n++) {
@@ -608,7 +630,7 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
   // 8-row tiles (2 waves/SIMD, 256 VGPRs, smaller LDS planes) for the
   // register/LDS-hungry variants: the Newton solver, the 27-point slope, the
   // PLMDE tracing and runs with passive scalars
-  const bool heavy = (RS == RIEMANN_EXACT) || (ST == 3) || (scheme != 0) || (nvar != 5);
+  const bool heavy = (RS == RIEMANN_EXACT) || (ST == 3) || (ST == 4) || (ST == 5) || (ST == 6) || (scheme != 0) || (nvar != 5);
   if (by == 0 || heavy) by = heavy ? 8 : 12;
   // tiles of the whole brick, then the boxes this launch covers (A.region)
   const int NTX = (A.nx + (BX - 4) - 1) / (BX - 4);
@@ -648,15 +670,21 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
   }
   if (nblocks == 0) return hipSuccess;
   A.nblocks = nblocks;
-  if (nvar == 6) return scheme == 0 ? launch2<ST, RS, 8, 0, 6>(A, grav, s) : hipErrorInvalidValue;
-  if (nvar == 7) return scheme == 0 ? launch2<ST, RS, 8, 0, 7>(A, grav, s) : hipErrorInvalidValue;
-  if (nvar != 5) return hipErrorInvalidValue;
-  if (scheme == 1) return launch2<ST, RS, 8, 1, 5>(A, grav, s);
-  if (by == 8) return launch2<ST, RS, 8, 0, 5>(A, grav, s);
-  if constexpr (ST != 3 && RS != RIEMANN_EXACT) {
-    if (by == 12) return launch2<ST, RS, 12, 0, 5>(A, grav, s);
+  if constexpr (ST == 4 || ST == 5 || ST == 6) {
+    // NDIM=1 slope types: the plain configuration only (the reference's 1-D tests: NVAR=3 embedded as 5, muscl, no gravity)
+    if (nvar != 5 || scheme != 0 || grav) return hipErrorInvalidValue;
+    return launch3<ST, RS, 8, false, 0, 5>(A, s);
+  } else {
+    if (nvar == 6) return scheme == 0 ? launch2<ST, RS, 8, 0, 6>(A, grav, s) : hipErrorInvalidValue;
+    if (nvar == 7) return scheme == 0 ? launch2<ST, RS, 8, 0, 7>(A, grav, s) : hipErrorInvalidValue;
+    if (nvar != 5) return hipErrorInvalidValue;
+    if (scheme == 1) return launch2<ST, RS, 8, 1, 5>(A, grav, s);
+    if (by == 8) return launch2<ST, RS, 8, 0, 5>(A, grav, s);
+    if constexpr (ST != 3 && RS != RIEMANN_EXACT) {
+      if (by == 12) return launch2<ST, RS, 12, 0, 5>(A, grav, s);
+    }
+    return hipErrorInvalidValue;
   }
-  return hipErrorInvalidValue;
 }
 
 template <int ST>
@@ -681,6 +709,9 @@ hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int b
     case 1: return launch0<1>(A, riemann, by, scheme, nvar, grav, s);
     case 2: return launch0<2>(A, riemann, by, scheme, nvar, grav, s);
     case 3: return launch0<3>(A, riemann, by, scheme, nvar, grav, s);
+    case 4: return launch0<4>(A, riemann, by, scheme, nvar, grav, s);
+    case 5: return launch0<5>(A, riemann, by, scheme, nvar, grav, s);
+    case 6: return launch0<6>(A, riemann, by, scheme, nvar, grav, s);
     case 7: return launch0<7>(A, riemann, by, scheme, nvar, grav, s);
     case 8: return launch0<8>(A, riemann, by, scheme, nvar, grav, s);
   }

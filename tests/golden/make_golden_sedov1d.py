@@ -53,7 +53,7 @@ tout=1000.0
 &HYDRO_PARAMS
 gamma=1.4
 courant_factor=0.8
-slope_type=2
+slope_type={slope}
 riemann='hllc'
 /
 
@@ -68,12 +68,15 @@ bound_type= {bt}
 # (&BOUNDARY_PARAMS bound_type: 1 reflexive, 2 outflow, 3 imposed; the direction comes from
 # ibound_min/max, hydro/read_hydro_params.f90:352-365)
 CASES = [("reflexive", "1, 1", 40, (1, 11, 41)), ("outflow", "2, 2", 60, (61,))]
+# the slope types only the NDIM=1 branch of uslope has (hydro/umuscl.f90:1030-1090: 4 superbee, 5 ultrabee, 6 central
+# difference on the density) and type 3, which means type 2 there (:1014-1023): reflexive walls, snapshots at steps 0, 10, 20
+SLOPE_CASES = [("st3", 3), ("st4", 4), ("st5", 5), ("st6", 6)]
 
 
 def main():
     out = {}
     for tag, bt, nstep, snaps in CASES:
-        work, log = rs.run_reference(NML.format(level=7, nstep=nstep, foutput=10 if tag == "reflexive" else nstep, bt=bt), ndim=1)
+        work, log = rs.run_reference(NML.format(level=7, nstep=nstep, foutput=10 if tag == "reflexive" else nstep, bt=bt, slope=2), ndim=1)
         try:
             outs = sorted(d for d in os.listdir(work) if d.startswith("output_"))
             print(tag, outs)
@@ -81,6 +84,17 @@ def main():
                 s = rs.load_leaf_cells(os.path.join(work, d))
                 order = np.argsort(s["x"][:, 0])
                 out["%s_x%d" % (tag, k)] = s["x"][order, 0]
+                out["%s_prim%d" % (tag, k)] = s["prim"][:, order]
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    for tag, slope in SLOPE_CASES:
+        work, log = rs.run_reference(NML.format(level=7, nstep=20, foutput=10, bt="1, 1", slope=slope), ndim=1)
+        try:
+            outs = sorted(d for d in os.listdir(work) if d.startswith("output_"))
+            print(tag, outs)
+            for k, d in enumerate(outs):
+                s = rs.load_leaf_cells(os.path.join(work, d))
+                order = np.argsort(s["x"][:, 0])
                 out["%s_prim%d" % (tag, k)] = s["prim"][:, order]
         finally:
             shutil.rmtree(work, ignore_errors=True)
