@@ -207,6 +207,55 @@ if __name__ == "__main__":
         if which in ("all", "ref"):
             run_c5("reference (1 core)", ref, {"RAMSES_AMD": "0"})
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "c5mpi":
+        # config C5's shape on several ranks (sedov3d.nml, AMR, hydro only): lmin lmax nstep nproc
+        lmin, lmax, nstep, nproc = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+        which = sys.argv[6] if len(sys.argv) > 6 else "all"
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("mkb", os.path.join(ROOT, "tests", "golden", "make_golden_baseline.py"))
+        mkb = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mkb)
+        ngt = {7: 2000000, 8: 8000000}.get(lmin, 600000)
+        nml = mkb.c5_namelist(lmin, lmax, nstep, ngt).replace("foutput=%d" % nstep, "foutput=1000")
+
+        def run_c5mpi(tag, binary, env):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            t0 = time.time()
+            try:
+                work, out = rs.run_reference(nml, binary=binary, nproc=nproc, timeout=3000)
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            wall = time.time() - t0
+            shutil.rmtree(work, ignore_errors=True)
+            rows = {}
+            for line in out.splitlines():
+                m = re.match(r"^\s*([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+\S+\s+([0-9.]+)\s+(\d+)\s+(\d+)\s+([a-zA-Z].*?)\s*$", line)
+                if m:
+                    rows[m.group(8)] = float(m.group(3))
+                m = re.match(r"^\s*([0-9.]+)\s+100\.0\s+TOTAL", line)
+                if m:
+                    rows["TOTAL"] = float(m.group(1))
+            last = {}
+            for l, g in re.findall(r"Level\s+(\d+) has\s+(\d+) grids", out):
+                last[int(l)] = int(g)
+            note = [l.strip() for l in out.splitlines() if "ramses_amd:" in l]
+            print(json.dumps({"config": tag, "levels": [lmin, lmax], "steps": nstep, "ranks": nproc, "wall_s": round(wall, 3),
+                              "octs_per_level": {k: v for k, v in last.items() if k >= lmin}, "timers_max_s": rows, "notes": note[:4]}), flush=True)
+
+        ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi")
+        pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi_patch")
+        if which in ("all", "gpu"):
+            run_c5mpi("patched, every rank's cell vectors and tree resident on the GPU, virtual boundaries on the device", pat, {"RAMSES_AMD": "1"})
+            run_c5mpi("patched, arrays staged around every godunov_fine + the reference's host MPI halo (round 1 path)", pat,
+                      {"RAMSES_AMD": "1", "RAMSES_AMD_RESIDENT_AMR_MPI": "0"})
+        if which in ("all", "ref"):
+            run_c5mpi("reference (MPI)", ref, {"RAMSES_AMD": "0"})
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "grav":
         level, nstep = int(sys.argv[2]), int(sys.argv[3])
         which = sys.argv[4] if len(sys.argv) > 4 else "all"
