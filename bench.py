@@ -469,6 +469,8 @@ def main():
     if world > 1:
         elapsed = exchange.transport.allreduce(elapsed, "cuda", op="max")
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    if os.environ.get("RAMSES_AMD_BENCH_STEPS"):      # debugging aid: the kernel time of every timed step
+        sys.stderr.write("bench.py rank %d: ms per step %s\n" % (rank, " ".join("%.3f" % a.elapsed_time(b) for a, b in ev)))
 
     # sanity: the state must still be physical
     chk = lev.courant_fine()

@@ -518,6 +518,10 @@ module ramses_amd_iface
        integer(c_int) :: son(*), nbor(*), father(*)
        integer(c_int) :: rc
      end function ramses_amd_amrres_tree
+     function ramses_amd_amrres_invalidate() bind(C, name='ramses_amd_amrres_invalidate') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_invalidate
      function ramses_amd_amrres_sync_level(ngrid, igrid, uold) bind(C, name='ramses_amd_amrres_sync_level') result(rc)
        import :: c_int, c_double
        integer(c_int), value :: ngrid
@@ -1256,7 +1260,8 @@ contains
        if (stat == 0) then
           if (trim(val) == '0') ramses_amd_amr_ok = .false.
        end if
-       if (levelmin >= nlevelmax .or. nboundary > 0 .or. nremap > 0) ramses_amd_amr_ok = .false.
+       if (levelmin >= nlevelmax .or. nboundary > 0) ramses_amd_amr_ok = .false.
+       ! (nremap > 0: load_balance.f90 of this directory hands the state back to the host before the octs move)
        if (ncpu > 1) then
           ! several ranks: the virtual-boundary exchanges of the hydro state run on the device too
           ! (virtual_boundaries.f90 of this directory); RAMSES_AMD_RESIDENT_AMR_MPI=0 keeps such runs staged.
@@ -1408,6 +1413,34 @@ contains
     ramses_amd_amr_host_from = min(ramses_amd_amr_host_from, max(ilevel - 1, levelmin))
     ramses_amd_amr_reload_from = min(ramses_amd_amr_reload_from, ilevel + 1)      ! refine_fine(ilevel) rebuilds level ilevel+1
   end subroutine ramses_amd_amr_refine_hook
+
+  !---------------------------------------------------------------------------
+  ! The reference is about to move octs between ranks (load_balance): every level the device holds the only
+  ! current copy of goes back to the host arrays, then the device image is dropped; the next device routine
+  ! loads everything again (ramses_amd_amr_ensure's first branch).
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_amr_host_takeover(where)
+    use amr_commons
+    use hydro_commons
+    character(len=*), intent(in) :: where
+    integer :: rc, l, nl
+    integer, allocatable :: list(:)
+    ramses_amd_tree_epoch = ramses_amd_tree_epoch + 1
+    if (.not. ramses_amd_amr_resident()) return
+    if (ramses_amd_amrres_active() == 0) return
+    do l = levelmin, min(nlevelmax, ramses_amd_amr_host_from - 1)
+       if (numbtot(1, l) > 0) then
+          call ramses_amd_amr_level_octs(l, nl, list)
+          rc = ramses_amd_amrres_sync_level(nl, list, uold)
+          deallocate(list)
+          if (rc /= 0) call ramses_amd_fatal('AMR residency (level sync before '//where//')')
+       end if
+    end do
+    rc = ramses_amd_amrres_invalidate()
+    if (rc /= 0) call ramses_amd_fatal('AMR residency (invalidate before '//where//')')
+    ramses_amd_amr_reload_from = 1000
+    ramses_amd_amr_host_from = 1000
+  end subroutine ramses_amd_amr_host_takeover
 
   !---------------------------------------------------------------------------
   ! AMR residency with several MPI ranks.  The octs of a level whose cells a rank holds: its own

@@ -46,7 +46,7 @@ def _mka():
     return mka
 
 
-def _namelist(lmin, lmax, nsub, riemann, slope, nstep, init=None, pfix=False):
+def _namelist(lmin, lmax, nsub, riemann, slope, nstep, init=None, pfix=False, nremap=0):
     from oracle import ramses_snapshot as rs
     mka = _mka()
     kw = {} if init is None else {"init": init}
@@ -55,6 +55,8 @@ def _namelist(lmin, lmax, nsub, riemann, slope, nstep, init=None, pfix=False):
     nml = rs.sedov3d_namelist(level=lmin, nstepmax=nstep, foutput=nstep, riemann=riemann, slope_type=slope,
                               extra=mka.REFINE.format(ivar=0, itype=2), mem_factor=1.0, **kw)
     nml = nml.replace("levelmax=%d" % lmin, "levelmax=%d" % lmax).replace("nsubcycle=10*1", "nsubcycle=" + nsub)
+    assert "nremap=0" in nml
+    nml = nml.replace("nremap=0", "nremap=%d" % nremap)
     return nml.replace("ngridtot=", "ngridtot=%d !" % (40000 if lmax >= 7 else 12000))
 
 
@@ -125,3 +127,29 @@ def test_amr_resident_under_mpi_off_switch(gpu_lib):
     finally:
         shutil.rmtree(workr, ignore_errors=True)
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2])
+
+
+@pytest.mark.parametrize("nproc,nremap", [(2, 1), (4, 2)])
+def test_amr_resident_under_mpi_with_load_balancing(gpu_lib, nproc, nremap):
+    """nremap > 0: every nremap coarse steps load_balance moves octs of every level between the ranks and rebuilds the
+    communicators (amr/amr_step.f90:109, amr/load_balance.f90:5-280).  The shim load_balance.f90 hands the state back to
+    the host first and drops the device image; the next device routine loads the re-balanced arrays.  Blast off the rank
+    boundaries, so that the balance really changes; leaf cells equal the MPI reference bit for bit."""
+    if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED_MPI)):
+        pytest.skip("oracle/_ref/ramses3d_mpi[_patch] not built")
+    nml = _namelist(4, 6, "1,1,2,2", "llf", 1, 6, OFF_CENTRE, nremap=nremap)
+    workp, outp = _run(nml, PATCHED_MPI, nproc, {"RAMSES_AMD": "1"})
+    try:
+        assert "AMR levels stay resident on the GPU" in outp, outp[-3000:]
+        got = _leaves(workp, 2)
+    finally:
+        shutil.rmtree(workp, ignore_errors=True)
+    workr, outr = _run(nml, REF_MPI, nproc, {})
+    try:
+        assert "Load balancing" in outr or "load balanc" in outr.lower(), outr[-2000:]
+        ref = _leaves(workr, 2)
+    finally:
+        shutil.rmtree(workr, ignore_errors=True)
+    assert got[3] == ref[3]
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert np.array_equal(got[2], ref[2]), np.abs(got[2] - ref[2]).max()
