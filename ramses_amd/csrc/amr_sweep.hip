@@ -377,6 +377,8 @@ constexpr int GRP_THREADS = 256;
 // workgroups per CU the register allocation must allow (256 threads: waves per SIMD).  The kernel is latency-bound: measured
 // on the 256^3 tree (profiles/r02_amr_probe_walk.txt) 3 groups (148 VGPRs, no spills) 4.46 ms, 4 (128 VGPRs, 13 spilled)
 // 3.44 ms, 5 (96 VGPRs, 144 spilled to scratch) 3.08 ms, 6 3.37 ms, 7 3.10 ms per sweep
+// (tried and dropped: unew of the updated cells fetched by the idle fourth wavefront behind the gather and parked in LDS --
+// 3.02 -> 3.30 ms, the extra live registers spill)
 #define RAMSES_AMD_GRP_MINWAVES 5
 #endif
 
@@ -573,8 +575,24 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
   // ---- (D) slopes + trace of the inner 6^3 cells -----------------------------------------
   const double dtdx = A.dt / A.dx;
   double qm[3][NV], qp[3][NV];
+  // Of the 6^3 cells around the updated 4^3 only 160 feed an interface: the inner 4^3 (all three directions) and the 6 x 16
+  // cells of the face shells (their one face towards the block); the 56 edge and corner cells feed none.  Threads 0..63
+  // trace the inner cells, 64..159 the shells (RAMSES_AMD_GRP_TRACE_ALL=1: all 216, the first form, A/B).
+#if defined(RAMSES_AMD_GRP_TRACE_ALL) && RAMSES_AMD_GRP_TRACE_ALL
   const bool tracer = t < 216;
   const int ti = t % 6, tj = (t / 6) % 6, tk = t / 36;
+#else
+  const bool tracer = t < 160;
+  int ti, tj, tk;
+  if (t < 64) {
+    ti = 1 + (t & 3); tj = 1 + ((t >> 2) & 3); tk = 1 + (t >> 4);
+  } else {
+    const int e = t - 64, f = e >> 4, pb = 1 + (e & 3), pc = 1 + ((e >> 2) & 3), pa = (f & 1) ? 5 : 0;
+    ti = (f >> 1) == 0 ? pa : pb;
+    tj = (f >> 1) == 1 ? pa : ((f >> 1) == 0 ? pb : pc);
+    tk = (f >> 1) == 2 ? pa : pc;
+  }
+#endif
   if (tracer) {
     const int s = gsidx(ti + 1, tj + 1, tk + 1);
     double qb[NV], dq[3][NV];

@@ -158,6 +158,43 @@ def test_c5_levels_7_9_checksum(gpu_lib, resident):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def test_c5_levels_7_10_on_8_ranks_equals_the_mpi_reference(gpu_lib):
+    """BASELINE config C5 as stated (sedov3d.nml, levelmin=7, levelmax=10, 8 ranks), 8 coarse steps: the patched MPI
+    program with every rank's cell vectors and tree resident on the GPU and both virtual-boundary exchanges of every level
+    on the device (the eight ranks share this box's one GPU: host-MPI transport) against the MPI reference on the same
+    eight ranks, live: leaf cells (level, position, primitive variables) and the time, bit for bit."""
+    ref_mpi = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi")
+    pat_mpi = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi_patch")
+    if not (os.path.exists(ref_mpi) and os.path.exists(pat_mpi)):
+        pytest.skip("oracle/_ref/ramses3d_mpi[_patch] not built")
+    from oracle import ramses_snapshot as rs
+    mkb = _mkb()
+    nml = mkb.c5_namelist(7, 10, 8, 3000000)
+    os.environ["RAMSES_AMD"] = "1"
+    work, out = rs.run_reference(nml, nproc=8, binary=pat_mpi)
+    try:
+        assert "AMR levels stay resident on the GPU" in out, out[-2000:]
+        got = rs.load_leaf_cells(os.path.join(work, "output_00002"))
+        dg = mkb.digest_leaves(got)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    os.environ["RAMSES_AMD"] = "0"
+    try:
+        work, out = rs.run_reference(nml, nproc=8, binary=ref_mpi)
+    finally:
+        os.environ["RAMSES_AMD"] = "1"
+    try:
+        ref = rs.load_leaf_cells(os.path.join(work, "output_00002"))
+        dr = mkb.digest_leaves(ref)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    counts = [int((ref["level"] == l).sum()) for l in (7, 8, 9, 10)]
+    assert min(counts) > 1000, counts                      # all four levels are populated
+    assert [int((got["level"] == l).sum()) for l in (7, 8, 9, 10)] == counts
+    assert got["info"]["t"] == ref["info"]["t"]
+    assert dg == dr
+
+
 @pytest.mark.parametrize("mode", ["resident", "staged", "host-driver"])
 def test_amr_self_gravity_levels_6_8_checksum(gpu_lib, mode):
     """AMR + self-gravity at levels 6-8 (0.53 M leaf cells, 3 coarse steps with regridding) through the patched
