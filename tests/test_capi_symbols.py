@@ -74,3 +74,25 @@ def test_no_gpu_means_no_silent_fallback():
     from ramses_amd.hydro import HydroLevel
     with pytest.raises(RamsesAmdError):
         HydroLevel(8, 8, 8, 0.1)
+
+
+def test_which_column_recognises_an_anonymous_array_by_address():
+    """make_virtual_fine_dp(xx,ilevel) receives an anonymous array (amr/amr_step.f90:61,397,505: uold(1,ivar),
+    unew(1,ivar)); the shim asks which column of a module array it is.  Host pointers only: no GPU needed."""
+    import numpy as np
+    from ramses_amd import _capi
+    L = _capi.lib()
+    ncell, nvar = 1000, 5
+    base = np.zeros(ncell * nvar)
+    other = np.zeros(ncell)
+    p = base.ctypes.data
+    for ivar in range(nvar):
+        assert L.ramses_amd_which_column(C.c_void_p(p + 8 * ncell * ivar), C.c_void_p(p), ncell, nvar) == ivar + 1
+    assert L.ramses_amd_which_column(C.c_void_p(p + 8), C.c_void_p(p), ncell, nvar) == 0              # inside a column
+    assert L.ramses_amd_which_column(C.c_void_p(p + 8 * ncell * nvar), C.c_void_p(p), ncell, nvar) == 0  # past the end
+    assert L.ramses_amd_which_column(C.c_void_p(other.ctypes.data), C.c_void_p(p), ncell, nvar) == 0
+    assert L.ramses_amd_which_column(None, C.c_void_p(p), ncell, nvar) == 0
+    # no communicators on the device before ramses_amd_amrres_comm_set
+    assert L.ramses_amd_amrres_comm_epoch(3) == -1
+    assert L.ramses_amd_amrres_comm_set(0, 1, 2, None, None, None, None) != 0
+    assert b"comm_set" in L.ramses_amd_last_error()

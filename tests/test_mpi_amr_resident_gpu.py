@@ -86,7 +86,7 @@ def _leaves(work, k):
     (4, 4, 6, "1,1,2,2", "hllc", 2, 5, OFF_CENTRE, False),
     (2, 5, 7, "10*2", "llf", 1, 4, OFF_CENTRE, False),
     (2, 3, 5, "1,1,2,2", "hllc", 1, 5, None, True),
-])
+], ids=["2ranks-3to5", "4ranks-4to6-offcentre", "2ranks-5to7-subcycled-offcentre", "2ranks-3to5-pressure_fix"])
 def test_amr_resident_under_mpi_equals_mpi_reference(gpu_lib, nproc, lmin, lmax, nsub, riemann, slope, nstep, init, pfix):
     if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED_MPI)):
         pytest.skip("oracle/_ref/ramses3d_mpi[_patch] not built")
