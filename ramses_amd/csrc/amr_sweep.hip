@@ -397,6 +397,11 @@ struct GrpFaces {
   double qp[3][80][NV];
 #endif
 };
+// pressure_fix: cmpflxm's tmp per face (normal velocity and internal-energy flux, hydro/umuscl.f90:714-856)
+template <bool PFIX>
+struct GrpTmp { double tp[3][2][80]; };
+template <>
+struct GrpTmp<false> {};
 #if RAMSES_AMD_GRP_SOA
 #define GU(s, v) u[v][s]
 #define GF(arr, d, r, v) f.arr[d][v][r]
@@ -404,8 +409,8 @@ struct GrpFaces {
 #define GU(s, v) u[s][v]
 #define GF(arr, d, r, v) f.arr[d][r][v]
 #endif
-template <int NV>
-struct GrpLds {
+template <int NV, bool PFIX>
+struct GrpLds : GrpTmp<PFIX> {
   union {
 #if RAMSES_AMD_GRP_SOA
     double u[NV][512];     // primitive variables of the 8^3 stencil (until the traces are done)
@@ -457,10 +462,10 @@ __global__ __launch_bounds__(256) void amr_group_walk_kernel(AmrSweepArgs A, con
   w[128 + t] = og > 0 ? posof[og - 1] : -1;
 }
 
-template <int ST, int RS, bool GRAV, int NV, int SCHEME>
+template <int ST, int RS, bool GRAV, int NV, int SCHEME, bool PFIX>
 __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_group_kernel(AmrSweepArgs A, const int *__restrict__ groups,
                                                                  const int *__restrict__ posof, const int *__restrict__ walk) {
-  __shared__ GrpLds<NV> L;
+  __shared__ GrpLds<NV, PFIX> L;
   const int t = threadIdx.x;
   const HydroConst &P = A.P;
   const int gF = groups[blockIdx.x];          // the father oct (level l-1)
@@ -646,9 +651,16 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
 #pragma unroll
     for (int v = 0; v < NV; v++) { qL[v] = L.GF(qm, d, r, v); qR[v] = L.GF(qp, d, r, v); }
     const bool pow2 = A.pow2 != 0;
-    if (d == 0) scaled_interface_flux<RS, NV, 0>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
-    else if (d == 1) scaled_interface_flux<RS, NV, 1>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
-    else scaled_interface_flux<RS, NV, 2>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
+    double tp2[2] = {0.0, 0.0};
+    if constexpr (PFIX) {
+      if (d == 0) scaled_interface_flux_tmp<RS, NV, 0>(qL, qR, P, A.dt, A.dx, A.rdx, pow2, fx, tp2);
+      else if (d == 1) scaled_interface_flux_tmp<RS, NV, 1>(qL, qR, P, A.dt, A.dx, A.rdx, pow2, fx, tp2);
+      else scaled_interface_flux_tmp<RS, NV, 2>(qL, qR, P, A.dt, A.dx, A.rdx, pow2, fx, tp2);
+    } else {
+      if (d == 0) scaled_interface_flux<RS, NV, 0>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
+      else if (d == 1) scaled_interface_flux<RS, NV, 1>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
+      else scaled_interface_flux<RS, NV, 2>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
+    }
     const int t0 = d == 0 ? 1 : 0, t1 = d == 2 ? 1 : 2;
     int cl[3];
     cl[d] = a + 1; cl[t0] = b + 2; cl[t1] = c + 2;            // stencil coordinates of the low cell of the face
@@ -657,6 +669,10 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
     const bool zero = L.ok[sl] || L.ok[sl + stride];
 #pragma unroll
     for (int v = 0; v < NV; v++) L.GF(qm, d, r, v) = zero ? 0.0 : fx[v];
+    if constexpr (PFIX) {
+      L.tp[d][0][r] = zero ? 0.0 : tp2[0];
+      L.tp[d][1][r] = zero ? 0.0 : tp2[1];
+    }
   }
   __syncthreads();
 
@@ -680,6 +696,19 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
         }
         A.unew[(long)v * ncell + cell - 1] = un;
       }
+      if constexpr (PFIX) {
+        // pressure_fix: velocity divergence and internal energy (hydro/godunov_fine.f90:771-786)
+        double dv = A.divu[cell - 1], en = A.enew[cell - 1];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          const int t0 = d == 0 ? 1 : 0, t1 = d == 2 ? 1 : 2;
+          const int a = ic[d], b = ic[t0], c = ic[t1];
+          dv = dv + (L.tp[d][0][gface(a, b, c)] - L.tp[d][0][gface(a + 1, b, c)]);
+          en = en + (L.tp[d][1][gface(a, b, c)] - L.tp[d][1][gface(a + 1, b, c)]);
+        }
+        A.divu[cell - 1] = dv;
+        A.enew[cell - 1] = en;
+      }
     }
   }
   // ---- (G) fluxes owed to coarse neighbour cells (same records as the single-oct kernel) --------
@@ -702,8 +731,13 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
           const int fi = gface(a, 2 * sc[t0] + (q & 1), 2 * sc[t1] + (q >> 1));
 #pragma unroll
           for (int v = 0; v < NV; v++) dst[q * CV + v] = L.GF(qm, d, fi, v);
-          dst[q * CV + NV] = 0.0;
-          dst[q * CV + NV + 1] = 0.0;
+          if constexpr (PFIX) {
+            dst[q * CV + NV] = L.tp[d][0][fi];
+            dst[q * CV + NV + 1] = L.tp[d][1][fi];
+          } else {
+            dst[q * CV + NV] = 0.0;
+            dst[q * CV + NV + 1] = 0.0;
+          }
         }
       }
     }
@@ -856,15 +890,21 @@ static hipError_t launch3(const AmrSweepArgs &A, const int *groups, int ngroups,
     const dim3 grid(ngroups), block(GRP_THREADS);
     if (A.scheme == 1) {
       if constexpr (NV == 5) {
-        if (A.grav) hipLaunchKernelGGL((amr_group_kernel<ST, RS, true, NV, 1>), grid, block, 0, s, A, groups, posof, walk);
-        else hipLaunchKernelGGL((amr_group_kernel<ST, RS, false, NV, 1>), grid, block, 0, s, A, groups, posof, walk);
+        if (A.grav) hipLaunchKernelGGL((amr_group_kernel<ST, RS, true, NV, 1, false>), grid, block, 0, s, A, groups, posof, walk);
+        else hipLaunchKernelGGL((amr_group_kernel<ST, RS, false, NV, 1, false>), grid, block, 0, s, A, groups, posof, walk);
         return hipGetLastError();
       } else {
         return hipErrorInvalidValue;
       }
     }
-    if (A.grav) hipLaunchKernelGGL((amr_group_kernel<ST, RS, true, NV, 0>), grid, block, 0, s, A, groups, posof, walk);
-    else hipLaunchKernelGGL((amr_group_kernel<ST, RS, false, NV, 0>), grid, block, 0, s, A, groups, posof, walk);
+    if (A.divu) {
+      // pressure_fix (the launcher sends plmde + pressure_fix to the single-oct kernel)
+      if (A.grav) hipLaunchKernelGGL((amr_group_kernel<ST, RS, true, NV, 0, true>), grid, block, 0, s, A, groups, posof, walk);
+      else hipLaunchKernelGGL((amr_group_kernel<ST, RS, false, NV, 0, true>), grid, block, 0, s, A, groups, posof, walk);
+      return hipGetLastError();
+    }
+    if (A.grav) hipLaunchKernelGGL((amr_group_kernel<ST, RS, true, NV, 0, false>), grid, block, 0, s, A, groups, posof, walk);
+    else hipLaunchKernelGGL((amr_group_kernel<ST, RS, false, NV, 0, false>), grid, block, 0, s, A, groups, posof, walk);
     return hipGetLastError();
   }
   const int blocks = (A.ngrid + OCTS_PER_BLOCK - 1) / OCTS_PER_BLOCK;
@@ -931,7 +971,7 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A_in, int slope_type, int riem
     const char *env = getenv("RAMSES_AMD_AMR_GROUP");
     use_groups = !(env && env[0] == '0');
   }
-  if (use_groups && !(A.difmag > 0.0) && A.divu == nullptr) {
+  if (use_groups && !(A.difmag > 0.0) && !(A.divu != nullptr && A.scheme == 1)) {
     e = hipMemsetAsync(count, 0, sizeof(int), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(amr_group_build_kernel, dim3((A.ngrid + 1023) / 1024), dim3(1024), 0, s, A, posof, groups, count);
