@@ -105,3 +105,26 @@ def test_mpi_build_through_the_reference_routines():
         assert np.array_equal(snap["prim"][:, order], z[tag + "_prim"])
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi_patch"))
+                         and os.path.exists("/opt/conda/bin/mpiexec")), reason="MPI build or mpiexec missing")
+def test_mpi_amr_run_with_load_balancing_through_the_reference_routines():
+    """RAMSES_AMD=0 under MPI on an AMR run with nremap=1: the shims of load_balance, build_comm,
+    make_virtual_fine_dp / make_virtual_reverse_dp, refine_fine, set_unew and courant_fine all take their
+    reference branch -- leaf cells equal the untouched MPI reference (live, 2 ranks)."""
+    t = _load(os.path.join(ROOT, "tests", "test_mpi_amr_resident_gpu.py"), "tmpi")
+    nml = t._namelist(3, 5, "1,1,2,2", "llf", 1, 5, t.OFF_CENTRE, nremap=1)
+    workp, outp = t._run(nml, t.PATCHED_MPI, 2, {"RAMSES_AMD": "0"})
+    try:
+        assert "resident on the GPU" not in outp and "Load balancing" in outp
+        got = t._leaves(workp, 2)
+    finally:
+        shutil.rmtree(workp, ignore_errors=True)
+    workr, outr = t._run(nml, t.REF_MPI, 2, {})
+    try:
+        ref = t._leaves(workr, 2)
+    finally:
+        shutil.rmtree(workr, ignore_errors=True)
+    assert got[3] == ref[3] and len(set(int(l) for l in ref[0])) >= 2
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
