@@ -422,6 +422,7 @@ struct AmrRes {
   Buf sendbuf, recvbuf;
   PinBuf h_send, h_recv;
   std::vector<int64_t> f_send_off, f_recv_off; // [ncpu+1], doubles, of the exchange that is under way
+  int halo_level = 0, halo_dir = -1;           // the exchange halo_stage_out has opened (0: none)
   bool valid = false;
   int nvar = 0;
   long ncell = 0, ncoarse = 0, ngridmax = 0;
@@ -937,6 +938,7 @@ int ramses_amd_amrres_halo_stage_out(int ilevel, int dir, int ncpu, int64_t *h_s
   HCHK(hipStreamSynchronize(nullptr), "sync");
   *h_send_addr = (int64_t)(intptr_t)R.h_send.p; *h_recv_addr = (int64_t)(intptr_t)R.h_recv.p;
   for (int c = 0; c <= ncpu; c++) { send_off[c] = R.f_send_off[c]; recv_off[c] = R.f_recv_off[c]; }
+  R.halo_level = ilevel; R.halo_dir = dir;
   return 0;
 }
 int ramses_amd_amrres_halo_stage_in(int ilevel, int dir) {
@@ -945,7 +947,10 @@ int ramses_amd_amrres_halo_stage_in(int ilevel, int dir) {
   HaloSpec S;
   if (int rc = comm_of(R, ilevel, L)) return rc;
   if (int rc = halo_spec(R, dir, S)) return rc;
-  if (R.f_recv_off.size() != (size_t)L->ncpu + 1) return failf(RAMSES_AMD_EINVAL, "halo stage_in without stage_out");
+  if (R.halo_level != ilevel || R.halo_dir != dir || R.f_recv_off.size() != (size_t)L->ncpu + 1)
+    return failf(RAMSES_AMD_EINVAL, "halo_stage_in(level %d, dir %d) does not close the exchange halo_stage_out opened (level %d, dir %d)",
+                 ilevel, dir, R.halo_level, R.halo_dir);
+  R.halo_level = 0; R.halo_dir = -1;
   const size_t nr = (size_t)R.f_recv_off[L->ncpu];
   if (nr > 0) HCHK(hipMemcpyAsync(R.recvbuf.p, R.h_recv.p, sizeof(double) * nr, hipMemcpyHostToDevice, nullptr), "H2D halo");
   return halo_unpack(R, *L, S);
