@@ -96,3 +96,18 @@ def test_which_column_recognises_an_anonymous_array_by_address():
     assert L.ramses_amd_amrres_comm_epoch(3) == -1
     assert L.ramses_amd_amrres_comm_set(0, 1, 2, None, None, None, None) != 0
     assert b"comm_set" in L.ramses_amd_last_error()
+
+
+def test_mpi_entry_points_fail_loudly_without_their_state():
+    """The stepwise entry points of the MPI paths refuse to run out of order (before any device call)."""
+    from ramses_amd import _capi
+    L = _capi.lib()
+    assert L.ramses_amd_amrres_zero_unew_virtual(3) != 0
+    assert b"no resident AMR state" in L.ramses_amd_last_error()
+    assert L.ramses_amd_amrres_halo_stage_in(3, 0) != 0
+    assert L.ramses_amd_amrres_halo_rccl(3, 1, 1) != 0
+    assert L.ramses_amd_cgmpi_step(0, 1) != 0
+    assert b"no CG solve is open" in L.ramses_amd_last_error()
+    v = C.c_double(0.0)
+    assert L.ramses_amd_cgmpi_get(0, C.byref(v)) != 0
+    assert L.ramses_amd_cgmpi_set(0, 1.0) != 0
