@@ -167,23 +167,36 @@ cmd=${1:-kernels}
 case "$cmd" in
   kernels) build_kernels "${2:-3}" "${3:-}";;
   ramses) build_ramses "${2:-3}" "${3:-serial}" "${4:-}";;
-  all) # every artefact tests/ and bench.py look for
-       build_kernels 3; build_kernels 1; build_kernels 2; build_kernels 3 7
-       build_ramses 3 serial; build_ramses 1 serial; build_ramses 2 serial
-       REF_DEFS=-DOUTPUT_PARTICLE_DENSITY REF_TAG=rho build_ramses 3 serial
-       if [ -d /opt/conda/include ] && [ -f /opt/conda/lib/libmpifort.so ]; then build_ramses 3 mpi; fi
+  all) # every artefact tests/ and bench.py look for; the programs are independent (own object and stub directories):
+       # built side by side, REF_JOBS at a time (default: the number of cores)
+       JOBS=${REF_JOBS:-$(nproc 2>/dev/null || echo 4)}
+       fail=0
+       bg() { # run "$@" in a subshell, at most JOBS at a time
+         while [ "$(jobs -rp | wc -l)" -ge "$JOBS" ]; do wait -n || fail=1; done
+         ( "$@" ) &
+       }
+       k() { build_kernels "$@"; }
+       r() { build_ramses "$@"; }
+       r_rho() { REF_DEFS=-DOUTPUT_PARTICLE_DENSITY REF_TAG=rho build_ramses 3 serial; }
+       r_v7() { REF_NVAR=7 REF_TAG=v7 build_ramses 3 serial "$@"; }
+       bg k 3; bg k 1; bg k 2; bg k 3 7
+       bg r 3 serial; bg r 1 serial; bg r 2 serial
+       bg r_rho
+       if [ -d /opt/conda/include ] && [ -f /opt/conda/lib/libmpifort.so ]; then bg r 3 mpi; fi
        if [ -f "$HERE/../ramses_amd/lib/libramses_amd.so" ]; then
-         build_ramses 3 serial "$HERE/../ramses_amd/patch"
-         build_ramses 1 serial "$HERE/../ramses_amd/patch"     # the shims compile for NDIM=1,2 (A/B tests with RAMSES_AMD=0)
-         build_ramses 2 serial "$HERE/../ramses_amd/patch"
+         bg r 3 serial "$HERE/../ramses_amd/patch"
+         bg r 1 serial "$HERE/../ramses_amd/patch"     # the shims compile for NDIM=1,2 (A/B tests with RAMSES_AMD=0)
+         bg r 2 serial "$HERE/../ramses_amd/patch"
          if [ -d /opt/conda/include ] && [ -f /opt/conda/lib/libmpifort.so ]; then
-           build_ramses 3 mpi "$HERE/../ramses_amd/patch"
+           bg r 3 mpi "$HERE/../ramses_amd/patch"
          fi
        fi
-       build_ramses 3 serial "$HERE/dump_patch"
-       REF_NVAR=7 REF_TAG=v7 build_ramses 3 serial
+       bg r 3 serial "$HERE/dump_patch"
+       bg r_v7
        if [ -f "$HERE/../ramses_amd/lib/libramses_amd.so" ]; then
-         REF_NVAR=7 REF_TAG=v7 build_ramses 3 serial "$HERE/../ramses_amd/patch"
-       fi;;
+         bg r_v7 "$HERE/../ramses_amd/patch"
+       fi
+       while [ "$(jobs -rp | wc -l)" -gt 0 ]; do wait -n || fail=1; done
+       if [ "$fail" != 0 ]; then echo "build_ref.sh: a build failed" >&2; exit 1; fi;;
   *) echo "usage: $0 kernels [NDIM] | ramses [NDIM] [serial|mpi] [PATCHDIR] | all"; exit 2;;
 esac
