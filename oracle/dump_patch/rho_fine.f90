@@ -16,7 +16,7 @@ subroutine rho_fine(ilevel,icount)
   use hydro_commons
   use poisson_commons
   implicit none
-  integer::ilevel,icount,stat
+  integer::ilevel,icount,stat,l
   integer,save::ncall=0
   logical::dumping
   character(len=256)::val
@@ -43,6 +43,16 @@ subroutine rho_fine(ilevel,icount)
      write(78)nbor
      write(78)father
      write(78)uold(:,1)
+     close(78)
+     ! the oct lists of every level the call visits (pm/rho_fine.f90:45-60: nlevelmax down to ilevel), in list order:
+     ! the deposit of a level adds its contributions in that order
+     write(fname,'(A,I4.4,A)')'rho_',ncall,'_lists.bin'
+     open(unit=78,file=trim(fname),form='unformatted',access='stream',status='replace')
+     write(78)nlevelmax
+     do l=ilevel,nlevelmax
+        write(78)active(l)%ngrid
+        if(active(l)%ngrid>0)write(78)active(l)%igrid(1:active(l)%ngrid)
+     end do
      close(78)
   end if
   call rho_fine_reference(ilevel,icount)

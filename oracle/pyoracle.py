@@ -222,6 +222,30 @@ def rho_fine_hydro(ilevel, levelmin, nvector, igrid, xg, son, nbor, father, ngri
     return rho, mp, rt.value
 
 
+def rho_fine_amr(ilevel, nlevelmax, levelmin, nvector, first, igrid_all, xg, son, nbor, father, ngridmax, ncoarse, boxlen, smallr, dens):
+    """rho_fine's hydro deposit on AMR levels (ora_rho_fine_amr): what a call rho_fine(ilevel,icount) with ilevel == levelmin
+    or icount > 1 leaves.  first / igrid_all: the oct lists of levels ilevel..nlevelmax, concatenated.
+    Returns (rho[ncell], multipole[4], rho_tot, unew[4, ncell])."""
+    ncell = ncoarse + 8 * ngridmax
+    fi, ig, so, nb, fa = (np.ascontiguousarray(a, np.int32) for a in (first, igrid_all, son, nbor, father))
+    assert len(fi) == nlevelmax - ilevel + 2 and fi[-1] == len(ig)
+    xg = np.ascontiguousarray(xg, np.float64)
+    dens = np.ascontiguousarray(dens, np.float64)
+    unew = np.zeros((4, ncell))
+    rho = np.zeros(ncell)
+    mp = np.zeros(4)
+    rt = C.c_double()
+    L = lib()
+    L.ora_rho_fine_amr.restype = None
+    L.ora_rho_fine_amr.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]
+    L.ora_rho_fine_amr(ilevel, nlevelmax, levelmin, nvector, fi.ctypes.data, ig.ctypes.data, xg.ctypes.data, so.ctypes.data,
+                       nb.ctypes.data, fa.ctypes.data, ngridmax, ncoarse, boxlen, smallr, dens.ctypes.data, unew.ctypes.data,
+                       rho.ctypes.data, mp.ctypes.data, C.addressof(rt))
+    return rho, mp, rt.value, unew
+
+
 def rho_deposit_gather(ilevel, levelmin, nvector, igrid, xg, son, nbor, father, ngridmax, ncoarse, boxlen, smallr, dens):
     """The same deposit formulated as a gather with order tags (ora_rho_deposit_gather): returns rho[ncell]."""
     ncell = ncoarse + 8 * ngridmax
@@ -242,6 +266,23 @@ def rho_deposit_gather(ilevel, levelmin, nvector, igrid, xg, son, nbor, father, 
     L.ora_rho_deposit_gather.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]
     L.ora_rho_deposit_gather(ilevel, nvector, len(ig), ig.ctypes.data, xg.ctypes.data, so.ctypes.data, nb.ctypes.data,
+                             fa.ctypes.data, ngridmax, ncoarse, boxlen, unew.ctypes.data, out.ctypes.data)
+    return out
+
+
+def rho_deposit_gather_level(level, nvector, igrid, xg, son, nbor, father, ngridmax, ncoarse, boxlen, unew):
+    """The order-tagged gather (ora_rho_deposit_gather) on one level from given multipoles unew[4, ncell]: rho[ncell]
+    (only the cells of the level's octs are written)."""
+    ncell = ncoarse + 8 * ngridmax
+    ig, so, nb, fa = (np.ascontiguousarray(a, np.int32) for a in (igrid, son, nbor, father))
+    xg = np.ascontiguousarray(xg, np.float64)
+    unew = np.ascontiguousarray(unew, np.float64)
+    out = np.zeros(ncell)
+    L = lib()
+    L.ora_rho_deposit_gather.restype = None
+    L.ora_rho_deposit_gather.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int64, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]
+    L.ora_rho_deposit_gather(level, nvector, len(ig), ig.ctypes.data, xg.ctypes.data, so.ctypes.data, nb.ctypes.data,
                              fa.ctypes.data, ngridmax, ncoarse, boxlen, unew.ctypes.data, out.ctypes.data)
     return out
 
