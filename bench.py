@@ -141,10 +141,35 @@ def pmc_traffic(n, world, args):
         path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sweep_traffic.json")))[-1]
         t = json.load(open(path))
         if t["n"] == n and world == 1 and args.fast == 1 and not args.tile_rows and not args.zchunk:
-            return t["traffic_bytes_per_launch"]
+            return t["traffic_bytes_per_launch"], ("%s: rocprofv3 PMC passes of this command (scripts/profile_gpu.sh), "
+                                                   "NOT measured in this run" % os.path.relpath(path, ROOT))
     except Exception:
         pass
-    return None
+    return None, "no matching PMC profile under profiles/"
+
+
+def rank_census(rank, world, local_dev, transport_note):
+    """Who ran: every rank's device (ramses_amd_device_uid = hash of host name + PCI bus id, the number the Fortran shim
+    compares before it brings RCCL up), so that an N-GPU line proves N ranks on N distinct devices."""
+    import torch
+    import torch.distributed as dist
+    from ramses_amd._capi import lib, check
+    uid = C.c_int64(0)
+    check(lib().ramses_amd_device_uid(C.byref(uid)))
+    try:
+        bus = torch.cuda.get_device_properties(local_dev).pci_bus_id
+    except Exception:     # noqa: BLE001
+        bus = None
+    mine = {"rank": rank, "device": local_dev, "uid": "%016x" % uid.value, "pci_bus_id": bus,
+            "rccl_comm_of_the_library": bool(lib().ramses_amd_rccl_ready())}
+    if world > 1:
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+    else:
+        allr = [mine]
+    return {"world_size": world, "distinct_devices": len({r["uid"] for r in allr}), "per_rank": allr,
+            "library_rccl_ranks": sum(1 for r in allr if r["rccl_comm_of_the_library"]),
+            "transport": "none (single rank)" if world == 1 else (transport_note or "RCCL send/recv (torch.distributed)")}
 
 
 BYTES_PER_DOF_VCYCLE = 227   # SURVEY.md 8d: 202 B fine level + 178/7 B coarse hierarchy
@@ -499,9 +524,11 @@ def main():
     chk = lev.courant_fine()
     assert chk[0] > 0 and chk[1] > 0
 
+    census = rank_census(rank, world, local_dev, transport_note)     # collective
     if rank == 0:
         cells = n ** 3
         value = cells * world * args.steps / elapsed
+        traffic, traffic_src = pmc_traffic(n, world, args)
         achieved = cells * BYTES_PER_CELL_UPDATE / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "cell-updates/s (Godunov sweep), uniform Sedov3D",
@@ -515,6 +542,7 @@ def main():
                        "arithmetic": "fast (explicit FMAs, rcp/rsq + Newton; rel-Linf of strict <= 2e-15 over 24 Sedov steps at 64^3 and 128^3, "
                                      "bound 1e-12: tests/test_baseline_sizes_gpu.py::test_fast_build_multistep_within_tolerance)" if args.fast else "strict (bit-identical to the reference)",
                        "spinup": "%d untimed sweeps of a scratch 256^3 level before the warm-up steps (clock ramp, %d ms)" % (spin_sweeps, args.spinup_ms),
+                       "ranks": census,
                        "halo": "none (single rank, in-kernel periodic wrap)" if world == 1 else
                                ("RCCL send/recv (torch.distributed)" if transport_note is None else transport_note) +
                                " of 2-cell face slabs, all nvar fused, " +
@@ -523,7 +551,7 @@ def main():
                                ("" if tune is None else " (auto-selected: serial %.3f ms/step, overlapped %.3f ms/step)"
                                 % (tune[False] * 1e3, tune[True] * 1e3))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, world, args),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "godunov_sweep_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL_UPDATE},
         }

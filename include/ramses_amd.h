@@ -575,13 +575,18 @@ int ramses_amd_resident_invalidate(void);
  * rank calls ramses_amd_rccl_init after selecting its device (ramses_amd_set_device_auto).
  * ramses_amd_rccl_exchange: ONE grouped ncclSend/ncclRecv, message i to/from rank peer[i], offsets and
  * counts in doubles into device buffers (replaces the MPI_ISEND/MPI_IRECV rounds of make_virtual_fine_dp,
- * amr/virtual_boundaries.f90:373-528, with all nvar fields fused).  ramses_amd_rccl_allreduce: in-place
+ * amr/virtual_boundaries.f90:373-528, with all nvar fields fused); peer[i] may be the caller's own rank (the
+ * send to self matches the receive from self of the same group; counts must agree).  ramses_amd_rccl_allreduce: in-place
  * reduction of n device doubles, op 0 sum / 1 min / 2 max (courant_fine's MPI_ALLREDUCE,
  * hydro/courant_fine.f90:133-140; multigrid norms; CG dot products).
  * ------------------------------------------------------------------------- */
 #define RAMSES_AMD_RCCL_ID_BYTES 128
 /* equal for two processes exactly when they drive the same GPU of the same host (RCCL refuses that) */
 int ramses_amd_device_uid(int64_t *uid);
+/* local half of the bring-up (dlopen + symbols, no communication): the launcher reduces the result over the
+ * ranks BEFORE anyone enters the collective ramses_amd_rccl_init, so that one rank without librccl.so makes
+ * every rank fall back to the host transport instead of leaving the others blocked in ncclCommInitRank */
+int ramses_amd_rccl_probe(void);
 int ramses_amd_rccl_unique_id(char *id128);
 int ramses_amd_rccl_init(const char *id128, int nranks, int rank);
 int ramses_amd_rccl_ready(void);
@@ -652,7 +657,8 @@ int ramses_amd_mpires_invalidate(void);
  *   ramses_amd_amrres_upload_fine  upload_fine / upl  hydro/interpol_hydro.f90:5-263
  *   ramses_amd_amrres_courant      courant_fine  hydro/courant_fine.f90:1-159 (leaf cells; out4 as ramses_amd_resident_courant_f90)
  *   ramses_amd_amrres_hydro_flag   hydro_flag's gradient criteria (hydro/hydro_flag.f90:84-140, hydro_refine
- *                                  hydro/godunov_utils.f90:125-263): ok[(ind-1)*ngrid+i] = 1 where a cell asks for refinement
+ *                                  hydro/godunov_utils.f90:125-263): cells[0..*ncells) = the cells (1-based, ascending) that ask
+ *                                  for refinement, compacted on the device; capacity of cells: 8*ngrid
  * ------------------------------------------------------------------------- */
 int ramses_amd_amrres_active(void);
 int ramses_amd_amrres_load(int nvar, int64_t ngridmax, int64_t ncoarse, const double *uold, const int *son, const int *nbor,
@@ -684,7 +690,7 @@ int ramses_amd_amrres_set_unew_pfix(const ramses_amd_hydro_params *p, int ngrid,
 int ramses_amd_amrres_set_uold_pfix(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double dt, double dx_loc,
                                     double beta_fix, double hexp);
 int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double err_grad_d, double err_grad_p,
-                                 double err_grad_u, double floor_d, double floor_p, double floor_u, int *ok);
+                                 double err_grad_u, double floor_d, double floor_p, double floor_u, int *cells, int *ncells);
 int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, double dx, double dt,
                               int nvector, int interpol_var, int interpol_type);
 /* Several MPI ranks (one per GPU): the virtual-boundary exchanges of amr_step on the resident cell vectors.

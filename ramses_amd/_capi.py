@@ -131,6 +131,7 @@ SYMBOLS = [
     ("ramses_amd_resident_invalidate", _i, []),
     # MPI: one rank per GPU
     ("ramses_amd_device_uid", _i, [_vp]),
+    ("ramses_amd_rccl_probe", _i, []),
     ("ramses_amd_rccl_unique_id", _i, [_vp]),
     ("ramses_amd_rccl_init", _i, [_vp, _i, _i]),
     ("ramses_amd_rccl_ready", _i, []),
@@ -172,7 +173,7 @@ SYMBOLS = [
     ("ramses_amd_amrres_enable_pfix", _i, []),
     ("ramses_amd_amrres_set_unew_pfix", _i, [_PP, _i, _vp]),
     ("ramses_amd_amrres_set_uold_pfix", _i, [_PP, _i, _vp, _d, _d, _d, _d]),
-    ("ramses_amd_amrres_hydro_flag", _i, [_PP, _i, _vp, _d, _d, _d, _d, _d, _d, _vp]),
+    ("ramses_amd_amrres_hydro_flag", _i, [_PP, _i, _vp, _d, _d, _d, _d, _d, _d, _vp, _vp]),
     ("ramses_amd_amrres_godunov", _i, [_PP, _i, _i, _vp, _d, _d, _i, _i, _i]),
     # AMR residency under MPI: the virtual-boundary exchanges on the resident cell vectors
     ("ramses_amd_which_column", _i, [_vp, _vp, _i64, _i]),

@@ -373,50 +373,31 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
 // carry (difmag, pressure_fix) take the single-oct kernel.
 // ===========================================================================
 constexpr int GRP_THREADS = 256;
-#ifndef RAMSES_AMD_GRP_MINWAVES
 // workgroups per CU the register allocation must allow (256 threads: waves per SIMD).  The kernel is latency-bound: measured
 // on the 256^3 tree (profiles/r02_amr_probe_walk.txt) 3 groups (148 VGPRs, no spills) 4.46 ms, 4 (128 VGPRs, 13 spilled)
 // 3.44 ms, 5 (96 VGPRs, 144 spilled to scratch) 3.08 ms, 6 3.37 ms, 7 3.10 ms per sweep
 // (tried and dropped: unew of the updated cells fetched by the idle fourth wavefront behind the gather and parked in LDS --
 // 3.02 -> 3.30 ms, the extra live registers spill)
-#define RAMSES_AMD_GRP_MINWAVES 5
-#endif
+constexpr int GRP_MINWAVES = 5;
 
-// LDS layout of the stencil and the face arrays: variable-major (RAMSES_AMD_GRP_SOA=1, the default: consecutive lanes
-// touch consecutive doubles of one variable) or cell-major (0: the NV values of a cell together, 40-byte stride)
-#ifndef RAMSES_AMD_GRP_SOA
-#define RAMSES_AMD_GRP_SOA 1
-#endif
+// LDS layout of the stencil and the face arrays: variable-major (consecutive lanes touch consecutive doubles of one
+// variable; cell-major, the NV values of a cell together, measured the same: 3.795 vs 3.778 ms)
 template <int NV>
 struct GrpFaces {
-#if RAMSES_AMD_GRP_SOA
   double qm[3][NV][80];   // traced state on the +d face of the low cell of face (a = 0..4, 4x4 transverse); then the flux
   double qp[3][NV][80];   // traced state on the -d face of the high cell
-#else
-  double qm[3][80][NV];
-  double qp[3][80][NV];
-#endif
 };
 // pressure_fix: cmpflxm's tmp per face (normal velocity and internal-energy flux, hydro/umuscl.f90:714-856)
 template <bool PFIX>
 struct GrpTmp { double tp[3][2][80]; };
 template <>
 struct GrpTmp<false> {};
-#if RAMSES_AMD_GRP_SOA
 #define GU(s, v) u[v][s]
 #define GF(arr, d, r, v) f.arr[d][v][r]
-#else
-#define GU(s, v) u[s][v]
-#define GF(arr, d, r, v) f.arr[d][r][v]
-#endif
 template <int NV, bool PFIX>
 struct GrpLds : GrpTmp<PFIX> {
   union {
-#if RAMSES_AMD_GRP_SOA
     double u[NV][512];     // primitive variables of the 8^3 stencil (until the traces are done)
-#else
-    double u[512][NV];
-#endif
     GrpFaces<NV> f;
   };
   // tab[0..63]    fc: the 4^3 father cells (1-based cell index, 0: not there)
@@ -463,7 +444,7 @@ __global__ __launch_bounds__(256) void amr_group_walk_kernel(AmrSweepArgs A, con
 }
 
 template <int ST, int RS, bool GRAV, int NV, int SCHEME, bool PFIX>
-__global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_group_kernel(AmrSweepArgs A, const int *__restrict__ groups,
+__global__ __launch_bounds__(GRP_THREADS, GRP_MINWAVES) void amr_group_kernel(AmrSweepArgs A, const int *__restrict__ groups,
                                                                  const int *__restrict__ posof, const int *__restrict__ walk) {
   __shared__ GrpLds<NV, PFIX> L;
   const int t = threadIdx.x;
@@ -582,11 +563,7 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
   double qm[3][NV], qp[3][NV];
   // Of the 6^3 cells around the updated 4^3 only 160 feed an interface: the inner 4^3 (all three directions) and the 6 x 16
   // cells of the face shells (their one face towards the block); the 56 edge and corner cells feed none.  Threads 0..63
-  // trace the inner cells, 64..159 the shells (RAMSES_AMD_GRP_TRACE_ALL=1: all 216, the first form, A/B).
-#if defined(RAMSES_AMD_GRP_TRACE_ALL) && RAMSES_AMD_GRP_TRACE_ALL
-  const bool tracer = t < 216;
-  const int ti = t % 6, tj = (t / 6) % 6, tk = t / 36;
-#else
+  // trace the inner cells, 64..159 the shells.
   const bool tracer = t < 160;
   int ti, tj, tk;
   if (t < 64) {
@@ -597,7 +574,6 @@ __global__ __launch_bounds__(GRP_THREADS, RAMSES_AMD_GRP_MINWAVES) void amr_grou
     tj = (f >> 1) == 1 ? pa : ((f >> 1) == 0 ? pb : pc);
     tk = (f >> 1) == 2 ? pa : pc;
   }
-#endif
   if (tracer) {
     const int s = gsidx(ti + 1, tj + 1, tk + 1);
     double qb[NV], dq[3][NV];
@@ -952,7 +928,7 @@ static hipError_t launch1(const AmrSweepArgs &A, int rs, const int *groups, int 
 }  // namespace amrsweep
 
 hipError_t launch_amr_godunov(const AmrSweepArgs &A_in, int slope_type, int riemann, int *posof, int nvector,
-                              hipStream_t s, double *pack_area) {
+                              hipStream_t s, double *pack_area, int *walk_area) {
   using namespace amrsweep;
   AmrSweepArgs A = A_in;
   A.packed = nullptr; A.rec = 0;
@@ -991,19 +967,12 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A_in, int slope_type, int riem
       const char *env = getenv("RAMSES_AMD_AMR_WALK");
       use_walk = !(env && env[0] == '0');
     }
-    if (use_walk && ngroups > 0) {
-      static int *walk_buf = nullptr;         // grow-only scratch of the library (768 bytes per father oct)
-      static size_t walk_cap = 0;
-      const size_t need = sizeof(int) * 192 * (size_t)ngroups;
-      if (need > walk_cap) {
-        if (walk_buf) { (void)hipFree(walk_buf); walk_buf = nullptr; walk_cap = 0; }
-        e = hipMalloc(reinterpret_cast<void **>(&walk_buf), need + need / 4);
-        if (e != hipSuccess) return e;
-        walk_cap = need + need / 4;
-      }
+    if (use_walk && walk_area && ngroups > 0) {
+      // 768 bytes per father oct, carved out of the caller's workspace like every other scratch area of the call
+      // (two calls on two streams with two workspaces do not share anything)
       const long nthr = (long)ngroups * 64;
-      hipLaunchKernelGGL(amr_group_walk_kernel, dim3((int)((nthr + 255) / 256)), dim3(256), 0, s, A, groups, ngroups, posof, walk_buf);
-      walk = walk_buf;
+      hipLaunchKernelGGL(amr_group_walk_kernel, dim3((int)((nthr + 255) / 256)), dim3(256), 0, s, A, groups, ngroups, posof, walk_area);
+      walk = walk_area;
     }
     if (use_pack && pack_area && ngroups > 0) {
       const int nvt = A.nvar + (A.grav ? 3 : 0);

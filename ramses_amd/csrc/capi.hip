@@ -801,10 +801,15 @@ static size_t amr_ws_pack_offset(int ngrid, int64_t ngridmax) {
                       sizeof(int) * ((size_t)ngrid + 16) + 64;
   return (head + 127) / 128 * 128;
 }
+static size_t amr_ws_walk_offset(int ngrid, int64_t ngridmax) {
+  const size_t o = amr_ws_pack_offset(ngrid, ngridmax) + sizeof(double) * (size_t)AMR_PACK_REC_MAX * (size_t)ngrid;
+  return (o + 127) / 128 * 128;
+}
 int64_t ramses_amd_godunov_fine_amr_workspace(int ngrid, int64_t ngridmax) {
   if (ngrid < 0 || ngridmax < 1) return fail(RAMSES_AMD_EINVAL, "bad argument");
-  // coarse-correction records, their targets, oct -> list position, the father-oct groups and their counter
-  return (int64_t)(amr_ws_pack_offset(ngrid, ngridmax) + sizeof(double) * (size_t)AMR_PACK_REC_MAX * (size_t)ngrid);
+  // coarse-correction records, their targets, oct -> list position, the father-oct groups and their counter; the packed
+  // oct records; the father-cell walk table of the groups (192 ints per father oct, at most one group per oct of the list)
+  return (int64_t)(amr_ws_walk_offset(ngrid, ngridmax) + sizeof(int) * 192 * (size_t)ngrid);
 }
 
 static int amr_check(const ramses_amd_hydro_params *p, int ilevel, int nvector, int interpol_var, int interpol_type) {
@@ -848,7 +853,8 @@ int ramses_amd_godunov_fine_amr_device(const ramses_amd_hydro_params *p, int ile
   A.err = d_err;
   A.P = make_const(p);
   double *pack_area = reinterpret_cast<double *>(reinterpret_cast<char *>(d_work) + amr_ws_pack_offset(ngrid, ngridmax));
-  hipError_t e = launch_amr_godunov(A, p->slope_type, p->riemann, posof, nvector, reinterpret_cast<hipStream_t>(stream), pack_area);
+  int *walk_area = reinterpret_cast<int *>(reinterpret_cast<char *>(d_work) + amr_ws_walk_offset(ngrid, ngridmax));
+  hipError_t e = launch_amr_godunov(A, p->slope_type, p->riemann, posof, nvector, reinterpret_cast<hipStream_t>(stream), pack_area, walk_area);
   if (e != hipSuccess) return hipfail(e, "AMR godunov launch");
   return 0;
 }

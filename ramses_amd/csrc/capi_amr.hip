@@ -17,6 +17,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -146,10 +147,20 @@ __global__ __launch_bounds__(256) void lvl_courant_kernel(LvlArgs A, const doubl
     double d = red[0][0], m = red[0][1], e = red[0][2], ei = red[0][3];
     for (int w = 1; w < 4; w++) { d = __builtin_fmin(d, red[w][0]); m += red[w][1]; e += red[w][2]; ei += red[w][3]; }
     atomicMin(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(d));
-    atomicAdd(out + 1, m); atomicAdd(out + 2, e); atomicAdd(out + 3, ei);
+    // the diagnostics: one partial per workgroup, added in workgroup order by lvl_courant_final_kernel (reproducible
+    // prints of mcons / econs; the grid is fixed by the level's size, so the same run gives the same digits)
+    double *part = out + 4 + 3 * (long)blockIdx.x;
+    part[0] = m; part[1] = e; part[2] = ei;
   }
 }
 __global__ void lvl_courant_init_kernel(double *out, double dt_init) { out[0] = dt_init; out[1] = out[2] = out[3] = 0.0; }
+__global__ void lvl_courant_final_kernel(double *out, int nblocks) {
+  const int k = threadIdx.x;     // 0: mass, 1: total energy, 2: internal energy
+  if (k >= 3) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; b++) s += out[4 + 3 * (long)b + k];
+  out[1 + k] = s;
+}
 
 // hydro_flag's gradient criteria (hydro_refine): ok[ind*ngrid+i] = 1 when the cell is to be refined
 struct FlagCrit { double err_grad_d, err_grad_p, err_grad_u, floor_d, floor_p, floor_u, gamma, smallr; };
@@ -166,15 +177,21 @@ __device__ __forceinline__ void refine_prim(const LvlArgs &A, long c, const Flag
   for (int d = 0; d < 3; d++) ek = ek + 0.5 * q[0] * (q[1 + d] * q[1 + d]);
   q[4] = (F.gamma - 1.0) * (u[4] - ek);
 }
-__global__ __launch_bounds__(256) void lvl_flag_kernel(LvlArgs A, FlagCrit F, int *__restrict__ ok) {
+// out: the cells that ask for refinement as a compact list of 1-based cell indices (one atomic per wavefront; the order
+// is whatever the waves arrive in -- the host sorts the few that come back)
+__global__ __launch_bounds__(256) void lvl_flag_kernel(LvlArgs A, FlagCrit F, int *__restrict__ list, int *__restrict__ count) {
   const long total = (long)A.ngrid * 8;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+  const long span = (long)gridDim.x * blockDim.x;
+  for (long t0 = (long)blockIdx.x * blockDim.x; t0 < total; t0 += span) {
+    const long t = t0 + threadIdx.x;
+    bool flag = false;
+    long c = 0;
+    if (t < total) {
     const int ind = (int)(t / A.ngrid), i = (int)(t % A.ngrid);
     const int g = A.igrid[i];
-    const long c = A.ncoarse + (long)ind * A.ngridmax + g - 1;
+    c = A.ncoarse + (long)ind * A.ngridmax + g - 1;
     double qm[5];
     refine_prim(A, c, F, qm);
-    bool flag = false;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
       // neighbour cells in direction d (getnborcells); a missing one is replaced by the neighbouring father cell
@@ -216,7 +233,15 @@ __global__ __launch_bounds__(256) void lvl_flag_kernel(LvlArgs A, FlagCrit F, in
         }
       }
     }
-    ok[t] = flag ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(flag);
+    if (m) {
+      const int lane = threadIdx.x & 63;
+      int base = 0;
+      if (lane == 0) base = atomicAdd(count, __popcll(m));
+      base = __shfl(base, 0, 64);
+      if (flag) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)(c + 1);
+    }
   }
 }
 
@@ -501,7 +526,7 @@ int ramses_amd_amrres_load(int nvar, int64_t ngridmax, int64_t ncoarse, const do
   HCHK(R.son.ensure(sizeof(int) * (size_t)R.ncell), "hipMalloc son");
   HCHK(R.nbor.ensure(sizeof(int) * 6 * (size_t)ngridmax), "hipMalloc nbor");
   HCHK(R.father.ensure(sizeof(int) * (size_t)ngridmax), "hipMalloc father");
-  HCHK(R.err.ensure(sizeof(int)), "hipMalloc"); HCHK(R.red.ensure(sizeof(double) * 4), "hipMalloc");
+  HCHK(R.err.ensure(sizeof(int)), "hipMalloc"); HCHK(R.red.ensure(sizeof(double) * (4 + 3 * 2048)), "hipMalloc");
   HCHK(hipMemcpyAsync(R.uold.p, uold, vb, hipMemcpyHostToDevice, nullptr), "H2D uold");
   HCHK(hipMemsetAsync(R.unew.p, 0, vb, nullptr), "memset unew");
   R.valid = true;
@@ -613,6 +638,7 @@ int ramses_amd_amrres_courant(const ramses_amd_hydro_params *p, int ngrid, const
     if (g > 2048) g = 2048;
     if (R.grav) hipLaunchKernelGGL(lvl_courant_kernel<true>, dim3(g), dim3(256), 0, nullptr, A, R.f.as<double>(), make_const_amr(p), dx, dx * dx * dx, p->courant_factor, dt0, R.red.as<double>());
     else hipLaunchKernelGGL(lvl_courant_kernel<false>, dim3(g), dim3(256), 0, nullptr, A, (const double *)nullptr, make_const_amr(p), dx, dx * dx * dx, p->courant_factor, dt0, R.red.as<double>());
+    hipLaunchKernelGGL(lvl_courant_final_kernel, dim3(1), dim3(64), 0, nullptr, R.red.as<double>(), g);
   }
   HCHK(hipGetLastError(), "courant launch");
   HCHK(hipMemcpy(out4, R.red.p, sizeof(double) * 4, hipMemcpyDeviceToHost), "D2H courant");
@@ -620,20 +646,31 @@ int ramses_amd_amrres_courant(const ramses_amd_hydro_params *p, int ngrid, const
   return 0;
 }
 
-// hydro_flag's gradient criteria: ok[(ind-1)*ngrid + i] (host) = 1 where hydro_refine asks for refinement
+// hydro_flag's gradient criteria: the cells (1-based indices into the cell vectors, ascending) where hydro_refine asks
+// for refinement come back as a compact list -- cells[0..*ncells), capacity 8*ngrid -- and nothing else crosses PCIe
 int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double err_grad_d, double err_grad_p,
-                                 double err_grad_u, double floor_d, double floor_p, double floor_u, int *ok) {
-  if (!p || !ok) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+                                 double err_grad_u, double floor_d, double floor_p, double floor_u, int *cells, int *ncells) {
+  if (!p || !cells || !ncells) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  *ncells = 0;
   LvlArgs A;
   if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
   if (ngrid == 0) return 0;
   if (A.nvar < 5) return failf(RAMSES_AMD_EUNSUPPORTED, "NVAR");
   AmrRes &R = g_ar;
-  HCHK(R.okbuf.ensure(sizeof(int) * 8 * (size_t)ngrid), "hipMalloc");
+  HCHK(R.okbuf.ensure(sizeof(int) * (8 * (size_t)ngrid + 1)), "hipMalloc");
+  int *d_count = R.okbuf.as<int>(), *d_list = d_count + 1;
+  HCHK(hipMemsetAsync(d_count, 0, sizeof(int), nullptr), "memset");
   FlagCrit F = {err_grad_d, err_grad_p, err_grad_u, floor_d, floor_p, floor_u, p->gamma, p->smallr};
-  hipLaunchKernelGGL(lvl_flag_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, A, F, R.okbuf.as<int>());
+  hipLaunchKernelGGL(lvl_flag_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, A, F, d_list, d_count);
   HCHK(hipGetLastError(), "hydro_flag launch");
-  HCHK(hipMemcpy(ok, R.okbuf.p, sizeof(int) * 8 * (size_t)ngrid, hipMemcpyDeviceToHost), "D2H flags");
+  int n = 0;
+  HCHK(hipMemcpy(&n, d_count, sizeof(int), hipMemcpyDeviceToHost), "D2H flag count");
+  if (n < 0 || (long)n > 8L * ngrid) return failf(RAMSES_AMD_EHIP, "hydro_flag: bad flag count %d", n);
+  if (n > 0) {
+    HCHK(hipMemcpy(cells, d_list, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost), "D2H flagged cells");
+    std::sort(cells, cells + n);
+  }
+  *ncells = n;
   return 0;
 }
 
@@ -912,7 +949,9 @@ int ramses_amd_amrres_halo_rccl(int ilevel, int dir, int myid) {
   for (int c = 0; c < L->ncpu; c++) {
     const int64_t ns = R.f_send_off[c + 1] - R.f_send_off[c], nr = R.f_recv_off[c + 1] - R.f_recv_off[c];
     if (ns == 0 && nr == 0) continue;
-    if (c == myid - 1) return failf(RAMSES_AMD_EINVAL, "level %d: a communicator of the rank with itself", ilevel);
+    // c == myid - 1 (a communicator of the rank with itself) is legal: the grouped exchange matches the send to self with
+    // the receive from self; build_comm never produces one, the single-rank execution test of the transport does
+    (void)myid;
     peer.push_back(c); so.push_back(R.f_send_off[c]); sc.push_back(ns); ro.push_back(R.f_recv_off[c]); rcn.push_back(nr);
   }
   if (int rc = ramses_amd_rccl_exchange((int)peer.size(), peer.data(), R.sendbuf.as<double>(), so.data(), sc.data(), R.recvbuf.as<double>(),

@@ -88,6 +88,8 @@ int rccl_load() {
   return 0;
 }
 #define NCHK(call, what) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return failf(RAMSES_AMD_EHIP, "%s: %s", what, g_rccl.GetErrorString(r_)); } while (0)
+// inside ncclGroupStart ... ncclGroupEnd: close the group before reporting, so that the next exchange does not nest into it
+#define NCHK_GROUP(call, what) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { g_rccl.GroupEnd(); return failf(RAMSES_AMD_EHIP, "%s: %s", what, g_rccl.GetErrorString(r_)); } } while (0)
 }  // namespace
 
 extern "C" {
@@ -108,6 +110,16 @@ int ramses_amd_device_uid(int64_t *uid) {
   h ^= 0xff; h *= 1099511628211ull;
   for (const char *c = bus; *c; c++) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
   *uid = (int64_t)(h >> 1);
+  return 0;
+}
+
+// Local half of bringing RCCL up: dlopen + symbol lookup, no communication.  The launcher reduces the result over
+// the ranks and enters the collective ncclCommInitRank only when every rank passed (a rank that cannot load the
+// library would otherwise leave the others blocked in it).
+int ramses_amd_rccl_probe(void) {
+  if (int rc = rccl_load()) return rc;
+  int dev = 0;
+  HCHK(hipGetDevice(&dev), "hipGetDevice");
   return 0;
 }
 
@@ -154,9 +166,11 @@ int ramses_amd_rccl_exchange(int npeer, const int *peer, const double *d_send, c
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   NCHK(R.GroupStart(), "ncclGroupStart");
   for (int i = 0; i < npeer; i++) {
-    if (peer[i] < 0 || peer[i] >= R.nranks || peer[i] == R.rank) { R.GroupEnd(); return failf(RAMSES_AMD_EINVAL, "bad peer rank %d", peer[i]); }
-    if (recv_cnt[i] > 0) NCHK(R.Recv(d_recv + recv_off[i], (size_t)recv_cnt[i], ncclDouble, peer[i], R.comm, s), "ncclRecv");
-    if (send_cnt[i] > 0) NCHK(R.Send(d_send + send_off[i], (size_t)send_cnt[i], ncclDouble, peer[i], R.comm, s), "ncclSend");
+    // peer[i] == own rank is legal: RCCL matches a send to self with the receive from self of the same group
+    if (peer[i] < 0 || peer[i] >= R.nranks) { R.GroupEnd(); return failf(RAMSES_AMD_EINVAL, "bad peer rank %d", peer[i]); }
+    if (peer[i] == R.rank && send_cnt[i] != recv_cnt[i]) { R.GroupEnd(); return failf(RAMSES_AMD_EINVAL, "message to self: %lld doubles sent, %lld expected", (long long)send_cnt[i], (long long)recv_cnt[i]); }
+    if (recv_cnt[i] > 0) NCHK_GROUP(R.Recv(d_recv + recv_off[i], (size_t)recv_cnt[i], ncclDouble, peer[i], R.comm, s), "ncclRecv");
+    if (send_cnt[i] > 0) NCHK_GROUP(R.Send(d_send + send_off[i], (size_t)send_cnt[i], ncclDouble, peer[i], R.comm, s), "ncclSend");
   }
   NCHK(R.GroupEnd(), "ncclGroupEnd");
   return 0;
@@ -174,11 +188,11 @@ int ramses_amd_rccl_sendrecv(int nsend, const double *const *send_ptr, const int
   NCHK(R.GroupStart(), "ncclGroupStart");
   for (int i = 0; i < nrecv; i++) {
     if (recv_peer[i] < 0 || recv_peer[i] >= R.nranks) { R.GroupEnd(); return failf(RAMSES_AMD_EINVAL, "bad peer rank %d", recv_peer[i]); }
-    NCHK(R.Recv(recv_ptr[i], (size_t)recv_cnt[i], ncclDouble, recv_peer[i], R.comm, s), "ncclRecv");
+    NCHK_GROUP(R.Recv(recv_ptr[i], (size_t)recv_cnt[i], ncclDouble, recv_peer[i], R.comm, s), "ncclRecv");
   }
   for (int i = 0; i < nsend; i++) {
     if (send_peer[i] < 0 || send_peer[i] >= R.nranks) { R.GroupEnd(); return failf(RAMSES_AMD_EINVAL, "bad peer rank %d", send_peer[i]); }
-    NCHK(R.Send(send_ptr[i], (size_t)send_cnt[i], ncclDouble, send_peer[i], R.comm, s), "ncclSend");
+    NCHK_GROUP(R.Send(send_ptr[i], (size_t)send_cnt[i], ncclDouble, send_peer[i], R.comm, s), "ncclSend");
   }
   NCHK(R.GroupEnd(), "ncclGroupEnd");
   return 0;
@@ -323,6 +337,14 @@ int self_fill(MpiRes &M, double *d_u, hipStream_t s) {
       HCHK(launch_box_copy(A, s), "periodic self-fill launch");
     }
   }
+  return 0;
+}
+
+// Whatever the communication stream still has in flight (pack / exchange / unpack of the prefetched halo, which use
+// sendbuf, recvbuf, h_send and the ghost layer of bnew) must be over before the compute stream touches the same
+// buffers in an order other than amr_step's: every consumer that does not itself consume the prefetch joins first.
+int join_comm(MpiRes &M) {
+  if (M.prefetched) HCHK(hipStreamWaitEvent(M.s_comp, M.ev_comm, 0), "stream wait");
   return 0;
 }
 
@@ -477,6 +499,7 @@ int ramses_amd_mpires_courant(const ramses_amd_hydro_params *p, double dx, doubl
   if (!p || !out4) return failf(RAMSES_AMD_EINVAL, "NULL argument");
   MpiRes &M = g_mr;
   hipStream_t s = M.s_comp;
+  if (int rc = join_comm(M)) return rc;
   if (int rc = ramses_amd_courant_init(p, dx, M.red.as<double>(), s)) return rc;
   if (int rc = ramses_amd_courant_brick(p, &M.brick, M.bold.as<double>(), nullptr, dx, M.red.as<double>(), s)) return rc;
   HCHK(hipMemcpyAsync(out4, M.red.p, sizeof(double) * 4, hipMemcpyDeviceToHost, s), "D2H courant");
@@ -493,6 +516,7 @@ int ramses_amd_mpires_courant(const ramses_amd_hydro_params *p, double dx, doubl
 int ramses_amd_mpires_godunov(const ramses_amd_hydro_params *p, double dx, double dt) {
   NEED_VALID("godunov_fine");
   MpiRes &M = g_mr;
+  if (int rc = join_comm(M)) return rc;     // a repeated call: the previous prefetch may still be writing bnew's ghosts
   M.prefetched = 0;
   if (!M.overlap) {
     if (int rc = ramses_amd_godunov_brick(p, &M.brick, M.bold.as<double>(), nullptr, M.bnew.as<double>(), dx, dt, M.s_comp)) return rc;
@@ -561,6 +585,8 @@ int ramses_amd_mpires_halo_forward(void) {
     M.nexchanges++;
     return 0;
   }
+  if (int rc = join_comm(M)) return rc;
+  M.prefetched = 0;
   OctListArgs A = list_args(M, M.bold.as<double>(), M.sendbuf.as<double>(), M.em_org.as<int64_t>(), nullptr, M.plan.em_first[M.ncpu]);
   HCHK(launch_oct_list(A, OL_PACK, s), "halo pack launch");
   if (int rc = ramses_amd_rccl_exchange((int)M.peers.size(), M.peers.data(), M.sendbuf.as<double>(), M.send_off.data(), M.send_cnt.data(),
@@ -586,6 +612,8 @@ int ramses_amd_mpires_halo_stage_out(double **h_send, const int64_t **send_off, 
     HCHK(hipEventSynchronize(M.ev_comm), "event sync");
     M.prefetched = 0;
   } else {
+    if (int rc = join_comm(M)) return rc;
+    M.prefetched = 0;
     OctListArgs A = list_args(M, M.bold.as<double>(), M.sendbuf.as<double>(), M.em_org.as<int64_t>(), nullptr, nem);
     HCHK(launch_oct_list(A, OL_PACK, s), "halo pack launch");
     if (nem) HCHK(hipMemcpyAsync(M.h_send.p, M.sendbuf.p, sizeof(double) * 8 * M.nvar * (size_t)nem, hipMemcpyDeviceToHost, s), "D2H halo");
@@ -633,6 +661,9 @@ int ramses_amd_mpires_sync_host(double *uold) {
   A.ncoarse = M.ncoarse; A.ngridmax = M.ngridmax; A.ncell = M.ncell; A.pitch_var = M.plan.pitch_var;
   A.pitch_y = M.plan.pitch_y; A.pitch_z = M.plan.pitch_z;
   A.brick = M.bold.as<double>(); A.cellvec = M.vec.as<double>();
+  // the device copy of the cell vector dates from the setup: cells outside the level (coarser levels, free slots) are
+  // taken from the host as they are NOW, so that the copy back changes the level's octs and nothing else
+  HCHK(hipMemcpyAsync(M.vec.p, uold, sizeof(double) * M.nvar * (size_t)M.ncell, hipMemcpyHostToDevice, s), "H2D uold");
   HCHK(launch_oct_copy(A, false, s), "scatter launch");
   HCHK(hipMemcpyAsync(uold, M.vec.p, sizeof(double) * M.nvar * (size_t)M.ncell, hipMemcpyDeviceToHost, s), "D2H uold");
   HCHK(hipStreamSynchronize(s), "sync");

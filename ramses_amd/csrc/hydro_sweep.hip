@@ -35,19 +35,6 @@ namespace ramses_amd {
 #define SWEEP_NS strictmode
 #endif
 
-#ifndef RAMSES_AMD_SWEEP_BARRIERS
-#define RAMSES_AMD_SWEEP_BARRIERS 1   // 1: merged, double-buffered y exchange (one barrier per plane); 2: the older loop
-#endif
-#ifndef RAMSES_AMD_SWEEP_CLAMP
-#define RAMSES_AMD_SWEEP_CLAMP 0
-#endif
-#ifndef RAMSES_AMD_SWEEP_LATE_UCUR
-#define RAMSES_AMD_SWEEP_LATE_UCUR 0
-#endif
-#ifndef RAMSES_AMD_SWEEP_PREFETCH
-#define RAMSES_AMD_SWEEP_PREFETCH 1   // where plane c+2 is requested: 0 start of the iteration, 1 before the barrier (measured best), 2 after it
-#endif
-
 namespace SWEEP_NS {
 
 constexpr int BX = 64;   // lanes along x = one wavefront
@@ -80,16 +67,11 @@ __device__ __forceinline__ double wave_shl1(double v) {
 //   ROLE_HALO    : row 0        primitives only
 //   ROLE_LOW     : row 1        + slopes, the traced +y state (left state of row 2's y flux)
 //   ROLE_FULL    : rows 2..BY-3 everything, and the update
-//   ROLE_HIGH    : row BY-2     + slopes, the traced -y state (handed to row BY-1 through LDS)
-//   ROLE_HALO_HI : row BY-1     primitives, and the y flux through the -y face of row BY-2
-//                               (its wave has nothing else to do: evens out the SIMDs)
+//   ROLE_HIGH    : row BY-2     + slopes, the y flux through its -y face (the +y face flux of row BY-3)
+//   ROLE_HALO_HI : row BY-1     primitives only
 enum { ROLE_HALO = 0, ROLE_LOW = 1, ROLE_HIGH = 2, ROLE_FULL = 3, ROLE_HALO_HI = 4 };
-// Handing row BY-2's y flux to the otherwise idle wave of row BY-1 paid in the strict build of the
-// two-barrier loop (6.25 -> 5.86 ms at 512^3) and cost in the fast one (3.66 -> 3.75 ms).
-#ifndef RAMSES_AMD_SWEEP_OFFLOAD_HI
-#define RAMSES_AMD_SWEEP_OFFLOAD_HI 0   // with one barrier per plane the hand-off no longer pays in either build (measured)
-#endif
-constexpr bool OFFLOAD_HI = RAMSES_AMD_SWEEP_OFFLOAD_HI != 0;
+// (Handing row BY-2's y flux to the otherwise idle wave of row BY-1 paid with two barriers per plane only; with one
+// barrier it costs in both builds -- measured, profiles/r02_ab_sweep.txt -- and is gone.)
 
 // Raw buffer access: one scalar resource descriptor per variable (base of the
 // variable's brick), a wave-uniform byte offset of the plane (soffset) and one
@@ -115,8 +97,7 @@ template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV, int ROLE>
 __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *smem_raw) {
   const bool DXPOW2 = A.pow2 != 0;   // uniform
   Plane<BY, NV> *qring = reinterpret_cast<Plane<BY, NV> *>(smem_raw);  // [3] primitives of planes c-1, c, c+1
-  Plane<BY, NV> *smy = qring + 3;                                   // qm along y (state on the +y face)
-  Plane<BY, NV> *fyb = qring + 4;                                   // flux through the -y face
+  Plane<BY, NV> *mring = qring + 3;                                 // [2] +y traced state / y flux slots, by plane parity
 
   const int tx = threadIdx.x, ty = threadIdx.y;
   const HydroConst &P = A.P;
@@ -201,7 +182,6 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 
   // ---- register state carried along z --------------------------------------
   double qmz[NV];                 // qm along z of plane c-1 (state on its +z face)
-  double part[NV];                // u + x and y flux differences of plane c-1
   double fzlo[NV];                // z flux through the -z face of plane c-1
   double upre[NV], gpre[3];       // prefetch: plane c+1 on entry of iteration c
   double rold = 0.0, sold[NV > 5 ? NV - 5 : 1];   // uold density / scalars of plane c-1 (NV>5 only)
@@ -222,7 +202,7 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     for (int n = 0; n < NV; n++) qring[sb].v[n][ty][tx] = q[n];
     load_u(z0, upre); load_g(z0, gpre);
 #pragma unroll
-    for (int n = 0; n < NV; n++) { qmz[n] = 1.0; part[n] = 0.0; fzlo[n] = 0.0; }
+    for (int n = 0; n < NV; n++) { qmz[n] = 1.0; fzlo[n] = 0.0; }
   }
   // Enter the loop with no load in flight: otherwise the loop header inherits
   // "prefetch pending" from this path and waits (in issue order) behind the
@@ -235,15 +215,9 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   // variable or nothing at all (out-of-range LDS reads return 0): whatever they compute from it stays in
   // the two halo columns / rows, which are never stored (rows 0 and BY-1 take no slopes, lanes 0, 1, 62, 63
   // own no cell, and the x flux an owned cell uses reaches two lanes at most).
-#if RAMSES_AMD_SWEEP_CLAMP
-  const int txm = max(tx - 1, 0), txp = min(tx + 1, BX - 1);
-  const int tym = max(ty - 1, 0), typ = min(ty + 1, BY - 1);
-#else
   const int txm = tx - 1, txp = tx + 1;
   const int tym = ty - 1, typ = ty + 1;
-#endif
 
-#if RAMSES_AMD_SWEEP_BARRIERS == 1
   // ---- ONE barrier per plane --------------------------------------------------------------
   // The +y traced state and the y flux share ONE LDS slot per row, double-buffered by plane
   // parity: slot M[c&1][ty] is written by row ty with its +y state before the barrier of
@@ -252,7 +226,6 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   // -> c.  Nobody else touches the slot, so the second barrier of the two-barrier loop (and
   // the lock-step of the heavy waves it enforced) is gone.  Same operations in the same
   // order per cell: ((u + (fx- - fx+)) + (fy- - fy+)) + (fz- - fz+).
-  Plane<BY, NV> *mring = smy;            // [2]: smy and fyb of the two-barrier loop, merged
   double partx[NV];                      // u + x flux difference of plane c-1
   double fyown[NV];                      // y flux through the -y face of plane c-1 (computed by this row; its copy
                                          // in slot ty-1 belongs to row ty-1, which reuses the slot without a barrier)
@@ -269,12 +242,7 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #pragma unroll
     for (int n = 0; n < NV; n++) qring[sc].v[n][ty][tx] = qc[n];
     double ucur[NV];
-#if RAMSES_AMD_SWEEP_PREFETCH == 0
-    { const int pn = min(c + 2, z1 + 1); load_u(pn, upre); load_g(pn, gpre); }
-#endif
-#if !RAMSES_AMD_SWEEP_LATE_UCUR
     if (r_fxz) load_u(c, ucur);
-#endif
 
     double qpy[NV], dz[NV], px[NV];
     if (ST == 3) __syncthreads();  // the 27-point slope reads the neighbours' plane c+1 just written
@@ -327,25 +295,12 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
         const double cc = ctoprim_sound(qb[0], qb[4], P);
         tracexyz_cell<NV>(qb, dq, cc, dtdx, dtdx, dtdx, P, qm, qp);
       }
-      if constexpr (ROLE == ROLE_HIGH && OFFLOAD_HI) {
-        // nobody reads this row's +y state; its slot carries the -y state to row BY-1
 #pragma unroll
-        for (int n = 0; n < NV; n++) M.v[n][ty][tx] = qp[1][n];
-      } else {
-#pragma unroll
-        for (int n = 0; n < NV; n++) M.v[n][ty][tx] = qm[1][n];
-      }
+      for (int n = 0; n < NV; n++) M.v[n][ty][tx] = qm[1][n];
 #pragma unroll
       for (int n = 0; n < NV; n++) qpy[n] = qp[1][n];
       if constexpr (r_fxz) {
         double qL[NV], fx[NV], fz[NV];
-#if RAMSES_AMD_SWEEP_LATE_UCUR
-        // the conserved state of plane c (an L2 hit) is requested only now, behind the register
-        // peak of the tracing, and arrives while the two fluxes are computed
-        __builtin_amdgcn_sched_barrier(0);
-        load_u(c, ucur);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int n = 0; n < NV; n++) qL[n] = wave_shr1(qm[0][n]);  // +x state of column tx-1
         scaled_interface_flux<RS, NV, 0>(qL, qp[0], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fx);
@@ -366,20 +321,15 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
         }
       }
     }
-#if RAMSES_AMD_SWEEP_PREFETCH == 1
     // prefetch plane c+2 after the register peak of the trace and flux phase (still ~1 us ahead of its use)
     __builtin_amdgcn_sched_barrier(0);
     { const int pn = min(c + 2, z1 + 1); load_u(pn, upre); load_g(pn, gpre); }
     __builtin_amdgcn_sched_barrier(0);
-#endif
     __syncthreads();  // the one barrier: +y states of plane c and y fluxes of plane c-1 visible
-#if RAMSES_AMD_SWEEP_PREFETCH == 2
-    { const int pn = min(c + 2, z1 + 1); load_u(pn, upre); load_g(pn, gpre); }
-#endif
 
     // ---- phase B: y flux of plane c; finish plane c-1 --------------------------------
     double fy[NV];
-    if constexpr (ROLE == ROLE_FULL || (ROLE == ROLE_HIGH && !OFFLOAD_HI)) {
+    if constexpr (ROLE == ROLE_FULL || ROLE == ROLE_HIGH) {
       double qL[NV];
 #pragma unroll
       for (int n = 0; n < NV; n++) qL[n] = M.v[n][tym][tx];
@@ -387,15 +337,6 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
       // the flux through this row's -y face is the +y face flux of row ty-1: into ITS slot
 #pragma unroll
       for (int n = 0; n < NV; n++) M.v[n][tym][tx] = fy[n];
-    }
-    if constexpr (ROLE == ROLE_HALO_HI && OFFLOAD_HI) {
-      // y flux between rows BY-3 and BY-2, read by row BY-3 when it finishes the plane
-      double qL[NV], qR[NV];
-#pragma unroll
-      for (int n = 0; n < NV; n++) { qL[n] = M.v[n][BY - 3][tx]; qR[n] = M.v[n][BY - 2][tx]; }
-      scaled_interface_flux<RS, NV, 1>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fy);
-#pragma unroll
-      for (int n = 0; n < NV; n++) M.v[n][BY - 3][tx] = fy[n];
     }
     if constexpr (r_fxz) {
       // plane c-1: its x part and own -y flux were kept in registers, the +y face flux was left
@@ -434,161 +375,6 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     // rotate the ring
     const int t = sa; sa = sb; sb = sc; sc = t;
   }
-#else
-  for (int c = z0 - 1; c <= z1; c++) {
-    // ---- plane c+1 arrives: primitives into ring slot sc ---------------------
-    double qc[NV];
-    ctoprim_cell<NV, GRAV>(upre, gpre, dtxhalf, P, qc);
-#pragma unroll
-    for (int n = 0; n < NV; n++) qring[sc].v[n][ty][tx] = qc[n];
-    // prefetch plane c+2 (HBM) and re-read plane c's conserved state (L2) for
-    // the update at the end of this iteration
-    double ucur[NV];
-    { const int pn = min(c + 2, z1 + 1); load_u(pn, upre); load_g(pn, gpre); }   // (last iteration: a harmless re-read)
-    if (r_fxz) load_u(c, ucur);
-    // Slot sc was last read (as plane c-2) before barrier B2 of iteration c-1;
-    // plane c's neighbours were written one iteration (two barriers) ago.
-
-    // The x and y fluxes of the two end planes (c = z0-1 and c = z1, traced for
-    // their z states only) are computed and dropped: one plane in ~130, cheaper
-    // than carrying the condition through the loop.
-    double qpy[NV], fx[NV], fz[NV], fy[NV];
-    if (ST == 3) __syncthreads();  // the 27-point slope reads the neighbours' plane c+1 just written
-    if constexpr (r_trace) {
-      const Plane<BY, NV> &qs = qring[sb];
-      const Plane<BY, NV> &qprev = qring[sa];
-      double qb[NV], dq[3][NV];
-      if (ST == 3) {
-        const Plane<BY, NV> &qnext = qring[sc];
-        const int xs[3] = {txm, tx, txp}, ys[3] = {tym, ty, typ};
-#pragma unroll
-        for (int n = 0; n < NV; n++) {
-          double nb[27], d3[3];
-#pragma unroll
-          for (int dj = 0; dj < 3; dj++)
-#pragma unroll
-            for (int di = 0; di < 3; di++) {
-              nb[di + 3 * dj] = qprev.v[n][ys[dj]][xs[di]];
-              nb[di + 3 * dj + 9] = qs.v[n][ys[dj]][xs[di]];
-              nb[di + 3 * dj + 18] = qnext.v[n][ys[dj]][xs[di]];
-            }
-          qb[n] = nb[13];
-          slope3_var(nb, d3);
-          dq[0][n] = d3[0]; dq[1][n] = d3[1]; dq[2][n] = d3[2];
-        }
-      } else if (ST == 4 || ST == 5 || ST == 6) {
-        // the NDIM=1 slope types (embedded 1-D problems: ny = nz = 1, the transverse differences vanish)
-#pragma unroll
-        for (int n = 0; n < NV; n++) qb[n] = qs.v[n][ty][tx];
-        const double dc0 = qb[1] * A.dt / A.dx, dc1 = qb[2] * A.dt / A.dx, dc2 = qb[3] * A.dt / A.dx;
-#pragma unroll
-        for (int n = 0; n < NV; n++) {
-          dq[0][n] = slope1_1d<ST>(qs.v[n][ty][txm], qb[n], qs.v[n][ty][txp], dc0, n);
-          dq[1][n] = slope1_1d<ST>(qs.v[n][tym][tx], qb[n], qs.v[n][typ][tx], dc1, n);
-          dq[2][n] = slope1_1d<ST>(qprev.v[n][ty][tx], qb[n], qc[n], dc2, n);
-        }
-      } else {
-#pragma unroll
-        for (int n = 0; n < NV; n++) {
-          qb[n] = qs.v[n][ty][tx];
-          dq[0][n] = slope1<ST>(qs.v[n][ty][txm], qb[n], qs.v[n][ty][txp], P);
-          dq[1][n] = slope1<ST>(qs.v[n][tym][tx], qb[n], qs.v[n][typ][tx], P);
-          dq[2][n] = slope1<ST>(qprev.v[n][ty][tx], qb[n], qc[n], P);
-        }
-      }
-      double qm[3][NV], qp[3][NV];
-      if (SCHEME == 0) {
-        trace3d_cell<NV>(qb, dq, dtdx, dtdx, dtdx, P, qm, qp);
-      } else {
-        const double cc = ctoprim_sound(qb[0], qb[4], P);
-        tracexyz_cell<NV>(qb, dq, cc, dtdx, dtdx, dtdx, P, qm, qp);
-      }
-      if constexpr (ROLE == ROLE_HIGH && OFFLOAD_HI) {
-        // nobody reads this row's +y state; its smy slot carries the -y state to row BY-1
-#pragma unroll
-        for (int n = 0; n < NV; n++) smy->v[n][ty][tx] = qp[1][n];
-      } else {
-#pragma unroll
-        for (int n = 0; n < NV; n++) smy->v[n][ty][tx] = qm[1][n];
-      }
-#pragma unroll
-      for (int n = 0; n < NV; n++) qpy[n] = qp[1][n];
-      if constexpr (r_fxz) {
-        double qL[NV];
-#pragma unroll
-        for (int n = 0; n < NV; n++) qL[n] = wave_shr1(qm[0][n]);  // +x state of column tx-1
-        scaled_interface_flux<RS, NV, 0>(qL, qp[0], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fx);
-        // z flux through the face between planes c-1 and c
-        scaled_interface_flux<RS, NV, 2>(qmz, qp[2], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fz);
-#pragma unroll
-        for (int n = 0; n < NV; n++) qmz[n] = qm[2][n];
-      }
-    }
-    __syncthreads();  // (B2) +y traced states visible
-
-    if constexpr (ROLE == ROLE_FULL || (ROLE == ROLE_HIGH && !OFFLOAD_HI)) {
-      double qL[NV];
-#pragma unroll
-      for (int n = 0; n < NV; n++) qL[n] = smy->v[n][tym][tx];
-      scaled_interface_flux<RS, NV, 1>(qL, qpy, P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fy);
-#pragma unroll
-      for (int n = 0; n < NV; n++) fyb->v[n][ty][tx] = fy[n];
-    }
-    if constexpr (ROLE == ROLE_HALO_HI && OFFLOAD_HI) {
-      // y flux between rows BY-3 and BY-2, read by row BY-3's update
-      double qL[NV], qR[NV];
-#pragma unroll
-      for (int n = 0; n < NV; n++) { qL[n] = smy->v[n][BY - 3][tx]; qR[n] = smy->v[n][BY - 2][tx]; }
-      scaled_interface_flux<RS, NV, 1>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fy);
-#pragma unroll
-      for (int n = 0; n < NV; n++) fyb->v[n][BY - 2][tx] = fy[n];
-    }
-    __syncthreads();  // (B3) y fluxes visible
-
-    if constexpr (r_fxz) {
-      // finish plane c-1: its +z face flux is fz.  (The first two iterations of
-      // a chunk produce values from the not yet primed pipeline; they are
-      // computed and dropped by the store's range check.)
-      double un[NV];
-#pragma unroll
-      for (int n = 0; n < NV; n++) un[n] = part[n] + (fzlo[n] - fz[n]);
-      if (NV > 5) {
-        // set_uold's passive-scalar fix near the density floor
-        // (hydro/godunov_fine.f90:176-190), fused: the kernel's output is the new uold
-        if (rold < P.smallr && un[0] > rold) {
-#pragma unroll
-          for (int n = 5; n < NV; n++) un[n] = sold[n - 5] * dmaxd(un[0], P.smallr) / P.smallr;
-        } else if (un[0] < P.smallr && rold > un[0]) {
-#pragma unroll
-          for (int n = 5; n < NV; n++) un[n] = sold[n - 5] * P.smallr / dmaxd(rold, P.smallr);
-        }
-      }
-      // x and y flux differences of plane c (consumes the re-read conserved
-      // state BEFORE the stores are issued: vmcnt counts in order)
-#pragma unroll
-      for (int n = 0; n < NV; n++) {
-        const double fxhi = wave_shl1(fx[n]);  // -x face flux of column tx+1
-        const double t = ucur[n] + (fx[n] - fxhi);
-        part[n] = t + (fy[n] - fyb->v[n][typ][tx]);
-      }
-      if (NV > 5) {
-        rold = ucur[0];
-#pragma unroll
-        for (int n = 5; n < NV; n++) sold[n - 5] = ucur[n];
-      }
-#pragma unroll
-      for (int n = 0; n < NV; n++) fzlo[n] = fz[n];
-      {
-        const unsigned pb = plane_off(c - 1);
-        const unsigned so = (c >= z0 + 1) ? colb_upd : BUF_OOB;
-#pragma unroll
-        for (int n = 0; n < NV; n++) plane_store(unew + (long)n * A.pitch_var, pb, so, un[n]);
-      }
-    }
-    // rotate the ring
-    const int t = sa; sa = sb; sb = sc; sc = t;
-  }
-#endif
 }
 
 template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV>

@@ -5,9 +5,11 @@
 ! jeans_length_refine stays the reference's).  While the hydro state of an AMR run is
 ! device-resident the gradient criteria (hydro_refine, hydro/godunov_utils.f90:125-263:
 ! err_grad_d / err_grad_p / err_grad_u on a cell and its two neighbours per direction, a missing
-! neighbour replaced by the neighbouring father cell) are evaluated on the GPU; the host receives
-! one flag per cell and does the reference's bookkeeping (flag1, nflag).  Geometry-based
-! refinement (r_refine) needs no hydro data and is applied on the host as in the reference.
+! neighbour replaced by the neighbouring father cell) are evaluated on the GPU, which also compacts
+! the answer: the host receives the LIST of cells that ask for refinement (a few thousand ints at
+! most, not one flag per cell of the level) and marks them in flag1.  Geometry-based refinement
+! (r_refine: a mask on the cell position, no hydro data) filters that list through the reference's
+! own geometry_refine, a batch of nvector candidates at a time.
 !==============================================================================
 #define hydro_flag hydro_flag_reference
 #include "hydro/hydro_flag.f90"
@@ -19,14 +21,13 @@ subroutine hydro_flag(ilevel)
   use ramses_amd_iface
   implicit none
   integer::ilevel
-  integer::i,ind,idim,iskip,igrid,ngrid,ncache,nok,rc,nx_loc,ix,iy,iz
-  integer,allocatable,dimension(:)::okdev
-  integer,dimension(1:nvector),save::ind_grid,ind_cell
-  logical,dimension(1:nvector),save::ok
-  real(dp),dimension(1:nvector,1:ndim),save::xx
-  real(dp),dimension(1:twotondim,1:3)::xc
-  real(dp),dimension(1:3)::skip_loc
-  real(dp)::dx,scale
+  integer::ncache,ncand,rc,k,n,j,d,icell,ind,ig
+  integer,allocatable,dimension(:)::cand
+  logical,allocatable,dimension(:)::keep
+  logical,dimension(1:nvector)::inside
+  real(dp),dimension(1:nvector,1:ndim)::pos
+  real(dp)::half,scale
+  real(dp),dimension(1:3)::corner
   type(ramses_amd_hydro_params)::p
 
   if(.not.ramses_amd_amr_resident())then
@@ -41,62 +42,41 @@ subroutine hydro_flag(ilevel)
   call ramses_amd_amr_ensure()
   call ramses_amd_fill_hydro_params(p)
   ncache=active(ilevel)%ngrid
-  allocate(okdev(1:twotondim*ncache))
+  allocate(cand(1:twotondim*max(ncache,1)))
   rc=ramses_amd_amrres_hydro_flag(p,ncache,ramses_amd_octs(ilevel),dble(err_grad_d),dble(err_grad_p),dble(err_grad_u), &
-       & dble(floor_d),dble(floor_p),dble(floor_u),okdev)
+       & dble(floor_d),dble(floor_p),dble(floor_u),cand,ncand)
   if(rc/=0)call ramses_amd_fatal('hydro_flag')
 
-  ! cell centres for the geometry criteria (:36-53)
-  dx=0.5d0**ilevel
-  nx_loc=(icoarse_max-icoarse_min+1)
-  skip_loc=(/0.0d0,0.0d0,0.0d0/)
-  skip_loc(1)=dble(icoarse_min); skip_loc(2)=dble(jcoarse_min); skip_loc(3)=dble(kcoarse_min)
-  scale=boxlen/dble(nx_loc)
-  do ind=1,twotondim
-     iz=(ind-1)/4
-     iy=(ind-1-4*iz)/2
-     ix=(ind-1-2*iy-4*iz)
-     xc(ind,1)=(dble(ix)-0.5D0)*dx
-     xc(ind,2)=(dble(iy)-0.5D0)*dx
-     xc(ind,3)=(dble(iz)-0.5D0)*dx
-  end do
+  allocate(keep(1:max(ncand,1)))
+  keep=.true.
+  if(r_refine(ilevel)>-1.0)then
+     ! candidate cell -> (octant, oct) -> centre in user units, then the reference's region test
+     half=0.5d0**(ilevel+1)
+     scale=boxlen/dble(icoarse_max-icoarse_min+1)
+     corner=(/dble(icoarse_min),dble(jcoarse_min),dble(kcoarse_min)/)
+     do k=1,ncand,nvector
+        n=min(nvector,ncand-k+1)
+        do j=1,n
+           icell=cand(k+j-1)
+           ind=(icell-ncoarse-1)/ngridmax
+           ig=icell-ncoarse-ind*ngridmax
+           do d=1,ndim
+              pos(j,d)=(xg(ig,d)+merge(half,-half,btest(ind,d-1))-corner(d))*scale
+           end do
+           inside(j)=.true.
+        end do
+        call geometry_refine(pos,inside,n,ilevel)
+        keep(k:k+n-1)=inside(1:n)
+     end do
+  end if
 
-  ! same loop nest and bookkeeping as the reference (:84-171)
-  do igrid=1,ncache,nvector
-     ngrid=MIN(nvector,ncache-igrid+1)
-     do i=1,ngrid
-        ind_grid(i)=active(ilevel)%igrid(igrid+i-1)
-     end do
-     do ind=1,twotondim
-        iskip=ncoarse+(ind-1)*ngridmax
-        do i=1,ngrid
-           ind_cell(i)=iskip+ind_grid(i)
-           ok(i)=okdev((ind-1)*ncache+igrid+i-1)/=0
-        end do
-        if(r_refine(ilevel)>-1.0)then
-           do idim=1,ndim
-              do i=1,ngrid
-                 xx(i,idim)=xg(ind_grid(i),idim)+xc(ind,idim)
-              end do
-           end do
-           do idim=1,ndim
-              do i=1,ngrid
-                 xx(i,idim)=(xx(i,idim)-skip_loc(idim))*scale
-              end do
-           end do
-           call geometry_refine(xx,ok,ngrid,ilevel)
-        end if
-        nok=0
-        do i=1,ngrid
-           if(flag1(ind_cell(i))==0.and.ok(i))then
-              nok=nok+1
-           end if
-        end do
-        do i=1,ngrid
-           if(ok(i))flag1(ind_cell(i))=1
-        end do
-        nflag=nflag+nok
-     end do
+  ! mark the survivors; nflag counts the cells that were not marked before
+  do k=1,ncand
+     if(keep(k))then
+        icell=cand(k)
+        if(flag1(icell)==0)nflag=nflag+1
+        flag1(icell)=1
+     end if
   end do
-  deallocate(okdev)
+  deallocate(cand,keep)
 end subroutine hydro_flag

@@ -410,6 +410,10 @@ module ramses_amd_iface
        integer(c_int64_t) :: uid
        integer(c_int) :: rc
      end function ramses_amd_device_uid
+     function ramses_amd_rccl_probe() bind(C, name='ramses_amd_rccl_probe') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function ramses_amd_rccl_probe
      function ramses_amd_rccl_unique_id(id) bind(C, name='ramses_amd_rccl_unique_id') result(rc)
        import :: c_int, c_char
        character(kind=c_char) :: id(128)
@@ -620,12 +624,13 @@ module ramses_amd_iface
        real(c_double) :: out4(4)
        integer(c_int) :: rc
      end function ramses_amd_amrres_courant
-     function ramses_amd_amrres_hydro_flag(p, ngrid, igrid, egd, egp, egu, fld, flp, flu, ok) &
+     function ramses_amd_amrres_hydro_flag(p, ngrid, igrid, egd, egp, egu, fld, flp, flu, cells, ncells) &
           & bind(C, name='ramses_amd_amrres_hydro_flag') result(rc)
        import :: ramses_amd_hydro_params, c_int, c_double
        type(ramses_amd_hydro_params), intent(in) :: p
        integer(c_int), value :: ngrid
-       integer(c_int) :: igrid(*), ok(*)
+       integer(c_int) :: igrid(*), cells(*)
+       integer(c_int), intent(out) :: ncells
        real(c_double), value :: egd, egp, egu, fld, flp, flu
        integer(c_int) :: rc
      end function ramses_amd_amrres_hydro_flag
@@ -1175,15 +1180,17 @@ contains
        if (myid == 1) write(*,*) 'ramses_amd: several ranks share a GPU: halo exchange staged through host MPI (not RCCL)'
        return
     end if
+    ! every rank first checks LOCALLY that it can load the library (no communication); only when all of them can
+    ! does anyone enter the collective ncclCommInitRank -- a rank that failed alone would leave the others blocked in it
     id = c_null_char
-    rc = 0
-    if (myid == 1) rc = ramses_amd_rccl_unique_id(id)
-    call MPI_BCAST(rc, 1, MPI_INTEGER, 0, MPI_COMM_WORLD, info)
-    if (rc == 0) then
+    rc = ramses_amd_rccl_probe()
+    if (rc == 0 .and. myid == 1) rc = ramses_amd_rccl_unique_id(id)
+    call MPI_ALLREDUCE(rc, rcmax, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, info)   ! error codes are negative
+    if (rcmax == 0) then
        call MPI_BCAST(id, 128, MPI_CHARACTER, 0, MPI_COMM_WORLD, info)
        rc = ramses_amd_rccl_init(id, ncpu, myid - 1)
+       call MPI_ALLREDUCE(rc, rcmax, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, info)
     end if
-    call MPI_ALLREDUCE(rc, rcmax, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, info)   ! error codes are negative
     if (rcmax /= 0) then
        if (trim(val) == 'rccl') call ramses_amd_fatal('halo transport (RCCL requested with RAMSES_AMD_HALO=rccl)')
        rc = ramses_amd_rccl_finalize()

@@ -87,12 +87,23 @@ class RcclTransport(DistTransport):
         import ctypes as C
         from ._capi import check, lib
         self._C, self._check, self._lib = C, check, lib()
+        on_gpu = dist.get_backend(group) == "nccl"
+        # local probe first (dlopen + symbols), agreed on by every rank BEFORE the collective init
         idt = torch.zeros(128, dtype=torch.uint8)
-        if self.rank == 0:
+        ok = 1 if self._lib.ramses_amd_rccl_probe() == 0 else 0
+        if ok and self.rank == 0:
             buf = (C.c_char * 128)()
-            check(self._lib.ramses_amd_rccl_unique_id(buf))
-            idt = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
-        dev = idt.cuda() if dist.get_backend(group) == "nccl" else idt
+            if self._lib.ramses_amd_rccl_unique_id(buf) == 0:
+                idt = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+            else:
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32)
+        flag = flag.cuda() if on_gpu else flag
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            raise RuntimeError("RCCL cannot be brought up on every rank: " +
+                               (self._lib.ramses_amd_last_error() or b"").decode())
+        dev = idt.cuda() if on_gpu else idt
         dist.broadcast(dev, src=0, group=group)
         raw = bytes(dev.cpu().numpy().tobytes())
         check(self._lib.ramses_amd_rccl_init(C.c_char_p(raw), self.world, self.rank))
