@@ -689,6 +689,15 @@ int ramses_amd_amrres_enable_pfix(void);
 int ramses_amd_amrres_set_unew_pfix(const ramses_amd_hydro_params *p, int ngrid, const int *igrid);
 int ramses_amd_amrres_set_uold_pfix(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double dt, double dx_loc,
                                     double beta_fix, double hexp);
+/* rho_fine(ilevel,icount) on the resident density of an AMR run (single rank, periodic nx=ny=nz=1 box, no particles):
+ *   multipole_fine(l) + cic_from_multipole(l) for l = nlevelmax .. ilevel (pm/rho_fine.f90:45-60,666-1142): multipoles of leaf
+ *   and split cells, the CIC deposit at every cell's centre of mass added in the reference's order, the four sequential sums
+ *   multipole(1:4) over the cells of levelmin.  ramses_amd_amrres_xg: the oct centres xg(1:ngridmax,1:3), once per regrid.
+ *   first[0..nlevelmax-ilevel+1] / igrid_all: active(l)%igrid of the levels one after the other; rho (host, ncell) receives the
+ *   visited levels' cells; multipole4 is written when levelmin is visited. */
+int ramses_amd_amrres_xg(const double *xg);
+int ramses_amd_amrres_rho_fine(const ramses_amd_hydro_params *p, int ilevel, int nlevelmax, int levelmin, int nvector,
+                               const int *first, const int *igrid_all, double boxlen_over_nx, double *rho, double *multipole4);
 int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double err_grad_d, double err_grad_p,
                                  double err_grad_u, double floor_d, double floor_p, double floor_u, int *cells, int *ncells);
 int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, double dx, double dt,

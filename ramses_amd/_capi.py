@@ -173,6 +173,8 @@ SYMBOLS = [
     ("ramses_amd_amrres_enable_pfix", _i, []),
     ("ramses_amd_amrres_set_unew_pfix", _i, [_PP, _i, _vp]),
     ("ramses_amd_amrres_set_uold_pfix", _i, [_PP, _i, _vp, _d, _d, _d, _d]),
+    ("ramses_amd_amrres_xg", _i, [_vp]),
+    ("ramses_amd_amrres_rho_fine", _i, [_PP, _i, _i, _i, _i, _vp, _vp, _d, _vp, _vp]),
     ("ramses_amd_amrres_hydro_flag", _i, [_PP, _i, _vp, _d, _d, _d, _d, _d, _d, _vp, _vp]),
     ("ramses_amd_amrres_godunov", _i, [_PP, _i, _i, _vp, _d, _d, _i, _i, _i]),
     # AMR residency under MPI: the virtual-boundary exchanges on the resident cell vectors

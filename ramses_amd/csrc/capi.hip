@@ -1365,7 +1365,9 @@ int ramses_amd_resident_rho_fine_f90(const ramses_amd_hydro_params *p, int ileve
   A.smallr = p->smallr;
   HCHK(launch_rho_deposit(A, s), "rho deposit launch");
   double *d_mp = H.diag.as<double>() + FORCE_DIAG_SCRATCH + 2;
-  HCHK(launch_multipole(A, d_mp, s), "multipole launch");
+  static DevBuf mpscratch;
+  HCHK(mpscratch.ensure(multipole_scratch_bytes((long)ngrid * 8)), "hipMalloc multipole scratch");
+  HCHK(launch_multipole(A, d_mp, mpscratch.p, s), "multipole launch");
   HCHK(hipMemcpyAsync(multipole4, d_mp, sizeof(double) * 4, hipMemcpyDeviceToHost, s), "D2H multipole");
   HCHK(hipStreamSynchronize(s), "sync");
   H.res_rho_valid = true;

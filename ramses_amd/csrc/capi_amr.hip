@@ -24,6 +24,7 @@
 #include "../../include/ramses_amd.h"
 #include "amr_core.hpp"
 #include "hydro_core.hpp"
+#include "rho_args.hpp"
 
 using namespace ramses_amd;
 
@@ -453,6 +454,9 @@ struct AmrRes {
   long ncell = 0, ncoarse = 0, ngridmax = 0;
   const double *h_uold = nullptr;
   Buf uold, unew, son, nbor, father, igrid, work, err, red, okbuf, pack;
+  Buf xg;                // xg(1:ngridmax,1:3) (rho_fine's deposit needs the oct centres); sent with the tree when gravity is on
+  bool xg_valid = false;
+  Buf mp, rho, posof, mpscratch, lists;   // rho_fine: multipoles (4, ncell), the deposit (ncell), oct -> list position, scan scratch
   Buf f;                 // f(1:ncell,1:3), a copy of the host array refreshed after force_fine and after regrids
   bool grav = false;
   Buf divu, enew;        // pressure_fix: the reference's divu / enew work vectors (device only: scratch of one step)
@@ -728,6 +732,75 @@ int ramses_amd_amrres_load_f(int ngrid, const int *igrid, const double *f) {
   return 0;
 }
 int ramses_amd_amrres_has_gravity(void) { return g_ar.valid && g_ar.grav ? 1 : 0; }
+
+// the oct centres xg(1:ngridmax,1:3) (after refine_fine, with the tree): what rho_fine's deposit needs beyond the tree
+int ramses_amd_amrres_xg(const double *xg) {
+  AmrRes &R = g_ar;
+  if (!R.valid) return failf(RAMSES_AMD_EINVAL, "no resident AMR state");
+  if (!xg) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  HCHK(R.xg.ensure(sizeof(double) * 3 * (size_t)R.ngridmax), "hipMalloc xg");
+  HCHK(hipMemcpy(R.xg.p, xg, sizeof(double) * 3 * (size_t)R.ngridmax, hipMemcpyHostToDevice), "H2D xg");
+  R.xg_valid = true;
+  return 0;
+}
+
+// rho_fine(ilevel,icount)'s hydro deposit (pm/rho_fine.f90:45-60: multipole_fine(l) and cic_from_multipole(l) for
+// l = nlevelmax .. ilevel) on the resident density, single rank, periodic nx=ny=nz=1 box, no particles.
+//   first[0..nlev], igrid_all: active(l)%igrid for l = ilevel .. nlevelmax one after the other (first[l-ilevel] .. first[l-ilevel+1])
+//   rho (host, ncell): the cells of the visited levels receive the deposit;  multipole4: the four sums of cic_from_multipole at
+//   levelmin (written when ilevel == levelmin, where the reference has just reset them; untouched otherwise)
+int ramses_amd_amrres_rho_fine(const ramses_amd_hydro_params *p, int ilevel, int nlevelmax, int levelmin, int nvector,
+                               const int *first, const int *igrid_all, double boxlen_over_nx, double *rho, double *multipole4) {
+  AmrRes &R = g_ar;
+  if (!R.valid) return failf(RAMSES_AMD_EINVAL, "no resident AMR state (ramses_amd_amrres_load)");
+  if (!p || !first || !igrid_all || !rho || !multipole4) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  if (!R.xg_valid) return failf(RAMSES_AMD_EINVAL, "rho_fine: no oct centres on the device (ramses_amd_amrres_xg)");
+  if (ilevel < 2 || nlevelmax < ilevel || nvector < 1) return failf(RAMSES_AMD_EINVAL, "rho_fine: bad level range / nvector");
+  if (R.ncoarse != 1) return failf(RAMSES_AMD_EUNSUPPORTED, "rho_fine on the device covers a periodic box of one coarse cell");
+  const int nlev = nlevelmax - ilevel + 1;
+  const int ntot = first[nlev];
+  if (first[0] != 0 || ntot < 0) return failf(RAMSES_AMD_EINVAL, "rho_fine: bad list offsets");
+  hipStream_t s = nullptr;
+  const size_t cb = sizeof(double) * (size_t)R.ncell;
+  HCHK(R.mp.ensure(4 * cb), "hipMalloc multipoles"); HCHK(R.rho.ensure(cb), "hipMalloc rho");
+  if (R.posof.cap < sizeof(int) * (size_t)R.ngridmax) {
+    HCHK(R.posof.ensure(sizeof(int) * (size_t)R.ngridmax), "hipMalloc posof");
+    HCHK(hipMemsetAsync(R.posof.p, 0xff, sizeof(int) * (size_t)R.ngridmax, s), "memset posof");
+  }
+  HCHK(R.lists.ensure(sizeof(int) * (size_t)(ntot > 0 ? ntot : 1)), "hipMalloc lists");
+  if (ntot > 0) HCHK(hipMemcpyAsync(R.lists.p, igrid_all, sizeof(int) * (size_t)ntot, hipMemcpyHostToDevice, s), "H2D lists");
+  for (int lev = nlevelmax; lev >= ilevel; lev--) {
+    const int lo = first[lev - ilevel], n = first[lev - ilevel + 1] - lo;
+    if (n < 0 || lo + n > ntot || n > R.ngridmax) return failf(RAMSES_AMD_EINVAL, "rho_fine: bad list of level %d", lev);
+    if (n == 0) continue;
+    const int *d_ig = R.lists.as<int>() + lo;
+    HCHK(launch_amr_rho_level(R.uold.as<double>(), R.mp.as<double>(), R.rho.as<double>(), R.xg.as<double>(), R.son.as<int>(), R.nbor.as<int>(),
+                              R.father.as<int>(), d_ig, R.posof.as<int>(), n, nvector, R.ncoarse, R.ngridmax, lev, boxlen_over_nx, p->smallr, s),
+         "rho_fine level launch");
+    if (lev == levelmin) {
+      HCHK(R.mpscratch.ensure(multipole_scratch_bytes((long)n * 8)), "hipMalloc multipole scratch");
+      HCHK(launch_multipole_vec(R.mp.as<double>(), d_ig, n, nvector, R.ncell, R.ncoarse, R.ngridmax, R.red.as<double>(), R.mpscratch.p, s),
+           "multipole launch");
+      HCHK(hipMemcpyAsync(multipole4, R.red.p, sizeof(double) * 4, hipMemcpyDeviceToHost, s), "D2H multipole");
+    }
+    // the deposit of the level back into the host vector (multigrid_fine / phi_fine_cg / force_fine's diagnostics read it there)
+    const long tot = (long)n * 8;
+    HCHK(R.pack.ensure(sizeof(double) * (size_t)tot), "hipMalloc");
+    hipLaunchKernelGGL(lvl_pack_comp_kernel<true>, dim3(grid_for(tot)), dim3(256), 0, s, R.rho.as<double>(), R.pack.as<double>(), d_ig, n, 1,
+                       R.ncell, R.ncoarse, R.ngridmax);
+    HCHK(hipGetLastError(), "rho pack launch");
+    R.hpack.resize((size_t)tot);
+    HCHK(hipMemcpy(R.hpack.data(), R.pack.p, sizeof(double) * (size_t)tot, hipMemcpyDeviceToHost), "D2H rho");
+    const int *ig = igrid_all + lo;
+    for (int ind = 0; ind < 8; ind++) {
+      double *dst = rho + R.ncoarse + (size_t)ind * R.ngridmax - 1;
+      const double *src = R.hpack.data() + (size_t)ind * n;
+      for (int i = 0; i < n; i++) dst[ig[i]] = src[i];
+    }
+  }
+  HCHK(hipStreamSynchronize(s), "sync");
+  return 0;
+}
 
 // the density uold(:,1) of one level's cells back into the host array (rho_fine's multipole_fine reads nothing else)
 int ramses_amd_amrres_sync_density(int ngrid, const int *igrid, double *uold) {

@@ -18,6 +18,18 @@ struct RhoArgs {
 
 hipError_t launch_oct_index(const long *octorg, int ngrid, int n, int *octidx, hipStream_t s);
 hipError_t launch_rho_deposit(const RhoArgs &A, hipStream_t s);
-hipError_t launch_multipole(const RhoArgs &A, double *out4, hipStream_t s);
+// the four strictly sequential sums multipole(1:4), bit for bit, in parallel; scratch: multipole_scratch_bytes(8*ngrid) bytes;
+// the last 4 ints of the scratch area count the segments that took the slow path (tests, tuning)
+size_t multipole_scratch_bytes(long ncells);
+hipError_t launch_multipole(const RhoArgs &A, double *out4, void *scratch, hipStream_t s);
+// the same sums over the multipoles mp(4, ncell) of the cells of an AMR level (cic_from_multipole at levelmin, pm/rho_fine.f90:931-938)
+hipError_t launch_multipole_vec(const double *mp, const int *igrid, int ngrid, int nvector, long ncell, long ncoarse, long ngridmax,
+                                double *out4, void *scratch, hipStream_t s);
+
+// rho_fine's hydro deposit on one level of an AMR run (multipole_fine + cic_from_multipole on the cell vectors and the tree);
+// levels must be visited from the finest down (a split cell sums its children's multipoles).  posof: ngridmax ints, all -1.
+hipError_t launch_amr_rho_level(const double *dens, double *mp, double *rho, const double *xg, const int *son, const int *nbor,
+                                const int *father, const int *igrid, int *posof, int ngrid, int nvector, long ncoarse, long ngridmax,
+                                int ilevel, double boxlen_over_nx, double smallr, hipStream_t s);
 
 }  // namespace ramses_amd

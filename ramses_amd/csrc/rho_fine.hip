@@ -113,19 +113,28 @@ __global__ __launch_bounds__(DEP_THREADS) void rho_deposit_kernel(RhoArgs A) {
 }
 
 // multipole(d), d = 0..3: the SEQUENTIAL sum  s <- fl(s + a_i)  over the cells in the order (batch of nvector
-// octs, ind_son, oct in the batch) of cic_from_multipole (:858-866), reproduced bit for bit by a parallel scan.
+// octs, ind_son, oct in the batch) of cic_from_multipole (:858-866), reproduced bit for bit IN PARALLEL.
 //
 // While the running sum stays inside one binade [2^E, 2^(E+1)) its spacing is u = 2^(E-52), and adding a
 // positive a_i is an INTEGER operation on S = s/u: S <- S + n_i + (rem_i > u/2) + (rem_i == u/2 and S + n_i odd),
 // with n_i = floor(a_i/u) and rem_i the part of a_i below u (round to nearest, ties to even).  The increment
 // depends on what came before only through the parity of S, so a run of elements is a function
-// parity -> (increment for parity 0, increment for parity 1), and these functions compose associatively: a
-// workgroup scans them like a prefix sum.  Elements that could leave the binade (checked with a margin of one
-// unit per element) end the scan: the thread that owns them adds its elements with real floating-point adds,
-// the exponent is re-read and the scan restarts behind them.  The sum crosses ~log2(N) binades in all.
-// One workgroup per component; all additions are either exact integer sums or IEEE adds in the original order.
+// parity -> (increment for parity 0, increment for parity 1), and these functions compose associatively.
+//
+// Round 3: many workgroups.  The list is cut into segments of MP_SEG elements.
+//   pass 0  mp_sum_kernel     plain sums per segment (any order; only used to PREDICT the binade)
+//           mp_prefix_kernel  running sum at every segment start, approximately
+//   pass 1  mp_fn_kernel      the parity function of every segment in the predicted binade, all segments at once
+//   pass 2  mp_walk_kernel    one workgroup per component walks the segments in order with EXACT integer arithmetic:
+//                             a segment whose prediction holds (the exact running sum has the predicted exponent and
+//                             stays below 2^53 units through the segment -- the terms are positive, so the end value
+//                             decides) costs one table look-up; the others (the ~log2 N binade crossings, the first
+//                             segment, the rare misprediction next to a power of two) take the workgroup scan of
+//                             round 2, which adds the crossing elements with real floating-point adds.
+// All additions are exact integer sums or IEEE adds in the original order; 32 ms -> well under 1 ms at 256^3.
 constexpr int MP_THREADS = 1024;
 constexpr int MP_K = 8;                 // consecutive elements per thread and chunk
+constexpr long MP_SEG = (long)MP_THREADS * MP_K;
 struct ParFn { long t0, t1; };          // increment of S for incoming parity 0 / 1
 __device__ __forceinline__ ParFn par_compose(const ParFn &f, const ParFn &g) {   // f first, then g
   ParFn r;
@@ -139,23 +148,45 @@ __device__ __forceinline__ ParFn par_compose(const ParFn &f, const ParFn &g) {  
 }
 constexpr long MP_POISON = 1L << 53;
 
-__global__ __launch_bounds__(MP_THREADS) void multipole_kernel(RhoArgs A, double *__restrict__ out) {
-  __shared__ ParFn wavefn[MP_THREADS / 64];
-  __shared__ double sh_s;
-  __shared__ long sh_next;
-  __shared__ int sh_cross;
-  const int comp = blockIdx.x;       // 0: mass, 1..3: mass * position
-  const int n = A.n;
-  const long ncells = (long)A.ngrid * 8;
-  const int nv = A.nvector;
-  const long nfull = A.ngrid / nv;                 // full batches
-  const long full_cells = nfull * nv * 8;
-  const int nlast = A.ngrid - (int)(nfull * nv);   // octs of the last (partial) batch
-  auto operand = [&](long p) -> double {
+// one element as a parity function in the binade whose unit is 2^qu
+__device__ __forceinline__ ParFn par_element(double a, int qu, long &ub) {
+  const long ab = __double_as_longlong(a);
+  const int aexp = (int)((ab >> 52) & 0x7ff);
+  const long m = aexp ? ((ab & 0xfffffffffffffL) | (1L << 52)) : (ab & 0xfffffffffffffL);
+  const int q = (aexp ? aexp : 1) - 1075;         // a = m * 2^q
+  const int k = qu - q;                           // a / u = m / 2^k
+  long nint, inc_gt;
+  int tie;
+  if (m == 0) { nint = 0; inc_gt = 0; tie = 0; }
+  else if (k <= 0) { nint = MP_POISON; inc_gt = 0; tie = 0; }       // a >= 2^E: leaves the binade
+  else if (k >= 64) { nint = 0; inc_gt = 0; tie = 0; }
+  else {
+    nint = m >> k;
+    const long rem = m & ((1L << k) - 1), half = 1L << (k - 1);
+    inc_gt = rem > half ? 1 : 0;
+    tie = rem == half ? 1 : 0;
+  }
+  const long bsum = nint + inc_gt;
+  ParFn g;
+  g.t0 = bsum + (tie ? (nint & 1) : 0);           // incoming parity 0: S + n odd  <=>  n odd
+  g.t1 = bsum + (tie ? ((nint + 1) & 1) : 0);
+  ub += nint + 1;
+  if (ub > MP_POISON) ub = MP_POISON;
+  return g;
+}
+
+// Where the operands come from.  Brick: the uniform resident level (mass and mass * position computed from the
+// density brick).  Vec: the multipoles of the cells of an AMR level, already in a (4, ncell) cell vector.
+struct MpBrickSrc {
+  RhoArgs A;
+  __device__ long count() const { return (long)A.ngrid * 8; }
+  __device__ double operator()(int comp, long p) const {
+    const int nv = A.nvector, n = A.n;
+    const long nfull = A.ngrid / nv, full_cells = nfull * nv * 8;
     long batch, r;
     int np;
     if (p < full_cells) { batch = p / (8L * nv); r = p % (8L * nv); np = nv; }
-    else { batch = nfull; r = p - full_cells; np = nlast; }
+    else { batch = nfull; r = p - full_cells; np = A.ngrid - (int)(nfull * nv); }
     const int ind_son = (int)(r / np), j = (int)(r % np);
     const long org = A.octorg[batch * nv + j];
     const int bx = ind_son & 1, by = (ind_son >> 1) & 1, bz = ind_son >> 2;
@@ -169,59 +200,151 @@ __global__ __launch_bounds__(MP_THREADS) void multipole_kernel(RhoArgs A, double
     const double xc = ((double)bit - 0.5) * A.dx;
     const double xx = (xg + xc - 0.0) * A.scale;
     return mm * xx;
-  };
+  }
+};
+struct MpVecSrc {
+  const double *mp;       // (4, ncell)
+  const int *igrid;       // the level's list
+  int ngrid, nvector;
+  long ncell, ncoarse, ngridmax;
+  __device__ long count() const { return (long)ngrid * 8; }
+  __device__ double operator()(int comp, long p) const {
+    const int nv = nvector;
+    const long nfull = ngrid / nv, full_cells = nfull * nv * 8;
+    long batch, r;
+    int np;
+    if (p < full_cells) { batch = p / (8L * nv); r = p % (8L * nv); np = nv; }
+    else { batch = nfull; r = p - full_cells; np = ngrid - (int)(nfull * nv); }
+    const int ind_son = (int)(r / np), j = (int)(r % np);
+    const long cell = ncoarse + (long)ind_son * ngridmax + igrid[batch * nv + j] - 1;
+    return mp[(long)comp * ncell + cell];
+  }
+};
+
+// pass 0: plain per-segment sums (prediction only)
+template <class Src>
+__global__ __launch_bounds__(MP_THREADS) void mp_sum_kernel(Src S, long nseg, double *__restrict__ segsum) {
+  __shared__ double wsum[MP_THREADS / 64];
+  const long seg = blockIdx.x;
+  const long ncells = S.count();
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int comp = 0; comp < 4; comp++) {
+    double a = 0.0;
+    const long base = seg * MP_SEG + (long)tid * MP_K;
+#pragma unroll
+    for (int e = 0; e < MP_K; e++) a += (base + e) < ncells ? S(comp, base + e) : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if (lane == 0) wsum[wv] = a;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < MP_THREADS / 64; w++) t += wsum[w];
+      segsum[(long)comp * nseg + seg] = t;
+    }
+    __syncthreads();
+  }
+}
+// running sum at the start of every segment (exclusive prefix of the segment sums), one workgroup per component
+__global__ __launch_bounds__(MP_THREADS) void mp_prefix_kernel(long nseg, const double *__restrict__ segsum, double *__restrict__ pre) {
+  __shared__ double part[MP_THREADS];
+  const int comp = blockIdx.x, tid = threadIdx.x;
+  const long per = (nseg + MP_THREADS - 1) / MP_THREADS;
+  const long lo = (long)tid * per, hi = lo + per < nseg ? lo + per : nseg;
+  double t = 0.0;
+  for (long k = lo; k < hi; k++) t += segsum[(long)comp * nseg + k];
+  part[tid] = t;
+  __syncthreads();
+  if (tid == 0) {
+    double run = 0.0;
+    for (int k = 0; k < MP_THREADS; k++) { const double v = part[k]; part[k] = run; run += v; }
+  }
+  __syncthreads();
+  double run = part[tid];
+  for (long k = lo; k < hi; k++) { pre[(long)comp * nseg + k] = run; run += segsum[(long)comp * nseg + k]; }
+}
+// pass 1: the parity function of every segment in the binade its (approximate) starting sum predicts;
+// qupred = unit exponent used (INT_MIN: no prediction -- the walk takes the slow path there)
+template <class Src>
+__global__ __launch_bounds__(MP_THREADS) void mp_fn_kernel(Src S, long nseg, const double *__restrict__ pre, ParFn *__restrict__ fn,
+                                                           int *__restrict__ qupred) {
+  __shared__ ParFn wavefn[MP_THREADS / 64];
+  const long seg = blockIdx.x;
+  const long ncells = S.count();
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int comp = 0; comp < 4; comp++) {
+    const double s0 = pre[(long)comp * nseg + seg];
+    const long sbits = __double_as_longlong(s0);
+    const int sexp = (int)((sbits >> 52) & 0x7ff);
+    const bool usable = seg > 0 && sexp > 0 && sexp < 0x7ff && s0 > 0.0;
+    const int qu = sexp - 1075;
+    ParFn f = {0, 0};
+    if (usable) {
+      long ub = 0;
+      const long base = seg * MP_SEG + (long)tid * MP_K;
+#pragma unroll
+      for (int e = 0; e < MP_K; e++) {
+        const double a = (base + e) < ncells ? S(comp, base + e) : 0.0;
+        f = par_compose(f, par_element(a, qu, ub));
+      }
+      // ordered reduction (composition is associative, not commutative): lanes, then waves
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        ParFn o;
+        o.t0 = __shfl_down(f.t0, off, 64);
+        o.t1 = __shfl_down(f.t1, off, 64);
+        if ((lane & (2 * off - 1)) == 0) f = par_compose(f, o);
+      }
+    }
+    if (lane == 0) wavefn[wv] = f;
+    __syncthreads();
+    if (tid == 0) {
+      ParFn tot = wavefn[0];
+      for (int w = 1; w < MP_THREADS / 64; w++) tot = par_compose(tot, wavefn[w]);
+      fn[(long)comp * nseg + seg] = tot;
+      qupred[(long)comp * nseg + seg] = usable ? qu : (int)0x80000000;
+    }
+    __syncthreads();
+  }
+}
+
+// pass 2: the exact walk.  slow_range adds the elements [i0, lim) to sh_s with the workgroup scan (binade crossings
+// handled by real floating-point adds of the crossing thread's elements).
+template <class Src>
+__device__ void mp_slow_range(const Src &S, int comp, long i0_in, long lim, double &sh_s, long &sh_next, int &sh_cross, ParFn *wavefn) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) {
-    // the first elements cross a binade at almost every addition: plain sequential adds
-    double s = 0.0;
-    const long m = ncells < 64 ? ncells : 64;
-    for (long p = 0; p < m; p++) s = s + operand(p);
+    double s = sh_s;
+    long p = i0_in;
+    if (i0_in == 0) {
+      // the first elements cross a binade at almost every addition: plain sequential adds
+      const long m = lim < 64 ? lim : 64;
+      for (; p < m; p++) s = s + S(comp, p);
+    }
+    // (a sum that is still zero or subnormal cannot be scanned: keep adding one by one)
+    while (p < lim && !(s >= 2.3e-308)) { s = s + S(comp, p); p++; }
     sh_s = s;
-    sh_next = m;
+    sh_next = p;
   }
   __syncthreads();
   while (true) {
     const long i0 = sh_next;
-    if (i0 >= ncells) break;
+    if (i0 >= lim) break;
     const double s = sh_s;
     const long sbits = __double_as_longlong(s);
     const int sexp = (int)((sbits >> 52) & 0x7ff);
     // (s is a positive normal number here: sums of positive normal operands)
-    const long S = (sbits & 0xfffffffffffffL) | (1L << 52);
-    const int qu = sexp - 1075;                       // s = S * 2^qu
+    const long Sx = (sbits & 0xfffffffffffffL) | (1L << 52);
+    const int qu = sexp - 1075;                       // s = Sx * 2^qu
     // ---- this thread's MP_K elements as one parity function (+ an upper bound of their increments) ----
     double a[MP_K];
     const long base = i0 + (long)tid * MP_K;
 #pragma unroll
-    for (int e = 0; e < MP_K; e++) a[e] = (base + e) < ncells ? operand(base + e) : 0.0;
+    for (int e = 0; e < MP_K; e++) a[e] = (base + e) < lim ? S(comp, base + e) : 0.0;
     ParFn f = {0, 0};
     long ub = 0;
 #pragma unroll
-    for (int e = 0; e < MP_K; e++) {
-      const long ab = __double_as_longlong(a[e]);
-      const int aexp = (int)((ab >> 52) & 0x7ff);
-      const long m = aexp ? ((ab & 0xfffffffffffffL) | (1L << 52)) : (ab & 0xfffffffffffffL);
-      const int q = (aexp ? aexp : 1) - 1075;         // a = m * 2^q
-      const int k = qu - q;                           // a / u = m / 2^k
-      long nint, inc_gt;
-      int tie;
-      if (m == 0) { nint = 0; inc_gt = 0; tie = 0; }
-      else if (k <= 0) { nint = MP_POISON; inc_gt = 0; tie = 0; }       // a >= 2^E: leaves the binade
-      else if (k >= 64) { nint = 0; inc_gt = 0; tie = 0; }
-      else {
-        nint = m >> k;
-        const long rem = m & ((1L << k) - 1), half = 1L << (k - 1);
-        inc_gt = rem > half ? 1 : 0;
-        tie = rem == half ? 1 : 0;
-      }
-      const long bsum = nint + inc_gt;
-      ParFn g;
-      g.t0 = bsum + (tie ? (nint & 1) : 0);           // incoming parity 0: S + n odd  <=>  n odd
-      g.t1 = bsum + (tie ? ((nint + 1) & 1) : 0);
-      f = par_compose(f, g);
-      ub += nint + 1;
-      if (ub > MP_POISON) ub = MP_POISON;
-    }
+    for (int e = 0; e < MP_K; e++) f = par_compose(f, par_element(a[e], qu, ub));
     // ---- inclusive scan of the functions over the workgroup (wave shuffles, then the 16 wave totals) ----
     ParFn inc = f;
 #pragma unroll
@@ -233,18 +356,18 @@ __global__ __launch_bounds__(MP_THREADS) void multipole_kernel(RhoArgs A, double
     }
     if (lane == 63) wavefn[wv] = inc;
     __syncthreads();
-    ParFn pre = {0, 0};                                // everything before this thread's wave
-    for (int w = 0; w < wv; w++) pre = par_compose(pre, wavefn[w]);
+    ParFn prew = {0, 0};                               // everything before this thread's wave
+    for (int w = 0; w < wv; w++) prew = par_compose(prew, wavefn[w]);
     ParFn excl;                                        // everything before this thread
     {
       ParFn o;
       o.t0 = __shfl_up(inc.t0, 1, 64);
       o.t1 = __shfl_up(inc.t1, 1, 64);
       if (lane == 0) { o.t0 = 0; o.t1 = 0; }
-      excl = par_compose(pre, o);
+      excl = par_compose(prew, o);
     }
-    const int p0 = (int)(S & 1);
-    const long S_t = S + (p0 ? excl.t1 : excl.t0);     // S on entry of this thread's elements
+    const int p0 = (int)(Sx & 1);
+    const long S_t = Sx + (p0 ? excl.t1 : excl.t0);    // S on entry of this thread's elements
     const bool unsafe = (ub >= MP_POISON) || (S_t + ub >= MP_POISON) || (S_t >= MP_POISON);
     if (tid == 0) sh_cross = MP_THREADS;
     __syncthreads();
@@ -254,9 +377,9 @@ __global__ __launch_bounds__(MP_THREADS) void multipole_kernel(RhoArgs A, double
     if (tc == MP_THREADS) {
       if (tid == MP_THREADS - 1) {
         const ParFn tot = par_compose(excl, f);
-        const long S_end = S + (p0 ? tot.t1 : tot.t0);
+        const long S_end = Sx + (p0 ? tot.t1 : tot.t0);
         sh_s = __builtin_ldexp((double)S_end, qu);
-        sh_next = i0 + (long)MP_THREADS * MP_K;
+        sh_next = i0 + MP_SEG;
       }
     } else if (tid == tc) {
       // everything before this thread stayed inside the binade; its own elements are added one by one
@@ -268,7 +391,262 @@ __global__ __launch_bounds__(MP_THREADS) void multipole_kernel(RhoArgs A, double
     }
     __syncthreads();
   }
-  if (tid == 0) out[comp] = sh_s;
+}
+
+constexpr int MP_WALK_TILE = 2048;      // segments whose functions sit in LDS at a time
+template <class Src>
+__global__ __launch_bounds__(MP_THREADS) void mp_walk_kernel(Src S, long nseg, const ParFn *__restrict__ fn, const int *__restrict__ qupred,
+                                                             double *__restrict__ out, int *__restrict__ nslow) {
+  __shared__ ParFn wavefn[MP_THREADS / 64];
+  __shared__ ParFn tfn[MP_WALK_TILE];
+  __shared__ int tqu[MP_WALK_TILE];
+  __shared__ double sh_s;
+  __shared__ long sh_next, sh_seg;
+  __shared__ int sh_cross, sh_slow;
+  const int comp = blockIdx.x, tid = threadIdx.x;
+  const long ncells = S.count();
+  if (tid == 0) { sh_s = 0.0; sh_seg = 0; sh_slow = 0; }
+  __syncthreads();
+  int slow_count = 0;
+  for (long t0 = 0; t0 < nseg; t0 += MP_WALK_TILE) {
+    const int nt = (int)(nseg - t0 < MP_WALK_TILE ? nseg - t0 : MP_WALK_TILE);
+    for (int k = tid; k < nt; k += MP_THREADS) { tfn[k] = fn[(long)comp * nseg + t0 + k]; tqu[k] = qupred[(long)comp * nseg + t0 + k]; }
+    __syncthreads();
+    while (true) {
+      if (tid == 0) {
+        long seg = sh_seg;
+        double s = sh_s;
+        int slow = 0;
+        while (seg < t0 + nt) {
+          const long sbits = __double_as_longlong(s);
+          const int sexp = (int)((sbits >> 52) & 0x7ff);
+          const long Sx = (sbits & 0xfffffffffffffL) | (1L << 52);
+          const int k = (int)(seg - t0);
+          const long inc = (Sx & 1) ? tfn[k].t1 : tfn[k].t0;
+          if (sexp == 0 || sexp - 1075 != tqu[k] || inc >= MP_POISON || Sx + inc >= MP_POISON) { slow = 1; break; }
+          s = __builtin_ldexp((double)(Sx + inc), sexp - 1075);
+          seg++;
+        }
+        sh_s = s; sh_seg = seg; sh_slow = slow;
+      }
+      __syncthreads();
+      if (!sh_slow) break;                             // the tile is done
+      const long seg = sh_seg;
+      const long lim = (seg + 1) * MP_SEG < ncells ? (seg + 1) * MP_SEG : ncells;
+      mp_slow_range(S, comp, seg * MP_SEG, lim, sh_s, sh_next, sh_cross, wavefn);
+      slow_count++;
+      if (tid == 0) sh_seg = seg + 1;
+      __syncthreads();
+    }
+  }
+  if (tid == 0) { out[comp] = sh_s; if (nslow) nslow[comp] = slow_count; }
+}
+
+template <class Src>
+static hipError_t launch_multipole_src(const Src &S, long ncells, double *out4, void *scratch, hipStream_t s) {
+  const long nseg = (ncells + MP_SEG - 1) / MP_SEG;
+  if (nseg < 1) {
+    return hipMemsetAsync(out4, 0, sizeof(double) * 4, s);
+  }
+  // scratch: segsum[4*nseg] doubles, pre[4*nseg] doubles, fn[4*nseg] ParFn, qupred[4*nseg] ints, nslow[4]
+  char *w = reinterpret_cast<char *>(scratch);
+  double *segsum = reinterpret_cast<double *>(w); w += sizeof(double) * 4 * nseg;
+  double *pre = reinterpret_cast<double *>(w); w += sizeof(double) * 4 * nseg;
+  ParFn *fn = reinterpret_cast<ParFn *>(w); w += sizeof(ParFn) * 4 * nseg;
+  int *qupred = reinterpret_cast<int *>(w); w += sizeof(int) * 4 * nseg;
+  int *nslow = reinterpret_cast<int *>(w);
+  hipLaunchKernelGGL(mp_sum_kernel<Src>, dim3((unsigned)nseg), dim3(MP_THREADS), 0, s, S, nseg, segsum);
+  hipLaunchKernelGGL(mp_prefix_kernel, dim3(4), dim3(MP_THREADS), 0, s, nseg, segsum, pre);
+  hipLaunchKernelGGL(mp_fn_kernel<Src>, dim3((unsigned)nseg), dim3(MP_THREADS), 0, s, S, nseg, pre, fn, qupred);
+  hipLaunchKernelGGL(mp_walk_kernel<Src>, dim3(4), dim3(MP_THREADS), 0, s, S, nseg, fn, qupred, out4, nslow);
+  return hipGetLastError();
+}
+size_t multipole_scratch_bytes(long ncells) {
+  const long nseg = (ncells + MP_SEG - 1) / MP_SEG + 1;
+  return (sizeof(double) * 8 + sizeof(ParFn) * 4 + sizeof(int) * 4) * (size_t)nseg + 64;
+}
+
+// ===========================================================================================================
+// rho_fine's hydro deposit on the levels of an AMR run, on the reference's own cell vectors and tree
+// (oracle: ora_rho_fine_amr / ora_rho_deposit_gather, pinned on dumps of the reference).
+//   amr_multipole_kernel   multipole_fine(l), pm/rho_fine.f90:666-820: leaf cell -> (m, m x) with m = max(rho,smallr) vol at
+//                          the cell centre; split cell -> the sum of its eight children's multipoles, child by child from zero
+//   amr_deposit_kernel     cic_from_multipole(l) / cic_cell :825-1142 as a gather: one thread per TARGET cell of the level
+//                          visits the 3^3 cells around it (through the FATHER cells: the 3^3 father cells around an oct
+//                          exist by the refinement rules, get3cubefather's assumption), recomputes the CIC split of each
+//                          source at its centre of mass, tags what it receives with the position of that addition in the
+//                          reference's loop nest (batch of nvector octs, ind_son, CIC corner, oct in the batch) and adds in
+//                          tag order.  A source whose oct does not exist contributes nothing; a corner whose target oct does
+//                          not exist is dropped by the reference (:1128-1139) and is never asked for here.
+// ===========================================================================================================
+struct AmrRhoArgs {
+  const double *dens;     // uold(:,1), cell vector
+  double *mp;             // (4, ncell) multipoles (the reference's unew(:,1:4) scratch)
+  double *rho;            // (ncell) out
+  const double *xg;       // (3, ngridmax)
+  const int *son, *nbor, *father;
+  const int *igrid;       // the level's octs in list order
+  const int *posof;       // oct -> position in that list (-1: not of this level's list)
+  int ngrid, nvector;
+  long ncell, ncoarse, ngridmax;
+  double dx, scale, vol_loc, smallr;
+};
+
+__global__ __launch_bounds__(256) void amr_multipole_kernel(AmrRhoArgs A) {
+  const long total = (long)A.ngrid * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ind = (int)(t / A.ngrid), i = (int)(t % A.ngrid);
+    const int g = A.igrid[i];
+    const long c = A.ncoarse + (long)ind * A.ngridmax + g - 1;
+    const int sn = A.son[c];
+    double m[4];
+    if (sn == 0) {
+      const double mm = __builtin_fmax(A.dens[c], A.smallr) * A.vol_loc;
+      m[0] = 0.0 + mm;
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const double xc = ((double)((ind >> d) & 1) - 0.5) * A.dx;
+        const double xx = (A.xg[(long)d * A.ngridmax + g - 1] + xc - 0.0) * A.scale;
+        m[1 + d] = 0.0 + mm * xx;
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < 4; d++) m[d] = 0.0;
+      for (int is = 0; is < 8; is++) {
+        const long cs = A.ncoarse + (long)is * A.ngridmax + sn - 1;
+#pragma unroll
+        for (int d = 0; d < 4; d++) m[d] = m[d] + A.mp[(long)d * A.ncell + cs];
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; d++) A.mp[(long)d * A.ncell + c] = m[d];
+  }
+}
+
+// same-level neighbour of cell c (1-based, level >= 2) in direction dir, 0 if its oct does not exist
+__device__ __forceinline__ long amr_rho_nbor_cell(const AmrRhoArgs &A, long c, int dir) {
+  const int pos = (int)((c - A.ncoarse - 1) / A.ngridmax);
+  const long g = c - A.ncoarse - (long)pos * A.ngridmax;
+  const int axis = dir >> 1, up = dir & 1;
+  const int bit = (pos >> axis) & 1;
+  if (bit != up) return c + (up ? 1 : -1) * ((long)(1 << axis) * A.ngridmax);
+  const int nb = A.nbor[(long)dir * A.ngridmax + g - 1];
+  const int g2 = A.son[nb - 1];
+  if (g2 == 0) return 0;
+  return A.ncoarse + (long)(pos ^ (1 << axis)) * A.ngridmax + g2;
+}
+
+constexpr int ADEP_THREADS = 128;
+__global__ __launch_bounds__(ADEP_THREADS) void amr_deposit_kernel(AmrRhoArgs A) {
+  __shared__ long skey[27][ADEP_THREADS];
+  __shared__ double sval[27][ADEP_THREADS];
+  const long total = (long)A.ngrid * 8;
+  const long t = (long)blockIdx.x * ADEP_THREADS + threadIdx.x;
+  if (t >= total) return;                     // (no barrier below: each thread uses its own LDS column)
+  const int ind_t = (int)(t / A.ngrid), it = (int)(t % A.ngrid);
+  const int g_t = A.igrid[it];
+  const long F_t = A.father[g_t - 1];         // father cell of the target's oct
+  const double dx = A.dx, scale = A.scale;
+  int cnt = 0;
+  for (int oz = -1; oz <= 1; oz++)
+    for (int oy = -1; oy <= 1; oy++)
+      for (int ox = -1; ox <= 1; ox++) {
+        // source cell = target cell - o: its octant bits, and the step (per direction) to its oct's father cell
+        const int o[3] = {ox, oy, oz};
+        int sb[3], step[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          const int st = ((ind_t >> d) & 1) - o[d];
+          step[d] = st < 0 ? -1 : (st > 1 ? 1 : 0);
+          sb[d] = st & 1;
+        }
+        long F_s = F_t;
+        if (F_t > A.ncoarse) {
+#pragma unroll
+          for (int d = 0; d < 3; d++)
+            if (step[d] != 0 && F_s > 0) F_s = amr_rho_nbor_cell(A, F_s, 2 * d + (step[d] > 0 ? 1 : 0));
+        }
+        if (F_s <= 0) continue;
+        const int g_s = A.son[F_s - 1];
+        if (g_s <= 0) continue;
+        const int i_s = A.posof[g_s - 1];
+        if (i_s < 0) continue;                 // not a source of this call's list
+        const int ind_son = sb[0] + 2 * sb[1] + 4 * sb[2];
+        const long cs = A.ncoarse + (long)ind_son * A.ngridmax + g_s - 1;
+        const double m0 = A.mp[cs];
+        double w[3];
+        int b[3];
+        bool hit = true;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          const double xgs = A.xg[(long)d * A.ngridmax + g_s - 1];
+          double x = A.mp[(long)(1 + d) * A.ncell + cs] / m0;              // centre of mass
+          x = x / scale + 0.0;
+          x = x - (xgs - 3.0 * dx);
+          x = x / dx;
+          double dd = x + 0.5;
+          const int id = (int)dd;
+          dd = dd - id;
+          const double dg = 1.0 - dd;
+          const int ig = id - 1;
+          const int kt = 2 + sb[d] + o[d];                                   // block coordinate of the target cell
+          if (kt == ig) { b[d] = 0; w[d] = dg; }
+          else if (kt == id) { b[d] = 1; w[d] = dd; }
+          else hit = false;
+        }
+        if (!hit) continue;
+        const double vol = w[0] * w[1] * w[2];
+        const double vol2 = m0 * vol / A.vol_loc;
+        if (vol2 == 0.0) continue;                                           // + 0.0 leaves the (non-negative) sum unchanged
+        const int ind = b[0] + 2 * b[1] + 4 * b[2];
+        const long batch = i_s / A.nvector, j = i_s % A.nvector;
+        skey[cnt][threadIdx.x] = ((batch * 8 + ind_son) * 8 + ind) * A.nvector + j;
+        sval[cnt][threadIdx.x] = vol2;
+        cnt++;
+      }
+  double r = 0.0;
+  long last = -1;
+  for (int k = 0; k < cnt; k++) {
+    long best = 0x7fffffffffffffffL;
+    double v = 0.0;
+    for (int c = 0; c < cnt; c++) {
+      const long key = skey[c][threadIdx.x];
+      if (key > last && key < best) { best = key; v = sval[c][threadIdx.x]; }
+    }
+    r = r + v;
+    last = best;
+  }
+  A.rho[A.ncoarse + (long)ind_t * A.ngridmax + g_t - 1] = r;
+}
+
+__global__ void amr_rho_posof_kernel(const int *igrid, int ngrid, int *posof, int set) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ngrid) posof[igrid[i] - 1] = set ? i : -1;
+}
+
+// one level of the call: multipoles, then the deposit; posof (ngridmax ints, all -1 on entry and again on return)
+hipError_t launch_amr_rho_level(const double *dens, double *mp, double *rho, const double *xg, const int *son, const int *nbor,
+                                const int *father, const int *igrid, int *posof, int ngrid, int nvector, long ncoarse, long ngridmax,
+                                int ilevel, double boxlen_over_nx, double smallr, hipStream_t s) {
+  if (ngrid <= 0) return hipSuccess;
+  AmrRhoArgs A;
+  A.dens = dens; A.mp = mp; A.rho = rho; A.xg = xg; A.son = son; A.nbor = nbor; A.father = father;
+  A.igrid = igrid; A.posof = posof; A.ngrid = ngrid; A.nvector = nvector;
+  A.ncoarse = ncoarse; A.ngridmax = ngridmax; A.ncell = ncoarse + 8 * ngridmax;
+  double dx = 1.0;
+  for (int l = 0; l < ilevel; l++) dx *= 0.5;
+  A.dx = dx; A.scale = boxlen_over_nx;
+  const double dx_loc = dx * A.scale;
+  A.vol_loc = dx_loc * dx_loc * dx_loc;
+  A.smallr = smallr;
+  const long total = (long)ngrid * 8;
+  long gm = (total + 255) / 256;
+  if (gm > 16384) gm = 16384;
+  hipLaunchKernelGGL(amr_multipole_kernel, dim3((unsigned)gm), dim3(256), 0, s, A);
+  hipLaunchKernelGGL(amr_rho_posof_kernel, dim3((ngrid + 255) / 256), dim3(256), 0, s, igrid, ngrid, posof, 1);
+  hipLaunchKernelGGL(amr_deposit_kernel, dim3((unsigned)((total + ADEP_THREADS - 1) / ADEP_THREADS)), dim3(ADEP_THREADS), 0, s, A);
+  hipLaunchKernelGGL(amr_rho_posof_kernel, dim3((ngrid + 255) / 256), dim3(256), 0, s, igrid, ngrid, posof, 0);
+  return hipGetLastError();
 }
 
 hipError_t launch_oct_index(const long *octorg, int ngrid, int n, int *octidx, hipStream_t s) {
@@ -280,9 +658,16 @@ hipError_t launch_rho_deposit(const RhoArgs &A, hipStream_t s) {
   hipLaunchKernelGGL(rho_deposit_kernel, dim3((unsigned)((N + DEP_THREADS - 1) / DEP_THREADS)), dim3(DEP_THREADS), 0, s, A);
   return hipGetLastError();
 }
-hipError_t launch_multipole(const RhoArgs &A, double *out4, hipStream_t s) {
-  hipLaunchKernelGGL(multipole_kernel, dim3(4), dim3(MP_THREADS), 0, s, A, out4);
-  return hipGetLastError();
+hipError_t launch_multipole(const RhoArgs &A, double *out4, void *scratch, hipStream_t s) {
+  MpBrickSrc S;
+  S.A = A;
+  return launch_multipole_src(S, (long)A.ngrid * 8, out4, scratch, s);
+}
+hipError_t launch_multipole_vec(const double *mp, const int *igrid, int ngrid, int nvector, long ncell, long ncoarse, long ngridmax,
+                                double *out4, void *scratch, hipStream_t s) {
+  MpVecSrc S;
+  S.mp = mp; S.igrid = igrid; S.ngrid = ngrid; S.nvector = nvector; S.ncell = ncell; S.ncoarse = ncoarse; S.ngridmax = ngridmax;
+  return launch_multipole_src(S, (long)ngrid * 8, out4, scratch, s);
 }
 
 }  // namespace ramses_amd

@@ -29,6 +29,7 @@ subroutine hydro_flag(ilevel)
   real(dp)::half,scale
   real(dp),dimension(1:3)::corner
   type(ramses_amd_hydro_params)::p
+  integer(8)::t0
 
   if(.not.ramses_amd_amr_resident())then
      call hydro_flag_reference(ilevel)
@@ -40,6 +41,7 @@ subroutine hydro_flag(ilevel)
   if(err_grad_d==-1.0.and.err_grad_p==-1.0.and.err_grad_u==-1.0.and.jeans_refine(ilevel)==-1.0)return
 
   call ramses_amd_amr_ensure()
+  call ramses_amd_tic(t0)
   call ramses_amd_fill_hydro_params(p)
   ncache=active(ilevel)%ngrid
   allocate(cand(1:twotondim*max(ncache,1)))
@@ -79,4 +81,5 @@ subroutine hydro_flag(ilevel)
      end if
   end do
   deallocate(cand,keep)
+  call ramses_amd_toc('hydro_flag (shim: kernel + list + flag1)',ilevel,t0)
 end subroutine hydro_flag

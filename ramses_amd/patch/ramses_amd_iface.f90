@@ -624,6 +624,21 @@ module ramses_amd_iface
        real(c_double) :: out4(4)
        integer(c_int) :: rc
      end function ramses_amd_amrres_courant
+     function ramses_amd_amrres_xg(xg) bind(C, name='ramses_amd_amrres_xg') result(rc)
+       import :: c_int, c_double
+       real(c_double) :: xg(*)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_xg
+     function ramses_amd_amrres_rho_fine(p, ilevel, nlevelmax, levelmin, nvector, first, igrid_all, boxlen_over_nx, rho, mp4) &
+          & bind(C, name='ramses_amd_amrres_rho_fine') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ilevel, nlevelmax, levelmin, nvector
+       integer(c_int) :: first(*), igrid_all(*)
+       real(c_double), value :: boxlen_over_nx
+       real(c_double) :: rho(*), mp4(4)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_rho_fine
      function ramses_amd_amrres_hydro_flag(p, ngrid, igrid, egd, egp, egu, fld, flp, flu, cells, ncells) &
           & bind(C, name='ramses_amd_amrres_hydro_flag') result(rc)
        import :: ramses_amd_hydro_params, c_int, c_double

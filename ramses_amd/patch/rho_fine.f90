@@ -67,14 +67,106 @@ subroutine rho_fine_amd(ilevel,icount)
 111 format('   Entering rho_fine (MI355X) for level ',I2)
 end subroutine rho_fine_amd
 
-subroutine rho_fine(ilevel,icount)
+!------------------------------------------------------------------------------
+! rho_fine(ilevel,icount) of an AMR run whose hydro state lives on the device (single rank, periodic box, no
+! particles): the deposit loop of the reference (pm/rho_fine.f90:45-60: multipole_fine(l) and cic_from_multipole(l)
+! for l = nlevelmax .. ilevel) runs on the GPU on the resident density -- multipoles of leaf and split cells, the
+! order-tagged CIC gather through the tree, the four sequential multipole sums at levelmin (csrc/rho_fine.hip) -- and
+! only rho of the visited levels comes back.  What else the reference's routine does in this configuration is the
+! reset of phi on the level and rho_tot (:66-70,176-183); everything tied to particles, cic_levelmax, m_refine,
+! physical boundaries or several ranks keeps the reference's routine (ramses_amd_rho_amr_device says no).
+!------------------------------------------------------------------------------
+logical function ramses_amd_rho_amr_device(ilevel)
   use amr_commons
-  use hydro_commons, only: uold
+  use pm_commons
+  use hydro_commons
+  use poisson_commons
   use ramses_amd_iface
   implicit none
-  integer::ilevel,icount,l,rc
+  integer,intent(in)::ilevel
+  character(len=16)::val
+  integer::stat,l
+  logical,save::first=.true.,enabled=.true.
+  if(first)then
+     call get_environment_variable('RAMSES_AMD_RESIDENT_RHO',val,status=stat)
+     if(stat==0)then
+        if(trim(val)=='0')enabled=.false.
+     end if
+     first=.false.
+  end if
+  ramses_amd_rho_amr_device=.false.
+  if(.not.enabled)return
+#ifdef TSC
+  return
+#endif
+  if(.not.(poisson.and.hydro))return
+  if(ramses_amd_amrres_active()==0)return
+  if(ncpu>1.or.pic.or.nboundary>0.or.cic_levelmax>0.or.ilevel<2.or.ndim/=3)return
+  if(icoarse_max/=icoarse_min)return
+  do l=ilevel,nlevelmax
+     if(m_refine(l)>-1.0d0)return
+  end do
+  ramses_amd_rho_amr_device=.true.
+end function ramses_amd_rho_amr_device
+
+subroutine rho_fine(ilevel,icount)
+  use amr_commons
+  use hydro_commons, only: uold, smallr
+  use poisson_commons
+  use ramses_amd_iface
+  implicit none
+  integer::ilevel,icount,l,rc,n,k,ind,i
   integer(8)::t0
+  integer,allocatable,dimension(:)::first,lists
+  real(kind=8),dimension(4)::mp4
+  type(ramses_amd_hydro_params)::p
+  logical,external::ramses_amd_rho_amr_device
+  integer,save::xg_epoch=-1
   call ramses_amd_tic(t0)
+  if(ramses_amd_amr_resident().and.poisson.and.numbtot(1,ilevel)>0)then
+     if(ramses_amd_rho_amr_device(ilevel))then
+        call ramses_amd_amr_ensure()
+        if(xg_epoch/=ramses_amd_tree_epoch)then
+           rc=ramses_amd_amrres_xg(xg)
+           if(rc/=0)call ramses_amd_fatal('rho_fine (oct centres)')
+           xg_epoch=ramses_amd_tree_epoch
+        end if
+        if(ilevel==levelmin)multipole=0d0
+        if(ilevel==levelmin.or.icount>1)then
+           allocate(first(0:nlevelmax-ilevel+1))
+           first(0)=0
+           do l=ilevel,nlevelmax
+              n=0
+              if(numbtot(1,l)>0)n=active(l)%ngrid
+              first(l-ilevel+1)=first(l-ilevel)+n
+           end do
+           allocate(lists(1:max(first(nlevelmax-ilevel+1),1)))
+           do l=ilevel,nlevelmax
+              k=first(l-ilevel)
+              n=first(l-ilevel+1)-k
+              if(n>0)lists(k+1:k+n)=active(l)%igrid(1:n)
+           end do
+           call ramses_amd_fill_hydro_params(p)
+           mp4=0d0
+           rc=ramses_amd_amrres_rho_fine(p,ilevel,nlevelmax,levelmin,nvector,first,lists,boxlen,rho,mp4)
+           if(rc/=0)call ramses_amd_fatal('rho_fine (AMR deposit)')
+           if(ilevel==levelmin)multipole(1:ndim+1)=mp4(1:ndim+1)
+           deallocate(first,lists)
+        end if
+        ! the level's first guess starts from zero (:66-70); rho_tot (:176-183)
+        do ind=1,twotondim
+           k=ncoarse+(ind-1)*ngridmax
+           do i=1,active(ilevel)%ngrid
+              phi(k+active(ilevel)%igrid(i))=0.0d0
+           end do
+        end do
+        rho_tot=multipole(1)/boxlen**ndim
+        ramses_amd_pois_dev=.false.
+        ramses_amd_pois_amr_level=0
+        call ramses_amd_toc('rho_fine',ilevel,t0)
+        return
+     end if
+  end if
   ! AMR run with the hydro state on the device: multipole_fine (pm/rho_fine.f90:666-770) reads the density of the
   ! levels it visits (:45-47) from the host array -- bring it back (nothing else of uold is read)
   if(ramses_amd_amr_resident())then

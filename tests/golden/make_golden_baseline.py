@@ -7,6 +7,7 @@ BASELINE.json configurations at sizes too large for per-cell fixtures:
            periodic level, rho = 1 background + 'square' over-density rho = 10 of side 0.25,
            P = 1, epsilon = 1d-6, three coarse steps; digest of (prim, phi, f) and the
            V-cycle counts of every solve
+  c4_256   the same at BASELINE's stated size for config C4, uniform 256^3 (levelmin = levelmax = 8)
   c5_79    config C5 at levels 7-9 (sedov3d.nml, levelmin=7 levelmax=9, interpol_var=0,
            interpol_type=2, err_grad_p=0.1; 8 coarse steps); digest of the sorted leaf data
 
@@ -17,7 +18,7 @@ the GPU box instead (tests/test_baseline_sizes_gpu.py).
 
   amr_grav_68  AMR levels 6-8 with self-gravity (blob + blast), 3 coarse steps: sha256 of the sorted leaf data
            (level, x, prim, phi, f), cells per level, V-cycle counts
-Run:  python tests/golden/make_golden_baseline.py [c4_128] [c5_79] [amr_grav_68]
+Run:  python tests/golden/make_golden_baseline.py [c4_128] [c4_256] [c5_79] [amr_grav_68]
 Writes tests/golden/baseline_sizes.json (merged with what is there).
 """
 import hashlib
@@ -127,6 +128,15 @@ def main():
             out["c4_128"] = dict(sha256=digest_uniform(snap), solves=solves(log), rho_tot=snap["info"]["rho_tot"],
                                  t=snap["info"]["t"])
             print("c4_128", out["c4_128"])
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    if "c4_256" in todo:
+        work, log = rs.run_reference(c4_namelist(level=8))
+        try:
+            snap = rs.load_uniform_level(os.path.join(work, "output_00002"), 8, with_grav=True)
+            out["c4_256"] = dict(sha256=digest_uniform(snap), solves=solves(log), rho_tot=snap["info"]["rho_tot"],
+                                 t=snap["info"]["t"])
+            print("c4_256", out["c4_256"])
         finally:
             shutil.rmtree(work, ignore_errors=True)
     if "c5_79" in todo:

@@ -1,0 +1,177 @@
+"""Live A/B against the reference program AT THE SIZES BASELINE.json STATES for configs C3 and C4 (VERDICT round 2,
+weak #2: the largest MPI run compared so far was 128^3 on 8 ranks, i.e. 64^3 bricks -- below the brick size at which the
+12-row tiling, the 128-plane z-chunks and the shell / interior split of the dense sweep engage).
+
+ * C3 at half size: sedov3d.nml as shipped (nstepmax=10) at 256^3 on 8 ranks = 128^3 bricks, exchange behind the interior
+   sweep and after the sweep, against ONE run of the MPI reference (any rank count gives the same snapshot: the update of a
+   uniform level does not depend on the decomposition, and the assembled level is compared).
+ * C3 AS STATED: 512^3 on 8 ranks = 256^3 bricks per rank (about 25 GB of host arrays for either program, SURVEY.md
+   section 8), two coarse steps -- enough for every launch shape of the 256^3 brick (4 z-chunks of 128 planes, 9 x 64 tiles
+   of 12 rows, the six-box shell launch) to produce cells that are compared.  Skipped, with the reason, on a box that
+   cannot hold it.
+ * C4 AS STATED: hydro + self-gravity at 256^3 (rho_fine, multigrid_fine, force_fine, the gravity terms; level resident):
+   bit for bit against the checksum of the SERIAL reference (tests/golden/baseline_sizes.json "c4_256", made by
+   tests/golden/make_golden_baseline.py), and live against the MPI reference: same V-cycle counts, prim / phi / f within
+   north_star's 1e-12 (an MPI run adds its density multipoles and residual norms in another order than a serial one, so the
+   two REFERENCE runs differ from each other in the last bits; the serial one is the bit-exact oracle).
+
+All ranks share the box's one GPU (host-MPI transport; the run says so); the RCCL entry points themselves are executed by
+tests/test_rccl_gpu.py."""
+import importlib.util
+import json
+import os
+import shutil
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_MPI = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi")
+PATCHED = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch")
+PATCHED_MPI = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi_patch")
+GOLD = os.path.join(ROOT, "tests", "golden", "baseline_sizes.json")
+TOL = 1e-12
+
+
+def _mkb():
+    spec = importlib.util.spec_from_file_location("mkb", os.path.join(ROOT, "tests", "golden", "make_golden_baseline.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _cores():
+    n = os.cpu_count() or 1
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False) or n
+    except Exception:     # noqa: BLE001
+        pass
+    return n
+
+
+def _pow2_ranks(limit):
+    p = 1
+    while p * 2 <= min(_cores(), limit):
+        p *= 2
+    return p
+
+
+def _ram_gb():
+    try:
+        import psutil
+        return psutil.virtual_memory().available / 2 ** 30
+    except Exception:     # noqa: BLE001
+        return 0.0
+
+
+def _run(nml, binary, nproc, env, timeout=1500):
+    from oracle import ramses_snapshot as rs
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    t0 = time.time()
+    try:
+        work, out = rs.run_reference(nml, binary=binary, nproc=nproc, timeout=timeout)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return work, out, time.time() - t0
+
+
+def _need(*paths):
+    for p in paths:
+        if not os.path.exists(p):
+            pytest.skip("%s not built" % os.path.relpath(p, ROOT))
+
+
+def _uniform_ab(level, nstep, nref, overlaps):
+    from oracle import ramses_snapshot as rs
+    nml = rs.sedov3d_namelist(level=level, nstepmax=nstep, foutput=nstep, mem_factor=3.0)
+    workr, outr, tr = _run(nml, REF_MPI, nref, {"RAMSES_AMD": "0"})
+    try:
+        ref = rs.load_uniform_level(os.path.join(workr, "output_00002"), level)
+    finally:
+        shutil.rmtree(workr, ignore_errors=True)
+    for ov in overlaps:
+        workp, outp, tp = _run(nml, PATCHED_MPI, 8, {"RAMSES_AMD": "1", "RAMSES_AMD_OVERLAP": ov})
+        try:
+            assert "stays resident on the GPUs" in outp, outp[-2000:]
+            assert ("halo exchange over RCCL" in outp) or ("staged through host MPI" in outp)
+            got = rs.load_uniform_level(os.path.join(workp, "output_00002"), level)
+        finally:
+            shutil.rmtree(workp, ignore_errors=True)
+        print("level %d, %d steps: reference on %d ranks %.1f s, patched on 8 ranks (overlap %s) %.1f s" % (level, nstep, nref, tr, ov, tp))
+        assert got["info"]["t"] == ref["info"]["t"]
+        assert got["info"]["nstep"] == ref["info"]["nstep"] == nstep
+        same = np.array_equal(got["prim"].view(np.int64), ref["prim"].view(np.int64))     # bit patterns (signed zeros too)
+        assert same, "overlap %s: max |diff| %g" % (ov, np.abs(got["prim"] - ref["prim"]).max())
+        del got
+
+
+def test_c3_half_size_256_on_8_ranks_overlap_on_and_off(gpu_lib):
+    """256^3 on 8 ranks (128^3 bricks), nstepmax=10 as shipped, both schedules of the exchange."""
+    _need(REF_MPI, PATCHED_MPI)
+    _uniform_ab(8, 10, _pow2_ranks(32), ("1", "0"))
+
+
+def test_c3_as_stated_512_on_8_ranks(gpu_lib):
+    """BASELINE config C3: 512^3, 8 ranks, 256^3 bricks per rank."""
+    _need(REF_MPI, PATCHED_MPI)
+    if os.environ.get("RAMSES_AMD_SKIP_C3_512") == "1":
+        pytest.skip("RAMSES_AMD_SKIP_C3_512=1")
+    if _ram_gb() < 110.0:
+        pytest.skip("config C3 as stated needs ~25 GB of host arrays per program plus ~11 GB per assembled snapshot; "
+                    "this box offers %.0f GB: the 256^3 run (128^3 bricks) above is the largest that fits" % _ram_gb())
+    if _cores() < 32:
+        pytest.skip("the MPI reference at 512^3 takes too long on %d cores; the 256^3 run above stays" % _cores())
+    _uniform_ab(9, 2, _pow2_ranks(64), ("1",))
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_c4_as_stated_256_serial_checksum_and_live_mpi_reference(gpu_lib):
+    """BASELINE config C4: uniform 256^3 hydro + self-gravity on one MI355X, three coarse steps."""
+    _need(REF_MPI, PATCHED)
+    from oracle import ramses_snapshot as rs
+    mkb = _mkb()
+    gold = json.load(open(GOLD)).get("c4_256") if os.path.exists(GOLD) else None
+    nml = mkb.c4_namelist(level=8)
+    workp, outp, tp = _run(nml, PATCHED, 1, {"RAMSES_AMD": "1"})
+    try:
+        assert "stays resident on the GPU" in outp
+        got = rs.load_uniform_level(os.path.join(workp, "output_00002"), 8, with_grav=True)
+        got_solves = mkb.solves(outp)
+    finally:
+        shutil.rmtree(workp, ignore_errors=True)
+    assert len(got_solves) >= 3 and all(lv == 8 for lv, _ in got_solves)
+    if gold is not None:
+        # the serial reference, bit for bit
+        assert got_solves == gold["solves"]
+        assert got["info"]["t"] == gold["t"] and got["info"]["rho_tot"] == gold["rho_tot"]
+        assert mkb.digest_uniform(got) == gold["sha256"]
+    # the MPI reference, live: another summation order of the multipoles and norms -> rounding-level differences
+    nref = _pow2_ranks(32)
+    nml_mpi = nml.replace("ngridtot=", "ngridtot=%d !" % (3 * sum(8 ** l for l in range(8)) + 1000))
+    workr, outr, tr = _run(nml_mpi, REF_MPI, nref, {"RAMSES_AMD": "0"})
+    try:
+        ref = rs.load_uniform_level(os.path.join(workr, "output_00002"), 8, with_grav=True)
+        ref_solves = mkb.solves(outr)
+    finally:
+        shutil.rmtree(workr, ignore_errors=True)
+    print("C4 256^3: patched %.1f s, MPI reference on %d ranks %.1f s; V-cycles %s" % (tp, nref, tr, got_solves))
+    assert got_solves == ref_solves
+    assert abs(got["info"]["t"] - ref["info"]["t"]) <= TOL * ref["info"]["t"]
+    errs = {"rho": _rel(got["prim"][0], ref["prim"][0]), "vel": _rel(got["prim"][1:4], ref["prim"][1:4]),
+            "P": _rel(got["prim"][4], ref["prim"][4]), "phi": _rel(got["grav"][0], ref["grav"][0]),
+            "f": _rel(got["grav"][1:4], ref["grav"][1:4])}
+    print("C4 256^3 vs the MPI reference, rel-Linf:", errs)
+    assert max(errs.values()) <= TOL, errs
+    if gold is None:
+        pytest.fail("tests/golden/baseline_sizes.json has no c4_256 entry: the bit-exact half of this test did not run")
