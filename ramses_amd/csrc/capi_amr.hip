@@ -523,6 +523,7 @@ int ramses_amd_amrres_load(int nvar, int64_t ngridmax, int64_t ncoarse, const do
   if (nvar < 5 || nvar > 7 || ngridmax < 1 || ncoarse < 1) return failf(RAMSES_AMD_EUNSUPPORTED, "AMR residency implements NVAR=5..7");
   AmrRes &R = g_ar;
   R.valid = false; R.grav = false; R.pfix = false;
+  R.xg_valid = false;          // the oct centres belong to the tree that is loaded below: rho_fine's shim sends them again
   R.nvar = nvar; R.ngridmax = ngridmax; R.ncoarse = ncoarse; R.ncell = ncoarse + 8 * ngridmax;
   R.h_uold = uold;
   const size_t vb = sizeof(double) * (size_t)nvar * (size_t)R.ncell;

@@ -1353,6 +1353,8 @@ contains
     if (ramses_amd_amrres_active() == 0) then
        rc = ramses_amd_amrres_load(nvar, int(ngridmax, 8), int(ncoarse, 8), uold, son, nbor, father)
        if (rc /= 0) call ramses_amd_fatal('AMR residency (load)')
+       ! whatever is cached per tree epoch on the device (rho_fine's oct centres) went with the old image
+       ramses_amd_tree_epoch = ramses_amd_tree_epoch + 1
        if (pressure_fix) then
           rc = ramses_amd_amrres_enable_pfix()
           if (rc /= 0) call ramses_amd_fatal('AMR residency (pressure_fix)')

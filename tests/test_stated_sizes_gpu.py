@@ -11,8 +11,9 @@ weak #2: the largest MPI run compared so far was 128^3 on 8 ranks, i.e. 64^3 bri
    cannot hold it.
  * C4 AS STATED: hydro + self-gravity at 256^3 (rho_fine, multigrid_fine, force_fine, the gravity terms; level resident):
    bit for bit against the checksum of the SERIAL reference (tests/golden/baseline_sizes.json "c4_256", made by
-   tests/golden/make_golden_baseline.py), and live against the MPI reference: same V-cycle counts, prim / phi / f within
-   north_star's 1e-12 (an MPI run adds its density multipoles and residual norms in another order than a serial one, so the
+   tests/golden/make_golden_baseline.py), and live against the MPI reference: same V-cycle counts, prim / f / phi minus
+   its mean within north_star's 1e-12; the constant mode of a periodic potential is not pinned by the reference's smoother and
+   differs between the reference's own serial and MPI runs at 1e-9 (an MPI run adds its density multipoles and residual norms in another order than a serial one, so the
    two REFERENCE runs differ from each other in the last bits; the serial one is the bit-exact oracle).
 
 All ranks share the box's one GPU (host-MPI transport; the run says so); the RCCL entry points themselves are executed by
@@ -107,7 +108,7 @@ def _uniform_ab(level, nstep, nref, overlaps):
             shutil.rmtree(workp, ignore_errors=True)
         print("level %d, %d steps: reference on %d ranks %.1f s, patched on 8 ranks (overlap %s) %.1f s" % (level, nstep, nref, tr, ov, tp))
         assert got["info"]["t"] == ref["info"]["t"]
-        assert got["info"]["nstep"] == ref["info"]["nstep"] == nstep
+        assert int(np.ravel(got["info"]["nstep"])[0]) == int(np.ravel(ref["info"]["nstep"])[0]) == nstep
         same = np.array_equal(got["prim"].view(np.int64), ref["prim"].view(np.int64))     # bit patterns (signed zeros too)
         assert same, "overlap %s: max |diff| %g" % (ov, np.abs(got["prim"] - ref["prim"]).max())
         del got
@@ -168,10 +169,20 @@ def test_c4_as_stated_256_serial_checksum_and_live_mpi_reference(gpu_lib):
     print("C4 256^3: patched %.1f s, MPI reference on %d ranks %.1f s; V-cycles %s" % (tp, nref, tr, got_solves))
     assert got_solves == ref_solves
     assert abs(got["info"]["t"] - ref["info"]["t"]) <= TOL * ref["info"]["t"]
+    # The potential of a periodic box is defined up to a constant, and the reference's smoother does not pin it: the
+    # rounding-level difference in rho_tot between a serial and an MPI run of the REFERENCE (another summation order of the
+    # multipoles) leaves a uniform right-hand-side residue that every Gauss-Seidel pass integrates into phi's mean
+    # (measured on the GPU box: serial vs 32-rank reference differ by 8.5e-10 of max|phi| in that one mode, f by 3e-14).
+    # The constant mode is compared separately (bounded, not a tolerance claim); phi minus its mean, f and the hydro
+    # state are held to north_star's 1e-12.
+    dphi = got["grav"][0] - ref["grav"][0]
+    offset = dphi.mean()
+    scale_phi = max(np.abs(ref["grav"][0]).max(), 1e-300)
     errs = {"rho": _rel(got["prim"][0], ref["prim"][0]), "vel": _rel(got["prim"][1:4], ref["prim"][1:4]),
-            "P": _rel(got["prim"][4], ref["prim"][4]), "phi": _rel(got["grav"][0], ref["grav"][0]),
+            "P": _rel(got["prim"][4], ref["prim"][4]), "phi - mean": np.abs(dphi - offset).max() / scale_phi,
             "f": _rel(got["grav"][1:4], ref["grav"][1:4])}
-    print("C4 256^3 vs the MPI reference, rel-Linf:", errs)
+    print("C4 256^3 vs the MPI reference, rel-Linf:", errs, "; constant mode of phi:", offset / scale_phi)
     assert max(errs.values()) <= TOL, errs
+    assert abs(offset) / scale_phi <= 1e-7, offset / scale_phi
     if gold is None:
         pytest.fail("tests/golden/baseline_sizes.json has no c4_256 entry: the bit-exact half of this test did not run")
