@@ -706,6 +706,7 @@ module ramses_amd_iface
   ! stands in for active(l)%igrid where a rank holds no oct of a level (see ramses_amd_octs)
   integer, target, save :: ramses_amd_no_octs(1) = 0
   logical, save :: ramses_amd_checked = .false.
+  logical, save :: ramses_amd_arith_said = .false.
   logical, save :: ramses_amd_on = .true.
   ! AMR multigrid: the reference driver is running with the device routines (set by the
   ! multigrid_fine shim); the level arrays have been handed to the device (first routine call)
@@ -1588,6 +1589,7 @@ contains
   !---------------------------------------------------------------------------
   subroutine ramses_amd_fill_hydro_params(p)
     use amr_parameters, only: ndim
+    use amr_commons, only: myid
     use hydro_parameters
     type(ramses_amd_hydro_params), intent(out) :: p
     character(len=16) :: val
@@ -1617,11 +1619,30 @@ contains
     p%niter_riemann = niter_riemann
     p%difmag = difmag
     p%courant_factor = courant_factor
-    ! strict arithmetic (bit-identical to the reference) unless RAMSES_AMD_FAST=1
-    p%fast_math = 0
+    ! Arithmetic of the dense brick sweep.  DEFAULT = the fast build (written-out FMAs, v_rcp_f64 / v_rsq_f64 + Newton):
+    ! certified against the reference program within north_star's 1e-12 relative L-infinity at config C2's size over 100
+    ! coarse steps with a developed blast wave (tests/test_fast_certificate_gpu.py).  RAMSES_AMD_STRICT=1 (or
+    ! RAMSES_AMD_FAST=0) selects the verification mode: the reference's operation order, bit-identical snapshots.
+    ! Every other kernel (tree-walking sweep, multigrid, CG, rho_fine, exchanges) is strict in both modes.
+    p%fast_math = 1
+    call get_environment_variable('RAMSES_AMD_STRICT', val, status=stat)
+    if (stat == 0) then
+       if (trim(val) == '1') p%fast_math = 0
+    end if
     call get_environment_variable('RAMSES_AMD_FAST', val, status=stat)
     if (stat == 0) then
+       if (trim(val) == '0') p%fast_math = 0
        if (trim(val) == '1') p%fast_math = 1
+    end if
+    if (.not. ramses_amd_arith_said) then
+       ramses_amd_arith_said = .true.
+       if (myid == 1) then
+          if (p%fast_math == 1) then
+             write(*,*) 'ramses_amd: dense sweep arithmetic = fast (<= 1e-12 of the reference; RAMSES_AMD_STRICT=1: bit-identical)'
+          else
+             write(*,*) 'ramses_amd: dense sweep arithmetic = strict (bit-identical to the reference)'
+          end if
+       end if
     end if
     p%reserved = 0
   end subroutine ramses_amd_fill_hydro_params

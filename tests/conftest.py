@@ -8,6 +8,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The patched program's DEFAULT dense-sweep arithmetic is the fast build (certified against the reference program to
+# north_star's 1e-12 by tests/test_fast_certificate_gpu.py, which removes this variable).  Every other test compares
+# snapshots BIT FOR BIT with the reference, which is what the verification mode is for.
+os.environ.setdefault("RAMSES_AMD_STRICT", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -1,0 +1,107 @@
+"""Certificate of the drop-in's DEFAULT arithmetic.
+
+The patched program runs the FAST build of the dense sweep unless RAMSES_AMD_STRICT=1 (ramses_amd_fill_hydro_params,
+ramses_amd/patch/ramses_amd_iface.f90).  The fast build is held to north_star's tolerance -- 1e-12 relative L-infinity
+per snapshot variable -- against the REFERENCE PROGRAM, not against the strict build:
+
+ 1. config C2's size, developed shock: sedov3d.nml at 256^3 over 100 coarse steps (the blast is ~45 cells wide, density
+    between 0.036 and 2.27: limiter and floor branches warm).  The reference's run is kept as a golden
+    (tests/golden/fast_cert_256_100.npz from tests/golden/make_golden_fast_cert.py: sha256 of the whole primitive
+    state, max |value| per variable, three full planes through the blast).  STRICT mode must reproduce the sha256 bit
+    for bit; the DEFAULT mode (no environment variable) must say it is fast and agree with the planes to 1e-12.
+ 2. live A/B on the GPU box at 128^3: the unmodified MPI reference vs the patched program in its default mode over 120
+    steps (LLF + minmod) and 60 steps (HLLC + moncen), the whole level compared.
+"""
+import hashlib
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_MPI = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi")
+PATCHED = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch")
+GOLD = os.path.join(ROOT, "tests", "golden", "fast_cert_256_100.npz")
+TOL = 1e-12     # north_star: "results within 1e-12 relative L-infinity of the F90 reference"
+
+
+def _nproc():
+    n = os.cpu_count() or 1
+    p = 1
+    while p * 2 <= min(n, 32):
+        p *= 2
+    return p
+
+
+def _run_patched(nml, level, mode, monkeypatch):
+    from oracle import ramses_snapshot as rs
+    monkeypatch.setenv("RAMSES_AMD", "1")
+    monkeypatch.delenv("RAMSES_AMD_FAST", raising=False)
+    if mode == "strict":
+        monkeypatch.setenv("RAMSES_AMD_STRICT", "1")
+    else:
+        monkeypatch.delenv("RAMSES_AMD_STRICT", raising=False)      # the default of a user's run
+    work, out = rs.run_reference(nml, binary=PATCHED)
+    try:
+        assert "stays resident on the GPU" in out
+        assert ("dense sweep arithmetic = " + mode) in out, out[-1500:]
+        return rs.load_uniform_level(os.path.join(work, "output_00002"), level)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def _rel(got, ref, vmax):
+    """rel-Linf per snapshot variable (rho, u, v, w, P); the three velocities share one scale"""
+    scale = np.array(vmax, float).copy()
+    scale[1:4] = scale[1:4].max()
+    d = np.abs(got - ref).reshape(got.shape[0], -1).max(axis=1)
+    return d / np.maximum(scale, 1e-300)
+
+
+def test_default_mode_at_256_over_100_steps_against_the_reference_golden(gpu_lib, monkeypatch):
+    if not os.path.exists(PATCHED) or not os.path.exists(GOLD):
+        pytest.skip("patched program or golden missing")
+    from oracle import ramses_snapshot as rs
+    z = np.load(GOLD)
+    nstep = int(z["nstep"])
+    nml = rs.sedov3d_namelist(level=8, nstepmax=nstep, foutput=nstep, mem_factor=1.3)
+    # verification mode: the reference's bits
+    got = _run_patched(nml, 8, "strict", monkeypatch)
+    assert int(np.ravel(got["info"]["nstep"])[0]) == nstep
+    assert float(np.ravel(got["info"]["t"])[0]) == float(z["t"])
+    assert hashlib.sha256(np.ascontiguousarray(got["prim"]).tobytes()).hexdigest() == str(z["sha256"])
+    del got
+    # default mode: fast, within north_star's tolerance of the reference
+    got = _run_patched(nml, 8, "fast", monkeypatch)
+    assert int(np.ravel(got["info"]["nstep"])[0]) == nstep
+    t = float(np.ravel(got["info"]["t"])[0])
+    assert abs(t - float(z["t"])) <= TOL * float(z["t"])
+    planes = got["prim"][:, [int(k) for k in z["plane_k"]], :, :]
+    err = _rel(planes, z["planes"], z["vmax"])
+    print("default (fast) vs the reference, 256^3, %d steps: rel-Linf (rho, u, v, w, P) = %s" % (nstep, err))
+    assert (err <= TOL).all(), err
+
+
+@pytest.mark.parametrize("riemann,slope_type,nstep", [("llf", 1, 120), ("hllc", 2, 60)])
+def test_default_mode_live_ab_at_128(gpu_lib, monkeypatch, riemann, slope_type, nstep):
+    if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED)):
+        pytest.skip("oracle/_ref/ramses3d_mpi / ramses3d_patch not built")
+    from oracle import ramses_snapshot as rs
+    nproc = _nproc()
+    kw = dict(level=7, nstepmax=nstep, foutput=nstep, riemann=riemann, slope_type=slope_type)
+    got = _run_patched(rs.sedov3d_namelist(mem_factor=1.3, **kw), 7, "fast", monkeypatch)
+    monkeypatch.setenv("RAMSES_AMD", "0")
+    workr, outr = rs.run_reference(rs.sedov3d_namelist(mem_factor=3.0 if nproc > 1 else 1.3, **kw), binary=REF_MPI, nproc=nproc)
+    try:
+        ref = rs.load_uniform_level(os.path.join(workr, "output_00002"), 7)
+    finally:
+        shutil.rmtree(workr, ignore_errors=True)
+    assert int(np.ravel(got["info"]["nstep"])[0]) == int(np.ravel(ref["info"]["nstep"])[0]) == nstep
+    tr = float(np.ravel(ref["info"]["t"])[0])
+    assert abs(float(np.ravel(got["info"]["t"])[0]) - tr) <= TOL * tr
+    vmax = np.abs(ref["prim"]).reshape(ref["prim"].shape[0], -1).max(axis=1)
+    err = _rel(got["prim"], ref["prim"], vmax)
+    print("default (fast) vs the live MPI reference, 128^3, %s slope %d, %d steps: rel-Linf = %s" % (riemann, slope_type, nstep, err))
+    assert (err <= TOL).all(), err
