@@ -246,35 +246,56 @@ def vcycle_bench_dist(level_local, pgrid, rank, world, transport=None):
 BYTES_PER_CELL_UPDATE_AMR = 84   # 80 B + 4 B of `son` per cell on AMR levels
 
 
-def amr_sweep_bench(level=8, steps=5):
+def amr_sweep_bench(level=8, steps=5, partial=False):
     """The other sweep kernel of the path, for the record: godunov_fine of an AMR level through the tree-walking sweep
-    (csrc/amr_sweep.hip: the level's octs in the reference's own cell vectors and tree arrays son/nbor/father) on a
-    synthetic fully refined 2^level^3 tree whose octs are numbered along a Z-order curve (what refine_fine produces);
-    strict arithmetic.  One call = group build + father-cell walk + oct-record pack + sweep + coarse corrections."""
+    (csrc/amr_sweep.hip: the level's octs in the reference's own cell vectors and tree arrays son/nbor/father); strict
+    arithmetic.  One call = group build + (father-cell walk | oct records of primitive variables) + sweep + coarse
+    corrections.  Two trees, octs numbered along a Z-order curve (what refine_fine produces):
+      partial=False  a fully refined 2^level^3 level (the best case of the father-oct grouping);
+      partial=True   level-1 fully refined and `level` present only in a spherical shell (where a blast wave refines):
+                     a third of the father octs have fewer than 8 sons, the shell's two surfaces interpolate their ghost
+                     octs from level-1, every oct on a surface owes fluxes to coarse cells."""
     import numpy as np
     import torch
     import ramses_amd
     from ramses_amd import ic
     from ramses_amd._capi import check, lib
     n = 2 ** level
-    T = ic.uniform_tree(level, order="morton")
+    if partial:
+        nc = n // 2
+        z, y, x = np.meshgrid(np.arange(nc), np.arange(nc), np.arange(nc), indexing="ij")
+        r = np.sqrt((x - nc / 2 + 0.5) ** 2 + (y - nc / 2 + 0.5) ** 2 + (z - nc / 2 + 0.5) ** 2)
+        mask = (r >= 0.23 * nc) & (r <= 0.36 * nc)
+        T = ic.uniform_tree(level - 1, order="morton", refine_mask=mask)
+        igrid = T["igrid_fine"]
+        # father octs (level-1 octs) by their number of sons
+        fz, fy, fx = np.nonzero(mask)
+        key = ((fz >> 1) * (nc // 2) + (fy >> 1)) * (nc // 2) + (fx >> 1)
+        sons = np.bincount(key)
+        sons = sons[sons > 0]
+        census = {"father_octs": int(sons.size), "with_fewer_than_8_sons": int((sons < 8).sum())}
+    else:
+        T = ic.uniform_tree(level, order="morton")
+        igrid = T["igrid"]
+        census = None
+    ncells = 8 * len(igrid)
     dx = 0.5 / n
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
     # sedov3d.nml's state built on the device in the tree's cell vectors: rho = 1, P = 1e-5, the blast energy in one cell
     d_uold = torch.zeros((5, T["ncell"]), dtype=torch.float64, device="cuda")
     d_uold[0].fill_(1.0)
     d_uold[4].fill_(1e-5 / 0.4)
-    d_uold[4, T["ncoarse"] + int(T["igrid"][0]) - 1] = (1e-5 + 0.4 * 0.125 / dx ** 3) / 0.4
+    d_uold[4, T["ncoarse"] + int(igrid[0]) - 1] = (1e-5 + 0.4 * 0.125 / dx ** 3) / 0.4
     d_unew = d_uold.clone()
-    d_son, d_nbor, d_father, d_igrid = dev(T["son"]), dev(T["nbor"]), dev(T["father"]), dev(T["igrid"])
-    nw = lib().ramses_amd_godunov_fine_amr_workspace(len(T["igrid"]), T["ngridmax"])
+    d_son, d_nbor, d_father, d_igrid = dev(T["son"]), dev(T["nbor"]), dev(T["father"]), dev(igrid)
+    nw = lib().ramses_amd_godunov_fine_amr_workspace(len(igrid), T["ngridmax"])
     d_work = torch.zeros(int(nw), dtype=torch.uint8, device="cuda")
     d_err = torch.zeros(1, dtype=torch.int32, device="cuda")
     p = ramses_amd.make_params(courant_factor=0.8)
     ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 
     def run():
-        check(lib().ramses_amd_godunov_fine_amr_device(C.byref(p), level, len(T["igrid"]), ptr(d_igrid), ptr(d_son), ptr(d_nbor),
+        check(lib().ramses_amd_godunov_fine_amr_device(C.byref(p), level, len(igrid), ptr(d_igrid), ptr(d_son), ptr(d_nbor),
                                                        ptr(d_father), T["ngridmax"], T["ncoarse"], ptr(d_uold), ptr(d_unew),
                                                        None, None, None, dx, 1e-6, 32, 0, 1, ptr(d_work), ptr(d_err),
                                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
@@ -288,13 +309,18 @@ def amr_sweep_bench(level=8, steps=5):
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / steps
-    gbs = n ** 3 * BYTES_PER_CELL_UPDATE_AMR / (ms * 1e-3) / 1e9
-    return {"metric": "cell-updates/s (godunov_fine of an AMR level, tree-walking sweep)", "value": n ** 3 / (ms * 1e-3),
-            "unit": "cell-updates/s", "ms_per_sweep": ms, "arithmetic": "strict (bit-identical to the reference)",
-            "workload": "fully refined synthetic %d^3 tree in the reference's cell-vector layout, Z-order oct numbering" % n,
-            "tree_errors": int(d_err.item()),
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "bytes_per_cell": BYTES_PER_CELL_UPDATE_AMR}}
+    gbs = ncells * BYTES_PER_CELL_UPDATE_AMR / (ms * 1e-3) / 1e9
+    out = {"metric": "cell-updates/s (godunov_fine of an AMR level, tree-walking sweep)", "value": ncells / (ms * 1e-3),
+           "unit": "cell-updates/s", "ms_per_sweep": ms, "cells": ncells, "arithmetic": "strict (bit-identical to the reference)",
+           "workload": ("level %d in a spherical shell over a fully refined level %d" % (level, level - 1)) if partial else
+                       ("fully refined synthetic %d^3 tree" % n),
+           "layout": "the reference's cell vectors and tree arrays, Z-order oct numbering",
+           "tree_errors": int(d_err.item()),
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "bytes_per_cell": BYTES_PER_CELL_UPDATE_AMR}}
+    if census:
+        out["census"] = census
+    return out
 
 
 def pick_transport(rank, world, timeout):
@@ -581,6 +607,7 @@ def main():
             try:
                 torch.cuda.empty_cache()
                 out["amr_sweep"] = amr_sweep_bench(args.amr_level)
+                out["amr_sweep_partial"] = amr_sweep_bench(args.amr_level + 1, partial=True)
             except Exception as exc:     # noqa: BLE001  (an extra line, never a reason to lose the headline)
                 out["amr_sweep"] = {"value": None, "error": str(exc)[:300]}
         if world == 1 and not args.no_cpu_baseline:

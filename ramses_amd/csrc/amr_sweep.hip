@@ -358,8 +358,23 @@ constexpr int GRP_THREADS = 256;
 // 3.44 ms, 5 (96 VGPRs, 144 spilled to scratch) 3.08 ms, 6 3.37 ms, 7 3.10 ms per sweep
 // (tried and dropped: unew of the updated cells fetched by the idle fourth wavefront behind the gather and parked in LDS --
 // 3.02 -> 3.30 ms, the extra live registers spill)
-constexpr int GRP_MINWAVES = 5;
+#ifndef RAMSES_AMD_GRP_MINWAVES
+#define RAMSES_AMD_GRP_MINWAVES 5
+#endif
+constexpr int GRP_MINWAVES = RAMSES_AMD_GRP_MINWAVES;
+#ifndef RAMSES_AMD_GRP_XCD
+#define RAMSES_AMD_GRP_XCD 1
+#endif
 
+// z stride of the 8^3 stencil in LDS.  With 64 the 4 x 4 x 4 inner cells a wave traces sit on x + 8j (mod 32 doubles = the
+// 64 four-byte banks) whatever their plane: 16 bank pairs for 64 lanes, every stencil read a 4-way conflict
+// (profiles/r03_amr_sweep_pmc.txt: 4.0e8 conflict cycles of 7.3e8 LDS-active ones).  68 puts plane k on x + 8j + 4k: each
+// bank pair twice, the minimum for 64 eight-byte lanes.
+#ifndef RAMSES_AMD_GRP_ZS
+#define RAMSES_AMD_GRP_ZS 68
+#endif
+constexpr int GRP_ZS = RAMSES_AMD_GRP_ZS;
+constexpr int GRP_STENCIL = 7 * GRP_ZS + 64;
 // LDS layout of the stencil and the face arrays: variable-major (consecutive lanes touch consecutive doubles of one
 // variable; cell-major, the NV values of a cell together, measured the same: 3.795 vs 3.778 ms)
 template <int NV>
@@ -377,7 +392,7 @@ struct GrpTmp<false> {};
 template <int NV, bool PFIX>
 struct GrpLds : GrpTmp<PFIX> {
   union {
-    double u[NV][512];     // primitive variables of the 8^3 stencil (until the traces are done)
+    double u[NV][GRP_STENCIL]; // primitive variables of the 8^3 stencil (until the traces are done)
     GrpFaces<NV> f;
   };
   // tab[0..63]    fc: the 4^3 father cells (1-based cell index, 0: not there)
@@ -385,17 +400,66 @@ struct GrpLds : GrpTmp<PFIX> {
   // tab[128..191] px: position of the son oct of each father cell in the call's list (-1: none / not in the list)
   int tab[192];
   int io[8];               // position of each son of the father oct in the call's list (-1: not active)
-  unsigned char ok[512];   // cell is refined
+  unsigned char ok[GRP_STENCIL];   // cell is refined
 };
-__device__ __forceinline__ int gsidx(int i, int j, int k) { return i + 8 * (j + 8 * k); }
+__device__ __forceinline__ int gsidx(int i, int j, int k) { return i + 8 * j + GRP_ZS * k; }
 __device__ __forceinline__ int gface(int a, int b, int c) { return a * 16 + b + 4 * c; }
+
+// Stencil cells of a father cell c0 that has no son oct (thread t of the 4^3 father cells): interpol_hydro of the father
+// cell with its 2*ndim neighbours (hydro/interpol_hydro.f90:268-444, getnborfather's coarser fallback), then ctoprim.
+// u = the stencil [NV][GRP_STENCIL] in LDS.
+template <int NV, bool GRAV>
+__device__ __forceinline__ void grp_fill_missing(const AmrSweepArgs &A, int c0, int t, double *__restrict__ u,
+                                                          unsigned char *__restrict__ ok) {
+  const HydroConst &P = A.P;
+  const long ncell = A.ncell;
+  const int i0 = 2 * (t & 3), j0 = 2 * ((t >> 2) & 3), k0 = 2 * (t >> 4);
+  if (c0 > 0) {
+    double u1[7][NV], u2[8][NV];
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      int c = c0;
+      if (j > 0) {
+        c = nbor_cell(c0, j - 1, A);
+        if (c < 0) c = -c;
+      }
+#pragma unroll
+      for (int v = 0; v < NV; v++) u1[j][v] = A.uold[(long)v * ncell + c - 1];
+    }
+    interpol_hydro_cell<NV>(u1, u2, A.interpol_var, A.interpol_type, P.smallr);
+    double gz[3] = {0.0, 0.0, 0.0};
+    if (GRAV) {
+#pragma unroll
+      for (int d = 0; d < 3; d++) gz[d] = A.grav[(long)d * ncell + c0 - 1];
+    }
+#pragma unroll
+    for (int ind = 0; ind < 8; ind++) {
+      const int s = gsidx(i0 + (ind & 1), j0 + ((ind >> 1) & 1), k0 + (ind >> 2));
+      double q[NV];
+      ctoprim_cell<NV, GRAV>(u2[ind], gz, A.dt * 0.5, P, q);
+#pragma unroll
+      for (int v = 0; v < NV; v++) u[v * GRP_STENCIL + s] = q[v];
+      ok[s] = 0;
+    }
+  } else {
+    // no father cell: nothing that is stored depends on these cells; keep them finite
+#pragma unroll
+    for (int ind = 0; ind < 8; ind++) {
+      const int s = gsidx(i0 + (ind & 1), j0 + ((ind >> 1) & 1), k0 + (ind >> 2));
+#pragma unroll
+      for (int v = 0; v < NV; v++) u[v * GRP_STENCIL + s] = 1.0;
+      ok[s] = 0;
+    }
+  }
+}
+
 
 // The walk of every group in a pass of its own (one thread per father cell, nothing but dependent loads: the
 // latency hides behind thousands of waves here, not behind the four groups a CU holds in the sweep kernel):
 // walk[g*192 + t] = father cell, [+64] its son oct, [+128] the son's position in the call's list
-__global__ __launch_bounds__(256) void amr_group_walk_kernel(AmrSweepArgs A, const int *__restrict__ groups, int ngroups,
-                                                             const int *__restrict__ posof, int *__restrict__ walk) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void group_walk_block(const AmrSweepArgs &A, int block, const int *__restrict__ groups, int ngroups,
+                                                 const int *__restrict__ posof, int *__restrict__ walk) {
+  const long e = (long)block * 256 + threadIdx.x;
   if (e >= (long)ngroups * 64) return;
   const int g = (int)(e >> 6), t = (int)(e & 63);
   const int c = group_father_cell(A, groups[g], t);
@@ -405,6 +469,10 @@ __global__ __launch_bounds__(256) void amr_group_walk_kernel(AmrSweepArgs A, con
   w[64 + t] = og;
   w[128 + t] = og > 0 ? posof[og - 1] : -1;
 }
+__global__ __launch_bounds__(256) void amr_group_walk_kernel(AmrSweepArgs A, const int *__restrict__ groups, int ngroups,
+                                                             const int *__restrict__ posof, int *__restrict__ walk) {
+  group_walk_block(A, blockIdx.x, groups, ngroups, posof, walk);
+}
 
 template <int ST, int RS, bool GRAV, int NV, int SCHEME, bool PFIX>
 __global__ __launch_bounds__(GRP_THREADS, GRP_MINWAVES) void amr_group_kernel(AmrSweepArgs A, const int *__restrict__ groups,
@@ -412,13 +480,24 @@ __global__ __launch_bounds__(GRP_THREADS, GRP_MINWAVES) void amr_group_kernel(Am
   __shared__ GrpLds<NV, PFIX> L;
   const int t = threadIdx.x;
   const HydroConst &P = A.P;
-  const int gF = groups[blockIdx.x];          // the father oct (level l-1)
+  // Workgroup b runs on XCD b % 8 (each with its own L2).  Neighbouring father octs read the same ghost octs: give every
+  // XCD a contiguous run of the list (on a tree numbered along a Z-order curve: one octant of the level), so that those
+  // re-reads hit its L2 (profiles/r03_amr_sweep_pmc.txt: 9.0 GB fetched per sweep with the round-robin order = every
+  // record from HBM by every group that reads it).
+  int bid = blockIdx.x;
+#if RAMSES_AMD_GRP_XCD
+  {
+    const int nblk = gridDim.x, per = nblk >> 3, rem = nblk & 7, x = bid & 7;
+    bid = x * per + (x < rem ? x : rem) + (bid >> 3);
+  }
+#endif
+  const int gF = groups[bid];                 // the father oct (level l-1)
   const long ncell = A.ncell;
 
   // ---- (A) the 4^3 father cells around the father oct --------------------------------
   if (walk) {
     // the pre-pass has walked: one coalesced 768-byte read (fc, ex, px are contiguous)
-    if (t < 192) L.tab[t] = walk[(long)blockIdx.x * 192 + t];
+    if (t < 192) L.tab[t] = walk[(long)bid * 192 + t];
   } else if (t < 64) {
     const int c = group_father_cell(A, gF, t);
     L.tab[t] = c;
@@ -444,14 +523,12 @@ __global__ __launch_bounds__(GRP_THREADS, GRP_MINWAVES) void amr_group_kernel(Am
       bool refined;
       const int px = L.tab[128 + f];
       if (packed && px >= 0) {
+        // the record holds the cell's primitive variables (ctoprim ran once per cell in amr_pack_kernel)
         const double *__restrict__ r = A.packed + (long)px * A.rec;
 #pragma unroll
-        for (int v = 0; v < NV; v++) u[v] = r[v * 8 + ind];
-        if (GRAV) {
-#pragma unroll
-          for (int d = 0; d < 3; d++) gz[d] = r[(NV + d) * 8 + ind];
-        }
-        refined = reinterpret_cast<const int *>(r + 8 * (NV + (GRAV ? 3 : 0)))[ind] != 0;
+        for (int v = 0; v < NV; v++) L.GU(s, v) = r[v * 8 + ind];
+        L.ok[s] = reinterpret_cast<const int *>(r + 8 * NV)[ind] != 0;
+        continue;
       } else {
         const long cell = A.ncoarse + (long)ind * A.ngridmax + og;   // 1-based
 #pragma unroll
@@ -468,48 +545,11 @@ __global__ __launch_bounds__(GRP_THREADS, GRP_MINWAVES) void amr_group_kernel(Am
       L.ok[s] = refined;
     }
   }
-  if (t < 64 && L.tab[64 + t] == 0) {
-    const int c0 = L.tab[t];
-    const int i0 = 2 * (t & 3), j0 = 2 * ((t >> 2) & 3), k0 = 2 * (t >> 4);
-    if (c0 > 0) {
-      // missing oct: interpolate the father cell with its 2*ndim neighbours
-      double u1[7][NV], u2[8][NV];
-#pragma unroll
-      for (int j = 0; j < 7; j++) {
-        int c = c0;
-        if (j > 0) {
-          c = nbor_cell(c0, j - 1, A);
-          if (c < 0) c = -c;
-        }
-#pragma unroll
-        for (int v = 0; v < NV; v++) u1[j][v] = A.uold[(long)v * ncell + c - 1];
-      }
-      interpol_hydro_cell<NV>(u1, u2, A.interpol_var, A.interpol_type, P.smallr);
-      double gz[3] = {0.0, 0.0, 0.0};
-      if (GRAV) {
-#pragma unroll
-        for (int d = 0; d < 3; d++) gz[d] = A.grav[(long)d * ncell + c0 - 1];
-      }
-#pragma unroll
-      for (int ind = 0; ind < 8; ind++) {
-        const int s = gsidx(i0 + (ind & 1), j0 + ((ind >> 1) & 1), k0 + (ind >> 2));
-        double q[NV];
-        ctoprim_cell<NV, GRAV>(u2[ind], gz, dtxhalf, P, q);
-#pragma unroll
-        for (int v = 0; v < NV; v++) L.GU(s, v) = q[v];
-        L.ok[s] = 0;
-      }
-    } else {
-      // no father cell: nothing that is stored depends on these cells; keep them finite
-#pragma unroll
-      for (int ind = 0; ind < 8; ind++) {
-        const int s = gsidx(i0 + (ind & 1), j0 + ((ind >> 1) & 1), k0 + (ind >> 2));
-#pragma unroll
-        for (int v = 0; v < NV; v++) L.GU(s, v) = 1.0;
-        L.ok[s] = 0;
-      }
-    }
-  }
+  // father cells without a son oct (a level's edge): interpolated from the father level.  (The 75 doubles of
+  // interpol_hydro's stencil cost the kernel 136 spilled registers; without the branch it runs 5 % faster, 2.33 vs 2.46 ms
+  // on the 256^3 tree -- and as a call to a function of its own 3.4x SLOWER, 7.98 ms: the callee's private arrays become a
+  // stack frame every wave of the kernel has to reserve.)
+  if (t < 64 && L.tab[64 + t] == 0) grp_fill_missing<NV, GRAV>(A, L.tab[t], t, &L.u[0][0], L.ok);
   __syncthreads();
 
   // a father cell that an active son needs and that does not exist: the tree breaks the refinement rules
@@ -546,13 +586,13 @@ __global__ __launch_bounds__(GRP_THREADS, GRP_MINWAVES) void amr_group_kernel(Am
       if constexpr (ST == 3) {
         double nb[27], d3[3];
 #pragma unroll
-        for (int n = 0; n < 27; n++) nb[n] = L.GU(s + (n % 3 - 1) + 8 * ((n / 3) % 3 - 1) + 64 * (n / 9 - 1), v);
+        for (int n = 0; n < 27; n++) nb[n] = L.GU(s + (n % 3 - 1) + 8 * ((n / 3) % 3 - 1) + GRP_ZS * (n / 9 - 1), v);
         slope3_var(nb, d3);
         dq[0][v] = d3[0]; dq[1][v] = d3[1]; dq[2][v] = d3[2];
       } else {
         dq[0][v] = slope1<ST>(L.GU(s - 1, v), qb[v], L.GU(s + 1, v), P);
         dq[1][v] = slope1<ST>(L.GU(s - 8, v), qb[v], L.GU(s + 8, v), P);
-        dq[2][v] = slope1<ST>(L.GU(s - 64, v), qb[v], L.GU(s + 64, v), P);
+        dq[2][v] = slope1<ST>(L.GU(s - GRP_ZS, v), qb[v], L.GU(s + GRP_ZS, v), P);
       }
     }
     if constexpr (SCHEME == 0) {
@@ -604,7 +644,7 @@ __global__ __launch_bounds__(GRP_THREADS, GRP_MINWAVES) void amr_group_kernel(Am
     int cl[3];
     cl[d] = a + 1; cl[t0] = b + 2; cl[t1] = c + 2;            // stencil coordinates of the low cell of the face
     const int sl = gsidx(cl[0], cl[1], cl[2]);
-    const int stride = d == 0 ? 1 : (d == 1 ? 8 : 64);
+    const int stride = d == 0 ? 1 : (d == 1 ? 8 : GRP_ZS);
     const bool zero = L.ok[sl] || L.ok[sl + stride];
 #pragma unroll
     for (int v = 0; v < NV; v++) L.GF(qm, d, r, v) = zero ? 0.0 : fx[v];
@@ -687,27 +727,35 @@ __global__ __launch_bounds__(GRP_THREADS, GRP_MINWAVES) void amr_group_kernel(Am
 #undef GF
 
 // The octs of the call's list repacked as contiguous records, record i = oct igrid[i]:
-//   [8 x uold(:,1)] ... [8 x uold(:,nvar)] [8 x f(:,1..3) with gravity] [8 ints: cell is refined], padded to 128 bytes.
-// The grouped kernel then reads a father cell's son oct as one 3-5 line burst instead of 8 x nvar eight-byte gathers at
-// stride ngridmax (profiles/r02_amr_sweep_pmc.txt: those gathers moved 24x the algorithmic traffic).  32 octs per
-// workgroup: cell-vector reads run over consecutive octs, the records leave through LDS in record order.
+//   [8 x q(:,1)] ... [8 x q(:,nvar)] [8 ints: cell is refined], padded to 128 bytes
+// with q = the PRIMITIVE variables of the cell (ctoprim with the gravity predictor, hydro/umuscl.f90:862-954): a cell is read
+// by up to 27 father-oct groups, and converting it here makes that once per cell instead of once per reader (the same
+// function of the same values: bit-identical).  The grouped kernel then reads a father cell's son oct as one 3-line burst
+// instead of 8 x nvar eight-byte gathers at stride ngridmax (profiles/r02_amr_sweep_pmc.txt: those gathers moved 24x the
+// algorithmic traffic).  32 octs per workgroup, one cell per thread: cell-vector reads run over consecutive octs, the
+// records leave through LDS in record order.
 constexpr int PACK_OCTS = 32;
-__global__ __launch_bounds__(256) void amr_pack_kernel(AmrSweepArgs A, double *__restrict__ out, int rec, int nvt) {
+template <int NV, bool GRAV>
+__device__ __forceinline__ void pack_block(const AmrSweepArgs &A, int block, double *__restrict__ out, int rec) {
   __shared__ double tile[PACK_OCTS][AMR_PACK_REC_MAX + 1];
-  const int base = blockIdx.x * PACK_OCTS;
+  const int base = block * PACK_OCTS;
   const int n = min(PACK_OCTS, A.ngrid - base);
-  const int nval = 8 * nvt;                               // doubles of data per record
-  for (int e = threadIdx.x; e < PACK_OCTS * (nval + 8); e += 256) {
-    const int o = e % PACK_OCTS, k = e / PACK_OCTS;       // consecutive lanes: consecutive octs
-    if (o >= n) continue;
-    const int g = A.igrid[base + o];
-    if (k < nval) {
-      const int v = k >> 3, ind = k & 7;
+  constexpr int nval = 8 * NV;                            // doubles of data per record
+  {
+    const int o = threadIdx.x % PACK_OCTS, ind = threadIdx.x / PACK_OCTS;       // consecutive lanes: consecutive octs
+    if (o < n) {
+      const int g = A.igrid[base + o];
       const long cell = A.ncoarse + (long)ind * A.ngridmax + g - 1;
-      tile[o][k] = v < A.nvar ? A.uold[(long)v * A.ncell + cell] : A.grav[(long)(v - A.nvar) * A.ncell + cell];
-    } else {
-      const int ind = k - nval;
-      const long cell = A.ncoarse + (long)ind * A.ngridmax + g - 1;
+      double u[NV], q[NV], gz[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int v = 0; v < NV; v++) u[v] = A.uold[(long)v * A.ncell + cell];
+      if (GRAV) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) gz[d] = A.grav[(long)d * A.ncell + cell];
+      }
+      ctoprim_cell<NV, GRAV>(u, gz, A.dt * 0.5, A.P, q);
+#pragma unroll
+      for (int v = 0; v < NV; v++) tile[o][v * 8 + ind] = q[v];
       reinterpret_cast<int *>(&tile[o][nval])[ind] = A.son[cell] > 0 ? 1 : 0;
     }
   }
@@ -716,6 +764,20 @@ __global__ __launch_bounds__(256) void amr_pack_kernel(AmrSweepArgs A, double *_
     const int o = e / rec, k = e % rec;
     out[(long)(base + o) * rec + k] = k < nval + 4 ? tile[o][k] : 0.0;
   }
+}
+// The records and the father-cell walk in ONE launch, their workgroups alternating: the walk is nothing but dependent
+// loads (latency), the pack streams the level (bandwidth); side by side on a CU they overlap (walk_blocks = 0: pack only).
+template <int NV, bool GRAV>
+__global__ __launch_bounds__(256) void amr_prep_kernel(AmrSweepArgs A, double *__restrict__ out, int rec, int pack_blocks,
+                                                       int walk_blocks, const int *__restrict__ groups, int ngroups,
+                                                       const int *__restrict__ posof, int *__restrict__ walk) {
+  const int b = blockIdx.x, both = 2 * min(pack_blocks, walk_blocks);
+  bool is_pack;
+  int idx;
+  if (b < both) { is_pack = (b & 1) == 0; idx = b >> 1; }
+  else { is_pack = pack_blocks > walk_blocks; idx = b - both + (both >> 1); }
+  if (is_pack) pack_block<NV, GRAV>(A, idx, out, rec);
+  else group_walk_block(A, idx, groups, ngroups, posof, walk);
 }
 
 // groups[] = the father octs that have at least one son in the call's list, each once: the son at the lowest
@@ -930,19 +992,34 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A_in, int slope_type, int riem
       const char *env = getenv("RAMSES_AMD_AMR_WALK");
       use_walk = !(env && env[0] == '0');
     }
-    if (use_walk && walk_area && ngroups > 0) {
+    const bool do_walk = use_walk && walk_area && ngroups > 0, do_pack = use_pack && pack_area && ngroups > 0;
+    const int walk_blocks = do_walk ? (int)(((long)ngroups * 64 + 255) / 256) : 0;
+    if (do_pack) {
+      // records of primitive variables + (alternating workgroups of the same launch) the father-cell walk of every group:
       // 768 bytes per father oct, carved out of the caller's workspace like every other scratch area of the call
       // (two calls on two streams with two workspaces do not share anything)
-      const long nthr = (long)ngroups * 64;
-      hipLaunchKernelGGL(amr_group_walk_kernel, dim3((int)((nthr + 255) / 256)), dim3(256), 0, s, A, groups, ngroups, posof, walk_area);
-      walk = walk_area;
-    }
-    if (use_pack && pack_area && ngroups > 0) {
-      const int nvt = A.nvar + (A.grav ? 3 : 0);
-      const int rec = amr_pack_rec(A.nvar, A.grav != nullptr);
-      hipLaunchKernelGGL(amr_pack_kernel, dim3((A.ngrid + PACK_OCTS - 1) / PACK_OCTS), dim3(256), 0, s, A, pack_area, rec, nvt);
+      const int rec = amr_pack_rec(A.nvar);
+      const int pack_blocks = (A.ngrid + PACK_OCTS - 1) / PACK_OCTS;
+      const dim3 pgrid(pack_blocks + walk_blocks), pblock(256);
+      switch (A.nvar * 2 + (A.grav ? 1 : 0)) {
+#define RAMSES_AMD_PREP(NV, G) hipLaunchKernelGGL((amr_prep_kernel<NV, G>), pgrid, pblock, 0, s, A, pack_area, rec, pack_blocks, \
+                                                   walk_blocks, groups, ngroups, posof, walk_area)
+        case 10: RAMSES_AMD_PREP(5, false); break;
+        case 11: RAMSES_AMD_PREP(5, true); break;
+#ifndef RAMSES_AMD_AMR_DEV
+        case 12: RAMSES_AMD_PREP(6, false); break;
+        case 13: RAMSES_AMD_PREP(6, true); break;
+        case 14: RAMSES_AMD_PREP(7, false); break;
+        case 15: RAMSES_AMD_PREP(7, true); break;
+#endif
+#undef RAMSES_AMD_PREP
+        default: return hipErrorInvalidValue;
+      }
       A.packed = pack_area; A.rec = rec;
+    } else if (do_walk) {
+      hipLaunchKernelGGL(amr_group_walk_kernel, dim3(walk_blocks), dim3(256), 0, s, A, groups, ngroups, posof, walk_area);
     }
+    if (do_walk) walk = walk_area;
   }
   switch (slope_type) {
     case 1: e = launch1<1>(A, riemann, groups, ngroups, posof, walk, s); break;

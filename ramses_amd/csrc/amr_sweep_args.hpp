@@ -32,8 +32,8 @@ struct AmrSweepArgs {
 
 hipError_t launch_amr_godunov(const AmrSweepArgs &A, int slope_type, int riemann, int *posof, int nvector,
                               hipStream_t s, double *pack_area = nullptr, int *walk_area = nullptr);
-// doubles per packed oct record for nvar variables (+3 with gravity): 8 values per variable, 8 refinement flags, padded to 128 bytes
-inline int amr_pack_rec(int nvar, bool grav) { return ((8 * (nvar + (grav ? 3 : 0)) + 4) + 15) / 16 * 16; }
-constexpr int AMR_PACK_REC_MAX = 96;   // nvar = 7 with gravity
+// doubles per packed oct record for nvar variables: 8 primitive values per variable, 8 refinement flags, padded to 128 bytes
+inline int amr_pack_rec(int nvar) { return ((8 * nvar + 4) + 15) / 16 * 16; }
+constexpr int AMR_PACK_REC_MAX = 64;   // nvar = 7
 
 }  // namespace ramses_amd

@@ -120,7 +120,7 @@ def _morton_rank(no):
     return np.argsort(np.argsort(key.reshape(-1))).reshape(no, no, no)
 
 
-def uniform_tree(L, slack=7, order="scrambled", refine_box=None):
+def uniform_tree(L, slack=7, order="scrambled", refine_box=None, refine_mask=None):
     """RAMSES tree arrays (amr/amr_commons.f90:67-75) of a periodic nx=ny=nz=1 box
     whose levels 1..L are fully refined; octs are numbered level by level in a
     scrambled order (the reference's lists are not lexicographic either).
@@ -133,6 +133,8 @@ def uniform_tree(L, slack=7, order="scrambled", refine_box=None):
     if refine_box is not None:
         (x0, x1), (y0, y1), (z0, z1) = refine_box
         nextra = (x1 - x0) * (y1 - y0) * (z1 - z0)
+    if refine_mask is not None:
+        nextra = int(np.count_nonzero(refine_mask))
     ngridmax = sum(counts) + nextra + slack
     ncell = ncoarse + 8 * ngridmax
     son = np.zeros(ncell, np.int32)
@@ -183,13 +185,25 @@ def uniform_tree(L, slack=7, order="scrambled", refine_box=None):
 
     out = dict(son=son, nbor=nbor, father=father, igrid=igrid, ncoarse=ncoarse, ngridmax=ngridmax, ncell=ncell,
                to_cells=to_cells, from_cells=from_cells)
-    if refine_box is not None:
-        # level L+1 octs in every level-L cell of the (periodic) box: a partially refined level whose
+    if refine_box is not None or refine_mask is not None:
+        # level L+1 octs in every level-L cell of the (periodic) box / of the mask[z,y,x]: a partially refined level whose
         # father cells all have their 3^3 neighbours (level L is fully refined)
-        (x0, x1), (y0, y1), (z0, z1) = refine_box
-        cz, cy, cx = np.meshgrid(np.arange(z0, z1) % n, np.arange(y0, y1) % n, np.arange(x0, x1) % n, indexing="ij")
-        cz, cy, cx = cz.reshape(-1), cy.reshape(-1), cx.reshape(-1)
-        idf = free[used:used + cx.size].astype(np.int32)
+        if refine_mask is not None:
+            cz, cy, cx = np.nonzero(refine_mask)
+        else:
+            (x0, x1), (y0, y1), (z0, z1) = refine_box
+            cz, cy, cx = np.meshgrid(np.arange(z0, z1) % n, np.arange(y0, y1) % n, np.arange(x0, x1) % n, indexing="ij")
+            cz, cy, cx = cz.reshape(-1), cy.reshape(-1), cx.reshape(-1)
+        if order == "morton":
+            # numbered along the Z-order curve of their father cells (siblings contiguous), after the coarser levels
+            key = np.zeros(cx.size, dtype=np.int64)
+            for b in range(L):
+                key |= ((cx >> b) & 1) << (3 * b) | ((cy >> b) & 1) << (3 * b + 1) | ((cz >> b) & 1) << (3 * b + 2)
+            o = np.argsort(key, kind="stable")
+            cz, cy, cx = cz[o], cy[o], cx[o]
+            idf = (used + 1 + np.arange(cx.size)).astype(np.int32)
+        else:
+            idf = free[used:used + cx.size].astype(np.int32)
         fcell = cell_of(L, cx, cy, cz)
         father[idf - 1] = fcell
         son[fcell - 1] = idf
@@ -198,6 +212,6 @@ def uniform_tree(L, slack=7, order="scrambled", refine_box=None):
             c = [cx.copy(), cy.copy(), cz.copy()]
             c[axis] = (c[axis] + (1 if up else -1)) % n
             nbor[d, idf - 1] = cell_of(L, c[0], c[1], c[2])
-        out["igrid_fine"] = rng.permutation(idf).astype(np.int32)
+        out["igrid_fine"] = idf.copy() if order == "morton" else rng.permutation(idf).astype(np.int32)
         out["fine_cells"] = lambda: np.concatenate([ncoarse + ind * ngridmax + idf for ind in range(8)])
     return out
