@@ -454,14 +454,21 @@ int ramses_amd_prof_add(const char *name, int level, double seconds);
  * what the reference's loop leaves; *iter = iterations, err[0] = last rms residual
  * (:186), err[1] = the first, err[2] = rhs_norm (:63-78, 0 if rho is NULL).
  * fact = fourpi*dx^2/6 (:45), ncell_level = twotondim*numbtot(1,ilevel).  One rank (several: the
- * ramses_amd_cgmpi_* routines below).  ordered != 0: the dot products are summed in the
- * reference's order (bit-identical, slow); 0: fixed parallel tree (deterministic, phi equal to
- * ~1e-13 relative); < 0: taken from the environment (RAMSES_AMD_CG_ORDERED=1).
+ * ramses_amd_cgmpi_* routines below).  ordered = 1: the dot products are summed in the
+ * reference's order by the parallel parity scan (bit-identical; the default); 2: in the same
+ * order by one lane (slow; the scan's check); 0: fixed parallel tree (deterministic, equal to
+ * rounding only -- CG amplifies it to ~1e-9 on f); < 0: as RAMSES_AMD_CG_ORDERED says
+ * ("1", "chain", "0"; unset: 1).
  * ------------------------------------------------------------------------- */
 int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int *son, const int *nbor,
                              int64_t ngridmax, int64_t ncoarse, double *phi, double *f, const double *rho_or_null,
                              double rho_tot, double fact, double ncell_level, double epsilon, int itermax,
                              int ordered, int *iter, double *err);
+/* The strictly sequential sum  s <- fl(s + x[i]), i = 0..n-1  (the reference's accumulation loops), bit for bit, in
+ * parallel (csrc/parity_scan.hpp): *d_out = the sum.  d_x, d_out, d_scratch are device pointers;
+ * ramses_amd_ordered_sum_scratch(n) bytes of scratch. */
+size_t ramses_amd_ordered_sum_scratch(int64_t n);
+int ramses_amd_ordered_sum_device(const double *d_x, int64_t n, double *d_out, void *d_scratch, void *stream);
 /* The same loop with several MPI ranks (the two MPI_ALLREDUCEs per iteration poisson/phi_fine_cg.f90:108,154 and the halo
  * exchange of p :134 stay with the caller): cgmpi_begin uploads the state (arguments as above; ngrid may be 0) and returns
  * out2 = {local rhs norm^2, local r.r}; cgmpi_step runs one routine of the loop body on the rank's octs -- 0: p = r + beta p,

@@ -118,6 +118,8 @@ SYMBOLS = [
     ("ramses_amd_resident_force_fine_f90", _i, [_i, _d, _vp]),
     ("ramses_amd_resident_sync_poisson_f90", _i, [_vp, _vp, _vp]),
     ("ramses_amd_cg_solve_host", _i, [_i, _i, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _i, _i, _vp, _vp]),
+    ("ramses_amd_ordered_sum_scratch", C.c_size_t, [_i64]),
+    ("ramses_amd_ordered_sum_device", _i, [_vp, _i64, _vp, _vp, _vp]),
     ("ramses_amd_cgmpi_begin", _i, [_i, _i, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _d, _d, _i, _vp]),
     ("ramses_amd_cgmpi_get", _i, [_i, _vp]),
     ("ramses_amd_cgmpi_set", _i, [_i, _d]),

@@ -67,5 +67,5 @@ def phi_fine_cg(tree, ilevel, igrid, phi, f, epsilon, itermax=10000, ordered=Fal
     check(lib().ramses_amd_cg_solve_host(int(ilevel), len(igrid), _vp(igrid), _vp(tree.son), _vp(tree.nbor), tree.ngridmax,
                                          tree.ncoarse, _vp(phi), _vp(f), _vp(rho), float(rho_tot), float(fact),
                                          float(8 * len(igrid) if ncell_level is None else ncell_level), float(epsilon),
-                                         int(itermax), 1 if ordered else 0, C.byref(it), err))
+                                         int(itermax), int(ordered), C.byref(it), err))
     return it.value, err[0], err[1], err[2]

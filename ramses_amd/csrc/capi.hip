@@ -1798,12 +1798,23 @@ int ramses_amd_mgamr_end(void) {
 extern "C++" {
 namespace {
 struct CgCtx {
-  DevBuf son, nbor, igrid, nb, x, r, p, z, rho, scal, partial, prod;
+  DevBuf son, nbor, igrid, nb, x, r, p, z, rho, scal, partial, prod, scan;
   double *pin = nullptr;      // pinned, device-visible: r2 of each iteration (ring of 4, written by the kernels), rhs norm
   double *pin_dev = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 CgCtx g_cg;
+// How the solver's dot products are summed.  Argument: 1 the reference's order by the parallel parity scan (bit-identical;
+// the default), 2 the same order by a one-lane chain (slow: the scan's check), 0 a fixed parallel tree (fastest; equal to
+// rounding only), < 0 as RAMSES_AMD_CG_ORDERED says ("0", "1", "chain"; unset: 1).
+int cg_sum_mode(int ordered) {
+  if (ordered >= 0) return ordered > 2 ? 1 : ordered;
+  const char *e = getenv("RAMSES_AMD_CG_ORDERED");
+  if (!e || !e[0]) return 1;
+  if (e[0] == '0') return 0;
+  if (e[0] == 'c') return 2;
+  return 1;
+}
 }  // namespace
 }  // extern "C++"
 
@@ -1818,10 +1829,7 @@ int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int 
   if (int rc = resident_release("phi_fine_cg")) return rc;
   CgCtx &G = g_cg;
   hipStream_t s = nullptr;
-  if (ordered < 0) {   // the Fortran shim: RAMSES_AMD_CG_ORDERED=1 selects the reference's summation order
-    const char *e = getenv("RAMSES_AMD_CG_ORDERED");
-    ordered = e && e[0] == '1';
-  }
+  ordered = cg_sum_mode(ordered);
   const long ncell = ncoarse + 8 * ngridmax;
   const size_t vb = sizeof(double) * ncell;
   HCHK(G.son.ensure(sizeof(int) * ncell), "hipMalloc son");
@@ -1832,6 +1840,7 @@ int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int 
   HCHK(G.p.ensure(vb), "hipMalloc p"); HCHK(G.z.ensure(vb), "hipMalloc z");
   HCHK(G.scal.ensure(sizeof(double) * 8), "hipMalloc"); HCHK(G.partial.ensure(sizeof(double) * CG_MAX_BLOCKS), "hipMalloc");
   if (ordered) HCHK(G.prod.ensure(sizeof(double) * 8 * (size_t)ngrid), "hipMalloc prod");
+  if (ordered == 1) HCHK(G.scan.ensure(cg_scan_bytes(ngrid)), "hipMalloc scan");
   if (!G.pin) {
     HCHK(hipHostMalloc(reinterpret_cast<void **>(&G.pin), sizeof(double) * 8, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
     HCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&G.pin_dev), G.pin, 0), "hipHostGetDevicePointer");
@@ -1851,6 +1860,7 @@ int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int 
   L.x = G.x.as<double>(); L.r = G.r.as<double>(); L.p = G.p.as<double>(); L.z = G.z.as<double>();
   L.host_r2 = G.pin_dev;
   L.scal = G.scal.as<double>(); L.partial = G.partial.as<double>(); L.prod = ordered ? G.prod.as<double>() : nullptr;
+  L.scan = ordered == 1 ? G.scan.p : nullptr;
   double rhs_norm = 0.0;
   if (rho_or_null) {
     HCHK(G.rho.ensure(vb), "hipMalloc rho");
@@ -1879,6 +1889,13 @@ int ramses_amd_cg_solve_host(int ilevel, int ngrid, const int *igrid, const int 
   if (rho_or_null) rhs_norm = std::sqrt(G.pin[4] / ncell_level);   // :78
   *iter_out = iter;
   err_out[0] = error; err_out[1] = error_ini; err_out[2] = rhs_norm;
+  return 0;
+}
+
+size_t ramses_amd_ordered_sum_scratch(int64_t n) { return ordered_sum_bytes((long)n); }
+int ramses_amd_ordered_sum_device(const double *d_x, int64_t n, double *d_out, void *d_scratch, void *stream) {
+  if (n < 0 || (n > 0 && !d_x) || !d_out || !d_scratch) return fail(RAMSES_AMD_EINVAL, "ordered_sum: bad argument");
+  HCHK(ordered_sum_launch(d_x, (long)n, d_out, d_scratch, static_cast<hipStream_t>(stream)), "ordered sum");
   return 0;
 }
 
@@ -1923,10 +1940,7 @@ int ramses_amd_cgmpi_begin(int ilevel, int ngrid, const int *igrid, const int *s
   CgCtx &G = g_cg;
   CgMpi &M = g_cgm;
   hipStream_t s = nullptr;
-  if (ordered < 0) {
-    const char *e = getenv("RAMSES_AMD_CG_ORDERED");
-    ordered = e && e[0] == '1';
-  }
+  ordered = cg_sum_mode(ordered);
   const long ncell = ncoarse + 8 * ngridmax;
   const size_t vb = sizeof(double) * ncell;
   const int ng1 = ngrid > 0 ? ngrid : 1;
@@ -1938,6 +1952,7 @@ int ramses_amd_cgmpi_begin(int ilevel, int ngrid, const int *igrid, const int *s
   HCHK(G.p.ensure(vb), "hipMalloc p"); HCHK(G.z.ensure(vb), "hipMalloc z");
   HCHK(G.scal.ensure(sizeof(double) * 8), "hipMalloc"); HCHK(G.partial.ensure(sizeof(double) * CG_MAX_BLOCKS), "hipMalloc");
   if (ordered) HCHK(G.prod.ensure(sizeof(double) * 8 * (size_t)ng1), "hipMalloc prod");
+  if (ordered == 1) HCHK(G.scan.ensure(cg_scan_bytes(ng1)), "hipMalloc scan");
   if (!G.pin) {
     HCHK(hipHostMalloc(reinterpret_cast<void **>(&G.pin), sizeof(double) * 8, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
     HCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&G.pin_dev), G.pin, 0), "hipHostGetDevicePointer");
@@ -1957,6 +1972,7 @@ int ramses_amd_cgmpi_begin(int ilevel, int ngrid, const int *igrid, const int *s
   L.x = G.x.as<double>(); L.r = G.r.as<double>(); L.p = G.p.as<double>(); L.z = G.z.as<double>();
   L.host_r2 = G.pin_dev;
   L.scal = G.scal.as<double>(); L.partial = G.partial.as<double>(); L.prod = ordered ? G.prod.as<double>() : nullptr;
+  L.scan = ordered == 1 ? G.scan.p : nullptr;
   M.ncell = ncell; M.h_f = f;
   out2[0] = 0.0; out2[1] = 0.0;
   if (rho_or_null) {

@@ -15,15 +15,18 @@
 //
 // Every cell update is the reference's expression, operation for operation (this unit is
 // compiled with -ffp-contract=off).  The three dot products of an iteration are either
-//   * ordered: products written in the reference's summation order (ind outermost, then the
-//     oct list) and added one after the other by a single lane -- bit-identical to the
-//     reference, slow (a dependent chain of N adds); or
-//   * parallel (default): a fixed reduction tree (per oct, per block, over the blocks) --
-//     deterministic, equal to the ordered sum to rounding, so phi agrees with the reference to
-//     ~1e-13 relative instead of bit for bit.
+//   * ordered (default): products written in the reference's summation order (ind outermost, then the
+//     oct list) and summed SEQUENTIALLY IN PARALLEL by the scan of parity functions of parity_scan.hpp
+//     (signed terms; exact integer arithmetic inside a binade, IEEE adds where the sum crosses one) --
+//     bit-identical to the reference; as a check of the scan a single lane can add them one after
+//     the other instead (a dependent chain of N adds: ~650 ms per sum at 16.8 M cells); or
+//   * parallel (RAMSES_AMD_CG_ORDERED=0): a fixed reduction tree (per oct, per block, over the blocks)
+//     -- deterministic, equal to the ordered sum to rounding only, and CG amplifies that: phi agrees
+//     with the reference to ~1e-9..1e-13 relative depending on the iteration count.
 // Per iteration and cell, r, p (x2), z (x2), x are read and p, z, x, r written = 80 B algorithmic
 // (+3 B of neighbour table).
 #include "cg_amr_args.hpp"
+#include "parity_scan.hpp"
 
 namespace ramses_amd {
 namespace {
@@ -253,12 +256,43 @@ inline int blocks_for(long work) {
   if (b > CG_MAX_BLOCKS) b = CG_MAX_BLOCKS;
   return (int)b;
 }
+// the ordered products as a source of the parity scan, and what happens to the sum (final_kernel's epilogue)
+struct ProdSrc {
+  const double *prod;
+  long n;
+  __device__ long count() const { return n; }
+  __device__ double operator()(int, long p) const { return prod[p]; }
+};
+struct ScalFin {
+  double *scal;
+  int slot;
+  double *host_r2;
+  int host_slot;
+  __device__ void operator()(int, double total) const {
+    if (slot == CG_R2) scal[CG_R2_OLD] = scal[CG_R2];
+    scal[slot] = total;
+    if (host_slot >= 0) host_r2[host_slot] = total;
+  }
+};
 inline void launch_final(const CgLevel &L, int nb, int slot, int host_slot, hipStream_t s) {
+  if (L.prod && L.scan) {
+    ProdSrc S{L.prod, 8L * L.ngrid};
+    ScalFin F{L.scal, slot, L.host_r2, host_slot};
+    (void)pscan::launch<ProdSrc, 1, ScalFin>(S, S.n, L.scal + 5, L.scan, s, F);
+    return;
+  }
   hipLaunchKernelGGL(final_kernel, dim3(1), dim3(TPB), 0, s, (const double *)L.partial, nb, (const double *)L.prod,
                      8L * L.ngrid, L.scal, slot, L.host_r2, host_slot);
 }
 
 }  // namespace
+
+size_t cg_scan_bytes(int ngrid) { return pscan::scratch_bytes(8L * (ngrid > 0 ? ngrid : 1), 1); }
+size_t ordered_sum_bytes(long n) { return pscan::scratch_bytes(n > 0 ? n : 1, 1); }
+hipError_t ordered_sum_launch(const double *x, long n, double *out, void *scratch, hipStream_t s) {
+  ProdSrc S{x, n};
+  return pscan::launch<ProdSrc, 1>(S, n, out, scratch, s);
+}
 
 hipError_t cg_launch_setup(const int *igrid, int ngrid, const int *son, const int *nbor, long ngridmax, int *nb, hipStream_t s) {
   if (ngrid <= 0) return hipSuccess;

@@ -16,8 +16,14 @@ struct CgLevel {
                         // [6] (as unsigned) count of finished blocks of the running reduction
   double *host_r2;      // pinned ring of 4 (device-visible): r2 of iteration k goes to slot k & 3
   double *partial;      // [CG_MAX_BLOCKS] per-block partial sums
-  double *prod;         // [8*ngrid] products in the reference's summation order (ordered mode) or nullptr
+  double *prod;         // [8*ngrid] products in the reference's summation order (ordered modes) or nullptr
+  void *scan;           // ordered sums by the parallel parity scan (parity_scan.hpp): cg_scan_bytes(ngrid) bytes of scratch;
+                        // nullptr with prod set: one lane adds the products one after the other (verification of the scan)
 };
+size_t cg_scan_bytes(int ngrid);
+// *out = the sequential sum of x[0..n-1] (parity scan); scratch: ordered_sum_bytes(n)
+size_t ordered_sum_bytes(long n);
+hipError_t ordered_sum_launch(const double *x, long n, double *out, void *scratch, hipStream_t s);
 constexpr int CG_MAX_BLOCKS = 1024;
 enum { CG_R2 = 0, CG_R2_OLD = 1, CG_PAP = 2, CG_RHS = 3 };
 
@@ -27,7 +33,7 @@ hipError_t cg_launch_rhs_norm(const CgLevel &L, const double *rho, double rho_to
 // scal[CG_R2] = r.r   (start of the first iteration), also stored to host_r2[slot]
 hipError_t cg_launch_dot_rr(const CgLevel &L, int slot, hipStream_t s);
 // one iteration (:96-183): p = r + beta p; z = A p; pAp; x += alpha p; r -= alpha z; r2 of the new r
-// (stored to host_r2[slot]).  Three launches (parallel sums) or five (ordered sums).
+// (stored to host_r2[slot]).  Three launches (parallel sums), eleven (ordered sums by the scan) or five (one-lane chain).
 hipError_t cg_launch_iteration(const CgLevel &L, int iter, int slot, hipStream_t s);
 // its three routines one by one (several MPI ranks: the caller reduces scal[CG_PAP] / scal[CG_R2] over the ranks in between)
 hipError_t cg_launch_update_p(const CgLevel &L, int iter, hipStream_t s);

@@ -16,6 +16,7 @@
 // This unit is compiled with -ffp-contract=off: IEEE operations in the reference's order.
 #include <hip/hip_runtime.h>
 
+#include "parity_scan.hpp"
 #include "rho_args.hpp"
 
 namespace ramses_amd {
@@ -113,68 +114,9 @@ __global__ __launch_bounds__(DEP_THREADS) void rho_deposit_kernel(RhoArgs A) {
 }
 
 // multipole(d), d = 0..3: the SEQUENTIAL sum  s <- fl(s + a_i)  over the cells in the order (batch of nvector
-// octs, ind_son, oct in the batch) of cic_from_multipole (:858-866), reproduced bit for bit IN PARALLEL.
-//
-// While the running sum stays inside one binade [2^E, 2^(E+1)) its spacing is u = 2^(E-52), and adding a
-// positive a_i is an INTEGER operation on S = s/u: S <- S + n_i + (rem_i > u/2) + (rem_i == u/2 and S + n_i odd),
-// with n_i = floor(a_i/u) and rem_i the part of a_i below u (round to nearest, ties to even).  The increment
-// depends on what came before only through the parity of S, so a run of elements is a function
-// parity -> (increment for parity 0, increment for parity 1), and these functions compose associatively.
-//
-// Round 3: many workgroups.  The list is cut into segments of MP_SEG elements.
-//   pass 0  mp_sum_kernel     plain sums per segment (any order; only used to PREDICT the binade)
-//           mp_prefix_kernel  running sum at every segment start, approximately
-//   pass 1  mp_fn_kernel      the parity function of every segment in the predicted binade, all segments at once
-//   pass 2  mp_walk_kernel    one workgroup per component walks the segments in order with EXACT integer arithmetic:
-//                             a segment whose prediction holds (the exact running sum has the predicted exponent and
-//                             stays below 2^53 units through the segment -- the terms are positive, so the end value
-//                             decides) costs one table look-up; the others (the ~log2 N binade crossings, the first
-//                             segment, the rare misprediction next to a power of two) take the workgroup scan of
-//                             round 2, which adds the crossing elements with real floating-point adds.
-// All additions are exact integer sums or IEEE adds in the original order; 32 ms -> well under 1 ms at 256^3.
-constexpr int MP_THREADS = 1024;
-constexpr int MP_K = 8;                 // consecutive elements per thread and chunk
-constexpr long MP_SEG = (long)MP_THREADS * MP_K;
-struct ParFn { long t0, t1; };          // increment of S for incoming parity 0 / 1
-__device__ __forceinline__ ParFn par_compose(const ParFn &f, const ParFn &g) {   // f first, then g
-  ParFn r;
-  r.t0 = f.t0 + ((f.t0 & 1) ? g.t1 : g.t0);
-  r.t1 = f.t1 + (((1 + f.t1) & 1) ? g.t1 : g.t0);
-  // saturate (elements that leave the binade carry 2^53): anything beyond 2^53 only has to stay beyond it
-  const long cap = 1L << 60;
-  r.t0 = r.t0 < cap ? r.t0 : cap;
-  r.t1 = r.t1 < cap ? r.t1 : cap;
-  return r;
-}
-constexpr long MP_POISON = 1L << 53;
-
-// one element as a parity function in the binade whose unit is 2^qu
-__device__ __forceinline__ ParFn par_element(double a, int qu, long &ub) {
-  const long ab = __double_as_longlong(a);
-  const int aexp = (int)((ab >> 52) & 0x7ff);
-  const long m = aexp ? ((ab & 0xfffffffffffffL) | (1L << 52)) : (ab & 0xfffffffffffffL);
-  const int q = (aexp ? aexp : 1) - 1075;         // a = m * 2^q
-  const int k = qu - q;                           // a / u = m / 2^k
-  long nint, inc_gt;
-  int tie;
-  if (m == 0) { nint = 0; inc_gt = 0; tie = 0; }
-  else if (k <= 0) { nint = MP_POISON; inc_gt = 0; tie = 0; }       // a >= 2^E: leaves the binade
-  else if (k >= 64) { nint = 0; inc_gt = 0; tie = 0; }
-  else {
-    nint = m >> k;
-    const long rem = m & ((1L << k) - 1), half = 1L << (k - 1);
-    inc_gt = rem > half ? 1 : 0;
-    tie = rem == half ? 1 : 0;
-  }
-  const long bsum = nint + inc_gt;
-  ParFn g;
-  g.t0 = bsum + (tie ? (nint & 1) : 0);           // incoming parity 0: S + n odd  <=>  n odd
-  g.t1 = bsum + (tie ? ((nint + 1) & 1) : 0);
-  ub += nint + 1;
-  if (ub > MP_POISON) ub = MP_POISON;
-  return g;
-}
-
+// octs, ind_son, oct in the batch) of cic_from_multipole (:858-866), reproduced bit for bit IN PARALLEL by the scan of
+// parity functions of parity_scan.hpp (round 2: one workgroup per component, 32 ms at 256^3; round 3: segments scanned
+// by many workgroups and walked with exact integer arithmetic, well under 1 ms).
 // Where the operands come from.  Brick: the uniform resident level (mass and mass * position computed from the
 // density brick).  Vec: the multipoles of the cells of an AMR level, already in a (4, ncell) cell vector.
 struct MpBrickSrc {
@@ -221,250 +163,7 @@ struct MpVecSrc {
   }
 };
 
-// pass 0: plain per-segment sums (prediction only)
-template <class Src>
-__global__ __launch_bounds__(MP_THREADS) void mp_sum_kernel(Src S, long nseg, double *__restrict__ segsum) {
-  __shared__ double wsum[MP_THREADS / 64];
-  const long seg = blockIdx.x;
-  const long ncells = S.count();
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int comp = 0; comp < 4; comp++) {
-    double a = 0.0;
-    const long base = seg * MP_SEG + (long)tid * MP_K;
-#pragma unroll
-    for (int e = 0; e < MP_K; e++) a += (base + e) < ncells ? S(comp, base + e) : 0.0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
-    if (lane == 0) wsum[wv] = a;
-    __syncthreads();
-    if (tid == 0) {
-      double t = 0.0;
-      for (int w = 0; w < MP_THREADS / 64; w++) t += wsum[w];
-      segsum[(long)comp * nseg + seg] = t;
-    }
-    __syncthreads();
-  }
-}
-// running sum at the start of every segment (exclusive prefix of the segment sums), one workgroup per component
-__global__ __launch_bounds__(MP_THREADS) void mp_prefix_kernel(long nseg, const double *__restrict__ segsum, double *__restrict__ pre) {
-  __shared__ double part[MP_THREADS];
-  const int comp = blockIdx.x, tid = threadIdx.x;
-  const long per = (nseg + MP_THREADS - 1) / MP_THREADS;
-  const long lo = (long)tid * per, hi = lo + per < nseg ? lo + per : nseg;
-  double t = 0.0;
-  for (long k = lo; k < hi; k++) t += segsum[(long)comp * nseg + k];
-  part[tid] = t;
-  __syncthreads();
-  if (tid == 0) {
-    double run = 0.0;
-    for (int k = 0; k < MP_THREADS; k++) { const double v = part[k]; part[k] = run; run += v; }
-  }
-  __syncthreads();
-  double run = part[tid];
-  for (long k = lo; k < hi; k++) { pre[(long)comp * nseg + k] = run; run += segsum[(long)comp * nseg + k]; }
-}
-// pass 1: the parity function of every segment in the binade its (approximate) starting sum predicts;
-// qupred = unit exponent used (INT_MIN: no prediction -- the walk takes the slow path there)
-template <class Src>
-__global__ __launch_bounds__(MP_THREADS) void mp_fn_kernel(Src S, long nseg, const double *__restrict__ pre, ParFn *__restrict__ fn,
-                                                           int *__restrict__ qupred) {
-  __shared__ ParFn wavefn[MP_THREADS / 64];
-  const long seg = blockIdx.x;
-  const long ncells = S.count();
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int comp = 0; comp < 4; comp++) {
-    const double s0 = pre[(long)comp * nseg + seg];
-    const long sbits = __double_as_longlong(s0);
-    const int sexp = (int)((sbits >> 52) & 0x7ff);
-    const bool usable = seg > 0 && sexp > 0 && sexp < 0x7ff && s0 > 0.0;
-    const int qu = sexp - 1075;
-    ParFn f = {0, 0};
-    if (usable) {
-      long ub = 0;
-      const long base = seg * MP_SEG + (long)tid * MP_K;
-#pragma unroll
-      for (int e = 0; e < MP_K; e++) {
-        const double a = (base + e) < ncells ? S(comp, base + e) : 0.0;
-        f = par_compose(f, par_element(a, qu, ub));
-      }
-      // ordered reduction (composition is associative, not commutative): lanes, then waves
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        ParFn o;
-        o.t0 = __shfl_down(f.t0, off, 64);
-        o.t1 = __shfl_down(f.t1, off, 64);
-        if ((lane & (2 * off - 1)) == 0) f = par_compose(f, o);
-      }
-    }
-    if (lane == 0) wavefn[wv] = f;
-    __syncthreads();
-    if (tid == 0) {
-      ParFn tot = wavefn[0];
-      for (int w = 1; w < MP_THREADS / 64; w++) tot = par_compose(tot, wavefn[w]);
-      fn[(long)comp * nseg + seg] = tot;
-      qupred[(long)comp * nseg + seg] = usable ? qu : (int)0x80000000;
-    }
-    __syncthreads();
-  }
-}
-
-// pass 2: the exact walk.  slow_range adds the elements [i0, lim) to sh_s with the workgroup scan (binade crossings
-// handled by real floating-point adds of the crossing thread's elements).
-template <class Src>
-__device__ void mp_slow_range(const Src &S, int comp, long i0_in, long lim, double &sh_s, long &sh_next, int &sh_cross, ParFn *wavefn) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) {
-    double s = sh_s;
-    long p = i0_in;
-    if (i0_in == 0) {
-      // the first elements cross a binade at almost every addition: plain sequential adds
-      const long m = lim < 64 ? lim : 64;
-      for (; p < m; p++) s = s + S(comp, p);
-    }
-    // (a sum that is still zero or subnormal cannot be scanned: keep adding one by one)
-    while (p < lim && !(s >= 2.3e-308)) { s = s + S(comp, p); p++; }
-    sh_s = s;
-    sh_next = p;
-  }
-  __syncthreads();
-  while (true) {
-    const long i0 = sh_next;
-    if (i0 >= lim) break;
-    const double s = sh_s;
-    const long sbits = __double_as_longlong(s);
-    const int sexp = (int)((sbits >> 52) & 0x7ff);
-    // (s is a positive normal number here: sums of positive normal operands)
-    const long Sx = (sbits & 0xfffffffffffffL) | (1L << 52);
-    const int qu = sexp - 1075;                       // s = Sx * 2^qu
-    // ---- this thread's MP_K elements as one parity function (+ an upper bound of their increments) ----
-    double a[MP_K];
-    const long base = i0 + (long)tid * MP_K;
-#pragma unroll
-    for (int e = 0; e < MP_K; e++) a[e] = (base + e) < lim ? S(comp, base + e) : 0.0;
-    ParFn f = {0, 0};
-    long ub = 0;
-#pragma unroll
-    for (int e = 0; e < MP_K; e++) f = par_compose(f, par_element(a[e], qu, ub));
-    // ---- inclusive scan of the functions over the workgroup (wave shuffles, then the 16 wave totals) ----
-    ParFn inc = f;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      ParFn o;
-      o.t0 = __shfl_up(inc.t0, off, 64);
-      o.t1 = __shfl_up(inc.t1, off, 64);
-      if (lane >= off) inc = par_compose(o, inc);
-    }
-    if (lane == 63) wavefn[wv] = inc;
-    __syncthreads();
-    ParFn prew = {0, 0};                               // everything before this thread's wave
-    for (int w = 0; w < wv; w++) prew = par_compose(prew, wavefn[w]);
-    ParFn excl;                                        // everything before this thread
-    {
-      ParFn o;
-      o.t0 = __shfl_up(inc.t0, 1, 64);
-      o.t1 = __shfl_up(inc.t1, 1, 64);
-      if (lane == 0) { o.t0 = 0; o.t1 = 0; }
-      excl = par_compose(prew, o);
-    }
-    const int p0 = (int)(Sx & 1);
-    const long S_t = Sx + (p0 ? excl.t1 : excl.t0);    // S on entry of this thread's elements
-    const bool unsafe = (ub >= MP_POISON) || (S_t + ub >= MP_POISON) || (S_t >= MP_POISON);
-    if (tid == 0) sh_cross = MP_THREADS;
-    __syncthreads();
-    if (unsafe) atomicMin(&sh_cross, tid);
-    __syncthreads();
-    const int tc = sh_cross;
-    if (tc == MP_THREADS) {
-      if (tid == MP_THREADS - 1) {
-        const ParFn tot = par_compose(excl, f);
-        const long S_end = Sx + (p0 ? tot.t1 : tot.t0);
-        sh_s = __builtin_ldexp((double)S_end, qu);
-        sh_next = i0 + MP_SEG;
-      }
-    } else if (tid == tc) {
-      // everything before this thread stayed inside the binade; its own elements are added one by one
-      double sc = __builtin_ldexp((double)S_t, qu);
-#pragma unroll
-      for (int e = 0; e < MP_K; e++) sc = sc + a[e];
-      sh_s = sc;
-      sh_next = base + MP_K;
-    }
-    __syncthreads();
-  }
-}
-
-constexpr int MP_WALK_TILE = 2048;      // segments whose functions sit in LDS at a time
-template <class Src>
-__global__ __launch_bounds__(MP_THREADS) void mp_walk_kernel(Src S, long nseg, const ParFn *__restrict__ fn, const int *__restrict__ qupred,
-                                                             double *__restrict__ out, int *__restrict__ nslow) {
-  __shared__ ParFn wavefn[MP_THREADS / 64];
-  __shared__ ParFn tfn[MP_WALK_TILE];
-  __shared__ int tqu[MP_WALK_TILE];
-  __shared__ double sh_s;
-  __shared__ long sh_next, sh_seg;
-  __shared__ int sh_cross, sh_slow;
-  const int comp = blockIdx.x, tid = threadIdx.x;
-  const long ncells = S.count();
-  if (tid == 0) { sh_s = 0.0; sh_seg = 0; sh_slow = 0; }
-  __syncthreads();
-  int slow_count = 0;
-  for (long t0 = 0; t0 < nseg; t0 += MP_WALK_TILE) {
-    const int nt = (int)(nseg - t0 < MP_WALK_TILE ? nseg - t0 : MP_WALK_TILE);
-    for (int k = tid; k < nt; k += MP_THREADS) { tfn[k] = fn[(long)comp * nseg + t0 + k]; tqu[k] = qupred[(long)comp * nseg + t0 + k]; }
-    __syncthreads();
-    while (true) {
-      if (tid == 0) {
-        long seg = sh_seg;
-        double s = sh_s;
-        int slow = 0;
-        while (seg < t0 + nt) {
-          const long sbits = __double_as_longlong(s);
-          const int sexp = (int)((sbits >> 52) & 0x7ff);
-          const long Sx = (sbits & 0xfffffffffffffL) | (1L << 52);
-          const int k = (int)(seg - t0);
-          const long inc = (Sx & 1) ? tfn[k].t1 : tfn[k].t0;
-          if (sexp == 0 || sexp - 1075 != tqu[k] || inc >= MP_POISON || Sx + inc >= MP_POISON) { slow = 1; break; }
-          s = __builtin_ldexp((double)(Sx + inc), sexp - 1075);
-          seg++;
-        }
-        sh_s = s; sh_seg = seg; sh_slow = slow;
-      }
-      __syncthreads();
-      if (!sh_slow) break;                             // the tile is done
-      const long seg = sh_seg;
-      const long lim = (seg + 1) * MP_SEG < ncells ? (seg + 1) * MP_SEG : ncells;
-      mp_slow_range(S, comp, seg * MP_SEG, lim, sh_s, sh_next, sh_cross, wavefn);
-      slow_count++;
-      if (tid == 0) sh_seg = seg + 1;
-      __syncthreads();
-    }
-  }
-  if (tid == 0) { out[comp] = sh_s; if (nslow) nslow[comp] = slow_count; }
-}
-
-template <class Src>
-static hipError_t launch_multipole_src(const Src &S, long ncells, double *out4, void *scratch, hipStream_t s) {
-  const long nseg = (ncells + MP_SEG - 1) / MP_SEG;
-  if (nseg < 1) {
-    return hipMemsetAsync(out4, 0, sizeof(double) * 4, s);
-  }
-  // scratch: segsum[4*nseg] doubles, pre[4*nseg] doubles, fn[4*nseg] ParFn, qupred[4*nseg] ints, nslow[4]
-  char *w = reinterpret_cast<char *>(scratch);
-  double *segsum = reinterpret_cast<double *>(w); w += sizeof(double) * 4 * nseg;
-  double *pre = reinterpret_cast<double *>(w); w += sizeof(double) * 4 * nseg;
-  ParFn *fn = reinterpret_cast<ParFn *>(w); w += sizeof(ParFn) * 4 * nseg;
-  int *qupred = reinterpret_cast<int *>(w); w += sizeof(int) * 4 * nseg;
-  int *nslow = reinterpret_cast<int *>(w);
-  hipLaunchKernelGGL(mp_sum_kernel<Src>, dim3((unsigned)nseg), dim3(MP_THREADS), 0, s, S, nseg, segsum);
-  hipLaunchKernelGGL(mp_prefix_kernel, dim3(4), dim3(MP_THREADS), 0, s, nseg, segsum, pre);
-  hipLaunchKernelGGL(mp_fn_kernel<Src>, dim3((unsigned)nseg), dim3(MP_THREADS), 0, s, S, nseg, pre, fn, qupred);
-  hipLaunchKernelGGL(mp_walk_kernel<Src>, dim3(4), dim3(MP_THREADS), 0, s, S, nseg, fn, qupred, out4, nslow);
-  return hipGetLastError();
-}
-size_t multipole_scratch_bytes(long ncells) {
-  const long nseg = (ncells + MP_SEG - 1) / MP_SEG + 1;
-  return (sizeof(double) * 8 + sizeof(ParFn) * 4 + sizeof(int) * 4) * (size_t)nseg + 64;
-}
+size_t multipole_scratch_bytes(long ncells) { return pscan::scratch_bytes(ncells, 4); }
 
 // ===========================================================================================================
 // rho_fine's hydro deposit on the levels of an AMR run, on the reference's own cell vectors and tree
@@ -661,13 +360,13 @@ hipError_t launch_rho_deposit(const RhoArgs &A, hipStream_t s) {
 hipError_t launch_multipole(const RhoArgs &A, double *out4, void *scratch, hipStream_t s) {
   MpBrickSrc S;
   S.A = A;
-  return launch_multipole_src(S, (long)A.ngrid * 8, out4, scratch, s);
+  return pscan::launch<MpBrickSrc, 4>(S, (long)A.ngrid * 8, out4, scratch, s);
 }
 hipError_t launch_multipole_vec(const double *mp, const int *igrid, int ngrid, int nvector, long ncell, long ncoarse, long ngridmax,
                                 double *out4, void *scratch, hipStream_t s) {
   MpVecSrc S;
   S.mp = mp; S.igrid = igrid; S.ngrid = ngrid; S.nvector = nvector; S.ncell = ncell; S.ncoarse = ncoarse; S.ngridmax = ngridmax;
-  return launch_multipole_src(S, (long)ngrid * 8, out4, scratch, s);
+  return pscan::launch<MpVecSrc, 4>(S, (long)ngrid * 8, out4, scratch, s);
 }
 
 }  // namespace ramses_amd

@@ -18,12 +18,13 @@ GOLD = os.path.join(ROOT, "tests", "golden", "cg_ref.npz")
 vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
 
 
-def _solve(gpu_lib, d, ordered, rho=None, rho_tot=0.0, fact=1.0):
-    """through the host mirror ramses_amd.amr.phi_fine_cg (the C ABI's ramses_amd_cg_solve_host)"""
+def _solve(gpu_lib, d, ordered, rho=None, rho_tot=0.0, fact=1.0, itermax=10000):
+    """through the host mirror ramses_amd.amr.phi_fine_cg (the C ABI's ramses_amd_cg_solve_host);
+    ordered: 1 parity scan, 2 one-lane chain, 0 parallel tree, -1 what the environment says"""
     from ramses_amd import amr
     tree = amr.AmrTree(d["son"], d["nbor"], np.zeros(d["ngridmax"], np.int32), d["ngridmax"], d["ncoarse"])
-    it, e, e_ini, rhs = amr.phi_fine_cg(tree, d["ilevel"], d["igrid"], d["phi"], d["f"], d["epsilon"], ordered=bool(ordered),
-                                        rho=rho, rho_tot=rho_tot, fact=fact)
+    it, e, e_ini, rhs = amr.phi_fine_cg(tree, d["ilevel"], d["igrid"], d["phi"], d["f"], d["epsilon"], ordered=int(ordered),
+                                        rho=rho, rho_tot=rho_tot, fact=fact, itermax=itermax)
     return it, [e, e_ini, rhs]
 
 
@@ -36,12 +37,16 @@ def _load(z, s):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [-1, 1, 2])
 @pytest.mark.parametrize("solve", [1, 2, 6])
-def test_cg_ordered_equals_reference_dump(gpu_lib, solve):
-    """Dot products summed in the reference's order: iteration count, phi and r/p/Ap bit for bit."""
+def test_cg_ordered_equals_reference_dump(gpu_lib, solve, mode, monkeypatch):
+    """Dot products summed in the reference's order -- by the parallel parity scan (1; -1: what the environment says, which
+    without RAMSES_AMD_CG_ORDERED is the same: the DEFAULT) or by a one-lane chain (2): iteration count, phi and r/p/Ap bit
+    for bit."""
+    monkeypatch.delenv("RAMSES_AMD_CG_ORDERED", raising=False)
     z = np.load(GOLD)
     d = _load(z, solve)
-    it, err = _solve(gpu_lib, d, ordered=1)
+    it, err = _solve(gpu_lib, d, ordered=mode)
     assert it == int(z["solves"][solve - 1][1])
     assert np.array_equal(d["phi"], d["phi_out"]), np.abs(d["phi"] - d["phi_out"]).max()
     lev = np.zeros(d["phi"].size, bool)
@@ -55,8 +60,8 @@ def test_cg_ordered_equals_reference_dump(gpu_lib, solve):
 @pytest.mark.gpu
 @pytest.mark.parametrize("solve", [1, 2, 6])
 def test_cg_parallel_sums_agree_with_reference_dump(gpu_lib, solve):
-    """Default mode (fixed parallel reduction tree): same iteration count on these solves, phi equal
-    to 1e-12 of its range, and the result is reproducible run to run."""
+    """RAMSES_AMD_CG_ORDERED=0 (fixed parallel reduction tree, not the default any more): same iteration count on these
+    solves, phi equal to 1e-12 of its range, and the result is reproducible run to run."""
     z = np.load(GOLD)
     d = _load(z, solve)
     it, _ = _solve(gpu_lib, d, ordered=0)
@@ -69,7 +74,7 @@ def test_cg_parallel_sums_agree_with_reference_dump(gpu_lib, solve):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ordered", [1, 0])
+@pytest.mark.parametrize("ordered", [1, 2, 0])
 def test_cg_on_a_synthetic_tree_equals_the_oracle(gpu_lib, oracle, ordered):
     """Random right-hand side on a two-level synthetic tree (level 5 octs in a box crossing the
     periodic boundary, zero outside the level): HIP against oracle/cg_oracle.c, incl. rhs_norm."""
@@ -108,11 +113,12 @@ def test_cg_on_a_synthetic_tree_equals_the_oracle(gpu_lib, oracle, ordered):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ordered", ["1", "0"])
+@pytest.mark.parametrize("ordered", ["default", "chain", "0"])
 def test_patched_program_with_cg_levels_equals_reference(gpu_lib, ordered):
     """The self-gravitating AMR run with cg_levelmin=4 (levels 4 and 5 solved by phi_fine_cg, level 3
-    by multigrid) through the patched reference program: ordered sums -> the reference's snapshot
-    bit for bit and the same iteration counts; parallel sums -> equal to rounding."""
+    by multigrid) through the patched reference program: ordered sums (the DEFAULT: no environment variable; or the
+    one-lane chain) -> the reference's snapshot bit for bit and the same iteration counts; parallel sums
+    (RAMSES_AMD_CG_ORDERED=0) -> equal to rounding."""
     patched = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch")
     if not os.path.exists(patched):
         pytest.skip("oracle/_ref/ramses3d_patch not built")
@@ -121,7 +127,9 @@ def test_patched_program_with_cg_levels_equals_reference(gpu_lib, ordered):
     mk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mk)
     z = np.load(GOLD)
-    os.environ["RAMSES_AMD_CG_ORDERED"] = ordered
+    os.environ.pop("RAMSES_AMD_CG_ORDERED", None)
+    if ordered != "default":
+        os.environ["RAMSES_AMD_CG_ORDERED"] = ordered
     try:
         work, out = rs.run_reference(mk.cg_namelist(), binary=patched)
     finally:
@@ -133,7 +141,7 @@ def test_patched_program_with_cg_levels_equals_reference(gpu_lib, ordered):
         snap = rs.load_leaf_cells(os.path.join(work, "output_00002"), with_grav=True)
         order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
         assert np.array_equal(snap["level"][order], z["level"])
-        if ordered == "1":
+        if ordered != "0":
             assert np.array_equal(solves, z["solves"])
             assert np.array_equal(snap["grav"][:, order], z["grav"]), np.abs(snap["grav"][:, order] - z["grav"]).max()
             assert np.array_equal(snap["prim"][:, order], z["prim"])
@@ -175,10 +183,12 @@ def test_patched_program_with_cg_levels_inside_walls_equals_reference(gpu_lib):
 
 
 @pytest.mark.gpu
-def test_cg_homogeneity_on_a_full_level(gpu_lib):
+@pytest.mark.parametrize("ordered", [1, 0])
+def test_cg_homogeneity_on_a_full_level(gpu_lib, ordered):
     """A fully refined periodic level of 2.1 M cells (no CPU oracle run at this size): every
     operation of the iteration is linear and a factor 2 is exact, so doubling r and p doubles phi
-    and r/p/Ap bit for bit with the same iteration count (alpha and beta are ratios)."""
+    and r/p/Ap bit for bit with the same iteration count (alpha and beta are ratios) -- with the ordered sums of
+    the parity scan (1) as with the parallel tree (0)."""
     from helpers import uniform_tree
     L = 7
     T = uniform_tree(L, order="morton")
@@ -197,10 +207,41 @@ def test_cg_homogeneity_on_a_full_level(gpu_lib):
         d = dict(ilevel=L, ngrid=len(igrid), ngridmax=T["ngridmax"], ncoarse=T["ncoarse"], igrid=igrid,
                  son=np.ascontiguousarray(T["son"], np.int32), nbor=np.ascontiguousarray(T["nbor"], np.int32),
                  epsilon=1e-6, phi=np.zeros(ncell), f=f)
-        it, err = _solve(gpu_lib, d, ordered=0)
+        it, err = _solve(gpu_lib, d, ordered=ordered)
         outs.append((it, err, d["phi"], d["f"]))
     (it1, e1, phi1, f1), (it2, e2, phi2, f2) = outs
     assert it1 == it2 and it1 > 30
     assert e2[0] == 2.0 * e1[0] and e2[1] == 2.0 * e1[1]
     assert np.array_equal(phi2, 2.0 * phi1) and np.array_equal(f2, 2.0 * f1)
     assert np.abs(phi1[lev]).max() > 0 and e1[0] <= 1e-6 * e1[1]
+
+
+@pytest.mark.gpu
+def test_cg_scan_equals_the_one_lane_chain_on_a_full_level(gpu_lib):
+    """2.1 M cells, 12 iterations: the ordered sums of the parallel parity scan (the default) and of the one-lane chain
+    (N dependent adds in the reference's order) give the same bits in phi, r, p, Ap and the residual norms -- the signed
+    products p*Ap included."""
+    from helpers import uniform_tree
+    L = 7
+    T = uniform_tree(L, order="morton")
+    ncell = T["ncell"]
+    igrid = np.ascontiguousarray(T["igrid"], np.int32)
+    rng = np.random.default_rng(11)
+    lev = np.concatenate([T["ncoarse"] + ind * T["ngridmax"] + igrid - 1 for ind in range(8)])
+    r0 = np.zeros(ncell)
+    r0[lev] = rng.normal(size=lev.size)
+    r0[lev] -= r0[lev].mean()
+    outs = []
+    for mode in (1, 2):
+        f = np.zeros((3, ncell))
+        f[0] = r0
+        f[1] = r0
+        d = dict(ilevel=L, ngrid=len(igrid), ngridmax=T["ngridmax"], ncoarse=T["ncoarse"], igrid=igrid,
+                 son=np.ascontiguousarray(T["son"], np.int32), nbor=np.ascontiguousarray(T["nbor"], np.int32),
+                 epsilon=1e-30, phi=np.zeros(ncell), f=f)
+        it, (e, e_ini, _) = _solve(gpu_lib, d, mode, itermax=12)
+        outs.append((it, e, e_ini, d["phi"], d["f"]))
+    a, b = outs
+    assert a[0] == b[0] == 12 and a[1] == b[1] and a[2] == b[2]
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    assert (a[4][1][lev] * a[4][2][lev] < 0).any()          # p*Ap has negative terms: the signed scan was exercised
