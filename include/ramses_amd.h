@@ -408,6 +408,22 @@ int ramses_amd_mgamr_norm2(int level, double *norm2);
 int ramses_amd_mgamr_restrict(int finelevel);
 int ramses_amd_mgamr_interpolate(int finelevel);
 int ramses_amd_mgamr_end(void);
+/* Several ranks, levels of the solve resident on the device (ramses_amd_mgamr_force_sync(0)): the virtual boundaries of
+ * the solved level -- make_virtual_fine_dp(phi / f(:,1)), amr/virtual_boundaries.f90:373-528 -- and of the multigrid levels
+ * -- make_virtual_mg_dp / make_reverse_mg_dp, poisson/multigrid_fine_commons.f90:1172-1290,1378-1475 -- exchanged from the
+ * device.  comm_set: per peer icpu the emission list of the level (octs of emission(icpu,level)%igrid with list_is_octs = 1,
+ * positions 1..n in the rank's own buffer as in emission_mg(icpu,level)%igrid with 0), concatenated in icpu order, and the
+ * number of reception octs (their blocks follow the rank's own octs in the layout, in icpu order).  comp = 1..4 (u(:,1..4):
+ * phi/correction, rhs, residual, mask), dir 0 forward, 1 reverse (added peer by peer in icpu order).  halo_rccl: one grouped
+ * RCCL send/recv; halo_stage_out / _in: the caller's own MPI between them on pinned host buffers (message of peer icpu at
+ * h_send + send_off[icpu-1]; addresses as integers for c_f_pointer).  stats: [0] bytes / [1] copies of level arrays that
+ * crossed PCIe after the first routine of the solve, [2] bytes / [3] number of halo exchanges. */
+int ramses_amd_mgamr_comm_set(int level, int ncpu, int myid, const int *em_n, const int *em_list, int list_is_octs, const int *rc_n);
+int ramses_amd_mgamr_halo_stage_out(int level, int comp, int dir, int ncpu, int64_t *h_send_addr, int64_t *h_recv_addr,
+                                    int64_t *send_off, int64_t *recv_off);
+int ramses_amd_mgamr_halo_stage_in(int level, int comp, int dir);
+int ramses_amd_mgamr_halo_rccl(int level, int comp, int dir);
+int ramses_amd_mgamr_stats(int64_t *out4);
 
 /* ---------------------------------------------------------------------------
  * multigrid_fine(ilevel,icount) on an AMR level of a periodic single-rank run, driver AND per-solve

@@ -107,6 +107,11 @@ build_ramses() {
     libs="$libs ${PATCH_LIBS:-}"
     extra_objs="${PATCH_EXTRA_SRC:-}"
   fi
+  if [ -n "$patch" ] && [ -x "$patch/prepare.sh" ]; then
+    # sources a patch derives from the reference tree (generated next to the other stubs, included by its shims)
+    "$patch/prepare.sh" "$REF" "$gen"
+    flags="$flags -I$gen"
+  fi
   # generated stubs the reference's Makefile would create with shell scripts
   cat > "$gen/write_makefile.f90" <<'EOF'
 subroutine output_makefile(filename)

@@ -100,6 +100,11 @@ SYMBOLS = [
     ("ramses_amd_mgamr_restrict", _i, [_i]),
     ("ramses_amd_mgamr_interpolate", _i, [_i]),
     ("ramses_amd_mgamr_end", _i, []),
+    ("ramses_amd_mgamr_comm_set", _i, [_i, _i, _i, _vp, _vp, _i, _vp]),
+    ("ramses_amd_mgamr_halo_stage_out", _i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    ("ramses_amd_mgamr_halo_stage_in", _i, [_i, _i, _i]),
+    ("ramses_amd_mgamr_halo_rccl", _i, [_i, _i, _i]),
+    ("ramses_amd_mgamr_stats", _i, [_vp]),
     ("ramses_amd_poisamr_tree", _i, [_i, _i64, _i64, _vp, _vp, _vp]),
     ("ramses_amd_poisamr_multigrid", _i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i, _d, _i, _i, _i, _vp, _vp, _vp]),
     ("ramses_amd_poisamr_levelmin_mg", _i, []),

@@ -1509,9 +1509,18 @@ struct MgAmrBlock {
   double *h_u;                // the block's host array u(1:ngrid*8, 1:4)
   const int *h_f;             // f(1:ngrid*8, 1)
 };
+// the virtual boundaries of one level of the solve (several ranks): emission = positions in the rank's own part of the
+// layout, per peer; reception = the peer's block of the layout (rc_off octs in, rc_n octs long)
+struct MgAmrComm {
+  bool set = false;
+  int ncpu = 0;
+  std::vector<int> em_first, rc_off, rc_n;
+  DevBuf em_pos;
+};
 struct MgAmrDev {
   int level = 0, ngrid = 0, nact = 0, filled = 0;
   DevBuf igrid, u1, u2, u3, u4, scan;
+  MgAmrComm comm;
   std::vector<MgAmrBlock> blocks;   // (coarse levels; host arrays only valid during the solve)
   MgAmrLevel view() {
     MgAmrLevel L;
@@ -1526,6 +1535,16 @@ struct MgAmrCtx {
   int ilevel = 0;
   long ncoarse = 0, ngridmax = 0, ncell = 0;
   DevBuf son, nbor, father, lookup, vec, ivec, partial, norm;
+  // halo exchanges of the solve: device message buffers, pinned host twins (host-MPI transport), the open exchange
+  DevBuf sendbuf, recvbuf, tmpidx;
+  void *h_send = nullptr, *h_recv = nullptr;
+  size_t h_send_cap = 0, h_recv_cap = 0;
+  std::vector<int64_t> send_off, recv_off;
+  int halo_level = 0, halo_comp = 0, halo_dir = -1;
+  // what crossed PCIe: [0] bytes of level arrays moved by the routines AFTER the first one of the solve uploaded them,
+  // [1] number of such copies, [2] bytes of halo messages (host-MPI transport), [3] halo exchanges
+  long long stats[4] = {0, 0, 0, 0};
+  bool uploaded = false;
   MgAmrDev lev[32];
   // host arrays of the fine level
   double *h_phi = nullptr, *h_f = nullptr;   // f(1:ncell,1:3)
@@ -1545,9 +1564,14 @@ bool g_mg_force_sync = false;     // several MPI ranks: every routine exchanges 
 #define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipfail(e_, what); } while (0)
 
 // (re)load the fine level from the host arrays: phi -> u1, f(:,2) -> u2, f(:,3) -> u4, flag2 -> scan
+static void mgamr_count(size_t bytes) {
+  MgAmrCtx &M = g_mg;
+  if (M.uploaded) { M.stats[0] += (long long)bytes; M.stats[1] += 1; }
+}
 static int mgamr_load_fine(bool with_residual) {
   MgAmrCtx &M = g_mg;
   MgAmrDev &D = M.lev[M.ilevel];
+  mgamr_count(sizeof(double) * (size_t)M.ncell * (with_residual ? 4 : 3) + sizeof(int) * (size_t)M.ncell);
   hipStream_t s = nullptr;
   const long ncell = M.ncell;
   HCHK(M.vec.ensure(sizeof(double) * ncell), "hipMalloc");
@@ -1563,12 +1587,13 @@ static int mgamr_load_fine(bool with_residual) {
   return 0;
 }
 // write one array of the fine level back into its host cell vector (other cells untouched)
-static int mgamr_store_fine(double *h_vec, const double *d_col) {
+static int mgamr_store_fine(double *h_vec, const double *d_col, bool whole_layout = false) {
   MgAmrCtx &M = g_mg;
   MgAmrDev &D = M.lev[M.ilevel];
   hipStream_t s = nullptr;
+  if (M.open) mgamr_count(2 * sizeof(double) * (size_t)M.ncell);
   HCHK(hipMemcpyAsync(M.vec.p, h_vec, sizeof(double) * M.ncell, hipMemcpyHostToDevice, s), "H2D");
-  HCHK(mgamr_launch_scatter(M.vec.as<double>(), d_col, D.igrid.as<int>(), D.nact, D.ngrid, M.ncoarse, M.ngridmax, s), "scatter");
+  HCHK(mgamr_launch_scatter(M.vec.as<double>(), d_col, D.igrid.as<int>(), whole_layout ? D.ngrid : D.nact, D.ngrid, M.ncoarse, M.ngridmax, s), "scatter");
   HCHK(hipMemcpyAsync(h_vec, M.vec.p, sizeof(double) * M.ncell, hipMemcpyDeviceToHost, s), "D2H");
   HCHK(hipStreamSynchronize(s), "sync");
   return 0;
@@ -1581,6 +1606,7 @@ static int mgamr_copy_comp(MgAmrDev &D, DevBuf &dev, int k, bool to_device, bool
     if (B.ngrid == 0 || (mine_only && b > 0)) continue;
     double *host = B.h_u + (size_t)(k - 1) * 8 * B.ngrid;
     double *devp = dev.as<double>() + B.off;
+    mgamr_count(sizeof(double) * 8 * (size_t)B.ngrid);
     if (to_device) HCHK(hipMemcpy2DAsync(devp, sizeof(double) * D.ngrid, host, sizeof(double) * B.ngrid, sizeof(double) * B.ngrid, 8, hipMemcpyHostToDevice, s), "H2D level");
     else HCHK(hipMemcpy2DAsync(host, sizeof(double) * B.ngrid, devp, sizeof(double) * D.ngrid, sizeof(double) * B.ngrid, 8, hipMemcpyDeviceToHost, s), "D2H level");
   }
@@ -1618,8 +1644,10 @@ int ramses_amd_mgamr_begin(int ilevel, int64_t ngridmax, int64_t ncoarse, const 
   const char *e = getenv("RAMSES_AMD_MG_SYNC");
   M.sync = (e && e[0] == '1') || g_mg_force_sync;
   M.open = true; M.ilevel = ilevel; M.ncoarse = ncoarse; M.ngridmax = ngridmax; M.ncell = ncoarse + 8 * ngridmax;
+  M.uploaded = false; M.halo_level = 0; M.halo_dir = -1;
+  for (int k = 0; k < 4; k++) M.stats[k] = 0;
   M.h_phi = phi; M.h_f = f; M.h_flag2 = flag2;
-  for (int l = 0; l < 32; l++) { M.lev[l].ngrid = 0; M.lev[l].nact = 0; M.lev[l].filled = 0; M.lev[l].level = l; M.lev[l].blocks.clear(); }
+  for (int l = 0; l < 32; l++) { M.lev[l].ngrid = 0; M.lev[l].nact = 0; M.lev[l].filled = 0; M.lev[l].level = l; M.lev[l].blocks.clear(); M.lev[l].comm.set = false; }
   HCHK(M.son.ensure(sizeof(int) * M.ncell), "hipMalloc son");
   HCHK(M.nbor.ensure(sizeof(int) * 6 * ngridmax), "hipMalloc nbor");
   HCHK(M.father.ensure(sizeof(int) * ngridmax), "hipMalloc father");
@@ -1715,6 +1743,7 @@ static int mgamr_level(int level, MgAmrDev **out) {
   if (!M.open) return fail(RAMSES_AMD_EINVAL, "AMR multigrid routine called outside begin/end");
   if (level < 1 || level > M.ilevel) return fail(RAMSES_AMD_EINVAL, "level %d is not part of the solve", level);
   *out = &M.lev[level];
+  M.uploaded = true;         // a compute routine runs: the levels are on the device, what moves from here on is counted
   return 0;
 }
 static int mgamr_sync_in(int level, bool with_residual) {
@@ -1781,9 +1810,210 @@ int ramses_amd_mgamr_end(void) {
   MgAmrCtx &M = g_mg;
   if (!M.open) return 0;
   int rc = 0;
-  if (!M.sync) rc = mgamr_store_fine(M.h_phi, M.lev[M.ilevel].u1.as<double>());
+  M.uploaded = false;        // (the solution's way home is part of the solve, not of a routine)
+  // several ranks: the reception octs' phi is current on the device as well (the last make_virtual_fine_dp ran there)
+  if (!M.sync) rc = mgamr_store_fine(M.h_phi, M.lev[M.ilevel].u1.as<double>(), true);
   M.open = false;
+  const char *e = getenv("RAMSES_AMD_MG_STATS");
+  if (e && e[0] == '1') {
+    printf(" ramses_amd: multigrid level %d: level arrays across PCIe after the upload: %lld bytes in %lld copies; halo: %lld bytes in %lld exchanges\n",
+           M.ilevel, M.stats[0], M.stats[1], M.stats[2], M.stats[3]);
+    fflush(stdout);
+  }
   return rc;
+}
+int ramses_amd_mgamr_stats(int64_t *out4) {
+  if (!out4) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  for (int k = 0; k < 4; k++) out4[k] = (int64_t)g_mg.stats[k];
+  return 0;
+}
+
+// ---- virtual boundaries of the levels of the solve (several ranks), on the device -----------------------------------
+// make_virtual_fine_dp(phi / f(:,1)) of the solved level, make_virtual_mg_dp / make_reverse_mg_dp of the multigrid levels
+// (poisson/multigrid_fine_commons.f90:1172-1290,1378-1475): the level's layout is the rank's own octs followed by every
+// peer's reception block, so a forward exchange gathers the emission cells (positions in the own part) into one message per
+// peer and drops what arrives into the peer's block; a reverse exchange sends the blocks and ADDS what arrives to the
+// emission cells, peer by peer in icpu order like the reference (:1443-1457; floating-point addition is not associative).
+// Message layout = the reference's: u(i + (ind-1)*n).
+__global__ void mgamr_pos_from_octs_kernel(const int *octs, int n, const int *lookup, int *pos, int *bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int j = lookup[octs[i] - 1];
+  if (j <= 0) atomicAdd(bad, 1);
+  pos[i] = j - 1;
+}
+__global__ void mgamr_pos_shift_kernel(int *pos, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pos[i] -= 1;
+}
+// buf[ind*n + i] <-> comp[ind*ngrid + pos[i]]  (pos == nullptr: the block of n octs starting at off)
+extern "C++" {
+template <int MODE>   // 0 gather into buf, 1 scatter from buf, 2 add buf
+__global__ void mgamr_halo_kernel(double *__restrict__ comp, int ngrid, const int *__restrict__ pos, int off, int n, double *__restrict__ buf) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 8L * n) return;
+  const int i = (int)(t % n), ind = (int)(t / n);
+  const long c = (long)ind * ngrid + (pos ? pos[i] : off + i);
+  if (MODE == 0) buf[t] = comp[c];
+  else if (MODE == 1) comp[c] = buf[t];
+  else comp[c] = comp[c] + buf[t];
+}
+}  // extern "C++"
+
+int ramses_amd_mgamr_comm_set(int level, int ncpu, int myid, const int *em_n, const int *em_list, int list_is_octs, const int *rc_n) {
+  MgAmrDev *D;
+  if (int rc = mgamr_level(level, &D)) return rc;
+  g_mg.uploaded = false;     // (setup, not a routine)
+  if (ncpu < 1 || myid < 1 || myid > ncpu || !em_n || !rc_n) return fail(RAMSES_AMD_EINVAL, "mgamr_comm_set: bad argument");
+  MgAmrComm &Cm = D->comm;
+  Cm.set = false; Cm.ncpu = ncpu;
+  Cm.em_first.assign((size_t)ncpu + 1, 0); Cm.rc_off.assign((size_t)ncpu, 0); Cm.rc_n.assign((size_t)ncpu, 0);
+  int off = D->nact;
+  for (int c = 0; c < ncpu; c++) {
+    if (em_n[c] < 0 || rc_n[c] < 0) return fail(RAMSES_AMD_EINVAL, "mgamr_comm_set: negative list length");
+    Cm.em_first[c + 1] = Cm.em_first[c] + em_n[c];
+    const int n = c == myid - 1 ? 0 : rc_n[c];
+    Cm.rc_off[c] = off; Cm.rc_n[c] = n;
+    off += n;
+  }
+  if (off != D->ngrid) return fail(RAMSES_AMD_EINVAL, "mgamr_comm_set(level %d): own %d + reception octs = %d, the layout has %d", level, D->nact, off, D->ngrid);
+  const int nem = Cm.em_first[ncpu];
+  if (nem > 0 && !em_list) return fail(RAMSES_AMD_EINVAL, "mgamr_comm_set: NULL list");
+  HCHK(Cm.em_pos.ensure(sizeof(int) * (size_t)(nem > 0 ? nem : 1)), "hipMalloc");
+  if (nem > 0) {
+    hipStream_t s = nullptr;
+    if (list_is_octs) {
+      HCHK(g_mg.tmpidx.ensure(sizeof(int) * ((size_t)nem + 1)), "hipMalloc");
+      int *d_octs = g_mg.tmpidx.as<int>(), *d_bad = d_octs + nem;
+      HCHK(hipMemcpyAsync(d_octs, em_list, sizeof(int) * (size_t)nem, hipMemcpyHostToDevice, s), "H2D emission list");
+      HCHK(hipMemsetAsync(d_bad, 0, sizeof(int), s), "memset");
+      hipLaunchKernelGGL(mgamr_pos_from_octs_kernel, dim3((nem + 255) / 256), dim3(256), 0, s, d_octs, nem, g_mg.lookup.as<int>(), Cm.em_pos.as<int>(), d_bad);
+      int bad = 0;
+      HCHK(hipMemcpy(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost), "D2H");
+      if (bad) return fail(RAMSES_AMD_EINVAL, "mgamr_comm_set(level %d): %d emission octs are not octs of the level", level, bad);
+    } else {
+      HCHK(hipMemcpyAsync(Cm.em_pos.p, em_list, sizeof(int) * (size_t)nem, hipMemcpyHostToDevice, s), "H2D emission list");
+      hipLaunchKernelGGL(mgamr_pos_shift_kernel, dim3((nem + 255) / 256), dim3(256), 0, s, Cm.em_pos.as<int>(), nem);
+      HCHK(hipStreamSynchronize(s), "sync");
+      for (int k = 0; k < nem; k++) if (em_list[k] < 1 || em_list[k] > D->nact) return fail(RAMSES_AMD_EINVAL, "mgamr_comm_set(level %d): emission position %d outside 1..%d", level, em_list[k], D->nact);
+    }
+  }
+  Cm.set = true;
+  return 0;
+}
+
+namespace {
+int mgamr_halo_args(int level, int comp, int dir, MgAmrDev **D, double **vec) {
+  if (int rc = mgamr_level(level, D)) return rc;
+  if (!(*D)->comm.set) return fail(RAMSES_AMD_EINVAL, "level %d: no communicators on the device (ramses_amd_mgamr_comm_set)", level);
+  if (comp < 1 || comp > 4 || dir < 0 || dir > 1) return fail(RAMSES_AMD_EINVAL, "mgamr halo: bad component %d / direction %d", comp, dir);
+  DevBuf *b[4] = {&(*D)->u1, &(*D)->u2, &(*D)->u3, &(*D)->u4};
+  *vec = b[comp - 1]->as<double>();
+  return 0;
+}
+// messages of every peer into sendbuf; offsets in doubles
+int mgamr_halo_pack(MgAmrDev &D, double *vec, int dir) {
+  MgAmrCtx &M = g_mg;
+  MgAmrComm &Cm = D.comm;
+  M.send_off.assign((size_t)Cm.ncpu + 1, 0); M.recv_off.assign((size_t)Cm.ncpu + 1, 0);
+  for (int c = 0; c < Cm.ncpu; c++) {
+    const int64_t ne = 8 * (int64_t)(Cm.em_first[c + 1] - Cm.em_first[c]), nr = 8 * (int64_t)Cm.rc_n[c];
+    M.send_off[c + 1] = M.send_off[c] + (dir == 0 ? ne : nr);
+    M.recv_off[c + 1] = M.recv_off[c] + (dir == 0 ? nr : ne);
+  }
+  const size_t ns = (size_t)M.send_off[Cm.ncpu], nr = (size_t)M.recv_off[Cm.ncpu];
+  HCHK(M.sendbuf.ensure(sizeof(double) * (ns > 0 ? ns : 1)), "hipMalloc sendbuf");
+  HCHK(M.recvbuf.ensure(sizeof(double) * (nr > 0 ? nr : 1)), "hipMalloc recvbuf");
+  for (int c = 0; c < Cm.ncpu; c++) {
+    const int n = (int)((M.send_off[c + 1] - M.send_off[c]) / 8);
+    if (n <= 0) continue;
+    double *buf = M.sendbuf.as<double>() + M.send_off[c];
+    const dim3 g((unsigned)((8L * n + 255) / 256)), b(256);
+    if (dir == 0) hipLaunchKernelGGL(mgamr_halo_kernel<0>, g, b, 0, nullptr, vec, D.ngrid, Cm.em_pos.as<int>() + Cm.em_first[c], 0, n, buf);
+    else hipLaunchKernelGGL(mgamr_halo_kernel<0>, g, b, 0, nullptr, vec, D.ngrid, (const int *)nullptr, Cm.rc_off[c], n, buf);
+  }
+  HCHK(hipGetLastError(), "mgamr halo pack launch");
+  return 0;
+}
+int mgamr_halo_unpack(MgAmrDev &D, double *vec, int dir) {
+  MgAmrCtx &M = g_mg;
+  MgAmrComm &Cm = D.comm;
+  for (int c = 0; c < Cm.ncpu; c++) {      // icpu order: the reverse exchange adds peer by peer
+    const int n = (int)((M.recv_off[c + 1] - M.recv_off[c]) / 8);
+    if (n <= 0) continue;
+    double *buf = M.recvbuf.as<double>() + M.recv_off[c];
+    const dim3 g((unsigned)((8L * n + 255) / 256)), b(256);
+    if (dir == 0) hipLaunchKernelGGL(mgamr_halo_kernel<1>, g, b, 0, nullptr, vec, D.ngrid, (const int *)nullptr, Cm.rc_off[c], n, buf);
+    else hipLaunchKernelGGL(mgamr_halo_kernel<2>, g, b, 0, nullptr, vec, D.ngrid, Cm.em_pos.as<int>() + Cm.em_first[c], 0, n, buf);
+  }
+  HCHK(hipGetLastError(), "mgamr halo unpack launch");
+  return 0;
+}
+int pin_ensure(void *&p, size_t &cap, size_t bytes) {
+  if (bytes <= cap) return 0;
+  if (p) { hipHostFree(p); p = nullptr; cap = 0; }
+  const size_t want = bytes + bytes / 2;
+  HCHK(hipHostMalloc(&p, want, hipHostMallocDefault), "hipHostMalloc");
+  cap = want;
+  return 0;
+}
+}  // namespace
+
+// host-MPI transport (several ranks on one GPU, or no RCCL): stage_out packs on the device and hands pinned host buffers over
+// -- the message for peer icpu at h_send + send_off[icpu-1], likewise h_recv / recv_off -- stage_in applies what arrived
+int ramses_amd_mgamr_halo_stage_out(int level, int comp, int dir, int ncpu, int64_t *h_send_addr, int64_t *h_recv_addr, int64_t *send_off,
+                                    int64_t *recv_off) {
+  MgAmrCtx &M = g_mg;
+  MgAmrDev *D;
+  double *vec;
+  if (!h_send_addr || !h_recv_addr || !send_off || !recv_off) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (int rc = mgamr_halo_args(level, comp, dir, &D, &vec)) return rc;
+  if (ncpu != D->comm.ncpu) return fail(RAMSES_AMD_EINVAL, "ncpu mismatch");
+  if (int rc = mgamr_halo_pack(*D, vec, dir)) return rc;
+  const size_t ns = (size_t)M.send_off[ncpu], nr = (size_t)M.recv_off[ncpu];
+  if (int rc = pin_ensure(M.h_send, M.h_send_cap, sizeof(double) * (ns > 0 ? ns : 1))) return rc;
+  if (int rc = pin_ensure(M.h_recv, M.h_recv_cap, sizeof(double) * (nr > 0 ? nr : 1))) return rc;
+  if (ns > 0) HCHK(hipMemcpyAsync(M.h_send, M.sendbuf.p, sizeof(double) * ns, hipMemcpyDeviceToHost, nullptr), "D2H halo");
+  HCHK(hipStreamSynchronize(nullptr), "sync");
+  *h_send_addr = (int64_t)(intptr_t)M.h_send; *h_recv_addr = (int64_t)(intptr_t)M.h_recv;
+  for (int c = 0; c <= ncpu; c++) { send_off[c] = M.send_off[c]; recv_off[c] = M.recv_off[c]; }
+  M.halo_level = level; M.halo_comp = comp; M.halo_dir = dir;
+  M.stats[2] += (long long)(sizeof(double) * (ns + nr)); M.stats[3] += 1;
+  return 0;
+}
+int ramses_amd_mgamr_halo_stage_in(int level, int comp, int dir) {
+  MgAmrCtx &M = g_mg;
+  MgAmrDev *D;
+  double *vec;
+  if (int rc = mgamr_halo_args(level, comp, dir, &D, &vec)) return rc;
+  if (M.halo_level != level || M.halo_comp != comp || M.halo_dir != dir)
+    return fail(RAMSES_AMD_EINVAL, "mgamr_halo_stage_in(level %d, component %d, dir %d) does not close the exchange stage_out opened (%d, %d, %d)",
+                level, comp, dir, M.halo_level, M.halo_comp, M.halo_dir);
+  M.halo_level = 0; M.halo_dir = -1;
+  const size_t nr = (size_t)M.recv_off[D->comm.ncpu];
+  if (nr > 0) HCHK(hipMemcpyAsync(M.recvbuf.p, M.h_recv, sizeof(double) * nr, hipMemcpyHostToDevice, nullptr), "H2D halo");
+  return mgamr_halo_unpack(*D, vec, dir);
+}
+// the same exchange over RCCL (every rank on its own GPU): one grouped send/recv, nothing crosses PCIe
+extern "C" int ramses_amd_rccl_exchange(int npeer, const int *peer, const double *d_send, const int64_t *send_off, const int64_t *send_cnt,
+                                        double *d_recv, const int64_t *recv_off, const int64_t *recv_cnt, void *stream);
+int ramses_amd_mgamr_halo_rccl(int level, int comp, int dir) {
+  MgAmrCtx &M = g_mg;
+  MgAmrDev *D;
+  double *vec;
+  if (int rc = mgamr_halo_args(level, comp, dir, &D, &vec)) return rc;
+  if (int rc = mgamr_halo_pack(*D, vec, dir)) return rc;
+  std::vector<int> peer;
+  std::vector<int64_t> so, sc, ro, rcn;
+  for (int c = 0; c < D->comm.ncpu; c++) {
+    const int64_t ns = M.send_off[c + 1] - M.send_off[c], nr = M.recv_off[c + 1] - M.recv_off[c];
+    if (ns == 0 && nr == 0) continue;
+    peer.push_back(c); so.push_back(M.send_off[c]); sc.push_back(ns); ro.push_back(M.recv_off[c]); rcn.push_back(nr);
+  }
+  if (int rc = ramses_amd_rccl_exchange((int)peer.size(), peer.data(), M.sendbuf.as<double>(), so.data(), sc.data(), M.recvbuf.as<double>(),
+                                        ro.data(), rcn.data(), nullptr)) return rc;
+  M.stats[3] += 1;
+  return mgamr_halo_unpack(*D, vec, dir);
 }
 
 // ---------------------------------------------------------------------------

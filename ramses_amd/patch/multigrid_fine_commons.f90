@@ -5,13 +5,53 @@
 ! untouched reference file is pulled in by the preprocessor with
 ! multigrid_fine renamed to multigrid_fine_reference, so every other symbol of
 ! that file (recursive_multigrid_coarse, build_parent_comms_mg, make_fine_mask,
-! make_fine_bc_rhs, make_virtual_mg_*, ...) stays the reference's; the new
+! make_fine_bc_rhs, make_virtual_mg_int, ...) stays the reference's; make_virtual_mg_dp
+! and make_reverse_mg_dp are shadowed the same way (below); the new
 ! multigrid_fine(ilevel,icount) keeps the reference's name, arguments and
 ! meaning and runs the V-cycles on the MI355X through the C ABI.
 !==============================================================================
+! (multigrid_fine_commons_ref.f90: the reference's file with the DEFINITIONS of make_virtual_mg_dp and make_reverse_mg_dp
+!  renamed to *_reference, generated into the build directory by prepare.sh -- their callers live in the same file, where a
+!  preprocessor rename would catch the calls too)
 #define multigrid_fine multigrid_fine_reference
-#include "poisson/multigrid_fine_commons.f90"
+#include "multigrid_fine_commons_ref.f90"
 #undef multigrid_fine
+
+!------------------------------------------------------------------------------
+! Virtual boundaries of the multigrid levels (poisson/multigrid_fine_commons.f90:1172-1290, 1378-1475), same names,
+! arguments and meaning.  While a solve runs on the device with several ranks and its levels are resident there
+! (ramses_amd_mg_mpi_resident), active_mg(:,ilevel)%u(:,ivar) lives on the device: the exchange gathers the emission cells
+! there, moves one message per peer (RCCL, or this program's MPI on pinned buffers when ranks share a GPU) and drops /
+! adds what arrives on the device -- the reverse exchange peer by peer in icpu order like the reference.  Before the first
+! device routine of a solve (the masks, ivar=4) and otherwise: the reference's routines.
+!------------------------------------------------------------------------------
+subroutine make_virtual_mg_dp(ivar,ilevel)
+  use amr_commons
+  use ramses_amd_iface
+  implicit none
+  integer::ilevel,ivar
+#ifndef WITHOUTMPI
+  if(ramses_amd_mg_active.and.ramses_amd_mg_started.and.ramses_amd_mg_mpi_resident.and.ncpu>1)then
+     call ramses_amd_mg_halo(ilevel,ivar,0)
+     return
+  end if
+#endif
+  call make_virtual_mg_dp_reference(ivar,ilevel)
+end subroutine make_virtual_mg_dp
+
+subroutine make_reverse_mg_dp(ivar,ilevel)
+  use amr_commons
+  use ramses_amd_iface
+  implicit none
+  integer::ilevel,ivar
+#ifndef WITHOUTMPI
+  if(ramses_amd_mg_active.and.ramses_amd_mg_started.and.ramses_amd_mg_mpi_resident.and.ncpu>1)then
+     call ramses_amd_mg_halo(ilevel,ivar,1)
+     return
+  end if
+#endif
+  call make_reverse_mg_dp_reference(ivar,ilevel)
+end subroutine make_reverse_mg_dp
 
 subroutine multigrid_fine_amd(ilevel,icount)
   use amr_commons

@@ -271,6 +271,31 @@ module ramses_amd_iface
        import :: c_int
        integer(c_int) :: rc
      end function ramses_amd_mgamr_end
+     function ramses_amd_mgamr_comm_set(level, ncpu, myid, em_n, em_list, list_is_octs, rc_n) &
+          & bind(C, name='ramses_amd_mgamr_comm_set') result(rc)
+       import :: c_int
+       integer(c_int), value :: level, ncpu, myid, list_is_octs
+       integer(c_int) :: em_n(*), em_list(*), rc_n(*)
+       integer(c_int) :: rc
+     end function ramses_amd_mgamr_comm_set
+     function ramses_amd_mgamr_halo_stage_out(level, comp, dir, ncpu, h_send_addr, h_recv_addr, send_off, recv_off) &
+          & bind(C, name='ramses_amd_mgamr_halo_stage_out') result(rc)
+       import :: c_int, c_int64_t, c_ptr
+       integer(c_int), value :: level, comp, dir, ncpu
+       type(c_ptr) :: h_send_addr, h_recv_addr        ! int64_t* on the C side: the addresses of the pinned buffers
+       integer(c_int64_t) :: send_off(*), recv_off(*)
+       integer(c_int) :: rc
+     end function ramses_amd_mgamr_halo_stage_out
+     function ramses_amd_mgamr_halo_stage_in(level, comp, dir) bind(C, name='ramses_amd_mgamr_halo_stage_in') result(rc)
+       import :: c_int
+       integer(c_int), value :: level, comp, dir
+       integer(c_int) :: rc
+     end function ramses_amd_mgamr_halo_stage_in
+     function ramses_amd_mgamr_halo_rccl(level, comp, dir) bind(C, name='ramses_amd_mgamr_halo_rccl') result(rc)
+       import :: c_int
+       integer(c_int), value :: level, comp, dir
+       integer(c_int) :: rc
+     end function ramses_amd_mgamr_halo_rccl
      function ramses_amd_poisamr_tree(epoch, ngridmax, ncoarse, son, nbor, father) &
           & bind(C, name='ramses_amd_poisamr_tree') result(rc)
        import :: c_int, c_int64_t
@@ -740,6 +765,11 @@ module ramses_amd_iface
   ! the AMR level whose potential the device multigrid driver has just left on the device (0: none)
   integer, save :: ramses_amd_pois_amr_level = 0
   logical, save :: ramses_amd_mg_mpi_said = .false.
+  ! several ranks: the levels of the solve stay on the device between the routines, their virtual boundaries are exchanged
+  ! from there (ramses_amd_mg_halo); .false. with RAMSES_AMD_MG_MPI_SYNC=1: every routine exchanges its arrays with the host
+  ! and the reference's host exchanges run (the round-2 path, kept as the A/B of the new one)
+  logical, save :: ramses_amd_mg_mpi_resident = .false.
+  logical, save :: ramses_amd_mg_comm_done(64) = .false.
 
 contains
 
@@ -851,8 +881,9 @@ contains
   subroutine ramses_amd_mg_ensure()
     use amr_commons
     use poisson_commons
-    integer :: rc, l, ilevel, icpu, ntot, n, i
+    integer :: rc, l, ilevel, icpu, ntot, n, i, stat
     integer, allocatable :: list(:)
+    character(len=16) :: val
     if (ramses_amd_mg_started) return
     ilevel = ramses_amd_mg_level
     if (ncpu == 1) then
@@ -870,9 +901,23 @@ contains
        ! several ranks: the level's reception octs follow the active ones (their phi, mask and residual are kept current in
        ! the host cell vectors by the reference's make_virtual_fine_dp); every multigrid level is this rank's buffer
        ! followed by its reception buffers active_mg(icpu,l); every device routine exchanges its arrays with the host
-       rc = ramses_amd_mgamr_force_sync(1)
+       ramses_amd_mg_mpi_resident = .true.
+       call get_environment_variable('RAMSES_AMD_MG_MPI_SYNC', val, status=stat)
+       if (stat == 0) then
+          if (trim(val) == '1') ramses_amd_mg_mpi_resident = .false.
+       end if
+       ramses_amd_mg_comm_done = .false.
+       if (ramses_amd_mg_mpi_resident) then
+          rc = ramses_amd_mgamr_force_sync(0)
+       else
+          rc = ramses_amd_mgamr_force_sync(1)
+       end if
        if (.not. ramses_amd_mg_mpi_said .and. myid == 1) then
-          write(*,*) 'ramses_amd: multigrid under MPI: compute routines on the GPUs (own + reception octs), halo exchanges on the host'
+          if (ramses_amd_mg_mpi_resident) then
+             write(*,*) 'ramses_amd: multigrid under MPI: levels resident on the GPUs (own + reception octs), virtual boundaries exchanged from the device'
+          else
+             write(*,*) 'ramses_amd: multigrid under MPI: compute routines on the GPUs (own + reception octs), halo exchanges on the host'
+          end if
           ramses_amd_mg_mpi_said = .true.
        end if
        ntot = active(ilevel)%ngrid
@@ -1558,6 +1603,98 @@ contains
     rc = ramses_amd_amrres_halo_stage_in(ilevel, dir)
     if (rc /= 0) call ramses_amd_fatal('virtual boundaries of an AMR level (unpack)')
   end subroutine ramses_amd_amr_halo
+#endif
+
+#ifndef WITHOUTMPI
+  !---------------------------------------------------------------------------
+  ! One virtual-boundary exchange of a level of the running multigrid solve, on the device (several ranks):
+  !   level = the solved level:  comp 1 phi, 3 the residual f(:,1)      make_virtual_fine_dp  (amr/virtual_boundaries.f90:373-528)
+  !   a multigrid level:         comp = ivar of active_mg(:,level)%u     make_virtual_mg_dp / make_reverse_mg_dp
+  !                                                                      (poisson/multigrid_fine_commons.f90:1172-1290,1378-1475)
+  ! dir 0 forward, 1 reverse (added peer by peer in icpu order).  RCCL, or the program's own MPI on pinned host buffers when
+  ! ranks share a GPU.  The communicators go to the device with the first exchange of a level in a solve.
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_mg_halo(level, comp, dir)
+    use amr_commons
+    use poisson_commons
+    use mpi_mod
+    integer, intent(in) :: level, comp, dir
+    integer :: rc, icpu, info, nreq, cnt, n, i, isoct
+    type(c_ptr) :: hs, hr
+    real(c_double), pointer :: sbuf(:), rbuf(:)
+    integer(c_int64_t), dimension(ncpu + 1) :: soff, roff
+    integer, dimension(2*ncpu) :: req
+    integer, dimension(MPI_STATUS_SIZE, 2*ncpu) :: statuses
+    integer, dimension(ncpu) :: em_n, rc_n
+    integer, allocatable :: em_list(:)
+    integer, parameter :: tag = 139
+    if (.not. ramses_amd_mg_comm_done(level)) then
+       n = 0
+       if (level == ramses_amd_mg_level) then
+          isoct = 1
+          do icpu = 1, ncpu
+             em_n(icpu) = emission(icpu, level)%ngrid
+             rc_n(icpu) = reception(icpu, level)%ngrid
+             n = n + em_n(icpu)
+          end do
+          allocate(em_list(max(n, 1)))
+          n = 0
+          do icpu = 1, ncpu
+             do i = 1, em_n(icpu)
+                em_list(n + i) = emission(icpu, level)%igrid(i)
+             end do
+             n = n + em_n(icpu)
+          end do
+       else
+          isoct = 0
+          do icpu = 1, ncpu
+             em_n(icpu) = emission_mg(icpu, level)%ngrid
+             rc_n(icpu) = active_mg(icpu, level)%ngrid
+             n = n + em_n(icpu)
+          end do
+          rc_n(myid) = 0
+          allocate(em_list(max(n, 1)))
+          n = 0
+          do icpu = 1, ncpu
+             do i = 1, em_n(icpu)
+                em_list(n + i) = emission_mg(icpu, level)%igrid(i)
+             end do
+             n = n + em_n(icpu)
+          end do
+       end if
+       rc = ramses_amd_mgamr_comm_set(level, ncpu, myid, em_n, em_list, isoct, rc_n)
+       deallocate(em_list)
+       if (rc /= 0) call ramses_amd_fatal('multigrid_fine (communicators of a level of the solve)')
+       ramses_amd_mg_comm_done(level) = .true.
+    end if
+    if (ramses_amd_halo_rccl) then
+       rc = ramses_amd_mgamr_halo_rccl(level, comp, dir)
+       if (rc /= 0) call ramses_amd_fatal('multigrid_fine (virtual boundaries, RCCL exchange)')
+       return
+    end if
+    rc = ramses_amd_mgamr_halo_stage_out(level, comp, dir, ncpu, hs, hr, soff, roff)
+    if (rc /= 0) call ramses_amd_fatal('multigrid_fine (virtual boundaries, pack)')
+    call c_f_pointer(hs, sbuf, [max(soff(ncpu + 1), 1_8)])
+    call c_f_pointer(hr, rbuf, [max(roff(ncpu + 1), 1_8)])
+    nreq = 0
+    do icpu = 1, ncpu
+       cnt = int(roff(icpu + 1) - roff(icpu))
+       if (cnt > 0) then
+          nreq = nreq + 1
+          call MPI_IRECV(rbuf(roff(icpu) + 1), cnt, MPI_DOUBLE_PRECISION, icpu - 1, tag, MPI_COMM_WORLD, req(nreq), info)
+       end if
+    end do
+    do icpu = 1, ncpu
+       cnt = int(soff(icpu + 1) - soff(icpu))
+       if (cnt > 0) then
+          nreq = nreq + 1
+          call MPI_ISEND(sbuf(soff(icpu) + 1), cnt, MPI_DOUBLE_PRECISION, icpu - 1, tag, MPI_COMM_WORLD, req(nreq), info)
+       end if
+    end do
+    call MPI_WAITALL(nreq, req, statuses, info)
+    rc = ramses_amd_mgamr_halo_stage_in(level, comp, dir)
+    if (rc /= 0) call ramses_amd_fatal('multigrid_fine (virtual boundaries, unpack)')
+  end subroutine ramses_amd_mg_halo
 #endif
 
   !---------------------------------------------------------------------------

@@ -28,6 +28,10 @@
 ! (:857-867).  A level the host has just rebuilt (refine_fine; it is re-sent to
 ! the device before the next device routine) takes the reference's path; a level
 ! current on both sides takes both, so that both stay current.
+!
+! While a multigrid solve of a level runs on the device with several ranks
+! (poisson/multigrid_fine_commons.f90:194-257), make_virtual_fine_dp on phi and on the
+! residual f(:,1) of that level exchanges the device arrays (ramses_amd_mg_halo).
 !==============================================================================
 #define make_virtual_fine_dp make_virtual_fine_dp_reference
 #define make_virtual_reverse_dp make_virtual_reverse_dp_reference
@@ -40,12 +44,33 @@
 subroutine make_virtual_fine_dp(xx,ilevel)
   use amr_commons
   use hydro_commons
+  use poisson_commons, only: phi, f
   use ramses_amd_iface
   implicit none
   integer::ilevel
   real(dp),dimension(1:ncoarse+ngridmax*twotondim)::xx
 #ifndef WITHOUTMPI
   integer::k
+  ! the level a device multigrid solve is running on (several ranks, levels resident): phi and the residual f(:,1) live on
+  ! the device between the routines of the solve (poisson/multigrid_fine_commons.f90:194-257); their virtual boundaries are
+  ! exchanged from there
+  if(ramses_amd_mg_active.and.ramses_amd_mg_started.and.ramses_amd_mg_mpi_resident.and.ncpu>1)then
+     if(ilevel==ramses_amd_mg_level)then
+        if(ramses_amd_which_column(xx,phi,int(ncoarse,8)+int(twotondim,8)*int(ngridmax,8),1)==1)then
+           call ramses_amd_mg_halo(ilevel,1,0)
+           return
+        end if
+        k=ramses_amd_which_column(xx,f,int(ncoarse,8)+int(twotondim,8)*int(ngridmax,8),3)
+        if(k==1)then
+           call ramses_amd_mg_halo(ilevel,3,0)
+           return
+        end if
+        if(k/=0)then
+           write(*,*)'ramses_amd: make_virtual_fine_dp on f(:,',k,') while the level is solved on the device'
+           call ramses_amd_fatal('make_virtual_fine_dp (multigrid level)')
+        end if
+     end if
+  end if
   if(ramses_amd_mpi_on)then
      if(ramses_amd_mpires_active()/=0)then
         k=ramses_amd_mpires_which(xx)

@@ -1,13 +1,16 @@
-"""GPU test of the AMR multigrid under MPI: the patched MPI program
+"""GPU test of the AMR multigrid under MPI (round 2, item 3): the patched MPI program
 (oracle/_ref/ramses3d_mpi_patch) on 2 and 4 ranks runs hydro + self-gravity on AMR levels 3-5.  Every level
-(levelmin included) takes the reference's own multigrid driver with its halo exchanges on the host
-(make_virtual_fine_dp, make_virtual_mg_dp, make_reverse_mg_dp, the MPI_ALLREDUCE of the norms) and every
-compute routine -- Gauss-Seidel fine / coarse with the masked branch, residual, norm, restriction,
-prolongation -- on the rank's GPU, over the rank's own octs followed by the reception octs of its neighbours
-(csrc/capi.hip: ramses_amd_mgamr_level_begin / _level_block / _fine_active; the arrays cross PCIe around
-every routine, which is what keeps the reference's host halo code usable).  phi, f, the hydro state of every
-leaf cell and the V-cycle counts must equal the untouched MPI reference (oracle/_ref/ramses3d_mpi, same rank
-count) bit for bit."""
+(levelmin included) takes the reference's own multigrid driver (the MPI_ALLREDUCE of the norms stays with it) and
+every compute routine -- Gauss-Seidel fine / coarse with the masked branch, residual, norm, restriction,
+prolongation -- runs on the rank's GPU, over the rank's own octs followed by the reception octs of its neighbours
+(csrc/capi.hip: ramses_amd_mgamr_level_begin / _level_block / _fine_active).
+  default (round 3)          the levels of the solve STAY on the device between the routines; make_virtual_fine_dp on phi and
+                             the residual, make_virtual_mg_dp and make_reverse_mg_dp exchange the device arrays
+                             (ramses_amd_mgamr_halo_*): no level array crosses PCIe after the upload -- asserted on the
+                             transfer counters the library prints with RAMSES_AMD_MG_STATS=1
+  RAMSES_AMD_MG_MPI_SYNC=1   (round 2) the arrays cross PCIe around every routine and the reference's host exchanges run.
+phi, f, the hydro state of every leaf cell and the V-cycle counts must equal the untouched MPI reference
+(oracle/_ref/ramses3d_mpi, same rank count) bit for bit."""
 import importlib.util
 import os
 import re
@@ -48,19 +51,34 @@ def _sorted(snap):
     return snap["level"][order], snap["x"][order], snap["prim"][:, order], snap["grav"][:, order]
 
 
-@pytest.mark.parametrize("nproc,resident", [(2, "1"), (4, "1"), (2, "0")])
-def test_amr_multigrid_under_mpi_equals_the_mpi_reference(gpu_lib, nproc, resident):
+@pytest.mark.parametrize("nproc,resident,mgsync", [(2, "1", "0"), (4, "1", "0"), (8, "1", "0"), (2, "0", "0"), (2, "1", "1"), (4, "1", "1")])
+def test_amr_multigrid_under_mpi_equals_the_mpi_reference(gpu_lib, nproc, resident, mgsync):
     """resident=1 (default): the hydro state and the tree stay on every rank's GPU as well (virtual-boundary
     exchanges of uold / unew on the device, the acceleration mirrored incl. the virtual octs, density back for
-    rho_fine); resident=0 (RAMSES_AMD_RESIDENT_AMR_MPI=0): hydro arrays staged around every call."""
+    rho_fine); resident=0 (RAMSES_AMD_RESIDENT_AMR_MPI=0): hydro arrays staged around every call.
+    mgsync=0 (default): the multigrid levels stay on the device during a solve; 1: RAMSES_AMD_MG_MPI_SYNC=1."""
     if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED_MPI)):
         pytest.skip("oracle/_ref/ramses3d_mpi[_patch] not built")
+    if nproc > (os.cpu_count() or 1):
+        pytest.skip("fewer cores than ranks")
     from oracle import ramses_snapshot as rs
     nml = _mka().selfgrav_namelist().replace("ngridtot=6000 !", "ngridtot=60000 !")
-    workp, outp = _run(nml, PATCHED_MPI, nproc, {"RAMSES_AMD": "1", "RAMSES_AMD_RESIDENT_AMR_MPI": resident})
+    env = {"RAMSES_AMD": "1", "RAMSES_AMD_RESIDENT_AMR_MPI": resident, "RAMSES_AMD_MG_STATS": "1"}
+    if mgsync == "1":
+        env["RAMSES_AMD_MG_MPI_SYNC"] = "1"
+    workp, outp = _run(nml, PATCHED_MPI, nproc, env)
     try:
         assert ("AMR levels stay resident on the GPU" in outp) == (resident == "1"), outp[-1500:]
-        assert "multigrid under MPI: compute routines on the GPUs" in outp, outp[-1500:]
+        stats = [[int(v) for v in m] for m in re.findall(
+            r"multigrid level\s+\d+: level arrays across PCIe after the upload:\s*(\d+) bytes in\s*(\d+) copies; halo:\s*(\d+) bytes in\s*(\d+) exchanges", outp)]
+        assert len(stats) >= nproc          # every rank reports every solve
+        if mgsync == "1":
+            assert "multigrid under MPI: compute routines on the GPUs (own + reception octs), halo exchanges on the host" in outp, outp[-1500:]
+            assert all(s[0] > 0 and s[3] == 0 for s in stats)
+        else:
+            assert "multigrid under MPI: levels resident on the GPUs" in outp, outp[-1500:]
+            assert all(s[0] == 0 and s[1] == 0 for s in stats), stats[:4]      # no level array crossed PCIe after the upload
+            assert sum(s[3] for s in stats) > 100 and sum(s[2] for s in stats) > 0      # the exchanges ran on the device arrays
         sol_p = re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+)", outp)
         got = _sorted(rs.load_leaf_cells(os.path.join(workp, "output_00002"), with_grav=True))
     finally:
