@@ -73,7 +73,7 @@ def test_amr_multigrid_under_mpi_equals_the_mpi_reference(gpu_lib, nproc, reside
             r"multigrid level\s+\d+: level arrays across PCIe after the upload:\s*(\d+) bytes in\s*(\d+) copies; halo:\s*(\d+) bytes in\s*(\d+) exchanges", outp)]
         assert len(stats) >= nproc          # every rank reports every solve
         if mgsync == "1":
-            assert "multigrid under MPI: compute routines on the GPUs (own + reception octs), halo exchanges on the host" in outp, outp[-1500:]
+            assert "multigrid under MPI: compute routines on the GPUs" in outp, outp[-1500:]      # (list-directed output wraps the line)
             assert all(s[0] > 0 and s[3] == 0 for s in stats)
         else:
             assert "multigrid under MPI: levels resident on the GPUs" in outp, outp[-1500:]
