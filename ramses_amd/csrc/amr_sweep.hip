@@ -349,8 +349,8 @@ __global__ __launch_bounds__(64 * OCTS_PER_BLOCK) void amr_godunov_kernel(AmrSwe
 // single-oct waves gather 8 x 216 cells, trace 8 x 64 and solve 8 x 36 interfaces.  Every cell,
 // slope, traced state and flux is the same function of the same stencil values as in the
 // single-oct kernel (and in the reference), so the results are bit-identical; octs of the group
-// that are not in the call's list (posof < 0) are left alone.  Options this variant does not
-// carry (difmag, pressure_fix) take the single-oct kernel.
+// that are not in the call's list (posof < 0) are left alone.  pressure_fix and difmag ride along as template flags
+// (PFIX, DIFMAG); only scheme='plmde' with pressure_fix takes the single-oct kernel.
 // ===========================================================================
 constexpr int GRP_THREADS = 256;
 // workgroups per CU the register allocation must allow (256 threads: waves per SIMD).  The kernel is latency-bound: measured
@@ -387,10 +387,27 @@ template <bool PFIX>
 struct GrpTmp { double tp[3][2][80]; };
 template <>
 struct GrpTmp<false> {};
+// difmag (cmpdivu + consup, hydro/uplmde.f90:702-866): the conserved variables of the 160 traced cells and the velocity
+// divergence at the 5^3 cell corners of the updated block
+template <int NV, bool DIFMAG>
+struct GrpDif { double uc[NV][160]; double divc[125]; };
+template <int NV>
+struct GrpDif<NV, false> {};
+// slot of cell (i, j, k) of the 6^3 trace block among the 160 traced cells (the thread that traces it), -1: an edge / corner
+// cell.  Threads 0..63 own the inner 4^3, threads 64 + 16 f + (pb - 1) + 4 (pc - 1) the shell of face f = 2 axis + high.
+__device__ __forceinline__ int trace_slot(int i, int j, int k) {
+  const bool ei = i == 0 || i == 5, ej = j == 0 || j == 5, ek = k == 0 || k == 5;
+  const int ne = (ei ? 1 : 0) + (ej ? 1 : 0) + (ek ? 1 : 0);
+  if (ne == 0) return (i - 1) + 4 * (j - 1) + 16 * (k - 1);
+  if (ne > 1) return -1;
+  if (ei) return 64 + 16 * (0 + (i == 5 ? 1 : 0)) + (j - 1) + 4 * (k - 1);
+  if (ej) return 64 + 16 * (2 + (j == 5 ? 1 : 0)) + (i - 1) + 4 * (k - 1);
+  return 64 + 16 * (4 + (k == 5 ? 1 : 0)) + (i - 1) + 4 * (j - 1);
+}
 #define GU(s, v) u[v][s]
 #define GF(arr, d, r, v) f.arr[d][v][r]
-template <int NV, bool PFIX>
-struct GrpLds : GrpTmp<PFIX> {
+template <int NV, bool PFIX, bool DIFMAG>
+struct GrpLds : GrpTmp<PFIX>, GrpDif<NV, DIFMAG> {
   union {
     double u[NV][GRP_STENCIL]; // primitive variables of the 8^3 stencil (until the traces are done)
     GrpFaces<NV> f;
@@ -410,7 +427,7 @@ __device__ __forceinline__ int gface(int a, int b, int c) { return a * 16 + b + 
 // u = the stencil [NV][GRP_STENCIL] in LDS.
 template <int NV, bool GRAV>
 __device__ __forceinline__ void grp_fill_missing(const AmrSweepArgs &A, int c0, int t, double *__restrict__ u,
-                                                          unsigned char *__restrict__ ok) {
+                                                          unsigned char *__restrict__ ok, double *__restrict__ uc) {
   const HydroConst &P = A.P;
   const long ncell = A.ncell;
   const int i0 = 2 * (t & 3), j0 = 2 * ((t >> 2) & 3), k0 = 2 * (t >> 4);
@@ -440,6 +457,17 @@ __device__ __forceinline__ void grp_fill_missing(const AmrSweepArgs &A, int c0, 
 #pragma unroll
       for (int v = 0; v < NV; v++) u[v * GRP_STENCIL + s] = q[v];
       ok[s] = 0;
+      if (uc) {
+        // difmag: the interpolated conserved variables of the traced cells (the reference's uloc)
+        const int i6 = i0 + (ind & 1) - 1, j6 = j0 + ((ind >> 1) & 1) - 1, k6 = k0 + (ind >> 2) - 1;
+        if (i6 >= 0 && i6 <= 5 && j6 >= 0 && j6 <= 5 && k6 >= 0 && k6 <= 5) {
+          const int sl = trace_slot(i6, j6, k6);
+          if (sl >= 0) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) uc[v * 160 + sl] = u2[ind][v];
+          }
+        }
+      }
     }
   } else {
     // no father cell: nothing that is stored depends on these cells; keep them finite
@@ -474,10 +502,10 @@ __global__ __launch_bounds__(256) void amr_group_walk_kernel(AmrSweepArgs A, con
   group_walk_block(A, blockIdx.x, groups, ngroups, posof, walk);
 }
 
-template <int ST, int RS, bool GRAV, int NV, int SCHEME, bool PFIX>
+template <int ST, int RS, bool GRAV, int NV, int SCHEME, bool PFIX, bool DIFMAG>
 __global__ __launch_bounds__(GRP_THREADS, GRP_MINWAVES) void amr_group_kernel(AmrSweepArgs A, const int *__restrict__ groups,
                                                                  const int *__restrict__ posof, const int *__restrict__ walk) {
-  __shared__ GrpLds<NV, PFIX> L;
+  __shared__ GrpLds<NV, PFIX, DIFMAG> L;
   const int t = threadIdx.x;
   const HydroConst &P = A.P;
   // Workgroup b runs on XCD b % 8 (each with its own L2).  Neighbouring father octs read the same ghost octs: give every
@@ -549,7 +577,11 @@ __global__ __launch_bounds__(GRP_THREADS, GRP_MINWAVES) void amr_group_kernel(Am
   // interpol_hydro's stencil cost the kernel 136 spilled registers; without the branch it runs 5 % faster, 2.33 vs 2.46 ms
   // on the 256^3 tree -- and as a call to a function of its own 3.4x SLOWER, 7.98 ms: the callee's private arrays become a
   // stack frame every wave of the kernel has to reserve.)
-  if (t < 64 && L.tab[64 + t] == 0) grp_fill_missing<NV, GRAV>(A, L.tab[t], t, &L.u[0][0], L.ok);
+  {
+    double *ucp = nullptr;
+    if constexpr (DIFMAG) ucp = &L.uc[0][0];
+    if (t < 64 && L.tab[64 + t] == 0) grp_fill_missing<NV, GRAV>(A, L.tab[t], t, &L.u[0][0], L.ok, ucp);
+  }
   __syncthreads();
 
   // a father cell that an active son needs and that does not exist: the tree breaks the refinement rules
@@ -576,6 +608,36 @@ __global__ __launch_bounds__(GRP_THREADS, GRP_MINWAVES) void amr_group_kernel(Am
     ti = (f >> 1) == 0 ? pa : pb;
     tj = (f >> 1) == 1 ? pa : ((f >> 1) == 0 ? pb : pc);
     tk = (f >> 1) == 2 ? pa : pc;
+  }
+  if constexpr (DIFMAG) {
+    // conserved variables of the traced cells of existing octs (missing octs: filled by grp_fill_missing)
+    if (tracer) {
+      const int i3 = ti + 1, j3 = tj + 1, k3 = tk + 1;
+      const int f = (i3 >> 1) + 4 * ((j3 >> 1) + 4 * (k3 >> 1)), ind = (i3 & 1) + 2 * (j3 & 1) + 4 * (k3 & 1);
+      const int og = L.tab[64 + f];
+      if (og > 0) {
+        const long cell = A.ncoarse + (long)ind * A.ngridmax + og;
+#pragma unroll
+        for (int v = 0; v < NV; v++) L.uc[v][t] = A.uold[(long)v * ncell + cell - 1];
+      }
+    }
+    // cmpdivu (hydro/uplmde.f90:702-764): velocity divergence at the 5^3 corners (i,j,k = 1..5 in the reference's flux
+    // indexing; corner i sits on the low side of stencil cell i + 1), by the threads that do not trace
+    const int tcn = t - (GRP_THREADS - 125);
+    if (tcn >= 0) {
+      const int ci = tcn % 5 + 2, cj = (tcn / 5) % 5 + 2, ck = tcn / 25 + 2;
+      const double fct = 0.25 / A.dx;
+      auto Q = [&](int di, int dj, int dk, int v) { return L.GU(gsidx(ci + di, cj + dj, ck + dk), v); };
+      double ux = 0.0, vy = 0.0, wz = 0.0;
+      ux = ux + fct * (Q(0, 0, 0, 1) - Q(-1, 0, 0, 1));
+      ux = ux + fct * (Q(0, -1, 0, 1) - Q(-1, -1, 0, 1));
+      vy = vy + fct * (Q(0, 0, 0, 2) - Q(0, -1, 0, 2) + Q(-1, 0, 0, 2) - Q(-1, -1, 0, 2));
+      ux = ux + fct * (Q(0, 0, -1, 1) - Q(-1, 0, -1, 1) + Q(0, -1, -1, 1) - Q(-1, -1, -1, 1));
+      vy = vy + fct * (Q(0, 0, -1, 2) - Q(0, -1, -1, 2) + Q(-1, 0, -1, 2) - Q(-1, -1, -1, 2));
+      wz = wz + fct * (Q(0, 0, 0, 3) - Q(0, 0, -1, 3) + Q(0, -1, 0, 3) - Q(0, -1, -1, 3) + Q(-1, 0, 0, 3) - Q(-1, 0, -1, 3) +
+                       Q(-1, -1, 0, 3) - Q(-1, -1, -1, 3));
+      L.divc[tcn] = ux + vy + wz;
+    }
   }
   if (tracer) {
     const int s = gsidx(ti + 1, tj + 1, tk + 1);
@@ -641,6 +703,34 @@ __global__ __launch_bounds__(GRP_THREADS, GRP_MINWAVES) void amr_group_kernel(Am
       else scaled_interface_flux<RS, NV, 2>(qL, qR, P, A.dt, A.dx, A.rdx, dtdx, pow2, fx);
     }
     const int t0 = d == 0 ? 1 : 0, t1 = d == 2 ? 1 : 2;
+    if constexpr (DIFMAG) {
+      // consup (hydro/uplmde.f90:769-866): the face's flux index along d is a + 1, the own cells' transverse indices are
+      // b + 1, c + 1; corner (i,j,k) lives at divc[(i-1) + 5 (j-1) + 25 (k-1)]
+      int fi[3];
+      fi[d] = a + 1; fi[t0] = b + 1; fi[t1] = c + 1;
+      auto DV = [&](int i, int j, int k) { return L.divc[(i - 1) + 5 * (j - 1) + 25 * (k - 1)]; };
+      const int i = fi[0], j = fi[1], k = fi[2];
+      const double factor = 0.25;
+      double div1;
+      if (d == 0) {
+        div1 = factor * DV(i, j, k);
+        div1 = div1 + factor * DV(i, j + 1, k);
+        div1 = div1 + factor * (DV(i, j, k + 1) + DV(i, j + 1, k + 1));
+      } else if (d == 1) {
+        div1 = 0.0;
+        div1 = div1 + factor * (DV(i, j, k) + DV(i + 1, j, k));
+        div1 = div1 + factor * (DV(i, j, k + 1) + DV(i + 1, j, k + 1));
+      } else {
+        div1 = factor * (DV(i, j, k) + DV(i + 1, j, k) + DV(i, j + 1, k) + DV(i + 1, j + 1, k));
+      }
+      div1 = A.difmag * __builtin_fmin(0.0, div1);
+      // conserved variables of the two cells of the face (coordinates in the 6^3 trace block = the reference's cell index)
+      int cr6[3] = {fi[0], fi[1], fi[2]}, cl6[3] = {fi[0], fi[1], fi[2]};
+      cl6[d] -= 1;
+      const int ir = trace_slot(cr6[0], cr6[1], cr6[2]), il = trace_slot(cl6[0], cl6[1], cl6[2]);
+#pragma unroll
+      for (int v = 0; v < NV; v++) fx[v] = fx[v] + A.dt * div1 * (L.uc[v][ir] - L.uc[v][il]);
+    }
     int cl[3];
     cl[d] = a + 1; cl[t0] = b + 2; cl[t1] = c + 2;            // stencil coordinates of the low cell of the face
     const int sl = gsidx(cl[0], cl[1], cl[2]);
@@ -889,24 +979,29 @@ template <int ST, int RS, int NV>
 static hipError_t launch3(const AmrSweepArgs &A, const int *groups, int ngroups, const int *posof, const int *walk, hipStream_t s) {
   if (ngroups > 0) {
     const dim3 grid(ngroups), block(GRP_THREADS);
+    const bool dif = A.difmag > 0.0;
+#define RAMSES_AMD_GRP(SCH, PF, DF)                                                                                           \
+  do {                                                                                                                        \
+    if (A.grav) hipLaunchKernelGGL((amr_group_kernel<ST, RS, true, NV, SCH, PF, DF>), grid, block, 0, s, A, groups, posof, walk);  \
+    else hipLaunchKernelGGL((amr_group_kernel<ST, RS, false, NV, SCH, PF, DF>), grid, block, 0, s, A, groups, posof, walk);        \
+    return hipGetLastError();                                                                                                 \
+  } while (0)
     if (A.scheme == 1) {
       if constexpr (NV == 5) {
-        if (A.grav) hipLaunchKernelGGL((amr_group_kernel<ST, RS, true, NV, 1, false>), grid, block, 0, s, A, groups, posof, walk);
-        else hipLaunchKernelGGL((amr_group_kernel<ST, RS, false, NV, 1, false>), grid, block, 0, s, A, groups, posof, walk);
-        return hipGetLastError();
+        if (dif) RAMSES_AMD_GRP(1, false, true);
+        RAMSES_AMD_GRP(1, false, false);
       } else {
         return hipErrorInvalidValue;
       }
     }
     if (A.divu) {
       // pressure_fix (the launcher sends plmde + pressure_fix to the single-oct kernel)
-      if (A.grav) hipLaunchKernelGGL((amr_group_kernel<ST, RS, true, NV, 0, true>), grid, block, 0, s, A, groups, posof, walk);
-      else hipLaunchKernelGGL((amr_group_kernel<ST, RS, false, NV, 0, true>), grid, block, 0, s, A, groups, posof, walk);
-      return hipGetLastError();
+      if (dif) RAMSES_AMD_GRP(0, true, true);
+      RAMSES_AMD_GRP(0, true, false);
     }
-    if (A.grav) hipLaunchKernelGGL((amr_group_kernel<ST, RS, true, NV, 0, false>), grid, block, 0, s, A, groups, posof, walk);
-    else hipLaunchKernelGGL((amr_group_kernel<ST, RS, false, NV, 0, false>), grid, block, 0, s, A, groups, posof, walk);
-    return hipGetLastError();
+    if (dif) RAMSES_AMD_GRP(0, false, true);
+    RAMSES_AMD_GRP(0, false, false);
+#undef RAMSES_AMD_GRP
   }
   const int blocks = (A.ngrid + OCTS_PER_BLOCK - 1) / OCTS_PER_BLOCK;
   const dim3 grid(blocks), block(64 * OCTS_PER_BLOCK);
@@ -972,7 +1067,7 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A_in, int slope_type, int riem
     const char *env = getenv("RAMSES_AMD_AMR_GROUP");
     use_groups = !(env && env[0] == '0');
   }
-  if (use_groups && !(A.difmag > 0.0) && !(A.divu != nullptr && A.scheme == 1)) {
+  if (use_groups && !(A.divu != nullptr && A.scheme == 1)) {
     e = hipMemsetAsync(count, 0, sizeof(int), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(amr_group_build_kernel, dim3((A.ngrid + 1023) / 1024), dim3(1024), 0, s, A, posof, groups, count);

@@ -454,11 +454,21 @@ int ramses_amd_mg_tune(int fused) {
 }
 // 4 colour passes (2 red-black sweeps) from *cur, optionally with the residual (+norm) of the
 // result; on return *cur points at the result and *other at the scratch copy
+// rhs_c / u1_c (optional, with *restricted): the level below; if the smoother of this configuration can restrict its own
+// residual it does (the residual is then NOT stored in res) and *restricted is set -- otherwise the caller restricts res
 static hipError_t mg_smooth4(double **cur, double **other, const double *rhs, double *res, double *partial,
-                             double *norm, int n, double dx, hipStream_t s) {
+                             double *norm, int n, double dx, hipStream_t s, double *rhs_c = nullptr, double *u1_c = nullptr,
+                             bool *restricted = nullptr) {
   hipError_t e;
+  if (restricted) *restricted = false;
   if (g_mg_split_rows) {
     if ((e = mg_launch_smooth_fused(*cur, *other, rhs, nullptr, nullptr, nullptr, n, dx, 2, s)) != hipSuccess) return e;
+    static int fuse_restrict = -1;       // RAMSES_AMD_MG_FUSE_RESTRICT=0: the restriction in a pass of its own (A/B; same bits)
+    if (fuse_restrict < 0) { const char *ev = getenv("RAMSES_AMD_MG_FUSE_RESTRICT"); fuse_restrict = !(ev && ev[0] == '0'); }
+    if (rhs_c && u1_c && restricted && fuse_restrict && mg_smooth_can_restrict(n, 2)) {
+      *restricted = true;
+      return mg_launch_smooth_fused(*other, *cur, rhs, nullptr, partial, norm, n, dx, 2, s, 0, rhs_c, u1_c);
+    }
     return mg_launch_smooth_fused(*other, *cur, rhs, res, partial, norm, n, dx, 2, s);
   }
   if ((e = mg_launch_smooth_fused(*cur, *other, rhs, res, partial, norm, n, dx, 4, s)) != hipSuccess) return e;
@@ -525,8 +535,10 @@ static hipError_t mg_coarse_cycle(double *w, int level, int l, int safe, hipStre
     if (n >= MG_FUSED_MIN_N) {
       // pre-smoothing + residual, correction, post-smoothing; the result ends in u1
       double *cur = u1, *oth = w + mg_hier_offset(level, l, 3);
-      if ((e = mg_smooth4(&cur, &oth, u2, u3, partial, nullptr, n, dx, s)) != hipSuccess) return e;
-      if ((e = mg_launch_restrict(u3, w + mg_hier_offset(level, l - 1, 1), w + mg_hier_offset(level, l - 1, 0), n, s)) != hipSuccess) return e;
+      bool restricted = false;
+      if ((e = mg_smooth4(&cur, &oth, u2, u3, partial, nullptr, n, dx, s, w + mg_hier_offset(level, l - 1, 1), w + mg_hier_offset(level, l - 1, 0),
+                          &restricted)) != hipSuccess) return e;
+      if (!restricted && (e = mg_launch_restrict(u3, w + mg_hier_offset(level, l - 1, 1), w + mg_hier_offset(level, l - 1, 0), n, s)) != hipSuccess) return e;
       if ((e = mg_coarse_cycle(w, level, l - 1, safe, s)) != hipSuccess) return e;
       if ((e = mg_launch_interp(cur, w + mg_hier_offset(level, l - 1, 0), n, s)) != hipSuccess) return e;
       if ((e = mg_smooth4(&cur, &oth, u2, nullptr, nullptr, nullptr, n, dx, s)) != hipSuccess) return e;
@@ -629,8 +641,11 @@ int ramses_amd_multigrid_fine_brick(int level, const double *d_rho, double rho_t
   for (;;) {
     iter++;
     double *cur = d_phi, *oth = d_phi2;
+    bool restricted = false;
     if (fused) {
-      MGCHK(mg_smooth4(&cur, &oth, d_f2, d_f1, partial, iter == 1 ? d_norm : nullptr, n, dx, s), "mg fused smoother launch");
+      MGCHK(mg_smooth4(&cur, &oth, d_f2, d_f1, partial, iter == 1 ? d_norm : nullptr, n, dx, s,
+                       level > 1 ? d_work + mg_hier_offset(level, level - 1, 1) : nullptr,
+                       level > 1 ? d_work + mg_hier_offset(level, level - 1, 0) : nullptr, &restricted), "mg fused smoother launch");
     } else {
       for (int i = 0; i < ngs_fine; i++) {
         MGCHK(mg_launch_gs(d_phi, d_f2, n, dx2, 0, s), "mg gs launch");
@@ -642,7 +657,7 @@ int ramses_amd_multigrid_fine_brick(int level, const double *d_rho, double rho_t
       MGCHK(hipMemcpyAsync(&i_res_norm2, d_norm, sizeof(double), hipMemcpyDeviceToHost, s), "norm copy");
     }
     if (level > 1) {
-      MGCHK(mg_launch_restrict(d_f1, d_work + mg_hier_offset(level, level - 1, 1), d_work + mg_hier_offset(level, level - 1, 0), n, s), "mg restrict launch");
+      if (!restricted) MGCHK(mg_launch_restrict(d_f1, d_work + mg_hier_offset(level, level - 1, 1), d_work + mg_hier_offset(level, level - 1, 0), n, s), "mg restrict launch");
       MGCHK(mg_coarse_cycle(d_work, level, level - 1, *safe_mode, s), "mg coarse cycle");
       MGCHK(mg_launch_interp(cur, d_work + mg_hier_offset(level, level - 1, 0), n, s), "mg interp launch");
     }

@@ -478,15 +478,24 @@ struct SmoothGeom {
 
 // 4 tile rows per wavefront: 24 rows = 6 wavefronts (384 threads), 16 = 4, 12 = 3
 
-template <int P, bool RESID, int LYT = 24>
+// RESTR (with RESID, dense periodic levels): the residual does not leave the chip at all -- every plane of it is parked in
+// LDS for one step, 377 threads add the four children of their coarse cell of that plane in octant order (the second
+// plane of a pair continues the sum of the first, which waits in a register: the reference's order, child by child), and
+// the coarse right-hand side is stored and the coarse correction zeroed: restrict_residual_fine_reverse + the reset of
+// multigrid_fine_commons.f90:217-238 without a pass of their own (0.25 ms + the 1.07 GB residual store at 512^3).
+template <int P, bool RESID, int LYT = 24, bool RESTR = false>
 __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double *__restrict__ phi_in,
                                                                           double *__restrict__ phi_out,
                                                                           const double *__restrict__ rhs,
                                                                           double *__restrict__ res,
                                                                           double *__restrict__ partial, int n,
                                                                           int ng, double dx2, double oneoverdx2,
-                                                                          int zchunk, int ntx, int nty) {
+                                                                          int zchunk, int ntx, int nty,
+                                                                          double *__restrict__ rhs_c,
+                                                                          double *__restrict__ u1_c) {
   using G = SmoothGeom<P, RESID, LYT>;
+  static_assert(!RESTR || RESID, "the fused restriction restricts the fused residual");
+  static_assert(!RESTR || ((G::IX % 2 == 0) && (G::IY % 2 == 0) && (G::IX / 2) * (G::IY / 2) <= LYT * 16), "coarse cells of a tile plane: one per thread");
   constexpr int H = G::H;
   constexpr int SMOOTH_THREADS = LYT * 16;
   constexpr int NW = SMOOTH_THREADS / 64;                  // 6 waves at 24 rows
@@ -540,6 +549,30 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
   const int m_begin = z0 - H - 2;
   const int m_end = (z1 - 1) + 2 * P;
 
+  // fused restriction: two residual planes [IY][IX] behind the ring (written in step m, read in step m + 1), this thread's
+  // coarse cell and the sum of its first four children
+  double *resbuf = ring + G::R * G::PLANE;
+  constexpr int RB = G::IX * G::IY;
+  const int cxl = tid % (G::IX / 2), cyl = tid / (G::IX / 2);
+  const int cgx = x0 + H + 2 * cxl, cgy = y0 + H + 2 * cyl;
+  const bool coarse_on = RESTR && (tid < (G::IX / 2) * (G::IY / 2)) && cgx < n && cgy < n;
+  double cacc = 0.0;
+  auto restrict_plane = [&](int zr, int buf) {
+    if (!coarse_on || zr < z0 || zr > z1 - 1) return;
+    const double *rb = resbuf + buf * RB + (2 * cyl) * G::IX + 2 * cxl;
+    if ((zr & 1) == 0) cacc = 0.0;
+    cacc = cacc + rb[0] / 8.0;
+    cacc = cacc + rb[1] / 8.0;
+    cacc = cacc + rb[G::IX] / 8.0;
+    cacc = cacc + rb[G::IX + 1] / 8.0;
+    if (zr & 1) {
+      const int nc = n >> 1;
+      const long c = (long)(cgx >> 1) + (long)nc * ((cgy >> 1) + (long)nc * (zr >> 1));
+      rhs_c[c] = cacc;
+      u1_c[c] = 0.0;
+    }
+  };
+
   // All global reads of a step (the new phi plane, the rhs of the P colour
   // passes and of the residual plane) are issued one step AHEAD into registers:
   // every address is valid (wrapped), so the loads are unconditional and their
@@ -583,6 +616,8 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
   issue(m_begin + 1, nxt);
   for (int m = m_begin; m <= m_end; m++) {
     issue(m + 2, nx2);
+    // the residual plane the previous step parked (plane m - 1 - 2P) joins its coarse cells
+    if constexpr (RESTR) restrict_plane(m - 1 - 2 * P, (m + 1) & 1);
     const int zl = m + 2;
     const bool do_load = (zl >= z0 - H) && (zl <= z1 - 1 + H);
     // ---- gather phase: every LDS read of this step is issued before any LDS
@@ -695,6 +730,7 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
               const double rr = (e == ered) ? fifo[0][0][j] : fifo[2][1][j];
               const double r = -oneoverdx2 * (nbb[j][e] - 6.0 * phb[j][e]) + rr;
               if (res) res[g] = r;      // norm-only callers pass NULL: the residual never leaves the chip
+              if constexpr (RESTR) resbuf[(m & 1) * RB + (lyC[j] - H) * G::IX + (2 * pr + e - H)] = r;
               acc = acc + r * r;
             }
           }
@@ -721,6 +757,7 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
     cur = nxt;
     nxt = nx2;
   }
+  if constexpr (RESTR) restrict_plane(m_end - 2 * P, m_end & 1);       // the last plane (the loop's last barrier is behind us)
   if (RESID && partial) {
     sm[tid] = acc;
     for (int i = SMOOTH_THREADS + tid; i < 512; i += SMOOTH_THREADS) sm[i] = 0.0;
@@ -741,13 +778,18 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
 static int g_smooth_ly = 32;
 void mg_set_smooth_rows(int ly) { g_smooth_ly = (ly == 12 || ly == 16 || ly == 32) ? ly : 24; }
 
+// can the fused smoother of this level restrict its residual itself (mg_launch_smooth_fused with rhs_c / u1_c)?
+bool mg_smooth_can_restrict(int n, int npass) { return npass == 2 && g_smooth_ly == 32 && n >= 64; }
+
 hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const double *rhs, double *res,
                                   double *partial, double *norm_out, int n, double dx, int npass,
-                                  hipStream_t s, int ng) {
+                                  hipStream_t s, int ng, double *rhs_c, double *u1_c) {
   if (npass != 4 && npass != 2) return hipErrorInvalidValue;
+  const bool restr = rhs_c != nullptr;
+  if (restr && (!u1_c || ng != 0 || !mg_smooth_can_restrict(n, npass) || (n & 1))) return hipErrorInvalidValue;
   if (n < 64) return hipErrorInvalidValue;   // tile wider than the level: use the per-colour kernels
   const int P = npass;
-  const bool resid = (res != nullptr) || (norm_out != nullptr);
+  const bool resid = restr || (res != nullptr) || (norm_out != nullptr);
   const int H = resid ? P + 1 : P;
   if (ng != 0 && ng < H) return hipErrorInvalidValue;   // ghost layers must cover the dependency cone
   const int LY = (P == 2) ? g_smooth_ly : 24;
@@ -758,7 +800,7 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
   const int ntz = (n + zchunk - 1) / zchunk;
   const int blocks = ntx * nty * ntz;
   if (resid && blocks > MG_MAX_PARTIALS) return hipErrorInvalidValue;
-  const size_t lds = sizeof(double) * (size_t)(2 * P + 4) * 64 * LY;
+  const size_t lds = sizeof(double) * ((size_t)(2 * P + 4) * 64 * LY + (restr ? 2 * (size_t)IX * IY : 0));
   const double dx2 = dx * dx, oneoverdx2 = 1.0 / (dx * dx);
   hipError_t e;
 #define SM_LAUNCH(PP, RR, LL)                                                                                 \
@@ -768,8 +810,16 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
                             (int)lds);                                                                        \
     if (e != hipSuccess) return e;                                                                            \
     hipLaunchKernelGGL(k, dim3(blocks), dim3(LL * 16), lds, s, phi_in, phi_out, rhs, res, partial, n, ng, dx2,    \
-                       oneoverdx2, zchunk, ntx, nty);                                                         \
+                       oneoverdx2, zchunk, ntx, nty, (double *)nullptr, (double *)nullptr);                   \
   } while (0)
+  if (restr) {
+    // (the residual itself is not stored: the restricted right-hand side is all the coarse level needs of it)
+    auto k = mg_smooth_fused_kernel<2, true, 32, true>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(32 * 16), lds, s, phi_in, phi_out, rhs, res, partial, n, ng, dx2, oneoverdx2, zchunk, ntx, nty,
+                       rhs_c, u1_c);
+  } else
   if (P == 4) { if (resid) SM_LAUNCH(4, true, 24); else SM_LAUNCH(4, false, 24); }
   else if (LY == 12) { if (resid) SM_LAUNCH(2, true, 12); else SM_LAUNCH(2, false, 12); }
   else if (LY == 16) { if (resid) SM_LAUNCH(2, true, 16); else SM_LAUNCH(2, false, 16); }
