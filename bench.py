@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--zchunk", type=int, default=0)
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stress-steps", type=int, default=60,
+                    help="N=1: also time the sweep on the state after this many steps in all (0 = skip)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange after the sweep instead of behind it")
     ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
                     help="N>1: hide the halo exchange behind the interior sweep (auto: measure both, keep the faster)")
@@ -565,8 +567,9 @@ def main():
             "config": {"workload": "sedov3d.nml uniform %d^3 per GPU (%dx%dx%d ranks, global %dx%dx%d), "
                                    "hydro-only Godunov sweep, LLF + minmod, muscl"
                                    % (n, pgrid[0], pgrid[1], pgrid[2], n * pgrid[0], n * pgrid[1], n * pgrid[2]),
-                       "arithmetic": "fast (explicit FMAs, rcp/rsq + Newton; rel-Linf of strict <= 2e-15 over 24 Sedov steps at 64^3 and 128^3, "
-                                     "bound 1e-12: tests/test_baseline_sizes_gpu.py::test_fast_build_multistep_within_tolerance)" if args.fast else "strict (bit-identical to the reference)",
+                       "arithmetic": "fast = the patched program's default (explicit FMAs, rcp/rsq + Newton; rel-Linf of the REFERENCE PROGRAM "
+                                     "<= 4e-15 at 256^3 over 100 steps and at 128^3 over 120 steps, bound 1e-12: tests/test_fast_certificate_gpu.py; "
+                                     "RAMSES_AMD_STRICT=1 selects the bit-identical build)" if args.fast else "strict (bit-identical to the reference)",
                        "spinup": "%d untimed sweeps of a scratch 256^3 level before the warm-up steps (clock ramp, %d ms)" % (spin_sweeps, args.spinup_ms),
                        "ranks": census,
                        "halo": "none (single rank, in-kernel periodic wrap)" if world == 1 else
@@ -598,6 +601,30 @@ def main():
             out["strict_build"] = {"kernel_ms": ms, "cell_updates_per_s": cells / (ms * 1e-3), "achieved": gbs,
                                    "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                    "note": "same kernel, -ffp-contract=off and the reference's operation order: bit-identical results"}
+            lev.params.fast_math = 1
+        if world == 1 and args.stress_steps > 0:
+            # the same kernel on a DEVELOPED state (SURVEY.md 8d's stress variant, "step >= 50"): the run goes on with the
+            # Courant step of every step until it has taken stress_steps steps in all, then K sweeps are timed
+            done = args.warmup + args.steps
+            dts = dt
+            while done < args.stress_steps:
+                dts = lev.courant_fine()[0]
+                lev.step(dts)
+                done += 1
+            dts = lev.courant_fine()[0]
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(10):
+                lev.godunov_fine(dts)
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b) / 10
+            gbs = cells * BYTES_PER_CELL_UPDATE / (ms * 1e-3) / 1e9
+            out["stress"] = {"after_steps": done, "kernel_ms": ms, "cell_updates_per_s": cells / (ms * 1e-3), "achieved": gbs, "unit": "GB/s",
+                             "frac": gbs / HBM_PEAK_GBS, "arithmetic": "fast" if args.fast else "strict",
+                             "note": "10 sweeps of the state the run reaches after that many Courant-limited steps (blast wave developed: "
+                                     "limiter and floor branches warm where it is)"}
             lev.params.fast_math = 1
         if world == 1 and args.vcycle_level > 0:
             del lev

@@ -150,7 +150,55 @@ def run_mpi(tag, binary, env, level, nstep, nproc):
                       "timers_max_s": rows, "notes": note[:4]}), flush=True)
 
 
+def run_grav_mpi(tag, binary, env, level, nstep, nproc):
+    """BASELINE config C4 (uniform periodic level, hydro + self-gravity) on nproc MPI ranks: every level takes the AMR
+    multigrid path under MPI (the reference's driver, device operators); MAX column of the MPI timer table"""
+    nml = rs.sedov3d_namelist(level=level, nstepmax=nstep, foutput=1000, boxlen=1.0, poisson=True, init=GRAV_BLOB, mem_factor=4.0,
+                              extra="&POISSON_PARAMS\nepsilon=1d-6\n/\n")
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    t0 = time.time()
+    try:
+        work, out = rs.run_reference(nml, binary=binary, nproc=nproc, timeout=3000)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    wall = time.time() - t0
+    shutil.rmtree(work, ignore_errors=True)
+    rows = {}
+    for line in out.splitlines():
+        m = re.match(r"^\s*([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+\S+\s+([0-9.]+)\s+(\d+)\s+(\d+)\s+([a-zA-Z].*?)\s*$", line)
+        if m:
+            rows[m.group(8)] = float(m.group(3))
+        m = re.match(r"^\s*([0-9.]+)\s+100\.0\s+TOTAL", line)
+        if m:
+            rows["TOTAL"] = float(m.group(1))
+    solves = re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+) Error=\s*(\S+)", out)
+    stats = re.findall(r"level arrays across PCIe after the upload:\s*(\d+) bytes in\s*(\d+) copies; halo:\s*(\d+) bytes in\s*(\d+) exchanges", out)
+    pcie = {"level_array_bytes": sum(int(a) for a, _, _, _ in stats), "halo_bytes": sum(int(c) for _, _, c, _ in stats),
+            "halo_exchanges": sum(int(d) for _, _, _, d in stats)} if stats else None
+    print(json.dumps({"config": tag, "level": level, "steps": nstep, "ranks": nproc, "wall_s": round(wall, 3),
+                      "vcycles": [int(b) for _, b, _ in solves], "timers_max_s": rows, "multigrid_pcie_all_ranks": pcie}), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "gravmpi":
+        # python scripts/dropin_timing.py gravmpi LEVEL NSTEP NPROC [all|gpu|ref]
+        level, nstep, nproc = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+        which = sys.argv[5] if len(sys.argv) > 5 else "all"
+        ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi")
+        pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi_patch")
+        if which in ("all", "gpu"):
+            run_grav_mpi("patched: multigrid levels resident on the device, virtual boundaries exchanged from there (round 3)", pat,
+                         {"RAMSES_AMD": "1", "RAMSES_AMD_MG_STATS": "1"}, level, nstep, nproc)
+            run_grav_mpi("patched: arrays across PCIe around every multigrid routine, host exchanges (RAMSES_AMD_MG_MPI_SYNC=1, round 2)", pat,
+                         {"RAMSES_AMD": "1", "RAMSES_AMD_MG_STATS": "1", "RAMSES_AMD_MG_MPI_SYNC": "1"}, level, nstep, nproc)
+        if which in ("all", "ref"):
+            run_grav_mpi("reference (MPI)", ref, {"RAMSES_AMD": "0"}, level, nstep, nproc)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "mpi":
         level, nstep, nproc = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
         which = sys.argv[5] if len(sys.argv) > 5 else "all"
