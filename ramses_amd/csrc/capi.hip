@@ -458,11 +458,18 @@ int ramses_amd_mg_tune(int fused) {
 // residual it does (the residual is then NOT stored in res) and *restricted is set -- otherwise the caller restricts res
 static hipError_t mg_smooth4(double **cur, double **other, const double *rhs, double *res, double *partial,
                              double *norm, int n, double dx, hipStream_t s, double *rhs_c = nullptr, double *u1_c = nullptr,
-                             bool *restricted = nullptr) {
+                             bool *restricted = nullptr, const double *corr_c = nullptr) {
+  // corr_c: the correction of the level below, to be prolongated and added to *cur first (interpolate_and_correct_fine) --
+  // inside the first smoother launch where that configuration can, in a pass of its own otherwise
   hipError_t e;
   if (restricted) *restricted = false;
+  static int fuse_prolong = -1;          // RAMSES_AMD_MG_FUSE_PROLONG=0: the prolongation in a pass of its own (A/B; same bits)
+  if (fuse_prolong < 0) { const char *ev = getenv("RAMSES_AMD_MG_FUSE_PROLONG"); fuse_prolong = !(ev && ev[0] == '0'); }
+  const bool prol_fused = corr_c && g_mg_split_rows && fuse_prolong && mg_smooth_can_restrict(n, 2);
+  if (corr_c && !prol_fused && (e = mg_launch_interp(*cur, corr_c, n, s)) != hipSuccess) return e;
   if (g_mg_split_rows) {
-    if ((e = mg_launch_smooth_fused(*cur, *other, rhs, nullptr, nullptr, nullptr, n, dx, 2, s)) != hipSuccess) return e;
+    if ((e = mg_launch_smooth_fused(*cur, *other, rhs, nullptr, nullptr, nullptr, n, dx, 2, s, 0, nullptr, nullptr,
+                                    prol_fused ? corr_c : nullptr)) != hipSuccess) return e;
     static int fuse_restrict = -1;       // RAMSES_AMD_MG_FUSE_RESTRICT=0: the restriction in a pass of its own (A/B; same bits)
     if (fuse_restrict < 0) { const char *ev = getenv("RAMSES_AMD_MG_FUSE_RESTRICT"); fuse_restrict = !(ev && ev[0] == '0'); }
     if (rhs_c && u1_c && restricted && fuse_restrict && mg_smooth_can_restrict(n, 2)) {
@@ -540,8 +547,7 @@ static hipError_t mg_coarse_cycle(double *w, int level, int l, int safe, hipStre
                           &restricted)) != hipSuccess) return e;
       if (!restricted && (e = mg_launch_restrict(u3, w + mg_hier_offset(level, l - 1, 1), w + mg_hier_offset(level, l - 1, 0), n, s)) != hipSuccess) return e;
       if ((e = mg_coarse_cycle(w, level, l - 1, safe, s)) != hipSuccess) return e;
-      if ((e = mg_launch_interp(cur, w + mg_hier_offset(level, l - 1, 0), n, s)) != hipSuccess) return e;
-      if ((e = mg_smooth4(&cur, &oth, u2, nullptr, nullptr, nullptr, n, dx, s)) != hipSuccess) return e;
+      if ((e = mg_smooth4(&cur, &oth, u2, nullptr, nullptr, nullptr, n, dx, s, nullptr, nullptr, nullptr, w + mg_hier_offset(level, l - 1, 0))) != hipSuccess) return e;
       continue;
     }
     for (int i = 0; i < ngs_coarse; i++) {
@@ -659,12 +665,13 @@ int ramses_amd_multigrid_fine_brick(int level, const double *d_rho, double rho_t
     if (level > 1) {
       if (!restricted) MGCHK(mg_launch_restrict(d_f1, d_work + mg_hier_offset(level, level - 1, 1), d_work + mg_hier_offset(level, level - 1, 0), n, s), "mg restrict launch");
       MGCHK(mg_coarse_cycle(d_work, level, level - 1, *safe_mode, s), "mg coarse cycle");
-      MGCHK(mg_launch_interp(cur, d_work + mg_hier_offset(level, level - 1, 0), n, s), "mg interp launch");
+      if (!fused) MGCHK(mg_launch_interp(cur, d_work + mg_hier_offset(level, level - 1, 0), n, s), "mg interp launch");
     }
     if (fused) {
-      // post-smoothing: only the norm of the residual is needed (f(:,1) is scratch in
+      // prolongation + post-smoothing: only the norm of the residual is needed (f(:,1) is scratch in
       // the reference and force_fine overwrites it next): it is not written to HBM
-      MGCHK(mg_smooth4(&cur, &oth, d_f2, nullptr, partial, d_norm + 1, n, dx, s), "mg fused smoother launch");
+      MGCHK(mg_smooth4(&cur, &oth, d_f2, nullptr, partial, d_norm + 1, n, dx, s, nullptr, nullptr, nullptr,
+                       level > 1 ? d_work + mg_hier_offset(level, level - 1, 0) : nullptr), "mg fused smoother launch");
       // the result is back in d_phi (two buffer swaps, or none)
     } else {
       for (int i = 0; i < ngs_fine; i++) {

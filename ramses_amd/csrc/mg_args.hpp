@@ -26,9 +26,11 @@ hipError_t mg_launch_restrict(const double *res_f, double *rhs_c, double *u1_c, 
 hipError_t mg_launch_interp(double *phi_f, const double *corr_c, int nf, hipStream_t s);
 hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const double *rhs, double *res,
                                   double *partial, double *norm_out, int n, double dx, int npass,
-                                  hipStream_t s, int ng = 0, double *rhs_c = nullptr, double *u1_c = nullptr);
+                                  hipStream_t s, int ng = 0, double *rhs_c = nullptr, double *u1_c = nullptr,
+                                  const double *corr_c = nullptr);
 // rhs_c / u1_c given (dense periodic level, 2 colour passes on 32-row tiles: mg_smooth_can_restrict): the kernel restricts its
-// residual into the coarse right-hand side and zeroes the coarse correction itself; res may then be NULL
+// residual into the coarse right-hand side and zeroes the coarse correction itself; res may then be NULL.
+// corr_c given (same condition, no residual): the planes the kernel reads are phi_in + the prolongation of corr_c
 bool mg_smooth_can_restrict(int n, int npass);
 // one rank's brick of a distributed level (ng ghost layers)
 hipError_t mg_launch_restrict_ghost(const double *res_f, double *rhs_c, int nf, int ngf, int ngc, hipStream_t s);

@@ -483,7 +483,13 @@ struct SmoothGeom {
 // plane of a pair continues the sum of the first, which waits in a register: the reference's order, child by child), and
 // the coarse right-hand side is stored and the coarse correction zeroed: restrict_residual_fine_reverse + the reset of
 // multigrid_fine_commons.f90:217-238 without a pass of their own (0.25 ms + the 1.07 GB residual store at 512^3).
-template <int P, bool RESID, int LYT = 24, bool RESTR = false>
+//
+// PROL (without RESID, dense periodic levels): the planes that enter the ring are phi + the trilinear interpolation of the
+// coarse correction (interpolate_and_correct_fine, multigrid_fine_fine.f90:596-698: 8 of the 27 parents, weights
+// 1,3,3,9,3,9,9,27 / 64 in the reference's order) -- the prolongation without a pass of its own (0.51 ms at 512^3: phi read
+// and written once more).  The (LX/2 + 2) x (LY/2 + 2) coarse cells under a tile plane wait in an LDS ring of three coarse
+// planes (K - 1, K, K + 1 around the parent plane); a new one is fetched two steps ahead of the step that needs it.
+template <int P, bool RESID, int LYT = 24, bool RESTR = false, bool PROL = false>
 __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double *__restrict__ phi_in,
                                                                           double *__restrict__ phi_out,
                                                                           const double *__restrict__ rhs,
@@ -492,8 +498,10 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
                                                                           int ng, double dx2, double oneoverdx2,
                                                                           int zchunk, int ntx, int nty,
                                                                           double *__restrict__ rhs_c,
-                                                                          double *__restrict__ u1_c) {
+                                                                          double *__restrict__ u1_c,
+                                                                          const double *__restrict__ corr_c) {
   using G = SmoothGeom<P, RESID, LYT>;
+  static_assert(!PROL || (!RESID && P == 2 && (LYT * 16) * 2 >= (G::LX / 2 + 2) * (G::LY / 2 + 2)), "fused prolongation: the smoother without residual");
   static_assert(!RESTR || RESID, "the fused restriction restricts the fused residual");
   static_assert(!RESTR || ((G::IX % 2 == 0) && (G::IY % 2 == 0) && (G::IX / 2) * (G::IY / 2) <= LYT * 16), "coarse cells of a tile plane: one per thread");
   constexpr int H = G::H;
@@ -612,6 +620,37 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
     for (int b = 0; b < 2; b++)
 #pragma unroll
       for (int j = 0; j < NPAIR; j++) fifo[a][b][j] = 0.0;
+  // fused prolongation: the coarse planes under the tile
+  constexpr int CW = G::LX / 2 + 2, CH = G::LY / 2 + 2, CPL = CW * CH;
+  double *cring = ring + G::R * G::PLANE;            // [3][CH][CW]  (PROL and RESTR never come together)
+  const int nc = n >> 1;
+  double cpre[2] = {0.0, 0.0};
+  auto cwrap = [&](int v) { return v < 0 ? v + nc : (v >= nc ? v - nc : v); };
+  auto cslot = [&](int K) { int r = K % 3; return r < 0 ? r + 3 : r; };
+  auto coarse_fetch = [&](int K, double (&dst)[2]) {   // this thread's (up to) two cells of coarse plane K
+    const long zo = (long)cwrap(K) * nc * nc;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int e = tid + h * SMOOTH_THREADS;
+      if (e < CPL) dst[h] = corr_c[zo + (long)cwrap((y0 >> 1) - 1 + e / CW) * nc + cwrap((x0 >> 1) - 1 + e % CW)];
+    }
+  };
+  auto coarse_put = [&](int K, const double (&src)[2]) {
+    double *cp = cring + cslot(K) * CPL;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int e = tid + h * SMOOTH_THREADS;
+      if (e < CPL) cp[e] = src[h];
+    }
+  };
+  if constexpr (PROL) {
+    // the first plane that enters the ring is z0 - H (even): parents K0 = (z0 - H) / 2 and K0 - 1; K0 + 1 follows in the loop
+    const int K0 = (z0 - H) >> 1;
+    coarse_fetch(K0 - 1, cpre); coarse_put(K0 - 1, cpre);
+    coarse_fetch(K0, cpre); coarse_put(K0, cpre);
+    coarse_fetch(K0 + 1, cpre);
+    __syncthreads();
+  }
   issue(m_begin, cur);
   issue(m_begin + 1, nxt);
   for (int m = m_begin; m <= m_end; m++) {
@@ -740,8 +779,37 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
     // ---- stage 0: plane m+2 (values from before the sweeps) into its ring slot --
     if (do_load) {
       double *pl = ring + slot(zl) * G::PLANE;
+      if constexpr (PROL) {
+        // phi + interpolated correction: parent (lane/2, ly/2, zl/2) of the coarse tile (which starts one cell earlier), the
+        // neighbour on the child's side where bit t is clear; t = 0..7 in the reference's order
+        const int K = zl >> 1, Kn = K + ((zl & 1) ? 1 : -1);
+        const double *cK = cring + cslot(K) * CPL, *cN = cring + cslot(Kn) * CPL;
+        const double wa = 1.0 / 64.0, wb = 3 * wa, wc = 9 * wa, wd = 27 * wa;
+        const int pxl = (lane >> 1) + 1, nxl = pxl + ((lane & 1) ? 1 : -1);
 #pragma unroll
-      for (int i = 0; i < NROW; i++) pl[lofsR[i]] = cur.ph[i];
+        for (int i = 0; i < NROW; i++) {
+          const int ly = wv + NW * i;
+          const int pyl = (ly >> 1) + 1, nyl = pyl + ((ly & 1) ? 1 : -1);
+          double corr = 0.0;
+          corr = corr + wa * cN[nyl * CW + nxl];
+          corr = corr + wb * cN[nyl * CW + pxl];
+          corr = corr + wb * cN[pyl * CW + nxl];
+          corr = corr + wc * cN[pyl * CW + pxl];
+          corr = corr + wb * cK[nyl * CW + nxl];
+          corr = corr + wc * cK[nyl * CW + pxl];
+          corr = corr + wc * cK[pyl * CW + nxl];
+          corr = corr + wd * cK[pyl * CW + pxl];
+          pl[lofsR[i]] = cur.ph[i] + corr;
+        }
+        // the coarse plane the next odd fine plane needs: fetched two steps ago, parked now; the one after it is asked for
+        if ((zl & 1) == 0) {
+          coarse_put(K + 1, cpre);
+          coarse_fetch(K + 2, cpre);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NROW; i++) pl[lofsR[i]] = cur.ph[i];
+      }
     }
     __syncthreads();
     if (P > 2 || RESID) {
@@ -783,9 +851,11 @@ bool mg_smooth_can_restrict(int n, int npass) { return npass == 2 && g_smooth_ly
 
 hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const double *rhs, double *res,
                                   double *partial, double *norm_out, int n, double dx, int npass,
-                                  hipStream_t s, int ng, double *rhs_c, double *u1_c) {
+                                  hipStream_t s, int ng, double *rhs_c, double *u1_c, const double *corr_c) {
   if (npass != 4 && npass != 2) return hipErrorInvalidValue;
   const bool restr = rhs_c != nullptr;
+  const bool prol = corr_c != nullptr;
+  if (prol && (restr || res || norm_out || ng != 0 || !mg_smooth_can_restrict(n, npass) || (n & 1))) return hipErrorInvalidValue;
   if (restr && (!u1_c || ng != 0 || !mg_smooth_can_restrict(n, npass) || (n & 1))) return hipErrorInvalidValue;
   if (n < 64) return hipErrorInvalidValue;   // tile wider than the level: use the per-colour kernels
   const int P = npass;
@@ -800,7 +870,7 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
   const int ntz = (n + zchunk - 1) / zchunk;
   const int blocks = ntx * nty * ntz;
   if (resid && blocks > MG_MAX_PARTIALS) return hipErrorInvalidValue;
-  const size_t lds = sizeof(double) * ((size_t)(2 * P + 4) * 64 * LY + (restr ? 2 * (size_t)IX * IY : 0));
+  const size_t lds = sizeof(double) * ((size_t)(2 * P + 4) * 64 * LY + (restr ? 2 * (size_t)IX * IY : 0) + (prol ? 3 * (size_t)(64 / 2 + 2) * (LY / 2 + 2) : 0));
   const double dx2 = dx * dx, oneoverdx2 = 1.0 / (dx * dx);
   hipError_t e;
 #define SM_LAUNCH(PP, RR, LL)                                                                                 \
@@ -810,7 +880,7 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
                             (int)lds);                                                                        \
     if (e != hipSuccess) return e;                                                                            \
     hipLaunchKernelGGL(k, dim3(blocks), dim3(LL * 16), lds, s, phi_in, phi_out, rhs, res, partial, n, ng, dx2,    \
-                       oneoverdx2, zchunk, ntx, nty, (double *)nullptr, (double *)nullptr);                   \
+                       oneoverdx2, zchunk, ntx, nty, (double *)nullptr, (double *)nullptr, (const double *)nullptr); \
   } while (0)
   if (restr) {
     // (the residual itself is not stored: the restricted right-hand side is all the coarse level needs of it)
@@ -818,7 +888,13 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(32 * 16), lds, s, phi_in, phi_out, rhs, res, partial, n, ng, dx2, oneoverdx2, zchunk, ntx, nty,
-                       rhs_c, u1_c);
+                       rhs_c, u1_c, (const double *)nullptr);
+  } else if (prol) {
+    auto k = mg_smooth_fused_kernel<2, false, 32, false, true>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(32 * 16), lds, s, phi_in, phi_out, rhs, res, partial, n, ng, dx2, oneoverdx2, zchunk, ntx, nty,
+                       (double *)nullptr, (double *)nullptr, corr_c);
   } else
   if (P == 4) { if (resid) SM_LAUNCH(4, true, 24); else SM_LAUNCH(4, false, 24); }
   else if (LY == 12) { if (resid) SM_LAUNCH(2, true, 12); else SM_LAUNCH(2, false, 12); }
