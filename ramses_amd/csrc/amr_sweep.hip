@@ -358,22 +358,13 @@ constexpr int GRP_THREADS = 256;
 // 3.44 ms, 5 (96 VGPRs, 144 spilled to scratch) 3.08 ms, 6 3.37 ms, 7 3.10 ms per sweep
 // (tried and dropped: unew of the updated cells fetched by the idle fourth wavefront behind the gather and parked in LDS --
 // 3.02 -> 3.30 ms, the extra live registers spill)
-#ifndef RAMSES_AMD_GRP_MINWAVES
-#define RAMSES_AMD_GRP_MINWAVES 5
-#endif
-constexpr int GRP_MINWAVES = RAMSES_AMD_GRP_MINWAVES;
-#ifndef RAMSES_AMD_GRP_XCD
-#define RAMSES_AMD_GRP_XCD 1
-#endif
+constexpr int GRP_MINWAVES = 5;
 
 // z stride of the 8^3 stencil in LDS.  With 64 the 4 x 4 x 4 inner cells a wave traces sit on x + 8j (mod 32 doubles = the
 // 64 four-byte banks) whatever their plane: 16 bank pairs for 64 lanes, every stencil read a 4-way conflict
 // (profiles/r03_amr_sweep_pmc.txt: 4.0e8 conflict cycles of 7.3e8 LDS-active ones).  68 puts plane k on x + 8j + 4k: each
 // bank pair twice, the minimum for 64 eight-byte lanes.
-#ifndef RAMSES_AMD_GRP_ZS
-#define RAMSES_AMD_GRP_ZS 68
-#endif
-constexpr int GRP_ZS = RAMSES_AMD_GRP_ZS;
+constexpr int GRP_ZS = 68;
 constexpr int GRP_STENCIL = 7 * GRP_ZS + 64;
 // LDS layout of the stencil and the face arrays: variable-major (consecutive lanes touch consecutive doubles of one
 // variable; cell-major, the NV values of a cell together, measured the same: 3.795 vs 3.778 ms)
@@ -513,12 +504,10 @@ __global__ __launch_bounds__(GRP_THREADS, GRP_MINWAVES) void amr_group_kernel(Am
   // re-reads hit its L2 (profiles/r03_amr_sweep_pmc.txt: 9.0 GB fetched per sweep with the round-robin order = every
   // record from HBM by every group that reads it).
   int bid = blockIdx.x;
-#if RAMSES_AMD_GRP_XCD
   {
     const int nblk = gridDim.x, per = nblk >> 3, rem = nblk & 7, x = bid & 7;
     bid = x * per + (x < rem ? x : rem) + (bid >> 3);
   }
-#endif
   const int gF = groups[bid];                 // the father oct (level l-1)
   const long ncell = A.ncell;
 

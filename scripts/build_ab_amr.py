@@ -1,5 +1,6 @@
 """A/B variants of libramses_amd.so that differ in the compile-time knobs of amr_sweep.hip (development builds: minmod +
 LLF + NVAR=5 only, seconds to compile):  scripts/build_ab_amr.py TAG=-DFLAG=1,-DOTHER=2 [TAG2=...]
+(the flags are whatever temporary #ifdef a tuning session puts into the kernel; the shipped file carries none)
 -> ramses_amd/lib/ab/libramses_amd_amr_TAG.so (load with RAMSES_AMD_LIB=...); the other objects come from the regular build."""
 import os
 import subprocess
