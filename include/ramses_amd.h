@@ -501,6 +501,14 @@ int ramses_amd_cgmpi_set(int slot, double val);
 int ramses_amd_cgmpi_step(int step, int iter);
 int ramses_amd_cgmpi_p_cells(int n, const int *igrid, int to_host);
 int ramses_amd_cgmpi_end(double *phi, double *f);
+/* The halo of p (make_virtual_fine_dp(f(1,2),ilevel), poisson/phi_fine_cg.f90:134) on the device vector: comm_set = the level's
+ * emission / reception oct lists per peer (em_n / rc_n [ncpu], lists concatenated in icpu order), once per solve; then per
+ * iteration either p_halo_rccl (one grouped RCCL send/recv) or p_halo_stage_out / the caller's MPI on the pinned buffers /
+ * p_halo_stage_in (message of peer icpu at h_send + send_off[icpu-1]; addresses as integers for c_f_pointer). */
+int ramses_amd_cgmpi_comm_set(int ncpu, const int *em_n, const int *em_ig, const int *rc_n, const int *rc_ig);
+int ramses_amd_cgmpi_p_halo_stage_out(int ncpu, int64_t *h_send_addr, int64_t *h_recv_addr, int64_t *send_off, int64_t *recv_off);
+int ramses_amd_cgmpi_p_halo_stage_in(void);
+int ramses_amd_cgmpi_p_halo_rccl(void);
 
 /* ---------------------------------------------------------------------------
  * Device-resident level.  For a fully refined periodic

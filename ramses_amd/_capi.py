@@ -131,6 +131,10 @@ SYMBOLS = [
     ("ramses_amd_cgmpi_step", _i, [_i, _i]),
     ("ramses_amd_cgmpi_p_cells", _i, [_i, _vp, _i]),
     ("ramses_amd_cgmpi_end", _i, [_vp, _vp]),
+    ("ramses_amd_cgmpi_comm_set", _i, [_i, _vp, _vp, _vp, _vp]),
+    ("ramses_amd_cgmpi_p_halo_stage_out", _i, [_i, _vp, _vp, _vp, _vp]),
+    ("ramses_amd_cgmpi_p_halo_stage_in", _i, []),
+    ("ramses_amd_cgmpi_p_halo_rccl", _i, []),
     ("ramses_amd_resident_courant_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _d, _vp]),
     ("ramses_amd_resident_godunov_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _d]),
     ("ramses_amd_resident_set_uold_f90", _i, [_i]),

@@ -2168,6 +2168,14 @@ struct CgMpi {
   double *h_f = nullptr;
   DevBuf list, pack;
   std::vector<double> hpack;
+  // the level's communicators on the device (round 3): p's virtual cells are exchanged from the device vector
+  bool comm = false;
+  int ncpu = 0;
+  std::vector<int> em_first, rc_first;
+  DevBuf em_ig, rc_ig, sendbuf, recvbuf;
+  void *h_send = nullptr, *h_recv = nullptr;
+  size_t h_send_cap = 0, h_recv_cap = 0;
+  bool halo_open = false;
 };
 CgMpi g_cgm;
 
@@ -2296,6 +2304,97 @@ int ramses_amd_cgmpi_p_cells(int n, const int *igrid, int to_host) {
   }
   return 0;
 }
+// make_virtual_fine_dp(f(1,2),ilevel) of the loop (poisson/phi_fine_cg.f90:134) on the DEVICE vector p: comm_set sends the level's
+// emission / reception oct lists once per solve; one message per peer in the reference's layout (u(i + (ind-1)*n)); RCCL
+// (p_halo_rccl) or the caller's own MPI on pinned host buffers between p_halo_stage_out and p_halo_stage_in
+int ramses_amd_cgmpi_comm_set(int ncpu, const int *em_n, const int *em_ig, const int *rc_n, const int *rc_ig) {
+  CGM_OPEN("cgmpi_comm_set");
+  CgMpi &M = g_cgm;
+  if (ncpu < 1 || !em_n || !rc_n) return fail(RAMSES_AMD_EINVAL, "cgmpi_comm_set: bad argument");
+  M.comm = false; M.ncpu = ncpu;
+  M.em_first.assign((size_t)ncpu + 1, 0); M.rc_first.assign((size_t)ncpu + 1, 0);
+  for (int c = 0; c < ncpu; c++) {
+    if (em_n[c] < 0 || rc_n[c] < 0) return fail(RAMSES_AMD_EINVAL, "cgmpi_comm_set: negative list length");
+    M.em_first[c + 1] = M.em_first[c] + em_n[c];
+    M.rc_first[c + 1] = M.rc_first[c] + rc_n[c];
+  }
+  const int nem = M.em_first[ncpu], nrc = M.rc_first[ncpu];
+  if ((nem > 0 && !em_ig) || (nrc > 0 && !rc_ig)) return fail(RAMSES_AMD_EINVAL, "cgmpi_comm_set: NULL list");
+  HCHK(M.em_ig.ensure(sizeof(int) * (size_t)(nem > 0 ? nem : 1)), "hipMalloc"); HCHK(M.rc_ig.ensure(sizeof(int) * (size_t)(nrc > 0 ? nrc : 1)), "hipMalloc");
+  if (nem > 0) HCHK(hipMemcpy(M.em_ig.p, em_ig, sizeof(int) * (size_t)nem, hipMemcpyHostToDevice), "H2D emission list");
+  if (nrc > 0) HCHK(hipMemcpy(M.rc_ig.p, rc_ig, sizeof(int) * (size_t)nrc, hipMemcpyHostToDevice), "H2D reception list");
+  HCHK(M.sendbuf.ensure(sizeof(double) * 8 * (size_t)(nem > 0 ? nem : 1)), "hipMalloc sendbuf");
+  HCHK(M.recvbuf.ensure(sizeof(double) * 8 * (size_t)(nrc > 0 ? nrc : 1)), "hipMalloc recvbuf");
+  M.comm = true;
+  return 0;
+}
+namespace {
+int cgmpi_pack(CgMpi &M) {
+  for (int c = 0; c < M.ncpu; c++) {
+    const int n = M.em_first[c + 1] - M.em_first[c];
+    if (n <= 0) continue;
+    int nb = (int)((8L * n + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(cg_cells_kernel, dim3(nb), dim3(256), 0, nullptr, M.L.p, M.sendbuf.as<double>() + 8L * M.em_first[c],
+                       M.em_ig.as<int>() + M.em_first[c], n, M.L.ncoarse, M.L.ngridmax, 1);
+  }
+  HCHK(hipGetLastError(), "cg halo pack launch");
+  return 0;
+}
+int cgmpi_unpack(CgMpi &M) {
+  for (int c = 0; c < M.ncpu; c++) {
+    const int n = M.rc_first[c + 1] - M.rc_first[c];
+    if (n <= 0) continue;
+    int nb = (int)((8L * n + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(cg_cells_kernel, dim3(nb), dim3(256), 0, nullptr, M.L.p, M.recvbuf.as<double>() + 8L * M.rc_first[c],
+                       M.rc_ig.as<int>() + M.rc_first[c], n, M.L.ncoarse, M.L.ngridmax, 0);
+  }
+  HCHK(hipGetLastError(), "cg halo unpack launch");
+  return 0;
+}
+}  // namespace
+int ramses_amd_cgmpi_p_halo_stage_out(int ncpu, int64_t *h_send_addr, int64_t *h_recv_addr, int64_t *send_off, int64_t *recv_off) {
+  CGM_OPEN("cgmpi_p_halo_stage_out");
+  CgMpi &M = g_cgm;
+  if (!M.comm || ncpu != M.ncpu) return fail(RAMSES_AMD_EINVAL, "cgmpi_p_halo_stage_out: no communicators (ramses_amd_cgmpi_comm_set) / ncpu mismatch");
+  if (!h_send_addr || !h_recv_addr || !send_off || !recv_off) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  if (int rc = cgmpi_pack(M)) return rc;
+  const size_t ns = 8 * (size_t)M.em_first[ncpu], nr = 8 * (size_t)M.rc_first[ncpu];
+  if (int rc = pin_ensure(M.h_send, M.h_send_cap, sizeof(double) * (ns > 0 ? ns : 1))) return rc;
+  if (int rc = pin_ensure(M.h_recv, M.h_recv_cap, sizeof(double) * (nr > 0 ? nr : 1))) return rc;
+  if (ns > 0) HCHK(hipMemcpyAsync(M.h_send, M.sendbuf.p, sizeof(double) * ns, hipMemcpyDeviceToHost, nullptr), "D2H halo");
+  HCHK(hipStreamSynchronize(nullptr), "sync");
+  *h_send_addr = (int64_t)(intptr_t)M.h_send; *h_recv_addr = (int64_t)(intptr_t)M.h_recv;
+  for (int c = 0; c <= ncpu; c++) { send_off[c] = 8 * (int64_t)M.em_first[c]; recv_off[c] = 8 * (int64_t)M.rc_first[c]; }
+  M.halo_open = true;
+  return 0;
+}
+int ramses_amd_cgmpi_p_halo_stage_in(void) {
+  CGM_OPEN("cgmpi_p_halo_stage_in");
+  CgMpi &M = g_cgm;
+  if (!M.halo_open) return fail(RAMSES_AMD_EINVAL, "cgmpi_p_halo_stage_in without cgmpi_p_halo_stage_out");
+  M.halo_open = false;
+  const size_t nr = 8 * (size_t)M.rc_first[M.ncpu];
+  if (nr > 0) HCHK(hipMemcpyAsync(M.recvbuf.p, M.h_recv, sizeof(double) * nr, hipMemcpyHostToDevice, nullptr), "H2D halo");
+  return cgmpi_unpack(M);
+}
+int ramses_amd_cgmpi_p_halo_rccl(void) {
+  CGM_OPEN("cgmpi_p_halo_rccl");
+  CgMpi &M = g_cgm;
+  if (!M.comm) return fail(RAMSES_AMD_EINVAL, "cgmpi_p_halo_rccl: no communicators (ramses_amd_cgmpi_comm_set)");
+  if (int rc = cgmpi_pack(M)) return rc;
+  std::vector<int> peer;
+  std::vector<int64_t> so, sc, ro, rcn;
+  for (int c = 0; c < M.ncpu; c++) {
+    const int64_t ns = 8 * (int64_t)(M.em_first[c + 1] - M.em_first[c]), nr = 8 * (int64_t)(M.rc_first[c + 1] - M.rc_first[c]);
+    if (ns == 0 && nr == 0) continue;
+    peer.push_back(c); so.push_back(8 * (int64_t)M.em_first[c]); sc.push_back(ns); ro.push_back(8 * (int64_t)M.rc_first[c]); rcn.push_back(nr);
+  }
+  if (int rc = ramses_amd_rccl_exchange((int)peer.size(), peer.data(), M.sendbuf.as<double>(), so.data(), sc.data(), M.recvbuf.as<double>(),
+                                        ro.data(), rcn.data(), nullptr)) return rc;
+  return cgmpi_unpack(M);
+}
 // phi and f = (r, p, A p) back into the host arrays (what the reference's loop leaves)
 int ramses_amd_cgmpi_end(double *phi, double *f) {
   CGM_OPEN("cgmpi_end");
@@ -2307,6 +2406,7 @@ int ramses_amd_cgmpi_end(double *phi, double *f) {
   HCHK(hipMemcpy(f + g_cgm.ncell, G.p.p, vb, hipMemcpyDeviceToHost), "D2H p");
   HCHK(hipMemcpy(f + 2 * g_cgm.ncell, G.z.p, vb, hipMemcpyDeviceToHost), "D2H z");
   g_cgm.open = false;
+  g_cgm.comm = false; g_cgm.halo_open = false;
   return 0;
 }
 #undef CGM_OPEN

@@ -867,6 +867,7 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
   const int ntx = (n + IX - 1) / IX, nty = (n + IY - 1) / IY;
   int zchunk = n >= 512 ? 128 : (n >= 128 ? 64 : n);      // (256^3: 64 planes per workgroup measured faster than 128, round 2)
   if (const char *e = getenv("RAMSES_AMD_MG_ZCHUNK")) { const int z = atoi(e); if (z >= 8 && n >= 256) zchunk = z; }   // tuning aid
+  if (const char *e = getenv("RAMSES_AMD_MG_ZCHUNK_SMALL")) { const int z = atoi(e); if (z >= 8 && n < 256) zchunk = z < n ? z : n; }   // tuning aid
   const int ntz = (n + zchunk - 1) / zchunk;
   const int blocks = ntx * nty * ntz;
   if (resid && blocks > MG_MAX_PARTIALS) return hipErrorInvalidValue;

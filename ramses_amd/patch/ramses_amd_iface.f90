@@ -195,6 +195,28 @@ module ramses_amd_iface
        integer(c_int) :: igrid(*)
        integer(c_int) :: rc
      end function ramses_amd_cgmpi_p_cells
+     function ramses_amd_cgmpi_comm_set(ncpu, em_n, em_ig, rc_n, rc_ig) bind(C, name='ramses_amd_cgmpi_comm_set') result(rc)
+       import :: c_int
+       integer(c_int), value :: ncpu
+       integer(c_int) :: em_n(*), em_ig(*), rc_n(*), rc_ig(*)
+       integer(c_int) :: rc
+     end function ramses_amd_cgmpi_comm_set
+     function ramses_amd_cgmpi_p_halo_stage_out(ncpu, h_send_addr, h_recv_addr, send_off, recv_off) &
+          & bind(C, name='ramses_amd_cgmpi_p_halo_stage_out') result(rc)
+       import :: c_int, c_int64_t, c_ptr
+       integer(c_int), value :: ncpu
+       type(c_ptr) :: h_send_addr, h_recv_addr        ! int64_t* on the C side: the addresses of the pinned buffers
+       integer(c_int64_t) :: send_off(*), recv_off(*)
+       integer(c_int) :: rc
+     end function ramses_amd_cgmpi_p_halo_stage_out
+     function ramses_amd_cgmpi_p_halo_stage_in() bind(C, name='ramses_amd_cgmpi_p_halo_stage_in') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function ramses_amd_cgmpi_p_halo_stage_in
+     function ramses_amd_cgmpi_p_halo_rccl() bind(C, name='ramses_amd_cgmpi_p_halo_rccl') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function ramses_amd_cgmpi_p_halo_rccl
      function ramses_amd_cgmpi_end(phi, f) bind(C, name='ramses_amd_cgmpi_end') result(rc)
        import :: c_int, c_double
        real(c_double) :: phi(*), f(*)
@@ -1695,6 +1717,51 @@ contains
     rc = ramses_amd_mgamr_halo_stage_in(level, comp, dir)
     if (rc /= 0) call ramses_amd_fatal('multigrid_fine (virtual boundaries, unpack)')
   end subroutine ramses_amd_mg_halo
+#endif
+
+#ifndef WITHOUTMPI
+  !---------------------------------------------------------------------------
+  ! make_virtual_fine_dp(f(1,2),ilevel) of the conjugate-gradient loop (poisson/phi_fine_cg.f90:134) on the device vector p:
+  ! RCCL, or the program's own MPI on pinned host buffers when ranks share a GPU (ramses_amd_cgmpi_comm_set has sent the lists)
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_cg_p_halo()
+    use amr_commons
+    use mpi_mod
+    integer :: rc, icpu, info, nreq, cnt
+    type(c_ptr) :: hs, hr
+    real(c_double), pointer :: sbuf(:), rbuf(:)
+    integer(c_int64_t), dimension(ncpu + 1) :: soff, roff
+    integer, dimension(2*ncpu) :: req
+    integer, dimension(MPI_STATUS_SIZE, 2*ncpu) :: statuses
+    integer, parameter :: tag = 141
+    if (ramses_amd_halo_rccl) then
+       rc = ramses_amd_cgmpi_p_halo_rccl()
+       if (rc /= 0) call ramses_amd_fatal('phi_fine_cg (halo of p, RCCL exchange)')
+       return
+    end if
+    rc = ramses_amd_cgmpi_p_halo_stage_out(ncpu, hs, hr, soff, roff)
+    if (rc /= 0) call ramses_amd_fatal('phi_fine_cg (halo of p, pack)')
+    call c_f_pointer(hs, sbuf, [max(soff(ncpu + 1), 1_8)])
+    call c_f_pointer(hr, rbuf, [max(roff(ncpu + 1), 1_8)])
+    nreq = 0
+    do icpu = 1, ncpu
+       cnt = int(roff(icpu + 1) - roff(icpu))
+       if (cnt > 0) then
+          nreq = nreq + 1
+          call MPI_IRECV(rbuf(roff(icpu) + 1), cnt, MPI_DOUBLE_PRECISION, icpu - 1, tag, MPI_COMM_WORLD, req(nreq), info)
+       end if
+    end do
+    do icpu = 1, ncpu
+       cnt = int(soff(icpu + 1) - soff(icpu))
+       if (cnt > 0) then
+          nreq = nreq + 1
+          call MPI_ISEND(sbuf(soff(icpu) + 1), cnt, MPI_DOUBLE_PRECISION, icpu - 1, tag, MPI_COMM_WORLD, req(nreq), info)
+       end if
+    end do
+    call MPI_WAITALL(nreq, req, statuses, info)
+    rc = ramses_amd_cgmpi_p_halo_stage_in()
+    if (rc /= 0) call ramses_amd_fatal('phi_fine_cg (halo of p, unpack)')
+  end subroutine ramses_amd_cg_p_halo
 #endif
 
   !---------------------------------------------------------------------------

@@ -95,7 +95,7 @@ def test_amr_multigrid_under_mpi_equals_the_mpi_reference(gpu_lib, nproc, reside
     assert np.array_equal(got[2], ref[2]), np.abs(got[2] - ref[2]).max()     # hydro state
 
 
-@pytest.mark.parametrize("nproc,ordered", [(2, "1"), (4, "1"), (2, "0")])
+@pytest.mark.parametrize("nproc,ordered", [(2, "default"), (4, "default"), (8, "default"), (2, "hosthalo"), (2, "0")])
 def test_cg_levels_under_mpi_equal_the_mpi_reference(gpu_lib, nproc, ordered):
     """phi_fine_cg under MPI: cg_levelmin=4, so levels 4 and 5 of the self-gravitating AMR run
     are solved by the conjugate-gradient loop -- every loop body on the rank's GPU (ramses_amd_cgmpi_*), the two
@@ -110,7 +110,16 @@ def test_cg_levels_under_mpi_equal_the_mpi_reference(gpu_lib, nproc, ordered):
     spec.loader.exec_module(mk)
     nml = mk.cg_namelist().replace("ngridtot=6000 !", "ngridtot=60000 !")
     pat = r"==> Level=\s*(\d+) Step=\s*(\d+)"
-    workp, outp = _run(nml, PATCHED_MPI, nproc, {"RAMSES_AMD": "1", "RAMSES_AMD_CG_ORDERED": ordered})
+    # default: dot products in the reference's order (parity scan), the halo of p exchanged from the device vector;
+    # hosthalo: round 2's detour of p's virtual cells through the host array; "0": parallel-tree sums (equal to rounding)
+    if nproc > (os.cpu_count() or 1):
+        pytest.skip("fewer cores than ranks")
+    env = {"RAMSES_AMD": "1"}
+    if ordered == "0":
+        env["RAMSES_AMD_CG_ORDERED"] = "0"
+    if ordered == "hosthalo":
+        env["RAMSES_AMD_CG_HOST_HALO"] = "1"
+    workp, outp = _run(nml, PATCHED_MPI, nproc, env)
     try:
         assert "Entering phi_fine_cg" not in outp or "MI355X" in outp
         sol_p = np.array([[int(a), int(b)] for a, b in re.findall(pat, outp)])
@@ -125,7 +134,7 @@ def test_cg_levels_under_mpi_equal_the_mpi_reference(gpu_lib, nproc, ordered):
         shutil.rmtree(workr, ignore_errors=True)
     assert len(sol_r) > 0 and {4, 5} <= set(int(l) for l in sol_r[:, 0])
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
-    if ordered == "1":
+    if ordered != "0":
         assert np.array_equal(sol_p, sol_r)
         assert np.array_equal(got[3], ref[3]), np.abs(got[3] - ref[3]).max()     # phi, f
         assert np.array_equal(got[2], ref[2]), np.abs(got[2] - ref[2]).max()     # hydro state
