@@ -202,25 +202,40 @@ def vcycle_bench(level):
                          "frac": gbs / HBM_PEAK_GBS, "bytes_per_dof": BYTES_PER_DOF_VCYCLE}}
 
 
-def vcycle_bench_dist(level_local, pgrid, rank, world, transport=None):
-    """The same measurement on p^3 GPUs (weak scaling: 2^level_local cells per
-    direction per rank): distributed V-cycles with the 5-cell communication-
-    avoiding halo and replicated coarse levels (ramses_amd/poisson_parallel.py).
-    Collective: every rank calls it."""
+def mg_rank_grid(nranks):
+    """The rank grid of the distributed multigrid: the cubic box is cut along z first, then y, then x (2 ranks: two half
+    boxes, 4: four quarter columns, 8: the octants -- the brick shapes the reference's Hilbert decomposition gives 2^k ranks
+    on a uniform level); z first keeps the rows of a brick, which the smoother's tiles and the halo slabs stream, long."""
+    p = [1, 1, 1]
+    d = 2
+    r = nranks
+    while r > 1:
+        assert r % 2 == 0, "rank count must be a power of two"
+        p[d] *= 2
+        r //= 2
+        d = (d - 1) % 3
+    return tuple(p)
+
+
+def vcycle_bench_dist(level_local, rank, world, transport=None):
+    """The same measurement on N = 2^k GPUs: the reference's box is a cube (nx = ny = nz = 1 is not a namelist item), so the
+    level is the smallest cubic level that gives every GPU at least 2^level_local cells per direction's worth of work
+    (N = 2, 4, 8 with level_local = 9: the 1024^3 level in bricks of 1024 x 1024 x 512, 1024 x 512 x 512, 512^3);
+    distributed V-cycles with the 5-cell communication-avoiding halo and replicated coarse levels
+    (ramses_amd/poisson_parallel.py).  Collective: every rank calls it."""
+    import math
     import torch
-    import torch.distributed as dist
-    from ramses_amd.parallel import rank_coords
     from ramses_amd.poisson_parallel import PoissonDecomposition
-    n = 2 ** level_local
-    p = pgrid[0]
-    pd = PoissonDecomposition(pgrid, rank, n, boxlen=1.0, epsilon=1e-30, transport=transport)   # exactly MAXITER=10 V-cycles
-    N = n * p
+    pgrid = mg_rank_grid(world)
+    level = level_local + int(math.ceil(math.log2(world) / 3.0))
+    pd = PoissonDecomposition(pgrid, rank, level=level, boxlen=1.0, epsilon=1e-30, transport=transport)   # exactly MAXITER=10 V-cycles
+    N = 1 << level
     a, b = int(0.375 * N), int(0.625 * N)
-    c = rank_coords(rank, pgrid)
+    nx, ny, nz = pd.dims
     pd.rho.fill_(1.0)
     sl = []
-    for d in (2, 1, 0):                       # tensor axes are z, y, x
-        lo, hi = max(a - c[d] * n, 0), min(b - c[d] * n, n)
+    for d, nd in ((2, nz), (1, ny), (0, nx)):                       # tensor axes are z, y, x
+        lo, hi = max(a - pd.coords[d] * nd, 0), min(b - pd.coords[d] * nd, nd)
         sl.append(slice(lo, max(hi, lo)))
     pd.rho[sl[0], sl[1], sl[2]] = 10.0
     rho_tot = 1.0 + 9.0 * ((b - a) / N) ** 3
@@ -237,7 +252,7 @@ def vcycle_bench_dist(level_local, pgrid, rank, world, transport=None):
     dof = float(N) ** 3 * iters / t
     gbs = dof * BYTES_PER_DOF_VCYCLE / 1e9
     return {"metric": "V-cycle DOF/s (multigrid_fine)", "value": dof, "unit": "DOF/s", "n_gpus": world,
-            "level": int(round(__import__("math").log2(N))), "cells_per_gpu": "%d^3" % n,
+            "level": level, "rank_grid": "%dx%dx%d" % pgrid, "cells_per_gpu": "%dx%dx%d" % (nx, ny, nz),
             "vcycles": iters, "ms_per_vcycle": t / iters * 1e3, "final_error": err,
             "halo_exchanges_per_vcycle": pd.exchanges / iters,
             "replicated_levels_from": pd.lrep,
@@ -655,23 +670,18 @@ def main():
                 print(json.dumps(out), flush=True)
             os._exit(0)
 
-        if pgrid[0] == pgrid[1] == pgrid[2]:
-            wd = threading.Timer(args.vcycle_deadline, bail)
-            wd.daemon = True
-            wd.start()
-            try:
-                del lev, exchange, dec
-                torch.cuda.empty_cache()
-                vc = vcycle_bench_dist(args.vcycle_level, pgrid, rank, world, transport)
-            except Exception as exc:
-                vc = dict(note, error=str(exc)[:300])
-            wd.cancel()
-            if rank == 0:
-                out["vcycle"] = vc
-        elif rank == 0:
-            note["note"] = ("a periodic RAMSES box is a cube (nx=ny=nz=1; they are not namelist items of the reference), so a "
-                            "weak-scaling V-cycle at a fixed brick per GPU exists only on cubic rank grids: 1 and 8 GPUs")
-            out["vcycle"] = note
+        wd = threading.Timer(args.vcycle_deadline, bail)
+        wd.daemon = True
+        wd.start()
+        try:
+            del lev, exchange, dec
+            torch.cuda.empty_cache()
+            vc = vcycle_bench_dist(args.vcycle_level, rank, world, transport)
+        except Exception as exc:
+            vc = dict(note, error=str(exc)[:300])
+        wd.cancel()
+        if rank == 0:
+            out["vcycle"] = vc
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -344,28 +344,30 @@ int ramses_amd_godunov_fine_amr_device(const ramses_amd_hydro_params *p, int ile
                                        void *d_work, int *d_err, void *stream);
 
 /* ---------------------------------------------------------------------------
- * Distributed multigrid: one rank's n^3 brick of a periodic level with ng
- * ghost layers (pitch n+2ng), ghosts filled by the halo exchange
- * (make_virtual_mg_dp, poisson/multigrid_fine_commons.f90:1172-1270, replaced
- * by ramses_amd_halo_pack/unpack + RCCL).  The fused smoother recomputes the
+ * Distributed multigrid: one rank's nx x ny x nz brick of a periodic level
+ * (power-of-two extents; the bricks of 2 or 4 ranks in the reference's cubic
+ * box are not cubes) with ng ghost layers (pitches nx+2ng, ny+2ng), ghosts
+ * filled by the halo exchange (make_virtual_mg_dp,
+ * poisson/multigrid_fine_commons.f90:1172-1270, replaced by
+ * ramses_amd_halo_pack/unpack + RCCL).  The fused smoother recomputes the
  * neighbours' updates inside its ghost layers, so ONE ng-wide exchange replaces
  * the exchange after every colour pass (multigrid_fine_commons.f90:197-202).
  * Same arithmetic and operation order as the dense entry points.
  * ------------------------------------------------------------------------- */
 int ramses_amd_mg_smooth_fused_ghost(const double *d_phi_in, double *d_phi_out, const double *d_rhs,
-                                     double *d_res, double *d_work, double *d_norm2, int n, int ng,
+                                     double *d_res, double *d_work, double *d_norm2, int nx, int ny, int nz, int ng,
                                      double dx, int npass, void *stream);
 /* make_fine_bc_rhs (multigrid_fine_commons.f90:1058-1159), unmasked: f2 = fourpi*(rho-rho_tot) */
 int ramses_amd_mg_rhs(const double *d_rho, double *d_f2, int64_t N, double fourpi, double rho_tot, void *stream);
-/* restrict_residual_fine_reverse (multigrid_fine_fine.f90:528-590) on local bricks */
-int ramses_amd_mg_restrict_ghost(const double *d_res_f, double *d_rhs_c, int nf, int ngf, int ngc, void *stream);
+/* restrict_residual_fine_reverse (multigrid_fine_fine.f90:528-590) on local bricks (nf*: the FINE brick) */
+int ramses_amd_mg_restrict_ghost(const double *d_res_f, double *d_rhs_c, int nfx, int nfy, int nfz, int ngf, int ngc, void *stream);
 /* interpolate_and_correct_fine (:596-698): coarse correction = local brick with >= 1 valid
  * ghost layer (cglob = 0) or a replicated dense periodic cglob^3 level whose cell
  * coarse_origin[] is this rank's first coarse cell */
-int ramses_amd_mg_interp_correct_ghost(double *d_phi_f, int nf, int ngf, const double *d_corr_c, int ngc,
+int ramses_amd_mg_interp_correct_ghost(double *d_phi_f, int nfx, int nfy, int nfz, int ngf, const double *d_corr_c, int ngc,
                                        int cglob, const int *coarse_origin, void *stream);
-/* gradient_phi (poisson/force_fine.f90:199-324) on a local brick, d_f dense [3][n][n][n] */
-int ramses_amd_gradient_phi_ghost(const double *d_phi, double *d_f, int n, int ng, double dx, void *stream);
+/* gradient_phi (poisson/force_fine.f90:199-324) on a local brick, d_f dense [3][nz][ny][nx] */
+int ramses_amd_gradient_phi_ghost(const double *d_phi, double *d_f, int nx, int ny, int nz, int ng, double dx, void *stream);
 /* recursive_multigrid_coarse (multigrid_fine_commons.f90:307-390) on a dense periodic level */
 int ramses_amd_mg_coarse_solve_dense(int level, const double *d_rhs, double *d_u1, double *d_work, int safe,
                                      void *stream);
@@ -629,6 +631,50 @@ int ramses_amd_rccl_exchange(int npeer, const int *peer, const double *d_send, c
 int ramses_amd_rccl_sendrecv(int nsend, const double *const *send_ptr, const int64_t *send_cnt, const int *send_peer,
                              int nrecv, double *const *recv_ptr, const int64_t *recv_cnt, const int *recv_peer, void *stream);
 int ramses_amd_rccl_allreduce(double *d_buf, int n, int op, void *stream);
+/* d_recv[r*count .. (r+1)*count) = d_send of rank r */
+int ramses_amd_rccl_allgather(const double *d_send, int64_t count, double *d_recv, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * multigrid_fine of a periodic, fully refined level cut into one brick per rank, the V-cycle driver WITH its halo
+ * exchanges behind the C ABI (csrc/mg_dist.hip).  Replaces multigrid_fine + recursive_multigrid_coarse
+ * (poisson/multigrid_fine_commons.f90:25-296,307-390) and their make_virtual_mg_dp / make_virtual_fine_dp rounds
+ * (:1172-1290; amr/virtual_boundaries.f90:373-528) for a level whose rank domains are boxes: the 2^level cube on
+ * pgrid[0] x pgrid[1] x pgrid[2] ranks (powers of two; bricks of (2^level / pgrid[d]) cells, every extent >= 64).
+ * Brick b = x + pgrid[0]*(y + pgrid[1]*z) belongs to rank rank_of_brick[b] (NULL: the identity) -- the reference's
+ * Hilbert order of the domains is the caller's to state.
+ * transport NULL: RCCL inside the library (ramses_amd_rccl_init first).  Otherwise the caller's message layer on
+ * pinned HOST buffers, blocking calls (several ranks sharing one GPU; the Fortran shim's MPI; CPU protocol tests):
+ *   exchange      message i: send h_send[send_off[i] .. +send_cnt[i]) to rank peer[i], receive h_recv[recv_off[i] ..
+ *                 +recv_cnt[i]) from it (doubles; one message per peer, the caller's own rank never appears)
+ *   allgather     h_recv[r*count ..) = h_send of rank r
+ *   allreduce_sum *value = sum over the ranks, the same on every rank
+ * each returning 0 on success.
+ * ramses_amd_mgdist_solve: d_rho = this rank's dense [nz][ny][nx] brick of the density; phi starts from zero;
+ * convergence test, MAXITER and the safe-mode switch of multigrid_fine_commons.f90:261-282 (the flag persists in the
+ * context like the reference's safe_mode(ilevel)).  _get_phi / _set_phi: dense bricks; _force: halo of phi +
+ * gradient_phi into a dense [3][nz][ny][nx] array (poisson/force_fine.f90:199-324).
+ * ------------------------------------------------------------------------- */
+typedef struct ramses_amd_mg_transport {
+  void *user;
+  int (*exchange)(void *user, int npeer, const int *peer, const double *h_send, const int64_t *send_off,
+                  const int64_t *send_cnt, double *h_recv, const int64_t *recv_off, const int64_t *recv_cnt);
+  int (*allgather)(void *user, const double *h_send, int64_t count, double *h_recv);
+  int (*allreduce_sum)(void *user, double *value);
+} ramses_amd_mg_transport;
+typedef struct ramses_amd_mgdist ramses_amd_mgdist;
+int ramses_amd_mgdist_create(int level, const int *pgrid, int rank, const int *rank_of_brick,
+                             const ramses_amd_mg_transport *transport, ramses_amd_mgdist **out);
+int ramses_amd_mgdist_destroy(ramses_amd_mgdist *ctx);
+/* any output may be NULL: brick extents and coordinates of this rank, number of distributed levels, first replicated
+ * level (0: none), the safe-mode flag, halo exchanges so far */
+int ramses_amd_mgdist_info(const ramses_amd_mgdist *ctx, int *dims, int *coords, int *n_distributed_levels,
+                           int *first_replicated_level, int *safe_mode, int64_t *exchanges);
+int ramses_amd_mgdist_set_safe_mode(ramses_amd_mgdist *ctx, int safe_mode);
+int ramses_amd_mgdist_solve(ramses_amd_mgdist *ctx, const double *d_rho, double rho_tot, double fourpi, double epsilon,
+                            int *iters_out, double *err_out, void *stream);
+int ramses_amd_mgdist_get_phi(ramses_amd_mgdist *ctx, double *d_phi, void *stream);
+int ramses_amd_mgdist_set_phi(ramses_amd_mgdist *ctx, const double *d_phi, void *stream);
+int ramses_amd_mgdist_force(ramses_amd_mgdist *ctx, double *d_f, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Device image of the reference's communicators (type communicator, amr/amr_commons.f90:108-119;

@@ -76,7 +76,7 @@ SYMBOLS = [
     ("ramses_amd_multigrid_fine_f90", _i, [_i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _d, _d, _d,
                                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     ("ramses_amd_godunov_fine_f90", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _i, _d, _d]),
-    ("ramses_amd_mg_smooth_fused_ghost", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _i, _vp]),
+    ("ramses_amd_mg_smooth_fused_ghost", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _i, _vp]),
     ("ramses_amd_godunov_fine_amr_host", _i, [_PP, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _d, _d, _i, _i, _i]),
     ("ramses_amd_godunov_fine_amr_f90", _i, [_PP, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _d, _d, _i, _i, _i]),
     ("ramses_amd_godunov_fine_amr_workspace", _i64, [_i, _i64]),
@@ -84,9 +84,9 @@ SYMBOLS = [
     ("ramses_amd_halo_multi", _i, [_PB, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
     ("ramses_amd_make_boundary_hydro", _i, [_PP, _PB, _vp, _i, _i, _vp, _i, _vp]),
     ("ramses_amd_mg_rhs", _i, [_vp, _vp, _i64, _d, _d, _vp]),
-    ("ramses_amd_mg_restrict_ghost", _i, [_vp, _vp, _i, _i, _i, _vp]),
-    ("ramses_amd_mg_interp_correct_ghost", _i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
-    ("ramses_amd_gradient_phi_ghost", _i, [_vp, _vp, _i, _i, _d, _vp]),
+    ("ramses_amd_mg_restrict_ghost", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    ("ramses_amd_mg_interp_correct_ghost", _i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    ("ramses_amd_gradient_phi_ghost", _i, [_vp, _vp, _i, _i, _i, _i, _d, _vp]),
     ("ramses_amd_mg_coarse_solve_dense", _i, [_i, _vp, _vp, _vp, _i, _vp]),
     ("ramses_amd_mgamr_begin", _i, [_i, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     ("ramses_amd_mgamr_add_level", _i, [_i, _i, _vp, _vp, _vp]),
@@ -150,6 +150,15 @@ SYMBOLS = [
     ("ramses_amd_rccl_exchange", _i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("ramses_amd_rccl_sendrecv", _i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     ("ramses_amd_rccl_allreduce", _i, [_vp, _i, _i, _vp]),
+    ("ramses_amd_rccl_allgather", _i, [_vp, _i64, _vp, _vp]),
+    ("ramses_amd_mgdist_create", _i, [_i, _vp, _i, _vp, _vp, _vp]),
+    ("ramses_amd_mgdist_destroy", _i, [_vp]),
+    ("ramses_amd_mgdist_info", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("ramses_amd_mgdist_set_safe_mode", _i, [_vp, _i]),
+    ("ramses_amd_mgdist_solve", _i, [_vp, _vp, _d, _d, _d, _vp, _vp, _vp]),
+    ("ramses_amd_mgdist_get_phi", _i, [_vp, _vp, _vp]),
+    ("ramses_amd_mgdist_set_phi", _i, [_vp, _vp, _vp]),
+    ("ramses_amd_mgdist_force", _i, [_vp, _vp, _vp]),
     ("ramses_amd_halo_plan", _i, [_i, _i, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     ("ramses_amd_mpires_setup", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("ramses_amd_mpires_active", _i, []),

@@ -35,6 +35,7 @@ UNITS = [
     ("capi_mpi.o", "capi_mpi.hip", ["-ffp-contract=off"]),
     ("capi_amr.o", "capi_amr.hip", ["-ffp-contract=off"]),
     ("pois_amr.o", "pois_amr.hip", ["-ffp-contract=off"]),
+    ("mg_dist.o", "mg_dist.hip", ["-ffp-contract=off"]),
 ]
 
 
@@ -48,9 +49,32 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libramses_amd.so cannot be built")
 
 
-def _deps():
-    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))] + \
-           [os.path.join(HERE, "..", "include", "ramses_amd.h")]
+_INC = None
+
+
+def _deps(src):
+    """the headers a source file reaches through #include "..." (csrc/ and include/), transitively:
+    a change of the C ABI header rebuilds only the units that include it, not the ten-minute sweep kernels"""
+    import re
+    global _INC
+    if _INC is None:
+        _INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+    seen, todo = set(), [src]
+    while todo:
+        f = todo.pop()
+        try:
+            text = open(f).read()
+        except OSError:
+            continue
+        for inc in _INC.findall(text):
+            for base in (os.path.dirname(f), CSRC, os.path.join(HERE, "..", "include")):
+                cand = os.path.normpath(os.path.join(base, inc))
+                if os.path.exists(cand):
+                    if cand not in seen:
+                        seen.add(cand)
+                        todo.append(cand)
+                    break
+    return sorted(seen)
 
 
 def _stale(target, sources):
@@ -64,7 +88,6 @@ def build(force=False, verbose=False):
     os.makedirs(BUILD, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    deps = _deps()
     jobs = []
     objs = []
     for obj, src, flags in UNITS:
@@ -73,7 +96,7 @@ def build(force=False, verbose=False):
             continue
         objp = os.path.join(BUILD, obj)
         objs.append(objp)
-        if force or _stale(objp, [srcp] + deps):
+        if force or _stale(objp, [srcp] + _deps(srcp)):
             jobs.append([hipcc] + COMMON + flags + ["-c", srcp, "-o", objp])
 
     def run(cmd):

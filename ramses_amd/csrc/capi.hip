@@ -570,16 +570,19 @@ static hipError_t mg_coarse_cycle(double *w, int level, int l, int safe, hipStre
 // Distributed multigrid (one rank's brick with ghost layers per level; the
 // V-cycle driver with its halo exchanges is ramses_amd/poisson_parallel.py).
 // ---------------------------------------------------------------------------
+static bool brick_extent_ok(int n) { return n >= 2 && !(n & (n - 1)); }
 int ramses_amd_mg_smooth_fused_ghost(const double *d_phi_in, double *d_phi_out, const double *d_rhs,
-                                     double *d_res, double *d_work, double *d_norm2, int n, int ng,
+                                     double *d_res, double *d_work, double *d_norm2, int nx, int ny, int nz, int ng,
                                      double dx, int npass, void *stream) {
-  if (!d_phi_in || !d_phi_out || !d_rhs || d_phi_in == d_phi_out || n < 2 || (n & 1)) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  if (!d_phi_in || !d_phi_out || !d_rhs || d_phi_in == d_phi_out) return fail(RAMSES_AMD_EINVAL, "bad argument");
+  if (!brick_extent_ok(nx) || !brick_extent_ok(ny) || !brick_extent_ok(nz)) return fail(RAMSES_AMD_EINVAL, "brick extents must be powers of two (got %d x %d x %d)", nx, ny, nz);
   if (npass != 2 && npass != 4) return fail(RAMSES_AMD_EINVAL, "npass must be 2 or 4");
-  if (n < 64) return fail(RAMSES_AMD_EINVAL, "the fused smoother needs n >= 64 (got %d)", n);
+  if (nx < 64 || ny < 64 || nz < 64) return fail(RAMSES_AMD_EINVAL, "the fused smoother needs every extent >= 64 (got %d x %d x %d)", nx, ny, nz);
   const int H = (d_res || d_norm2) ? npass + 1 : npass;
   if (ng < H) return fail(RAMSES_AMD_EINVAL, "ghost width %d does not cover the %d-cell dependency cone of %d colour passes", ng, H, npass);
   if ((d_res || d_norm2) && !d_work) return fail(RAMSES_AMD_EINVAL, "residual/norm need a workspace of %d doubles", MG_MAX_PARTIALS);
-  MGCHK(mg_launch_smooth_fused(d_phi_in, d_phi_out, d_rhs, d_res, d_work, d_norm2, n, dx, npass, reinterpret_cast<hipStream_t>(stream), ng), "mg fused smoother launch");
+  MGCHK(mg_launch_smooth_fused(d_phi_in, d_phi_out, d_rhs, d_res, d_work, d_norm2, nx, dx, npass, reinterpret_cast<hipStream_t>(stream), ng,
+                               nullptr, nullptr, nullptr, ny, nz), "mg fused smoother launch");
   return 0;
 }
 // f2 = fourpi*(rho - rho_tot) over N doubles (make_fine_bc_rhs on an unmasked level)
@@ -588,25 +591,28 @@ int ramses_amd_mg_rhs(const double *d_rho, double *d_f2, int64_t N, double fourp
   MGCHK(mg_launch_rhs(d_rho, d_f2, (long)N, fourpi, rho_tot, reinterpret_cast<hipStream_t>(stream)), "mg rhs launch");
   return 0;
 }
-int ramses_amd_mg_restrict_ghost(const double *d_res_f, double *d_rhs_c, int nf, int ngf, int ngc, void *stream) {
-  if (!d_res_f || !d_rhs_c || nf < 2 || (nf & (nf - 1)) || ngf < 0 || ngc < 0) return fail(RAMSES_AMD_EINVAL, "bad argument (nf must be a power of two)");
-  MGCHK(mg_launch_restrict_ghost(d_res_f, d_rhs_c, nf, ngf, ngc, reinterpret_cast<hipStream_t>(stream)), "mg restrict launch");
+int ramses_amd_mg_restrict_ghost(const double *d_res_f, double *d_rhs_c, int nfx, int nfy, int nfz, int ngf, int ngc, void *stream) {
+  if (!d_res_f || !d_rhs_c || !brick_extent_ok(nfx) || !brick_extent_ok(nfy) || !brick_extent_ok(nfz) || ngf < 0 || ngc < 0)
+    return fail(RAMSES_AMD_EINVAL, "bad argument (brick extents must be powers of two)");
+  MGCHK(mg_launch_restrict_ghost(d_res_f, d_rhs_c, nfx, nfy, nfz, ngf, ngc, reinterpret_cast<hipStream_t>(stream)), "mg restrict launch");
   return 0;
 }
-int ramses_amd_mg_interp_correct_ghost(double *d_phi_f, int nf, int ngf, const double *d_corr_c, int ngc,
+int ramses_amd_mg_interp_correct_ghost(double *d_phi_f, int nfx, int nfy, int nfz, int ngf, const double *d_corr_c, int ngc,
                                        int cglob, const int *coarse_origin, void *stream) {
-  if (!d_phi_f || !d_corr_c || nf < 2 || (nf & (nf - 1)) || ngf < 0) return fail(RAMSES_AMD_EINVAL, "bad argument (nf must be a power of two)");
+  if (!d_phi_f || !d_corr_c || !brick_extent_ok(nfx) || !brick_extent_ok(nfy) || !brick_extent_ok(nfz) || ngf < 0)
+    return fail(RAMSES_AMD_EINVAL, "bad argument (brick extents must be powers of two)");
   if (cglob == 0 && ngc < 1) return fail(RAMSES_AMD_EINVAL, "the local coarse brick needs >= 1 ghost layer");
   if (cglob != 0 && !coarse_origin) return fail(RAMSES_AMD_EINVAL, "replicated coarse level needs the origin of this rank's part");
   const int ox = coarse_origin ? coarse_origin[0] : 0, oy = coarse_origin ? coarse_origin[1] : 0, oz = coarse_origin ? coarse_origin[2] : 0;
-  MGCHK(mg_launch_interp_ghost(d_phi_f, nf, ngf, d_corr_c, ngc, cglob, ox, oy, oz, reinterpret_cast<hipStream_t>(stream)), "mg interp launch");
+  MGCHK(mg_launch_interp_ghost(d_phi_f, nfx, nfy, nfz, ngf, d_corr_c, ngc, cglob, ox, oy, oz, reinterpret_cast<hipStream_t>(stream)), "mg interp launch");
   return 0;
 }
-int ramses_amd_gradient_phi_ghost(const double *d_phi, double *d_f, int n, int ng, double dx, void *stream) {
-  if (!d_phi || !d_f || n < 2 || (n & (n - 1)) || ng < 2) return fail(RAMSES_AMD_EINVAL, "gradient_phi needs a power-of-two brick with 2 ghost layers of phi");
+int ramses_amd_gradient_phi_ghost(const double *d_phi, double *d_f, int nx, int ny, int nz, int ng, double dx, void *stream) {
+  if (!d_phi || !d_f || !brick_extent_ok(nx) || !brick_extent_ok(ny) || !brick_extent_ok(nz) || ng < 2)
+    return fail(RAMSES_AMD_EINVAL, "gradient_phi needs a brick of power-of-two extents with 2 ghost layers of phi");
   const double a = 0.50 * 4.0 / 3.0 / dx;   // force_fine.f90:233-234
   const double b = 0.25 * 1.0 / 3.0 / dx;
-  MGCHK(mg_launch_gradient_ghost(d_phi, d_f, n, ng, a, b, reinterpret_cast<hipStream_t>(stream)), "gradient_phi launch");
+  MGCHK(mg_launch_gradient_ghost(d_phi, d_f, nx, ny, nz, ng, a, b, reinterpret_cast<hipStream_t>(stream)), "gradient_phi launch");
   return 0;
 }
 // recursive_multigrid_coarse on a dense periodic level (a replicated coarse level

@@ -57,6 +57,7 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   ncclComm_t comm = nullptr;
   int nranks = 0, rank = -1;
@@ -83,6 +84,7 @@ int rccl_load() {
   SYM(GroupStart, "ncclGroupStart");
   SYM(GroupEnd, "ncclGroupEnd");
   SYM(AllReduce, "ncclAllReduce");
+  SYM(AllGather, "ncclAllGather");
   SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
   return 0;
@@ -206,6 +208,15 @@ int ramses_amd_rccl_allreduce(double *d_buf, int n, int op, void *stream) {
   if (!d_buf || n < 1 || op < 0 || op > 2) return failf(RAMSES_AMD_EINVAL, "bad argument");
   const ncclRedOp_t o = op == 0 ? ncclSum : (op == 1 ? ncclMin : ncclMax);
   NCHK(R.AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, o, R.comm, reinterpret_cast<hipStream_t>(stream)), "ncclAllReduce");
+  return 0;
+}
+
+// d_recv[r*count .. (r+1)*count) = d_send of rank r (the replicated coarse levels of the distributed multigrid)
+int ramses_amd_rccl_allgather(const double *d_send, int64_t count, double *d_recv, void *stream) {
+  Rccl &R = g_rccl;
+  if (!R.comm) return failf(RAMSES_AMD_EINVAL, "RCCL communicator not initialised (ramses_amd_rccl_init)");
+  if (!d_send || !d_recv || count < 1) return failf(RAMSES_AMD_EINVAL, "bad argument");
+  NCHK(R.AllGather(d_send, d_recv, (size_t)count, ncclDouble, R.comm, reinterpret_cast<hipStream_t>(stream)), "ncclAllGather");
   return 0;
 }
 

@@ -1,0 +1,512 @@
+// mg_dist.hip -- multigrid_fine of a periodic, fully refined level cut into one brick per rank (one rank per GPU):
+// the V-cycle driver WITH its halo exchanges behind the C ABI (ramses_amd_mgdist_*), so that the Fortran shim
+// (ramses_amd/patch/multigrid_fine_commons.f90) and the Python mirror (ramses_amd/poisson_parallel.py) bind the same
+// entry points.  Reference:
+//     multigrid_fine(ilevel,icount)      poisson/multigrid_fine_commons.f90:25-296
+//     recursive_multigrid_coarse         :307-390
+//     make_virtual_mg_dp / _fine_dp      :1172-1290, amr/virtual_boundaries.f90:373-528   (the exchanges replaced here)
+//     force_fine / gradient_phi          poisson/force_fine.f90:5-324
+//
+// The reference's box is a cube; 2^k ranks own bricks of power-of-two extents (2 ranks: half boxes, 4: quarter columns,
+// 8: octants -- the Hilbert decomposition of a uniform level).  MI355X-first choices:
+//  * every level of a rank is a brick inside NG = 5 ghost layers; the fused smoother recomputes the neighbours' updates
+//    inside them, so ONE 5-cell exchange per smoother launch replaces the reference's exchange after every colour pass;
+//    the 26 neighbour regions travel as one message per peer (7 peers on a 2x2x2 node: every xGMI link at once);
+//  * levels whose brick would fall below the smoother's 64-cell tile in any direction are REPLICATED: one all-gather of
+//    the restricted residual, then every rank runs the rest of the V-cycle on the whole coarse level (the single-GPU
+//    code) and reads its part of the correction;
+//  * transport: RCCL inside this library (ramses_amd_rccl_*), or -- ranks sharing a GPU, CPU protocol tests -- the
+//    caller's own message layer through three callbacks on pinned host buffers.
+// All arithmetic is that of the dense single-brick kernels in the reference's operation order: phi equals the
+// single-rank solve bit for bit whenever the iteration counts agree.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/ramses_amd.h"
+#include "mg_args.hpp"
+
+using namespace ramses_amd;
+
+extern "C" int ramses_amd_set_error(int code, const char *msg);   // capi.hip
+
+namespace {
+
+constexpr int NG = 5;            // ghost layers: 4 colour passes + the residual's stencil
+constexpr int MIN_FUSED = 64;    // the fused smoother's tile width
+constexpr int MAXITER = 10;      // multigrid_fine_commons.f90:34
+constexpr double SAFE_FACTOR = 0.5;   // :35
+
+int failf(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return ramses_amd_set_error(code, buf);
+}
+#define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return failf(RAMSES_AMD_EHIP, "%s: %s", what, hipGetErrorString(e_)); } while (0)
+#define RCHK(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+struct Seg {
+  int peer;
+  int64_t off, cnt;
+};
+
+// the 26 neighbour regions of a brick, ordered by peer so that every peer gets ONE message.  Region g (an offset in
+// {-1,0,1}^3) of MY ghost layers is filled from the neighbour at coords+g, which sends its interior region next to its
+// side -g; both sides order a peer's regions by the sender's offset index.
+struct HaloPlan {
+  int boxes_s[26 * 6], boxes_r[26 * 6];
+  int64_t offs_s[26], offs_r[26];
+  std::vector<Seg> segs_s, segs_r;   // one per peer, same peers in the same order on both sides
+  int64_t total = 0;
+  double *d_send = nullptr, *d_recv = nullptr;
+  double *h_send = nullptr, *h_recv = nullptr;   // pinned, callback transport only
+};
+
+struct Level {
+  int l = 0;
+  int n[3] = {0, 0, 0};
+  ramses_amd_brick brick;
+  size_t cells = 0;        // allocated cells (with ghosts)
+  double *u[4] = {nullptr, nullptr, nullptr, nullptr};
+  HaloPlan plan;
+  bool built = false;
+};
+
+// whole replicated level from the all-gathered parts: parts[r] = the [nz][ny][nx] brick of rank r
+__global__ __launch_bounds__(256) void assemble_kernel(const double *__restrict__ parts, double *__restrict__ cube,
+                                                       const int *__restrict__ rank_of_brick, int px, int py, int nx,
+                                                       int ny, int nz, int N) {
+  const long total = (long)N * N * N;
+  const long part = (long)nx * ny * nz;
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(c % N), j = (int)((c / N) % N), k = (int)(c / ((long)N * N));
+    const int bx = i / nx, by = j / ny, bz = k / nz;
+    const int r = rank_of_brick[bx + px * (by + py * bz)];
+    cube[c] = parts[(long)r * part + (i - bx * nx) + (long)nx * ((j - by * ny) + (long)ny * (k - bz * nz))];
+  }
+}
+
+}  // namespace
+
+struct ramses_amd_mgdist {
+  int level = 0, pgrid[3] = {1, 1, 1}, coords[3] = {0, 0, 0}, rank = 0, world = 1;
+  int dims[3] = {0, 0, 0};
+  std::vector<int> rank_of_brick;
+  int *d_rank_of_brick = nullptr;
+  bool use_rccl = false;
+  ramses_amd_mg_transport tr;
+  std::vector<Level> lev;     // indexed by level; built = distributed
+  int lrep = 0, rep_dims[3] = {0, 0, 0};
+  Level rep_local;
+  double *rep_rhs = nullptr, *rep_u1 = nullptr, *rep_work = nullptr, *rep_parts = nullptr, *rep_mine = nullptr;
+  double *h_parts = nullptr, *h_mine = nullptr;
+  double *work = nullptr, *norm = nullptr, *dense = nullptr;   // dense: one brick without ghosts (rhs staging)
+  int safe_mode = 0;
+  int64_t exchanges = 0;
+  int last_iters = 0;
+  double last_err = 0.0;
+};
+
+namespace {
+
+int brick_rank(const ramses_amd_mgdist *M, int cx, int cy, int cz) {
+  const int px = M->pgrid[0], py = M->pgrid[1], pz = M->pgrid[2];
+  cx = ((cx % px) + px) % px; cy = ((cy % py) + py) % py; cz = ((cz % pz) + pz) % pz;
+  return M->rank_of_brick[cx + px * (cy + py * cz)];
+}
+
+int build_plan(ramses_amd_mgdist *M, Level &L) {
+  const int ng = NG;
+  int offs[26][3], nof = 0;
+  for (int oz = -1; oz <= 1; oz++)
+    for (int oy = -1; oy <= 1; oy++)
+      for (int ox = -1; ox <= 1; ox++)
+        if (ox || oy || oz) { offs[nof][0] = ox; offs[nof][1] = oy; offs[nof][2] = oz; nof++; }
+  auto index_of = [&](int ox, int oy, int oz) {
+    for (int i = 0; i < 26; i++) if (offs[i][0] == ox && offs[i][1] == oy && offs[i][2] == oz) return i;
+    return -1;
+  };
+  auto peer = [&](const int *o) { return brick_rank(M, M->coords[0] + o[0], M->coords[1] + o[1], M->coords[2] + o[2]); };
+  int order_s[26], order_r[26];
+  for (int i = 0; i < 26; i++) order_s[i] = order_r[i] = i;
+  std::sort(order_s, order_s + 26, [&](int a, int b) {
+    const int pa = peer(offs[a]), pb = peer(offs[b]);
+    return pa != pb ? pa < pb : a < b;
+  });
+  std::sort(order_r, order_r + 26, [&](int a, int b) {
+    const int pa = peer(offs[a]), pb = peer(offs[b]);
+    if (pa != pb) return pa < pb;
+    return index_of(-offs[a][0], -offs[a][1], -offs[a][2]) < index_of(-offs[b][0], -offs[b][1], -offs[b][2]);
+  });
+  HaloPlan &P = L.plan;
+  for (int side = 0; side < 2; side++) {
+    const int *order = side == 0 ? order_s : order_r;
+    int *boxes = side == 0 ? P.boxes_s : P.boxes_r;
+    int64_t *offsets = side == 0 ? P.offs_s : P.offs_r;
+    std::vector<Seg> &segs = side == 0 ? P.segs_s : P.segs_r;
+    int64_t pos = 0;
+    for (int r = 0; r < 26; r++) {
+      const int *o = offs[order[r]];
+      int64_t size = 1;
+      for (int d = 0; d < 3; d++) {
+        int org, ext = o[d] == 0 ? L.n[d] : ng;
+        if (side == 0) org = o[d] <= 0 ? ng : L.n[d];                         // interior cells next to side o
+        else org = o[d] < 0 ? 0 : (o[d] == 0 ? ng : ng + L.n[d]);            // ghost cells on side g
+        boxes[6 * r + d] = org;
+        boxes[6 * r + 3 + d] = ext;
+        size *= ext;
+      }
+      offsets[r] = pos;
+      const int q = peer(o);
+      if (!segs.empty() && segs.back().peer == q) segs.back().cnt += size;
+      else segs.push_back(Seg{q, pos, size});
+      pos += size;
+    }
+    P.total = pos;
+  }
+  if (P.segs_s.size() != P.segs_r.size()) return failf(RAMSES_AMD_EINVAL, "halo plan: send and receive peers differ");
+  for (size_t i = 0; i < P.segs_s.size(); i++)
+    if (P.segs_s[i].peer != P.segs_r[i].peer || P.segs_s[i].cnt != P.segs_r[i].cnt)
+      return failf(RAMSES_AMD_EINVAL, "halo plan: message sizes of peer %d differ", P.segs_s[i].peer);
+  HCHK(hipMalloc(&P.d_send, sizeof(double) * P.total), "hipMalloc");
+  HCHK(hipMalloc(&P.d_recv, sizeof(double) * P.total), "hipMalloc");
+  if (!M->use_rccl) {
+    HCHK(hipHostMalloc(&P.h_send, sizeof(double) * P.total), "hipHostMalloc");
+    HCHK(hipHostMalloc(&P.h_recv, sizeof(double) * P.total), "hipHostMalloc");
+  }
+  return 0;
+}
+
+int build_level(ramses_amd_mgdist *M, Level &L, int l, const int *dims, bool with_plan) {
+  L.l = l;
+  for (int d = 0; d < 3; d++) L.n[d] = dims[d];
+  ramses_amd_brick_dense(&L.brick, dims[0], dims[1], dims[2], NG);
+  L.cells = (size_t)(dims[0] + 2 * NG) * (dims[1] + 2 * NG) * (dims[2] + 2 * NG);
+  for (int a = 0; a < 4; a++) {
+    HCHK(hipMalloc(&L.u[a], sizeof(double) * L.cells), "hipMalloc (multigrid level)");
+    HCHK(hipMemset(L.u[a], 0, sizeof(double) * L.cells), "hipMemset");
+  }
+  L.built = true;
+  if (with_plan) RCHK(build_plan(M, L));
+  return 0;
+}
+
+void free_level(Level &L) {
+  for (int a = 0; a < 4; a++) if (L.u[a]) { (void)hipFree(L.u[a]); L.u[a] = nullptr; }
+  HaloPlan &P = L.plan;
+  if (P.d_send) (void)hipFree(P.d_send);
+  if (P.d_recv) (void)hipFree(P.d_recv);
+  if (P.h_send) (void)hipHostFree(P.h_send);
+  if (P.h_recv) (void)hipHostFree(P.h_recv);
+  P.d_send = P.d_recv = P.h_send = P.h_recv = nullptr;
+  L.built = false;
+}
+
+// forward halo of the brick tensor t (NG layers, faces + edges + corners) in ONE round
+int exchange(ramses_amd_mgdist *M, Level &L, double *t, hipStream_t s) {
+  HaloPlan &P = L.plan;
+  RCHK(ramses_amd_halo_multi(&L.brick, t, 1, 26, P.boxes_s, P.offs_s, P.d_send, 1, s));
+  const int np = (int)P.segs_s.size();
+  std::vector<int> peers;
+  std::vector<int64_t> so, sc, ro, rc;
+  for (int i = 0; i < np; i++) {
+    const Seg &a = P.segs_s[i], &b = P.segs_r[i];
+    if (a.peer == M->rank) {
+      if (M->use_rccl)   // periodic wrap onto myself
+        HCHK(hipMemcpyAsync(P.d_recv + b.off, P.d_send + a.off, sizeof(double) * a.cnt, hipMemcpyDeviceToDevice, s), "self copy");
+      continue;
+    }
+    peers.push_back(a.peer); so.push_back(a.off); sc.push_back(a.cnt); ro.push_back(b.off); rc.push_back(b.cnt);
+  }
+  if (M->use_rccl) {
+    if (!peers.empty())
+      RCHK(ramses_amd_rccl_exchange((int)peers.size(), peers.data(), P.d_send, so.data(), sc.data(), P.d_recv, ro.data(), rc.data(), s));
+  } else {
+    HCHK(hipMemcpyAsync(P.h_send, P.d_send, sizeof(double) * P.total, hipMemcpyDeviceToHost, s), "halo D2H");
+    HCHK(hipStreamSynchronize(s), "stream sync");
+    for (int i = 0; i < np; i++)
+      if (P.segs_s[i].peer == M->rank)
+        std::memcpy(P.h_recv + P.segs_r[i].off, P.h_send + P.segs_s[i].off, sizeof(double) * P.segs_s[i].cnt);
+    if (!peers.empty()) {
+      if (!M->tr.exchange) return failf(RAMSES_AMD_EINVAL, "distributed multigrid: no transport (exchange callback missing)");
+      const int rc_ = M->tr.exchange(M->tr.user, (int)peers.size(), peers.data(), P.h_send, so.data(), sc.data(), P.h_recv, ro.data(), rc.data());
+      if (rc_) return failf(RAMSES_AMD_EHIP, "distributed multigrid: the transport's exchange failed (%d)", rc_);
+    }
+    HCHK(hipMemcpyAsync(P.d_recv, P.h_recv, sizeof(double) * P.total, hipMemcpyHostToDevice, s), "halo H2D");
+  }
+  RCHK(ramses_amd_halo_multi(&L.brick, t, 1, 26, P.boxes_r, P.offs_r, P.d_recv, 0, s));
+  M->exchanges++;
+  return 0;
+}
+
+// interior of a ghost brick <-> a dense [nz][ny][nx] array
+int interior_copy(Level &L, double *t, double *dense, int pack, hipStream_t s) {
+  const int box[6] = {NG, NG, NG, L.n[0], L.n[1], L.n[2]};
+  const int64_t off = 0;
+  return ramses_amd_halo_multi(&L.brick, t, 1, 1, box, &off, dense, pack, s);
+}
+
+int allreduce_sum(ramses_amd_mgdist *M, double *d_value, double *out, hipStream_t s) {
+  if (M->use_rccl && M->world > 1) RCHK(ramses_amd_rccl_allreduce(d_value, 1, 0, s));
+  HCHK(hipMemcpyAsync(out, d_value, sizeof(double), hipMemcpyDeviceToHost, s), "norm copy");
+  HCHK(hipStreamSynchronize(s), "stream sync");
+  if (!M->use_rccl && M->world > 1) {
+    if (!M->tr.allreduce_sum) return failf(RAMSES_AMD_EINVAL, "distributed multigrid: no transport (allreduce callback missing)");
+    const int rc_ = M->tr.allreduce_sum(M->tr.user, out);
+    if (rc_) return failf(RAMSES_AMD_EHIP, "distributed multigrid: the transport's allreduce failed (%d)", rc_);
+  }
+  return 0;
+}
+
+hipError_t fused(ramses_amd_mgdist *M, Level &L, const double *src, double *dst, const double *rhs, double *res, double *norm, hipStream_t s) {
+  const double dx = std::ldexp(1.0, -L.l);
+  return mg_launch_smooth_fused(src, dst, rhs, res, (res || norm) ? M->work : nullptr, norm, L.n[0], dx, 4, s, NG, nullptr, nullptr, nullptr,
+                                L.n[1], L.n[2]);
+}
+
+bool distributed(const ramses_amd_mgdist *M, int l) { return l >= 1 && l < (int)M->lev.size() && M->lev[l].built; }
+
+// restrict the residual of level l into level l-1 (its u2) and zero that level's correction
+int restrict_to(ramses_amd_mgdist *M, int l, const double *res, hipStream_t s) {
+  if (l - 1 < 1) return 0;
+  Level &Lf = M->lev[l];
+  Level *Lc = distributed(M, l - 1) ? &M->lev[l - 1] : &M->rep_local;
+  if (distributed(M, l - 1)) HCHK(hipMemsetAsync(Lc->u[0], 0, sizeof(double) * Lc->cells, s), "memset");
+  HCHK(mg_launch_restrict_ghost(res, Lc->u[1], Lf.n[0], Lf.n[1], Lf.n[2], NG, NG, s), "mg restrict launch");
+  return 0;
+}
+
+// phi_f += prolongation of the correction of level lc
+int interp_from(ramses_amd_mgdist *M, Level &Lf, double *phi_f, int lc, hipStream_t s) {
+  if (distributed(M, lc)) {
+    Level &Lc = M->lev[lc];
+    RCHK(exchange(M, Lc, Lc.u[0], s));     // one ghost layer is needed; the region mover sends all NG
+    HCHK(mg_launch_interp_ghost(phi_f, Lf.n[0], Lf.n[1], Lf.n[2], NG, Lc.u[0], NG, 0, 0, 0, 0, s), "mg interp launch");
+  } else {
+    HCHK(mg_launch_interp_ghost(phi_f, Lf.n[0], Lf.n[1], Lf.n[2], NG, M->rep_u1, 0, 1 << M->lrep, M->coords[0] * M->rep_dims[0],
+                                M->coords[1] * M->rep_dims[1], M->coords[2] * M->rep_dims[2], s), "mg interp launch");
+  }
+  return 0;
+}
+
+// recursive_multigrid_coarse (multigrid_fine_commons.f90:307-390); on entry the restricted residual is in the level's
+// u2 interior and u1 is zero
+int coarse_cycle(ramses_amd_mgdist *M, int l, int safe, hipStream_t s) {
+  if (l < 1) return 0;
+  if (!distributed(M, l)) {
+    // replicated levels: gather the right-hand side, solve everywhere
+    const size_t part = (size_t)M->rep_dims[0] * M->rep_dims[1] * M->rep_dims[2];
+    RCHK(interior_copy(M->rep_local, M->rep_local.u[1], M->rep_mine, 1, s));
+    if (M->world == 1) {
+      HCHK(hipMemcpyAsync(M->rep_parts, M->rep_mine, sizeof(double) * part, hipMemcpyDeviceToDevice, s), "gather copy");
+    } else if (M->use_rccl) {
+      RCHK(ramses_amd_rccl_allgather(M->rep_mine, (int64_t)part, M->rep_parts, s));
+    } else {
+      HCHK(hipMemcpyAsync(M->h_mine, M->rep_mine, sizeof(double) * part, hipMemcpyDeviceToHost, s), "gather D2H");
+      HCHK(hipStreamSynchronize(s), "stream sync");
+      if (!M->tr.allgather) return failf(RAMSES_AMD_EINVAL, "distributed multigrid: no transport (allgather callback missing)");
+      const int rc_ = M->tr.allgather(M->tr.user, M->h_mine, (int64_t)part, M->h_parts);
+      if (rc_) return failf(RAMSES_AMD_EHIP, "distributed multigrid: the transport's allgather failed (%d)", rc_);
+      HCHK(hipMemcpyAsync(M->rep_parts, M->h_parts, sizeof(double) * part * M->world, hipMemcpyHostToDevice, s), "gather H2D");
+    }
+    const int N = 1 << l;
+    const long total = (long)N * N * N;
+    const int grid = (int)std::min<long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(assemble_kernel, dim3(grid), dim3(256), 0, s, M->rep_parts, M->rep_rhs, M->d_rank_of_brick, M->pgrid[0], M->pgrid[1],
+                       M->rep_dims[0], M->rep_dims[1], M->rep_dims[2], N);
+    HCHK(hipGetLastError(), "assemble launch");
+    return ramses_amd_mg_coarse_solve_dense(l, M->rep_rhs, M->rep_u1, M->rep_work, safe, s);
+  }
+  Level &L = M->lev[l];
+  RCHK(exchange(M, L, L.u[1], s));
+  HCHK(fused(M, L, L.u[0], L.u[3], L.u[1], L.u[2], nullptr, s), "mg fused smoother launch");   // pre-smoothing + residual
+  RCHK(restrict_to(M, l, L.u[2], s));
+  RCHK(coarse_cycle(M, l - 1, safe, s));
+  if (l - 1 >= 1) RCHK(interp_from(M, L, L.u[3], l - 1, s));
+  RCHK(exchange(M, L, L.u[3], s));
+  HCHK(fused(M, L, L.u[3], L.u[0], L.u[1], nullptr, nullptr, s), "mg fused smoother launch");  // post-smoothing
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ramses_amd_mgdist_create(int level, const int *pgrid, int rank, const int *rank_of_brick,
+                             const ramses_amd_mg_transport *transport, ramses_amd_mgdist **out) {
+  if (!pgrid || !out) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (level < 1 || level > 11) return failf(RAMSES_AMD_EINVAL, "multigrid level must be in [1,11] (got %d)", level);
+  int world = 1;
+  for (int d = 0; d < 3; d++) {
+    if (pgrid[d] < 1 || (pgrid[d] & (pgrid[d] - 1))) return failf(RAMSES_AMD_EINVAL, "distributed multigrid needs a power-of-two rank grid (got %d x %d x %d)", pgrid[0], pgrid[1], pgrid[2]);
+    world *= pgrid[d];
+  }
+  if (rank < 0 || rank >= world) return failf(RAMSES_AMD_EINVAL, "rank %d outside the %d ranks of the grid", rank, world);
+  ramses_amd_mgdist *M = new ramses_amd_mgdist();
+  M->level = level; M->rank = rank; M->world = world;
+  M->rank_of_brick.resize(world);
+  std::vector<int> seen(world, 0);
+  int mine = -1;
+  for (int b = 0; b < world; b++) {
+    const int r = rank_of_brick ? rank_of_brick[b] : b;
+    if (r < 0 || r >= world || seen[r]) { delete M; return failf(RAMSES_AMD_EINVAL, "rank_of_brick is not a permutation of the ranks"); }
+    seen[r] = 1;
+    M->rank_of_brick[b] = r;
+    if (r == rank) mine = b;
+  }
+  for (int d = 0; d < 3; d++) {
+    M->pgrid[d] = pgrid[d];
+    M->dims[d] = (1 << level) / pgrid[d];
+    if (M->dims[d] < MIN_FUSED) {
+      const int dd = M->dims[d];
+      delete M;
+      return failf(RAMSES_AMD_EINVAL, "per-rank brick of level %d on %d x %d x %d ranks: every extent must be >= %d (got %d)", level, pgrid[0], pgrid[1], pgrid[2], MIN_FUSED, dd);
+    }
+  }
+  M->coords[0] = mine % pgrid[0]; M->coords[1] = (mine / pgrid[0]) % pgrid[1]; M->coords[2] = mine / (pgrid[0] * pgrid[1]);
+  M->use_rccl = (transport == nullptr);
+  if (transport) M->tr = *transport; else std::memset(&M->tr, 0, sizeof(M->tr));
+  if (M->use_rccl && world > 1 && !ramses_amd_rccl_ready()) {
+    delete M;
+    return failf(RAMSES_AMD_EINVAL, "distributed multigrid without a transport table needs the RCCL communicator (ramses_amd_rccl_init)");
+  }
+  int rc = 0;
+  auto bail = [&](int code) { ramses_amd_mgdist_destroy(M); return code; };
+  M->lev.resize(level + 1);
+  int l = level, dl[3] = {M->dims[0], M->dims[1], M->dims[2]};
+  while (std::min(dl[0], std::min(dl[1], dl[2])) >= MIN_FUSED && l >= 1) {
+    if ((rc = build_level(M, M->lev[l], l, dl, true))) return bail(rc);
+    l--;
+    for (int d = 0; d < 3; d++) dl[d] /= 2;
+  }
+  M->lrep = l;
+  for (int d = 0; d < 3; d++) M->rep_dims[d] = dl[d];
+  hipError_t e = hipSuccess;
+  auto dmalloc = [&](double **p, size_t n) { if (e == hipSuccess) e = hipMalloc(p, sizeof(double) * n); };
+  if (M->lrep >= 1) {
+    if ((rc = build_level(M, M->rep_local, M->lrep, dl, false))) return bail(rc);
+    const size_t cube = (size_t)1 << (3 * M->lrep), part = (size_t)dl[0] * dl[1] * dl[2];
+    const int64_t nwork = ramses_amd_mg_workspace_doubles(M->lrep + 1);
+    if (nwork < 0) return bail((int)nwork);
+    dmalloc(&M->rep_rhs, cube); dmalloc(&M->rep_u1, cube); dmalloc(&M->rep_work, (size_t)nwork);
+    dmalloc(&M->rep_parts, part * world); dmalloc(&M->rep_mine, part);
+    if (e == hipSuccess) e = hipMemset(M->rep_work, 0, sizeof(double) * (size_t)nwork);
+    if (!M->use_rccl && e == hipSuccess) e = hipHostMalloc(&M->h_mine, sizeof(double) * part);
+    if (!M->use_rccl && e == hipSuccess) e = hipHostMalloc(&M->h_parts, sizeof(double) * part * world);
+  }
+  dmalloc(&M->work, MG_MAX_PARTIALS + 8);
+  dmalloc(&M->norm, 2);
+  dmalloc(&M->dense, (size_t)M->dims[0] * M->dims[1] * M->dims[2]);
+  if (e == hipSuccess) e = hipMalloc(&M->d_rank_of_brick, sizeof(int) * world);
+  if (e == hipSuccess) e = hipMemcpy(M->d_rank_of_brick, M->rank_of_brick.data(), sizeof(int) * world, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return bail(failf(RAMSES_AMD_EHIP, "distributed multigrid: device allocation: %s", hipGetErrorString(e)));
+  *out = M;
+  return 0;
+}
+
+int ramses_amd_mgdist_destroy(ramses_amd_mgdist *M) {
+  if (!M) return 0;
+  for (Level &L : M->lev) free_level(L);
+  free_level(M->rep_local);
+  double **dev[] = {&M->rep_rhs, &M->rep_u1, &M->rep_work, &M->rep_parts, &M->rep_mine, &M->work, &M->norm, &M->dense};
+  for (double **p : dev) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (M->d_rank_of_brick) (void)hipFree(M->d_rank_of_brick);
+  if (M->h_mine) (void)hipHostFree(M->h_mine);
+  if (M->h_parts) (void)hipHostFree(M->h_parts);
+  delete M;
+  return 0;
+}
+
+int ramses_amd_mgdist_info(const ramses_amd_mgdist *M, int *dims, int *coords, int *n_distributed_levels, int *first_replicated_level,
+                           int *safe_mode, int64_t *exchanges) {
+  if (!M) return failf(RAMSES_AMD_EINVAL, "NULL context");
+  for (int d = 0; d < 3; d++) {
+    if (dims) dims[d] = M->dims[d];
+    if (coords) coords[d] = M->coords[d];
+  }
+  if (n_distributed_levels) *n_distributed_levels = M->level - M->lrep;
+  if (first_replicated_level) *first_replicated_level = M->lrep;
+  if (safe_mode) *safe_mode = M->safe_mode;
+  if (exchanges) *exchanges = M->exchanges;
+  return 0;
+}
+
+int ramses_amd_mgdist_set_safe_mode(ramses_amd_mgdist *M, int safe_mode) {
+  if (!M) return failf(RAMSES_AMD_EINVAL, "NULL context");
+  M->safe_mode = safe_mode ? 1 : 0;
+  return 0;
+}
+
+// multigrid_fine from a zero first guess.  d_rho: this rank's dense [nz][ny][nx] brick of the density.
+int ramses_amd_mgdist_solve(ramses_amd_mgdist *M, const double *d_rho, double rho_tot, double fourpi, double epsilon,
+                            int *iters_out, double *err_out, void *stream) {
+  if (!M || !d_rho) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Level &L = M->lev[M->level];
+  double *phi = L.u[0], *phi2 = L.u[3], *f1 = L.u[2], *f2 = L.u[1];
+  const long N = (long)L.n[0] * L.n[1] * L.n[2];
+  HCHK(hipMemsetAsync(phi, 0, sizeof(double) * L.cells, s), "memset");
+  HCHK(mg_launch_rhs(d_rho, M->dense, N, fourpi, rho_tot, s), "mg rhs launch");
+  RCHK(interior_copy(L, f2, M->dense, 0, s));
+  RCHK(exchange(M, L, f2, s));
+  int it = 0, safe = M->safe_mode;
+  double err = 1.0, i_res_norm2 = 0.0, res_norm2 = 0.0;
+  for (;;) {
+    it++;
+    if (it > 1) RCHK(exchange(M, L, phi, s));
+    HCHK(fused(M, L, phi, phi2, f2, f1, it == 1 ? M->norm : nullptr, s), "mg fused smoother launch");
+    if (it == 1) RCHK(allreduce_sum(M, M->norm, &i_res_norm2, s));
+    if (M->level > 1) {
+      RCHK(restrict_to(M, M->level, f1, s));
+      RCHK(coarse_cycle(M, M->level - 1, safe, s));
+      RCHK(interp_from(M, L, phi2, M->level - 1, s));
+    }
+    RCHK(exchange(M, L, phi2, s));
+    // post-smoothing; only the norm of the residual is needed
+    HCHK(fused(M, L, phi2, phi, f2, nullptr, M->norm + 1, s), "mg fused smoother launch");
+    RCHK(allreduce_sum(M, M->norm + 1, &res_norm2, s));
+    const double last_err = err;
+    err = std::sqrt(res_norm2 / (i_res_norm2 + 1e-20 * (rho_tot * rho_tot)));
+    if (err < epsilon || it >= MAXITER) break;
+    if (err > last_err * SAFE_FACTOR && !safe) safe = 1;
+  }
+  M->safe_mode = safe;
+  M->last_iters = it; M->last_err = err;
+  if (iters_out) *iters_out = it;
+  if (err_out) *err_out = err;
+  return 0;
+}
+
+// phi of this rank's brick as a dense [nz][ny][nx] array
+int ramses_amd_mgdist_get_phi(ramses_amd_mgdist *M, double *d_phi, void *stream) {
+  if (!M || !d_phi) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  Level &L = M->lev[M->level];
+  return interior_copy(L, L.u[0], d_phi, 1, reinterpret_cast<hipStream_t>(stream));
+}
+
+// first guess / restart: phi of this rank's brick from a dense array (ghosts are exchanged by the next call)
+int ramses_amd_mgdist_set_phi(ramses_amd_mgdist *M, const double *d_phi, void *stream) {
+  if (!M || !d_phi) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  Level &L = M->lev[M->level];
+  return interior_copy(L, L.u[0], const_cast<double *>(d_phi), 0, reinterpret_cast<hipStream_t>(stream));
+}
+
+// force_fine: halo of phi, then gradient_phi into the dense [3][nz][ny][nx] array d_f
+int ramses_amd_mgdist_force(ramses_amd_mgdist *M, double *d_f, void *stream) {
+  if (!M || !d_f) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Level &L = M->lev[M->level];
+  RCHK(exchange(M, L, L.u[0], s));
+  return ramses_amd_gradient_phi_ghost(L.u[0], d_f, L.n[0], L.n[1], L.n[2], NG, std::ldexp(1.0, -M->level), s);
+}
+
+}  // extern "C"

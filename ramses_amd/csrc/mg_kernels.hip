@@ -284,27 +284,38 @@ __global__ __launch_bounds__(256) void mg_gradient_kernel(const double *__restri
 // layers (pitch n+2ng; ghosts filled by the halo exchange).  Same arithmetic
 // and operation order as the dense kernels above.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ long gidx(int i, int j, int k, int ng, int pitch) {
-  return (long)(i + ng) + (long)pitch * ((j + ng) + (long)pitch * (k + ng));
+// a rank's brick of a distributed level: nx x ny x nz cells (each a power of two; bricks of 2 or 4 ranks in a cubic box
+// are not cubes) inside ng ghost layers
+struct BrickDims {
+  int nx, ny, nz;
+};
+__device__ __forceinline__ long gidx(int i, int j, int k, int ng, int px, int py) {
+  return (long)(i + ng) + (long)px * ((j + ng) + (long)py * (k + ng));
+}
+__device__ __forceinline__ void decode3b(long c, int lgx, int lgy, int &i, int &j, int &k) {
+  i = (int)(c & ((1 << lgx) - 1));
+  j = (int)((c >> lgx) & ((1 << lgy) - 1));
+  k = (int)(c >> (lgx + lgy));
 }
 
 // restriction of the residual of the local fine brick into the local coarse brick
 __global__ __launch_bounds__(256) void mg_restrict_ghost_kernel(const double *__restrict__ res_f,
-                                                                 double *__restrict__ rhs_c, int nf, int ngf,
+                                                                 double *__restrict__ rhs_c, BrickDims F, int ngf,
                                                                  int ngc) {
-  const int nc = nf >> 1;
-  const long Nc = (long)nc * nc * nc;
-  const int pf = nf + 2 * ngf, pc = nc + 2 * ngc;
+  const int ncx = F.nx >> 1, ncy = F.ny >> 1, ncz = F.nz >> 1;
+  const long Nc = (long)ncx * ncy * ncz;
+  const int pfx = F.nx + 2 * ngf, pfy = F.ny + 2 * ngf, pcx = ncx + 2 * ngc, pcy = ncy + 2 * ngc;
+  const int lgx = ilog2(ncx), lgy = ilog2(ncy);
   for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < Nc; c += (long)gridDim.x * blockDim.x) {
     int I, J, K;
-    decode3(c, ilog2(nc), I, J, K);
+    decode3b(c, lgx, lgy, I, J, K);
     double acc = 0.0;
 #pragma unroll
     for (int ind = 0; ind < 8; ind++) {
       const int ix = ind & 1, iy = (ind >> 1) & 1, iz = (ind >> 2) & 1;
-      acc = acc + res_f[gidx(2 * I + ix, 2 * J + iy, 2 * K + iz, ngf, pf)] / 8.0;
+      acc = acc + res_f[gidx(2 * I + ix, 2 * J + iy, 2 * K + iz, ngf, pfx, pfy)] / 8.0;
     }
-    rhs_c[gidx(I, J, K, ngc, pc)] = acc;
+    rhs_c[gidx(I, J, K, ngc, pcx, pcy)] = acc;
   }
 }
 
@@ -312,19 +323,19 @@ __global__ __launch_bounds__(256) void mg_restrict_ghost_kernel(const double *__
 // either the local coarse brick with >= 1 valid ghost layer (cglob = 0) or a
 // replicated dense periodic level of cglob^3 cells, of which this rank's part
 // starts at (cox, coy, coz).
-__global__ __launch_bounds__(256) void mg_interp_ghost_kernel(double *__restrict__ phi_f, int nf, int ngf,
+__global__ __launch_bounds__(256) void mg_interp_ghost_kernel(double *__restrict__ phi_f, BrickDims F, int ngf,
                                                                const double *__restrict__ corr_c, int ngc,
                                                                int cglob, int cox, int coy, int coz) {
   // one thread per coarse cell, as mg_interp_kernel
-  const int nc = nf >> 1;
-  const int lgc = ilog2(nc);
-  const long Nc = (long)nc * nc * nc;
-  const int pf = nf + 2 * ngf, pc = nc + 2 * ngc;
+  const int ncx = F.nx >> 1, ncy = F.ny >> 1, ncz = F.nz >> 1;
+  const int lgx = ilog2(ncx), lgy = ilog2(ncy);
+  const long Nc = (long)ncx * ncy * ncz;
+  const int pfx = F.nx + 2 * ngf, pfy = F.ny + 2 * ngf, pcx = ncx + 2 * ngc, pcy = ncy + 2 * ngc;
   const double a = 1.0 / 64.0, b = 3 * a, cc = 9 * a, d = 27 * a;
   const double bbb[8] = {a, b, b, cc, b, cc, cc, d};
   for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < Nc; c += (long)gridDim.x * blockDim.x) {
     int I, J, K;
-    decode3(c, lgc, I, J, K);
+    decode3b(c, lgx, lgy, I, J, K);
     double v[3][3][3];
 #pragma unroll
     for (int kz = 0; kz < 3; kz++)
@@ -337,14 +348,14 @@ __global__ __launch_bounds__(256) void mg_interp_ghost_kernel(double *__restrict
             v[kz][ky][kx] = corr_c[(long)wrapi(pi + cox, cglob) +
                                    (long)cglob * (wrapi(pj + coy, cglob) + (long)cglob * wrapi(pk + coz, cglob))];
           } else {
-            v[kz][ky][kx] = corr_c[gidx(pi, pj, pk, ngc, pc)];
+            v[kz][ky][kx] = corr_c[gidx(pi, pj, pk, ngc, pcx, pcy)];
           }
         }
 #pragma unroll
     for (int iz = 0; iz < 2; iz++)
 #pragma unroll
       for (int iy = 0; iy < 2; iy++) {
-        const long row = gidx(2 * I, 2 * J + iy, 2 * K + iz, ngf, pf);
+        const long row = gidx(2 * I, 2 * J + iy, 2 * K + iz, ngf, pfx, pfy);
         double out[2];
 #pragma unroll
         for (int ix = 0; ix < 2; ix++) {
@@ -365,17 +376,18 @@ __global__ __launch_bounds__(256) void mg_interp_ghost_kernel(double *__restrict
 }
 
 // gradient_phi on the local brick (needs 2 valid ghost layers of phi); f is a
-// dense [3][n][n][n] array
+// dense [3][nz][ny][nx] array
 __global__ __launch_bounds__(256) void mg_gradient_ghost_kernel(const double *__restrict__ phi,
-                                                                 double *__restrict__ f, int n, int ng, double a,
+                                                                 double *__restrict__ f, BrickDims B, int ng, double a,
                                                                  double b) {
-  const long N = (long)n * n * n;
-  const int p = n + 2 * ng;
-  const long pp = (long)p * p;
+  const long N = (long)B.nx * B.ny * B.nz;
+  const int p = B.nx + 2 * ng, py = B.ny + 2 * ng;
+  const long pp = (long)p * py;
+  const int lgx = ilog2(B.nx), lgy = ilog2(B.ny);
   for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (long)gridDim.x * blockDim.x) {
     int i, j, k;
-    decode3(c, ilog2(n), i, j, k);
-    const long o = gidx(i, j, k, ng, p);
+    decode3b(c, lgx, lgy, i, j, k);
+    const long o = gidx(i, j, k, ng, p, py);
     f[c] = a * (phi[o - 1] - phi[o + 1]) - b * (phi[o - 2] - phi[o + 2]);
     f[c + N] = a * (phi[o - p] - phi[o + p]) - b * (phi[o - 2 * p] - phi[o + 2 * p]);
     f[c + 2 * N] = a * (phi[o - pp] - phi[o + pp]) - b * (phi[o - 2 * pp] - phi[o + 2 * pp]);
@@ -401,7 +413,7 @@ hipError_t mg_launch_gs(double *phi, const double *rhs, int n, double dx2, int c
   hipLaunchKernelGGL(mg_gs_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, s, phi, rhs, n, dx2, color);
   return hipGetLastError();
 }
-int mg_residual_blocks(int n) { return grid_for((long)n * n * n, MG_MAX_PARTIALS); }
+int mg_residual_blocks(int n) { return grid_for((long)n * n * n, MG_RESIDUAL_BLOCKS); }
 hipError_t mg_launch_residual(const double *phi, const double *rhs, double *res, int n, double dx,
                               double *partial, double *norm_out, hipStream_t s) {
   const int blocks = mg_residual_blocks(n);
@@ -426,21 +438,21 @@ hipError_t mg_launch_coarse_tail(const MgTailArgs &T, hipStream_t s) {
   hipLaunchKernelGGL(mg_coarse_tail_kernel, dim3(1), dim3(1024), 0, s, T);
   return hipGetLastError();
 }
-hipError_t mg_launch_restrict_ghost(const double *res_f, double *rhs_c, int nf, int ngf, int ngc, hipStream_t s) {
-  const long Nc = (long)(nf >> 1) * (nf >> 1) * (nf >> 1);
-  hipLaunchKernelGGL(mg_restrict_ghost_kernel, dim3(grid_for(Nc)), dim3(256), 0, s, res_f, rhs_c, nf, ngf, ngc);
+hipError_t mg_launch_restrict_ghost(const double *res_f, double *rhs_c, int nfx, int nfy, int nfz, int ngf, int ngc, hipStream_t s) {
+  const long Nc = (long)(nfx >> 1) * (nfy >> 1) * (nfz >> 1);
+  hipLaunchKernelGGL(mg_restrict_ghost_kernel, dim3(grid_for(Nc)), dim3(256), 0, s, res_f, rhs_c, BrickDims{nfx, nfy, nfz}, ngf, ngc);
   return hipGetLastError();
 }
-hipError_t mg_launch_interp_ghost(double *phi_f, int nf, int ngf, const double *corr_c, int ngc, int cglob,
+hipError_t mg_launch_interp_ghost(double *phi_f, int nfx, int nfy, int nfz, int ngf, const double *corr_c, int ngc, int cglob,
                                   int cox, int coy, int coz, hipStream_t s) {
-  const int nc = nf >> 1;
-  hipLaunchKernelGGL(mg_interp_ghost_kernel, dim3(grid_for((long)nc * nc * nc, 8192)), dim3(256), 0, s, phi_f, nf,
+  const long Nc = (long)(nfx >> 1) * (nfy >> 1) * (nfz >> 1);
+  hipLaunchKernelGGL(mg_interp_ghost_kernel, dim3(grid_for(Nc, 8192)), dim3(256), 0, s, phi_f, BrickDims{nfx, nfy, nfz},
                      ngf, corr_c, ngc, cglob, cox, coy, coz);
   return hipGetLastError();
 }
-hipError_t mg_launch_gradient_ghost(const double *phi, double *f, int n, int ng, double a, double b, hipStream_t s) {
-  hipLaunchKernelGGL(mg_gradient_ghost_kernel, dim3(grid_for((long)n * n * n, 8192)), dim3(256), 0, s, phi, f, n, ng,
-                     a, b);
+hipError_t mg_launch_gradient_ghost(const double *phi, double *f, int nx, int ny, int nz, int ng, double a, double b, hipStream_t s) {
+  hipLaunchKernelGGL(mg_gradient_ghost_kernel, dim3(grid_for((long)nx * ny * nz, 8192)), dim3(256), 0, s, phi, f,
+                     BrickDims{nx, ny, nz}, ng, a, b);
   return hipGetLastError();
 }
 hipError_t mg_launch_gradient(const double *phi, double *f, int n, double a, double b, hipStream_t s) {
@@ -499,7 +511,9 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
                                                                           int zchunk, int ntx, int nty,
                                                                           double *__restrict__ rhs_c,
                                                                           double *__restrict__ u1_c,
-                                                                          const double *__restrict__ corr_c) {
+                                                                          const double *__restrict__ corr_c,
+                                                                          int ny, int nz) {
+  // n = cells along x; ny, nz along y, z (a rank's brick of a distributed level need not be a cube; dense levels: all equal)
   using G = SmoothGeom<P, RESID, LYT>;
   static_assert(!PROL || (!RESID && P == 2 && (LYT * 16) * 2 >= (G::LX / 2 + 2) * (G::LY / 2 + 2)), "fused prolongation: the smoother without residual");
   static_assert(!RESTR || RESID, "the fused restriction restricts the fused residual");
@@ -518,17 +532,20 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
   const int tix = bid % ntx, tiy = (bid / ntx) % nty, tiz = bid / (ntx * nty);
   const int x0 = tix * G::IX - H, y0 = tiy * G::IY - H;   // global coords of tile cell (0,0)
   const int z0 = tiz * zchunk;
-  const int z1 = min(z0 + zchunk, n);                     // planes [z0,z1) are produced
+  const int z1 = min(z0 + zchunk, nz);                    // planes [z0,z1) are produced
   // ng = 0: dense periodic level, neighbours wrap; ng >= H: one rank's brick of a
   // distributed level with ghost layers filled by the halo exchange (addresses
   // outside the allocation are clamped: those values are never used)
   const int pitch = n + 2 * ng;
-  const long nn = (long)pitch * pitch;
-  // n >= LX (the launcher guarantees it): one conditional wrap is enough
-  auto wrap1 = [&](int v) {
-    if (ng == 0) return v < 0 ? v + n : (v >= n ? v - n : v);
-    return min(max(v, -ng), n + ng - 1) + ng;
+  const long nn = (long)pitch * (ny + 2 * ng);
+  // every extent >= LX (the launcher guarantees it): one conditional wrap is enough
+  auto wrapd = [&](int v, int nd) {
+    if (ng == 0) return v < 0 ? v + nd : (v >= nd ? v - nd : v);
+    return min(max(v, -ng), nd + ng - 1) + ng;
   };
+  auto wrapx = [&](int v) { return wrapd(v, n); };
+  auto wrapy = [&](int v) { return wrapd(v, ny); };
+  auto wrapz = [&](int v) { return wrapd(v, nz); };
   auto slot = [&](int z) { int s = z % G::R; return s < 0 ? s + G::R : s; };
 
   // (a) row mapping: lane = x, wave wv owns rows wv + NW*i -- coalesced loads/stores
@@ -537,7 +554,7 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
 #pragma unroll
   for (int i = 0; i < NROW; i++) {
     const int ly = wv + NW * i;
-    goffR[i] = wrap1(y0 + ly) * pitch + wrap1(gxu);
+    goffR[i] = wrapy(y0 + ly) * pitch + wrapx(gxu);
     lofsR[i] = ly * G::LX + lane;
   }
   // (b) colour mapping: a wave owns row pairs; lanes 0-31 take the even row of the
@@ -548,9 +565,9 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
 #pragma unroll
   for (int j = 0; j < NPAIR; j++) {
     lyC[j] = 2 * (wv + NW * j) + sub;
-    const int gy = wrap1(y0 + lyC[j]) * pitch;
-    goffC[j][0] = gy + wrap1(x0 + 2 * pr);
-    goffC[j][1] = gy + wrap1(x0 + 2 * pr + 1);
+    const int gy = wrapy(y0 + lyC[j]) * pitch;
+    goffC[j][0] = gy + wrapx(x0 + 2 * pr);
+    goffC[j][1] = gy + wrapx(x0 + 2 * pr + 1);
   }
   double acc = 0.0;
 
@@ -563,7 +580,7 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
   constexpr int RB = G::IX * G::IY;
   const int cxl = tid % (G::IX / 2), cyl = tid / (G::IX / 2);
   const int cgx = x0 + H + 2 * cxl, cgy = y0 + H + 2 * cyl;
-  const bool coarse_on = RESTR && (tid < (G::IX / 2) * (G::IY / 2)) && cgx < n && cgy < n;
+  const bool coarse_on = RESTR && (tid < (G::IX / 2) * (G::IY / 2)) && cgx < n && cgy < ny;
   double cacc = 0.0;
   auto restrict_plane = [&](int zr, int buf) {
     if (!coarse_on || zr < z0 || zr > z1 - 1) return;
@@ -593,14 +610,14 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
   auto pair_off = [&](int ly, int z, int color) { return ((x0 + y0 + ly + z) & 1) ^ color; };
   auto issue = [&](int m, StepLoads &L) {
     {
-      const double *__restrict__ base = phi_in + (long)wrap1(m + 2) * nn;
+      const double *__restrict__ base = phi_in + (long)wrapz(m + 2) * nn;
 #pragma unroll
       for (int i = 0; i < NROW; i++) L.ph[i] = base[goffR[i]];
     }
 #pragma unroll
     for (int s = 1; s <= 2; s++) {
       const int z = m - 2 * (s - 1);
-      const double *__restrict__ base = rhs + (long)wrap1(z) * nn;
+      const double *__restrict__ base = rhs + (long)wrapz(z) * nn;
 #pragma unroll
       for (int j = 0; j < NPAIR; j++) L.rv[s - 1][j] = base[goffC[j][pair_off(lyC[j], z, (s & 1) ? 0 : 1)]];
     }
@@ -710,7 +727,7 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
 #pragma unroll
         for (int i = 0; i < NROW; i++) {
           const int ly = wv + NW * i;
-          onf[i] = xin && ly >= H && ly < G::LY - H && (y0 + ly) < n;
+          onf[i] = xin && ly >= H && ly < G::LY - H && (y0 + ly) < ny;
           phf[i] = onf[i] ? pc[lofsR[i]] : 0.0;
           nbf[i] = 0.0;
         }
@@ -718,7 +735,7 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
 #pragma unroll
         for (int j = 0; j < NPAIR; j++) {
           const int ly = lyC[j];
-          const bool yin = zin && ly >= H && ly < G::LY - H && (y0 + ly) < n;
+          const bool yin = zin && ly >= H && ly < G::LY - H && (y0 + ly) < ny;
 #pragma unroll
           for (int e = 0; e < 2; e++) {
             const int lx = 2 * pr + e;
@@ -752,7 +769,7 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
     }
     // ---- final stage: store phi (+ residual and its norm) of plane m-2P -------
     {
-      const long zoff = (long)wrap1(zf) * nn;
+      const long zoff = (long)wrapz(zf) * nn;
       if (!RESID) {
 #pragma unroll
         for (int i = 0; i < NROW; i++)
@@ -851,8 +868,12 @@ bool mg_smooth_can_restrict(int n, int npass) { return npass == 2 && g_smooth_ly
 
 hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const double *rhs, double *res,
                                   double *partial, double *norm_out, int n, double dx, int npass,
-                                  hipStream_t s, int ng, double *rhs_c, double *u1_c, const double *corr_c) {
+                                  hipStream_t s, int ng, double *rhs_c, double *u1_c, const double *corr_c, int ny, int nz) {
   if (npass != 4 && npass != 2) return hipErrorInvalidValue;
+  if (ny <= 0) ny = n;
+  if (nz <= 0) nz = n;
+  if ((ny != n || nz != n) && (ng == 0 || rhs_c || corr_c)) return hipErrorInvalidValue;   // dense periodic levels are cubes
+  if (ny < 64 || nz < 64) return hipErrorInvalidValue;
   const bool restr = rhs_c != nullptr;
   const bool prol = corr_c != nullptr;
   if (prol && (restr || res || norm_out || ng != 0 || !mg_smooth_can_restrict(n, npass) || (n & 1))) return hipErrorInvalidValue;
@@ -864,11 +885,11 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
   if (ng != 0 && ng < H) return hipErrorInvalidValue;   // ghost layers must cover the dependency cone
   const int LY = (P == 2) ? g_smooth_ly : 24;
   const int IX = 64 - 2 * H, IY = LY - 2 * H;
-  const int ntx = (n + IX - 1) / IX, nty = (n + IY - 1) / IY;
-  int zchunk = n >= 512 ? 128 : (n >= 128 ? 64 : n);      // (256^3: 64 planes per workgroup measured faster than 128, round 2)
-  if (const char *e = getenv("RAMSES_AMD_MG_ZCHUNK")) { const int z = atoi(e); if (z >= 8 && n >= 256) zchunk = z; }   // tuning aid
-  if (const char *e = getenv("RAMSES_AMD_MG_ZCHUNK_SMALL")) { const int z = atoi(e); if (z >= 8 && n < 256) zchunk = z < n ? z : n; }   // tuning aid
-  const int ntz = (n + zchunk - 1) / zchunk;
+  const int ntx = (n + IX - 1) / IX, nty = (ny + IY - 1) / IY;
+  int zchunk = nz >= 512 ? 128 : (nz >= 128 ? 64 : nz);   // (256^3: 64 planes per workgroup measured faster than 128, round 2)
+  if (const char *e = getenv("RAMSES_AMD_MG_ZCHUNK")) { const int z = atoi(e); if (z >= 8 && nz >= 256) zchunk = z; }   // tuning aid
+  if (const char *e = getenv("RAMSES_AMD_MG_ZCHUNK_SMALL")) { const int z = atoi(e); if (z >= 8 && nz < 256) zchunk = z < nz ? z : nz; }   // tuning aid
+  const int ntz = (nz + zchunk - 1) / zchunk;
   const int blocks = ntx * nty * ntz;
   if (resid && blocks > MG_MAX_PARTIALS) return hipErrorInvalidValue;
   const size_t lds = sizeof(double) * ((size_t)(2 * P + 4) * 64 * LY + (restr ? 2 * (size_t)IX * IY : 0) + (prol ? 3 * (size_t)(64 / 2 + 2) * (LY / 2 + 2) : 0));
@@ -881,7 +902,7 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
                             (int)lds);                                                                        \
     if (e != hipSuccess) return e;                                                                            \
     hipLaunchKernelGGL(k, dim3(blocks), dim3(LL * 16), lds, s, phi_in, phi_out, rhs, res, partial, n, ng, dx2,    \
-                       oneoverdx2, zchunk, ntx, nty, (double *)nullptr, (double *)nullptr, (const double *)nullptr); \
+                       oneoverdx2, zchunk, ntx, nty, (double *)nullptr, (double *)nullptr, (const double *)nullptr, ny, nz); \
   } while (0)
   if (restr) {
     // (the residual itself is not stored: the restricted right-hand side is all the coarse level needs of it)
@@ -889,13 +910,13 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(32 * 16), lds, s, phi_in, phi_out, rhs, res, partial, n, ng, dx2, oneoverdx2, zchunk, ntx, nty,
-                       rhs_c, u1_c, (const double *)nullptr);
+                       rhs_c, u1_c, (const double *)nullptr, ny, nz);
   } else if (prol) {
     auto k = mg_smooth_fused_kernel<2, false, 32, false, true>;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(32 * 16), lds, s, phi_in, phi_out, rhs, res, partial, n, ng, dx2, oneoverdx2, zchunk, ntx, nty,
-                       (double *)nullptr, (double *)nullptr, corr_c);
+                       (double *)nullptr, (double *)nullptr, corr_c, ny, nz);
   } else
   if (P == 4) { if (resid) SM_LAUNCH(4, true, 24); else SM_LAUNCH(4, false, 24); }
   else if (LY == 12) { if (resid) SM_LAUNCH(2, true, 12); else SM_LAUNCH(2, false, 12); }

@@ -40,22 +40,26 @@ def coords_rank(c, pgrid):
 
 class BrickDecomposition:
     """pgrid=(px,py,pz) ranks, each owning an n^3 brick (weak scaling) of the
-    periodic (n*px, n*py, n*pz) level; boxlen is the x extent of the box."""
+    periodic (n*px, n*py, n*pz) level -- or, n = (nx, ny, nz), a brick of those
+    extents (the parts of a cubic box on 2 or 4 ranks); boxlen is the x extent
+    of the box."""
 
     def __init__(self, pgrid, rank, n, boxlen=0.5, ng=2, transport=None):
         self.pgrid = tuple(pgrid)
         self.rank = rank
         self.transport = transport if transport is not None else DistTransport()
-        self.n = n
+        self.dims = (n, n, n) if isinstance(n, int) else tuple(int(v) for v in n)
+        self.n = self.dims[0]
         self.ng = ng
         self.coords = rank_coords(rank, self.pgrid)
-        self.dx = boxlen / (n * self.pgrid[0])
-        self.lo = tuple(c * n for c in self.coords)
+        self.dx = boxlen / (self.dims[0] * self.pgrid[0])
+        self.lo = tuple(c * d for c, d in zip(self.coords, self.dims))
         self._bufs = {}
 
     # -- construction ----------------------------------------------------------
     def make_level(self, params, poisson=False):
-        return HydroLevel(self.n, self.n, self.n, self.dx, params=params, ng=self.ng, poisson=poisson)
+        nx, ny, nz = self.dims
+        return HydroLevel(nx, ny, nz, self.dx, params=params, ng=self.ng, poisson=poisson)
 
     def init_sedov(self, lev, gamma=1.4):
         """namelist/sedov3d.nml on the global level, restricted to this brick

@@ -5,8 +5,13 @@ of
     recursive_multigrid_coarse      :307-390
     force_fine / gradient_phi       poisson/force_fine.f90:5-324
 
-One rank (GPU) owns an n^3 brick of the (n*p)^3 level, p^3 ranks.  MI355X-first
-choices:
+The level is the reference's cubic periodic box (nx = ny = nz = 1 coarse cell,
+amr/amr_parameters.f90:81: not a namelist item), N = 2^level cells per
+direction, cut into px x py x pz bricks, each a power of two -- the shapes the
+reference's Hilbert decomposition gives 2^k ranks on a uniform level (2 ranks:
+two half boxes, 4 ranks: four quarter columns, 8 ranks: the octants).  One rank
+(GPU) owns an (N/px) x (N/py) x (N/pz) brick.  MI355X-first choices (DESIGN.md
+section 6):
 
 * every multigrid level of a rank is a brick with NG = 5 ghost layers.  The
   fused smoother recomputes the neighbours' updates inside the ghost layers
@@ -17,7 +22,7 @@ choices:
 * restriction is local (octs never straddle ranks); prolongation needs one
   ghost layer of the coarse correction;
 * levels whose per-rank brick would fall below the smoother's 64-cell tile
-  are REPLICATED: one all-gather of the restricted residual, then every rank
+  in any direction are REPLICATED: one all-gather of the restricted residual, then every rank
   runs the remaining V-cycle on the whole coarse level (the single-GPU code)
   and reads its part of the correction -- no latency-bound tiny exchanges;
 * scalar reductions: the residual norms (sum) per iteration.
@@ -29,193 +34,188 @@ reference) whenever the iteration counts agree.
 import ctypes as C
 import math
 
+import numpy as np
 import torch
 
 from . import _capi
 from ._capi import check, lib
 from .hydro import _ptr, _stream
-from .parallel import BrickDecomposition, rank_coords
+from .parallel import rank_coords
 from .poisson import TWOPI
+from .transport import DistTransport, RcclTransport
 
 NG = 5                 # ghost layers: 4 colour passes + the residual's stencil
 MIN_FUSED = 64         # the fused smoother's tile width
-MAXITER = 10           # multigrid_fine_commons.f90:34
-SAFE_FACTOR = 0.5      # :35
-MG_MAX_PARTIALS = 4096
 
 
-class _Lev:
-    """One multigrid level of this rank: local n^3 cells + NG ghost layers."""
+def brick_dims(level, pgrid):
+    """extents (x, y, z) of one rank's brick of the 2^level cubic box"""
+    N = 1 << level
+    return tuple(N // p for p in pgrid)
 
-    def __init__(self, l, n, dev):
-        self.l, self.n = l, n
-        self.nx = self.ny = self.nz = n
-        self.brick = _capi.dense_brick(n, n, n, NG)
-        p = n + 2 * NG
-        z = lambda: torch.zeros(p, p, p, dtype=torch.float64, device=dev)  # noqa: E731
-        self.u1, self.u2, self.u3, self.u4 = z(), z(), z(), z()
-        self.ng = NG
 
-    def interior(self, t):
-        g, n = NG, self.n
-        return t[g:g + n, g:g + n, g:g + n]
+def assemble_level(parts, pgrid, dims):
+    """parts[rank] = the [nz][ny][nx] brick of rank = x + px*(y + py*z) (an all-gather in rank order);
+    returns the whole [pz*nz][py*ny][px*nx] level (what the library's assemble kernel builds)."""
+    (px, py, pz), (nx, ny, nz) = pgrid, dims
+    g = parts.view(pz, py, px, nz, ny, nx).permute(0, 3, 1, 4, 2, 5)   # [pz, k, py, j, px, i]
+    return g.reshape(pz * nz, py * ny, px * nx)
+
+
+# ---- include/ramses_amd.h: ramses_amd_mg_transport ---------------------------------------------------------------
+_I64P, _IP, _DP = C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_double)
+_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _IP, _DP, _I64P, _I64P, _DP, _I64P, _I64P)
+_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, _DP, C.c_int64, _DP)
+_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, _DP)
+
+
+class MgTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("exchange", _EXCHANGE), ("allgather", _ALLGATHER), ("allreduce_sum", _ALLREDUCE)]
+
+
+def _host(ptr, off, cnt):
+    """torch view of cnt doubles of a host buffer"""
+    return torch.from_numpy(np.ctypeslib.as_array(C.cast(C.addressof(ptr.contents) + 8 * off, _DP), shape=(cnt,)))
+
+
+class _Callbacks:
+    """The caller's message layer behind the library's three host-buffer callbacks: a transport of
+    ramses_amd/transport.py (torch.distributed gloo / nccl, or the virtual ranks of LocalWorld)."""
+
+    def __init__(self, tr, device):
+        self.tr, self.device = tr, device
+        self.error = None
+        # torch.distributed with a device backend moves device tensors only
+        self.on_device = isinstance(tr, DistTransport) and not tr.staged and tr.world > 1
+        self.table = MgTransport(None, _EXCHANGE(self._exchange), _ALLGATHER(self._allgather), _ALLREDUCE(self._allreduce))
+
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except BaseException as exc:      # noqa: BLE001  (an exception must not cross the C frames)
+            self.error = exc
+            return 1
+
+    def _exchange(self, user, npeer, peer, h_send, soff, scnt, h_recv, roff, rcnt):
+        def go():
+            sends = [(_host(h_send, soff[i], scnt[i]), peer[i]) for i in range(npeer)]
+            recvs = [(_host(h_recv, roff[i], rcnt[i]), peer[i]) for i in range(npeer)]
+            if self.on_device:
+                dsend = [(t.to(self.device), q) for t, q in sends]
+                drecv = [(torch.empty(t.shape, dtype=t.dtype, device=self.device), q) for t, q in recvs]
+                self.tr.sendrecv(dsend, drecv)
+                for (t, _), (d, _) in zip(recvs, drecv):
+                    t.copy_(d)
+            else:
+                self.tr.sendrecv(sends, recvs)
+        return self._guard(go)
+
+    def _allgather(self, user, h_send, count, h_recv):
+        def go():
+            src = _host(h_send, 0, count)
+            out = self.tr.allgather(src.to(self.device) if self.on_device else src)
+            _host(h_recv, 0, count * self.tr.world).copy_(out.reshape(-1))
+        return self._guard(go)
+
+    def _allreduce(self, user, value):
+        def go():
+            value[0] = self.tr.allreduce(float(value[0]), self.device)
+        return self._guard(go)
 
 
 class PoissonDecomposition:
-    def __init__(self, pgrid, rank, n, boxlen=1.0, epsilon=1e-4, transport=None, device="cuda"):
+    """Host mirror of ramses_amd_mgdist_* (csrc/mg_dist.hip): the V-cycle driver and its halo exchanges run behind
+    the C ABI; this class owns the rank's density / force arrays and the transport."""
+
+    def __init__(self, pgrid, rank, n=None, boxlen=1.0, epsilon=1e-4, transport=None, device="cuda", level=None):
+        """pgrid = (px, py, pz) ranks (powers of two) on the 2^level box; `n` (kept for cubic rank grids):
+        the brick's extent, level = log2(n * px)."""
         if not torch.cuda.is_available():
             raise _capi.RamsesAmdError("PoissonDecomposition needs a GPU; there is no CPU fallback")
-        px, py, pz = pgrid
-        if not (px == py == pz) or px & (px - 1):
-            raise _capi.RamsesAmdError("distributed multigrid needs a cubic power-of-two rank grid (got %r)" % (pgrid,))
-        if n < MIN_FUSED or n & (n - 1):
-            raise _capi.RamsesAmdError("per-rank brick must be a power of two >= %d (got %d)" % (MIN_FUSED, n))
-        self.p = px
-        self.n = n
-        self.level = int(round(math.log2(n * px)))
+        pgrid = tuple(int(p) for p in pgrid)
+        if any(p < 1 or p & (p - 1) for p in pgrid):
+            raise _capi.RamsesAmdError("distributed multigrid needs a power-of-two rank grid (got %r)" % (pgrid,))
+        if level is None:
+            if n is None or not (pgrid[0] == pgrid[1] == pgrid[2]) or n & (n - 1):
+                raise _capi.RamsesAmdError("give the level of the box (a brick extent n only names it on a cubic rank grid)")
+            level = int(round(math.log2(n * pgrid[0])))
+        self.pgrid, self.level = pgrid, level
         self.boxlen, self.epsilon = boxlen, epsilon
         self.fourpi = 2 * TWOPI * boxlen
-        self.dec = BrickDecomposition(pgrid, rank, n, boxlen=boxlen, ng=NG, transport=transport)
-        self.tr = self.dec.transport
-        self.coords = rank_coords(rank, pgrid)
-        dev = torch.device(device)
-        self.dev = dev
-        # distributed levels: local size >= MIN_FUSED
-        self.lev = {}
-        l, nl = self.level, n
-        while nl >= MIN_FUSED and l >= 1:
-            self.lev[l] = _Lev(l, nl, dev)
-            l, nl = l - 1, nl // 2
-        self.lrep = l                          # first replicated level (0: none)
-        self.nrep_local = nl
-        if self.lrep >= 1:
-            self.rep_local = _Lev(self.lrep, nl, dev)   # target of the last distributed restriction
-            ng_ = 1 << self.lrep
-            self.rep_rhs = torch.zeros(ng_, ng_, ng_, dtype=torch.float64, device=dev)
-            self.rep_u1 = torch.zeros_like(self.rep_rhs)
-            nwork = lib().ramses_amd_mg_workspace_doubles(self.lrep + 1)
-            if nwork < 0:
-                check(int(nwork))
-            self.rep_work = torch.zeros(int(nwork), dtype=torch.float64, device=dev)
-        self._work = torch.zeros(MG_MAX_PARTIALS + 8, dtype=torch.float64, device=dev)
-        self._norm = torch.zeros(2, dtype=torch.float64, device=dev)
-        self._origin = (C.c_int * 3)()
-        fine = self.lev[self.level]
-        self.phi = fine.u1                     # with ghosts; interior via phi_interior()
-        self.rho = torch.zeros(n, n, n, dtype=torch.float64, device=dev)
-        self.f = torch.zeros(3, n, n, n, dtype=torch.float64, device=dev)
-        self.safe_mode = 0
+        self.tr = transport if transport is not None else DistTransport()
+        self.dev = torch.device(device)
+        # RCCL inside the library when the transport is the library's own communicator, the callbacks otherwise
+        self._cb = None if isinstance(self.tr, RcclTransport) else _Callbacks(self.tr, self.dev)
+        ctx = C.c_void_p()
+        pg = (C.c_int * 3)(*pgrid)
+        check(lib().ramses_amd_mgdist_create(level, pg, rank, None, C.byref(self._cb.table) if self._cb else None, C.byref(ctx)))
+        self._ctx = ctx
+        dims, coords = (C.c_int * 3)(), (C.c_int * 3)()
+        nlev, lrep = C.c_int(), C.c_int()
+        check(lib().ramses_amd_mgdist_info(ctx, dims, coords, C.byref(nlev), C.byref(lrep), None, None))
+        self.dims, self.coords = tuple(dims), tuple(coords)
+        assert self.dims == brick_dims(level, pgrid) and self.coords == rank_coords(rank, pgrid)
+        self.nlev, self.lrep = nlev.value, lrep.value
+        nx, ny, nz = self.dims
+        self.rho = torch.zeros(nz, ny, nx, dtype=torch.float64, device=self.dev)
+        self.phi = torch.zeros(nz, ny, nx, dtype=torch.float64, device=self.dev)
+        self.f = torch.zeros(3, nz, ny, nx, dtype=torch.float64, device=self.dev)
         self.last_iters, self.last_err = 0, 0.0
-        self.exchanges = 0
+        self._exch0 = 0
 
-    # ------------------------------------------------------------------ helpers
+    def __del__(self):
+        ctx = getattr(self, "_ctx", None)
+        if ctx:
+            try:
+                lib().ramses_amd_mgdist_destroy(ctx)
+            except Exception:       # noqa: BLE001  (interpreter shutdown)
+                pass
+            self._ctx = None
+
+    def _call(self, rc):
+        if rc and self._cb is not None and self._cb.error is not None:
+            exc, self._cb.error = self._cb.error, None
+            raise exc
+        check(rc)
+
+    def my_slices(self):
+        """this rank's part of a [z][y][x] array of the whole level"""
+        nx, ny, nz = self.dims
+        cx, cy, cz = self.coords
+        return (slice(cz * nz, (cz + 1) * nz), slice(cy * ny, (cy + 1) * ny), slice(cx * nx, (cx + 1) * nx))
+
+    @property
+    def exchanges(self):
+        n = C.c_int64()
+        check(lib().ramses_amd_mgdist_info(self._ctx, None, None, None, None, None, C.byref(n)))
+        return n.value - self._exch0
+
+    @exchanges.setter
+    def exchanges(self, v):
+        n = C.c_int64()
+        check(lib().ramses_amd_mgdist_info(self._ctx, None, None, None, None, None, C.byref(n)))
+        self._exch0 = n.value - int(v)
+
+    @property
+    def safe_mode(self):
+        v = C.c_int()
+        check(lib().ramses_amd_mgdist_info(self._ctx, None, None, None, None, C.byref(v), None))
+        return v.value
+
     def phi_interior(self):
-        return self.lev[self.level].interior(self.lev[self.level].u1)
-
-    def _exchange(self, L, t):
-        self.dec.exchange_direct(L, t, 1)      # one round, one message per peer
-        self.exchanges += 1
-
-    def _fused(self, L, src, dst, rhs, res, norm_slot):
-        dx = 2.0 ** (-L.l)
-        check(lib().ramses_amd_mg_smooth_fused_ghost(
-            _ptr(src), _ptr(dst), _ptr(rhs), _ptr(res) if res is not None else None, _ptr(self._work),
-            C.c_void_p(self._norm.data_ptr() + 8 * norm_slot) if norm_slot is not None else None,
-            L.n, NG, dx, 4, _stream()))
-
-    def _restrict(self, Lf, res, Lc, rhs_c):
-        check(lib().ramses_amd_mg_restrict_ghost(_ptr(res), _ptr(rhs_c), Lf.n, NG, NG, _stream()))
-
-    def _interp_from(self, Lf, phi_f, l_coarse):
-        """phi_f += prolongation of the correction of level l_coarse."""
-        if l_coarse in self.lev:
-            Lc = self.lev[l_coarse]
-            self._exchange(Lc, Lc.u1)          # one ghost layer is needed; the slab mover sends all NG
-            check(lib().ramses_amd_mg_interp_correct_ghost(_ptr(phi_f), Lf.n, NG, _ptr(Lc.u1), NG, 0, None, _stream()))
-        else:
-            for d in range(3):
-                self._origin[d] = self.coords[d] * self.nrep_local
-            check(lib().ramses_amd_mg_interp_correct_ghost(_ptr(phi_f), Lf.n, NG, _ptr(self.rep_u1), 0,
-                                                           1 << self.lrep, self._origin, _stream()))
-
-    def _coarse_cycle(self, l, safe):
-        """recursive_multigrid_coarse (multigrid_fine_commons.f90:307-390); on entry
-        the restricted residual is in the level's u2 interior and u1 is zero."""
-        if l < 1:
-            return
-        if l not in self.lev:
-            # replicated levels: gather the right-hand side, solve everywhere
-            local = self.rep_local.interior(self.rep_local.u2).contiguous()
-            parts = self.tr.allgather(local)                     # [world, nl, nl, nl], rank = x + p*(y + p*z)
-            p, nl = self.p, self.nrep_local
-            g = parts.view(p, p, p, nl, nl, nl).permute(0, 3, 1, 4, 2, 5)   # [pz, k, py, j, px, i]
-            self.rep_rhs.copy_(g.reshape(p * nl, p * nl, p * nl))
-            check(lib().ramses_amd_mg_coarse_solve_dense(l, _ptr(self.rep_rhs), _ptr(self.rep_u1), _ptr(self.rep_work),
-                                                         safe, _stream()))
-            return
-        L = self.lev[l]
-        self._exchange(L, L.u2)
-        self._fused(L, L.u1, L.u4, L.u2, L.u3, None)              # pre-smoothing + residual
-        self._restrict_to(l, L.u3)
-        self._coarse_cycle(l - 1, safe)
-        if l - 1 >= 1:
-            self._interp_from(L, L.u4, l - 1)
-        self._exchange(L, L.u4)
-        check(lib().ramses_amd_mg_smooth_fused_ghost(_ptr(L.u4), _ptr(L.u1), _ptr(L.u2), None, None, None,
-                                                     L.n, NG, 2.0 ** (-l), 4, _stream()))   # post-smoothing
-
-    def _restrict_to(self, l, res):
-        """restrict the residual of level l into level l-1 (u2) and zero its correction."""
-        if l - 1 < 1:
-            return
-        Lf = self.lev[l]
-        if (l - 1) in self.lev:
-            Lc = self.lev[l - 1]
-            Lc.u1.zero_()
-            self._restrict(Lf, res, Lc, Lc.u2)
-        else:
-            self._restrict(Lf, res, self.rep_local, self.rep_local.u2)
+        self._call(lib().ramses_amd_mgdist_get_phi(self._ctx, _ptr(self.phi), _stream()))
+        return self.phi
 
     # ------------------------------------------------------------------ API
     def multigrid_fine(self, rho_tot):
         """Solve for phi of the level from a zero first guess.  rho (this rank's
-        interior) is self.rho; rho_tot the mean density of the whole box."""
-        L = self.lev[self.level]
-        rho_tot = float(rho_tot)
-        phi, phi2, f1, f2 = L.u1, L.u4, L.u3, L.u2
-        phi.zero_()
-        rhs = torch.empty_like(self.rho)
-        check(lib().ramses_amd_mg_rhs(_ptr(self.rho), _ptr(rhs), self.rho.numel(), self.fourpi, rho_tot, _stream()))
-        L.interior(f2).copy_(rhs)
-        self._exchange(L, f2)
-        it, err, i_res_norm2 = 0, 1.0, 0.0
-        safe = self.safe_mode
-        while True:
-            it += 1
-            if it > 1:
-                self._exchange(L, phi)
-            self._fused(L, phi, phi2, f2, f1, 0 if it == 1 else None)
-            if it == 1:
-                i_res_norm2 = self.tr.allreduce(float(self._norm[0].item()), self.dev)
-            if self.level > 1:
-                self._restrict_to(self.level, f1)
-                self._coarse_cycle(self.level - 1, safe)
-                self._interp_from(L, phi2, self.level - 1)
-            self._exchange(L, phi2)
-            # post-smoothing; only the norm of the residual is needed
-            self._fused(L, phi2, phi, f2, None, 1)
-            res_norm2 = self.tr.allreduce(float(self._norm[1].item()), self.dev)
-            last_err = err
-            err = math.sqrt(res_norm2 / (i_res_norm2 + 1e-20 * rho_tot * rho_tot))
-            if err < self.epsilon or it >= MAXITER:
-                break
-            if err > last_err * SAFE_FACTOR and not safe:
-                safe = 1
-        self.safe_mode = safe
-        self.last_iters, self.last_err = it, err
-        return it, err
+        brick) is self.rho; rho_tot the mean density of the whole box."""
+        it, err = C.c_int(), C.c_double()
+        self._call(lib().ramses_amd_mgdist_solve(self._ctx, _ptr(self.rho), float(rho_tot), self.fourpi, self.epsilon,
+                                                 C.byref(it), C.byref(err), _stream()))
+        self.last_iters, self.last_err = it.value, err.value
+        return it.value, err.value
 
     def force_fine(self):
-        L = self.lev[self.level]
-        self._exchange(L, L.u1)
-        check(lib().ramses_amd_gradient_phi_ghost(_ptr(L.u1), _ptr(self.f), L.n, NG, 2.0 ** (-self.level), _stream()))
+        self._call(lib().ramses_amd_mgdist_force(self._ctx, _ptr(self.f), _stream()))

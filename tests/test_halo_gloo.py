@@ -193,3 +193,50 @@ def test_weak_scaling_rank_grid_matches_bench():
     assert bench.rank_grid(2) == (2, 1, 1)
     assert bench.rank_grid(4) == (2, 2, 1)
     assert bench.rank_grid(8) == (2, 2, 2)
+
+
+class FakeBrick(FakeLevel):
+    def __init__(self, dims, ng, nvar):
+        self.nx, self.ny, self.nz = dims
+        self.ng, self.nvar = ng, nvar
+        self.brick = None
+        self.f = None
+        self.uold = torch.zeros((nvar, self.nz + 2 * ng, self.ny + 2 * ng, self.nx + 2 * ng), dtype=torch.float64)
+
+
+@pytest.mark.parametrize("pgrid", [(1, 1, 2), (1, 2, 2), (2, 1, 1), (1, 2, 4)])
+def test_bricks_that_are_not_cubes_exchange_their_deep_halo(pgrid):
+    """The distributed multigrid on 2 or 4 ranks: the cubic box in bricks of unequal extents, the 5-cell halo moved in
+    one round (one message per peer, self-wrap along the uncut axes), and the all-gather assembly of a replicated level."""
+    from ramses_amd.poisson_parallel import assemble_level, brick_dims
+    from ramses_amd.transport import LocalWorld
+    world = pgrid[0] * pgrid[1] * pgrid[2]
+    level, ng = 4, 3
+    N = 1 << level
+    dims = brick_dims(level, pgrid)
+    assert tuple(d * p for d, p in zip(dims, pgrid)) == (N, N, N)
+    G = global_field(1, N, N, N)
+
+    def body(tr):
+        dec = TorchMoverDecomposition(pgrid, tr.rank, dims, boxlen=1.0, ng=ng, transport=tr)
+        lev = FakeBrick(dims, ng, 1)
+        nx, ny, nz = dims
+        cx, cy, cz = rank_coords(tr.rank, pgrid)
+        own = G[:, cz * nz:(cz + 1) * nz, cy * ny:(cy + 1) * ny, cx * nx:(cx + 1) * nx]
+        lev.uold[:, ng:ng + nz, ng:ng + ny, ng:ng + nx] = torch.from_numpy(own.copy())
+        dec.exchange_direct(lev, lev.uold, 1)
+        idx = lambda c, n: (np.arange(c * n - ng, (c + 1) * n + ng)) % N  # noqa: E731
+        exp = G[:, idx(cz, nz)][:, :, idx(cy, ny)][:, :, :, idx(cx, nx)]
+        parts = tr.allgather(torch.from_numpy(own[0].copy()))
+        whole = assemble_level(parts, pgrid, dims)
+        return bool(np.array_equal(lev.uold.numpy(), exp)) and bool(np.array_equal(whole.numpy(), G[0]))
+
+    assert all(LocalWorld(world).run(body))
+
+
+def test_multigrid_rank_grid_cuts_z_first():
+    import bench
+    assert bench.mg_rank_grid(1) == (1, 1, 1)
+    assert bench.mg_rank_grid(2) == (1, 1, 2)
+    assert bench.mg_rank_grid(4) == (1, 2, 2)
+    assert bench.mg_rank_grid(8) == (2, 2, 2)

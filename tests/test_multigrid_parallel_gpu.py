@@ -83,3 +83,38 @@ def test_eight_virtual_ranks_equal_single_brick(gpu_lib, n):
     # correction once); the reference exchanges after each of the 8 colour passes
     nlev = 1 if n == 64 else 2
     assert out[0][4] <= 2 + it0 * (2 + 4 * (nlev - 1) + 1) + 1
+
+
+@pytest.mark.parametrize("level,pgrid", [(7, (2, 1, 1)), (7, (1, 1, 2)), (7, (2, 2, 1)), (7, (1, 2, 2)),
+                                         (8, (1, 2, 4)), (8, (2, 1, 1)), (8, (1, 2, 2))])
+def test_bricks_of_two_and_four_ranks_equal_single_brick(gpu_lib, level, pgrid):
+    """The reference's box is a cube, so 2 or 4 ranks own bricks that are not cubes (half boxes, quarter columns):
+    non-cubic ghost bricks through the fused smoother, the ghost restriction / prolongation / gradient kernels, the
+    halo plan and the all-gather assembly of the replicated levels.  Level 8 with >= 128-cell extents: two distributed
+    levels (the coarse halo of the prolongation too)."""
+    import torch
+    from ramses_amd.poisson_parallel import PoissonDecomposition
+    from ramses_amd.transport import LocalWorld
+    N = 1 << level
+    rho = _density(N, 5)
+    rho_tot = float(rho.mean())
+    it0, err0, phi0, f0 = _single(rho, 1e-6)
+    world = pgrid[0] * pgrid[1] * pgrid[2]
+
+    def body(tr):
+        pd = PoissonDecomposition(pgrid, tr.rank, level=level, boxlen=1.0, epsilon=1e-6, transport=tr)
+        sl = pd.my_slices()
+        pd.rho.copy_(torch.from_numpy(np.ascontiguousarray(rho[sl])).cuda())
+        it, err = pd.multigrid_fine(rho_tot)
+        pd.force_fine()
+        torch.cuda.synchronize()
+        return (it, err, pd.phi_interior().cpu().numpy(), pd.f.cpu().numpy(), sl, pd.nlev)
+
+    out = LocalWorld(world).run(body)
+    for it, err, phi, f, sl, nlev in out:
+        assert it == it0
+        assert np.array_equal(phi, phi0[sl]), (pgrid, sl)
+        assert np.array_equal(f, f0[(slice(None),) + sl]), (pgrid, sl)
+        assert abs(err - err0) <= 1e-10 * err0
+    if level == 8 and pgrid != (1, 2, 4):
+        assert out[0][5] == 2
