@@ -675,6 +675,17 @@ int ramses_amd_mgdist_solve(ramses_amd_mgdist *ctx, const double *d_rho, double 
 int ramses_amd_mgdist_get_phi(ramses_amd_mgdist *ctx, double *d_phi, void *stream);
 int ramses_amd_mgdist_set_phi(ramses_amd_mgdist *ctx, const double *d_phi, void *stream);
 int ramses_amd_mgdist_force(ramses_amd_mgdist *ctx, double *d_f, void *stream);
+/* The Fortran shim's side (patch/multigrid_fine_commons.f90, several ranks, levelmin fully refined and periodic):
+ * _oct_box: the box the rank's octs of the level fill -- lo[3] first cell, dims[3] cells -- from their centres xg
+ * (host only; RAMSES_AMD_EUNSUPPORTED when they do not fill one: the caller keeps the multigrid of AMR levels);
+ * _multigrid_f90: multigrid_fine(ilevel,icount) on the reference's own arrays: rho / phi are the cell vectors
+ * (1:ncoarse+8*ngridmax), igrid = active(ilevel)%igrid; phi of the rank's own cells is written back (the caller
+ * refreshes the virtual octs with make_virtual_fine_dp like the reference, multigrid_fine_commons.f90:284-287);
+ * safe_mode in/out = the reference's safe_mode(ilevel). */
+int ramses_amd_mgdist_oct_box(int ilevel, int ngrid, const int *igrid, const double *xg, int64_t ngridmax, int *lo, int *dims);
+int ramses_amd_mgdist_multigrid_f90(ramses_amd_mgdist *ctx, int ilevel, int ngrid, const int *igrid, const double *xg,
+                                    int64_t ngridmax, int64_t ncoarse, const int *lo, const double *rho, double *phi,
+                                    double rho_tot, double fourpi, double epsilon, int *safe_mode, int *iters, double *err);
 
 /* ---------------------------------------------------------------------------
  * Device image of the reference's communicators (type communicator, amr/amr_commons.f90:108-119;

@@ -30,6 +30,7 @@
 
 #include "../../include/ramses_amd.h"
 #include "mg_args.hpp"
+#include "pack_args.hpp"
 
 using namespace ramses_amd;
 
@@ -507,6 +508,106 @@ int ramses_amd_mgdist_force(ramses_amd_mgdist *M, double *d_f, void *stream) {
   Level &L = M->lev[M->level];
   RCHK(exchange(M, L, L.u[0], s));
   return ramses_amd_gradient_phi_ghost(L.u[0], d_f, L.n[0], L.n[1], L.n[2], NG, std::ldexp(1.0, -M->level), s);
+}
+
+// ---------------------------------------------------------------------------
+// The Fortran shim's side: the reference's own arrays (rho, phi as cell vectors; the rank's octs of the level).
+// ---------------------------------------------------------------------------
+namespace {
+// integer position (in cells of the level) of an oct's first cell, from its centre xg (amr/amr_commons.f90:67-75)
+inline bool oct_cell_origin(const double *xg, int64_t ngridmax, int ig, int n, int *o) {
+  for (int d = 0; d < 3; d++) {
+    const double c = xg[(size_t)d * ngridmax + (ig - 1)] * n;     // centre in cells: an odd multiple of 1 ... i.e. origin + 1
+    const long v = (long)std::floor(c + 0.5) - 1;
+    if (v < 0 || v + 1 >= n || (v & 1)) return false;
+    o[d] = (int)v;
+  }
+  return true;
+}
+struct DevArr {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+};
+}  // namespace
+
+// The box the rank's octs of the level fill: lo[3] (first cell) and dims[3] (cells), host only.  RAMSES_AMD_EUNSUPPORTED
+// when they do not fill a box (the caller then keeps the multigrid of AMR levels).
+int ramses_amd_mgdist_oct_box(int ilevel, int ngrid, const int *igrid, const double *xg, int64_t ngridmax, int *lo, int *dims) {
+  if (!igrid || !xg || !lo || !dims || ilevel < 1 || ilevel > 11 || ngrid < 1) return failf(RAMSES_AMD_EINVAL, "bad argument");
+  const int n = 1 << ilevel;
+  int mn[3] = {n, n, n}, mx[3] = {-1, -1, -1};
+  for (int g = 0; g < ngrid; g++) {
+    int o[3];
+    if (!oct_cell_origin(xg, ngridmax, igrid[g], n, o)) return failf(RAMSES_AMD_EINVAL, "oct %d of level %d does not sit on the level lattice", igrid[g], ilevel);
+    for (int d = 0; d < 3; d++) { mn[d] = std::min(mn[d], o[d]); mx[d] = std::max(mx[d], o[d] + 2); }
+  }
+  long vol = 1;
+  for (int d = 0; d < 3; d++) { lo[d] = mn[d]; dims[d] = mx[d] - mn[d]; vol *= dims[d]; }
+  if (vol != (long)ngrid * 8) return failf(RAMSES_AMD_EUNSUPPORTED, "the rank's %d octs of level %d do not fill their bounding box (%d x %d x %d cells)", ngrid, ilevel, dims[0], dims[1], dims[2]);
+  return 0;
+}
+
+// multigrid_fine(ilevel,icount) of the reference on its own arrays, several ranks: rho of the rank's octs is gathered
+// into the brick, the distributed solve runs, phi of the rank's octs is written back (the caller refreshes the virtual
+// octs with its own make_virtual_fine_dp, as the reference does at the end of multigrid_fine).  lo = the box origin
+// ramses_amd_mgdist_oct_box returned.
+int ramses_amd_mgdist_multigrid_f90(ramses_amd_mgdist *M, int ilevel, int ngrid, const int *igrid, const double *xg,
+                                    int64_t ngridmax, int64_t ncoarse, const int *lo, const double *rho, double *phi,
+                                    double rho_tot, double fourpi, double epsilon, int *safe_mode, int *iters, double *err) {
+  if (!M || !igrid || !xg || !lo || !rho || !phi || !safe_mode) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  if (ilevel != M->level) return failf(RAMSES_AMD_EINVAL, "context built for level %d, called for level %d", M->level, ilevel);
+  const int n = 1 << ilevel;
+  const long N = (long)M->dims[0] * M->dims[1] * M->dims[2];
+  if ((long)ngrid * 8 != N) return failf(RAMSES_AMD_EINVAL, "the rank holds %d octs, its brick %ld cells", ngrid, N);
+  for (int d = 0; d < 3; d++)
+    if (lo[d] != M->coords[d] * M->dims[d]) return failf(RAMSES_AMD_EINVAL, "the rank's box does not start where its brick does");
+  const long ncell = ncoarse + 8 * ngridmax;
+  hipStream_t s = nullptr;
+  static DevArr d_vec, d_igrid, d_org, d_rho, d_phi;
+  static std::vector<long> org;
+  org.resize(ngrid);
+  for (int g = 0; g < ngrid; g++) {
+    int o[3];
+    if (!oct_cell_origin(xg, ngridmax, igrid[g], n, o)) return failf(RAMSES_AMD_EINVAL, "oct %d of level %d does not sit on the level lattice", igrid[g], ilevel);
+    for (int d = 0; d < 3; d++) {
+      o[d] -= lo[d];
+      if (o[d] < 0 || o[d] + 2 > M->dims[d]) return failf(RAMSES_AMD_EINVAL, "oct %d lies outside the rank's box", igrid[g]);
+    }
+    org[g] = o[0] + (long)M->dims[0] * (o[1] + (long)M->dims[1] * o[2]);
+  }
+  HCHK(d_vec.ensure(sizeof(double) * ncell), "hipMalloc");
+  HCHK(d_igrid.ensure(sizeof(int) * ngrid), "hipMalloc");
+  HCHK(d_org.ensure(sizeof(long) * ngrid), "hipMalloc");
+  HCHK(d_rho.ensure(sizeof(double) * N), "hipMalloc");
+  HCHK(d_phi.ensure(sizeof(double) * N), "hipMalloc");
+  HCHK(hipMemcpyAsync(d_vec.p, rho, sizeof(double) * ncell, hipMemcpyHostToDevice, s), "H2D rho");
+  HCHK(hipMemcpyAsync(d_igrid.p, igrid, sizeof(int) * ngrid, hipMemcpyHostToDevice, s), "H2D igrid");
+  HCHK(hipMemcpyAsync(d_org.p, org.data(), sizeof(long) * ngrid, hipMemcpyHostToDevice, s), "H2D oct origins");
+  PackArgs A;
+  A.igrid = reinterpret_cast<const int *>(d_igrid.p); A.octorg = reinterpret_cast<const long *>(d_org.p);
+  A.ngrid = ngrid; A.n = n; A.nvar = 1;
+  A.ncoarse = ncoarse; A.ngridmax = ngridmax; A.ncell = ncell; A.pitch_var = N;
+  A.pitch_y = M->dims[0]; A.pitch_z = (long)M->dims[0] * M->dims[1];
+  A.brick = reinterpret_cast<double *>(d_rho.p); A.cellvec = reinterpret_cast<double *>(d_vec.p);
+  HCHK(launch_oct_copy(A, true, s), "gather launch");
+  M->safe_mode = *safe_mode ? 1 : 0;
+  RCHK(ramses_amd_mgdist_solve(M, reinterpret_cast<const double *>(d_rho.p), rho_tot, fourpi, epsilon, iters, err, s));
+  *safe_mode = M->safe_mode;
+  RCHK(ramses_amd_mgdist_get_phi(M, reinterpret_cast<double *>(d_phi.p), s));
+  // phi of the rank's own cells into the cell vector (the other cells keep the host's values)
+  HCHK(hipMemcpyAsync(d_vec.p, phi, sizeof(double) * ncell, hipMemcpyHostToDevice, s), "H2D phi");
+  A.brick = reinterpret_cast<double *>(d_phi.p);
+  HCHK(launch_oct_copy(A, false, s), "scatter launch");
+  HCHK(hipMemcpyAsync(phi, d_vec.p, sizeof(double) * ncell, hipMemcpyDeviceToHost, s), "D2H phi");
+  HCHK(hipStreamSynchronize(s), "sync");
+  return 0;
 }
 
 }  // extern "C"

@@ -70,6 +70,7 @@ subroutine multigrid_fine_amd(ilevel,icount)
   integer::rc,nx_loc,isafe,iters,interp
   real(dp)::scale,fourpi,tfrac
   real(kind=8)::err
+  logical::dist
 
   if(gravity_type>0)return
   if(numbtot(1,ilevel)==0)return
@@ -87,7 +88,19 @@ subroutine multigrid_fine_amd(ilevel,icount)
   ! (a box with physical boundaries: the Dirichlet values enter through the masks and the
   !  right-hand side the reference prepares, so every level takes this path)
   nx_loc=icoarse_max-icoarse_min+1
-  ! (several MPI ranks: every level takes this path too -- the reference's driver with its halo exchanges on the host,
+  ! several MPI ranks, levelmin fully refined and periodic, every rank's domain a power-of-two box: the dense V-cycles of
+  ! the single-rank path, distributed (one brick per rank, one deep-halo exchange per smoother launch, coarse levels
+  ! replicated: csrc/mg_dist.hip)
+  if(ncpu>1.and.ilevel==levelmin.and.nboundary==0.and.nx_loc==1.and.jcoarse_max==jcoarse_min.and.kcoarse_max==kcoarse_min)then
+     call ramses_amd_mgdist_multigrid(ilevel,dist,iters,err)
+     if(dist)then
+        if(myid==1) print '(A,I5,A,I5,A,1pE10.3)','   ==> Level=',ilevel, ' Step=', &
+             iters,' Error=',err
+        if(myid==1 .and. iters==10) print *,'WARN: Fine multigrid Poisson failed to converge...'
+        return
+     end if
+  end if
+  ! (several MPI ranks otherwise: every level takes this path -- the reference's driver with its halo exchanges,
   !  each compute routine on the rank's GPU over its own octs and the reception octs of its neighbours)
   if(ilevel>levelmin.or.nboundary>0.or.ncpu>1.or.nx_loc/=1.or.jcoarse_max/=jcoarse_min.or.kcoarse_max/=kcoarse_min &
        & .or.int(active(ilevel)%ngrid,8)*8_8/=(2_8**ilevel)**3*int(nx_loc,8)**3)then

@@ -27,7 +27,57 @@ module ramses_amd_iface
      integer(c_int64_t) :: pitch_y, pitch_z, pitch_var
   end type ramses_amd_brick
 
+  ! struct ramses_amd_mg_transport: the caller's message layer of the distributed multigrid (host buffers)
+  type, bind(C) :: ramses_amd_mg_transport
+     type(c_ptr)    :: user
+     type(c_funptr) :: exchange, allgather, allreduce_sum
+  end type ramses_amd_mg_transport
+
   interface
+     ! distributed dense multigrid of a fully refined periodic level, one brick per rank (csrc/mg_dist.hip)
+     function ramses_amd_mgdist_create(level, pgrid, rank, rank_of_brick, transport, ctx) &
+          & bind(C, name='ramses_amd_mgdist_create') result(rc)
+       import :: c_int, c_ptr
+       integer(c_int), value :: level, rank
+       integer(c_int) :: pgrid(3), rank_of_brick(*)
+       type(c_ptr), value :: transport        ! c_loc of a ramses_amd_mg_transport, or c_null_ptr: RCCL inside the library
+       type(c_ptr) :: ctx
+       integer(c_int) :: rc
+     end function ramses_amd_mgdist_create
+
+     function ramses_amd_mgdist_destroy(ctx) bind(C, name='ramses_amd_mgdist_destroy') result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int) :: rc
+     end function ramses_amd_mgdist_destroy
+
+     function ramses_amd_mgdist_oct_box(ilevel, ngrid, igrid, xg, ngridmax, lo, dims) &
+          & bind(C, name='ramses_amd_mgdist_oct_box') result(rc)
+       import :: c_int, c_int64_t, c_double
+       integer(c_int), value :: ilevel, ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: xg(*)
+       integer(c_int64_t), value :: ngridmax
+       integer(c_int) :: lo(3), dims(3)
+       integer(c_int) :: rc
+     end function ramses_amd_mgdist_oct_box
+
+     function ramses_amd_mgdist_multigrid_f90(ctx, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, lo, rho, phi, &
+          & rho_tot, fourpi, epsilon, safe_mode, iters, err) bind(C, name='ramses_amd_mgdist_multigrid_f90') result(rc)
+       import :: c_int, c_int64_t, c_double, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: ilevel, ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: xg(*)
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       integer(c_int) :: lo(3)
+       real(c_double) :: rho(*), phi(*)
+       real(c_double), value :: rho_tot, fourpi, epsilon
+       integer(c_int) :: safe_mode, iters
+       real(c_double) :: err
+       integer(c_int) :: rc
+     end function ramses_amd_mgdist_multigrid_f90
+
      function ramses_amd_abi_check(sz_params, sz_brick) bind(C, name='ramses_amd_abi_check') result(rc)
        import :: c_size_t, c_int
        integer(c_size_t), value :: sz_params, sz_brick
@@ -792,6 +842,15 @@ module ramses_amd_iface
   ! and the reference's host exchanges run (the round-2 path, kept as the A/B of the new one)
   logical, save :: ramses_amd_mg_mpi_resident = .false.
   logical, save :: ramses_amd_mg_comm_done(64) = .false.
+  logical, save :: ramses_amd_halo_inited = .false.
+  ! levelmin fully refined and periodic, several ranks whose domains are boxes: multigrid_fine through the distributed
+  ! dense driver (csrc/mg_dist.hip); RAMSES_AMD_MG_DIST=0 keeps the multigrid of AMR levels (the round-3 path)
+  type(c_ptr), save :: ramses_amd_mgdist_ctx = c_null_ptr
+  integer, save :: ramses_amd_mgdist_level = 0
+  integer, save :: ramses_amd_mgdist_pg(3) = 0
+  integer, allocatable, save :: ramses_amd_mgdist_rob(:)
+  logical, save :: ramses_amd_mgdist_said = .false.
+  type(ramses_amd_mg_transport), save, target :: ramses_amd_mgdist_tr
 
 contains
 
@@ -1244,6 +1303,7 @@ contains
     val = 'auto'
     call get_environment_variable('RAMSES_AMD_HALO', val, status=stat)
     if (stat /= 0) val = 'auto'
+    ramses_amd_halo_inited = .true.
     ramses_amd_halo_rccl = .false.
     if (trim(val) == 'host') then
        if (myid == 1) write(*,*) 'ramses_amd: halo exchange staged through host MPI (RAMSES_AMD_HALO=host)'
@@ -1850,5 +1910,192 @@ contains
     end if
     p%reserved = 0
   end subroutine ramses_amd_fill_hydro_params
+
+#ifndef WITHOUTMPI
+  !---------------------------------------------------------------------------
+  ! The message layer of the distributed multigrid when the ranks cannot use RCCL (several ranks on one GPU): this
+  ! program's own MPI on the library's pinned host buffers (struct ramses_amd_mg_transport, include/ramses_amd.h)
+  !---------------------------------------------------------------------------
+  function ramses_amd_mgdist_cb_exchange(user, npeer, peer, h_send, send_off, send_cnt, h_recv, recv_off, recv_cnt) &
+       & bind(C) result(rc)
+    use mpi_mod
+    type(c_ptr), value :: user
+    integer(c_int), value :: npeer
+    integer(c_int), intent(in) :: peer(*)
+    real(c_double) :: h_send(*), h_recv(*)
+    integer(c_int64_t), intent(in) :: send_off(*), send_cnt(*), recv_off(*), recv_cnt(*)
+    integer(c_int) :: rc
+    integer :: i, nreq, info
+    integer :: req(2*npeer + 1)
+    integer :: statuses(MPI_STATUS_SIZE, 2*npeer + 1)
+    integer, parameter :: tag = 141
+    nreq = 0
+    do i = 1, npeer
+       if (recv_cnt(i) > 0) then
+          nreq = nreq + 1
+          call MPI_IRECV(h_recv(recv_off(i) + 1), int(recv_cnt(i)), MPI_DOUBLE_PRECISION, peer(i), tag, MPI_COMM_WORLD, &
+               & req(nreq), info)
+       end if
+    end do
+    do i = 1, npeer
+       if (send_cnt(i) > 0) then
+          nreq = nreq + 1
+          call MPI_ISEND(h_send(send_off(i) + 1), int(send_cnt(i)), MPI_DOUBLE_PRECISION, peer(i), tag, MPI_COMM_WORLD, &
+               & req(nreq), info)
+       end if
+    end do
+    call MPI_WAITALL(nreq, req, statuses, info)
+    rc = 0
+  end function ramses_amd_mgdist_cb_exchange
+
+  function ramses_amd_mgdist_cb_allgather(user, h_send, count, h_recv) bind(C) result(rc)
+    use mpi_mod
+    type(c_ptr), value :: user
+    real(c_double) :: h_send(*), h_recv(*)
+    integer(c_int64_t), value :: count
+    integer(c_int) :: rc
+    integer :: info
+    call MPI_ALLGATHER(h_send, int(count), MPI_DOUBLE_PRECISION, h_recv, int(count), MPI_DOUBLE_PRECISION, MPI_COMM_WORLD, info)
+    rc = info
+  end function ramses_amd_mgdist_cb_allgather
+
+  ! (the reference's own reduction of the residual norms, poisson/multigrid_fine_commons.f90:205-209,253-257)
+  function ramses_amd_mgdist_cb_allreduce(user, x) bind(C) result(rc)
+    use mpi_mod
+    type(c_ptr), value :: user
+    real(c_double) :: x
+    integer(c_int) :: rc
+    integer :: info
+    real(kind=8) :: tot
+    call MPI_ALLREDUCE(x, tot, 1, MPI_DOUBLE_PRECISION, MPI_SUM, MPI_COMM_WORLD, info)
+    x = tot
+    rc = info
+  end function ramses_amd_mgdist_cb_allreduce
+#endif
+
+  !---------------------------------------------------------------------------
+  ! multigrid_fine(levelmin) with several ranks, levelmin fully refined and periodic, every rank's domain a box (what
+  ! the Hilbert decomposition gives 2^k ranks): rho of the rank's octs -> its brick, the distributed dense V-cycles on
+  ! the GPUs (one 5-cell halo exchange per smoother launch, coarse levels replicated; csrc/mg_dist.hip), phi of the
+  ! rank's octs back; the virtual octs of phi through the reference's make_virtual_fine_dp, as at the end of its loop.
+  ! ok = .false.: another configuration -- the caller goes on to the multigrid of AMR levels.  Collective.
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_mgdist_multigrid(ilevel, ok, iters, err)
+    use amr_commons
+    use poisson_commons
+    use poisson_parameters
+    use constants, only: twopi
+#ifndef WITHOUTMPI
+    use mpi_mod
+#endif
+    integer, intent(in) :: ilevel
+    logical, intent(out) :: ok
+    integer, intent(out) :: iters
+    real(kind=8), intent(out) :: err
+#ifndef WITHOUTMPI
+    character(len=16) :: val
+    integer :: stat, rc, info, i, b, d, n, nx_loc, isafe
+    integer :: lo(3), dims(3), mine(7), pg(3), c(3)
+    integer, allocatable :: every(:,:), rob(:)
+    logical :: same, fit
+    real(dp) :: scale, fourpi
+#endif
+    ok = .false.
+    iters = 0
+    err = 0.0d0
+#ifndef WITHOUTMPI
+    if (ncpu == 1 .or. ilevel /= levelmin .or. ilevel > 11 .or. nboundary > 0) return
+    call get_environment_variable('RAMSES_AMD_MG_DIST', val, status=stat)
+    if (stat == 0) then
+       if (trim(val) == '0') return
+    end if
+    n = 2**ilevel
+    if (int(numbtot(1, ilevel), 8)*8_8 /= int(n, 8)**3) return
+    ! the box of my octs, and everybody else's
+    mine = 0
+    if (active(ilevel)%ngrid > 0) then
+       rc = ramses_amd_mgdist_oct_box(ilevel, active(ilevel)%ngrid, ramses_amd_octs(ilevel), xg, int(ngridmax, 8), lo, dims)
+       if (rc == 0) then
+          mine(1:3) = lo
+          mine(4:6) = dims
+          mine(7) = 1
+       end if
+    end if
+    allocate(every(7, ncpu), rob(ncpu))
+    call MPI_ALLGATHER(mine, 7, MPI_INTEGER, every, 7, MPI_INTEGER, MPI_COMM_WORLD, info)
+    fit = all(every(7, :) == 1)
+    if (fit) then
+       dims = every(4:6, 1)
+       do d = 1, 3
+          if (dims(d) < 64 .or. iand(dims(d), dims(d) - 1) /= 0 .or. dims(d) > n) fit = .false.
+       end do
+    end if
+    if (fit) then
+       pg = n/dims
+       if (pg(1)*pg(2)*pg(3) /= ncpu) fit = .false.
+    end if
+    if (fit) then
+       rob = -1
+       do i = 1, ncpu
+          if (any(every(4:6, i) /= dims) .or. any(mod(every(1:3, i), dims) /= 0)) then
+             fit = .false.
+             exit
+          end if
+          c = every(1:3, i)/dims
+          b = c(1) + pg(1)*(c(2) + pg(2)*c(3)) + 1
+          if (rob(b) /= -1) fit = .false.
+          rob(b) = i - 1
+       end do
+       if (any(rob < 0)) fit = .false.
+    end if
+    if (.not. fit) then
+       if (myid == 1 .and. .not. ramses_amd_mgdist_said) write(*,*) 'ramses_amd: the rank domains of level ', ilevel, &
+            & ' are not equal power-of-two boxes of >= 64 cells: multigrid of AMR levels'
+       ramses_amd_mgdist_said = .true.
+       deallocate(every, rob)
+       return
+    end if
+    ! (re)build the context when the decomposition changed (load balancing)
+    same = c_associated(ramses_amd_mgdist_ctx) .and. ramses_amd_mgdist_level == ilevel .and. all(ramses_amd_mgdist_pg == pg)
+    if (same) same = all(ramses_amd_mgdist_rob == rob)
+    if (.not. same) then
+       if (c_associated(ramses_amd_mgdist_ctx)) rc = ramses_amd_mgdist_destroy(ramses_amd_mgdist_ctx)
+       ramses_amd_mgdist_ctx = c_null_ptr
+       if (.not. ramses_amd_halo_inited) call ramses_amd_halo_init()
+       if (ramses_amd_halo_rccl) then
+          rc = ramses_amd_mgdist_create(ilevel, pg, myid - 1, rob, c_null_ptr, ramses_amd_mgdist_ctx)
+       else
+          ramses_amd_mgdist_tr%user = c_null_ptr
+          ramses_amd_mgdist_tr%exchange = c_funloc(ramses_amd_mgdist_cb_exchange)
+          ramses_amd_mgdist_tr%allgather = c_funloc(ramses_amd_mgdist_cb_allgather)
+          ramses_amd_mgdist_tr%allreduce_sum = c_funloc(ramses_amd_mgdist_cb_allreduce)
+          rc = ramses_amd_mgdist_create(ilevel, pg, myid - 1, rob, c_loc(ramses_amd_mgdist_tr), ramses_amd_mgdist_ctx)
+       end if
+       if (rc /= 0) call ramses_amd_fatal('multigrid_fine (distributed dense multigrid, setup)')
+       ramses_amd_mgdist_level = ilevel
+       ramses_amd_mgdist_pg = pg
+       if (allocated(ramses_amd_mgdist_rob)) deallocate(ramses_amd_mgdist_rob)
+       allocate(ramses_amd_mgdist_rob(ncpu))
+       ramses_amd_mgdist_rob = rob
+       if (myid == 1) write(*,'(A,I3,A,I2,A,I2,A,I2,A,I5,A,I5,A,I5,A)') ' ramses_amd: multigrid of level ', ilevel, &
+            & ' distributed over ', pg(1), ' x', pg(2), ' x', pg(3), ' bricks of ', dims(1), ' x', dims(2), ' x', dims(3), &
+            & ' cells, one per rank (dense V-cycles, 5-cell halo per smoother launch)'
+    end if
+    lo = every(1:3, myid)
+    deallocate(every, rob)
+    nx_loc = icoarse_max - icoarse_min + 1
+    scale = boxlen/dble(nx_loc)
+    fourpi = 2*twopi*scale
+    if (cosmo) fourpi = 1.5D0*omega_m*aexp*scale
+    isafe = 0
+    if (safe_mode(ilevel)) isafe = 1
+    rc = ramses_amd_mgdist_multigrid_f90(ramses_amd_mgdist_ctx, ilevel, active(ilevel)%ngrid, ramses_amd_octs(ilevel), xg, &
+         & int(ngridmax, 8), int(ncoarse, 8), lo, rho, phi, rho_tot, fourpi, epsilon, isafe, iters, err)
+    if (rc /= 0) call ramses_amd_fatal('multigrid_fine (distributed dense multigrid)')
+    safe_mode(ilevel) = (isafe /= 0)
+    call make_virtual_fine_dp(phi(1), ilevel)
+    ok = .true.
+#endif
+  end subroutine ramses_amd_mgdist_multigrid
 
 end module ramses_amd_iface

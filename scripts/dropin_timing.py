@@ -192,10 +192,13 @@ if __name__ == "__main__":
         ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi")
         pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi_patch")
         if which in ("all", "gpu"):
-            run_grav_mpi("patched: multigrid levels resident on the device, virtual boundaries exchanged from there (round 3)", pat,
+            run_grav_mpi("patched: dense V-cycles distributed over one brick per rank, one deep-halo exchange per smoother launch (csrc/mg_dist.hip; default)", pat,
                          {"RAMSES_AMD": "1", "RAMSES_AMD_MG_STATS": "1"}, level, nstep, nproc)
-            run_grav_mpi("patched: arrays across PCIe around every multigrid routine, host exchanges (RAMSES_AMD_MG_MPI_SYNC=1, round 2)", pat,
-                         {"RAMSES_AMD": "1", "RAMSES_AMD_MG_STATS": "1", "RAMSES_AMD_MG_MPI_SYNC": "1"}, level, nstep, nproc)
+            run_grav_mpi("patched: multigrid of AMR levels, levels resident on the device, virtual boundaries exchanged from there (RAMSES_AMD_MG_DIST=0)", pat,
+                         {"RAMSES_AMD": "1", "RAMSES_AMD_MG_STATS": "1", "RAMSES_AMD_MG_DIST": "0"}, level, nstep, nproc)
+            if which == "all":
+                run_grav_mpi("patched: arrays across PCIe around every multigrid routine, host exchanges (RAMSES_AMD_MG_DIST=0 RAMSES_AMD_MG_MPI_SYNC=1, round 2)", pat,
+                             {"RAMSES_AMD": "1", "RAMSES_AMD_MG_STATS": "1", "RAMSES_AMD_MG_DIST": "0", "RAMSES_AMD_MG_MPI_SYNC": "1"}, level, nstep, nproc)
         if which in ("all", "ref"):
             run_grav_mpi("reference (MPI)", ref, {"RAMSES_AMD": "0"}, level, nstep, nproc)
         sys.exit(0)

@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -111,3 +112,33 @@ def test_mpi_entry_points_fail_loudly_without_their_state():
     v = C.c_double(0.0)
     assert L.ramses_amd_cgmpi_get(0, C.byref(v)) != 0
     assert L.ramses_amd_cgmpi_set(0, 1.0) != 0
+
+
+def test_mgdist_oct_box_finds_the_box_a_rank_fills(built_lib):
+    """ramses_amd_mgdist_oct_box (host only): the octs of a rank's domain, in any order, fill a box -- or the call says
+    they do not (the Fortran shim then keeps the multigrid of AMR levels)."""
+    import ctypes as C
+    from ramses_amd import _capi
+    L = _capi.lib()
+    level, n = 4, 16
+    ngridmax = 700
+    rng = np.random.default_rng(2)
+    # a quarter column: cells [8,16) x [0,8) x [0,16)  ->  octs 4 x 4 x 8
+    octs = [(i, j, k) for k in range(0, 16, 2) for j in range(0, 8, 2) for i in range(8, 16, 2)]
+    slots = rng.permutation(ngridmax)[:len(octs)] + 1
+    xg = np.zeros((3, ngridmax))
+    for s, (i, j, k) in zip(slots, octs):
+        xg[:, s - 1] = [(i + 1) / n, (j + 1) / n, (k + 1) / n]
+    igrid = slots.astype(np.int32)
+    lo, dims = (C.c_int * 3)(), (C.c_int * 3)()
+    rc = L.ramses_amd_mgdist_oct_box(level, len(octs), igrid.ctypes.data_as(C.c_void_p), xg.ctypes.data_as(C.c_void_p), ngridmax, lo, dims)
+    assert rc == 0, L.ramses_amd_last_error()
+    assert tuple(lo) == (8, 0, 0) and tuple(dims) == (8, 8, 16)
+    # one oct missing: not a box
+    rc = L.ramses_amd_mgdist_oct_box(level, len(octs) - 1, igrid.ctypes.data_as(C.c_void_p), xg.ctypes.data_as(C.c_void_p), ngridmax, lo, dims)
+    assert rc != 0 and b"do not fill" in L.ramses_amd_last_error()
+    # a rank grid that is not a power of two, a brick below the smoother's tile: loud
+    ctx = C.c_void_p()
+    assert L.ramses_amd_mgdist_create(7, (C.c_int * 3)(3, 1, 1), 0, None, None, C.byref(ctx)) != 0
+    assert L.ramses_amd_mgdist_create(7, (C.c_int * 3)(4, 1, 1), 0, None, None, C.byref(ctx)) != 0
+    assert b"every extent must be >= 64" in L.ramses_amd_last_error()

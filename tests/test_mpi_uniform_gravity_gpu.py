@@ -1,0 +1,83 @@
+"""GPU test of multigrid_fine on a uniform level with several MPI ranks (SURVEY.md 8 rows a21,
+a28, a30, e): BASELINE config C4's shape -- hydro + self-gravity on a fully refined periodic level -- run by the
+patched MPI program (oracle/_ref/ramses3d_mpi_patch) on 2, 4 and 8 ranks.  The rank domains of the Hilbert
+decomposition are half boxes, quarter columns, octants; multigrid_fine(levelmin) takes the distributed DENSE V-cycles
+behind the C ABI (csrc/mg_dist.hip through ramses_amd/patch/multigrid_fine_commons.f90: one brick per rank inside 5 ghost
+layers, one deep-halo exchange per smoother launch instead of one per colour pass, coarse levels replicated), the
+messages through the program's own MPI on the library's pinned buffers (the ranks share the test box's one GPU).
+V-cycle counts, phi, f and the hydro state must equal the untouched MPI reference on the same number of ranks; with
+RAMSES_AMD_MG_DIST=0 the same run takes the multigrid of AMR levels (round 3's path) and must give the same."""
+import importlib.util
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_MPI = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi")
+PATCHED_MPI = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi_patch")
+
+
+def _mkb():
+    spec = importlib.util.spec_from_file_location("mkb", os.path.join(ROOT, "tests", "golden", "make_golden_baseline.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _run(nml, binary, nproc, env):
+    from oracle import ramses_snapshot as rs
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return rs.run_reference(nml, binary=binary, nproc=nproc)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+_REF = {}
+
+
+def _reference(nml, nproc, level):
+    """the MPI reference on nproc ranks (once per rank count)"""
+    from oracle import ramses_snapshot as rs
+    if nproc not in _REF:
+        work, out = _run(nml, REF_MPI, nproc, {"RAMSES_AMD": "0"})
+        try:
+            _REF[nproc] = (rs.load_uniform_level(os.path.join(work, "output_00002"), level, with_grav=True), _mkb().solves(out))
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    return _REF[nproc]
+
+
+@pytest.mark.parametrize("nproc,dist", [(2, "1"), (4, "1"), (8, "1"), (2, "0")])
+def test_uniform_self_gravity_under_mpi_equals_the_mpi_reference(gpu_lib, nproc, dist):
+    if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED_MPI)):
+        pytest.skip("oracle/_ref/ramses3d_mpi[_patch] not built")
+    if nproc > (os.cpu_count() or 1):
+        pytest.skip("fewer cores than ranks")
+    from oracle import ramses_snapshot as rs
+    mkb = _mkb()
+    level = 7
+    nml = mkb.c4_namelist(level=level).replace("ngridtot=", "ngridtot=%d !" % (3 * sum(8 ** l for l in range(level)) + 1000))
+    ref, ref_solves = _reference(nml, nproc, level)
+    work, out = _run(nml, PATCHED_MPI, nproc, {"RAMSES_AMD": "1", "RAMSES_AMD_MG_DIST": dist})
+    try:
+        got = rs.load_uniform_level(os.path.join(work, "output_00002"), level, with_grav=True)
+        got_solves = mkb.solves(out)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    said = "distributed over" in out
+    assert said == (dist == "1"), out[-2000:]
+    if dist == "1":
+        assert "one per rank (dense V-cycles" in out
+    assert len(got_solves) >= 3 and got_solves == ref_solves, (got_solves, ref_solves)
+    assert got["info"]["t"] == ref["info"]["t"]
+    assert np.array_equal(got["grav"], ref["grav"]), np.abs(got["grav"] - ref["grav"]).max()     # phi, f
+    assert np.array_equal(got["prim"], ref["prim"]), np.abs(got["prim"] - ref["prim"]).max()     # hydro state
