@@ -512,7 +512,7 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
                                                                           double *__restrict__ rhs_c,
                                                                           double *__restrict__ u1_c,
                                                                           const double *__restrict__ corr_c,
-                                                                          int ny, int nz, int seg_planes) {
+                                                                          int ny, int nz) {
   // n = cells along x; ny, nz along y, z (a rank's brick of a distributed level need not be a cube; dense levels: all equal)
   using G = SmoothGeom<P, RESID, LYT>;
   static_assert(!PROL || (!RESID && P == 2 && (LYT * 16) * 2 >= (G::LX / 2 + 2) * (G::LY / 2 + 2)), "fused prolongation: the smoother without residual");
@@ -529,31 +529,10 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int bid = blockIdx.x;
-  // The work of a launch = (tiles) x (nz planes), linearised tile-major.  seg_planes = 0: a block is (tile, chunk of zchunk
-  // planes).  seg_planes > 0 (balanced): block b takes the plane-units [b*seg_planes, (b+1)*seg_planes) -- the end of one
-  // tile's column and the beginning of the next one's -- so that one workgroup per CU gets the same number of planes
-  // whatever the tile count: no partly filled last round of workgroups (512^3: 720 chunks on 256 CUs = 2.8 rounds), and a
-  // pipeline fill (2H + 4 planes) per ~360 planes instead of per 128.
-  double acc = 0.0;
-  long gpos, gend;
-  if (seg_planes > 0) {
-    gpos = (long)bid * seg_planes;
-    gend = min(gpos + (long)seg_planes, (long)ntx * nty * nz);
-  } else {
-    const int tile_ = bid % (ntx * nty), tiz_ = bid / (ntx * nty);
-    gpos = (long)tile_ * nz + (long)tiz_ * zchunk;
-    gend = (long)tile_ * nz + min(tiz_ * zchunk + zchunk, nz);
-  }
-  bool first_seg = true;
-  while (gpos < gend) {
-  const int tile = (int)(gpos / nz);
-  const int z0 = (int)(gpos - (long)tile * nz);
-  const int z1 = (int)min((long)nz, (long)z0 + (gend - gpos));   // planes [z0,z1) are produced
-  gpos += z1 - z0;
-  if (!first_seg) __syncthreads();      // the ring and the residual / coarse buffers start over
-  first_seg = false;
-  const int tix = tile % ntx, tiy = tile / ntx;
+  const int tix = bid % ntx, tiy = (bid / ntx) % nty, tiz = bid / (ntx * nty);
   const int x0 = tix * G::IX - H, y0 = tiy * G::IY - H;   // global coords of tile cell (0,0)
+  const int z0 = tiz * zchunk;
+  const int z1 = min(z0 + zchunk, nz);                    // planes [z0,z1) are produced
   // ng = 0: dense periodic level, neighbours wrap; ng >= H: one rank's brick of a
   // distributed level with ghost layers filled by the halo exchange (addresses
   // outside the allocation are clamped: those values are never used)
@@ -590,6 +569,7 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
     goffC[j][0] = gy + wrapx(x0 + 2 * pr);
     goffC[j][1] = gy + wrapx(x0 + 2 * pr + 1);
   }
+  double acc = 0.0;
 
   const int m_begin = z0 - H - 2;
   const int m_end = (z1 - 1) + 2 * P;
@@ -863,7 +843,6 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
     nxt = nx2;
   }
   if constexpr (RESTR) restrict_plane(m_end - 2 * P, m_end & 1);       // the last plane (the loop's last barrier is behind us)
-  }   // segments of this block
   if (RESID && partial) {
     sm[tid] = acc;
     for (int i = SMOOTH_THREADS + tid; i < 512; i += SMOOTH_THREADS) sm[i] = 0.0;
@@ -882,7 +861,6 @@ __global__ __launch_bounds__(LYT * 16) void mg_smooth_fused_kernel(const double 
 // workgroups per CU -- a tuning knob, results do not depend on it.  Measured at 512^3 per V-cycle:
 // one 4-pass launch 7.75 ms, 2+2 passes on 24 rows 7.73, on 32 rows 7.27.
 static int g_smooth_ly = 32;
-constexpr int MG_BALANCE_DEFAULT = 0;
 void mg_set_smooth_rows(int ly) { g_smooth_ly = (ly == 12 || ly == 16 || ly == 32) ? ly : 24; }
 
 // can the fused smoother of this level restrict its residual itself (mg_launch_smooth_fused with rhs_c / u1_c)?
@@ -912,33 +890,7 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
   if (const char *e = getenv("RAMSES_AMD_MG_ZCHUNK")) { const int z = atoi(e); if (z >= 8 && nz >= 256) zchunk = z; }   // tuning aid
   if (const char *e = getenv("RAMSES_AMD_MG_ZCHUNK_SMALL")) { const int z = atoi(e); if (z >= 8 && nz < 256) zchunk = z < nz ? z : nz; }   // tuning aid
   const int ntz = (nz + zchunk - 1) / zchunk;
-  int blocks = ntx * nty * ntz;
-  // balanced decomposition (RAMSES_AMD_MG_BALANCE=0: the (tile, z chunk) blocks above): the same number of planes for every
-  // one of (CUs) workgroups, a multiple of 8 (plane pairs of the fused restriction / prolongation stay together), at least
-  // 32; levels too small to give every CU that much keep more planes per block and fewer blocks.  Results do not depend on it
-  // (the partial sums of the norm are grouped differently: its last bits may).
-  int seg_planes = 0;
-  {
-    static int balance = -1, ncu = 0;
-    if (balance < 0) {
-      const char *ev = getenv("RAMSES_AMD_MG_BALANCE");
-      balance = ev ? atoi(ev) : MG_BALANCE_DEFAULT;
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-      if (ncu <= 0) ncu = 256;
-    }
-    const int wg_per_cu = (P == 2 && LY <= 16) ? (LY == 12 ? 3 : 2) : 1;
-    if (balance > 0) {
-      const long gtot = (long)ntx * nty * nz;
-      const long want = (long)ncu * wg_per_cu * (balance > 1 ? balance : 1);     // balance = k > 1: k blocks per CU slot
-      long seg = (gtot + want - 1) / want;
-      seg = (seg + 7) / 8 * 8;
-      if (seg < 32) seg = 32;
-      seg_planes = (int)seg;
-      blocks = (int)((gtot + seg - 1) / seg);
-    }
-  }
+  const int blocks = ntx * nty * ntz;
   if (resid && blocks > MG_MAX_PARTIALS) return hipErrorInvalidValue;
   const size_t lds = sizeof(double) * ((size_t)(2 * P + 4) * 64 * LY + (restr ? 2 * (size_t)IX * IY : 0) + (prol ? 3 * (size_t)(64 / 2 + 2) * (LY / 2 + 2) : 0));
   const double dx2 = dx * dx, oneoverdx2 = 1.0 / (dx * dx);
@@ -950,7 +902,7 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
                             (int)lds);                                                                        \
     if (e != hipSuccess) return e;                                                                            \
     hipLaunchKernelGGL(k, dim3(blocks), dim3(LL * 16), lds, s, phi_in, phi_out, rhs, res, partial, n, ng, dx2,    \
-                       oneoverdx2, zchunk, ntx, nty, (double *)nullptr, (double *)nullptr, (const double *)nullptr, ny, nz, seg_planes); \
+                       oneoverdx2, zchunk, ntx, nty, (double *)nullptr, (double *)nullptr, (const double *)nullptr, ny, nz); \
   } while (0)
   if (restr) {
     // (the residual itself is not stored: the restricted right-hand side is all the coarse level needs of it)
@@ -958,13 +910,13 @@ hipError_t mg_launch_smooth_fused(const double *phi_in, double *phi_out, const d
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(32 * 16), lds, s, phi_in, phi_out, rhs, res, partial, n, ng, dx2, oneoverdx2, zchunk, ntx, nty,
-                       rhs_c, u1_c, (const double *)nullptr, ny, nz, seg_planes);
+                       rhs_c, u1_c, (const double *)nullptr, ny, nz);
   } else if (prol) {
     auto k = mg_smooth_fused_kernel<2, false, 32, false, true>;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(32 * 16), lds, s, phi_in, phi_out, rhs, res, partial, n, ng, dx2, oneoverdx2, zchunk, ntx, nty,
-                       (double *)nullptr, (double *)nullptr, corr_c, ny, nz, seg_planes);
+                       (double *)nullptr, (double *)nullptr, corr_c, ny, nz);
   } else
   if (P == 4) { if (resid) SM_LAUNCH(4, true, 24); else SM_LAUNCH(4, false, 24); }
   else if (LY == 12) { if (resid) SM_LAUNCH(2, true, 12); else SM_LAUNCH(2, false, 12); }
