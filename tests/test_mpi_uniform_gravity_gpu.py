@@ -47,24 +47,25 @@ _REF = {}
 def _reference(nml, nproc, level):
     """the MPI reference on nproc ranks (once per rank count)"""
     from oracle import ramses_snapshot as rs
-    if nproc not in _REF:
+    if (level, nproc) not in _REF:
         work, out = _run(nml, REF_MPI, nproc, {"RAMSES_AMD": "0"})
         try:
-            _REF[nproc] = (rs.load_uniform_level(os.path.join(work, "output_00002"), level, with_grav=True), _mkb().solves(out))
+            _REF[(level, nproc)] = (rs.load_uniform_level(os.path.join(work, "output_00002"), level, with_grav=True), _mkb().solves(out))
         finally:
             shutil.rmtree(work, ignore_errors=True)
-    return _REF[nproc]
+    return _REF[(level, nproc)]
 
 
-@pytest.mark.parametrize("nproc,dist", [(2, "1"), (4, "1"), (8, "1"), (2, "0")])
-def test_uniform_self_gravity_under_mpi_equals_the_mpi_reference(gpu_lib, nproc, dist):
+@pytest.mark.parametrize("level,nproc,dist", [(7, 2, "1"), (7, 4, "1"), (7, 8, "1"), (7, 2, "0"), (8, 8, "1")])
+def test_uniform_self_gravity_under_mpi_equals_the_mpi_reference(gpu_lib, level, nproc, dist):
+    """level 7: 128^3 (one distributed level above the replicated ones on 8 ranks); level 8 on 8 ranks: BASELINE config C4
+    as stated (256^3) under MPI, 128^3 bricks, two distributed levels."""
     if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED_MPI)):
         pytest.skip("oracle/_ref/ramses3d_mpi[_patch] not built")
     if nproc > (os.cpu_count() or 1):
         pytest.skip("fewer cores than ranks")
     from oracle import ramses_snapshot as rs
     mkb = _mkb()
-    level = 7
     nml = mkb.c4_namelist(level=level).replace("ngridtot=", "ngridtot=%d !" % (3 * sum(8 ** l for l in range(level)) + 1000))
     ref, ref_solves = _reference(nml, nproc, level)
     work, out = _run(nml, PATCHED_MPI, nproc, {"RAMSES_AMD": "1", "RAMSES_AMD_MG_DIST": dist})
