@@ -21,6 +21,15 @@ pass() { # name counters...
   echo "== pmc $name: $* ==" >> $OUT/log.txt
   timeout 600 rocprofv3 --pmc "$@" --kernel-include-regex "${KREGEX:-godunov}" -f csv -d $OUT/$name -o c -- $BENCH --steps 2 --warmup 1 >> $OUT/log.txt 2>&1
 }
+if [ "${PASSES:-all}" = traffic ]; then
+  # only what roofline.traffic needs: FETCH_SIZE, WRITE_SIZE and the calibration pass
+  pass pmc_fetch FETCH_SIZE
+  pass pmc_write WRITE_SIZE
+  KREGEX=courant pass pmc_cal_fetch FETCH_SIZE
+  python $REPO/scripts/summarize_prof.py $OUT "$@" > $OUT/summary.txt 2>&1
+  cat $OUT/summary.txt
+  exit 0
+fi
 pass pmc_sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 pass pmc_sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS
 pass pmc_fetch FETCH_SIZE
