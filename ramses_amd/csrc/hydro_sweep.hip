@@ -107,18 +107,26 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   // the same L2) -------------------------------------------------------------
   int bid = blockIdx.x;
   {
-    const int nblk = gridDim.x;
+    // (SWEEP_OVERLAP: the shell blocks [0, nsig_blocks) keep the front of the launch -- they are dispatched first -- and
+    //  the interior blocks behind them; each range is spread over the XCDs on its own)
     const int nxcd = 8;
-    if (nblk % nxcd == 0) {
-      const int per = nblk / nxcd;
-      bid = (bid % nxcd) * per + bid / nxcd;
+    int lo = 0, cnt = gridDim.x;
+    if (A.nsig_blocks > 0) {
+      if (bid < A.nsig_blocks) cnt = A.nsig_blocks;
+      else { lo = A.nsig_blocks; cnt -= lo; }
     }
+    int r = bid - lo;
+    if (cnt % nxcd == 0) {
+      const int per = cnt / nxcd;
+      r = (r % nxcd) * per + r / nxcd;
+    }
+    bid = lo + r;
   }
-  // a launch covers up to 6 boxes of tiles x planes (one for a whole-brick or
-  // interior sweep, six for the boundary shell); find this block's box (uniform)
+  // a launch covers up to 7 boxes of tiles x planes (one for a whole-brick or
+  // interior sweep, six for the boundary shell, all seven for the overlapped sweep); find this block's box (uniform)
   int bi = 0;
 #pragma unroll
-  for (int i = 1; i < 6; i++)
+  for (int i = 1; i < 7; i++)
     if (i < A.nbox && bid >= A.box[i].first) bi = i;
   const SweepBox &B = A.box[bi];
   const int lb = bid - B.first;
@@ -389,6 +397,19 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
   else if (ty == 1) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_LOW>(A, smem_raw);
   else if (ty == BY - 2) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_HIGH>(A, smem_raw);
   else sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_FULL>(A, smem_raw);
+  if (A.nsig_blocks > 0 && (int)blockIdx.x < A.nsig_blocks) {
+    // a shell block of the overlapped sweep is done: every wave waits for its own stores to reach the L2, one thread
+    // writes this XCD's dirty lines back (device-scope release) and counts the block; the last one raises the flag
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (atomicAdd(A.sig_count, 1) == A.nsig_blocks - 1) {
+        __hip_atomic_store(A.sig_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(A.sig_flag, A.sig_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -439,18 +460,29 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
     nblocks += B.ntx * B.nty * ((zhi - zlo + B.zchunk - 1) / B.zchunk);
   };
   const int zc = A.zchunk;
+  A.nsig_blocks = 0;
   if (A.region == SWEEP_ALL || (A.region == SWEEP_SHELL && !splittable)) {
     add_box(0, NTX, 0, NTY, 0, A.nz, zc);
   } else if (A.region == SWEEP_INTERIOR) {
     if (splittable) add_box(1, NTX - 1, 1, NTY - 1, zb, A.nz - zb, zc);
-  } else if (A.region == SWEEP_SHELL) {
-    const int zs = 32;
-    add_box(0, NTX, 0, NTY, 0, zb, zs);                                 // z low slab
-    add_box(0, NTX, 0, NTY, A.nz - zb, A.nz, zs);                       // z high slab
-    add_box(0, NTX, 0, 1, zb, A.nz - zb, zs);                           // y low tile row
-    add_box(0, NTX, NTY - 1, NTY, zb, A.nz - zb, zs);                   // y high tile row
-    add_box(0, 1, 1, NTY - 1, zb, A.nz - zb, zs);                       // x low tile column
-    add_box(NTX - 1, NTX, 1, NTY - 1, zb, A.nz - zb, zs);               // x high tile column
+  } else if (A.region == SWEEP_SHELL || A.region == SWEEP_OVERLAP) {
+    // (one launch for everything: the tile rows and columns of the shell keep the full z chunk -- they only have to come
+    //  first, not to fill the chip on their own)
+    const int zs = A.region == SWEEP_OVERLAP ? zc : 32;
+    if (splittable) {
+      add_box(0, NTX, 0, NTY, 0, zb, zs);                                 // z low slab
+      add_box(0, NTX, 0, NTY, A.nz - zb, A.nz, zs);                       // z high slab
+      add_box(0, NTX, 0, 1, zb, A.nz - zb, zs);                           // y low tile row
+      add_box(0, NTX, NTY - 1, NTY, zb, A.nz - zb, zs);                   // y high tile row
+      add_box(0, 1, 1, NTY - 1, zb, A.nz - zb, zs);                       // x low tile column
+      add_box(NTX - 1, NTX, 1, NTY - 1, zb, A.nz - zb, zs);               // x high tile column
+    } else {
+      add_box(0, NTX, 0, NTY, 0, A.nz, zc);                               // (SWEEP_OVERLAP of a brick too small to split)
+    }
+    if (A.region == SWEEP_OVERLAP) {
+      A.nsig_blocks = nblocks;
+      if (splittable) add_box(1, NTX - 1, 1, NTY - 1, zb, A.nz - zb, zc);
+    }
   } else {
     return hipErrorInvalidValue;
   }
