@@ -125,20 +125,6 @@ int ramses_amd_godunov_brick_interior(const ramses_amd_hydro_params *p,
                                       const ramses_amd_brick *b, const double *d_uold,
                                       const double *d_grav, double *d_unew, double dx,
                                       double dt, void *stream);
-/* The same sweep in ONE launch whose shell blocks come first: the block of the shell that finishes last raises `sig`;
- * a stream that called ramses_amd_signal_wait(sig, stream) after this call continues once every cell within 2 of a
- * face holds its new value, while the interior blocks of the same launch still run -- the halo exchange of the new
- * state (make_virtual_fine_dp, amr/virtual_boundaries.f90:373-528; the reference runs it after the sweep,
- * amr/amr_step.f90:388-510) hides behind them without the 0.7 ms the shell + interior pair costs at 512^3.
- * ramses_amd_signal_check (after a synchronisation): non-zero if a wait gave up after ~4 s. */
-typedef struct ramses_amd_signal ramses_amd_signal;
-int ramses_amd_signal_create(ramses_amd_signal **out);
-int ramses_amd_signal_destroy(ramses_amd_signal *sig);
-int ramses_amd_signal_wait(ramses_amd_signal *sig, void *stream);
-int ramses_amd_signal_check(ramses_amd_signal *sig);
-int ramses_amd_godunov_brick_overlap(const ramses_amd_hydro_params *p, const ramses_amd_brick *b,
-                                     const double *d_uold, const double *d_grav, double *d_unew,
-                                     double dx, double dt, ramses_amd_signal *sig, void *stream);
 
 /* Tuning knobs of the sweep (tile rows per workgroup, planes per z-chunk);
  * 0 keeps the built-in default.  Results do not depend on them. */

@@ -53,11 +53,6 @@ SYMBOLS = [
     ("ramses_amd_godunov_brick", _i, [_PP, _PB, _vp, _vp, _vp, _d, _d, _vp]),
     ("ramses_amd_godunov_brick_shell", _i, [_PP, _PB, _vp, _vp, _vp, _d, _d, _vp]),
     ("ramses_amd_godunov_brick_interior", _i, [_PP, _PB, _vp, _vp, _vp, _d, _d, _vp]),
-    ("ramses_amd_godunov_brick_overlap", _i, [_PP, _PB, _vp, _vp, _vp, _d, _d, _vp, _vp]),
-    ("ramses_amd_signal_create", _i, [_vp]),
-    ("ramses_amd_signal_destroy", _i, [_vp]),
-    ("ramses_amd_signal_wait", _i, [_vp, _vp]),
-    ("ramses_amd_signal_check", _i, [_vp]),
     ("ramses_amd_godunov_tune", _i, [_i, _i]),
     ("ramses_amd_courant_init", _i, [_PP, _d, _vp, _vp]),
     ("ramses_amd_courant_brick", _i, [_PP, _PB, _vp, _vp, _d, _vp, _vp]),

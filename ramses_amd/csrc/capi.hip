@@ -149,20 +149,9 @@ static int check_ndim(const ramses_amd_hydro_params *p, const ramses_amd_brick *
   return 0;
 }
 
-// "shell done" signal of the overlapped sweep (ramses_amd_godunov_brick_overlap): a 64-bit flag in fine-grained memory
-// (visible across XCDs and to a polling kernel while the sweep still runs), the shell blocks' arrival counter, the value
-// of the last launch
-struct ramses_amd_signal {
-  unsigned long long *flag = nullptr;
-  int *count = nullptr;       // [0] arrival counter, [1] time-out mark of a wait
-  unsigned long long value = 0;
-  bool host_flag = false;
-};
-
 static int godunov_brick_region(const ramses_amd_hydro_params *p, const ramses_amd_brick *b,
                                 const double *d_uold, const double *d_grav, double *d_unew,
-                                double dx, double dt, int region_first, int region_last, void *stream,
-                                ramses_amd_signal *sig = nullptr) {
+                                double dx, double dt, int region_first, int region_last, void *stream) {
   if (!p) return fail(RAMSES_AMD_EINVAL, "params is NULL");
   if (int rc = check_brick(b)) return rc;
   if (!d_uold || !d_unew) return fail(RAMSES_AMD_EINVAL, "uold/unew device pointers are NULL");
@@ -195,11 +184,6 @@ static int godunov_brick_region(const ramses_amd_hydro_params *p, const ramses_a
   A.P = make_const(p);
   A.pow2 = is_pow2(dx) ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (sig) {
-    A.sig_count = sig->count;
-    A.sig_flag = sig->flag;
-    A.sig_value = ++sig->value;
-  }
   for (int region = region_first; region <= region_last; region++) {
     A.region = region;
     hipError_t e = p->fast_math
@@ -226,67 +210,6 @@ int ramses_amd_godunov_brick_interior(const ramses_amd_hydro_params *p, const ra
                                       const double *d_uold, const double *d_grav, double *d_unew,
                                       double dx, double dt, void *stream) {
   return godunov_brick_region(p, b, d_uold, d_grav, d_unew, dx, dt, SWEEP_INTERIOR, SWEEP_INTERIOR, stream);
-}
-
-// The whole brick in one launch, shell blocks first; the last shell block to finish raises sig (sweep_args.hpp, SWEEP_OVERLAP).
-// A stream that has called ramses_amd_signal_wait(sig, ...) AFTER this call goes on once every cell within 2 of a face holds
-// its new value -- while the interior blocks of the same launch are still running.
-int ramses_amd_godunov_brick_overlap(const ramses_amd_hydro_params *p, const ramses_amd_brick *b,
-                                     const double *d_uold, const double *d_grav, double *d_unew,
-                                     double dx, double dt, ramses_amd_signal *sig, void *stream) {
-  if (!sig || !sig->flag || !sig->count) return fail(RAMSES_AMD_EINVAL, "the overlapped sweep needs a signal (ramses_amd_signal_create)");
-  return godunov_brick_region(p, b, d_uold, d_grav, d_unew, dx, dt, SWEEP_OVERLAP, SWEEP_OVERLAP, stream, sig);
-}
-
-int ramses_amd_signal_create(ramses_amd_signal **out) {
-  if (!out) return fail(RAMSES_AMD_EINVAL, "NULL argument");
-  *out = nullptr;
-  ramses_amd_signal *S = new ramses_amd_signal();
-  void *f = nullptr;
-  if (hipExtMallocWithFlags(&f, sizeof(unsigned long long), hipDeviceMallocFinegrained) != hipSuccess) {
-    (void)hipGetLastError();
-    f = nullptr;
-    hipError_t e = hipHostMalloc(&f, sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped);
-    if (e != hipSuccess) { delete S; return hipfail(e, "signal flag allocation"); }
-    S->host_flag = true;
-  }
-  S->flag = reinterpret_cast<unsigned long long *>(f);
-  hipError_t e = hipMalloc(&S->count, 2 * sizeof(int));
-  if (e == hipSuccess) e = hipMemset(S->count, 0, 2 * sizeof(int));
-  if (e == hipSuccess) e = hipMemset(S->flag, 0, sizeof(unsigned long long));
-  if (e == hipSuccess) e = hipDeviceSynchronize();
-  if (e != hipSuccess) { ramses_amd_signal_destroy(S); return hipfail(e, "signal allocation"); }
-  *out = S;
-  return 0;
-}
-
-int ramses_amd_signal_destroy(ramses_amd_signal *S) {
-  if (!S) return 0;
-  if (S->flag) { if (S->host_flag) (void)hipHostFree(S->flag); else (void)hipFree(S->flag); }
-  if (S->count) (void)hipFree(S->count);
-  delete S;
-  return 0;
-}
-
-// Enqueue on `stream` a wait for the signal of the LAST overlapped sweep launched with sig (one polling lane).
-int ramses_amd_signal_wait(ramses_amd_signal *S, void *stream) {
-  if (!S || !S->flag) return fail(RAMSES_AMD_EINVAL, "NULL signal");
-  hipError_t e = launch_signal_wait(S->flag, S->value, S->count + 1, reinterpret_cast<hipStream_t>(stream));
-  if (e != hipSuccess) return hipfail(e, "signal wait launch");
-  return 0;
-}
-
-// after a synchronisation: did a wait give up (the sweep never raised the flag)?  Clears the mark.
-int ramses_amd_signal_check(ramses_amd_signal *S) {
-  if (!S || !S->count) return fail(RAMSES_AMD_EINVAL, "NULL signal");
-  int t = 0;
-  hipError_t e = hipMemcpy(&t, S->count + 1, sizeof(int), hipMemcpyDeviceToHost);
-  if (e != hipSuccess) return hipfail(e, "signal check");
-  if (t) {
-    (void)hipMemset(S->count, 0, 2 * sizeof(int));
-    return fail(RAMSES_AMD_EHIP, "a stream waited 4 s for the shell of an overlapped sweep that never signalled");
-  }
-  return 0;
 }
 
 int ramses_amd_courant_init(const ramses_amd_hydro_params *p, double dx, double *d_out, void *stream) {

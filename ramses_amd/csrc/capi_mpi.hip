@@ -315,10 +315,6 @@ struct MpiRes {
   hipStream_t s_comp = nullptr, s_comm = nullptr;
   hipEvent_t ev_shell = nullptr, ev_comm = nullptr;
   bool overlap = false;         // configured (RAMSES_AMD_OVERLAP != 0 and every emission oct lies in the boundary layer)
-  // round 3: the overlapped sweep is ONE launch with its shell blocks first; the communication stream polls the flag the last
-  // of them raises (ramses_amd_godunov_brick_overlap).  RAMSES_AMD_OVERLAP_SPLIT=1 (or no signal): shell launch, event, interior launch
-  ramses_amd_signal *sig = nullptr;
-  int sig_state = 0;            // 0 not tried, 1 in use, -1 split schedule
   int prefetched = 0;           // 0 no; 1 packed and staged to the host buffer; 2 exchanged and unpacked (RCCL)
 };
 MpiRes g_mr;
@@ -538,19 +534,9 @@ int ramses_amd_mpires_godunov(const ramses_amd_hydro_params *p, double dx, doubl
     M.new_ready = true;
     return 0;
   }
-  if (M.sig_state == 0) {
-    const char *e = getenv("RAMSES_AMD_OVERLAP_SPLIT");
-    M.sig_state = ((e && e[0] == '1') || ramses_amd_signal_create(&M.sig) != 0) ? -1 : 1;
-  }
-  if (M.sig_state == 1) {
-    // (the sweep is enqueued BEFORE the wait: if both streams share a hardware queue the polling lane must not sit in front of it)
-    if (int rc = ramses_amd_godunov_brick_overlap(p, &M.brick, M.bold.as<double>(), nullptr, M.bnew.as<double>(), dx, dt, M.sig, M.s_comp)) return rc;
-    if (int rc = ramses_amd_signal_wait(M.sig, M.s_comm)) return rc;
-  } else {
-    if (int rc = ramses_amd_godunov_brick_shell(p, &M.brick, M.bold.as<double>(), nullptr, M.bnew.as<double>(), dx, dt, M.s_comp)) return rc;
-    HCHK(hipEventRecord(M.ev_shell, M.s_comp), "event record");
-    HCHK(hipStreamWaitEvent(M.s_comm, M.ev_shell, 0), "stream wait");
-  }
+  if (int rc = ramses_amd_godunov_brick_shell(p, &M.brick, M.bold.as<double>(), nullptr, M.bnew.as<double>(), dx, dt, M.s_comp)) return rc;
+  HCHK(hipEventRecord(M.ev_shell, M.s_comp), "event record");
+  HCHK(hipStreamWaitEvent(M.s_comm, M.ev_shell, 0), "stream wait");
   {
     hipStream_t s = M.s_comm;
     const int nem = M.plan.em_first[M.ncpu];
@@ -571,8 +557,7 @@ int ramses_amd_mpires_godunov(const ramses_amd_hydro_params *p, double dx, doubl
     }
     HCHK(hipEventRecord(M.ev_comm, s), "event record");
   }
-  if (M.sig_state != 1)
-    if (int rc = ramses_amd_godunov_brick_interior(p, &M.brick, M.bold.as<double>(), nullptr, M.bnew.as<double>(), dx, dt, M.s_comp)) return rc;
+  if (int rc = ramses_amd_godunov_brick_interior(p, &M.brick, M.bold.as<double>(), nullptr, M.bnew.as<double>(), dx, dt, M.s_comp)) return rc;
   M.new_ready = true;
   return 0;
 }

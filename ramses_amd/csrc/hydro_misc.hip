@@ -362,21 +362,6 @@ hipError_t launch_add_gravity_source(double *unew, const double *uold, const dou
   return hipGetLastError();
 }
 
-// One lane waits until *flag >= value (the overlapped sweep's "shell done"): what the communication stream runs before it
-// packs the new state's halo.  Bounded: after a few seconds of polling it gives up and says so in *timed_out (the caller checks it at
-// its next synchronisation), so that a sweep that never raises the flag cannot hang the GPU.
-__global__ void signal_wait_kernel(const unsigned long long *flag, unsigned long long value, int *timed_out) {
-  for (long i = 0; i < 4000000L; i++) {
-    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= value) return;
-    __builtin_amdgcn_s_sleep(32);
-  }
-  *timed_out = 1;
-}
-hipError_t launch_signal_wait(const unsigned long long *flag, unsigned long long value, int *timed_out, hipStream_t s) {
-  hipLaunchKernelGGL(signal_wait_kernel, dim3(1), dim3(1), 0, s, flag, value, timed_out);
-  return hipGetLastError();
-}
-
 }  // namespace ramses_amd
 
 #include "warm.hpp"

@@ -105,31 +105,28 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   // ---- tile decode (XCD-aware: block b runs on XCD b%8; give each XCD a
   // contiguous run of tiles so the halo re-reads of neighbouring tiles hit
   // the same L2) -------------------------------------------------------------
-  int bid = blockIdx.x;
-  {
-    // (SWEEP_OVERLAP: the shell blocks [0, nsig_blocks) keep the front of the launch -- they are dispatched first -- and
-    //  the interior blocks behind them; each range is spread over the XCDs on its own)
-    const int nxcd = 8;
-    int lo = 0, cnt = gridDim.x;
-    if (A.nsig_blocks > 0) {
-      if (bid < A.nsig_blocks) cnt = A.nsig_blocks;
-      else { lo = A.nsig_blocks; cnt -= lo; }
-    }
-    int r = bid - lo;
-    if (cnt % nxcd == 0) {
-      const int per = cnt / nxcd;
-      r = (r % nxcd) * per + r / nxcd;
-    }
-    bid = lo + r;
-  }
-  // a launch covers up to 7 boxes of tiles x planes (one for a whole-brick or
-  // interior sweep, six for the boundary shell, all seven for the overlapped sweep); find this block's box (uniform)
+  // a launch covers up to 6 boxes of tiles x planes (one for a whole-brick or
+  // interior sweep, six for the boundary shell); find this block's box (uniform)
+  const int hb = blockIdx.x;
   int bi = 0;
 #pragma unroll
-  for (int i = 1; i < 7; i++)
-    if (i < A.nbox && bid >= A.box[i].first) bi = i;
+  for (int i = 1; i < 6; i++)
+    if (i < A.nbox && hb >= A.box[i].first) bi = i;
   const SweepBox &B = A.box[bi];
-  const int lb = bid - B.first;
+  // XCD-aware: block b runs on XCD b%8; inside its box a block is handed a tile so that each XCD works on a contiguous
+  // run of them (neighbouring tiles then re-read each other's halo rows and columns in ONE L2) -- box by box, because the
+  // blocks of different boxes cost very differently (the shell's 2-plane slabs next to its 32-plane columns) and every
+  // XCD has to get its share of each kind: one run over the whole shell launch left five XCDs with the slabs (shell
+  // 1.29 -> 1.04 ms at 512^3, the overlapped step 4.23 -> 4.00 ms)
+  int lb = hb - B.first;
+  {
+    const int nxcd = 8;
+    const int cnt = (bi + 1 < A.nbox ? A.box[bi + 1].first : (int)gridDim.x) - B.first;
+    if (cnt % nxcd == 0) {
+      const int per = cnt / nxcd;
+      lb = (lb % nxcd) * per + lb / nxcd;
+    }
+  }
   const int tix = B.tx0 + lb % B.ntx;
   const int tiy = B.ty0 + (lb / B.ntx) % B.nty;
   const int tiz = lb / (B.ntx * B.nty);
@@ -397,19 +394,6 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
   else if (ty == 1) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_LOW>(A, smem_raw);
   else if (ty == BY - 2) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_HIGH>(A, smem_raw);
   else sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_FULL>(A, smem_raw);
-  if (A.nsig_blocks > 0 && (int)blockIdx.x < A.nsig_blocks) {
-    // a shell block of the overlapped sweep is done: every wave waits for its own stores to reach the L2, one thread
-    // writes this XCD's dirty lines back (device-scope release) and counts the block; the last one raises the flag
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (threadIdx.x == 0 && threadIdx.y == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      if (atomicAdd(A.sig_count, 1) == A.nsig_blocks - 1) {
-        __hip_atomic_store(A.sig_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(A.sig_flag, A.sig_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -460,29 +444,19 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
     nblocks += B.ntx * B.nty * ((zhi - zlo + B.zchunk - 1) / B.zchunk);
   };
   const int zc = A.zchunk;
-  A.nsig_blocks = 0;
   if (A.region == SWEEP_ALL || (A.region == SWEEP_SHELL && !splittable)) {
     add_box(0, NTX, 0, NTY, 0, A.nz, zc);
   } else if (A.region == SWEEP_INTERIOR) {
     if (splittable) add_box(1, NTX - 1, 1, NTY - 1, zb, A.nz - zb, zc);
-  } else if (A.region == SWEEP_SHELL || A.region == SWEEP_OVERLAP) {
-    // (one launch for everything: the tile rows and columns of the shell keep the full z chunk -- they only have to come
-    //  first, not to fill the chip on their own)
-    const int zs = A.region == SWEEP_OVERLAP ? zc : 32;
-    if (splittable) {
-      add_box(0, NTX, 0, NTY, 0, zb, zs);                                 // z low slab
-      add_box(0, NTX, 0, NTY, A.nz - zb, A.nz, zs);                       // z high slab
-      add_box(0, NTX, 0, 1, zb, A.nz - zb, zs);                           // y low tile row
-      add_box(0, NTX, NTY - 1, NTY, zb, A.nz - zb, zs);                   // y high tile row
-      add_box(0, 1, 1, NTY - 1, zb, A.nz - zb, zs);                       // x low tile column
-      add_box(NTX - 1, NTX, 1, NTY - 1, zb, A.nz - zb, zs);               // x high tile column
-    } else {
-      add_box(0, NTX, 0, NTY, 0, A.nz, zc);                               // (SWEEP_OVERLAP of a brick too small to split)
-    }
-    if (A.region == SWEEP_OVERLAP) {
-      A.nsig_blocks = nblocks;
-      if (splittable) add_box(1, NTX - 1, 1, NTY - 1, zb, A.nz - zb, zc);
-    }
+  } else if (A.region == SWEEP_SHELL) {
+    const int zs = 32;
+    // (long blocks first, the 2-plane slabs fill the gaps at the end)
+    add_box(0, 1, 1, NTY - 1, zb, A.nz - zb, zs);                       // x low tile column
+    add_box(NTX - 1, NTX, 1, NTY - 1, zb, A.nz - zb, zs);               // x high tile column
+    add_box(0, NTX, 0, 1, zb, A.nz - zb, zs);                           // y low tile row
+    add_box(0, NTX, NTY - 1, NTY, zb, A.nz - zb, zs);                   // y high tile row
+    add_box(0, NTX, 0, NTY, 0, zb, zs);                                 // z low slab
+    add_box(0, NTX, 0, NTY, A.nz - zb, A.nz, zs);                       // z high slab
   } else {
     return hipErrorInvalidValue;
   }

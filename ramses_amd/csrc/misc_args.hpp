@@ -25,7 +25,6 @@ struct BoxCopyArgs {
 };
 
 hipError_t launch_courant_init(double *out, double dt_init, hipStream_t s);
-hipError_t launch_signal_wait(const unsigned long long *flag, unsigned long long value, int *timed_out, hipStream_t s);
 hipError_t launch_courant(const CourantArgs &A, bool grav, hipStream_t s);
 hipError_t launch_box_copy(const BoxCopyArgs &A, hipStream_t s);
 

@@ -5,11 +5,7 @@
 namespace ramses_amd {
 
 // what one sweep launch covers
-// SWEEP_OVERLAP: the whole brick in ONE launch whose shell blocks (the six SWEEP_SHELL boxes) come first and whose interior
-// blocks follow; the shell block that finishes last raises a flag (sig_*), on which another stream waits before it packs
-// and sends the new state's halo -- the exchange then runs behind the interior blocks of the same launch, and nothing is
-// computed, launched or drained twice (the SHELL + INTERIOR pair costs 0.7 ms more than one launch at 512^3)
-enum { SWEEP_ALL = 0, SWEEP_INTERIOR = 1, SWEEP_SHELL = 2, SWEEP_OVERLAP = 3 };
+enum { SWEEP_ALL = 0, SWEEP_INTERIOR = 1, SWEEP_SHELL = 2 };
 
 // a box of tiles x planes inside the brick, cut into z-chunks; `first` = index
 // of its first workgroup in the launch
@@ -27,13 +23,7 @@ struct SweepArgs {
   int zchunk;           // planes marched per workgroup
   int region;           // SWEEP_* (in); the launcher fills the boxes
   int nbox, nblocks;
-  SweepBox box[7];
-  // SWEEP_OVERLAP: blocks [0, nsig_blocks) are the shell; sig_count (device int, zero between launches) counts the ones that
-  // are done, the last of them stores sig_value to *sig_flag (fine-grained memory another stream polls)
-  int nsig_blocks = 0;
-  int *sig_count = nullptr;
-  unsigned long long *sig_flag = nullptr;
-  unsigned long long sig_value = 0;
+  SweepBox box[6];
   double dt, dx, rdx;   // rdx = 1/dx (exact when dx is a power of two)
   int pow2;             // dx is a power of two: (f*dt)/dx == (f*dt)*rdx bit for bit
   HydroConst P;

@@ -141,35 +141,6 @@ class HydroLevel:
         check(lib().ramses_amd_godunov_brick_interior(C.byref(self.params), C.byref(self.brick), _ptr(self.uold),
                                                       _ptr(self.f), _ptr(self.unew), self.dx, float(dt), _stream()))
 
-    def shell_signal(self):
-        """The "shell done" signal of godunov_fine_overlap (created on first use)."""
-        if getattr(self, "_sig", None) is None:
-            sig = C.c_void_p()
-            check(lib().ramses_amd_signal_create(C.byref(sig)))
-            self._sig = sig
-        return self._sig
-
-    def godunov_fine_overlap(self, dt=None):
-        """godunov_fine in ONE launch whose shell blocks come first; shell_signal() is raised when every cell within 2
-        of a face holds its new value (wait_shell(stream) makes another stream wait for that), the interior blocks of
-        the same launch go on.  Same unew as godunov_fine bit for bit."""
-        dt = self.dtnew if dt is None else dt
-        check(lib().ramses_amd_godunov_brick_overlap(C.byref(self.params), C.byref(self.brick), _ptr(self.uold), _ptr(self.f),
-                                                     _ptr(self.unew), self.dx, float(dt), self.shell_signal(), _stream()))
-
-    def wait_shell(self, stream):
-        """Make `stream` (a torch.cuda.Stream) wait for the shell of the last godunov_fine_overlap."""
-        check(lib().ramses_amd_signal_wait(self.shell_signal(), C.c_void_p(stream.cuda_stream)))
-
-    def __del__(self):
-        sig = getattr(self, "_sig", None)
-        if sig is not None:
-            try:
-                lib().ramses_amd_signal_destroy(sig)
-            except Exception:       # noqa: BLE001  (interpreter shutdown)
-                pass
-            self._sig = None
-
     def set_uold(self):
         """uold = unew (hydro/godunov_fine.f90:193-197): a buffer swap on the device."""
         self.uold, self.unew = self.unew, self.uold

@@ -204,39 +204,29 @@ class BrickDecomposition:
         if lev.f is not None:
             ex(lev, lev.f, 3)
 
-    def step_overlapped(self, lev, dt, split=False):
+    def step_overlapped(self, lev, dt):
         """One hydro step with the halo exchange of the NEW state hidden behind the
         interior sweep (the reference runs them back to back, amr/amr_step.f90:388-510):
 
-            compute stream:  ONE sweep launch: shell blocks first | interior blocks ......... | swap
-            comm stream:          (waits for "shell done")        | pack, RCCL send/recv, unpack |
+            compute stream:  shell sweep | interior sweep ................ | swap
+            comm stream:                 | pack, RCCL send/recv, unpack    |
 
-        The shell blocks produce every cell within 2 of a brick face, i.e. all the
-        data the face slabs carry; the last of them raises a flag the communication stream
-        polls (HydroLevel.godunov_fine_overlap / wait_shell); the interior blocks write only
-        cells the exchange never touches, and all read the old state, so the result equals
-        godunov_fine -> set_uold -> make_virtual_fine_dp bit for bit.
-        split=True: round 2's schedule -- a shell launch, an event, an interior launch (0.7 ms more at 512^3)."""
+        The shell launches produce every cell within 2 of a brick face, i.e. all the
+        data the face slabs carry; the interior launch writes only cells the exchange
+        never touches, and both read the old state, so the result equals
+        godunov_fine -> set_uold -> make_virtual_fine_dp bit for bit."""
         if getattr(self, "_comm_stream", None) is None:
             self._comm_stream = torch.cuda.Stream(device=lev.uold.device)
         comp = torch.cuda.current_stream()
-        if split:
-            lev.godunov_fine_shell(dt)
-            shell_done = torch.cuda.Event()
-            shell_done.record(comp)
-        else:
-            # the sweep must not start before the previous step's exchange has left the buffers it writes
-            lev.godunov_fine_overlap(dt)
+        lev.godunov_fine_shell(dt)
+        shell_done = torch.cuda.Event()
+        shell_done.record(comp)
         with torch.cuda.stream(self._comm_stream):
-            if split:
-                self._comm_stream.wait_event(shell_done)
-            else:
-                lev.wait_shell(self._comm_stream)
+            self._comm_stream.wait_event(shell_done)
             self.exchange_direct(lev, lev.unew, lev.nvar)  # ghosts of the new state
             comm_done = torch.cuda.Event()
             comm_done.record(self._comm_stream)
-        if split:
-            lev.godunov_fine_interior(dt)
+        lev.godunov_fine_interior(dt)
         comp.wait_event(comm_done)
         lev.set_uold()
 

@@ -1,9 +1,8 @@
 #!/usr/bin/env python
 """What the shell / interior split of the dense sweep costs on one GPU: an n^3 brick with one ghost
 oct per side (the MPI-resident layout), fast and strict build: ms of the whole sweep, of the shell launch, of the interior
-launch, of the periodic self-fill standing in for the exchange, of the overlapped schedule of round 2 (shell launch -> {fill
-on a second stream || interior launch}) and of round 3's (ONE launch with the shell blocks first; the second stream waits for
-the "shell done" flag and fills behind the interior blocks).   python scripts/overlap_probe.py [n]"""
+launch, of the periodic self-fill standing in for the exchange, and of the overlapped schedule (shell -> {fill on a
+second stream || interior}).   python scripts/overlap_probe.py [n]"""
 import json
 import os
 import sys
@@ -56,18 +55,6 @@ def main():
             lev.godunov_fine_interior(dt)
             comp.wait_event(e2)
 
-        def overlapped_one_launch():
-            # round 3: ONE launch, shell blocks first; the side stream polls the "shell done" flag
-            comp = torch.cuda.current_stream()
-            lev.godunov_fine_overlap(dt)
-            with torch.cuda.stream(side):
-                lev.wait_shell(side)
-                lev.uold, lev.unew = lev.unew, lev.uold
-                lev.make_virtual_fine_dp()
-                lev.uold, lev.unew = lev.unew, lev.uold
-                e2 = torch.cuda.Event(); e2.record(side)
-            comp.wait_event(e2)
-
         def serial():
             lev.godunov_fine(dt)
             lev.uold, lev.unew = lev.unew, lev.uold
@@ -79,9 +66,7 @@ def main():
                "shell_ms": timed(lambda: lev.godunov_fine_shell(dt)),
                "interior_ms": timed(lambda: lev.godunov_fine_interior(dt)),
                "self_fill_ms": timed(lev.make_virtual_fine_dp),
-               "serial_step_ms": timed(serial), "overlapped_step_ms": timed(overlapped),
-               "one_launch_sweep_ms": timed(lambda: lev.godunov_fine_overlap(dt)),
-               "one_launch_overlapped_step_ms": timed(overlapped_one_launch)}
+               "serial_step_ms": timed(serial), "overlapped_step_ms": timed(overlapped)}
         print(json.dumps(out), flush=True)
         del lev
         torch.cuda.empty_cache()

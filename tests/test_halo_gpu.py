@@ -90,49 +90,9 @@ def test_shell_plus_interior_equals_full_sweep(gpu_lib, n):
     assert (outs[0] != -7.0).all()
 
 
-@pytest.mark.parametrize("n", [(200, 40, 24), (64, 16, 16), (130, 30, 12), (128, 128, 128)])
-def test_one_launch_overlapped_sweep_equals_full_sweep(gpu_lib, n):
-    """godunov_fine_overlap (shell blocks first in one launch, "shell done" flag raised by the last of them) writes the
-    same unew as godunov_fine; a second stream that waits for the flag sees every cell within 2 of a face."""
-    import torch
-    import ramses_amd
-    from ramses_amd.hydro import HydroLevel
-    from helpers import random_brick
-    u = random_brick(n[0], n[1], n[2], seed=n[1])
-    dx, dt = 1.0 / 64, 0.02 / 64
-    lev = HydroLevel(n[0], n[1], n[2], dx, params=ramses_amd.make_params(riemann="hllc", slope_type=2), ng=2)
-    lev.upload(u)
-    lev.make_virtual_fine_dp()
-    lev.godunov_fine(dt)
-    torch.cuda.synchronize()
-    want = lev.download(lev.unew)
-    side = torch.cuda.Stream()
-    g = 2
-    for rep in range(3):
-        lev.unew.fill_(-7.0)
-        torch.cuda.synchronize()
-        lev.godunov_fine_overlap(dt)
-        with torch.cuda.stream(side):
-            lev.wait_shell(side)
-            # what the exchange would pack: the two cell layers next to every face, copied while the interior still runs
-            faces = [lev.interior(lev.unew)[:, :g].clone(), lev.interior(lev.unew)[:, -g:].clone(),
-                     lev.interior(lev.unew)[:, :, :g].clone(), lev.interior(lev.unew)[:, :, -g:].clone(),
-                     lev.interior(lev.unew)[:, :, :, :g].clone(), lev.interior(lev.unew)[:, :, :, -g:].clone()]
-        torch.cuda.synchronize()
-        from ramses_amd._capi import check, lib
-        check(lib().ramses_amd_signal_check(lev.shell_signal()))
-        got = lev.download(lev.unew)
-        assert np.array_equal(got, want)
-        exp = [want[:, :g], want[:, -g:], want[:, :, :g], want[:, :, -g:], want[:, :, :, :g], want[:, :, :, -g:]]
-        for a, b in zip(faces, exp):
-            assert np.array_equal(a.cpu().numpy(), b)
-
-
-@pytest.mark.parametrize("split", [False, True])
-def test_overlapped_step_equals_plain_step(gpu_lib, split):
-    """step_overlapped (second stream; one launch + "shell done" flag, or split=True: shell launch, event, interior launch)
-    == godunov_fine; set_uold; make_virtual_fine_dp on a single-rank periodic decomposition (the exchange is the periodic
-    self-fill)."""
+def test_overlapped_step_equals_plain_step(gpu_lib):
+    """step_overlapped (second stream, events) == godunov_fine; set_uold; make_virtual_fine_dp
+    on a single-rank periodic decomposition (the exchange is the periodic self-fill)."""
     import torch
     import ramses_amd
     from ramses_amd.parallel import BrickDecomposition
@@ -148,7 +108,7 @@ def test_overlapped_step_equals_plain_step(gpu_lib, split):
         for _ in range(3):
             dt = lev.courant_fine()[0]
             if overlapped:
-                dec.step_overlapped(lev, dt, split=split)
+                dec.step_overlapped(lev, dt)
             else:
                 lev.godunov_fine(dt)
                 lev.set_uold()
