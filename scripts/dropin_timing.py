@@ -247,11 +247,17 @@ if __name__ == "__main__":
             last = {}
             for l, g in re.findall(r"Level\s+(\d+) has\s+(\d+) grids", out):
                 last[int(l)] = int(g)
-            print(json.dumps({"config": tag, "levels": [lmin, lmax], "steps": nstep, "wall_s": round(wall, 3),
-                              "octs_per_level": {k: v for k, v in last.items() if k >= lmin}, "timers_s": rows}), flush=True)
+            rec = {"config": tag, "levels": [lmin, lmax], "steps": nstep, "wall_s": round(wall, 3),
+                   "octs_per_level": {k: v for k, v in last.items() if k >= lmin}, "timers_s": rows}
+            if env.get("RAMSES_AMD_PROFILE"):
+                # the shims' own wall-clock table (ramses_amd_tic / ramses_amd_toc): what of the reference's "flag" timer is the shim
+                rec["shim_profile"] = [ln.strip() for ln in out.splitlines() if "hydro_flag" in ln or "ramses_amd profile" in ln][:12]
+            print(json.dumps(rec), flush=True)
 
         ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d")
         pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch")
+        if which == "prof":
+            run_c5("patched, state and tree resident on the GPU, RAMSES_AMD_PROFILE=1", pat, {"RAMSES_AMD": "1", "RAMSES_AMD_PROFILE": "1"})
         if which in ("all", "gpu"):
             run_c5("patched, state and tree resident on the GPU", pat, {"RAMSES_AMD": "1"})
             run_c5("patched, arrays staged around every godunov_fine (round 1 path)", pat, {"RAMSES_AMD": "1", "RAMSES_AMD_RESIDENT_AMR": "0"})
