@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round-3 GPU session J: balanced work decomposition of the fused smoother (RAMSES_AMD_MG_BALANCE: the same number of planes for
 # every one of (CUs) workgroups instead of (tile, z chunk) blocks in 2.8 rounds) -- same bits? faster?
+# (RAMSES_AMD_MG_BALANCE was an A/B switch of that session only: the balanced decomposition did not pay and was removed again,
+#  profiles/r03_vcycle_ab.txt)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 for b in 1; do

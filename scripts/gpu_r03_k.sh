@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round-3 GPU session K: XCD-aware block order of the fused smoother (RAMSES_AMD_MG_XCD=0/1) -- same bits? faster?
+# (RAMSES_AMD_MG_XCD was an A/B switch of that session only: no gain, removed again, profiles/r03_vcycle_ab.txt)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ( time timeout 500 python -m pytest tests/test_multigrid_gpu.py tests/test_multigrid_parallel_gpu.py -m gpu -q -x --timeout 300 ) > gpurun_out/pytest_k.txt 2>&1

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round-3 GPU session M: the overlapped sweep as ONE launch (shell blocks first, "shell done" flag, polling lane on the
 # communication stream): same bits? what does the schedule cost on one GPU?  MPI-resident runs with it.
+# (the one-launch overlapped sweep -- godunov_fine_overlap, ramses_amd_signal_* -- was measured in sessions M-O, was not faster than the
+#  shell + interior launches and was removed again: profiles/r03_overlap_probe.txt; what stayed is the XCD mapping box by box)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ( time timeout 600 python -m pytest tests/test_halo_gpu.py tests/test_godunov_gpu.py -m gpu -q -x --timeout 300 ) > gpurun_out/pytest_m1.txt 2>&1

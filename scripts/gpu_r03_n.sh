@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-3 GPU session N: the one-launch overlapped sweep without the per-block L2 write-back (the polling kernel's end does
 # it once): same bits? cost?
+# (see scripts/gpu_r03_m.sh: a record of a session whose subject was removed again; RAMSES_AMD_OVERLAP_FENCE existed in that session only)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ( time timeout 600 python -m pytest tests/test_halo_gpu.py -m gpu -q -x --timeout 300 ) > gpurun_out/pytest_n1.txt 2>&1

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-3 GPU session O: the one-launch overlapped sweep with the shell blocks spread round-robin over the XCDs (long
 # blocks first): same bits? cost of the schedule on one GPU?  MPI-resident runs with it.
+# (see scripts/gpu_r03_m.sh: a record of a session whose subject was removed again)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ( time timeout 600 python -m pytest tests/test_halo_gpu.py -m gpu -q -x --timeout 300 ) > gpurun_out/pytest_o1.txt 2>&1
