@@ -82,3 +82,41 @@ def test_uniform_self_gravity_under_mpi_equals_the_mpi_reference(gpu_lib, level,
     assert got["info"]["t"] == ref["info"]["t"]
     assert np.array_equal(got["grav"], ref["grav"]), np.abs(got["grav"] - ref["grav"]).max()     # phi, f
     assert np.array_equal(got["prim"], ref["prim"]), np.abs(got["prim"] - ref["prim"]).max()     # hydro state
+
+
+def test_amr_run_with_a_fully_refined_levelmin_under_mpi(gpu_lib):
+    """AMR + self-gravity on 2 ranks with levelmin = 7 (128^3, fully refined, two half boxes) and a refined patch at level 8:
+    multigrid_fine(levelmin) takes the distributed dense V-cycles, level 8 the multigrid of AMR levels (the reference's
+    driver, device operators, first guess and boundary values interpolated from the level-7 phi the dense solve left on
+    the host), the hydro state stays resident on the GPUs -- leaf cells, phi, f and the V-cycle counts of every level must
+    equal the MPI reference."""
+    if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED_MPI)):
+        pytest.skip("oracle/_ref/ramses3d_mpi[_patch] not built")
+    if (os.cpu_count() or 1) < 2:
+        pytest.skip("fewer cores than ranks")
+    import re
+    from oracle import ramses_snapshot as rs
+    nml = _mkb().amr_grav_namelist(lmin=7, lmax=8, nstep=2)
+
+    def leaves(work):
+        snap = rs.load_leaf_cells(os.path.join(work, "output_00002"), with_grav=True)
+        order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+        return snap["level"][order], snap["x"][order], snap["prim"][:, order], snap["grav"][:, order]
+
+    work, out = _run(nml, PATCHED_MPI, 2, {"RAMSES_AMD": "1"})
+    try:
+        assert "distributed over" in out, out[-2000:]
+        got = leaves(work)
+        sol_p = re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+)", out)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    work, out = _run(nml, REF_MPI, 2, {"RAMSES_AMD": "0"})
+    try:
+        ref = leaves(work)
+        sol_r = re.findall(r"==> Level=\s*(\d+) Step=\s*(\d+)", out)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    assert (got[0] == 8).any() and sol_p == sol_r, (sol_p, sol_r)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert np.array_equal(got[3], ref[3]), np.abs(got[3] - ref[3]).max()     # phi, f
+    assert np.array_equal(got[2], ref[2]), np.abs(got[2] - ref[2]).max()     # hydro state
