@@ -683,6 +683,14 @@ int ramses_amd_mgdist_force(ramses_amd_mgdist *ctx, double *d_f, void *stream);
  * refreshes the virtual octs with make_virtual_fine_dp like the reference, multigrid_fine_commons.f90:284-287);
  * safe_mode in/out = the reference's safe_mode(ilevel). */
 int ramses_amd_mgdist_oct_box(int ilevel, int ngrid, const int *igrid, const double *xg, int64_t ngridmax, int *lo, int *dims);
+/* host only (no device): the deep-halo plan ramses_amd_mgdist_create builds for one rank and a level whose bricks have
+ * dims[3] cells inside ng ghost layers -- 26 send / receive regions (org x,y,z + ext x,y,z in allocated coordinates) with
+ * their positions in the message buffers, and the messages (one per peer; the caller's own rank where the box wraps onto
+ * itself).  For the CPU tests of the multi-rank protocol. */
+int ramses_amd_mgdist_plan(const int *pgrid, int rank, const int *rank_of_brick, const int *dims, int ng,
+                           int *send_boxes, int64_t *send_offs, int *recv_boxes, int64_t *recv_offs,
+                           int *npeer, int *seg_peer, int64_t *seg_send_off, int64_t *seg_send_cnt,
+                           int64_t *seg_recv_off, int64_t *seg_recv_cnt, int64_t *total);
 int ramses_amd_mgdist_multigrid_f90(ramses_amd_mgdist *ctx, int ilevel, int ngrid, const int *igrid, const double *xg,
                                     int64_t ngridmax, int64_t ncoarse, const int *lo, const double *rho, double *phi,
                                     double rho_tot, double fourpi, double epsilon, int *safe_mode, int *iters, double *err);

@@ -118,14 +118,8 @@ struct ramses_amd_mgdist {
 
 namespace {
 
-int brick_rank(const ramses_amd_mgdist *M, int cx, int cy, int cz) {
-  const int px = M->pgrid[0], py = M->pgrid[1], pz = M->pgrid[2];
-  cx = ((cx % px) + px) % px; cy = ((cy % py) + py) % py; cz = ((cz % pz) + pz) % pz;
-  return M->rank_of_brick[cx + px * (cy + py * cz)];
-}
-
-int build_plan(ramses_amd_mgdist *M, Level &L) {
-  const int ng = NG;
+// host only: the regions and messages of one rank's brick of n[0] x n[1] x n[2] cells inside ng ghost layers
+int plan_regions(const int *pgrid, const int *coords, const int *rank_of_brick, const int *n, int ng, HaloPlan &P) {
   int offs[26][3], nof = 0;
   for (int oz = -1; oz <= 1; oz++)
     for (int oy = -1; oy <= 1; oy++)
@@ -135,7 +129,11 @@ int build_plan(ramses_amd_mgdist *M, Level &L) {
     for (int i = 0; i < 26; i++) if (offs[i][0] == ox && offs[i][1] == oy && offs[i][2] == oz) return i;
     return -1;
   };
-  auto peer = [&](const int *o) { return brick_rank(M, M->coords[0] + o[0], M->coords[1] + o[1], M->coords[2] + o[2]); };
+  auto peer = [&](const int *o) {
+    int c[3];
+    for (int d = 0; d < 3; d++) c[d] = (((coords[d] + o[d]) % pgrid[d]) + pgrid[d]) % pgrid[d];
+    return rank_of_brick[c[0] + pgrid[0] * (c[1] + pgrid[1] * c[2])];
+  };
   int order_s[26], order_r[26];
   for (int i = 0; i < 26; i++) order_s[i] = order_r[i] = i;
   std::sort(order_s, order_s + 26, [&](int a, int b) {
@@ -147,7 +145,7 @@ int build_plan(ramses_amd_mgdist *M, Level &L) {
     if (pa != pb) return pa < pb;
     return index_of(-offs[a][0], -offs[a][1], -offs[a][2]) < index_of(-offs[b][0], -offs[b][1], -offs[b][2]);
   });
-  HaloPlan &P = L.plan;
+  P.segs_s.clear(); P.segs_r.clear();
   for (int side = 0; side < 2; side++) {
     const int *order = side == 0 ? order_s : order_r;
     int *boxes = side == 0 ? P.boxes_s : P.boxes_r;
@@ -158,9 +156,9 @@ int build_plan(ramses_amd_mgdist *M, Level &L) {
       const int *o = offs[order[r]];
       int64_t size = 1;
       for (int d = 0; d < 3; d++) {
-        int org, ext = o[d] == 0 ? L.n[d] : ng;
-        if (side == 0) org = o[d] <= 0 ? ng : L.n[d];                         // interior cells next to side o
-        else org = o[d] < 0 ? 0 : (o[d] == 0 ? ng : ng + L.n[d]);            // ghost cells on side g
+        int org, ext = o[d] == 0 ? n[d] : ng;
+        if (side == 0) org = o[d] <= 0 ? ng : n[d];                           // interior cells next to side o
+        else org = o[d] < 0 ? 0 : (o[d] == 0 ? ng : ng + n[d]);              // ghost cells on side g
         boxes[6 * r + d] = org;
         boxes[6 * r + 3 + d] = ext;
         size *= ext;
@@ -177,6 +175,12 @@ int build_plan(ramses_amd_mgdist *M, Level &L) {
   for (size_t i = 0; i < P.segs_s.size(); i++)
     if (P.segs_s[i].peer != P.segs_r[i].peer || P.segs_s[i].cnt != P.segs_r[i].cnt)
       return failf(RAMSES_AMD_EINVAL, "halo plan: message sizes of peer %d differ", P.segs_s[i].peer);
+  return 0;
+}
+
+int build_plan(ramses_amd_mgdist *M, Level &L) {
+  HaloPlan &P = L.plan;
+  RCHK(plan_regions(M->pgrid, M->coords, M->rank_of_brick.data(), L.n, NG, P));
   HCHK(hipMalloc(&P.d_send, sizeof(double) * P.total), "hipMalloc");
   HCHK(hipMalloc(&P.d_recv, sizeof(double) * P.total), "hipMalloc");
   if (!M->use_rccl) {
@@ -536,6 +540,45 @@ struct DevArr {
   }
 };
 }  // namespace
+
+// The deep-halo plan of one rank, host only (no device): what ramses_amd_mgdist_create builds for a level whose bricks have
+// dims[3] cells -- for the CPU tests of the multi-rank protocol.  send_boxes / recv_boxes: 26 x (org x,y,z, ext x,y,z) in
+// allocated coordinates (ng ghost layers), send_offs / recv_offs: positions in the message buffers (doubles); the
+// messages: *npeer <= 26 peers, seg_peer[i] with seg_send_off/cnt[i] and seg_recv_off/cnt[i] (the caller's own rank appears
+// where the box wraps onto itself).  Returns the buffer length in *total.
+int ramses_amd_mgdist_plan(const int *pgrid, int rank, const int *rank_of_brick, const int *dims, int ng,
+                           int *send_boxes, int64_t *send_offs, int *recv_boxes, int64_t *recv_offs,
+                           int *npeer, int *seg_peer, int64_t *seg_send_off, int64_t *seg_send_cnt,
+                           int64_t *seg_recv_off, int64_t *seg_recv_cnt, int64_t *total) {
+  if (!pgrid || !dims || !send_boxes || !send_offs || !recv_boxes || !recv_offs || !npeer || !seg_peer || !seg_send_off ||
+      !seg_send_cnt || !seg_recv_off || !seg_recv_cnt || !total || ng < 1)
+    return failf(RAMSES_AMD_EINVAL, "bad argument");
+  int world = 1;
+  for (int d = 0; d < 3; d++) {
+    if (pgrid[d] < 1 || dims[d] < ng) return failf(RAMSES_AMD_EINVAL, "bad rank grid / brick");
+    world *= pgrid[d];
+  }
+  std::vector<int> rob(world);
+  int mine = -1;
+  for (int b = 0; b < world; b++) {
+    rob[b] = rank_of_brick ? rank_of_brick[b] : b;
+    if (rob[b] == rank) mine = b;
+  }
+  if (mine < 0) return failf(RAMSES_AMD_EINVAL, "rank %d owns no brick", rank);
+  const int coords[3] = {mine % pgrid[0], (mine / pgrid[0]) % pgrid[1], mine / (pgrid[0] * pgrid[1])};
+  HaloPlan P;
+  RCHK(plan_regions(pgrid, coords, rob.data(), dims, ng, P));
+  std::memcpy(send_boxes, P.boxes_s, sizeof(P.boxes_s)); std::memcpy(recv_boxes, P.boxes_r, sizeof(P.boxes_r));
+  std::memcpy(send_offs, P.offs_s, sizeof(P.offs_s)); std::memcpy(recv_offs, P.offs_r, sizeof(P.offs_r));
+  *npeer = (int)P.segs_s.size();
+  for (size_t i = 0; i < P.segs_s.size(); i++) {
+    seg_peer[i] = P.segs_s[i].peer;
+    seg_send_off[i] = P.segs_s[i].off; seg_send_cnt[i] = P.segs_s[i].cnt;
+    seg_recv_off[i] = P.segs_r[i].off; seg_recv_cnt[i] = P.segs_r[i].cnt;
+  }
+  *total = P.total;
+  return 0;
+}
 
 // The box the rank's octs of the level fill: lo[3] (first cell) and dims[3] (cells), host only.  RAMSES_AMD_EUNSUPPORTED
 // when they do not fill a box (the caller then keeps the multigrid of AMR levels).
