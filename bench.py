@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--vcycle-level", type=int, default=9,
                     help="multigrid V-cycle measurement: 2^level cells per direction per GPU (0 = skip)")
     ap.add_argument("--spinup-ms", type=int, default=150,
-                    help="keep the sweep kernel busy on a scratch 256^3 level this long before the warm-up steps (clock ramp; 0 = none)")
+                    help="keep the sweep kernel busy on a scratch level of the same size this long before the warm-up steps (ramp; 0 = none)")
     ap.add_argument("--amr-level", type=int, default=8,
                     help="tree-walking (AMR) sweep measurement on a fully refined synthetic 2^level^3 tree (0 = skip)")
     ap.add_argument("--mg-tune", type=int, default=-1,
@@ -511,26 +511,27 @@ def main():
             tune[mode] = exchange.transport.allreduce((time.perf_counter() - t0) / 4, "cuda", op="max")
         overlap = tune[True] < tune[False]
 
-    # Clock ramp: after an idle phase the first ~8 sweeps run up to 10 % slower (per-step kernel times of a cold run: 3.56,
-    # 3.48, 3.37, 3.28, 3.25, 3.23 ... ms, RAMSES_AMD_BENCH_STEPS=1; memory-bound fills beforehand do not change that, the
-    # ramp follows VALU load).  A run of the reference lasts hours, so the steady state is the honest number: the same
-    # sweep kernel is kept busy on a scratch 256^3 level for --spinup-ms first.  Not a step of the workload (its state and
+    # Ramp: the first ~8 sweeps of THIS kernel at THIS size run up to 10 % slower (per-step kernel times of a run that goes
+    # straight into its timed steps: 3.54, 3.44, 3.35, 3.29, 3.24, 3.22 ... ms, RAMSES_AMD_BENCH_STEPS=1), and keeping another
+    # kernel busy beforehand does not change that (the strict build on a 256^3 scratch level, round 2's spin-up, for 150, 600
+    # or 1500 ms: the same five slow steps, profiles/r03_spinup_ab.txt) -- the power management follows the load of the kernel
+    # that runs.  A run of the reference lasts hours, so the steady state is the honest number: the SAME sweep (same build,
+    # same brick size) is kept busy on scratch buffers for --spinup-ms first.  Not a step of the workload (its state and
     # buffers are untouched); W and K below are exactly the requested ones; reported in `config`.
     spin_sweeps = 0
     if args.spinup_ms > 0:
-        ns = min(256, n)
-        # (the strict build's kernel: same instruction mix, and the fast kernel's rocprof statistics stay those of the workload)
-        spin = HydroLevel(ns, ns, ns, 0.5 / ns, params=ramses_amd.make_params(courant_factor=0.8, fast_math=False), ng=0)
+        spin = HydroLevel(n, n, n, lev.dx, params=ramses_amd.make_params(courant_factor=0.8, fast_math=bool(args.fast)), ng=lev.ng)
         spin.uold[0].fill_(1.0)
         spin.uold[4].fill_(2.5)
         t_spin = time.perf_counter()
         while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
             for _ in range(8):
-                spin.godunov_fine(1e-6)
+                spin.godunov_fine(1e-6 * lev.dx)
                 spin.set_uold()
             spin_sweeps += 8
             torch.cuda.synchronize()
         del spin
+        torch.cuda.empty_cache()
 
     for _ in range(args.warmup):
         step(overlap)
@@ -585,7 +586,8 @@ def main():
                        "arithmetic": "fast = the patched program's default (explicit FMAs, rcp/rsq + Newton; rel-Linf of the REFERENCE PROGRAM "
                                      "<= 4e-15 at 256^3 over 100 steps and at 128^3 over 120 steps, bound 1e-12: tests/test_fast_certificate_gpu.py; "
                                      "RAMSES_AMD_STRICT=1 selects the bit-identical build)" if args.fast else "strict (bit-identical to the reference)",
-                       "spinup": "%d untimed sweeps of a scratch 256^3 level before the warm-up steps (clock ramp, %d ms)" % (spin_sweeps, args.spinup_ms),
+                       "spinup": "%d untimed sweeps of the same kernel on a scratch level of the same size before the warm-up steps (%d ms; the first ~8 "
+                                 "sweeps of a kernel run up to 10 %% slower whatever ran before: profiles/r03_spinup_ab.txt)" % (spin_sweeps, args.spinup_ms),
                        "ranks": census,
                        "halo": "none (single rank, in-kernel periodic wrap)" if world == 1 else
                                ("RCCL send/recv (torch.distributed)" if transport_note is None else transport_note) +
