@@ -82,3 +82,72 @@ def test_plan_rejects_a_rank_without_a_brick():
     args = [(I * 156)(), (I64 * 26)(), (I * 156)(), (I64 * 26)(), C.byref(I()), (I * 26)(), (I64 * 26)(), (I64 * 26)(), (I64 * 26)(),
             (I64 * 26)(), C.byref(I64())]
     assert L.ramses_amd_mgdist_plan((I * 3)(2, 1, 1), 5, None, (I * 3)(8, 16, 16), 3, *args) != 0
+
+
+def _two_process_worker(rank, world, pgrid, port, ret):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ramses_amd import _capi
+        from ramses_amd.poisson_parallel import _Callbacks
+        from ramses_amd.transport import DistTransport
+        L = _capi.lib()
+        N, ng = 16, 5
+        dims = tuple(N // p for p in pgrid)
+        nx, ny, nz = dims
+        G = np.random.default_rng(4).normal(size=(N, N, N))
+        c = (rank % pgrid[0], (rank // pgrid[0]) % pgrid[1], rank // (pgrid[0] * pgrid[1]))
+        P = _plan(L, pgrid, rank, None, dims, ng)
+        u = np.full((nz + 2 * ng, ny + 2 * ng, nx + 2 * ng), np.nan)
+        u[ng:ng + nz, ng:ng + ny, ng:ng + nx] = G[c[2] * nz:(c[2] + 1) * nz, c[1] * ny:(c[1] + 1) * ny, c[0] * nx:(c[0] + 1) * nx]
+        send = np.full(P["total"], np.nan)
+        recv = np.full(P["total"], np.nan)
+        for (ox, oy, oz, ex, ey, ez), off in zip(P["send_boxes"], P["send_offs"]):
+            send[off:off + ex * ey * ez] = u[oz:oz + ez, oy:oy + ey, ox:ox + ex].reshape(-1)
+        # what csrc/mg_dist.hip does with a callback transport: self messages copied, the others through the callback
+        cb = _Callbacks(DistTransport(), "cpu")
+        DP = C.POINTER(C.c_double)
+        peers, so, sc, ro, rcn = [], [], [], [], []
+        for q, a, n, b, m in zip(P["peers"], P["send_off"], P["send_cnt"], P["recv_off"], P["recv_cnt"]):
+            if q == rank:
+                recv[b:b + m] = send[a:a + n]
+            else:
+                peers.append(q); so.append(a); sc.append(n); ro.append(b); rcn.append(m)
+        k = len(peers)
+        rc = cb.table.exchange(None, k, (C.c_int * k)(*peers), send.ctypes.data_as(DP), (C.c_int64 * k)(*so), (C.c_int64 * k)(*sc),
+                               recv.ctypes.data_as(DP), (C.c_int64 * k)(*ro), (C.c_int64 * k)(*rcn))
+        ok = rc == 0 and cb.error is None
+        for (ox, oy, oz, ex, ey, ez), off in zip(P["recv_boxes"], P["recv_offs"]):
+            u[oz:oz + ez, oy:oy + ey, ox:ox + ex] = recv[off:off + ex * ey * ez].reshape(ez, ey, ex)
+        idx = lambda cc, n: (np.arange(cc * n - ng, (cc + 1) * n + ng)) % N      # noqa: E731
+        ok = ok and np.array_equal(u, G[idx(c[2], nz)][:, idx(c[1], ny)][:, :, idx(c[0], nx)])
+        # the replicated level's all-gather and the norm's all-reduce
+        mine = np.full(6, float(rank + 1))
+        parts = np.zeros(6 * world)
+        ok = ok and cb.table.allgather(None, mine.ctypes.data_as(DP), 6, parts.ctypes.data_as(DP)) == 0
+        ok = ok and np.array_equal(parts.reshape(world, 6), np.arange(1, world + 1)[:, None] * np.ones(6))
+        val = C.c_double(float(rank + 1))
+        ok = ok and cb.table.allreduce_sum(None, C.byref(val)) == 0 and val.value == world * (world + 1) / 2
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pgrid", [(1, 1, 2), (2, 1, 1)])
+def test_callback_transport_between_two_processes(pgrid):
+    """World size 2 on CPU (gloo): the three callbacks of struct ramses_amd_mg_transport as ramses_amd/poisson_parallel.py
+    hands them to the library, driven the way csrc/mg_dist.hip drives them (one message per peer at the library's offsets
+    into its host buffers, the all-gather of a replicated level, the sum of a residual norm), on the plan the library built."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_two_process_worker, args=(2, pgrid, port, ret), nprocs=2, join=True)
+    assert len(ret) == 2 and all(ret.values()), dict(ret)
