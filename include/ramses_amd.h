@@ -683,6 +683,14 @@ int ramses_amd_mgdist_force(ramses_amd_mgdist *ctx, double *d_f, void *stream);
  * refreshes the virtual octs with make_virtual_fine_dp like the reference, multigrid_fine_commons.f90:284-287);
  * safe_mode in/out = the reference's safe_mode(ilevel). */
 int ramses_amd_mgdist_oct_box(int ilevel, int ngrid, const int *igrid, const double *xg, int64_t ngridmax, int *lo, int *dims);
+/* force_fine(ilevel,icount) (poisson/force_fine.f90:5-194) right after _multigrid_f90 of the same level: halo of phi +
+ * gradient_phi on the brick the solve left on the device, f(:,1:3) of the rank's own cells into the host cell vectors
+ * f (ncell,3); diag[0] = the local sum of fact*f**2 over the leaf cells in the reference's order (:162-172, batches of
+ * nvector octs), diag[1] = max |rho| (:174-176) for the caller's two MPI_ALLREDUCEs (:182-184).  The caller refreshes
+ * the virtual octs of f with make_virtual_fine_dp (:136-138). */
+int ramses_amd_mgdist_force_f90(ramses_amd_mgdist *ctx, int ilevel, int ngrid, const int *igrid, const double *xg,
+                                int64_t ngridmax, int64_t ncoarse, const int *lo, double *f, const double *rho, const int *son,
+                                int nvector, double fact, double *diag);
 /* host only (no device): the deep-halo plan ramses_amd_mgdist_create builds for one rank and a level whose bricks have
  * dims[3] cells inside ng ghost layers -- 26 send / receive regions (org x,y,z + ext x,y,z in allocated coordinates) with
  * their positions in the message buffers, and the messages (one per peer; the caller's own rank where the box wraps onto

@@ -161,6 +161,7 @@ SYMBOLS = [
     ("ramses_amd_mgdist_force", _i, [_vp, _vp, _vp]),
     ("ramses_amd_mgdist_oct_box", _i, [_i, _i, _vp, _vp, _i64, _vp, _vp]),
     ("ramses_amd_mgdist_plan", _i, [_vp, _i, _vp, _vp, _i] + [_vp] * 11),
+    ("ramses_amd_mgdist_force_f90", _i, [_vp, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i, _d, _vp]),
     ("ramses_amd_mgdist_multigrid_f90", _i, [_vp, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _vp]),
     ("ramses_amd_halo_plan", _i, [_i, _i, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     ("ramses_amd_mpires_setup", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),

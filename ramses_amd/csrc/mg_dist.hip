@@ -111,6 +111,7 @@ struct ramses_amd_mgdist {
   double *h_parts = nullptr, *h_mine = nullptr;
   double *work = nullptr, *norm = nullptr, *dense = nullptr;   // dense: one brick without ghosts (rhs staging)
   int safe_mode = 0;
+  bool phi_fresh = false;      // u[0] of the finest level holds the potential of the last solve (force_fine may use it)
   int64_t exchanges = 0;
   int last_iters = 0;
   double last_err = 0.0;
@@ -485,6 +486,7 @@ int ramses_amd_mgdist_solve(ramses_amd_mgdist *M, const double *d_rho, double rh
     if (err > last_err * SAFE_FACTOR && !safe) safe = 1;
   }
   M->safe_mode = safe;
+  M->phi_fresh = true;
   M->last_iters = it; M->last_err = err;
   if (iters_out) *iters_out = it;
   if (err_out) *err_out = err;
@@ -650,6 +652,63 @@ int ramses_amd_mgdist_multigrid_f90(ramses_amd_mgdist *M, int ilevel, int ngrid,
   HCHK(launch_oct_copy(A, false, s), "scatter launch");
   HCHK(hipMemcpyAsync(phi, d_vec.p, sizeof(double) * ncell, hipMemcpyDeviceToHost, s), "D2H phi");
   HCHK(hipStreamSynchronize(s), "sync");
+  return 0;
+}
+
+// force_fine(ilevel,icount) of the reference on its own arrays, several ranks, right after ramses_amd_mgdist_multigrid_f90 of
+// the same level: the halo of phi and gradient_phi run on the brick the solve left on the device (poisson/force_fine.f90:
+// 113-127,199-324), f(:,1:3) of the rank's own cells is written into the host cell vectors, and the two local diagnostics of
+// :150-181 are returned -- diag[0] = sum over the leaf cells of fact*f**2 in the reference's order (batches of nvector octs,
+// octant by octant, direction by direction), diag[1] = max |rho| -- for the caller's MPI_ALLREDUCEs.  The caller refreshes
+// the virtual octs of f with its own make_virtual_fine_dp.
+int ramses_amd_mgdist_force_f90(ramses_amd_mgdist *M, int ilevel, int ngrid, const int *igrid, const double *xg,
+                                int64_t ngridmax, int64_t ncoarse, const int *lo, double *f, const double *rho, const int *son,
+                                int nvector, double fact, double *diag) {
+  if (!M || !igrid || !xg || !lo || !f || !rho || !son || !diag || nvector < 1) return failf(RAMSES_AMD_EINVAL, "bad argument");
+  if (ilevel != M->level) return failf(RAMSES_AMD_EINVAL, "context built for level %d, called for level %d", M->level, ilevel);
+  if (!M->phi_fresh) return failf(RAMSES_AMD_EINVAL, "force_fine: the context holds no potential (ramses_amd_mgdist_multigrid_f90 first)");
+  const int n = 1 << ilevel;
+  const long N = (long)M->dims[0] * M->dims[1] * M->dims[2];
+  if ((long)ngrid * 8 != N) return failf(RAMSES_AMD_EINVAL, "the rank holds %d octs, its brick %ld cells", ngrid, N);
+  const long ncell = ncoarse + 8 * ngridmax;
+  hipStream_t s = nullptr;
+  static DevArr d_f;
+  static std::vector<double> h_f;
+  HCHK(d_f.ensure(sizeof(double) * 3 * N), "hipMalloc");
+  h_f.resize(3 * (size_t)N);
+  RCHK(ramses_amd_mgdist_force(M, reinterpret_cast<double *>(d_f.p), s));
+  HCHK(hipMemcpyAsync(h_f.data(), d_f.p, sizeof(double) * 3 * N, hipMemcpyDeviceToHost, s), "D2H f");
+  HCHK(hipStreamSynchronize(s), "sync");
+  const long py = M->dims[0], pz = (long)M->dims[0] * M->dims[1];
+  for (int g = 0; g < ngrid; g++) {
+    int o[3];
+    if (!oct_cell_origin(xg, ngridmax, igrid[g], n, o)) return failf(RAMSES_AMD_EINVAL, "oct %d of level %d does not sit on the level lattice", igrid[g], ilevel);
+    for (int d = 0; d < 3; d++) {
+      o[d] -= lo[d];
+      if (o[d] < 0 || o[d] + 2 > M->dims[d]) return failf(RAMSES_AMD_EINVAL, "oct %d lies outside the rank's box", igrid[g]);
+    }
+    const long org = o[0] + py * o[1] + pz * o[2];
+    for (int ind = 0; ind < 8; ind++) {
+      const long icell = ncoarse + (long)ind * ngridmax + (igrid[g] - 1);
+      const long b = org + (ind & 1) + py * ((ind >> 1) & 1) + pz * ((ind >> 2) & 1);
+      for (int d = 0; d < 3; d++) f[(long)d * ncell + icell] = h_f[(size_t)d * N + b];
+    }
+  }
+  double epot = 0.0, rmax = 0.0;
+  for (int g0 = 0; g0 < ngrid; g0 += nvector) {
+    const int nb = std::min(nvector, ngrid - g0);
+    for (int ind = 0; ind < 8; ind++) {
+      const long skip = ncoarse + (long)ind * ngridmax;
+      for (int d = 0; d < 3; d++)
+        for (int i = 0; i < nb; i++) {
+          const long icell = skip + (igrid[g0 + i] - 1);
+          if (son[icell] == 0) { const double v = f[(long)d * ncell + icell]; epot = epot + fact * (v * v); }
+        }
+      for (int i = 0; i < nb; i++) rmax = std::max(rmax, std::fabs(rho[skip + (igrid[g0 + i] - 1)]));
+    }
+  }
+  diag[0] = epot;
+  diag[1] = rmax;
   return 0;
 }
 

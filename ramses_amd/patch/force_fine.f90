@@ -64,6 +64,16 @@ subroutine force_fine_amd(ilevel,icount)
      rho_max(ilevel)=diag(2)
      return
   end if
+  ! several ranks, right after the distributed dense multigrid of this level (patch/multigrid_fine_commons.f90): the
+  ! potential still sits on the rank's brick on the device, gradient_phi runs there
+  if(ramses_amd_enabled().and.ncpu>1.and.ramses_amd_mgdist_phi_level==ilevel.and.gravity_type==0.and.nboundary==0 &
+       & .and..not.sink.and.ndim==3)then
+     ramses_amd_mgdist_phi_level=0
+     if(verbose)write(*,111)ilevel
+     call ramses_amd_mgdist_force_fine(ilevel)
+     return
+  end if
+  ramses_amd_mgdist_phi_level=0
   if(.not.ramses_amd_enabled().or.gravity_type>0.or.ncpu>1.or.nboundary>0.or.sink.or.ndim/=3.or.ilevel<2 &
        & .or.nx_loc/=1.or.int(active(ilevel)%ngrid,8)*8_8/=(2_8**ilevel)**3*int(nx_loc,8)**3)then
      call force_fine_reference(ilevel,icount)

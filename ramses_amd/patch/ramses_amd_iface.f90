@@ -78,6 +78,19 @@ module ramses_amd_iface
        integer(c_int) :: rc
      end function ramses_amd_mgdist_multigrid_f90
 
+     function ramses_amd_mgdist_force_f90(ctx, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, lo, f, rho, son, nvec, fact, diag) &
+          & bind(C, name='ramses_amd_mgdist_force_f90') result(rc)
+       import :: c_int, c_int64_t, c_double, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: ilevel, ngrid, nvec
+       integer(c_int) :: igrid(*), lo(3), son(*)
+       real(c_double) :: xg(*), f(*), rho(*)
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       real(c_double), value :: fact
+       real(c_double) :: diag(2)
+       integer(c_int) :: rc
+     end function ramses_amd_mgdist_force_f90
+
      function ramses_amd_abi_check(sz_params, sz_brick) bind(C, name='ramses_amd_abi_check') result(rc)
        import :: c_size_t, c_int
        integer(c_size_t), value :: sz_params, sz_brick
@@ -850,6 +863,10 @@ module ramses_amd_iface
   integer, save :: ramses_amd_mgdist_pg(3) = 0
   integer, allocatable, save :: ramses_amd_mgdist_rob(:)
   logical, save :: ramses_amd_mgdist_said = .false.
+  ! the level whose potential the distributed solve has just left on the device (0: none), and the rank's box origin:
+  ! force_fine of that level computes the acceleration there (ramses_amd_mgdist_force_fine)
+  integer, save :: ramses_amd_mgdist_phi_level = 0
+  integer, save :: ramses_amd_mgdist_lo(3) = 0
   type(ramses_amd_mg_transport), save, target :: ramses_amd_mgdist_tr
 
 contains
@@ -2094,8 +2111,48 @@ contains
     if (rc /= 0) call ramses_amd_fatal('multigrid_fine (distributed dense multigrid)')
     safe_mode(ilevel) = (isafe /= 0)
     call make_virtual_fine_dp(phi(1), ilevel)
+    ramses_amd_mgdist_phi_level = ilevel
+    ramses_amd_mgdist_lo = lo
     ok = .true.
 #endif
   end subroutine ramses_amd_mgdist_multigrid
+
+  !---------------------------------------------------------------------------
+  ! force_fine(ilevel,icount) right after ramses_amd_mgdist_multigrid of the same level (several ranks, gravity_type = 0,
+  ! periodic, no sinks): halo of phi and gradient_phi on the rank's brick on the device, f(:,1:3) of the rank's cells
+  ! back into the host arrays; then, like the reference (poisson/force_fine.f90:135-138,182-188): the virtual octs of
+  ! f through make_virtual_fine_dp, the two diagnostics reduced over the ranks.
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_mgdist_force_fine(ilevel)
+    use amr_commons
+    use poisson_commons
+    use constants, only: twopi
+#ifndef WITHOUTMPI
+    use mpi_mod
+#endif
+    integer, intent(in) :: ilevel
+#ifndef WITHOUTMPI
+    integer :: rc, info, idim, nx_loc
+    real(dp) :: dx, scale, dx_loc, fourpi, fact
+    real(kind=8) :: diag(2), epot_all, rho_all
+    nx_loc = icoarse_max - icoarse_min + 1
+    dx = 0.5D0**ilevel
+    scale = boxlen/dble(nx_loc)
+    dx_loc = dx*scale
+    fourpi = 2*twopi
+    if (cosmo) fourpi = 1.5D0*omega_m*aexp
+    fact = -dx_loc**ndim/fourpi/2.0D0
+    rc = ramses_amd_mgdist_force_f90(ramses_amd_mgdist_ctx, ilevel, active(ilevel)%ngrid, ramses_amd_octs(ilevel), xg, &
+         & int(ngridmax, 8), int(ncoarse, 8), ramses_amd_mgdist_lo, f, rho, son, nvector, fact, diag)
+    if (rc /= 0) call ramses_amd_fatal('force_fine (distributed dense multigrid)')
+    do idim = 1, ndim
+       call make_virtual_fine_dp(f(1, idim), ilevel)
+    end do
+    call MPI_ALLREDUCE(diag(1), epot_all, 1, MPI_DOUBLE_PRECISION, MPI_SUM, MPI_COMM_WORLD, info)
+    call MPI_ALLREDUCE(diag(2), rho_all, 1, MPI_DOUBLE_PRECISION, MPI_MAX, MPI_COMM_WORLD, info)
+    epot_tot = epot_tot + epot_all
+    rho_max(ilevel) = rho_all
+#endif
+  end subroutine ramses_amd_mgdist_force_fine
 
 end module ramses_amd_iface
