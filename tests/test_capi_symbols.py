@@ -142,3 +142,19 @@ def test_mgdist_oct_box_finds_the_box_a_rank_fills(built_lib):
     assert L.ramses_amd_mgdist_create(7, (C.c_int * 3)(3, 1, 1), 0, None, None, C.byref(ctx)) != 0
     assert L.ramses_amd_mgdist_create(7, (C.c_int * 3)(4, 1, 1), 0, None, None, C.byref(ctx)) != 0
     assert b"every extent must be >= 64" in L.ramses_amd_last_error()
+
+
+def test_mgdist_fortran_entries_refuse_to_run_without_a_context(built_lib):
+    """ramses_amd_mgdist_multigrid_f90 / _force_f90 without a context (or with NULL arrays): an error code and a message,
+    never a crash or a silent return."""
+    from ramses_amd import _capi
+    L = _capi.lib()
+    buf = (C.c_double * 8)()
+    ints = (C.c_int * 8)()
+    it, err, safe = C.c_int(), C.c_double(), C.c_int()
+    rc = L.ramses_amd_mgdist_multigrid_f90(None, 7, 8, ints, buf, 100, 1, ints, buf, buf, 1.0, 1.0, 1e-4,
+                                           C.byref(safe), C.byref(it), C.byref(err))
+    assert rc != 0 and L.ramses_amd_last_error()
+    rc = L.ramses_amd_mgdist_force_f90(None, 7, 8, ints, buf, 100, 1, ints, buf, buf, ints, 32, 1.0, buf)
+    assert rc != 0 and L.ramses_amd_last_error()
+    assert L.ramses_amd_mgdist_destroy(None) == 0
