@@ -457,6 +457,14 @@ int ramses_amd_poisamr_levelmin_mg(void);
 int ramses_amd_poisamr_force(int ilevel, int ngrid, const int *igrid, int ngrid_c, const int *igrid_c, const double *phi,
                              const double *phi_old, const double *rho, double *f, double tfrac, int interp, int fresh,
                              double fact, double *diag);
+/* The same with several ranks: igrid_all = the rank's ngrid_own own octs of the level followed by its reception octs (ngrid_all in
+ * all), igrid_c_all likewise for the level above.  phi / rho of all of them are read from the host vectors (the virtual cells
+ * carry what the solver's last make_virtual_fine_dp left there), f is written on the own octs' cells -- the caller's
+ * make_virtual_fine_dp(f(1,idim),ilevel) follows (poisson/force_fine.f90:137-139) -- and diag holds the RANK's share of the two
+ * diagnostics, before the caller's MPI_ALLREDUCEs (:181-186). */
+int ramses_amd_poisamr_force_mpi(int ilevel, int ngrid_own, int ngrid_all, const int *igrid_all, int ngrid_c_all, const int *igrid_c_all,
+                                 const double *phi, const double *phi_old, const double *rho, double *f, double tfrac, int interp,
+                                 double fact, double *diag);
 /* create the HIP context and load the device code of every kernel now (one-time ~0.2 s, otherwise paid by the
  * first call of each kernel family inside the reference's timed loop) */
 int ramses_amd_warmup(void);
@@ -802,6 +810,17 @@ int ramses_amd_amrres_set_uold_pfix(const ramses_amd_hydro_params *p, int ngrid,
 int ramses_amd_amrres_xg(const double *xg);
 int ramses_amd_amrres_rho_fine(const ramses_amd_hydro_params *p, int ilevel, int nlevelmax, int levelmin, int nvector,
                                const int *first, const int *igrid_all, double boxlen_over_nx, double *rho, double *multipole4);
+/* The same with several ranks (one per GPU), one level at a time from nlevelmax down to ilevel; igrid_all = the rank's n_own own
+ * octs of the level followed by its reception octs (n_all in all).  cic_cell loops over the own octs only and deposits into own
+ * and virtual cells alike (pm/rho_fine.f90:896-1142); the reference's exchanges stay with the caller, on the device vectors
+ * through ramses_amd_amrres_halo_* (dir 6: make_virtual_fine_dp on the four multipoles, :814-817; dir 4 / 5:
+ * make_virtual_reverse_dp(rho) / make_virtual_fine_dp(rho), :58-59):
+ *   _multipole -> [dir 6] -> _deposit -> [dir 4] -> [dir 5] -> _finish (rho of the level's own + reception cells into the host
+ *   vector; multipole4 = the rank's four sequential sums when ilevel == levelmin, before the caller's MPI_ALLREDUCE, :176-183) */
+int ramses_amd_amrres_rho_mpi_multipole(const ramses_amd_hydro_params *p, int ilevel, int n_own, int n_all, const int *igrid_all,
+                                        double boxlen_over_nx);
+int ramses_amd_amrres_rho_mpi_deposit(int ilevel, int nvector, double boxlen_over_nx);
+int ramses_amd_amrres_rho_mpi_finish(int ilevel, int levelmin, int nvector, const int *igrid_all, double *rho, double *multipole4);
 int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double err_grad_d, double err_grad_p,
                                  double err_grad_u, double floor_d, double floor_p, double floor_u, int *cells, int *ncells);
 int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, double dx, double dt,

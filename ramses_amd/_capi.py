@@ -109,6 +109,7 @@ SYMBOLS = [
     ("ramses_amd_poisamr_multigrid", _i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i, _d, _i, _i, _i, _vp, _vp, _vp]),
     ("ramses_amd_poisamr_levelmin_mg", _i, []),
     ("ramses_amd_poisamr_force", _i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _d, _vp]),
+    ("ramses_amd_poisamr_force_mpi", _i, [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _i, _d, _vp]),
     ("ramses_amd_prof_add", _i, [C.c_char_p, _i, _d]),
     ("ramses_amd_warmup", _i, []),
     ("ramses_amd_host_register", _i, [_vp, _i64]),
@@ -199,6 +200,9 @@ SYMBOLS = [
     ("ramses_amd_amrres_set_uold_pfix", _i, [_PP, _i, _vp, _d, _d, _d, _d]),
     ("ramses_amd_amrres_xg", _i, [_vp]),
     ("ramses_amd_amrres_rho_fine", _i, [_PP, _i, _i, _i, _i, _vp, _vp, _d, _vp, _vp]),
+    ("ramses_amd_amrres_rho_mpi_multipole", _i, [_PP, _i, _i, _i, _vp, _d]),
+    ("ramses_amd_amrres_rho_mpi_deposit", _i, [_i, _i, _d]),
+    ("ramses_amd_amrres_rho_mpi_finish", _i, [_i, _i, _i, _vp, _vp, _vp]),
     ("ramses_amd_amrres_hydro_flag", _i, [_PP, _i, _vp, _d, _d, _d, _d, _d, _d, _vp, _vp]),
     ("ramses_amd_amrres_godunov", _i, [_PP, _i, _i, _vp, _d, _d, _i, _i, _i]),
     # AMR residency under MPI: the virtual-boundary exchanges on the resident cell vectors

@@ -457,6 +457,8 @@ struct AmrRes {
   Buf xg;                // xg(1:ngridmax,1:3) (rho_fine's deposit needs the oct centres); sent with the tree when gravity is on
   bool xg_valid = false;
   Buf mp, rho, posof, mpscratch, lists;   // rho_fine: multipoles (4, ncell), the deposit (ncell), oct -> list position, scan scratch
+  Buf hkeys, hvals;                       // rho_fine with several ranks: the own octs of the level by position
+  int rl_level = 0, rl_nown = 0, rl_nall = 0;   // the level ramses_amd_amrres_rho_mpi_multipole opened (its list is in `lists`)
   Buf f;                 // f(1:ncell,1:3), a copy of the host array refreshed after force_fine and after regrids
   bool grav = false;
   Buf divu, enew;        // pressure_fix: the reference's divu / enew work vectors (device only: scratch of one step)
@@ -803,6 +805,78 @@ int ramses_amd_amrres_rho_fine(const ramses_amd_hydro_params *p, int ilevel, int
   return 0;
 }
 
+// rho_fine's hydro deposit with several ranks, one level at a time from nlevelmax down (pm/rho_fine.f90:45-60); the caller does
+// the reference's exchanges between the steps (ramses_amd_amrres_halo_* with dir 6, 4, 5):
+//   _multipole(l)   multipole_fine(l) on the rank's own octs (igrid_all: n_own own octs followed by the reception octs, n_all)
+//   [dir 6]         make_virtual_fine_dp(unew(1,1:4),l): a split cell's son oct may belong to another rank (:814-817)
+//   _deposit(l)     cic_from_multipole(l): rho of own + reception cells from the own octs' pseudo-particles
+//   [dir 4, dir 5]  make_virtual_reverse_dp(rho,l), make_virtual_fine_dp(rho,l) (:58-59)
+//   _finish(l)      rho of the level's cells (own + reception) into the host vector; at levelmin the rank's four sequential
+//                   multipole sums (the caller's MPI_ALLREDUCE follows, :176-183)
+int ramses_amd_amrres_rho_mpi_multipole(const ramses_amd_hydro_params *p, int ilevel, int n_own, int n_all, const int *igrid_all,
+                                        double boxlen_over_nx) {
+  AmrRes &R = g_ar;
+  if (!R.valid) return failf(RAMSES_AMD_EINVAL, "no resident AMR state (ramses_amd_amrres_load)");
+  if (!p || (n_all > 0 && !igrid_all)) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  if (!R.xg_valid) return failf(RAMSES_AMD_EINVAL, "rho_fine: no oct centres on the device (ramses_amd_amrres_xg)");
+  if (ilevel < 2 || ilevel > 30 || n_own < 0 || n_all < n_own || n_all > R.ngridmax) return failf(RAMSES_AMD_EINVAL, "rho_fine: bad level / list");
+  if (R.ncoarse != 1) return failf(RAMSES_AMD_EUNSUPPORTED, "rho_fine on the device covers a periodic box of one coarse cell");
+  hipStream_t s = nullptr;
+  const size_t cb = sizeof(double) * (size_t)R.ncell;
+  if (R.mp.cap < 4 * cb) { HCHK(R.mp.ensure(4 * cb), "hipMalloc multipoles"); HCHK(hipMemsetAsync(R.mp.p, 0, 4 * cb, s), "memset"); }
+  if (R.rho.cap < cb) { HCHK(R.rho.ensure(cb), "hipMalloc rho"); HCHK(hipMemsetAsync(R.rho.p, 0, cb, s), "memset"); }
+  HCHK(R.lists.ensure(sizeof(int) * (size_t)(n_all > 0 ? n_all : 1)), "hipMalloc lists");
+  if (n_all > 0) HCHK(hipMemcpyAsync(R.lists.p, igrid_all, sizeof(int) * (size_t)n_all, hipMemcpyHostToDevice, s), "H2D lists");
+  R.rl_level = ilevel; R.rl_nown = n_own; R.rl_nall = n_all;
+  HCHK(launch_amr_multipole_level(R.uold.as<double>(), R.mp.as<double>(), R.xg.as<double>(), R.son.as<int>(), R.lists.as<int>(), n_own, R.ncoarse,
+                                  R.ngridmax, ilevel, boxlen_over_nx, p->smallr, s), "multipole_fine launch");
+  return 0;
+}
+int ramses_amd_amrres_rho_mpi_deposit(int ilevel, int nvector, double boxlen_over_nx) {
+  AmrRes &R = g_ar;
+  if (!R.valid || R.rl_level != ilevel) return failf(RAMSES_AMD_EINVAL, "rho_fine: level %d was not opened by ramses_amd_amrres_rho_mpi_multipole", ilevel);
+  if (nvector < 1) return failf(RAMSES_AMD_EINVAL, "rho_fine: bad nvector");
+  unsigned hcap = 1024;
+  while (hcap < 2u * (unsigned)R.rl_nown) hcap <<= 1;
+  HCHK(R.hkeys.ensure(sizeof(unsigned long long) * (size_t)hcap), "hipMalloc"); HCHK(R.hvals.ensure(sizeof(int) * (size_t)hcap), "hipMalloc");
+  HCHK(launch_amr_deposit_level(R.mp.as<double>(), R.rho.as<double>(), R.xg.as<double>(), R.lists.as<int>(), R.rl_nown, R.rl_nall, nvector, R.ncoarse,
+                                R.ngridmax, ilevel, boxlen_over_nx, R.hkeys.as<unsigned long long>(), R.hvals.as<int>(), hcap, nullptr), "cic_from_multipole launch");
+  return 0;
+}
+int ramses_amd_amrres_rho_mpi_finish(int ilevel, int levelmin, int nvector, const int *igrid_all, double *rho, double *multipole4) {
+  AmrRes &R = g_ar;
+  if (!R.valid || R.rl_level != ilevel) return failf(RAMSES_AMD_EINVAL, "rho_fine: level %d was not opened by ramses_amd_amrres_rho_mpi_multipole", ilevel);
+  if (!rho || !multipole4 || (R.rl_nall > 0 && !igrid_all)) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  hipStream_t s = nullptr;
+  const int n_own = R.rl_nown, n = R.rl_nall;
+  R.rl_level = 0;
+  if (ilevel == levelmin) {
+    for (int d = 0; d < 4; d++) multipole4[d] = 0.0;
+    if (n_own > 0) {
+      HCHK(R.mpscratch.ensure(multipole_scratch_bytes((long)n_own * 8)), "hipMalloc multipole scratch");
+      HCHK(launch_multipole_vec(R.mp.as<double>(), R.lists.as<int>(), n_own, nvector, R.ncell, R.ncoarse, R.ngridmax, R.red.as<double>(), R.mpscratch.p, s),
+           "multipole launch");
+      HCHK(hipMemcpyAsync(multipole4, R.red.p, sizeof(double) * 4, hipMemcpyDeviceToHost, s), "D2H multipole");
+    }
+  }
+  if (n > 0) {
+    const long tot = (long)n * 8;
+    HCHK(R.pack.ensure(sizeof(double) * (size_t)tot), "hipMalloc");
+    hipLaunchKernelGGL(lvl_pack_comp_kernel<true>, dim3(grid_for(tot)), dim3(256), 0, s, R.rho.as<double>(), R.pack.as<double>(), R.lists.as<int>(), n, 1,
+                       R.ncell, R.ncoarse, R.ngridmax);
+    HCHK(hipGetLastError(), "rho pack launch");
+    R.hpack.resize((size_t)tot);
+    HCHK(hipMemcpy(R.hpack.data(), R.pack.p, sizeof(double) * (size_t)tot, hipMemcpyDeviceToHost), "D2H rho");
+    for (int ind = 0; ind < 8; ind++) {
+      double *dst = rho + R.ncoarse + (size_t)ind * R.ngridmax - 1;
+      const double *src = R.hpack.data() + (size_t)ind * n;
+      for (int i = 0; i < n; i++) dst[igrid_all[i]] = src[i];
+    }
+  }
+  HCHK(hipStreamSynchronize(s), "sync");
+  return 0;
+}
+
 // the density uold(:,1) of one level's cells back into the host array (rho_fine's multipole_fine reads nothing else)
 int ramses_amd_amrres_sync_density(int ngrid, const int *igrid, double *uold) {
   AmrRes &R = g_ar;
@@ -943,7 +1017,8 @@ int comm_of(AmrRes &R, int ilevel, CommLevel *&L) {
   L = &R.comm[ilevel];
   return 0;
 }
-// dir 0: make_virtual_fine_dp on uold(:,1:nvar); 1: make_virtual_reverse_dp on unew(:,1:nvar); 2 / 3: the same on enew / divu
+// dir 0: make_virtual_fine_dp on uold(:,1:nvar); 1: make_virtual_reverse_dp on unew(:,1:nvar); 2 / 3: the same on enew / divu;
+// rho_fine with several ranks: 4 make_virtual_reverse_dp(rho), 5 make_virtual_fine_dp(rho), 6 make_virtual_fine_dp on the multipoles
 struct HaloSpec { double *vec; int ncomp; bool reverse; };
 int halo_spec(AmrRes &R, int dir, HaloSpec &S) {
   switch (dir) {
@@ -952,6 +1027,11 @@ int halo_spec(AmrRes &R, int dir, HaloSpec &S) {
     case 2: case 3:
       if (!R.pfix) return failf(RAMSES_AMD_EINVAL, "halo on enew/divu: pressure_fix is not enabled");
       S = {dir == 2 ? R.enew.as<double>() : R.divu.as<double>(), 1, true}; return 0;
+    case 4: case 5: case 6:
+      if (!R.rho.p || !R.mp.p) return failf(RAMSES_AMD_EINVAL, "halo on rho / the multipoles: rho_fine has not run on the device");
+      if (dir == 6) S = {R.mp.as<double>(), 4, false};
+      else S = {R.rho.as<double>(), 1, dir == 4};
+      return 0;
   }
   return failf(RAMSES_AMD_EINVAL, "halo: bad direction %d", dir);
 }

@@ -39,6 +39,16 @@ namespace SWEEP_NS {
 
 constexpr int BX = 64;   // lanes along x = one wavefront
 
+// SWEEP_ZREG (default 0 until measured): every slope type but the 27-point one needs plane c-1 and c+1 only in the
+// thread's OWN column, so those two values ride in registers and the LDS ring of primitive planes
+// shrinks from three slots to two (plane c for the x/y neighbours, plane c+1 being written); the +y
+// state / y flux slots exist for rows 1..BY-3 only.  3*NV*BY + 2*NV*BY -> 2*NV*BY + 2*NV*(BY-3) rows of
+// 512 B: 16-row tiles (16 waves per CU = 4 per SIMD, 12 of 16 rows updating cells) fit in 145 KB
+// where 12-row tiles took 150 KB.  SWEEP_ZREG=0 is the round-3 kernel (A/B: profiles/r04_ab_sweep.txt).
+#ifndef SWEEP_ZREG
+#define SWEEP_ZREG 0
+#endif
+
 // LDS plane of NV doubles per column: [n][ty][tx]; NV = rho, u, v, w, P + passive scalars
 template <int BY, int NV>
 struct Plane {
@@ -93,11 +103,25 @@ __device__ __forceinline__ void plane_store(double *var_base, unsigned plane_byt
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, x), r, off, plane_bytes, 0);
 }
 
+// LDS layout of a tile (see SWEEP_ZREG above)
+template <int ST, int BY, int NV>
+struct TileLds {
+  static constexpr bool ZREG = (SWEEP_ZREG != 0) && (ST != 3);
+  static constexpr int NQ = ZREG ? 2 : 3;          // slots of the primitive ring
+  static constexpr int BYM = ZREG ? BY - 3 : BY;   // rows of a +y state / y flux plane
+  static constexpr int MOFF = ZREG ? 1 : 0;        // its first row is tile row MOFF
+  static constexpr size_t bytes = NQ * sizeof(Plane<BY, NV>) + 2 * sizeof(Plane<BYM, NV>);
+};
+
 template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV, int ROLE>
 __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *smem_raw) {
   const bool DXPOW2 = A.pow2 != 0;   // uniform
-  Plane<BY, NV> *qring = reinterpret_cast<Plane<BY, NV> *>(smem_raw);  // [3] primitives of planes c-1, c, c+1
-  Plane<BY, NV> *mring = qring + 3;                                 // [2] +y traced state / y flux slots, by plane parity
+  using L = TileLds<ST, BY, NV>;
+  constexpr bool ZREG = L::ZREG;
+  constexpr int MOFF = L::MOFF;
+  using MPlane = Plane<L::BYM, NV>;
+  Plane<BY, NV> *qring = reinterpret_cast<Plane<BY, NV> *>(smem_raw);  // primitives of planes (c-1,) c, c+1
+  MPlane *mring = reinterpret_cast<MPlane *>(qring + L::NQ);           // [2] +y traced state / y flux slots, by plane parity
 
   const int tx = threadIdx.x, ty = threadIdx.y;
   const HydroConst &P = A.P;
@@ -191,8 +215,11 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   double upre[NV], gpre[3];       // prefetch: plane c+1 on entry of iteration c
   double rold = 0.0, sold[NV > 5 ? NV - 5 : 1];   // uold density / scalars of plane c-1 (NV>5 only)
 
-  // ring slots of planes c-1, c, c+1
-  int sa = 0, sb = 1, sc = 2;
+  // ring slots of planes c-1, c, c+1 (ZREG: planes c and c+1 in slots sb, sc; c-1 in registers)
+  int sa = 0, sb = ZREG ? 0 : 1, sc = ZREG ? 1 : 2;
+  double qzm[NV], qz0[NV];        // ZREG: this column's primitives of planes c-1 and c
+#pragma unroll
+  for (int n = 0; n < NV; n++) { qzm[n] = 0.0; qz0[n] = 0.0; }
 
   // prologue: primitives of planes z0-2 -> slot sa, z0-1 -> slot sb; c starts at z0-1
   {
@@ -200,11 +227,14 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     load_u(z0 - 2, u); load_g(z0 - 2, g);
     ctoprim_cell<NV, GRAV>(u, g, dtxhalf, P, q);
 #pragma unroll
-    for (int n = 0; n < NV; n++) qring[sa].v[n][ty][tx] = q[n];
+    for (int n = 0; n < NV; n++) {
+      if constexpr (ZREG) qzm[n] = q[n];
+      else qring[sa].v[n][ty][tx] = q[n];
+    }
     load_u(z0 - 1, u); load_g(z0 - 1, g);
     ctoprim_cell<NV, GRAV>(u, g, dtxhalf, P, q);
 #pragma unroll
-    for (int n = 0; n < NV; n++) qring[sb].v[n][ty][tx] = q[n];
+    for (int n = 0; n < NV; n++) { qring[sb].v[n][ty][tx] = q[n]; qz0[n] = q[n]; }
     load_u(z0, upre); load_g(z0, gpre);
 #pragma unroll
     for (int n = 0; n < NV; n++) { qmz[n] = 1.0; fzlo[n] = 0.0; }
@@ -239,8 +269,8 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   for (int n = 0; n < NV; n++) { partx[n] = 0.0; fyown[n] = 0.0; }
 
   for (int c = z0 - 1; c <= z1; c++) {
-    Plane<BY, NV> &M = mring[c & 1];
-    Plane<BY, NV> &Mprev = mring[(c & 1) ^ 1];
+    MPlane &M = mring[c & 1];
+    MPlane &Mprev = mring[(c & 1) ^ 1];
     // ---- phase A: plane c+1 arrives; trace plane c; x and z fluxes ------------------
     double qc[NV];
     ctoprim_cell<NV, GRAV>(upre, gpre, dtxhalf, P, qc);
@@ -276,21 +306,23 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
       } else if (ST == 4 || ST == 5 || ST == 6) {
         // the NDIM=1 slope types (embedded 1-D problems: ny = nz = 1, the transverse differences vanish)
 #pragma unroll
-        for (int n = 0; n < NV; n++) qb[n] = qs.v[n][ty][tx];
+        for (int n = 0; n < NV; n++) qb[n] = ZREG ? qz0[n] : qs.v[n][ty][tx];
         const double dc0 = qb[1] * A.dt / A.dx, dc1 = qb[2] * A.dt / A.dx, dc2 = qb[3] * A.dt / A.dx;
 #pragma unroll
         for (int n = 0; n < NV; n++) {
+          const double qlo = ZREG ? qzm[n] : qprev.v[n][ty][tx];
           dq[0][n] = slope1_1d<ST>(qs.v[n][ty][txm], qb[n], qs.v[n][ty][txp], dc0, n);
           dq[1][n] = slope1_1d<ST>(qs.v[n][tym][tx], qb[n], qs.v[n][typ][tx], dc1, n);
-          dq[2][n] = slope1_1d<ST>(qprev.v[n][ty][tx], qb[n], qc[n], dc2, n);
+          dq[2][n] = slope1_1d<ST>(qlo, qb[n], qc[n], dc2, n);
         }
       } else {
 #pragma unroll
         for (int n = 0; n < NV; n++) {
-          qb[n] = qs.v[n][ty][tx];
+          qb[n] = ZREG ? qz0[n] : qs.v[n][ty][tx];
+          const double qlo = ZREG ? qzm[n] : qprev.v[n][ty][tx];
           dq[0][n] = slope1<ST>(qs.v[n][ty][txm], qb[n], qs.v[n][ty][txp], P);
           dq[1][n] = slope1<ST>(qs.v[n][tym][tx], qb[n], qs.v[n][typ][tx], P);
-          dq[2][n] = slope1<ST>(qprev.v[n][ty][tx], qb[n], qc[n], P);
+          dq[2][n] = slope1<ST>(qlo, qb[n], qc[n], P);
         }
       }
       double qm[3][NV], qp[3][NV];
@@ -300,8 +332,11 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
         const double cc = ctoprim_sound(qb[0], qb[4], P);
         tracexyz_cell<NV>(qb, dq, cc, dtdx, dtdx, dtdx, P, qm, qp);
       }
+      // (row BY-2's +y state has no reader: the slots cover rows MOFF..)
+      if constexpr (ROLE != ROLE_HIGH) {
 #pragma unroll
-      for (int n = 0; n < NV; n++) M.v[n][ty][tx] = qm[1][n];
+        for (int n = 0; n < NV; n++) M.v[n][ty - MOFF][tx] = qm[1][n];
+      }
 #pragma unroll
       for (int n = 0; n < NV; n++) qpy[n] = qp[1][n];
       if constexpr (r_fxz) {
@@ -337,11 +372,11 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     if constexpr (ROLE == ROLE_FULL || ROLE == ROLE_HIGH) {
       double qL[NV];
 #pragma unroll
-      for (int n = 0; n < NV; n++) qL[n] = M.v[n][tym][tx];
+      for (int n = 0; n < NV; n++) qL[n] = M.v[n][tym - MOFF][tx];
       scaled_interface_flux<RS, NV, 1>(qL, qpy, P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fy);
       // the flux through this row's -y face is the +y face flux of row ty-1: into ITS slot
 #pragma unroll
-      for (int n = 0; n < NV; n++) M.v[n][tym][tx] = fy[n];
+      for (int n = 0; n < NV; n++) M.v[n][tym - MOFF][tx] = fy[n];
     }
     if constexpr (r_fxz) {
       // plane c-1: its x part and own -y flux were kept in registers, the +y face flux was left
@@ -351,7 +386,7 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
       double un[NV];
 #pragma unroll
       for (int n = 0; n < NV; n++) {
-        const double part = partx[n] + (fyown[n] - Mprev.v[n][ty][tx]);
+        const double part = partx[n] + (fyown[n] - Mprev.v[n][ty - MOFF][tx]);
         un[n] = part + dz[n];
       }
       if (NV > 5) {
@@ -378,7 +413,15 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
       }
     }
     // rotate the ring
-    const int t = sa; sa = sb; sb = sc; sc = t;
+    if constexpr (ZREG) {
+      const int t = sb; sb = sc; sc = t;
+      if constexpr (r_trace) {
+#pragma unroll
+        for (int n = 0; n < NV; n++) { qzm[n] = qz0[n]; qz0[n] = qc[n]; }
+      }
+    } else {
+      const int t = sa; sa = sb; sb = sc; sc = t;
+    }
   }
 }
 
@@ -401,7 +444,7 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
 // ---------------------------------------------------------------------------
 template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV>
 static hipError_t launch3(const SweepArgs &A, hipStream_t s) {
-  const size_t lds = 5 * sizeof(Plane<BY, NV>);
+  const size_t lds = TileLds<ST, BY, NV>::bytes;
   dim3 block(BX, BY);
   dim3 grid(A.nblocks);
   auto k = godunov_sweep_kernel<ST, RS, BY, GRAV, SCHEME, NV>;
@@ -474,6 +517,10 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
     if (by == 8) return launch2<ST, RS, 8, 0, 5>(A, grav, s);
     if constexpr (ST != 3 && RS != RIEMANN_EXACT) {
       if (by == 12) return launch2<ST, RS, 12, 0, 5>(A, grav, s);
+#if SWEEP_ZREG
+      if (by == 14) return launch2<ST, RS, 14, 0, 5>(A, grav, s);
+      if (by == 16) return launch2<ST, RS, 16, 0, 5>(A, grav, s);
+#endif
     }
     return hipErrorInvalidValue;
   }
@@ -483,10 +530,12 @@ template <int ST>
 static hipError_t launch0(SweepArgs &A, int rs, int by, int scheme, int nvar, bool grav, hipStream_t s) {
   switch (rs) {
     case RIEMANN_LLF: return launch1<ST, RIEMANN_LLF>(A, by, scheme, nvar, grav, s);
+#ifndef SWEEP_FLAGSHIP_ONLY   // (scripts/sweep_regs.sh, build_ab.py: the LLF + minmod instantiations only, a one-minute compile)
     case RIEMANN_HLLC: return launch1<ST, RIEMANN_HLLC>(A, by, scheme, nvar, grav, s);
     case RIEMANN_HLL: return launch1<ST, RIEMANN_HLL>(A, by, scheme, nvar, grav, s);
     case RIEMANN_ACOUSTIC: return launch1<ST, RIEMANN_ACOUSTIC>(A, by, scheme, nvar, grav, s);
     case RIEMANN_EXACT: return launch1<ST, RIEMANN_EXACT>(A, by, scheme, nvar, grav, s);
+#endif
   }
   return hipErrorInvalidValue;
 }
@@ -497,8 +546,9 @@ hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int b
   if ((unsigned long)A.pitch_z * 8ul >= (1ul << 31) || (unsigned long)A.pitch_var * 8ul >= (1ul << 32))
     return hipErrorInvalidValue;
   switch (slope_type) {
-    case 0: return launch0<0>(A, riemann, by, scheme, nvar, grav, s);
     case 1: return launch0<1>(A, riemann, by, scheme, nvar, grav, s);
+#ifndef SWEEP_FLAGSHIP_ONLY
+    case 0: return launch0<0>(A, riemann, by, scheme, nvar, grav, s);
     case 2: return launch0<2>(A, riemann, by, scheme, nvar, grav, s);
     case 3: return launch0<3>(A, riemann, by, scheme, nvar, grav, s);
     case 4: return launch0<4>(A, riemann, by, scheme, nvar, grav, s);
@@ -506,6 +556,7 @@ hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int b
     case 6: return launch0<6>(A, riemann, by, scheme, nvar, grav, s);
     case 7: return launch0<7>(A, riemann, by, scheme, nvar, grav, s);
     case 8: return launch0<8>(A, riemann, by, scheme, nvar, grav, s);
+#endif
   }
   return hipErrorInvalidValue;
 }

@@ -648,9 +648,27 @@ int ramses_amd_poisamr_multigrid(int ilevel, int ngrid, const int *igrid, int ng
 //   fresh = 1: ramses_amd_poisamr_multigrid has just solved this level -- phi, rho of the level and phi, phi_old of the
 //   level above are still on the device; otherwise they are read from the host vectors.  f = f(1:ncell,1:3) (host), written
 //   on the level's cells.
+// several ranks: igrid = the rank's ngrid_own own octs of the level followed by its reception octs (ngrid in all), igrid_c likewise
+// for the level above; phi / rho of all of them are read, f and the two diagnostics (the rank's own share, before the caller's
+// MPI_ALLREDUCEs, poisson/force_fine.f90:181-186) are computed on the own octs.
+static int poisamr_force_impl(int ilevel, int ngrid_own, int ngrid, const int *igrid, int ngrid_c, const int *igrid_c, const double *phi,
+                              const double *phi_old, const double *rho, double *f, double tfrac, int interp, int fresh, double fact,
+                              double *diag);
 int ramses_amd_poisamr_force(int ilevel, int ngrid, const int *igrid, int ngrid_c, const int *igrid_c, const double *phi,
                              const double *phi_old, const double *rho, double *f, double tfrac, int interp, int fresh, double fact,
                              double *diag) {
+  return poisamr_force_impl(ilevel, ngrid, ngrid, igrid, ngrid_c, igrid_c, phi, phi_old, rho, f, tfrac, interp, fresh, fact, diag);
+}
+int ramses_amd_poisamr_force_mpi(int ilevel, int ngrid_own, int ngrid_all, const int *igrid_all, int ngrid_c_all, const int *igrid_c_all,
+                                 const double *phi, const double *phi_old, const double *rho, double *f, double tfrac, int interp,
+                                 double fact, double *diag) {
+  if (ngrid_own < 0 || ngrid_own > ngrid_all) return failf(RAMSES_AMD_EINVAL, "poisamr_force_mpi: bad own / total oct counts");
+  if (ngrid_own == 0) { if (diag) { diag[0] = 0.0; diag[1] = 0.0; } return 0; }
+  return poisamr_force_impl(ilevel, ngrid_own, ngrid_all, igrid_all, ngrid_c_all, igrid_c_all, phi, phi_old, rho, f, tfrac, interp, 0, fact, diag);
+}
+static int poisamr_force_impl(int ilevel, int ngrid_own, int ngrid, const int *igrid, int ngrid_c, const int *igrid_c, const double *phi,
+                              const double *phi_old, const double *rho, double *f, double tfrac, int interp, int fresh, double fact,
+                              double *diag) {
   PoisAmr &P = g_pa;
   if (!P.tree_valid) return failf(RAMSES_AMD_EINVAL, "poisamr_force: no tree (ramses_amd_poisamr_tree)");
   if (!igrid || !phi || !phi_old || !rho || !f || !diag) return failf(RAMSES_AMD_EINVAL, "NULL argument");
@@ -659,6 +677,7 @@ int ramses_amd_poisamr_force(int ilevel, int ngrid, const int *igrid, int ngrid_
   hipStream_t s = nullptr;
   const long ncoarse = P.ncoarse, ngridmax = P.ngridmax;
   const long nf = 8L * ngrid, nc = interp ? 8L * ngrid_c : 0;
+  const long nfo = 8L * ngrid_own;     // the cells f is computed on
   const size_t vb = sizeof(double) * (size_t)P.ncell;
   HCHK(P.phi.ensure(vb), "hipMalloc phi"); HCHK(P.phi_old.ensure(vb), "hipMalloc phi_old"); HCHK(P.rho.ensure(vb), "hipMalloc rho");
   HCHK(P.f.ensure(3 * vb), "hipMalloc f");
@@ -666,7 +685,7 @@ int ramses_amd_poisamr_force(int ilevel, int ngrid, const int *igrid, int ngrid_
   HCHK(P.diag.ensure(sizeof(double) * (2 * 512 + 2)), "hipMalloc"); HCHK(P.pack.ensure(sizeof(double) * (size_t)(2 * nf + 2 * nc)), "hipMalloc pack");
   HCHK(P.stage.ensure(sizeof(double) * (size_t)(3 * nf + 2 * nc)), "hipHostMalloc");
   Level &F = P.lev[ilevel];
-  const bool have = fresh && P.have_level == ilevel && P.have_ngrid == ngrid && P.have_epoch == P.epoch && (!interp || P.have_above);
+  const bool have = fresh && ngrid_own == ngrid && P.have_level == ilevel && P.have_ngrid == ngrid && P.have_epoch == P.epoch && (!interp || P.have_above);
   double *hs = P.stage.as<double>();
   if (!have) {
     F.ngrid = ngrid;
@@ -697,27 +716,27 @@ int ramses_amd_poisamr_force(int ilevel, int ngrid, const int *igrid, int ngrid_
   }
   P.have_level = 0;
   ForceArgs A;
-  A.L = F.view(); A.L.ngrid = ngrid; A.T = P.tree();
+  A.L = F.view(); A.L.ngrid = ngrid_own; A.T = P.tree();
   A.phi = P.phi.as<double>(); A.phi_old = P.phi_old.as<double>();
   A.tfrac = tfrac; A.interp = interp ? 1 : 0;
   const double dx = std::ldexp(1.0, -ilevel);
   A.a = 0.50 * 4.0 / 3.0 / dx;
   A.b = 0.25 * 1.0 / 3.0 / dx;
   A.out = P.fpack.as<double>(); A.leaf = P.leaf.as<int>();
-  hipLaunchKernelGGL(force_kernel, dim3(grid_for(nf)), dim3(256), 0, s, A);
+  hipLaunchKernelGGL(force_kernel, dim3(grid_for(nfo)), dim3(256), 0, s, A);
   HCHK(hipGetLastError(), "force launch");
   // diagnostics over the level's cells (rho packed from the device vector)
-  hipLaunchKernelGGL(vec_gather_kernel, dim3(grid_for(nf)), dim3(256), 0, s, P.rho.as<double>(), P.pack.as<double>(), F.igrid.as<int>(), ngrid, ncoarse, ngridmax);
-  HCHK(launch_force_diag(P.fpack.as<double>(), P.pack.as<double>(), P.leaf.as<int>(), nf, fact, P.diag.as<double>() + 2, P.diag.as<double>(), s), "diag launch");
-  hipLaunchKernelGGL(vec3_scatter_kernel, dim3(grid_for(nf)), dim3(256), 0, s, P.f.as<double>(), P.fpack.as<double>(), F.igrid.as<int>(), ngrid, ncoarse, ngridmax, P.ncell);
-  HCHK(hipMemcpyAsync(hs, P.fpack.p, sizeof(double) * 3 * (size_t)nf, hipMemcpyDeviceToHost, s), "D2H f");
+  hipLaunchKernelGGL(vec_gather_kernel, dim3(grid_for(nfo)), dim3(256), 0, s, P.rho.as<double>(), P.pack.as<double>(), F.igrid.as<int>(), ngrid_own, ncoarse, ngridmax);
+  HCHK(launch_force_diag(P.fpack.as<double>(), P.pack.as<double>(), P.leaf.as<int>(), nfo, fact, P.diag.as<double>() + 2, P.diag.as<double>(), s), "diag launch");
+  hipLaunchKernelGGL(vec3_scatter_kernel, dim3(grid_for(nfo)), dim3(256), 0, s, P.f.as<double>(), P.fpack.as<double>(), F.igrid.as<int>(), ngrid_own, ncoarse, ngridmax, P.ncell);
+  HCHK(hipMemcpyAsync(hs, P.fpack.p, sizeof(double) * 3 * (size_t)nfo, hipMemcpyDeviceToHost, s), "D2H f");
   HCHK(hipMemcpyAsync(diag, P.diag.p, sizeof(double) * 2, hipMemcpyDeviceToHost, s), "D2H diag");
   HCHK(hipStreamSynchronize(s), "sync");
   for (int d = 0; d < 3; d++)
     for (int ind = 0; ind < 8; ind++) {
       double *dst = f + (size_t)d * P.ncell + ncoarse + (size_t)ind * ngridmax - 1;
-      const double *src = hs + (size_t)d * nf + (size_t)ind * ngrid;
-      for (int i = 0; i < ngrid; i++) dst[igrid[i]] = src[i];
+      const double *src = hs + (size_t)d * nfo + (size_t)ind * ngrid_own;
+      for (int i = 0; i < ngrid_own; i++) dst[igrid[i]] = src[i];
     }
   return 0;
 }

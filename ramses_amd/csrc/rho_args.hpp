@@ -32,4 +32,13 @@ hipError_t launch_amr_rho_level(const double *dens, double *mp, double *rho, con
                                 const int *father, const int *igrid, int *posof, int ngrid, int nvector, long ncoarse, long ngridmax,
                                 int ilevel, double boxlen_over_nx, double smallr, hipStream_t s);
 
+// the same with several ranks (own octs deposit into own and reception cells; the exchanges between the two steps and after the
+// second belong to the caller): step 1 multipole_fine on the own octs, step 2 the gather over own + reception target cells with the
+// own octs found by position (hkeys / hvals: hcap slots, a power of two >= 2 n_own)
+hipError_t launch_amr_multipole_level(const double *dens, double *mp, const double *xg, const int *son, const int *igrid, int n_own,
+                                      long ncoarse, long ngridmax, int ilevel, double boxlen_over_nx, double smallr, hipStream_t s);
+hipError_t launch_amr_deposit_level(double *mp, double *rho, const double *xg, const int *igrid, int n_own, int n_all, int nvector,
+                                    long ncoarse, long ngridmax, int ilevel, double boxlen_over_nx, unsigned long long *hkeys, int *hvals,
+                                    unsigned hcap, hipStream_t s);
+
 }  // namespace ramses_amd

@@ -189,6 +189,12 @@ struct AmrRhoArgs {
   int ngrid, nvector;
   long ncell, ncoarse, ngridmax;
   double dx, scale, vol_loc, smallr;
+  // several ranks (amr_deposit_hash_kernel): the targets are the first ntarget octs of igrid (the rank's own octs, which
+  // deposit, followed by its reception octs); own octs by integer position in an open-addressing table
+  int ntarget, level;
+  unsigned long long *hkeys;
+  int *hvals;
+  unsigned hmask;
 };
 
 __global__ __launch_bounds__(256) void amr_multipole_kernel(AmrRhoArgs A) {
@@ -235,6 +241,44 @@ __device__ __forceinline__ long amr_rho_nbor_cell(const AmrRhoArgs &A, long c, i
   return A.ncoarse + (long)(pos ^ (1 << axis)) * A.ngridmax + g2;
 }
 
+// what the source cell (oct g_s at position i_s of the list of depositing octs, octant bits sb) gives the cell at offset o
+// (target = source + o): the CIC weight at its centre of mass and the tag of that addition in the reference's loop nest
+// (batch of nvector octs, ind_son, CIC corner, oct in the batch); false: the target is not one of the source's 8 corners
+__device__ __forceinline__ bool amr_cic_from_source(const AmrRhoArgs &A, int g_s, int i_s, const int (&sb)[3], const int (&o)[3], long &key,
+                                                    double &val) {
+  const double dx = A.dx, scale = A.scale;
+  const int ind_son = sb[0] + 2 * sb[1] + 4 * sb[2];
+  const long cs = A.ncoarse + (long)ind_son * A.ngridmax + g_s - 1;
+  const double m0 = A.mp[cs];
+  double w[3];
+  int b[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const double xgs = A.xg[(long)d * A.ngridmax + g_s - 1];
+    double x = A.mp[(long)(1 + d) * A.ncell + cs] / m0;              // centre of mass
+    x = x / scale + 0.0;
+    x = x - (xgs - 3.0 * dx);
+    x = x / dx;
+    double dd = x + 0.5;
+    const int id = (int)dd;
+    dd = dd - id;
+    const double dg = 1.0 - dd;
+    const int ig = id - 1;
+    const int kt = 2 + sb[d] + o[d];                                   // block coordinate of the target cell
+    if (kt == ig) { b[d] = 0; w[d] = dg; }
+    else if (kt == id) { b[d] = 1; w[d] = dd; }
+    else return false;
+  }
+  const double vol = w[0] * w[1] * w[2];
+  const double vol2 = m0 * vol / A.vol_loc;
+  if (vol2 == 0.0) return false;                                       // + 0.0 leaves the (non-negative) sum unchanged
+  const int ind = b[0] + 2 * b[1] + 4 * b[2];
+  const long batch = i_s / A.nvector, j = i_s % A.nvector;
+  key = ((batch * 8 + ind_son) * 8 + ind) * A.nvector + j;
+  val = vol2;
+  return true;
+}
+
 constexpr int ADEP_THREADS = 128;
 __global__ __launch_bounds__(ADEP_THREADS) void amr_deposit_kernel(AmrRhoArgs A) {
   __shared__ long skey[27][ADEP_THREADS];
@@ -245,7 +289,6 @@ __global__ __launch_bounds__(ADEP_THREADS) void amr_deposit_kernel(AmrRhoArgs A)
   const int ind_t = (int)(t / A.ngrid), it = (int)(t % A.ngrid);
   const int g_t = A.igrid[it];
   const long F_t = A.father[g_t - 1];         // father cell of the target's oct
-  const double dx = A.dx, scale = A.scale;
   int cnt = 0;
   for (int oz = -1; oz <= 1; oz++)
     for (int oy = -1; oy <= 1; oy++)
@@ -270,37 +313,11 @@ __global__ __launch_bounds__(ADEP_THREADS) void amr_deposit_kernel(AmrRhoArgs A)
         if (g_s <= 0) continue;
         const int i_s = A.posof[g_s - 1];
         if (i_s < 0) continue;                 // not a source of this call's list
-        const int ind_son = sb[0] + 2 * sb[1] + 4 * sb[2];
-        const long cs = A.ncoarse + (long)ind_son * A.ngridmax + g_s - 1;
-        const double m0 = A.mp[cs];
-        double w[3];
-        int b[3];
-        bool hit = true;
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          const double xgs = A.xg[(long)d * A.ngridmax + g_s - 1];
-          double x = A.mp[(long)(1 + d) * A.ncell + cs] / m0;              // centre of mass
-          x = x / scale + 0.0;
-          x = x - (xgs - 3.0 * dx);
-          x = x / dx;
-          double dd = x + 0.5;
-          const int id = (int)dd;
-          dd = dd - id;
-          const double dg = 1.0 - dd;
-          const int ig = id - 1;
-          const int kt = 2 + sb[d] + o[d];                                   // block coordinate of the target cell
-          if (kt == ig) { b[d] = 0; w[d] = dg; }
-          else if (kt == id) { b[d] = 1; w[d] = dd; }
-          else hit = false;
-        }
-        if (!hit) continue;
-        const double vol = w[0] * w[1] * w[2];
-        const double vol2 = m0 * vol / A.vol_loc;
-        if (vol2 == 0.0) continue;                                           // + 0.0 leaves the (non-negative) sum unchanged
-        const int ind = b[0] + 2 * b[1] + 4 * b[2];
-        const long batch = i_s / A.nvector, j = i_s % A.nvector;
-        skey[cnt][threadIdx.x] = ((batch * 8 + ind_son) * 8 + ind) * A.nvector + j;
-        sval[cnt][threadIdx.x] = vol2;
+        long key;
+        double val;
+        if (!amr_cic_from_source(A, g_s, i_s, sb, o, key, val)) continue;
+        skey[cnt][threadIdx.x] = key;
+        sval[cnt][threadIdx.x] = val;
         cnt++;
       }
   double r = 0.0;
@@ -316,6 +333,139 @@ __global__ __launch_bounds__(ADEP_THREADS) void amr_deposit_kernel(AmrRhoArgs A)
     last = best;
   }
   A.rho[A.ncoarse + (long)ind_t * A.ngridmax + g_t - 1] = r;
+}
+
+// ---- several ranks ------------------------------------------------------------------------------------------------
+// cic_cell loops over the rank's OWN octs only and deposits into own and virtual (reception) cells alike; the reference then
+// returns the virtual cells' share to their owners (make_virtual_reverse_dp(rho), added peer by peer) and refreshes the virtual
+// copies (make_virtual_fine_dp(rho)), pm/rho_fine.f90:58-60.  The gather below therefore runs over own + reception target cells
+// and looks for the source cells among the own octs BY POSITION (integer oct coordinates from xg in a hash table): the tree
+// pointers of a virtual oct (nbor) need not be complete (amr/refine_utils.f90:684-700 insists on them for own octs only).
+__device__ __forceinline__ unsigned long long amr_rho_oct_key(int x, int y, int z) {
+  return (((unsigned long long)z << 42) | ((unsigned long long)y << 21) | (unsigned long long)x) + 1ull;    // never 0 (= empty)
+}
+__device__ __forceinline__ unsigned amr_rho_hash(unsigned long long k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+  return (unsigned)k;
+}
+// integer position of oct g on its level (nx = ny = nz = 1: centre = (2 i + 1) dx, an exact binary fraction)
+__device__ __forceinline__ void amr_rho_oct_pos(const AmrRhoArgs &A, int g, int (&p)[3]) {
+  const double half = 0.5 / A.dx;      // 2^(level-1), exact
+#pragma unroll
+  for (int d = 0; d < 3; d++) p[d] = (int)(A.xg[(long)d * A.ngridmax + g - 1] * half);
+}
+__global__ __launch_bounds__(256) void amr_rho_hash_build_kernel(AmrRhoArgs A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A.ngrid) return;
+  int p[3];
+  amr_rho_oct_pos(A, A.igrid[i], p);
+  const unsigned long long key = amr_rho_oct_key(p[0], p[1], p[2]);
+  unsigned slot = amr_rho_hash(key) & A.hmask;
+  for (;;) {
+    const unsigned long long prev = atomicCAS(A.hkeys + slot, 0ull, key);
+    if (prev == 0ull || prev == key) { A.hvals[slot] = i; return; }
+    slot = (slot + 1) & A.hmask;
+  }
+}
+__device__ __forceinline__ int amr_rho_hash_find(const AmrRhoArgs &A, int x, int y, int z) {
+  const unsigned long long key = amr_rho_oct_key(x, y, z);
+  unsigned slot = amr_rho_hash(key) & A.hmask;
+  for (;;) {
+    const unsigned long long k = A.hkeys[slot];
+    if (k == key) return A.hvals[slot];
+    if (k == 0ull) return -1;
+    slot = (slot + 1) & A.hmask;
+  }
+}
+__global__ __launch_bounds__(ADEP_THREADS) void amr_deposit_hash_kernel(AmrRhoArgs A) {
+  __shared__ long skey[27][ADEP_THREADS];
+  __shared__ double sval[27][ADEP_THREADS];
+  const long total = (long)A.ntarget * 8;
+  const long t = (long)blockIdx.x * ADEP_THREADS + threadIdx.x;
+  if (t >= total) return;                     // (no barrier below: each thread uses its own LDS column)
+  const int ind_t = (int)(t / A.ntarget), it = (int)(t % A.ntarget);
+  const int g_t = A.igrid[it];
+  int pt[3];
+  amr_rho_oct_pos(A, g_t, pt);
+  const int n = 1 << A.level;                 // cells per direction of the (periodic) box on this level
+  int cnt = 0;
+  for (int oz = -1; oz <= 1; oz++)
+    for (int oy = -1; oy <= 1; oy++)
+      for (int ox = -1; ox <= 1; ox++) {
+        const int o[3] = {ox, oy, oz};
+        int sb[3], so[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          int sc = 2 * pt[d] + ((ind_t >> d) & 1) - o[d];      // source cell = target cell - o
+          sc = sc < 0 ? sc + n : (sc >= n ? sc - n : sc);
+          sb[d] = sc & 1;
+          so[d] = sc >> 1;
+        }
+        const int i_s = amr_rho_hash_find(A, so[0], so[1], so[2]);
+        if (i_s < 0) continue;                 // no oct there, or not one of this rank's own
+        const int g_s = A.igrid[i_s];
+        long key;
+        double val;
+        if (!amr_cic_from_source(A, g_s, i_s, sb, o, key, val)) continue;
+        skey[cnt][threadIdx.x] = key;
+        sval[cnt][threadIdx.x] = val;
+        cnt++;
+      }
+  double r = 0.0;
+  long last = -1;
+  for (int k = 0; k < cnt; k++) {
+    long best = 0x7fffffffffffffffL;
+    double v = 0.0;
+    for (int c = 0; c < cnt; c++) {
+      const long key = skey[c][threadIdx.x];
+      if (key > last && key < best) { best = key; v = sval[c][threadIdx.x]; }
+    }
+    r = r + v;
+    last = best;
+  }
+  A.rho[A.ncoarse + (long)ind_t * A.ngridmax + g_t - 1] = r;
+}
+
+static AmrRhoArgs amr_rho_args(const double *dens, double *mp, double *rho, const double *xg, const int *son, const int *igrid, int ngrid,
+                               int nvector, long ncoarse, long ngridmax, int ilevel, double boxlen_over_nx, double smallr) {
+  AmrRhoArgs A;
+  A.dens = dens; A.mp = mp; A.rho = rho; A.xg = xg; A.son = son; A.nbor = nullptr; A.father = nullptr;
+  A.igrid = igrid; A.posof = nullptr; A.ngrid = ngrid; A.nvector = nvector;
+  A.ncoarse = ncoarse; A.ngridmax = ngridmax; A.ncell = ncoarse + 8 * ngridmax;
+  double dx = 1.0;
+  for (int l = 0; l < ilevel; l++) dx *= 0.5;
+  A.dx = dx; A.scale = boxlen_over_nx;
+  const double dx_loc = dx * A.scale;
+  A.vol_loc = dx_loc * dx_loc * dx_loc;
+  A.smallr = smallr;
+  A.ntarget = ngrid; A.level = ilevel; A.hkeys = nullptr; A.hvals = nullptr; A.hmask = 0;
+  return A;
+}
+// several ranks, step 1 of a level: multipole_fine(l) on the rank's own octs (the children's multipoles of level l+1, own or
+// received, are in mp); the caller then exchanges mp(:,1:4) of the level (make_virtual_fine_dp(unew(1,idim),l), :814-817)
+hipError_t launch_amr_multipole_level(const double *dens, double *mp, const double *xg, const int *son, const int *igrid, int n_own,
+                                      long ncoarse, long ngridmax, int ilevel, double boxlen_over_nx, double smallr, hipStream_t s) {
+  if (n_own <= 0) return hipSuccess;
+  AmrRhoArgs A = amr_rho_args(dens, mp, nullptr, xg, son, igrid, n_own, 1, ncoarse, ngridmax, ilevel, boxlen_over_nx, smallr);
+  long gm = ((long)n_own * 8 + 255) / 256;
+  if (gm > 16384) gm = 16384;
+  hipLaunchKernelGGL(amr_multipole_kernel, dim3((unsigned)gm), dim3(256), 0, s, A);
+  return hipGetLastError();
+}
+// step 2: cic_from_multipole(l) -- rho of the own AND reception cells (igrid: n_own own octs followed by the reception octs,
+// n_all in all) from the own octs' multipoles; hkeys / hvals: hcap slots (a power of two >= 2 n_own), hkeys zeroed here
+hipError_t launch_amr_deposit_level(double *mp, double *rho, const double *xg, const int *igrid, int n_own, int n_all, int nvector,
+                                    long ncoarse, long ngridmax, int ilevel, double boxlen_over_nx, unsigned long long *hkeys, int *hvals,
+                                    unsigned hcap, hipStream_t s) {
+  if (n_all <= 0) return hipSuccess;
+  AmrRhoArgs A = amr_rho_args(nullptr, mp, rho, xg, nullptr, igrid, n_own, nvector, ncoarse, ngridmax, ilevel, boxlen_over_nx, 0.0);
+  A.ntarget = n_all; A.hkeys = hkeys; A.hvals = hvals; A.hmask = hcap - 1;
+  hipError_t e = hipMemsetAsync(hkeys, 0, sizeof(unsigned long long) * (size_t)hcap, s);
+  if (e != hipSuccess) return e;
+  if (n_own > 0) hipLaunchKernelGGL(amr_rho_hash_build_kernel, dim3((n_own + 255) / 256), dim3(256), 0, s, A);
+  const long total = (long)n_all * 8;
+  hipLaunchKernelGGL(amr_deposit_hash_kernel, dim3((unsigned)((total + ADEP_THREADS - 1) / ADEP_THREADS)), dim3(ADEP_THREADS), 0, s, A);
+  return hipGetLastError();
 }
 
 __global__ void amr_rho_posof_kernel(const int *igrid, int ngrid, int *posof, int set) {

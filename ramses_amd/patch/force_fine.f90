@@ -28,6 +28,7 @@ subroutine force_fine_amd(ilevel,icount)
   ! particles; anything else is the reference's routine.
   !--------------------------------------------------------------------------
   integer::rc,nx_loc,has_son,fresh
+  integer(8)::tm
   real(dp)::dx,dx_loc,scale,fact,fourpi,tfrac
   real(kind=8),dimension(2)::diag
 
@@ -64,6 +65,24 @@ subroutine force_fine_amd(ilevel,icount)
      rho_max(ilevel)=diag(2)
      return
   end if
+#ifndef WITHOUTMPI
+  ! several ranks, AMR run resident on the GPUs, any level the distributed dense multigrid has not just solved: gradient_phi
+  ! (with interpol_phi at the level's edge) of the rank's own octs on its GPU -- phi of the own and the virtual octs of the
+  ! level and of the level above goes up from the host vectors, f of the own cells comes back; the halo of f and the two
+  ! all-reduces of the diagnostics stay the reference's (poisson/force_fine.f90:137-139,181-186).  RAMSES_AMD_FORCE_MPI=0:
+  ! the reference's host loops.
+  if(ramses_amd_enabled().and.ncpu>1.and.gravity_type==0.and.nboundary==0.and..not.sink.and.ndim==3.and.ilevel>=levelmin &
+       & .and.ilevel>=2.and.ncoarse==1.and.ramses_amd_mgdist_phi_level/=ilevel.and.ramses_amd_force_mpi_on())then
+     if(ramses_amd_amr_resident())then
+        if(verbose)write(*,111)ilevel
+        ramses_amd_mgdist_phi_level=0
+        call ramses_amd_tic(tm)
+        call ramses_amd_force_fine_mpi(ilevel,icount)
+        call ramses_amd_toc('force_fine (device, MPI)',ilevel,tm)
+        return
+     end if
+  end if
+#endif
   ! several ranks, right after the distributed dense multigrid of this level (patch/multigrid_fine_commons.f90): the
   ! potential still sits on the rank's brick on the device, gradient_phi runs there
   if(ramses_amd_enabled().and.ncpu>1.and.ramses_amd_mgdist_phi_level==ilevel.and.gravity_type==0.and.nboundary==0 &
@@ -110,6 +129,54 @@ subroutine force_fine_amd(ilevel,icount)
 111 format('   Entering force_fine (MI355X) for level ',I2)
 
 end subroutine force_fine_amd
+
+#ifndef WITHOUTMPI
+subroutine ramses_amd_force_fine_mpi(ilevel,icount)
+  use amr_commons
+  use pm_commons
+  use poisson_commons
+  use constants, only : twopi
+  use ramses_amd_iface
+  use mpi_mod
+  implicit none
+  integer,intent(in)::ilevel,icount
+  integer::rc,nx_loc,nl,nlc,idim,info
+  integer,allocatable,dimension(:)::list,listc
+  real(dp)::dx,dx_loc,scale,fact,fourpi,tfrac
+  real(kind=8),dimension(2)::diag
+  real(kind=8)::epot_loc,epot_all,rho_loc,rho_all
+  nx_loc=(icoarse_max-icoarse_min+1)
+  ! a regrid or a load balance since the tree went to the device: ramses_amd_tree_epoch has moved
+  rc=ramses_amd_poisamr_tree(ramses_amd_tree_epoch,int(ngridmax,8),int(ncoarse,8),son,nbor,father)
+  if(rc/=0)call ramses_amd_fatal('force_fine (MPI, tree)')
+  dx=0.5D0**ilevel
+  scale=boxlen/dble(nx_loc)
+  dx_loc=dx*scale
+  fourpi=2*twopi
+  if(cosmo)fourpi=1.5D0*omega_m*aexp
+  fact=-dx_loc**ndim/fourpi/2.0D0
+  if(icount/=1.and.icount/=2)then
+     write(*,*)'icount has bad value'
+     call clean_stop
+  end if
+  tfrac=0.0d0
+  if(dtold(ilevel-1)>0)tfrac=1d0*dtnew(ilevel)/dtold(ilevel-1)*(icount-1)
+  call ramses_amd_amr_level_octs(ilevel,nl,list)
+  call ramses_amd_amr_level_octs(ilevel-1,nlc,listc)
+  diag=0d0
+  rc=ramses_amd_poisamr_force_mpi(ilevel,active(ilevel)%ngrid,nl,list,nlc,listc,phi,phi_old,rho,f,tfrac,1,fact,diag)
+  if(rc/=0)call ramses_amd_fatal('force_fine (MPI, AMR level)')
+  deallocate(list,listc)
+  do idim=1,ndim
+     call make_virtual_fine_dp(f(1,idim),ilevel)
+  end do
+  epot_loc=diag(1); rho_loc=diag(2)
+  call MPI_ALLREDUCE(epot_loc,epot_all,1,MPI_DOUBLE_PRECISION,MPI_SUM,MPI_COMM_WORLD,info)
+  call MPI_ALLREDUCE(rho_loc ,rho_all ,1,MPI_DOUBLE_PRECISION,MPI_MAX,MPI_COMM_WORLD,info)
+  epot_tot=epot_tot+epot_all
+  rho_max(ilevel)=rho_all
+end subroutine ramses_amd_force_fine_mpi
+#endif
 
 subroutine force_fine(ilevel,icount)
   use amr_commons, only: numbtot

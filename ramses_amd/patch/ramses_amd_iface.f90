@@ -402,6 +402,15 @@ module ramses_amd_iface
        real(c_double), value :: tfrac, fact
        integer(c_int) :: rc
      end function ramses_amd_poisamr_force
+     function ramses_amd_poisamr_force_mpi(ilevel, ngrid_own, ngrid_all, igrid_all, ngrid_c_all, igrid_c_all, phi, phi_old, rho, f, &
+          & tfrac, interp, fact, diag) bind(C, name='ramses_amd_poisamr_force_mpi') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: ilevel, ngrid_own, ngrid_all, ngrid_c_all, interp
+       integer(c_int) :: igrid_all(*), igrid_c_all(*)
+       real(c_double) :: phi(*), phi_old(*), rho(*), f(*), diag(2)
+       real(c_double), value :: tfrac, fact
+       integer(c_int) :: rc
+     end function ramses_amd_poisamr_force_mpi
      function ramses_amd_prof_add(name, level, seconds) bind(C, name='ramses_amd_prof_add') result(rc)
        import :: c_int, c_double, c_char
        character(kind=c_char) :: name(*)
@@ -749,6 +758,30 @@ module ramses_amd_iface
        real(c_double) :: rho(*), mp4(4)
        integer(c_int) :: rc
      end function ramses_amd_amrres_rho_fine
+     function ramses_amd_amrres_rho_mpi_multipole(p, ilevel, n_own, n_all, igrid_all, boxlen_over_nx) &
+          & bind(C, name='ramses_amd_amrres_rho_mpi_multipole') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ilevel, n_own, n_all
+       integer(c_int) :: igrid_all(*)
+       real(c_double), value :: boxlen_over_nx
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_rho_mpi_multipole
+     function ramses_amd_amrres_rho_mpi_deposit(ilevel, nvector, boxlen_over_nx) &
+          & bind(C, name='ramses_amd_amrres_rho_mpi_deposit') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: ilevel, nvector
+       real(c_double), value :: boxlen_over_nx
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_rho_mpi_deposit
+     function ramses_amd_amrres_rho_mpi_finish(ilevel, levelmin, nvector, igrid_all, rho, mp4) &
+          & bind(C, name='ramses_amd_amrres_rho_mpi_finish') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: ilevel, levelmin, nvector
+       integer(c_int) :: igrid_all(*)
+       real(c_double) :: rho(*), mp4(4)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_rho_mpi_finish
      function ramses_amd_amrres_hydro_flag(p, ngrid, igrid, egd, egp, egu, fld, flp, flu, cells, ncells) &
           & bind(C, name='ramses_amd_amrres_hydro_flag') result(rc)
        import :: ramses_amd_hydro_params, c_int, c_double
@@ -1479,6 +1512,21 @@ contains
     end if
     ramses_amd_amr_config = ramses_amd_amr_ok
   end function ramses_amd_amr_config
+
+  ! RAMSES_AMD_FORCE_MPI=0: force_fine of AMR levels with several ranks keeps the reference's host loops
+  logical function ramses_amd_force_mpi_on()
+    character(len=16) :: val
+    integer :: stat
+    logical, save :: first = .true., on = .true.
+    if (first) then
+       call get_environment_variable('RAMSES_AMD_FORCE_MPI', val, status=stat)
+       if (stat == 0) then
+          if (trim(val) == '0') on = .false.
+       end if
+       first = .false.
+    end if
+    ramses_amd_force_mpi_on = on
+  end function ramses_amd_force_mpi_on
 
   logical function ramses_amd_amr_resident()
     ramses_amd_amr_resident = .false.

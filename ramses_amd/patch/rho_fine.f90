@@ -86,11 +86,15 @@ logical function ramses_amd_rho_amr_device(ilevel)
   integer,intent(in)::ilevel
   character(len=16)::val
   integer::stat,l
-  logical,save::first=.true.,enabled=.true.
+  logical,save::first=.true.,enabled=.true.,enabled_mpi=.true.
   if(first)then
      call get_environment_variable('RAMSES_AMD_RESIDENT_RHO',val,status=stat)
      if(stat==0)then
         if(trim(val)=='0')enabled=.false.
+     end if
+     call get_environment_variable('RAMSES_AMD_RESIDENT_RHO_MPI',val,status=stat)
+     if(stat==0)then
+        if(trim(val)=='0')enabled_mpi=.false.
      end if
      first=.false.
   end if
@@ -101,7 +105,13 @@ logical function ramses_amd_rho_amr_device(ilevel)
 #endif
   if(.not.(poisson.and.hydro))return
   if(ramses_amd_amrres_active()==0)return
-  if(ncpu>1.or.pic.or.nboundary>0.or.cic_levelmax>0.or.ilevel<2.or.ndim/=3)return
+  if(pic.or.nboundary>0.or.cic_levelmax>0.or.ilevel<2.or.ndim/=3)return
+#ifdef WITHOUTMPI
+  if(ncpu>1)return
+#endif
+  ! several ranks: the deposit and its three exchanges per level run on every rank's GPU (ramses_amd_rho_fine_mpi below);
+  ! RAMSES_AMD_RESIDENT_RHO_MPI=0 keeps the reference's host routine there (the density comes back first)
+  if(ncpu>1.and..not.enabled_mpi)return
   if(icoarse_max/=icoarse_min)return
   do l=ilevel,nlevelmax
      if(m_refine(l)>-1.0d0)return
@@ -132,6 +142,12 @@ subroutine rho_fine(ilevel,icount)
            xg_epoch=ramses_amd_tree_epoch
         end if
         if(ilevel==levelmin)multipole=0d0
+        if(ncpu>1)then
+           call ramses_amd_rho_fine_mpi(ilevel,icount)
+           call ramses_amd_toc('rho_fine (device, MPI)',ilevel,t0)
+           call ramses_amd_toc('rho_fine',ilevel,t0)
+           return
+        end if
         if(ilevel==levelmin.or.icount>1)then
            allocate(first(0:nlevelmax-ilevel+1))
            first(0)=0
@@ -182,3 +198,69 @@ subroutine rho_fine(ilevel,icount)
   call rho_fine_amd(ilevel,icount)
   call ramses_amd_toc('rho_fine',ilevel,t0)
 end subroutine rho_fine
+
+!------------------------------------------------------------------------------
+! The same with several ranks (one per GPU; hydro state, tree and communicators of the AMR levels resident,
+! ramses_amd_iface: AMR residency under MPI).  The reference's loop (pm/rho_fine.f90:45-60), level by level from
+! nlevelmax down: multipole_fine(l) on the rank's own octs, the exchange of the four multipoles (:814-817; a split
+! cell's son oct may belong to another rank), cic_from_multipole(l) into the own AND the reception cells (cic_cell loops
+! over the own octs only, :858-866), make_virtual_reverse_dp(rho,l) added peer by peer, make_virtual_fine_dp(rho,l) --
+! all five on the device vectors; rho of the level's cells then goes to the host vector, where multigrid_fine /
+! phi_fine_cg / force_fine of the MPI path read it.  What rho_fine does after the loop (:66-183): phi = 0 on the
+! level's own and reception cells, the reset of rho in the virtual boundaries followed by the two exchanges that
+! restore it (no particles: + 0 on the owners' side, then the same values back), the MPI_ALLREDUCE of the multipole.
+!------------------------------------------------------------------------------
+subroutine ramses_amd_rho_fine_mpi(ilevel,icount)
+  use amr_commons
+  use hydro_commons, only: uold
+  use poisson_commons
+  use ramses_amd_iface
+  use mpi_mod
+  implicit none
+  integer,intent(in)::ilevel,icount
+#ifndef WITHOUTMPI
+  integer::l,rc,nl,ind,i,k,icpu,info
+  integer,allocatable,dimension(:)::list
+  real(kind=8),dimension(4)::mp4
+  real(kind=8),dimension(1:ndim+1)::multipole_in,multipole_out
+  type(ramses_amd_hydro_params)::p
+  if(ilevel==levelmin.or.icount>1)then
+     call ramses_amd_fill_hydro_params(p)
+     do l=nlevelmax,ilevel,-1
+        if(numbtot(1,l)==0)cycle
+        call ramses_amd_amr_level_octs(l,nl,list)
+        rc=ramses_amd_amrres_rho_mpi_multipole(p,l,active(l)%ngrid,nl,list,boxlen)
+        if(rc/=0)call ramses_amd_fatal('rho_fine (multipole_fine under MPI)')
+        call ramses_amd_amr_halo(l,6)
+        rc=ramses_amd_amrres_rho_mpi_deposit(l,nvector,boxlen)
+        if(rc/=0)call ramses_amd_fatal('rho_fine (cic_from_multipole under MPI)')
+        call ramses_amd_amr_halo(l,4)
+        call ramses_amd_amr_halo(l,5)
+        mp4=0d0
+        rc=ramses_amd_amrres_rho_mpi_finish(l,levelmin,nvector,list,rho,mp4)
+        if(rc/=0)call ramses_amd_fatal('rho_fine (deposit back to the host vector)')
+        if(l==levelmin)multipole(1:ndim+1)=mp4(1:ndim+1)
+        deallocate(list)
+     end do
+  end if
+  do ind=1,twotondim
+     k=ncoarse+(ind-1)*ngridmax
+     do i=1,active(ilevel)%ngrid
+        phi(k+active(ilevel)%igrid(i))=0.0d0
+     end do
+     do icpu=1,ncpu
+        do i=1,reception(icpu,ilevel)%ngrid
+           phi(k+reception(icpu,ilevel)%igrid(i))=0.0d0
+        end do
+     end do
+  end do
+  if(ilevel==levelmin)then
+     multipole_in=multipole(1:ndim+1)
+     call MPI_ALLREDUCE(multipole_in,multipole_out,ndim+1,MPI_DOUBLE_PRECISION,MPI_SUM,MPI_COMM_WORLD,info)
+     multipole(1:ndim+1)=multipole_out
+  endif
+  rho_tot=multipole(1)/boxlen**ndim
+  ramses_amd_pois_dev=.false.
+  ramses_amd_pois_amr_level=0
+#endif
+end subroutine ramses_amd_rho_fine_mpi

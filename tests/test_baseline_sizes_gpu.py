@@ -195,6 +195,72 @@ def test_c5_levels_7_10_on_8_ranks_equals_the_mpi_reference(gpu_lib):
     assert dg == dr
 
 
+def _c5_gravity_namelist(mkb, lmin, lmax, nstep, ngridtot, kind):
+    """BASELINE config C5 WITH its multigrid: kind 'sedov' = sedov3d.nml + poisson=.true. (uniform density, the blast's
+    shell is the source), 'blob' = the blob + blast setup of tests/golden/make_golden_amr.py moved to these levels"""
+    from oracle import ramses_snapshot as rs
+    if kind == "blob":
+        return mkb.amr_grav_namelist(lmin, lmax, nstep).replace("ngridtot=600000 !", "ngridtot=%d !" % ngridtot)
+    nml = rs.sedov3d_namelist(level=lmin, nstepmax=nstep, foutput=nstep, poisson=True,
+                              extra=mkb.REFINE + "&POISSON_PARAMS\nepsilon=1d-5\n/\n")
+    return nml.replace("levelmax=%d" % lmin, "levelmax=%d" % lmax).replace("ngridtot=", "ngridtot=%d !" % ngridtot)
+
+
+@pytest.mark.parametrize("lmin,lmax,nproc,nstep,kind", [(7, 10, 8, 8, "sedov"), (7, 9, 4, 8, "sedov"), (7, 9, 4, 3, "blob")])
+def test_c5_with_multigrid_equals_the_mpi_reference(gpu_lib, tmp_path, lmin, lmax, nproc, nstep, kind):
+    """BASELINE config C5 as stated -- "sedov3d.nml with AMR levelmin=7 levelmax=10: Godunov + multigrid, 8 ranks" -- live
+    against the MPI reference on the same ranks: leaf cells (level, position, primitive variables, phi, f), the time and the
+    V-cycle count of every solve, bit for bit.  The whole gravity step of the patched program runs on the ranks' GPU (they
+    share this box's one device, host-MPI transport): rho_fine's deposit with its three exchanges per level
+    (ramses_amd_rho_fine_mpi), the multigrid with the levels resident, force_fine of every level
+    (ramses_amd_force_fine_mpi / the distributed dense solve's brick at levelmin) -- asserted on the profile rows."""
+    ref_mpi = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi")
+    pat_mpi = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi_patch")
+    if not (os.path.exists(ref_mpi) and os.path.exists(pat_mpi)):
+        pytest.skip("oracle/_ref/ramses3d_mpi[_patch] not built")
+    if nproc > (os.cpu_count() or 1):
+        pytest.skip("fewer cores than ranks")
+    import re
+    from oracle import ramses_snapshot as rs
+    mkb = _mkb()
+    nml = _c5_gravity_namelist(mkb, lmin, lmax, nstep, 3000000 if lmax == 10 else 1500000, kind)
+    pat = r"==> Level=\s*(\d+) Step=\s*(\d+)"
+    prof = str(tmp_path / "profile.txt")
+    os.environ["RAMSES_AMD"] = "1"
+    os.environ["RAMSES_AMD_PROFILE"] = prof
+    try:
+        work, out = rs.run_reference(nml, nproc=nproc, binary=pat_mpi)
+    finally:
+        os.environ.pop("RAMSES_AMD_PROFILE", None)
+    try:
+        assert "AMR levels stay resident on the GPU" in out, out[-2000:]
+        sol_p = re.findall(pat, out)
+        got = rs.load_leaf_cells(os.path.join(work, "output_00002"), with_grav=True)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    rows = open(prof).read()
+    assert "rho_fine (device, MPI)" in rows and "force_fine (device, MPI)" in rows, rows[-1500:]
+    os.environ["RAMSES_AMD"] = "0"
+    try:
+        work, out = rs.run_reference(nml, nproc=nproc, binary=ref_mpi)
+    finally:
+        os.environ["RAMSES_AMD"] = "1"
+    try:
+        sol_r = re.findall(pat, out)
+        ref = rs.load_leaf_cells(os.path.join(work, "output_00002"), with_grav=True)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    levels = list(range(lmin, lmax + 1))
+    counts = [int((ref["level"] == l).sum()) for l in levels]
+    assert min(counts) > 500, counts                      # every level is populated
+    assert len(sol_r) > 0 and {int(a) for a, _ in sol_r} >= set(levels[:-1])
+    assert sol_p == sol_r
+    assert [int((got["level"] == l).sum()) for l in levels] == counts
+    assert got["info"]["t"] == ref["info"]["t"]
+    assert mkb.digest_leaves_grav(got) == mkb.digest_leaves_grav(ref), (
+        np.abs(np.sort(got["grav"], axis=1) - np.sort(ref["grav"], axis=1)).max())
+
+
 @pytest.mark.parametrize("mode", ["resident", "staged", "host-driver"])
 def test_amr_self_gravity_levels_6_8_checksum(gpu_lib, mode):
     """AMR + self-gravity at levels 6-8 (0.53 M leaf cells, 3 coarse steps with regridding) through the patched
