@@ -456,11 +456,13 @@ def main():
         lev = HydroLevel(n, n, n, 0.5 / n, params=params, ng=0)
         u, dx = ic.sedov3d(n) if n <= 256 else (None, 0.5 / n)
         if u is None:
-            # build the IC on the device to avoid a 5 GB host array
-            lev.uold[0].fill_(1.0)
-            gam = 1.4
-            lev.uold[4].fill_(1e-5 / (gam - 1.0))
-            lev.uold[4, 0, 0, 0] = (1e-5 + 0.4 * 0.125 / dx ** 3) / (gam - 1.0)
+            # sedov3d.nml built on the device (no 5 GB host array): the reference's IC is a uniform background plus ONE cell --
+            # the 'point' region sits at the box corner and its non-periodic CIC cloud keeps cell (0,0,0) only
+            # (ic.sedov3d_corner_and_background, hydro/init_flow_fine.f90:555-594; tests/test_ic_sedov.py)
+            corner, back, dx = ic.sedov3d_corner_and_background(n)
+            for v in range(5):
+                lev.uold[v].fill_(float(back[v]))
+                lev.uold[v, 0, 0, 0] = float(corner[v])
         else:
             lev.upload(u)
         exchange = None
@@ -564,6 +566,27 @@ def main():
     if os.environ.get("RAMSES_AMD_BENCH_STEPS"):      # debugging aid: the kernel time of every timed step
         sys.stderr.write("bench.py rank %d: ms per step %s\n" % (rank, " ".join("%.3f" % a.elapsed_time(b) for a, b in ev)))
 
+    # N>1: where a step's time goes (untimed extra steps of the serial schedule, an event after every stage; max over ranks)
+    breakdown = None
+    if exchange is not None:
+        acc = {"sweep": 0.0, "pack": 0.0, "sendrecv": 0.0, "unpack": 0.0}
+        nprof, nbytes = 5, 0
+        for _ in range(nprof):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            lev.godunov_fine(dt)
+            b.record()
+            lev.set_uold()
+            pk, sr, up, nbytes = exchange.exchange_direct_profiled(lev, lev.uold, lev.nvar)
+            torch.cuda.synchronize()
+            acc["sweep"] += a.elapsed_time(b); acc["pack"] += pk; acc["sendrecv"] += sr; acc["unpack"] += up
+        breakdown = {k + "_ms": exchange.transport.allreduce(v / nprof, "cuda", op="max") for k, v in acc.items()}
+        breakdown["bytes_sent_per_rank"] = nbytes
+        breakdown["sendrecv_GBps_per_rank"] = nbytes / max(breakdown["sendrecv_ms"], 1e-9) / 1e6
+        breakdown["note"] = ("%d extra steps of the serial schedule after the timed region: full-brick sweep, pack of the 26 regions, one "
+                             "grouped send/recv (one message per peer), unpack; each stage between events on the launch stream, max over ranks"
+                             % nprof)
+
     # sanity: the state must still be physical
     chk = lev.courant_fine()
     assert chk[0] > 0 and chk[1] > 0
@@ -589,6 +612,7 @@ def main():
                        "spinup": "%d untimed sweeps of the same kernel on a scratch level of the same size before the warm-up steps (%d ms; the first ~8 "
                                  "sweeps of a kernel run up to 10 %% slower whatever ran before: profiles/r03_spinup_ab.txt)" % (spin_sweeps, args.spinup_ms),
                        "ranks": census,
+                       "step_breakdown": breakdown,
                        "halo": "none (single rank, in-kernel periodic wrap)" if world == 1 else
                                ("RCCL send/recv (torch.distributed)" if transport_note is None else transport_note) +
                                " of 2-cell face slabs, all nvar fused, " +

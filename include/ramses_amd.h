@@ -847,6 +847,32 @@ int ramses_amd_amrres_halo_stage_out(int ilevel, int dir, int ncpu, int64_t *h_s
                                      int64_t *recv_off);
 int ramses_amd_amrres_halo_stage_in(int ilevel, int dir);
 
+/* ---------------------------------------------------------------------------
+ * SOLVER=mhd: the constrained-transport MHD Godunov sweep.
+ * Replaces: mhd/godunov_fine.f90 godfine1 :538-1459 on a fully refined periodic level (no coarse-fine boundaries),
+ *           mhd/umuscl.f90 mag_unsplit :31-238 (ctoprim :2029-2186, uslope :2187-2844, trace3d :750-1307, cmpflxm
+ *           :1308-1448, cmp_mag_flx :1453-2028), mhd/godunov_utils.f90 lax_friedrich / hll / hlld :352-699, fused with
+ *           set_unew (mhd/godunov_fine.f90:40-110).  NDIM = 3, NVAR = 8, NENER = 0, scheme = 'muscl'.
+ * riemann: 0 llf, 2 hll, 3 hlld, 4 upwind (= llf in cmpflxm);  riemann2d: 0 llf, 3 hll, 5 hlld (the reference's iriemann /
+ * iriemann2d codes, hydro/read_hydro_params.f90:184-220);  slope_type / slope_mag_type: 0, 1, 2, 7, 8 (slope_mag_type = -1
+ * means slope_type, :528-530).  Anything else returns RAMSES_AMD_EUNSUPPORTED.
+ * d_uold / d_unew: [11][nz][ny][nx] device doubles -- rho, rho u, rho v, rho w, E, the three left-face fields (uold(:,6:8)),
+ * the three right-face fields (uold(:,nvar+1:nvar+3)) -- periodic, distinct buffers; the right-face field of a cell must equal
+ * the left-face field of its neighbour bit for bit (it does on any level the scheme has advanced; RAMSES_AMD_EINVAL if not).
+ * d_work: ramses_amd_mhd_workspace_bytes(nx,ny,nz) bytes of device scratch.  Bit-identical to the reference. */
+typedef struct ramses_amd_mhd_params {
+  double gamma, smallr, smallc, slope_theta;
+  int32_t slope_type, slope_mag_type, riemann, riemann2d;
+} ramses_amd_mhd_params;
+int64_t ramses_amd_mhd_workspace_bytes(int nx, int ny, int nz);
+int ramses_amd_mhd_godunov_brick(const ramses_amd_mhd_params *p, int nx, int ny, int nz, const double *d_uold, double *d_unew,
+                                 double dx, double dt, void *d_work, int64_t work_bytes, void *stream);
+/* godunov_fine(ilevel) of a SOLVER=mhd run on the reference's own arrays uold / unew (1:ncell,1:nvar+3), staged through the
+ * device: the level's cells go up, unew of the level's cells comes back (ramses_amd/patch_mhd/godunov_fine.f90). */
+int ramses_amd_mhd_godunov_fine_f90(const ramses_amd_mhd_params *p, int ilevel, int ngrid, const int *igrid, const double *xg,
+                                    int64_t ngridmax, int64_t ncoarse, int nx_loc, const double *uold, double *unew, double dx,
+                                    double dt);
+
 #ifdef __cplusplus
 }
 #endif

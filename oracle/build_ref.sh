@@ -57,6 +57,23 @@ build_kernels() { # ndim [nvar]: nvar>ndim+2 adds passive scalars (tag _vN)
   echo "built $OUT/libref_kernels${tag}.so"
 }
 
+build_kernels_mhd() { # the MHD solver's mag_unsplit (NDIM=3, NVAR=8) behind oracle/ref_shim_mhd.f90
+  local obj="$OUT/obj_kernels3d_mhd"
+  mkdir -p "$obj"
+  local flags="-cpp -DNVECTOR=$NVECTOR -DNDIM=3 -DNPRE=8 -DNENER=0 -DNVAR=8 -DSOLVERmhd -DWITHOUTMPI -fPIC $OPT -module-dir $obj -I$obj"
+  local srcs=(amr/amr_parameters.f90 amr/amr_commons.f90 mhd/hydro_parameters.f90 hydro/hydro_commons.f90
+              poisson/poisson_parameters.f90 poisson/poisson_commons.f90 mhd/umuscl.f90 mhd/godunov_utils.f90)
+  local objs=()
+  for s in "${srcs[@]}"; do
+    local o="$obj/$(basename "${s%.f90}").o"
+    $F90 $flags -c "$REF/$s" -o "$o"
+    objs+=("$o")
+  done
+  $F90 $flags -c "$HERE/ref_shim_mhd.f90" -o "$obj/ref_shim_mhd.o"
+  $F90 -shared -o "$OUT/libref_kernels3d_mhd.so" "${objs[@]}" "$obj/ref_shim_mhd.o"
+  echo "built $OUT/libref_kernels3d_mhd.so"
+}
+
 # Ordered object list of the full program (module files first), resolved
 # through the same search order the reference uses: PATCH, hydro, pm, poisson,
 # amr, io.
@@ -171,6 +188,7 @@ EOF
 cmd=${1:-kernels}
 case "$cmd" in
   kernels) build_kernels "${2:-3}" "${3:-}";;
+  kernels_mhd) build_kernels_mhd;;
   ramses) build_ramses "${2:-3}" "${3:-serial}" "${4:-}";;
   all) # every artefact tests/ and bench.py look for; the programs are independent (own object and stub directories):
        # built side by side, REF_JOBS at a time (default: the number of cores)
@@ -185,6 +203,7 @@ case "$cmd" in
        r_rho() { REF_DEFS=-DOUTPUT_PARTICLE_DENSITY REF_TAG=rho build_ramses 3 serial; }
        r_v7() { REF_NVAR=7 REF_TAG=v7 build_ramses 3 serial "$@"; }
        bg k 3; bg k 1; bg k 2; bg k 3 7
+       bg build_kernels_mhd
        bg r 3 serial; bg r 1 serial; bg r 2 serial
        bg r_rho
        if [ -d /opt/conda/include ] && [ -f /opt/conda/lib/libmpifort.so ]; then bg r 3 mpi; fi

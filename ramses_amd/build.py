@@ -36,6 +36,7 @@ UNITS = [
     ("capi_amr.o", "capi_amr.hip", ["-ffp-contract=off"]),
     ("pois_amr.o", "pois_amr.hip", ["-ffp-contract=off"]),
     ("mg_dist.o", "mg_dist.hip", ["-ffp-contract=off"]),
+    ("mhd_sweep.o", "mhd_sweep.hip", ["-ffp-contract=off"]),
 ]
 
 

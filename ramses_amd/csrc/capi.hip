@@ -2470,6 +2470,7 @@ extern "C" int ramses_amd_warm_pois_amr(void);
 extern "C" int ramses_amd_warm_capi(void);
 extern "C" int ramses_amd_warm_hydro_sweep_fast(void);
 extern "C" int ramses_amd_warm_hydro_sweep_strict(void);
+extern "C" int ramses_amd_warm_mhd_sweep(void);
 
 extern "C" int ramses_amd_warmup(void) {
   static bool done = false;
@@ -2491,6 +2492,7 @@ extern "C" int ramses_amd_warmup(void) {
   bad += ramses_amd_warm_capi();
   bad += ramses_amd_warm_hydro_sweep_fast();
   bad += ramses_amd_warm_hydro_sweep_strict();
+  bad += ramses_amd_warm_mhd_sweep();
   if (hipDeviceSynchronize() != hipSuccess || bad) return fail(RAMSES_AMD_EHIP, "warm-up launches failed (%d)", bad);
   return 0;
 }

@@ -24,6 +24,8 @@
 // contraction, rcp/rsq-based division and square root, fused LLF).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "hydro_core.hpp"
 #include "sweep_args.hpp"
 
@@ -268,25 +270,35 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #pragma unroll
   for (int n = 0; n < NV; n++) { partx[n] = 0.0; fyown[n] = 0.0; }
 
-  for (int c = z0 - 1; c <= z1; c++) {
-    MPlane &M = mring[c & 1];
-    MPlane &Mprev = mring[(c & 1) ^ 1];
+  // SWEEP_UNROLL (A/B knob): the marching loop unrolled by the period of the ring (2 with SWEEP_ZREG, else 6 = 3 slots x
+  // 2 flux buffers) so that the slots are compile-time offsets and the loop-carried copies (24 moves per plane) vanish
+#ifndef SWEEP_UNROLL
+#define SWEEP_UNROLL 1
+#endif
+  int mpar = 0;   // which of the two +y state / y flux buffers this plane uses (the same on every wave of the workgroup)
+  constexpr bool UNR2 = ZREG && (SWEEP_UNROLL == 2);
+  auto step = [&](const int c, auto ktag) __attribute__((always_inline)) {
+    constexpr int K = decltype(ktag)::value;      // UNR2: the plane's position in the period of the ring
+    const int SA = sa, SB = UNR2 ? K : sb, SC = UNR2 ? (K ^ 1) : sc;
+    MPlane &M = mring[UNR2 ? K : mpar];
+    MPlane &Mprev = mring[(UNR2 ? K : mpar) ^ 1];
+    mpar ^= 1;
     // ---- phase A: plane c+1 arrives; trace plane c; x and z fluxes ------------------
     double qc[NV];
     ctoprim_cell<NV, GRAV>(upre, gpre, dtxhalf, P, qc);
 #pragma unroll
-    for (int n = 0; n < NV; n++) qring[sc].v[n][ty][tx] = qc[n];
+    for (int n = 0; n < NV; n++) qring[SC].v[n][ty][tx] = qc[n];
     double ucur[NV];
     if (r_fxz) load_u(c, ucur);
 
     double qpy[NV], dz[NV], px[NV];
     if (ST == 3) __syncthreads();  // the 27-point slope reads the neighbours' plane c+1 just written
     if constexpr (r_trace) {
-      const Plane<BY, NV> &qs = qring[sb];
-      const Plane<BY, NV> &qprev = qring[sa];
+      const Plane<BY, NV> &qs = qring[SB];
+      const Plane<BY, NV> &qprev = qring[SA];
       double qb[NV], dq[3][NV];
       if (ST == 3) {
-        const Plane<BY, NV> &qnext = qring[sc];
+        const Plane<BY, NV> &qnext = qring[SC];
         const int xs[3] = {txm, tx, txp}, ys[3] = {tym, ty, typ};
 #pragma unroll
         for (int n = 0; n < NV; n++) {
@@ -414,7 +426,7 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     }
     // rotate the ring
     if constexpr (ZREG) {
-      const int t = sb; sb = sc; sc = t;
+      if constexpr (!UNR2) { const int t = sb; sb = sc; sc = t; }
       if constexpr (r_trace) {
 #pragma unroll
         for (int n = 0; n < NV; n++) { qzm[n] = qz0[n]; qz0[n] = qc[n]; }
@@ -422,8 +434,19 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     } else {
       const int t = sa; sa = sb; sb = sc; sc = t;
     }
+  };
+  if constexpr (UNR2) {
+    int c = z0 - 1;
+    for (; c + 1 <= z1; c += 2) {
+      step(c, std::integral_constant<int, 0>{});
+      step(c + 1, std::integral_constant<int, 1>{});
+    }
+    if (c <= z1) step(c, std::integral_constant<int, 0>{});
+  } else {
+    for (int c = z0 - 1; c <= z1; c++) step(c, std::integral_constant<int, 0>{});
   }
 }
+
 
 template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV>
 __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {

@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -103,6 +104,8 @@ struct ramses_amd_mgdist {
   std::vector<int> rank_of_brick;
   int *d_rank_of_brick = nullptr;
   bool use_rccl = false;
+  bool rccl_self = false;    // RAMSES_AMD_MGDIST_RCCL_SELF=1 (tests): with the library's communicator up, a rank's messages to itself
+                             // (periodic wrap), the all-reduce and the all-gather go through RCCL even on ONE rank -- what N ranks execute
   ramses_amd_mg_transport tr;
   std::vector<Level> lev;     // indexed by level; built = distributed
   int lrep = 0, rep_dims[3] = {0, 0, 0};
@@ -225,7 +228,7 @@ int exchange(ramses_amd_mgdist *M, Level &L, double *t, hipStream_t s) {
   std::vector<int64_t> so, sc, ro, rc;
   for (int i = 0; i < np; i++) {
     const Seg &a = P.segs_s[i], &b = P.segs_r[i];
-    if (a.peer == M->rank) {
+    if (a.peer == M->rank && !M->rccl_self) {
       if (M->use_rccl)   // periodic wrap onto myself
         HCHK(hipMemcpyAsync(P.d_recv + b.off, P.d_send + a.off, sizeof(double) * a.cnt, hipMemcpyDeviceToDevice, s), "self copy");
       continue;
@@ -261,7 +264,7 @@ int interior_copy(Level &L, double *t, double *dense, int pack, hipStream_t s) {
 }
 
 int allreduce_sum(ramses_amd_mgdist *M, double *d_value, double *out, hipStream_t s) {
-  if (M->use_rccl && M->world > 1) RCHK(ramses_amd_rccl_allreduce(d_value, 1, 0, s));
+  if (M->use_rccl && (M->world > 1 || M->rccl_self)) RCHK(ramses_amd_rccl_allreduce(d_value, 1, 0, s));
   HCHK(hipMemcpyAsync(out, d_value, sizeof(double), hipMemcpyDeviceToHost, s), "norm copy");
   HCHK(hipStreamSynchronize(s), "stream sync");
   if (!M->use_rccl && M->world > 1) {
@@ -311,7 +314,7 @@ int coarse_cycle(ramses_amd_mgdist *M, int l, int safe, hipStream_t s) {
     // replicated levels: gather the right-hand side, solve everywhere
     const size_t part = (size_t)M->rep_dims[0] * M->rep_dims[1] * M->rep_dims[2];
     RCHK(interior_copy(M->rep_local, M->rep_local.u[1], M->rep_mine, 1, s));
-    if (M->world == 1) {
+    if (M->world == 1 && !M->rccl_self) {
       HCHK(hipMemcpyAsync(M->rep_parts, M->rep_mine, sizeof(double) * part, hipMemcpyDeviceToDevice, s), "gather copy");
     } else if (M->use_rccl) {
       RCHK(ramses_amd_rccl_allgather(M->rep_mine, (int64_t)part, M->rep_parts, s));
@@ -380,6 +383,10 @@ int ramses_amd_mgdist_create(int level, const int *pgrid, int rank, const int *r
   }
   M->coords[0] = mine % pgrid[0]; M->coords[1] = (mine / pgrid[0]) % pgrid[1]; M->coords[2] = mine / (pgrid[0] * pgrid[1]);
   M->use_rccl = (transport == nullptr);
+  {
+    const char *e = getenv("RAMSES_AMD_MGDIST_RCCL_SELF");
+    M->rccl_self = M->use_rccl && e && e[0] == '1' && ramses_amd_rccl_ready();
+  }
   if (transport) M->tr = *transport; else std::memset(&M->tr, 0, sizeof(M->tr));
   if (M->use_rccl && world > 1 && !ramses_amd_rccl_ready()) {
     delete M;

@@ -89,6 +89,19 @@ def sedov3d(n, boxlen=0.5, gamma=1.4, lo=(0, 0, 0), shape=None):
     return uniform_brick_ic(n, boxlen, SEDOV3D_REGIONS, gamma, lo, shape)
 
 
+def sedov3d_corner_and_background(n, boxlen=0.5, gamma=1.4):
+    """sedov3d.nml on an n^3 level WITHOUT building the level on the host (bench.py at 512^3: 5 GB): the 'point'
+    region sits at the box corner (x_center = y_center = z_center = 0) and region_condinit's CIC weights
+    max(1 - |x - x_center|/dx, 0) are not periodic (hydro/init_flow_fine.f90:555-594), so of the eight cells of its
+    cloud only cell (0,0,0) lies inside the box: the level is a uniform background plus that ONE cell.  Returns
+    (u_corner[5], u_background[5], dx), the reference's own arithmetic (condinit.f90:44-57) on the 2^3 corner brick;
+    tests/test_ic_sedov.py checks the statement against the full construction."""
+    u, dx = uniform_brick_ic(n, boxlen, SEDOV3D_REGIONS, gamma, (0, 0, 0), (2, 2, 2))
+    corner, back = u[:, 0, 0, 0].copy(), u[:, 1, 1, 1].copy()
+    assert all(np.array_equal(u[:, k, j, i], back) for k in range(2) for j in range(2) for i in range(2) if (i, j, k) != (0, 0, 0))
+    return corner, back, dx
+
+
 # namelist/sedov1d.nml &INIT_PARAMS
 SEDOV1D_REGIONS = [
     dict(type="square", x_center=0.5, y_center=0.0, z_center=0.0, length_x=1.0, length_y=1.0, length_z=1.0,

@@ -52,6 +52,7 @@ class BrickDecomposition:
         self.n = self.dims[0]
         self.ng = ng
         self.coords = rank_coords(rank, self.pgrid)
+        self.boxlen = boxlen
         self.dx = boxlen / (self.dims[0] * self.pgrid[0])
         self.lo = tuple(c * d for c, d in zip(self.coords, self.dims))
         self._bufs = {}
@@ -65,14 +66,14 @@ class BrickDecomposition:
         """namelist/sedov3d.nml on the global level, restricted to this brick
         (hydro/init_flow_fine.f90:455-596: the 'point' region deposits into the
         cell whose centre is within dx of the origin -- global cell (0,0,0))."""
-        g = lev.ng
+        from . import ic
+        # the level is a uniform background plus ONE cell (ic.sedov3d_corner_and_background): the reference's own values
+        corner, back, _ = ic.sedov3d_corner_and_background(self.dims[0] * self.pgrid[0], boxlen=self.boxlen, gamma=gamma)
         u = lev.interior(lev.uold)
-        u.zero_()
-        u[0].fill_(1.0)
-        u[4].fill_(1e-5 / (gamma - 1.0))
-        if self.lo == (0, 0, 0):
-            u[4, 0, 0, 0] = (1e-5 + 0.4 * 0.125 / lev.dx ** 3) / (gamma - 1.0)
-        del g
+        for v in range(5):
+            u[v].fill_(float(back[v]))
+            if self.lo == (0, 0, 0):
+                u[v, 0, 0, 0] = float(corner[v])
 
     def neighbour(self, axis, direction):
         c = list(self.coords)
@@ -196,6 +197,31 @@ class BrickDecomposition:
                 recvs.append((R["buf"][pos2:pos2 + size2], q))
         self.transport.sendrecv(sends, recvs)
         self._multi(lev, t, nvar, R, False)
+
+    def exchange_direct_profiled(self, lev, t, nvar):
+        """exchange_direct with an event after every stage on the current stream: returns
+        (pack_ms, sendrecv_ms, unpack_ms, bytes sent to other ranks) -- bench.py's N>1 line
+        explains its own efficiency with them."""
+        plan = self._direct_plan(lev, nvar, t)
+        S, R = plan["send"], plan["recv"]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        self._multi(lev, t, nvar, S, True)
+        ev[1].record()
+        sends, recvs, nbytes = [], [], 0
+        for (q, pos, size), (q2, pos2, size2) in zip(S["segs"], R["segs"]):
+            if q == self.rank:
+                R["buf"][pos2:pos2 + size2].copy_(S["buf"][pos:pos + size])
+            else:
+                sends.append((S["buf"][pos:pos + size], q))
+                recvs.append((R["buf"][pos2:pos2 + size2], q))
+                nbytes += 8 * size
+        self.transport.sendrecv(sends, recvs)
+        ev[2].record()
+        self._multi(lev, t, nvar, R, False)
+        ev[3].record()
+        ev[3].synchronize()
+        return ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3]), nbytes
 
     def make_virtual_fine_dp(self, lev, direct=True):
         """Refresh the ghost octs of uold (and of f when poisson) on every rank."""

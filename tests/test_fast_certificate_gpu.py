@@ -105,3 +105,34 @@ def test_default_mode_live_ab_at_128(gpu_lib, monkeypatch, riemann, slope_type, 
     err = _rel(got["prim"], ref["prim"], vmax)
     print("default (fast) vs the live MPI reference, 128^3, %s slope %d, %d steps: rel-Linf = %s" % (riemann, slope_type, nstep, err))
     assert (err <= TOL).all(), err
+
+
+@pytest.mark.parametrize("riemann,slope_type,scheme", [
+    ("hll", 1, "muscl"), ("acoustic", 1, "muscl"), ("exact", 1, "muscl"),
+    ("llf", 3, "muscl"), ("llf", 7, "muscl"), ("llf", 8, "muscl"), ("hllc", 8, "muscl"),
+    ("llf", 1, "plmde"), ("hllc", 2, "plmde"),
+])
+def test_default_mode_solver_matrix_live_ab_at_64(gpu_lib, monkeypatch, riemann, slope_type, scheme):
+    """The rest of the solver matrix in the DEFAULT (fast) arithmetic: hll, acoustic,
+    exact, slope types 3 / 7 / 8 and scheme='plmde', each 60 coarse steps of sedov3d.nml at 64^3 through the patched
+    program against the unmodified MPI reference run live beside it; rel-Linf per snapshot variable <= 1e-12."""
+    if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED)):
+        pytest.skip("oracle/_ref/ramses3d_mpi / ramses3d_patch not built")
+    from oracle import ramses_snapshot as rs
+    nproc = min(_nproc(), 8)
+    nstep = 60
+    kw = dict(level=6, nstepmax=nstep, foutput=nstep, riemann=riemann, slope_type=slope_type, scheme=scheme)
+    got = _run_patched(rs.sedov3d_namelist(mem_factor=1.3, **kw), 6, "fast", monkeypatch)
+    monkeypatch.setenv("RAMSES_AMD", "0")
+    workr, outr = rs.run_reference(rs.sedov3d_namelist(mem_factor=3.0 if nproc > 1 else 1.3, **kw), binary=REF_MPI, nproc=nproc)
+    try:
+        ref = rs.load_uniform_level(os.path.join(workr, "output_00002"), 6)
+    finally:
+        shutil.rmtree(workr, ignore_errors=True)
+    assert int(np.ravel(got["info"]["nstep"])[0]) == int(np.ravel(ref["info"]["nstep"])[0]) == nstep
+    tr = float(np.ravel(ref["info"]["t"])[0])
+    assert abs(float(np.ravel(got["info"]["t"])[0]) - tr) <= TOL * tr
+    vmax = np.abs(ref["prim"]).reshape(ref["prim"].shape[0], -1).max(axis=1)
+    err = _rel(got["prim"], ref["prim"], vmax)
+    print("default (fast) vs the live MPI reference, 64^3, %s slope %d %s, %d steps: rel-Linf = %s" % (riemann, slope_type, scheme, nstep, err))
+    assert (err <= TOL).all(), err

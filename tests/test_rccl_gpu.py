@@ -165,3 +165,52 @@ def test_amr_virtual_boundaries_over_rccl_equal_host_transport(rccl, nvar):
     exp[:, cr] = exp[:, ce]
     assert np.array_equal(got_host.view(np.int64), exp.view(np.int64))
     assert np.array_equal(got_rccl.view(np.int64), got_host.view(np.int64))
+
+
+@pytest.mark.parametrize("n", [64, 128])
+def test_distributed_multigrid_in_library_rccl_leg_equals_the_callback_transport(rccl, monkeypatch, n):
+    """What `bench.py --gpus N`'s V-cycle leg and the Fortran drop-in on N GPUs execute first:
+    ramses_amd_mgdist_create with transport == NULL, i.e. the library's own RCCL communicator inside the distributed
+    multigrid (csrc/mg_dist.hip: the deep-halo exchange through ramses_amd_rccl_exchange, the all-reduce of the residual
+    norm, the all-gather that assembles the replicated coarse levels).  On the one-GPU box the communicator has ONE rank;
+    RAMSES_AMD_MGDIST_RCCL_SELF=1 sends the rank's periodic wrap-around messages, the all-reduce and the all-gather
+    through RCCL all the same (26 messages to self per exchange inside one group).  phi, f, the V-cycle count and the
+    error must equal the solve through the three host callbacks bit for bit."""
+    import torch
+    from ramses_amd._capi import check
+    from ramses_amd.poisson_parallel import PoissonDecomposition
+    L = rccl
+    rng = np.random.default_rng(5)
+    rho = 1.0 + 0.5 * rng.random((n, n, n))
+    rho[n // 8:n // 3, n // 4:n // 2, -n // 10:] += 15.0          # straddles the periodic boundary
+    rho_tot = float(rho.mean())
+    level = int(np.log2(n))
+    # the callback transport (what the one-GPU tests and the MPI shim use)
+    pd = PoissonDecomposition((1, 1, 1), 0, n, boxlen=1.0, epsilon=1e-6)
+    pd.rho.copy_(torch.from_numpy(rho).cuda())
+    it0, err0 = pd.multigrid_fine(rho_tot)
+    pd.force_fine()
+    torch.cuda.synchronize()
+    phi0, f0, ex0 = pd.phi_interior().cpu().numpy(), pd.f.cpu().numpy(), pd.exchanges
+    # the in-library RCCL leg
+    monkeypatch.setenv("RAMSES_AMD_MGDIST_RCCL_SELF", "1")
+    ctx = C.c_void_p()
+    check(L.ramses_amd_mgdist_create(level, _i32(1, 1, 1), 0, None, None, C.byref(ctx)))
+    try:
+        d_rho = torch.from_numpy(rho).cuda()
+        phi = torch.zeros(n, n, n, dtype=torch.float64, device="cuda")
+        f = torch.zeros(3, n, n, n, dtype=torch.float64, device="cuda")
+        it, err = C.c_int(), C.c_double()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(L.ramses_amd_mgdist_solve(ctx, C.c_void_p(d_rho.data_ptr()), rho_tot, pd.fourpi, 1e-6, C.byref(it), C.byref(err), st))
+        check(L.ramses_amd_mgdist_get_phi(ctx, C.c_void_p(phi.data_ptr()), st))
+        check(L.ramses_amd_mgdist_force(ctx, C.c_void_p(f.data_ptr()), st))
+        torch.cuda.synchronize()
+        nex = C.c_int64()
+        check(L.ramses_amd_mgdist_info(ctx, None, None, None, None, None, C.byref(nex)))
+    finally:
+        check(L.ramses_amd_mgdist_destroy(ctx))
+    assert it.value == it0 and err.value == err0
+    assert nex.value >= 10 and ex0 >= 10                    # both legs exchanged halos (26 regions each, all to self)
+    assert np.array_equal(phi.cpu().numpy(), phi0)
+    assert np.array_equal(f.cpu().numpy(), f0)
