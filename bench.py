@@ -45,6 +45,8 @@ def parse():
                     help="keep the sweep kernel busy on a scratch level of the same size this long before the warm-up steps (ramp; 0 = none)")
     ap.add_argument("--amr-level", type=int, default=8,
                     help="tree-walking (AMR) sweep measurement on a fully refined synthetic 2^level^3 tree (0 = skip)")
+    ap.add_argument("--mhd-level", type=int, default=7,
+                    help="MHD sweep measurement (SOLVER=mhd) on a uniform 2^level^3 level (0 = skip)")
     ap.add_argument("--mg-tune", type=int, default=-1,
                     help="fused smoother: 1 = library default (2+2 colour passes on 32-row tiles), 4 = one 4-pass launch, "
                          "12/16/24/32 = 2+2 passes on that many tile rows, 0 = one kernel per colour pass (-1: leave the default)")
@@ -338,6 +340,108 @@ def amr_sweep_bench(level=8, steps=5, partial=False):
     if census:
         out["census"] = census
     return out
+
+
+def amr_covered_bench(level=8, steps=5):
+    """godunov_fine of a FULLY COVERED level that has refined cells (levelmin of every AMR run): level `level` complete, level+1
+    present in a spherical shell.  ramses_amd_amrres_godunov routes such a level through the dense sweep with its refinement
+    mask (gather from the resident cell vectors, masked z-marching kernel, scatter; csrc/capi_amr.hip covered_level_sweep);
+    the same call with RAMSES_AMD_COVERED_DENSE=0 walks the tree.  Strict arithmetic in both."""
+    import numpy as np
+    import torch
+    import ramses_amd
+    from ramses_amd import ic
+    from ramses_amd._capi import check, lib
+    n = 2 ** level
+    z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    r = np.sqrt((x - n / 2 + 0.5) ** 2 + (y - n / 2 + 0.5) ** 2 + (z - n / 2 + 0.5) ** 2)
+    mask = (r >= 0.23 * n) & (r <= 0.36 * n)
+    del x, y, z, r
+    T = ic.uniform_tree(level, order="morton", refine_mask=mask)
+    igrid = np.ascontiguousarray(T["igrid"])
+    ncells = 8 * len(igrid)
+    dx = 0.5 / n
+    u = np.zeros((5, T["ncell"]))
+    u[0] = 1.0
+    u[4] = 1e-5 / 0.4
+    u[4, T["ncoarse"] + int(igrid[0]) - 1] = (1e-5 + 0.4 * 0.125 / dx ** 3) / 0.4
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)      # noqa: E731
+    p = ramses_amd.make_params(courant_factor=0.8)
+    L = lib()
+    out = {}
+    for tag, env in (("dense", "1"), ("tree", "0")):
+        os.environ["RAMSES_AMD_COVERED_DENSE"] = env
+        check(L.ramses_amd_amrres_invalidate())
+        check(L.ramses_amd_amrres_load(5, T["ngridmax"], T["ncoarse"], vp(u), vp(T["son"]), vp(T["nbor"]), vp(T["father"])))
+        before = L.ramses_amd_amrres_covered_sweeps()
+        for _ in range(2):
+            check(L.ramses_amd_amrres_set_unew(len(igrid), vp(igrid)))
+            check(L.ramses_amd_amrres_godunov(C.byref(p), level, len(igrid), vp(igrid), dx, 1e-6, 32, 0, 1))
+        torch.cuda.synchronize()
+        t = 0.0
+        for _ in range(steps):
+            check(L.ramses_amd_amrres_set_unew(len(igrid), vp(igrid)))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            check(L.ramses_amd_amrres_godunov(C.byref(p), level, len(igrid), vp(igrid), dx, 1e-6, 32, 0, 1))
+            torch.cuda.synchronize()
+            t += time.perf_counter() - t0
+        out[tag] = (t / steps * 1e3, L.ramses_amd_amrres_covered_sweeps() - before)
+    os.environ.pop("RAMSES_AMD_COVERED_DENSE", None)
+    check(L.ramses_amd_amrres_invalidate())
+    ms, took = out["dense"]
+    gbs = ncells * BYTES_PER_CELL_UPDATE_AMR / (ms * 1e-3) / 1e9
+    return {"metric": "cell-updates/s (godunov_fine of a fully covered AMR level, dense sweep with the refinement mask)",
+            "value": ncells / (ms * 1e-3), "unit": "cell-updates/s", "ms_per_sweep": ms, "cells": ncells,
+            "dense_sweeps_taken": int(took), "tree_walking_ms_per_sweep": out["tree"][0],
+            "arithmetic": "strict (bit-identical to the reference)",
+            "workload": "level %d complete (%d^3), level %d in a spherical shell: %d of its cells refined" % (level, n, level + 1, int(mask.sum())),
+            "includes": "oct origins from the father pointers, gather of uold / unew into bricks, the mask, the sweep, scatter of unew; host-timed",
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "bytes_per_cell": BYTES_PER_CELL_UPDATE_AMR}}
+
+
+BYTES_PER_CELL_UPDATE_MHD = 176   # 11 fields (5 Euler + 3 left-face + 3 right-face fields) read and written, FP64
+
+
+def mhd_sweep_bench(level=7, steps=5):
+    """SOLVER=mhd: the constrained-transport MHD sweep of a uniform periodic 2^level^3 level through
+    ramses_amd_mhd_godunov_brick (csrc/mhd_sweep.hip: the first correct path, one kernel per stage of mag_unsplit with the
+    intermediates in HBM); hlld + hlld, moncen, a magnetised blast; strict arithmetic (bit-identical to the reference)."""
+    import numpy as np
+    import torch
+    from ramses_amd.mhd import MhdLevel, make_mhd_params
+    n = 2 ** level
+    lev = MhdLevel(n, n, n, 1.0 / n, params=make_mhd_params(gamma=5.0 / 3.0, slope_type=2, riemann="hlld", riemann2d="hlld"))
+    x = (torch.arange(n, dtype=torch.float64, device="cuda") + 0.5) / n
+    Z, Y, X = torch.meshgrid(x, x, x, indexing="ij")
+    r2 = (X - 0.5) ** 2 + (Y - 0.5) ** 2 + (Z - 0.5) ** 2
+    b = (1.0, 0.5, -0.3)
+    lev.uold[0].fill_(1.0)
+    for c in range(3):
+        lev.uold[5 + c].fill_(b[c])
+        lev.uold[8 + c].fill_(b[c])
+    lev.uold[4] = (0.1 + 10.0 * torch.exp(-r2 / (2 * 0.05 ** 2))) / (5.0 / 3.0 - 1.0) + 0.5 * sum(v * v for v in b)
+    dt = 0.2 / n / 5.0
+    for _ in range(2):
+        lev.step(dt)
+    torch.cuda.synchronize()
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps):
+        lev.step(dt)
+    e.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(e) / steps
+    assert bool(torch.isfinite(lev.uold).all().item())
+    cells = n ** 3
+    gbs = cells * BYTES_PER_CELL_UPDATE_MHD / (ms * 1e-3) / 1e9
+    return {"metric": "cell-updates/s (MHD godunov_fine, SOLVER=mhd, constrained transport)", "value": cells / (ms * 1e-3),
+            "unit": "cell-updates/s", "ms_per_sweep": ms, "cells": cells, "solver": "hlld + hlld (2-D), moncen",
+            "arithmetic": "strict (bit-identical to the reference)", "workload": "uniform periodic %d^3, magnetised blast" % n,
+            "kernels": "mhd_prim / efield / trace / flux / emf / update (first correct path: intermediates in HBM)",
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "bytes_per_cell": BYTES_PER_CELL_UPDATE_MHD}}
 
 
 def pick_transport(rank, world, timeout):
@@ -676,8 +780,16 @@ def main():
                 torch.cuda.empty_cache()
                 out["amr_sweep"] = amr_sweep_bench(args.amr_level)
                 out["amr_sweep_partial"] = amr_sweep_bench(args.amr_level + 1, partial=True)
+                torch.cuda.empty_cache()
+                out["amr_sweep_covered"] = amr_covered_bench(args.amr_level)
             except Exception as exc:     # noqa: BLE001  (an extra line, never a reason to lose the headline)
                 out["amr_sweep"] = {"value": None, "error": str(exc)[:300]}
+        if world == 1 and args.mhd_level > 0:
+            try:
+                torch.cuda.empty_cache()
+                out["mhd_sweep"] = mhd_sweep_bench(args.mhd_level)
+            except Exception as exc:     # noqa: BLE001  (an extra line, never a reason to lose the headline)
+                out["mhd_sweep"] = {"value": None, "error": str(exc)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()     # rank 0 at N=1 only
     else:

@@ -825,6 +825,12 @@ int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, co
                                  double err_grad_u, double floor_d, double floor_p, double floor_u, int *cells, int *ncells);
 int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, double dx, double dt,
                               int nvector, int interpol_var, int interpol_type);
+/* A level whose octs fill the periodic box (levelmin, any complete level) takes the DENSE sweep inside ramses_amd_amrres_godunov:
+ * gathered into bricks, swept with its refinement mask (fluxes through the faces of refined cells reset, the update starting from
+ * unew: hydro/godunov_fine.f90:661-666,720-790), scattered back -- strict arithmetic, bit-identical to the tree-walking sweep.
+ * NVAR = 5, muscl, slope types 0/1/2/7/8, every Riemann solver but 'exact', no difmag / pressure_fix; RAMSES_AMD_COVERED_DENSE=0
+ * keeps the tree-walking sweep.  ramses_amd_amrres_covered_sweeps: how many sweeps took the dense path so far. */
+int64_t ramses_amd_amrres_covered_sweeps(void);
 /* Several MPI ranks (one per GPU): the virtual-boundary exchanges of amr_step on the resident cell vectors.
  *   make_virtual_fine_dp(uold(1,ivar),ilevel)     amr/virtual_boundaries.f90:373-528, callers amr/amr_step.f90:61,287,505
  *   make_virtual_reverse_dp(unew(1,ivar),ilevel)  amr/virtual_boundaries.f90:693-983, caller amr/amr_step.f90:397

@@ -29,9 +29,13 @@ if [ ! -d "$REF/hydro" ]; then
 fi
 mkdir -p "$OUT"
 
-defines() { # ndim [nvar]
+defines() { # ndim [nvar]   (REF_SOLVER=mhd: the reference's SOLVER=mhd build, NVAR=8)
   local ndim=$1 nvar=${2:-$(( $1 + 2 ))}
-  echo "-cpp -DNVECTOR=$NVECTOR -DNDIM=$ndim -DNPRE=8 -DNENER=0 -DNVAR=$nvar -DSOLVERhydro"
+  if [ "${REF_SOLVER:-hydro}" = mhd ]; then
+    echo "-cpp -DNVECTOR=$NVECTOR -DNDIM=$ndim -DNPRE=8 -DNENER=0 -DNVAR=${2:-8} -DSOLVERmhd"
+  else
+    echo "-cpp -DNVECTOR=$NVECTOR -DNDIM=$ndim -DNPRE=8 -DNENER=0 -DNVAR=$nvar -DSOLVERhydro"
+  fi
 }
 
 build_kernels() { # ndim [nvar]: nvar>ndim+2 adds passive scalars (tag _vN)
@@ -164,7 +168,9 @@ EOF
   fi
   find_src() { # name -> path
     local n=$1
-    for d in "$patch" "$gen" "$REF/hydro" "$REF/pm" "$REF/poisson" "$REF/amr" "$REF/io"; do
+    local solver_dir=""
+    [ "${REF_SOLVER:-hydro}" = mhd ] && solver_dir="$REF/mhd"      # bin/Makefile: VPATH puts ../mhd before ../hydro
+    for d in "$patch" "$gen" "$solver_dir" "$REF/hydro" "$REF/pm" "$REF/poisson" "$REF/amr" "$REF/io"; do
       [ -n "$d" ] || continue
       for ext in f90 F; do
         if [ -f "$d/$n.$ext" ]; then echo "$d/$n.$ext"; return; fi
@@ -202,6 +208,7 @@ case "$cmd" in
        r() { build_ramses "$@"; }
        r_rho() { REF_DEFS=-DOUTPUT_PARTICLE_DENSITY REF_TAG=rho build_ramses 3 serial; }
        r_v7() { REF_NVAR=7 REF_TAG=v7 build_ramses 3 serial "$@"; }
+       r_mhd() { REF_SOLVER=mhd REF_TAG=mhd build_ramses 3 serial "$@"; }
        bg k 3; bg k 1; bg k 2; bg k 3 7
        bg build_kernels_mhd
        bg r 3 serial; bg r 1 serial; bg r 2 serial
@@ -215,6 +222,8 @@ case "$cmd" in
            bg r 3 mpi "$HERE/../ramses_amd/patch"
          fi
        fi
+       bg r_mhd
+       if [ -f "$HERE/../ramses_amd/lib/libramses_amd.so" ]; then bg r_mhd "$HERE/../ramses_amd/patch_mhd"; fi
        bg r 3 serial "$HERE/dump_patch"
        bg r_v7
        if [ -f "$HERE/../ramses_amd/lib/libramses_amd.so" ]; then

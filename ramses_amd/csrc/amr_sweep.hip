@@ -1047,16 +1047,11 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A_in, int slope_type, int riem
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(amr_posof_kernel, dim3((A.ngrid + 255) / 256), dim3(256), 0, s, A.igrid, A.ngrid, posof);
   // One workgroup per father oct (its sons share one stencil) unless an option only the single-oct kernel
-  // carries is on; RAMSES_AMD_AMR_GROUP=0 forces the single-oct kernel (A/B).
+  // carries is on (scheme='plmde' with pressure_fix).
   int *groups = posof + A.ngridmax, *count = groups + A.ngrid;     // workspace tail (ramses_amd_godunov_fine_amr_workspace)
   int ngroups = 0;
   const int *walk = nullptr;
-  static int use_groups = -1;
-  if (use_groups < 0) {
-    const char *env = getenv("RAMSES_AMD_AMR_GROUP");
-    use_groups = !(env && env[0] == '0');
-  }
-  if (use_groups && !(A.divu != nullptr && A.scheme == 1)) {
+  if (!(A.divu != nullptr && A.scheme == 1)) {
     e = hipMemsetAsync(count, 0, sizeof(int), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(amr_group_build_kernel, dim3((A.ngrid + 1023) / 1024), dim3(1024), 0, s, A, posof, groups, count);
@@ -1064,19 +1059,9 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A_in, int slope_type, int riem
     if (e != hipSuccess) return e;
     e = hipStreamSynchronize(s);
     if (e != hipSuccess) return e;
-    // the grouped kernel reads the level from packed oct records (RAMSES_AMD_AMR_PACK=0: straight from the cell vectors)
-    static int use_pack = -1;
-    if (use_pack < 0) {
-      const char *env = getenv("RAMSES_AMD_AMR_PACK");
-      use_pack = !(env && env[0] == '0');
-    }
-    // the father-cell walk of all groups in a pass of its own (RAMSES_AMD_AMR_WALK=0: inside the sweep kernel, A/B)
-    static int use_walk = -1;
-    if (use_walk < 0) {
-      const char *env = getenv("RAMSES_AMD_AMR_WALK");
-      use_walk = !(env && env[0] == '0');
-    }
-    const bool do_walk = use_walk && walk_area && ngroups > 0, do_pack = use_pack && pack_area && ngroups > 0;
+    // the grouped kernel reads the level from packed oct records, the father-cell walk of all groups runs in the same
+    // pre-pass (a caller without the two scratch areas gets the gather from the cell vectors / the walk inside the kernel)
+    const bool do_walk = walk_area && ngroups > 0, do_pack = pack_area && ngroups > 0;
     const int walk_blocks = do_walk ? (int)(((long)ngroups * 64 + 255) / 256) : 0;
     if (do_pack) {
       // records of primitive variables + (alternating workgroups of the same launch) the father-cell walk of every group:

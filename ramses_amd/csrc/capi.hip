@@ -131,8 +131,7 @@ int ramses_amd_device_info(char *name, size_t name_len, int *n_cu, size_t *hbm_b
 }
 
 int ramses_amd_godunov_tune(int tile_rows, int zchunk) {
-  if (tile_rows != 0 && tile_rows != 8 && tile_rows != 12 && tile_rows != 14 && tile_rows != 16)
-    return fail(RAMSES_AMD_EINVAL, "tile_rows must be 8, 12, 14 or 16 (got %d)", tile_rows);
+  if (tile_rows != 0 && tile_rows != 8 && tile_rows != 12) return fail(RAMSES_AMD_EINVAL, "tile_rows must be 8 or 12 (got %d)", tile_rows);
   if (zchunk < 0) return fail(RAMSES_AMD_EINVAL, "zchunk must be >=0");
   g_tile_rows = tile_rows;
   g_zchunk = zchunk ? zchunk : 128;

@@ -18,6 +18,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -25,6 +27,8 @@
 #include "amr_core.hpp"
 #include "hydro_core.hpp"
 #include "rho_args.hpp"
+#include "pack_args.hpp"
+#include "sweep_args.hpp"
 
 using namespace ramses_amd;
 
@@ -407,6 +411,43 @@ __global__ __launch_bounds__(256) void lvl_pfix_switch_kernel(LvlArgs A, const d
   }
 }
 
+// ---- godunov_fine of a FULLY COVERED level of an AMR run (levelmin, and any level whose octs fill the periodic box) ----------
+// The tree-walking sweep recomputes a 6^3 stencil per father oct; a level that covers the box is a brick, and the dense
+// z-marching sweep (csrc/hydro_sweep.hip) updates it several times faster.  The level is gathered from the resident cell
+// vectors into bricks (uold, unew, f), the dense kernel runs with the refinement mask of the level -- fluxes through the faces
+// of refined cells reset to zero, the update starting from unew, which already holds what the finer level owes to this one
+// (hydro/godunov_fine.f90:661-666,720-747,752-790) -- and unew is scattered back.  Strict arithmetic: bit-identical.
+// oct -> brick origin from the father pointers alone (no xg): the octant of the father cell at every level up to the root
+__global__ __launch_bounds__(256) void lvl_oct_origin_kernel(const int *igrid, int ngrid, const int *father, long ncoarse, long ngridmax,
+                                                              int level, int n, long *octorg, int *bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ngrid) return;
+  int g = igrid[i];
+  int x = 0, y = 0, z = 0;
+  bool ok = true;
+  for (int l = level; l >= 2; l--) {
+    const long c = father[g - 1];
+    if (c <= ncoarse) { ok = false; break; }
+    const int ind = (int)((c - ncoarse - 1) / ngridmax);
+    g = (int)((c - ncoarse - 1) % ngridmax) + 1;
+    const int sh = level - l;
+    x |= (ind & 1) << sh; y |= ((ind >> 1) & 1) << sh; z |= (ind >> 2) << sh;
+  }
+  if (ok && father[g - 1] > ncoarse) ok = false;      // the walk must end on the level-1 oct
+  if (!ok) { atomicAdd(bad, 1); octorg[i] = 0; return; }
+  octorg[i] = 2L * x + (long)n * (2L * y + (long)n * 2L * z);
+}
+__global__ __launch_bounds__(256) void lvl_mask_kernel(const int *igrid, const long *octorg, int ngrid, const int *son, long ncoarse, long ngridmax,
+                                                        int n, unsigned char *mask) {
+  const long total = (long)ngrid * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ind = (int)(t / ngrid), i = (int)(t % ngrid);
+    const long c = ncoarse + (long)ind * ngridmax + igrid[i] - 1;
+    const long b = octorg[i] + (ind & 1) + (long)n * (((ind >> 1) & 1) + (long)n * (ind >> 2));
+    mask[b] = son[c] > 0 ? 1 : 0;
+  }
+}
+
 struct Buf {
   void *p = nullptr;
   size_t cap = 0;
@@ -458,6 +499,8 @@ struct AmrRes {
   bool xg_valid = false;
   Buf mp, rho, posof, mpscratch, lists;   // rho_fine: multipoles (4, ncell), the deposit (ncell), oct -> list position, scan scratch
   Buf hkeys, hvals;                       // rho_fine with several ranks: the own octs of the level by position
+  Buf cb_old, cb_new, cb_f, cb_mask, cb_org;   // godunov_fine of a fully covered level: bricks of uold / unew / f, refinement mask, oct origins
+  long covered_sweeps = 0;                     // how many sweeps took that path (tests, ramses_amd_amrres_covered_sweeps)
   int rl_level = 0, rl_nown = 0, rl_nall = 0;   // the level ramses_amd_amrres_rho_mpi_multipole opened (its list is in `lists`)
   Buf f;                 // f(1:ncell,1:3), a copy of the host array refreshed after force_fine and after regrids
   bool grav = false;
@@ -681,6 +724,74 @@ int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, co
   return 0;
 }
 
+namespace {
+bool covered_dense_enabled() {      // (read on every sweep: the A/B test flips it inside one process)
+  const char *e = getenv("RAMSES_AMD_COVERED_DENSE");
+  return !(e && e[0] == '0');
+}
+// returns 0 and sets done when the level took the dense path; done = false: the caller walks the tree
+int covered_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, int ngrid, double dx, double dt, bool &done) {
+  done = false;
+  if (!covered_dense_enabled() || R.ncoarse != 1 || ilevel < 4 || ilevel > 10) return 0;
+  const int n = 1 << ilevel;
+  const long N = (long)n * n * n;
+  if ((long)ngrid * 8 != N) return 0;
+  if (R.nvar != 5 || p->nvar != 5 || p->ndim != 3 || p->scheme != RAMSES_AMD_SCHEME_MUSCL || p->difmag > 0.0 || R.pfix) return 0;
+  const int st = p->slope_type;
+  if (!(st == 0 || st == 1 || st == 2 || st == 7 || st == 8) || p->riemann == RAMSES_AMD_RIEMANN_EXACT) return 0;
+  hipStream_t s = nullptr;
+  HCHK(R.cb_old.ensure(sizeof(double) * 5 * (size_t)N), "hipMalloc"); HCHK(R.cb_new.ensure(sizeof(double) * 5 * (size_t)N), "hipMalloc");
+  HCHK(R.cb_mask.ensure((size_t)N), "hipMalloc"); HCHK(R.cb_org.ensure(sizeof(long) * (size_t)ngrid), "hipMalloc");
+  if (R.grav) HCHK(R.cb_f.ensure(sizeof(double) * 3 * (size_t)N), "hipMalloc");
+  HCHK(hipMemsetAsync(R.err.p, 0, sizeof(int), s), "memset");
+  hipLaunchKernelGGL(lvl_oct_origin_kernel, dim3((ngrid + 255) / 256), dim3(256), 0, s, R.igrid.as<int>(), ngrid, R.father.as<int>(), R.ncoarse, R.ngridmax,
+                     ilevel, n, R.cb_org.as<long>(), R.err.as<int>());
+  int bad = 0;
+  HCHK(hipMemcpyAsync(&bad, R.err.p, sizeof(int), hipMemcpyDeviceToHost, s), "D2H flag");
+  HCHK(hipStreamSynchronize(s), "sync");
+  if (bad) return 0;                                  // not a tree of one coarse cell: the tree-walking sweep knows what to do
+  PackArgs PA;
+  PA.igrid = R.igrid.as<int>(); PA.octorg = R.cb_org.as<long>();
+  PA.ngrid = ngrid; PA.n = n; PA.nvar = 5;
+  PA.ncoarse = R.ncoarse; PA.ngridmax = R.ngridmax; PA.ncell = R.ncell; PA.pitch_var = N;
+  PA.brick = R.cb_old.as<double>(); PA.cellvec = R.uold.as<double>();
+  HCHK(launch_oct_copy(PA, true, s), "gather uold");
+  PA.brick = R.cb_new.as<double>(); PA.cellvec = R.unew.as<double>();
+  HCHK(launch_oct_copy(PA, true, s), "gather unew");
+  if (R.grav) {
+    PA.nvar = 3; PA.brick = R.cb_f.as<double>(); PA.cellvec = R.f.as<double>();
+    HCHK(launch_oct_copy(PA, true, s), "gather f");
+    PA.nvar = 5;
+  }
+  hipLaunchKernelGGL(lvl_mask_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, s, R.igrid.as<int>(), R.cb_org.as<long>(), ngrid, R.son.as<int>(),
+                     R.ncoarse, R.ngridmax, n, R.cb_mask.as<unsigned char>());
+  HCHK(hipGetLastError(), "mask launch");
+  SweepArgs A;
+  A.uold = R.cb_old.as<double>(); A.unew = R.cb_new.as<double>(); A.grav = R.grav ? R.cb_f.as<double>() : nullptr;
+  A.mask = R.cb_mask.as<unsigned char>(); A.base = R.cb_new.as<double>();
+  A.nx = A.ny = A.nz = n; A.ng = 0;
+  A.pitch_y = n; A.pitch_z = (long)n * n; A.pitch_var = N;
+  A.zchunk = n < 128 ? n : 128;
+  A.region = SWEEP_ALL;
+  A.dt = dt; A.dx = dx; A.rdx = 1.0 / dx;
+  int ex = 0;
+  const double m = std::frexp(dx, &ex);
+  A.pow2 = (m == 0.5) ? 1 : 0;
+  A.P = make_const_amr(p);
+  // strict arithmetic, like every other sweep of an AMR run (the fast build is certified on uniform runs only)
+  hipError_t e = strictmode::launch_godunov_sweep(A, st, p->riemann, 12, p->scheme, 5, R.grav, s);
+  if (e == hipErrorInvalidValue) { (void)hipGetLastError(); return 0; }     // a variant the masked kernels do not cover
+  HCHK(e, "dense sweep of a covered level");
+  PA.brick = R.cb_new.as<double>(); PA.cellvec = R.unew.as<double>();
+  HCHK(launch_oct_copy(PA, false, s), "scatter unew");
+  R.covered_sweeps++;
+  done = true;
+  return 0;
+}
+}  // namespace
+
+extern "C" int64_t ramses_amd_amrres_covered_sweeps(void) { return g_ar.covered_sweeps; }
+
 // godunov_fine(ilevel) on the resident arrays
 int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, double dx, double dt,
                               int nvector, int interpol_var, int interpol_type) {
@@ -689,6 +800,11 @@ int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int 
   if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
   if (ngrid == 0) return 0;
   AmrRes &R = g_ar;
+  {
+    bool done = false;
+    if (int rc = covered_level_sweep(R, p, ilevel, ngrid, dx, dt, done)) return rc;
+    if (done) return 0;
+  }
   const int64_t nw = ramses_amd_godunov_fine_amr_workspace(ngrid, R.ngridmax);
   if (nw < 0) return (int)nw;
   HCHK(R.work.ensure((size_t)nw), "hipMalloc work");

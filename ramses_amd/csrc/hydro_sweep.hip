@@ -24,8 +24,6 @@
 // contraction, rcp/rsq-based division and square root, fused LLF).
 #include <hip/hip_runtime.h>
 
-#include <type_traits>
-
 #include "hydro_core.hpp"
 #include "sweep_args.hpp"
 
@@ -40,16 +38,6 @@ namespace ramses_amd {
 namespace SWEEP_NS {
 
 constexpr int BX = 64;   // lanes along x = one wavefront
-
-// SWEEP_ZREG (default 0 until measured): every slope type but the 27-point one needs plane c-1 and c+1 only in the
-// thread's OWN column, so those two values ride in registers and the LDS ring of primitive planes
-// shrinks from three slots to two (plane c for the x/y neighbours, plane c+1 being written); the +y
-// state / y flux slots exist for rows 1..BY-3 only.  3*NV*BY + 2*NV*BY -> 2*NV*BY + 2*NV*(BY-3) rows of
-// 512 B: 16-row tiles (16 waves per CU = 4 per SIMD, 12 of 16 rows updating cells) fit in 145 KB
-// where 12-row tiles took 150 KB.  SWEEP_ZREG=0 is the round-3 kernel (A/B: profiles/r04_ab_sweep.txt).
-#ifndef SWEEP_ZREG
-#define SWEEP_ZREG 0
-#endif
 
 // LDS plane of NV doubles per column: [n][ty][tx]; NV = rho, u, v, w, P + passive scalars
 template <int BY, int NV>
@@ -105,25 +93,18 @@ __device__ __forceinline__ void plane_store(double *var_base, unsigned plane_byt
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, x), r, off, plane_bytes, 0);
 }
 
-// LDS layout of a tile (see SWEEP_ZREG above)
-template <int ST, int BY, int NV>
-struct TileLds {
-  static constexpr bool ZREG = (SWEEP_ZREG != 0) && (ST != 3);
-  static constexpr int NQ = ZREG ? 2 : 3;          // slots of the primitive ring
-  static constexpr int BYM = ZREG ? BY - 3 : BY;   // rows of a +y state / y flux plane
-  static constexpr int MOFF = ZREG ? 1 : 0;        // its first row is tile row MOFF
-  static constexpr size_t bytes = NQ * sizeof(Plane<BY, NV>) + 2 * sizeof(Plane<BYM, NV>);
-};
+__device__ __forceinline__ int wave_shr1_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int mask_load(const unsigned char *base, unsigned plane_bytes, unsigned off) {
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(base), 0, BUF_RANGE, 0x00020000);
+  return (int)__builtin_amdgcn_raw_buffer_load_b8(r, off, plane_bytes, 0);
+}
 
-template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV, int ROLE>
+// MASK: the sweep of a fully covered level that has refined cells (see SweepArgs::mask / base)
+template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV, int ROLE, bool MASK>
 __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *smem_raw) {
   const bool DXPOW2 = A.pow2 != 0;   // uniform
-  using L = TileLds<ST, BY, NV>;
-  constexpr bool ZREG = L::ZREG;
-  constexpr int MOFF = L::MOFF;
-  using MPlane = Plane<L::BYM, NV>;
-  Plane<BY, NV> *qring = reinterpret_cast<Plane<BY, NV> *>(smem_raw);  // primitives of planes (c-1,) c, c+1
-  MPlane *mring = reinterpret_cast<MPlane *>(qring + L::NQ);           // [2] +y traced state / y flux slots, by plane parity
+  Plane<BY, NV> *qring = reinterpret_cast<Plane<BY, NV> *>(smem_raw);  // [3] primitives of planes c-1, c, c+1
+  Plane<BY, NV> *mring = qring + 3;                                 // [2] +y traced state / y flux slots, by plane parity
 
   const int tx = threadIdx.x, ty = threadIdx.y;
   const HydroConst &P = A.P;
@@ -178,6 +159,15 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   // are wave-uniform (scalar base + 32-bit lane offset addressing)
   // (byte offset < 2 GB per plane, checked by the launcher)
   const unsigned colb = (unsigned)(xi + yi * (int)A.pitch_y) * 8u;
+  // MASK (periodic dense brick, ng = 0): byte offsets of this column and of its -y neighbour in a plane of the mask
+  unsigned colm = 0, colm_ym = 0;
+  if (MASK) {
+    int yim = yu - 1;
+    yim = yim < 0 ? yim + A.ny : (yim >= A.ny ? yim - A.ny : yim);
+    yim = yim >= A.ny ? yim % A.ny : yim;
+    colm = (unsigned)(xi + yi * A.nx);
+    colm_ym = (unsigned)(xi + yim * A.nx);
+  }
   const double *__restrict__ uold = A.uold;
   double *__restrict__ unew = A.unew;
   const double *__restrict__ grav = A.grav;
@@ -201,6 +191,16 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #pragma unroll
     for (int n = 0; n < NV; n++) u[n] = plane_load(uold + (long)n * A.pitch_var, pb, colb);
   };
+  auto load_base = [&](int p, double (&u)[NV]) {   // MASK: the state the update starts from (unew)
+    const unsigned pb = plane_off(p);
+#pragma unroll
+    for (int n = 0; n < NV; n++) u[n] = plane_load(A.base + (long)n * A.pitch_var, pb, colb);
+  };
+  auto mask_plane = [&](int p) -> unsigned {
+    const int pz = p < 0 ? p + A.nz : (p >= A.nz ? p - A.nz : p);
+    return (unsigned)pz * (unsigned)(A.nx * A.ny);
+  };
+  int ok_zlo = 0;   // MASK: plane c-1's refinement flag of this column
   auto load_g = [&](int p, double (&g)[3]) {
     if (GRAV) {
       const unsigned pb = plane_off(p);
@@ -217,11 +217,8 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   double upre[NV], gpre[3];       // prefetch: plane c+1 on entry of iteration c
   double rold = 0.0, sold[NV > 5 ? NV - 5 : 1];   // uold density / scalars of plane c-1 (NV>5 only)
 
-  // ring slots of planes c-1, c, c+1 (ZREG: planes c and c+1 in slots sb, sc; c-1 in registers)
-  int sa = 0, sb = ZREG ? 0 : 1, sc = ZREG ? 1 : 2;
-  double qzm[NV], qz0[NV];        // ZREG: this column's primitives of planes c-1 and c
-#pragma unroll
-  for (int n = 0; n < NV; n++) { qzm[n] = 0.0; qz0[n] = 0.0; }
+  // ring slots of planes c-1, c, c+1
+  int sa = 0, sb = 1, sc = 2;
 
   // prologue: primitives of planes z0-2 -> slot sa, z0-1 -> slot sb; c starts at z0-1
   {
@@ -229,14 +226,11 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     load_u(z0 - 2, u); load_g(z0 - 2, g);
     ctoprim_cell<NV, GRAV>(u, g, dtxhalf, P, q);
 #pragma unroll
-    for (int n = 0; n < NV; n++) {
-      if constexpr (ZREG) qzm[n] = q[n];
-      else qring[sa].v[n][ty][tx] = q[n];
-    }
+    for (int n = 0; n < NV; n++) qring[sa].v[n][ty][tx] = q[n];
     load_u(z0 - 1, u); load_g(z0 - 1, g);
     ctoprim_cell<NV, GRAV>(u, g, dtxhalf, P, q);
 #pragma unroll
-    for (int n = 0; n < NV; n++) { qring[sb].v[n][ty][tx] = q[n]; qz0[n] = q[n]; }
+    for (int n = 0; n < NV; n++) qring[sb].v[n][ty][tx] = q[n];
     load_u(z0, upre); load_g(z0, gpre);
 #pragma unroll
     for (int n = 0; n < NV; n++) { qmz[n] = 1.0; fzlo[n] = 0.0; }
@@ -270,35 +264,31 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #pragma unroll
   for (int n = 0; n < NV; n++) { partx[n] = 0.0; fyown[n] = 0.0; }
 
-  // SWEEP_UNROLL (A/B knob): the marching loop unrolled by the period of the ring (2 with SWEEP_ZREG, else 6 = 3 slots x
-  // 2 flux buffers) so that the slots are compile-time offsets and the loop-carried copies (24 moves per plane) vanish
-#ifndef SWEEP_UNROLL
-#define SWEEP_UNROLL 1
-#endif
-  int mpar = 0;   // which of the two +y state / y flux buffers this plane uses (the same on every wave of the workgroup)
-  constexpr bool UNR2 = ZREG && (SWEEP_UNROLL == 2);
-  auto step = [&](const int c, auto ktag) __attribute__((always_inline)) {
-    constexpr int K = decltype(ktag)::value;      // UNR2: the plane's position in the period of the ring
-    const int SA = sa, SB = UNR2 ? K : sb, SC = UNR2 ? (K ^ 1) : sc;
-    MPlane &M = mring[UNR2 ? K : mpar];
-    MPlane &Mprev = mring[(UNR2 ? K : mpar) ^ 1];
-    mpar ^= 1;
+  for (int c = z0 - 1; c <= z1; c++) {
+    Plane<BY, NV> &M = mring[c & 1];
+    Plane<BY, NV> &Mprev = mring[(c & 1) ^ 1];
     // ---- phase A: plane c+1 arrives; trace plane c; x and z fluxes ------------------
     double qc[NV];
     ctoprim_cell<NV, GRAV>(upre, gpre, dtxhalf, P, qc);
 #pragma unroll
-    for (int n = 0; n < NV; n++) qring[SC].v[n][ty][tx] = qc[n];
+    for (int n = 0; n < NV; n++) qring[sc].v[n][ty][tx] = qc[n];
     double ucur[NV];
-    if (r_fxz) load_u(c, ucur);
+    if (r_fxz) { if (MASK) load_base(c, ucur); else load_u(c, ucur); }
+    int okc = 0, ok_ym = 0;
+    if (MASK && (ROLE == ROLE_FULL || ROLE == ROLE_HIGH)) {
+      const unsigned mp = mask_plane(c);
+      okc = mask_load(A.mask, mp, colm);
+      ok_ym = mask_load(A.mask, mp, colm_ym);
+    }
 
     double qpy[NV], dz[NV], px[NV];
     if (ST == 3) __syncthreads();  // the 27-point slope reads the neighbours' plane c+1 just written
     if constexpr (r_trace) {
-      const Plane<BY, NV> &qs = qring[SB];
-      const Plane<BY, NV> &qprev = qring[SA];
+      const Plane<BY, NV> &qs = qring[sb];
+      const Plane<BY, NV> &qprev = qring[sa];
       double qb[NV], dq[3][NV];
       if (ST == 3) {
-        const Plane<BY, NV> &qnext = qring[SC];
+        const Plane<BY, NV> &qnext = qring[sc];
         const int xs[3] = {txm, tx, txp}, ys[3] = {tym, ty, typ};
 #pragma unroll
         for (int n = 0; n < NV; n++) {
@@ -318,23 +308,21 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
       } else if (ST == 4 || ST == 5 || ST == 6) {
         // the NDIM=1 slope types (embedded 1-D problems: ny = nz = 1, the transverse differences vanish)
 #pragma unroll
-        for (int n = 0; n < NV; n++) qb[n] = ZREG ? qz0[n] : qs.v[n][ty][tx];
+        for (int n = 0; n < NV; n++) qb[n] = qs.v[n][ty][tx];
         const double dc0 = qb[1] * A.dt / A.dx, dc1 = qb[2] * A.dt / A.dx, dc2 = qb[3] * A.dt / A.dx;
 #pragma unroll
         for (int n = 0; n < NV; n++) {
-          const double qlo = ZREG ? qzm[n] : qprev.v[n][ty][tx];
           dq[0][n] = slope1_1d<ST>(qs.v[n][ty][txm], qb[n], qs.v[n][ty][txp], dc0, n);
           dq[1][n] = slope1_1d<ST>(qs.v[n][tym][tx], qb[n], qs.v[n][typ][tx], dc1, n);
-          dq[2][n] = slope1_1d<ST>(qlo, qb[n], qc[n], dc2, n);
+          dq[2][n] = slope1_1d<ST>(qprev.v[n][ty][tx], qb[n], qc[n], dc2, n);
         }
       } else {
 #pragma unroll
         for (int n = 0; n < NV; n++) {
-          qb[n] = ZREG ? qz0[n] : qs.v[n][ty][tx];
-          const double qlo = ZREG ? qzm[n] : qprev.v[n][ty][tx];
+          qb[n] = qs.v[n][ty][tx];
           dq[0][n] = slope1<ST>(qs.v[n][ty][txm], qb[n], qs.v[n][ty][txp], P);
           dq[1][n] = slope1<ST>(qs.v[n][tym][tx], qb[n], qs.v[n][typ][tx], P);
-          dq[2][n] = slope1<ST>(qlo, qb[n], qc[n], P);
+          dq[2][n] = slope1<ST>(qprev.v[n][ty][tx], qb[n], qc[n], P);
         }
       }
       double qm[3][NV], qp[3][NV];
@@ -344,11 +332,8 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
         const double cc = ctoprim_sound(qb[0], qb[4], P);
         tracexyz_cell<NV>(qb, dq, cc, dtdx, dtdx, dtdx, P, qm, qp);
       }
-      // (row BY-2's +y state has no reader: the slots cover rows MOFF..)
-      if constexpr (ROLE != ROLE_HIGH) {
 #pragma unroll
-        for (int n = 0; n < NV; n++) M.v[n][ty - MOFF][tx] = qm[1][n];
-      }
+      for (int n = 0; n < NV; n++) M.v[n][ty][tx] = qm[1][n];
 #pragma unroll
       for (int n = 0; n < NV; n++) qpy[n] = qp[1][n];
       if constexpr (r_fxz) {
@@ -358,6 +343,13 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
         scaled_interface_flux<RS, NV, 0>(qL, qp[0], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fx);
         // z flux through the face between planes c-1 and c
         scaled_interface_flux<RS, NV, 2>(qmz, qp[2], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fz);
+        if (MASK) {
+          // hydro/godunov_fine.f90:720-747: the flux through a face is reset when the cell on either side is refined
+          const bool zx = (okc | wave_shr1_i(okc)) != 0, zz = (okc | ok_zlo) != 0;
+#pragma unroll
+          for (int n = 0; n < NV; n++) { fx[n] = zx ? 0.0 : fx[n]; fz[n] = zz ? 0.0 : fz[n]; }
+          ok_zlo = okc;
+        }
 #pragma unroll
         for (int n = 0; n < NV; n++) {
           qmz[n] = qm[2][n];
@@ -384,11 +376,16 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     if constexpr (ROLE == ROLE_FULL || ROLE == ROLE_HIGH) {
       double qL[NV];
 #pragma unroll
-      for (int n = 0; n < NV; n++) qL[n] = M.v[n][tym - MOFF][tx];
+      for (int n = 0; n < NV; n++) qL[n] = M.v[n][tym][tx];
       scaled_interface_flux<RS, NV, 1>(qL, qpy, P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fy);
+      if (MASK) {
+        const bool zy = (okc | ok_ym) != 0;
+#pragma unroll
+        for (int n = 0; n < NV; n++) fy[n] = zy ? 0.0 : fy[n];
+      }
       // the flux through this row's -y face is the +y face flux of row ty-1: into ITS slot
 #pragma unroll
-      for (int n = 0; n < NV; n++) M.v[n][tym - MOFF][tx] = fy[n];
+      for (int n = 0; n < NV; n++) M.v[n][tym][tx] = fy[n];
     }
     if constexpr (r_fxz) {
       // plane c-1: its x part and own -y flux were kept in registers, the +y face flux was left
@@ -398,7 +395,7 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
       double un[NV];
 #pragma unroll
       for (int n = 0; n < NV; n++) {
-        const double part = partx[n] + (fyown[n] - Mprev.v[n][ty - MOFF][tx]);
+        const double part = partx[n] + (fyown[n] - Mprev.v[n][ty][tx]);
         un[n] = part + dz[n];
       }
       if (NV > 5) {
@@ -425,52 +422,33 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
       }
     }
     // rotate the ring
-    if constexpr (ZREG) {
-      if constexpr (!UNR2) { const int t = sb; sb = sc; sc = t; }
-      if constexpr (r_trace) {
-#pragma unroll
-        for (int n = 0; n < NV; n++) { qzm[n] = qz0[n]; qz0[n] = qc[n]; }
-      }
-    } else {
-      const int t = sa; sa = sb; sb = sc; sc = t;
-    }
-  };
-  if constexpr (UNR2) {
-    int c = z0 - 1;
-    for (; c + 1 <= z1; c += 2) {
-      step(c, std::integral_constant<int, 0>{});
-      step(c + 1, std::integral_constant<int, 1>{});
-    }
-    if (c <= z1) step(c, std::integral_constant<int, 0>{});
-  } else {
-    for (int c = z0 - 1; c <= z1; c++) step(c, std::integral_constant<int, 0>{});
+    const int t = sa; sa = sb; sb = sc; sc = t;
   }
 }
 
-
-template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV>
+template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV, bool MASK = false>
 __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ty = threadIdx.y;   // wave-uniform
   // the full rows are the critical path between two barriers: let them win the issue
   // arbitration over the light rows (measured: -1.1 % at 512^3)
   if (ty >= 2 && ty <= BY - 3) __builtin_amdgcn_s_setprio(3);
-  if (ty == 0) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_HALO>(A, smem_raw);
-  else if (ty == BY - 1) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_HALO_HI>(A, smem_raw);
-  else if (ty == 1) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_LOW>(A, smem_raw);
-  else if (ty == BY - 2) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_HIGH>(A, smem_raw);
-  else sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_FULL>(A, smem_raw);
+  if (ty == 0) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_HALO, MASK>(A, smem_raw);
+  else if (ty == BY - 1) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_HALO_HI, MASK>(A, smem_raw);
+  else if (ty == 1) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_LOW, MASK>(A, smem_raw);
+  else if (ty == BY - 2) sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_HIGH, MASK>(A, smem_raw);
+  else sweep_march<ST, RS, BY, GRAV, SCHEME, NV, ROLE_FULL, MASK>(A, smem_raw);
 }
 
 // ---------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------
-template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV>
+template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV, bool MASK = false>
 static hipError_t launch3(const SweepArgs &A, hipStream_t s) {
-  const size_t lds = TileLds<ST, BY, NV>::bytes;
+  const size_t lds = 5 * sizeof(Plane<BY, NV>);
   dim3 block(BX, BY);
   dim3 grid(A.nblocks);
-  auto k = godunov_sweep_kernel<ST, RS, BY, GRAV, SCHEME, NV>;
+  auto k = godunov_sweep_kernel<ST, RS, BY, GRAV, SCHEME, NV, MASK>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, grid, block, lds, s, A);
@@ -528,6 +506,16 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
   }
   if (nblocks == 0) return hipSuccess;
   A.nblocks = nblocks;
+  if (A.mask || A.base) {
+    // a fully covered level with refined cells: the 12-row muscl kernels on a periodic brick (anything else: the caller
+    // keeps the tree-walking sweep)
+    if constexpr (ST != 3 && ST != 4 && ST != 5 && ST != 6 && RS != RIEMANN_EXACT) {
+      if (!A.mask || !A.base || A.ng != 0 || nvar != 5 || scheme != 0 || by != 12 || A.region != SWEEP_ALL) return hipErrorInvalidValue;
+      return grav ? launch3<ST, RS, 12, true, 0, 5, true>(A, s) : launch3<ST, RS, 12, false, 0, 5, true>(A, s);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if constexpr (ST == 4 || ST == 5 || ST == 6) {
     // NDIM=1 slope types: the plain configuration only (the reference's 1-D tests: NVAR=3 embedded as 5, muscl, no gravity)
     if (nvar != 5 || scheme != 0 || grav) return hipErrorInvalidValue;
@@ -540,10 +528,6 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
     if (by == 8) return launch2<ST, RS, 8, 0, 5>(A, grav, s);
     if constexpr (ST != 3 && RS != RIEMANN_EXACT) {
       if (by == 12) return launch2<ST, RS, 12, 0, 5>(A, grav, s);
-#if SWEEP_ZREG
-      if (by == 14) return launch2<ST, RS, 14, 0, 5>(A, grav, s);
-      if (by == 16) return launch2<ST, RS, 16, 0, 5>(A, grav, s);
-#endif
     }
     return hipErrorInvalidValue;
   }

@@ -467,6 +467,7 @@ int ramses_amd_mgdist_solve(ramses_amd_mgdist *M, const double *d_rho, double rh
   Level &L = M->lev[M->level];
   double *phi = L.u[0], *phi2 = L.u[3], *f1 = L.u[2], *f2 = L.u[1];
   const long N = (long)L.n[0] * L.n[1] * L.n[2];
+  M->phi_fresh = false;      // until this solve has gone through: an early return leaves a zeroed / half-smoothed field behind
   HCHK(hipMemsetAsync(phi, 0, sizeof(double) * L.cells, s), "memset");
   HCHK(mg_launch_rhs(d_rho, M->dense, N, fourpi, rho_tot, s), "mg rhs launch");
   RCHK(interior_copy(L, f2, M->dense, 0, s));
@@ -511,7 +512,10 @@ int ramses_amd_mgdist_get_phi(ramses_amd_mgdist *M, double *d_phi, void *stream)
 int ramses_amd_mgdist_set_phi(ramses_amd_mgdist *M, const double *d_phi, void *stream) {
   if (!M || !d_phi) return failf(RAMSES_AMD_EINVAL, "NULL argument");
   Level &L = M->lev[M->level];
-  return interior_copy(L, L.u[0], const_cast<double *>(d_phi), 0, reinterpret_cast<hipStream_t>(stream));
+  M->phi_fresh = false;
+  RCHK(interior_copy(L, L.u[0], const_cast<double *>(d_phi), 0, reinterpret_cast<hipStream_t>(stream)));
+  M->phi_fresh = true;       // the context holds the caller's potential: ramses_amd_mgdist_force may differentiate it
+  return 0;
 }
 
 // force_fine: halo of phi, then gradient_phi into the dense [3][nz][ny][nx] array d_f
@@ -674,6 +678,10 @@ int ramses_amd_mgdist_force_f90(ramses_amd_mgdist *M, int ilevel, int ngrid, con
   if (!M || !igrid || !xg || !lo || !f || !rho || !son || !diag || nvector < 1) return failf(RAMSES_AMD_EINVAL, "bad argument");
   if (ilevel != M->level) return failf(RAMSES_AMD_EINVAL, "context built for level %d, called for level %d", M->level, ilevel);
   if (!M->phi_fresh) return failf(RAMSES_AMD_EINVAL, "force_fine: the context holds no potential (ramses_amd_mgdist_multigrid_f90 first)");
+  for (int d = 0; d < 3; d++)
+    if (lo[d] != M->coords[d] * M->dims[d])
+      return failf(RAMSES_AMD_EINVAL, "force_fine: lo = (%d,%d,%d) is not the origin of this rank's brick (%d,%d,%d)", lo[0], lo[1], lo[2],
+                   M->coords[0] * M->dims[0], M->coords[1] * M->dims[1], M->coords[2] * M->dims[2]);
   const int n = 1 << ilevel;
   const long N = (long)M->dims[0] * M->dims[1] * M->dims[2];
   if ((long)ngrid * 8 != N) return failf(RAMSES_AMD_EINVAL, "the rank holds %d octs, its brick %ld cells", ngrid, N);

@@ -94,9 +94,12 @@ subroutine multigrid_fine_amd(ilevel,icount)
   if(ncpu>1.and.ilevel==levelmin.and.nboundary==0.and.nx_loc==1.and.jcoarse_max==jcoarse_min.and.kcoarse_max==kcoarse_min)then
      call ramses_amd_mgdist_multigrid(ilevel,dist,iters,err)
      if(dist)then
+        ! what the reference's per-solve setup leaves behind for an unmasked periodic box: the coarsest multigrid level is 1
+        ! (poisson/multigrid_fine_commons.f90:134-180)
+        levelmin_mg=1
         if(myid==1) print '(A,I5,A,I5,A,1pE10.3)','   ==> Level=',ilevel, ' Step=', &
              iters,' Error=',err
-        if(myid==1 .and. iters==10) print *,'WARN: Fine multigrid Poisson failed to converge...'
+        if(myid==1 .and. iters==ramses_amd_mg_maxiter) print *,'WARN: Fine multigrid Poisson failed to converge...'
         return
      end if
   end if
@@ -134,7 +137,7 @@ subroutine multigrid_fine_amd(ilevel,icount)
         ramses_amd_pois_amr_level=ilevel
         if(myid==1) print '(A,I5,A,I5,A,1pE10.3)','   ==> Level=',ilevel, ' Step=', &
              iters,' Error=',err
-        if(myid==1 .and. iters==10) print *,'WARN: Fine multigrid Poisson failed to converge...'
+        if(myid==1 .and. iters==ramses_amd_mg_maxiter) print *,'WARN: Fine multigrid Poisson failed to converge...'
         return
      end if
      ramses_amd_mg_active=.true.
@@ -175,7 +178,7 @@ subroutine multigrid_fine_amd(ilevel,icount)
 
   if(myid==1) print '(A,I5,A,I5,A,1pE10.3)','   ==> Level=',ilevel, ' Step=', &
        iters,' Error=',err
-  if(myid==1 .and. iters==10) print *,'WARN: Fine multigrid Poisson failed to converge...'
+  if(myid==1 .and. iters==ramses_amd_mg_maxiter) print *,'WARN: Fine multigrid Poisson failed to converge...'
 
 end subroutine multigrid_fine_amd
 

@@ -875,6 +875,9 @@ module ramses_amd_iface
   integer, save :: ramses_amd_amr_host_from = 1000     ! levels >= this are current on the host (synced or rebuilt) since the last device routine
   ! advanced whenever the reference may have changed the tree (refine_fine); the device copies of son/nbor/father
   ! are re-sent when their epoch is behind
+  ! MAXITER of the reference's V-cycle loop (poisson/multigrid_fine_commons.f90:34) = MAXITER of csrc/capi.hip, pois_amr.hip, mg_dist.hip
+  integer, parameter :: ramses_amd_mg_maxiter = 10
+  integer, parameter :: RAMSES_AMD_EUNSUPPORTED_CODE = -2     ! include/ramses_amd.h: RAMSES_AMD_EUNSUPPORTED
   integer, save :: ramses_amd_tree_epoch = 0
   ! AMR residency with several MPI ranks: count of build_comm calls per level (the device copy of a level's
   ! communicators is re-sent when its epoch is behind); the transport has been chosen (ramses_amd_halo_init)
@@ -1953,7 +1956,11 @@ contains
     ! coarse steps with a developed blast wave (tests/test_fast_certificate_gpu.py).  RAMSES_AMD_STRICT=1 (or
     ! RAMSES_AMD_FAST=0) selects the verification mode: the reference's operation order, bit-identical snapshots.
     ! Every other kernel (tree-walking sweep, multigrid, CG, rho_fine, exchanges) is strict in both modes.
+    ! slope_type = 3 (the positivity-preserving 27-point slope) is NOT certified in fast arithmetic: its limiter divides two
+    ! nearly equal sums, and 60 steps of sedov3d.nml at 64^3 end 8e-11 away from the reference in time step and state
+    ! (tests/test_fast_certificate_gpu.py, round 4) -- such runs take the strict build unless RAMSES_AMD_FAST=1 insists.
     p%fast_math = 1
+    if (slope_type == 3) p%fast_math = 0
     call get_environment_variable('RAMSES_AMD_STRICT', val, status=stat)
     if (stat == 0) then
        if (trim(val) == '1') p%fast_math = 0
@@ -2070,24 +2077,33 @@ contains
     err = 0.0d0
 #ifndef WITHOUTMPI
     if (ncpu == 1 .or. ilevel /= levelmin .or. ilevel > 11 .or. nboundary > 0) return
-    call get_environment_variable('RAMSES_AMD_MG_DIST', val, status=stat)
-    if (stat == 0) then
-       if (trim(val) == '0') return
-    end if
     n = 2**ilevel
     if (int(numbtot(1, ilevel), 8)*8_8 /= int(n, 8)**3) return
-    ! the box of my octs, and everybody else's
+    ! the box of my octs, and everybody else's.  RAMSES_AMD_MG_DIST=0 (the reference's driver with the device operators
+    ! instead) is read by every rank from ITS environment: the switch travels with the boxes, so that a launcher that does
+    ! not export it uniformly cannot send some ranks into this collective path and others past it
     mine = 0
-    if (active(ilevel)%ngrid > 0) then
+    call get_environment_variable('RAMSES_AMD_MG_DIST', val, status=stat)
+    if (stat == 0) then
+       if (trim(val) == '0') mine(7) = -1
+    end if
+    if (mine(7) == 0 .and. active(ilevel)%ngrid > 0) then
        rc = ramses_amd_mgdist_oct_box(ilevel, active(ilevel)%ngrid, ramses_amd_octs(ilevel), xg, int(ngridmax, 8), lo, dims)
        if (rc == 0) then
           mine(1:3) = lo
           mine(4:6) = dims
           mine(7) = 1
+       else if (rc /= RAMSES_AMD_EUNSUPPORTED_CODE) then
+          ! an oct off the level lattice (EINVAL) is a broken tree, not "does not fit"
+          call ramses_amd_fatal('multigrid_fine (distributed dense multigrid, box of the rank''s octs)')
        end if
     end if
     allocate(every(7, ncpu), rob(ncpu))
     call MPI_ALLGATHER(mine, 7, MPI_INTEGER, every, 7, MPI_INTEGER, MPI_COMM_WORLD, info)
+    if (any(every(7, :) == -1)) then
+       deallocate(every, rob)
+       return
+    end if
     fit = all(every(7, :) == 1)
     if (fit) then
        dims = every(4:6, 1)

@@ -34,7 +34,7 @@ def main():
             if path:
                 env["RAMSES_AMD_LIB"] = path
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--vcycle-level", "0",
-                                "--amr-level", "0", "--stress-steps", "0",
+                                "--amr-level", "0", "--stress-steps", "0", "--mhd-level", "0",
                                 "--steps", "20", "--warmup", "3", "--n", n] + extra, env=env, stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT, text=True)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: the whole -m gpu suite (log kept), then the tree-walking sweep probe (Z-order and scrambled oct
-# numbering; RAMSES_AMD_AMR_WALK=0: the father-cell walk inside the sweep kernel).  Everything lands in gpurun_out/.
+# numbering).  Everything lands in gpurun_out/.
 #   gpurun --timeout 900 -- 'bash scripts/gpu_check.sh'
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -9,7 +9,6 @@ tail -5 gpurun_out/pytest_gpu.txt | cut -c1-300
 {
   echo "# tree-walking sweep, fully refined 256^3 tree (scripts/amr_probe.py 8)"
   timeout 200 python scripts/amr_probe.py 8 morton 2>&1 | tail -1
-  RAMSES_AMD_AMR_WALK=0 timeout 200 python scripts/amr_probe.py 8 morton 2>&1 | tail -1
   timeout 200 python scripts/amr_probe.py 8 scrambled 2>&1 | tail -1
 } > gpurun_out/amr_probe.txt 2>&1
 cat gpurun_out/amr_probe.txt

@@ -21,7 +21,7 @@ def test_two_ranks_on_one_gpu(gpu_lib, backend):
     env = dict(os.environ, RAMSES_AMD_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29611" if backend == "gloo" else "29612", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--n", "64", "--vcycle-level", "6", "--spinup-ms", "0", "--deadline", "240", "--vcycle-deadline", "120"]
+           "--warmup", "1", "--cells", "64", "--vcycle-level", "6", "--spinup-ms", "0", "--deadline", "240", "--vcycle-deadline", "120"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert lines, (r.stdout[-1500:], r.stderr[-3000:])

@@ -35,6 +35,25 @@ def _nproc():
     return p
 
 
+class _NoStrict:
+    """monkeypatch wrapper: mode "strict" is what the program must CHOOSE, the environment stays a user's default"""
+    def __init__(self, mp):
+        self.mp = mp
+
+    def setenv(self, k, v):
+        if k != "RAMSES_AMD_STRICT":
+            self.mp.setenv(k, v)
+        else:
+            self.mp.delenv(k, raising=False)
+
+    def delenv(self, k, raising=False):
+        self.mp.delenv(k, raising=raising)
+
+
+def monkeypatch_no_strict(mp):
+    return _NoStrict(mp)
+
+
 def _run_patched(nml, level, mode, monkeypatch):
     from oracle import ramses_snapshot as rs
     monkeypatch.setenv("RAMSES_AMD", "1")
@@ -109,13 +128,15 @@ def test_default_mode_live_ab_at_128(gpu_lib, monkeypatch, riemann, slope_type, 
 
 @pytest.mark.parametrize("riemann,slope_type,scheme", [
     ("hll", 1, "muscl"), ("acoustic", 1, "muscl"), ("exact", 1, "muscl"),
-    ("llf", 3, "muscl"), ("llf", 7, "muscl"), ("llf", 8, "muscl"), ("hllc", 8, "muscl"),
+    ("llf", 7, "muscl"), ("llf", 8, "muscl"), ("hllc", 8, "muscl"),
     ("llf", 1, "plmde"), ("hllc", 2, "plmde"),
 ])
 def test_default_mode_solver_matrix_live_ab_at_64(gpu_lib, monkeypatch, riemann, slope_type, scheme):
     """The rest of the solver matrix in the DEFAULT (fast) arithmetic: hll, acoustic,
-    exact, slope types 3 / 7 / 8 and scheme='plmde', each 60 coarse steps of sedov3d.nml at 64^3 through the patched
-    program against the unmodified MPI reference run live beside it; rel-Linf per snapshot variable <= 1e-12."""
+    exact, slope types 7 / 8 and scheme='plmde', each 60 coarse steps of sedov3d.nml at 64^3 through the patched
+    program against the unmodified MPI reference run live beside it; rel-Linf per snapshot variable <= 1e-12.
+    (slope_type = 3 FAILED this certificate in round 4 -- 8e-11 in the time after 60 steps -- and is no longer fast by
+    default: test_slope_type_3_runs_strict_by_default below.)"""
     if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED)):
         pytest.skip("oracle/_ref/ramses3d_mpi / ramses3d_patch not built")
     from oracle import ramses_snapshot as rs
@@ -136,3 +157,23 @@ def test_default_mode_solver_matrix_live_ab_at_64(gpu_lib, monkeypatch, riemann,
     err = _rel(got["prim"], ref["prim"], vmax)
     print("default (fast) vs the live MPI reference, 64^3, %s slope %d %s, %d steps: rel-Linf = %s" % (riemann, slope_type, scheme, nstep, err))
     assert (err <= TOL).all(), err
+
+
+def test_slope_type_3_runs_strict_by_default(gpu_lib, monkeypatch):
+    """slope_type = 3 is outside the fast certificate (see above): the patched program must pick the strict build for it on
+    its own and then equal the reference bit for bit."""
+    if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED)):
+        pytest.skip("oracle/_ref/ramses3d_mpi / ramses3d_patch not built")
+    from oracle import ramses_snapshot as rs
+    nproc = min(_nproc(), 8)
+    nstep = 30
+    kw = dict(level=6, nstepmax=nstep, foutput=nstep, riemann="llf", slope_type=3)
+    got = _run_patched(rs.sedov3d_namelist(mem_factor=1.3, **kw), 6, "strict", monkeypatch_no_strict(monkeypatch))
+    monkeypatch.setenv("RAMSES_AMD", "0")
+    workr, outr = rs.run_reference(rs.sedov3d_namelist(mem_factor=3.0 if nproc > 1 else 1.3, **kw), binary=REF_MPI, nproc=nproc)
+    try:
+        ref = rs.load_uniform_level(os.path.join(workr, "output_00002"), 6)
+    finally:
+        shutil.rmtree(workr, ignore_errors=True)
+    assert float(np.ravel(got["info"]["t"])[0]) == float(np.ravel(ref["info"]["t"])[0])
+    assert np.array_equal(got["prim"], ref["prim"])

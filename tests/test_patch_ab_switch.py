@@ -128,3 +128,33 @@ def test_mpi_amr_run_with_load_balancing_through_the_reference_routines():
         shutil.rmtree(workr, ignore_errors=True)
     assert got[3] == ref[3] and len(set(int(l) for l in ref[0])) >= 2
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+
+
+def test_mhd_patch_with_the_switch_off_is_the_reference_program():
+    """SOLVER=mhd, PATCH=ramses_amd/patch_mhd with RAMSES_AMD=0: the shim hands every level to the reference's own
+    godunov_fine -- same snapshot as the unmodified SOLVER=mhd program (CPU only)."""
+    import shutil
+    import sys
+    ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mhd")
+    pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch_mhd_mhd")
+    if not (os.path.exists(ref) and os.path.exists(pat)):
+        pytest.skip("oracle/_ref/ramses3d_mhd / ramses3d_patch_mhd_mhd not built")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from mhd_common import mhd_namelist
+    from oracle import ramses_snapshot as rs
+    old = os.environ.get("RAMSES_AMD")
+    os.environ["RAMSES_AMD"] = "0"
+    try:
+        snaps = []
+        for binary in (ref, pat):
+            work, out = rs.run_reference(mhd_namelist(4, 6, "hlld", "hlld", 2), binary=binary)
+            try:
+                snaps.append(rs.load_uniform_level(os.path.join(work, "output_00002"), 4)["prim"])
+            finally:
+                shutil.rmtree(work, ignore_errors=True)
+    finally:
+        if old is None:
+            os.environ.pop("RAMSES_AMD", None)
+        else:
+            os.environ["RAMSES_AMD"] = old
+    assert snaps[0].shape[0] == 11 and np.array_equal(snaps[0], snaps[1])
