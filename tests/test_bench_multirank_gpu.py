@@ -24,7 +24,11 @@ def test_two_ranks_on_one_gpu(gpu_lib, backend):
            "--warmup", "1", "--cells", "64", "--vcycle-level", "6", "--spinup-ms", "0", "--deadline", "240", "--vcycle-deadline", "120"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert lines, (r.stdout[-1500:], r.stderr[-3000:])
+    if not lines:       # keep the whole story for the session log (pytest shortens long assertion messages)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_multirank_%s.err" % backend), "w") as fo:
+            fo.write(r.stdout + "\n==== stderr ====\n" + r.stderr)
+    assert lines, (r.stdout[-800:], r.stderr[-1500:])
     j = json.loads(lines[-1])
     assert j.get("error") is None, j
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"

@@ -76,6 +76,9 @@ def test_uniform_self_gravity_under_mpi_equals_the_mpi_reference(gpu_lib, level,
         shutil.rmtree(work, ignore_errors=True)
     said = "distributed over" in out
     assert said == (dist == "1"), out[-2000:]
+    # round 4: the hydro state of a uniform self-gravitating level stays on the ranks' GPUs too (cell vectors + tree resident,
+    # virtual boundaries, rho_fine's deposit and the gravity terms on the device) instead of being staged around every sweep
+    assert "AMR levels stay resident on the GPU" in out, out[-2000:]
     if dist == "1":
         assert "one per rank (dense V-cycles" in out
     assert len(got_solves) >= 3 and got_solves == ref_solves, (got_solves, ref_solves)
