@@ -1471,10 +1471,8 @@ contains
           ! every rank's GPU, both virtual-boundary exchanges, rho_fine's deposit and force_fine on the device
           if (.not. (ncpu > 1 .and. poisson .and. levelmin == nlevelmax)) ramses_amd_amr_ok = .false.
        end if
-       ! nremap > 0 with several ranks: load_balance.f90 of this directory hands the state back to the host before the octs
-       ! move and the device image is rebuilt afterwards.  On one rank load_balance is a no-op but defrag still renumbers the
-       ! octs every nremap steps (amr/amr_step.f90:109-118) with the device image kept: not covered by a test, staged path.
-       if (ncpu == 1 .and. nremap > 0) ramses_amd_amr_ok = .false.
+       ! nremap > 0: load_balance.f90 of this directory hands the state back to the host before the octs move between the
+       ! ranks (load_balance) or are renumbered (defrag, one rank too); the device image is rebuilt afterwards.
        if (ncpu > 1) then
           ! several ranks: the virtual-boundary exchanges of the hydro state run on the device too
           ! (virtual_boundaries.f90 of this directory); RAMSES_AMD_RESIDENT_AMR_MPI=0 keeps such runs staged.
