@@ -152,7 +152,7 @@ def pmc_traffic(n, world, args):
     return None, "no matching PMC profile under profiles/"
 
 
-def rank_census(rank, world, local_dev, transport_note):
+def rank_census(rank, world, local_dev, transport_note, group=None):
     """Who ran: every rank's device (ramses_amd_device_uid = hash of host name + PCI bus id, the number the Fortran shim
     compares before it brings RCCL up), so that an N-GPU line proves N ranks on N distinct devices."""
     import torch
@@ -168,7 +168,7 @@ def rank_census(rank, world, local_dev, transport_note):
             "rccl_comm_of_the_library": bool(lib().ramses_amd_rccl_ready())}
     if world > 1:
         allr = [None] * world
-        dist.all_gather_object(allr, mine)
+        dist.all_gather_object(allr, mine, group=group)     # the transport's group: after a failed RCCL self-test the default group is unusable
     else:
         allr = [mine]
     return {"world_size": world, "distinct_devices": len({r["uid"] for r in allr}), "per_rank": allr,
@@ -695,7 +695,7 @@ def main():
     chk = lev.courant_fine()
     assert chk[0] > 0 and chk[1] > 0
 
-    census = rank_census(rank, world, local_dev, transport_note)     # collective
+    census = rank_census(rank, world, local_dev, transport_note, getattr(transport, "group", None))     # collective
     if rank == 0:
         cells = n ** 3
         value = cells * world * args.steps / elapsed

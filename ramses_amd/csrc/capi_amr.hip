@@ -437,17 +437,13 @@ __global__ __launch_bounds__(256) void lvl_oct_origin_kernel(const int *igrid, i
   octorg[i] = 2L * x + (long)n * (2L * y + (long)n * 2L * z);
 }
 
-// gather of a covered level in ONE pass, one thread per oct: uold and unew of its eight cells (each read coalesced across the
-// octs of the list, octant by octant) go into the two bricks as 16-byte x-pairs, the refinement flags as byte pairs; the
-// scatter of unew is the reverse.  (The per-cell copies of octree_pack.hip write the bricks 8 bytes at a time: 2.2 of the
-// 3.5 ms of a 256^3 covered sweep before this kernel.)
-template <int NV>
-__global__ __launch_bounds__(256) void lvl_covered_gather_kernel(const int *__restrict__ igrid, const long *__restrict__ octorg, int ngrid,
-                                                                  const double *__restrict__ uold, const double *__restrict__ unew,
-                                                                  const int *__restrict__ son, long ncell, long ncoarse, long ngridmax, int n,
-                                                                  double *__restrict__ bold, double *__restrict__ bnew,
-                                                                  unsigned char *__restrict__ mask) {
-  const long N = (long)n * n * n;
+// the two maps of a covered level, one thread per oct: brick cell -> 0-based index in the cell vectors (int pairs along x) and
+// the refinement flags (byte pairs).  The dense kernel then works IN PLACE on the cell vectors through the index: no copy of
+// the level is made (the first version gathered uold / unew into bricks and scattered unew back: 2.2 of 3.5 ms at 256^3; a
+// one-pass gather / scatter: 1.5 of 2.8 ms -- as slow as the tree-walking sweep it was to replace).
+__global__ __launch_bounds__(256) void lvl_covered_index_kernel(const int *__restrict__ igrid, const long *__restrict__ octorg, int ngrid,
+                                                                 const int *__restrict__ son, long ncoarse, long ngridmax, int n,
+                                                                 int *__restrict__ cellidx, unsigned char *__restrict__ mask) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ngrid; i += gridDim.x * blockDim.x) {
     const long c0 = ncoarse + igrid[i] - 1;
     const long org = octorg[i];
@@ -455,33 +451,8 @@ __global__ __launch_bounds__(256) void lvl_covered_gather_kernel(const int *__re
     for (int r = 0; r < 4; r++) {                   // r = iy + 2 iz: the x-pair (ind = 2r, 2r + 1)
       const long b = org + (long)n * ((r & 1) + (long)n * (r >> 1));
       const long ca = c0 + (long)(2 * r) * ngridmax, cb = ca + ngridmax;
-#pragma unroll
-      for (int v = 0; v < NV; v++) {
-        *reinterpret_cast<double2 *>(bold + (long)v * N + b) = make_double2(uold[ca + (long)v * ncell], uold[cb + (long)v * ncell]);
-        *reinterpret_cast<double2 *>(bnew + (long)v * N + b) = make_double2(unew[ca + (long)v * ncell], unew[cb + (long)v * ncell]);
-      }
+      *reinterpret_cast<int2 *>(cellidx + b) = make_int2((int)ca, (int)cb);
       *reinterpret_cast<unsigned short *>(mask + b) = (unsigned short)((son[ca] > 0 ? 1 : 0) | ((son[cb] > 0 ? 1 : 0) << 8));
-    }
-  }
-}
-template <int NV>
-__global__ __launch_bounds__(256) void lvl_covered_scatter_kernel(const int *__restrict__ igrid, const long *__restrict__ octorg, int ngrid,
-                                                                   const double *__restrict__ brick, long ncell, long ncoarse, long ngridmax, int n,
-                                                                   double *__restrict__ vec) {
-  const long N = (long)n * n * n;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ngrid; i += gridDim.x * blockDim.x) {
-    const long c0 = ncoarse + igrid[i] - 1;
-    const long org = octorg[i];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const long b = org + (long)n * ((r & 1) + (long)n * (r >> 1));
-      const long ca = c0 + (long)(2 * r) * ngridmax, cb = ca + ngridmax;
-#pragma unroll
-      for (int v = 0; v < NV; v++) {
-        const double2 x = *reinterpret_cast<const double2 *>(brick + (long)v * N + b);
-        vec[ca + (long)v * ncell] = x.x;
-        vec[cb + (long)v * ncell] = x.y;
-      }
     }
   }
 }
@@ -537,7 +508,7 @@ struct AmrRes {
   bool xg_valid = false;
   Buf mp, rho, posof, mpscratch, lists;   // rho_fine: multipoles (4, ncell), the deposit (ncell), oct -> list position, scan scratch
   Buf hkeys, hvals;                       // rho_fine with several ranks: the own octs of the level by position
-  Buf cb_old, cb_new, cb_f, cb_mask, cb_org;   // godunov_fine of a fully covered level: bricks of uold / unew / f, refinement mask, oct origins
+  Buf cb_idx, cb_mask, cb_org;   // godunov_fine of a fully covered level: brick cell -> cell-vector index, refinement mask, oct origins
   long covered_sweeps = 0;                     // how many sweeps took that path (tests, ramses_amd_amrres_covered_sweeps)
   int rl_level = 0, rl_nown = 0, rl_nall = 0;   // the level ramses_amd_amrres_rho_mpi_multipole opened (its list is in `lists`)
   Buf f;                 // f(1:ncell,1:3), a copy of the host array refreshed after force_fine and after regrids
@@ -778,9 +749,9 @@ int covered_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel,
   const int st = p->slope_type;
   if (!(st == 0 || st == 1 || st == 2 || st == 7 || st == 8) || p->riemann == RAMSES_AMD_RIEMANN_EXACT) return 0;
   hipStream_t s = nullptr;
-  HCHK(R.cb_old.ensure(sizeof(double) * 5 * (size_t)N), "hipMalloc"); HCHK(R.cb_new.ensure(sizeof(double) * 5 * (size_t)N), "hipMalloc");
-  HCHK(R.cb_mask.ensure((size_t)N), "hipMalloc"); HCHK(R.cb_org.ensure(sizeof(long) * (size_t)ngrid), "hipMalloc");
-  if (R.grav) HCHK(R.cb_f.ensure(sizeof(double) * 3 * (size_t)N), "hipMalloc");
+  if ((unsigned long)R.ncell * 8ul >= (1ul << 31)) return 0;      // lane offsets into a cell vector are 31-bit byte offsets
+  HCHK(R.cb_idx.ensure(sizeof(int) * (size_t)N), "hipMalloc"); HCHK(R.cb_mask.ensure((size_t)N), "hipMalloc");
+  HCHK(R.cb_org.ensure(sizeof(long) * (size_t)ngrid), "hipMalloc");
   HCHK(hipMemsetAsync(R.err.p, 0, sizeof(int), s), "memset");
   hipLaunchKernelGGL(lvl_oct_origin_kernel, dim3((ngrid + 255) / 256), dim3(256), 0, s, R.igrid.as<int>(), ngrid, R.father.as<int>(), R.ncoarse, R.ngridmax,
                      ilevel, n, R.cb_org.as<long>(), R.err.as<int>());
@@ -791,20 +762,15 @@ int covered_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel,
   {
     int g = (ngrid + 255) / 256;
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(lvl_covered_gather_kernel<5>, dim3(g), dim3(256), 0, s, R.igrid.as<int>(), R.cb_org.as<long>(), ngrid, R.uold.as<double>(),
-                       R.unew.as<double>(), R.son.as<int>(), R.ncell, R.ncoarse, R.ngridmax, n, R.cb_old.as<double>(), R.cb_new.as<double>(),
-                       R.cb_mask.as<unsigned char>());
-    if (R.grav)       // f(1:ncell,1:3): the same kernel shape with three variables (bnew unused: gathered twice into the same brick)
-      hipLaunchKernelGGL(lvl_covered_gather_kernel<3>, dim3(g), dim3(256), 0, s, R.igrid.as<int>(), R.cb_org.as<long>(), ngrid, R.f.as<double>(),
-                         R.f.as<double>(), R.son.as<int>(), R.ncell, R.ncoarse, R.ngridmax, n, R.cb_f.as<double>(), R.cb_f.as<double>(),
-                         R.cb_mask.as<unsigned char>());
-    HCHK(hipGetLastError(), "gather of a covered level");
+    hipLaunchKernelGGL(lvl_covered_index_kernel, dim3(g), dim3(256), 0, s, R.igrid.as<int>(), R.cb_org.as<long>(), ngrid, R.son.as<int>(), R.ncoarse,
+                       R.ngridmax, n, R.cb_idx.as<int>(), R.cb_mask.as<unsigned char>());
+    HCHK(hipGetLastError(), "index of a covered level");
   }
   SweepArgs A;
-  A.uold = R.cb_old.as<double>(); A.unew = R.cb_new.as<double>(); A.grav = R.grav ? R.cb_f.as<double>() : nullptr;
-  A.mask = R.cb_mask.as<unsigned char>(); A.base = R.cb_new.as<double>();
+  A.uold = R.uold.as<double>(); A.unew = R.unew.as<double>(); A.grav = R.grav ? R.f.as<double>() : nullptr;      // the cell vectors themselves
+  A.mask = R.cb_mask.as<unsigned char>(); A.cellidx = R.cb_idx.as<int>();
   A.nx = A.ny = A.nz = n; A.ng = 0;
-  A.pitch_y = n; A.pitch_z = (long)n * n; A.pitch_var = N;
+  A.pitch_y = n; A.pitch_z = (long)n * n; A.pitch_var = R.ncell;
   A.zchunk = n < 128 ? n : 128;
   A.region = SWEEP_ALL;
   A.dt = dt; A.dx = dx; A.rdx = 1.0 / dx;
@@ -816,13 +782,6 @@ int covered_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel,
   hipError_t e = strictmode::launch_godunov_sweep(A, st, p->riemann, 12, p->scheme, 5, R.grav, s);
   if (e == hipErrorInvalidValue) { (void)hipGetLastError(); return 0; }     // a variant the masked kernels do not cover
   HCHK(e, "dense sweep of a covered level");
-  {
-    int g = (ngrid + 255) / 256;
-    if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(lvl_covered_scatter_kernel<5>, dim3(g), dim3(256), 0, s, R.igrid.as<int>(), R.cb_org.as<long>(), ngrid, R.cb_new.as<double>(),
-                       R.ncell, R.ncoarse, R.ngridmax, n, R.unew.as<double>());
-    HCHK(hipGetLastError(), "scatter of a covered level");
-  }
   R.covered_sweeps++;
   done = true;
   return 0;

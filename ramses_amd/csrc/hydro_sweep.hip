@@ -99,7 +99,13 @@ __device__ __forceinline__ int mask_load(const unsigned char *base, unsigned pla
   return (int)__builtin_amdgcn_raw_buffer_load_b8(r, off, plane_bytes, 0);
 }
 
-// MASK: the sweep of a fully covered level that has refined cells (see SweepArgs::mask / base)
+__device__ __forceinline__ unsigned index_load(const int *base, unsigned plane_ints, unsigned col) {
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(base), 0, BUF_RANGE, 0x00020000);
+  return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, col * 4u, plane_ints * 4u, 0);
+}
+
+// MASK: the sweep of a fully covered level that has refined cells, IN PLACE on the reference's cell vectors (see SweepArgs::mask /
+// cellidx): every HBM access of a lane goes through the cell index of its (plane, column), loaded three planes ahead
 template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV, int ROLE, bool MASK>
 __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *smem_raw) {
   const bool DXPOW2 = A.pow2 != 0;   // uniform
@@ -186,26 +192,27 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     else { pz = p + A.ng; }
     return (unsigned)pz * (unsigned)(A.pitch_z * 8);
   };
-  auto load_u = [&](int p, double (&u)[NV]) {
-    const unsigned pb = plane_off(p);
+  // (o: MASK only -- the lane's byte offset inside a variable's cell vector for that plane; else plane offset + column)
+  auto load_u = [&](int p, unsigned o, double (&u)[NV]) {
+    const unsigned pb = MASK ? 0u : plane_off(p), off = MASK ? o : colb;
 #pragma unroll
-    for (int n = 0; n < NV; n++) u[n] = plane_load(uold + (long)n * A.pitch_var, pb, colb);
+    for (int n = 0; n < NV; n++) u[n] = plane_load(uold + (long)n * A.pitch_var, pb, off);
   };
-  auto load_base = [&](int p, double (&u)[NV]) {   // MASK: the state the update starts from (unew)
-    const unsigned pb = plane_off(p);
+  auto load_base = [&](unsigned o, double (&u)[NV]) {   // MASK: the state the update starts from (unew, in place)
 #pragma unroll
-    for (int n = 0; n < NV; n++) u[n] = plane_load(A.base + (long)n * A.pitch_var, pb, colb);
+    for (int n = 0; n < NV; n++) u[n] = plane_load(unew + (long)n * A.pitch_var, 0u, o);
   };
   auto mask_plane = [&](int p) -> unsigned {
     const int pz = p < 0 ? p + A.nz : (p >= A.nz ? p - A.nz : p);
     return (unsigned)pz * (unsigned)(A.nx * A.ny);
   };
+  auto cell_off = [&](int p) -> unsigned { return index_load(A.cellidx, mask_plane(p), colm) * 8u; };
   int ok_zlo = 0;   // MASK: plane c-1's refinement flag of this column
-  auto load_g = [&](int p, double (&g)[3]) {
+  auto load_g = [&](int p, unsigned o, double (&g)[3]) {
     if (GRAV) {
-      const unsigned pb = plane_off(p);
+      const unsigned pb = MASK ? 0u : plane_off(p), off = MASK ? o : colb;
 #pragma unroll
-      for (int d = 0; d < 3; d++) g[d] = plane_load(grav + (long)d * A.pitch_var, pb, colb);
+      for (int d = 0; d < 3; d++) g[d] = plane_load(grav + (long)d * A.pitch_var, pb, off);
     } else {
       g[0] = g[1] = g[2] = 0.0;
     }
@@ -221,17 +228,20 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   int sa = 0, sb = 1, sc = 2;
 
   // prologue: primitives of planes z0-2 -> slot sa, z0-1 -> slot sb; c starts at z0-1
+  // MASK: cell offsets of planes c-1, c, c+1, c+2 (c = z0-1 on entry of the loop)
+  unsigned o_m1 = 0, o_0 = 0, o_p1 = 0, o_p2 = 0;
+  if (MASK) { o_m1 = cell_off(z0 - 2); o_0 = cell_off(z0 - 1); o_p1 = cell_off(z0); o_p2 = cell_off(min(z0 + 1, z1 + 1)); }
   {
     double u[NV], g[3], q[NV];
-    load_u(z0 - 2, u); load_g(z0 - 2, g);
+    load_u(z0 - 2, o_m1, u); load_g(z0 - 2, o_m1, g);
     ctoprim_cell<NV, GRAV>(u, g, dtxhalf, P, q);
 #pragma unroll
     for (int n = 0; n < NV; n++) qring[sa].v[n][ty][tx] = q[n];
-    load_u(z0 - 1, u); load_g(z0 - 1, g);
+    load_u(z0 - 1, o_0, u); load_g(z0 - 1, o_0, g);
     ctoprim_cell<NV, GRAV>(u, g, dtxhalf, P, q);
 #pragma unroll
     for (int n = 0; n < NV; n++) qring[sb].v[n][ty][tx] = q[n];
-    load_u(z0, upre); load_g(z0, gpre);
+    load_u(z0, o_p1, upre); load_g(z0, o_p1, gpre);
 #pragma unroll
     for (int n = 0; n < NV; n++) { qmz[n] = 1.0; fzlo[n] = 0.0; }
   }
@@ -273,7 +283,7 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #pragma unroll
     for (int n = 0; n < NV; n++) qring[sc].v[n][ty][tx] = qc[n];
     double ucur[NV];
-    if (r_fxz) { if (MASK) load_base(c, ucur); else load_u(c, ucur); }
+    if (r_fxz) { if (MASK) load_base(o_0, ucur); else load_u(c, 0u, ucur); }
     int okc = 0, ok_ym = 0;
     if (MASK && (ROLE == ROLE_FULL || ROLE == ROLE_HIGH)) {
       const unsigned mp = mask_plane(c);
@@ -367,7 +377,9 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     }
     // prefetch plane c+2 after the register peak of the trace and flux phase (still ~1 us ahead of its use)
     __builtin_amdgcn_sched_barrier(0);
-    { const int pn = min(c + 2, z1 + 1); load_u(pn, upre); load_g(pn, gpre); }
+    unsigned o_p3 = 0;
+    { const int pn = min(c + 2, z1 + 1); load_u(pn, o_p2, upre); load_g(pn, o_p2, gpre); }
+    if (MASK) o_p3 = cell_off(min(c + 3, z1 + 1));      // the index runs one plane ahead of the data it addresses
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // the one barrier: +y states of plane c and y fluxes of plane c-1 visible
 
@@ -415,14 +427,15 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #pragma unroll
       for (int n = 0; n < NV; n++) { partx[n] = px[n]; fyown[n] = fy[n]; }
       {
-        const unsigned pb = plane_off(c - 1);
-        const unsigned so = (c >= z0 + 1) ? colb_upd : BUF_OOB;
+        const unsigned pb = MASK ? 0u : plane_off(c - 1);
+        const unsigned so = (c >= z0 + 1) ? (MASK ? (r_upd ? o_m1 : BUF_OOB) : colb_upd) : BUF_OOB;
 #pragma unroll
         for (int n = 0; n < NV; n++) plane_store(unew + (long)n * A.pitch_var, pb, so, un[n]);
       }
     }
     // rotate the ring
     const int t = sa; sa = sb; sb = sc; sc = t;
+    if (MASK) { o_m1 = o_0; o_0 = o_p1; o_p1 = o_p2; o_p2 = o_p3; }
   }
 }
 
@@ -506,11 +519,11 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
   }
   if (nblocks == 0) return hipSuccess;
   A.nblocks = nblocks;
-  if (A.mask || A.base) {
+  if (A.mask || A.cellidx) {
     // a fully covered level with refined cells: the 12-row muscl kernels on a periodic brick (anything else: the caller
     // keeps the tree-walking sweep)
     if constexpr (ST != 3 && ST != 4 && ST != 5 && ST != 6 && RS != RIEMANN_EXACT) {
-      if (!A.mask || !A.base || A.ng != 0 || nvar != 5 || scheme != 0 || by != 12 || A.region != SWEEP_ALL) return hipErrorInvalidValue;
+      if (!A.mask || !A.cellidx || A.ng != 0 || nvar != 5 || scheme != 0 || by != 12 || A.region != SWEEP_ALL) return hipErrorInvalidValue;
       return grav ? launch3<ST, RS, 12, true, 0, 5, true>(A, s) : launch3<ST, RS, 12, false, 0, 5, true>(A, s);
     } else {
       return hipErrorInvalidValue;

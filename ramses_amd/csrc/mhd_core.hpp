@@ -119,10 +119,22 @@ struct TraceOut {
   MHD_FN const double (&get(int kind, int d) const)[8] { return st[kind][d]; }
 };
 
-template <class Sink>
-MHD_FN void trace3d_cell(const TraceIn &I, double dtdx, double dtdy, double dtdz, const MhdConst &P, Sink &O) {
-  const double smallr = P.smallr, gamma = P.gamma;
-  const double smallp = smallr * (P.smallc * P.smallc) / gamma;
+// trace3d in two steps, so that the sweep can keep 47 numbers per cell instead of the 144 of its eighteen traced states:
+//   trace_predict  the predicted cell-centred state c[0..7], the predicted face fields f[0..5] = AL, AR, BL, BR, CL, CR, the
+//                  21 half slopes of the cell-centred variables (x: r u v w p B C, y: r u v w p A C, z: r u v w p A B) and the
+//                  12 half slopes of the face fields (dALy dARy dALz dARz dBLx dBRx dBLz dBRz dCLx dCRx dCLy dCRy)   (:841-983)
+//   trace_state<KIND, D>  one traced state from those numbers, floors included (:985-1276); a source S offers c(n), f(n), h(n)
+//                  (compile-time indices: a device source loads from HBM exactly what the state needs)
+constexpr int NPRED = 8 + 6 + 21 + 12;
+struct TracePred {
+  double v[NPRED];
+  MHD_FN double c(int n) const { return v[n]; }
+  MHD_FN double f(int n) const { return v[8 + n]; }
+  MHD_FN double h(int n) const { return v[14 + n]; }
+};
+
+MHD_FN void trace_predict(const TraceIn &I, double dtdx, double dtdy, double dtdz, const MhdConst &P, TracePred &O) {
+  const double gamma = P.gamma;
   const double half = 0.5;
   double r = I.q[0], u = I.q[1], v = I.q[2], w = I.q[3], p = I.q[4], A = I.q[5], B = I.q[6], C = I.q[7];
   double AL = I.AL, AR = I.AR, BL = I.BL, BR = I.BR, CL = I.CL, CR = I.CR;
@@ -132,9 +144,6 @@ MHD_FN void trace3d_cell(const TraceIn &I, double dtdx, double dtdy, double dtdz
                dpy = half * I.dq[1][4], dAy = half * I.dq[1][5], dCy = half * I.dq[1][7];
   const double drz = half * I.dq[2][0], duz = half * I.dq[2][1], dvz = half * I.dq[2][2], dwz = half * I.dq[2][3],
                dpz = half * I.dq[2][4], dAz = half * I.dq[2][5], dBz = half * I.dq[2][6];
-  const double dALy = half * I.dALy, dARy = half * I.dARy, dALz = half * I.dALz, dARz = half * I.dARz;
-  const double dBLx = half * I.dBLx, dBRx = half * I.dBRx, dBLz = half * I.dBLz, dBRz = half * I.dBRz;
-  const double dCLx = half * I.dCLx, dCRx = half * I.dCRx, dCLy = half * I.dCLy, dCRy = half * I.dCRy;
   const double ELL = I.ELL, ELR = I.ELR, ERL = I.ERL, ERR = I.ERR;
   const double FLL = I.FLL, FLR = I.FLR, FRL = I.FRL, FRR = I.FRR;
   const double GLL = I.GLL, GLR = I.GLR, GRL = I.GRL, GRR = I.GRR;
@@ -160,33 +169,54 @@ MHD_FN void trace3d_cell(const TraceIn &I, double dtdx, double dtdy, double dtdz
   // cell-centred predicted states
   r = r + sr0; u = u + su0; v = v + sv0; w = w + sw0; p = p + sp0;
   A = 0.5 * (AL + AR); B = 0.5 * (BL + BR); C = 0.5 * (CL + CR);
+  double *o = O.v;
+  o[0] = r; o[1] = u; o[2] = v; o[3] = w; o[4] = p; o[5] = A; o[6] = B; o[7] = C;
+  o[8] = AL; o[9] = AR; o[10] = BL; o[11] = BR; o[12] = CL; o[13] = CR;
+  o[14] = drx; o[15] = dux; o[16] = dvx; o[17] = dwx; o[18] = dpx; o[19] = dBx; o[20] = dCx;
+  o[21] = dry; o[22] = duy; o[23] = dvy; o[24] = dwy; o[25] = dpy; o[26] = dAy; o[27] = dCy;
+  o[28] = drz; o[29] = duz; o[30] = dvz; o[31] = dwz; o[32] = dpz; o[33] = dAz; o[34] = dBz;
+  o[35] = half * I.dALy; o[36] = half * I.dARy; o[37] = half * I.dALz; o[38] = half * I.dARz;
+  o[39] = half * I.dBLx; o[40] = half * I.dBRx; o[41] = half * I.dBLz; o[42] = half * I.dBRz;
+  o[43] = half * I.dCLx; o[44] = half * I.dCRx; o[45] = half * I.dCLy; o[46] = half * I.dCRy;
+}
 
-#define MHD_FLOOR(S) { if ((S)[0] < smallr) (S)[0] = r; (S)[4] = fmax2(smallp, (S)[4]); }
-  // x faces
-  { double s[8]; s[0] = r - drx; s[1] = u - dux; s[2] = v - dvx; s[3] = w - dwx; s[4] = p - dpx; s[5] = AL; s[6] = B - dBx; s[7] = C - dCx; MHD_FLOOR(s) O.put(1, 0, s); }
-  { double s[8]; s[0] = r + drx; s[1] = u + dux; s[2] = v + dvx; s[3] = w + dwx; s[4] = p + dpx; s[5] = AR; s[6] = B + dBx; s[7] = C + dCx; MHD_FLOOR(s) O.put(0, 0, s); }
-  // y faces
-  { double s[8]; s[0] = r - dry; s[1] = u - duy; s[2] = v - dvy; s[3] = w - dwy; s[4] = p - dpy; s[5] = A - dAy; s[6] = BL; s[7] = C - dCy; MHD_FLOOR(s) O.put(1, 1, s); }
-  { double s[8]; s[0] = r + dry; s[1] = u + duy; s[2] = v + dvy; s[3] = w + dwy; s[4] = p + dpy; s[5] = A + dAy; s[6] = BR; s[7] = C + dCy; MHD_FLOOR(s) O.put(0, 1, s); }
-  // z faces
-  { double s[8]; s[0] = r - drz; s[1] = u - duz; s[2] = v - dvz; s[3] = w - dwz; s[4] = p - dpz; s[5] = A - dAz; s[6] = B - dBz; s[7] = CL; MHD_FLOOR(s) O.put(1, 2, s); }
-  { double s[8]; s[0] = r + drz; s[1] = u + duz; s[2] = v + dvz; s[3] = w + dwz; s[4] = p + dpz; s[5] = A + dAz; s[6] = B + dBz; s[7] = CR; MHD_FLOOR(s) O.put(0, 2, s); }
-  // x edges
-  { double s[8]; s[0] = r + (+dry + drz); s[1] = u + (+duy + duz); s[2] = v + (+dvy + dvz); s[3] = w + (+dwy + dwz); s[4] = p + (+dpy + dpz); s[5] = A + (+dAy + dAz); s[6] = BR + (+dBRz); s[7] = CR + (+dCRy); MHD_FLOOR(s) O.put(2, 0, s); }
-  { double s[8]; s[0] = r + (+dry - drz); s[1] = u + (+duy - duz); s[2] = v + (+dvy - dvz); s[3] = w + (+dwy - dwz); s[4] = p + (+dpy - dpz); s[5] = A + (+dAy - dAz); s[6] = BR + (-dBRz); s[7] = CL + (+dCLy); MHD_FLOOR(s) O.put(3, 0, s); }
-  { double s[8]; s[0] = r + (-dry + drz); s[1] = u + (-duy + duz); s[2] = v + (-dvy + dvz); s[3] = w + (-dwy + dwz); s[4] = p + (-dpy + dpz); s[5] = A + (-dAy + dAz); s[6] = BL + (+dBLz); s[7] = CR + (-dCRy); MHD_FLOOR(s) O.put(4, 0, s); }
-  { double s[8]; s[0] = r + (-dry - drz); s[1] = u + (-duy - duz); s[2] = v + (-dvy - dvz); s[3] = w + (-dwy - dwz); s[4] = p + (-dpy - dpz); s[5] = A + (-dAy - dAz); s[6] = BL + (-dBLz); s[7] = CL + (-dCLy); MHD_FLOOR(s) O.put(5, 0, s); }
-  // y edges
-  { double s[8]; s[0] = r + (+drx + drz); s[1] = u + (+dux + duz); s[2] = v + (+dvx + dvz); s[3] = w + (+dwx + dwz); s[4] = p + (+dpx + dpz); s[5] = AR + (+dARz); s[6] = B + (+dBx + dBz); s[7] = CR + (+dCRx); MHD_FLOOR(s) O.put(2, 1, s); }
-  { double s[8]; s[0] = r + (+drx - drz); s[1] = u + (+dux - duz); s[2] = v + (+dvx - dvz); s[3] = w + (+dwx - dwz); s[4] = p + (+dpx - dpz); s[5] = AR + (-dARz); s[6] = B + (+dBx - dBz); s[7] = CL + (+dCLx); MHD_FLOOR(s) O.put(3, 1, s); }
-  { double s[8]; s[0] = r + (-drx + drz); s[1] = u + (-dux + duz); s[2] = v + (-dvx + dvz); s[3] = w + (-dwx + dwz); s[4] = p + (-dpx + dpz); s[5] = AL + (+dALz); s[6] = B + (-dBx + dBz); s[7] = CR + (-dCRx); MHD_FLOOR(s) O.put(4, 1, s); }
-  { double s[8]; s[0] = r + (-drx - drz); s[1] = u + (-dux - duz); s[2] = v + (-dvx - dvz); s[3] = w + (-dwx - dwz); s[4] = p + (-dpx - dpz); s[5] = AL + (-dALz); s[6] = B + (-dBx - dBz); s[7] = CL + (-dCLx); MHD_FLOOR(s) O.put(5, 1, s); }
-  // z edges
-  { double s[8]; s[0] = r + (+drx + dry); s[1] = u + (+dux + duy); s[2] = v + (+dvx + dvy); s[3] = w + (+dwx + dwy); s[4] = p + (+dpx + dpy); s[5] = AR + (+dARy); s[6] = BR + (+dBRx); s[7] = C + (+dCx + dCy); MHD_FLOOR(s) O.put(2, 2, s); }
-  { double s[8]; s[0] = r + (+drx - dry); s[1] = u + (+dux - duy); s[2] = v + (+dvx - dvy); s[3] = w + (+dwx - dwy); s[4] = p + (+dpx - dpy); s[5] = AR + (-dARy); s[6] = BL + (+dBLx); s[7] = C + (+dCx - dCy); MHD_FLOOR(s) O.put(3, 2, s); }
-  { double s[8]; s[0] = r + (-drx + dry); s[1] = u + (-dux + duy); s[2] = v + (-dvx + dvy); s[3] = w + (-dwx + dwy); s[4] = p + (-dpx + dpy); s[5] = AL + (+dALy); s[6] = BR + (-dBRx); s[7] = C + (-dCx + dCy); MHD_FLOOR(s) O.put(4, 2, s); }
-  { double s[8]; s[0] = r + (-drx - dry); s[1] = u + (-dux - duy); s[2] = v + (-dvx - dvy); s[3] = w + (-dwx - dwy); s[4] = p + (-dpx - dpy); s[5] = AL + (-dALy); s[6] = BL + (-dBLx); s[7] = C + (-dCx - dCy); MHD_FLOOR(s) O.put(5, 2, s); }
-#undef MHD_FLOOR
+template <int KIND, int D, class Src>
+MHD_FN void trace_state(const Src &S, const MhdConst &P, double (&s)[8]) {
+  const double smallr = P.smallr;
+  const double smallp = smallr * (P.smallc * P.smallc) / P.gamma;
+  if constexpr (KIND == 1 && D == 0) { s[0] = S.c(0) - S.h(0); s[1] = S.c(1) - S.h(1); s[2] = S.c(2) - S.h(2); s[3] = S.c(3) - S.h(3); s[4] = S.c(4) - S.h(4); s[5] = S.f(0); s[6] = S.c(6) - S.h(5); s[7] = S.c(7) - S.h(6); }
+  if constexpr (KIND == 0 && D == 0) { s[0] = S.c(0) + S.h(0); s[1] = S.c(1) + S.h(1); s[2] = S.c(2) + S.h(2); s[3] = S.c(3) + S.h(3); s[4] = S.c(4) + S.h(4); s[5] = S.f(1); s[6] = S.c(6) + S.h(5); s[7] = S.c(7) + S.h(6); }
+  if constexpr (KIND == 1 && D == 1) { s[0] = S.c(0) - S.h(7); s[1] = S.c(1) - S.h(8); s[2] = S.c(2) - S.h(9); s[3] = S.c(3) - S.h(10); s[4] = S.c(4) - S.h(11); s[5] = S.c(5) - S.h(12); s[6] = S.f(2); s[7] = S.c(7) - S.h(13); }
+  if constexpr (KIND == 0 && D == 1) { s[0] = S.c(0) + S.h(7); s[1] = S.c(1) + S.h(8); s[2] = S.c(2) + S.h(9); s[3] = S.c(3) + S.h(10); s[4] = S.c(4) + S.h(11); s[5] = S.c(5) + S.h(12); s[6] = S.f(3); s[7] = S.c(7) + S.h(13); }
+  if constexpr (KIND == 1 && D == 2) { s[0] = S.c(0) - S.h(14); s[1] = S.c(1) - S.h(15); s[2] = S.c(2) - S.h(16); s[3] = S.c(3) - S.h(17); s[4] = S.c(4) - S.h(18); s[5] = S.c(5) - S.h(19); s[6] = S.c(6) - S.h(20); s[7] = S.f(4); }
+  if constexpr (KIND == 0 && D == 2) { s[0] = S.c(0) + S.h(14); s[1] = S.c(1) + S.h(15); s[2] = S.c(2) + S.h(16); s[3] = S.c(3) + S.h(17); s[4] = S.c(4) + S.h(18); s[5] = S.c(5) + S.h(19); s[6] = S.c(6) + S.h(20); s[7] = S.f(5); }
+  if constexpr (KIND == 2 && D == 0) { s[0] = S.c(0) + (+S.h(7) + S.h(14)); s[1] = S.c(1) + (+S.h(8) + S.h(15)); s[2] = S.c(2) + (+S.h(9) + S.h(16)); s[3] = S.c(3) + (+S.h(10) + S.h(17)); s[4] = S.c(4) + (+S.h(11) + S.h(18)); s[5] = S.c(5) + (+S.h(12) + S.h(19)); s[6] = S.f(3) + (+S.h(28)); s[7] = S.f(5) + (+S.h(32)); }
+  if constexpr (KIND == 3 && D == 0) { s[0] = S.c(0) + (+S.h(7) - S.h(14)); s[1] = S.c(1) + (+S.h(8) - S.h(15)); s[2] = S.c(2) + (+S.h(9) - S.h(16)); s[3] = S.c(3) + (+S.h(10) - S.h(17)); s[4] = S.c(4) + (+S.h(11) - S.h(18)); s[5] = S.c(5) + (+S.h(12) - S.h(19)); s[6] = S.f(3) + (-S.h(28)); s[7] = S.f(4) + (+S.h(31)); }
+  if constexpr (KIND == 4 && D == 0) { s[0] = S.c(0) + (-S.h(7) + S.h(14)); s[1] = S.c(1) + (-S.h(8) + S.h(15)); s[2] = S.c(2) + (-S.h(9) + S.h(16)); s[3] = S.c(3) + (-S.h(10) + S.h(17)); s[4] = S.c(4) + (-S.h(11) + S.h(18)); s[5] = S.c(5) + (-S.h(12) + S.h(19)); s[6] = S.f(2) + (+S.h(27)); s[7] = S.f(5) + (-S.h(32)); }
+  if constexpr (KIND == 5 && D == 0) { s[0] = S.c(0) + (-S.h(7) - S.h(14)); s[1] = S.c(1) + (-S.h(8) - S.h(15)); s[2] = S.c(2) + (-S.h(9) - S.h(16)); s[3] = S.c(3) + (-S.h(10) - S.h(17)); s[4] = S.c(4) + (-S.h(11) - S.h(18)); s[5] = S.c(5) + (-S.h(12) - S.h(19)); s[6] = S.f(2) + (-S.h(27)); s[7] = S.f(4) + (-S.h(31)); }
+  if constexpr (KIND == 2 && D == 1) { s[0] = S.c(0) + (+S.h(0) + S.h(14)); s[1] = S.c(1) + (+S.h(1) + S.h(15)); s[2] = S.c(2) + (+S.h(2) + S.h(16)); s[3] = S.c(3) + (+S.h(3) + S.h(17)); s[4] = S.c(4) + (+S.h(4) + S.h(18)); s[5] = S.f(1) + (+S.h(24)); s[6] = S.c(6) + (+S.h(5) + S.h(20)); s[7] = S.f(5) + (+S.h(30)); }
+  if constexpr (KIND == 3 && D == 1) { s[0] = S.c(0) + (+S.h(0) - S.h(14)); s[1] = S.c(1) + (+S.h(1) - S.h(15)); s[2] = S.c(2) + (+S.h(2) - S.h(16)); s[3] = S.c(3) + (+S.h(3) - S.h(17)); s[4] = S.c(4) + (+S.h(4) - S.h(18)); s[5] = S.f(1) + (-S.h(24)); s[6] = S.c(6) + (+S.h(5) - S.h(20)); s[7] = S.f(4) + (+S.h(29)); }
+  if constexpr (KIND == 4 && D == 1) { s[0] = S.c(0) + (-S.h(0) + S.h(14)); s[1] = S.c(1) + (-S.h(1) + S.h(15)); s[2] = S.c(2) + (-S.h(2) + S.h(16)); s[3] = S.c(3) + (-S.h(3) + S.h(17)); s[4] = S.c(4) + (-S.h(4) + S.h(18)); s[5] = S.f(0) + (+S.h(23)); s[6] = S.c(6) + (-S.h(5) + S.h(20)); s[7] = S.f(5) + (-S.h(30)); }
+  if constexpr (KIND == 5 && D == 1) { s[0] = S.c(0) + (-S.h(0) - S.h(14)); s[1] = S.c(1) + (-S.h(1) - S.h(15)); s[2] = S.c(2) + (-S.h(2) - S.h(16)); s[3] = S.c(3) + (-S.h(3) - S.h(17)); s[4] = S.c(4) + (-S.h(4) - S.h(18)); s[5] = S.f(0) + (-S.h(23)); s[6] = S.c(6) + (-S.h(5) - S.h(20)); s[7] = S.f(4) + (-S.h(29)); }
+  if constexpr (KIND == 2 && D == 2) { s[0] = S.c(0) + (+S.h(0) + S.h(7)); s[1] = S.c(1) + (+S.h(1) + S.h(8)); s[2] = S.c(2) + (+S.h(2) + S.h(9)); s[3] = S.c(3) + (+S.h(3) + S.h(10)); s[4] = S.c(4) + (+S.h(4) + S.h(11)); s[5] = S.f(1) + (+S.h(22)); s[6] = S.f(3) + (+S.h(26)); s[7] = S.c(7) + (+S.h(6) + S.h(13)); }
+  if constexpr (KIND == 3 && D == 2) { s[0] = S.c(0) + (+S.h(0) - S.h(7)); s[1] = S.c(1) + (+S.h(1) - S.h(8)); s[2] = S.c(2) + (+S.h(2) - S.h(9)); s[3] = S.c(3) + (+S.h(3) - S.h(10)); s[4] = S.c(4) + (+S.h(4) - S.h(11)); s[5] = S.f(1) + (-S.h(22)); s[6] = S.f(2) + (+S.h(25)); s[7] = S.c(7) + (+S.h(6) - S.h(13)); }
+  if constexpr (KIND == 4 && D == 2) { s[0] = S.c(0) + (-S.h(0) + S.h(7)); s[1] = S.c(1) + (-S.h(1) + S.h(8)); s[2] = S.c(2) + (-S.h(2) + S.h(9)); s[3] = S.c(3) + (-S.h(3) + S.h(10)); s[4] = S.c(4) + (-S.h(4) + S.h(11)); s[5] = S.f(0) + (+S.h(21)); s[6] = S.f(3) + (-S.h(26)); s[7] = S.c(7) + (-S.h(6) + S.h(13)); }
+  if constexpr (KIND == 5 && D == 2) { s[0] = S.c(0) + (-S.h(0) - S.h(7)); s[1] = S.c(1) + (-S.h(1) - S.h(8)); s[2] = S.c(2) + (-S.h(2) - S.h(9)); s[3] = S.c(3) + (-S.h(3) - S.h(10)); s[4] = S.c(4) + (-S.h(4) - S.h(11)); s[5] = S.f(0) + (-S.h(21)); s[6] = S.f(2) + (-S.h(25)); s[7] = S.c(7) + (-S.h(6) - S.h(13)); }
+  if (s[0] < smallr) s[0] = S.c(0);
+  s[4] = fmax2(smallp, s[4]);
+}
+
+template <class Sink>
+MHD_FN void trace3d_cell(const TraceIn &I, double dtdx, double dtdy, double dtdz, const MhdConst &P, Sink &O) {
+  TracePred T;
+  trace_predict(I, dtdx, dtdy, dtdz, P, T);
+  double s[8];
+#define MHD_PUT(K, D_) trace_state<K, D_>(T, P, s); O.put(K, D_, s);
+  MHD_PUT(1, 0) MHD_PUT(0, 0) MHD_PUT(1, 1) MHD_PUT(0, 1) MHD_PUT(1, 2) MHD_PUT(0, 2)
+  MHD_PUT(2, 0) MHD_PUT(3, 0) MHD_PUT(4, 0) MHD_PUT(5, 0)
+  MHD_PUT(2, 1) MHD_PUT(3, 1) MHD_PUT(4, 1) MHD_PUT(5, 1)
+  MHD_PUT(2, 2) MHD_PUT(3, 2) MHD_PUT(4, 2) MHD_PUT(5, 2)
+#undef MHD_PUT
 }
 
 // ---- 1-D Riemann solvers (mhd/godunov_utils.f90) ----------------------------------------------------------------------

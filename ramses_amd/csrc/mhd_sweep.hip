@@ -5,14 +5,14 @@
 // Round 4: the FIRST correct path -- one kernel per stage of mag_unsplit over the dense brick, intermediates in HBM:
 //   prim     ctoprim (:2029-2186)                                   q[8] per cell
 //   efield   trace3d's edge-centred v x B (:811-838)                E[3] per cell (its low x-, y-, z-edge)
-//   trace    uslope + trace3d (:2187-2844, :841-1276)               6 x 3 x 8 traced states per cell
-//   flux     cmpflxm x 3 (:95-157, :1308-1448)                      the five Euler fluxes through the cell's three low faces
-//   emf      cmp_mag_flx x 3 (:160-236, :1453-2028)                 the EMF on the cell's three low edges
+//   trace    uslope + trace3d's predictor (:2187-2844, :841-983)    47 numbers per cell: predicted state, face fields, half slopes
+//   flux     the traced face states rebuilt (:985-1052) + cmpflxm x 3 (:95-157, :1308-1448): the five Euler fluxes through the three low faces
+//   emf      the traced corner states rebuilt (:1054-1276) + cmp_mag_flx x 3 (:160-236, :1453-2028): the EMF on the three low edges
 //   update   godfine1's conservative update + constrained transport (mhd/godunov_fine.f90:909-1022), fused with
 //            set_unew (unew = uold + ...)
 // Every stage calls the functions of mhd_core.hpp / mhd_assemble.hpp, which tests/test_mhd_core_host.py holds bit-exact
 // against the compiled reference on the CPU; each cell, face and edge is computed ONCE (the reference recomputes a 6^3
-// stencil per oct).  HBM traffic of this version: ~3.0 kB per cell update against 176 B algorithmic (11 fields read and
+// stencil per oct).  HBM traffic of this version: ~1.6 kB per cell update against 176 B algorithmic (11 fields read and
 // written) -- the z-marching LDS pipeline of the hydro sweep (hydro_sweep.hip) is the model for the next step.
 //
 // Layout: uold / unew = [11][nz][ny][nx] doubles: rho, rho u, rho v, rho w, E, the three LEFT-face fields (uold(:,6:8)),
@@ -47,7 +47,7 @@ static int failf(int code, const char *fmt, ...) {
 namespace {
 
 constexpr int NF = 11;          // fields of uold / unew
-constexpr int NTR = 6 * 3 * 8;  // traced states per cell
+constexpr int NTR = NPRED;     // numbers the trace leaves per cell (mhd_core.hpp: trace_predict)
 
 struct MhdArgs {
   const double *uold;
@@ -113,13 +113,13 @@ __global__ __launch_bounds__(256) void mhd_efield_kernel(MhdArgs A) {
   }
 }
 
-struct TraceSink {
-  double *tr;
+// what the trace leaves in HBM: the 47 numbers of trace_predict per cell (mhd_core.hpp), plane n at pred + n * ncell
+struct PredSrc {
+  const double *pr;
   long ncell, cell;
-  __device__ __forceinline__ void put(int kind, int d, const double (&s)[8]) {
-#pragma unroll
-    for (int n = 0; n < 8; n++) tr[(long)((kind * 3 + d) * 8 + n) * ncell + cell] = s[n];
-  }
+  __device__ __forceinline__ double c(int n) const { return pr[(long)n * ncell + cell]; }
+  __device__ __forceinline__ double f(int n) const { return pr[(long)(8 + n) * ncell + cell]; }
+  __device__ __forceinline__ double h(int n) const { return pr[(long)(14 + n) * ncell + cell]; }
 };
 __global__ __launch_bounds__(128) void mhd_trace_kernel(MhdArgs A) {
   DevAcc a{{A.nx, A.ny, A.nz}, A.q, A.uold + 5 * A.ncell, A.E, A.ncell};
@@ -128,48 +128,61 @@ __global__ __launch_bounds__(128) void mhd_trace_kernel(MhdArgs A) {
     MHD_IJK(A);
     TraceIn I;
     trace_inputs(a, i, j, k, A.P, I);
-    TraceSink S{A.tr, A.ncell, c_};
-    trace3d_cell(I, dtdx, dtdx, dtdx, A.P, S);
+    TracePred T;
+    trace_predict(I, dtdx, dtdx, dtdx, A.P, T);
+#pragma unroll
+    for (int n = 0; n < NPRED; n++) A.tr[(long)n * A.ncell + c_] = T.v[n];
   }
 }
 
-__device__ __forceinline__ void load_state(const double *tr, long ncell, int kind, int d, long cell, double (&s)[8]) {
+// flux[d][0..4] through the LOW face of direction d of the cell, scaled as mag_unsplit does (fx*dt/dx, :105-111): the +d
+// state of the cell below and the -d state of the cell, each rebuilt from its predicted state and half slopes
+template <int D>
+__device__ __forceinline__ void mhd_face_flux(const MhdArgs &A, const Grid &g, int i, int j, int k, long c_) {
+  const PredSrc lo{A.tr, A.ncell, g.at(i - (D == 0), j - (D == 1), k - (D == 2))}, me{A.tr, A.ncell, c_};
+  double qm_[8], qp_[8], f[8];
+  trace_state<T_QM, D>(lo, A.P, qm_);
+  trace_state<T_QP, D>(me, A.P, qp_);
+  cmpflxm_face(qm_, qp_, D, A.P, f);
 #pragma unroll
-  for (int n = 0; n < 8; n++) s[n] = tr[(long)((kind * 3 + d) * 8 + n) * ncell + cell];
+  for (int n = 0; n < 5; n++) A.flux[(long)(D * 5 + n) * A.ncell + c_] = f[n] * A.dt / A.dx;
 }
-
-// flux[d][0..4] through the LOW face of direction d of every cell, scaled as mag_unsplit does (fx*dt/dx, :105-111)
 __global__ __launch_bounds__(128) void mhd_flux_kernel(MhdArgs A) {
   const Grid g{A.nx, A.ny, A.nz};
-  const long total = 3 * A.ncell;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    const int d = (int)(t / A.ncell);
-    const long c_ = t % A.ncell;
+  MHD_CELL_LOOP(A) {
     MHD_IJK(A);
-    const long lo = g.at(i - (d == 0), j - (d == 1), k - (d == 2));
-    double qm_[8], qp_[8], f[8];
-    load_state(A.tr, A.ncell, T_QM, d, lo, qm_);
-    load_state(A.tr, A.ncell, T_QP, d, c_, qp_);
-    cmpflxm_face(qm_, qp_, d, A.P, f);
-#pragma unroll
-    for (int n = 0; n < 5; n++) A.flux[(long)(d * 5 + n) * A.ncell + c_] = f[n] * A.dt / A.dx;
+    mhd_face_flux<0>(A, g, i, j, k, c_);
+    mhd_face_flux<1>(A, g, i, j, k, c_);
+    mhd_face_flux<2>(A, g, i, j, k, c_);
   }
 }
 
-// emf[e] on the LOW edge of direction e of every cell, scaled as mag_unsplit does (emf*dt/dx, :171-177)
+// emf[e] on the LOW edge of direction e of the cell, scaled as mag_unsplit does (emf*dt/dx, :171-177); which cell's corner
+// state plays which part: mhd_assemble.hpp edge_sources
+template <int E>
+__device__ __forceinline__ void mhd_edge_emf(const MhdArgs &A, const Grid &g, int i, int j, int k, long c_) {
+  double rt[8], rb[8], lt[8], lb[8];
+  const PredSrc me{A.tr, A.ncell, c_};
+  if constexpr (E == 2) {
+    const PredSrc a{A.tr, A.ncell, g.at(i - 1, j - 1, k)}, b{A.tr, A.ncell, g.at(i - 1, j, k)}, c{A.tr, A.ncell, g.at(i, j - 1, k)};
+    trace_state<T_QRT, 2>(a, A.P, rt); trace_state<T_QRB, 2>(b, A.P, rb); trace_state<T_QLT, 2>(c, A.P, lt);
+  } else if constexpr (E == 1) {
+    const PredSrc a{A.tr, A.ncell, g.at(i - 1, j, k - 1)}, b{A.tr, A.ncell, g.at(i, j, k - 1)}, c{A.tr, A.ncell, g.at(i - 1, j, k)};
+    trace_state<T_QRT, 1>(a, A.P, rt); trace_state<T_QLT, 1>(b, A.P, rb); trace_state<T_QRB, 1>(c, A.P, lt);
+  } else {
+    const PredSrc a{A.tr, A.ncell, g.at(i, j - 1, k - 1)}, b{A.tr, A.ncell, g.at(i, j - 1, k)}, c{A.tr, A.ncell, g.at(i, j, k - 1)};
+    trace_state<T_QRT, 0>(a, A.P, rt); trace_state<T_QRB, 0>(b, A.P, rb); trace_state<T_QLT, 0>(c, A.P, lt);
+  }
+  trace_state<T_QLB, E>(me, A.P, lb);
+  A.emf[(long)E * A.ncell + c_] = cmp_mag_flx_edge(rt, rb, lt, lb, E, A.P) * A.dt / A.dx;
+}
 __global__ __launch_bounds__(128) void mhd_emf_kernel(MhdArgs A) {
   const Grid g{A.nx, A.ny, A.nz};
-  const long total = 3 * A.ncell;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    const int e = (int)(t / A.ncell);
-    const long c_ = t % A.ncell;
+  MHD_CELL_LOOP(A) {
     MHD_IJK(A);
-    const EdgeSource src = edge_sources(e);
-    double s[4][8];
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-      load_state(A.tr, A.ncell, T_QRT + src.kind[m], e, g.at(i + src.off[m][0], j + src.off[m][1], k + src.off[m][2]), s[m]);
-    A.emf[(long)e * A.ncell + c_] = cmp_mag_flx_edge(s[0], s[1], s[2], s[3], e, A.P) * A.dt / A.dx;
+    mhd_edge_emf<0>(A, g, i, j, k, c_);
+    mhd_edge_emf<1>(A, g, i, j, k, c_);
+    mhd_edge_emf<2>(A, g, i, j, k, c_);
   }
 }
 
@@ -273,8 +286,8 @@ int ramses_amd_mhd_godunov_brick(const ramses_amd_mhd_params *p, int nx, int ny,
   hipLaunchKernelGGL(mhd_prim_kernel, dim3(grid_for(N, 256)), dim3(256), 0, s, A);
   hipLaunchKernelGGL(mhd_efield_kernel, dim3(grid_for(N, 256)), dim3(256), 0, s, A);
   hipLaunchKernelGGL(mhd_trace_kernel, dim3(grid_for(N, 128)), dim3(128), 0, s, A);
-  hipLaunchKernelGGL(mhd_flux_kernel, dim3(grid_for(3 * N, 128)), dim3(128), 0, s, A);
-  hipLaunchKernelGGL(mhd_emf_kernel, dim3(grid_for(3 * N, 128)), dim3(128), 0, s, A);
+  hipLaunchKernelGGL(mhd_flux_kernel, dim3(grid_for(N, 128)), dim3(128), 0, s, A);
+  hipLaunchKernelGGL(mhd_emf_kernel, dim3(grid_for(N, 128)), dim3(128), 0, s, A);
   hipLaunchKernelGGL(mhd_update_kernel, dim3(grid_for(N, 256)), dim3(256), 0, s, A);
   HCHK(hipGetLastError(), "MHD sweep launch");
   int bad = 0;

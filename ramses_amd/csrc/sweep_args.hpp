@@ -17,12 +17,16 @@ struct SweepArgs {
   const double *uold;
   double *unew;
   const double *grav;   // may be null
-  // A fully covered level of an AMR run (hydro/godunov_fine.f90:661-666,720-747): mask = 1 byte per cell, [nz][ny][nx],
-  // non-zero where the cell is refined (son > 0) -- fluxes through the faces of such cells are reset to zero; base = the
-  // brick the update starts from (unew: it already holds the corrections the finer level owes to this one) and lands in
-  // (unew is updated in place; uold feeds the stencil only).  Both null: the plain sweep (unew = uold + updates).
+  // A fully covered level of an AMR run (hydro/godunov_fine.f90:661-666,720-747), swept IN PLACE on the reference's cell vectors:
+  //   mask    1 byte per cell of the level's brick, [nz][ny][nx]: non-zero where the cell is refined (son > 0) -- the fluxes through
+  //           the faces of such cells are reset to zero;
+  //   cellidx the 0-based index of every brick cell in the cell vectors, [nz][ny][nx] ints: uold / grav / unew are then the cell
+  //           vectors themselves (pitch_var = ncell; pitch_y, pitch_z unused), every lane addresses them through the index of its
+  //           (plane, column), and the update starts from unew -- which already holds what the finer level owes to this one --
+  //           and lands there.
+  // Both null: the plain brick sweep (unew = uold + updates).
   const unsigned char *mask = nullptr;
-  const double *base = nullptr;
+  const int *cellidx = nullptr;
   int nx, ny, nz;       // interior cells
   int ng;               // ghost width (0 = periodic wrap in-kernel)
   long pitch_y, pitch_z, pitch_var;
