@@ -32,6 +32,8 @@ UNITS = [
     ("cg_amr.o", "cg_amr.hip", ["-ffp-contract=off"]),
     ("rho_fine.o", "rho_fine.hip", ["-ffp-contract=off"]),
     ("capi.o", "capi.hip", ["-ffp-contract=off"]),
+    ("capi_host.o", "capi_host.hip", ["-ffp-contract=off"]),
+    ("capi_tree_poisson.o", "capi_tree_poisson.hip", ["-ffp-contract=off"]),
     ("capi_mpi.o", "capi_mpi.hip", ["-ffp-contract=off"]),
     ("capi_amr.o", "capi_amr.hip", ["-ffp-contract=off"]),
     ("pois_amr.o", "pois_amr.hip", ["-ffp-contract=off"]),

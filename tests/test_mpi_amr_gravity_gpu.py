@@ -3,7 +3,7 @@
 (levelmin included) takes the reference's own multigrid driver (the MPI_ALLREDUCE of the norms stays with it) and
 every compute routine -- Gauss-Seidel fine / coarse with the masked branch, residual, norm, restriction,
 prolongation -- runs on the rank's GPU, over the rank's own octs followed by the reception octs of its neighbours
-(csrc/capi.hip: ramses_amd_mgamr_level_begin / _level_block / _fine_active).
+(csrc/capi_tree_poisson.hip: ramses_amd_mgamr_level_begin / _level_block / _fine_active).
   default (round 3)          the levels of the solve STAY on the device between the routines; make_virtual_fine_dp on phi and
                              the residual, make_virtual_mg_dp and make_reverse_mg_dp exchange the device arrays
                              (ramses_amd_mgamr_halo_*): no level array crosses PCIe after the upload -- asserted on the
