@@ -457,6 +457,83 @@ __global__ __launch_bounds__(256) void lvl_covered_index_kernel(const int *__res
   }
 }
 
+// ---- make_boundary_hydro (hydro/hydro_boundary.f90:5-269) on the resident cell vectors ------------------------------
+// One physical boundary region of one level: every cell of a boundary oct takes the state of its reference cell -- the
+// cell ind_ref(ind) of the oct son(nbor(oct, inbor)) next to it towards the box -- mirrored (reflexive walls: the normal
+// momentum changes sign) or copied with the optional no_inflow clamp (free boundaries; the kinetic energy is taken out
+// before and put back after, as the reference does).  The reference walks the region's oct list in chunks of NVECTOR octs
+// and, inside a chunk, cell index by cell index -- gather the reference cells of the whole chunk, then scatter (:119-262) --
+// writing in place.  A boundary oct whose reference oct is itself an oct of the SAME region (regions two octs deep)
+// therefore reads that oct's NEW state if the oct sits in an earlier chunk, or in the same chunk and the reference cell
+// has a smaller cell index than the cell being filled; its OLD state otherwise.  The device reproduces exactly that:
+// pos[] holds the position of every oct of the region in the list, a thread follows the chain of reference cells while
+// they are NEW by that rule, reads the state the region had on entry at the end of the chain and applies the boundary
+// rule once per link.
+struct BndArgs {
+  double *uold, *tmp;
+  const int *son, *nbor, *list;
+  int *pos;
+  int n, nvar, type, no_inflow, nvector;
+  long ncell, ncoarse, ngridmax;
+  double smallr;
+};
+__global__ __launch_bounds__(256) void bnd_mark_kernel(BndArgs A, int clear) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += gridDim.x * blockDim.x) A.pos[A.list[i] - 1] = clear ? 0 : i + 1;
+}
+__global__ __launch_bounds__(256) void bnd_compute_kernel(BndArgs A) {
+  const int dir = A.type % 10, kind = A.type / 10;          // boundary_dir 1..6; 0 reflexive, 1 free
+  const int axis = (dir - 1) >> 1, high = (dir - 1) & 1;    // the wall's normal; low (x < 0 side) or high wall
+  const int inbor = high ? 2 * axis + 1 : 2 * axis + 2;     // :59-64: towards the box
+  const int bit = 1 << axis;
+  const long total = (long)A.n * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ind = (int)(t / A.n), i = (int)(t % A.n);
+    int oct = A.list[i], cind = ind, napply = 0, ref = 0, rind = 0;
+    for (;;) {
+      const int fc = A.nbor[(long)(inbor - 1) * A.ngridmax + oct - 1];
+      ref = fc > 0 ? A.son[fc - 1] : 0;
+      // ind_ref (:66-87): reflexive walls mirror the octant across the wall, free boundaries take the reference oct's layer next to the wall
+      rind = kind == 0 ? (cind ^ bit) : (high ? (cind | bit) : (cind & ~bit));
+      napply++;
+      if (ref > 0 && napply < 64) {
+        const int pr = A.pos[ref - 1];
+        if (pr != 0) {
+          const int chunk_ref = (pr - 1) / A.nvector, chunk_oct = (A.pos[oct - 1] - 1) / A.nvector;
+          if (chunk_ref < chunk_oct || (chunk_ref == chunk_oct && rind < cind)) { oct = ref; cind = rind; continue; }
+        }
+      }
+      break;
+    }
+    const long cref = A.ncoarse + (long)rind * A.ngridmax + ref;          // 1-based, as the reference computes it
+    double uu[8];
+    for (int v = 0; v < A.nvar; v++) uu[v] = A.uold[(long)v * A.ncell + cref - 1];
+    for (int a = 0; a < napply; a++) {
+      if (kind == 0) {
+        uu[1 + axis] = uu[1 + axis] * -1.0;
+      } else {
+        double ekin = 0.0;
+        double d = __builtin_fmax(uu[0], A.smallr);
+        for (int k = 0; k < 3; k++) { const double vel = uu[1 + k] / d; ekin = ekin + 0.5 * d * (vel * vel); }
+        uu[4] = uu[4] - ekin;
+        if (A.no_inflow) uu[1 + axis] = high ? __builtin_fmax(0.0, uu[1 + axis]) : __builtin_fmin(0.0, uu[1 + axis]);
+        ekin = 0.0;
+        d = __builtin_fmax(uu[0], A.smallr);
+        for (int k = 0; k < 3; k++) { const double vel = uu[1 + k] / d; ekin = ekin + 0.5 * d * (vel * vel); }
+        uu[4] = uu[4] + ekin;
+      }
+    }
+    for (int v = 0; v < A.nvar; v++) A.tmp[(long)v * total + t] = uu[v];
+  }
+}
+__global__ __launch_bounds__(256) void bnd_store_kernel(BndArgs A) {
+  const long total = (long)A.n * 8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ind = (int)(t / A.n), i = (int)(t % A.n);
+    const long c = A.ncoarse + (long)ind * A.ngridmax + A.list[i] - 1;
+    for (int v = 0; v < A.nvar; v++) A.uold[(long)v * A.ncell + c] = A.tmp[(long)v * total + t];
+  }
+}
+
 struct Buf {
   void *p = nullptr;
   size_t cap = 0;
@@ -513,6 +590,8 @@ struct AmrRes {
   int rl_level = 0, rl_nown = 0, rl_nall = 0;   // the level ramses_amd_amrres_rho_mpi_multipole opened (its list is in `lists`)
   Buf f;                 // f(1:ncell,1:3), a copy of the host array refreshed after force_fine and after regrids
   bool grav = false;
+  Buf bnd_list, bnd_pos, bnd_tmp;   // make_boundary_hydro: the regions' oct lists, oct -> position in its region, the new states
+  bool bnd_pos_clean = false;
   Buf divu, enew;        // pressure_fix: the reference's divu / enew work vectors (device only: scratch of one step)
   bool pfix = false;
   std::vector<double> hpack;
@@ -1184,6 +1263,60 @@ int halo_unpack(AmrRes &R, CommLevel &L, const HaloSpec &S) {
   return 0;
 }
 }  // namespace
+
+// make_boundary_hydro(ilevel) of a run with physical boundaries (hydro/hydro_boundary.f90:5-269): nregion regions in the
+// reference's order (a later region may read what an earlier one wrote: corners), btype = boundary_type(1:nregion)
+// (1-6 reflexive, 11-16 free), ngrid[r] octs of region r on this level, igrid = the regions' lists one after the other,
+// nvector = the reference build's NVECTOR (the chunking of its loop decides what a region two octs deep reads).
+int ramses_amd_amrres_boundary_hydro(int nregion, const int *btype, const int *ngrid, const int *igrid, int no_inflow, double smallr,
+                                     int nvector) {
+  AmrRes &R = g_ar;
+  if (!R.valid) return failf(RAMSES_AMD_EINVAL, "no resident AMR state (ramses_amd_amrres_load)");
+  if (nregion < 0 || (nregion > 0 && (!btype || !ngrid))) return failf(RAMSES_AMD_EINVAL, "bad boundary description");
+  if (R.nvar > 8) return failf(RAMSES_AMD_EUNSUPPORTED, "make_boundary_hydro on the device: nvar <= 8 (got %d)", R.nvar);
+  if (nvector < 1) return failf(RAMSES_AMD_EINVAL, "nvector must be >= 1");
+  long ntot = 0;
+  int nmax = 0;
+  for (int r = 0; r < nregion; r++) {
+    const int k = btype[r] / 10, d = btype[r] % 10;
+    if ((k != 0 && k != 1) || d < 1 || d > 6)
+      return failf(RAMSES_AMD_EUNSUPPORTED, "make_boundary_hydro on the device: reflexive (1-6) and free (11-16) boundaries (got boundary_type %d)", btype[r]);
+    if (ngrid[r] < 0) return failf(RAMSES_AMD_EINVAL, "bad boundary oct count");
+    ntot += ngrid[r];
+    if (ngrid[r] > nmax) nmax = ngrid[r];
+  }
+  if (ntot == 0) return 0;
+  if (!igrid) return failf(RAMSES_AMD_EINVAL, "NULL oct list");
+  HCHK(R.bnd_list.ensure(sizeof(int) * (size_t)ntot), "hipMalloc boundary octs");
+  HCHK(R.bnd_tmp.ensure(sizeof(double) * (size_t)nmax * 8 * (size_t)R.nvar), "hipMalloc boundary states");
+  if (!R.bnd_pos.p || R.bnd_pos.cap < sizeof(int) * (size_t)R.ngridmax) R.bnd_pos_clean = false;
+  HCHK(R.bnd_pos.ensure(sizeof(int) * (size_t)R.ngridmax), "hipMalloc boundary positions");
+  if (!R.bnd_pos_clean) {
+    HCHK(hipMemsetAsync(R.bnd_pos.p, 0, sizeof(int) * (size_t)R.ngridmax, nullptr), "memset");
+    R.bnd_pos_clean = true;
+  }
+  HCHK(hipMemcpyAsync(R.bnd_list.p, igrid, sizeof(int) * (size_t)ntot, hipMemcpyHostToDevice, nullptr), "H2D boundary octs");
+  BndArgs A;
+  A.uold = R.uold.as<double>(); A.tmp = R.bnd_tmp.as<double>();
+  A.son = R.son.as<int>(); A.nbor = R.nbor.as<int>(); A.pos = R.bnd_pos.as<int>();
+  A.nvar = R.nvar; A.no_inflow = no_inflow; A.nvector = nvector; A.ncell = R.ncell; A.ncoarse = R.ncoarse; A.ngridmax = R.ngridmax; A.smallr = smallr;
+  long off = 0;
+  for (int r = 0; r < nregion; r++) {
+    const int n = ngrid[r];
+    if (n > 0) {
+      A.list = R.bnd_list.as<int>() + off; A.n = n; A.type = btype[r];
+      hipLaunchKernelGGL(bnd_mark_kernel, dim3(grid_for(n)), dim3(256), 0, nullptr, A, 0);
+      hipLaunchKernelGGL(bnd_compute_kernel, dim3(grid_for((long)n * 8)), dim3(256), 0, nullptr, A);
+      hipLaunchKernelGGL(bnd_store_kernel, dim3(grid_for((long)n * 8)), dim3(256), 0, nullptr, A);
+      hipLaunchKernelGGL(bnd_mark_kernel, dim3(grid_for(n)), dim3(256), 0, nullptr, A, 1);
+    }
+    off += n;
+  }
+  HCHK(hipGetLastError(), "make_boundary_hydro launch");
+  // the list buffer is reused by the next call: the copy above must not overtake these launches, and the caller's list may go
+  HCHK(hipStreamSynchronize(nullptr), "sync");
+  return 0;
+}
 
 // set_unew's second loop: unew (and divu, enew with pressure_fix) of the virtual octs = 0
 int ramses_amd_amrres_zero_unew_virtual(int ilevel) {

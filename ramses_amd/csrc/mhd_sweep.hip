@@ -25,6 +25,8 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 #include "../../include/ramses_amd.h"
 #include "mhd_assemble.hpp"
@@ -113,13 +115,18 @@ __global__ __launch_bounds__(256) void mhd_efield_kernel(MhdArgs A) {
   }
 }
 
-// what the trace leaves in HBM: the 47 numbers of trace_predict per cell (mhd_core.hpp), plane n at pred + n * ncell
+// what the trace leaves in HBM: the 47 numbers of trace_predict per cell (mhd_core.hpp), the cells in groups of 64 (one
+// wavefront of the trace kernel): number n of cell c at tr[(c / 64) * 47 * 64 + n * 64 + c % 64].  A wavefront writes ONE
+// contiguous 24 KB piece, the 47 addresses of a cell differ by constants, and what the flux and EMF kernels read of a cell
+// and of its x neighbour sits in the same piece (47 separate planes, the first layout: 12.2 instead of 10.0 ms per sweep at
+// 256^3, profiles/r04_mhd_prof.txt)
+__device__ __forceinline__ long pred_at(int n, long cell) { return (cell >> 6) * (long)(NPRED * 64) + (long)n * 64 + (cell & 63); }
 struct PredSrc {
   const double *pr;
-  long ncell, cell;
-  __device__ __forceinline__ double c(int n) const { return pr[(long)n * ncell + cell]; }
-  __device__ __forceinline__ double f(int n) const { return pr[(long)(8 + n) * ncell + cell]; }
-  __device__ __forceinline__ double h(int n) const { return pr[(long)(14 + n) * ncell + cell]; }
+  long cell;
+  __device__ __forceinline__ double c(int n) const { return pr[pred_at(n, cell)]; }
+  __device__ __forceinline__ double f(int n) const { return pr[pred_at(8 + n, cell)]; }
+  __device__ __forceinline__ double h(int n) const { return pr[pred_at(14 + n, cell)]; }
 };
 __global__ __launch_bounds__(128) void mhd_trace_kernel(MhdArgs A) {
   DevAcc a{{A.nx, A.ny, A.nz}, A.q, A.uold + 5 * A.ncell, A.E, A.ncell};
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(128) void mhd_trace_kernel(MhdArgs A) {
     TracePred T;
     trace_predict(I, dtdx, dtdx, dtdx, A.P, T);
 #pragma unroll
-    for (int n = 0; n < NPRED; n++) A.tr[(long)n * A.ncell + c_] = T.v[n];
+    for (int n = 0; n < NPRED; n++) A.tr[pred_at(n, c_)] = T.v[n];
   }
 }
 
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(128) void mhd_trace_kernel(MhdArgs A) {
 // state of the cell below and the -d state of the cell, each rebuilt from its predicted state and half slopes
 template <int D>
 __device__ __forceinline__ void mhd_face_flux(const MhdArgs &A, const Grid &g, int i, int j, int k, long c_) {
-  const PredSrc lo{A.tr, A.ncell, g.at(i - (D == 0), j - (D == 1), k - (D == 2))}, me{A.tr, A.ncell, c_};
+  const PredSrc lo{A.tr, g.at(i - (D == 0), j - (D == 1), k - (D == 2))}, me{A.tr, c_};
   double qm_[8], qp_[8], f[8];
   trace_state<T_QM, D>(lo, A.P, qm_);
   trace_state<T_QP, D>(me, A.P, qp_);
@@ -162,15 +169,16 @@ __global__ __launch_bounds__(128) void mhd_flux_kernel(MhdArgs A) {
 template <int E>
 __device__ __forceinline__ void mhd_edge_emf(const MhdArgs &A, const Grid &g, int i, int j, int k, long c_) {
   double rt[8], rb[8], lt[8], lb[8];
-  const PredSrc me{A.tr, A.ncell, c_};
+  using Src = PredSrc;
+  const Src me{A.tr, c_};
   if constexpr (E == 2) {
-    const PredSrc a{A.tr, A.ncell, g.at(i - 1, j - 1, k)}, b{A.tr, A.ncell, g.at(i - 1, j, k)}, c{A.tr, A.ncell, g.at(i, j - 1, k)};
+    const Src a{A.tr, g.at(i - 1, j - 1, k)}, b{A.tr, g.at(i - 1, j, k)}, c{A.tr, g.at(i, j - 1, k)};
     trace_state<T_QRT, 2>(a, A.P, rt); trace_state<T_QRB, 2>(b, A.P, rb); trace_state<T_QLT, 2>(c, A.P, lt);
   } else if constexpr (E == 1) {
-    const PredSrc a{A.tr, A.ncell, g.at(i - 1, j, k - 1)}, b{A.tr, A.ncell, g.at(i, j, k - 1)}, c{A.tr, A.ncell, g.at(i - 1, j, k)};
+    const Src a{A.tr, g.at(i - 1, j, k - 1)}, b{A.tr, g.at(i, j, k - 1)}, c{A.tr, g.at(i - 1, j, k)};
     trace_state<T_QRT, 1>(a, A.P, rt); trace_state<T_QLT, 1>(b, A.P, rb); trace_state<T_QRB, 1>(c, A.P, lt);
   } else {
-    const PredSrc a{A.tr, A.ncell, g.at(i, j - 1, k - 1)}, b{A.tr, A.ncell, g.at(i, j - 1, k)}, c{A.tr, A.ncell, g.at(i, j, k - 1)};
+    const Src a{A.tr, g.at(i, j - 1, k - 1)}, b{A.tr, g.at(i, j - 1, k)}, c{A.tr, g.at(i, j, k - 1)};
     trace_state<T_QRT, 0>(a, A.P, rt); trace_state<T_QRB, 0>(b, A.P, rb); trace_state<T_QLT, 0>(c, A.P, lt);
   }
   trace_state<T_QLB, E>(me, A.P, lb);
@@ -257,7 +265,7 @@ extern "C" {
 
 int64_t ramses_amd_mhd_workspace_bytes(int nx, int ny, int nz) {
   if (nx < 1 || ny < 1 || nz < 1) return failf(RAMSES_AMD_EINVAL, "bad brick extents");
-  return (int64_t)sizeof(double) * WORK_DOUBLES_PER_CELL * nx * ny * nz + 256;
+  return (int64_t)sizeof(double) * (WORK_DOUBLES_PER_CELL * nx * ny * nz + NTR * 64) + 256;   // (the trace's last block of 64 cells)
 }
 
 // One MHD sweep of a periodic nx x ny x nz level: d_unew = d_uold advanced by dt (set_unew + godunov_fine of SOLVER=mhd).
@@ -277,7 +285,7 @@ int ramses_amd_mhd_godunov_brick(const ramses_amd_mhd_params *p, int nx, int ny,
   double *w = reinterpret_cast<double *>(d_work);
   A.q = w; w += 8 * N;
   A.E = w; w += 3 * N;
-  A.tr = w; w += (long)NTR * N;
+  A.tr = w; w += (long)NTR * ((N + 63) / 64 * 64);
   A.flux = w; w += 15 * N;
   A.emf = w; w += 3 * N;
   A.bad = reinterpret_cast<int *>(w);

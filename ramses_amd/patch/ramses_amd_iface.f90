@@ -659,6 +659,14 @@ module ramses_amd_iface
        real(c_double) :: uold(*)
        integer(c_int) :: rc
      end function ramses_amd_amrres_load_level
+     function ramses_amd_amrres_boundary_hydro(nregion, btype, ngrid, igrid, no_inflow, smallr, nvector) &
+          & bind(C, name='ramses_amd_amrres_boundary_hydro') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: nregion, no_inflow, nvector
+       integer(c_int) :: btype(*), ngrid(*), igrid(*)
+       real(c_double), value :: smallr
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_boundary_hydro
      function ramses_amd_amrres_sync_all(uold) bind(C, name='ramses_amd_amrres_sync_all') result(rc)
        import :: c_int, c_double
        real(c_double) :: uold(*)
@@ -1463,12 +1471,26 @@ contains
        if (stat == 0) then
           if (trim(val) == '0') ramses_amd_amr_ok = .false.
        end if
-       if (nboundary > 0) ramses_amd_amr_ok = .false.
-       if (levelmin >= nlevelmax) then
+       if (nboundary > 0) then
+          ! physical boundaries: make_boundary_hydro runs on the resident cell vectors (hydro_boundary.f90 of this
+          ! directory) for reflexive and free boundaries of a hydro-only run; imposed boundaries (boundana) and
+          ! self-gravity between walls keep the staging path.  RAMSES_AMD_RESIDENT_WALLS=0: staging path.
+          if (.not. simple_boundary .or. poisson) ramses_amd_amr_ok = .false.
+          do l = 1, nboundary
+             if (boundary_type(l) / 10 > 1 .or. mod(boundary_type(l), 10) < 1 .or. mod(boundary_type(l), 10) > 6) &
+                  & ramses_amd_amr_ok = .false.
+          end do
+          call get_environment_variable('RAMSES_AMD_RESIDENT_WALLS', val, status=stat)
+          if (stat == 0) then
+             if (trim(val) == '0') ramses_amd_amr_ok = .false.
+          end if
+       end if
+       if (levelmin >= nlevelmax .and. .not. (nboundary > 0 .and. levelmin == nlevelmax)) then
           ! one uniform level: hydro-only runs have the brick paths (ramses_amd_resident, ramses_amd_mpi_resident), a
           ! self-gravitating run on one rank too; with SEVERAL ranks and self-gravity there is no brick path (round 4,
           ! VERDICT round 3 missing #3) and the level takes this one: cell vectors, tree and communicators resident on
           ! every rank's GPU, both virtual-boundary exchanges, rho_fine's deposit and force_fine on the device
+          ! (a single level between walls has no brick path either and takes this one too)
           if (.not. (ncpu > 1 .and. poisson .and. levelmin == nlevelmax)) ramses_amd_amr_ok = .false.
        end if
        ! nremap > 0: load_balance.f90 of this directory hands the state back to the host before the octs move between the
@@ -1575,8 +1597,9 @@ contains
        if (rc /= 0) call ramses_amd_fatal('AMR residency (tree)')
        do l = ramses_amd_amr_reload_from, nlevelmax
           if (numbtot(1, l) > 0) then
-             if (ncpu > 1) then
-                ! the virtual octs too: the host has just exchanged them itself (amr/amr_step.f90:49-62)
+             if (ncpu > 1 .or. nboundary > 0) then
+                ! the virtual octs too: the host has just exchanged them itself (amr/amr_step.f90:49-62); the boundary
+                ! octs too: the host has just filled them (:70)
                 call ramses_amd_amr_level_octs(l, nl, list)
                 rc = ramses_amd_amrres_load_level(nl, list, uold)
                 deallocate(list)
@@ -1627,8 +1650,9 @@ contains
     if (ilevel < levelmin) return      ! fully refined coarse levels: nothing is created, no hydro data is read
     do l = max(ilevel - 1, levelmin), min(nlevelmax, ramses_amd_amr_host_from - 1)
        if (numbtot(1, l) > 0) then
-          if (ncpu > 1) then
-             ! the virtual octs too: refine_fine interpolates the new virtual octs from them
+          if (ncpu > 1 .or. nboundary > 0) then
+             ! the virtual octs too: refine_fine interpolates the new virtual octs from them (and the new boundary octs from
+             ! the boundary octs)
              call ramses_amd_amr_level_octs(l, nl, list)
              rc = ramses_amd_amrres_sync_level(nl, list, uold)
              deallocate(list)
@@ -1672,7 +1696,8 @@ contains
 
   !---------------------------------------------------------------------------
   ! AMR residency with several MPI ranks.  The octs of a level whose cells a rank holds: its own
-  ! (active) followed by the virtual ones (reception lists of every peer).
+  ! (active) followed by the virtual ones (reception lists of every peer) and by the octs of the
+  ! physical boundary regions (boundary(1:nboundary,ilevel)).
   !---------------------------------------------------------------------------
   subroutine ramses_amd_amr_level_octs(ilevel, n, list)
     use amr_commons
@@ -1683,6 +1708,9 @@ contains
     n = active(ilevel)%ngrid
     do icpu = 1, ncpu
        n = n + reception(icpu, ilevel)%ngrid
+    end do
+    do icpu = 1, nboundary
+       n = n + boundary(icpu, ilevel)%ngrid
     end do
     allocate(list(max(n, 1)))
     do i = 1, active(ilevel)%ngrid
@@ -1695,7 +1723,44 @@ contains
        end do
        n = n + reception(icpu, ilevel)%ngrid
     end do
+    do icpu = 1, nboundary
+       do i = 1, boundary(icpu, ilevel)%ngrid
+          list(n + i) = boundary(icpu, ilevel)%igrid(i)
+       end do
+       n = n + boundary(icpu, ilevel)%ngrid
+    end do
   end subroutine ramses_amd_amr_level_octs
+
+  !---------------------------------------------------------------------------
+  ! make_boundary_hydro(ilevel) on the resident cell vectors (hydro/hydro_boundary.f90:5-269): the regions' oct lists
+  ! go down one after the other, the device walks them in the reference's order
+  !---------------------------------------------------------------------------
+  subroutine ramses_amd_amr_boundary(ilevel)
+    use amr_commons
+    use hydro_parameters, only: smallr
+    integer, intent(in) :: ilevel
+    integer :: ib, i, n, rc, flag
+    integer, allocatable :: cnt(:), list(:)
+    n = 0
+    do ib = 1, nboundary
+       n = n + boundary(ib, ilevel)%ngrid
+    end do
+    if (n == 0) return
+    allocate(cnt(nboundary), list(n))
+    n = 0
+    do ib = 1, nboundary
+       cnt(ib) = boundary(ib, ilevel)%ngrid
+       do i = 1, cnt(ib)
+          list(n + i) = boundary(ib, ilevel)%igrid(i)
+       end do
+       n = n + cnt(ib)
+    end do
+    flag = 0
+    if (no_inflow) flag = 1
+    rc = ramses_amd_amrres_boundary_hydro(nboundary, boundary_type, cnt, list, flag, smallr, nvector)
+    if (rc /= 0) call ramses_amd_fatal('make_boundary_hydro')
+    deallocate(cnt, list)
+  end subroutine ramses_amd_amr_boundary
 
 #ifndef WITHOUTMPI
   !---------------------------------------------------------------------------

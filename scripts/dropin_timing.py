@@ -214,8 +214,10 @@ if __name__ == "__main__":
         if which in ("all", "ref"):
             run_mpi("reference (MPI)", ref, {"RAMSES_AMD": "0"}, level, nstep, nproc)
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "c5":
-        # BASELINE config C5 (sedov3d.nml, AMR, hydro only) at levels lmin..lmax, nstep coarse steps
+    if len(sys.argv) > 1 and sys.argv[1] in ("c5", "c5walls"):
+        # BASELINE config C5 (sedov3d.nml, AMR, hydro only) at levels lmin..lmax, nstep coarse steps;
+        # c5walls: the same run between six physical boundaries (x, z reflexive, y free): make_boundary_hydro on the device
+        walls = sys.argv[1] == "c5walls"
         lmin, lmax, nstep = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
         which = sys.argv[5] if len(sys.argv) > 5 else "all"
         import importlib.util
@@ -224,6 +226,19 @@ if __name__ == "__main__":
         spec.loader.exec_module(mkb)
         ngt = {7: 900000, 8: 4000000}.get(lmin, 300000)
         nml = mkb.c5_namelist(lmin, lmax, nstep, ngt).replace("foutput=%d" % nstep, "foutput=1000")
+        if walls:
+            nml += """
+&BOUNDARY_PARAMS
+nboundary=6
+ibound_min=-1,+1,-1,-1,-1,-1
+ibound_max=-1,+1,+1,+1,+1,+1
+jbound_min= 0, 0,-1,+1,-1,-1
+jbound_max= 0, 0,-1,+1,+1,+1
+kbound_min= 0, 0, 0, 0,-1,+1
+kbound_max= 0, 0, 0, 0,-1,+1
+bound_type= 1, 1, 2, 2, 1, 1
+/
+"""
 
         def run_c5(tag, binary, env):
             old = {k: os.environ.get(k) for k in env}
@@ -260,7 +275,8 @@ if __name__ == "__main__":
             run_c5("patched, state and tree resident on the GPU, RAMSES_AMD_PROFILE=1", pat, {"RAMSES_AMD": "1", "RAMSES_AMD_PROFILE": "1"})
         if which in ("all", "gpu"):
             run_c5("patched, state and tree resident on the GPU", pat, {"RAMSES_AMD": "1"})
-            run_c5("patched, arrays staged around every godunov_fine (round 1 path)", pat, {"RAMSES_AMD": "1", "RAMSES_AMD_RESIDENT_AMR": "0"})
+            run_c5("patched, arrays staged around every godunov_fine (round 1 path)", pat,
+                   {"RAMSES_AMD": "1", "RAMSES_AMD_RESIDENT_WALLS" if walls else "RAMSES_AMD_RESIDENT_AMR": "0"})
         if which in ("all", "ref"):
             run_c5("reference (1 core)", ref, {"RAMSES_AMD": "0"})
         sys.exit(0)
@@ -274,6 +290,19 @@ if __name__ == "__main__":
         spec.loader.exec_module(mkb)
         ngt = {7: 2000000, 8: 8000000}.get(lmin, 600000)
         nml = mkb.c5_namelist(lmin, lmax, nstep, ngt).replace("foutput=%d" % nstep, "foutput=1000")
+        if walls:
+            nml += """
+&BOUNDARY_PARAMS
+nboundary=6
+ibound_min=-1,+1,-1,-1,-1,-1
+ibound_max=-1,+1,+1,+1,+1,+1
+jbound_min= 0, 0,-1,+1,-1,-1
+jbound_max= 0, 0,-1,+1,+1,+1
+kbound_min= 0, 0, 0, 0,-1,+1
+kbound_max= 0, 0, 0, 0,-1,+1
+bound_type= 1, 1, 2, 2, 1, 1
+/
+"""
 
         def run_c5mpi(tag, binary, env):
             old = {k: os.environ.get(k) for k in env}
