@@ -1473,9 +1473,12 @@ contains
        end if
        if (nboundary > 0) then
           ! physical boundaries: make_boundary_hydro runs on the resident cell vectors (hydro_boundary.f90 of this
-          ! directory) for reflexive and free boundaries of a hydro-only run; imposed boundaries (boundana) and
-          ! self-gravity between walls keep the staging path.  RAMSES_AMD_RESIDENT_WALLS=0: staging path.
-          if (.not. simple_boundary .or. poisson) ramses_amd_amr_ok = .false.
+          ! directory) for reflexive and free boundaries; imposed boundaries (boundana) keep the staging path.  With
+          ! self-gravity the density goes back for the reference's rho_fine, the solve takes the routines of the
+          ! multigrid shims under the reference's driver (Dirichlet set-up on the host), force_fine +
+          ! make_boundary_force stay the reference's and f of the level's octs, boundary octs included, is mirrored.
+          ! RAMSES_AMD_RESIDENT_WALLS=0: staging path.
+          if (.not. simple_boundary) ramses_amd_amr_ok = .false.
           do l = 1, nboundary
              if (boundary_type(l) / 10 > 1 .or. mod(boundary_type(l), 10) < 1 .or. mod(boundary_type(l), 10) > 6) &
                   & ramses_amd_amr_ok = .false.
@@ -1621,9 +1624,9 @@ contains
     integer, intent(in) :: ilevel
     integer :: rc, nl
     integer, allocatable :: list(:)
-    if (ncpu > 1) then
-       ! the virtual octs too (force_fine has exchanged f itself, poisson/force_fine.f90:107,137): the sweep's
-       ! gravity predictor reads f of every stencil cell
+    if (ncpu > 1 .or. nboundary > 0) then
+       ! the virtual octs too (force_fine has exchanged f itself, poisson/force_fine.f90:107,137) and the boundary octs
+       ! (make_boundary_force, :109,139): the sweep's gravity predictor reads f of every stencil cell
        call ramses_amd_amr_level_octs(ilevel, nl, list)
        rc = ramses_amd_amrres_load_f(nl, list, f)
        deallocate(list)

@@ -227,3 +227,29 @@ def test_deep_boundary_regions_follow_the_references_in_place_loop(gpu_lib, btyp
             _capi.check(lib.ramses_amd_amrres_sync_all(got.ctypes.data_as(C.c_void_p)))
             _capi.check(lib.ramses_amd_amrres_invalidate())
             assert np.array_equal(got.view(np.int64), want.view(np.int64)), (btype, nvector, order, no_inflow)
+
+
+def test_self_gravity_between_walls_stays_resident(gpu_lib):
+    """hydro + self-gravity inside six reflexive walls (levels 3-5): the hydro state stays on the device (make_boundary_hydro
+    there, f of the boundary octs mirrored after make_boundary_force), the Dirichlet solve keeps the reference's driver;
+    leaf cells, phi and f equal the reference program bit for bit"""
+    from oracle import ramses_snapshot as rs
+    if not (os.path.exists(REF) and os.path.exists(PATCHED)):
+        pytest.skip("oracle/_ref programs not built")
+    nml = _mka().walls_selfgrav_namelist()
+    workp, outp = _run(nml, PATCHED, 1, {"RAMSES_AMD": "1", "RAMSES_AMD_PROFILE": "1"})
+    try:
+        assert "AMR levels stay resident on the GPU" in outp, outp[-3000:]
+        assert "make_boundary_hydro (device)" in outp, outp[-3000:]
+        got = rs.load_leaf_cells(os.path.join(workp, "output_00002"))
+    finally:
+        shutil.rmtree(workp, ignore_errors=True)
+    workr, outr = _run(nml, REF, 1, {})
+    try:
+        ref = rs.load_leaf_cells(os.path.join(workr, "output_00002"))
+    finally:
+        shutil.rmtree(workr, ignore_errors=True)
+    assert np.array_equal(got["level"], ref["level"]) and np.array_equal(got["x"], ref["x"])
+    assert np.array_equal(got["prim"].view(np.int64), ref["prim"].view(np.int64)), np.abs(got["prim"] - ref["prim"]).max()
+    if "grav" in ref:
+        assert np.array_equal(np.asarray(got["grav"]).view(np.int64), np.asarray(ref["grav"]).view(np.int64))
