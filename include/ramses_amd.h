@@ -836,9 +836,10 @@ int64_t ramses_amd_amrres_covered_sweeps(void);
  * (11-16, with the no_inflow clamp :176-189) state of their reference cells, region after region in the reference's order,
  * octs of a region in list order, in chunks of nvector octs, cell index by cell index inside a chunk (a region two octs deep
  * reads what the same pass has already written, exactly as the reference's in-place loop :119-262 does).  btype = boundary_type(1:nregion), ngrid[r] = boundary(r,ilevel)%ngrid, igrid = the regions' oct lists
- * one after the other.  Imposed boundaries (21-26) are refused: the caller keeps such runs on the host path. */
+ * one after the other.  Imposed boundaries (21-26): the caller evaluates the reference's boundana (:215-241) for the cells of the
+ * region and passes the states, [nvar][8][ngrid[r]] per imposed region in order (host array; NULL when there is none). */
 int ramses_amd_amrres_boundary_hydro(int nregion, const int *btype, const int *ngrid, const int *igrid, int no_inflow, double smallr,
-                                     int nvector);
+                                     int nvector, const double *imposed);
 /* Several MPI ranks (one per GPU): the virtual-boundary exchanges of amr_step on the resident cell vectors.
  *   make_virtual_fine_dp(uold(1,ivar),ilevel)     amr/virtual_boundaries.f90:373-528, callers amr/amr_step.f90:61,287,505
  *   make_virtual_reverse_dp(unew(1,ivar),ilevel)  amr/virtual_boundaries.f90:693-983, caller amr/amr_step.f90:397

@@ -1267,9 +1267,10 @@ int halo_unpack(AmrRes &R, CommLevel &L, const HaloSpec &S) {
 // make_boundary_hydro(ilevel) of a run with physical boundaries (hydro/hydro_boundary.f90:5-269): nregion regions in the
 // reference's order (a later region may read what an earlier one wrote: corners), btype = boundary_type(1:nregion)
 // (1-6 reflexive, 11-16 free), ngrid[r] octs of region r on this level, igrid = the regions' lists one after the other,
-// nvector = the reference build's NVECTOR (the chunking of its loop decides what a region two octs deep reads).
+// nvector = the reference build's NVECTOR (the chunking of its loop decides what a region two octs deep reads); imposed =
+// for the imposed regions (21-26) in order, the states boundana returned, [nvar][8][ngrid[r]] each (host; NULL: none).
 int ramses_amd_amrres_boundary_hydro(int nregion, const int *btype, const int *ngrid, const int *igrid, int no_inflow, double smallr,
-                                     int nvector) {
+                                     int nvector, const double *imposed) {
   AmrRes &R = g_ar;
   if (!R.valid) return failf(RAMSES_AMD_EINVAL, "no resident AMR state (ramses_amd_amrres_load)");
   if (nregion < 0 || (nregion > 0 && (!btype || !ngrid))) return failf(RAMSES_AMD_EINVAL, "bad boundary description");
@@ -1279,8 +1280,8 @@ int ramses_amd_amrres_boundary_hydro(int nregion, const int *btype, const int *n
   int nmax = 0;
   for (int r = 0; r < nregion; r++) {
     const int k = btype[r] / 10, d = btype[r] % 10;
-    if ((k != 0 && k != 1) || d < 1 || d > 6)
-      return failf(RAMSES_AMD_EUNSUPPORTED, "make_boundary_hydro on the device: reflexive (1-6) and free (11-16) boundaries (got boundary_type %d)", btype[r]);
+    if (k < 0 || k > 2 || d < 1 || d > 6) return failf(RAMSES_AMD_EINVAL, "make_boundary_hydro: bad boundary_type %d", btype[r]);
+    if (k == 2 && !imposed) return failf(RAMSES_AMD_EINVAL, "make_boundary_hydro: an imposed boundary needs its states (boundana's output)");
     if (ngrid[r] < 0) return failf(RAMSES_AMD_EINVAL, "bad boundary oct count");
     ntot += ngrid[r];
     if (ngrid[r] > nmax) nmax = ngrid[r];
@@ -1300,15 +1301,23 @@ int ramses_amd_amrres_boundary_hydro(int nregion, const int *btype, const int *n
   A.uold = R.uold.as<double>(); A.tmp = R.bnd_tmp.as<double>();
   A.son = R.son.as<int>(); A.nbor = R.nbor.as<int>(); A.pos = R.bnd_pos.as<int>();
   A.nvar = R.nvar; A.no_inflow = no_inflow; A.nvector = nvector; A.ncell = R.ncell; A.ncoarse = R.ncoarse; A.ngridmax = R.ngridmax; A.smallr = smallr;
-  long off = 0;
+  long off = 0, imp_off = 0;
   for (int r = 0; r < nregion; r++) {
     const int n = ngrid[r];
     if (n > 0) {
       A.list = R.bnd_list.as<int>() + off; A.n = n; A.type = btype[r];
-      hipLaunchKernelGGL(bnd_mark_kernel, dim3(grid_for(n)), dim3(256), 0, nullptr, A, 0);
-      hipLaunchKernelGGL(bnd_compute_kernel, dim3(grid_for((long)n * 8)), dim3(256), 0, nullptr, A);
-      hipLaunchKernelGGL(bnd_store_kernel, dim3(grid_for((long)n * 8)), dim3(256), 0, nullptr, A);
-      hipLaunchKernelGGL(bnd_mark_kernel, dim3(grid_for(n)), dim3(256), 0, nullptr, A, 1);
+      if (btype[r] / 10 == 2) {
+        // imposed boundary (:215-241): the caller evaluated boundana for every cell of the region; [nvar][8][n] like tmp
+        const size_t cnt = (size_t)n * 8 * (size_t)R.nvar;
+        HCHK(hipMemcpyAsync(A.tmp, imposed + imp_off, sizeof(double) * cnt, hipMemcpyHostToDevice, nullptr), "H2D imposed states");
+        imp_off += (long)cnt;
+        hipLaunchKernelGGL(bnd_store_kernel, dim3(grid_for((long)n * 8)), dim3(256), 0, nullptr, A);
+      } else {
+        hipLaunchKernelGGL(bnd_mark_kernel, dim3(grid_for(n)), dim3(256), 0, nullptr, A, 0);
+        hipLaunchKernelGGL(bnd_compute_kernel, dim3(grid_for((long)n * 8)), dim3(256), 0, nullptr, A);
+        hipLaunchKernelGGL(bnd_store_kernel, dim3(grid_for((long)n * 8)), dim3(256), 0, nullptr, A);
+        hipLaunchKernelGGL(bnd_mark_kernel, dim3(grid_for(n)), dim3(256), 0, nullptr, A, 1);
+      }
     }
     off += n;
   }

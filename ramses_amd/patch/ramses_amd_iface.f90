@@ -659,12 +659,13 @@ module ramses_amd_iface
        real(c_double) :: uold(*)
        integer(c_int) :: rc
      end function ramses_amd_amrres_load_level
-     function ramses_amd_amrres_boundary_hydro(nregion, btype, ngrid, igrid, no_inflow, smallr, nvector) &
+     function ramses_amd_amrres_boundary_hydro(nregion, btype, ngrid, igrid, no_inflow, smallr, nvector, imposed) &
           & bind(C, name='ramses_amd_amrres_boundary_hydro') result(rc)
        import :: c_int, c_double
        integer(c_int), value :: nregion, no_inflow, nvector
        integer(c_int) :: btype(*), ngrid(*), igrid(*)
        real(c_double), value :: smallr
+       real(c_double) :: imposed(*)
        integer(c_int) :: rc
      end function ramses_amd_amrres_boundary_hydro
      function ramses_amd_amrres_sync_all(uold) bind(C, name='ramses_amd_amrres_sync_all') result(rc)
@@ -1473,14 +1474,14 @@ contains
        end if
        if (nboundary > 0) then
           ! physical boundaries: make_boundary_hydro runs on the resident cell vectors (hydro_boundary.f90 of this
-          ! directory) for reflexive and free boundaries; imposed boundaries (boundana) keep the staging path.  With
+          ! directory); the states of imposed boundaries come from the reference's boundana, evaluated by the shim.  With
           ! self-gravity the density goes back for the reference's rho_fine, the solve takes the routines of the
           ! multigrid shims under the reference's driver (Dirichlet set-up on the host), force_fine +
           ! make_boundary_force stay the reference's and f of the level's octs, boundary octs included, is mirrored.
           ! RAMSES_AMD_RESIDENT_WALLS=0: staging path.
           if (.not. simple_boundary) ramses_amd_amr_ok = .false.
           do l = 1, nboundary
-             if (boundary_type(l) / 10 > 1 .or. mod(boundary_type(l), 10) < 1 .or. mod(boundary_type(l), 10) > 6) &
+             if (boundary_type(l) / 10 > 2 .or. mod(boundary_type(l), 10) < 1 .or. mod(boundary_type(l), 10) > 6) &
                   & ramses_amd_amr_ok = .false.
           end do
           call get_environment_variable('RAMSES_AMD_RESIDENT_WALLS', val, status=stat)
@@ -1740,16 +1741,23 @@ contains
   !---------------------------------------------------------------------------
   subroutine ramses_amd_amr_boundary(ilevel)
     use amr_commons
-    use hydro_parameters, only: smallr
+    use hydro_parameters, only: smallr, nvar
     integer, intent(in) :: ilevel
-    integer :: ib, i, n, rc, flag
+    integer :: ib, i, n, rc, flag, nimp, ind, idim, i0, ng, ivar, ix, iy, iz, nx_loc
+    integer(8) :: base
     integer, allocatable :: cnt(:), list(:)
+    real(dp), allocatable :: imposed(:)
+    real(dp) :: dx, dx_loc, scale, skip_loc(3), xc(8, 3)
+    real(dp), dimension(1:nvector, 1:ndim) :: xx
+    real(dp), dimension(1:nvector, 1:nvar) :: uu
     n = 0
+    nimp = 0
     do ib = 1, nboundary
        n = n + boundary(ib, ilevel)%ngrid
+       if (boundary_type(ib) / 10 == 2) nimp = nimp + boundary(ib, ilevel)%ngrid
     end do
     if (n == 0) return
-    allocate(cnt(nboundary), list(n))
+    allocate(cnt(nboundary), list(n), imposed(max(1, nimp * 8 * nvar)))
     n = 0
     do ib = 1, nboundary
        cnt(ib) = boundary(ib, ilevel)%ngrid
@@ -1758,11 +1766,56 @@ contains
        end do
        n = n + cnt(ib)
     end do
+    if (nimp > 0) then
+       ! imposed boundaries: the reference's boundana evaluated for every cell of the region, as make_boundary_hydro
+       ! does (hydro/hydro_boundary.f90:36-49,215-241: cell centres in user units, chunks of nvector octs)
+       dx = 0.5d0**ilevel
+       nx_loc = icoarse_max - icoarse_min + 1
+       skip_loc = (/dble(icoarse_min), dble(jcoarse_min), dble(kcoarse_min)/)
+       scale = boxlen / dble(nx_loc)
+       dx_loc = dx * scale
+       do ind = 1, twotondim
+          iz = (ind - 1) / 4
+          iy = (ind - 1 - 4 * iz) / 2
+          ix = (ind - 1 - 2 * iy - 4 * iz)
+          xc(ind, 1) = (dble(ix) - 0.5d0) * dx
+          xc(ind, 2) = (dble(iy) - 0.5d0) * dx
+          xc(ind, 3) = (dble(iz) - 0.5d0) * dx
+       end do
+       base = 0
+       do ib = 1, nboundary
+          if (boundary_type(ib) / 10 /= 2) cycle
+          ng = boundary(ib, ilevel)%ngrid
+          do i0 = 1, ng, nvector
+             n = min(nvector, ng - i0 + 1)
+             do ind = 1, twotondim
+                do idim = 1, ndim
+                   do i = 1, n
+                      xx(i, idim) = xg(boundary(ib, ilevel)%igrid(i0 + i - 1), idim) + xc(ind, idim)
+                   end do
+                end do
+                do idim = 1, ndim
+                   do i = 1, n
+                      xx(i, idim) = (xx(i, idim) - skip_loc(idim)) * scale
+                   end do
+                end do
+                call boundana(xx, uu, dx_loc, ib, n)
+                ! [nvar][8][ng] of the region
+                do ivar = 1, nvar
+                   do i = 1, n
+                      imposed(base + (int(ivar - 1, 8) * 8 + int(ind - 1, 8)) * int(ng, 8) + int(i0 + i - 1, 8)) = uu(i, ivar)
+                   end do
+                end do
+             end do
+          end do
+          base = base + int(ng, 8) * 8 * int(nvar, 8)
+       end do
+    end if
     flag = 0
     if (no_inflow) flag = 1
-    rc = ramses_amd_amrres_boundary_hydro(nboundary, boundary_type, cnt, list, flag, smallr, nvector)
+    rc = ramses_amd_amrres_boundary_hydro(nboundary, boundary_type, cnt, list, flag, smallr, nvector, imposed)
     if (rc /= 0) call ramses_amd_fatal('make_boundary_hydro')
-    deallocate(cnt, list)
+    deallocate(cnt, list, imposed)
   end subroutine ramses_amd_amr_boundary
 
 #ifndef WITHOUTMPI

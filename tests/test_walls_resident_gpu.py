@@ -1,7 +1,7 @@
 """GPU tests of AMR residency in a box with physical boundaries (missing #6): the patched program keeps
 uold / unew and the tree on the GPU through a run with &BOUNDARY_PARAMS, and make_boundary_hydro (hydro/hydro_boundary.f90:5-269;
 callers amr/amr_step.f90:70,293,514) fills the boundary octs on the device (csrc/capi_amr.hip:
-ramses_amd_amrres_boundary_hydro) -- reflexive walls, free boundaries, the no_inflow clamp, regions processed in the
+ramses_amd_amrres_boundary_hydro) -- reflexive walls, free boundaries, the no_inflow clamp, imposed states, regions processed in the
 reference's order (corners read what an earlier region wrote).  Live against the untouched reference program: leaf cells
 bit for bit, on one rank and under MPI, on AMR levels and on a single uniform level."""
 import importlib.util
@@ -136,12 +136,11 @@ def test_amr_run_between_boundaries_under_mpi(gpu_lib, nproc):
     _ab(_namelist(3, 5, "1,1,2,2", "hllc", 2, 10, "1, 2, 2, 1, 1, 2", True), nproc, {})
 
 
-def test_imposed_boundaries_are_not_resident(gpu_lib):
-    """bound_type = 3 (boundana's imposed state) stays the reference's host routine: such a run is not resident"""
-    from oracle import ramses_snapshot as rs  # noqa: F401
-    nml = _namelist(3, 5, "1,1,2,2", "llf", 1, 6, "3, 1, 1, 1, 1, 1", False)
-    nml = nml.replace("no_inflow=.false.", "no_inflow=.false.\nd_bound=1.0\nu_bound=0.0\nv_bound=0.0\nw_bound=0.0\np_bound=1e-5")
-    _ab(nml, 1, {}, expect_resident=False)
+def test_imposed_boundaries_are_resident_too(gpu_lib):
+    """bound_type = 3: the shim evaluates the reference's boundana for the cells of the region, the device stores the states"""
+    nml = _namelist(3, 5, "1,1,2,2", "llf", 1, 12, "3, 1, 2, 3, 1, 1", False)
+    nml = nml.replace("no_inflow=.false.", "no_inflow=.false.\nd_bound=1.0,0,0,2.0\nu_bound=0.1,0,0,0.0\nv_bound=0.0,0,0,-0.2\nw_bound=0.0\np_bound=1e-5,0,0,2e-5")
+    _ab(nml, 1, {})
 
 
 # ---- regions more than one oct deep: the reference's in-place loop decides what is read (hydro/hydro_boundary.f90:119-262) ----
@@ -223,7 +222,7 @@ def test_deep_boundary_regions_follow_the_references_in_place_loop(gpu_lib, btyp
             ng = np.array([len(order)], dtype=np.int32)
             ig = np.array(order, dtype=np.int32)
             _capi.check(lib.ramses_amd_amrres_boundary_hydro(1, bt.ctypes.data_as(C.c_void_p), ng.ctypes.data_as(C.c_void_p),
-                                                             ig.ctypes.data_as(C.c_void_p), int(no_inflow), 1e-10, nvector))
+                                                             ig.ctypes.data_as(C.c_void_p), int(no_inflow), 1e-10, nvector, None))
             _capi.check(lib.ramses_amd_amrres_sync_all(got.ctypes.data_as(C.c_void_p)))
             _capi.check(lib.ramses_amd_amrres_invalidate())
             assert np.array_equal(got.view(np.int64), want.view(np.int64)), (btype, nvector, order, no_inflow)
