@@ -887,6 +887,23 @@ int ramses_amd_mhd_godunov_brick(const ramses_amd_mhd_params *p, int nx, int ny,
 int ramses_amd_mhd_godunov_fine_f90(const ramses_amd_mhd_params *p, int ilevel, int ngrid, const int *igrid, const double *xg,
                                     int64_t ngridmax, int64_t ncoarse, int nx_loc, const double *uold, double *unew, double dx,
                                     double dt);
+/* The level of a SOLVER=mhd run RESIDENT on the device between the routines of amr_step (one rank, one fully refined periodic
+ * level, levelmin = nlevelmax, no gravity / pressure_fix / magnetic diffusion): uold(1:ncell,1:nvar+3) goes up once, then
+ *   ramses_amd_mhd_resident_courant_f90    courant_fine  mhd/courant_fine.f90:1-160 (cmpdt mhd/godunov_utils.f90:5-115 per cell:
+ *                                          out5 = {min(dt_in, CFL step), mass, total, internal, magnetic energy of the level})
+ *   ramses_amd_mhd_resident_godunov_f90    set_unew + godunov_fine  mhd/godunov_fine.f90:5-109  (a second brick = uold advanced)
+ *   ramses_amd_mhd_resident_set_uold_f90   set_uold  mhd/godunov_fine.f90:185-281 (the bricks swap roles; the host array is stale)
+ *   ramses_amd_mhd_resident_sync_host_f90  the level's cells back into uold (backup_hydro; no-op while the host is current)
+ * ramses_amd/patch_mhd/{courant_fine,godunov_fine,output_hydro}.f90 bind them; RAMSES_AMD_MHD_RESIDENT=0 keeps the staged sweep. */
+int ramses_amd_mhd_resident_active(void);
+int ramses_amd_mhd_resident_courant_f90(const ramses_amd_mhd_params *p, int ilevel, int ngrid, const int *igrid, const double *xg,
+                                        int64_t ngridmax, int64_t ncoarse, int nx_loc, const double *uold, double dx, double dt_in,
+                                        double courant_factor, double *out5);
+int ramses_amd_mhd_resident_godunov_f90(const ramses_amd_mhd_params *p, int ilevel, int ngrid, const int *igrid, const double *xg,
+                                        int64_t ngridmax, int64_t ncoarse, int nx_loc, const double *uold, double dx, double dt);
+int ramses_amd_mhd_resident_set_uold_f90(int ilevel);
+int ramses_amd_mhd_resident_sync_host_f90(double *uold);
+int ramses_amd_mhd_resident_invalidate(void);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,27 @@ subroutine ref_mag_unsplit(uin, gravin, flux, emfx, emfy, emfz, tmp, dx, dy, dz,
   call mag_unsplit(uin, gravin, flux, emfx, emfy, emfz, tmp, dxl, dyl, dzl, dtl, ng)
 end subroutine ref_mag_unsplit
 
+! cmpdt of the MHD solver (mhd/godunov_utils.f90:5-115) on ncell <= nvector cells without gravity: uu(nvector,nvar+3) is
+! overwritten by the routine, dt returned
+subroutine ref_mhd_cmpdt(uu, dx, courant_factor_in, ncell, dt) bind(C, name='ref_mhd_cmpdt')
+  use iso_c_binding
+  use amr_parameters
+  use hydro_parameters
+  implicit none
+  real(c_double) :: uu(*)
+  real(c_double), value :: dx, courant_factor_in
+  integer(c_int), value :: ncell
+  real(c_double), intent(out) :: dt
+  real(dp), dimension(1:nvector, 1:ndim) :: gg
+  real(dp) :: dxl, dtl
+  integer :: nc
+  gg = 0.0d0
+  courant_factor = courant_factor_in
+  dxl = dx; nc = ncell
+  call cmpdt(uu, gg, dxl, dtl, nc)
+  dt = dtl
+end subroutine ref_mhd_cmpdt
+
 ! cmpflxm / cmp_mag_flx call clean_stop on an unknown solver code (amr/update_time.f90 in the full program)
 subroutine clean_stop
   implicit none

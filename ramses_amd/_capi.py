@@ -205,6 +205,12 @@ SYMBOLS = [
     ("ramses_amd_mhd_workspace_bytes", _i64, [_i, _i, _i]),
     ("ramses_amd_mhd_godunov_brick", _i, [_vp, _i, _i, _i, _vp, _vp, _d, _d, _vp, _i64, _vp]),
     ("ramses_amd_mhd_godunov_fine_f90", _i, [_vp, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _d, _d]),
+    ("ramses_amd_mhd_resident_active", _i, []),
+    ("ramses_amd_mhd_resident_courant_f90", _i, [_vp, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _d, _d, _vp]),
+    ("ramses_amd_mhd_resident_godunov_f90", _i, [_vp, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _d]),
+    ("ramses_amd_mhd_resident_set_uold_f90", _i, [_i]),
+    ("ramses_amd_mhd_resident_sync_host_f90", _i, [_vp]),
+    ("ramses_amd_mhd_resident_invalidate", _i, []),
     ("ramses_amd_amrres_rho_mpi_multipole", _i, [_PP, _i, _i, _i, _vp, _d]),
     ("ramses_amd_amrres_rho_mpi_deposit", _i, [_i, _i, _d]),
     ("ramses_amd_amrres_rho_mpi_finish", _i, [_i, _i, _i, _vp, _vp, _vp]),

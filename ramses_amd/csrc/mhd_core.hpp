@@ -62,6 +62,35 @@ MHD_FN void ctoprim_cell(const double (&u)[5], const double (&bl)[3], const doub
   }
 }
 
+// ---- cmpdt (mhd/godunov_utils.f90:5-115, ischeme = 0, no gravity), one cell: u[0..10] = rho, rho u, rho v, rho w, E, the
+// fields on the left faces, the fields on the right faces; returns dtcell (the caller starts from courant_factor*dx/smallc
+// and takes the minimum) ----------------------------------------------------------------------------------------------
+MHD_FN double cmpdt_cell(const double (&u)[11], double dx, double courant_factor, const MhdConst &P) {
+  const double smallp = P.smallr * (P.smallc * P.smallc) / P.gamma;
+  const double rho = fmax2(u[0], P.smallr);
+  const double v[3] = {u[1] / rho, u[2] / rho, u[3] / rho};
+  double B2 = 0.0, e = u[4];
+  for (int d = 0; d < 3; d++) {
+    const double Bc = 0.5 * (u[5 + d] + u[8 + d]);
+    B2 = B2 + Bc * Bc;
+    e = e - 0.5 * rho * (v[d] * v[d]) - 0.5 * (Bc * Bc);
+  }
+  const double p = fmax2((P.gamma - 1.0) * e, smallp);
+  const double a2 = P.gamma * p / rho;
+  double ctot = 0.0;
+  for (int d = 0; d < 3; d++) {
+    const double cc = 0.5 * (B2 / rho + a2);
+    const double BN = 0.5 * (u[5 + d] + u[8 + d]);
+    const double cf = __builtin_sqrt(cc + __builtin_sqrt(cc * cc - a2 * (BN * BN) / rho));
+    ctot = ctot + __builtin_fabs(v[d]) + cf;
+  }
+  // gravity strength ratio: no gravity, rho = max(0 * dx / ctot**2, 1e-4)
+  double g = 0.0;
+  g = g * dx / (ctot * ctot);
+  g = fmax2(g, 0.0001);
+  return dx / ctot * (__builtin_sqrt(1.0 + 2.0 * courant_factor * g) - 1.0) / g;
+}
+
 // ---- one TVD slope (uslope :2375-2571 for the cell-centred variables, :2572-2842 for the face-centred fields: the same
 // limiter, chosen by slope_type / slope_mag_type) ---------------------------------------------------------------------
 MHD_FN bool slope_type_supported(int st) { return st == 0 || st == 1 || st == 2 || st == 7 || st == 8; }

@@ -25,6 +25,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <utility>
 #include <cstdlib>
 #include <cstring>
 
@@ -234,6 +235,66 @@ __global__ __launch_bounds__(256) void mhd_update_kernel(MhdArgs A) {
   }
 }
 
+// courant_fine of the resident level (mhd/courant_fine.f90:56-146): the minimum of cmpdt's cell time steps (exact) and the
+// four sums of the conservation diagnostics -- mass, total energy, internal energy, magnetic energy -- as a fixed two-stage
+// tree (they feed the printed mass / energy balance only: amr/update_time.f90; deterministic, equal to the reference's serial
+// sums up to rounding).  partial[block][5] -> courant_final_kernel.
+constexpr int COUR_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void mhd_courant_kernel(MhdArgs A, double vol, double courant_factor, double *__restrict__ partial) {
+  const long N = A.ncell;
+  double dt = 1.0e300, mass = 0.0, etot = 0.0, eint = 0.0, emag = 0.0;
+  MHD_CELL_LOOP(A) {
+    double u[11];
+#pragma unroll
+    for (int n = 0; n < 11; n++) u[n] = A.uold[(long)n * N + c_];
+    dt = fmin2(dt, cmpdt_cell(u, A.dx, courant_factor, A.P));
+    mass = mass + u[0] * vol;
+    etot = etot + u[4] * vol;
+    double ei = u[4] * vol, em = 0.0;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const double b = u[5 + d] + u[8 + d];
+      em = em + 0.125 * (b * b) * vol;
+      ei = ei - 0.5 * (u[1 + d] * u[1 + d]) / u[0] * vol - 0.125 * (b * b) * vol;
+    }
+    eint = eint + ei;
+    emag = emag + em;
+  }
+  __shared__ double red[256][5];
+  red[threadIdx.x][0] = dt; red[threadIdx.x][1] = mass; red[threadIdx.x][2] = etot; red[threadIdx.x][3] = eint; red[threadIdx.x][4] = emag;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      red[threadIdx.x][0] = fmin2(red[threadIdx.x][0], red[threadIdx.x + s][0]);
+#pragma unroll
+      for (int q = 1; q < 5; q++) red[threadIdx.x][q] = red[threadIdx.x][q] + red[threadIdx.x + s][q];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 5) partial[(long)blockIdx.x * 5 + threadIdx.x] = red[0][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void mhd_courant_final_kernel(const double *__restrict__ partial, int nblocks, double *__restrict__ out5) {
+  __shared__ double red[256][5];
+  double v[5] = {1.0e300, 0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < nblocks; b += 256) {
+    v[0] = fmin2(v[0], partial[(long)b * 5]);
+#pragma unroll
+    for (int q = 1; q < 5; q++) v[q] = v[q] + partial[(long)b * 5 + q];
+  }
+#pragma unroll
+  for (int q = 0; q < 5; q++) red[threadIdx.x][q] = v[q];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      red[threadIdx.x][0] = fmin2(red[threadIdx.x][0], red[threadIdx.x + s][0]);
+#pragma unroll
+      for (int q = 1; q < 5; q++) red[threadIdx.x][q] = red[threadIdx.x][q] + red[threadIdx.x + s][q];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 5) out5[threadIdx.x] = red[0][threadIdx.x];
+}
+
 inline int grid_for(long n, int block) {
   long g = (n + block - 1) / block;
   if (g < 1) g = 1;
@@ -365,6 +426,158 @@ int ramses_amd_mhd_godunov_fine_f90(const ramses_amd_mhd_params *p, int ilevel, 
   HCHK(launch_oct_copy(PA, false, s), "scatter launch");
   HCHK(hipMemcpyAsync(unew, d_vec, sizeof(double) * NF * ncell, hipMemcpyDeviceToHost, s), "D2H unew");
   HCHK(hipStreamSynchronize(s), "sync");
+  return 0;
+}
+
+
+// ---- the level resident on the device between the routines of amr_step (single rank, one fully refined periodic level,
+// levelmin = nlevelmax): courant_fine, godunov_fine (set_unew is implied), set_uold run on two bricks that swap roles; the
+// host array uold is stale from the first set_uold until ramses_amd_mhd_resident_sync_host_f90 (backup_hydro).  Mirrors
+// ramses_amd_resident_* of the hydro solver (capi_host.hip). ---------------------------------------------------------
+namespace {
+struct MhdBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap && p) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+};
+struct MhdResident {
+  bool valid = false, host_stale = false, new_ready = false;
+  int level = 0, ngrid = 0, n = 0;
+  long ncell = 0, ncoarse = 0, ngridmax = 0;
+  const double *h_uold = nullptr;
+  MhdBuf vec, cur, nxt, work, ig, xg, org, flag, red;
+};
+MhdResident g_mres;
+
+int mres_ensure(int ilevel, int ngrid, const int *igrid, const double *xg, int64_t ngridmax, int64_t ncoarse, int nx_loc,
+                const double *uold) {
+  MhdResident &R = g_mres;
+  if (!igrid || !xg || !uold) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  if (nx_loc != 1) return failf(RAMSES_AMD_EUNSUPPORTED, "MHD residency needs a periodic box with nx=ny=nz=1 (got nx_loc=%d)", nx_loc);
+  if (ilevel < 2 || ilevel > 10) return failf(RAMSES_AMD_EINVAL, "level out of range");
+  const int n = 1 << ilevel;
+  const long N = (long)n * n * n;
+  if ((long)ngrid * 8 != N) return failf(RAMSES_AMD_EUNSUPPORTED, "level %d is not fully refined on this rank (ngrid=%d)", ilevel, ngrid);
+  const long ncell = ncoarse + 8 * ngridmax;
+  if (R.valid && R.level == ilevel && R.ngrid == ngrid && R.h_uold == uold && R.ncell == ncell) return 0;
+  if (R.valid && R.host_stale)
+    return failf(RAMSES_AMD_EINVAL, "MHD residency: level %d is resident and the host array is stale; ramses_amd_mhd_resident_sync_host_f90 first", R.level);
+  R.valid = false;
+  hipStream_t s = nullptr;
+  HCHK(R.vec.ensure(sizeof(double) * NF * ncell), "hipMalloc cell vectors");
+  HCHK(R.cur.ensure(sizeof(double) * NF * N), "hipMalloc brick");
+  HCHK(R.nxt.ensure(sizeof(double) * NF * N), "hipMalloc brick");
+  HCHK(R.work.ensure((size_t)ramses_amd_mhd_workspace_bytes(n, n, n)), "hipMalloc workspace");
+  HCHK(R.org.ensure(sizeof(long) * ngrid), "hipMalloc octorg");
+  HCHK(R.ig.ensure(sizeof(int) * ngrid), "hipMalloc igrid");
+  HCHK(R.xg.ensure(sizeof(double) * 3 * ngridmax), "hipMalloc xg");
+  HCHK(R.flag.ensure(sizeof(int)), "hipMalloc flag");
+  HCHK(R.red.ensure(sizeof(double) * (COUR_BLOCKS * 5 + 8)), "hipMalloc reduction");
+  HCHK(hipMemcpyAsync(R.vec.p, uold, sizeof(double) * NF * ncell, hipMemcpyHostToDevice, s), "H2D uold");
+  HCHK(hipMemcpyAsync(R.ig.p, igrid, sizeof(int) * ngrid, hipMemcpyHostToDevice, s), "H2D igrid");
+  HCHK(hipMemcpyAsync(R.xg.p, xg, sizeof(double) * 3 * ngridmax, hipMemcpyHostToDevice, s), "H2D xg");
+  HCHK(hipMemsetAsync(R.flag.p, 0, sizeof(int), s), "memset");
+  const double skip[3] = {0.0, 0.0, 0.0};
+  HCHK(launch_oct_origin((const int *)R.ig.p, (const double *)R.xg.p, ngridmax, ngrid, n, skip, (long *)R.org.p, (int *)R.flag.p, s), "oct origin launch");
+  int bad = 0;
+  HCHK(hipMemcpyAsync(&bad, R.flag.p, sizeof(int), hipMemcpyDeviceToHost, s), "D2H flag");
+  HCHK(hipStreamSynchronize(s), "sync");
+  if (bad) return failf(RAMSES_AMD_EINVAL, "%d octs of level %d do not sit on the level lattice", bad, ilevel);
+  PackArgs PA;
+  PA.igrid = (const int *)R.ig.p; PA.octorg = (const long *)R.org.p;
+  PA.ngrid = ngrid; PA.n = n; PA.nvar = NF;
+  PA.ncoarse = ncoarse; PA.ngridmax = ngridmax; PA.ncell = ncell; PA.pitch_var = N;
+  PA.brick = (double *)R.cur.p; PA.cellvec = (double *)R.vec.p;
+  HCHK(launch_oct_copy(PA, true, s), "gather launch");
+  R.valid = true; R.host_stale = false; R.new_ready = false;
+  R.level = ilevel; R.ngrid = ngrid; R.n = n; R.ncell = ncell; R.ncoarse = ncoarse; R.ngridmax = ngridmax; R.h_uold = uold;
+  return 0;
+}
+}  // namespace
+
+int ramses_amd_mhd_resident_active(void) { return g_mres.valid ? 1 : 0; }
+
+// courant_fine(ilevel) (mhd/courant_fine.f90:1-160): out5 = {min(dt_in, the level's CFL step), mass, total energy, internal
+// energy, magnetic energy} of the level (the four sums x dx^3 as the reference accumulates them)
+int ramses_amd_mhd_resident_courant_f90(const ramses_amd_mhd_params *p, int ilevel, int ngrid, const int *igrid, const double *xg,
+                                        int64_t ngridmax, int64_t ncoarse, int nx_loc, const double *uold, double dx, double dt_in,
+                                        double courant_factor, double *out5) {
+  if (!out5) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  MhdArgs A;
+  if (int rc = make_const(p, A.P)) return rc;
+  if (int rc = mres_ensure(ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, uold)) return rc;
+  MhdResident &R = g_mres;
+  if (R.new_ready) return failf(RAMSES_AMD_EINVAL, "courant_fine between godunov_fine and set_uold");
+  if (!(dx > 0.0) || !(courant_factor > 0.0)) return failf(RAMSES_AMD_EINVAL, "dx and courant_factor must be > 0");
+  const long N = (long)R.n * R.n * R.n;
+  A.uold = (const double *)R.cur.p; A.unew = nullptr;
+  A.nx = A.ny = A.nz = R.n; A.ncell = N; A.dx = dx; A.dt = 0.0;
+  double *partial = (double *)R.red.p, *d_out = partial + COUR_BLOCKS * 5;
+  const int nb = (int)((N + 255) / 256 < COUR_BLOCKS ? (N + 255) / 256 : COUR_BLOCKS);
+  hipLaunchKernelGGL(mhd_courant_kernel, dim3(nb), dim3(256), 0, nullptr, A, dx * dx * dx, courant_factor, partial);
+  hipLaunchKernelGGL(mhd_courant_final_kernel, dim3(1), dim3(256), 0, nullptr, partial, nb, d_out);
+  HCHK(hipGetLastError(), "courant launch");
+  double h[5];
+  HCHK(hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost), "D2H courant");
+  const double dt0 = courant_factor * dx / p->smallc;            // cmpdt's starting value (:108)
+  double dt = h[0] < dt0 ? h[0] : dt0;
+  out5[0] = dt < dt_in ? dt : dt_in;
+  for (int q = 1; q < 5; q++) out5[q] = h[q];
+  return 0;
+}
+
+// set_unew + godunov_fine(ilevel) on the resident level: the other brick = uold advanced by dt
+int ramses_amd_mhd_resident_godunov_f90(const ramses_amd_mhd_params *p, int ilevel, int ngrid, const int *igrid, const double *xg,
+                                        int64_t ngridmax, int64_t ncoarse, int nx_loc, const double *uold, double dx, double dt) {
+  if (int rc = mres_ensure(ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, uold)) return rc;
+  MhdResident &R = g_mres;
+  if (int rc = ramses_amd_mhd_godunov_brick(p, R.n, R.n, R.n, (const double *)R.cur.p, (double *)R.nxt.p, dx, dt, R.work.p,
+                                            (int64_t)R.work.cap, nullptr)) return rc;
+  R.new_ready = true;
+  return 0;
+}
+
+// set_uold(ilevel) (mhd/godunov_fine.f90:185-281 without gravity / pressure_fix / passive scalars): the bricks swap roles
+int ramses_amd_mhd_resident_set_uold_f90(int ilevel) {
+  MhdResident &R = g_mres;
+  if (!R.valid || R.level != ilevel) return failf(RAMSES_AMD_EINVAL, "set_uold: level %d is not resident", ilevel);
+  if (!R.new_ready) return failf(RAMSES_AMD_EINVAL, "set_uold without a godunov_fine before it");
+  std::swap(R.cur, R.nxt);
+  R.new_ready = false;
+  R.host_stale = true;
+  return 0;
+}
+
+// backup_hydro and anything else on the host that reads uold: the level's cells come back (the other cells of the array
+// keep the values they were loaded with -- nothing on the host changes them while the level is resident)
+int ramses_amd_mhd_resident_sync_host_f90(double *uold) {
+  MhdResident &R = g_mres;
+  if (!R.valid || !R.host_stale) return 0;
+  if (uold != R.h_uold) return failf(RAMSES_AMD_EINVAL, "sync: not the array the level was loaded from");
+  if (R.new_ready) return failf(RAMSES_AMD_EINVAL, "sync between godunov_fine and set_uold");
+  const long N = (long)R.n * R.n * R.n;
+  PackArgs PA;
+  PA.igrid = (const int *)R.ig.p; PA.octorg = (const long *)R.org.p;
+  PA.ngrid = R.ngrid; PA.n = R.n; PA.nvar = NF;
+  PA.ncoarse = R.ncoarse; PA.ngridmax = R.ngridmax; PA.ncell = R.ncell; PA.pitch_var = N;
+  PA.brick = (double *)R.cur.p; PA.cellvec = (double *)R.vec.p;
+  HCHK(launch_oct_copy(PA, false, nullptr), "scatter launch");
+  HCHK(hipMemcpy(uold, R.vec.p, sizeof(double) * NF * R.ncell, hipMemcpyDeviceToHost), "D2H uold");
+  R.host_stale = false;
+  return 0;
+}
+
+int ramses_amd_mhd_resident_invalidate(void) {
+  MhdResident &R = g_mres;
+  if (R.valid && R.host_stale) return failf(RAMSES_AMD_EINVAL, "invalidate: the host array is stale; sync first");
+  R.valid = false;
   return 0;
 }
 

@@ -22,6 +22,42 @@ module ramses_amd_mhd_iface
        real(c_double), value :: dx, dt
        integer(c_int) :: rc
      end function ramses_amd_mhd_godunov_fine_f90
+     function ramses_amd_mhd_resident_active() bind(C, name='ramses_amd_mhd_resident_active') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function ramses_amd_mhd_resident_active
+     function ramses_amd_mhd_resident_courant_f90(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, uold, dx, dt_in, &
+          & courant_factor, out5) bind(C, name='ramses_amd_mhd_resident_courant_f90') result(rc)
+       import :: ramses_amd_mhd_params, c_int, c_int64_t, c_double
+       type(ramses_amd_mhd_params), intent(in) :: p
+       integer(c_int), value :: ilevel, ngrid, nx_loc
+       integer(c_int) :: igrid(*)
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       real(c_double) :: xg(*), uold(*), out5(5)
+       real(c_double), value :: dx, dt_in, courant_factor
+       integer(c_int) :: rc
+     end function ramses_amd_mhd_resident_courant_f90
+     function ramses_amd_mhd_resident_godunov_f90(p, ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, uold, dx, dt) &
+          & bind(C, name='ramses_amd_mhd_resident_godunov_f90') result(rc)
+       import :: ramses_amd_mhd_params, c_int, c_int64_t, c_double
+       type(ramses_amd_mhd_params), intent(in) :: p
+       integer(c_int), value :: ilevel, ngrid, nx_loc
+       integer(c_int) :: igrid(*)
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       real(c_double) :: xg(*), uold(*)
+       real(c_double), value :: dx, dt
+       integer(c_int) :: rc
+     end function ramses_amd_mhd_resident_godunov_f90
+     function ramses_amd_mhd_resident_set_uold_f90(ilevel) bind(C, name='ramses_amd_mhd_resident_set_uold_f90') result(rc)
+       import :: c_int
+       integer(c_int), value :: ilevel
+       integer(c_int) :: rc
+     end function ramses_amd_mhd_resident_set_uold_f90
+     function ramses_amd_mhd_resident_sync_host_f90(uold) bind(C, name='ramses_amd_mhd_resident_sync_host_f90') result(rc)
+       import :: c_int, c_double
+       real(c_double) :: uold(*)
+       integer(c_int) :: rc
+     end function ramses_amd_mhd_resident_sync_host_f90
      function ramses_amd_last_error() bind(C, name='ramses_amd_last_error') result(msg)
        import :: c_ptr
        type(c_ptr) :: msg
@@ -42,6 +78,55 @@ contains
     end if
     ramses_amd_mhd_enabled = on
   end function ramses_amd_mhd_enabled
+
+  ! What the device sweep covers that does not depend on the level (the caller adds: the level is fully refined and has
+  ! no finer level)
+  logical function ramses_amd_mhd_device_config()
+    use amr_commons
+    use hydro_commons
+    integer :: nx_loc
+    nx_loc = icoarse_max - icoarse_min + 1
+    ramses_amd_mhd_device_config = ramses_amd_mhd_enabled() .and. hydro .and. ndim == 3 .and. nvar == 8 .and. ncpu == 1 &
+         & .and. nboundary == 0 .and. nx_loc == 1 .and. jcoarse_max == jcoarse_min .and. kcoarse_max == kcoarse_min &
+         & .and. .not. poisson .and. .not. pressure_fix .and. ischeme == 0 .and. .not. allow_switch_solver &
+         & .and. .not. allow_switch_solver2D &
+         & .and. (iriemann == 0 .or. iriemann == 2 .or. iriemann == 3 .or. iriemann == 4) &
+         & .and. (iriemann2d == 0 .or. iriemann2d == 3 .or. iriemann2d == 5) &
+         & .and. (slope_type == 0 .or. slope_type == 1 .or. slope_type == 2 .or. slope_type == 7 .or. slope_type == 8) &
+         & .and. (slope_mag_type == 0 .or. slope_mag_type == 1 .or. slope_mag_type == 2 .or. slope_mag_type == 7 &
+         &        .or. slope_mag_type == 8)
+  end function ramses_amd_mhd_device_config
+
+  ! The level stays on the device between courant_fine, godunov_fine and set_uold: one level (levelmin = nlevelmax), and
+  ! nothing else in the time loop that reads or writes uold on the host (magnetic diffusion, cooling, particles, ...).
+  ! RAMSES_AMD_MHD_RESIDENT=0 keeps the staged sweep.
+  logical function ramses_amd_mhd_resident()
+    use amr_commons
+    use hydro_commons
+    character(len=16) :: val
+    integer :: stat
+    logical, save :: first = .true., on = .false.
+    if (first) then
+       first = .false.
+       on = ramses_amd_mhd_device_config() .and. levelmin == nlevelmax .and. levelmin >= 2 .and. levelmin <= 10
+       if (eta_mag > 0.0d0) on = .false.
+       if (pic .or. rt .or. cooling .or. star .or. sink .or. tracer .or. clumpfind .or. lightcone .or. movie) on = .false.
+       if (static .or. cosmo) on = .false.
+       call get_environment_variable('RAMSES_AMD_MHD_RESIDENT', val, status=stat)
+       if (stat == 0) then
+          if (trim(val) == '0') on = .false.
+       end if
+       if (on) write(*,*) 'ramses_amd: the MHD level stays resident on the GPU (courant_fine, godunov_fine, set_uold)'
+    end if
+    ramses_amd_mhd_resident = on
+  end function ramses_amd_mhd_resident
+
+  subroutine ramses_amd_mhd_fill_params(p)
+    use hydro_commons
+    type(ramses_amd_mhd_params), intent(out) :: p
+    p%gamma = gamma; p%smallr = smallr; p%smallc = smallc; p%slope_theta = slope_theta
+    p%slope_type = slope_type; p%slope_mag_type = slope_mag_type; p%riemann = iriemann; p%riemann2d = iriemann2d
+  end subroutine ramses_amd_mhd_fill_params
 
   subroutine ramses_amd_mhd_fatal(where)
     character(len=*), intent(in) :: where

@@ -342,6 +342,43 @@ bound_type= 1, 1, 2, 2, 1, 1
         if which in ("all", "ref"):
             run_c5mpi("reference (MPI)", ref, {"RAMSES_AMD": "0"})
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "mhd":
+        # SOLVER=mhd: a magnetised blast on a uniform periodic level (tests/mhd_common.py), hlld + hlld
+        level, nstep = int(sys.argv[2]), int(sys.argv[3])
+        which = sys.argv[4] if len(sys.argv) > 4 else "all"
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from mhd_common import mhd_namelist
+        nml = mhd_namelist(level, nstep, "hlld", "hlld", 2).replace("foutput=%d" % nstep, "foutput=1000")
+
+        def run_mhd(tag, binary, env):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            t0 = time.time()
+            try:
+                work, out = rs.run_reference(nml, binary=binary, timeout=3000)
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            wall = time.time() - t0
+            shutil.rmtree(work, ignore_errors=True)
+            rows = {}
+            for line in out.splitlines():
+                m = re.match(r"^\s*([0-9.]+)\s+([0-9.]+)\s+([a-zA-Z].*?)\s*$", line)
+                if m and "STEP" not in m.group(3):
+                    rows[m.group(3)] = float(m.group(1))
+            print(json.dumps({"config": tag, "level": level, "steps": nstep, "wall_s": round(wall, 3), "timers_s": rows}), flush=True)
+
+        ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mhd")
+        pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch_mhd_mhd")
+        if which in ("all", "gpu"):
+            run_mhd("patched (SOLVER=mhd), level resident on the GPU", pat, {"RAMSES_AMD": "1"})
+            run_mhd("patched (SOLVER=mhd), godunov_fine staged", pat, {"RAMSES_AMD": "1", "RAMSES_AMD_MHD_RESIDENT": "0"})
+        if which in ("all", "ref"):
+            run_mhd("reference SOLVER=mhd (1 core)", ref, {"RAMSES_AMD": "0"})
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "grav":
         level, nstep = int(sys.argv[2]), int(sys.argv[3])
         which = sys.argv[4] if len(sys.argv) > 4 else "all"

@@ -114,3 +114,19 @@ extern "C" int mhd_host_unsplit(const double *uin, int ngrid, int nvector, doubl
   }
   return 0;
 }
+
+// cmpdt of ncell cells: uu(nvector, 11) in Fortran order (cell index fastest); returns min(courant_factor*dx/smallc, dtcell...)
+extern "C" double mhd_host_cmpdt(const double *uu, int ncell, int nvector, double dx, double courant_factor, double gamma, double smallr,
+                                 double smallc) {
+  MhdConst P;
+  P.gamma = gamma; P.smallr = smallr; P.smallc = smallc; P.slope_theta = 1.5;
+  P.slope_type = 1; P.slope_mag_type = 1; P.riemann = 0; P.riemann2d = 0;
+  double dt = courant_factor * dx / smallc;
+  for (int l = 0; l < ncell; l++) {
+    double u[11];
+    for (int n = 0; n < 11; n++) u[n] = uu[l + (size_t)nvector * n];
+    const double d = cmpdt_cell(u, dx, courant_factor, P);
+    dt = d < dt ? d : dt;
+  }
+  return dt;
+}

@@ -95,3 +95,44 @@ def test_headers_equal_the_compiled_reference(libs, slope_type, riemann, riemann
         a, b = emf_h[e][sl[0], sl[1], sl[2]], emf_r[e][sl[0], sl[1], sl[2]]
         assert np.isfinite(b).all()
         assert np.array_equal(a, b), (e, np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_cmpdt_cell_equals_the_compiled_reference(libs, seed):
+    """cmpdt of the MHD solver (mhd/godunov_utils.f90:5-115; fast magnetosonic speed, ischeme = 0): the product's cmpdt_cell
+    (csrc/mhd_core.hpp, what the resident courant_fine runs per cell) against the compiled routine, cell by cell and as a
+    minimum over a vector of cells"""
+    host, ref, nvec = libs
+    rng = np.random.default_rng(seed)
+    gamma, smallr, smallc, cfl = 5.0 / 3.0, 1e-10, 1e-10, 0.8
+    ref.ref_mhd_set_params(C.c_double(gamma), C.c_double(smallr), C.c_double(smallc), 1, 1, C.c_double(1.5), 0, 0)
+    ref.ref_mhd_cmpdt.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p]
+    host.mhd_host_cmpdt.restype = C.c_double
+    host.mhd_host_cmpdt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]
+    u = np.zeros((11, nvec))
+    u[0] = rng.uniform(1e-3, 3.0, nvec)
+    u[0, :2] = [1e-12, 5e-11]                       # below the density floor
+    vel = rng.normal(0.0, 1.5, (3, nvec))
+    u[1:4] = u[0] * vel
+    u[5:8] = rng.normal(0.0, 1.0, (3, nvec))
+    u[8:11] = u[5:8] + rng.normal(0.0, 0.05, (3, nvec))
+    bc = 0.5 * (u[5:8] + u[8:11])
+    pth = rng.uniform(1e-6, 2.0, nvec)
+    pth[2] = -1.0                                   # a cell whose pressure falls on the floor
+    u[4] = pth / (gamma - 1.0) + 0.5 * u[0] * (vel ** 2).sum(0) + 0.5 * (bc ** 2).sum(0)
+    for dx in (1.0 / 64, 0.37):
+        for ncell in (1, 7, nvec):
+            work = np.ascontiguousarray(u).copy()
+            dt = C.c_double()
+            ref.ref_mhd_cmpdt(work.ctypes.data_as(C.c_void_p), dx, cfl, ncell, C.byref(dt))
+            got = host.mhd_host_cmpdt(np.ascontiguousarray(u).ctypes.data_as(C.c_void_p), ncell, nvec, dx, cfl, gamma, smallr, smallc)
+            assert np.float64(got).view(np.int64) == np.float64(dt.value).view(np.int64), (dx, ncell, got, dt.value)
+        # cell by cell
+        for l in range(0, nvec, 5):
+            one = np.zeros((11, nvec))
+            one[:, 0] = u[:, l]
+            work = one.copy()
+            dt = C.c_double()
+            ref.ref_mhd_cmpdt(work.ctypes.data_as(C.c_void_p), dx, cfl, 1, C.byref(dt))
+            got = host.mhd_host_cmpdt(one.ctypes.data_as(C.c_void_p), 1, nvec, dx, cfl, gamma, smallr, smallc)
+            assert np.float64(got).view(np.int64) == np.float64(dt.value).view(np.int64)

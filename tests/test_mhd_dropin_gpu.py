@@ -1,6 +1,7 @@
 """The MHD drop-in end to end: the reference program built with SOLVER=mhd, NVAR=8 and
-PATCH=ramses_amd/patch_mhd (oracle/_ref/ramses3d_patch_mhd_mhd: godunov_fine of a fully refined periodic level through
-ramses_amd_mhd_godunov_fine_f90, everything else the reference's) against the unmodified SOLVER=mhd program
+PATCH=ramses_amd/patch_mhd (oracle/_ref/ramses3d_patch_mhd_mhd: the level RESIDENT on the device -- courant_fine,
+godunov_fine, set_uold there, backup_hydro fetches it -- or, with RAMSES_AMD_MHD_RESIDENT=0, godunov_fine staged through
+ramses_amd_mhd_godunov_fine_f90; everything else the reference's) against the unmodified SOLVER=mhd program
 (oracle/_ref/ramses3d_mhd) on the same namelist -- a blast in a magnetised medium on a uniform 32^3 / 64^3 level:
 density, velocity, the six face fields and the pressure of every cell after the run, bit for bit."""
 import os
@@ -17,19 +18,23 @@ REF = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mhd")
 PATCHED = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch_mhd_mhd")
 
 
-@pytest.mark.parametrize("level,nstep,riemann,riemann2d,slope_type", [
-    (5, 12, "llf", "llf", 1), (5, 12, "hlld", "hlld", 2), (6, 10, "hlld", "hlld", 1), (5, 8, "hll", "hll", 8), (5, 8, "hlld", "llf", 7),
+@pytest.mark.parametrize("level,nstep,riemann,riemann2d,slope_type,resident", [
+    (5, 12, "llf", "llf", 1, "1"), (5, 12, "hlld", "hlld", 2, "1"), (6, 10, "hlld", "hlld", 1, "1"), (5, 8, "hll", "hll", 8, "1"),
+    (5, 8, "hlld", "llf", 7, "1"), (5, 12, "hlld", "hlld", 2, "0"), (5, 8, "hll", "hll", 8, "0"),
 ])
-def test_patched_mhd_program_equals_the_reference(gpu_lib, monkeypatch, level, nstep, riemann, riemann2d, slope_type):
+def test_patched_mhd_program_equals_the_reference(gpu_lib, monkeypatch, level, nstep, riemann, riemann2d, slope_type, resident):
     if not (os.path.exists(REF) and os.path.exists(PATCHED)):
         pytest.skip("oracle/_ref/ramses3d_mhd / ramses3d_patch_mhd_mhd not built")
     from mhd_common import mhd_namelist
     from oracle import ramses_snapshot as rs
     nml = mhd_namelist(level, nstep, riemann, riemann2d, slope_type)
     monkeypatch.setenv("RAMSES_AMD", "1")
+    monkeypatch.setenv("RAMSES_AMD_MHD_RESIDENT", resident)
     work, out = rs.run_reference(nml, binary=PATCHED)
     try:
-        assert "MHD godunov_fine of fully refined levels on the MI355X" in out, out[-1500:]
+        assert ("the MHD level stays resident on the GPU" in out) == (resident == "1"), out[-1500:]
+        assert ("MHD godunov_fine of fully refined levels on the MI355X (staged)" in out) == (resident == "0"), out[-1500:]
+        # the time steps come from the device's courant_fine: the run must take the reference's steps (checked below through t)
         got = rs.load_uniform_level(os.path.join(work, "output_00002"), level)
     finally:
         shutil.rmtree(work, ignore_errors=True)
