@@ -5,7 +5,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOCS = ["DESIGN.md", "INTEGRATION.md", "README.md", os.path.join("profiles", "README.md")]
+DOCS = ["DESIGN.md", "INTEGRATION.md", "README.md", os.path.join("profiles", "README.md"), os.path.join("docs", "REVIEW_HISTORY.md")]
 PAT = re.compile(r"`((?:tests|profiles|scripts|ramses_amd|oracle|include)/[A-Za-z0-9_./\-]+\.(?:py|hip|hpp|h|f90|c|sh|txt|json|csv|npz|md))`")
 # built artefacts and files of the reference tree that the docs name on purpose
 ALLOW = ("oracle/_ref/", "ramses_amd/lib/", "ramses_amd/build/")
