@@ -294,6 +294,22 @@ MHD_FN void lax_friedrich(double (&ql)[8], double (&qr)[8], double zero_flux, do
     fg[n] = fmean - vm * udiff;
   }
 }
+// upwind :313-347 (the 2-D solver 'upwind' calls it; cmpflxm's own case 4 calls lax_friedrich, umuscl.f90:1409-1410)
+MHD_FN void upwind(double (&ql)[8], double (&qr)[8], double zero_flux, double gamma, double (&fg)[9]) {
+  const double bx_mean = 0.5 * (ql[3] + qr[3]);
+  ql[3] = bx_mean; qr[3] = bx_mean;
+  double ul[9], fl[9], ur[9], fr[9];
+  find_mhd_flux(ql, gamma, ul, fl);
+  find_mhd_flux(qr, gamma, ur, fr);
+  const double vleft = 0.5 * (ql[2] + qr[2]);
+  for (int n = 0; n < 9; n++) {
+    const double fmean = 0.5 * (fr[n] + fl[n]) * zero_flux;
+    const double udiff = 0.5 * (ur[n] - ul[n]);
+    fg[n] = fmean - __builtin_fabs(vleft) * udiff;
+  }
+}
+// find_speed_alfven :857-873
+MHD_FN double find_speed_alfven(const double (&qv)[8]) { return __builtin_sqrt(qv[3] * qv[3] / qv[0]); }
 // hll :391-421
 MHD_FN void hll(double (&ql)[8], double (&qr)[8], double gamma, double (&fg)[9]) {
   const double bx_mean = 0.5 * (ql[3] + qr[3]);
@@ -407,7 +423,9 @@ MHD_FN void hlld(double (&ql)[8], double (&qr)[8], double gamma, double (&fg)[9]
 }
 
 MHD_FN bool riemann_supported(int r) { return r == RIEMANN_LLF || r == RIEMANN_HLL || r == RIEMANN_HLLD || r == RIEMANN_UPWIND; }
-MHD_FN bool riemann2d_supported(int r) { return r == RIEMANN2D_LLF || r == RIEMANN2D_HLL || r == RIEMANN2D_HLLD; }
+MHD_FN bool riemann2d_supported(int r) {
+  return r == RIEMANN2D_LLF || r == RIEMANN2D_UPWIND || r == RIEMANN2D_HLL || r == RIEMANN2D_HLLA || r == RIEMANN2D_HLLD;
+}
 
 // ---- cmpflxm :1308-1448, one face of direction d (0,1,2): qm_ = the state on the +d face of the cell below, qp_ = the state
 // on the -d face of the cell above; flx[0..7] in the reference's variable order (1..8), before the dt/dx scaling ----------
@@ -559,7 +577,26 @@ MHD_FN double cmp_mag_flx_edge(const double (&RT_)[8], const double (&RB_)[8], c
     return (SL * SB * ERR - SL * ST * ERL - SR * SB * ELR + SR * ST * ELL) / (SR - SL) / (ST - SB)
            - ST * SB / (ST - SB) * (qRR[5] - qLL[5]) + SR * SL / (SR - SL) * (qRR[6] - qLL[6]);
   }
-  // llf (iriemann2d = 0): the mean of the four edge values plus the diffusive terms of two 1-D solves (:1881-2021)
+  if (P.riemann2d == RIEMANN2D_HLLA) {
+    // :1859-1896: the HLL formula with the Alfven speeds of the four states
+    double t[8];
+    tmpx(qLL, t); const double vLLx = t[2], cLLx = find_speed_alfven(t);
+    tmpx(qLR, t); const double vLRx = t[2], cLRx = find_speed_alfven(t);
+    tmpx(qRL, t); const double vRLx = t[2], cRLx = find_speed_alfven(t);
+    tmpx(qRR, t); const double vRRx = t[2], cRRx = find_speed_alfven(t);
+    tmpy(qLL, t); const double vLLy = t[2], cLLy = find_speed_alfven(t);
+    tmpy(qLR, t); const double vLRy = t[2], cLRy = find_speed_alfven(t);
+    tmpy(qRL, t); const double vRLy = t[2], cRLy = find_speed_alfven(t);
+    tmpy(qRR, t); const double vRRy = t[2], cRRy = find_speed_alfven(t);
+    const double SL = fmin2(fmin4(vLLx, vLRx, vRLx, vRRx) - fmax4(cLLx, cLRx, cRLx, cRRx), 0.0);
+    const double SR = fmax2(fmax4(vLLx, vLRx, vRLx, vRRx) + fmax4(cLLx, cLRx, cRLx, cRRx), 0.0);
+    const double SB = fmin2(fmin4(vLLy, vLRy, vRLy, vRRy) - fmax4(cLLy, cLRy, cRLy, cRRy), 0.0);
+    const double ST = fmax2(fmax4(vLLy, vLRy, vRLy, vRRy) + fmax4(cLLy, cLRy, cRLy, cRRy), 0.0);
+    return (SL * SB * ERR - SL * ST * ERL - SR * SB * ELR + SR * ST * ELL) / (SR - SL) / (ST - SB)
+           - ST * SB / (ST - SB) * (qRR[5] - qLL[5]) + SR * SL / (SR - SL) * (qRR[6] - qLL[6]);
+  }
+  // llf (iriemann2d = 0) and upwind (2): the mean of the four edge values plus the diffusive terms of two 1-D solves (:1898-2021)
+  const bool up = P.riemann2d == RIEMANN2D_UPWIND;
   const double E = 0.25 * (ELL + ERL + ELR + ERR);
   double ql[8], qr[8], fx[9], fy[9];
   ql[0] = 0.5 * (qLL[0] + qLR[0]); qr[0] = 0.5 * (qRR[0] + qRL[0]);
@@ -570,7 +607,7 @@ MHD_FN double cmp_mag_flx_edge(const double (&RT_)[8], const double (&RB_)[8], c
   ql[5] = 0.5 * (qLL[6] + qLR[6]); qr[5] = 0.5 * (qRR[6] + qRL[6]);
   ql[6] = 0.5 * (qLL[4] + qLR[4]); qr[6] = 0.5 * (qRR[4] + qRL[4]);
   ql[7] = 0.5 * (qLL[7] + qLR[7]); qr[7] = 0.5 * (qRR[7] + qRL[7]);
-  lax_friedrich(ql, qr, 0.0, gamma, fx);
+  if (up) upwind(ql, qr, 0.0, gamma, fx); else lax_friedrich(ql, qr, 0.0, gamma, fx);
   ql[0] = 0.5 * (qLL[0] + qRL[0]); qr[0] = 0.5 * (qRR[0] + qLR[0]);
   ql[1] = 0.5 * (qLL[1] + qRL[1]); qr[1] = 0.5 * (qRR[1] + qLR[1]);
   ql[2] = 0.5 * (qLL[3] + qRL[3]); qr[2] = 0.5 * (qRR[3] + qLR[3]);
@@ -579,7 +616,7 @@ MHD_FN double cmp_mag_flx_edge(const double (&RT_)[8], const double (&RB_)[8], c
   ql[5] = 0.5 * (qLL[5] + qRL[5]); qr[5] = 0.5 * (qRR[5] + qLR[5]);
   ql[6] = 0.5 * (qLL[4] + qRL[4]); qr[6] = 0.5 * (qRR[4] + qLR[4]);
   ql[7] = 0.5 * (qLL[7] + qRL[7]); qr[7] = 0.5 * (qRR[7] + qLR[7]);
-  lax_friedrich(ql, qr, 0.0, gamma, fy);
+  if (up) upwind(ql, qr, 0.0, gamma, fy); else lax_friedrich(ql, qr, 0.0, gamma, fy);
   return E + (fx[5] - fy[5]);
 }
 

@@ -314,7 +314,7 @@ int make_const(const ramses_amd_mhd_params *p, MhdConst &P) {
   if (!riemann_supported(P.riemann))
     return failf(RAMSES_AMD_EUNSUPPORTED, "MHD sweep: riemann = llf (0), hll (2), hlld (3), upwind (4) are on the device (got %d)", P.riemann);
   if (!riemann2d_supported(P.riemann2d))
-    return failf(RAMSES_AMD_EUNSUPPORTED, "MHD sweep: riemann2d = llf (0), hll (3), hlld (5) are on the device (got %d)", P.riemann2d);
+    return failf(RAMSES_AMD_EUNSUPPORTED, "MHD sweep: riemann2d = llf (0), upwind (2), hll (3), hlla (4), hlld (5) are on the device (got %d)", P.riemann2d);
   return 0;
 }
 
