@@ -869,7 +869,7 @@ int ramses_amd_amrres_halo_stage_in(int ilevel, int dir);
  *           :1308-1448, cmp_mag_flx :1453-2028), mhd/godunov_utils.f90 lax_friedrich / hll / hlld :352-699, fused with
  *           set_unew (mhd/godunov_fine.f90:40-110).  NDIM = 3, NVAR = 8, NENER = 0, scheme = 'muscl'.
  * riemann: 0 llf, 2 hll, 3 hlld, 4 upwind (= llf in cmpflxm);  riemann2d: 0 llf, 2 upwind, 3 hll, 4 hlla, 5 hlld (the reference's iriemann /
- * iriemann2d codes, hydro/read_hydro_params.f90:184-220);  slope_type / slope_mag_type: 0, 1, 2, 7, 8 (slope_mag_type = -1
+ * iriemann2d codes, hydro/read_hydro_params.f90:184-220);  slope_type: 0, 1, 2, 3, 7, 8; slope_mag_type: 0, 1, 2, 7, 8 (slope_mag_type = -1
  * means slope_type, :528-530).  Anything else returns RAMSES_AMD_EUNSUPPORTED.
  * d_uold / d_unew: [11][nz][ny][nx] device doubles -- rho, rho u, rho v, rho w, E, the three left-face fields (uold(:,6:8)),
  * the three right-face fields (uold(:,nvar+1:nvar+3)) -- periodic, distinct buffers; the right-face field of a cell must equal

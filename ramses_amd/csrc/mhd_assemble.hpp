@@ -44,6 +44,27 @@ MHD_FN void trace_inputs(const A &a, int i, int j, int k, const MhdConst &P, Tra
   for (int n = 0; n < 8; n++) {
     const double q0 = a.q(n, i, j, k);
     I.q[n] = q0;
+    if (st == 3) {
+      // positivity-preserving 3-D unsplit slope (uslope :2420-2484): the central differences, scaled back so that no corner
+      // value leaves the range of the 27 neighbours
+      double vmin = 0.0, vmax = 0.0;      // (the centre's own difference is 0)
+      for (int dk = -1; dk <= 1; dk++)
+        for (int dj = -1; dj <= 1; dj++)
+          for (int di = -1; di <= 1; di++) {
+            const double df = a.q(n, i + di, j + dj, k + dk) - q0;
+            vmin = fmin2(vmin, df);
+            vmax = fmax2(vmax, df);
+          }
+      const double dfx = 0.5 * (a.q(n, i + 1, j, k) - a.q(n, i - 1, j, k));
+      const double dfy = 0.5 * (a.q(n, i, j + 1, k) - a.q(n, i, j - 1, k));
+      const double dfz = 0.5 * (a.q(n, i, j, k + 1) - a.q(n, i, j, k - 1));
+      const double dff = 0.5 * (__builtin_fabs(dfx) + __builtin_fabs(dfy) + __builtin_fabs(dfz));
+      const double slop = dff > 0.0 ? fmin2(1.0, fmin2(__builtin_fabs(vmin), __builtin_fabs(vmax)) / dff) : 1.0;
+      I.dq[0][n] = slop * dfx;
+      I.dq[1][n] = slop * dfy;
+      I.dq[2][n] = slop * dfz;
+      continue;
+    }
     I.dq[0][n] = slope(st, th, a.q(n, i - 1, j, k), q0, a.q(n, i + 1, j, k));
     I.dq[1][n] = slope(st, th, a.q(n, i, j - 1, k), q0, a.q(n, i, j + 1, k));
     I.dq[2][n] = slope(st, th, a.q(n, i, j, k - 1), q0, a.q(n, i, j, k + 1));

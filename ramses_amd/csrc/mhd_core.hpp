@@ -93,7 +93,10 @@ MHD_FN double cmpdt_cell(const double (&u)[11], double dx, double courant_factor
 
 // ---- one TVD slope (uslope :2375-2571 for the cell-centred variables, :2572-2842 for the face-centred fields: the same
 // limiter, chosen by slope_type / slope_mag_type) ---------------------------------------------------------------------
-MHD_FN bool slope_type_supported(int st) { return st == 0 || st == 1 || st == 2 || st == 7 || st == 8; }
+MHD_FN bool slope_mag_type_supported(int st) { return st == 0 || st == 1 || st == 2 || st == 7 || st == 8; }
+// (slope_type = 3, the positivity-preserving unsplit slope :2420-2484, needs the 27 neighbours: mhd_assemble.hpp trace_inputs;
+//  uslope has no such branch for the face fields, so it goes with an explicit slope_mag_type)
+MHD_FN bool slope_type_supported(int st) { return slope_mag_type_supported(st) || st == 3; }
 MHD_FN double slope(int st, double theta, double qm1, double q0, double qp1) {
   if (st == 1 || st == 2) {
     const double s = (double)st;

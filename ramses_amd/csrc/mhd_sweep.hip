@@ -309,8 +309,8 @@ int make_const(const ramses_amd_mhd_params *p, MhdConst &P) {
   P.slope_mag_type = p->slope_mag_type == -1 ? p->slope_type : p->slope_mag_type;      // hydro/read_hydro_params.f90:528-530
   P.riemann = p->riemann; P.riemann2d = p->riemann2d;
   if (!(p->gamma > 1.0)) return failf(RAMSES_AMD_EINVAL, "gamma must be > 1");
-  if (!slope_type_supported(P.slope_type) || !slope_type_supported(P.slope_mag_type))
-    return failf(RAMSES_AMD_EUNSUPPORTED, "MHD sweep: slope_type / slope_mag_type 0, 1, 2, 7, 8 are on the device (got %d / %d)", P.slope_type, P.slope_mag_type);
+  if (!slope_type_supported(P.slope_type) || !slope_mag_type_supported(P.slope_mag_type))
+    return failf(RAMSES_AMD_EUNSUPPORTED, "MHD sweep: slope_type 0, 1, 2, 3, 7, 8 and slope_mag_type 0, 1, 2, 7, 8 are on the device (got %d / %d)", P.slope_type, P.slope_mag_type);
   if (!riemann_supported(P.riemann))
     return failf(RAMSES_AMD_EUNSUPPORTED, "MHD sweep: riemann = llf (0), hll (2), hlld (3), upwind (4) are on the device (got %d)", P.riemann);
   if (!riemann2d_supported(P.riemann2d))

@@ -92,7 +92,8 @@ contains
          & .and. .not. allow_switch_solver2D &
          & .and. (iriemann == 0 .or. iriemann == 2 .or. iriemann == 3 .or. iriemann == 4) &
          & .and. (iriemann2d == 0 .or. iriemann2d == 2 .or. iriemann2d == 3 .or. iriemann2d == 4 .or. iriemann2d == 5) &
-         & .and. (slope_type == 0 .or. slope_type == 1 .or. slope_type == 2 .or. slope_type == 7 .or. slope_type == 8) &
+         & .and. (slope_type == 0 .or. slope_type == 1 .or. slope_type == 2 .or. slope_type == 3 .or. slope_type == 7 &
+         &        .or. slope_type == 8) &
          & .and. (slope_mag_type == 0 .or. slope_mag_type == 1 .or. slope_mag_type == 2 .or. slope_mag_type == 7 &
          &        .or. slope_mag_type == 8)
   end function ramses_amd_mhd_device_config

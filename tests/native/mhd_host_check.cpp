@@ -37,7 +37,7 @@ extern "C" int mhd_host_unsplit(const double *uin, int ngrid, int nvector, doubl
   MhdConst P;
   P.gamma = gamma; P.smallr = smallr; P.smallc = smallc; P.slope_theta = slope_theta;
   P.slope_type = slope_type; P.slope_mag_type = slope_mag_type; P.riemann = iriemann; P.riemann2d = iriemann2d;
-  if (!slope_type_supported(slope_type) || !slope_type_supported(slope_mag_type) || !riemann_supported(iriemann) || !riemann2d_supported(iriemann2d))
+  if (!slope_type_supported(slope_type) || !slope_mag_type_supported(slope_mag_type) || !riemann_supported(iriemann) || !riemann2d_supported(iriemann2d))
     return -2;
   const double dtdx = dt / dx;
   const int nv = nvector;

@@ -3,7 +3,7 @@ built from) against the COMPILED REFERENCE on the CPU: the headers are compiled 
 mhd_host_check.cpp) and driven over batches of the reference's own 6^3 stencils; mag_unsplit of the unmodified
 reference (mhd/umuscl.f90:31-238 behind oracle/ref_shim_mhd.f90, oracle/_ref/libref_kernels3d_mhd.so) sees the same
 stencils.  Fluxes of the five Euler variables and the three edge EMFs must be equal bit for bit, for every supported
-combination of 1-D solver (llf, hll, hlld, upwind), 2-D solver (llf, upwind, hll, hlla, hlld) and slope type (0, 1, 2, 7, 8).
+combination of 1-D solver (llf, hll, hlld, upwind), 2-D solver (llf, upwind, hll, hlla, hlld) and slope type (0, 1, 2, 7, 8, and 3 with slope_mag_type 1 / 8).
 SURVEY.md 8 row f4; the GPU leg is tests/test_mhd_gpu.py."""
 import ctypes as C
 import os
@@ -61,11 +61,13 @@ def stencils(nvec, seed, kind):
     return np.ascontiguousarray(u)
 
 
-@pytest.mark.parametrize("slope_type", [1, 2, 0, 7, 8])
+@pytest.mark.parametrize("slope_type", [1, 2, 0, 7, 8, (3, 1), (3, 8)])
 @pytest.mark.parametrize("riemann,riemann2d", [(0, 0), (3, 5), (2, 3), (3, 0), (0, 5), (4, 0), (3, 4), (0, 2), (2, 2), (4, 4)])
 @pytest.mark.parametrize("kind", ["smooth", "jump"])
 def test_headers_equal_the_compiled_reference(libs, slope_type, riemann, riemann2d, kind):
     host, ref, nvec = libs
+    # (slope_type, slope_mag_type): uslope has no branch 3 for the face fields, slope_type = 3 goes with an explicit slope_mag_type
+    slope_type, slope_mag_type = slope_type if isinstance(slope_type, tuple) else (slope_type, slope_type)
     gamma, smallr, smallc, theta = 5.0 / 3.0, 1e-10, 1e-10, 1.5
     uin = stencils(nvec, 100 * slope_type + 10 * riemann + riemann2d, kind)
     dx, dt = 1.0 / 64, 0.2 / 64
@@ -76,12 +78,12 @@ def test_headers_equal_the_compiled_reference(libs, slope_type, riemann, riemann
     flux_r = np.full((3, 8, 3, 3, 3, nvec), np.nan)
     tmp_r = np.full((3, 2, 3, 3, 3, nvec), np.nan)
     emf_r = [np.full((3, 3, 3, nvec), np.nan) for _ in range(3)]
-    ref.ref_mhd_set_params(dbl(gamma), dbl(smallr), dbl(smallc), slope_type, slope_type, dbl(theta), riemann, riemann2d)
+    ref.ref_mhd_set_params(dbl(gamma), dbl(smallr), dbl(smallc), slope_type, slope_mag_type, dbl(theta), riemann, riemann2d)
     ref.ref_mag_unsplit(vp(uin), vp(grav), vp(flux_r), vp(emf_r[0]), vp(emf_r[1]), vp(emf_r[2]), vp(tmp_r), dbl(dx), dbl(dx), dbl(dx), dbl(dt), nvec)
     # the product's headers on the host
     flux_h = np.full_like(flux_r, np.nan)
     emf_h = [np.full_like(e, np.nan) for e in emf_r]
-    rc = host.mhd_host_unsplit(vp(uin), nvec, nvec, dbl(dx), dbl(dt), dbl(gamma), dbl(smallr), dbl(smallc), slope_type, slope_type, dbl(theta),
+    rc = host.mhd_host_unsplit(vp(uin), nvec, nvec, dbl(dx), dbl(dt), dbl(gamma), dbl(smallr), dbl(smallc), slope_type, slope_mag_type, dbl(theta),
                                riemann, riemann2d, vp(flux_h), vp(emf_h[0]), vp(emf_h[1]), vp(emf_h[2]))
     assert rc == 0
     # where mag_unsplit defines its outputs (:100-236): fluxes through the faces of the central 2^3 cells, EMFs on their edges

@@ -53,13 +53,14 @@ def mhd_ic(n, gamma, seed=1):
 class StencilReference:
     """godfine1 of a fully refined periodic level through the compiled reference's mag_unsplit"""
 
-    def __init__(self, gamma, smallr, smallc, slope_type, theta, riemann, riemann2d):
+    def __init__(self, gamma, smallr, smallc, slope_type, theta, riemann, riemann2d, slope_mag_type=None):
         self.ref = C.CDLL(REF)
         nd, nvar, nvec = C.c_int(), C.c_int(), C.c_int()
         self.ref.ref_mhd_get_dims(C.byref(nd), C.byref(nvar), C.byref(nvec))
         assert (nd.value, nvar.value) == (3, 8)
         self.nvec = nvec.value
-        self.ref.ref_mhd_set_params(C.c_double(gamma), C.c_double(smallr), C.c_double(smallc), slope_type, slope_type, C.c_double(theta),
+        self.ref.ref_mhd_set_params(C.c_double(gamma), C.c_double(smallr), C.c_double(smallc), slope_type,
+                                    slope_type if slope_mag_type is None else slope_mag_type, C.c_double(theta),
                                     riemann, riemann2d)
 
     def step(self, u, dx, dt):
@@ -120,7 +121,7 @@ def divb(u, dx):
 @pytest.mark.parametrize("riemann,riemann2d,slope_type,n,nsteps", [
     ("llf", "llf", 1, 16, 4), ("hlld", "hlld", 2, 16, 4), ("hll", "hll", 1, 16, 3), ("hlld", "llf", 8, 16, 3),
     ("llf", "hlld", 7, 16, 3), ("upwind", "llf", 0, 16, 2), ("hlld", "hlld", 1, 24, 3), ("hlld", "hlla", 2, 16, 3),
-    ("llf", "upwind", 1, 16, 3),
+    ("llf", "upwind", 1, 16, 3), ("hlld", "hlld", (3, 1), 16, 3),
 ])
 def test_mhd_sweep_equals_the_compiled_reference(gpu_lib, riemann, riemann2d, slope_type, n, nsteps):
     if not os.path.exists(REF):
@@ -130,10 +131,14 @@ def test_mhd_sweep_equals_the_compiled_reference(gpu_lib, riemann, riemann2d, sl
     gamma, smallr, smallc, theta = 5.0 / 3.0, 1e-10, 1e-10, 1.5
     u = mhd_ic(n, gamma)
     dx = 1.0 / n
+    # (slope_type, slope_mag_type): slope_type = 3 goes with an explicit slope type of the face fields
+    slope_type, slope_mag = slope_type if isinstance(slope_type, tuple) else (slope_type, -1)
     lev = MhdLevel(n, n, n, dx, params=make_mhd_params(gamma=gamma, smallr=smallr, smallc=smallc, slope_type=slope_type,
-                                                         slope_theta=theta, riemann=riemann, riemann2d=riemann2d))
+                                                         slope_mag_type=slope_mag, slope_theta=theta, riemann=riemann,
+                                                         riemann2d=riemann2d))
     lev.upload(u)
-    ref = StencilReference(gamma, smallr, smallc, slope_type, theta, RIEMANN[riemann], RIEMANN2D[riemann2d])
+    ref = StencilReference(gamma, smallr, smallc, slope_type, theta, RIEMANN[riemann], RIEMANN2D[riemann2d],
+                           slope_mag_type=None if slope_mag == -1 else slope_mag)
     uo = u
     dt = 0.2 * dx / 4.0        # fast speed ~ 3-4 in the blast
     assert np.abs(divb(uo, dx)).max() < 1e-10
@@ -156,7 +161,7 @@ def test_mhd_sweep_refuses_what_it_does_not_implement(gpu_lib):
     import torch
     from ramses_amd import RamsesAmdError
     from ramses_amd.mhd import MhdLevel, make_mhd_params
-    for kw in (dict(riemann="roe"), dict(riemann2d="roe"), dict(slope_type=3), dict(riemann="hydro")):
+    for kw in (dict(riemann="roe"), dict(riemann2d="roe"), dict(slope_type=3), dict(riemann="hydro"), dict(slope_type=1, slope_mag_type=3)):
         lev = MhdLevel(8, 8, 8, 0.125, params=make_mhd_params(**kw))
         lev.uold[0].fill_(1.0)
         lev.uold[4].fill_(1.0)
