@@ -425,7 +425,46 @@ MHD_FN void hlld(double (&ql)[8], double (&qr)[8], double gamma, double (&fg)[9]
   fg[8] = uo * einto;
 }
 
-MHD_FN bool riemann_supported(int r) { return r == RIEMANN_LLF || r == RIEMANN_HLL || r == RIEMANN_HLLD || r == RIEMANN_UPWIND; }
+// hydro_acoustic :1092-1201 (riemann = 'hydro': the acoustic hydro solver on density, pressure, normal velocity; the other
+// components ride with the contact)
+MHD_FN void hydro_acoustic(double (&ql)[8], double (&qr)[8], double gamma, double smallr, double smallc, double (&fg)[9]) {
+  const double smallp = smallr * (smallc * smallc);
+  const double bx_mean = 0.5 * (ql[3] + qr[3]);
+  ql[3] = bx_mean; qr[3] = bx_mean;
+  const double rl = fmax2(ql[0], smallr), rr = fmax2(qr[0], smallr);
+  const double pl = fmax2(ql[1], smallp), pr = fmax2(qr[1], smallp);
+  const double ul = ql[2], ur = qr[2];
+  const double cl = __builtin_sqrt(gamma * pl / rl), cr = __builtin_sqrt(gamma * pr / rr);
+  const double wl = cl * rl, wr = cr * rr;
+  const double pstar = ((wr * pl + wl * pr) + wl * wr * (ul - ur)) / (wl + wr);
+  const double ustar = ((wr * ur + wl * ul) + (pl - pr)) / (wl + wr);
+  const double sgnm = __builtin_copysign(1.0, ustar);
+  const bool left = sgnm == 1.0;
+  const double ro = left ? rl : rr, uo = left ? ul : ur, po = left ? pl : pr, co = left ? cl : cr;
+  double rstar = ro + (pstar - po) / (co * co);
+  rstar = fmax2(rstar, smallr);
+  double cstar = __builtin_sqrt(__builtin_fabs(gamma * pstar / rstar));
+  cstar = fmax2(cstar, smallc);
+  double spout = co - sgnm * uo;
+  double spin = cstar - sgnm * ustar;
+  double ushock = 0.5 * (spin + spout);
+  ushock = fmax2(ushock, -sgnm * ustar);
+  if (pstar >= po) { spout = ushock; spin = spout; }
+  double qg[8];
+  if (spout < 0.0) { qg[0] = ro; qg[1] = po; qg[2] = uo; }
+  else if (spin >= 0.0) { qg[0] = rstar; qg[1] = pstar; qg[2] = ustar; }
+  else {
+    const double frac = spout / (spout - spin);
+    qg[0] = frac * rstar + (1.0 - frac) * ro;
+    qg[1] = frac * pstar + (1.0 - frac) * po;
+    qg[2] = frac * ustar + (1.0 - frac) * uo;
+  }
+  for (int n = 3; n < 8; n++) qg[n] = left ? ql[n] : qr[n];
+  double ug[9];
+  find_mhd_flux(qg, gamma, ug, fg);
+}
+
+MHD_FN bool riemann_supported(int r) { return r == RIEMANN_LLF || r == RIEMANN_HLL || r == RIEMANN_HLLD || r == RIEMANN_UPWIND || r == RIEMANN_HYDRO; }
 MHD_FN bool riemann2d_supported(int r) {
   return r == RIEMANN2D_LLF || r == RIEMANN2D_UPWIND || r == RIEMANN2D_HLL || r == RIEMANN2D_HLLA || r == RIEMANN2D_HLLD;
 }
@@ -443,6 +482,7 @@ MHD_FN void cmpflxm_face(const double (&qm_)[8], const double (&qp_)[8], int d, 
   switch (P.riemann) {
     case RIEMANN_HLL: hll(ql, qr, P.gamma, fg); break;
     case RIEMANN_HLLD: hlld(ql, qr, P.gamma, fg); break;
+    case RIEMANN_HYDRO: hydro_acoustic(ql, qr, P.gamma, P.smallr, P.smallc, fg); break;
     default: lax_friedrich(ql, qr, 1.0, P.gamma, fg); break;     // llf (0) and 'upwind' (4, cmpflxm :1409-1410)
   }
   flx[0] = fg[0]; flx[4] = fg[1]; flx[ln] = fg[2]; flx[bn] = fg[3]; flx[lt1] = fg[4]; flx[bt1] = fg[5]; flx[lt2] = fg[6]; flx[bt2] = fg[7];

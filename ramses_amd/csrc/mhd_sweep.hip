@@ -312,7 +312,7 @@ int make_const(const ramses_amd_mhd_params *p, MhdConst &P) {
   if (!slope_type_supported(P.slope_type) || !slope_mag_type_supported(P.slope_mag_type))
     return failf(RAMSES_AMD_EUNSUPPORTED, "MHD sweep: slope_type 0, 1, 2, 3, 7, 8 and slope_mag_type 0, 1, 2, 7, 8 are on the device (got %d / %d)", P.slope_type, P.slope_mag_type);
   if (!riemann_supported(P.riemann))
-    return failf(RAMSES_AMD_EUNSUPPORTED, "MHD sweep: riemann = llf (0), hll (2), hlld (3), upwind (4) are on the device (got %d)", P.riemann);
+    return failf(RAMSES_AMD_EUNSUPPORTED, "MHD sweep: riemann = llf (0), hll (2), hlld (3), upwind (4), hydro (5) are on the device (got %d)", P.riemann);
   if (!riemann2d_supported(P.riemann2d))
     return failf(RAMSES_AMD_EUNSUPPORTED, "MHD sweep: riemann2d = llf (0), upwind (2), hll (3), hlla (4), hlld (5) are on the device (got %d)", P.riemann2d);
   return 0;
