@@ -866,9 +866,10 @@ int ramses_amd_amrres_halo_stage_in(int ilevel, int dir);
  * SOLVER=mhd: the constrained-transport MHD Godunov sweep.
  * Replaces: mhd/godunov_fine.f90 godfine1 :538-1459 on a fully refined periodic level (no coarse-fine boundaries),
  *           mhd/umuscl.f90 mag_unsplit :31-238 (ctoprim :2029-2186, uslope :2187-2844, trace3d :750-1307, cmpflxm
- *           :1308-1448, cmp_mag_flx :1453-2028), mhd/godunov_utils.f90 upwind / lax_friedrich / hll / hlld / hydro_acoustic :313-1201, fused with
+ *           :1308-1448, cmp_mag_flx :1453-2028), mhd/godunov_utils.f90 upwind / lax_friedrich / hll / hlld / athena_roe / hydro_acoustic / eigen_cons :313-1517, fused with
  *           set_unew (mhd/godunov_fine.f90:40-110).  NDIM = 3, NVAR = 8, NENER = 0, scheme = 'muscl'.
- * riemann: 0 llf, 2 hll, 3 hlld, 4 upwind (= llf in cmpflxm), 5 hydro (hydro_acoustic);  riemann2d: 0 llf, 2 upwind, 3 hll, 4 hlla, 5 hlld (the reference's iriemann /
+ * riemann: 0 llf, 1 roe, 2 hll, 3 hlld, 4 upwind (= llf in cmpflxm), 5 hydro (hydro_acoustic);  riemann2d: 0 llf, 1 roe, 2 upwind,
+ * 3 hll, 4 hlla, 5 hlld -- every solver of the reference (its iriemann /
  * iriemann2d codes, hydro/read_hydro_params.f90:184-220);  slope_type: 0, 1, 2, 3, 7, 8; slope_mag_type: 0, 1, 2, 7, 8 (slope_mag_type = -1
  * means slope_type, :528-530).  Anything else returns RAMSES_AMD_EUNSUPPORTED.
  * d_uold / d_unew: [11][nz][ny][nx] device doubles -- rho, rho u, rho v, rho w, E, the three left-face fields (uold(:,6:8)),

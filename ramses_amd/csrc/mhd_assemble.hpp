@@ -37,14 +37,16 @@ MHD_FN double efield(const A &a, int c, int i, int j, int k) {
 }
 
 // uslope + the gathers of trace3d (:841-925) for cell (i,j,k)
-template <class A>
+// (S3: slope_type = 3 is compiled in -- its loop over the 27 neighbours indexes the slope arrays dynamically, which costs the
+// device kernel its registers; the device instantiates the trace with and without it)
+template <bool S3 = true, class A>
 MHD_FN void trace_inputs(const A &a, int i, int j, int k, const MhdConst &P, TraceIn &I) {
   const int st = P.slope_type, sm = P.slope_mag_type;
   const double th = P.slope_theta;
   for (int n = 0; n < 8; n++) {
     const double q0 = a.q(n, i, j, k);
     I.q[n] = q0;
-    if (st == 3) {
+    if (S3 && st == 3) {
       // positivity-preserving 3-D unsplit slope (uslope :2420-2484): the central differences, scaled back so that no corner
       // value leaves the range of the 27 neighbours
       double vmin = 0.0, vmax = 0.0;      // (the centre's own difference is 0)

@@ -425,6 +425,273 @@ MHD_FN void hlld(double (&ql)[8], double (&qr)[8], double gamma, double (&fg)[9]
   fg[8] = uo * einto;
 }
 
+// eigenvalues :1207-1261 (MHD adiabatic eigenvalues of one state; athena_roe uses entries 1, 3, 5, 7 for its entropy fix)
+MHD_FN void roe_eigenvalues(double d, double vx, double p, double bx, double by, double bz, double gamma, double smallc, double (&lambda)[7]) {
+  const double btsq = by * by + bz * bz;
+  const double vaxsq = bx * bx / d;
+  const double vax = __builtin_sqrt(vaxsq);
+  double asq = gamma * p / d;
+  asq = fmax2(asq, smallc * smallc);
+  const double astarsq = asq + vaxsq + btsq / d;
+  const double disc = __builtin_sqrt(astarsq * astarsq - 4.0 * asq * vaxsq);
+  const double cfsq = 0.5 * (astarsq + disc);
+  const double cfast = __builtin_sqrt(cfsq);
+  double cssq = 0.5 * (astarsq - disc);
+  if (cssq <= 0.0) cssq = 0.0;
+  const double cslow = __builtin_sqrt(cssq);
+  lambda[0] = vx - cfast; lambda[1] = vx - vax; lambda[2] = vx - cslow; lambda[3] = vx;
+  lambda[4] = vx + cslow; lambda[5] = vx + vax; lambda[6] = vx + cfast;
+}
+// eigen_cons :1266-1517: eigenvalues, right (rem[wave][component]) and left (lem[component][wave]) eigenmatrices of the
+// Roe-averaged state in conserved variables (rho, rho vx, rho vy, rho vz, E, by, bz)
+MHD_FN void roe_eigen_cons(double d, double vx, double vy, double vz, double h, double Bx, double by, double bz, double Xfac, double Yfac,
+                           double gamma, double smallc, double (&lambda)[7], double (&rem)[7][7], double (&lem)[7][7]) {
+  const double gm1 = gamma - 1.0, gm2 = gamma - 2.0;
+  const double vsq = vx * vx + vy * vy + vz * vz;
+  const double btsq = by * by + bz * bz;
+  const double bt_starsq = (gm1 - gm2 * Yfac) * btsq;
+  const double bt = __builtin_sqrt(btsq);
+  const double bt_star = __builtin_sqrt(bt_starsq);
+  const double vaxsq = Bx * Bx / d;
+  const double vax = __builtin_sqrt(vaxsq);
+  const double hp = h - (vaxsq + btsq / d);
+  double twid_asq = (gm1 * (hp - 0.5 * vsq) - gm2 * Xfac);
+  twid_asq = fmax2(twid_asq, smallc * smallc);
+  const double q_starsq = twid_asq + (vaxsq + bt_starsq / d);
+  const double disc = __builtin_sqrt(q_starsq * q_starsq - 4.0 * twid_asq * vaxsq);
+  const double cfsq = 0.5 * (q_starsq + disc);
+  const double cfast = __builtin_sqrt(cfsq);
+  double cssq = 0.5 * (q_starsq - disc);
+  if (cssq <= 0.0) cssq = 0.0;
+  const double cslow = __builtin_sqrt(cssq);
+  double beta_y, beta_z, beta_ystar, beta_zstar;
+  if (bt == 0.0) {
+    // the reference writes .5*sqrt(2.): default-REAL arithmetic, then promoted
+    const double hs = (double)(0.5f * __builtin_sqrtf(2.0f));
+    beta_y = hs; beta_z = hs; beta_ystar = hs; beta_zstar = hs;
+  } else {
+    beta_y = by / bt; beta_z = bz / bt; beta_ystar = by / bt_star; beta_zstar = bz / bt_star;
+  }
+  const double beta_starsq = beta_ystar * beta_ystar + beta_zstar * beta_zstar;
+  const double vbeta = vy * beta_ystar + vz * beta_zstar;
+  double alpha_f, alpha_s;
+  if ((cfsq - cssq) == 0.0) { alpha_f = 1.0; alpha_s = 0.0; }
+  else if ((twid_asq - cssq) <= 0.0) { alpha_f = 0.0; alpha_s = 1.0; }
+  else if ((cfsq - twid_asq) <= 0.0) { alpha_f = 1.0; alpha_s = 0.0; }
+  else {
+    alpha_f = __builtin_sqrt((twid_asq - cssq) / (cfsq - cssq));
+    alpha_s = __builtin_sqrt((cfsq - twid_asq) / (cfsq - cssq));
+  }
+  const double droot = __builtin_sqrt(d);
+  const double s = __builtin_copysign(1.0, Bx);
+  const double twid_a = __builtin_sqrt(twid_asq);
+  double Qfast = s * cfast * alpha_f;
+  double Qslow = s * cslow * alpha_s;
+  const double af_prime = twid_a * alpha_f / droot;
+  const double as_prime = twid_a * alpha_s / droot;
+  const double Afpbb = af_prime * bt_star * beta_starsq;
+  const double Aspbb = as_prime * bt_star * beta_starsq;
+  lambda[0] = vx - cfast; lambda[1] = vx - vax; lambda[2] = vx - cslow; lambda[3] = vx;
+  lambda[4] = vx + cslow; lambda[5] = vx + vax; lambda[6] = vx + cfast;
+  // right eigenmatrix
+  rem[0][0] = alpha_f;
+  rem[0][1] = alpha_f * (vx - cfast);
+  rem[0][2] = alpha_f * vy + Qslow * beta_ystar;
+  rem[0][3] = alpha_f * vz + Qslow * beta_zstar;
+  rem[0][4] = alpha_f * (hp - vx * cfast) + Qslow * vbeta + Aspbb;
+  rem[0][5] = as_prime * beta_ystar;
+  rem[0][6] = as_prime * beta_zstar;
+  rem[1][0] = 0.0; rem[1][1] = 0.0;
+  rem[1][2] = -beta_z;
+  rem[1][3] = beta_y;
+  rem[1][4] = -(vy * beta_z - vz * beta_y);
+  rem[1][5] = -s * beta_z / droot;
+  rem[1][6] = s * beta_y / droot;
+  rem[2][0] = alpha_s;
+  rem[2][1] = alpha_s * (vx - cslow);
+  rem[2][2] = alpha_s * vy - Qfast * beta_ystar;
+  rem[2][3] = alpha_s * vz - Qfast * beta_zstar;
+  rem[2][4] = alpha_s * (hp - vx * cslow) - Qfast * vbeta - Afpbb;
+  rem[2][5] = -af_prime * beta_ystar;
+  rem[2][6] = -af_prime * beta_zstar;
+  rem[3][0] = 1.0; rem[3][1] = vx; rem[3][2] = vy; rem[3][3] = vz;
+  rem[3][4] = 0.5 * vsq + gm2 * Xfac / gm1;
+  rem[3][5] = 0.0; rem[3][6] = 0.0;
+  rem[4][0] = alpha_s;
+  rem[4][1] = alpha_s * (vx + cslow);
+  rem[4][2] = alpha_s * vy + Qfast * beta_ystar;
+  rem[4][3] = alpha_s * vz + Qfast * beta_zstar;
+  rem[4][4] = alpha_s * (hp + vx * cslow) + Qfast * vbeta - Afpbb;
+  rem[4][5] = rem[2][5];
+  rem[4][6] = rem[2][6];
+  rem[5][0] = 0.0; rem[5][1] = 0.0;
+  rem[5][2] = beta_z;
+  rem[5][3] = -beta_y;
+  rem[5][4] = -rem[1][4];
+  rem[5][5] = rem[1][5];
+  rem[5][6] = rem[1][6];
+  rem[6][0] = alpha_f;
+  rem[6][1] = alpha_f * (vx + cfast);
+  rem[6][2] = alpha_f * vy - Qslow * beta_ystar;
+  rem[6][3] = alpha_f * vz - Qslow * beta_zstar;
+  rem[6][4] = alpha_f * (hp + vx * cfast) - Qslow * vbeta + Aspbb;
+  rem[6][5] = rem[0][5];
+  rem[6][6] = rem[0][6];
+  // left eigenmatrix: some quantities normalised by 1/(2 a^2), some by (gamma-1)/(2 a^2)
+  const double na = 0.5 / twid_asq;
+  const double cff = na * alpha_f * cfast;
+  const double css = na * alpha_s * cslow;
+  Qfast = Qfast * na;
+  Qslow = Qslow * na;
+  const double af = na * af_prime * d;
+  const double as = na * as_prime * d;
+  const double Afpb = na * af_prime * bt_star;
+  const double Aspb = na * as_prime * bt_star;
+  alpha_f = gm1 * na * alpha_f;
+  alpha_s = gm1 * na * alpha_s;
+  const double Q_ystar = beta_ystar / beta_starsq;
+  const double Q_zstar = beta_zstar / beta_starsq;
+  const double vqstr = (vy * Q_ystar + vz * Q_zstar);
+  const double norm = gm1 * 2.0 * na;
+  lem[0][0] = alpha_f * (vsq - hp) + cff * (cfast + vx) - Qslow * vqstr - Aspb;
+  lem[1][0] = -alpha_f * vx - cff;
+  lem[2][0] = -alpha_f * vy + Qslow * Q_ystar;
+  lem[3][0] = -alpha_f * vz + Qslow * Q_zstar;
+  lem[4][0] = alpha_f;
+  lem[5][0] = as * Q_ystar - alpha_f * by;
+  lem[6][0] = as * Q_zstar - alpha_f * bz;
+  lem[0][1] = 0.5 * (vy * beta_z - vz * beta_y);
+  lem[1][1] = 0.0;
+  lem[2][1] = -0.5 * beta_z;
+  lem[3][1] = 0.5 * beta_y;
+  lem[4][1] = 0.0;
+  lem[5][1] = -0.5 * droot * beta_z * s;
+  lem[6][1] = 0.5 * droot * beta_y * s;
+  lem[0][2] = alpha_s * (vsq - hp) + css * (cslow + vx) + Qfast * vqstr + Afpb;
+  lem[1][2] = -alpha_s * vx - css;
+  lem[2][2] = -alpha_s * vy - Qfast * Q_ystar;
+  lem[3][2] = -alpha_s * vz - Qfast * Q_zstar;
+  lem[4][2] = alpha_s;
+  lem[5][2] = -af * Q_ystar - alpha_s * by;
+  lem[6][2] = -af * Q_zstar - alpha_s * bz;
+  lem[0][3] = 1.0 - norm * (0.5 * vsq - gm2 * Xfac / gm1);
+  lem[1][3] = norm * vx;
+  lem[2][3] = norm * vy;
+  lem[3][3] = norm * vz;
+  lem[4][3] = -norm;
+  lem[5][3] = norm * by;
+  lem[6][3] = norm * bz;
+  lem[0][4] = alpha_s * (vsq - hp) + css * (cslow - vx) - Qfast * vqstr + Afpb;
+  lem[1][4] = -alpha_s * vx + css;
+  lem[2][4] = -alpha_s * vy + Qfast * Q_ystar;
+  lem[3][4] = -alpha_s * vz + Qfast * Q_zstar;
+  lem[4][4] = alpha_s;
+  lem[5][4] = lem[5][2];
+  lem[6][4] = lem[6][2];
+  lem[0][5] = -lem[0][1];
+  lem[1][5] = 0.0;
+  lem[2][5] = -lem[2][1];
+  lem[3][5] = -lem[3][1];
+  lem[4][5] = 0.0;
+  lem[5][5] = lem[5][1];
+  lem[6][5] = lem[6][1];
+  lem[0][6] = alpha_f * (vsq - hp) + cff * (cfast - vx) + Qslow * vqstr - Aspb;
+  lem[1][6] = -alpha_f * vx + cff;
+  lem[2][6] = -alpha_f * vy - Qslow * Q_ystar;
+  lem[3][6] = -alpha_f * vz - Qslow * Q_zstar;
+  lem[4][6] = alpha_f;
+  lem[5][6] = lem[5][0];
+  lem[6][6] = lem[6][0];
+}
+// athena_roe :878-1087: the Roe flux with the entropy fix of the genuinely non-linear waves; falls back to the
+// Lax-Friedrichs flux when an intermediate state has a negative density or thermal energy
+MHD_FN void athena_roe(double (&ql)[8], double (&qr)[8], double zero_flux, double gamma, double smallc, double (&fg)[9]) {
+  const double bx_mean = 0.5 * (ql[3] + qr[3]);
+  ql[3] = bx_mean; qr[3] = bx_mean;
+  double ul[9], fl[9], ur[9], fr[9];
+  find_mhd_flux(ql, gamma, ul, fl);
+  find_mhd_flux(qr, gamma, ur, fr);
+  const double dl = ql[0], dr = qr[0], pl = ql[1], pr = qr[1], vxl = ql[2], vxr = qr[2];
+  const double vyl = ql[4], vyr = qr[4], byl = ql[5], byr = qr[5], vzl = ql[6], vzr = qr[6], bzl = ql[7], bzr = qr[7];
+  const double bx = 0.5 * (ql[3] + qr[3]);
+  const double el = ul[1], er = ur[1], mxl = ul[2], mxr = ur[2], myl = ul[4], myr = ur[4], mzl = ul[6], mzr = ur[6];
+  const double pbl = 0.5 * (bx * bx + byl * byl + bzl * bzl);
+  const double pbr = 0.5 * (bx * bx + byr * byr + bzr * bzr);
+  const double hl = (el + pl + pbl) / dl, hr = (er + pr + pbr) / dr;
+  const double sqrtdl = __builtin_sqrt(dl), sqrtdr = __builtin_sqrt(dr);
+  const double droe = sqrtdl * sqrtdr;
+  const double vxroe = (sqrtdl * vxl + sqrtdr * vxr) / (sqrtdl + sqrtdr);
+  const double vyroe = (sqrtdl * vyl + sqrtdr * vyr) / (sqrtdl + sqrtdr);
+  const double vzroe = (sqrtdl * vzl + sqrtdr * vzr) / (sqrtdl + sqrtdr);
+  const double byroe = (sqrtdr * byl + sqrtdl * byr) / (sqrtdl + sqrtdr);
+  const double bzroe = (sqrtdr * bzl + sqrtdl * bzr) / (sqrtdl + sqrtdr);
+  const double hroe = (sqrtdl * hl + sqrtdr * hr) / (sqrtdl + sqrtdr);
+  const double Xfactor = ((byroe * byroe - byl * byr) + (bzroe * bzroe - bzl * bzr)) / (2.0 * droe);
+  const double Yfactor = (dl + dr) / (2.0 * droe);
+  double lambda[7], lambdal[7], lambdar[7], rem[7][7], lem[7][7], a[7];
+  roe_eigen_cons(droe, vxroe, vyroe, vzroe, hroe, bx, byroe, bzroe, Xfactor, Yfactor, gamma, smallc, lambda, rem, lem);
+  roe_eigenvalues(dl, vxl, pl, bx, byl, bzl, gamma, smallc, lambdal);
+  roe_eigenvalues(dr, vxr, pr, bx, byr, bzr, gamma, smallc, lambdar);
+  for (int n = 0; n < 7; n++) {
+    double an = 0.0;
+    an = an + (dr - dl) * lem[0][n];
+    an = an + (mxr - mxl) * lem[1][n];
+    an = an + (myr - myl) * lem[2][n];
+    an = an + (mzr - mzl) * lem[3][n];
+    an = an + (er - el) * lem[4][n];
+    an = an + (byr - byl) * lem[5][n];
+    an = an + (bzr - bzl) * lem[6][n];
+    a[n] = an;
+  }
+  bool llf = false;
+  double dim = dl, mxm = mxl, mym = myl, mzm = mzl, eim = el, bym = byl, bzm = bzl;
+  for (int n = 0; n < 7; n++) {
+    dim = dim + a[n] * rem[n][0];
+    mxm = mxm + a[n] * rem[n][1];
+    mym = mym + a[n] * rem[n][2];
+    mzm = mzm + a[n] * rem[n][3];
+    eim = eim + a[n] * rem[n][4];
+    bym = bym + a[n] * rem[n][5];
+    bzm = bzm + a[n] * rem[n][6];
+    const double etm = eim - 0.5 * (mxm * mxm + mym * mym + mzm * mzm) / dim - 0.5 * (bx * bx + bym * bym + bzm * bzm);
+    if (dim <= 0.0 || etm <= 0.0) llf = true;
+  }
+  if (llf) {
+    const double vleft = find_speed_info(ql, gamma), vright = find_speed_info(qr, gamma);
+    const double vm = fmax2(vleft, vright);
+    for (int n = 0; n < 9; n++) {
+      const double fmean = 0.5 * (fr[n] + fl[n]) * zero_flux;
+      const double udiff = 0.5 * (ur[n] - ul[n]);
+      fg[n] = fmean - vm * udiff;
+    }
+    return;
+  }
+  for (int n = 0; n < 7; n += 2) {
+    const double l1 = fmin2(lambdal[n], lambda[n]);
+    const double l2 = fmax2(lambdar[n], lambda[n]);
+    if (l1 < 0.0 && l2 > 0.0) lambda[n] = (lambda[n] * (l2 + l1) - 2.0 * l2 * l1) / (l2 - l1);
+  }
+  double fluxd = fl[0] * zero_flux + fr[0] * zero_flux;
+  double fluxe = fl[1] * zero_flux + fr[1] * zero_flux;
+  double fluxmx = fl[2] * zero_flux + fr[2] * zero_flux;
+  double fluxmy = fl[4] * zero_flux + fr[4] * zero_flux;
+  double fluxby = fl[5] * zero_flux + fr[5] * zero_flux;
+  double fluxmz = fl[6] * zero_flux + fr[6] * zero_flux;
+  double fluxbz = fl[7] * zero_flux + fr[7] * zero_flux;
+  for (int n = 0; n < 7; n++) {
+    const double coef = __builtin_fabs(lambda[n]) * a[n];
+    fluxd = fluxd - coef * rem[n][0];
+    fluxe = fluxe - coef * rem[n][4];
+    fluxmx = fluxmx - coef * rem[n][1];
+    fluxmy = fluxmy - coef * rem[n][2];
+    fluxby = fluxby - coef * rem[n][5];
+    fluxmz = fluxmz - coef * rem[n][3];
+    fluxbz = fluxbz - coef * rem[n][6];
+  }
+  fg[0] = 0.5 * fluxd; fg[1] = 0.5 * fluxe; fg[2] = 0.5 * fluxmx; fg[3] = 0.0; fg[4] = 0.5 * fluxmy; fg[5] = 0.5 * fluxby;
+  fg[6] = 0.5 * fluxmz; fg[7] = 0.5 * fluxbz; fg[8] = 0.0;
+}
+
 // hydro_acoustic :1092-1201 (riemann = 'hydro': the acoustic hydro solver on density, pressure, normal velocity; the other
 // components ride with the contact)
 MHD_FN void hydro_acoustic(double (&ql)[8], double (&qr)[8], double gamma, double smallr, double smallc, double (&fg)[9]) {
@@ -464,13 +731,14 @@ MHD_FN void hydro_acoustic(double (&ql)[8], double (&qr)[8], double gamma, doubl
   find_mhd_flux(qg, gamma, ug, fg);
 }
 
-MHD_FN bool riemann_supported(int r) { return r == RIEMANN_LLF || r == RIEMANN_HLL || r == RIEMANN_HLLD || r == RIEMANN_UPWIND || r == RIEMANN_HYDRO; }
-MHD_FN bool riemann2d_supported(int r) {
-  return r == RIEMANN2D_LLF || r == RIEMANN2D_UPWIND || r == RIEMANN2D_HLL || r == RIEMANN2D_HLLA || r == RIEMANN2D_HLLD;
-}
+MHD_FN bool riemann_supported(int r) { return r >= RIEMANN_LLF && r <= RIEMANN_HYDRO; }
+MHD_FN bool riemann2d_supported(int r) { return r >= RIEMANN2D_LLF && r <= RIEMANN2D_HLLD; }
 
 // ---- cmpflxm :1308-1448, one face of direction d (0,1,2): qm_ = the state on the +d face of the cell below, qp_ = the state
 // on the -d face of the cell above; flx[0..7] in the reference's variable order (1..8), before the dt/dx scaling ----------
+// (RS = -1: P.riemann decides at run time; RS = -2: the same without the Roe solver, whose eigenmatrices would cost every
+// solver its registers -- the device's general kernel; RS >= 0: the solver is a compile-time constant)
+template <int RS = -1>
 MHD_FN void cmpflxm_face(const double (&qm_)[8], const double (&qp_)[8], int d, const MhdConst &P, double (&flx)[8]) {
   // ln, lt1, lt2 / bn, bt1, bt2 (0-based) of mag_unsplit's three calls (:96-98, :118-120, :142-144)
   const int ln = 1 + d, lt1 = d == 0 ? 2 : 1, lt2 = d == 2 ? 2 : 3;
@@ -479,10 +747,11 @@ MHD_FN void cmpflxm_face(const double (&qm_)[8], const double (&qp_)[8], int d, 
   double ql[8] = {qm_[0], qm_[4], qm_[ln], bn_mean, qm_[lt1], qm_[bt1], qm_[lt2], qm_[bt2]};
   double qr[8] = {qp_[0], qp_[4], qp_[ln], bn_mean, qp_[lt1], qp_[bt1], qp_[lt2], qp_[bt2]};
   double fg[9];
-  switch (P.riemann) {
+  switch (RS >= 0 ? RS : P.riemann) {
     case RIEMANN_HLL: hll(ql, qr, P.gamma, fg); break;
     case RIEMANN_HLLD: hlld(ql, qr, P.gamma, fg); break;
     case RIEMANN_HYDRO: hydro_acoustic(ql, qr, P.gamma, P.smallr, P.smallc, fg); break;
+    case RIEMANN_ROE: if (RS != -2) { athena_roe(ql, qr, 1.0, P.gamma, P.smallc, fg); break; }
     default: lax_friedrich(ql, qr, 1.0, P.gamma, fg); break;     // llf (0) and 'upwind' (4, cmpflxm :1409-1410)
   }
   flx[0] = fg[0]; flx[4] = fg[1]; flx[ln] = fg[2]; flx[bn] = fg[3]; flx[lt1] = fg[4]; flx[bt1] = fg[5]; flx[lt2] = fg[6]; flx[bt2] = fg[7];
@@ -491,8 +760,10 @@ MHD_FN void cmpflxm_face(const double (&qm_)[8], const double (&qp_)[8], int d, 
 // ---- cmp_mag_flx :1453-2028, one edge of direction e (0,1,2 = x, y, z).  The four states around the edge, as the routine
 // names them AFTER its dummy-argument shuffle: RT_, RB_, LT_, LB_ (which cell's qRT / qRB / qLT / qLB each one is depends on
 // the direction: mag_unsplit :165-169, :199-203, :216-220 -- the caller knows) ---------------------------------------------
+template <int R2 = -1>
 MHD_FN double cmp_mag_flx_edge(const double (&RT_)[8], const double (&RB_)[8], const double (&LT_)[8], const double (&LB_)[8], int e,
                                const MhdConst &P) {
+  const int riemann2d = R2 >= 0 ? R2 : P.riemann2d;
   // lp1, lp2, lor / bp1, bp2, bor (0-based) of the three calls: z: 2,3,4,6,7,8; y: 4,2,3,8,6,7; x: 3,4,2,7,8,6
   const int lp1 = e == 2 ? 1 : (e == 1 ? 3 : 2), lp2 = e == 2 ? 2 : (e == 1 ? 1 : 3), lor = e == 2 ? 3 : (e == 1 ? 2 : 1);
   const int bp1 = lp1 + 4, bp2 = lp2 + 4, bor = lor + 4;
@@ -515,7 +786,7 @@ MHD_FN double cmp_mag_flx_edge(const double (&RT_)[8], const double (&RB_)[8], c
   // the 1-D states find_speed_fast sees: relative to x (p1 normal) and to y (p2 normal)
   auto tmpx = [](const double (&s)[8], double (&t)[8]) { t[0] = s[0]; t[1] = s[1]; t[6] = s[4]; t[7] = s[7]; t[2] = s[2]; t[3] = s[5]; t[4] = s[3]; t[5] = s[6]; };
   auto tmpy = [](const double (&s)[8], double (&t)[8]) { t[0] = s[0]; t[1] = s[1]; t[6] = s[4]; t[7] = s[7]; t[2] = s[3]; t[3] = s[6]; t[4] = s[2]; t[5] = s[5]; };
-  if (P.riemann2d == RIEMANN2D_HLLD) {
+  if (riemann2d == RIEMANN2D_HLLD) {
     const double rLL = qLL[0], pLL = qLL[1], uLL = qLL[2], vLL = qLL[3], ALL = qLL[5], BLL = qLL[6], CLL = qLL[7];
     const double rLR = qLR[0], pLR = qLR[1], uLR = qLR[2], vLR = qLR[3], ALR = qLR[5], BLR = qLR[6], CLR = qLR[7];
     const double rRL = qRL[0], pRL = qRL[1], uRL = qRL[2], vRL = qRL[3], ARL = qRL[5], BRL = qRL[6], CRL = qRL[7];
@@ -603,7 +874,7 @@ MHD_FN double cmp_mag_flx_edge(const double (&RT_)[8], const double (&RB_)[8], c
     }
     return E;      // (allow_switch_solver2D = .false., the default: :1771-1777)
   }
-  if (P.riemann2d == RIEMANN2D_HLL) {
+  if (riemann2d == RIEMANN2D_HLL) {
     double t[8];
     tmpx(qLL, t); const double vLLx = t[2], cLLx = find_speed_fast(t, gamma);
     tmpx(qLR, t); const double vLRx = t[2], cLRx = find_speed_fast(t, gamma);
@@ -620,7 +891,7 @@ MHD_FN double cmp_mag_flx_edge(const double (&RT_)[8], const double (&RB_)[8], c
     return (SL * SB * ERR - SL * ST * ERL - SR * SB * ELR + SR * ST * ELL) / (SR - SL) / (ST - SB)
            - ST * SB / (ST - SB) * (qRR[5] - qLL[5]) + SR * SL / (SR - SL) * (qRR[6] - qLL[6]);
   }
-  if (P.riemann2d == RIEMANN2D_HLLA) {
+  if (riemann2d == RIEMANN2D_HLLA) {
     // :1859-1896: the HLL formula with the Alfven speeds of the four states
     double t[8];
     tmpx(qLL, t); const double vLLx = t[2], cLLx = find_speed_alfven(t);
@@ -639,7 +910,7 @@ MHD_FN double cmp_mag_flx_edge(const double (&RT_)[8], const double (&RB_)[8], c
            - ST * SB / (ST - SB) * (qRR[5] - qLL[5]) + SR * SL / (SR - SL) * (qRR[6] - qLL[6]);
   }
   // llf (iriemann2d = 0) and upwind (2): the mean of the four edge values plus the diffusive terms of two 1-D solves (:1898-2021)
-  const bool up = P.riemann2d == RIEMANN2D_UPWIND;
+  const bool up = riemann2d == RIEMANN2D_UPWIND, roe = R2 != -2 && riemann2d == RIEMANN2D_ROE;
   const double E = 0.25 * (ELL + ERL + ELR + ERR);
   double ql[8], qr[8], fx[9], fy[9];
   ql[0] = 0.5 * (qLL[0] + qLR[0]); qr[0] = 0.5 * (qRR[0] + qRL[0]);
@@ -650,7 +921,7 @@ MHD_FN double cmp_mag_flx_edge(const double (&RT_)[8], const double (&RB_)[8], c
   ql[5] = 0.5 * (qLL[6] + qLR[6]); qr[5] = 0.5 * (qRR[6] + qRL[6]);
   ql[6] = 0.5 * (qLL[4] + qLR[4]); qr[6] = 0.5 * (qRR[4] + qRL[4]);
   ql[7] = 0.5 * (qLL[7] + qLR[7]); qr[7] = 0.5 * (qRR[7] + qRL[7]);
-  if (up) upwind(ql, qr, 0.0, gamma, fx); else lax_friedrich(ql, qr, 0.0, gamma, fx);
+  if (roe) athena_roe(ql, qr, 0.0, gamma, P.smallc, fx); else if (up) upwind(ql, qr, 0.0, gamma, fx); else lax_friedrich(ql, qr, 0.0, gamma, fx);
   ql[0] = 0.5 * (qLL[0] + qRL[0]); qr[0] = 0.5 * (qRR[0] + qLR[0]);
   ql[1] = 0.5 * (qLL[1] + qRL[1]); qr[1] = 0.5 * (qRR[1] + qLR[1]);
   ql[2] = 0.5 * (qLL[3] + qRL[3]); qr[2] = 0.5 * (qRR[3] + qLR[3]);
@@ -659,7 +930,7 @@ MHD_FN double cmp_mag_flx_edge(const double (&RT_)[8], const double (&RB_)[8], c
   ql[5] = 0.5 * (qLL[5] + qRL[5]); qr[5] = 0.5 * (qRR[5] + qLR[5]);
   ql[6] = 0.5 * (qLL[4] + qRL[4]); qr[6] = 0.5 * (qRR[4] + qLR[4]);
   ql[7] = 0.5 * (qLL[7] + qRL[7]); qr[7] = 0.5 * (qRR[7] + qLR[7]);
-  if (up) upwind(ql, qr, 0.0, gamma, fy); else lax_friedrich(ql, qr, 0.0, gamma, fy);
+  if (roe) athena_roe(ql, qr, 0.0, gamma, P.smallc, fy); else if (up) upwind(ql, qr, 0.0, gamma, fy); else lax_friedrich(ql, qr, 0.0, gamma, fy);
   return E + (fx[5] - fy[5]);
 }
 

@@ -129,13 +129,14 @@ struct PredSrc {
   __device__ __forceinline__ double f(int n) const { return pr[pred_at(8 + n, cell)]; }
   __device__ __forceinline__ double h(int n) const { return pr[pred_at(14 + n, cell)]; }
 };
+template <bool S3>
 __global__ __launch_bounds__(128) void mhd_trace_kernel(MhdArgs A) {
   DevAcc a{{A.nx, A.ny, A.nz}, A.q, A.uold + 5 * A.ncell, A.E, A.ncell};
   const double dtdx = A.dt / A.dx;
   MHD_CELL_LOOP(A) {
     MHD_IJK(A);
     TraceIn I;
-    trace_inputs(a, i, j, k, A.P, I);
+    trace_inputs<S3>(a, i, j, k, A.P, I);
     TracePred T;
     trace_predict(I, dtdx, dtdx, dtdx, A.P, T);
 #pragma unroll
@@ -145,29 +146,30 @@ __global__ __launch_bounds__(128) void mhd_trace_kernel(MhdArgs A) {
 
 // flux[d][0..4] through the LOW face of direction d of the cell, scaled as mag_unsplit does (fx*dt/dx, :105-111): the +d
 // state of the cell below and the -d state of the cell, each rebuilt from its predicted state and half slopes
-template <int D>
+template <int D, int RS>
 __device__ __forceinline__ void mhd_face_flux(const MhdArgs &A, const Grid &g, int i, int j, int k, long c_) {
   const PredSrc lo{A.tr, g.at(i - (D == 0), j - (D == 1), k - (D == 2))}, me{A.tr, c_};
   double qm_[8], qp_[8], f[8];
   trace_state<T_QM, D>(lo, A.P, qm_);
   trace_state<T_QP, D>(me, A.P, qp_);
-  cmpflxm_face(qm_, qp_, D, A.P, f);
+  cmpflxm_face<RS>(qm_, qp_, D, A.P, f);
 #pragma unroll
   for (int n = 0; n < 5; n++) A.flux[(long)(D * 5 + n) * A.ncell + c_] = f[n] * A.dt / A.dx;
 }
+template <int RS>
 __global__ __launch_bounds__(128) void mhd_flux_kernel(MhdArgs A) {
   const Grid g{A.nx, A.ny, A.nz};
   MHD_CELL_LOOP(A) {
     MHD_IJK(A);
-    mhd_face_flux<0>(A, g, i, j, k, c_);
-    mhd_face_flux<1>(A, g, i, j, k, c_);
-    mhd_face_flux<2>(A, g, i, j, k, c_);
+    mhd_face_flux<0, RS>(A, g, i, j, k, c_);
+    mhd_face_flux<1, RS>(A, g, i, j, k, c_);
+    mhd_face_flux<2, RS>(A, g, i, j, k, c_);
   }
 }
 
 // emf[e] on the LOW edge of direction e of the cell, scaled as mag_unsplit does (emf*dt/dx, :171-177); which cell's corner
 // state plays which part: mhd_assemble.hpp edge_sources
-template <int E>
+template <int E, int R2>
 __device__ __forceinline__ void mhd_edge_emf(const MhdArgs &A, const Grid &g, int i, int j, int k, long c_) {
   double rt[8], rb[8], lt[8], lb[8];
   using Src = PredSrc;
@@ -183,15 +185,16 @@ __device__ __forceinline__ void mhd_edge_emf(const MhdArgs &A, const Grid &g, in
     trace_state<T_QRT, 0>(a, A.P, rt); trace_state<T_QRB, 0>(b, A.P, rb); trace_state<T_QLT, 0>(c, A.P, lt);
   }
   trace_state<T_QLB, E>(me, A.P, lb);
-  A.emf[(long)E * A.ncell + c_] = cmp_mag_flx_edge(rt, rb, lt, lb, E, A.P) * A.dt / A.dx;
+  A.emf[(long)E * A.ncell + c_] = cmp_mag_flx_edge<R2>(rt, rb, lt, lb, E, A.P) * A.dt / A.dx;
 }
+template <int R2>
 __global__ __launch_bounds__(128) void mhd_emf_kernel(MhdArgs A) {
   const Grid g{A.nx, A.ny, A.nz};
   MHD_CELL_LOOP(A) {
     MHD_IJK(A);
-    mhd_edge_emf<0>(A, g, i, j, k, c_);
-    mhd_edge_emf<1>(A, g, i, j, k, c_);
-    mhd_edge_emf<2>(A, g, i, j, k, c_);
+    mhd_edge_emf<0, R2>(A, g, i, j, k, c_);
+    mhd_edge_emf<1, R2>(A, g, i, j, k, c_);
+    mhd_edge_emf<2, R2>(A, g, i, j, k, c_);
   }
 }
 
@@ -312,9 +315,9 @@ int make_const(const ramses_amd_mhd_params *p, MhdConst &P) {
   if (!slope_type_supported(P.slope_type) || !slope_mag_type_supported(P.slope_mag_type))
     return failf(RAMSES_AMD_EUNSUPPORTED, "MHD sweep: slope_type 0, 1, 2, 3, 7, 8 and slope_mag_type 0, 1, 2, 7, 8 are on the device (got %d / %d)", P.slope_type, P.slope_mag_type);
   if (!riemann_supported(P.riemann))
-    return failf(RAMSES_AMD_EUNSUPPORTED, "MHD sweep: riemann = llf (0), hll (2), hlld (3), upwind (4), hydro (5) are on the device (got %d)", P.riemann);
+    return failf(RAMSES_AMD_EINVAL, "MHD sweep: riemann must be 0 (llf) .. 5 (hydro) (got %d)", P.riemann);
   if (!riemann2d_supported(P.riemann2d))
-    return failf(RAMSES_AMD_EUNSUPPORTED, "MHD sweep: riemann2d = llf (0), upwind (2), hll (3), hlla (4), hlld (5) are on the device (got %d)", P.riemann2d);
+    return failf(RAMSES_AMD_EINVAL, "MHD sweep: riemann2d must be 0 (llf) .. 5 (hlld) (got %d)", P.riemann2d);
   return 0;
 }
 
@@ -354,9 +357,16 @@ int ramses_amd_mhd_godunov_brick(const ramses_amd_mhd_params *p, int nx, int ny,
   HCHK(hipMemsetAsync(A.bad, 0, sizeof(int), s), "memset");
   hipLaunchKernelGGL(mhd_prim_kernel, dim3(grid_for(N, 256)), dim3(256), 0, s, A);
   hipLaunchKernelGGL(mhd_efield_kernel, dim3(grid_for(N, 256)), dim3(256), 0, s, A);
-  hipLaunchKernelGGL(mhd_trace_kernel, dim3(grid_for(N, 128)), dim3(128), 0, s, A);
-  hipLaunchKernelGGL(mhd_flux_kernel, dim3(grid_for(N, 128)), dim3(128), 0, s, A);
-  hipLaunchKernelGGL(mhd_emf_kernel, dim3(grid_for(N, 128)), dim3(128), 0, s, A);
+  if (A.P.slope_type == 3) hipLaunchKernelGGL(mhd_trace_kernel<true>, dim3(grid_for(N, 128)), dim3(128), 0, s, A);
+  else hipLaunchKernelGGL(mhd_trace_kernel<false>, dim3(grid_for(N, 128)), dim3(128), 0, s, A);
+  // the flux / EMF kernels: one general instance (the solver is a run-time switch) and one for the Roe solver, whose
+  // eigenmatrices would otherwise cost every solver its registers.  (One instance per solver was measured too: fewer
+  // registers -- hlld: flux 136 instead of 156, EMF 188 instead of 214 -- but 10.95 instead of 10.08 ms per sweep at 256^3.)
+  const dim3 g128(grid_for(N, 128)), b128(128);
+  if (A.P.riemann == RIEMANN_ROE) hipLaunchKernelGGL(mhd_flux_kernel<RIEMANN_ROE>, g128, b128, 0, s, A);
+  else hipLaunchKernelGGL(mhd_flux_kernel<-2>, g128, b128, 0, s, A);
+  if (A.P.riemann2d == RIEMANN2D_ROE) hipLaunchKernelGGL(mhd_emf_kernel<RIEMANN2D_ROE>, g128, b128, 0, s, A);
+  else hipLaunchKernelGGL(mhd_emf_kernel<-2>, g128, b128, 0, s, A);
   hipLaunchKernelGGL(mhd_update_kernel, dim3(grid_for(N, 256)), dim3(256), 0, s, A);
   HCHK(hipGetLastError(), "MHD sweep launch");
   int bad = 0;

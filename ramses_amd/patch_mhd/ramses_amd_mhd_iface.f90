@@ -90,8 +90,7 @@ contains
          & .and. nboundary == 0 .and. nx_loc == 1 .and. jcoarse_max == jcoarse_min .and. kcoarse_max == kcoarse_min &
          & .and. .not. poisson .and. .not. pressure_fix .and. ischeme == 0 .and. .not. allow_switch_solver &
          & .and. .not. allow_switch_solver2D &
-         & .and. (iriemann == 0 .or. iriemann == 2 .or. iriemann == 3 .or. iriemann == 4 .or. iriemann == 5) &
-         & .and. (iriemann2d == 0 .or. iriemann2d == 2 .or. iriemann2d == 3 .or. iriemann2d == 4 .or. iriemann2d == 5) &
+         & .and. iriemann >= 0 .and. iriemann <= 5 .and. iriemann2d >= 0 .and. iriemann2d <= 5 &
          & .and. (slope_type == 0 .or. slope_type == 1 .or. slope_type == 2 .or. slope_type == 3 .or. slope_type == 7 &
          &        .or. slope_type == 8) &
          & .and. (slope_mag_type == 0 .or. slope_mag_type == 1 .or. slope_mag_type == 2 .or. slope_mag_type == 7 &

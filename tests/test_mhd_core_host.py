@@ -3,7 +3,7 @@ built from) against the COMPILED REFERENCE on the CPU: the headers are compiled 
 mhd_host_check.cpp) and driven over batches of the reference's own 6^3 stencils; mag_unsplit of the unmodified
 reference (mhd/umuscl.f90:31-238 behind oracle/ref_shim_mhd.f90, oracle/_ref/libref_kernels3d_mhd.so) sees the same
 stencils.  Fluxes of the five Euler variables and the three edge EMFs must be equal bit for bit, for every supported
-combination of 1-D solver (llf, hll, hlld, upwind, hydro), 2-D solver (llf, upwind, hll, hlla, hlld) and slope type (0, 1, 2, 7, 8, and 3 with slope_mag_type 1 / 8).
+combination of 1-D solver (llf, roe, hll, hlld, upwind, hydro), 2-D solver (llf, roe, upwind, hll, hlla, hlld) and slope type (0, 1, 2, 7, 8, and 3 with slope_mag_type 1 / 8).
 SURVEY.md 8 row f4; the GPU leg is tests/test_mhd_gpu.py."""
 import ctypes as C
 import os
@@ -62,7 +62,7 @@ def stencils(nvec, seed, kind):
 
 
 @pytest.mark.parametrize("slope_type", [1, 2, 0, 7, 8, (3, 1), (3, 8)])
-@pytest.mark.parametrize("riemann,riemann2d", [(0, 0), (3, 5), (2, 3), (3, 0), (0, 5), (4, 0), (3, 4), (0, 2), (2, 2), (4, 4), (5, 0), (5, 5)])
+@pytest.mark.parametrize("riemann,riemann2d", [(0, 0), (3, 5), (2, 3), (3, 0), (0, 5), (4, 0), (3, 4), (0, 2), (2, 2), (4, 4), (5, 0), (5, 5), (1, 0), (1, 1), (3, 1), (1, 5)])
 @pytest.mark.parametrize("kind", ["smooth", "jump"])
 def test_headers_equal_the_compiled_reference(libs, slope_type, riemann, riemann2d, kind):
     host, ref, nvec = libs

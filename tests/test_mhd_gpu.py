@@ -121,7 +121,8 @@ def divb(u, dx):
 @pytest.mark.parametrize("riemann,riemann2d,slope_type,n,nsteps", [
     ("llf", "llf", 1, 16, 4), ("hlld", "hlld", 2, 16, 4), ("hll", "hll", 1, 16, 3), ("hlld", "llf", 8, 16, 3),
     ("llf", "hlld", 7, 16, 3), ("upwind", "llf", 0, 16, 2), ("hlld", "hlld", 1, 24, 3), ("hlld", "hlla", 2, 16, 3),
-    ("llf", "upwind", 1, 16, 3), ("hlld", "hlld", (3, 1), 16, 3), ("hydro", "llf", 1, 16, 3),
+    ("llf", "upwind", 1, 16, 3), ("hlld", "hlld", (3, 1), 16, 3), ("hydro", "llf", 1, 16, 3), ("roe", "roe", 1, 16, 3),
+    ("hlld", "roe", 2, 16, 2), ("roe", "hlld", 8, 16, 2),
 ])
 def test_mhd_sweep_equals_the_compiled_reference(gpu_lib, riemann, riemann2d, slope_type, n, nsteps):
     if not os.path.exists(REF):
@@ -161,7 +162,7 @@ def test_mhd_sweep_refuses_what_it_does_not_implement(gpu_lib):
     import torch
     from ramses_amd import RamsesAmdError
     from ramses_amd.mhd import MhdLevel, make_mhd_params
-    for kw in (dict(riemann="roe"), dict(riemann2d="roe"), dict(slope_type=3), dict(slope_type=1, slope_mag_type=3)):
+    for kw in (dict(slope_type=3), dict(slope_type=1, slope_mag_type=3), dict(slope_type=4), dict(riemann=7)):
         lev = MhdLevel(8, 8, 8, 0.125, params=make_mhd_params(**kw))
         lev.uold[0].fill_(1.0)
         lev.uold[4].fill_(1.0)
