@@ -158,3 +158,21 @@ def test_mhd_patch_with_the_switch_off_is_the_reference_program():
         else:
             os.environ["RAMSES_AMD"] = old
     assert snaps[0].shape[0] == 11 and np.array_equal(snaps[0], snaps[1])
+
+
+@pytest.mark.skipif(not os.path.exists(PATCHED), reason="oracle/_ref/ramses3d_patch not built")
+def test_amr_run_between_walls_through_the_reference_routines():
+    """RAMSES_AMD=0 behind the round-4 shims too: hydro_boundary.f90 (make_boundary_hydro) and the boundary octs in the
+    level lists -- the walls golden of tests/golden/make_golden_amr.py"""
+    mka = _load(os.path.join(ROOT, "tests", "golden", "make_golden_amr.py"), "mka")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "amr_godunov_ref.npz"))
+    rs, (work, out) = _run(mka.walls_namelist())
+    try:
+        assert "MI355X" not in out and "resident on the GPU" not in out
+        snap = rs.load_leaf_cells(os.path.join(work, "output_00002"))
+        order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+        assert np.array_equal(snap["level"][order], z["walls_level"])
+        assert np.array_equal(snap["x"][order], z["walls_x"])
+        assert np.array_equal(snap["prim"][:, order], z["walls_prim"])
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
