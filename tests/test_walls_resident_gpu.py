@@ -252,3 +252,28 @@ def test_self_gravity_between_walls_stays_resident(gpu_lib):
     assert np.array_equal(got["prim"].view(np.int64), ref["prim"].view(np.int64)), np.abs(got["prim"] - ref["prim"]).max()
     if "grav" in ref:
         assert np.array_equal(np.asarray(got["grav"]).view(np.int64), np.asarray(ref["grav"]).view(np.int64))
+
+
+def test_self_gravity_between_walls_under_mpi_stays_resident(gpu_lib):
+    """the same on 2 ranks: hydro state, tree and communicators resident on every rank, make_boundary_hydro on the device; the
+    Dirichlet solves, rho_fine and force_fine + make_boundary_force keep the reference's MPI routines"""
+    from oracle import ramses_snapshot as rs
+    if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED_MPI)):
+        pytest.skip("oracle/_ref MPI programs not built")
+    nml = _mka().walls_selfgrav_namelist().replace("ngridtot=20000 !", "ngridtot=60000 !")
+    workp, outp = _run(nml, PATCHED_MPI, 2, {"RAMSES_AMD": "1", "RAMSES_AMD_PROFILE": "1"})
+    try:
+        assert "AMR levels stay resident on the GPU" in outp, outp[-3000:]
+        assert "make_boundary_hydro (device)" in outp, outp[-3000:]
+        got = rs.load_leaf_cells(os.path.join(workp, "output_00002"))
+    finally:
+        shutil.rmtree(workp, ignore_errors=True)
+    workr, outr = _run(nml, REF_MPI, 2, {})
+    try:
+        ref = rs.load_leaf_cells(os.path.join(workr, "output_00002"))
+    finally:
+        shutil.rmtree(workr, ignore_errors=True)
+    og = np.lexsort((got["x"][:, 0], got["x"][:, 1], got["x"][:, 2], got["level"]))
+    orf = np.lexsort((ref["x"][:, 0], ref["x"][:, 1], ref["x"][:, 2], ref["level"]))
+    assert np.array_equal(got["level"][og], ref["level"][orf]) and np.array_equal(got["x"][og], ref["x"][orf])
+    assert np.array_equal(got["prim"][:, og].view(np.int64), ref["prim"][:, orf].view(np.int64))
