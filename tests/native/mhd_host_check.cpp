@@ -31,6 +31,10 @@ struct Acc {
 };
 }  // namespace
 
+// gravin: null, or the acceleration gravin(nvector,-1:4,-1:4,-1:4,3) of the reference (ctoprim's half-step kick :2160-2170)
+static const double *g_gravin = nullptr;
+extern "C" void mhd_host_set_gravin(const double *gravin) { g_gravin = gravin; }
+
 extern "C" int mhd_host_unsplit(const double *uin, int ngrid, int nvector, double dx, double dt, double gamma, double smallr, double smallc,
                                 int slope_type, int slope_mag_type, double slope_theta, int iriemann, int iriemann2d, double *flux,
                                 double *emfx, double *emfy, double *emfz) {
@@ -59,7 +63,10 @@ extern "C" int mhd_host_unsplit(const double *uin, int ngrid, int nvector, doubl
           const double bl[3] = {S.u(5, i, j, k), S.u(6, i, j, k), S.u(7, i, j, k)};
           const double br[3] = {S.u(8, i, j, k), S.u(9, i, j, k), S.u(10, i, j, k)};
           double q[8];
-          ctoprim_cell(u, bl, br, nullptr, dt, P, q);
+          double gv[3];
+          if (g_gravin)
+            for (int d = 0; d < 3; d++) gv[d] = g_gravin[l + (size_t)nv * ((i + 1) + 6 * ((j + 1) + 6 * ((k + 1) + 6 * (size_t)d)))];
+          ctoprim_cell(u, bl, br, g_gravin ? gv : nullptr, dt, P, q);
           for (int n = 0; n < 8; n++) a.qw(n, i, j, k) = q[n];
         }
     for (int k = -1; k <= 5; k++)
