@@ -342,25 +342,34 @@ def amr_sweep_bench(level=8, steps=5, partial=False):
     return out
 
 
-def amr_covered_bench(level=8, steps=5):
-    """godunov_fine of a FULLY COVERED level that has refined cells (levelmin of every AMR run): level `level` complete, level+1
-    present in a spherical shell.  ramses_amd_amrres_godunov routes such a level through the dense sweep with its refinement
-    mask (gather from the resident cell vectors, masked z-marching kernel, scatter; csrc/capi_amr.hip covered_level_sweep);
-    the same call with RAMSES_AMD_COVERED_DENSE=0 walks the tree.  Strict arithmetic in both."""
+def amr_resident_bench(level=8, steps=5, kind="covered"):
+    """godunov_fine of a level of a RESIDENT AMR run (ramses_amd_amrres_godunov: the path the patched program takes).  The device
+    numbers the octs itself -- levels in tiles of 32 x 4 x 4 octs (csrc/amr_layout.hpp) -- and sweeps such a level with the dense
+    z-marching kernel in place (ghost octs interpolated into free tile slots, fluxes owed to the coarser level filed and
+    replayed); the same call with RAMSES_AMD_TILE_DENSE=0 / RAMSES_AMD_COVERED_DENSE=0 walks the tree on the same layout.
+      kind="full"     level `level` complete, nothing finer                (the tree-walking sweep's best case)
+      kind="covered"  level `level` complete, level+1 in a spherical shell (levelmin of an AMR run: refined cells inside)
+      kind="partial"  level `level` in a spherical shell over a complete level-1 (ghost octs and coarse-fine fluxes on both surfaces)
+    Strict arithmetic in all of them.  Timed with events around the call (list upload, ghost pre-pass, sweep, replay)."""
     import numpy as np
     import torch
     import ramses_amd
     from ramses_amd import ic
     from ramses_amd._capi import check, lib
-    n = 2 ** level
-    z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
-    r = np.sqrt((x - n / 2 + 0.5) ** 2 + (y - n / 2 + 0.5) ** 2 + (z - n / 2 + 0.5) ** 2)
-    mask = (r >= 0.23 * n) & (r <= 0.36 * n)
-    del x, y, z, r
-    T = ic.uniform_tree(level, order="morton", refine_mask=mask)
-    igrid = np.ascontiguousarray(T["igrid"])
+    Lfull = level - 1 if kind == "partial" else level
+    n = 2 ** Lfull
+    mask = None
+    if kind != "full":
+        z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+        r = np.sqrt((x - n / 2 + 0.5) ** 2 + (y - n / 2 + 0.5) ** 2 + (z - n / 2 + 0.5) ** 2)
+        mask = (r >= 0.23 * n) & (r <= 0.36 * n)
+        del x, y, z, r
+    # room in ngridmax for the tiles of the partial level (a production namelist's ngridmax has that slack anyway)
+    T = ic.uniform_tree(Lfull, order="morton", refine_mask=mask, slack=7 if mask is None else int(1.6 * mask.sum()) + 4096)
+    igrid = np.ascontiguousarray(T["igrid_fine"] if kind == "partial" else T["igrid"])
+    lists = [np.ascontiguousarray(T["igrid"])] + ([np.ascontiguousarray(T["igrid_fine"])] if mask is not None else [])
     ncells = 8 * len(igrid)
-    dx = 0.5 / n
+    dx = 0.5 / 2 ** level
     u = np.zeros((5, T["ncell"]))
     u[0] = 1.0
     u[4] = 1e-5 / 0.4
@@ -371,32 +380,45 @@ def amr_covered_bench(level=8, steps=5):
     out = {}
     for tag, env in (("dense", "1"), ("tree", "0")):
         os.environ["RAMSES_AMD_COVERED_DENSE"] = env
+        os.environ["RAMSES_AMD_TILE_DENSE"] = env
         check(L.ramses_amd_amrres_invalidate())
         check(L.ramses_amd_amrres_load(5, T["ngridmax"], T["ncoarse"], vp(u), vp(T["son"]), vp(T["nbor"]), vp(T["father"])))
-        before = L.ramses_amd_amrres_covered_sweeps()
+        before = L.ramses_amd_amrres_tile_sweeps()
+
+        def one():
+            for ig in lists:
+                check(L.ramses_amd_amrres_set_unew(len(ig), vp(ig)))
         for _ in range(2):
-            check(L.ramses_amd_amrres_set_unew(len(igrid), vp(igrid)))
+            one()
             check(L.ramses_amd_amrres_godunov(C.byref(p), level, len(igrid), vp(igrid), dx, 1e-6, 32, 0, 1))
         torch.cuda.synchronize()
         t = 0.0
         for _ in range(steps):
-            check(L.ramses_amd_amrres_set_unew(len(igrid), vp(igrid)))
+            one()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            a.record()
             check(L.ramses_amd_amrres_godunov(C.byref(p), level, len(igrid), vp(igrid), dx, 1e-6, 32, 0, 1))
+            b.record()
             torch.cuda.synchronize()
-            t += time.perf_counter() - t0
-        out[tag] = (t / steps * 1e3, L.ramses_amd_amrres_covered_sweeps() - before)
+            t += a.elapsed_time(b)
+        out[tag] = (t / steps, L.ramses_amd_amrres_tile_sweeps() - before, L.ramses_amd_amrres_tiled_levels())
     os.environ.pop("RAMSES_AMD_COVERED_DENSE", None)
+    os.environ.pop("RAMSES_AMD_TILE_DENSE", None)
     check(L.ramses_amd_amrres_invalidate())
-    ms, took = out["dense"]
+    ms, took, tiled = out["dense"]
     gbs = ncells * BYTES_PER_CELL_UPDATE_AMR / (ms * 1e-3) / 1e9
-    return {"metric": "cell-updates/s (godunov_fine of a fully covered AMR level, dense sweep with the refinement mask)",
+    work = {"full": "level %d complete (%d^3), nothing finer" % (level, 2 ** level),
+            "covered": "level %d complete (%d^3), level %d in a spherical shell: %d of its cells refined" % (level, n, level + 1, 0 if mask is None else int(mask.sum())),
+            "partial": "level %d in a spherical shell (%d cells) over a complete level %d" % (level, ncells, level - 1)}[kind]
+    return {"metric": "cell-updates/s (godunov_fine of a level of a resident AMR run, dense sweep on the device's tiles)",
             "value": ncells / (ms * 1e-3), "unit": "cell-updates/s", "ms_per_sweep": ms, "cells": ncells,
-            "dense_sweeps_taken": int(took), "tree_walking_ms_per_sweep": out["tree"][0],
-            "arithmetic": "strict (bit-identical to the reference)",
-            "workload": "level %d complete (%d^3), level %d in a spherical shell: %d of its cells refined" % (level, n, level + 1, int(mask.sum())),
-            "includes": "oct origins from the father pointers, gather of uold / unew into bricks, the mask, the sweep, scatter of unew; host-timed",
+            "dense_sweeps_taken": int(took), "levels_in_tiles": int(tiled), "tree_walking_ms_per_sweep": out["tree"][0],
+            "tree_walking_frac": ncells * BYTES_PER_CELL_UPDATE_AMR / (out["tree"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "arithmetic": "strict (bit-identical to the reference)", "workload": work,
+            "layout": "device numbering: tiles of 32x4x4 octs (csrc/amr_layout.hpp); host tree numbered along a Z-order curve",
+            "includes": "oct list upload, ghost-oct interpolation pre-pass, the dense sweep in place on the cell vectors, the replay of the "
+                        "fluxes owed to the coarser level; HIP events around ramses_amd_amrres_godunov",
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "bytes_per_cell": BYTES_PER_CELL_UPDATE_AMR}}
 
@@ -778,12 +800,16 @@ def main():
         if world == 1 and args.amr_level > 0:
             try:
                 torch.cuda.empty_cache()
-                out["amr_sweep"] = amr_sweep_bench(args.amr_level)
-                out["amr_sweep_partial"] = amr_sweep_bench(args.amr_level + 1, partial=True)
+                # the resident path (what the patched program runs): device numbering in tiles + the dense sweep in place;
+                # the tree-walking kernel on the host's own numbering beside it
+                out["amr_sweep"] = amr_resident_bench(args.amr_level, kind="full")
+                out["amr_sweep_partial"] = amr_resident_bench(args.amr_level + 1, kind="partial")
+                out["amr_sweep_covered"] = amr_resident_bench(args.amr_level, kind="covered")
                 torch.cuda.empty_cache()
-                out["amr_sweep_covered"] = amr_covered_bench(args.amr_level)
+                out["amr_sweep_tree_walking"] = amr_sweep_bench(args.amr_level)
+                out["amr_sweep_partial_tree_walking"] = amr_sweep_bench(args.amr_level + 1, partial=True)
             except Exception as exc:     # noqa: BLE001  (an extra line, never a reason to lose the headline)
-                out["amr_sweep"] = {"value": None, "error": str(exc)[:300]}
+                out.setdefault("amr_sweep", {"value": None})["error"] = str(exc)[:300]
         if world == 1 and args.mhd_level > 0:
             try:
                 torch.cuda.empty_cache()

@@ -825,12 +825,25 @@ int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, co
                                  double err_grad_u, double floor_d, double floor_p, double floor_u, int *cells, int *ncells);
 int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, double dx, double dt,
                               int nvector, int interpol_var, int interpol_type);
-/* A level whose octs fill the periodic box (levelmin, any complete level) takes the DENSE sweep inside ramses_amd_amrres_godunov:
- * gathered into bricks, swept with its refinement mask (fluxes through the faces of refined cells reset, the update starting from
- * unew: hydro/godunov_fine.f90:661-666,720-790), scattered back -- strict arithmetic, bit-identical to the tree-walking sweep.
- * NVAR = 5, muscl, slope types 0/1/2/7/8, every Riemann solver but 'exact', no difmag / pressure_fix; RAMSES_AMD_COVERED_DENSE=0
- * keeps the tree-walking sweep.  ramses_amd_amrres_covered_sweeps: how many sweeps took the dense path so far. */
+/* The device numbers the octs of a resident run itself (csrc/amr_layout.hpp): the cell vectors keep the reference's formula
+ * icell = ncoarse + (ind-1)*ngridmax + igrid (hydro/godunov_fine.f90:600-601), but levels of 64^3 .. 4096^3 cells are stored in
+ * TILES of 32 x 4 x 4 octs -- level-contiguous SoA blocks, 256-byte runs along x -- and every list / index that crosses this
+ * interface is translated.  godunov_fine of such a level runs the DENSE z-marching sweep in place inside
+ * ramses_amd_amrres_godunov: fluxes through the faces of refined cells reset, the update starting from unew
+ * (hydro/godunov_fine.f90:661-666,720-790), missing neighbour octs interpolated once per sweep into free tile slots (:563-626),
+ * the fluxes owed to the coarser level filed and replayed in the reference's order (:798-908) -- strict arithmetic,
+ * bit-identical to the tree-walking sweep and to the reference.  NVAR = 5, muscl, slope types 0/1/2/7/8, every Riemann solver
+ * but 'exact', no difmag / pressure_fix, one coarse cell (no physical boundaries); anything else keeps the tree-walking sweep.
+ * Switches: RAMSES_AMD_DEVICE_ORDER=0 (the host's numbering on the device, tree-walking sweep everywhere), RAMSES_AMD_TILES=0
+ * (Z-order numbering, no tiles), RAMSES_AMD_COVERED_DENSE=0 / RAMSES_AMD_TILE_DENSE=0 (fully refined / partial levels keep the
+ * tree-walking sweep), RAMSES_AMD_DEVICE_OCTS=f (the device's index space = f x ngridmax: tiles that are not full cost
+ * indices; a level that does not fit is numbered along the Z-order curve and keeps the tree-walking sweep).
+ * _covered_sweeps: sweeps of fully refined levels through the dense kernel so far; _tile_sweeps: of any level in tiles;
+ * _tree_sweeps: through the tree-walking kernel; _tiled_levels: levels stored in tiles (0: host numbering in force). */
 int64_t ramses_amd_amrres_covered_sweeps(void);
+int64_t ramses_amd_amrres_tile_sweeps(void);
+int64_t ramses_amd_amrres_tree_sweeps(void);
+int ramses_amd_amrres_tiled_levels(void);
 /* make_boundary_hydro(ilevel) on the resident cell vectors (hydro/hydro_boundary.f90:5-269; callers amr/amr_step.f90:70,293,514):
  * the boundary octs of every physical boundary region of a level take the mirrored (boundary_type 1-6) or the copied
  * (11-16, with the no_inflow clamp :176-189) state of their reference cells, region after region in the reference's order,

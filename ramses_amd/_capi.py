@@ -201,6 +201,9 @@ SYMBOLS = [
     ("ramses_amd_amrres_xg", _i, [_vp]),
     ("ramses_amd_amrres_rho_fine", _i, [_PP, _i, _i, _i, _i, _vp, _vp, _d, _vp, _vp]),
     ("ramses_amd_amrres_covered_sweeps", _i64, []),
+    ("ramses_amd_amrres_tile_sweeps", _i64, []),
+    ("ramses_amd_amrres_tree_sweeps", _i64, []),
+    ("ramses_amd_amrres_tiled_levels", _i, []),
     ("ramses_amd_amrres_boundary_hydro", _i, [_i, _vp, _vp, _vp, _i, _d, _i, _vp]),
     ("ramses_amd_mhd_workspace_bytes", _i64, [_i, _i, _i]),
     ("ramses_amd_mhd_godunov_brick", _i, [_vp, _i, _i, _i, _vp, _vp, _d, _d, _vp, _i64, _vp]),

@@ -1107,6 +1107,14 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A_in, int slope_type, int riem
   return hipGetLastError();
 }
 
+// the replay alone: for a caller whose own sweep filed the records (the dense sweep of a level in tiles, csrc/capi_amr.hip)
+hipError_t launch_amr_coarse_update(const AmrSweepArgs &A, const int *posof, int nvector, hipStream_t s) {
+  if (A.ngrid <= 0) return hipSuccess;
+  const long nev = (long)A.ngrid * 6;
+  hipLaunchKernelGGL(amrsweep::amr_coarse_update_kernel, dim3((int)((nev + 255) / 256)), dim3(256), 0, s, A, posof, nvector);
+  return hipGetLastError();
+}
+
 }  // namespace ramses_amd
 
 #include "warm.hpp"

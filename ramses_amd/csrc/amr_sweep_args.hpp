@@ -32,6 +32,7 @@ struct AmrSweepArgs {
 
 hipError_t launch_amr_godunov(const AmrSweepArgs &A, int slope_type, int riemann, int *posof, int nvector,
                               hipStream_t s, double *pack_area = nullptr, int *walk_area = nullptr);
+hipError_t launch_amr_coarse_update(const AmrSweepArgs &A, const int *posof, int nvector, hipStream_t s);
 // doubles per packed oct record for nvar variables: 8 primitive values per variable, 8 refinement flags, padded to 128 bytes
 inline int amr_pack_rec(int nvar) { return ((8 * nvar + 4) + 15) / 16 * 16; }
 constexpr int AMR_PACK_REC_MAX = 64;   // nvar = 7

@@ -9,7 +9,10 @@
 //   hydro_flag    hydro/hydro_flag.f90:1-178 + hydro_refine hydro/godunov_utils.f90:125-263   lvl_flag_kernel
 // The mesh itself stays the reference's host code: before refine_fine rebuilds levels the shim brings the
 // levels it reads back to the host (sync_level), and afterwards the tree and the rebuilt levels are sent
-// again (tree, load_level) -- the other levels never leave the device.  Single rank, NDIM=3, hydro only.
+// again (tree, load_level) -- the other levels never leave the device.  NDIM=3, hydro only.
+// The octs carry the DEVICE's own numbers here (csrc/amr_layout.hpp: levels in tiles of 32 x 4 x 4 octs, so that the dense
+// sweep reads them in 256-byte runs): `ngridmax` / `ncell` of the kernels below are the device's, oct lists are translated as
+// they arrive (set_level, upload_list), the host arrays are addressed with R.ngh / R.ncell_h.
 // Compiled with -ffp-contract=off: the reference's operation order.
 #include <hip/hip_runtime.h>
 
@@ -25,6 +28,9 @@
 
 #include "../../include/ramses_amd.h"
 #include "amr_core.hpp"
+#include "amr_layout.hpp"
+#include "amr_sweep_args.hpp"
+#include "amr_tree.hpp"
 #include "hydro_core.hpp"
 #include "rho_args.hpp"
 #include "sweep_args.hpp"
@@ -410,49 +416,142 @@ __global__ __launch_bounds__(256) void lvl_pfix_switch_kernel(LvlArgs A, const d
   }
 }
 
-// ---- godunov_fine of a FULLY COVERED level of an AMR run (levelmin, and any level whose octs fill the periodic box) ----------
-// The tree-walking sweep recomputes a 6^3 stencil per father oct; a level that covers the box is a brick, and the dense
-// z-marching sweep (csrc/hydro_sweep.hip) updates it several times faster.  The level is gathered from the resident cell
-// vectors into bricks (uold, unew, f), the dense kernel runs with the refinement mask of the level -- fluxes through the faces
-// of refined cells reset to zero, the update starting from unew, which already holds what the finer level owes to this one
-// (hydro/godunov_fine.f90:661-666,720-747,752-790) -- and unew is scattered back.  Strict arithmetic: bit-identical.
-// oct -> brick origin from the father pointers alone (no xg): the octant of the father cell at every level up to the root
-__global__ __launch_bounds__(256) void lvl_oct_origin_kernel(const int *igrid, int ngrid, const int *father, long ncoarse, long ngridmax,
-                                                              int level, int n, long *octorg, int *bad) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ngrid) return;
-  int g = igrid[i];
-  int x = 0, y = 0, z = 0;
-  bool ok = true;
-  for (int l = level; l >= 2; l--) {
-    const long c = father[g - 1];
-    if (c <= ncoarse) { ok = false; break; }
-    const int ind = (int)((c - ncoarse - 1) / ngridmax);
-    g = (int)((c - ncoarse - 1) % ngridmax) + 1;
-    const int sh = level - l;
-    x |= (ind & 1) << sh; y |= ((ind >> 1) & 1) << sh; z |= (ind >> 2) << sh;
-  }
-  if (ok && father[g - 1] > ncoarse) ok = false;      // the walk must end on the level-1 oct
-  if (!ok) { atomicAdd(bad, 1); octorg[i] = 0; return; }
-  octorg[i] = 2L * x + (long)n * (2L * y + (long)n * 2L * z);
+// ---- godunov_fine of a level stored in TILES (csrc/amr_layout.hpp) through the dense sweep -------------------------------
+// The tree-walking sweep recomputes an 8^3 stencil per father oct; the dense z-marching sweep (csrc/hydro_sweep.hip) converts,
+// traces and solves every cell and face once.  It runs IN PLACE on the device's cell vectors through the level's tile
+// directory; what it needs beyond them is prepared once per (tree, oct list) -- the PLAN of the level:
+//   * the status byte of every cell: refined (set with the tree), OWNED = in the call's list (updated), GHOST;
+//   * the GHOST octs: the positions next to a listed oct (its 26 neighbours) where the level has no oct.  The reference
+//     interpolates those from the father cell and its six neighbours for every oct that needs them (hydro/godunov_fine.f90:
+//     563-600, interpol_hydro); here a pre-pass writes them once per sweep into the free slots of the tiles (plan_ghost_fill_kernel:
+//     the same function of the same values), the acceleration of the father cell with them (:616-626);
+//   * the work list: the 60 x 8-column tiles and plane ranges that hold listed cells;
+//   * the flux records' targets (the leaf cell of the coarser level behind each oct face, :798-908) and the position of every
+//     listed oct in the list (the replay kernel's order).
+struct PlanArgs {
+  const int *son, *nbor, *father, *iperm;
+  unsigned char *stat;
+  int *octpos;
+  const int *ig;               // the call's list, device indices
+  int n;
+  long ncell, ncoarse, ngd;
+  // the level's tiles
+  const int *dir, *tileid;
+  long base;                   // first device index of the level (1-based)
+  int no, ntx, nty, ntz;
+};
+// coordinates of a device oct of a level in tiles
+__device__ __forceinline__ void plan_oct_pos(const PlanArgs &A, int d, int &x, int &y, int &z) {
+  const long r = (long)d - A.base;
+  const int t = A.tileid[r / TILE_OCTS], l = (int)(r % TILE_OCTS);
+  const int tx = t % A.ntx, ty = (t / A.ntx) % A.nty, tz = t / (A.ntx * A.nty);
+  x = tx * TILE_OX + l % TILE_OX; y = ty * TILE_OY + (l / TILE_OX) % TILE_OY; z = tz * TILE_OZ + l / (TILE_OX * TILE_OY);
 }
-
-// the two maps of a covered level, one thread per oct: brick cell -> 0-based index in the cell vectors (int pairs along x) and
-// the refinement flags (byte pairs).  The dense kernel then works IN PLACE on the cell vectors through the index: no copy of
-// the level is made (the first version gathered uold / unew into bricks and scattered unew back: 2.2 of 3.5 ms at 256^3; a
-// one-pass gather / scatter: 1.5 of 2.8 ms -- as slow as the tree-walking sweep it was to replace).
-__global__ __launch_bounds__(256) void lvl_covered_index_kernel(const int *__restrict__ igrid, const long *__restrict__ octorg, int ngrid,
-                                                                 const int *__restrict__ son, long ncoarse, long ngridmax, int n,
-                                                                 int *__restrict__ cellidx, unsigned char *__restrict__ mask) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ngrid; i += gridDim.x * blockDim.x) {
-    const long c0 = ncoarse + igrid[i] - 1;
-    const long org = octorg[i];
+// device oct index (1-based) at a position, 0: no tile there
+__device__ __forceinline__ int plan_oct_at(const PlanArgs &A, int x, int y, int z) {
+  const int t = (x / TILE_OX) + A.ntx * ((y / TILE_OY) + A.nty * (z / TILE_OZ));
+  const int c0 = A.dir[t];
+  if (c0 < 0) return 0;
+  return (int)(c0 - A.ncoarse + 1) + (x % TILE_OX) + TILE_OX * ((y % TILE_OY) + TILE_OY * (z % TILE_OZ));
+}
+// a range of device octs of every octant position: status bits cleared, list positions forgotten
+__global__ __launch_bounds__(256) void plan_clear_kernel(unsigned char *stat, int *octpos, long ncoarse, long ngd, long base, long cap, int *gfather) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < cap * 8; t += (long)gridDim.x * blockDim.x) {
+    const int ind = (int)(t / cap);
+    const long o = t % cap;
+    const long c = ncoarse + (long)ind * ngd + base - 1 + o;
+    stat[c] &= (unsigned char)CELL_REFINED;
+    if (ind == 0) { octpos[base - 1 + o] = -1; if (gfather) gfather[o] = 0; }
+  }
+}
+__global__ __launch_bounds__(256) void plan_owned_kernel(PlanArgs A) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (long)A.n * 8; t += (long)gridDim.x * blockDim.x) {
+    const int ind = (int)(t / A.n), i = (int)(t % A.n);
+    const int d = A.ig[i];
+    A.stat[A.ncoarse + (long)ind * A.ngd + d - 1] |= (unsigned char)CELL_OWNED;
+    if (ind == 0) A.octpos[d - 1] = i;
+  }
+}
+// the ghost octs of the listed octs: slot (0-based device oct index) and father cell, each once
+__global__ __launch_bounds__(256) void plan_ghost_kernel(PlanArgs A, int *gfather, int *gslot, int *gcell, int *count, int cap, int *err) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (long)A.n * 26; t += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(t / 26);
+    int o = (int)(t % 26);
+    if (o >= 13) o++;                                   // skip the oct itself
+    const int sx = o % 3 - 1, sy = (o / 3) % 3 - 1, sz = o / 9 - 1;
+    const int d = A.ig[i];
+    int x, y, z;
+    plan_oct_pos(A, d, x, y, z);
+    const int m = A.no - 1;
+    const int dn = plan_oct_at(A, (x + sx) & m, (y + sy) & m, (z + sz) & m);
+    if (dn == 0) { atomicAdd(err, 1); continue; }       // (the layout gave every neighbour position a tile)
+    if (A.iperm[dn - 1] != 0) continue;                  // an oct of the tree: nothing to interpolate
+    // its father cell: from the oct's own father cell, x, then y, then z steps through son(nbor(...)) (getnborfather)
+    AmrSweepArgs T;
+    T.son = A.son; T.nbor = A.nbor; T.ncoarse = A.ncoarse; T.ngridmax = A.ngd;
+    int c = A.father[d - 1];
+    const int st[3] = {sx, sy, sz};
 #pragma unroll
-    for (int r = 0; r < 4; r++) {                   // r = iy + 2 iz: the x-pair (ind = 2r, 2r + 1)
-      const long b = org + (long)n * ((r & 1) + (long)n * (r >> 1));
-      const long ca = c0 + (long)(2 * r) * ngridmax, cb = ca + ngridmax;
-      *reinterpret_cast<int2 *>(cellidx + b) = make_int2((int)ca, (int)cb);
-      *reinterpret_cast<unsigned short *>(mask + b) = (unsigned short)((son[ca] > 0 ? 1 : 0) | ((son[cb] > 0 ? 1 : 0) << 8));
+    for (int axis = 0; axis < 3; axis++)
+      if (st[axis] != 0 && c > A.ncoarse) c = amrsweep::nbor_cell(c, 2 * axis + (st[axis] > 0 ? 1 : 0), T);
+    if (c <= A.ncoarse || A.son[c - 1] != 0) { atomicAdd(err, 1); continue; }
+    if (atomicCAS(&gfather[dn - A.base], 0, c) != 0) continue;
+    const int pos = atomicAdd(count, 1);
+    if (pos < cap) { gslot[pos] = dn - 1; gcell[pos] = c; }
+    for (int ind = 0; ind < 8; ind++) A.stat[A.ncoarse + (long)ind * A.ngd + dn - 1] |= (unsigned char)CELL_GHOST;
+  }
+}
+// the leaf cell of the coarser level behind each (listed oct, face), 0: the neighbour oct exists
+__global__ __launch_bounds__(256) void plan_target_kernel(PlanArgs A, int *corr_tgt) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (long)A.n * 6; t += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(t / 6), f = (int)(t % 6);
+    const int nb = A.nbor[(long)f * A.ngd + A.ig[i] - 1];
+    corr_tgt[t] = (nb > 0 && A.son[nb - 1] == 0) ? nb : 0;
+  }
+}
+// which (tile column of 60 x 8 cells, chunk of 8 planes) hold listed cells
+__global__ __launch_bounds__(256) void plan_work_kernel(PlanArgs A, int wtx, int wty, int wz, unsigned char *flag) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (long)gridDim.x * blockDim.x) {
+    int x, y, z;
+    plan_oct_pos(A, A.ig[i], x, y, z);
+    flag[((long)((2 * y) / 8) * wtx + (2 * x) / 60) * wz + (2 * z) / 8] = 1;
+  }
+  (void)wty;
+}
+// the ghost octs' cells: interpol_hydro of the father cell with its six neighbours (getnborfather's coarser fallback), the
+// father cell's acceleration (hydro/godunov_fine.f90:563-626) -- into the free slots of the level's tiles
+template <int NV>
+__global__ __launch_bounds__(128) void plan_ghost_fill_kernel(double *__restrict__ uold, double *__restrict__ grav, const int *__restrict__ son,
+                                                              const int *__restrict__ nbor, const int *__restrict__ gslot, const int *__restrict__ gcell,
+                                                              int nghost, long ncell, long ncoarse, long ngd, int interpol_var, int interpol_type, double smallr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nghost) return;
+  AmrSweepArgs T;
+  T.son = son; T.nbor = nbor; T.ncoarse = ncoarse; T.ngridmax = ngd;
+  const int c0 = gcell[i];
+  double u1[7][NV], u2[8][NV];
+#pragma unroll
+  for (int j = 0; j < 7; j++) {
+    int c = c0;
+    if (j > 0) {
+      c = amrsweep::nbor_cell(c0, j - 1, T);
+      if (c < 0) c = -c;
+    }
+#pragma unroll
+    for (int v = 0; v < NV; v++) u1[j][v] = uold[(long)v * ncell + c - 1];
+  }
+  interpol_hydro_cell<NV>(u1, u2, interpol_var, interpol_type, smallr);
+  const long o = ncoarse + gslot[i];
+#pragma unroll
+  for (int ind = 0; ind < 8; ind++)
+#pragma unroll
+    for (int v = 0; v < NV; v++) uold[(long)v * ncell + o + (long)ind * ngd] = u2[ind][v];
+  if (grav) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const double g = grav[(long)k * ncell + c0 - 1];
+#pragma unroll
+      for (int ind = 0; ind < 8; ind++) grav[(long)k * ncell + o + (long)ind * ngd] = g;
     }
   }
 }
@@ -534,19 +633,7 @@ __global__ __launch_bounds__(256) void bnd_store_kernel(BndArgs A) {
   }
 }
 
-struct Buf {
-  void *p = nullptr;
-  size_t cap = 0;
-  hipError_t ensure(size_t bytes) {
-    if (bytes <= cap && p) return hipSuccess;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-    if (bytes == 0) bytes = 8;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e == hipSuccess) cap = bytes;
-    return e;
-  }
-  template <class T> T *as() { return reinterpret_cast<T *>(p); }
-};
+using amrlayout::Buf;
 
 struct PinBuf {
   void *p = nullptr;
@@ -567,7 +654,16 @@ struct PinBuf {
 struct CommLevel {
   int epoch = -1, ncpu = 0;
   std::vector<int> em_first, rc_first;        // [ncpu+1] positions in the concatenated lists
-  Buf em_ig, rc_ig;
+  Buf em_ig, rc_ig;                           // device indices (translated for the layout `serial`)
+  Buf em_raw, rc_raw;                         // the lists as build_comm left them (host indices)
+  int serial = -1;
+};
+
+// what the dense sweep of a level in tiles needs beyond the cell vectors (see plan_* above), valid for one layout and one list
+struct LevelPlan {
+  int serial = -1, ngrid = -1, ig_first = 0, ig_last = 0;
+  int nghost = 0, nwork = 0;
+  Buf gfather, gslot, gcell, work, corr, corr_tgt, flag;
 };
 
 struct AmrRes {
@@ -578,15 +674,20 @@ struct AmrRes {
   int halo_level = 0, halo_dir = -1;           // the exchange halo_stage_out has opened (0: none)
   bool valid = false;
   int nvar = 0;
-  long ncell = 0, ncoarse = 0, ngridmax = 0;
+  long ncell = 0, ncoarse = 0, ngridmax = 0;   // of the DEVICE's cell vectors (ngridmax = map.ngd)
+  long ngh = 0, ncell_h = 0;                   // of the host's
+  amrlayout::DevMap map;
+  Buf stat, octpos, bad;                       // status byte per device cell; device oct -> position in the list of its level's plan; bad-index counter
+  std::vector<LevelPlan> plan;
+  long tile_sweeps = 0, tree_sweeps = 0;
+  bool announced = false;
   const double *h_uold = nullptr;
   Buf uold, unew, son, nbor, father, igrid, work, err, red, okbuf, pack;
   Buf xg;                // xg(1:ngridmax,1:3) (rho_fine's deposit needs the oct centres); sent with the tree when gravity is on
   bool xg_valid = false;
   Buf mp, rho, posof, mpscratch, lists;   // rho_fine: multipoles (4, ncell), the deposit (ncell), oct -> list position, scan scratch
   Buf hkeys, hvals;                       // rho_fine with several ranks: the own octs of the level by position
-  Buf cb_idx, cb_mask, cb_org;   // godunov_fine of a fully covered level: brick cell -> cell-vector index, refinement mask, oct origins
-  long covered_sweeps = 0;                     // how many sweeps took that path (tests, ramses_amd_amrres_covered_sweeps)
+  long covered_sweeps = 0;                     // how many sweeps of fully refined levels took the dense path (tests, ramses_amd_amrres_covered_sweeps)
   int rl_level = 0, rl_nown = 0, rl_nall = 0;   // the level ramses_amd_amrres_rho_mpi_multipole opened (its list is in `lists`)
   Buf f;                 // f(1:ncell,1:3), a copy of the host array refreshed after force_fine and after regrids
   bool grav = false;
@@ -605,11 +706,32 @@ inline int grid_for(long n) {
   return (int)g;
 }
 
+// an oct list of the host on the device, in device indices (amr_layout.hpp); an index that is not in the tree is an error of
+// the caller, reported by the next routine that synchronises anyway (check_lists)
+int upload_list(AmrRes &R, Buf &dst, const int *h, int n) {
+  HCHK(dst.ensure(sizeof(int) * (size_t)(n > 0 ? n : 1)), "hipMalloc oct list");
+  if (n <= 0) return 0;
+  HCHK(hipMemcpyAsync(dst.p, h, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, nullptr), "H2D oct list");
+  if (R.map.on) {
+    hipLaunchKernelGGL(amrlayout::xlate_list_kernel, dim3(amrlayout::grid1(n)), dim3(256), 0, nullptr, dst.as<int>(), n, R.map.perm.as<int>(), R.ngh, R.bad.as<int>());
+    HCHK(hipGetLastError(), "oct list translation");
+  }
+  return 0;
+}
+int check_lists(AmrRes &R, const char *where) {
+  if (!R.map.on) return 0;
+  int bad = 0;
+  HCHK(hipMemcpy(&bad, R.bad.p, sizeof(int), hipMemcpyDeviceToHost), "D2H");
+  if (bad) {
+    HCHK(hipMemset(R.bad.p, 0, sizeof(int)), "memset");
+    return failf(RAMSES_AMD_EINVAL, "%s: %d octs of a list are not in the tree the device holds", where, bad);
+  }
+  return 0;
+}
 int set_level(AmrRes &R, int ngrid, const int *igrid, LvlArgs &A) {
   if (!R.valid) return failf(RAMSES_AMD_EINVAL, "no resident AMR state (ramses_amd_amrres_load)");
   if (ngrid < 0 || (ngrid > 0 && !igrid)) return failf(RAMSES_AMD_EINVAL, "bad oct list");
-  HCHK(R.igrid.ensure(sizeof(int) * (size_t)(ngrid > 0 ? ngrid : 1)), "hipMalloc igrid");
-  if (ngrid > 0) HCHK(hipMemcpyAsync(R.igrid.p, igrid, sizeof(int) * (size_t)ngrid, hipMemcpyHostToDevice, nullptr), "H2D igrid");
+  if (int rc = upload_list(R, R.igrid, igrid, ngrid)) return rc;
   A.uold = R.uold.as<double>(); A.unew = R.unew.as<double>();
   A.son = R.son.as<int>(); A.nbor = R.nbor.as<int>(); A.igrid = R.igrid.as<int>();
   A.ngrid = ngrid; A.nvar = R.nvar; A.ncell = R.ncell; A.ncoarse = R.ncoarse; A.ngridmax = R.ngridmax;
@@ -637,15 +759,23 @@ extern "C" {
 
 int ramses_amd_amrres_active(void) { return g_ar.valid ? 1 : 0; }
 
-// the tree arrays again (after refine_fine): son(1:ncell), nbor(1:ngridmax,1:6), father(1:ngridmax)
+// the tree arrays again (after refine_fine): son(1:ncell), nbor(1:ngridmax,1:6), father(1:ngridmax) of the host.  The levels
+// whose octs changed (and every finer one) are laid out again in device numbers; the others keep theirs, and their data.
 int ramses_amd_amrres_tree(const int *son, const int *nbor, const int *father) {
   AmrRes &R = g_ar;
   if (!R.valid) return failf(RAMSES_AMD_EINVAL, "no resident AMR state");
   if (!son || !nbor || !father) return failf(RAMSES_AMD_EINVAL, "NULL argument");
-  HCHK(hipMemcpyAsync(R.son.p, son, sizeof(int) * (size_t)R.ncell, hipMemcpyHostToDevice, nullptr), "H2D son");
-  HCHK(hipMemcpyAsync(R.nbor.p, nbor, sizeof(int) * 6 * (size_t)R.ngridmax, hipMemcpyHostToDevice, nullptr), "H2D nbor");
-  HCHK(hipMemcpyAsync(R.father.p, father, sizeof(int) * (size_t)R.ngridmax, hipMemcpyHostToDevice, nullptr), "H2D father");
-  HCHK(hipStreamSynchronize(nullptr), "sync");
+  hipError_t e = R.map.build(son, nbor, father, R.son.as<int>(), R.nbor.as<int>(), R.father.as<int>(), R.stat.as<unsigned char>(), nullptr);
+  if (e != hipSuccess) return failf(e == hipErrorInvalidValue ? RAMSES_AMD_EINVAL : RAMSES_AMD_EHIP, "tree layout on the device: %s", e == hipErrorInvalidValue ? R.map.why_not : hipGetErrorString(e));
+  if (R.map.on) {
+    HCHK(hipMemsetAsync(R.octpos.p, 0xff, sizeof(int) * (size_t)R.ngridmax, nullptr), "memset");
+    R.xg_valid = false;                    // the oct centres are indexed by device oct: rho_fine's shim sends them with every tree epoch
+    if (!R.announced) {
+      R.announced = true;
+      if (getenv("RAMSES_AMD_VERBOSE")) fprintf(stderr, "ramses_amd: %d levels on the device, %ld of them in tiles of 32x4x4 octs\n", R.map.nlev, R.map.tiles_levels);
+    }
+  }
+  R.bnd_pos_clean = false;
   return 0;
 }
 
@@ -657,18 +787,47 @@ int ramses_amd_amrres_load(int nvar, int64_t ngridmax, int64_t ncoarse, const do
   AmrRes &R = g_ar;
   R.valid = false; R.grav = false; R.pfix = false;
   R.xg_valid = false;          // the oct centres belong to the tree that is loaded below: rho_fine's shim sends them again
-  R.nvar = nvar; R.ngridmax = ngridmax; R.ncoarse = ncoarse; R.ncell = ncoarse + 8 * ngridmax;
+  R.nvar = nvar; R.ngh = ngridmax; R.ncoarse = ncoarse; R.ncell_h = ncoarse + 8 * ngridmax;
+  // the device's index space: the host's ngridmax times RAMSES_AMD_DEVICE_OCTS (default 1; tiles that are not full cost indices)
+  double fac = 1.0;
+  if (const char *e = getenv("RAMSES_AMD_DEVICE_OCTS")) { fac = atof(e); if (!(fac >= 1.0 && fac <= 16.0)) fac = 1.0; }
+  long ngd = (long)((double)ngridmax * fac);
+  if ((unsigned long)(ncoarse + 8 * ngd) >= (1ul << 31)) ngd = ngridmax;      // cell indices are 32-bit ints
+  R.map.reset(ngridmax, ngd, ncoarse, true);
+  R.ngridmax = R.map.ngd; R.ncell = ncoarse + 8 * R.ngridmax;
+  R.plan.clear();
+  for (CommLevel &L : R.comm) L.epoch = -1;
   R.h_uold = uold;
   const size_t vb = sizeof(double) * (size_t)nvar * (size_t)R.ncell;
   HCHK(R.uold.ensure(vb), "hipMalloc uold"); HCHK(R.unew.ensure(vb), "hipMalloc unew");
   HCHK(R.son.ensure(sizeof(int) * (size_t)R.ncell), "hipMalloc son");
-  HCHK(R.nbor.ensure(sizeof(int) * 6 * (size_t)ngridmax), "hipMalloc nbor");
-  HCHK(R.father.ensure(sizeof(int) * (size_t)ngridmax), "hipMalloc father");
+  HCHK(R.nbor.ensure(sizeof(int) * 6 * (size_t)R.ngridmax), "hipMalloc nbor");
+  HCHK(R.father.ensure(sizeof(int) * (size_t)R.ngridmax), "hipMalloc father");
+  HCHK(R.stat.ensure((size_t)R.ncell), "hipMalloc stat"); HCHK(R.octpos.ensure(sizeof(int) * (size_t)R.ngridmax), "hipMalloc octpos");
+  HCHK(R.bad.ensure(sizeof(int)), "hipMalloc"); HCHK(hipMemsetAsync(R.bad.p, 0, sizeof(int), nullptr), "memset");
   HCHK(R.err.ensure(sizeof(int)), "hipMalloc"); HCHK(R.red.ensure(sizeof(double) * (4 + 3 * 2048)), "hipMalloc");
-  HCHK(hipMemcpyAsync(R.uold.p, uold, vb, hipMemcpyHostToDevice, nullptr), "H2D uold");
   HCHK(hipMemsetAsync(R.unew.p, 0, vb, nullptr), "memset unew");
   R.valid = true;
-  return ramses_amd_amrres_tree(son, nbor, father);
+  if (int rc = ramses_amd_amrres_tree(son, nbor, father)) { R.valid = false; return rc; }
+  if (!R.map.on) {
+    HCHK(hipMemcpyAsync(R.uold.p, uold, vb, hipMemcpyHostToDevice, nullptr), "H2D uold");
+  } else {
+    // variable by variable through a staging vector in the host's numbering: the octs of the tree into their device slots
+    HCHK(hipMemsetAsync(R.uold.p, 0, vb, nullptr), "memset uold");
+    HCHK(R.work.ensure(sizeof(double) * (size_t)R.ncell_h), "hipMalloc staging");
+    for (int v = 0; v < nvar; v++) {
+      HCHK(hipMemcpyAsync(R.work.p, uold + (size_t)v * R.ncell_h, sizeof(double) * (size_t)R.ncell_h, hipMemcpyHostToDevice, nullptr), "H2D uold");
+      HCHK(hipMemcpyAsync(R.uold.as<double>() + (size_t)v * R.ncell, R.work.p, sizeof(double) * (size_t)ncoarse, hipMemcpyDeviceToDevice, nullptr), "coarse cells");
+      for (int l = 1; l <= R.map.nlev; l++) {
+        amrlayout::LevelMap &L = R.map.lev[l];
+        hipLaunchKernelGGL(amrlayout::move_var_kernel<true>, dim3(amrlayout::grid1((long)L.n * 8)), dim3(256), 0, nullptr, L.hoct.as<int>(), L.doct.as<int>(), L.n,
+                           R.ncoarse, R.ngh, R.ngridmax, R.work.as<double>(), R.uold.as<double>() + (size_t)v * R.ncell);
+      }
+    }
+    HCHK(hipGetLastError(), "uold into the device's numbering");
+  }
+  HCHK(hipStreamSynchronize(nullptr), "sync");
+  return 0;
 }
 
 int ramses_amd_amrres_invalidate(void) { g_ar.valid = false; return 0; }
@@ -689,11 +848,11 @@ int ramses_amd_amrres_sync_level(int ngrid, const int *igrid, double *uold) {
   const long tot = (long)ngrid * 8;
   for (int v = 0; v < R.nvar; v++)
     for (int ind = 0; ind < 8; ind++) {
-      double *dst = uold + (size_t)v * R.ncell + R.ncoarse + (size_t)ind * R.ngridmax - 1;
+      double *dst = uold + (size_t)v * R.ncell_h + R.ncoarse + (size_t)ind * R.ngh - 1;
       const double *src = R.hpack.data() + (size_t)v * tot + (size_t)ind * ngrid;
       for (int i = 0; i < ngrid; i++) dst[igrid[i]] = src[i];
     }
-  return 0;
+  return check_lists(R, "sync_level");
 }
 
 // uold of one level's cells from the host array (after refine_fine rebuilt the level)
@@ -707,7 +866,7 @@ int ramses_amd_amrres_load_level(int ngrid, const int *igrid, const double *uold
   R.hpack.resize(n);
   for (int v = 0; v < R.nvar; v++)
     for (int ind = 0; ind < 8; ind++) {
-      const double *src = uold + (size_t)v * R.ncell + R.ncoarse + (size_t)ind * R.ngridmax - 1;
+      const double *src = uold + (size_t)v * R.ncell_h + R.ncoarse + (size_t)ind * R.ngh - 1;
       double *dst = R.hpack.data() + (size_t)v * tot + (size_t)ind * ngrid;
       for (int i = 0; i < ngrid; i++) dst[i] = src[igrid[i]];
     }
@@ -724,7 +883,25 @@ int ramses_amd_amrres_sync_all(double *uold) {
   AmrRes &R = g_ar;
   if (!R.valid) return 0;
   if (uold != R.h_uold) return failf(RAMSES_AMD_EINVAL, "sync_all: not the array the state was loaded from");
-  HCHK(hipMemcpy(uold, R.uold.p, sizeof(double) * (size_t)R.nvar * (size_t)R.ncell, hipMemcpyDeviceToHost), "D2H uold");
+  if (!R.map.on) {
+    HCHK(hipMemcpy(uold, R.uold.p, sizeof(double) * (size_t)R.nvar * (size_t)R.ncell, hipMemcpyDeviceToHost), "D2H uold");
+    return 0;
+  }
+  // the cells of the tree's octs, variable by variable through a staging vector in the host's numbering (cells of octs that
+  // are not in the tree keep what the host array holds)
+  HCHK(R.work.ensure(sizeof(double) * (size_t)R.ncell_h), "hipMalloc staging");
+  for (int v = 0; v < R.nvar; v++) {
+    double *hv = uold + (size_t)v * R.ncell_h;
+    HCHK(hipMemcpyAsync(R.work.p, hv, sizeof(double) * (size_t)R.ncell_h, hipMemcpyHostToDevice, nullptr), "H2D staging");
+    HCHK(hipMemcpyAsync(R.work.p, R.uold.as<double>() + (size_t)v * R.ncell, sizeof(double) * (size_t)R.ncoarse, hipMemcpyDeviceToDevice, nullptr), "coarse cells");
+    for (int l = 1; l <= R.map.nlev; l++) {
+      amrlayout::LevelMap &L = R.map.lev[l];
+      hipLaunchKernelGGL(amrlayout::move_var_kernel<false>, dim3(amrlayout::grid1((long)L.n * 8)), dim3(256), 0, nullptr, L.hoct.as<int>(), L.doct.as<int>(), L.n,
+                         R.ncoarse, R.ngh, R.ngridmax, R.work.as<double>(), R.uold.as<double>() + (size_t)v * R.ncell);
+    }
+    HCHK(hipGetLastError(), "uold into the host's numbering");
+    HCHK(hipMemcpy(hv, R.work.p, sizeof(double) * (size_t)R.ncell_h, hipMemcpyDeviceToHost), "D2H uold");
+  }
   return 0;
 }
 
@@ -781,7 +958,7 @@ int ramses_amd_amrres_courant(const ramses_amd_hydro_params *p, int ngrid, const
   HCHK(hipGetLastError(), "courant launch");
   HCHK(hipMemcpy(out4, R.red.p, sizeof(double) * 4, hipMemcpyDeviceToHost), "D2H courant");
   if (dt_in < out4[0]) out4[0] = dt_in;
-  return 0;
+  return check_lists(R, "courant_fine");
 }
 
 // hydro_flag's gradient criteria: the cells (1-based indices into the cell vectors, ascending) where hydro_refine asks
@@ -805,49 +982,128 @@ int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, co
   HCHK(hipMemcpy(&n, d_count, sizeof(int), hipMemcpyDeviceToHost), "D2H flag count");
   if (n < 0 || (long)n > 8L * ngrid) return failf(RAMSES_AMD_EHIP, "hydro_flag: bad flag count %d", n);
   if (n > 0) {
+    if (R.map.on) hipLaunchKernelGGL(amrlayout::cells_d2h_kernel, dim3(amrlayout::grid1(n)), dim3(256), 0, nullptr, d_list, n, R.map.iperm.as<int>(), R.ncoarse, R.ngh, R.ngridmax);
     HCHK(hipMemcpy(cells, d_list, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost), "D2H flagged cells");
     std::sort(cells, cells + n);
   }
   *ncells = n;
-  return 0;
+  return check_lists(R, "hydro_flag");
 }
 
 namespace {
-bool covered_dense_enabled() {      // (read on every sweep: the A/B test flips it inside one process)
-  const char *e = getenv("RAMSES_AMD_COVERED_DENSE");
+bool env_on(const char *name) {      // (read on every sweep: the A/B tests flip the switches inside one process)
+  const char *e = getenv(name);
   return !(e && e[0] == '0');
 }
+
+// the plan of a level in tiles for the list in R.igrid (see plan_* above); rebuilt when the layout or the list changed
+int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &P) {
+  amrlayout::LevelMap &L = R.map.lev[ilevel];
+  hipStream_t s = nullptr;
+  P.serial = -1;
+  PlanArgs A;
+  A.son = R.son.as<int>(); A.nbor = R.nbor.as<int>(); A.father = R.father.as<int>(); A.iperm = R.map.iperm.as<int>();
+  A.stat = R.stat.as<unsigned char>(); A.octpos = R.octpos.as<int>(); A.ig = R.igrid.as<int>(); A.n = ngrid;
+  A.ncell = R.ncell; A.ncoarse = R.ncoarse; A.ngd = R.ngridmax;
+  A.dir = L.dir.as<int>(); A.tileid = L.tileid.as<int>(); A.base = L.base; A.no = L.no; A.ntx = L.ntx; A.nty = L.nty; A.ntz = L.ntz;
+  HCHK(P.gfather.ensure(sizeof(int) * (size_t)L.cap), "hipMalloc");
+  const int gcap = (int)std::min<long>(L.cap - L.n, (long)ngrid * 26);
+  HCHK(P.gslot.ensure(sizeof(int) * (size_t)(gcap > 0 ? gcap : 1)), "hipMalloc"); HCHK(P.gcell.ensure(sizeof(int) * (size_t)(gcap > 0 ? gcap : 1)), "hipMalloc");
+  HCHK(P.corr_tgt.ensure(sizeof(int) * (size_t)ngrid * 6), "hipMalloc");
+  const size_t corr_bytes = sizeof(double) * (size_t)ngrid * 6 * 4 * (size_t)(R.nvar + 2);
+  if (P.corr.cap < corr_bytes) { HCHK(P.corr.ensure(corr_bytes), "hipMalloc flux records"); }
+  HCHK(hipMemsetAsync(P.corr.p, 0, corr_bytes, s), "memset");
+  HCHK(R.okbuf.ensure(sizeof(int) * 2), "hipMalloc");
+  int *cnt = R.okbuf.as<int>();
+  HCHK(hipMemsetAsync(cnt, 0, sizeof(int) * 2, s), "memset");
+  hipLaunchKernelGGL(plan_clear_kernel, dim3(grid_for(L.cap * 8)), dim3(256), 0, s, A.stat, A.octpos, R.ncoarse, R.ngridmax, L.base, L.cap, P.gfather.as<int>());
+  hipLaunchKernelGGL(plan_owned_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, s, A);
+  hipLaunchKernelGGL(plan_ghost_kernel, dim3(grid_for((long)ngrid * 26)), dim3(256), 0, s, A, P.gfather.as<int>(), P.gslot.as<int>(), P.gcell.as<int>(), cnt, gcap, cnt + 1);
+  hipLaunchKernelGGL(plan_target_kernel, dim3(grid_for((long)ngrid * 6)), dim3(256), 0, s, A, P.corr_tgt.as<int>());
+  // work items: columns of 60 x 8 cells, runs of 8-plane chunks up to 128 planes
+  const int n = 2 * L.no, wtx = (n + 59) / 60, wty = n / 8, wz = n / 8;
+  const size_t nflag = (size_t)wtx * wty * wz;
+  HCHK(P.flag.ensure(nflag), "hipMalloc");
+  HCHK(hipMemsetAsync(P.flag.p, 0, nflag, s), "memset");
+  hipLaunchKernelGGL(plan_work_kernel, dim3(grid_for(ngrid)), dim3(256), 0, s, A, wtx, wty, wz, P.flag.as<unsigned char>());
+  HCHK(hipGetLastError(), "plan launch");
+  int hc[2] = {0, 0};
+  std::vector<unsigned char> flag(nflag);
+  HCHK(hipMemcpyAsync(hc, cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, s), "D2H");
+  HCHK(hipMemcpyAsync(flag.data(), P.flag.p, nflag, hipMemcpyDeviceToHost, s), "D2H");
+  HCHK(hipStreamSynchronize(s), "sync");
+  if (hc[1]) return failf(RAMSES_AMD_EINVAL, "level %d: %d neighbour positions of an oct have no father cell or no tile (tree inconsistent)", ilevel, hc[1]);
+  if (hc[0] > gcap) return failf(RAMSES_AMD_EINVAL, "level %d: more ghost octs (%d) than free slots in the level's tiles (%d)", ilevel, hc[0], gcap);
+  P.nghost = hc[0];
+  std::vector<int> items;
+  int zmax = 128;
+  if (const char *e = getenv("RAMSES_AMD_TILE_ZRUN")) { const int v = atoi(e); if (v >= 8 && v <= 4096) zmax = v / 8 * 8; }
+  for (int ty = 0; ty < wty; ty++)
+    for (int tx = 0; tx < wtx; tx++) {
+      const unsigned char *col = flag.data() + ((size_t)ty * wtx + tx) * wz;
+      for (int z = 0; z < wz;) {
+        if (!col[z]) { z++; continue; }
+        int z1 = z;
+        while (z1 < wz && col[z1] && (z1 - z) * 8 < zmax) z1++;
+        items.push_back(tx * 60); items.push_back(ty * 8); items.push_back(z * 8); items.push_back(z1 * 8);
+        z = z1;
+      }
+    }
+  const int nw = (int)(items.size() / 4);
+  // workgroup b runs on XCD b mod 8: give each XCD a contiguous run of the list (neighbouring columns re-read each other's
+  // halo from ONE L2)
+  std::vector<int> order((size_t)nw * 4);
+  {
+    const int per = (nw + 7) / 8;
+    int b = 0;
+    for (int k = 0; k < per; k++)
+      for (int x = 0; x < 8; x++) {
+        const int j = x * per + k;
+        if (j < nw) { for (int q = 0; q < 4; q++) order[(size_t)b * 4 + q] = items[(size_t)j * 4 + q]; b++; }
+      }
+  }
+  HCHK(P.work.ensure(sizeof(int) * 4 * (size_t)(nw > 0 ? nw : 1)), "hipMalloc");
+  if (nw > 0) HCHK(hipMemcpy(P.work.p, order.data(), sizeof(int) * 4 * (size_t)nw, hipMemcpyHostToDevice), "H2D work list");
+  P.nwork = nw;
+  P.ngrid = ngrid; P.ig_first = ngrid > 0 ? h_igrid[0] : 0; P.ig_last = ngrid > 0 ? h_igrid[ngrid - 1] : 0;
+  P.serial = R.map.serial;
+  return 0;
+}
+
 // returns 0 and sets done when the level took the dense path; done = false: the caller walks the tree
-int covered_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, int ngrid, double dx, double dt, bool &done) {
+int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *h_igrid, double dx, double dt, int nvector,
+                     int interpol_var, int interpol_type, bool &done) {
   done = false;
-  if (!covered_dense_enabled() || R.ncoarse != 1 || ilevel < 4 || ilevel > 10) return 0;
-  const int n = 1 << ilevel;
-  const long N = (long)n * n * n;
-  if ((long)ngrid * 8 != N) return 0;
+  if (!R.map.on || ilevel < 3 || ilevel > R.map.nlev || R.map.lev[ilevel].layout != 1) return 0;
+  amrlayout::LevelMap &L = R.map.lev[ilevel];
+  const bool covered = (long)L.n == (long)L.no * L.no * L.no && ngrid == L.n;
+  if (!env_on(covered ? "RAMSES_AMD_COVERED_DENSE" : "RAMSES_AMD_TILE_DENSE") || !env_on("RAMSES_AMD_TILE_SWEEP")) return 0;
   if (R.nvar != 5 || p->nvar != 5 || p->ndim != 3 || p->scheme != RAMSES_AMD_SCHEME_MUSCL || p->difmag > 0.0 || R.pfix) return 0;
   const int st = p->slope_type;
   if (!(st == 0 || st == 1 || st == 2 || st == 7 || st == 8) || p->riemann == RAMSES_AMD_RIEMANN_EXACT) return 0;
+  if (interpol_var < 0 || interpol_var > 2 || interpol_type < 0 || interpol_type > 4) return 0;
+  if ((unsigned long)R.ncell * 8ul >= (1ul << 31)) {      // lane offsets into a cell vector are 31-bit byte offsets
+    static bool told = false;
+    if (!told) { told = true; fprintf(stderr, "ramses_amd: the device's cell vectors hold %ld cells (>= 2^28): the levels keep the tree-walking sweep\n", R.ncell); }
+    return 0;
+  }
   hipStream_t s = nullptr;
-  if ((unsigned long)R.ncell * 8ul >= (1ul << 31)) return 0;      // lane offsets into a cell vector are 31-bit byte offsets
-  HCHK(R.cb_idx.ensure(sizeof(int) * (size_t)N), "hipMalloc"); HCHK(R.cb_mask.ensure((size_t)N), "hipMalloc");
-  HCHK(R.cb_org.ensure(sizeof(long) * (size_t)ngrid), "hipMalloc");
-  HCHK(hipMemsetAsync(R.err.p, 0, sizeof(int), s), "memset");
-  hipLaunchKernelGGL(lvl_oct_origin_kernel, dim3((ngrid + 255) / 256), dim3(256), 0, s, R.igrid.as<int>(), ngrid, R.father.as<int>(), R.ncoarse, R.ngridmax,
-                     ilevel, n, R.cb_org.as<long>(), R.err.as<int>());
-  int bad = 0;
-  HCHK(hipMemcpyAsync(&bad, R.err.p, sizeof(int), hipMemcpyDeviceToHost, s), "D2H flag");
-  HCHK(hipStreamSynchronize(s), "sync");
-  if (bad) return 0;                                  // not a tree of one coarse cell: the tree-walking sweep knows what to do
-  {
-    int g = (ngrid + 255) / 256;
-    if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(lvl_covered_index_kernel, dim3(g), dim3(256), 0, s, R.igrid.as<int>(), R.cb_org.as<long>(), ngrid, R.son.as<int>(), R.ncoarse,
-                       R.ngridmax, n, R.cb_idx.as<int>(), R.cb_mask.as<unsigned char>());
-    HCHK(hipGetLastError(), "index of a covered level");
+  if ((size_t)ilevel >= R.plan.size()) R.plan.resize((size_t)ilevel + 1);
+  LevelPlan &P = R.plan[ilevel];
+  if (P.serial != R.map.serial || P.ngrid != ngrid || P.ig_first != h_igrid[0] || P.ig_last != h_igrid[ngrid - 1])
+    if (int rc = build_plan(R, ilevel, ngrid, h_igrid, P)) return rc;
+  if (P.nwork == 0) { done = true; return 0; }
+  if (P.nghost > 0) {
+    hipLaunchKernelGGL(plan_ghost_fill_kernel<5>, dim3((P.nghost + 127) / 128), dim3(128), 0, s, R.uold.as<double>(), R.grav ? R.f.as<double>() : nullptr, R.son.as<int>(),
+                       R.nbor.as<int>(), P.gslot.as<int>(), P.gcell.as<int>(), P.nghost, R.ncell, R.ncoarse, R.ngridmax, interpol_var, interpol_type, p->smallr);
+    HCHK(hipGetLastError(), "ghost octs");
   }
   SweepArgs A;
   A.uold = R.uold.as<double>(); A.unew = R.unew.as<double>(); A.grav = R.grav ? R.f.as<double>() : nullptr;      // the cell vectors themselves
-  A.mask = R.cb_mask.as<unsigned char>(); A.cellidx = R.cb_idx.as<int>();
+  A.stat = R.stat.as<unsigned char>(); A.dir = L.dir.as<int>(); A.work = P.work.as<int>(); A.nwork = P.nwork;
+  A.corr = P.corr.as<double>(); A.octpos = R.octpos.as<int>();
+  A.ntx = L.ntx; A.nty = L.nty; A.ntz = L.ntz; A.ngd = R.ngridmax; A.ncoarse = R.ncoarse;
+  const int n = 2 * L.no;
   A.nx = A.ny = A.nz = n; A.ng = 0;
   A.pitch_y = n; A.pitch_z = (long)n * n; A.pitch_var = R.ncell;
   A.zchunk = n < 128 ? n : 128;
@@ -859,15 +1115,29 @@ int covered_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel,
   A.P = make_const_amr(p);
   // strict arithmetic, like every other sweep of an AMR run (the fast build is certified on uniform runs only)
   hipError_t e = strictmode::launch_godunov_sweep(A, st, p->riemann, 12, p->scheme, 5, R.grav, s);
-  if (e == hipErrorInvalidValue) { (void)hipGetLastError(); return 0; }     // a variant the masked kernels do not cover
-  HCHK(e, "dense sweep of a covered level");
-  R.covered_sweeps++;
+  if (e == hipErrorInvalidValue) { (void)hipGetLastError(); return 0; }     // a variant the tile kernels do not cover
+  HCHK(e, "dense sweep of a level in tiles");
+  // what the level owes to the leaf cells of the coarser one, replayed in the reference's order
+  AmrSweepArgs C;
+  C.uold = A.uold; C.unew = A.unew; C.grav = nullptr; C.divu = nullptr; C.enew = nullptr;
+  C.son = R.son.as<int>(); C.nbor = R.nbor.as<int>(); C.father = R.father.as<int>(); C.igrid = R.igrid.as<int>();
+  C.ngrid = ngrid; C.nvar = 5; C.scheme = 0; C.ncell = R.ncell; C.ncoarse = R.ncoarse; C.ngridmax = R.ngridmax;
+  C.dt = dt; C.dx = dx; C.rdx = A.rdx; C.difmag = 0.0; C.pow2 = A.pow2; C.interpol_var = interpol_var; C.interpol_type = interpol_type;
+  C.corr = P.corr.as<double>(); C.corr_tgt = P.corr_tgt.as<int>(); C.err = R.err.as<int>(); C.packed = nullptr; C.rec = 0; C.P = A.P;
+  HCHK(launch_amr_coarse_update(C, R.octpos.as<int>(), nvector, s), "coarse corrections");
+  if (covered) R.covered_sweeps++;
+  R.tile_sweeps++;
   done = true;
   return 0;
 }
 }  // namespace
 
 extern "C" int64_t ramses_amd_amrres_covered_sweeps(void) { return g_ar.covered_sweeps; }
+// sweeps of AMR levels so far: through the dense kernel on tiles / through the tree-walking kernel
+extern "C" int64_t ramses_amd_amrres_tile_sweeps(void) { return g_ar.tile_sweeps; }
+extern "C" int64_t ramses_amd_amrres_tree_sweeps(void) { return g_ar.tree_sweeps; }
+// levels the device stores in tiles (0: the host's numbering is in force)
+extern "C" int ramses_amd_amrres_tiled_levels(void) { return g_ar.valid && g_ar.map.on ? (int)g_ar.map.tiles_levels : 0; }
 
 // godunov_fine(ilevel) on the resident arrays
 int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, double dx, double dt,
@@ -879,9 +1149,10 @@ int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int 
   AmrRes &R = g_ar;
   {
     bool done = false;
-    if (int rc = covered_level_sweep(R, p, ilevel, ngrid, dx, dt, done)) return rc;
-    if (done) return 0;
+    if (int rc = tile_level_sweep(R, p, ilevel, ngrid, igrid, dx, dt, nvector, interpol_var, interpol_type, done)) return rc;
+    if (done) return 0;          // (asynchronous: a bad oct list is reported by the next routine that reads something back)
   }
+  R.tree_sweeps++;
   const int64_t nw = ramses_amd_godunov_fine_amr_workspace(ngrid, R.ngridmax);
   if (nw < 0) return (int)nw;
   HCHK(R.work.ensure((size_t)nw), "hipMalloc work");
@@ -892,7 +1163,7 @@ int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int 
   int bad = 0;
   HCHK(hipMemcpy(&bad, R.err.p, sizeof(int), hipMemcpyDeviceToHost), "D2H flag");
   if (bad) return failf(RAMSES_AMD_EINVAL, "level %d: %d father cells needed by an oct do not exist (tree inconsistent)", ilevel, bad);
-  return 0;
+  return check_lists(R, "godunov_fine");
 }
 
 
@@ -915,7 +1186,7 @@ int ramses_amd_amrres_load_f(int ngrid, const int *igrid, const double *f) {
   R.hpack.resize((size_t)tot * 3);
   for (int k = 0; k < 3; k++)
     for (int ind = 0; ind < 8; ind++) {
-      const double *src = f + (size_t)k * R.ncell + R.ncoarse + (size_t)ind * R.ngridmax - 1;
+      const double *src = f + (size_t)k * R.ncell_h + R.ncoarse + (size_t)ind * R.ngh - 1;
       double *dst = R.hpack.data() + (size_t)k * tot + (size_t)ind * ngrid;
       for (int i = 0; i < ngrid; i++) dst[i] = src[igrid[i]];
     }
@@ -935,7 +1206,19 @@ int ramses_amd_amrres_xg(const double *xg) {
   if (!R.valid) return failf(RAMSES_AMD_EINVAL, "no resident AMR state");
   if (!xg) return failf(RAMSES_AMD_EINVAL, "NULL argument");
   HCHK(R.xg.ensure(sizeof(double) * 3 * (size_t)R.ngridmax), "hipMalloc xg");
-  HCHK(hipMemcpy(R.xg.p, xg, sizeof(double) * 3 * (size_t)R.ngridmax, hipMemcpyHostToDevice), "H2D xg");
+  if (!R.map.on) {
+    HCHK(hipMemcpy(R.xg.p, xg, sizeof(double) * 3 * (size_t)R.ngridmax, hipMemcpyHostToDevice), "H2D xg");
+  } else {
+    HCHK(R.work.ensure(sizeof(double) * 3 * (size_t)R.ngh), "hipMalloc staging");
+    HCHK(hipMemcpyAsync(R.work.p, xg, sizeof(double) * 3 * (size_t)R.ngh, hipMemcpyHostToDevice, nullptr), "H2D xg");
+    for (int l = 1; l <= R.map.nlev; l++) {
+      amrlayout::LevelMap &L = R.map.lev[l];
+      hipLaunchKernelGGL(amrlayout::move_oct_kernel, dim3(amrlayout::grid1((long)L.n * 3)), dim3(256), 0, nullptr, L.hoct.as<int>(), L.doct.as<int>(), L.n, 3, R.ngh,
+                         R.ngridmax, R.work.as<double>(), R.xg.as<double>());
+    }
+    HCHK(hipGetLastError(), "xg into the device's numbering");
+    HCHK(hipStreamSynchronize(nullptr), "sync");
+  }
   R.xg_valid = true;
   return 0;
 }
@@ -963,8 +1246,7 @@ int ramses_amd_amrres_rho_fine(const ramses_amd_hydro_params *p, int ilevel, int
     HCHK(R.posof.ensure(sizeof(int) * (size_t)R.ngridmax), "hipMalloc posof");
     HCHK(hipMemsetAsync(R.posof.p, 0xff, sizeof(int) * (size_t)R.ngridmax, s), "memset posof");
   }
-  HCHK(R.lists.ensure(sizeof(int) * (size_t)(ntot > 0 ? ntot : 1)), "hipMalloc lists");
-  if (ntot > 0) HCHK(hipMemcpyAsync(R.lists.p, igrid_all, sizeof(int) * (size_t)ntot, hipMemcpyHostToDevice, s), "H2D lists");
+  if (int rc = upload_list(R, R.lists, igrid_all, ntot)) return rc;
   for (int lev = nlevelmax; lev >= ilevel; lev--) {
     const int lo = first[lev - ilevel], n = first[lev - ilevel + 1] - lo;
     if (n < 0 || lo + n > ntot || n > R.ngridmax) return failf(RAMSES_AMD_EINVAL, "rho_fine: bad list of level %d", lev);
@@ -989,7 +1271,7 @@ int ramses_amd_amrres_rho_fine(const ramses_amd_hydro_params *p, int ilevel, int
     HCHK(hipMemcpy(R.hpack.data(), R.pack.p, sizeof(double) * (size_t)tot, hipMemcpyDeviceToHost), "D2H rho");
     const int *ig = igrid_all + lo;
     for (int ind = 0; ind < 8; ind++) {
-      double *dst = rho + R.ncoarse + (size_t)ind * R.ngridmax - 1;
+      double *dst = rho + R.ncoarse + (size_t)ind * R.ngh - 1;
       const double *src = R.hpack.data() + (size_t)ind * n;
       for (int i = 0; i < n; i++) dst[ig[i]] = src[i];
     }
@@ -1018,8 +1300,7 @@ int ramses_amd_amrres_rho_mpi_multipole(const ramses_amd_hydro_params *p, int il
   const size_t cb = sizeof(double) * (size_t)R.ncell;
   if (R.mp.cap < 4 * cb) { HCHK(R.mp.ensure(4 * cb), "hipMalloc multipoles"); HCHK(hipMemsetAsync(R.mp.p, 0, 4 * cb, s), "memset"); }
   if (R.rho.cap < cb) { HCHK(R.rho.ensure(cb), "hipMalloc rho"); HCHK(hipMemsetAsync(R.rho.p, 0, cb, s), "memset"); }
-  HCHK(R.lists.ensure(sizeof(int) * (size_t)(n_all > 0 ? n_all : 1)), "hipMalloc lists");
-  if (n_all > 0) HCHK(hipMemcpyAsync(R.lists.p, igrid_all, sizeof(int) * (size_t)n_all, hipMemcpyHostToDevice, s), "H2D lists");
+  if (int rc = upload_list(R, R.lists, igrid_all, n_all)) return rc;
   R.rl_level = ilevel; R.rl_nown = n_own; R.rl_nall = n_all;
   HCHK(launch_amr_multipole_level(R.uold.as<double>(), R.mp.as<double>(), R.xg.as<double>(), R.son.as<int>(), R.lists.as<int>(), n_own, R.ncoarse,
                                   R.ngridmax, ilevel, boxlen_over_nx, p->smallr, s), "multipole_fine launch");
@@ -1061,7 +1342,7 @@ int ramses_amd_amrres_rho_mpi_finish(int ilevel, int levelmin, int nvector, cons
     R.hpack.resize((size_t)tot);
     HCHK(hipMemcpy(R.hpack.data(), R.pack.p, sizeof(double) * (size_t)tot, hipMemcpyDeviceToHost), "D2H rho");
     for (int ind = 0; ind < 8; ind++) {
-      double *dst = rho + R.ncoarse + (size_t)ind * R.ngridmax - 1;
+      double *dst = rho + R.ncoarse + (size_t)ind * R.ngh - 1;
       const double *src = R.hpack.data() + (size_t)ind * n;
       for (int i = 0; i < n; i++) dst[igrid_all[i]] = src[i];
     }
@@ -1085,7 +1366,7 @@ int ramses_amd_amrres_sync_density(int ngrid, const int *igrid, double *uold) {
   R.hpack.resize((size_t)tot);
   HCHK(hipMemcpy(R.hpack.data(), R.pack.p, sizeof(double) * (size_t)tot, hipMemcpyDeviceToHost), "D2H density");
   for (int ind = 0; ind < 8; ind++) {
-    double *dst = uold + R.ncoarse + (size_t)ind * R.ngridmax - 1;
+    double *dst = uold + R.ncoarse + (size_t)ind * R.ngh - 1;
     const double *src = R.hpack.data() + (size_t)ind * ngrid;
     for (int i = 0; i < ngrid; i++) dst[igrid[i]] = src[i];
   }
@@ -1196,8 +1477,10 @@ int ramses_amd_amrres_comm_set(int ilevel, int epoch, int ncpu, const int *em_n,
   const int nem = L.em_first[ncpu], nrc = L.rc_first[ncpu];
   if ((nem > 0 && !em_ig) || (nrc > 0 && !rc_ig)) return failf(RAMSES_AMD_EINVAL, "comm_set: NULL list");
   HCHK(L.em_ig.ensure(sizeof(int) * (size_t)(nem > 0 ? nem : 1)), "hipMalloc"); HCHK(L.rc_ig.ensure(sizeof(int) * (size_t)(nrc > 0 ? nrc : 1)), "hipMalloc");
-  if (nem > 0) HCHK(hipMemcpy(L.em_ig.p, em_ig, sizeof(int) * (size_t)nem, hipMemcpyHostToDevice), "H2D emission list");
-  if (nrc > 0) HCHK(hipMemcpy(L.rc_ig.p, rc_ig, sizeof(int) * (size_t)nrc, hipMemcpyHostToDevice), "H2D reception list");
+  HCHK(L.em_raw.ensure(sizeof(int) * (size_t)(nem > 0 ? nem : 1)), "hipMalloc"); HCHK(L.rc_raw.ensure(sizeof(int) * (size_t)(nrc > 0 ? nrc : 1)), "hipMalloc");
+  if (nem > 0) HCHK(hipMemcpy(L.em_raw.p, em_ig, sizeof(int) * (size_t)nem, hipMemcpyHostToDevice), "H2D emission list");
+  if (nrc > 0) HCHK(hipMemcpy(L.rc_raw.p, rc_ig, sizeof(int) * (size_t)nrc, hipMemcpyHostToDevice), "H2D reception list");
+  L.serial = -1;             // translated into device indices by the exchange that uses them (comm_of)
   L.epoch = epoch;
   return 0;
 }
@@ -1208,6 +1491,21 @@ int comm_of(AmrRes &R, int ilevel, CommLevel *&L) {
   if (ilevel < 1 || (size_t)ilevel >= R.comm.size() || R.comm[ilevel].epoch < 0)
     return failf(RAMSES_AMD_EINVAL, "level %d: no communicators on the device (ramses_amd_amrres_comm_set)", ilevel);
   L = &R.comm[ilevel];
+  if (L->serial != R.map.serial) {
+    // the lists in the numbers of the layout in force (a regrid of OTHER levels renumbers nothing here, but costs nothing either)
+    const int nem = L->em_first[L->ncpu], nrc = L->rc_first[L->ncpu];
+    if (R.map.on) {
+      if (nem > 0) hipLaunchKernelGGL(amrlayout::xlate_list_copy_kernel, dim3(amrlayout::grid1(nem)), dim3(256), 0, nullptr, L->em_raw.as<int>(), L->em_ig.as<int>(), nem,
+                                      R.map.perm.as<int>(), R.ngh, R.bad.as<int>());
+      if (nrc > 0) hipLaunchKernelGGL(amrlayout::xlate_list_copy_kernel, dim3(amrlayout::grid1(nrc)), dim3(256), 0, nullptr, L->rc_raw.as<int>(), L->rc_ig.as<int>(), nrc,
+                                      R.map.perm.as<int>(), R.ngh, R.bad.as<int>());
+      HCHK(hipGetLastError(), "communicator translation");
+    } else {
+      if (nem > 0) HCHK(hipMemcpyAsync(L->em_ig.p, L->em_raw.p, sizeof(int) * (size_t)nem, hipMemcpyDeviceToDevice, nullptr), "copy");
+      if (nrc > 0) HCHK(hipMemcpyAsync(L->rc_ig.p, L->rc_raw.p, sizeof(int) * (size_t)nrc, hipMemcpyDeviceToDevice, nullptr), "copy");
+    }
+    L->serial = R.map.serial;
+  }
   return 0;
 }
 // dir 0: make_virtual_fine_dp on uold(:,1:nvar); 1: make_virtual_reverse_dp on unew(:,1:nvar); 2 / 3: the same on enew / divu;
@@ -1296,7 +1594,7 @@ int ramses_amd_amrres_boundary_hydro(int nregion, const int *btype, const int *n
     HCHK(hipMemsetAsync(R.bnd_pos.p, 0, sizeof(int) * (size_t)R.ngridmax, nullptr), "memset");
     R.bnd_pos_clean = true;
   }
-  HCHK(hipMemcpyAsync(R.bnd_list.p, igrid, sizeof(int) * (size_t)ntot, hipMemcpyHostToDevice, nullptr), "H2D boundary octs");
+  if (int rc = upload_list(R, R.bnd_list, igrid, (int)ntot)) return rc;
   BndArgs A;
   A.uold = R.uold.as<double>(); A.tmp = R.bnd_tmp.as<double>();
   A.son = R.son.as<int>(); A.nbor = R.nbor.as<int>(); A.pos = R.bnd_pos.as<int>();

@@ -94,18 +94,21 @@ __device__ __forceinline__ void plane_store(double *var_base, unsigned plane_byt
 }
 
 __device__ __forceinline__ int wave_shr1_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int mask_load(const unsigned char *base, unsigned plane_bytes, unsigned off) {
+__device__ __forceinline__ int wave_shl1_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ int stat_load(const unsigned char *base, unsigned off) {
   __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(base), 0, BUF_RANGE, 0x00020000);
-  return (int)__builtin_amdgcn_raw_buffer_load_b8(r, off, plane_bytes, 0);
+  return (int)__builtin_amdgcn_raw_buffer_load_b8(r, off, 0u, 0);
 }
-
-__device__ __forceinline__ unsigned index_load(const int *base, unsigned plane_ints, unsigned col) {
+// the tile directory entry of (tile column of the lane, tile plane): col and plane in ints
+__device__ __forceinline__ int dir_load(const int *base, unsigned plane_ints, unsigned col) {
   __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(base), 0, BUF_RANGE, 0x00020000);
-  return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, col * 4u, plane_ints * 4u, 0);
+  return (int)__builtin_amdgcn_raw_buffer_load_b32(r, col * 4u, plane_ints * 4u, 0);
 }
 
-// MASK: the sweep of a fully covered level that has refined cells, IN PLACE on the reference's cell vectors (see SweepArgs::mask /
-// cellidx): every HBM access of a lane goes through the cell index of its (plane, column), loaded three planes ahead
+// MASK: the sweep of a level of a resident AMR run IN PLACE on the device's cell vectors (see SweepArgs::stat / dir / work):
+// the level is stored in tiles of 32 x 4 x 4 octs, a lane finds the cell of its (plane, column) through the tile directory
+// (one 4-byte load per plane, issued three planes ahead; 256-byte runs of a variable along x inside a tile), the status byte of
+// the cell says whether it is refined (fluxes reset), updated (stored) or a ghost (interpolated: fluxes filed for the coarser level)
 template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV, int ROLE, bool MASK>
 __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *smem_raw) {
   const bool DXPOW2 = A.pow2 != 0;   // uniform
@@ -143,10 +146,15 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   const int tix = B.tx0 + lb % B.ntx;
   const int tiy = B.ty0 + (lb / B.ntx) % B.nty;
   const int tiz = lb / (B.ntx * B.nty);
-  const int x0 = tix * (BX - 4);
-  const int y0 = tiy * (BY - 4);
-  const int z0 = B.zlo + tiz * B.zchunk;
-  const int z1 = min(z0 + B.zchunk, B.zhi);
+  int x0 = tix * (BX - 4);
+  int y0 = tiy * (BY - 4);
+  int z0 = B.zlo + tiz * B.zchunk;
+  int z1 = min(z0 + B.zchunk, B.zhi);
+  if (MASK) {
+    // the launch's work list (the host put it in the order the XCDs should see it)
+    const int4 w = reinterpret_cast<const int4 *>(A.work)[hb];
+    x0 = w.x; y0 = w.y; z0 = w.z; z1 = w.w;
+  }
 
   // ---- this thread's column ------------------------------------------------
   const int xu = x0 - 2 + tx;  // unwrapped interior coordinate
@@ -165,14 +173,14 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   // are wave-uniform (scalar base + 32-bit lane offset addressing)
   // (byte offset < 2 GB per plane, checked by the launcher)
   const unsigned colb = (unsigned)(xi + yi * (int)A.pitch_y) * 8u;
-  // MASK (periodic dense brick, ng = 0): byte offsets of this column and of its -y neighbour in a plane of the mask
-  unsigned colm = 0, colm_ym = 0;
+  // MASK (the level in tiles, periodic box, ng = 0): the lane's tile column in a plane of the directory, its part of the
+  // cell index inside a tile (octant bits of x and y at stride ngd, oct column and oct row) and of the octant position
+  unsigned dcol = 0, lloc = 0;
+  int lind = 0;
   if (MASK) {
-    int yim = yu - 1;
-    yim = yim < 0 ? yim + A.ny : (yim >= A.ny ? yim - A.ny : yim);
-    yim = yim >= A.ny ? yim % A.ny : yim;
-    colm = (unsigned)(xi + yi * A.nx);
-    colm_ym = (unsigned)(xi + yim * A.nx);
+    dcol = (unsigned)((xi >> 6) + A.ntx * (yi >> 3));
+    lind = (xi & 1) + 2 * (yi & 1);
+    lloc = (unsigned)((long)lind * A.ngd) + (unsigned)(((xi >> 1) & (TILE_OX - 1)) + TILE_OX * ((yi >> 1) & (TILE_OY - 1)));
   }
   const double *__restrict__ uold = A.uold;
   double *__restrict__ unew = A.unew;
@@ -202,12 +210,27 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #pragma unroll
     for (int n = 0; n < NV; n++) u[n] = plane_load(unew + (long)n * A.pitch_var, 0u, o);
   };
-  auto mask_plane = [&](int p) -> unsigned {
-    const int pz = p < 0 ? p + A.nz : (p >= A.nz ? p - A.nz : p);
-    return (unsigned)pz * (unsigned)(A.nx * A.ny);
+  auto wrap_z = [&](int p) -> int { return p < 0 ? p + A.nz : (p >= A.nz ? p - A.nz : p); };
+  // MASK: the directory entry of the lane's tile for plane p (raw: turned into a byte offset one iteration later, when the
+  // load has long returned -- the multiply must not wait for it inside the iteration that issues it)
+  auto dir_raw = [&](int p) -> int { return dir_load(A.dir, (unsigned)((wrap_z(p) >> 3) * (A.ntx * A.nty)), dcol); };
+  auto cell_off = [&](int raw, int p) -> unsigned {
+    const int pz = wrap_z(p);
+    const unsigned u = (unsigned)((long)(pz & 1) * 4 * A.ngd) + (unsigned)(TILE_OX * TILE_OY * ((pz >> 1) & (TILE_OZ - 1)));
+    return raw < 0 ? 0u : ((unsigned)raw + lloc + u) * 8u;      // a lane without a tile reads cell 0 (status 0: nothing is stored)
   };
-  auto cell_off = [&](int p) -> unsigned { return index_load(A.cellidx, mask_plane(p), colm) * 8u; };
-  int ok_zlo = 0;   // MASK: plane c-1's refinement flag of this column
+  int ok_zlo = 0;   // MASK: plane c-1's status byte of this column
+  int s_m1 = 0;     // MASK: the same, kept until plane c-1 is finished in phase B
+  unsigned char *smask = smem_raw + 5 * sizeof(Plane<BY, NV>);   // MASK: [3][BY][BX] status bytes of planes c-1, c, c+1 by plane mod 3
+  const int CV = NV + 2;
+  // a flux owed to the coarser level: record (oct of the cell at byte offset o, face f, fine face q)
+  auto file_flux = [&](unsigned o, int pz, int f, int q, const double (&fl)[NV]) {
+    const long oct0 = (long)(o >> 3) - A.ncoarse - (long)(lind + 4 * (pz & 1)) * A.ngd;
+    const int io = A.octpos[oct0];
+    double *dst = A.corr + (((long)io * 6 + f) * 4 + q) * CV;
+#pragma unroll
+    for (int n = 0; n < NV; n++) dst[n] = fl[n];
+  };
   auto load_g = [&](int p, unsigned o, double (&g)[3]) {
     if (GRAV) {
       const unsigned pb = MASK ? 0u : plane_off(p), off = MASK ? o : colb;
@@ -230,7 +253,11 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   // prologue: primitives of planes z0-2 -> slot sa, z0-1 -> slot sb; c starts at z0-1
   // MASK: cell offsets of planes c-1, c, c+1, c+2 (c = z0-1 on entry of the loop)
   unsigned o_m1 = 0, o_0 = 0, o_p1 = 0, o_p2 = 0;
-  if (MASK) { o_m1 = cell_off(z0 - 2); o_0 = cell_off(z0 - 1); o_p1 = cell_off(z0); o_p2 = cell_off(min(z0 + 1, z1 + 1)); }
+  int raw_next = -1;      // directory entry of plane c+2, loaded in iteration c-1
+  if (MASK) {
+    o_m1 = cell_off(dir_raw(z0 - 2), z0 - 2); o_0 = cell_off(dir_raw(z0 - 1), z0 - 1); o_p1 = cell_off(dir_raw(z0), z0);
+    raw_next = dir_raw(min(z0 + 1, z1 + 1));
+  }
   {
     double u[NV], g[3], q[NV];
     load_u(z0 - 2, o_m1, u); load_g(z0 - 2, o_m1, g);
@@ -285,10 +312,9 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     double ucur[NV];
     if (r_fxz) { if (MASK) load_base(o_0, ucur); else load_u(c, 0u, ucur); }
     int okc = 0, ok_ym = 0;
-    if (MASK && (ROLE == ROLE_FULL || ROLE == ROLE_HIGH)) {
-      const unsigned mp = mask_plane(c);
-      okc = mask_load(A.mask, mp, colm);
-      ok_ym = mask_load(A.mask, mp, colm_ym);
+    if (MASK && r_trace) {
+      okc = stat_load(A.stat, o_0 >> 3);
+      smask[((c + 3) % 3 * BY + ty) * BX + tx] = (unsigned char)okc;   // row ty+1 reads it after the barrier (its -y neighbour), row ty-1 one plane later
     }
 
     double qpy[NV], dz[NV], px[NV];
@@ -353,20 +379,35 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
         scaled_interface_flux<RS, NV, 0>(qL, qp[0], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fx);
         // z flux through the face between planes c-1 and c
         scaled_interface_flux<RS, NV, 2>(qmz, qp[2], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fz);
+        int s_xm = 0, s_xp = 0;
         if (MASK) {
           // hydro/godunov_fine.f90:720-747: the flux through a face is reset when the cell on either side is refined
-          const bool zx = (okc | wave_shr1_i(okc)) != 0, zz = (okc | ok_zlo) != 0;
+          s_xm = wave_shr1_i(okc); s_xp = wave_shl1_i(okc);
+          const bool zx = ((okc | s_xm) & CELL_REFINED) != 0, zz = ((okc | ok_zlo) & CELL_REFINED) != 0;
 #pragma unroll
           for (int n = 0; n < NV; n++) { fx[n] = zx ? 0.0 : fx[n]; fz[n] = zz ? 0.0 : fz[n]; }
-          ok_zlo = okc;
         }
+        double fxh[NV];
 #pragma unroll
         for (int n = 0; n < NV; n++) {
           qmz[n] = qm[2][n];
           dz[n] = fzlo[n] - fz[n];          // z flux difference of plane c-1
           fzlo[n] = fz[n];
-          const double fxhi = wave_shl1(fx[n]);   // -x face flux of column tx+1
-          px[n] = ucur[n] + (fx[n] - fxhi);       // consumes the re-read state before the barrier
+          fxh[n] = wave_shl1(fx[n]);        // -x face flux of column tx+1
+          px[n] = ucur[n] + (fx[n] - fxh[n]);     // consumes the re-read state before the barrier
+        }
+        if (MASK) {
+          // :798-908: what an updated cell exchanges with a ghost cell (an oct that does not exist: interpolated) is owed to the
+          // leaf cell of the coarser level there -- filed per (oct, face, fine face), replayed in the reference's order afterwards
+          const int pz = wrap_z(c);
+          if (r_upd && c >= z0 && c < z1 && (okc & CELL_OWNED)) {
+            if (s_xm & CELL_GHOST) file_flux(o_0, pz, 0, (yi & 1) + 2 * (pz & 1), fx);
+            if (s_xp & CELL_GHOST) file_flux(o_0, pz, 1, (yi & 1) + 2 * (pz & 1), fxh);
+            if (ok_zlo & CELL_GHOST) file_flux(o_0, pz, 4, (xi & 1) + 2 * (yi & 1), fz);
+          }
+          if (r_upd && c - 1 >= z0 && c - 1 < z1 && (ok_zlo & CELL_OWNED) && (okc & CELL_GHOST))
+            file_flux(o_m1, wrap_z(c - 1), 5, (xi & 1) + 2 * (yi & 1), fz);
+          ok_zlo = okc;
         }
         if (NV > 5) {
           rnew = ucur[0];
@@ -377,9 +418,11 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     }
     // prefetch plane c+2 after the register peak of the trace and flux phase (still ~1 us ahead of its use)
     __builtin_amdgcn_sched_barrier(0);
-    unsigned o_p3 = 0;
-    { const int pn = min(c + 2, z1 + 1); load_u(pn, o_p2, upre); load_g(pn, o_p2, gpre); }
-    if (MASK) o_p3 = cell_off(min(c + 3, z1 + 1));      // the index runs one plane ahead of the data it addresses
+    {
+      const int pn = min(c + 2, z1 + 1);
+      if (MASK) { o_p2 = cell_off(raw_next, pn); raw_next = dir_raw(min(c + 3, z1 + 1)); }   // the directory runs one plane ahead of the data
+      load_u(pn, o_p2, upre); load_g(pn, o_p2, gpre);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // the one barrier: +y states of plane c and y fluxes of plane c-1 visible
 
@@ -391,9 +434,14 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
       for (int n = 0; n < NV; n++) qL[n] = M.v[n][tym][tx];
       scaled_interface_flux<RS, NV, 1>(qL, qpy, P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fy);
       if (MASK) {
-        const bool zy = (okc | ok_ym) != 0;
+        ok_ym = smask[((c + 3) % 3 * BY + tym) * BX + tx];
+        const bool zy = ((okc | ok_ym) & CELL_REFINED) != 0;
 #pragma unroll
         for (int n = 0; n < NV; n++) fy[n] = zy ? 0.0 : fy[n];
+        if (ROLE == ROLE_FULL && r_upd && c >= z0 && c < z1 && (okc & CELL_OWNED) && (ok_ym & CELL_GHOST)) {
+          const int pz = wrap_z(c);
+          file_flux(o_0, pz, 2, (xi & 1) + 2 * (pz & 1), fy);
+        }
       }
       // the flux through this row's -y face is the +y face flux of row ty-1: into ITS slot
 #pragma unroll
@@ -404,11 +452,22 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
       // in this row's slot of the other buffer by row ty+1 before this iteration's barrier.
       // (The first two iterations of a chunk produce values from the not yet primed pipeline;
       // they are computed and dropped by the store's range check.)
-      double un[NV];
+      double un[NV], fyh[NV];
 #pragma unroll
       for (int n = 0; n < NV; n++) {
-        const double part = partx[n] + (fyown[n] - Mprev.v[n][ty][tx]);
+        fyh[n] = Mprev.v[n][ty][tx];
+        const double part = partx[n] + (fyown[n] - fyh[n]);
         un[n] = part + dz[n];
+      }
+      if (MASK) {
+        // the +y face of plane c-1: row ty+1 left the flux in this row's slot and its status byte in the plane's smask
+        if (r_upd && c - 1 >= z0 && c - 1 < z1 && (s_m1 & CELL_OWNED)) {
+          const int s_yp = smask[((c + 2) % 3 * BY + typ) * BX + tx];
+          if (s_yp & CELL_GHOST) {
+            const int pz = wrap_z(c - 1);
+            file_flux(o_m1, pz, 3, (xi & 1) + 2 * (pz & 1), fyh);
+          }
+        }
       }
       if (NV > 5) {
         // set_uold's passive-scalar fix near the density floor
@@ -428,14 +487,14 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
       for (int n = 0; n < NV; n++) { partx[n] = px[n]; fyown[n] = fy[n]; }
       {
         const unsigned pb = MASK ? 0u : plane_off(c - 1);
-        const unsigned so = (c >= z0 + 1) ? (MASK ? (r_upd ? o_m1 : BUF_OOB) : colb_upd) : BUF_OOB;
+        const unsigned so = (c >= z0 + 1) ? (MASK ? ((r_upd && (s_m1 & CELL_OWNED)) ? o_m1 : BUF_OOB) : colb_upd) : BUF_OOB;
 #pragma unroll
         for (int n = 0; n < NV; n++) plane_store(unew + (long)n * A.pitch_var, pb, so, un[n]);
       }
     }
     // rotate the ring
     const int t = sa; sa = sb; sb = sc; sc = t;
-    if (MASK) { o_m1 = o_0; o_0 = o_p1; o_p1 = o_p2; o_p2 = o_p3; }
+    if (MASK) { o_m1 = o_0; o_0 = o_p1; o_p1 = o_p2; s_m1 = okc; }
   }
 }
 
@@ -458,7 +517,7 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
 // ---------------------------------------------------------------------------
 template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV, bool MASK = false>
 static hipError_t launch3(const SweepArgs &A, hipStream_t s) {
-  const size_t lds = 5 * sizeof(Plane<BY, NV>);
+  const size_t lds = 5 * sizeof(Plane<BY, NV>) + (MASK ? 3 * BY * BX : 0);
   dim3 block(BX, BY);
   dim3 grid(A.nblocks);
   auto k = godunov_sweep_kernel<ST, RS, BY, GRAV, SCHEME, NV, MASK>;
@@ -519,15 +578,21 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
   }
   if (nblocks == 0) return hipSuccess;
   A.nblocks = nblocks;
-  if (A.mask || A.cellidx) {
-    // a fully covered level with refined cells: the 12-row muscl kernels on a periodic brick (anything else: the caller
-    // keeps the tree-walking sweep)
+  if (A.stat) {
+    // a level of a resident AMR run in tiles: the 12-row muscl kernels on the periodic box of the level, one workgroup per
+    // work item (anything else: the caller keeps the tree-walking sweep)
+#ifndef RAMSES_AMD_FAST
     if constexpr (ST != 3 && ST != 4 && ST != 5 && ST != 6 && RS != RIEMANN_EXACT) {
-      if (!A.mask || !A.cellidx || A.ng != 0 || nvar != 5 || scheme != 0 || by != 12 || A.region != SWEEP_ALL) return hipErrorInvalidValue;
+      if (!A.dir || !A.work || !A.corr || !A.octpos || A.ng != 0 || nvar != 5 || scheme != 0 || by != 12 || A.nwork <= 0) return hipErrorInvalidValue;
+      A.nblocks = A.nwork;
+      A.nbox = 1;          // (the box decode runs, its result is replaced by the work item)
       return grav ? launch3<ST, RS, 12, true, 0, 5, true>(A, s) : launch3<ST, RS, 12, false, 0, 5, true>(A, s);
     } else {
       return hipErrorInvalidValue;
     }
+#else
+    return hipErrorInvalidValue;      // strict arithmetic only (the fast build is certified on uniform runs)
+#endif
   }
   if constexpr (ST == 4 || ST == 5 || ST == 6) {
     // NDIM=1 slope types: the plain configuration only (the reference's 1-D tests: NVAR=3 embedded as 5, muscl, no gravity)

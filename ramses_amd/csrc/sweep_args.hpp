@@ -7,6 +7,11 @@ namespace ramses_amd {
 // what one sweep launch covers
 enum { SWEEP_ALL = 0, SWEEP_INTERIOR = 1, SWEEP_SHELL = 2 };
 
+// status bits of a device cell (SweepArgs::stat)
+enum { CELL_REFINED = 1, CELL_OWNED = 2, CELL_GHOST = 4 };
+// storage tiles of a level: 32 x 4 x 4 octs
+constexpr int TILE_OX = 32, TILE_OY = 4, TILE_OZ = 4, TILE_OCTS = TILE_OX * TILE_OY * TILE_OZ;
+
 // a box of tiles x planes inside the brick, cut into z-chunks; `first` = index
 // of its first workgroup in the launch
 struct SweepBox {
@@ -17,16 +22,29 @@ struct SweepArgs {
   const double *uold;
   double *unew;
   const double *grav;   // may be null
-  // A fully covered level of an AMR run (hydro/godunov_fine.f90:661-666,720-747), swept IN PLACE on the reference's cell vectors:
-  //   mask    1 byte per cell of the level's brick, [nz][ny][nx]: non-zero where the cell is refined (son > 0) -- the fluxes through
-  //           the faces of such cells are reset to zero;
-  //   cellidx the 0-based index of every brick cell in the cell vectors, [nz][ny][nx] ints: uold / grav / unew are then the cell
-  //           vectors themselves (pitch_var = ncell; pitch_y, pitch_z unused), every lane addresses them through the index of its
-  //           (plane, column), and the update starts from unew -- which already holds what the finer level owes to this one --
-  //           and lands there.
-  // Both null: the plain brick sweep (unew = uold + updates).
-  const unsigned char *mask = nullptr;
-  const int *cellidx = nullptr;
+  // A level of a resident AMR run, swept IN PLACE on the device's cell vectors (csrc/amr_layout.hpp: the octs of a level are
+  // numbered on the device so that they fill TILES of 32 x 4 x 4 octs = 64 x 8 x 8 cells; inside a tile the cell vectors of
+  // one octant position are a dense little brick, 256-byte runs along x).  stat != null selects this mode:
+  //   stat    one byte per device cell, indexed like a cell vector: bit 0 the cell is refined (son > 0: the fluxes through its
+  //           faces are reset, hydro/godunov_fine.f90:661-666,720-747), bit 1 the cell belongs to an oct of the call's list (it
+  //           is updated), bit 2 the cell belongs to a GHOST oct (a missing neighbour oct, interpolated from the coarser level
+  //           by a pre-pass: the flux between an updated cell and a ghost cell is also filed in `corr`, :798-908);
+  //   dir     the level's tile directory [ntz][nty][ntx]: 0-based index of the tile's first cell in a cell vector
+  //           (= ncoarse + first oct - 1), or -1 where no oct of the level and no ghost oct falls into the tile;
+  //   work    the launch's work items, one per workgroup: (x0, y0, z0, z1) = first interior column / row of the 60 x (BY-4)
+  //           tile and the planes [z0, z1) it marches;
+  //   corr    [ngrid][6][4][nvar+2] flux records of the (oct, face) pairs that border a leaf cell of the coarser level -- the
+  //           layout amr_coarse_update_kernel replays (csrc/amr_sweep.hip) -- and octpos[device oct - 1] = position of the oct
+  //           in the call's list.
+  // uold / grav / unew are then the cell vectors themselves (pitch_var = ncell of the device; pitch_y, pitch_z unused), the
+  // update starts from unew -- which already holds what the finer level owes to this one (:752-790) -- and lands there.
+  const unsigned char *stat = nullptr;
+  const int *dir = nullptr;
+  const int *work = nullptr;          // int4 per workgroup
+  double *corr = nullptr;
+  const int *octpos = nullptr;
+  int ntx = 0, nty = 0, ntz = 0, nwork = 0;
+  long ngd = 0, ncoarse = 0;
   int nx, ny, nz;       // interior cells
   int ng;               // ghost width (0 = periodic wrap in-kernel)
   long pitch_y, pitch_z, pitch_var;

@@ -103,6 +103,9 @@ contains
   logical function ramses_amd_mhd_resident()
     use amr_commons
     use hydro_commons
+#if USE_TURB==1
+    use turb_commons, only: turb
+#endif
     character(len=16) :: val
     integer :: stat
     logical, save :: first = .true., on = .false.
@@ -112,6 +115,14 @@ contains
        if (eta_mag > 0.0d0) on = .false.
        if (pic .or. rt .or. cooling .or. star .or. sink .or. tracer .or. clumpfind .or. lightcone .or. movie) on = .false.
        if (static .or. cosmo) on = .false.
+       ! every host routine of amr_step that reads or writes uold during the time loop sends the run to the staged path
+       ! (the list of the hydro gate, ramses_amd_amr_config): cooling_fine (amr/amr_step.f90:472) runs for T2_star > 0,
+       ! barotropic_eos, neq_chem too; the turbulent forcing of synchro_hydro_fine (:433-437) and courant_fine's gg
+       if (T2_star > 0.0d0 .or. barotropic_eos .or. neq_chem .or. isothermal) on = .false.
+       if (MC_tracer .or. momentum_feedback > 0 .or. strict_equilibrium > 0 .or. static_gas .or. metal .or. aton) on = .false.
+#if USE_TURB==1
+       if (turb) on = .false.
+#endif
        call get_environment_variable('RAMSES_AMD_MHD_RESIDENT', val, status=stat)
        if (stat == 0) then
           if (trim(val) == '0') on = .false.

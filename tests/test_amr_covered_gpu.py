@@ -1,4 +1,5 @@
-"""godunov_fine of a FULLY COVERED level of an AMR run through the dense sweep with the level's refinement mask
+"""godunov_fine of a FULLY COVERED level of an AMR run through the dense sweep (since round 5: on the device's tiles,
+csrc/amr_layout.hpp -- levels of 64^3 cells and more; tests/test_amr_tiles_gpu.py holds the same path against the ORACLE)
 (hydro/godunov_fine.f90:661-666 `ok`, :720-747 fluxes reset at refined faces, :752-790 the update
 of unew, which already holds what the finer level owes to this one) against the tree-walking sweep of the same level, which
 the reference dumps, goldens and live A/B runs pin bit for bit (tests/test_amr_godunov_gpu.py, test_baseline_sizes_gpu.py).
@@ -43,7 +44,7 @@ def _state(T, L, seed):
     return vec
 
 
-@pytest.mark.parametrize("L,riemann,slope_type,grav", [(5, 0, 1, False), (5, 1, 2, False), (4, 2, 8, True), (5, 3, 7, False), (6, 0, 1, True)])
+@pytest.mark.parametrize("L,riemann,slope_type,grav", [(6, 0, 1, False), (6, 1, 2, False), (6, 2, 8, True), (6, 3, 7, False), (6, 0, 1, True)])
 def test_dense_masked_sweep_equals_the_tree_walking_sweep(gpu_lib, monkeypatch, L, riemann, slope_type, grav):
     import ramses_amd
     from ramses_amd import ic

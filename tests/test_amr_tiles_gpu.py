@@ -1,0 +1,238 @@
+"""The device's own oct numbering (csrc/amr_layout.hpp: levels in tiles of 32 x 4 x 4 octs) and the dense sweep of AMR levels on
+it (csrc/capi_amr.hip tile_level_sweep, csrc/hydro_sweep.hip MASK) against the C ORACLE of godfine1
+(oracle/amr_godfine_oracle.c, itself pinned on the reference's dumps): hydro/godunov_fine.f90:486-911 -- interpolated ghost octs
+(:563-626), fluxes reset at refined faces (:720-747), the update of unew (:752-790), the fluxes owed to the coarser level
+(:798-908).  Everything goes through the C ABI with the HOST's oct numbers; what comes back must be the oracle's result bit for
+bit whatever the device did with the numbering -- tiles, Z-order (tiles that do not fit), or none (RAMSES_AMD_DEVICE_ORDER=0)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _shell_mask(nc, lo=0.23, hi=0.36, seam=True):
+    z, y, x = np.meshgrid(np.arange(nc), np.arange(nc), np.arange(nc), indexing="ij")
+    r = np.sqrt((x - nc / 2 + 0.5) ** 2 + (y - nc / 2 + 0.5) ** 2 + (z - nc / 2 + 0.5) ** 2)
+    mask = (r >= lo * nc) & (r <= hi * nc)
+    if seam:
+        mask[0, 0, :5] = True              # refined cells on the periodic seam too (tiles wrap)
+        mask[nc - 1, nc - 1, nc - 3:] = True
+    return mask
+
+
+def _random_state(T, seed, nvar=5):
+    rng = np.random.default_rng(seed)
+    ncell = T["ncell"]
+    uold = np.zeros((nvar, ncell))
+    n = ncell - 1
+    uold[0, 1:] = 1.0 + rng.random(n)
+    for d in (1, 2, 3):
+        uold[d, 1:] = uold[0, 1:] * (rng.random(n) - 0.5)
+    uold[4, 1:] = 1.0 + rng.random(n) + 0.5 * (uold[1, 1:] ** 2 + uold[2, 1:] ** 2 + uold[3, 1:] ** 2) / uold[0, 1:]
+    uold[:, 0] = uold[:, 1]
+    return uold
+
+
+def _oracle_step(oracle, po, T, L, uold, f, lists, ivar=0, itype=1):
+    """set_unew on both levels, godunov_fine of level L+1 then L (the order of amr_step), set_uold"""
+    unew = uold.copy()
+    for level, igrid in ((L + 1, lists[L + 1]), (L, lists[L])):
+        dx = 1.0 / 2 ** level
+        oracle.godunov_fine_amr(po, igrid, T["son"], T["nbor"], T["father"], T["ngridmax"], T["ncoarse"], uold, unew, dx, 0.02 * dx, 32,
+                                ivar, itype, f=f)
+    return unew
+
+
+def _device_step(Lb, p, T, L, u, f, lists, ivar=0, itype=1, load=True):
+    from ramses_amd._capi import check
+    if load:
+        check(Lb.ramses_amd_amrres_invalidate())
+        check(Lb.ramses_amd_amrres_load(5, T["ngridmax"], T["ncoarse"], _vp(u), _vp(T["son"]), _vp(T["nbor"]), _vp(T["father"])))
+        if f is not None:
+            for lev in (L, L + 1):
+                ig = np.ascontiguousarray(T["all_octs"][lev])
+                check(Lb.ramses_amd_amrres_load_f(len(ig), _vp(ig), _vp(f)))
+    for lev in (L, L + 1):
+        ig = np.ascontiguousarray(T["all_octs"][lev])
+        check(Lb.ramses_amd_amrres_set_unew(len(ig), _vp(ig)))
+    for lev in (L + 1, L):
+        ig = np.ascontiguousarray(lists[lev])
+        dx = 1.0 / 2 ** lev
+        check(Lb.ramses_amd_amrres_godunov(C.byref(p), lev, len(ig), _vp(ig), dx, 0.02 * dx, 32, ivar, itype))
+    for lev in (L, L + 1):
+        ig = np.ascontiguousarray(T["all_octs"][lev])
+        check(Lb.ramses_amd_amrres_set_uold(C.byref(p), len(ig), _vp(ig)))
+        check(Lb.ramses_amd_amrres_sync_level(len(ig), _vp(ig), _vp(u)))
+    return u
+
+
+def _tree(L, mask, order, slack):
+    from ramses_amd import ic
+    T = ic.uniform_tree(L, order=order, refine_mask=mask, slack=slack)
+    T["all_octs"] = {L: np.sort(T["igrid"]), L + 1: np.sort(T["igrid_fine"])}
+    return T
+
+
+@pytest.mark.parametrize("order,riemann,slope,grav,interp", [("morton", "llf", 1, False, (0, 1)), ("scrambled", "hllc", 2, True, (1, 2)),
+                                                             ("scrambled", "hll", 7, False, (2, 4)), ("morton", "acoustic", 8, True, (0, 3))])
+def test_levels_in_tiles_equal_the_oracle(gpu_lib, oracle, monkeypatch, order, riemann, slope, grav, interp):
+    """level 6 complete (64^3: 64 full tiles), level 7 in a spherical shell with refined cells on the periodic seam (tiles with free
+    slots: ghost octs on both surfaces, fluxes owed to level-6 leaf cells): one amr_step's worth of calls == the oracle"""
+    import ramses_amd
+    L = 6
+    mask = _shell_mask(2 ** L)
+    T = _tree(L, mask, order, slack=260000)
+    uold = _random_state(T, 11)
+    rng = np.random.default_rng(5)
+    f = rng.normal(size=(3, T["ncell"])) if grav else None
+    kw = dict(riemann=riemann, slope_type=slope)
+    p, po = ramses_amd.make_params(**kw), oracle.make_params(**kw)
+    lists = {L: T["igrid"], L + 1: T["igrid_fine"]}
+    ref = _oracle_step(oracle, po, T, L, uold, f, lists, *interp)
+    for var in ("RAMSES_AMD_DEVICE_ORDER", "RAMSES_AMD_TILES", "RAMSES_AMD_TILE_DENSE", "RAMSES_AMD_COVERED_DENSE"):
+        monkeypatch.delenv(var, raising=False)
+    t0, w0 = gpu_lib.ramses_amd_amrres_tile_sweeps(), gpu_lib.ramses_amd_amrres_tree_sweeps()
+    got = _device_step(gpu_lib, p, T, L, uold.copy(), f, lists, *interp)
+    assert gpu_lib.ramses_amd_amrres_tiled_levels() == 2
+    assert gpu_lib.ramses_amd_amrres_tile_sweeps() - t0 == 2 and gpu_lib.ramses_amd_amrres_tree_sweeps() == w0
+    cells = np.concatenate([T["ncoarse"] + ind * T["ngridmax"] + np.concatenate([T["igrid"], T["igrid_fine"]]) - 1 for ind in range(8)])
+    assert np.array_equal(got[:, cells], ref[:, cells]), np.abs(got[:, cells] - ref[:, cells]).max()
+    assert (ref[:, cells] != uold[:, cells]).any(0).mean() > 0.9
+    gpu_lib.ramses_amd_amrres_invalidate()
+
+
+@pytest.mark.parametrize("mode", ["host_order", "z_order", "no_room", "tree_walk_on_tiles"])
+def test_every_numbering_gives_the_same_result(gpu_lib, oracle, monkeypatch, mode):
+    """the switches of the layout: the host's numbering, Z-order without tiles, tiles that do not fit (ngridmax without slack: the
+    partial level falls back to Z-order and the tree-walking sweep), tiles with the tree-walking sweep -- all == the oracle"""
+    import ramses_amd
+    L = 6
+    mask = _shell_mask(2 ** L, seam=False)
+    T = _tree(L, mask, "scrambled", slack=7 if mode == "no_room" else 260000)
+    uold = _random_state(T, 13)
+    p, po = ramses_amd.make_params(riemann="llf", slope_type=1), oracle.make_params(riemann="llf", slope_type=1)
+    lists = {L: T["igrid"], L + 1: T["igrid_fine"]}
+    ref = _oracle_step(oracle, po, T, L, uold, None, lists)
+    for var in ("RAMSES_AMD_DEVICE_ORDER", "RAMSES_AMD_TILES", "RAMSES_AMD_TILE_DENSE", "RAMSES_AMD_COVERED_DENSE"):
+        monkeypatch.delenv(var, raising=False)
+    if mode == "host_order":
+        monkeypatch.setenv("RAMSES_AMD_DEVICE_ORDER", "0")
+    if mode == "z_order":
+        monkeypatch.setenv("RAMSES_AMD_TILES", "0")
+    if mode == "tree_walk_on_tiles":
+        monkeypatch.setenv("RAMSES_AMD_TILE_DENSE", "0")
+        monkeypatch.setenv("RAMSES_AMD_COVERED_DENSE", "0")
+    t0, w0 = gpu_lib.ramses_amd_amrres_tile_sweeps(), gpu_lib.ramses_amd_amrres_tree_sweeps()
+    got = _device_step(gpu_lib, p, T, L, uold.copy(), None, lists)
+    tiled = gpu_lib.ramses_amd_amrres_tiled_levels()
+    dt, dw = gpu_lib.ramses_amd_amrres_tile_sweeps() - t0, gpu_lib.ramses_amd_amrres_tree_sweeps() - w0
+    assert (tiled, dt, dw) == {"host_order": (0, 0, 2), "z_order": (0, 0, 2), "no_room": (1, 1, 1), "tree_walk_on_tiles": (2, 0, 2)}[mode]
+    cells = np.concatenate([T["ncoarse"] + ind * T["ngridmax"] + np.concatenate([T["igrid"], T["igrid_fine"]]) - 1 for ind in range(8)])
+    assert np.array_equal(got[:, cells], ref[:, cells]), np.abs(got[:, cells] - ref[:, cells]).max()
+    gpu_lib.ramses_amd_amrres_invalidate()
+
+
+def test_a_list_that_is_part_of_the_level(gpu_lib, oracle, monkeypatch):
+    """several ranks: the call's list holds the rank's own octs, the other octs of the level are there (virtual octs, filled by
+    the exchange) but are not updated, and a face between an own and a virtual oct owes nothing to the coarser level"""
+    import ramses_amd
+    L = 6
+    nc = 2 ** L
+    mask = _shell_mask(nc)
+    T = _tree(L, mask, "scrambled", slack=260000)
+    uold = _random_state(T, 17)
+    p, po = ramses_amd.make_params(riemann="hllc", slope_type=1), oracle.make_params(riemann="hllc", slope_type=1)
+    # own = a fixed subset of each level (by the index of the father cell): the oracle sees the same lists
+    fcL, fcF = T["father"][T["igrid"] - 1].astype(np.int64), T["father"][T["igrid_fine"] - 1].astype(np.int64)
+    own = {L: np.ascontiguousarray(T["igrid"][(fcL % 3) != 0]), L + 1: np.ascontiguousarray(T["igrid_fine"][(fcF % 5) < 3])}
+    assert 0 < len(own[L]) < len(T["igrid"]) and 0 < len(own[L + 1]) < len(T["igrid_fine"])
+    ref = _oracle_step(oracle, po, T, L, uold, None, own)
+    for var in ("RAMSES_AMD_DEVICE_ORDER", "RAMSES_AMD_TILES", "RAMSES_AMD_TILE_DENSE", "RAMSES_AMD_COVERED_DENSE"):
+        monkeypatch.delenv(var, raising=False)
+    t0 = gpu_lib.ramses_amd_amrres_tile_sweeps()
+    got = _device_step(gpu_lib, p, T, L, uold.copy(), None, own)
+    assert gpu_lib.ramses_amd_amrres_tile_sweeps() - t0 == 2
+    cells = np.concatenate([T["ncoarse"] + ind * T["ngridmax"] + np.concatenate([T["igrid"], T["igrid_fine"]]) - 1 for ind in range(8)])
+    assert np.array_equal(got[:, cells], ref[:, cells]), np.abs(got[:, cells] - ref[:, cells]).max()
+    gpu_lib.ramses_amd_amrres_invalidate()
+
+
+def test_a_regrid_keeps_the_levels_that_did_not_change(gpu_lib, oracle, monkeypatch):
+    """refine_fine's hook in small: after a step the finer level is rebuilt on the host (another set of octs, other host indices),
+    the tree goes down again and ONLY the rebuilt level is reloaded; level L stays where it was on the device with the state the
+    first step left there.  Two steps on the device == two steps of the oracle on the host arrays."""
+    import ramses_amd
+    from ramses_amd._capi import check
+    L = 6
+    nc = 2 ** L
+    m1 = _shell_mask(nc, 0.23, 0.36)
+    m2 = _shell_mask(nc, 0.15, 0.30, seam=False)
+    n1, n2 = int(m1.sum()), int(m2.sum())
+    T1 = _tree(L, m1, "morton", slack=260000 + max(n1, n2) - n1)
+    T2 = _tree(L, m2, "morton", slack=260000 + max(n1, n2) - n2)
+    assert T1["ngridmax"] == T2["ngridmax"] and np.array_equal(T1["igrid"], T2["igrid"])
+    p, po = ramses_amd.make_params(riemann="llf", slope_type=2), oracle.make_params(riemann="llf", slope_type=2)
+    for var in ("RAMSES_AMD_DEVICE_ORDER", "RAMSES_AMD_TILES", "RAMSES_AMD_TILE_DENSE", "RAMSES_AMD_COVERED_DENSE"):
+        monkeypatch.delenv(var, raising=False)
+    u0 = _random_state(T1, 19)
+    # oracle: step 1 on tree 1; the new finer octs take their father cell's state (times a factor per octant); step 2 on tree 2
+    l1 = {L: T1["igrid"], L + 1: T1["igrid_fine"]}
+    l2 = {L: T2["igrid"], L + 1: T2["igrid_fine"]}
+    h1 = _oracle_step(oracle, po, T1, L, u0, None, l1)
+
+    def refill(u):
+        # what refine_fine leaves on the host for the rebuilt level: interpolated from the (synced) coarser level
+        v = u.copy()
+        for ind in range(8):
+            c = T2["ncoarse"] + ind * T2["ngridmax"] + T2["igrid_fine"] - 1
+            v[:, c] = u[:, T2["father"][T2["igrid_fine"] - 1] - 1] * (1.0 + 0.01 * (ind - 3.5))
+        return v
+    h1r = refill(h1)
+    h2 = _oracle_step(oracle, po, T2, L, h1r, None, l2)
+    # device: step 1, level L back to the host (refine_fine reads it), new tree, ONLY level L+1 reloaded, step 2
+    u = _device_step(gpu_lib, p, T1, L, u0.copy(), None, l1)
+    ur = refill(u)
+    ur_for_device = ur.copy()
+    c_l = np.concatenate([T2["ncoarse"] + ind * T2["ngridmax"] + T2["igrid"] - 1 for ind in range(8)])
+    ur_for_device[:, c_l] = -7.0         # if the device read level L from the host again, the result would show it
+    check(gpu_lib.ramses_amd_amrres_tree(_vp(T2["son"]), _vp(T2["nbor"]), _vp(T2["father"])))
+    igf = np.ascontiguousarray(np.sort(T2["igrid_fine"]))
+    check(gpu_lib.ramses_amd_amrres_load_level(len(igf), _vp(igf), _vp(ur_for_device)))
+    t0 = gpu_lib.ramses_amd_amrres_tile_sweeps()
+    got = _device_step(gpu_lib, p, T2, L, ur_for_device, None, l2, load=False)
+    assert gpu_lib.ramses_amd_amrres_tile_sweeps() - t0 == 2
+    cells = np.concatenate([T2["ncoarse"] + ind * T2["ngridmax"] + np.concatenate([T2["igrid"], T2["igrid_fine"]]) - 1 for ind in range(8)])
+    assert np.array_equal(got[:, cells], h2[:, cells]), np.abs(got[:, cells] - h2[:, cells]).max()
+    gpu_lib.ramses_amd_amrres_invalidate()
+
+
+def test_flagged_cells_come_back_in_host_numbers(gpu_lib, monkeypatch):
+    """hydro_flag's compact list crosses the interface the other way: device cell indices -> the host's"""
+    import ramses_amd
+    from ramses_amd._capi import check
+    L = 6
+    T = _tree(L, _shell_mask(2 ** L, seam=False), "scrambled", slack=260000)
+    u = _random_state(T, 23)
+    p = ramses_amd.make_params()
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RAMSES_AMD_DEVICE_ORDER", mode)
+        check(gpu_lib.ramses_amd_amrres_invalidate())
+        check(gpu_lib.ramses_amd_amrres_load(5, T["ngridmax"], T["ncoarse"], _vp(u), _vp(T["son"]), _vp(T["nbor"]), _vp(T["father"])))
+        ig = np.ascontiguousarray(T["igrid_fine"])
+        cells = np.zeros(8 * len(ig), np.int32)
+        n = C.c_int(0)
+        check(gpu_lib.ramses_amd_amrres_hydro_flag(C.byref(p), len(ig), _vp(ig), 0.3, -1.0, -1.0, 1e-10, 1e-10, 1e-10, _vp(cells), C.byref(n)))
+        out[mode] = cells[:n.value].copy()
+        v = np.zeros_like(u)
+        v[:] = u
+        check(gpu_lib.ramses_amd_amrres_sync_all(_vp(u)))
+        assert np.array_equal(u, v)
+    assert len(out["0"]) > 100 and np.array_equal(out["0"], out["1"])
+    gpu_lib.ramses_amd_amrres_invalidate()
