@@ -501,22 +501,79 @@ __global__ __launch_bounds__(256) void plan_ghost_kernel(PlanArgs A, int *gfathe
     for (int ind = 0; ind < 8; ind++) A.stat[A.ncoarse + (long)ind * A.ngd + dn - 1] |= (unsigned char)CELL_GHOST;
   }
 }
-// the leaf cell of the coarser level behind each (listed oct, face), 0: the neighbour oct exists
+// the leaf cell of the coarser level behind each (listed oct, face), 0: the neighbour oct exists; indexed by the oct's slot in
+// the level's index range (device index - base), like the flux records
 __global__ __launch_bounds__(256) void plan_target_kernel(PlanArgs A, int *corr_tgt) {
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (long)A.n * 6; t += (long)gridDim.x * blockDim.x) {
     const int i = (int)(t / 6), f = (int)(t % 6);
-    const int nb = A.nbor[(long)f * A.ngd + A.ig[i] - 1];
-    corr_tgt[t] = (nb > 0 && A.son[nb - 1] == 0) ? nb : 0;
+    const int d = A.ig[i];
+    const int nb = A.nbor[(long)f * A.ngd + d - 1];
+    corr_tgt[((long)d - A.base) * 6 + f] = (nb > 0 && A.son[nb - 1] == 0) ? nb : 0;
+  }
+}
+// Conservative update at level ilevel-1 (hydro/godunov_fine.f90:798-908) from the records the dense sweep filed: every (oct,
+// face) whose neighbouring father cell is a leaf owes it 4 fluxes.  A coarse cell has at most 6 such creditors; the thread of
+// the creditor that comes first in the reference's loop order (batch of nvector octs of the LIST, idim, left before right)
+// replays all of them sequentially: floating-point addition is not associative.  (The twin of amr_coarse_update_kernel,
+// csrc/amr_sweep.hip, with the records indexed by device oct instead of list position.)
+__global__ __launch_bounds__(256) void tile_coarse_update_kernel(PlanArgs A, double *__restrict__ unew, const double *__restrict__ corr,
+                                                                 const int *__restrict__ corr_tgt, int nvector, int NV) {
+  const long ev = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ev >= (long)A.n * 6) return;
+  const int io = (int)(ev / 6), f = (int)(ev % 6);
+  const long slot = (long)A.ig[io] - A.base;
+  const int C = corr_tgt[slot * 6 + f];
+  if (C <= A.ncoarse) return;              // (0: nothing owed; a level-1 father cell: the launcher refuses ilevel < 3)
+  AmrSweepArgs T;
+  T.son = A.son; T.nbor = A.nbor; T.ncoarse = A.ncoarse; T.ngridmax = A.ngd;
+  const long mykey = ((long)(io / nvector) * 3 + (f >> 1)) * 2 + (f & 1);
+  long key[6], src[6];
+  int n = 0;
+  bool first = true;
+  for (int e = 0; e < 6; e++) {
+    // the cell on side e of C; if it is refined, its oct borders C with face e^1
+    const int Ne = amrsweep::nbor_cell(C, e, T);
+    if (Ne <= 0) continue;
+    const int g2 = A.son[Ne - 1];
+    if (g2 == 0) continue;
+    const int p2 = A.octpos[g2 - 1];
+    if (p2 < 0) continue;                       // not an oct of the call's list
+    const int f2 = e ^ 1;
+    const long s2 = ((long)g2 - A.base) * 6 + f2;
+    if (corr_tgt[s2] != C) continue;
+    const long k = ((long)(p2 / nvector) * 3 + (f2 >> 1)) * 2 + (f2 & 1);
+    key[n] = k; src[n] = s2; n++;
+    if (k < mykey) first = false;
+  }
+  if (!first) return;
+  for (int i = 1; i < n; i++) {                 // insertion sort of <= 6 creditors
+    const long k = key[i], sv = src[i];
+    int j = i - 1;
+    while (j >= 0 && key[j] > k) { key[j + 1] = key[j]; src[j + 1] = src[j]; j--; }
+    key[j + 1] = k; src[j + 1] = sv;
+  }
+  const double oneontwotondim = 1.0 / 8.0;
+  const int CV = NV + 2;
+  for (int v = 0; v < NV; v++) {
+    double val = unew[(long)v * A.ncell + C - 1];
+    for (int i = 0; i < n; i++) {
+      const double *c = corr + src[i] * 4 * CV;
+      const bool left = ((src[i] % 6) & 1) == 0;
+      for (int q = 0; q < 4; q++) {
+        const double t = c[q * CV + v] * oneontwotondim;
+        val = left ? val - t : val + t;
+      }
+    }
+    unew[(long)v * A.ncell + C - 1] = val;
   }
 }
 // which (tile column of 60 x 8 cells, chunk of 8 planes) hold listed cells
-__global__ __launch_bounds__(256) void plan_work_kernel(PlanArgs A, int wtx, int wty, int wz, unsigned char *flag) {
+__global__ __launch_bounds__(256) void plan_work_kernel(PlanArgs A, int wtx, int rows, int wz, unsigned char *flag) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (long)gridDim.x * blockDim.x) {
     int x, y, z;
     plan_oct_pos(A, A.ig[i], x, y, z);
-    flag[((long)((2 * y) / 8) * wtx + (2 * x) / 60) * wz + (2 * z) / 8] = 1;
+    flag[((long)((2 * y) / rows) * wtx + (2 * x) / 60) * wz + (2 * z) / 8] = 1;
   }
-  (void)wty;
 }
 // the ghost octs' cells: interpol_hydro of the father cell with its six neighbours (getnborfather's coarser fallback), the
 // father cell's acceleration (hydro/godunov_fine.f90:563-626) -- into the free slots of the level's tiles
@@ -1009,8 +1066,10 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   HCHK(P.gfather.ensure(sizeof(int) * (size_t)L.cap), "hipMalloc");
   const int gcap = (int)std::min<long>(L.cap - L.n, (long)ngrid * 26);
   HCHK(P.gslot.ensure(sizeof(int) * (size_t)(gcap > 0 ? gcap : 1)), "hipMalloc"); HCHK(P.gcell.ensure(sizeof(int) * (size_t)(gcap > 0 ? gcap : 1)), "hipMalloc");
-  HCHK(P.corr_tgt.ensure(sizeof(int) * (size_t)ngrid * 6), "hipMalloc");
-  const size_t corr_bytes = sizeof(double) * (size_t)ngrid * 6 * 4 * (size_t)(R.nvar + 2);
+  // flux records and their targets per slot of the level's index range (what a cell's lane can address without a load)
+  HCHK(P.corr_tgt.ensure(sizeof(int) * (size_t)L.cap * 6), "hipMalloc");
+  HCHK(hipMemsetAsync(P.corr_tgt.p, 0, sizeof(int) * (size_t)L.cap * 6, s), "memset");
+  const size_t corr_bytes = sizeof(double) * (size_t)L.cap * 6 * 4 * (size_t)(R.nvar + 2);
   if (P.corr.cap < corr_bytes) { HCHK(P.corr.ensure(corr_bytes), "hipMalloc flux records"); }
   HCHK(hipMemsetAsync(P.corr.p, 0, corr_bytes, s), "memset");
   HCHK(R.okbuf.ensure(sizeof(int) * 2), "hipMalloc");
@@ -1021,11 +1080,12 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   hipLaunchKernelGGL(plan_ghost_kernel, dim3(grid_for((long)ngrid * 26)), dim3(256), 0, s, A, P.gfather.as<int>(), P.gslot.as<int>(), P.gcell.as<int>(), cnt, gcap, cnt + 1);
   hipLaunchKernelGGL(plan_target_kernel, dim3(grid_for((long)ngrid * 6)), dim3(256), 0, s, A, P.corr_tgt.as<int>());
   // work items: columns of 60 x 8 cells, runs of 8-plane chunks up to 128 planes
-  const int n = 2 * L.no, wtx = (n + 59) / 60, wty = n / 8, wz = n / 8;
+  const int rows = strictmode::tile_sweep_rows();       // interior rows of a work item (even: an oct never straddles two)
+  const int n = 2 * L.no, wtx = (n + 59) / 60, wty = n / rows, wz = n / 8;
   const size_t nflag = (size_t)wtx * wty * wz;
   HCHK(P.flag.ensure(nflag), "hipMalloc");
   HCHK(hipMemsetAsync(P.flag.p, 0, nflag, s), "memset");
-  hipLaunchKernelGGL(plan_work_kernel, dim3(grid_for(ngrid)), dim3(256), 0, s, A, wtx, wty, wz, P.flag.as<unsigned char>());
+  hipLaunchKernelGGL(plan_work_kernel, dim3(grid_for(ngrid)), dim3(256), 0, s, A, wtx, rows, wz, P.flag.as<unsigned char>());
   HCHK(hipGetLastError(), "plan launch");
   int hc[2] = {0, 0};
   std::vector<unsigned char> flag(nflag);
@@ -1035,20 +1095,42 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   if (hc[1]) return failf(RAMSES_AMD_EINVAL, "level %d: %d neighbour positions of an oct have no father cell or no tile (tree inconsistent)", ilevel, hc[1]);
   if (hc[0] > gcap) return failf(RAMSES_AMD_EINVAL, "level %d: more ghost octs (%d) than free slots in the level's tiles (%d)", ilevel, hc[0], gcap);
   P.nghost = hc[0];
-  std::vector<int> items;
-  int zmax = 128;
-  if (const char *e = getenv("RAMSES_AMD_TILE_ZRUN")) { const int v = atoi(e); if (v >= 8 && v <= 4096) zmax = v / 8 * 8; }
+  // Work items = runs of flagged 8-plane chunks of a column, cut to at most `zrun` planes.  A workgroup fills a CU (LDS), so a
+  // launch proceeds in rounds of ncu items, each costing its planes + 3 (the pipeline's prologue): take the cut that minimises
+  // rounds x (planes + 3) -- long items for big levels (least redundant work), short ones when a level has few columns
+  // (a 256^3 level is 320 columns of 128 planes: two rounds of 131 planes with the longest cut, five of 35 with 32)
+  int ncu = 256;
+  { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
+  std::vector<int> runs;                       // (tx, ty, first chunk, chunks)
   for (int ty = 0; ty < wty; ty++)
     for (int tx = 0; tx < wtx; tx++) {
       const unsigned char *col = flag.data() + ((size_t)ty * wtx + tx) * wz;
       for (int z = 0; z < wz;) {
         if (!col[z]) { z++; continue; }
         int z1 = z;
-        while (z1 < wz && col[z1] && (z1 - z) * 8 < zmax) z1++;
-        items.push_back(tx * 60); items.push_back(ty * 8); items.push_back(z * 8); items.push_back(z1 * 8);
+        while (z1 < wz && col[z1]) z1++;
+        runs.push_back(tx); runs.push_back(ty); runs.push_back(z); runs.push_back(z1 - z);
         z = z1;
       }
     }
+  int zrun = 0;
+  if (const char *e = getenv("RAMSES_AMD_TILE_ZRUN")) { const int v = atoi(e); if (v >= 8 && v <= 4096) zrun = v / 8 * 8; }
+  if (zrun == 0) {
+    double best = 0.0;
+    for (int cand = 16; cand <= 256; cand *= 2) {
+      long nitems = 0;
+      for (size_t r = 0; r < runs.size(); r += 4) nitems += (runs[r + 3] * 8 + cand - 1) / cand;
+      const double cost = (double)((nitems + ncu - 1) / ncu) * (cand + 3);
+      if (zrun == 0 || cost < best) { best = cost; zrun = cand; }
+    }
+  }
+  std::vector<int> items;
+  for (size_t r = 0; r < runs.size(); r += 4) {
+    const int za = runs[r + 2] * 8, zb = za + runs[r + 3] * 8;
+    for (int z = za; z < zb; z += zrun) {
+      items.push_back(runs[r] * 60); items.push_back(runs[r + 1] * rows); items.push_back(z); items.push_back(std::min(z + zrun, zb));
+    }
+  }
   const int nw = (int)(items.size() / 4);
   // workgroup b runs on XCD b mod 8: give each XCD a contiguous run of the list (neighbouring columns re-read each other's
   // halo from ONE L2)
@@ -1101,7 +1183,7 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
   SweepArgs A;
   A.uold = R.uold.as<double>(); A.unew = R.unew.as<double>(); A.grav = R.grav ? R.f.as<double>() : nullptr;      // the cell vectors themselves
   A.stat = R.stat.as<unsigned char>(); A.dir = L.dir.as<int>(); A.work = P.work.as<int>(); A.nwork = P.nwork;
-  A.corr = P.corr.as<double>(); A.octpos = R.octpos.as<int>();
+  A.corr = P.corr.as<double>(); A.recbase = L.base - 1;
   A.ntx = L.ntx; A.nty = L.nty; A.ntz = L.ntz; A.ngd = R.ngridmax; A.ncoarse = R.ncoarse;
   const int n = 2 * L.no;
   A.nx = A.ny = A.nz = n; A.ng = 0;
@@ -1118,13 +1200,16 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
   if (e == hipErrorInvalidValue) { (void)hipGetLastError(); return 0; }     // a variant the tile kernels do not cover
   HCHK(e, "dense sweep of a level in tiles");
   // what the level owes to the leaf cells of the coarser one, replayed in the reference's order
-  AmrSweepArgs C;
-  C.uold = A.uold; C.unew = A.unew; C.grav = nullptr; C.divu = nullptr; C.enew = nullptr;
-  C.son = R.son.as<int>(); C.nbor = R.nbor.as<int>(); C.father = R.father.as<int>(); C.igrid = R.igrid.as<int>();
-  C.ngrid = ngrid; C.nvar = 5; C.scheme = 0; C.ncell = R.ncell; C.ncoarse = R.ncoarse; C.ngridmax = R.ngridmax;
-  C.dt = dt; C.dx = dx; C.rdx = A.rdx; C.difmag = 0.0; C.pow2 = A.pow2; C.interpol_var = interpol_var; C.interpol_type = interpol_type;
-  C.corr = P.corr.as<double>(); C.corr_tgt = P.corr_tgt.as<int>(); C.err = R.err.as<int>(); C.packed = nullptr; C.rec = 0; C.P = A.P;
-  HCHK(launch_amr_coarse_update(C, R.octpos.as<int>(), nvector, s), "coarse corrections");
+  {
+    PlanArgs Q;
+    Q.son = R.son.as<int>(); Q.nbor = R.nbor.as<int>(); Q.father = R.father.as<int>(); Q.iperm = R.map.iperm.as<int>();
+    Q.stat = R.stat.as<unsigned char>(); Q.octpos = R.octpos.as<int>(); Q.ig = R.igrid.as<int>(); Q.n = ngrid;
+    Q.ncell = R.ncell; Q.ncoarse = R.ncoarse; Q.ngd = R.ngridmax;
+    Q.dir = L.dir.as<int>(); Q.tileid = L.tileid.as<int>(); Q.base = L.base; Q.no = L.no; Q.ntx = L.ntx; Q.nty = L.nty; Q.ntz = L.ntz;
+    const long nev = (long)ngrid * 6;
+    hipLaunchKernelGGL(tile_coarse_update_kernel, dim3((int)((nev + 255) / 256)), dim3(256), 0, s, Q, R.unew.as<double>(), P.corr.as<double>(), P.corr_tgt.as<int>(), nvector, 5);
+    HCHK(hipGetLastError(), "coarse corrections");
+  }
   if (covered) R.covered_sweeps++;
   R.tile_sweeps++;
   done = true;

@@ -38,6 +38,9 @@ namespace ramses_amd {
 namespace SWEEP_NS {
 
 constexpr int BX = 64;   // lanes along x = one wavefront
+#ifndef TILE_SWEEP_BY
+#define TILE_SWEEP_BY 12   // rows of a workgroup of the sweep of a level in tiles (8: two waves per SIMD, 256 VGPRs)
+#endif
 
 // LDS plane of NV doubles per column: [n][ty][tx]; NV = rho, u, v, w, P + passive scalars
 template <int BY, int NV>
@@ -95,9 +98,10 @@ __device__ __forceinline__ void plane_store(double *var_base, unsigned plane_byt
 
 __device__ __forceinline__ int wave_shr1_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int wave_shl1_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
-__device__ __forceinline__ int stat_load(const unsigned char *base, unsigned off) {
-  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(base), 0, BUF_RANGE, 0x00020000);
-  return (int)__builtin_amdgcn_raw_buffer_load_b8(r, off, 0u, 0);
+// status byte of a cell: lane part and wave-uniform part of the cell index; a lane without a tile (index beyond ncell) reads 0
+__device__ __forceinline__ int stat_load(const unsigned char *base, unsigned ncell, unsigned lane_cell, unsigned plane_cell) {
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(base), 0, ncell, 0x00020000);
+  return (int)__builtin_amdgcn_raw_buffer_load_b8(r, lane_cell, plane_cell, 0);
 }
 // the tile directory entry of (tile column of the lane, tile plane): col and plane in ints
 __device__ __forceinline__ int dir_load(const int *base, unsigned plane_ints, unsigned col) {
@@ -107,7 +111,7 @@ __device__ __forceinline__ int dir_load(const int *base, unsigned plane_ints, un
 
 // MASK: the sweep of a level of a resident AMR run IN PLACE on the device's cell vectors (see SweepArgs::stat / dir / work):
 // the level is stored in tiles of 32 x 4 x 4 octs, a lane finds the cell of its (plane, column) through the tile directory
-// (one 4-byte load per plane, issued three planes ahead; 256-byte runs of a variable along x inside a tile), the status byte of
+// (one 4-byte load per 8 planes, issued four planes ahead; 256-byte runs of a variable along x inside a tile), the status byte of
 // the cell says whether it is refined (fluxes reset), updated (stored) or a ghost (interpolated: fluxes filed for the coarser level)
 template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV, int ROLE, bool MASK>
 __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *smem_raw) {
@@ -175,12 +179,24 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   const unsigned colb = (unsigned)(xi + yi * (int)A.pitch_y) * 8u;
   // MASK (the level in tiles, periodic box, ng = 0): the lane's tile column in a plane of the directory, its part of the
   // cell index inside a tile (octant bits of x and y at stride ngd, oct column and oct row) and of the octant position
-  unsigned dcol = 0, lloc = 0;
-  int lind = 0;
+  // Everything about the tiles is wave-uniform except the lane's place inside one: a row of 64 lanes lies in one tile row and
+  // in (at most) two neighbouring tiles along x, so the directory entries are SCALAR loads into scalar registers, the lane
+  // picks one of two with a constant lane mask, and the lane's own part of the cell index is parked in LDS -- the marching
+  // loop is at its register limit, and a vector register spilled to scratch costs a full vmcnt(0) drain per use.
+  int tyu = 0, yis = 0, xa = 0, tA = 0, tB = 0, drow = 0;
+  bool inB = false;
+  unsigned *sloc = reinterpret_cast<unsigned *>(smem_raw + 5 * sizeof(Plane<BY, NV>) + 3 * BY * BX);   // MASK: [BY][BX] lane part of the cell index (bytes)
   if (MASK) {
-    dcol = (unsigned)((xi >> 6) + A.ntx * (yi >> 3));
-    lind = (xi & 1) + 2 * (yi & 1);
-    lloc = (unsigned)((long)lind * A.ngd) + (unsigned)(((xi >> 1) & (TILE_OX - 1)) + TILE_OX * ((yi >> 1) & (TILE_OY - 1)));
+    tyu = __builtin_amdgcn_readfirstlane(ty);
+    const int ys = y0 - 2 + tyu;
+    yis = ys < 0 ? ys + A.ny : (ys >= A.ny ? ys - A.ny : ys);
+    const int xs = x0 - 2;
+    xa = xs < 0 ? xs + A.nx : xs;                      // column of lane 0 (x0 < nx)
+    tA = xa >> 6; tB = tA + 1 < A.ntx ? tA + 1 : 0;
+    inB = (xa & 63) + tx >= 64;
+    drow = A.ntx * (yis >> 3);
+    const int lind = (xi & 1) + 2 * (yis & 1);
+    sloc[ty * BX + tx] = ((unsigned)((long)lind * A.ngd) + (unsigned)(((xi >> 1) & (TILE_OX - 1)) + TILE_OX * ((yis >> 1) & (TILE_OY - 1)))) * 8u;
   }
   const double *__restrict__ uold = A.uold;
   double *__restrict__ unew = A.unew;
@@ -200,40 +216,62 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     else { pz = p + A.ng; }
     return (unsigned)pz * (unsigned)(A.pitch_z * 8);
   };
-  // (o: MASK only -- the lane's byte offset inside a variable's cell vector for that plane; else plane offset + column)
-  auto load_u = [&](int p, unsigned o, double (&u)[NV]) {
-    const unsigned pb = MASK ? 0u : plane_off(p), off = MASK ? o : colb;
+  auto wrap_z = [&](int p) -> int { return p < 0 ? p + A.nz : (p >= A.nz ? p - A.nz : p); };
+  // MASK: a cell's index in a cell vector = tile base (scalar: sdir, by z-tile parity and x-tile A / B) + the lane's part
+  // (LDS) + the plane's part (scalar, rides in the scalar offset of the buffer instructions).  TILE_VOID where the level has
+  // no tile: with the lane's part still beyond every buffer range, so such a lane loads zeros and stores nothing.
+  constexpr unsigned TILE_VOID = 0x80000000u;
+  unsigned sA0 = TILE_VOID, sA1 = TILE_VOID, sB0 = TILE_VOID, sB1 = TILE_VOID;    // (four scalars: an indexed local array would live in scratch)
+  auto tile_of_plane = [&](int p) -> int { return wrap_z(p) >> 3; };
+  auto tile_set = [&](int tz) {
+    // (through the constant address space: the directory is not written during the launch, and only such a load is scalar)
+    typedef const int __attribute__((address_space(4))) *cdir_p;
+    const cdir_p row = (cdir_p)(A.dir + (long)tz * (A.ntx * A.nty) + drow);
+    const int ra = row[tA], rb = row[tB];
+    const unsigned a = ra < 0 ? TILE_VOID : (unsigned)ra * 8u, b = rb < 0 ? TILE_VOID : (unsigned)rb * 8u;
+    if (tz & 1) { sA1 = a; sB1 = b; } else { sA0 = a; sB0 = b; }
+  };
+  auto zpart = [&](int p) -> unsigned {          // cells
+    const int pz = wrap_z(p);
+    return (unsigned)((long)(pz & 1) * 4 * A.ngd) + (unsigned)(TILE_OX * TILE_OY * ((pz >> 1) & (TILE_OZ - 1)));
+  };
+  auto tbp = [&](int p) -> unsigned {
+    const int par = tile_of_plane(p) & 1;
+    const unsigned a = par ? sA1 : sA0, b = par ? sB1 : sB0;
+    return (inB ? b : a) + sloc[ty * BX + tx];
+  };
+  // (MASK: plane p through the tiles; else plane offset + column)
+  auto load_u = [&](int p, double (&u)[NV]) {
+    const unsigned pb = MASK ? zpart(p) * 8u : plane_off(p), off = MASK ? tbp(p) : colb;
 #pragma unroll
     for (int n = 0; n < NV; n++) u[n] = plane_load(uold + (long)n * A.pitch_var, pb, off);
   };
-  auto load_base = [&](unsigned o, double (&u)[NV]) {   // MASK: the state the update starts from (unew, in place)
+  auto load_base = [&](int p, double (&u)[NV]) {   // MASK: the state the update starts from (unew, in place)
+    const unsigned pb = zpart(p) * 8u, off = tbp(p);
 #pragma unroll
-    for (int n = 0; n < NV; n++) u[n] = plane_load(unew + (long)n * A.pitch_var, 0u, o);
-  };
-  auto wrap_z = [&](int p) -> int { return p < 0 ? p + A.nz : (p >= A.nz ? p - A.nz : p); };
-  // MASK: the directory entry of the lane's tile for plane p (raw: turned into a byte offset one iteration later, when the
-  // load has long returned -- the multiply must not wait for it inside the iteration that issues it)
-  auto dir_raw = [&](int p) -> int { return dir_load(A.dir, (unsigned)((wrap_z(p) >> 3) * (A.ntx * A.nty)), dcol); };
-  auto cell_off = [&](int raw, int p) -> unsigned {
-    const int pz = wrap_z(p);
-    const unsigned u = (unsigned)((long)(pz & 1) * 4 * A.ngd) + (unsigned)(TILE_OX * TILE_OY * ((pz >> 1) & (TILE_OZ - 1)));
-    return raw < 0 ? 0u : ((unsigned)raw + lloc + u) * 8u;      // a lane without a tile reads cell 0 (status 0: nothing is stored)
+    for (int n = 0; n < NV; n++) u[n] = plane_load(unew + (long)n * A.pitch_var, pb, off);
   };
   int ok_zlo = 0;   // MASK: plane c-1's status byte of this column
   int s_m1 = 0;     // MASK: the same, kept until plane c-1 is finished in phase B
-  unsigned char *smask = smem_raw + 5 * sizeof(Plane<BY, NV>);   // MASK: [3][BY][BX] status bytes of planes c-1, c, c+1 by plane mod 3
+  int spre = 0;     // MASK: plane c+1's status byte, on its way
+  unsigned char *smask = smem_raw + 5 * sizeof(Plane<BY, NV>);   // MASK: [3][BY][BX] status bytes of planes c-1, c, c+1, by plane mod 3
   const int CV = NV + 2;
-  // a flux owed to the coarser level: record (oct of the cell at byte offset o, face f, fine face q)
-  auto file_flux = [&](unsigned o, int pz, int f, int q, const double (&fl)[NV]) {
-    const long oct0 = (long)(o >> 3) - A.ncoarse - (long)(lind + 4 * (pz & 1)) * A.ngd;
-    const int io = A.octpos[oct0];
-    double *dst = A.corr + (((long)io * 6 + f) * 4 + q) * CV;
+  // MASK: a flux owed to the coarser level (the surfaces of the level) -- record (oct of the lane's own cell in plane p, face f,
+  // fine face q), addressed by the oct's device index alone: no load, five stores that nobody waits for
+  auto file_flux = [&](int p, int f, int q, const double (&fl)[NV]) {
+#ifdef TILE_NOREC      // (kernel tuning only: no flux records)
+    return;
+#endif
+    const int pz = wrap_z(p);
+    const int lind = ((xa + tx) & 1) + 2 * (yis & 1);
+    const long oct0 = (long)((tbp(p) >> 3) + zpart(p)) - A.ncoarse - (long)(lind + 4 * (pz & 1)) * A.ngd;
+    double *dst = A.corr + (((oct0 - A.recbase) * 6 + f) * 4 + q) * CV;
 #pragma unroll
     for (int n = 0; n < NV; n++) dst[n] = fl[n];
   };
-  auto load_g = [&](int p, unsigned o, double (&g)[3]) {
+  auto load_g = [&](int p, double (&g)[3]) {
     if (GRAV) {
-      const unsigned pb = MASK ? 0u : plane_off(p), off = MASK ? o : colb;
+      const unsigned pb = MASK ? zpart(p) * 8u : plane_off(p), off = MASK ? tbp(p) : colb;
 #pragma unroll
       for (int d = 0; d < 3; d++) g[d] = plane_load(grav + (long)d * A.pitch_var, pb, off);
     } else {
@@ -251,24 +289,25 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   int sa = 0, sb = 1, sc = 2;
 
   // prologue: primitives of planes z0-2 -> slot sa, z0-1 -> slot sb; c starts at z0-1
-  // MASK: cell offsets of planes c-1, c, c+1, c+2 (c = z0-1 on entry of the loop)
-  unsigned o_m1 = 0, o_0 = 0, o_p1 = 0, o_p2 = 0;
-  int raw_next = -1;      // directory entry of plane c+2, loaded in iteration c-1
+  // MASK: the z-tile of plane z0-2 and the next one (the planes in flight -- c-1 .. c+2 -- never span more than two)
   if (MASK) {
-    o_m1 = cell_off(dir_raw(z0 - 2), z0 - 2); o_0 = cell_off(dir_raw(z0 - 1), z0 - 1); o_p1 = cell_off(dir_raw(z0), z0);
-    raw_next = dir_raw(min(z0 + 1, z1 + 1));
+    const int t0 = tile_of_plane(z0 - 2), t1 = t0 + 1 < A.ntz ? t0 + 1 : 0;
+    tile_set(t0);
+    tile_set(t1);
+    __syncthreads();      // (sloc is read by its own thread only; the barrier orders the LDS write for the compiler's sake)
+    if (r_trace) spre = stat_load(A.stat, (unsigned)A.pitch_var, tbp(z0 - 1) >> 3, zpart(z0 - 1));
   }
   {
     double u[NV], g[3], q[NV];
-    load_u(z0 - 2, o_m1, u); load_g(z0 - 2, o_m1, g);
+    load_u(z0 - 2, u); load_g(z0 - 2, g);
     ctoprim_cell<NV, GRAV>(u, g, dtxhalf, P, q);
 #pragma unroll
     for (int n = 0; n < NV; n++) qring[sa].v[n][ty][tx] = q[n];
-    load_u(z0 - 1, o_0, u); load_g(z0 - 1, o_0, g);
+    load_u(z0 - 1, u); load_g(z0 - 1, g);
     ctoprim_cell<NV, GRAV>(u, g, dtxhalf, P, q);
 #pragma unroll
     for (int n = 0; n < NV; n++) qring[sb].v[n][ty][tx] = q[n];
-    load_u(z0, o_p1, upre); load_g(z0, o_p1, gpre);
+    load_u(z0, upre); load_g(z0, gpre);
 #pragma unroll
     for (int n = 0; n < NV; n++) { qmz[n] = 1.0; fzlo[n] = 0.0; }
   }
@@ -310,10 +349,10 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #pragma unroll
     for (int n = 0; n < NV; n++) qring[sc].v[n][ty][tx] = qc[n];
     double ucur[NV];
-    if (r_fxz) { if (MASK) load_base(o_0, ucur); else load_u(c, 0u, ucur); }
+    if (r_fxz) { if (MASK) load_base(c, ucur); else load_u(c, ucur); }
     int okc = 0, ok_ym = 0;
     if (MASK && r_trace) {
-      okc = stat_load(A.stat, o_0 >> 3);
+      okc = spre;                  // loaded one plane ahead: nothing at the top of an iteration waits for memory
       smask[((c + 3) % 3 * BY + ty) * BX + tx] = (unsigned char)okc;   // row ty+1 reads it after the barrier (its -y neighbour), row ty-1 one plane later
     }
 
@@ -398,16 +437,17 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
         }
         if (MASK) {
           // :798-908: what an updated cell exchanges with a ghost cell (an oct that does not exist: interpolated) is owed to the
-          // leaf cell of the coarser level there -- filed per (oct, face, fine face), replayed in the reference's order afterwards
-          const int pz = wrap_z(c);
-          if (r_upd && c >= z0 && c < z1 && (okc & CELL_OWNED)) {
-            if (s_xm & CELL_GHOST) file_flux(o_0, pz, 0, (yi & 1) + 2 * (pz & 1), fx);
-            if (s_xp & CELL_GHOST) file_flux(o_0, pz, 1, (yi & 1) + 2 * (pz & 1), fxh);
-            if (ok_zlo & CELL_GHOST) file_flux(o_0, pz, 4, (xi & 1) + 2 * (yi & 1), fz);
+          // leaf cell of the coarser level behind that face -- filed per (oct, face, fine face) by the lane of the updated cell,
+          // replayed in the reference's order afterwards.  Ghost cells sit across oct faces only.
+          if (r_upd && (((s_xm | s_xp) & CELL_GHOST) | ((okc | ok_zlo) & CELL_GHOST))) {
+            if (c >= z0 && c < z1 && (okc & CELL_OWNED)) {
+              const int pz = wrap_z(c);
+              if (s_xm & CELL_GHOST) file_flux(c, 0, (yis & 1) + 2 * (pz & 1), fx);
+              if (s_xp & CELL_GHOST) file_flux(c, 1, (yis & 1) + 2 * (pz & 1), fxh);
+              if (ok_zlo & CELL_GHOST) file_flux(c, 4, ((xa + tx) & 1) + 2 * (yis & 1), fz);
+            }
+            if (c > z0 && c <= z1 && (ok_zlo & CELL_OWNED) && (okc & CELL_GHOST)) file_flux(c - 1, 5, ((xa + tx) & 1) + 2 * (yis & 1), fz);
           }
-          if (r_upd && c - 1 >= z0 && c - 1 < z1 && (ok_zlo & CELL_OWNED) && (okc & CELL_GHOST))
-            file_flux(o_m1, wrap_z(c - 1), 5, (xi & 1) + 2 * (yi & 1), fz);
-          ok_zlo = okc;
         }
         if (NV > 5) {
           rnew = ucur[0];
@@ -420,8 +460,15 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     __builtin_amdgcn_sched_barrier(0);
     {
       const int pn = min(c + 2, z1 + 1);
-      if (MASK) { o_p2 = cell_off(raw_next, pn); raw_next = dir_raw(min(c + 3, z1 + 1)); }   // the directory runs one plane ahead of the data
-      load_u(pn, o_p2, upre); load_g(pn, o_p2, gpre);
+      if (MASK) {
+        // the directory entries of the NEXT z-tile: loaded (scalar) when the prefetch is half way through this one, into the
+        // registers of the tile before it, which no plane in flight uses any more
+        const int lp = wrap_z(pn) & 7;
+        const int tn = tile_of_plane(pn) + 1 < A.ntz ? tile_of_plane(pn) + 1 : 0;
+        if (lp == 4) tile_set(tn);
+      }
+      load_u(pn, upre); load_g(pn, gpre);
+      if (MASK && r_trace) { const int ps = min(c + 1, z1 + 1); spre = stat_load(A.stat, (unsigned)A.pitch_var, tbp(ps) >> 3, zpart(ps)); }
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // the one barrier: +y states of plane c and y fluxes of plane c-1 visible
@@ -440,7 +487,7 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
         for (int n = 0; n < NV; n++) fy[n] = zy ? 0.0 : fy[n];
         if (ROLE == ROLE_FULL && r_upd && c >= z0 && c < z1 && (okc & CELL_OWNED) && (ok_ym & CELL_GHOST)) {
           const int pz = wrap_z(c);
-          file_flux(o_0, pz, 2, (xi & 1) + 2 * (pz & 1), fy);
+          file_flux(c, 2, ((xa + tx) & 1) + 2 * (pz & 1), fy);
         }
       }
       // the flux through this row's -y face is the +y face flux of row ty-1: into ITS slot
@@ -461,11 +508,11 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
       }
       if (MASK) {
         // the +y face of plane c-1: row ty+1 left the flux in this row's slot and its status byte in the plane's smask
-        if (r_upd && c - 1 >= z0 && c - 1 < z1 && (s_m1 & CELL_OWNED)) {
+        if (r_upd && c > z0 && c <= z1 && (s_m1 & CELL_OWNED)) {
           const int s_yp = smask[((c + 2) % 3 * BY + typ) * BX + tx];
           if (s_yp & CELL_GHOST) {
             const int pz = wrap_z(c - 1);
-            file_flux(o_m1, pz, 3, (xi & 1) + 2 * (pz & 1), fyh);
+            file_flux(c - 1, 3, ((xa + tx) & 1) + 2 * (pz & 1), fyh);
           }
         }
       }
@@ -486,15 +533,15 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #pragma unroll
       for (int n = 0; n < NV; n++) { partx[n] = px[n]; fyown[n] = fy[n]; }
       {
-        const unsigned pb = MASK ? 0u : plane_off(c - 1);
-        const unsigned so = (c >= z0 + 1) ? (MASK ? ((r_upd && (s_m1 & CELL_OWNED)) ? o_m1 : BUF_OOB) : colb_upd) : BUF_OOB;
+        const unsigned pb = MASK ? zpart(c - 1) * 8u : plane_off(c - 1);
+        const unsigned so = (c >= z0 + 1) ? (MASK ? ((r_upd && (s_m1 & CELL_OWNED)) ? tbp(c - 1) : BUF_OOB) : colb_upd) : BUF_OOB;
 #pragma unroll
         for (int n = 0; n < NV; n++) plane_store(unew + (long)n * A.pitch_var, pb, so, un[n]);
       }
     }
     // rotate the ring
     const int t = sa; sa = sb; sb = sc; sc = t;
-    if (MASK) { o_m1 = o_0; o_0 = o_p1; o_p1 = o_p2; s_m1 = okc; }
+    if (MASK) { ok_zlo = okc; s_m1 = okc; }
   }
 }
 
@@ -517,7 +564,7 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
 // ---------------------------------------------------------------------------
 template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV, bool MASK = false>
 static hipError_t launch3(const SweepArgs &A, hipStream_t s) {
-  const size_t lds = 5 * sizeof(Plane<BY, NV>) + (MASK ? 3 * BY * BX : 0);
+  const size_t lds = 5 * sizeof(Plane<BY, NV>) + (MASK ? 3 * BY * BX + 4 * BY * BX : 0);
   dim3 block(BX, BY);
   dim3 grid(A.nblocks);
   auto k = godunov_sweep_kernel<ST, RS, BY, GRAV, SCHEME, NV, MASK>;
@@ -583,10 +630,10 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
     // work item (anything else: the caller keeps the tree-walking sweep)
 #ifndef RAMSES_AMD_FAST
     if constexpr (ST != 3 && ST != 4 && ST != 5 && ST != 6 && RS != RIEMANN_EXACT) {
-      if (!A.dir || !A.work || !A.corr || !A.octpos || A.ng != 0 || nvar != 5 || scheme != 0 || by != 12 || A.nwork <= 0) return hipErrorInvalidValue;
+      if (!A.dir || !A.work || !A.corr || A.ng != 0 || nvar != 5 || scheme != 0 || A.nwork <= 0) return hipErrorInvalidValue;
       A.nblocks = A.nwork;
       A.nbox = 1;          // (the box decode runs, its result is replaced by the work item)
-      return grav ? launch3<ST, RS, 12, true, 0, 5, true>(A, s) : launch3<ST, RS, 12, false, 0, 5, true>(A, s);
+      return grav ? launch3<ST, RS, TILE_SWEEP_BY, true, 0, 5, true>(A, s) : launch3<ST, RS, TILE_SWEEP_BY, false, 0, 5, true>(A, s);
     } else {
       return hipErrorInvalidValue;
     }
@@ -624,6 +671,9 @@ static hipError_t launch0(SweepArgs &A, int rs, int by, int scheme, int nvar, bo
   }
   return hipErrorInvalidValue;
 }
+
+// interior rows of a work item of the sweep of a level in tiles (the plan of csrc/capi_amr.hip cuts the level accordingly)
+int tile_sweep_rows() { return TILE_SWEEP_BY - 4; }
 
 hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme, int nvar,
                                 bool grav, hipStream_t s) {

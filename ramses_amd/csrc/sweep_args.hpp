@@ -33,18 +33,17 @@ struct SweepArgs {
   //           (= ncoarse + first oct - 1), or -1 where no oct of the level and no ghost oct falls into the tile;
   //   work    the launch's work items, one per workgroup: (x0, y0, z0, z1) = first interior column / row of the 60 x (BY-4)
   //           tile and the planes [z0, z1) it marches;
-  //   corr    [ngrid][6][4][nvar+2] flux records of the (oct, face) pairs that border a leaf cell of the coarser level -- the
-  //           layout amr_coarse_update_kernel replays (csrc/amr_sweep.hip) -- and octpos[device oct - 1] = position of the oct
-  //           in the call's list.
+  //   corr    [cap][6][4][nvar+2] flux records of the (oct, face) pairs that border a leaf cell of the coarser level, indexed
+  //           by the oct's device index minus recbase (the level's first index: addressable from the cell index alone);
+  //           replayed in the reference's order by tile_coarse_update_kernel (csrc/capi_amr.hip).
   // uold / grav / unew are then the cell vectors themselves (pitch_var = ncell of the device; pitch_y, pitch_z unused), the
   // update starts from unew -- which already holds what the finer level owes to this one (:752-790) -- and lands there.
   const unsigned char *stat = nullptr;
   const int *dir = nullptr;
   const int *work = nullptr;          // int4 per workgroup
   double *corr = nullptr;
-  const int *octpos = nullptr;
   int ntx = 0, nty = 0, ntz = 0, nwork = 0;
-  long ngd = 0, ncoarse = 0;
+  long ngd = 0, ncoarse = 0, recbase = 0;
   int nx, ny, nz;       // interior cells
   int ng;               // ghost width (0 = periodic wrap in-kernel)
   long pitch_y, pitch_z, pitch_var;
@@ -60,10 +59,12 @@ struct SweepArgs {
 namespace strictmode {
 hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme, int nvar,
                                 bool grav, hipStream_t s);
+int tile_sweep_rows();
 }
 namespace fastmode {
 hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme, int nvar,
                                 bool grav, hipStream_t s);
+int tile_sweep_rows();
 }
 
 }  // namespace ramses_amd

@@ -197,15 +197,14 @@ def test_a_regrid_keeps_the_levels_that_did_not_change(gpu_lib, oracle, monkeypa
     h2 = _oracle_step(oracle, po, T2, L, h1r, None, l2)
     # device: step 1, level L back to the host (refine_fine reads it), new tree, ONLY level L+1 reloaded, step 2
     u = _device_step(gpu_lib, p, T1, L, u0.copy(), None, l1)
-    ur = refill(u)
-    ur_for_device = ur.copy()
+    u[:] = refill(u)                     # (the same host array all along: the one the state was loaded from)
     c_l = np.concatenate([T2["ncoarse"] + ind * T2["ngridmax"] + T2["igrid"] - 1 for ind in range(8)])
-    ur_for_device[:, c_l] = -7.0         # if the device read level L from the host again, the result would show it
+    u[:, c_l] = -7.0                     # if the device read level L from the host again, the result would show it
     check(gpu_lib.ramses_amd_amrres_tree(_vp(T2["son"]), _vp(T2["nbor"]), _vp(T2["father"])))
     igf = np.ascontiguousarray(np.sort(T2["igrid_fine"]))
-    check(gpu_lib.ramses_amd_amrres_load_level(len(igf), _vp(igf), _vp(ur_for_device)))
+    check(gpu_lib.ramses_amd_amrres_load_level(len(igf), _vp(igf), _vp(u)))
     t0 = gpu_lib.ramses_amd_amrres_tile_sweeps()
-    got = _device_step(gpu_lib, p, T2, L, ur_for_device, None, l2, load=False)
+    got = _device_step(gpu_lib, p, T2, L, u, None, l2, load=False)
     assert gpu_lib.ramses_amd_amrres_tile_sweeps() - t0 == 2
     cells = np.concatenate([T2["ncoarse"] + ind * T2["ngridmax"] + np.concatenate([T2["igrid"], T2["igrid_fine"]]) - 1 for ind in range(8)])
     assert np.array_equal(got[:, cells], h2[:, cells]), np.abs(got[:, cells] - h2[:, cells]).max()
