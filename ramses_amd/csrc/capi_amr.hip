@@ -850,7 +850,7 @@ int ramses_amd_amrres_load(int nvar, int64_t ngridmax, int64_t ncoarse, const do
   if (const char *e = getenv("RAMSES_AMD_DEVICE_OCTS")) { fac = atof(e); if (!(fac >= 1.0 && fac <= 16.0)) fac = 1.0; }
   long ngd = (long)((double)ngridmax * fac);
   if ((unsigned long)(ncoarse + 8 * ngd) >= (1ul << 31)) ngd = ngridmax;      // cell indices are 32-bit ints
-  R.map.reset(ngridmax, ngd, ncoarse, true);
+  R.map.reset(ngridmax, ngd, ncoarse, son[0] > 0);      // (no oct in the coarse cell: nothing to lay out -- the host's numbering)
   R.ngridmax = R.map.ngd; R.ncell = ncoarse + 8 * R.ngridmax;
   R.plan.clear();
   for (CommLevel &L : R.comm) L.epoch = -1;
