@@ -172,7 +172,7 @@ __global__ void xlate_tree_kernel(const int *__restrict__ hoct, const int *__res
     const int sd = s > 0 ? perm[s - 1] : s;
     const long c = ncoarse + (long)k * ngd + d - 1;
     son_d[c] = sd;
-    stat[c] = sd > 0 ? CELL_REFINED : 0;
+    stat[c] = (unsigned char)((stat[c] & ~CELL_REFINED) | (sd > 0 ? CELL_REFINED : 0));     // (the other bits belong to the level's sweep plan)
   } else if (k < 14) {
     nbor_d[(long)(k - 8) * ngd + d - 1] = cell_h2d(nbor_h[(long)(k - 8) * ngh + g - 1], perm, ncoarse, ngh, ngd);
   } else {
@@ -235,6 +235,7 @@ __global__ void move_oct_kernel(const int *__restrict__ hoct, const int *__restr
 // ---- host side ----------------------------------------------------------------------------------------------------------
 struct LevelMap {
   int level = 0, n = 0;
+  int version = 0;             // changes when the level is laid out again (what was derived from its device indices is stale)
   int layout = 0;              // 0: compact (Z-order), 1: tiles
   long base = 0, cap = 0;      // device indices [base, base + cap), 1-based
   int no = 0, ntx = 0, nty = 0, ntz = 0, ntiles = 0;
@@ -254,6 +255,8 @@ struct DevMap {
   Buf need, rank, cubtmp, cnt, mkey, mkey2, idx, idx2;
   Buf c_hoct[2], c_key[2];     // BFS double buffer
   int first_changed = 0;       // of the last build: the coarsest level that was laid out again (nlev + 1: none)
+  long kept_end = 1;           // of the last build: first device index after the levels that kept their layout
+  int version_counter = 0;
   long tiles_levels = 0;       // how many levels are stored in tiles (diagnostics)
   const char *why_not = "";
 
@@ -310,80 +313,70 @@ struct DevMap {
     if (fresh) {
       LCHK(hipMemsetAsync(perm.p, 0, sizeof(int) * (size_t)ngh, s));
       LCHK(hipMemsetAsync(okey.p, 0, sizeof(u64) * (size_t)ngh, s));
-      for (size_t l = 1; l < lev.size(); l++) drop(lev[l]);
-      nlev = 0; lev.clear(); lev.resize(1);
+      for (size_t l = 1; l < lev.size(); l++) lev[l].n = 0;
+      nlev = 0;
     }
-    // ---- 1. the octs of every level, top down (new lists; the old ones stay until a level is known to have changed) ------
-    std::vector<LevelMap> nl(1);
-    {
-      LevelMap L1;
-      L1.level = 1; L1.n = 1; L1.no = 1;
-      const int g1 = son[0];
-      if (g1 <= 0) { why_not = "the coarse cell has no oct"; return hipErrorInvalidValue; }
-      const u64 k0 = 0;
-      LCHK(L1.hoct.ensure(sizeof(int))); LCHK(L1.key.ensure(sizeof(u64))); LCHK(L1.doct.ensure(sizeof(int)));
-      LCHK(hipMemcpyAsync(L1.hoct.p, &g1, sizeof(int), hipMemcpyHostToDevice, s));
-      LCHK(hipMemcpyAsync(L1.key.p, &k0, sizeof(u64), hipMemcpyHostToDevice, s));
-      LCHK(hipStreamSynchronize(s));
-      nl.push_back(L1);
-    }
-    for (int l = 1; l < MAX_LEVEL; l++) {
-      LevelMap &P = nl[l];
-      const long capl = std::min<long>((long)P.n * 8, ngh);
+    // ---- 1. the octs of every level, top down, into scratch lists; a level whose set of (host oct, position) pairs is the one
+    //         it held before keeps its record (list order, device indices, directory); from the first level that differs on,
+    //         every level is taken over from the scratch lists and laid out again (the host re-sends those levels: a level can
+    //         only change when refine_fine rebuilt it, and it rebuilds a suffix of the levels).  No allocation unless a list grows.
+    if (lev.size() < (size_t)MAX_LEVEL + 2) lev.resize((size_t)MAX_LEVEL + 2);
+    const int g1 = son[0];
+    if (g1 <= 0) { why_not = "the coarse cell has no oct"; return hipErrorInvalidValue; }
+    bool keeping = !fresh;
+    int k0 = 0, nnew = 0;
+    for (int l = 1; l <= MAX_LEVEL + 1; l++) {
       Buf &bo = c_hoct[l & 1], &bk = c_key[l & 1];
-      LCHK(bo.ensure(sizeof(int) * (size_t)capl)); LCHK(bk.ensure(sizeof(u64) * (size_t)capl));
-      LCHK(hipMemsetAsync(cnt.p, 0, sizeof(int), s));
-      hipLaunchKernelGGL(bfs_kernel, dim3(grid1((long)P.n * 8, 1024)), dim3(1024), 0, s, son_h.as<int>(), ncoarse, ngh, P.hoct.as<int>(), P.key.as<u64>(), P.n,
-                         bo.as<int>(), bk.as<u64>(), cnt.as<int>(), (int)capl);
       int nc = 0;
-      LCHK(hipMemcpyAsync(&nc, cnt.p, sizeof(int), hipMemcpyDeviceToHost, s));
-      LCHK(hipStreamSynchronize(s));
-      if (nc == 0) break;
-      if (nc > capl) { why_not = "more octs in the tree than ngridmax"; return hipErrorInvalidValue; }
-      LevelMap C;
-      C.level = l + 1; C.n = nc; C.no = 1 << l;
-      LCHK(C.hoct.ensure(sizeof(int) * (size_t)nc)); LCHK(C.key.ensure(sizeof(u64) * (size_t)nc)); LCHK(C.doct.ensure(sizeof(int) * (size_t)nc));
-      LCHK(hipMemcpyAsync(C.hoct.p, bo.p, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, s));
-      LCHK(hipMemcpyAsync(C.key.p, bk.p, sizeof(u64) * (size_t)nc, hipMemcpyDeviceToDevice, s));
-      nl.push_back(C);
-    }
-    if ((int)nl.size() - 1 == MAX_LEVEL) {
-      // is there a level MAX_LEVEL + 1?  (it would not be laid out: refuse)
-      LevelMap &P = nl[MAX_LEVEL];
-      LCHK(hipMemsetAsync(cnt.p, 0, sizeof(int), s));
-      hipLaunchKernelGGL(bfs_kernel, dim3(grid1((long)P.n * 8, 1024)), dim3(1024), 0, s, son_h.as<int>(), ncoarse, ngh, P.hoct.as<int>(), P.key.as<u64>(), P.n,
-                         c_hoct[0].as<int>(), c_key[0].as<u64>(), cnt.as<int>(), 0);
-      int nc = 0;
-      LCHK(hipMemcpyAsync(&nc, cnt.p, sizeof(int), hipMemcpyDeviceToHost, s));
-      LCHK(hipStreamSynchronize(s));
-      if (nc > 0) { why_not = "more than 20 levels"; return hipErrorInvalidValue; }
-    }
-    const int nnew = (int)nl.size() - 1;
-    // ---- 2. the coarsest level whose set of octs changed: everything from there on is laid out again (the host re-sends
-    //         those levels: a level can only change when refine_fine rebuilt it) --------------------------------------------
-    int k0 = 1;
-    if (!fresh) {
-      for (k0 = 1; k0 <= nnew && k0 <= nlev; k0++) {
-        if (nl[k0].n != lev[k0].n) break;
-        LCHK(hipMemsetAsync(cnt.p, 0, sizeof(int), s));
-        hipLaunchKernelGGL(same_level_kernel, dim3(grid1(nl[k0].n)), dim3(256), 0, s, nl[k0].hoct.as<int>(), nl[k0].key.as<u64>(), nl[k0].n, k0, perm.as<int>(),
-                           okey.as<u64>(), cnt.as<int>());
-        int mis = 0;
-        LCHK(hipMemcpyAsync(&mis, cnt.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      if (l == 1) {
+        const u64 kz = 0;
+        LCHK(bo.ensure(sizeof(int))); LCHK(bk.ensure(sizeof(u64)));
+        LCHK(hipMemcpyAsync(bo.p, &g1, sizeof(int), hipMemcpyHostToDevice, s));
+        LCHK(hipMemcpyAsync(bk.p, &kz, sizeof(u64), hipMemcpyHostToDevice, s));
         LCHK(hipStreamSynchronize(s));
-        if (mis) break;
+        nc = 1;
+      } else {
+        LevelMap &P = lev[l - 1];
+        const long capl = std::min<long>((long)P.n * 8, ngh);
+        LCHK(bo.ensure(sizeof(int) * (size_t)capl)); LCHK(bk.ensure(sizeof(u64) * (size_t)capl));
+        LCHK(hipMemsetAsync(cnt.p, 0, sizeof(int), s));
+        hipLaunchKernelGGL(bfs_kernel, dim3(grid1((long)P.n * 8, 1024)), dim3(1024), 0, s, son_h.as<int>(), ncoarse, ngh, P.hoct.as<int>(), P.key.as<u64>(), P.n,
+                           bo.as<int>(), bk.as<u64>(), cnt.as<int>(), (int)capl);
+        LCHK(hipMemcpyAsync(&nc, cnt.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        LCHK(hipStreamSynchronize(s));
+        if (nc > capl) { why_not = "more octs in the tree than ngridmax"; return hipErrorInvalidValue; }
       }
+      if (nc == 0) break;
+      if (l > MAX_LEVEL) { why_not = "more than 20 levels"; return hipErrorInvalidValue; }
+      nnew = l;
+      LevelMap &L = lev[l];
+      if (keeping) {
+        bool same = l <= nlev && nc == L.n;
+        if (same) {
+          LCHK(hipMemsetAsync(cnt.p, 0, sizeof(int), s));
+          hipLaunchKernelGGL(same_level_kernel, dim3(grid1(nc)), dim3(256), 0, s, bo.as<int>(), bk.as<u64>(), nc, l, perm.as<int>(), okey.as<u64>(), cnt.as<int>());
+          int mis = 0;
+          LCHK(hipMemcpyAsync(&mis, cnt.p, sizeof(int), hipMemcpyDeviceToHost, s));
+          LCHK(hipStreamSynchronize(s));
+          same = mis == 0;
+        }
+        if (same) continue;            // the level keeps its record; its old list (the same set) feeds the next level
+        keeping = false;
+      }
+      if (k0 == 0) k0 = l;
+      L.level = l; L.n = nc; L.no = 1 << (l - 1);
+      LCHK(L.hoct.ensure(sizeof(int) * (size_t)nc)); LCHK(L.key.ensure(sizeof(u64) * (size_t)nc)); LCHK(L.doct.ensure(sizeof(int) * (size_t)nc));
+      LCHK(hipMemcpyAsync(L.hoct.p, bo.p, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, s));
+      LCHK(hipMemcpyAsync(L.key.p, bk.p, sizeof(u64) * (size_t)nc, hipMemcpyDeviceToDevice, s));
     }
+    if (k0 == 0) k0 = nnew + 1;        // nothing changed (or only levels at the fine end disappeared)
+    for (int l = nnew + 1; l <= nlev; l++) lev[l].n = 0;
     first_changed = k0;
-    // the kept levels keep their old records (lists in the old order, device indices, directories); free the new copies
-    for (int l = 1; l < k0; l++) drop(nl[l]);
-    for (int l = k0; l <= nlev; l++) drop(lev[l]);
-    lev.resize((size_t)nnew + 1);
-    for (int l = k0; l <= nnew; l++) lev[l] = nl[l];
     nlev = nnew;
     // ---- 3. lay out the levels from k0 on: tiles where they fit, Z-order otherwise -----------------------------------------
     long next = 1;
     for (int l = 1; l < k0; l++) next = std::max(next, lev[l].base + lev[l].cap);
+    kept_end = next;
     std::vector<long> after((size_t)nlev + 2, 0);            // octs of the finer levels (they need at least that much)
     for (int l = nlev; l >= 1; l--) after[l] = after[l + 1] + lev[l].n;
     const char *et = getenv("RAMSES_AMD_TILES");
@@ -391,6 +384,7 @@ struct DevMap {
     for (int l = k0; l <= nlev; l++) {
       LevelMap &L = lev[l];
       L.layout = 0; L.base = next; L.cap = L.n; L.ntiles = 0;
+      L.version = ++version_counter;
       if (tiles_on && l >= TILE_MIN_LEVEL && l <= TILE_MAX_LEVEL) {
         L.ntx = L.no / TILE_OX; L.nty = L.no / TILE_OY; L.ntz = L.no / TILE_OZ;
         const int nt = L.ntx * L.nty * L.ntz;
@@ -431,7 +425,12 @@ struct DevMap {
     LCHK(hipMemsetAsync(son_d, 0, sizeof(int) * ncell_d, s));
     LCHK(hipMemsetAsync(nbor_d, 0, sizeof(int) * 6 * (size_t)ngd, s));
     LCHK(hipMemsetAsync(father_d, 0, sizeof(int) * (size_t)ngd, s));
-    LCHK(hipMemsetAsync(stat, 0, ncell_d, s));
+    // the status bytes of the index range that was laid out again start from zero; the kept levels keep what their sweep plans
+    // wrote (only the "refined" bit follows the tree, below)
+    if (fresh) LCHK(hipMemsetAsync(stat, 0, ncell_d, s));
+    else
+      for (int ind = 0; ind < 8; ind++)
+        LCHK(hipMemsetAsync(stat + ncoarse + (size_t)ind * ngd + (kept_end - 1), 0, (size_t)(ngd - kept_end + 1), s));
     hipLaunchKernelGGL(xlate_coarse_kernel, dim3(grid1(ncoarse)), dim3(256), 0, s, son_h.as<int>(), perm.as<int>(), ncoarse, son_d);
     tiles_levels = 0;
     for (int l = 1; l <= nlev; l++) {

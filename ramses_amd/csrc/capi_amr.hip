@@ -718,7 +718,7 @@ struct CommLevel {
 
 // what the dense sweep of a level in tiles needs beyond the cell vectors (see plan_* above), valid for one layout and one list
 struct LevelPlan {
-  int serial = -1, ngrid = -1, ig_first = 0, ig_last = 0;
+  int version = -1, ngrid = -1, ig_first = 0, ig_last = 0;      // the layout version of the level and the list the plan was made for
   int nghost = 0, nwork = 0;
   Buf gfather, gslot, gcell, work, corr, corr_tgt, flag;
 };
@@ -814,6 +814,16 @@ static HydroConst make_const_amr(const ramses_amd_hydro_params *p) {
 
 extern "C" {
 
+// RAMSES_AMD_STATS=1: one line at exit with how godunov_fine of the AMR levels ran (tests and timing scripts read it)
+static void amrres_report(void) {
+  const char *e = getenv("RAMSES_AMD_STATS");
+  if (!e || e[0] == '0') return;
+  if (g_ar.tile_sweeps + g_ar.tree_sweeps == 0) return;
+  fprintf(stdout, " ramses_amd: godunov_fine of AMR levels: %ld sweeps through the dense kernel on tiles (%ld of them fully refined levels), %ld through the tree-walking kernel; %ld levels in tiles at the end\n",
+          g_ar.tile_sweeps, g_ar.covered_sweeps, g_ar.tree_sweeps, g_ar.map.on ? g_ar.map.tiles_levels : 0L);
+  fflush(stdout);
+}
+
 int ramses_amd_amrres_active(void) { return g_ar.valid ? 1 : 0; }
 
 // the tree arrays again (after refine_fine): son(1:ncell), nbor(1:ngridmax,1:6), father(1:ngridmax) of the host.  The levels
@@ -825,7 +835,9 @@ int ramses_amd_amrres_tree(const int *son, const int *nbor, const int *father) {
   hipError_t e = R.map.build(son, nbor, father, R.son.as<int>(), R.nbor.as<int>(), R.father.as<int>(), R.stat.as<unsigned char>(), nullptr);
   if (e != hipSuccess) return failf(e == hipErrorInvalidValue ? RAMSES_AMD_EINVAL : RAMSES_AMD_EHIP, "tree layout on the device: %s", e == hipErrorInvalidValue ? R.map.why_not : hipGetErrorString(e));
   if (R.map.on) {
-    HCHK(hipMemsetAsync(R.octpos.p, 0xff, sizeof(int) * (size_t)R.ngridmax, nullptr), "memset");
+    // (list positions of the levels that were laid out again; the kept levels keep their plans)
+    const long k = R.map.kept_end;
+    HCHK(hipMemsetAsync(R.octpos.as<int>() + (k - 1), 0xff, sizeof(int) * (size_t)(R.ngridmax - k + 1), nullptr), "memset");
     R.xg_valid = false;                    // the oct centres are indexed by device oct: rho_fine's shim sends them with every tree epoch
     if (!R.announced) {
       R.announced = true;
@@ -842,6 +854,7 @@ int ramses_amd_amrres_load(int nvar, int64_t ngridmax, int64_t ncoarse, const do
   if (!uold || !son || !nbor || !father) return failf(RAMSES_AMD_EINVAL, "NULL argument");
   if (nvar < 5 || nvar > 7 || ngridmax < 1 || ncoarse < 1) return failf(RAMSES_AMD_EUNSUPPORTED, "AMR residency implements NVAR=5..7");
   AmrRes &R = g_ar;
+  { static bool registered = false; if (!registered) { registered = true; atexit(amrres_report); } }
   R.valid = false; R.grav = false; R.pfix = false;
   R.xg_valid = false;          // the oct centres belong to the tree that is loaded below: rho_fine's shim sends them again
   R.nvar = nvar; R.ngh = ngridmax; R.ncoarse = ncoarse; R.ncell_h = ncoarse + 8 * ngridmax;
@@ -1057,7 +1070,7 @@ bool env_on(const char *name) {      // (read on every sweep: the A/B tests flip
 int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &P) {
   amrlayout::LevelMap &L = R.map.lev[ilevel];
   hipStream_t s = nullptr;
-  P.serial = -1;
+  P.version = -1;
   PlanArgs A;
   A.son = R.son.as<int>(); A.nbor = R.nbor.as<int>(); A.father = R.father.as<int>(); A.iperm = R.map.iperm.as<int>();
   A.stat = R.stat.as<unsigned char>(); A.octpos = R.octpos.as<int>(); A.ig = R.igrid.as<int>(); A.n = ngrid;
@@ -1077,7 +1090,9 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   HCHK(hipMemsetAsync(cnt, 0, sizeof(int) * 2, s), "memset");
   hipLaunchKernelGGL(plan_clear_kernel, dim3(grid_for(L.cap * 8)), dim3(256), 0, s, A.stat, A.octpos, R.ncoarse, R.ngridmax, L.base, L.cap, P.gfather.as<int>());
   hipLaunchKernelGGL(plan_owned_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, s, A);
-  hipLaunchKernelGGL(plan_ghost_kernel, dim3(grid_for((long)ngrid * 26)), dim3(256), 0, s, A, P.gfather.as<int>(), P.gslot.as<int>(), P.gcell.as<int>(), cnt, gcap, cnt + 1);
+  // (a level that holds every oct of the periodic box has no neighbour position without an oct)
+  if ((long)L.n < (long)L.no * L.no * L.no)
+    hipLaunchKernelGGL(plan_ghost_kernel, dim3(grid_for((long)ngrid * 26)), dim3(256), 0, s, A, P.gfather.as<int>(), P.gslot.as<int>(), P.gcell.as<int>(), cnt, gcap, cnt + 1);
   hipLaunchKernelGGL(plan_target_kernel, dim3(grid_for((long)ngrid * 6)), dim3(256), 0, s, A, P.corr_tgt.as<int>());
   // work items: columns of 60 x 8 cells, runs of 8-plane chunks up to 128 planes
   const int rows = strictmode::tile_sweep_rows();       // interior rows of a work item (even: an oct never straddles two)
@@ -1099,8 +1114,12 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   // launch proceeds in rounds of ncu items, each costing its planes + 3 (the pipeline's prologue): take the cut that minimises
   // rounds x (planes + 3) -- long items for big levels (least redundant work), short ones when a level has few columns
   // (a 256^3 level is 320 columns of 128 planes: two rounds of 131 planes with the longest cut, five of 35 with 32)
-  int ncu = 256;
-  { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
+  static int ncu = 0;
+  if (ncu == 0) {
+    ncu = 256;
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+  }
   std::vector<int> runs;                       // (tx, ty, first chunk, chunks)
   for (int ty = 0; ty < wty; ty++)
     for (int tx = 0; tx < wtx; tx++) {
@@ -1148,7 +1167,7 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   if (nw > 0) HCHK(hipMemcpy(P.work.p, order.data(), sizeof(int) * 4 * (size_t)nw, hipMemcpyHostToDevice), "H2D work list");
   P.nwork = nw;
   P.ngrid = ngrid; P.ig_first = ngrid > 0 ? h_igrid[0] : 0; P.ig_last = ngrid > 0 ? h_igrid[ngrid - 1] : 0;
-  P.serial = R.map.serial;
+  P.version = L.version;
   return 0;
 }
 
@@ -1160,6 +1179,13 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
   amrlayout::LevelMap &L = R.map.lev[ilevel];
   const bool covered = (long)L.n == (long)L.no * L.no * L.no && ngrid == L.n;
   if (!env_on(covered ? "RAMSES_AMD_COVERED_DENSE" : "RAMSES_AMD_TILE_DENSE") || !env_on("RAMSES_AMD_TILE_SWEEP")) return 0;
+  {
+    // a small level is quicker through the tree: the dense sweep is a pipeline of >= 19 plane iterations per workgroup whatever
+    // the level holds (measured crossover on MI355X around 1e5 octs; RAMSES_AMD_TILE_MIN_OCTS overrides, 0: always dense)
+    long min_octs = 65536;
+    if (const char *e = getenv("RAMSES_AMD_TILE_MIN_OCTS")) { const long v = atol(e); if (v >= 0) min_octs = v; }
+    if (ngrid < min_octs) return 0;
+  }
   if (R.nvar != 5 || p->nvar != 5 || p->ndim != 3 || p->scheme != RAMSES_AMD_SCHEME_MUSCL || p->difmag > 0.0 || R.pfix) return 0;
   const int st = p->slope_type;
   if (!(st == 0 || st == 1 || st == 2 || st == 7 || st == 8) || p->riemann == RAMSES_AMD_RIEMANN_EXACT) return 0;
@@ -1172,7 +1198,10 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
   hipStream_t s = nullptr;
   if ((size_t)ilevel >= R.plan.size()) R.plan.resize((size_t)ilevel + 1);
   LevelPlan &P = R.plan[ilevel];
-  if (P.serial != R.map.serial || P.ngrid != ngrid || P.ig_first != h_igrid[0] || P.ig_last != h_igrid[ngrid - 1])
+  // (the plan of a level that kept its layout survives a regrid of the finer levels: its octs, ghosts and work items are the same.
+  //  The list of a level must not change between two regrids without its first or last entry or its length changing: it is
+  //  active(ilevel)%igrid, which only build_comm / refine_fine / load_balance rewrite.)
+  if (P.version != L.version || P.ngrid != ngrid || P.ig_first != h_igrid[0] || P.ig_last != h_igrid[ngrid - 1])
     if (int rc = build_plan(R, ilevel, ngrid, h_igrid, P)) return rc;
   if (P.nwork == 0) { done = true; return 0; }
   if (P.nghost > 0) {

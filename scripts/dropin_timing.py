@@ -263,16 +263,27 @@ bound_type= 1, 1, 2, 2, 1, 1
             for l, g in re.findall(r"Level\s+(\d+) has\s+(\d+) grids", out):
                 last[int(l)] = int(g)
             rec = {"config": tag, "levels": [lmin, lmax], "steps": nstep, "wall_s": round(wall, 3),
-                   "octs_per_level": {k: v for k, v in last.items() if k >= lmin}, "timers_s": rows}
+                   "octs_per_level": {k: v for k, v in last.items() if k >= lmin}, "timers_s": rows,
+                   "notes": [ln.strip() for ln in out.splitlines() if "ramses_amd: godunov_fine of AMR levels" in ln][:2]}
             if env.get("RAMSES_AMD_PROFILE"):
                 # the shims' own wall-clock table (ramses_amd_tic / ramses_amd_toc): what of the reference's "flag" timer is the shim
-                rec["shim_profile"] = [ln.strip() for ln in out.splitlines() if "hydro_flag" in ln or "ramses_amd profile" in ln][:12]
+                rec["shim_profile"] = [ln.strip() for ln in out.splitlines() if "hydro_flag" in ln or "godunov" in ln or "ramses_amd profile" in ln][:16]
             print(json.dumps(rec), flush=True)
 
         ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d")
         pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch")
         if which == "prof":
             run_c5("patched, state and tree resident on the GPU, RAMSES_AMD_PROFILE=1", pat, {"RAMSES_AMD": "1", "RAMSES_AMD_PROFILE": "1"})
+        if which == "tiles":
+            # round 5: the device's own oct numbering -- levels in tiles + the dense sweep in place; the same layout with the
+            # tree-walking sweep; the host's numbering with the tree-walking sweep (what round 4 ran on the partial levels)
+            base = {"RAMSES_AMD": "1", "RAMSES_AMD_STATS": "1", "RAMSES_AMD_PROFILE": "1"}
+            run_c5("resident, levels in tiles, dense sweep in place (default: levels below 65536 octs walk the tree)", pat, dict(base))
+            run_c5("resident, levels in tiles, dense sweep in place on every level (RAMSES_AMD_TILE_MIN_OCTS=0)", pat, dict(base, RAMSES_AMD_TILE_MIN_OCTS="0"))
+            run_c5("resident, levels in tiles, tree-walking sweep (RAMSES_AMD_TILE_DENSE=0 RAMSES_AMD_COVERED_DENSE=0)", pat,
+                   dict(base, RAMSES_AMD_TILE_DENSE="0", RAMSES_AMD_COVERED_DENSE="0"))
+            run_c5("resident, host numbering on the device, tree-walking sweep (RAMSES_AMD_DEVICE_ORDER=0)", pat,
+                   dict(base, RAMSES_AMD_DEVICE_ORDER="0"))
         if which in ("all", "gpu"):
             run_c5("patched, state and tree resident on the GPU", pat, {"RAMSES_AMD": "1"})
             run_c5("patched, arrays staged around every godunov_fine (round 1 path)", pat,

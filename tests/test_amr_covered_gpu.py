@@ -15,6 +15,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _dense_sweep_on_small_levels_too(monkeypatch):
+    """(levels below RAMSES_AMD_TILE_MIN_OCTS octs take the tree-walking sweep in production: the tests force the tiles)"""
+    monkeypatch.setenv("RAMSES_AMD_TILE_MIN_OCTS", "0")
+
+
 def _state(T, L, seed):
     """a smooth flow with a blast on the covered level L, its restriction-consistent copy on the finer octs"""
     rng = np.random.default_rng(seed)

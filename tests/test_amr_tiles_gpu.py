@@ -12,6 +12,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _dense_sweep_on_small_levels_too(monkeypatch):
+    """(levels below RAMSES_AMD_TILE_MIN_OCTS octs take the tree-walking sweep in production: the tests force the tiles)"""
+    monkeypatch.setenv("RAMSES_AMD_TILE_MIN_OCTS", "0")
+
+
 def _vp(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 

@@ -144,12 +144,25 @@ def test_c5_levels_7_9_checksum(gpu_lib, resident):
     mkb = _mkb()
     os.environ["RAMSES_AMD"] = "1"
     os.environ["RAMSES_AMD_RESIDENT_AMR"] = resident
+    os.environ["RAMSES_AMD_STATS"] = "1"
+    os.environ["RAMSES_AMD_TILE_MIN_OCTS"] = "0"       # the small partial levels through the dense sweep too (production: the tree)
     try:
         work, out = rs.run_reference(mkb.c5_namelist(), binary=PATCHED)
     finally:
         os.environ.pop("RAMSES_AMD_RESIDENT_AMR", None)
+        os.environ.pop("RAMSES_AMD_STATS", None)
+        os.environ.pop("RAMSES_AMD_TILE_MIN_OCTS", None)
     try:
         assert ("AMR levels stay resident on the GPU" in out) == (resident == "1")
+        if resident == "1":
+            # round 5: the resident levels live in the device's tiles and take the DENSE sweep -- levelmin (fully refined) and
+            # the partial levels alike; this run against the reference's checksum is their live parity test
+            import re
+            m = re.search(r"godunov_fine of AMR levels: (\d+) sweeps through the dense kernel on tiles \((\d+) of them fully refined levels\), (\d+) through the tree-walking", out)
+            assert m, out[-1500:]
+            dense, covered, tree = (int(x) for x in m.groups())
+            print("C5 7-9: %d dense sweeps (%d of the fully refined levelmin), %d tree-walking" % (dense, covered, tree))
+            assert covered >= 8 and dense > covered and tree == 0, (dense, covered, tree)
         snap = rs.load_leaf_cells(os.path.join(work, "output_00002"))
         assert [int((snap["level"] == l).sum()) for l in (7, 8, 9)] == gold["ncell"]
         assert snap["info"]["t"] == gold["t"]
