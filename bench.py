@@ -708,6 +708,10 @@ def main():
             acc["sweep"] += a.elapsed_time(b); acc["pack"] += pk; acc["sendrecv"] += sr; acc["unpack"] += up
         breakdown = {k + "_ms": exchange.transport.allreduce(v / nprof, "cuda", op="max") for k, v in acc.items()}
         breakdown["bytes_sent_per_rank"] = nbytes
+        breakdown["bytes_to_peer_of_rank0"] = {str(k): v for k, v in sorted(getattr(exchange, "last_bytes_per_peer", {}).items())}
+        if tune is not None:
+            breakdown["schedule"] = {"serial_ms_per_step": tune[False] * 1e3, "overlapped_ms_per_step": tune[True] * 1e3,
+                                     "chosen": "overlapped" if overlap else "serial"}
         breakdown["sendrecv_GBps_per_rank"] = nbytes / max(breakdown["sendrecv_ms"], 1e-9) / 1e6
         breakdown["note"] = ("%d extra steps of the serial schedule after the timed region: full-brick sweep, pack of the 26 regions, one "
                              "grouped send/recv (one message per peer), unpack; each stage between events on the launch stream, max over ranks"
@@ -718,6 +722,23 @@ def main():
     assert chk[0] > 0 and chk[1] > 0
 
     census = rank_census(rank, world, local_dev, transport_note, getattr(transport, "group", None))     # collective
+    # Every rank on a device of its own and the exchange NOT behind the C ABI on every rank: the line would measure a transport
+    # the Fortran drop-in does not use (torch's RCCL, or gloo through the host).  That is a failed run, not a slower one --
+    # say so instead of printing a number (RAMSES_AMD_BENCH_ALLOW_FALLBACK=1 prints it anyway, marked).
+    fallback_error = None
+    if world > 1 and backend == "nccl" and census["distinct_devices"] == world and census["library_rccl_ranks"] != world:
+        fallback_error = ("%d ranks on %d distinct devices, but the library's own RCCL communicator is up on %d of them: the exchange ran "
+                          "through %s, not through ramses_amd_rccl_sendrecv" % (world, census["distinct_devices"], census["library_rccl_ranks"],
+                                                                                census["transport"]))
+        if os.environ.get("RAMSES_AMD_BENCH_ALLOW_FALLBACK", "0") != "1":
+            sys.stderr.write("bench.py rank %d: %s\n" % (rank, fallback_error))
+            if rank == 0:
+                print(json.dumps({"metric": "cell-updates/s (Godunov sweep), uniform Sedov3D", "value": None, "unit": "cell-updates/s",
+                                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "error": fallback_error,
+                                  "config": {"ranks": census, "step_breakdown": breakdown}}), flush=True)
+            if world > 1:
+                dist.destroy_process_group()
+            sys.exit(5)
     if rank == 0:
         cells = n ** 3
         value = cells * world * args.steps / elapsed
@@ -738,6 +759,7 @@ def main():
                        "spinup": "%d untimed sweeps of the same kernel on a scratch level of the same size before the warm-up steps (%d ms; the first ~8 "
                                  "sweeps of a kernel run up to 10 %% slower whatever ran before: profiles/r03_spinup_ab.txt)" % (spin_sweeps, args.spinup_ms),
                        "ranks": census,
+                       "transport_warning": fallback_error,
                        "step_breakdown": breakdown,
                        "halo": "none (single rank, in-kernel periodic wrap)" if world == 1 else
                                ("RCCL send/recv (torch.distributed)" if transport_note is None else transport_note) +

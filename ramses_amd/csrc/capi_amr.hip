@@ -1181,8 +1181,8 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
   if (!env_on(covered ? "RAMSES_AMD_COVERED_DENSE" : "RAMSES_AMD_TILE_DENSE") || !env_on("RAMSES_AMD_TILE_SWEEP")) return 0;
   {
     // a small level is quicker through the tree: the dense sweep is a pipeline of >= 19 plane iterations per workgroup whatever
-    // the level holds (measured crossover on MI355X around 1e5 octs; RAMSES_AMD_TILE_MIN_OCTS overrides, 0: always dense)
-    long min_octs = 65536;
+    // the level holds (measured on MI355X: equal at 32768 octs = a 64^3 level, 1.6x quicker at 262144; profiles/r05_tile_crossover.txt; RAMSES_AMD_TILE_MIN_OCTS overrides, 0: always dense)
+    long min_octs = 32768;
     if (const char *e = getenv("RAMSES_AMD_TILE_MIN_OCTS")) { const long v = atol(e); if (v >= 0) min_octs = v; }
     if (ngrid < min_octs) return 0;
   }
@@ -1704,10 +1704,11 @@ int ramses_amd_amrres_boundary_hydro(int nregion, const int *btype, const int *n
   HCHK(R.bnd_tmp.ensure(sizeof(double) * (size_t)nmax * 8 * (size_t)R.nvar), "hipMalloc boundary states");
   if (!R.bnd_pos.p || R.bnd_pos.cap < sizeof(int) * (size_t)R.ngridmax) R.bnd_pos_clean = false;
   HCHK(R.bnd_pos.ensure(sizeof(int) * (size_t)R.ngridmax), "hipMalloc boundary positions");
-  if (!R.bnd_pos_clean) {
-    HCHK(hipMemsetAsync(R.bnd_pos.p, 0, sizeof(int) * (size_t)R.ngridmax, nullptr), "memset");
-    R.bnd_pos_clean = true;
-  }
+  if (!R.bnd_pos_clean) HCHK(hipMemsetAsync(R.bnd_pos.p, 0, sizeof(int) * (size_t)R.ngridmax, nullptr), "memset");
+  // (the marks of a region are set and cleared around its kernels: an error return in between leaves marks behind, so the
+  //  table counts as clean again only after the last region's clear has been queued)
+  R.bnd_pos_clean = false;
+  if (R.nvar < 5) return failf(RAMSES_AMD_EUNSUPPORTED, "make_boundary_hydro on the device: the 3-D hydro layout (rho, rho u, rho v, rho w, E first)");
   if (int rc = upload_list(R, R.bnd_list, igrid, (int)ntot)) return rc;
   BndArgs A;
   A.uold = R.uold.as<double>(); A.tmp = R.bnd_tmp.as<double>();
@@ -1736,6 +1737,7 @@ int ramses_amd_amrres_boundary_hydro(int nregion, const int *btype, const int *n
   HCHK(hipGetLastError(), "make_boundary_hydro launch");
   // the list buffer is reused by the next call: the copy above must not overtake these launches, and the caller's list may go
   HCHK(hipStreamSynchronize(nullptr), "sync");
+  R.bnd_pos_clean = true;
   return 0;
 }
 

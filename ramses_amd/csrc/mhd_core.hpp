@@ -14,7 +14,7 @@
 #pragma once
 #include <cmath>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define MHD_FN __host__ __device__ __forceinline__
 #else
 #define MHD_FN inline

@@ -209,6 +209,7 @@ class BrickDecomposition:
         self._multi(lev, t, nvar, S, True)
         ev[1].record()
         sends, recvs, nbytes = [], [], 0
+        self.last_bytes_per_peer = {}
         for (q, pos, size), (q2, pos2, size2) in zip(S["segs"], R["segs"]):
             if q == self.rank:
                 R["buf"][pos2:pos2 + size2].copy_(S["buf"][pos:pos + size])
@@ -216,6 +217,7 @@ class BrickDecomposition:
                 sends.append((S["buf"][pos:pos + size], q))
                 recvs.append((R["buf"][pos2:pos2 + size2], q))
                 nbytes += 8 * size
+                self.last_bytes_per_peer[int(q)] = self.last_bytes_per_peer.get(int(q), 0) + 8 * size
         self.transport.sendrecv(sends, recvs)
         ev[2].record()
         self._multi(lev, t, nvar, R, False)
@@ -241,6 +243,13 @@ class BrickDecomposition:
         data the face slabs carry; the interior launch writes only cells the exchange
         never touches, and both read the old state, so the result equals
         godunov_fine -> set_uold -> make_virtual_fine_dp bit for bit."""
+        if lev.uold.device.type != "cuda":
+            # the schedule without streams (the CPU protocol tests, tests/test_halo_gloo.py): the same order of operations
+            lev.godunov_fine_shell(dt)
+            self.exchange_direct(lev, lev.unew, lev.nvar)
+            lev.godunov_fine_interior(dt)
+            lev.set_uold()
+            return
         if getattr(self, "_comm_stream", None) is None:
             self._comm_stream = torch.cuda.Stream(device=lev.uold.device)
         comp = torch.cuda.current_stream()

@@ -13,7 +13,8 @@
 !     make_boundary_hydro(ilevel)   amr/amr_step.f90:293   after synchro_hydro_fine
 !     make_boundary_hydro(ilevel)   amr/amr_step.f90:514   after set_uold / upload_fine
 ! fill them there (csrc/capi_amr.hip: ramses_amd_amrres_boundary_hydro --
-! reflexive and free boundaries; runs with imposed boundaries are not resident).
+! reflexive and free boundaries; imposed ones too: the shim evaluates the
+! reference's boundana for the cells of the region and the device stores them).
 ! A level the host has just rebuilt (refine_fine; it is re-sent to the device,
 ! boundary octs included, before the next device routine) takes the reference's
 ! routine; a level current on both sides takes both, so that both stay current.

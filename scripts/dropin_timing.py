@@ -278,7 +278,7 @@ bound_type= 1, 1, 2, 2, 1, 1
             # round 5: the device's own oct numbering -- levels in tiles + the dense sweep in place; the same layout with the
             # tree-walking sweep; the host's numbering with the tree-walking sweep (what round 4 ran on the partial levels)
             base = {"RAMSES_AMD": "1", "RAMSES_AMD_STATS": "1", "RAMSES_AMD_PROFILE": "1"}
-            run_c5("resident, levels in tiles, dense sweep in place (default: levels below 65536 octs walk the tree)", pat, dict(base))
+            run_c5("resident, levels in tiles, dense sweep in place (default: levels below 32768 octs walk the tree)", pat, dict(base))
             run_c5("resident, levels in tiles, dense sweep in place on every level (RAMSES_AMD_TILE_MIN_OCTS=0)", pat, dict(base, RAMSES_AMD_TILE_MIN_OCTS="0"))
             run_c5("resident, levels in tiles, tree-walking sweep (RAMSES_AMD_TILE_DENSE=0 RAMSES_AMD_COVERED_DENSE=0)", pat,
                    dict(base, RAMSES_AMD_TILE_DENSE="0", RAMSES_AMD_COVERED_DENSE="0"))

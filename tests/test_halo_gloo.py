@@ -240,3 +240,92 @@ def test_multigrid_rank_grid_cuts_z_first():
     assert bench.mg_rank_grid(2) == (1, 1, 2)
     assert bench.mg_rank_grid(4) == (1, 2, 2)
     assert bench.mg_rank_grid(8) == (2, 2, 2)
+
+
+# ---- the overlapped step's ORDER of operations on 8 processes ---------------------------------------
+class StencilLevel(FakeLevel):
+    """a level whose "sweep" is a 13-point stencil of reach 2 (what the Godunov sweep reads: two cells per side), split like
+    HydroLevel into the shell (cells within 2 of a brick face: what the neighbours receive) and the interior"""
+
+    def __init__(self, n, ng, nvar):
+        super().__init__(n, ng, nvar)
+        self.unew = torch.zeros_like(self.uold)
+
+    def _update(self, dt, mask):
+        n, g, u = self.nx, self.ng, self.uold
+        c = u[:, g:g + n, g:g + n, g:g + n]
+        acc = torch.zeros_like(c)
+        for d in range(3):
+            for o, w in ((-2, 0.25), (-1, 1.0), (1, 1.0), (2, 0.25)):
+                sl = [slice(g, g + n)] * 3
+                sl[d] = slice(g + o, g + o + n)
+                acc = acc + w * u[(slice(None),) + tuple(sl)]
+        new = c + dt * (acc - 7.5 * c)
+        tgt = self.unew[:, g:g + n, g:g + n, g:g + n]
+        tgt[:, mask] = new[:, mask]
+
+    def _shell_mask(self):
+        n = self.nx
+        i = torch.arange(n)
+        near = (i < 2) | (i >= n - 2)
+        return near[:, None, None] | near[None, :, None] | near[None, None, :]
+
+    def godunov_fine(self, dt):
+        self._update(dt, torch.ones((self.nx,) * 3, dtype=torch.bool))
+
+    def godunov_fine_shell(self, dt):
+        self._update(dt, self._shell_mask())
+
+    def godunov_fine_interior(self, dt):
+        self._update(dt, ~self._shell_mask())
+
+    def set_uold(self):
+        self.uold, self.unew = self.unew, self.uold
+
+
+def _overlap_worker(rank, world, pgrid, n, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ng, nvar, dt, nsteps = 2, 2, 0.01, 3
+        G = global_field(nvar, n * pgrid[2], n * pgrid[1], n * pgrid[0]) * 1e-6
+        cx, cy, cz = rank_coords(rank, pgrid)
+        own = G[:, cz * n:(cz + 1) * n, cy * n:(cy + 1) * n, cx * n:(cx + 1) * n]
+        out = {}
+        for mode in ("serial", "overlapped"):
+            dec = TorchMoverDecomposition(pgrid, rank, n, boxlen=1.0, ng=ng)
+            lev = StencilLevel(n, ng, nvar)
+            lev.uold[:, ng:ng + n, ng:ng + n, ng:ng + n] = torch.from_numpy(own.copy())
+            dec.exchange_direct(lev, lev.uold, nvar)
+            for _ in range(nsteps):
+                if mode == "serial":
+                    lev.godunov_fine(dt)               # amr/amr_step.f90:388-510: sweep, set_uold, make_virtual_fine_dp
+                    lev.set_uold()
+                    dec.make_virtual_fine_dp(lev)
+                else:
+                    dec.step_overlapped(lev, dt)       # shell, exchange of the NEW state, interior, swap
+            out[mode] = lev.uold.numpy().copy()
+        # the single-process answer: the same stencil on the periodic global field
+        U = G.copy()
+        for _ in range(nsteps):
+            acc = np.zeros_like(U)
+            for d in range(3):
+                for o, w in ((-2, 0.25), (-1, 1.0), (1, 1.0), (2, 0.25)):
+                    acc = acc + w * np.roll(U, -o, axis=1 + d)
+            U = U + dt * (acc - 7.5 * U)
+        idx = lambda c, ext: (np.arange(c * n - ng, (c + 1) * n + ng)) % ext  # noqa: E731
+        exp = U[:, idx(cz, U.shape[1])][:, :, idx(cy, U.shape[2])][:, :, :, idx(cx, U.shape[3])]
+        ret[rank] = bool(np.array_equal(out["serial"], out["overlapped"])) and bool(np.allclose(out["overlapped"], exp, rtol=1e-13, atol=0.0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_step_equals_the_serial_schedule_on_8_processes():
+    """BrickDecomposition.step_overlapped (shell sweep, exchange of the new state's ghosts, interior sweep, swap) against the
+    reference's order (sweep, set_uold, make_virtual_fine_dp) on a 2 x 2 x 2 grid of processes: every ghost cell after every
+    step, bit for bit, and the single-process result of the same stencil"""
+    pgrid, world = (2, 2, 2), 8
+    ret = mp.Manager().dict()
+    mp.spawn(_overlap_worker, args=(world, pgrid, 6, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world and all(ret.values()), dict(ret)
