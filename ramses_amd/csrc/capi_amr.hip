@@ -516,10 +516,27 @@ __global__ __launch_bounds__(256) void plan_target_kernel(PlanArgs A, int *corr_
 // the creditor that comes first in the reference's loop order (batch of nvector octs of the LIST, idim, left before right)
 // replays all of them sequentially: floating-point addition is not associative.  (The twin of amr_coarse_update_kernel,
 // csrc/amr_sweep.hip, with the records indexed by device oct instead of list position.)
+// the (list position, face) pairs that owe something: io * 6 + f, in whatever order the waves arrive (the replay picks the
+// first creditor of a coarse cell by the reference's key, not by this order)
+__global__ __launch_bounds__(256) void plan_events_kernel(PlanArgs A, const int *__restrict__ corr_tgt, int *__restrict__ events, int *__restrict__ count) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool have = false;
+  if (t < (long)A.n * 6) have = corr_tgt[((long)A.ig[t / 6] - A.base) * 6 + t % 6] > 0;
+  const unsigned long long m = __ballot(have);
+  if (m) {
+    const int lane = threadIdx.x & 63;
+    int b = 0;
+    if (lane == 0) b = atomicAdd(count, __popcll(m));
+    b = __shfl(b, 0, 64);
+    if (have) events[b + __popcll(m & ((1ull << lane) - 1ull))] = (int)t;
+  }
+}
 __global__ __launch_bounds__(256) void tile_coarse_update_kernel(PlanArgs A, double *__restrict__ unew, const double *__restrict__ corr,
-                                                                 const int *__restrict__ corr_tgt, int nvector, int NV) {
-  const long ev = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (ev >= (long)A.n * 6) return;
+                                                                 const int *__restrict__ corr_tgt, const int *__restrict__ events, int nevent, int nvector,
+                                                                 int NV) {
+  const long e0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e0 >= nevent) return;
+  const long ev = events[e0];
   const int io = (int)(ev / 6), f = (int)(ev % 6);
   const long slot = (long)A.ig[io] - A.base;
   const int C = corr_tgt[slot * 6 + f];
@@ -719,8 +736,8 @@ struct CommLevel {
 // what the dense sweep of a level in tiles needs beyond the cell vectors (see plan_* above), valid for one layout and one list
 struct LevelPlan {
   int version = -1, ngrid = -1, ig_first = 0, ig_last = 0;      // the layout version of the level and the list the plan was made for
-  int nghost = 0, nwork = 0;
-  Buf gfather, gslot, gcell, work, corr, corr_tgt, flag;
+  int nghost = 0, nwork = 0, nevent = 0;
+  Buf gfather, gslot, gcell, work, corr, corr_tgt, flag, events;
 };
 
 struct AmrRes {
@@ -735,6 +752,12 @@ struct AmrRes {
   long ngh = 0, ncell_h = 0;                   // of the host's
   amrlayout::DevMap map;
   Buf stat, octpos, bad;                       // status byte per device cell; device oct -> position in the list of its level's plan; bad-index counter
+  // the oct lists of the levels as they last arrived, translated: a level's list (active(ilevel)%igrid) comes down with every
+  // routine of a step and changes only with the tree
+  struct ListSlot { const int *h = nullptr; int n = 0, serial = -1; int sample[10] = {0}; Buf dev; long stamp = 0; };
+  ListSlot lcache[16];
+  long lstamp = 0;
+  int *cur_ig = nullptr;                       // the list of the routine under way (device indices)
   std::vector<LevelPlan> plan;
   long tile_sweeps = 0, tree_sweeps = 0;
   bool announced = false;
@@ -763,6 +786,10 @@ inline int grid_for(long n) {
   return (int)g;
 }
 
+bool env_on(const char *name) {      // (read on every sweep: the A/B tests flip the switches inside one process)
+  const char *e = getenv(name);
+  return !(e && e[0] == '0');
+}
 // an oct list of the host on the device, in device indices (amr_layout.hpp); an index that is not in the tree is an error of
 // the caller, reported by the next routine that synchronises anyway (check_lists)
 int upload_list(AmrRes &R, Buf &dst, const int *h, int n) {
@@ -788,9 +815,27 @@ int check_lists(AmrRes &R, const char *where) {
 int set_level(AmrRes &R, int ngrid, const int *igrid, LvlArgs &A) {
   if (!R.valid) return failf(RAMSES_AMD_EINVAL, "no resident AMR state (ramses_amd_amrres_load)");
   if (ngrid < 0 || (ngrid > 0 && !igrid)) return failf(RAMSES_AMD_EINVAL, "bad oct list");
-  if (int rc = upload_list(R, R.igrid, igrid, ngrid)) return rc;
+  {
+    // the same list as before (same array, length, layout; first, last and eight entries in between equal): already there.
+    // (Contract of the C ABI: an oct list does not change between two calls of ramses_amd_amrres_tree other than as a whole.)
+    AmrRes::ListSlot *hit = nullptr, *lru = &R.lcache[0];
+    int sample[10] = {0};
+    if (ngrid > 0) for (int k = 0; k < 10; k++) sample[k] = igrid[(long)k * (ngrid - 1) / 9];
+    for (AmrRes::ListSlot &S : R.lcache) {
+      if (S.h == igrid && S.n == ngrid && S.serial == R.map.serial && ngrid > 0 && memcmp(S.sample, sample, sizeof(sample)) == 0) { hit = &S; break; }
+      if (S.stamp < lru->stamp) lru = &S;
+    }
+    if (!hit || !env_on("RAMSES_AMD_LIST_CACHE")) {
+      hit = lru;
+      hit->serial = -1;
+      if (int rc = upload_list(R, hit->dev, igrid, ngrid)) return rc;
+      hit->h = igrid; hit->n = ngrid; hit->serial = R.map.serial; memcpy(hit->sample, sample, sizeof(sample));
+    }
+    hit->stamp = ++R.lstamp;
+    R.cur_ig = hit->dev.as<int>();
+  }
   A.uold = R.uold.as<double>(); A.unew = R.unew.as<double>();
-  A.son = R.son.as<int>(); A.nbor = R.nbor.as<int>(); A.igrid = R.igrid.as<int>();
+  A.son = R.son.as<int>(); A.nbor = R.nbor.as<int>(); A.igrid = R.cur_ig;
   A.ngrid = ngrid; A.nvar = R.nvar; A.ncell = R.ncell; A.ncoarse = R.ncoarse; A.ngridmax = R.ngridmax;
   return 0;
 }
@@ -1061,10 +1106,6 @@ int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, co
 }
 
 namespace {
-bool env_on(const char *name) {      // (read on every sweep: the A/B tests flip the switches inside one process)
-  const char *e = getenv(name);
-  return !(e && e[0] == '0');
-}
 
 // the plan of a level in tiles for the list in R.igrid (see plan_* above); rebuilt when the layout or the list changed
 int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &P) {
@@ -1073,7 +1114,7 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   P.version = -1;
   PlanArgs A;
   A.son = R.son.as<int>(); A.nbor = R.nbor.as<int>(); A.father = R.father.as<int>(); A.iperm = R.map.iperm.as<int>();
-  A.stat = R.stat.as<unsigned char>(); A.octpos = R.octpos.as<int>(); A.ig = R.igrid.as<int>(); A.n = ngrid;
+  A.stat = R.stat.as<unsigned char>(); A.octpos = R.octpos.as<int>(); A.ig = R.cur_ig; A.n = ngrid;
   A.ncell = R.ncell; A.ncoarse = R.ncoarse; A.ngd = R.ngridmax;
   A.dir = L.dir.as<int>(); A.tileid = L.tileid.as<int>(); A.base = L.base; A.no = L.no; A.ntx = L.ntx; A.nty = L.nty; A.ntz = L.ntz;
   HCHK(P.gfather.ensure(sizeof(int) * (size_t)L.cap), "hipMalloc");
@@ -1094,6 +1135,9 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   if ((long)L.n < (long)L.no * L.no * L.no)
     hipLaunchKernelGGL(plan_ghost_kernel, dim3(grid_for((long)ngrid * 26)), dim3(256), 0, s, A, P.gfather.as<int>(), P.gslot.as<int>(), P.gcell.as<int>(), cnt, gcap, cnt + 1);
   hipLaunchKernelGGL(plan_target_kernel, dim3(grid_for((long)ngrid * 6)), dim3(256), 0, s, A, P.corr_tgt.as<int>());
+  HCHK(P.events.ensure(sizeof(int) * ((size_t)ngrid * 6 + 1)), "hipMalloc");
+  HCHK(hipMemsetAsync(P.events.p, 0, sizeof(int), s), "memset");
+  hipLaunchKernelGGL(plan_events_kernel, dim3((unsigned)(((long)ngrid * 6 + 255) / 256)), dim3(256), 0, s, A, P.corr_tgt.as<int>(), P.events.as<int>() + 1, P.events.as<int>());
   // work items: columns of 60 x 8 cells, runs of 8-plane chunks up to 128 planes
   const int rows = strictmode::tile_sweep_rows();       // interior rows of a work item (even: an oct never straddles two)
   const int n = 2 * L.no, wtx = (n + 59) / 60, wty = n / rows, wz = n / 8;
@@ -1104,6 +1148,7 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   HCHK(hipGetLastError(), "plan launch");
   int hc[2] = {0, 0};
   std::vector<unsigned char> flag(nflag);
+  HCHK(hipMemcpyAsync(&P.nevent, P.events.p, sizeof(int), hipMemcpyDeviceToHost, s), "D2H");
   HCHK(hipMemcpyAsync(hc, cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, s), "D2H");
   HCHK(hipMemcpyAsync(flag.data(), P.flag.p, nflag, hipMemcpyDeviceToHost, s), "D2H");
   HCHK(hipStreamSynchronize(s), "sync");
@@ -1232,12 +1277,14 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
   {
     PlanArgs Q;
     Q.son = R.son.as<int>(); Q.nbor = R.nbor.as<int>(); Q.father = R.father.as<int>(); Q.iperm = R.map.iperm.as<int>();
-    Q.stat = R.stat.as<unsigned char>(); Q.octpos = R.octpos.as<int>(); Q.ig = R.igrid.as<int>(); Q.n = ngrid;
+    Q.stat = R.stat.as<unsigned char>(); Q.octpos = R.octpos.as<int>(); Q.ig = R.cur_ig; Q.n = ngrid;
     Q.ncell = R.ncell; Q.ncoarse = R.ncoarse; Q.ngd = R.ngridmax;
     Q.dir = L.dir.as<int>(); Q.tileid = L.tileid.as<int>(); Q.base = L.base; Q.no = L.no; Q.ntx = L.ntx; Q.nty = L.nty; Q.ntz = L.ntz;
-    const long nev = (long)ngrid * 6;
-    hipLaunchKernelGGL(tile_coarse_update_kernel, dim3((int)((nev + 255) / 256)), dim3(256), 0, s, Q, R.unew.as<double>(), P.corr.as<double>(), P.corr_tgt.as<int>(), nvector, 5);
-    HCHK(hipGetLastError(), "coarse corrections");
+    if (P.nevent > 0) {
+      hipLaunchKernelGGL(tile_coarse_update_kernel, dim3((P.nevent + 255) / 256), dim3(256), 0, s, Q, R.unew.as<double>(), P.corr.as<double>(), P.corr_tgt.as<int>(),
+                         P.events.as<int>() + 1, P.nevent, nvector, 5);
+      HCHK(hipGetLastError(), "coarse corrections");
+    }
   }
   if (covered) R.covered_sweeps++;
   R.tile_sweeps++;
@@ -1271,7 +1318,7 @@ int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int 
   if (nw < 0) return (int)nw;
   HCHK(R.work.ensure((size_t)nw), "hipMalloc work");
   HCHK(hipMemsetAsync(R.err.p, 0, sizeof(int), nullptr), "memset");
-  if (int rc = ramses_amd_godunov_fine_amr_device(p, ilevel, ngrid, R.igrid.as<int>(), R.son.as<int>(), R.nbor.as<int>(), R.father.as<int>(),
+  if (int rc = ramses_amd_godunov_fine_amr_device(p, ilevel, ngrid, R.cur_ig, R.son.as<int>(), R.nbor.as<int>(), R.father.as<int>(),
                                                   R.ngridmax, R.ncoarse, R.uold.as<double>(), R.unew.as<double>(), R.grav ? R.f.as<double>() : nullptr, R.pfix ? R.divu.as<double>() : nullptr, R.pfix ? R.enew.as<double>() : nullptr,
                                                   dx, dt, nvector, interpol_var, interpol_type, R.work.p, R.err.as<int>(), nullptr)) return rc;
   int bad = 0;
@@ -1306,7 +1353,7 @@ int ramses_amd_amrres_load_f(int ngrid, const int *igrid, const double *f) {
     }
   HCHK(R.pack.ensure(sizeof(double) * (size_t)tot * 3), "hipMalloc");
   HCHK(hipMemcpy(R.pack.p, R.hpack.data(), sizeof(double) * (size_t)tot * 3, hipMemcpyHostToDevice), "H2D f");
-  hipLaunchKernelGGL(lvl_pack_comp_kernel<false>, dim3(grid_for(tot)), dim3(256), 0, nullptr, R.f.as<double>(), R.pack.as<double>(), R.igrid.as<int>(), ngrid, 3,
+  hipLaunchKernelGGL(lvl_pack_comp_kernel<false>, dim3(grid_for(tot)), dim3(256), 0, nullptr, R.f.as<double>(), R.pack.as<double>(), R.cur_ig, ngrid, 3,
                      R.ncell, R.ncoarse, R.ngridmax);
   HCHK(hipGetLastError(), "f unpack launch");
   HCHK(hipStreamSynchronize(nullptr), "sync");
@@ -1474,7 +1521,7 @@ int ramses_amd_amrres_sync_density(int ngrid, const int *igrid, double *uold) {
   if (ngrid == 0) return 0;
   const long tot = (long)ngrid * 8;
   HCHK(R.pack.ensure(sizeof(double) * (size_t)tot), "hipMalloc");
-  hipLaunchKernelGGL(lvl_pack_comp_kernel<true>, dim3(grid_for(tot)), dim3(256), 0, nullptr, R.uold.as<double>(), R.pack.as<double>(), R.igrid.as<int>(), ngrid, 1,
+  hipLaunchKernelGGL(lvl_pack_comp_kernel<true>, dim3(grid_for(tot)), dim3(256), 0, nullptr, R.uold.as<double>(), R.pack.as<double>(), R.cur_ig, ngrid, 1,
                      R.ncell, R.ncoarse, R.ngridmax);
   HCHK(hipGetLastError(), "density pack launch");
   R.hpack.resize((size_t)tot);

@@ -241,15 +241,19 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     return (inB ? b : a) + sloc[ty * BX + tx];
   };
   // (MASK: plane p through the tiles; else plane offset + column)
+  // (MASK: two variables share a buffer descriptor -- the odd one rides in the scalar offset: 16 scalar registers the
+  //  masked instantiation does not have; pitch_var * 8 + the plane part < 2^32, checked by the launcher)
+  const unsigned odd_var = (unsigned)(A.pitch_var * 8);
   auto load_u = [&](int p, double (&u)[NV]) {
     const unsigned pb = MASK ? zpart(p) * 8u : plane_off(p), off = MASK ? tbp(p) : colb;
 #pragma unroll
-    for (int n = 0; n < NV; n++) u[n] = plane_load(uold + (long)n * A.pitch_var, pb, off);
+    for (int n = 0; n < NV; n++)
+      u[n] = MASK ? plane_load(uold + (long)(n & ~1) * A.pitch_var, pb + (n & 1) * odd_var, off) : plane_load(uold + (long)n * A.pitch_var, pb, off);
   };
   auto load_base = [&](int p, double (&u)[NV]) {   // MASK: the state the update starts from (unew, in place)
     const unsigned pb = zpart(p) * 8u, off = tbp(p);
 #pragma unroll
-    for (int n = 0; n < NV; n++) u[n] = plane_load(unew + (long)n * A.pitch_var, pb, off);
+    for (int n = 0; n < NV; n++) u[n] = plane_load(unew + (long)(n & ~1) * A.pitch_var, pb + (n & 1) * odd_var, off);
   };
   int ok_zlo = 0;   // MASK: plane c-1's status byte of this column
   int s_m1 = 0;     // MASK: the same, kept until plane c-1 is finished in phase B
@@ -536,7 +540,10 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
         const unsigned pb = MASK ? zpart(c - 1) * 8u : plane_off(c - 1);
         const unsigned so = (c >= z0 + 1) ? (MASK ? ((r_upd && (s_m1 & CELL_OWNED)) ? tbp(c - 1) : BUF_OOB) : colb_upd) : BUF_OOB;
 #pragma unroll
-        for (int n = 0; n < NV; n++) plane_store(unew + (long)n * A.pitch_var, pb, so, un[n]);
+        for (int n = 0; n < NV; n++) {
+          if (MASK) plane_store(unew + (long)(n & ~1) * A.pitch_var, pb + (n & 1) * odd_var, so, un[n]);
+          else plane_store(unew + (long)n * A.pitch_var, pb, so, un[n]);
+        }
       }
     }
     // rotate the ring
