@@ -754,7 +754,8 @@ struct AmrRes {
   Buf stat, octpos, bad;                       // status byte per device cell; device oct -> position in the list of its level's plan; bad-index counter
   // the oct lists of the levels as they last arrived, translated: a level's list (active(ilevel)%igrid) comes down with every
   // routine of a step and changes only with the tree
-  struct ListSlot { const int *h = nullptr; int n = 0, serial = -1; int sample[10] = {0}; Buf dev; long stamp = 0; };
+  struct ListSlot { const int *h = nullptr; int n = 0, serial = -1; int sample[10] = {0}; Buf dev, sorted, tmp; bool has_sorted = false; long stamp = 0; };
+  ListSlot *cur_slot = nullptr;
   ListSlot lcache[16];
   long lstamp = 0;
   int *cur_ig = nullptr;                       // the list of the routine under way (device indices)
@@ -812,6 +813,23 @@ int check_lists(AmrRes &R, const char *where) {
   }
   return 0;
 }
+// The list of the routine under way in ascending DEVICE order, for the kernels whose result does not depend on the order of
+// the list (copies, source terms, restriction): neighbouring threads then touch neighbouring octs of a tile -- the host's
+// order is the order of creation, which the device numbering scatters.
+int sorted_list(AmrRes &R, LvlArgs &A) {
+  AmrRes::ListSlot *S = R.cur_slot;
+  if (!R.map.on || !S || S->n < 2 || !env_on("RAMSES_AMD_SORTED_LISTS")) return 0;
+  if (!S->has_sorted) {
+    HCHK(S->sorted.ensure(sizeof(int) * (size_t)S->n), "hipMalloc");
+    size_t bytes = 0;
+    HCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, S->dev.as<int>(), S->sorted.as<int>(), S->n, 0, 32, (hipStream_t) nullptr), "sort");
+    HCHK(S->tmp.ensure(bytes), "hipMalloc");
+    HCHK(hipcub::DeviceRadixSort::SortKeys(S->tmp.p, bytes, S->dev.as<int>(), S->sorted.as<int>(), S->n, 0, 32, (hipStream_t) nullptr), "sort");
+    S->has_sorted = true;
+  }
+  A.igrid = S->sorted.as<int>();
+  return 0;
+}
 int set_level(AmrRes &R, int ngrid, const int *igrid, LvlArgs &A) {
   if (!R.valid) return failf(RAMSES_AMD_EINVAL, "no resident AMR state (ramses_amd_amrres_load)");
   if (ngrid < 0 || (ngrid > 0 && !igrid)) return failf(RAMSES_AMD_EINVAL, "bad oct list");
@@ -830,9 +848,11 @@ int set_level(AmrRes &R, int ngrid, const int *igrid, LvlArgs &A) {
       hit->serial = -1;
       if (int rc = upload_list(R, hit->dev, igrid, ngrid)) return rc;
       hit->h = igrid; hit->n = ngrid; hit->serial = R.map.serial; memcpy(hit->sample, sample, sizeof(sample));
+      hit->has_sorted = false;
     }
     hit->stamp = ++R.lstamp;
     R.cur_ig = hit->dev.as<int>();
+    R.cur_slot = hit;
   }
   A.uold = R.uold.as<double>(); A.unew = R.unew.as<double>();
   A.son = R.son.as<int>(); A.nbor = R.nbor.as<int>(); A.igrid = R.cur_ig;
@@ -1024,6 +1044,7 @@ int ramses_amd_amrres_set_unew(int ngrid, const int *igrid) {
   LvlArgs A;
   if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
   if (ngrid == 0) return 0;
+  if (int rc = sorted_list(g_ar, A)) return rc;
   hipLaunchKernelGGL(lvl_copy_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, A, A.unew, A.uold);
   HCHK(hipGetLastError(), "set_unew launch");
   return 0;
@@ -1034,6 +1055,7 @@ int ramses_amd_amrres_set_uold(const ramses_amd_hydro_params *p, int ngrid, cons
   LvlArgs A;
   if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
   if (ngrid == 0) return 0;
+  if (int rc = sorted_list(g_ar, A)) return rc;
   hipLaunchKernelGGL(lvl_set_uold_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, A, p->smallr);
   HCHK(hipGetLastError(), "set_uold launch");
   return 0;
@@ -1045,6 +1067,7 @@ int ramses_amd_amrres_upload_fine(const ramses_amd_hydro_params *p, int ngrid, c
   LvlArgs A;
   if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
   if (ngrid == 0) return 0;
+  if (int rc = sorted_list(g_ar, A)) return rc;
   const dim3 g(grid_for((long)ngrid * 8)), b(256);
   switch (A.nvar) {
     case 5: hipLaunchKernelGGL(lvl_upload_kernel<5>, g, b, 0, nullptr, A, interpol_var, p->smallr); break;
@@ -1155,6 +1178,19 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   if (hc[1]) return failf(RAMSES_AMD_EINVAL, "level %d: %d neighbour positions of an oct have no father cell or no tile (tree inconsistent)", ilevel, hc[1]);
   if (hc[0] > gcap) return failf(RAMSES_AMD_EINVAL, "level %d: more ghost octs (%d) than free slots in the level's tiles (%d)", ilevel, hc[0], gcap);
   P.nghost = hc[0];
+  if (P.nghost > 1) {
+    // the ghost octs in slot order: neighbouring threads of the fill kernel then write neighbouring octs of a tile (the search
+    // appended them in whatever order its waves arrived)
+    amrlayout::Buf &k2 = P.gfather, &v2 = P.flag;          // (both free from here on: the ghost table's job is done, the flags are on the host)
+    HCHK(k2.ensure(sizeof(int) * (size_t)P.nghost), "hipMalloc"); HCHK(v2.ensure(sizeof(int) * (size_t)P.nghost), "hipMalloc");
+    size_t bytes = 0;
+    HCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, P.gslot.as<int>(), k2.as<int>(), P.gcell.as<int>(), v2.as<int>(), P.nghost, 0, 32, s), "sort");
+    HCHK(R.work.ensure(bytes), "hipMalloc");
+    HCHK(hipcub::DeviceRadixSort::SortPairs(R.work.p, bytes, P.gslot.as<int>(), k2.as<int>(), P.gcell.as<int>(), v2.as<int>(), P.nghost, 0, 32, s), "sort");
+    HCHK(hipMemcpyAsync(P.gslot.p, k2.p, sizeof(int) * (size_t)P.nghost, hipMemcpyDeviceToDevice, s), "copy");
+    HCHK(hipMemcpyAsync(P.gcell.p, v2.p, sizeof(int) * (size_t)P.nghost, hipMemcpyDeviceToDevice, s), "copy");
+    HCHK(hipStreamSynchronize(s), "sync");
+  }
   // Work items = runs of flagged 8-plane chunks of a column, cut to at most `zrun` planes.  A workgroup fills a CU (LDS), so a
   // launch proceeds in rounds of ncu items, each costing its planes + 3 (the pipeline's prologue): take the cut that minimises
   // rounds x (planes + 3) -- long items for big levels (least redundant work), short ones when a level has few columns
@@ -1540,6 +1576,7 @@ int ramses_amd_amrres_synchro(const ramses_amd_hydro_params *p, int ngrid, const
   if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
   if (!g_ar.grav) return failf(RAMSES_AMD_EINVAL, "synchro_hydro_fine: no acceleration on the device (ramses_amd_amrres_load_f)");
   if (ngrid == 0) return 0;
+  if (int rc = sorted_list(g_ar, A)) return rc;
   hipLaunchKernelGGL(lvl_synchro_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, A, g_ar.f.as<double>(), dteff, p->smallr);
   HCHK(hipGetLastError(), "synchro launch");
   return 0;
@@ -1552,6 +1589,7 @@ int ramses_amd_amrres_set_uold_grav(const ramses_amd_hydro_params *p, int ngrid,
   if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
   if (!g_ar.grav) return failf(RAMSES_AMD_EINVAL, "set_uold: no acceleration on the device (ramses_amd_amrres_load_f)");
   if (ngrid == 0) return 0;
+  if (int rc = sorted_list(g_ar, A)) return rc;
   hipLaunchKernelGGL(lvl_gravity_source_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, A, g_ar.f.as<double>(), dt, p->smallr);
   hipLaunchKernelGGL(lvl_set_uold_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, A, p->smallr);
   HCHK(hipGetLastError(), "set_uold launch");
@@ -1576,6 +1614,7 @@ int ramses_amd_amrres_set_unew_pfix(const ramses_amd_hydro_params *p, int ngrid,
   if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
   if (!g_ar.pfix) return failf(RAMSES_AMD_EINVAL, "set_unew: pressure_fix not enabled (ramses_amd_amrres_enable_pfix)");
   if (ngrid == 0) return 0;
+  if (int rc = sorted_list(g_ar, A)) return rc;
   const dim3 g(grid_for((long)ngrid * 8)), b(256);
   hipLaunchKernelGGL(lvl_copy_kernel, g, b, 0, nullptr, A, A.unew, A.uold);
   hipLaunchKernelGGL(lvl_pfix_init_kernel, g, b, 0, nullptr, A, g_ar.divu.as<double>(), g_ar.enew.as<double>(), p->smallr);
@@ -1591,6 +1630,7 @@ int ramses_amd_amrres_set_uold_pfix(const ramses_amd_hydro_params *p, int ngrid,
   AmrRes &R = g_ar;
   if (!R.pfix) return failf(RAMSES_AMD_EINVAL, "set_uold: pressure_fix not enabled (ramses_amd_amrres_enable_pfix)");
   if (ngrid == 0) return 0;
+  if (int rc = sorted_list(g_ar, A)) return rc;
   const dim3 g(grid_for((long)ngrid * 8)), b(256);
   if (R.grav) hipLaunchKernelGGL(lvl_gravity_source_kernel, g, b, 0, nullptr, A, R.f.as<double>(), dt, p->smallr);
   hipLaunchKernelGGL(lvl_pdv_kernel, g, b, 0, nullptr, A, R.enew.as<double>(), dx_loc, dt, p->gamma, p->smallr);

@@ -180,8 +180,10 @@ def run_grav_mpi(tag, binary, env, level, nstep, nproc):
     stats = re.findall(r"level arrays across PCIe after the upload:\s*(\d+) bytes in\s*(\d+) copies; halo:\s*(\d+) bytes in\s*(\d+) exchanges", out)
     pcie = {"level_array_bytes": sum(int(a) for a, _, _, _ in stats), "halo_bytes": sum(int(c) for _, _, c, _ in stats),
             "halo_exchanges": sum(int(d) for _, _, _, d in stats)} if stats else None
+    sweeps = [l.strip()[11:] for l in out.splitlines() if "godunov_fine of AMR levels" in l]
     print(json.dumps({"config": tag, "level": level, "steps": nstep, "ranks": nproc, "wall_s": round(wall, 3),
-                      "vcycles": [int(b) for _, b, _ in solves], "timers_max_s": rows, "multigrid_pcie_all_ranks": pcie}), flush=True)
+                      "vcycles": [int(b) for _, b, _ in solves], "timers_max_s": rows, "multigrid_pcie_all_ranks": pcie,
+                      "sweeps_of_rank": sweeps[:2]}), flush=True)
 
 
 if __name__ == "__main__":
@@ -191,6 +193,11 @@ if __name__ == "__main__":
         which = sys.argv[5] if len(sys.argv) > 5 else "all"
         ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi")
         pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi_patch")
+        if which == "tiles":
+            base = {"RAMSES_AMD": "1", "RAMSES_AMD_STATS": "1"}
+            run_grav_mpi("patched (default): the rank's octs in tiles, dense sweep in place; distributed dense V-cycles", pat, dict(base), level, nstep, nproc)
+            run_grav_mpi("patched, RAMSES_AMD_DEVICE_ORDER=0: host numbering on the device, tree-walking sweep (the round-4 layout)", pat,
+                         dict(base, RAMSES_AMD_DEVICE_ORDER="0"), level, nstep, nproc)
         if which in ("all", "gpu"):
             run_grav_mpi("patched: dense V-cycles distributed over one brick per rank, one deep-halo exchange per smoother launch (csrc/mg_dist.hip; default)", pat,
                          {"RAMSES_AMD": "1", "RAMSES_AMD_MG_STATS": "1"}, level, nstep, nproc)
@@ -301,6 +308,7 @@ bound_type= 1, 1, 2, 2, 1, 1
         spec.loader.exec_module(mkb)
         ngt = {7: 2000000, 8: 8000000}.get(lmin, 600000)
         nml = mkb.c5_namelist(lmin, lmax, nstep, ngt).replace("foutput=%d" % nstep, "foutput=1000")
+        walls = False
         if walls:
             nml += """
 &BOUNDARY_PARAMS
@@ -340,12 +348,19 @@ bound_type= 1, 1, 2, 2, 1, 1
             last = {}
             for l, g in re.findall(r"Level\s+(\d+) has\s+(\d+) grids", out):
                 last[int(l)] = int(g)
-            note = [l.strip() for l in out.splitlines() if "ramses_amd:" in l]
+            note = [l.strip() for l in out.splitlines() if "ramses_amd:" in l and "godunov_fine of AMR levels" not in l]
+            sweeps = [l.strip()[11:] for l in out.splitlines() if "godunov_fine of AMR levels" in l]
             print(json.dumps({"config": tag, "levels": [lmin, lmax], "steps": nstep, "ranks": nproc, "wall_s": round(wall, 3),
-                              "octs_per_level": {k: v for k, v in last.items() if k >= lmin}, "timers_max_s": rows, "notes": note[:4]}), flush=True)
+                              "octs_per_level": {k: v for k, v in last.items() if k >= lmin}, "timers_max_s": rows, "notes": note[:4],
+                              "sweeps_of_rank": sweeps[:2]}), flush=True)
 
         ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi")
         pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi_patch")
+        if which == "tiles":
+            base = {"RAMSES_AMD": "1", "RAMSES_AMD_STATS": "1"}
+            run_c5mpi("resident, every rank's levels in tiles, dense sweep in place (default)", pat, dict(base))
+            run_c5mpi("resident, host numbering on the device, tree-walking sweep (RAMSES_AMD_DEVICE_ORDER=0: the round-4 layout)", pat,
+                      dict(base, RAMSES_AMD_DEVICE_ORDER="0"))
         if which in ("all", "gpu"):
             run_c5mpi("patched, every rank's cell vectors and tree resident on the GPU, virtual boundaries on the device", pat, {"RAMSES_AMD": "1"})
             run_c5mpi("patched, arrays staged around every godunov_fine + the reference's host MPI halo (round 1 path)", pat,
