@@ -592,25 +592,35 @@ __global__ __launch_bounds__(256) void plan_work_kernel(PlanArgs A, int wtx, int
     flag[((long)((2 * y) / rows) * wtx + (2 * x) / 60) * wz + (2 * z) / 8] = 1;
   }
 }
-// the ghost octs' cells: interpol_hydro of the father cell with its six neighbours (getnborfather's coarser fallback), the
-// father cell's acceleration (hydro/godunov_fine.f90:563-626) -- into the free slots of the level's tiles
-template <int NV>
-__global__ __launch_bounds__(128) void plan_ghost_fill_kernel(double *__restrict__ uold, double *__restrict__ grav, const int *__restrict__ son,
-                                                              const int *__restrict__ nbor, const int *__restrict__ gslot, const int *__restrict__ gcell,
-                                                              int nghost, long ncell, long ncoarse, long ngd, int interpol_var, int interpol_type, double smallr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nghost) return;
+// the seven cells interpol_hydro reads for a ghost oct: the father cell and its -x,+x,-y,+y,-z,+z neighbours, a neighbour that
+// does not exist replaced by the cell of the coarser level there (getnborfather's fallback) -- found once per plan, so that the
+// fill kernel of every sweep is loads and arithmetic only (the walk is nothing but dependent nbor -> son loads)
+__global__ __launch_bounds__(256) void plan_ghost_stencil_kernel(const int *__restrict__ son, const int *__restrict__ nbor, const int *__restrict__ gcell,
+                                                                 int nghost, long ncoarse, long ngd, int *__restrict__ gsten) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)nghost * 7) return;
+  const int j = (int)(t / nghost), i = (int)(t % nghost);
   AmrSweepArgs T;
   T.son = son; T.nbor = nbor; T.ncoarse = ncoarse; T.ngridmax = ngd;
-  const int c0 = gcell[i];
+  int c = gcell[i];
+  if (j > 0) {
+    c = amrsweep::nbor_cell(c, j - 1, T);
+    if (c < 0) c = -c;
+  }
+  gsten[(long)j * nghost + i] = c;
+}
+// the ghost octs' cells: interpol_hydro of the father cell with its six neighbours, the father cell's acceleration
+// (hydro/godunov_fine.f90:563-626) -- into the free slots of the level's tiles
+template <int NV>
+__global__ __launch_bounds__(128) void plan_ghost_fill_kernel(double *__restrict__ uold, double *__restrict__ grav, const int *__restrict__ gslot,
+                                                              const int *__restrict__ gsten, int nghost, long ncell, long ncoarse, long ngd,
+                                                              int interpol_var, int interpol_type, double smallr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nghost) return;
   double u1[7][NV], u2[8][NV];
 #pragma unroll
   for (int j = 0; j < 7; j++) {
-    int c = c0;
-    if (j > 0) {
-      c = amrsweep::nbor_cell(c0, j - 1, T);
-      if (c < 0) c = -c;
-    }
+    const int c = gsten[(long)j * nghost + i];
 #pragma unroll
     for (int v = 0; v < NV; v++) u1[j][v] = uold[(long)v * ncell + c - 1];
   }
@@ -621,6 +631,7 @@ __global__ __launch_bounds__(128) void plan_ghost_fill_kernel(double *__restrict
 #pragma unroll
     for (int v = 0; v < NV; v++) uold[(long)v * ncell + o + (long)ind * ngd] = u2[ind][v];
   if (grav) {
+    const int c0 = gsten[i];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const double g = grav[(long)k * ncell + c0 - 1];
@@ -737,7 +748,7 @@ struct CommLevel {
 struct LevelPlan {
   int version = -1, ngrid = -1, ig_first = 0, ig_last = 0;      // the layout version of the level and the list the plan was made for
   int nghost = 0, nwork = 0, nevent = 0;
-  Buf gfather, gslot, gcell, work, corr, corr_tgt, flag, events;
+  Buf gfather, gslot, gcell, gsten, work, corr, corr_tgt, flag, events;
 };
 
 struct AmrRes {
@@ -1191,6 +1202,12 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
     HCHK(hipMemcpyAsync(P.gcell.p, v2.p, sizeof(int) * (size_t)P.nghost, hipMemcpyDeviceToDevice, s), "copy");
     HCHK(hipStreamSynchronize(s), "sync");
   }
+  if (P.nghost > 0) {
+    HCHK(P.gsten.ensure(sizeof(int) * 7 * (size_t)P.nghost), "hipMalloc");
+    hipLaunchKernelGGL(plan_ghost_stencil_kernel, dim3(grid_for((long)P.nghost * 7)), dim3(256), 0, s, R.son.as<int>(), R.nbor.as<int>(), P.gcell.as<int>(), P.nghost,
+                       R.ncoarse, R.ngridmax, P.gsten.as<int>());
+    HCHK(hipGetLastError(), "ghost stencil");
+  }
   // Work items = runs of flagged 8-plane chunks of a column, cut to at most `zrun` planes.  A workgroup fills a CU (LDS), so a
   // launch proceeds in rounds of ncu items, each costing its planes + 3 (the pipeline's prologue): take the cut that minimises
   // rounds x (planes + 3) -- long items for big levels (least redundant work), short ones when a level has few columns
@@ -1286,8 +1303,8 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
     if (int rc = build_plan(R, ilevel, ngrid, h_igrid, P)) return rc;
   if (P.nwork == 0) { done = true; return 0; }
   if (P.nghost > 0) {
-    hipLaunchKernelGGL(plan_ghost_fill_kernel<5>, dim3((P.nghost + 127) / 128), dim3(128), 0, s, R.uold.as<double>(), R.grav ? R.f.as<double>() : nullptr, R.son.as<int>(),
-                       R.nbor.as<int>(), P.gslot.as<int>(), P.gcell.as<int>(), P.nghost, R.ncell, R.ncoarse, R.ngridmax, interpol_var, interpol_type, p->smallr);
+    hipLaunchKernelGGL(plan_ghost_fill_kernel<5>, dim3((P.nghost + 127) / 128), dim3(128), 0, s, R.uold.as<double>(), R.grav ? R.f.as<double>() : nullptr,
+                       P.gslot.as<int>(), P.gsten.as<int>(), P.nghost, R.ncell, R.ncoarse, R.ngridmax, interpol_var, interpol_type, p->smallr);
     HCHK(hipGetLastError(), "ghost octs");
   }
   SweepArgs A;

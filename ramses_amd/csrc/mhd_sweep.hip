@@ -100,9 +100,10 @@ __global__ __launch_bounds__(256) void mhd_prim_kernel(MhdArgs A) {
 #pragma unroll
     for (int n = 0; n < 8; n++) A.q[(long)n * N + c_] = q[n];
     // the right faces must be the neighbours' left faces (see the header)
-    if (__double_as_longlong(br[0]) != __double_as_longlong(A.uold[5 * N + g.at(i + 1, j, k)])) bad++;
-    if (__double_as_longlong(br[1]) != __double_as_longlong(A.uold[6 * N + g.at(i, j + 1, k)])) bad++;
-    if (__double_as_longlong(br[2]) != __double_as_longlong(A.uold[7 * N + g.at(i, j, k + 1)])) bad++;
+    // (by VALUE: +0.0 and -0.0 are the same field)
+    if (!(br[0] == A.uold[5 * N + g.at(i + 1, j, k)])) bad++;
+    if (!(br[1] == A.uold[6 * N + g.at(i, j + 1, k)])) bad++;
+    if (!(br[2] == A.uold[7 * N + g.at(i, j, k + 1)])) bad++;
   }
   if (bad) atomicAdd(A.bad, bad);
 }
