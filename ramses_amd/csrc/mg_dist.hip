@@ -626,7 +626,7 @@ int ramses_amd_mgdist_multigrid_f90(ramses_amd_mgdist *M, int ilevel, int ngrid,
     if (lo[d] != M->coords[d] * M->dims[d]) return failf(RAMSES_AMD_EINVAL, "the rank's box does not start where its brick does");
   const long ncell = ncoarse + 8 * ngridmax;
   hipStream_t s = nullptr;
-  static DevArr d_vec, d_igrid, d_org, d_rho, d_phi;
+  static DevArr d_rho, d_phi;
   static std::vector<long> org;
   org.resize(ngrid);
   for (int g = 0; g < ngrid; g++) {
@@ -638,30 +638,28 @@ int ramses_amd_mgdist_multigrid_f90(ramses_amd_mgdist *M, int ilevel, int ngrid,
     }
     org[g] = o[0] + (long)M->dims[0] * (o[1] + (long)M->dims[1] * o[2]);
   }
-  HCHK(d_vec.ensure(sizeof(double) * ncell), "hipMalloc");
-  HCHK(d_igrid.ensure(sizeof(int) * ngrid), "hipMalloc");
-  HCHK(d_org.ensure(sizeof(long) * ngrid), "hipMalloc");
+  // Only the rank's own N cells cross PCIe (the cell vectors hold ncoarse + 8 ngridmax doubles, most of them other levels' or
+  // nobody's): the brick of the density is assembled on the host from the rank's octs, the brick of the potential is spread
+  // into the cell vector there -- two transfers of N doubles per solve instead of three of ncell.
+  static std::vector<double> h_brick;
+  h_brick.resize((size_t)N);
+  const long py = M->dims[0], pz = (long)M->dims[0] * M->dims[1];
+  for (int g = 0; g < ngrid; g++)
+    for (int ind = 0; ind < 8; ind++)
+      h_brick[(size_t)(org[g] + (ind & 1) + py * ((ind >> 1) & 1) + pz * ((ind >> 2) & 1))] = rho[ncoarse + (long)ind * ngridmax + (igrid[g] - 1)];
   HCHK(d_rho.ensure(sizeof(double) * N), "hipMalloc");
   HCHK(d_phi.ensure(sizeof(double) * N), "hipMalloc");
-  HCHK(hipMemcpyAsync(d_vec.p, rho, sizeof(double) * ncell, hipMemcpyHostToDevice, s), "H2D rho");
-  HCHK(hipMemcpyAsync(d_igrid.p, igrid, sizeof(int) * ngrid, hipMemcpyHostToDevice, s), "H2D igrid");
-  HCHK(hipMemcpyAsync(d_org.p, org.data(), sizeof(long) * ngrid, hipMemcpyHostToDevice, s), "H2D oct origins");
-  PackArgs A;
-  A.igrid = reinterpret_cast<const int *>(d_igrid.p); A.octorg = reinterpret_cast<const long *>(d_org.p);
-  A.ngrid = ngrid; A.n = n; A.nvar = 1;
-  A.ncoarse = ncoarse; A.ngridmax = ngridmax; A.ncell = ncell; A.pitch_var = N;
-  A.pitch_y = M->dims[0]; A.pitch_z = (long)M->dims[0] * M->dims[1];
-  A.brick = reinterpret_cast<double *>(d_rho.p); A.cellvec = reinterpret_cast<double *>(d_vec.p);
-  HCHK(launch_oct_copy(A, true, s), "gather launch");
+  HCHK(hipMemcpyAsync(d_rho.p, h_brick.data(), sizeof(double) * N, hipMemcpyHostToDevice, s), "H2D rho");
   M->safe_mode = *safe_mode ? 1 : 0;
   RCHK(ramses_amd_mgdist_solve(M, reinterpret_cast<const double *>(d_rho.p), rho_tot, fourpi, epsilon, iters, err, s));
   *safe_mode = M->safe_mode;
   RCHK(ramses_amd_mgdist_get_phi(M, reinterpret_cast<double *>(d_phi.p), s));
+  HCHK(hipMemcpyAsync(h_brick.data(), d_phi.p, sizeof(double) * N, hipMemcpyDeviceToHost, s), "D2H phi");
+  HCHK(hipStreamSynchronize(s), "sync");
   // phi of the rank's own cells into the cell vector (the other cells keep the host's values)
-  HCHK(hipMemcpyAsync(d_vec.p, phi, sizeof(double) * ncell, hipMemcpyHostToDevice, s), "H2D phi");
-  A.brick = reinterpret_cast<double *>(d_phi.p);
-  HCHK(launch_oct_copy(A, false, s), "scatter launch");
-  HCHK(hipMemcpyAsync(phi, d_vec.p, sizeof(double) * ncell, hipMemcpyDeviceToHost, s), "D2H phi");
+  for (int g = 0; g < ngrid; g++)
+    for (int ind = 0; ind < 8; ind++)
+      phi[ncoarse + (long)ind * ngridmax + (igrid[g] - 1)] = h_brick[(size_t)(org[g] + (ind & 1) + py * ((ind >> 1) & 1) + pz * ((ind >> 2) & 1))];
   HCHK(hipStreamSynchronize(s), "sync");
   return 0;
 }
