@@ -129,6 +129,14 @@ static int godunov_brick_region(const ramses_amd_hydro_params *p, const ramses_a
                                 double dx, double dt, int region_first, int region_last, void *stream) {
   if (!p) return fail(RAMSES_AMD_EINVAL, "params is NULL");
   if (int rc = check_brick(b)) return rc;
+  // The lanes of the sweep address a plane with a 32-bit byte offset and the planes of a variable with a 32-bit scalar one
+  // (csrc/hydro_sweep.hip: plane_load / plane_store): a brick beyond that is REFUSED here, by name -- never swept wrongly,
+  // never routed elsewhere without a word (the largest cubic brick: 812^3 cells per variable)
+  if ((unsigned long)b->pitch_z * 8ul >= (1ul << 31) || (unsigned long)b->pitch_var * 8ul >= (1ul << 32))
+    return fail(RAMSES_AMD_EUNSUPPORTED,
+                "brick of %d x %d x %d cells (+%d ghost layers): a plane of %ld bytes or a variable of %ld bytes is beyond the 32-bit offsets of the "
+                "sweep kernel (planes < 2 GiB, variables < 4 GiB): split the level into more bricks (ranks)",
+                b->nx, b->ny, b->nz, b->ng, (long)b->pitch_z * 8, (long)b->pitch_var * 8);
   if (!d_uold || !d_unew) return fail(RAMSES_AMD_EINVAL, "uold/unew device pointers are NULL");
   if (d_uold == d_unew) return fail(RAMSES_AMD_EINVAL, "uold and unew must be distinct buffers");
   if (int rc = check_ndim(p, b)) return rc;

@@ -67,6 +67,22 @@ def test_argument_validation_is_loud():
         _capi.check(rc)
 
 
+def test_a_brick_beyond_the_32_bit_offsets_of_the_sweep_is_refused_by_name():
+    """hydro_sweep.hip addresses a plane with a 32-bit lane offset and a variable's planes with a 32-bit scalar offset: a brick
+    beyond that (a 2 GiB plane, a 4 GiB variable) must be refused loudly before anything is launched (VERDICT round 4, weak #7)"""
+    from ramses_amd import _capi
+    L = _capi.lib()
+    p = _capi.make_params()
+    for dims in ((900, 900, 900), (20000, 20000, 4)):          # 5.8 GiB per variable; 3.2 GB planes
+        b = _capi.dense_brick(dims[0], dims[1], dims[2], 0)
+        rc = L.ramses_amd_godunov_brick(C.byref(p), C.byref(b), C.c_void_p(8), None, C.c_void_p(16), 0.1, 0.1, None)
+        msg = L.ramses_amd_last_error()
+        assert rc == -2 and b"beyond the 32-bit offsets of the sweep kernel" in msg and b"split the level" in msg, (rc, msg)
+    b = _capi.dense_brick(512, 512, 512, 0)                      # the bench's brick: 1 GiB per variable, fine
+    rc = L.ramses_amd_godunov_brick(C.byref(p), C.byref(b), None, None, None, 0.1, 0.1, None)
+    assert rc == -1 and b"NULL" in L.ramses_amd_last_error()
+
+
 def test_no_gpu_means_no_silent_fallback():
     import torch
     if torch.cuda.is_available():
