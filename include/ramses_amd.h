@@ -272,6 +272,19 @@ int ramses_amd_godunov_fine_f90(const ramses_amd_hydro_params *p, int ilevel, in
                                 double *unew, const double *f_or_dummy, int has_f,
                                 double dx, double dt);
 
+/* godunov_fine(ilevel) of an NDIM=1 / NDIM=2 build of the reference on its own arrays (hydro/godunov_fine.f90:5-35 with
+ * twotondim = 2 / 4 cells per oct; BASELINE config C1 = namelist/sedov1d.nml on one uniform level): a fully refined level
+ * without finer octs, one rank, hydro variables only (NVAR = NDIM + 2).  igrid = active(ilevel)%igrid; igrid_bound = the octs
+ * of boundary(1:nboundary,ilevel) (their cells were filled by make_boundary_hydro, amr/amr_step.f90:293: they become the
+ * ghost cells of the level's brick; directions without boundary octs are periodic); xg(1:ngridmax,1:ndim) in coarse-cell
+ * units, skip = (icoarse_min, jcoarse_min), nloc = interior coarse cells per direction.  The problem is embedded in a 3-D
+ * brick (ny and/or nz = 1) and swept by the dense kernel: bit-identical to the NDIM=1/2 reference in strict mode.  On exit
+ * unew(active cells) = uold + flux differences.  AMR levels of such builds are refused (the caller keeps the reference's
+ * routine for them). */
+int ramses_amd_godunov_fine_lowdim_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, int nbound,
+                                       const int *igrid_bound, const double *xg, int64_t ngridmax, int64_t ncoarse, const int *skip,
+                                       const int *nloc, const double *uold, double *unew, double dx, double dt);
+
 /* ---------------------------------------------------------------------------
  * multigrid_fine(ilevel,icount) on the reference's OWN arrays: the entry point
  * ramses_amd/patch/multigrid_fine_commons.f90 binds.  Replaces

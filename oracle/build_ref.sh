@@ -179,10 +179,16 @@ EOF
     echo "MISSING:$n" >&2; return 1
   }
   local objs=()
+  # a patch module that changed (the C ABI's interfaces, the shims' shared state) rebuilds everything that may `use` it:
+  # an object older than the newest module source of the patch directory is stale whatever its own source says
+  local newest_mod=""
+  if [ -n "$patch" ]; then
+    newest_mod=$(ls -t "$patch"/ramses_amd_*.f90 2>/dev/null | head -1)
+  fi
   for n in $MODSRC $extra_objs $AMRSRC $HYDROSRC $PMSRC $POISSONSRC ramses; do
     local src; src=$(find_src "$n")
     local o="$obj/$n.o"
-    if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "${FORCE:-0}" = 1 ]; then
+    if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || { [ -n "$newest_mod" ] && [ "$newest_mod" -nt "$o" ]; } || [ "${FORCE:-0}" = 1 ]; then
       $F90 $flags -c "$src" -o "$o" 2> "$obj/$n.log" || { cat "$obj/$n.log"; exit 1; }
     fi
     objs+=("$o")

@@ -179,6 +179,7 @@ SYMBOLS = [
     ("ramses_amd_mpires_sync_host", _i, [_vp]),
     ("ramses_amd_mpires_invalidate", _i, []),
     # residency for AMR runs
+    ("ramses_amd_godunov_fine_lowdim_f90", _i, [_PP, _i, _i, _vp, _i, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _d, _d]),
     ("ramses_amd_amrres_active", _i, []),
     ("ramses_amd_amrres_load", _i, [_i, _i64, _i64, _vp, _vp, _vp, _vp]),
     ("ramses_amd_amrres_tree", _i, [_vp, _vp, _vp]),

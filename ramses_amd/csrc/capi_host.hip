@@ -277,6 +277,123 @@ int ramses_amd_godunov_fine_amr_f90(const ramses_amd_hydro_params *p, int ilevel
                                           has_pfix ? enew_or_dummy : nullptr, dx, dt, nvector, interpol_var, interpol_type);
 }
 
+// godunov_fine(ilevel) of an NDIM = 1 or 2 build of the reference on its own arrays (BASELINE config C1: sedov1d.nml on one
+// uniform level): a fully refined level without finer octs, one rank, hydro only.  The level -- its active octs and, where
+// the box has physical boundaries, the octs of the boundary regions next to it (make_boundary_hydro has just filled them,
+// amr/amr_step.f90:293) -- is assembled by position into a brick with two ghost layers, embedded in three dimensions (ny and /
+// or nz = 1, the missing momentum components zero: the transverse slopes and flux differences vanish identically and the
+// dense sweep returns the 1-D / 2-D result of the reference bit for bit, tests/test_embedded_ndim_gpu.py); directions without
+// boundary octs are periodic.  The cell vectors are uold(1:ncell,1:ndim+2) with ncell = ncoarse + 2^ndim ngridmax; xg is
+// xg(1:ngridmax,1:ndim) in coarse-cell units, skip = (icoarse_min, jcoarse_min), nloc = interior coarse cells per direction.
+// The level is a few thousand cells: the brick is put together on the host.
+int ramses_amd_godunov_fine_lowdim_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, int nbound,
+                                       const int *igrid_bound, const double *xg, int64_t ngridmax, int64_t ncoarse, const int *skip,
+                                       const int *nloc, const double *uold, double *unew, double dx, double dt) {
+  if (!p || !igrid || !xg || !skip || !nloc || !uold || !unew || (nbound > 0 && !igrid_bound)) return fail(RAMSES_AMD_EINVAL, "NULL argument");
+  const int ndim = p->ndim;
+  if (ndim != 1 && ndim != 2) return fail(RAMSES_AMD_EINVAL, "ramses_amd_godunov_fine_lowdim_f90 is the entry of NDIM=1 and NDIM=2 builds (got NDIM=%d)", ndim);
+  if (p->nvar != ndim + 2) return fail(RAMSES_AMD_EUNSUPPORTED, "NDIM=%d device sweep: hydro variables only (NVAR=%d, got %d)", ndim, ndim + 2, p->nvar);
+  if (ilevel < 1 || ilevel > 20 || ngrid < 1 || nbound < 0) return fail(RAMSES_AMD_EINVAL, "bad level / oct count");
+  const int twotondim = 1 << ndim, nvh = ndim + 2;
+  const long ncell = ncoarse + (long)twotondim * ngridmax;
+  const long nx = (long)nloc[0] << ilevel, ny = ndim > 1 ? (long)nloc[1] << ilevel : 1;
+  if ((long)ngrid * twotondim != nx * ny)
+    return fail(RAMSES_AMD_EUNSUPPORTED, "level %d is not fully refined (%d octs, %ld x %ld cells): AMR levels of NDIM<3 runs stay the reference's", ilevel,
+                ngrid, nx, ny);
+  if (nx > 65536 || ny > 65536 || nx * ny > (1L << 26)) return fail(RAMSES_AMD_EUNSUPPORTED, "level too large for the host-assembled brick");
+  ramses_amd_brick b;
+  ramses_amd_brick_dense(&b, (int)nx, (int)ny, 1, 2);
+  const int ng = 2;
+  const long NX = nx + 2 * ng, NY = ny + 2 * ng, NZ = 1 + 2 * ng;
+  if (b.pitch_y != NX || b.pitch_z != NX * NY || b.pitch_var != NX * NY * NZ) return fail(RAMSES_AMD_EINVAL, "unexpected brick pitches");
+  static std::vector<double> hb;
+  static std::vector<unsigned char> got;
+  hb.assign((size_t)5 * b.pitch_var, 0.0);
+  got.assign((size_t)NX * NY, 0);
+  // the embedded variables: rho, rho u [, rho v], E  ->  rho, rho u, rho v, rho w, E
+  int vmap[4];
+  vmap[0] = 0; vmap[1] = 1;
+  if (ndim == 2) { vmap[2] = 2; vmap[3] = 4; } else { vmap[2] = 4; vmap[3] = -1; }
+  const double scale_l = (double)(1L << ilevel);
+  long nghost_filled[2] = {0, 0};
+  auto place = [&](int g, bool active) -> int {
+    long o[2] = {0, 0};
+    for (int d = 0; d < ndim; d++) {
+      const double xc = (xg[(long)d * ngridmax + g - 1] - (double)skip[d]) * scale_l - 1.0;     // left cell of the oct
+      const long r = std::lround(xc);
+      if (std::fabs(xc - (double)r) > 1e-6) return fail(RAMSES_AMD_EINVAL, "oct %d of level %d does not sit on the level lattice", g, ilevel);
+      o[d] = r;
+    }
+    for (int ind = 0; ind < twotondim; ind++) {
+      const long ci = o[0] + (ind & 1), cj = ndim > 1 ? o[1] + ((ind >> 1) & 1) : 0;
+      const bool inside = ci >= 0 && ci < nx && cj >= 0 && cj < ny;
+      if (active && !inside) return fail(RAMSES_AMD_EINVAL, "active oct %d lies outside the box", g);
+      if (ci < -ng || ci >= nx + ng || cj < -(ndim > 1 ? ng : 0) || cj >= ny + (ndim > 1 ? ng : 0)) continue;   // deeper boundary layers: not read
+      const long at = (ci + ng) + NX * ((ndim > 1 ? cj + ng : ng) + NY * (long)ng);
+      const long icell = ncoarse + (long)ind * ngridmax + g - 1;
+      for (int v = 0; v < nvh; v++) hb[(size_t)vmap[v] * b.pitch_var + at] = uold[(size_t)v * ncell + icell];
+      got[(size_t)((ci + ng) + NX * (ndim > 1 ? cj + ng : ng))] = 1;
+      if (!inside) { if (ci < 0 || ci >= nx) nghost_filled[0]++; else nghost_filled[1]++; }
+    }
+    return 0;
+  };
+  for (int i = 0; i < ngrid; i++) if (int rc = place(igrid[i], true)) return rc;
+  for (int i = 0; i < nbound; i++) if (int rc = place(igrid_bound[i], false)) return rc;
+  // a direction is bounded when boundary octs filled its ghost cells (then all of them must be there), periodic otherwise
+  bool bounded[2] = {nghost_filled[0] > 0, ndim > 1 && nghost_filled[1] > 0};
+  int periodic_axes = 4;                                  // z is always a copy of the plane
+  if (!bounded[0]) periodic_axes |= 1;
+  if (ndim == 1 || !bounded[1]) periodic_axes |= 2;
+  for (long j = 0; j < (ndim > 1 ? NY : 1); j++)
+    for (long i = 0; i < NX; i++) {
+      const bool gx = i < ng || i >= nx + ng, gy = ndim > 1 && (j < ng || j >= ny + ng);
+      if (!gx && !gy) continue;
+      // ghost cells of a bounded direction come from the boundary octs; those of a periodic one are filled on the device
+      const bool need = (gx && bounded[0] && !(gy && !bounded[1])) || (gy && bounded[1] && !(gx && !bounded[0]));
+      if (need && !got[(size_t)(i + NX * (ndim > 1 ? j : ng))])
+        return fail(RAMSES_AMD_EUNSUPPORTED, "level %d: the boundary regions do not cover ghost cell (%ld,%ld) of the level's brick", ilevel, i - ng, j - ng);
+    }
+  {
+    static bool said = false;
+    if (!said) {
+      said = true;
+      printf(" ramses_amd: NDIM=%d: level %d (%ld x %ld cells) is swept on the device as a brick embedded in 3-D; x %s, y %s\n", ndim, ilevel, nx, ny,
+             bounded[0] ? "between boundary octs" : "periodic", ndim == 1 ? "-" : (bounded[1] ? "between boundary octs" : "periodic"));
+      fflush(stdout);
+    }
+  }
+  if (int rc = resident_release("godunov_fine (NDIM<3 brick sweep)")) return rc;
+  hipStream_t s = nullptr;
+  HostCtx &H = g_host;
+#define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hipfail(e_, what); } while (0)
+  const size_t bytes = sizeof(double) * 5 * (size_t)b.pitch_var;
+  HCHK(H.bold.ensure(bytes), "hipMalloc brick"); HCHK(H.bnew.ensure(bytes), "hipMalloc brick");
+  HCHK(hipMemcpyAsync(H.bold.p, hb.data(), bytes, hipMemcpyHostToDevice, s), "H2D brick");
+  // periodic directions, x first: a later direction copies the ghosts the earlier ones filled (corners)
+  for (int axis = 0; axis < 3; axis++)
+    if (periodic_axes & (1 << axis))
+      if (int rc = ramses_amd_fill_ghosts_periodic(&b, H.bold.as<double>(), 5, 1 << axis, s)) return rc;
+  ramses_amd_hydro_params q = *p;
+  q.nvar = 5;
+  if (int rc = ramses_amd_godunov_brick(&q, &b, H.bold.as<double>(), nullptr, H.bnew.as<double>(), dx, dt, s)) return rc;
+  HCHK(hipMemcpyAsync(hb.data(), H.bnew.p, bytes, hipMemcpyDeviceToHost, s), "D2H brick");
+  HCHK(hipStreamSynchronize(s), "sync");
+#undef HCHK
+  // unew(active cells) = uold + flux differences, as after the reference's set_unew + godunov_fine
+  for (int i = 0; i < ngrid; i++) {
+    const int g = igrid[i];
+    long o[2] = {0, 0};
+    for (int d = 0; d < ndim; d++) o[d] = std::lround((xg[(long)d * ngridmax + g - 1] - (double)skip[d]) * scale_l - 1.0);
+    for (int ind = 0; ind < twotondim; ind++) {
+      const long ci = o[0] + (ind & 1), cj = ndim > 1 ? o[1] + ((ind >> 1) & 1) : 0;
+      const long at = (ci + ng) + NX * ((ndim > 1 ? cj + ng : ng) + NY * (long)ng);
+      const long icell = ncoarse + (long)ind * ngridmax + g - 1;
+      for (int v = 0; v < nvh; v++) unew[(size_t)v * ncell + icell] = hb[(size_t)vmap[v] * b.pitch_var + at];
+    }
+  }
+  return 0;
+}
+
 // Fortran-friendly variant: f is always a valid array (ignored when has_f==0)
 int ramses_amd_godunov_fine_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid,
                                 const int *igrid, const double *xg, int64_t ngridmax,

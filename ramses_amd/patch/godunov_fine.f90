@@ -138,6 +138,15 @@ subroutine godunov_fine(ilevel)
   scale=boxlen/dble(nx_loc)
   dx=0.5d0**ilevel*scale
 
+#if NDIM<3
+  ! NDIM = 1, 2 (BASELINE config C1: sedov1d.nml on one uniform level): a fully refined level without finer octs goes to
+  ! the dense sweep, embedded in a 3-D brick with the boundary octs as its ghost cells (csrc/capi_host.hip
+  ! ramses_amd_godunov_fine_lowdim_f90); AMR levels, several ranks, self-gravity, difmag, pressure_fix and passive scalars
+  ! of such builds stay the reference's routine (said once).
+  call ramses_amd_godunov_lowdim(ilevel,p,dx)
+  return
+#endif
+
 #ifndef WITHOUTMPI
   ! MPI, one rank per GPU: the dense sweep on the rank's resident brick (ghost layer kept current
   ! by the device halo exchange, virtual_boundaries.f90 of this directory)
@@ -214,3 +223,56 @@ subroutine godunov_fine(ilevel)
 111 format('   Entering godunov_fine (MI355X) for level ',i2)
 
 end subroutine godunov_fine
+
+
+#if NDIM<3
+!------------------------------------------------------------------------------
+! godunov_fine(ilevel) of an NDIM = 1 / 2 build (see godunov_fine above)
+!------------------------------------------------------------------------------
+subroutine ramses_amd_godunov_lowdim(ilevel,p,dx)
+  use amr_commons
+  use hydro_commons
+  use ramses_amd_iface
+  implicit none
+  integer::ilevel
+  type(ramses_amd_hydro_params)::p
+  real(dp)::dx
+  integer::rc,ib,i,nb,skip(2),nloc(2)
+  integer(kind=8)::ncells_int
+  integer,allocatable::blist(:)
+  logical::ok
+  logical,save::said=.false.
+  skip(1)=icoarse_min; nloc(1)=icoarse_max-icoarse_min+1
+  skip(2)=jcoarse_min; nloc(2)=jcoarse_max-jcoarse_min+1
+  ncells_int=int(nloc(1),8)*2_8**ilevel
+  if(ndim>1)ncells_int=ncells_int*int(nloc(2),8)*2_8**ilevel
+  ok=ncpu==1.and..not.poisson.and.difmag<=0.0d0.and..not.pressure_fix.and.nvar==ndim+2
+  if(ilevel<nlevelmax)then
+     if(numbtot(1,ilevel+1)>0)ok=.false.
+  end if
+  if(int(active(ilevel)%ngrid,8)*int(twotondim,8)/=ncells_int)ok=.false.
+  if(.not.ok)then
+     if(.not.said.and.myid==1)write(*,*)'ramses_amd: NDIM<3 build: levels that are not uniform (or runs with gravity, difmag, ', &
+          & 'pressure_fix, passive scalars, several ranks) keep the reference godunov_fine'
+     said=.true.
+     call godunov_fine_reference(ilevel)
+     return
+  end if
+  nb=0
+  do ib=1,nboundary
+     nb=nb+boundary(ib,ilevel)%ngrid
+  end do
+  allocate(blist(max(nb,1)))
+  nb=0
+  do ib=1,nboundary
+     do i=1,boundary(ib,ilevel)%ngrid
+        blist(nb+i)=boundary(ib,ilevel)%igrid(i)
+     end do
+     nb=nb+boundary(ib,ilevel)%ngrid
+  end do
+  rc=ramses_amd_godunov_fine_lowdim_f90(p,ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),nb,blist,xg, &
+       & int(ngridmax,8),int(ncoarse,8),skip,nloc,uold,unew,dx,dtnew(ilevel))
+  deallocate(blist)
+  if(rc/=0)call ramses_amd_fatal('godunov_fine (NDIM<3)')
+end subroutine ramses_amd_godunov_lowdim
+#endif

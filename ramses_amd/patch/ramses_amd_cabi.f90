@@ -123,6 +123,19 @@ module ramses_amd_cabi
        real(c_double), value :: dx, dt
        integer(c_int) :: rc
      end function ramses_amd_godunov_fine_f90
+     ! NDIM = 1, 2 builds: a fully refined level, active octs + the octs of the boundary regions (csrc/capi_host.hip)
+     function ramses_amd_godunov_fine_lowdim_f90(p, ilevel, ngrid, igrid, nbound, igrid_bound, xg, ngridmax, ncoarse, skip, nloc, &
+          & uold, unew, dx, dt) bind(C, name='ramses_amd_godunov_fine_lowdim_f90') result(rc)
+       import :: ramses_amd_hydro_params, c_int, c_int64_t, c_double
+       type(ramses_amd_hydro_params), intent(in) :: p
+       integer(c_int), value :: ilevel, ngrid, nbound
+       integer(c_int) :: igrid(*), igrid_bound(*), skip(*), nloc(*)
+       real(c_double) :: xg(*)
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       real(c_double) :: uold(*), unew(*)
+       real(c_double), value :: dx, dt
+       integer(c_int) :: rc
+     end function ramses_amd_godunov_fine_lowdim_f90
      function ramses_amd_multigrid_fine_f90(ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, &
           & rho, phi, rho_tot, fourpi, epsilon, safe_mode, iters, err) &
           & bind(C, name='ramses_amd_multigrid_fine_f90') result(rc)
