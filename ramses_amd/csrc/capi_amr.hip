@@ -778,7 +778,7 @@ struct AmrRes {
   long tile_sweeps = 0, tree_sweeps = 0;
   bool announced = false;
   const double *h_uold = nullptr;
-  Buf uold, unew, son, nbor, father, igrid, work, err, red, okbuf, pack;
+  Buf uold, unew, son, nbor, father, work, err, red, okbuf, pack;
   Buf xg;                // xg(1:ngridmax,1:3) (rho_fine's deposit needs the oct centres); sent with the tree when gravity is on
   bool xg_valid = false;
   Buf mp, rho, posof, mpscratch, lists;   // rho_fine: multipoles (4, ncell), the deposit (ncell), oct -> list position, scan scratch
@@ -1150,7 +1150,7 @@ int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, co
 
 namespace {
 
-// the plan of a level in tiles for the list in R.igrid (see plan_* above); rebuilt when the layout or the list changed
+// the plan of a level in tiles for the list of the call (R.cur_ig; see plan_* above); rebuilt when the layout or the list changed
 int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &P) {
   amrlayout::LevelMap &L = R.map.lev[ilevel];
   hipStream_t s = nullptr;
