@@ -1104,6 +1104,8 @@ int ramses_amd_amrres_courant(const ramses_amd_hydro_params *p, int ngrid, const
   LvlArgs A;
   if (int rc = set_level(g_ar, ngrid, igrid, A)) return rc;
   AmrRes &R = g_ar;
+  // (dt is a minimum; the diagnostic sums are added per workgroup in workgroup order either way, not in the reference's)
+  if (int rc = sorted_list(R, A)) return rc;
   const double dt0 = p->courant_factor * dx / p->smallc;
   hipLaunchKernelGGL(lvl_courant_init_kernel, dim3(1), dim3(1), 0, nullptr, R.red.as<double>(), dt0);
   if (ngrid > 0) {
@@ -1130,6 +1132,7 @@ int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, co
   if (ngrid == 0) return 0;
   if (A.nvar < 5) return failf(RAMSES_AMD_EUNSUPPORTED, "NVAR");
   AmrRes &R = g_ar;
+  if (int rc = sorted_list(R, A)) return rc;          // (the flagged cells come back sorted anyway)
   HCHK(R.okbuf.ensure(sizeof(int) * (8 * (size_t)ngrid + 1)), "hipMalloc");
   int *d_count = R.okbuf.as<int>(), *d_list = d_count + 1;
   HCHK(hipMemsetAsync(d_count, 0, sizeof(int), nullptr), "memset");
