@@ -4,7 +4,7 @@
 mkdir -p gpurun_out
 R=$PWD
 export TMPDIR=/tmp
-( time timeout 1300 python -m pytest tests -m gpu -q --timeout 600 --durations=12 ) > gpurun_out/r05_final_pytest_gpu.txt 2>&1
+( time timeout 1300 python -m pytest tests -m gpu -q --timeout 600 --durations=12 ) > gpurun_out/r05_final_pytest_gpu.txt 2>&1; [ "${ONLY_TESTS:-0}" = 1 ] && { tail -8 gpurun_out/r05_final_pytest_gpu.txt; exit 0; }
 tail -24 gpurun_out/r05_final_pytest_gpu.txt | cut -c1-300
 timeout 600 python bench.py > gpurun_out/r05_final_bench_default.json 2> gpurun_out/r05_final_bench_default.err
 cut -c1-400 gpurun_out/r05_final_bench_default.json
