@@ -11,7 +11,7 @@ CMD=("$@")
 cd /tmp && export TMPDIR=/tmp
 pass() {
   local name=$1; shift
-  (cd $REPO && timeout 300 rocprofv3 --pmc "$@" --kernel-include-regex "$KREGEX" -f csv -d $OUT/$name -o c -- "${CMD[@]}") > $OUT/$name.log 2>&1
+  (cd $REPO && timeout ${PMC_TIMEOUT:-300} rocprofv3 --pmc "$@" --kernel-include-regex "$KREGEX" -f csv -d $OUT/$name -o c -- "${CMD[@]}") > $OUT/$name.log 2>&1
 }
 pass a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES
 pass c SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS
