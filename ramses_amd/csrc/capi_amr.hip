@@ -747,6 +747,7 @@ struct CommLevel {
 // what the dense sweep of a level in tiles needs beyond the cell vectors (see plan_* above), valid for one layout and one list
 struct LevelPlan {
   int version = -1, ngrid = -1, ig_first = 0, ig_last = 0;      // the layout version of the level and the list the plan was made for
+  int ig_sample[10] = {0};                                        // (ten entries of it, spread over the list: the fingerprint of the list cache)
   int nghost = 0, nwork = 0, nevent = 0;
   Buf gfather, gslot, gcell, gsten, work, corr, corr_tgt, flag, events;
   void release() {
@@ -1277,6 +1278,7 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   if (nw > 0) HCHK(hipMemcpy(P.work.p, order.data(), sizeof(int) * 4 * (size_t)nw, hipMemcpyHostToDevice), "H2D work list");
   P.nwork = nw;
   P.ngrid = ngrid; P.ig_first = ngrid > 0 ? h_igrid[0] : 0; P.ig_last = ngrid > 0 ? h_igrid[ngrid - 1] : 0;
+  for (int k = 0; k < 10; k++) P.ig_sample[k] = h_igrid[(long)k * (ngrid - 1) / 9];
   P.version = L.version;
   return 0;
 }
@@ -1311,7 +1313,9 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
   // (the plan of a level that kept its layout survives a regrid of the finer levels: its octs, ghosts and work items are the same.
   //  The list of a level must not change between two regrids without its first or last entry or its length changing: it is
   //  active(ilevel)%igrid, which only build_comm / refine_fine / load_balance rewrite.)
-  if (P.version != L.version || P.ngrid != ngrid || P.ig_first != h_igrid[0] || P.ig_last != h_igrid[ngrid - 1])
+  bool same_list = P.version == L.version && P.ngrid == ngrid && P.ig_first == h_igrid[0] && P.ig_last == h_igrid[ngrid - 1];
+  for (int k = 0; same_list && k < 10; k++) same_list = P.ig_sample[k] == h_igrid[(long)k * (ngrid - 1) / 9];
+  if (!same_list)
     if (int rc = build_plan(R, ilevel, ngrid, h_igrid, P)) return rc;
   if (P.nwork == 0) { done = true; return 0; }
   if (P.nghost > 0) {
