@@ -346,11 +346,11 @@ def amr_resident_bench(level=8, steps=5, kind="covered"):
     """godunov_fine of a level of a RESIDENT AMR run (ramses_amd_amrres_godunov: the path the patched program takes).  The device
     numbers the octs itself -- levels in tiles of 32 x 4 x 4 octs (csrc/amr_layout.hpp) -- and sweeps such a level with the dense
     z-marching kernel in place (ghost octs interpolated into free tile slots, fluxes owed to the coarser level filed and
-    replayed); the same call with RAMSES_AMD_TILE_DENSE=0 / RAMSES_AMD_COVERED_DENSE=0 walks the tree on the same layout.
+    computed by a surface pass and replayed); the same call with RAMSES_AMD_TILE_DENSE=0 / RAMSES_AMD_COVERED_DENSE=0 walks the tree on the same layout.
       kind="full"     level `level` complete, nothing finer                (the tree-walking sweep's best case)
       kind="covered"  level `level` complete, level+1 in a spherical shell (levelmin of an AMR run: refined cells inside)
       kind="partial"  level `level` in a spherical shell over a complete level-1 (ghost octs and coarse-fine fluxes on both surfaces)
-    Strict arithmetic in all of them.  Timed with events around the call (list upload, ghost pre-pass, sweep, replay)."""
+    Strict arithmetic is the headline of each leg, the fast build (the drop-in's default) rides beside it.  Timed with events around the call (list upload, ghost pre-pass, sweep, replay)."""
     import numpy as np
     import torch
     import ramses_amd
@@ -375,10 +375,10 @@ def amr_resident_bench(level=8, steps=5, kind="covered"):
     u[4] = 1e-5 / 0.4
     u[4, T["ncoarse"] + int(igrid[0]) - 1] = (1e-5 + 0.4 * 0.125 / dx ** 3) / 0.4
     vp = lambda a: a.ctypes.data_as(C.c_void_p)      # noqa: E731
-    p = ramses_amd.make_params(courant_factor=0.8)
     L = lib()
     out = {}
-    for tag, env in (("dense", "1"), ("tree", "0")):
+    for tag, env, fast in (("dense", "1", False), ("dense_fast", "1", True), ("tree", "0", False)):
+        p = ramses_amd.make_params(courant_factor=0.8, fast_math=fast)
         os.environ["RAMSES_AMD_COVERED_DENSE"] = env
         os.environ["RAMSES_AMD_TILE_DENSE"] = env
         check(L.ramses_amd_amrres_invalidate())
@@ -407,6 +407,7 @@ def amr_resident_bench(level=8, steps=5, kind="covered"):
     os.environ.pop("RAMSES_AMD_TILE_DENSE", None)
     check(L.ramses_amd_amrres_invalidate())
     ms, took, tiled = out["dense"]
+    ms_fast = out["dense_fast"][0]
     gbs = ncells * BYTES_PER_CELL_UPDATE_AMR / (ms * 1e-3) / 1e9
     work = {"full": "level %d complete (%d^3), nothing finer" % (level, 2 ** level),
             "covered": "level %d complete (%d^3), level %d in a spherical shell: %d of its cells refined" % (level, n, level + 1, 0 if mask is None else int(mask.sum())),
@@ -416,8 +417,11 @@ def amr_resident_bench(level=8, steps=5, kind="covered"):
             "dense_sweeps_taken": int(took), "levels_in_tiles": int(tiled), "tree_walking_ms_per_sweep": out["tree"][0],
             "tree_walking_frac": ncells * BYTES_PER_CELL_UPDATE_AMR / (out["tree"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "arithmetic": "strict (bit-identical to the reference)", "workload": work,
+            "fast_arithmetic": {"ms_per_sweep": ms_fast, "value": ncells / (ms_fast * 1e-3),
+                                "frac": ncells * BYTES_PER_CELL_UPDATE_AMR / (ms_fast * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "note": "the patched program's default on tiled levels (<= 1e-12 of the reference: tests/test_fast_certificate_gpu.py)"},
             "layout": "device numbering: tiles of 32x4x4 octs (csrc/amr_layout.hpp); host tree numbered along a Z-order curve",
-            "includes": "oct list upload, ghost-oct interpolation pre-pass, the dense sweep in place on the cell vectors, the replay of the "
+            "includes": "oct list upload, ghost-oct interpolation pre-pass, the surface pass (fluxes owed to the coarser level), the dense sweep in place on the cell vectors, the replay of the "
                         "fluxes owed to the coarser level; HIP events around ramses_amd_amrres_godunov",
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "bytes_per_cell": BYTES_PER_CELL_UPDATE_AMR}}

@@ -932,6 +932,35 @@ int ramses_amd_mhd_resident_set_uold_f90(int ilevel);
 int ramses_amd_mhd_resident_sync_host_f90(double *uold);
 int ramses_amd_mhd_resident_invalidate(void);
 
+/* SOLVER=mhd on the levels of an AMR tree: godfine1 as the reference writes it (mhd/godunov_fine.f90:538-1459) -- the 6^3
+ * stencil of every oct through get3cubefather (amr/nbors_utils.f90:5-194), missing neighbour octs interpolated from the
+ * coarser level by interpol_hydro (mhd/interpol_hydro.f90:612-793: limited slopes for the Euler variables, the
+ * divergence-free face interpolation interpol_mag :990-1047 with interpol_faces :1052-1241, copy_from_refined_faces
+ * :1246-1349, cmp_central_faces :1354-1473, compute_2d_tvd :1478-1527), mag_unsplit (mhd/umuscl.f90:31-238) on the stencil,
+ * fluxes and EMFs reset next to refined cells (:760-903), the update of unew with constrained transport (:909-1022) and the
+ * flux / EMF corrections of the leaf cells of level ilevel-1 (:1024-1457) added in the reference's order (batches of nvector
+ * octs of the list; Euler system per direction and side, then the twelve edges).  Bit-identical to the reference.
+ *   ramses_amd_mhd_godfine_amr_device    device arrays: d_uold / d_unew [11][ncell] (uold(1:ncell,1:nvar+3)), d_f [3][ncell]
+ *                                        or NULL (gravity: ctoprim's half kick), the tree son [ncell], nbor [6][ngridmax],
+ *                                        father [ngridmax], d_igrid the octs of the call; coarse != 0: ilevel > levelmin.
+ *   ramses_amd_mhd_godunov_fine_amr_f90  the same on the reference's host arrays (staged: ramses_amd/patch_mhd/godunov_fine.f90)
+ *                                        (f is read when use_f != 0: poisson)
+ *   ramses_amd_mhd_amr_sweeps / _octs    calls / octs swept so far
+ *   ramses_amd_mhd_note_reference_sweep  the drop-in reports a level it hands to the reference's host godunov_fine instead; the
+ *                                        library prints both counts, per level, in one line at exit
+ * Levels >= 3 of a periodic box; interpol_var 0..1, interpol_type 0..3, interpol_mag_type 0..3 (-1 resolved by the caller). */
+int ramses_amd_mhd_godfine_amr_device(const ramses_amd_mhd_params *p, int ilevel, int ngrid, const int *d_igrid, const int *d_son,
+                                      const int *d_nbor, const int *d_father, int64_t ngridmax, int64_t ncoarse, const double *d_uold,
+                                      double *d_unew, const double *d_f, double dx, double dt, int nvector, int interpol_var,
+                                      int interpol_type, int interpol_mag_type, int coarse, void *stream);
+int ramses_amd_mhd_godunov_fine_amr_f90(const ramses_amd_mhd_params *p, int ilevel, int levelmin, int ngrid, const int *igrid,
+                                        const int *son, const int *nbor, const int *father, int64_t ngridmax, int64_t ncoarse,
+                                        const double *uold, double *unew, const double *f, int use_f, double dx, double dt,
+                                        int nvector, int interpol_var, int interpol_type, int interpol_mag_type);
+int64_t ramses_amd_mhd_amr_sweeps(void);
+int64_t ramses_amd_mhd_amr_octs(void);
+int ramses_amd_mhd_note_reference_sweep(int ilevel);
+
 #ifdef __cplusplus
 }
 #endif

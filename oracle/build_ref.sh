@@ -183,7 +183,7 @@ EOF
   # an object older than the newest module source of the patch directory is stale whatever its own source says
   local newest_mod=""
   if [ -n "$patch" ]; then
-    newest_mod=$(ls -t "$patch"/ramses_amd_*.f90 2>/dev/null | head -1)
+    newest_mod=$(ls -t "$patch"/ramses_amd_*.f90 2>/dev/null | head -1 || true)      # (a patch directory without modules: dump_patch)
   fi
   for n in $MODSRC $extra_objs $AMRSRC $HYDROSRC $PMSRC $POISSONSRC ramses; do
     local src; src=$(find_src "$n")

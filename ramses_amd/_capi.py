@@ -215,6 +215,11 @@ SYMBOLS = [
     ("ramses_amd_mhd_resident_set_uold_f90", _i, [_i]),
     ("ramses_amd_mhd_resident_sync_host_f90", _i, [_vp]),
     ("ramses_amd_mhd_resident_invalidate", _i, []),
+    ("ramses_amd_mhd_godfine_amr_device", _i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _d, _d, _i, _i, _i, _i, _i, _vp]),
+    ("ramses_amd_mhd_godunov_fine_amr_f90", _i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i, _d, _d, _i, _i, _i, _i]),
+    ("ramses_amd_mhd_note_reference_sweep", _i, [_i]),
+    ("ramses_amd_mhd_amr_sweeps", _i64, []),
+    ("ramses_amd_mhd_amr_octs", _i64, []),
     ("ramses_amd_amrres_rho_mpi_multipole", _i, [_PP, _i, _i, _i, _vp, _d]),
     ("ramses_amd_amrres_rho_mpi_deposit", _i, [_i, _i, _d]),
     ("ramses_amd_amrres_rho_mpi_finish", _i, [_i, _i, _i, _vp, _vp, _vp]),

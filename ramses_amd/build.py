@@ -39,6 +39,7 @@ UNITS = [
     ("pois_amr.o", "pois_amr.hip", ["-ffp-contract=off"]),
     ("mg_dist.o", "mg_dist.hip", ["-ffp-contract=off"]),
     ("mhd_sweep.o", "mhd_sweep.hip", ["-ffp-contract=off"]),
+    ("mhd_amr.o", "mhd_amr.hip", ["-ffp-contract=off"]),
 ]
 
 

@@ -518,22 +518,28 @@ __global__ __launch_bounds__(256) void plan_target_kernel(PlanArgs A, int *corr_
 // csrc/amr_sweep.hip, with the records indexed by device oct instead of list position.)
 // the (list position, face) pairs that owe something: io * 6 + f, in whatever order the waves arrive (the replay picks the
 // first creditor of a coarse cell by the reference's key, not by this order)
-__global__ __launch_bounds__(256) void plan_events_kernel(PlanArgs A, const int *__restrict__ corr_tgt, int *__restrict__ events, int *__restrict__ count) {
+__global__ __launch_bounds__(256) void plan_events_kernel(PlanArgs A, const int *__restrict__ corr_tgt, int *__restrict__ events, int *__restrict__ count,
+                                                          int *__restrict__ evt_of) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   bool have = false;
-  if (t < (long)A.n * 6) have = corr_tgt[((long)A.ig[t / 6] - A.base) * 6 + t % 6] > 0;
+  long sf = 0;
+  if (t < (long)A.n * 6) { sf = ((long)A.ig[t / 6] - A.base) * 6 + t % 6; have = corr_tgt[sf] > 0; }
   const unsigned long long m = __ballot(have);
   if (m) {
     const int lane = threadIdx.x & 63;
     int b = 0;
     if (lane == 0) b = atomicAdd(count, __popcll(m));
     b = __shfl(b, 0, 64);
-    if (have) events[b + __popcll(m & ((1ull << lane) - 1ull))] = (int)t;
+    if (have) {
+      const int e = b + __popcll(m & ((1ull << lane) - 1ull));
+      events[e] = (int)t;
+      evt_of[sf] = e;              // where the surface pass files this (oct, face)'s four fluxes
+    }
   }
 }
 __global__ __launch_bounds__(256) void tile_coarse_update_kernel(PlanArgs A, double *__restrict__ unew, const double *__restrict__ corr,
-                                                                 const int *__restrict__ corr_tgt, const int *__restrict__ events, int nevent, int nvector,
-                                                                 int NV) {
+                                                                 const int *__restrict__ corr_tgt, const int *__restrict__ evt_of,
+                                                                 const int *__restrict__ events, int nevent, int nvector, int NV) {
   const long e0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e0 >= nevent) return;
   const long ev = events[e0];
@@ -574,7 +580,7 @@ __global__ __launch_bounds__(256) void tile_coarse_update_kernel(PlanArgs A, dou
   for (int v = 0; v < NV; v++) {
     double val = unew[(long)v * A.ncell + C - 1];
     for (int i = 0; i < n; i++) {
-      const double *c = corr + src[i] * 4 * CV;
+      const double *c = corr + (long)evt_of[src[i]] * 4 * CV;
       const bool left = ((src[i] % 6) & 1) == 0;
       for (int q = 0; q < 4; q++) {
         const double t = c[q * CV + v] * oneontwotondim;
@@ -749,9 +755,9 @@ struct LevelPlan {
   int version = -1, ngrid = -1, ig_first = 0, ig_last = 0;      // the layout version of the level and the list the plan was made for
   int ig_sample[10] = {0};                                        // (ten entries of it, spread over the list: the fingerprint of the list cache)
   int nghost = 0, nwork = 0, nevent = 0;
-  Buf gfather, gslot, gcell, gsten, work, corr, corr_tgt, flag, events;
+  Buf gfather, gslot, gcell, gsten, work, corr, corr_tgt, evt_of, flag, events;
   void release() {
-    for (Buf *b : {&gfather, &gslot, &gcell, &gsten, &work, &corr, &corr_tgt, &flag, &events}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    for (Buf *b : {&gfather, &gslot, &gcell, &gsten, &work, &corr, &corr_tgt, &evt_of, &flag, &events}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     version = -1;
   }
 };
@@ -1167,12 +1173,12 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   HCHK(P.gfather.ensure(sizeof(int) * (size_t)L.cap), "hipMalloc");
   const int gcap = (int)std::min<long>(L.cap - L.n, (long)ngrid * 26);
   HCHK(P.gslot.ensure(sizeof(int) * (size_t)(gcap > 0 ? gcap : 1)), "hipMalloc"); HCHK(P.gcell.ensure(sizeof(int) * (size_t)(gcap > 0 ? gcap : 1)), "hipMalloc");
-  // flux records and their targets per slot of the level's index range (what a cell's lane can address without a load)
+  // per slot of the level's index range and face: the leaf cell of the coarser level behind it, and the event that carries its
+  // four flux records (events = the (oct of the list, face) pairs with such a cell, compacted: the records take
+  // nevent x 4 x (nvar + 2) doubles -- a level without a surface has none)
   HCHK(P.corr_tgt.ensure(sizeof(int) * (size_t)L.cap * 6), "hipMalloc");
   HCHK(hipMemsetAsync(P.corr_tgt.p, 0, sizeof(int) * (size_t)L.cap * 6, s), "memset");
-  const size_t corr_bytes = sizeof(double) * (size_t)L.cap * 6 * 4 * (size_t)(R.nvar + 2);
-  if (P.corr.cap < corr_bytes) { HCHK(P.corr.ensure(corr_bytes), "hipMalloc flux records"); }
-  HCHK(hipMemsetAsync(P.corr.p, 0, corr_bytes, s), "memset");
+  HCHK(P.evt_of.ensure(sizeof(int) * (size_t)L.cap * 6), "hipMalloc");
   HCHK(R.okbuf.ensure(sizeof(int) * 2), "hipMalloc");
   int *cnt = R.okbuf.as<int>();
   HCHK(hipMemsetAsync(cnt, 0, sizeof(int) * 2, s), "memset");
@@ -1184,7 +1190,7 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   hipLaunchKernelGGL(plan_target_kernel, dim3(grid_for((long)ngrid * 6)), dim3(256), 0, s, A, P.corr_tgt.as<int>());
   HCHK(P.events.ensure(sizeof(int) * ((size_t)ngrid * 6 + 1)), "hipMalloc");
   HCHK(hipMemsetAsync(P.events.p, 0, sizeof(int), s), "memset");
-  hipLaunchKernelGGL(plan_events_kernel, dim3((unsigned)(((long)ngrid * 6 + 255) / 256)), dim3(256), 0, s, A, P.corr_tgt.as<int>(), P.events.as<int>() + 1, P.events.as<int>());
+  hipLaunchKernelGGL(plan_events_kernel, dim3((unsigned)(((long)ngrid * 6 + 255) / 256)), dim3(256), 0, s, A, P.corr_tgt.as<int>(), P.events.as<int>() + 1, P.events.as<int>(), P.evt_of.as<int>());
   // work items: columns of 60 x 8 cells, runs of 8-plane chunks up to 128 planes
   const int rows = strictmode::tile_sweep_rows();       // interior rows of a work item (even: an oct never straddles two)
   const int n = 2 * L.no, wtx = (n + 59) / 60, wty = n / rows, wz = n / 8;
@@ -1199,6 +1205,7 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   HCHK(hipMemcpyAsync(hc, cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, s), "D2H");
   HCHK(hipMemcpyAsync(flag.data(), P.flag.p, nflag, hipMemcpyDeviceToHost, s), "D2H");
   HCHK(hipStreamSynchronize(s), "sync");
+  HCHK(P.corr.ensure(sizeof(double) * 4 * (size_t)(R.nvar + 2) * (size_t)(P.nevent > 0 ? P.nevent : 1)), "hipMalloc flux records");
   if (hc[1]) return failf(RAMSES_AMD_EINVAL, "level %d: %d neighbour positions of an oct have no father cell or no tile (tree inconsistent)", ilevel, hc[1]);
   if (hc[0] > gcap) return failf(RAMSES_AMD_EINVAL, "level %d: more ghost octs (%d) than free slots in the level's tiles (%d)", ilevel, hc[0], gcap);
   P.nghost = hc[0];
@@ -1326,7 +1333,6 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
   SweepArgs A;
   A.uold = R.uold.as<double>(); A.unew = R.unew.as<double>(); A.grav = R.grav ? R.f.as<double>() : nullptr;      // the cell vectors themselves
   A.stat = R.stat.as<unsigned char>(); A.dir = L.dir.as<int>(); A.work = P.work.as<int>(); A.nwork = P.nwork;
-  A.corr = P.corr.as<double>(); A.recbase = L.base - 1;
   A.ntx = L.ntx; A.nty = L.nty; A.ntz = L.ntz; A.ngd = R.ngridmax; A.ncoarse = R.ncoarse;
   const int n = 2 * L.no;
   A.nx = A.ny = A.nz = n; A.ng = 0;
@@ -1338,8 +1344,24 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
   const double m = std::frexp(dx, &ex);
   A.pow2 = (m == 0.5) ? 1 : 0;
   A.P = make_const_amr(p);
-  // strict arithmetic, like every other sweep of an AMR run (the fast build is certified on uniform runs only)
-  hipError_t e = strictmode::launch_godunov_sweep(A, st, p->riemann, 12, p->scheme, 5, R.grav, s);
+  // the surface pass first (it reads uold and the ghost cells only): the fluxes owed to the coarser level, one record per
+  // (event, fine face).  Arithmetic: strict (bit-identical) unless the caller's parameters ask for the fast build (fast_math: the
+  // patched program's default, certified <= 1e-12 against the reference program on an AMR run with sub-cycling and regrids,
+  // tests/test_fast_certificate_gpu.py; RAMSES_AMD_STRICT=1 selects the bit-identical build)
+  const bool fast = p->fast_math != 0;
+  if (P.nevent > 0) {
+    SurfArgs S;
+    S.uold = A.uold; S.grav = A.grav; S.stat = A.stat; S.dir = A.dir; S.tileid = L.tileid.as<int>();
+    S.events = P.events.as<int>() + 1; S.ig = R.cur_ig; S.rec = P.corr.as<double>(); S.nevent = P.nevent;
+    S.base = L.base; S.ncoarse = R.ncoarse; S.ngd = R.ngridmax; S.ncell = R.ncell;
+    S.no = L.no; S.ntx = L.ntx; S.nty = L.nty; S.ntz = L.ntz;
+    S.dt = A.dt; S.dx = A.dx; S.rdx = A.rdx; S.pow2 = A.pow2; S.P = A.P;
+    hipError_t es = fast ? fastmode::launch_surface_flux(S, st, p->riemann, R.grav, s) : strictmode::launch_surface_flux(S, st, p->riemann, R.grav, s);
+    if (es == hipErrorInvalidValue) { (void)hipGetLastError(); return 0; }     // a variant the tile kernels do not cover
+    HCHK(es, "surface pass of a level in tiles");
+  }
+  hipError_t e = fast ? fastmode::launch_godunov_sweep(A, st, p->riemann, 12, p->scheme, 5, R.grav, s)
+                      : strictmode::launch_godunov_sweep(A, st, p->riemann, 12, p->scheme, 5, R.grav, s);
   if (e == hipErrorInvalidValue) { (void)hipGetLastError(); return 0; }     // a variant the tile kernels do not cover
   HCHK(e, "dense sweep of a level in tiles");
   // what the level owes to the leaf cells of the coarser one, replayed in the reference's order
@@ -1351,7 +1373,7 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
     Q.dir = L.dir.as<int>(); Q.tileid = L.tileid.as<int>(); Q.base = L.base; Q.no = L.no; Q.ntx = L.ntx; Q.nty = L.nty; Q.ntz = L.ntz;
     if (P.nevent > 0) {
       hipLaunchKernelGGL(tile_coarse_update_kernel, dim3((P.nevent + 255) / 256), dim3(256), 0, s, Q, R.unew.as<double>(), P.corr.as<double>(), P.corr_tgt.as<int>(),
-                         P.events.as<int>() + 1, P.nevent, nvector, 5);
+                         P.evt_of.as<int>(), P.events.as<int>() + 1, P.nevent, nvector, 5);
       HCHK(hipGetLastError(), "coarse corrections");
     }
   }

@@ -48,6 +48,26 @@ struct Plane {
   double v[NV][BY][BX];
 };
 
+// The LDS of a workgroup.  The primitives of plane c-1 are read by their own column only (the z slope), so unless the 27-point
+// slope is in use the ring holds TWO planes: plane c+1 takes the slot of plane c-1 once the thread has taken its z slope
+// (nobody else reads that slot between the barrier of iteration c-1 and the one of iteration c).  PARK (the sweep of a level
+// in tiles, and the 12-row kernels with gravity: both spill otherwise): the partial update of plane c-1 that the full rows carry
+// across the trace of plane c -- u + x flux difference and the own -y flux -- waits in LDS instead of in 20 VGPRs; the y slots
+// then hold the rows that use them (1 .. BY-2) only.
+template <int ST, int BY, int NV, bool MASK, bool GRAV>
+struct Lds {
+  static constexpr int RING = (ST == 3) ? 3 : 2;
+  static constexpr bool PARK = MASK || (GRAV && BY == 12);
+  static constexpr int MR = PARK ? BY - 2 : BY;          // rows of a y slot plane
+  static constexpr int M0 = PARK ? 1 : 0;                // first row that owns a slot
+  static constexpr size_t q_off = 0;
+  static constexpr size_t m_off = q_off + RING * sizeof(Plane<BY, NV>);
+  static constexpr size_t park_off = m_off + 2 * sizeof(Plane<MR, NV>);
+  static constexpr size_t mask_off = park_off + (PARK ? sizeof(double) * 2 * NV * (BY - 4) * BX : 0);   // MASK: [3][BY][BX] status bytes
+  static constexpr size_t sloc_off = mask_off + (MASK ? 3 * BY * BX : 0);                                // MASK: [BY][BX] lane part of the cell index
+  static constexpr size_t bytes = sloc_off + (MASK ? 4 * BY * BX : 0);
+};
+
 // wavefront shift by one lane: lane i receives the value of lane i-1 (shr) or
 // i+1 (shl); the edge lane keeps its own value (a halo lane, never stored).
 __device__ __forceinline__ double wave_shr1(double v) {
@@ -116,8 +136,13 @@ __device__ __forceinline__ int dir_load(const int *base, unsigned plane_ints, un
 template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV, int ROLE, bool MASK>
 __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *smem_raw) {
   const bool DXPOW2 = A.pow2 != 0;   // uniform
-  Plane<BY, NV> *qring = reinterpret_cast<Plane<BY, NV> *>(smem_raw);  // [3] primitives of planes c-1, c, c+1
-  Plane<BY, NV> *mring = qring + 3;                                 // [2] +y traced state / y flux slots, by plane parity
+  typedef Lds<ST, BY, NV, MASK, GRAV> L;
+  constexpr int RING = L::RING;
+  constexpr bool PARK = L::PARK;
+  constexpr int M0 = L::M0;
+  Plane<BY, NV> *qring = reinterpret_cast<Plane<BY, NV> *>(smem_raw + L::q_off);  // [RING] primitives of planes c-1, c (, c+1)
+  Plane<L::MR, NV> *mring = reinterpret_cast<Plane<L::MR, NV> *>(smem_raw + L::m_off);   // [2] +y traced state / y flux slots, by plane parity
+  double (*park)[BY - 4][BX] = reinterpret_cast<double (*)[BY - 4][BX]>(smem_raw + L::park_off);   // PARK: [2 NV] of the full rows
 
   const int tx = threadIdx.x, ty = threadIdx.y;
   const HydroConst &P = A.P;
@@ -185,7 +210,7 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   // loop is at its register limit, and a vector register spilled to scratch costs a full vmcnt(0) drain per use.
   int tyu = 0, yis = 0, xa = 0, tA = 0, tB = 0, drow = 0;
   bool inB = false;
-  unsigned *sloc = reinterpret_cast<unsigned *>(smem_raw + 5 * sizeof(Plane<BY, NV>) + 3 * BY * BX);   // MASK: [BY][BX] lane part of the cell index (bytes)
+  unsigned *sloc = reinterpret_cast<unsigned *>(smem_raw + L::sloc_off);   // MASK: [BY][BX] lane part of the cell index (bytes)
   if (MASK) {
     tyu = __builtin_amdgcn_readfirstlane(ty);
     const int ys = y0 - 2 + tyu;
@@ -202,6 +227,10 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   double *__restrict__ unew = A.unew;
   const double *__restrict__ grav = A.grav;
 
+#ifndef SWEEP_LATE_BASE
+#define SWEEP_LATE_BASE 1
+#endif
+  constexpr bool LATE = SWEEP_LATE_BASE && NV == 5;   // (the passive-scalar fix of NV > 5 wants the old state in phase A)
   constexpr bool r_trace = ROLE == ROLE_LOW || ROLE == ROLE_HIGH || ROLE == ROLE_FULL;
   constexpr bool r_fxz = ROLE == ROLE_FULL;
   const bool r_upd = r_fxz && (tx >= 2) && (tx <= BX - 3) && (xu < A.nx) && (yu < A.ny);
@@ -256,23 +285,8 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     for (int n = 0; n < NV; n++) u[n] = plane_load(unew + (long)(n & ~1) * A.pitch_var, pb + (n & 1) * odd_var, off);
   };
   int ok_zlo = 0;   // MASK: plane c-1's status byte of this column
-  int s_m1 = 0;     // MASK: the same, kept until plane c-1 is finished in phase B
   int spre = 0;     // MASK: plane c+1's status byte, on its way
-  unsigned char *smask = smem_raw + 5 * sizeof(Plane<BY, NV>);   // MASK: [3][BY][BX] status bytes of planes c-1, c, c+1, by plane mod 3
-  const int CV = NV + 2;
-  // MASK: a flux owed to the coarser level (the surfaces of the level) -- record (oct of the lane's own cell in plane p, face f,
-  // fine face q), addressed by the oct's device index alone: no load, five stores that nobody waits for
-  auto file_flux = [&](int p, int f, int q, const double (&fl)[NV]) {
-#ifdef TILE_NOREC      // (kernel tuning only: no flux records)
-    return;
-#endif
-    const int pz = wrap_z(p);
-    const int lind = ((xa + tx) & 1) + 2 * (yis & 1);
-    const long oct0 = (long)((tbp(p) >> 3) + zpart(p)) - A.ncoarse - (long)(lind + 4 * (pz & 1)) * A.ngd;
-    double *dst = A.corr + (((oct0 - A.recbase) * 6 + f) * 4 + q) * CV;
-#pragma unroll
-    for (int n = 0; n < NV; n++) dst[n] = fl[n];
-  };
+  unsigned char *smask = smem_raw + L::mask_off;   // MASK: [3][BY][BX] status bytes of planes c-1, c, c+1, by plane mod 3
   auto load_g = [&](int p, double (&g)[3]) {
     if (GRAV) {
       const unsigned pb = MASK ? zpart(p) * 8u : plane_off(p), off = MASK ? tbp(p) : colb;
@@ -341,19 +355,28 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   double fyown[NV];                      // y flux through the -y face of plane c-1 (computed by this row; its copy
                                          // in slot ty-1 belongs to row ty-1, which reuses the slot without a barrier)
   double rnew = 0.0, snew[NV > 5 ? NV - 5 : 1];
+  double bcar[NV];                       // LATE: the state the update of plane c-1 starts from
 #pragma unroll
-  for (int n = 0; n < NV; n++) { partx[n] = 0.0; fyown[n] = 0.0; }
+  for (int n = 0; n < NV; n++) { partx[n] = 0.0; fyown[n] = 0.0; bcar[n] = 0.0; }
+  if (PARK && r_fxz) {
+#pragma unroll
+    for (int n = 0; n < 2 * NV; n++) park[n][ty - 2][tx] = 0.0;
+  }
 
   for (int c = z0 - 1; c <= z1; c++) {
-    Plane<BY, NV> &M = mring[c & 1];
-    Plane<BY, NV> &Mprev = mring[(c & 1) ^ 1];
+    Plane<L::MR, NV> &M = mring[c & 1];
+    Plane<L::MR, NV> &Mprev = mring[(c & 1) ^ 1];
     // ---- phase A: plane c+1 arrives; trace plane c; x and z fluxes ------------------
     double qc[NV];
     ctoprim_cell<NV, GRAV>(upre, gpre, dtxhalf, P, qc);
+    // plane c+1 goes into the ring: into its own slot (RING 3), or into the slot of plane c-1 as soon as this thread has taken
+    // its z slope from it (RING 2; the rows that take no slopes have nothing to wait for)
+    if (RING == 3 || !r_trace) {
 #pragma unroll
-    for (int n = 0; n < NV; n++) qring[sc].v[n][ty][tx] = qc[n];
+      for (int n = 0; n < NV; n++) qring[RING == 3 ? sc : sa].v[n][ty][tx] = qc[n];
+    }
     double ucur[NV];
-    if (r_fxz) { if (MASK) load_base(c, ucur); else load_u(c, ucur); }
+    if (r_fxz && !LATE) { if (MASK) load_base(c, ucur); else load_u(c, ucur); }
     int okc = 0, ok_ym = 0;
     if (MASK && r_trace) {
       okc = spre;                  // loaded one plane ahead: nothing at the top of an iteration waits for memory
@@ -404,6 +427,10 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
           dq[2][n] = slope1<ST>(qprev.v[n][ty][tx], qb[n], qc[n], P);
         }
       }
+      if (RING == 2) {
+#pragma unroll
+        for (int n = 0; n < NV; n++) qring[sa].v[n][ty][tx] = qc[n];
+      }
       double qm[3][NV], qp[3][NV];
       if (SCHEME == 0) {
         trace3d_cell<NV>(qb, dq, dtdx, dtdx, dtdx, P, qm, qp);
@@ -412,7 +439,7 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
         tracexyz_cell<NV>(qb, dq, cc, dtdx, dtdx, dtdx, P, qm, qp);
       }
 #pragma unroll
-      for (int n = 0; n < NV; n++) M.v[n][ty][tx] = qm[1][n];
+      for (int n = 0; n < NV; n++) M.v[n][ty - M0][tx] = qm[1][n];
 #pragma unroll
       for (int n = 0; n < NV; n++) qpy[n] = qp[1][n];
       if constexpr (r_fxz) {
@@ -422,10 +449,9 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
         scaled_interface_flux<RS, NV, 0>(qL, qp[0], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fx);
         // z flux through the face between planes c-1 and c
         scaled_interface_flux<RS, NV, 2>(qmz, qp[2], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fz);
-        int s_xm = 0, s_xp = 0;
         if (MASK) {
           // hydro/godunov_fine.f90:720-747: the flux through a face is reset when the cell on either side is refined
-          s_xm = wave_shr1_i(okc); s_xp = wave_shl1_i(okc);
+          const int s_xm = wave_shr1_i(okc);
           const bool zx = ((okc | s_xm) & CELL_REFINED) != 0, zz = ((okc | ok_zlo) & CELL_REFINED) != 0;
 #pragma unroll
           for (int n = 0; n < NV; n++) { fx[n] = zx ? 0.0 : fx[n]; fz[n] = zz ? 0.0 : fz[n]; }
@@ -437,21 +463,8 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
           dz[n] = fzlo[n] - fz[n];          // z flux difference of plane c-1
           fzlo[n] = fz[n];
           fxh[n] = wave_shl1(fx[n]);        // -x face flux of column tx+1
-          px[n] = ucur[n] + (fx[n] - fxh[n]);     // consumes the re-read state before the barrier
-        }
-        if (MASK) {
-          // :798-908: what an updated cell exchanges with a ghost cell (an oct that does not exist: interpolated) is owed to the
-          // leaf cell of the coarser level behind that face -- filed per (oct, face, fine face) by the lane of the updated cell,
-          // replayed in the reference's order afterwards.  Ghost cells sit across oct faces only.
-          if (r_upd && (((s_xm | s_xp) & CELL_GHOST) | ((okc | ok_zlo) & CELL_GHOST))) {
-            if (c >= z0 && c < z1 && (okc & CELL_OWNED)) {
-              const int pz = wrap_z(c);
-              if (s_xm & CELL_GHOST) file_flux(c, 0, (yis & 1) + 2 * (pz & 1), fx);
-              if (s_xp & CELL_GHOST) file_flux(c, 1, (yis & 1) + 2 * (pz & 1), fxh);
-              if (ok_zlo & CELL_GHOST) file_flux(c, 4, ((xa + tx) & 1) + 2 * (yis & 1), fz);
-            }
-            if (c > z0 && c <= z1 && (ok_zlo & CELL_OWNED) && (okc & CELL_GHOST)) file_flux(c - 1, 5, ((xa + tx) & 1) + 2 * (yis & 1), fz);
-          }
+          // (LATE: the state the update starts from joins in phase B of the next iteration -- a whole trace after its load)
+          px[n] = LATE ? (fx[n] - fxh[n]) : ucur[n] + (fx[n] - fxh[n]);
         }
         if (NV > 5) {
           rnew = ucur[0];
@@ -482,21 +495,17 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     if constexpr (ROLE == ROLE_FULL || ROLE == ROLE_HIGH) {
       double qL[NV];
 #pragma unroll
-      for (int n = 0; n < NV; n++) qL[n] = M.v[n][tym][tx];
+      for (int n = 0; n < NV; n++) qL[n] = M.v[n][tym - M0][tx];
       scaled_interface_flux<RS, NV, 1>(qL, qpy, P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fy);
       if (MASK) {
         ok_ym = smask[((c + 3) % 3 * BY + tym) * BX + tx];
         const bool zy = ((okc | ok_ym) & CELL_REFINED) != 0;
 #pragma unroll
         for (int n = 0; n < NV; n++) fy[n] = zy ? 0.0 : fy[n];
-        if (ROLE == ROLE_FULL && r_upd && c >= z0 && c < z1 && (okc & CELL_OWNED) && (ok_ym & CELL_GHOST)) {
-          const int pz = wrap_z(c);
-          file_flux(c, 2, ((xa + tx) & 1) + 2 * (pz & 1), fy);
-        }
       }
       // the flux through this row's -y face is the +y face flux of row ty-1: into ITS slot
 #pragma unroll
-      for (int n = 0; n < NV; n++) M.v[n][tym][tx] = fy[n];
+      for (int n = 0; n < NV; n++) M.v[n][tym - M0][tx] = fy[n];
     }
     if constexpr (r_fxz) {
       // plane c-1: its x part and own -y flux were kept in registers, the +y face flux was left
@@ -506,19 +515,11 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
       double un[NV], fyh[NV];
 #pragma unroll
       for (int n = 0; n < NV; n++) {
-        fyh[n] = Mprev.v[n][ty][tx];
-        const double part = partx[n] + (fyown[n] - fyh[n]);
+        fyh[n] = Mprev.v[n][ty - M0][tx];
+        const double pxn = PARK ? park[n][ty - 2][tx] : partx[n];
+        const double fyn = PARK ? park[NV + n][ty - 2][tx] : fyown[n];
+        const double part = (LATE ? bcar[n] + pxn : pxn) + (fyn - fyh[n]);
         un[n] = part + dz[n];
-      }
-      if (MASK) {
-        // the +y face of plane c-1: row ty+1 left the flux in this row's slot and its status byte in the plane's smask
-        if (r_upd && c > z0 && c <= z1 && (s_m1 & CELL_OWNED)) {
-          const int s_yp = smask[((c + 2) % 3 * BY + typ) * BX + tx];
-          if (s_yp & CELL_GHOST) {
-            const int pz = wrap_z(c - 1);
-            file_flux(c - 1, 3, ((xa + tx) & 1) + 2 * (pz & 1), fyh);
-          }
-        }
       }
       if (NV > 5) {
         // set_uold's passive-scalar fix near the density floor
@@ -535,20 +536,28 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
         for (int n = 5; n < NV; n++) sold[n - 5] = snew[n - 5];
       }
 #pragma unroll
-      for (int n = 0; n < NV; n++) { partx[n] = px[n]; fyown[n] = fy[n]; }
+      for (int n = 0; n < NV; n++) {
+        if (PARK) { park[n][ty - 2][tx] = px[n]; park[NV + n][ty - 2][tx] = fy[n]; }
+        else { partx[n] = px[n]; fyown[n] = fy[n]; }
+      }
       {
         const unsigned pb = MASK ? zpart(c - 1) * 8u : plane_off(c - 1);
-        const unsigned so = (c >= z0 + 1) ? (MASK ? ((r_upd && (s_m1 & CELL_OWNED)) ? tbp(c - 1) : BUF_OOB) : colb_upd) : BUF_OOB;
+        const unsigned so = (c >= z0 + 1) ? (MASK ? ((r_upd && (ok_zlo & CELL_OWNED)) ? tbp(c - 1) : BUF_OOB) : colb_upd) : BUF_OOB;
 #pragma unroll
         for (int n = 0; n < NV; n++) {
           if (MASK) plane_store(unew + (long)(n & ~1) * A.pitch_var, pb + (n & 1) * odd_var, so, un[n]);
           else plane_store(unew + (long)n * A.pitch_var, pb, so, un[n]);
         }
       }
+      // LATE: the state the update of plane c starts from (MASK: unew, in place -- another array, an HBM miss; else the plane of
+      // uold this workgroup read two iterations ago), requested now and used in phase B of the next iteration: at the top of
+      // phase A it was due at the x flux, and every wave of the workgroup sat at that wait together
+      if (LATE) { if (MASK) load_base(c, bcar); else load_u(c, bcar); }
     }
     // rotate the ring
-    const int t = sa; sa = sb; sb = sc; sc = t;
-    if (MASK) { ok_zlo = okc; s_m1 = okc; }
+    if (RING == 3) { const int t = sa; sa = sb; sb = sc; sc = t; }
+    else { const int t = sa; sa = sb; sb = t; }
+    if (MASK) ok_zlo = okc;
   }
 }
 
@@ -567,11 +576,124 @@ __global__ __launch_bounds__(BX *BY) void godunov_sweep_kernel(SweepArgs A) {
 }
 
 // ---------------------------------------------------------------------------
+// surface pass of a level in tiles (SurfArgs): the fluxes owed to the coarser level
+// ---------------------------------------------------------------------------
+// index (0-based) of cell (x, y, z) of the level in a cell vector; the layout gave every position this pass asks for a tile
+__device__ __forceinline__ long surf_cell(const SurfArgs &A, int x, int y, int z) {
+  const int m = 2 * A.no - 1;
+  x &= m; y &= m; z &= m;
+  const int ox = x >> 1, oy = y >> 1, oz = z >> 1;
+  const int t = (ox / TILE_OX) + A.ntx * ((oy / TILE_OY) + A.nty * (oz / TILE_OZ));
+  const long c0 = A.dir[t];
+  const int ind = (x & 1) + 2 * (y & 1) + 4 * (z & 1);
+  return c0 + (ox % TILE_OX) + TILE_OX * ((oy % TILE_OY) + TILE_OY * (oz % TILE_OZ)) + (long)ind * A.ngd;
+}
+template <int NV, bool GRAV>
+__device__ __forceinline__ void surf_prim(const SurfArgs &A, int x, int y, int z, double (&q)[NV]) {
+  const long c = surf_cell(A, x, y, z);
+  double u[NV], g[3];
+#pragma unroll
+  for (int n = 0; n < NV; n++) u[n] = A.uold[(long)n * A.ncell + c];
+#pragma unroll
+  for (int d = 0; d < 3; d++) g[d] = GRAV ? A.grav[(long)d * A.ncell + c] : 0.0;
+  ctoprim_cell<NV, GRAV>(u, g, A.dt * 0.5, A.P, q);
+}
+// the traced states of cell (x, y, z): ctoprim of the cell and its six neighbours, the slopes, trace3d -- what a lane of the
+// marching kernel does for its cell in phase A
+template <int ST, int NV, bool GRAV>
+__device__ __noinline__ void surf_trace(const SurfArgs &A, int x, int y, int z, double (&qm)[3][NV], double (&qp)[3][NV]) {
+  double qb[NV], dq[3][NV];
+  surf_prim<NV, GRAV>(A, x, y, z, qb);
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    double ql[NV], qr[NV];
+    surf_prim<NV, GRAV>(A, x - (d == 0), y - (d == 1), z - (d == 2), ql);
+    surf_prim<NV, GRAV>(A, x + (d == 0), y + (d == 1), z + (d == 2), qr);
+#pragma unroll
+    for (int n = 0; n < NV; n++) dq[d][n] = slope1<ST>(ql[n], qb[n], qr[n], A.P);
+  }
+  const double dtdx = A.dt / A.dx;
+  trace3d_cell<NV>(qb, dq, dtdx, dtdx, dtdx, A.P, qm, qp);
+}
+template <int ST, int RS, int NV, bool GRAV>
+__global__ __launch_bounds__(256) void surface_flux_kernel(SurfArgs A) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)A.nevent * 4) return;
+  const int e = (int)(t >> 2), q = (int)(t & 3);
+  const int ev = A.events[e];
+  const int io = ev / 6, f = ev % 6;
+  const int dirn = f >> 1, side = f & 1;
+  // the oct's position from its device index (its slab of 512 indices is one tile)
+  const long r = (long)A.ig[io] - A.base;
+  const int tl = A.tileid[r / TILE_OCTS], l = (int)(r % TILE_OCTS);
+  int p[3] = {2 * ((tl % A.ntx) * TILE_OX + l % TILE_OX), 2 * (((tl / A.ntx) % A.nty) * TILE_OY + (l / TILE_OX) % TILE_OY),
+              2 * ((tl / (A.ntx * A.nty)) * TILE_OZ + l / (TILE_OX * TILE_OY))};
+  // the updated cell behind fine face q of face f (q: the two transverse coordinates, lower axis first), the ghost cell beyond
+  const int t0 = dirn == 0 ? 1 : 0, t1 = dirn == 2 ? 1 : 2;
+  p[dirn] += side; p[t0] += q & 1; p[t1] += q >> 1;
+  int g[3] = {p[0], p[1], p[2]};
+  g[dirn] += side ? 1 : -1;
+  const int *lo = side ? p : g, *hi = side ? g : p;       // left and right cell of the interface
+  double qm[3][NV], qp[3][NV], qL[NV], fl[NV];
+  surf_trace<ST, NV, GRAV>(A, lo[0], lo[1], lo[2], qm, qp);
+#pragma unroll
+  for (int n = 0; n < NV; n++) qL[n] = dirn == 0 ? qm[0][n] : (dirn == 1 ? qm[1][n] : qm[2][n]);
+  surf_trace<ST, NV, GRAV>(A, hi[0], hi[1], hi[2], qm, qp);
+  const double dtdx = A.dt / A.dx;
+  const bool DXPOW2 = A.pow2 != 0;
+  if (dirn == 0) scaled_interface_flux<RS, NV, 0>(qL, qp[0], A.P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fl);
+  else if (dirn == 1) scaled_interface_flux<RS, NV, 1>(qL, qp[1], A.P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fl);
+  else scaled_interface_flux<RS, NV, 2>(qL, qp[2], A.P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fl);
+  // hydro/godunov_fine.f90:720-747: reset when the cell on either side is refined (a ghost cell never is)
+  const bool zero = (A.stat[surf_cell(A, p[0], p[1], p[2])] & CELL_REFINED) != 0;
+  double *dst = A.rec + ((long)e * 4 + q) * (NV + 2);
+#pragma unroll
+  for (int n = 0; n < NV; n++) dst[n] = zero ? 0.0 : fl[n];
+}
+
+template <int ST, int RS>
+static hipError_t surface1(const SurfArgs &A, bool grav, hipStream_t s) {
+  if constexpr (ST == 3 || ST == 4 || ST == 5 || ST == 6 || RS == RIEMANN_EXACT) {
+    return hipErrorInvalidValue;
+  } else {
+    const dim3 grid((unsigned)(((long)A.nevent * 4 + 255) / 256)), block(256);
+    if (grav) hipLaunchKernelGGL((surface_flux_kernel<ST, RS, 5, true>), grid, block, 0, s, A);
+    else hipLaunchKernelGGL((surface_flux_kernel<ST, RS, 5, false>), grid, block, 0, s, A);
+    return hipGetLastError();
+  }
+}
+template <int ST>
+static hipError_t surface0(const SurfArgs &A, int rs, bool grav, hipStream_t s) {
+  switch (rs) {
+    case RIEMANN_LLF: return surface1<ST, RIEMANN_LLF>(A, grav, s);
+#ifndef SWEEP_FLAGSHIP_ONLY
+    case RIEMANN_HLLC: return surface1<ST, RIEMANN_HLLC>(A, grav, s);
+    case RIEMANN_HLL: return surface1<ST, RIEMANN_HLL>(A, grav, s);
+    case RIEMANN_ACOUSTIC: return surface1<ST, RIEMANN_ACOUSTIC>(A, grav, s);
+#endif
+  }
+  return hipErrorInvalidValue;
+}
+hipError_t launch_surface_flux(const SurfArgs &A, int slope_type, int riemann, bool grav, hipStream_t s) {
+  if (A.nevent <= 0) return hipSuccess;
+  switch (slope_type) {
+    case 1: return surface0<1>(A, riemann, grav, s);
+#ifndef SWEEP_FLAGSHIP_ONLY
+    case 0: return surface0<0>(A, riemann, grav, s);
+    case 2: return surface0<2>(A, riemann, grav, s);
+    case 7: return surface0<7>(A, riemann, grav, s);
+    case 8: return surface0<8>(A, riemann, grav, s);
+#endif
+  }
+  return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------
 template <int ST, int RS, int BY, bool GRAV, int SCHEME, int NV, bool MASK = false>
 static hipError_t launch3(const SweepArgs &A, hipStream_t s) {
-  const size_t lds = 5 * sizeof(Plane<BY, NV>) + (MASK ? 3 * BY * BX + 4 * BY * BX : 0);
+  const size_t lds = Lds<ST, BY, NV, MASK, GRAV>::bytes;
   dim3 block(BX, BY);
   dim3 grid(A.nblocks);
   auto k = godunov_sweep_kernel<ST, RS, BY, GRAV, SCHEME, NV, MASK>;
@@ -635,18 +757,14 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
   if (A.stat) {
     // a level of a resident AMR run in tiles: the 12-row muscl kernels on the periodic box of the level, one workgroup per
     // work item (anything else: the caller keeps the tree-walking sweep)
-#ifndef RAMSES_AMD_FAST
     if constexpr (ST != 3 && ST != 4 && ST != 5 && ST != 6 && RS != RIEMANN_EXACT) {
-      if (!A.dir || !A.work || !A.corr || A.ng != 0 || nvar != 5 || scheme != 0 || A.nwork <= 0) return hipErrorInvalidValue;
+      if (!A.dir || !A.work || A.ng != 0 || nvar != 5 || scheme != 0 || A.nwork <= 0) return hipErrorInvalidValue;
       A.nblocks = A.nwork;
       A.nbox = 1;          // (the box decode runs, its result is replaced by the work item)
       return grav ? launch3<ST, RS, TILE_SWEEP_BY, true, 0, 5, true>(A, s) : launch3<ST, RS, TILE_SWEEP_BY, false, 0, 5, true>(A, s);
     } else {
       return hipErrorInvalidValue;
     }
-#else
-    return hipErrorInvalidValue;      // strict arithmetic only (the fast build is certified on uniform runs)
-#endif
   }
   if constexpr (ST == 4 || ST == 5 || ST == 6) {
     // NDIM=1 slope types: the plain configuration only (the reference's 1-D tests: NVAR=3 embedded as 5, muscl, no gravity)

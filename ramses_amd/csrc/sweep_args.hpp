@@ -28,22 +28,19 @@ struct SweepArgs {
   //   stat    one byte per device cell, indexed like a cell vector: bit 0 the cell is refined (son > 0: the fluxes through its
   //           faces are reset, hydro/godunov_fine.f90:661-666,720-747), bit 1 the cell belongs to an oct of the call's list (it
   //           is updated), bit 2 the cell belongs to a GHOST oct (a missing neighbour oct, interpolated from the coarser level
-  //           by a pre-pass: the flux between an updated cell and a ghost cell is also filed in `corr`, :798-908);
+  //           by a pre-pass; the marching kernel treats it like any other cell it does not update);
   //   dir     the level's tile directory [ntz][nty][ntx]: 0-based index of the tile's first cell in a cell vector
   //           (= ncoarse + first oct - 1), or -1 where no oct of the level and no ghost oct falls into the tile;
   //   work    the launch's work items, one per workgroup: (x0, y0, z0, z1) = first interior column / row of the 60 x (BY-4)
   //           tile and the planes [z0, z1) it marches;
-  //   corr    [cap][6][4][nvar+2] flux records of the (oct, face) pairs that border a leaf cell of the coarser level, indexed
-  //           by the oct's device index minus recbase (the level's first index: addressable from the cell index alone);
-  //           replayed in the reference's order by tile_coarse_update_kernel (csrc/capi_amr.hip).
+  // (the fluxes owed to the coarser level are the surface pass's business: SurfArgs below)
   // uold / grav / unew are then the cell vectors themselves (pitch_var = ncell of the device; pitch_y, pitch_z unused), the
   // update starts from unew -- which already holds what the finer level owes to this one (:752-790) -- and lands there.
   const unsigned char *stat = nullptr;
   const int *dir = nullptr;
   const int *work = nullptr;          // int4 per workgroup
-  double *corr = nullptr;
   int ntx = 0, nty = 0, ntz = 0, nwork = 0;
-  long ngd = 0, ncoarse = 0, recbase = 0;
+  long ngd = 0, ncoarse = 0;
   int nx, ny, nz;       // interior cells
   int ng;               // ghost width (0 = periodic wrap in-kernel)
   long pitch_y, pitch_z, pitch_var;
@@ -56,12 +53,35 @@ struct SweepArgs {
   HydroConst P;
 };
 
+// The surface pass of the sweep of a level in tiles (hydro/godunov_fine.f90:798-908): the fluxes an updated cell exchanges with
+// a GHOST cell (an oct the level does not have, interpolated by the pre-pass) are owed to the leaf cell of the coarser level
+// behind that oct face.  One thread per (event = (oct of the list, face) with such a neighbour, fine face q): it rebuilds the
+// traced states of the two cells from their own seven-cell stencils with the functions of the marching kernel -- the same
+// operations on the same values, hence the same flux -- and files it in rec[event][q][nvar+2].  The marching loop itself knows
+// nothing about the surfaces of the level.
+struct SurfArgs {
+  const double *uold = nullptr, *grav = nullptr;     // the device's cell vectors
+  const unsigned char *stat = nullptr;
+  const int *dir = nullptr, *tileid = nullptr;       // the level's tile directory / the tile of every 512-oct slab of its index range
+  const int *events = nullptr;                       // list position * 6 + face
+  const int *ig = nullptr;                           // the call's list, device octs (1-based)
+  double *rec = nullptr;                             // [nevent][4][nvar + 2]
+  int nevent = 0;
+  long base = 0, ncoarse = 0, ngd = 0, ncell = 0;
+  int no = 0, ntx = 0, nty = 0, ntz = 0;
+  double dt = 0, dx = 0, rdx = 0;
+  int pow2 = 0;
+  HydroConst P;
+};
+
 namespace strictmode {
+hipError_t launch_surface_flux(const SurfArgs &A, int slope_type, int riemann, bool grav, hipStream_t s);
 hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme, int nvar,
                                 bool grav, hipStream_t s);
 int tile_sweep_rows();
 }
 namespace fastmode {
+hipError_t launch_surface_flux(const SurfArgs &A, int slope_type, int riemann, bool grav, hipStream_t s);
 hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme, int nvar,
                                 bool grav, hipStream_t s);
 int tile_sweep_rows();

@@ -9,7 +9,10 @@
 !     set_uold (ramses_amd_mhd_iface: ramses_amd_mhd_resident; set_unew is implied by the sweep, set_uold is a swap of two
 !     bricks, backup_hydro fetches the state back: output_hydro.f90 of this directory).  Otherwise staged: uold of the
 !     level's cells goes up, unew comes back (SURVEY.md 8 row f4).
-! Everything the device does not cover -- AMR levels, several ranks, physical boundaries, self-gravity, pressure_fix,
+!     Any other level of an AMR tree (partly refined, or with finer levels inside): godfine1 on the device, oct by oct with
+!     the 6^3 stencil, the divergence-free interpolation of missing neighbour octs and the flux / EMF corrections of the
+!     coarser level in the reference's order (ramses_amd_mhd_godunov_amr below, csrc/mhd_amr.hip; staged).
+! Everything the device does not cover -- several ranks, physical boundaries, self-gravity, pressure_fix,
 ! NENER>0, passive scalars, the solvers and slope types outside ramses_amd_mhd_params -- takes the reference's routines.
 !==============================================================================
 #define godunov_fine godunov_fine_reference
@@ -69,6 +72,13 @@ subroutine godunov_fine(ilevel)
      end if
   end if
   if(.not.dev)then
+     ! any other level of the tree: godfine1 as the reference writes it, on the device (csrc/mhd_amr.hip; staged)
+     if(ramses_amd_mhd_amr_config().and.ilevel>=3)then
+        call ramses_amd_mhd_godunov_amr(ilevel)
+        return
+     end if
+     ! nothing silent: the library counts the levels that take the reference's host routine and prints them at exit
+     if(ramses_amd_mhd_enabled())rc=ramses_amd_mhd_note_reference_sweep(ilevel)
      call godunov_fine_reference(ilevel)
      return
   end if
@@ -96,3 +106,45 @@ subroutine godunov_fine(ilevel)
   if(rc/=0)call ramses_amd_mhd_fatal('godunov_fine')
 111 format('   Entering godunov_fine (MHD, MI355X) for level ',i2)
 end subroutine godunov_fine
+
+!------------------------------------------------------------------------------
+! godunov_fine(ilevel) of a level of an AMR tree: the whole list of active octs in one call (the library follows the
+! reference's batches of nvector octs when it adds the corrections of the coarser level)
+!------------------------------------------------------------------------------
+subroutine ramses_amd_mhd_godunov_amr(ilevel)
+  use amr_commons
+  use hydro_commons
+  use poisson_commons
+  use ramses_amd_mhd_iface
+  implicit none
+  integer::ilevel
+  integer::rc,nx_loc,i,usef
+  real(dp)::dx,scale
+  type(ramses_amd_mhd_params)::p
+  integer,allocatable,dimension(:)::octs
+  if(verbose)write(*,112)ilevel
+  call ramses_amd_mhd_fill_params(p)
+  nx_loc=icoarse_max-icoarse_min+1
+  scale=boxlen/dble(nx_loc)
+  dx=0.5D0**ilevel*scale
+  allocate(octs(active(ilevel)%ngrid))
+  do i=1,active(ilevel)%ngrid
+     octs(i)=active(ilevel)%igrid(i)
+  end do
+  usef=0
+  if(poisson)usef=1
+  if(poisson)then
+     rc=ramses_amd_mhd_godunov_fine_amr_f90(p,ilevel,levelmin,active(ilevel)%ngrid,octs,son,nbor,father,int(ngridmax,8), &
+          & int(ncoarse,8),uold,unew,f,usef,dx,dtnew(ilevel),nvector,interpol_var,interpol_type,interpol_mag_type)
+  else
+     rc=ramses_amd_mhd_godunov_fine_amr_f90(p,ilevel,levelmin,active(ilevel)%ngrid,octs,son,nbor,father,int(ngridmax,8), &
+          & int(ncoarse,8),uold,unew,uold,usef,dx,dtnew(ilevel),nvector,interpol_var,interpol_type,interpol_mag_type)
+  end if
+  deallocate(octs)
+  if(rc/=0)call ramses_amd_mhd_fatal('godunov_fine (AMR level)')
+  if(ramses_amd_mhd_first)then
+     write(*,*)'ramses_amd: MHD godunov_fine of AMR levels on the MI355X (staged)'
+     ramses_amd_mhd_first=.false.
+  end if
+112 format('   Entering godunov_fine (MHD, AMR level, MI355X) for level ',i2)
+end subroutine ramses_amd_mhd_godunov_amr

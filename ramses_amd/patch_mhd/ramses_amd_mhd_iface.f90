@@ -22,6 +22,23 @@ module ramses_amd_mhd_iface
        real(c_double), value :: dx, dt
        integer(c_int) :: rc
      end function ramses_amd_mhd_godunov_fine_f90
+     function ramses_amd_mhd_godunov_fine_amr_f90(p, ilevel, levelmin, ngrid, igrid, son, nbor, father, ngridmax, ncoarse, uold, unew, &
+          & f, use_f, dx, dt, nvector, interpol_var, interpol_type, interpol_mag_type) &
+          & bind(C, name='ramses_amd_mhd_godunov_fine_amr_f90') result(rc)
+       import :: ramses_amd_mhd_params, c_int, c_int64_t, c_double
+       type(ramses_amd_mhd_params), intent(in) :: p
+       integer(c_int), value :: ilevel, levelmin, ngrid, use_f, nvector, interpol_var, interpol_type, interpol_mag_type
+       integer(c_int) :: igrid(*), son(*), nbor(*), father(*)
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       real(c_double) :: uold(*), unew(*), f(*)
+       real(c_double), value :: dx, dt
+       integer(c_int) :: rc
+     end function ramses_amd_mhd_godunov_fine_amr_f90
+     function ramses_amd_mhd_note_reference_sweep(ilevel) bind(C, name='ramses_amd_mhd_note_reference_sweep') result(rc)
+       import :: c_int
+       integer(c_int), value :: ilevel
+       integer(c_int) :: rc
+     end function ramses_amd_mhd_note_reference_sweep
      function ramses_amd_mhd_resident_active() bind(C, name='ramses_amd_mhd_resident_active') result(rc)
        import :: c_int
        integer(c_int) :: rc
@@ -96,6 +113,37 @@ contains
          & .and. (slope_mag_type == 0 .or. slope_mag_type == 1 .or. slope_mag_type == 2 .or. slope_mag_type == 7 &
          &        .or. slope_mag_type == 8)
   end function ramses_amd_mhd_device_config
+
+  ! godfine1 of ANY level of an AMR tree on the device (csrc/mhd_amr.hip, staged): what the brick sweep asks for, except that
+  ! self-gravity is allowed (ctoprim's half kick from f; the source terms stay the reference's host routines) -- one rank,
+  ! periodic box, no pressure_fix
+  logical function ramses_amd_mhd_amr_config()
+    use amr_commons
+    use hydro_commons
+    integer :: nx_loc
+    character(len=16) :: val
+    integer :: stat
+    logical, save :: first = .true., on = .true.
+    if (first) then
+       first = .false.
+       call get_environment_variable('RAMSES_AMD_MHD_AMR', val, status=stat)
+       if (stat == 0) then
+          if (trim(val) == '0') on = .false.
+       end if
+    end if
+    nx_loc = icoarse_max - icoarse_min + 1
+    ramses_amd_mhd_amr_config = on .and. ramses_amd_mhd_enabled() .and. hydro .and. ndim == 3 .and. nvar == 8 .and. ncpu == 1 &
+         & .and. nboundary == 0 .and. nx_loc == 1 .and. jcoarse_max == jcoarse_min .and. kcoarse_max == kcoarse_min &
+         & .and. .not. pressure_fix .and. ischeme == 0 .and. .not. allow_switch_solver &
+         & .and. .not. allow_switch_solver2D .and. .not. MC_tracer &
+         & .and. iriemann >= 0 .and. iriemann <= 5 .and. iriemann2d >= 0 .and. iriemann2d <= 5 &
+         & .and. (slope_type == 0 .or. slope_type == 1 .or. slope_type == 2 .or. slope_type == 3 .or. slope_type == 7 &
+         &        .or. slope_type == 8) &
+         & .and. (slope_mag_type == 0 .or. slope_mag_type == 1 .or. slope_mag_type == 2 .or. slope_mag_type == 7 &
+         &        .or. slope_mag_type == 8) &
+         & .and. interpol_var >= 0 .and. interpol_var <= 1 .and. interpol_type >= 0 .and. interpol_type <= 3 &
+         & .and. interpol_mag_type >= 0 .and. interpol_mag_type <= 3
+  end function ramses_amd_mhd_amr_config
 
   ! The level stays on the device between courant_fine, godunov_fine and set_uold: one level (levelmin = nlevelmax), and
   ! nothing else in the time loop that reads or writes uold on the host (magnetic diffusion, cooling, particles, ...).

@@ -177,3 +177,64 @@ def test_slope_type_3_runs_strict_by_default(gpu_lib, monkeypatch):
         shutil.rmtree(workr, ignore_errors=True)
     assert float(np.ravel(got["info"]["t"])[0]) == float(np.ravel(ref["info"]["t"])[0])
     assert np.array_equal(got["prim"], ref["prim"])
+
+
+def _sorted_leaves(snap):
+    order = np.lexsort((snap["x"][:, 0], snap["x"][:, 1], snap["x"][:, 2], snap["level"]))
+    return snap["level"][order], snap["x"][order], snap["prim"][:, order]
+
+
+@pytest.mark.parametrize("lmin,lmax,nstep", [(6, 8, 60)])
+def test_default_mode_amr_run_live_ab(gpu_lib, monkeypatch, lmin, lmax, nstep):
+    """The fast arithmetic on AMR levels (round 6): the levels of a resident AMR run live in the device's tiles and take the
+    dense z-marching sweep (csrc/hydro_sweep.hip MASK) + the surface pass in the DEFAULT (fast) build.  sedov3d.nml with
+    levelmin..levelmax and the gradient criteria of config C5, `nstep` coarse steps -- sub-cycling, a regrid every coarse step,
+    ghost octs, fluxes owed to the coarser levels -- through the patched program in its default mode against the unmodified
+    MPI reference run live beside it: the SAME leaf cells (level and position: every refinement decision agrees) and
+    rel-Linf <= 1e-12 per snapshot variable over all of them.  RAMSES_AMD_TILE_MIN_OCTS=0 sends the small levels through the
+    tile kernels too (production keeps the strict tree walker below 32768 octs), and the exit line must say so."""
+    if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED)):
+        pytest.skip("oracle/_ref/ramses3d_mpi / ramses3d_patch not built")
+    import importlib.util
+    import re
+    from oracle import ramses_snapshot as rs
+    spec = importlib.util.spec_from_file_location("mkb", os.path.join(ROOT, "tests", "golden", "make_golden_baseline.py"))
+    mkb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mkb)
+    nml = mkb.c5_namelist(lmin, lmax, nstep, 400000)
+    monkeypatch.setenv("RAMSES_AMD", "1")
+    monkeypatch.setenv("RAMSES_AMD_STATS", "1")
+    monkeypatch.setenv("RAMSES_AMD_TILE_MIN_OCTS", "0")
+    monkeypatch.delenv("RAMSES_AMD_FAST", raising=False)
+    monkeypatch.delenv("RAMSES_AMD_STRICT", raising=False)      # the default of a user's run
+    work, out = rs.run_reference(nml, binary=PATCHED)
+    try:
+        assert "AMR levels stay resident on the GPU" in out, out[-2000:]
+        assert "dense sweep arithmetic = fast" in out, out[-2000:]
+        m = re.search(r"godunov_fine of AMR levels: (\d+) sweeps through the dense kernel on tiles \((\d+) of them fully refined levels\), (\d+) through the tree-walking", out)
+        assert m, out[-1500:]
+        dense, covered, tree = (int(x) for x in m.groups())
+        assert dense > covered > 0 and tree == 0, (dense, covered, tree)
+        got = rs.load_leaf_cells(os.path.join(work, "output_00002"))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    monkeypatch.setenv("RAMSES_AMD", "0")
+    nproc = min(_nproc(), 8)
+    workr, outr = rs.run_reference(nml, binary=REF_MPI, nproc=nproc)
+    try:
+        ref = rs.load_leaf_cells(os.path.join(workr, "output_00002"))
+    finally:
+        shutil.rmtree(workr, ignore_errors=True)
+    lg, xg, pg = _sorted_leaves(got)
+    lr, xr, pr = _sorted_leaves(ref)
+    counts = [int((lr == l).sum()) for l in range(lmin, lmax + 1)]
+    assert min(counts) > 500, counts                      # every level is populated
+    assert int(np.ravel(got["info"]["nstep"])[0]) == int(np.ravel(ref["info"]["nstep"])[0]) == nstep
+    assert np.array_equal(lg, lr) and np.array_equal(xg, xr), "the two runs refined different cells"
+    tr = float(np.ravel(ref["info"]["t"])[0])
+    assert abs(float(np.ravel(got["info"]["t"])[0]) - tr) <= TOL * tr
+    vmax = np.abs(pr).max(axis=1)
+    err = _rel(pg, pr, vmax)
+    print("default (fast) AMR %d-%d vs the live MPI reference, %d steps, %d dense sweeps, leaves per level %s: rel-Linf = %s"
+          % (lmin, lmax, nstep, dense, counts, err))
+    assert (err <= TOL).all(), err
