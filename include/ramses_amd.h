@@ -284,6 +284,12 @@ int ramses_amd_godunov_fine_f90(const ramses_amd_hydro_params *p, int ilevel, in
 int ramses_amd_godunov_fine_lowdim_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, int nbound,
                                        const int *igrid_bound, const double *xg, int64_t ngridmax, int64_t ncoarse, const int *skip,
                                        const int *nloc, const double *uold, double *unew, double dx, double dt);
+/* NDIM<3 builds: the drop-in reports every level it hands to the reference's host godunov_fine (a level that is not uniform,
+ * gravity, ..., or a refusal of the entry above with RAMSES_AMD_EUNSUPPORTED); the library counts its own sweeps and prints both,
+ * level by level, in one line at exit. */
+int ramses_amd_lowdim_note_reference(int ilevel);
+int64_t ramses_amd_lowdim_device_sweeps(void);
+int64_t ramses_amd_lowdim_reference_sweeps(void);
 
 /* ---------------------------------------------------------------------------
  * multigrid_fine(ilevel,icount) on the reference's OWN arrays: the entry point
@@ -691,6 +697,13 @@ int ramses_amd_mgdist_destroy(ramses_amd_mgdist *ctx);
 int ramses_amd_mgdist_info(const ramses_amd_mgdist *ctx, int *dims, int *coords, int *n_distributed_levels,
                            int *first_replicated_level, int *safe_mode, int64_t *exchanges);
 int ramses_amd_mgdist_set_safe_mode(ramses_amd_mgdist *ctx, int safe_mode);
+/* The order in which the reference adds the squared residuals of this rank's cells (cmp_residual_norm2_fine,
+ * poisson/multigrid_fine_fine.f90:254-287: octant by octant over active(ilevel)%igrid): order[k] = index of the k-th cell of that
+ * loop in the rank's dense brick, a permutation of 0 .. N-1 (host array); n = 0 switches back.  With an order set, the two norms
+ * of every iteration (poisson/multigrid_fine_commons.f90:205-211, 261-276) are strictly sequential sums in it -- the reference's
+ * bits and therefore its convergence decision -- instead of the smoother's reduction tree.  ramses_amd_mgdist_multigrid_f90
+ * sets it from the list it is called with. */
+int ramses_amd_mgdist_set_order(ramses_amd_mgdist *ctx, const int *order, int64_t n);
 int ramses_amd_mgdist_solve(ramses_amd_mgdist *ctx, const double *d_rho, double rho_tot, double fourpi, double epsilon,
                             int *iters_out, double *err_out, void *stream);
 int ramses_amd_mgdist_get_phi(ramses_amd_mgdist *ctx, double *d_phi, void *stream);
@@ -856,6 +869,7 @@ int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int 
 int64_t ramses_amd_amrres_covered_sweeps(void);
 int64_t ramses_amd_amrres_tile_sweeps(void);
 int64_t ramses_amd_amrres_tree_sweeps(void);
+int64_t ramses_amd_amrres_relayouts(void);   /* regrids that moved the kept levels to new device indices (their tiles were in the way) */
 int ramses_amd_amrres_tiled_levels(void);
 /* make_boundary_hydro(ilevel) on the resident cell vectors (hydro/hydro_boundary.f90:5-269; callers amr/amr_step.f90:70,293,514):
  * the boundary octs of every physical boundary region of a level take the mirrored (boundary_type 1-6) or the copied

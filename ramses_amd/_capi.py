@@ -156,6 +156,7 @@ SYMBOLS = [
     ("ramses_amd_mgdist_destroy", _i, [_vp]),
     ("ramses_amd_mgdist_info", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("ramses_amd_mgdist_set_safe_mode", _i, [_vp, _i]),
+    ("ramses_amd_mgdist_set_order", _i, [_vp, _vp, _i64]),
     ("ramses_amd_mgdist_solve", _i, [_vp, _vp, _d, _d, _d, _vp, _vp, _vp]),
     ("ramses_amd_mgdist_get_phi", _i, [_vp, _vp, _vp]),
     ("ramses_amd_mgdist_set_phi", _i, [_vp, _vp, _vp]),
@@ -180,6 +181,9 @@ SYMBOLS = [
     ("ramses_amd_mpires_invalidate", _i, []),
     # residency for AMR runs
     ("ramses_amd_godunov_fine_lowdim_f90", _i, [_PP, _i, _i, _vp, _i, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _d, _d]),
+    ("ramses_amd_lowdim_note_reference", _i, [_i]),
+    ("ramses_amd_lowdim_device_sweeps", _i64, []),
+    ("ramses_amd_lowdim_reference_sweeps", _i64, []),
     ("ramses_amd_amrres_active", _i, []),
     ("ramses_amd_amrres_load", _i, [_i, _i64, _i64, _vp, _vp, _vp, _vp]),
     ("ramses_amd_amrres_tree", _i, [_vp, _vp, _vp]),
@@ -204,6 +208,7 @@ SYMBOLS = [
     ("ramses_amd_amrres_covered_sweeps", _i64, []),
     ("ramses_amd_amrres_tile_sweeps", _i64, []),
     ("ramses_amd_amrres_tree_sweeps", _i64, []),
+    ("ramses_amd_amrres_relayouts", _i64, []),
     ("ramses_amd_amrres_tiled_levels", _i, []),
     ("ramses_amd_amrres_boundary_hydro", _i, [_i, _vp, _vp, _vp, _i, _d, _i, _vp]),
     ("ramses_amd_mhd_workspace_bytes", _i64, [_i, _i, _i]),

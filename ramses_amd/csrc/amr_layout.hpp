@@ -259,6 +259,7 @@ struct DevMap {
   int version_counter = 0;
   long tiles_levels = 0;       // how many levels are stored in tiles (diagnostics)
   const char *why_not = "";
+  bool overflow = false;       // the last build failed because the levels that kept their tiles left too little room for the finer ones
 
 #define LCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -275,6 +276,9 @@ struct DevMap {
     serial++;
     first_changed = 1;
   }
+
+  // the next build lays every level out again (their device data is the caller's to move)
+  void forget() { nlev = 0; }
 
   hipError_t scan_need(int nt, int &ntiles, hipStream_t s) {
     size_t bytes = 0;
@@ -294,6 +298,7 @@ struct DevMap {
   // status bytes.  With `on` false the arrays are copied as they are.
   hipError_t build(const int *son, const int *nbor, const int *father, int *son_d, int *nbor_d, int *father_d, unsigned char *stat, hipStream_t s) {
     serial++;
+    overflow = false;
     const size_t ncell_h = (size_t)(ncoarse + 8 * ngh), ncell_d = (size_t)(ncoarse + 8 * ngd);
     if (!on) {
       LCHK(hipMemcpyAsync(son_d, son, sizeof(int) * ncell_h, hipMemcpyHostToDevice, s));
@@ -414,7 +419,14 @@ struct DevMap {
         LCHK(hipStreamSynchronize(s));
       }
       next = L.base + L.cap;
-      if (next > ngd + 1) { why_not = "the levels do not fit into the device's index space"; return hipErrorInvalidValue; }
+      if (next > ngd + 1) {
+        // The tree itself fits (the BFS counted <= ngridmax octs): what is in the way are the free slots of the tiles of levels
+        // that kept their layout -- their fit was checked against the finer levels of THAT moment.  The caller parks the kept
+        // levels' data, forgets the layout (forget()) and builds again from level 1 (csrc/capi_amr.hip ramses_amd_amrres_tree).
+        why_not = "the levels do not fit into the device's index space";
+        overflow = k0 > 1;
+        return hipErrorInvalidValue;
+      }
     }
     // ---- 4. perm / iperm / okey, the tree in device numbers, the status bytes -----------------------------------------------
     LCHK(hipMemsetAsync(perm.p, 0, sizeof(int) * (size_t)ngh, s));

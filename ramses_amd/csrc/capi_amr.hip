@@ -783,6 +783,7 @@ struct AmrRes {
   int *cur_ig = nullptr;                       // the list of the routine under way (device indices)
   std::vector<LevelPlan> plan;
   long tile_sweeps = 0, tree_sweeps = 0;
+  long relayouts = 0;                          // regrids that had to lay the kept levels out again (tiles in the way of the finer levels)
   bool announced = false;
   const double *h_uold = nullptr;
   Buf uold, unew, son, nbor, father, work, err, red, okbuf, pack;
@@ -920,6 +921,48 @@ int ramses_amd_amrres_tree(const int *son, const int *nbor, const int *father) {
   if (!R.valid) return failf(RAMSES_AMD_EINVAL, "no resident AMR state");
   if (!son || !nbor || !father) return failf(RAMSES_AMD_EINVAL, "NULL argument");
   hipError_t e = R.map.build(son, nbor, father, R.son.as<int>(), R.nbor.as<int>(), R.father.as<int>(), R.stat.as<unsigned char>(), nullptr);
+  if (e == hipErrorInvalidValue && R.map.on && R.map.overflow) {
+    // A legitimate regrid: the finer levels grew, and the free tile slots of the levels that kept their layout are in the way
+    // (their fit was checked against the finer levels of the time they were laid out).  Those levels' state lives on the device
+    // only: it is parked in the host's numbering, every level is laid out again -- tiles where they fit NOW -- and the state
+    // goes back to the new indices.  The rebuilt levels are the caller's to reload, as after any regrid.
+    (void)hipGetLastError();
+    const int kept = R.map.first_changed - 1;
+    const int nvec = 2 * R.nvar + (R.grav ? 3 : 0);
+    Buf park;
+    HCHK(park.ensure(sizeof(double) * (size_t)nvec * (size_t)R.ncell_h), "hipMalloc (parking the kept levels)");
+    auto vec_of = [&](int v, double *&dev) {          // device vector v of the parked set
+      if (v < R.nvar) dev = R.uold.as<double>() + (long)v * R.ncell;
+      else if (v < 2 * R.nvar) dev = R.unew.as<double>() + (long)(v - R.nvar) * R.ncell;
+      else dev = R.f.as<double>() + (long)(v - 2 * R.nvar) * R.ncell;
+    };
+    for (int l = 1; l <= kept; l++) {
+      amrlayout::LevelMap &L = R.map.lev[l];
+      for (int v = 0; v < nvec; v++) {
+        double *dev; vec_of(v, dev);
+        hipLaunchKernelGGL(amrlayout::move_var_kernel<false>, dim3(amrlayout::grid1((long)L.n * 8)), dim3(256), 0, nullptr, L.hoct.as<int>(), L.doct.as<int>(), L.n,
+                           R.ncoarse, R.ngh, R.ngridmax, park.as<double>() + (long)v * R.ncell_h, dev);
+      }
+    }
+    HCHK(hipGetLastError(), "parking the kept levels");
+    HCHK(hipDeviceSynchronize(), "sync");
+    R.map.forget();
+    e = R.map.build(son, nbor, father, R.son.as<int>(), R.nbor.as<int>(), R.father.as<int>(), R.stat.as<unsigned char>(), nullptr);
+    if (e == hipSuccess) {
+      for (int l = 1; l <= kept && l <= R.map.nlev; l++) {
+        amrlayout::LevelMap &L = R.map.lev[l];
+        for (int v = 0; v < nvec; v++) {
+          double *dev; vec_of(v, dev);
+          hipLaunchKernelGGL(amrlayout::move_var_kernel<true>, dim3(amrlayout::grid1((long)L.n * 8)), dim3(256), 0, nullptr, L.hoct.as<int>(), L.doct.as<int>(), L.n,
+                             R.ncoarse, R.ngh, R.ngridmax, park.as<double>() + (long)v * R.ncell_h, dev);
+        }
+      }
+      HCHK(hipGetLastError(), "restoring the kept levels");
+      HCHK(hipDeviceSynchronize(), "sync");
+      R.relayouts++;
+    }
+    if (park.p) (void)hipFree(park.p);
+  }
   if (e != hipSuccess) return failf(e == hipErrorInvalidValue ? RAMSES_AMD_EINVAL : RAMSES_AMD_EHIP, "tree layout on the device: %s", e == hipErrorInvalidValue ? R.map.why_not : hipGetErrorString(e));
   if (R.map.on) {
     // (list positions of the levels that were laid out again; the kept levels keep their plans)
@@ -1334,6 +1377,9 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
   A.uold = R.uold.as<double>(); A.unew = R.unew.as<double>(); A.grav = R.grav ? R.f.as<double>() : nullptr;      // the cell vectors themselves
   A.stat = R.stat.as<unsigned char>(); A.dir = L.dir.as<int>(); A.work = P.work.as<int>(); A.nwork = P.nwork;
   A.ntx = L.ntx; A.nty = L.nty; A.ntz = L.ntz; A.ngd = R.ngridmax; A.ncoarse = R.ncoarse;
+  // (the finest level of the tree: nothing has touched unew since set_unew copied uold into it -- the contract of this routine,
+  //  hydro/godunov_fine.f90:5-35 after amr_step's set_unew -- so the kernel re-reads uold from L2 instead of streaming unew)
+  A.base_uold = (ilevel >= R.map.nlev || R.map.lev[ilevel + 1].n == 0) && env_on("RAMSES_AMD_TILE_BASE_UOLD") ? 1 : 0;
   const int n = 2 * L.no;
   A.nx = A.ny = A.nz = n; A.ng = 0;
   A.pitch_y = n; A.pitch_z = (long)n * n; A.pitch_var = R.ncell;
@@ -1388,6 +1434,8 @@ extern "C" int64_t ramses_amd_amrres_covered_sweeps(void) { return g_ar.covered_
 // sweeps of AMR levels so far: through the dense kernel on tiles / through the tree-walking kernel
 extern "C" int64_t ramses_amd_amrres_tile_sweeps(void) { return g_ar.tile_sweeps; }
 extern "C" int64_t ramses_amd_amrres_tree_sweeps(void) { return g_ar.tree_sweeps; }
+// regrids after which the levels that had kept their layout were laid out again, their state moved on the device
+extern "C" int64_t ramses_amd_amrres_relayouts(void) { return g_ar.relayouts; }
 // levels the device stores in tiles (0: the host's numbering is in force)
 extern "C" int ramses_amd_amrres_tiled_levels(void) { return g_ar.valid && g_ar.map.on ? (int)g_ar.map.tiles_levels : 0; }
 

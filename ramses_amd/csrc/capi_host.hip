@@ -286,6 +286,31 @@ int ramses_amd_godunov_fine_amr_f90(const ramses_amd_hydro_params *p, int ilevel
 // boundary octs are periodic.  The cell vectors are uold(1:ncell,1:ndim+2) with ncell = ncoarse + 2^ndim ngridmax; xg is
 // xg(1:ngridmax,1:ndim) in coarse-cell units, skip = (icoarse_min, jcoarse_min), nloc = interior coarse cells per direction.
 // The level is a few thousand cells: the brick is put together on the host.
+// what godunov_fine of an NDIM<3 build did, level by level: sweeps on the device / sweeps the drop-in handed to the reference's host
+// routine (ramses_amd_lowdim_note_reference).  One line at exit whenever anything was counted: a run that regrids away from the
+// uniform level is a CPU run from then on and must not look like a device run.
+static long g_lowdim_dev[32] = {0}, g_lowdim_ref[32] = {0};
+static void lowdim_report(void) {
+  long nd = 0, nr = 0;
+  for (int l = 0; l < 32; l++) { nd += g_lowdim_dev[l]; nr += g_lowdim_ref[l]; }
+  if (nd + nr == 0) return;
+  printf(" ramses_amd: NDIM<3 godunov_fine: %ld sweeps on the device, %ld through the reference's host routine; per level (device/reference):", nd, nr);
+  for (int l = 0; l < 32; l++) if (g_lowdim_dev[l] + g_lowdim_ref[l]) printf(" %d:%ld/%ld", l, g_lowdim_dev[l], g_lowdim_ref[l]);
+  printf("\n");
+  fflush(stdout);
+}
+static void lowdim_register(void) {
+  static bool registered = false;
+  if (!registered) { registered = true; atexit(lowdim_report); }
+}
+int ramses_amd_lowdim_note_reference(int ilevel) {
+  lowdim_register();
+  if (ilevel >= 0 && ilevel < 32) g_lowdim_ref[ilevel]++;
+  return 0;
+}
+int64_t ramses_amd_lowdim_device_sweeps(void) { long n = 0; for (int l = 0; l < 32; l++) n += g_lowdim_dev[l]; return n; }
+int64_t ramses_amd_lowdim_reference_sweeps(void) { long n = 0; for (int l = 0; l < 32; l++) n += g_lowdim_ref[l]; return n; }
+
 int ramses_amd_godunov_fine_lowdim_f90(const ramses_amd_hydro_params *p, int ilevel, int ngrid, const int *igrid, int nbound,
                                        const int *igrid_bound, const double *xg, int64_t ngridmax, int64_t ncoarse, const int *skip,
                                        const int *nloc, const double *uold, double *unew, double dx, double dt) {
@@ -391,6 +416,8 @@ int ramses_amd_godunov_fine_lowdim_f90(const ramses_amd_hydro_params *p, int ile
       for (int v = 0; v < nvh; v++) unew[(size_t)v * ncell + icell] = hb[(size_t)vmap[v] * b.pitch_var + at];
     }
   }
+  lowdim_register();
+  if (ilevel < 32) g_lowdim_dev[ilevel]++;
   return 0;
 }
 

@@ -228,7 +228,7 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   const double *__restrict__ grav = A.grav;
 
 #ifndef SWEEP_LATE_BASE
-#define SWEEP_LATE_BASE 1
+#define SWEEP_LATE_BASE 0      // (measured on MI355X, round 6: 512^3 fast 3.237 -> 3.272 ms, the tiled 256^3 level unchanged: the wait at the x flux is not what costs)
 #endif
   constexpr bool LATE = SWEEP_LATE_BASE && NV == 5;   // (the passive-scalar fix of NV > 5 wants the old state in phase A)
   constexpr bool r_trace = ROLE == ROLE_LOW || ROLE == ROLE_HIGH || ROLE == ROLE_FULL;
@@ -279,10 +279,14 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
     for (int n = 0; n < NV; n++)
       u[n] = MASK ? plane_load(uold + (long)(n & ~1) * A.pitch_var, pb + (n & 1) * odd_var, off) : plane_load(uold + (long)n * A.pitch_var, pb, off);
   };
-  auto load_base = [&](int p, double (&u)[NV]) {   // MASK: the state the update starts from (unew, in place)
+  // MASK: the state the update starts from: unew, in place -- it holds what the finer level owes to this one (:752-790) -- or, on a
+  // level without finer octs (set_unew has just made unew = uold there), uold again: the planes this workgroup read two iterations
+  // ago, from L2 instead of a second stream from HBM
+  const double *__restrict__ bsrc = A.base_uold ? uold : unew;
+  auto load_base = [&](int p, double (&u)[NV]) {
     const unsigned pb = zpart(p) * 8u, off = tbp(p);
 #pragma unroll
-    for (int n = 0; n < NV; n++) u[n] = plane_load(unew + (long)(n & ~1) * A.pitch_var, pb + (n & 1) * odd_var, off);
+    for (int n = 0; n < NV; n++) u[n] = plane_load(bsrc + (long)(n & ~1) * A.pitch_var, pb + (n & 1) * odd_var, off);
   };
   int ok_zlo = 0;   // MASK: plane c-1's status byte of this column
   int spre = 0;     // MASK: plane c+1's status byte, on its way
@@ -588,35 +592,63 @@ __device__ __forceinline__ long surf_cell(const SurfArgs &A, int x, int y, int z
   const int ind = (x & 1) + 2 * (y & 1) + 4 * (z & 1);
   return c0 + (ox % TILE_OX) + TILE_OX * ((oy % TILE_OY) + TILE_OY * (oz % TILE_OZ)) + (long)ind * A.ngd;
 }
-template <int NV, bool GRAV>
-__device__ __forceinline__ void surf_prim(const SurfArgs &A, int x, int y, int z, double (&q)[NV]) {
-  const long c = surf_cell(A, x, y, z);
-  double u[NV], g[3];
+// One interface of direction DIR between the cells lo (left) and hi = lo + e_DIR: the twelve cells the two traces read -- four
+// along DIR (lo - 1 .. hi + 1), the four transverse neighbours of each of the two -- are addressed and requested FIRST (the kernel
+// is a gather of isolated 8-byte words: what it costs is the latency of dependent loads, so nothing may wait between them), then
+// converted (ctoprim), then the slopes and the two traces -- what a lane of the marching kernel does for its cell in phase A --
+// and the Riemann flux, scaled like the marching kernel's.
+template <int ST, int RS, int NV, bool GRAV, int DIR>
+__device__ __forceinline__ void surf_interface(const SurfArgs &A, const int (&lo)[3], double (&fl)[NV]) {
+  constexpr int T0 = DIR == 0 ? 1 : 0, T1 = DIR == 2 ? 1 : 2;
+  long c[12];
+  // 0..3: along DIR at lo-1, lo, hi, hi+1;  4..7: lo -T0, +T0, -T1, +T1;  8..11: the same of hi
 #pragma unroll
-  for (int n = 0; n < NV; n++) u[n] = A.uold[(long)n * A.ncell + c];
+  for (int k = 0; k < 4; k++) {
+    int p[3] = {lo[0], lo[1], lo[2]};
+    p[DIR] += k - 1;
+    c[k] = surf_cell(A, p[0], p[1], p[2]);
+  }
 #pragma unroll
-  for (int d = 0; d < 3; d++) g[d] = GRAV ? A.grav[(long)d * A.ncell + c] : 0.0;
-  ctoprim_cell<NV, GRAV>(u, g, A.dt * 0.5, A.P, q);
-}
-// the traced states of cell (x, y, z): ctoprim of the cell and its six neighbours, the slopes, trace3d -- what a lane of the
-// marching kernel does for its cell in phase A
-template <int ST, int NV, bool GRAV>
-__device__ __noinline__ void surf_trace(const SurfArgs &A, int x, int y, int z, double (&qm)[3][NV], double (&qp)[3][NV]) {
-  double qb[NV], dq[3][NV];
-  surf_prim<NV, GRAV>(A, x, y, z, qb);
+  for (int w = 0; w < 2; w++)
 #pragma unroll
-  for (int d = 0; d < 3; d++) {
-    double ql[NV], qr[NV];
-    surf_prim<NV, GRAV>(A, x - (d == 0), y - (d == 1), z - (d == 2), ql);
-    surf_prim<NV, GRAV>(A, x + (d == 0), y + (d == 1), z + (d == 2), qr);
+    for (int k = 0; k < 4; k++) {
+      int p[3] = {lo[0], lo[1], lo[2]};
+      p[DIR] += w;
+      p[k < 2 ? T0 : T1] += (k & 1) ? 1 : -1;
+      c[4 + 4 * w + k] = surf_cell(A, p[0], p[1], p[2]);
+    }
+  double q[12][NV];
+  {
+    double u[12][NV], g[12][3];
 #pragma unroll
-    for (int n = 0; n < NV; n++) dq[d][n] = slope1<ST>(ql[n], qb[n], qr[n], A.P);
+    for (int k = 0; k < 12; k++) {
+#pragma unroll
+      for (int n = 0; n < NV; n++) u[k][n] = A.uold[(long)n * A.ncell + c[k]];
+#pragma unroll
+      for (int d = 0; d < 3; d++) g[k][d] = GRAV ? A.grav[(long)d * A.ncell + c[k]] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) ctoprim_cell<NV, GRAV>(u[k], g[k], A.dt * 0.5, A.P, q[k]);
   }
   const double dtdx = A.dt / A.dx;
-  trace3d_cell<NV>(qb, dq, dtdx, dtdx, dtdx, A.P, qm, qp);
+  double qL[NV], qR[NV];
+#pragma unroll
+  for (int w = 0; w < 2; w++) {
+    double dq[3][NV], qm[3][NV], qp[3][NV];
+#pragma unroll
+    for (int n = 0; n < NV; n++) {
+      dq[DIR][n] = slope1<ST>(q[w][n], q[1 + w][n], q[2 + w][n], A.P);
+      dq[T0][n] = slope1<ST>(q[4 + 4 * w][n], q[1 + w][n], q[5 + 4 * w][n], A.P);
+      dq[T1][n] = slope1<ST>(q[6 + 4 * w][n], q[1 + w][n], q[7 + 4 * w][n], A.P);
+    }
+    trace3d_cell<NV>(q[1 + w], dq, dtdx, dtdx, dtdx, A.P, qm, qp);
+#pragma unroll
+    for (int n = 0; n < NV; n++) { if (w == 0) qL[n] = qm[DIR][n]; else qR[n] = qp[DIR][n]; }
+  }
+  scaled_interface_flux<RS, NV, DIR>(qL, qR, A.P, A.dt, A.dx, A.rdx, dtdx, A.pow2 != 0, fl);
 }
 template <int ST, int RS, int NV, bool GRAV>
-__global__ __launch_bounds__(256) void surface_flux_kernel(SurfArgs A) {
+__global__ __launch_bounds__(128) void surface_flux_kernel(SurfArgs A) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)A.nevent * 4) return;
   const int e = (int)(t >> 2), q = (int)(t & 3);
@@ -628,24 +660,18 @@ __global__ __launch_bounds__(256) void surface_flux_kernel(SurfArgs A) {
   const int tl = A.tileid[r / TILE_OCTS], l = (int)(r % TILE_OCTS);
   int p[3] = {2 * ((tl % A.ntx) * TILE_OX + l % TILE_OX), 2 * (((tl / A.ntx) % A.nty) * TILE_OY + (l / TILE_OX) % TILE_OY),
               2 * ((tl / (A.ntx * A.nty)) * TILE_OZ + l / (TILE_OX * TILE_OY))};
-  // the updated cell behind fine face q of face f (q: the two transverse coordinates, lower axis first), the ghost cell beyond
+  // the updated cell behind fine face q of face f (q: the two transverse coordinates, lower axis first); the ghost cell is the
+  // one beyond the face; lo = the left cell of the interface
   const int t0 = dirn == 0 ? 1 : 0, t1 = dirn == 2 ? 1 : 2;
   p[dirn] += side; p[t0] += q & 1; p[t1] += q >> 1;
-  int g[3] = {p[0], p[1], p[2]};
-  g[dirn] += side ? 1 : -1;
-  const int *lo = side ? p : g, *hi = side ? g : p;       // left and right cell of the interface
-  double qm[3][NV], qp[3][NV], qL[NV], fl[NV];
-  surf_trace<ST, NV, GRAV>(A, lo[0], lo[1], lo[2], qm, qp);
-#pragma unroll
-  for (int n = 0; n < NV; n++) qL[n] = dirn == 0 ? qm[0][n] : (dirn == 1 ? qm[1][n] : qm[2][n]);
-  surf_trace<ST, NV, GRAV>(A, hi[0], hi[1], hi[2], qm, qp);
-  const double dtdx = A.dt / A.dx;
-  const bool DXPOW2 = A.pow2 != 0;
-  if (dirn == 0) scaled_interface_flux<RS, NV, 0>(qL, qp[0], A.P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fl);
-  else if (dirn == 1) scaled_interface_flux<RS, NV, 1>(qL, qp[1], A.P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fl);
-  else scaled_interface_flux<RS, NV, 2>(qL, qp[2], A.P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fl);
   // hydro/godunov_fine.f90:720-747: reset when the cell on either side is refined (a ghost cell never is)
   const bool zero = (A.stat[surf_cell(A, p[0], p[1], p[2])] & CELL_REFINED) != 0;
+  int lo[3] = {p[0], p[1], p[2]};
+  if (!side) lo[dirn] -= 1;
+  double fl[NV];
+  if (dirn == 0) surf_interface<ST, RS, NV, GRAV, 0>(A, lo, fl);
+  else if (dirn == 1) surf_interface<ST, RS, NV, GRAV, 1>(A, lo, fl);
+  else surf_interface<ST, RS, NV, GRAV, 2>(A, lo, fl);
   double *dst = A.rec + ((long)e * 4 + q) * (NV + 2);
 #pragma unroll
   for (int n = 0; n < NV; n++) dst[n] = zero ? 0.0 : fl[n];
@@ -656,7 +682,7 @@ static hipError_t surface1(const SurfArgs &A, bool grav, hipStream_t s) {
   if constexpr (ST == 3 || ST == 4 || ST == 5 || ST == 6 || RS == RIEMANN_EXACT) {
     return hipErrorInvalidValue;
   } else {
-    const dim3 grid((unsigned)(((long)A.nevent * 4 + 255) / 256)), block(256);
+    const dim3 grid((unsigned)(((long)A.nevent * 4 + 127) / 128)), block(128);
     if (grav) hipLaunchKernelGGL((surface_flux_kernel<ST, RS, 5, true>), grid, block, 0, s, A);
     else hipLaunchKernelGGL((surface_flux_kernel<ST, RS, 5, false>), grid, block, 0, s, A);
     return hipGetLastError();

@@ -118,6 +118,13 @@ struct ramses_amd_mgdist {
   int64_t exchanges = 0;
   int last_iters = 0;
   double last_err = 0.0;
+  // the convergence test in the REFERENCE's summation order (cmp_residual_norm2_fine, poisson/multigrid_fine_fine.f90:254-287:
+  // octant by octant over the rank's oct list, one double after the other): order[k] = dense-brick index of the k-th cell of
+  // that loop (ramses_amd_mgdist_set_order); without it the norm is the smoother's own reduction tree
+  int *d_order = nullptr;
+  long order_n = 0;
+  double *ord_x = nullptr;
+  void *ord_scratch = nullptr;
 };
 
 namespace {
@@ -281,6 +288,25 @@ hipError_t fused(ramses_amd_mgdist *M, Level &L, const double *src, double *dst,
                                 L.n[1], L.n[2]);
 }
 
+// ---- the local residual norm in the reference's order (see ramses_amd_mgdist::d_order) -------------------------------------
+__global__ __launch_bounds__(256) void mgdist_gather_sq_kernel(const double *__restrict__ res, const int *__restrict__ order, long n, double *__restrict__ x) {
+  const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) { const double r = res[order[k]]; x[k] = r * r; }
+}
+__global__ void mgdist_scale_kernel(double *v, double a) { v[0] = a * v[0]; }   // norm2 = dx2*norm2 (:285)
+// res: the residual of level L with its ghost layers; *slot = dx^3 * (((r_1^2 + r_2^2) + r_3^2) + ...) over the rank's own cells
+int ordered_norm(ramses_amd_mgdist *M, Level &L, double *res, double *slot, hipStream_t s) {
+  const long N = M->order_n;
+  RCHK(interior_copy(L, res, M->dense, 1, s));
+  hipLaunchKernelGGL(mgdist_gather_sq_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, M->dense, M->d_order, N, M->ord_x);
+  HCHK(hipGetLastError(), "residual norm (gather)");
+  RCHK(ramses_amd_ordered_sum_device(M->ord_x, N, slot, M->ord_scratch, s));
+  const double dx = std::ldexp(1.0, -L.l);
+  hipLaunchKernelGGL(mgdist_scale_kernel, dim3(1), dim3(1), 0, s, slot, dx * dx * dx);
+  HCHK(hipGetLastError(), "residual norm (scale)");
+  return 0;
+}
+
 bool distributed(const ramses_amd_mgdist *M, int l) { return l >= 1 && l < (int)M->lev.size() && M->lev[l].built; }
 
 // restrict the residual of level l into level l-1 (its u2) and zero that level's correction
@@ -433,6 +459,9 @@ int ramses_amd_mgdist_destroy(ramses_amd_mgdist *M) {
   double **dev[] = {&M->rep_rhs, &M->rep_u1, &M->rep_work, &M->rep_parts, &M->rep_mine, &M->work, &M->norm, &M->dense};
   for (double **p : dev) if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (M->d_rank_of_brick) (void)hipFree(M->d_rank_of_brick);
+  if (M->d_order) (void)hipFree(M->d_order);
+  if (M->ord_x) (void)hipFree(M->ord_x);
+  if (M->ord_scratch) (void)hipFree(M->ord_scratch);
   if (M->h_mine) (void)hipHostFree(M->h_mine);
   if (M->h_parts) (void)hipHostFree(M->h_parts);
   delete M;
@@ -450,6 +479,28 @@ int ramses_amd_mgdist_info(const ramses_amd_mgdist *M, int *dims, int *coords, i
   if (first_replicated_level) *first_replicated_level = M->lrep;
   if (safe_mode) *safe_mode = M->safe_mode;
   if (exchanges) *exchanges = M->exchanges;
+  return 0;
+}
+
+// The order in which the reference adds the squared residuals of this rank's cells (cmp_residual_norm2_fine: octant by octant
+// over active(ilevel)%igrid): order[k] = index of the k-th cell of that loop in the rank's dense [nz][ny][nx] brick, a permutation
+// of 0 .. N-1 (host array).  From then on the two norms of every iteration are strictly sequential sums in that order -- the
+// reference's bits, and with them its convergence decision; n = 0 returns to the smoother's own reduction tree.
+int ramses_amd_mgdist_set_order(ramses_amd_mgdist *M, const int *order, int64_t n) {
+  if (!M) return failf(RAMSES_AMD_EINVAL, "NULL context");
+  const long N = (long)M->dims[0] * M->dims[1] * M->dims[2];
+  if (n == 0) { M->order_n = 0; return 0; }
+  if (!order || n != N) return failf(RAMSES_AMD_EINVAL, "the order must name each of the brick's %ld cells once (got %ld entries)", N, (long)n);
+  std::vector<unsigned char> seen((size_t)N, 0);
+  for (long k = 0; k < N; k++) {
+    if (order[k] < 0 || order[k] >= N || seen[(size_t)order[k]]) return failf(RAMSES_AMD_EINVAL, "the order is not a permutation of the brick's cells (entry %ld)", k);
+    seen[(size_t)order[k]] = 1;
+  }
+  if (!M->d_order) HCHK(hipMalloc(&M->d_order, sizeof(int) * (size_t)N), "hipMalloc");
+  if (!M->ord_x) HCHK(hipMalloc(&M->ord_x, sizeof(double) * (size_t)N), "hipMalloc");
+  if (!M->ord_scratch) HCHK(hipMalloc(&M->ord_scratch, ramses_amd_ordered_sum_scratch(N)), "hipMalloc");
+  HCHK(hipMemcpy(M->d_order, order, sizeof(int) * (size_t)N, hipMemcpyHostToDevice), "H2D order");
+  M->order_n = N;
   return 0;
 }
 
@@ -477,7 +528,9 @@ int ramses_amd_mgdist_solve(ramses_amd_mgdist *M, const double *d_rho, double rh
   for (;;) {
     it++;
     if (it > 1) RCHK(exchange(M, L, phi, s));
-    HCHK(fused(M, L, phi, phi2, f2, f1, it == 1 ? M->norm : nullptr, s), "mg fused smoother launch");
+    const bool ordered = M->order_n == N && M->d_order;
+    HCHK(fused(M, L, phi, phi2, f2, f1, (it == 1 && !ordered) ? M->norm : nullptr, s), "mg fused smoother launch");
+    if (it == 1 && ordered) RCHK(ordered_norm(M, L, f1, M->norm, s));
     if (it == 1) RCHK(allreduce_sum(M, M->norm, &i_res_norm2, s));
     if (M->level > 1) {
       RCHK(restrict_to(M, M->level, f1, s));
@@ -486,7 +539,13 @@ int ramses_amd_mgdist_solve(ramses_amd_mgdist *M, const double *d_rho, double rh
     }
     RCHK(exchange(M, L, phi2, s));
     // post-smoothing; only the norm of the residual is needed
-    HCHK(fused(M, L, phi2, phi, f2, nullptr, M->norm + 1, s), "mg fused smoother launch");
+    if (ordered) {
+      // (the residual leaves the chip once more per iteration: f1 is free after the restriction)
+      HCHK(fused(M, L, phi2, phi, f2, f1, nullptr, s), "mg fused smoother launch");
+      RCHK(ordered_norm(M, L, f1, M->norm + 1, s));
+    } else {
+      HCHK(fused(M, L, phi2, phi, f2, nullptr, M->norm + 1, s), "mg fused smoother launch");
+    }
     RCHK(allreduce_sum(M, M->norm + 1, &res_norm2, s));
     const double last_err = err;
     err = std::sqrt(res_norm2 / (i_res_norm2 + 1e-20 * (rho_tot * rho_tot)));
@@ -650,6 +709,15 @@ int ramses_amd_mgdist_multigrid_f90(ramses_amd_mgdist *M, int ilevel, int ngrid,
   HCHK(d_rho.ensure(sizeof(double) * N), "hipMalloc");
   HCHK(d_phi.ensure(sizeof(double) * N), "hipMalloc");
   HCHK(hipMemcpyAsync(d_rho.p, h_brick.data(), sizeof(double) * N, hipMemcpyHostToDevice, s), "H2D rho");
+  {
+    // the convergence test sums the squared residuals as cmp_residual_norm2_fine does: octant by octant over this very list
+    static std::vector<int> order;
+    order.resize((size_t)N);
+    for (int ind = 0; ind < 8; ind++)
+      for (int g = 0; g < ngrid; g++)
+        order[(size_t)ind * ngrid + g] = (int)(org[g] + (ind & 1) + py * ((ind >> 1) & 1) + pz * ((ind >> 2) & 1));
+    RCHK(ramses_amd_mgdist_set_order(M, order.data(), N));
+  }
   M->safe_mode = *safe_mode ? 1 : 0;
   RCHK(ramses_amd_mgdist_solve(M, reinterpret_cast<const double *>(d_rho.p), rho_tot, fourpi, epsilon, iters, err, s));
   *safe_mode = M->safe_mode;

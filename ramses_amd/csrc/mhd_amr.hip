@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64) void mhd_amr_oct_kernel(MhdAmrArgs A) {
     const int nb = t >> 3, ind = t & 7;
     const int s = L.fs[nb];
     if (s <= 0) continue;
-    const int i = 2 * (nb % 3 - 1) + (ind & 1), j = 2 * ((nb / 3) % 3 - 1) + ((ind >> 1) & 1), k = 2 * (nb / 9 - 1) + (ind >> 2);
+    const int i = 1 + 2 * (nb % 3 - 1) + (ind & 1), j = 1 + 2 * ((nb / 3) % 3 - 1) + ((ind >> 1) & 1), k = 1 + 2 * (nb / 9 - 1) + (ind >> 2);   // i3 = 1 + 2 (i1 - 1) + i2
     const long c = A.ncoarse + (long)ind * A.ngridmax + s - 1;
     const int o = sidx(i, j, k);
     for (int v = 0; v < NF; v++) L.U[v][o] = A.uold[(long)v * N + c];
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64) void mhd_amr_oct_kernel(MhdAmrArgs A) {
     }
     mhd_interpol_oct(A, u1, ind1, u2);
     for (int ind = 0; ind < 8; ind++) {
-      const int i = 2 * (nb % 3 - 1) + (ind & 1), j = 2 * ((nb / 3) % 3 - 1) + ((ind >> 1) & 1), k = 2 * (nb / 9 - 1) + (ind >> 2);
+      const int i = 1 + 2 * (nb % 3 - 1) + (ind & 1), j = 1 + 2 * ((nb / 3) % 3 - 1) + ((ind >> 1) & 1), k = 1 + 2 * (nb / 9 - 1) + (ind >> 2);   // i3 = 1 + 2 (i1 - 1) + i2
       const int o = sidx(i, j, k);
       for (int v = 0; v < NF; v++) L.U[v][o] = u2[ind][v];
       if (GRAV) for (int d = 0; d < 3; d++) L.G[d][o] = A.grav[(long)d * N + c0 - 1];

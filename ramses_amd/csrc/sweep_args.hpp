@@ -40,6 +40,7 @@ struct SweepArgs {
   const int *dir = nullptr;
   const int *work = nullptr;          // int4 per workgroup
   int ntx = 0, nty = 0, ntz = 0, nwork = 0;
+  int base_uold = 0;                  // the level has no finer octs: unew == uold on entry (set_unew), the update may start from uold
   long ngd = 0, ncoarse = 0;
   int nx, ny, nz;       // interior cells
   int ng;               // ghost width (0 = periodic wrap in-kernel)

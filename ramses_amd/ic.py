@@ -133,7 +133,7 @@ def _morton_rank(no):
     return np.argsort(np.argsort(key.reshape(-1))).reshape(no, no, no)
 
 
-def uniform_tree(L, slack=7, order="scrambled", refine_box=None, refine_mask=None):
+def uniform_tree(L, slack=7, order="scrambled", refine_box=None, refine_mask=None, refine_mask2=None):
     """RAMSES tree arrays (amr/amr_commons.f90:67-75) of a periodic nx=ny=nz=1 box
     whose levels 1..L are fully refined; octs are numbered level by level in a
     scrambled order (the reference's lists are not lexicographic either).
@@ -148,6 +148,8 @@ def uniform_tree(L, slack=7, order="scrambled", refine_box=None, refine_mask=Non
         nextra = (x1 - x0) * (y1 - y0) * (z1 - z0)
     if refine_mask is not None:
         nextra = int(np.count_nonzero(refine_mask))
+    if refine_mask2 is not None:
+        nextra += int(np.count_nonzero(refine_mask2))
     ngridmax = sum(counts) + nextra + slack
     ncell = ncoarse + 8 * ngridmax
     son = np.zeros(ncell, np.int32)
@@ -227,4 +229,34 @@ def uniform_tree(L, slack=7, order="scrambled", refine_box=None, refine_mask=Non
             nbor[d, idf - 1] = cell_of(L, c[0], c[1], c[2])
         out["igrid_fine"] = idf.copy() if order == "morton" else rng.permutation(idf).astype(np.int32)
         out["fine_cells"] = lambda: np.concatenate([ncoarse + ind * ngridmax + idf for ind in range(8)])
+        if refine_mask2 is not None:
+            # a third level: level L+2 octs in the level-(L+1) cells of refine_mask2[z,y,x] ((2n)^3, cells that exist and whose
+            # 3^3 neighbours exist: the caller keeps the mask inside the refined region)
+            used += cx.size
+            idsf = np.zeros((n, n, n), np.int32)
+            idsf[cz, cy, cx] = idf
+            ez, ey, ex = np.nonzero(refine_mask2)
+
+            def cell_f(fx, fy, fz):
+                g = idsf[(fz >> 1) % n, (fy >> 1) % n, (fx >> 1) % n].astype(np.int64)
+                assert (g > 0).all(), "refine_mask2 reaches outside level L+1"
+                return ncoarse + ((fx & 1) + 2 * (fy & 1) + 4 * (fz & 1)) * ngridmax + g
+            if order == "morton":
+                key = np.zeros(ex.size, dtype=np.int64)
+                for b in range(L + 1):
+                    key |= ((ex >> b) & 1) << (3 * b) | ((ey >> b) & 1) << (3 * b + 1) | ((ez >> b) & 1) << (3 * b + 2)
+                o = np.argsort(key, kind="stable")
+                ez, ey, ex = ez[o], ey[o], ex[o]
+                idg = (used + 1 + np.arange(ex.size)).astype(np.int32)
+            else:
+                idg = free[used:used + ex.size].astype(np.int32)
+            fc2 = cell_f(ex, ey, ez)
+            father[idg - 1] = fc2
+            son[fc2 - 1] = idg
+            for d in range(6):
+                axis, up = d >> 1, d & 1
+                c = [ex.copy(), ey.copy(), ez.copy()]
+                c[axis] = (c[axis] + (1 if up else -1)) % (2 * n)
+                nbor[d, idg - 1] = cell_f(c[0], c[1], c[2])
+            out["igrid_fine2"] = idg.copy() if order == "morton" else rng.permutation(idg).astype(np.int32)
     return out

@@ -145,7 +145,7 @@ subroutine godunov_fine(ilevel)
   ! of such builds stay the reference's routine (said once).
   call ramses_amd_godunov_lowdim(ilevel,p,dx)
   return
-#endif
+#else
 
 #ifndef WITHOUTMPI
   ! MPI, one rank per GPU: the dense sweep on the rank's resident brick (ghost layer kept current
@@ -219,6 +219,7 @@ subroutine godunov_fine(ilevel)
           & int(ngridmax,8),int(ncoarse,8),nx_loc,uold,unew,uold,has_f,dx,dtnew(ilevel))
   end if
   if(rc/=0)call ramses_amd_fatal('godunov_fine')
+#endif
 
 111 format('   Entering godunov_fine (MI355X) for level ',i2)
 
@@ -255,6 +256,9 @@ subroutine ramses_amd_godunov_lowdim(ilevel,p,dx)
      if(.not.said.and.myid==1)write(*,*)'ramses_amd: NDIM<3 build: levels that are not uniform (or runs with gravity, difmag, ', &
           & 'pressure_fix, passive scalars, several ranks) keep the reference godunov_fine'
      said=.true.
+     ! counted per level by the library and printed in its exit line (nothing silent: a run that regrids away from the
+     ! uniform level is a CPU run from then on)
+     rc=ramses_amd_lowdim_note_reference(ilevel)
      call godunov_fine_reference(ilevel)
      return
   end if
@@ -273,6 +277,14 @@ subroutine ramses_amd_godunov_lowdim(ilevel,p,dx)
   rc=ramses_amd_godunov_fine_lowdim_f90(p,ilevel,active(ilevel)%ngrid,ramses_amd_octs(ilevel),nb,blist,xg, &
        & int(ngridmax,8),int(ncoarse,8),skip,nloc,uold,unew,dx,dtnew(ilevel))
   deallocate(blist)
+  if(rc==-2)then
+     ! RAMSES_AMD_EUNSUPPORTED: a limit of the embedded brick (level too large, boundary regions that do not cover the
+     ! ghost cells, a solver the brick sweep does not have): the reference's routine, counted like the cases above
+     if(myid==1)write(*,*)'ramses_amd: NDIM<3 build: level ',ilevel,' is not covered by the device sweep; reference godunov_fine'
+     rc=ramses_amd_lowdim_note_reference(ilevel)
+     call godunov_fine_reference(ilevel)
+     return
+  end if
   if(rc/=0)call ramses_amd_fatal('godunov_fine (NDIM<3)')
 end subroutine ramses_amd_godunov_lowdim
 #endif

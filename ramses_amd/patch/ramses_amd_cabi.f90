@@ -136,6 +136,11 @@ module ramses_amd_cabi
        real(c_double), value :: dx, dt
        integer(c_int) :: rc
      end function ramses_amd_godunov_fine_lowdim_f90
+     function ramses_amd_lowdim_note_reference(ilevel) bind(C, name='ramses_amd_lowdim_note_reference') result(rc)
+       import :: c_int
+       integer(c_int), value :: ilevel
+       integer(c_int) :: rc
+     end function ramses_amd_lowdim_note_reference
      function ramses_amd_multigrid_fine_f90(ilevel, ngrid, igrid, xg, ngridmax, ncoarse, nx_loc, &
           & rho, phi, rho_tot, fourpi, epsilon, safe_mode, iters, err) &
           & bind(C, name='ramses_amd_multigrid_fine_f90') result(rc)

@@ -241,3 +241,85 @@ def test_flagged_cells_come_back_in_host_numbers(gpu_lib, monkeypatch):
         assert np.array_equal(u, v)
     assert len(out["0"]) > 100 and np.array_equal(out["0"], out["1"])
     gpu_lib.ramses_amd_amrres_invalidate()
+
+
+def test_a_regrid_whose_finer_level_outgrows_the_room_the_kept_tiles_left(gpu_lib, oracle, monkeypatch):
+    """ADVICE round 5 (medium): a level in tiles keeps its layout -- free tile slots included -- across a regrid of the finer levels;
+    its fit was checked against the finer levels of THAT moment.  Here level 8 grows sevenfold between two steps: the tree still
+    fits into ngridmax, but not behind the 97 000 free slots of level 7's tiles.  ramses_amd_amrres_tree must not fail: it parks the
+    kept levels' state (which lives on the device only), lays every level out again and puts the state back
+    (ramses_amd_amrres_relayouts counts it); two steps on the device == two steps of the oracle, with level 6 and 7 never re-sent."""
+    import ramses_amd
+    from ramses_amd import ic
+    from ramses_amd._capi import check
+    L = 6
+    nc = 2 ** L
+
+    def shell(n, lo, hi):
+        z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+        r = np.sqrt((x - n / 2 + 0.5) ** 2 + (y - n / 2 + 0.5) ** 2 + (z - n / 2 + 0.5) ** 2)
+        return (r >= lo * n) & (r <= hi * n)
+    m1 = shell(nc, 0.23, 0.36)
+    m2a, m2b = shell(2 * nc, 0.29, 0.30), shell(2 * nc, 0.26, 0.33)
+    base = sum(8 ** (l - 1) for l in range(1, L + 1))
+    ngm = base + int(m1.sum()) + int(m2b.sum()) + 10                    # the second tree fills ngridmax to ten octs
+    T1 = ic.uniform_tree(L, order="morton", refine_mask=m1, refine_mask2=m2a, slack=ngm - base - int(m1.sum()) - int(m2a.sum()))
+    T2 = ic.uniform_tree(L, order="morton", refine_mask=m1, refine_mask2=m2b, slack=10)
+    assert T1["ngridmax"] == T2["ngridmax"] == ngm
+    assert np.array_equal(T1["igrid"], T2["igrid"]) and np.array_equal(T1["igrid_fine"], T2["igrid_fine"])
+    p, po = ramses_amd.make_params(riemann="hllc", slope_type=1), oracle.make_params(riemann="hllc", slope_type=1)
+    for var in ("RAMSES_AMD_DEVICE_ORDER", "RAMSES_AMD_TILES", "RAMSES_AMD_TILE_DENSE", "RAMSES_AMD_COVERED_DENSE", "RAMSES_AMD_DEVICE_OCTS"):
+        monkeypatch.delenv(var, raising=False)
+    levels = (L, L + 1, L + 2)
+
+    def lists(T):
+        return {L: np.ascontiguousarray(np.sort(T["igrid"])), L + 1: np.ascontiguousarray(np.sort(T["igrid_fine"])),
+                L + 2: np.ascontiguousarray(np.sort(T["igrid_fine2"]))}
+
+    def oracle_step(T, uold):
+        unew = uold.copy()
+        for lev in reversed(levels):
+            dx = 1.0 / 2 ** lev
+            oracle.godunov_fine_amr(po, lists(T)[lev], T["son"], T["nbor"], T["father"], T["ngridmax"], T["ncoarse"], uold, unew, dx, 0.02 * dx, 32, 0, 1, f=None)
+        return unew
+
+    def device_step(T, u):
+        ll = lists(T)
+        for lev in levels:
+            check(gpu_lib.ramses_amd_amrres_set_unew(len(ll[lev]), _vp(ll[lev])))
+        for lev in reversed(levels):
+            dx = 1.0 / 2 ** lev
+            check(gpu_lib.ramses_amd_amrres_godunov(C.byref(p), lev, len(ll[lev]), _vp(ll[lev]), dx, 0.02 * dx, 32, 0, 1))
+        for lev in levels:
+            check(gpu_lib.ramses_amd_amrres_set_uold(C.byref(p), len(ll[lev]), _vp(ll[lev])))
+            check(gpu_lib.ramses_amd_amrres_sync_level(len(ll[lev]), _vp(ll[lev]), _vp(u)))
+        return u
+
+    def refill(T, u):
+        v = u.copy()
+        ig = T["igrid_fine2"]
+        for ind in range(8):
+            c = T["ncoarse"] + ind * T["ngridmax"] + ig - 1
+            v[:, c] = u[:, T["father"][ig - 1] - 1] * (1.0 + 0.01 * (ind - 3.5))
+        return v
+    u0 = _random_state(T1, 29)
+    h1 = oracle_step(T1, u0)
+    h2 = oracle_step(T2, refill(T2, h1))
+    u = u0.copy()
+    check(gpu_lib.ramses_amd_amrres_invalidate())
+    check(gpu_lib.ramses_amd_amrres_load(5, T1["ngridmax"], T1["ncoarse"], _vp(u), _vp(T1["son"]), _vp(T1["nbor"]), _vp(T1["father"])))
+    assert gpu_lib.ramses_amd_amrres_tiled_levels() >= 2          # level 6 and the shell of level 7 live in tiles
+    u = device_step(T1, u)
+    u[:] = refill(T2, u)
+    for lev, ig in ((L, T2["igrid"]), (L + 1, T2["igrid_fine"])):
+        c = np.concatenate([T2["ncoarse"] + ind * T2["ngridmax"] + ig - 1 for ind in range(8)])
+        u[:, c] = -7.0                     # if the device read these levels from the host again, the result would show it
+    before = gpu_lib.ramses_amd_amrres_relayouts()
+    check(gpu_lib.ramses_amd_amrres_tree(_vp(T2["son"]), _vp(T2["nbor"]), _vp(T2["father"])))
+    assert gpu_lib.ramses_amd_amrres_relayouts() - before == 1
+    ig8 = lists(T2)[L + 2]
+    check(gpu_lib.ramses_amd_amrres_load_level(len(ig8), _vp(ig8), _vp(u)))
+    got = device_step(T2, u)
+    cells = np.concatenate([T2["ncoarse"] + ind * T2["ngridmax"] + np.concatenate([T2["igrid"], T2["igrid_fine"], T2["igrid_fine2"]]) - 1 for ind in range(8)])
+    assert np.array_equal(got[:, cells], h2[:, cells]), np.abs(got[:, cells] - h2[:, cells]).max()
+    gpu_lib.ramses_amd_amrres_invalidate()

@@ -229,7 +229,7 @@ def test_default_mode_amr_run_live_ab(gpu_lib, monkeypatch, lmin, lmax, nstep):
     lr, xr, pr = _sorted_leaves(ref)
     counts = [int((lr == l).sum()) for l in range(lmin, lmax + 1)]
     assert min(counts) > 500, counts                      # every level is populated
-    assert int(np.ravel(got["info"]["nstep"])[0]) == int(np.ravel(ref["info"]["nstep"])[0]) == nstep
+    assert int(np.ravel(got["info"]["nstep"])[0]) == int(np.ravel(ref["info"]["nstep"])[0]) >= nstep      # (fine steps of the sub-cycling)
     assert np.array_equal(lg, lr) and np.array_equal(xg, xr), "the two runs refined different cells"
     tr = float(np.ravel(ref["info"]["t"])[0])
     assert abs(float(np.ravel(got["info"]["t"])[0]) - tr) <= TOL * tr

@@ -36,6 +36,11 @@ def _ab(nml, ndim, note):
         finally:
             shutil.rmtree(work, ignore_errors=True)
     assert note in out["gpu"][1], out["gpu"][1][-2000:]
+    # nothing silent: the library's exit line counts the sweeps per level, on the device and through the reference's host routine
+    import re
+    m = re.search(r"NDIM<3 godunov_fine: (\d+) sweeps on the device, (\d+) through the reference's host routine", out["gpu"][1])
+    assert m, out["gpu"][1][-2000:]
+    assert int(m.group(1)) > 0 and int(m.group(2)) == 0, m.group(0)
     assert "swept on the device" not in out["ref"][1]
     assert len(out["ref"][0]) == len(out["gpu"][0]) >= 2
     for a, b in zip(out["ref"][0], out["gpu"][0]):

@@ -27,6 +27,9 @@ PATCHED = os.path.join(ROOT, "oracle", "_ref", "ramses3d_patch_mhd_mhd")
 def amr_namelist(lmin, lmax, nstep, riemann, riemann2d, slope_type, interpol_var, interpol_type, poisson=False, nsub="1,2,2,2,2"):
     from mhd_common import mhd_namelist
     nml = mhd_namelist(lmin, nstep, riemann, riemann2d, slope_type)
+    if slope_type == 3:
+        # the reference has no 27-point slope for the face fields ("Unknown slope_mag_type", mhd/umuscl.f90): name one
+        nml = nml.replace("slope_type=3", "slope_type=3\nslope_mag_type=2")
     nml = nml.replace("levelmax=%d" % lmin, "levelmax=%d" % lmax)
     nml = re.sub(r"ngridtot=\d+", "ngridtot=300000", nml)
     nml = nml.replace("nsubcycle=10*1", "nsubcycle=%s" % nsub)
@@ -79,7 +82,8 @@ def test_patched_mhd_program_on_an_amr_tree_equals_the_reference(gpu_lib, monkey
           % (lmin, lmax, riemann, riemann2d, slope_type, ivar, itype, " +gravity" if poisson else "", dev, octs, counts))
     assert min(counts) > 100, counts                      # every level is populated: coarse-fine boundaries on both sides
     assert pr.shape[0] == 11
-    assert int(np.ravel(got["info"]["nstep"])[0]) == int(np.ravel(ref["info"]["nstep"])[0]) == nstep
+    # (info's nstep counts the fine steps of the sub-cycling: nstep coarse steps are at least as many)
+    assert int(np.ravel(got["info"]["nstep"])[0]) == int(np.ravel(ref["info"]["nstep"])[0]) >= nstep
     assert float(np.ravel(got["info"]["t"])[0]) == float(np.ravel(ref["info"]["t"])[0])
     assert np.array_equal(lg, lr) and np.array_equal(xg, xr), "the two runs refined different cells"
     assert np.abs(pr[4:7]).max() > 0.5                    # a magnetised run
