@@ -135,6 +135,51 @@ def cpu_baseline():
         return out
 
 
+def vcycle_cpu_baseline():
+    """The reference's own multigrid beside the V-cycle leg: the unmodified MPI program on config C4's stand-in --
+    hydro + self-gravity of a dense block on a uniform level, 256^3 from 16 cores on (128^3 below) -- and its `poisson` timer row
+    (amr/update_time.f90:59-178: save_phi_old + multigrid_fine + force_fine, maximum over the ranks) against the V-cycles its
+    `==> Level= Step=` lines count (poisson/multigrid_fine_commons.f90:284): DOF/s = N^3 x V-cycles / t(poisson).  A lower bound
+    of the reference's V-cycle rate (the row also holds force_fine and the first guess), which is the direction a baseline may err."""
+    import importlib.util
+    import re
+    import shutil
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    mpi_bin, mpiexec = os.path.join(ref, "ramses3d_mpi"), "/opt/conda/bin/mpiexec"
+    try:
+        from oracle import ramses_snapshot as rs
+        spec = importlib.util.spec_from_file_location("mkb", os.path.join(ROOT, "tests", "golden", "make_golden_baseline.py"))
+        mkb = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mkb)
+        ncores = os.cpu_count() or 1
+        try:
+            import psutil
+            ncores = psutil.cpu_count(logical=False) or ncores
+        except Exception:
+            pass
+        if not (os.path.exists(mpi_bin) and os.path.exists(mpiexec)) or ncores < 2:
+            return {"value": None, "note": "no MPI reference binary on this box"}
+        P = 1
+        while P * 2 <= min(ncores, 64):
+            P *= 2
+        level, nstep = (8 if P >= 16 else 7), 3
+        nml = mkb.c4_namelist(level, nstep).replace("ngridtot=", "ngridtot=%d !" % int(3.0 * sum(8 ** l for l in range(level)) + 1000))
+        t0 = time.perf_counter()
+        work, out = rs.run_reference(nml, nproc=P, binary=mpi_bin, timeout=900)
+        wall = time.perf_counter() - t0
+        shutil.rmtree(work, ignore_errors=True)
+        cycles = [int(m.group(1)) for m in re.finditer(r"==> Level=\s*%d Step=\s*(\d+)" % level, out)]
+        row = [l for l in out.splitlines() if l.strip().endswith("poisson") or " poisson " in l + " "][-1].split()
+        tp = float(row[2])                                   # MPI table: min avg MAX ...
+        n = 2 ** level
+        return {"value": float(n) ** 3 * sum(cycles) / tp, "unit": "DOF/s", "cores": P, "kind": "reference",
+                "sample": "unmodified reference F90 (amdflang -O2, NVECTOR=32, MPICH %d ranks), hydro + self-gravity of a dense block at %d^3 "
+                          "(config C4's stand-in), %d solves with %s V-cycles, 'poisson' timer (multigrid_fine + force_fine + first guess) "
+                          "max over ranks %.2f s (run wall %.1f s)" % (P, n, len(cycles), cycles, tp, wall)}
+    except Exception as exc:      # noqa: BLE001  (a report, never a reason to lose the GPU number)
+        return {"value": None, "error": str(exc)[:300]}
+
+
 def pmc_traffic(n, world, args):
     """HBM bytes per sweep launch from the rocprofv3 PMC passes (FETCH_SIZE with the
     gfx950 calibration + WRITE_SIZE), measured by scripts/profile_gpu.sh on this
@@ -425,6 +470,85 @@ def amr_resident_bench(level=8, steps=5, kind="covered"):
                         "fluxes owed to the coarser level; HIP events around ramses_amd_amrres_godunov",
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "bytes_per_cell": BYTES_PER_CELL_UPDATE_AMR}}
+
+
+def amr_c5_shape_bench(steps=5):
+    """BASELINE config C5 in its REAL shape (sedov3d.nml, levelmin=7, levelmax=10, 8 ranks), one rank's share of one coarse step:
+    the rank's octant of levelmin (32768 of the 262144 octs of level 7: a list that is part of the level, the rest are its
+    neighbours' octs) and three small levels around the blast -- ~1000 octs each at levels 8, 9, 10 -- with the reference's
+    sub-cycling (nsubcycle=2: 1 + 2 + 4 + 8 = 15 godunov_fine calls, each between its set_unew and set_uold, in amr_step's order).
+    The small levels take the tree-walking sweep (below RAMSES_AMD_TILE_MIN_OCTS = 32768 octs a level is a few launches of
+    latency, not of work); reported: ms per coarse step of the hydro calls, and the same with every level forced onto tiles."""
+    import numpy as np
+    import torch
+    import ramses_amd
+    from ramses_amd import ic
+    from ramses_amd._capi import check, lib
+    L, n = 7, 128
+
+    def sph(m, c, r):
+        z, y, x = np.meshgrid(np.arange(m), np.arange(m), np.arange(m), indexing="ij")
+        return ((x - c + 0.5) ** 2 + (y - c + 0.5) ** 2 + (z - c + 0.5) ** 2) < r * r
+    T = ic.uniform_tree(L, order="morton", refine_mask=sph(n, 32, 6.2), refine_mask2=sph(2 * n, 64, 6.2), refine_mask3=sph(4 * n, 128, 6.2), slack=300000)
+    # the rank's share of levelmin: the octs of the octant that holds the blast (level-7 octs sit at level-6 cell positions)
+    ig7 = np.sort(T["igrid"])
+    no = 2 ** (L - 1)
+    # Z-order numbering: the first eighth of the level's octs is the low octant
+    own7 = np.ascontiguousarray(ig7[: len(ig7) // 8])
+    lists = {7: own7, 8: np.ascontiguousarray(np.sort(T["igrid_fine"])), 9: np.ascontiguousarray(np.sort(T["igrid_fine2"])),
+             10: np.ascontiguousarray(np.sort(T["igrid_fine3"]))}
+    alls = dict(lists)
+    alls[7] = np.ascontiguousarray(ig7)
+    u = np.zeros((5, T["ncell"]))
+    u[0] = 1.0
+    u[4] = 1e-5 / 0.4
+    u[4, T["ncoarse"] + int(lists[10][0]) - 1] = (1e-5 + 0.4 * 0.125 / (0.5 / 2 ** 10) ** 3) / 0.4
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)      # noqa: E731
+    Lb = lib()
+    p = ramses_amd.make_params(courant_factor=0.8, fast_math=True)
+    out = {}
+    ncalls = [0]
+
+    def amr_step(lev, dt):
+        check(Lb.ramses_amd_amrres_set_unew(len(alls[lev]), vp(alls[lev])))
+        if lev < 10:
+            amr_step(lev + 1, dt / 2)
+            amr_step(lev + 1, dt / 2)
+        check(Lb.ramses_amd_amrres_godunov(C.byref(p), lev, len(lists[lev]), vp(lists[lev]), 0.5 / 2 ** lev, dt, 32, 0, 1))
+        ncalls[0] += 1
+        check(Lb.ramses_amd_amrres_set_uold(C.byref(p), len(alls[lev]), vp(alls[lev])))
+    for tag, min_octs in (("production", None), ("all_levels_on_tiles", "0")):
+        if min_octs is None:
+            os.environ.pop("RAMSES_AMD_TILE_MIN_OCTS", None)
+        else:
+            os.environ["RAMSES_AMD_TILE_MIN_OCTS"] = min_octs
+        check(Lb.ramses_amd_amrres_invalidate())
+        check(Lb.ramses_amd_amrres_load(5, T["ngridmax"], T["ncoarse"], vp(u), vp(T["son"]), vp(T["nbor"]), vp(T["father"])))
+        t0, d0 = Lb.ramses_amd_amrres_tree_sweeps(), Lb.ramses_amd_amrres_tile_sweeps()
+        amr_step(7, 1e-7)
+        amr_step(7, 1e-7)
+        torch.cuda.synchronize()
+        ncalls[0] = 0
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0 = time.perf_counter()
+        a.record()
+        for _ in range(steps):
+            amr_step(7, 1e-7)
+        b.record()
+        torch.cuda.synchronize()
+        out[tag] = {"ms_per_coarse_step": a.elapsed_time(b) / steps, "host_ms_per_coarse_step": (time.perf_counter() - w0) / steps * 1e3,
+                    "godunov_calls_per_coarse_step": ncalls[0] // steps,
+                    "tree_walking_sweeps": int(Lb.ramses_amd_amrres_tree_sweeps() - t0), "dense_sweeps": int(Lb.ramses_amd_amrres_tile_sweeps() - d0)}
+    os.environ.pop("RAMSES_AMD_TILE_MIN_OCTS", None)
+    check(Lb.ramses_amd_amrres_invalidate())
+    cells = 8 * sum(len(lists[l]) * 2 ** (l - 7) for l in lists)        # cell updates of one coarse step (sub-cycling)
+    ms = out["production"]["ms_per_coarse_step"]
+    return {"metric": "ms per coarse step of one rank's share of BASELINE config C5 (set_unew + godunov_fine + set_uold, levels 7-10, sub-cycled)",
+            "value": ms, "unit": "ms", "octs_per_level": {str(l): int(len(lists[l])) for l in lists}, "cell_updates_per_coarse_step": int(cells),
+            "cell_updates_per_s": cells / (ms * 1e-3), "arithmetic": "fast on tiled levels (the drop-in's default), strict in the tree-walking sweep",
+            "production": out["production"], "all_levels_on_tiles": out["all_levels_on_tiles"],
+            "note": "levels 8-10 hold ~1000 octs each: their 14 sweeps per coarse step are launch latency, not work; levelmin's octant (32768 octs) "
+                    "takes the dense sweep on tiles"}
 
 
 BYTES_PER_CELL_UPDATE_MHD = 176   # 11 fields (5 Euler + 3 left-face + 3 right-face fields) read and written, FP64
@@ -832,6 +956,10 @@ def main():
                 out["amr_sweep"] = amr_resident_bench(args.amr_level, kind="full")
                 out["amr_sweep_partial"] = amr_resident_bench(args.amr_level + 1, kind="partial")
                 out["amr_sweep_covered"] = amr_resident_bench(args.amr_level, kind="covered")
+                try:
+                    out["amr_c5_shape"] = amr_c5_shape_bench()
+                except Exception as exc:     # noqa: BLE001
+                    out["amr_c5_shape"] = {"value": None, "error": str(exc)[:300]}
                 torch.cuda.empty_cache()
                 out["amr_sweep_tree_walking"] = amr_sweep_bench(args.amr_level)
                 out["amr_sweep_partial_tree_walking"] = amr_sweep_bench(args.amr_level + 1, partial=True)
@@ -845,6 +973,8 @@ def main():
                 out["mhd_sweep"] = {"value": None, "error": str(exc)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()     # rank 0 at N=1 only
+            if isinstance(out.get("vcycle"), dict) and out["vcycle"].get("value"):
+                out["vcycle"]["cpu_baseline"] = vcycle_cpu_baseline()
     else:
         out = None
 

@@ -16,7 +16,11 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libramses_amd.so")
 ARCH = "gfx950"
 
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
+# --offload-compress: the device code objects of the fat binary are stored compressed (the HIP runtime inflates a translation
+# unit's code when its first kernel is launched): libramses_amd.so is 17 MB instead of 110 MB -- the template matrix of the
+# option space (amr_sweep: 1080 kernels) compresses tenfold -- and loads and passes the GPU suite the same
+# (profiles/r06_compressed_library.txt)
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "--offload-compress",
           "-I", os.path.join(HERE, "..", "include")]
 
 # (object name, source, extra flags)
@@ -28,6 +32,12 @@ UNITS = [
     ("octree_pack.o", "octree_pack.hip", ["-ffp-contract=off"]),
     ("amr_ops.o", "amr_ops.hip", ["-ffp-contract=off"]),
     ("amr_sweep.o", "amr_sweep.hip", ["-ffp-contract=off"]),
+    ("amr_sweep_st0.o", "amr_sweep.hip", ["-ffp-contract=off", "-DAMR_SWEEP_ST=0"]),
+    ("amr_sweep_st1.o", "amr_sweep.hip", ["-ffp-contract=off", "-DAMR_SWEEP_ST=1"]),
+    ("amr_sweep_st2.o", "amr_sweep.hip", ["-ffp-contract=off", "-DAMR_SWEEP_ST=2"]),
+    ("amr_sweep_st3.o", "amr_sweep.hip", ["-ffp-contract=off", "-DAMR_SWEEP_ST=3"]),
+    ("amr_sweep_st7.o", "amr_sweep.hip", ["-ffp-contract=off", "-DAMR_SWEEP_ST=7"]),
+    ("amr_sweep_st8.o", "amr_sweep.hip", ["-ffp-contract=off", "-DAMR_SWEEP_ST=8"]),
     ("mg_amr.o", "mg_amr.hip", ["-ffp-contract=off"]),
     ("cg_amr.o", "cg_amr.hip", ["-ffp-contract=off"]),
     ("rho_fine.o", "rho_fine.hip", ["-ffp-contract=off"]),
@@ -89,9 +99,18 @@ def _stale(target, sources):
 
 
 def build(force=False, verbose=False):
+    global BUILD, LIB
+    if os.environ.get("RAMSES_AMD_BUILD_VARIANT"):
+        # an A/B build of the whole library with extra compiler flags (RAMSES_AMD_BUILD_FLAGS), objects and library kept apart:
+        # ramses_amd/lib/ab/libramses_amd_<variant>.so (load with RAMSES_AMD_LIB=...)
+        tag = os.environ["RAMSES_AMD_BUILD_VARIANT"]
+        BUILD = os.path.join(HERE, "build", "variant_" + tag)
+        os.makedirs(os.path.join(LIBDIR, "ab"), exist_ok=True)
+        LIB = os.path.join(LIBDIR, "ab", "libramses_amd_%s.so" % tag)
     os.makedirs(BUILD, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
+    extra = os.environ.get("RAMSES_AMD_BUILD_FLAGS", "").split()
     jobs = []
     objs = []
     for obj, src, flags in UNITS:
@@ -101,7 +120,7 @@ def build(force=False, verbose=False):
         objp = os.path.join(BUILD, obj)
         objs.append(objp)
         if force or _stale(objp, [srcp] + _deps(srcp)):
-            jobs.append([hipcc] + COMMON + flags + ["-c", srcp, "-o", objp])
+            jobs.append([hipcc] + COMMON + flags + extra + ["-c", srcp, "-o", objp])
 
     def run(cmd):
         if verbose:

@@ -35,6 +35,7 @@ namespace ramses_amd {
 namespace amrsweep {
 
 constexpr int OCTS_PER_BLOCK = 4;
+constexpr int AMR_SMALL_LEVEL_OCTS = 4096;     // below: the single-oct kernel straight away (launch_amr_godunov)
 
 template <int NV>
 struct OctFaces {
@@ -488,10 +489,12 @@ __device__ __forceinline__ void group_walk_block(const AmrSweepArgs &A, int bloc
   w[64 + t] = og;
   w[128 + t] = og > 0 ? posof[og - 1] : -1;
 }
+#ifndef AMR_SWEEP_ST
 __global__ __launch_bounds__(256) void amr_group_walk_kernel(AmrSweepArgs A, const int *__restrict__ groups, int ngroups,
                                                              const int *__restrict__ posof, int *__restrict__ walk) {
   group_walk_block(A, blockIdx.x, groups, ngroups, posof, walk);
 }
+#endif
 
 template <int ST, int RS, bool GRAV, int NV, int SCHEME, bool PFIX, bool DIFMAG>
 __global__ __launch_bounds__(GRP_THREADS, GRP_MINWAVES) void amr_group_kernel(AmrSweepArgs A, const int *__restrict__ groups,
@@ -861,6 +864,7 @@ __global__ __launch_bounds__(256) void amr_prep_kernel(AmrSweepArgs A, double *_
 
 // groups[] = the father octs that have at least one son in the call's list, each once: the son at the lowest
 // octant position enters it
+#ifndef AMR_SWEEP_ST
 __global__ __launch_bounds__(1024) void amr_group_build_kernel(AmrSweepArgs A, const int *posof, int *groups, int *count) {
   const int io = blockIdx.x * blockDim.x + threadIdx.x;
   bool lead = false;
@@ -893,18 +897,22 @@ __global__ __launch_bounds__(1024) void amr_group_build_kernel(AmrSweepArgs A, c
   __syncthreads();
   if (lead) groups[wbase[wave] + __popcll(m & ((1ull << lane) - 1ull))] = gF;
 }
+#endif
 
 // posof[oct-1] = position (0-based) of the oct in the active list
+#ifndef AMR_SWEEP_ST
 __global__ void amr_posof_kernel(const int *igrid, int ngrid, int *posof) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < ngrid) posof[igrid[i] - 1] = i;
 }
+#endif
 
 // Conservative update at level ilevel-1 (hydro/godunov_fine.f90:798-908): every
 // (oct, face) whose neighbouring father cell is a leaf owes it 4 fluxes.  A coarse
 // cell has at most 6 such creditors; the thread of the creditor that comes first in
 // the reference's loop order (batch of nvector octs, idim, left before right)
 // replays all of them sequentially.
+#ifndef AMR_SWEEP_ST
 __global__ __launch_bounds__(256) void amr_coarse_update_kernel(AmrSweepArgs A, const int *posof, int nvector) {
   const int NV = A.nvar;
   const long ev = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -963,6 +971,7 @@ __global__ __launch_bounds__(256) void amr_coarse_update_kernel(AmrSweepArgs A, 
     tgt[C - 1] = val;
   }
 }
+#endif
 
 template <int ST, int RS, int NV>
 static hipError_t launch3(const AmrSweepArgs &A, const int *groups, int ngroups, const int *posof, const int *walk, hipStream_t s) {
@@ -1020,8 +1029,11 @@ static hipError_t launch2(const AmrSweepArgs &A, const int *groups, int ngroups,
   return hipErrorInvalidValue;
 }
 
+// One translation unit per slope type (ramses_amd/build.py compiles this file once without AMR_SWEEP_ST -- the shared kernels and
+// the dispatcher -- and once per slope type with -DAMR_SWEEP_ST=<type>: the 1080 instantiations of the option matrix build side
+// by side instead of in one 14-minute compile)
 template <int ST>
-static hipError_t launch1(const AmrSweepArgs &A, int rs, const int *groups, int ngroups, const int *posof, const int *walk, hipStream_t s) {
+hipError_t launch1(const AmrSweepArgs &A, int rs, const int *groups, int ngroups, const int *posof, const int *walk, hipStream_t s) {
   switch (rs) {
     case RIEMANN_LLF: return launch2<ST, RIEMANN_LLF>(A, groups, ngroups, posof, walk, s);
 #ifndef RAMSES_AMD_AMR_DEV     // development build (kernel tuning with scripts/amr_probe.py): minmod + LLF + NVAR=5 only
@@ -1034,8 +1046,20 @@ static hipError_t launch1(const AmrSweepArgs &A, int rs, const int *groups, int 
   }
 }
 
+#ifdef AMR_SWEEP_ST
+template hipError_t launch1<AMR_SWEEP_ST>(const AmrSweepArgs &, int, const int *, int, const int *, const int *, hipStream_t);
+#else
+#define RAMSES_AMD_EXTERN_ST(K) extern template hipError_t launch1<K>(const AmrSweepArgs &, int, const int *, int, const int *, const int *, hipStream_t);
+RAMSES_AMD_EXTERN_ST(1)
+#ifndef RAMSES_AMD_AMR_DEV
+RAMSES_AMD_EXTERN_ST(0) RAMSES_AMD_EXTERN_ST(2) RAMSES_AMD_EXTERN_ST(3) RAMSES_AMD_EXTERN_ST(7) RAMSES_AMD_EXTERN_ST(8)
+#endif
+#undef RAMSES_AMD_EXTERN_ST
+#endif
+
 }  // namespace amrsweep
 
+#ifndef AMR_SWEEP_ST
 hipError_t launch_amr_godunov(const AmrSweepArgs &A_in, int slope_type, int riemann, int *posof, int nvector,
                               hipStream_t s, double *pack_area, int *walk_area) {
   using namespace amrsweep;
@@ -1051,7 +1075,11 @@ hipError_t launch_amr_godunov(const AmrSweepArgs &A_in, int slope_type, int riem
   int *groups = posof + A.ngridmax, *count = groups + A.ngrid;     // workspace tail (ramses_amd_godunov_fine_amr_workspace)
   int ngroups = 0;
   const int *walk = nullptr;
-  if (!(A.divu != nullptr && A.scheme == 1)) {
+  // A level of a few thousand octs is launch latency, not work: the one-oct-per-wavefront kernel needs no groups, no father-cell
+  // pre-pass and -- what counts -- no answer from the device before it can be launched (the group count is a blocking copy).
+  // (It carries neither the artificial diffusion nor, outside plmde, pressure_fix: those keep the grouped kernel.)
+  const bool small_level = A.ngrid <= AMR_SMALL_LEVEL_OCTS && A.difmag <= 0.0 && A.divu == nullptr;
+  if (!(A.divu != nullptr && A.scheme == 1) && !small_level) {
     e = hipMemsetAsync(count, 0, sizeof(int), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(amr_group_build_kernel, dim3((A.ngrid + 1023) / 1024), dim3(1024), 0, s, A, posof, groups, count);
@@ -1115,7 +1143,15 @@ hipError_t launch_amr_coarse_update(const AmrSweepArgs &A, const int *posof, int
   return hipGetLastError();
 }
 
+#endif   // AMR_SWEEP_ST
+
 }  // namespace ramses_amd
 
 #include "warm.hpp"
+#ifndef AMR_SWEEP_ST
 RAMSES_AMD_TU_WARM(amr_sweep)
+#else
+#define RAMSES_AMD_WARM_CAT2(a, b) RAMSES_AMD_TU_WARM(a##b)
+#define RAMSES_AMD_WARM_CAT(a, b) RAMSES_AMD_WARM_CAT2(a, b)
+RAMSES_AMD_WARM_CAT(amr_sweep_st, AMR_SWEEP_ST)
+#endif

@@ -735,6 +735,12 @@ extern "C" int ramses_amd_warm_capi_tree_poisson(void);
 extern "C" int ramses_amd_warm_hydro_sweep_fast(void);
 extern "C" int ramses_amd_warm_hydro_sweep_strict(void);
 extern "C" int ramses_amd_warm_mhd_sweep(void);
+extern "C" int ramses_amd_warm_amr_sweep_st0(void);
+extern "C" int ramses_amd_warm_amr_sweep_st1(void);
+extern "C" int ramses_amd_warm_amr_sweep_st2(void);
+extern "C" int ramses_amd_warm_amr_sweep_st3(void);
+extern "C" int ramses_amd_warm_amr_sweep_st7(void);
+extern "C" int ramses_amd_warm_amr_sweep_st8(void);
 
 extern "C" int ramses_amd_warmup(void) {
   static bool done = false;
@@ -747,6 +753,8 @@ extern "C" int ramses_amd_warmup(void) {
   bad += ramses_amd_warm_octree_pack();
   bad += ramses_amd_warm_amr_ops();
   bad += ramses_amd_warm_amr_sweep();
+  bad += ramses_amd_warm_amr_sweep_st0(); bad += ramses_amd_warm_amr_sweep_st1(); bad += ramses_amd_warm_amr_sweep_st2();
+  bad += ramses_amd_warm_amr_sweep_st3(); bad += ramses_amd_warm_amr_sweep_st7(); bad += ramses_amd_warm_amr_sweep_st8();
   bad += ramses_amd_warm_mg_amr();
   bad += ramses_amd_warm_cg_amr();
   bad += ramses_amd_warm_rho_fine();

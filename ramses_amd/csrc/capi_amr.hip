@@ -530,12 +530,22 @@ __global__ __launch_bounds__(256) void plan_events_kernel(PlanArgs A, const int 
     int b = 0;
     if (lane == 0) b = atomicAdd(count, __popcll(m));
     b = __shfl(b, 0, 64);
-    if (have) {
-      const int e = b + __popcll(m & ((1ull << lane) - 1ull));
-      events[e] = (int)t;
-      evt_of[sf] = e;              // where the surface pass files this (oct, face)'s four fluxes
-    }
+    if (have) events[b + __popcll(m & ((1ull << lane) - 1ull))] = (int)t;      // (sorted and indexed by the caller: evt_of)
   }
+}
+// the events by (face, device oct): neighbouring threads of the surface pass then read neighbouring octs of a tile row -- its
+// gathers are isolated 8-byte words otherwise, a cache line each (profiles/r06_tile_sweep_pmc.txt: 3 GB fetched for 35 MB of records)
+__global__ __launch_bounds__(256) void plan_event_keys_kernel(PlanArgs A, const int *__restrict__ events, int nevent, unsigned long long *__restrict__ keys) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nevent) return;
+  const int ev = events[e];
+  keys[e] = ((unsigned long long)(ev % 6) << 32) | (unsigned)A.ig[ev / 6];
+}
+__global__ __launch_bounds__(256) void plan_event_index_kernel(PlanArgs A, const int *__restrict__ events, int nevent, int *__restrict__ evt_of) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nevent) return;
+  const int ev = events[e];
+  evt_of[((long)A.ig[ev / 6] - A.base) * 6 + ev % 6] = e;              // where the surface pass files this (oct, face)'s four fluxes
 }
 __global__ __launch_bounds__(256) void tile_coarse_update_kernel(PlanArgs A, double *__restrict__ unew, const double *__restrict__ corr,
                                                                  const int *__restrict__ corr_tgt, const int *__restrict__ evt_of,
@@ -784,6 +794,7 @@ struct AmrRes {
   std::vector<LevelPlan> plan;
   long tile_sweeps = 0, tree_sweeps = 0;
   long relayouts = 0;                          // regrids that had to lay the kept levels out again (tiles in the way of the finer levels)
+  int err_pending = 0;                         // a tree-walking sweep has run since R.err was last read (the finest level it swept)
   bool announced = false;
   const double *h_uold = nullptr;
   Buf uold, unew, son, nbor, father, work, err, red, okbuf, pack;
@@ -827,6 +838,19 @@ int upload_list(AmrRes &R, Buf &dst, const int *h, int n) {
   return 0;
 }
 int check_lists(AmrRes &R, const char *where) {
+  // (the tree-walking sweeps count the father cells they did not find into R.err and do not wait for the answer: a sweep of a
+  //  1000-oct level is a handful of launches, a blocking copy per call would double it.  Whoever reads something back anyway --
+  //  courant_fine, hydro_flag, a level going home -- asks for both counters.)
+  if (R.err_pending) {
+    int miss = 0;
+    HCHK(hipMemcpy(&miss, R.err.p, sizeof(int), hipMemcpyDeviceToHost), "D2H");
+    const int lev = R.err_pending;
+    R.err_pending = 0;
+    if (miss) {
+      HCHK(hipMemset(R.err.p, 0, sizeof(int)), "memset");
+      return failf(RAMSES_AMD_EINVAL, "%s: %d father cells needed by an oct do not exist (tree inconsistent; godunov_fine up to level %d since the last check)", where, miss, lev);
+    }
+  }
   if (!R.map.on) return 0;
   int bad = 0;
   HCHK(hipMemcpy(&bad, R.bad.p, sizeof(int), hipMemcpyDeviceToHost), "D2H");
@@ -1249,6 +1273,24 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   HCHK(hipMemcpyAsync(flag.data(), P.flag.p, nflag, hipMemcpyDeviceToHost, s), "D2H");
   HCHK(hipStreamSynchronize(s), "sync");
   HCHK(P.corr.ensure(sizeof(double) * 4 * (size_t)(R.nvar + 2) * (size_t)(P.nevent > 0 ? P.nevent : 1)), "hipMalloc flux records");
+  if (P.nevent > 1) {
+    // (once per plan) the events sorted by face and device oct, their index table after the sort
+    amrlayout::Buf &k1 = P.corr, &k2 = P.gfather, &v2 = P.flag;        // (free here: the records are written by the first sweep, the ghost table and the flags have done their job)
+    HCHK(k1.ensure(sizeof(unsigned long long) * (size_t)P.nevent), "hipMalloc"); HCHK(k2.ensure(sizeof(unsigned long long) * (size_t)P.nevent), "hipMalloc");
+    HCHK(v2.ensure(sizeof(int) * (size_t)P.nevent), "hipMalloc");
+    hipLaunchKernelGGL(plan_event_keys_kernel, dim3((P.nevent + 255) / 256), dim3(256), 0, s, A, P.events.as<int>() + 1, P.nevent, k1.as<unsigned long long>());
+    size_t bytes = 0;
+    HCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k1.as<unsigned long long>(), k2.as<unsigned long long>(), P.events.as<int>() + 1, v2.as<int>(), P.nevent, 0, 35, s), "sort");
+    HCHK(R.work.ensure(bytes), "hipMalloc");
+    HCHK(hipcub::DeviceRadixSort::SortPairs(R.work.p, bytes, k1.as<unsigned long long>(), k2.as<unsigned long long>(), P.events.as<int>() + 1, v2.as<int>(), P.nevent, 0, 35, s), "sort");
+    HCHK(hipMemcpyAsync(P.events.as<int>() + 1, v2.p, sizeof(int) * (size_t)P.nevent, hipMemcpyDeviceToDevice, s), "copy");
+    HCHK(hipStreamSynchronize(s), "sync");
+    HCHK(P.corr.ensure(sizeof(double) * 4 * (size_t)(R.nvar + 2) * (size_t)P.nevent), "hipMalloc flux records");
+  }
+  if (P.nevent > 0) {
+    hipLaunchKernelGGL(plan_event_index_kernel, dim3((P.nevent + 255) / 256), dim3(256), 0, s, A, P.events.as<int>() + 1, P.nevent, P.evt_of.as<int>());
+    HCHK(hipGetLastError(), "event index");
+  }
   if (hc[1]) return failf(RAMSES_AMD_EINVAL, "level %d: %d neighbour positions of an oct have no father cell or no tile (tree inconsistent)", ilevel, hc[1]);
   if (hc[0] > gcap) return failf(RAMSES_AMD_EINVAL, "level %d: more ghost octs (%d) than free slots in the level's tiles (%d)", ilevel, hc[0], gcap);
   P.nghost = hc[0];
@@ -1379,7 +1421,7 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
   A.ntx = L.ntx; A.nty = L.nty; A.ntz = L.ntz; A.ngd = R.ngridmax; A.ncoarse = R.ncoarse;
   // (the finest level of the tree: nothing has touched unew since set_unew copied uold into it -- the contract of this routine,
   //  hydro/godunov_fine.f90:5-35 after amr_step's set_unew -- so the kernel re-reads uold from L2 instead of streaming unew)
-  A.base_uold = (ilevel >= R.map.nlev || R.map.lev[ilevel + 1].n == 0) && env_on("RAMSES_AMD_TILE_BASE_UOLD") ? 1 : 0;
+  A.base_uold = (ilevel >= R.map.nlev || R.map.lev[ilevel + 1].n == 0) ? 1 : 0;
   const int n = 2 * L.no;
   A.nx = A.ny = A.nz = n; A.ng = 0;
   A.pitch_y = n; A.pitch_z = (long)n * n; A.pitch_var = R.ncell;
@@ -1456,14 +1498,14 @@ int ramses_amd_amrres_godunov(const ramses_amd_hydro_params *p, int ilevel, int 
   const int64_t nw = ramses_amd_godunov_fine_amr_workspace(ngrid, R.ngridmax);
   if (nw < 0) return (int)nw;
   HCHK(R.work.ensure((size_t)nw), "hipMalloc work");
-  HCHK(hipMemsetAsync(R.err.p, 0, sizeof(int), nullptr), "memset");
+  if (!R.err_pending) HCHK(hipMemsetAsync(R.err.p, 0, sizeof(int), nullptr), "memset");
   if (int rc = ramses_amd_godunov_fine_amr_device(p, ilevel, ngrid, R.cur_ig, R.son.as<int>(), R.nbor.as<int>(), R.father.as<int>(),
                                                   R.ngridmax, R.ncoarse, R.uold.as<double>(), R.unew.as<double>(), R.grav ? R.f.as<double>() : nullptr, R.pfix ? R.divu.as<double>() : nullptr, R.pfix ? R.enew.as<double>() : nullptr,
                                                   dx, dt, nvector, interpol_var, interpol_type, R.work.p, R.err.as<int>(), nullptr)) return rc;
-  int bad = 0;
-  HCHK(hipMemcpy(&bad, R.err.p, sizeof(int), hipMemcpyDeviceToHost), "D2H flag");
-  if (bad) return failf(RAMSES_AMD_EINVAL, "level %d: %d father cells needed by an oct do not exist (tree inconsistent)", ilevel, bad);
-  return check_lists(R, "godunov_fine");
+  // (asynchronous, like the sweep of a level in tiles: the counter of missing father cells is read by the next routine that
+  //  synchronises anyway -- check_lists)
+  R.err_pending = std::max(R.err_pending, ilevel);
+  return 0;
 }
 
 

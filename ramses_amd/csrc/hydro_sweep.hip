@@ -57,7 +57,14 @@ struct Plane {
 template <int ST, int BY, int NV, bool MASK, bool GRAV>
 struct Lds {
   static constexpr int RING = (ST == 3) ? 3 : 2;
-  static constexpr bool PARK = MASK || (GRAV && BY == 12);
+#ifndef SWEEP_PARK_PLAIN
+#ifdef RAMSES_AMD_FAST
+#define SWEEP_PARK_PLAIN 1     // the fast 12-row kernels park too: with the plane held in registers (KEEP) 3.23 -> 3.08 ms at 512^3
+#else
+#define SWEEP_PARK_PLAIN 0     // (the strict ones do not: 5.40 -> 5.50 ms; profiles/r06_ab_sweep.txt)
+#endif
+#endif
+  static constexpr bool PARK = MASK || ((GRAV || SWEEP_PARK_PLAIN) && BY == 12);
   static constexpr int MR = PARK ? BY - 2 : BY;          // rows of a y slot plane
   static constexpr int M0 = PARK ? 1 : 0;                // first row that owns a slot
   static constexpr size_t q_off = 0;
@@ -231,6 +238,18 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #define SWEEP_LATE_BASE 0      // (measured on MI355X, round 6: 512^3 fast 3.237 -> 3.272 ms, the tiled 256^3 level unchanged: the wait at the x flux is not what costs)
 #endif
   constexpr bool LATE = SWEEP_LATE_BASE && NV == 5;   // (the passive-scalar fix of NV > 5 wants the old state in phase A)
+  // KEEP (the fast build of the sweep of a level in tiles: the instantiations with ten registers to spare): the
+  // conservative state of plane c+1 is held from its arrival to the x flux of the NEXT iteration, where the update of that plane
+  // starts from it -- on a level that starts from uold (base_uold) the re-read of the plane disappears: 5 of the 11 loads a full
+  // lane issues per plane.  That kernel is bound by L2 misses, not by instruction issue (profiles/r06_tile_sweep_pmc.txt).
+#ifndef SWEEP_KEEP_PLAIN
+#define SWEEP_KEEP_PLAIN 1     // the plain fast 12-row kernel holds the plane too instead of re-reading it from L2 (profiles/r06_ab_sweep.txt)
+#endif
+#ifdef RAMSES_AMD_FAST
+  constexpr bool KEEP = (MASK || (SWEEP_KEEP_PLAIN && BY == 12)) && NV == 5 && !LATE;
+#else
+  constexpr bool KEEP = false;
+#endif
   constexpr bool r_trace = ROLE == ROLE_LOW || ROLE == ROLE_HIGH || ROLE == ROLE_FULL;
   constexpr bool r_fxz = ROLE == ROLE_FULL;
   const bool r_upd = r_fxz && (tx >= 2) && (tx <= BX - 3) && (xu < A.nx) && (yu < A.ny);
@@ -306,6 +325,9 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
   double fzlo[NV];                // z flux through the -z face of plane c-1
   double upre[NV], gpre[3];       // prefetch: plane c+1 on entry of iteration c
   double rold = 0.0, sold[NV > 5 ? NV - 5 : 1];   // uold density / scalars of plane c-1 (NV>5 only)
+  double ukeep[NV];               // KEEP: the conservative state of plane c
+#pragma unroll
+  for (int n = 0; n < NV; n++) ukeep[n] = 0.0;
 
   // ring slots of planes c-1, c, c+1
   int sa = 0, sb = 1, sc = 2;
@@ -326,6 +348,10 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #pragma unroll
     for (int n = 0; n < NV; n++) qring[sa].v[n][ty][tx] = q[n];
     load_u(z0 - 1, u); load_g(z0 - 1, g);
+    if (KEEP) {
+#pragma unroll
+      for (int n = 0; n < NV; n++) ukeep[n] = u[n];
+    }
     ctoprim_cell<NV, GRAV>(u, g, dtxhalf, P, q);
 #pragma unroll
     for (int n = 0; n < NV; n++) qring[sb].v[n][ty][tx] = q[n];
@@ -380,7 +406,17 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
       for (int n = 0; n < NV; n++) qring[RING == 3 ? sc : sa].v[n][ty][tx] = qc[n];
     }
     double ucur[NV];
-    if (r_fxz && !LATE) { if (MASK) load_base(c, ucur); else load_u(c, ucur); }
+    if (r_fxz && !LATE) {
+      if (KEEP && (!MASK || A.base_uold)) {
+#pragma unroll
+        for (int n = 0; n < NV; n++) ucur[n] = ukeep[n];          // plane c, held since it arrived
+      } else if (MASK) load_base(c, ucur);
+      else load_u(c, ucur);
+    }
+    if (KEEP && r_fxz) {
+#pragma unroll
+      for (int n = 0; n < NV; n++) ukeep[n] = upre[n];            // plane c+1, for the next iteration
+    }
     int okc = 0, ok_ym = 0;
     if (MASK && r_trace) {
       okc = spre;                  // loaded one plane ahead: nothing at the top of an iteration waits for memory
@@ -651,7 +687,9 @@ template <int ST, int RS, int NV, bool GRAV>
 __global__ __launch_bounds__(128) void surface_flux_kernel(SurfArgs A) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)A.nevent * 4) return;
-  const int e = (int)(t >> 2), q = (int)(t & 3);
+  // (events arrive sorted by face and device oct, a wave takes 64 consecutive ones of one fine face q: its gathers run along
+  //  the rows of a tile instead of touching a cache line per lane)
+  const int e = (int)(t % A.nevent), q = (int)(t / A.nevent);
   const int ev = A.events[e];
   const int io = ev / 6, f = ev % 6;
   const int dirn = f >> 1, side = f & 1;

@@ -86,6 +86,38 @@ struct DevAcc {
 #define MHD_IJK(A)                                                                \
   const int i = (int)(c_ % (A).nx), j = (int)((c_ / (A).nx) % (A).ny), k = (int)(c_ / ((long)(A).nx * (A).ny))
 
+// The stencil kernels (trace, flux, emf, update) read their neighbours in y and z from rows and planes that other workgroups
+// touch: what decides their HBM traffic is whether those lines are still in the L2 of the XCD that asks again.  Workgroup b runs
+// on XCD b mod 8, so XCD x is given ONE slab of planes (nz / 8 of them), and inside its slab the cells are visited x first, then
+// MHD_YS rows of y, then z, then the next strip of rows: the plane below a cell was visited nx * MHD_YS cells ago (1.5 MB of
+// predicted states at 256^3) instead of a whole plane ago (25 MB against 4 MB of L2).  One cell per thread; the launch covers
+// 8 x (workgroups of the largest slab).
+constexpr int MHD_YS = 16;
+struct CellMap {
+  int nx, ny, nz, zs;            // zs: planes per XCD slab
+  __host__ __device__ long slab_cells(int x) const { const int z0 = x * zs, z1 = z0 + zs < nz ? z0 + zs : nz; return z1 > z0 ? (long)nx * ny * (z1 - z0) : 0; }
+};
+__device__ __forceinline__ bool mhd_cell_of(const CellMap &M, int tpb, int &i, int &j, int &k, long &c) {
+  const int xcd = blockIdx.x & 7;
+  const long p = (long)(blockIdx.x >> 3) * tpb + threadIdx.x;
+  const int z0 = xcd * M.zs, nzs = (z0 + M.zs < M.nz ? z0 + M.zs : M.nz) - z0;
+  if (nzs <= 0 || p >= (long)M.nx * M.ny * nzs) return false;
+  const long strip = (long)M.nx * MHD_YS * nzs;
+  const int ys = (int)(p / strip);
+  const long q = p - (long)ys * strip;
+  const int sy = M.ny - ys * MHD_YS < MHD_YS ? M.ny - ys * MHD_YS : MHD_YS;
+  i = (int)(q % M.nx);
+  j = ys * MHD_YS + (int)((q / M.nx) % sy);
+  k = z0 + (int)(q / ((long)M.nx * sy));
+  c = i + (long)M.nx * (j + (long)M.ny * k);
+  return true;
+}
+#define MHD_CELL_REMAP(A, TPB)                                           \
+  const CellMap cm_{(A).nx, (A).ny, (A).nz, ((A).nz + 7) / 8};           \
+  int i, j, k;                                                           \
+  long c_;                                                               \
+  if (mhd_cell_of(cm_, TPB, i, j, k, c_))
+
 __global__ __launch_bounds__(256) void mhd_prim_kernel(MhdArgs A) {
   const Grid g{A.nx, A.ny, A.nz};
   int bad = 0;
@@ -134,8 +166,7 @@ template <bool S3>
 __global__ __launch_bounds__(128) void mhd_trace_kernel(MhdArgs A) {
   DevAcc a{{A.nx, A.ny, A.nz}, A.q, A.uold + 5 * A.ncell, A.E, A.ncell};
   const double dtdx = A.dt / A.dx;
-  MHD_CELL_LOOP(A) {
-    MHD_IJK(A);
+  MHD_CELL_REMAP(A, 128) {
     TraceIn I;
     trace_inputs<S3>(a, i, j, k, A.P, I);
     TracePred T;
@@ -160,8 +191,7 @@ __device__ __forceinline__ void mhd_face_flux(const MhdArgs &A, const Grid &g, i
 template <int RS>
 __global__ __launch_bounds__(128) void mhd_flux_kernel(MhdArgs A) {
   const Grid g{A.nx, A.ny, A.nz};
-  MHD_CELL_LOOP(A) {
-    MHD_IJK(A);
+  MHD_CELL_REMAP(A, 128) {
     mhd_face_flux<0, RS>(A, g, i, j, k, c_);
     mhd_face_flux<1, RS>(A, g, i, j, k, c_);
     mhd_face_flux<2, RS>(A, g, i, j, k, c_);
@@ -191,8 +221,7 @@ __device__ __forceinline__ void mhd_edge_emf(const MhdArgs &A, const Grid &g, in
 template <int R2>
 __global__ __launch_bounds__(128) void mhd_emf_kernel(MhdArgs A) {
   const Grid g{A.nx, A.ny, A.nz};
-  MHD_CELL_LOOP(A) {
-    MHD_IJK(A);
+  MHD_CELL_REMAP(A, 128) {
     mhd_edge_emf<0, R2>(A, g, i, j, k, c_);
     mhd_edge_emf<1, R2>(A, g, i, j, k, c_);
     mhd_edge_emf<2, R2>(A, g, i, j, k, c_);
@@ -203,8 +232,7 @@ __global__ __launch_bounds__(128) void mhd_emf_kernel(MhdArgs A) {
 __global__ __launch_bounds__(256) void mhd_update_kernel(MhdArgs A) {
   const Grid g{A.nx, A.ny, A.nz};
   const long N = A.ncell;
-  MHD_CELL_LOOP(A) {
-    MHD_IJK(A);
+  MHD_CELL_REMAP(A, 256) {
     const long cx = g.at(i + 1, j, k), cy = g.at(i, j + 1, k), cz = g.at(i, j, k + 1);
     // Euler system: ((u + (Fx- - Fx+)) + (Fy- - Fy+)) + (Fz- - Fz+)
 #pragma unroll
@@ -358,17 +386,21 @@ int ramses_amd_mhd_godunov_brick(const ramses_amd_mhd_params *p, int nx, int ny,
   HCHK(hipMemsetAsync(A.bad, 0, sizeof(int), s), "memset");
   hipLaunchKernelGGL(mhd_prim_kernel, dim3(grid_for(N, 256)), dim3(256), 0, s, A);
   hipLaunchKernelGGL(mhd_efield_kernel, dim3(grid_for(N, 256)), dim3(256), 0, s, A);
-  if (A.P.slope_type == 3) hipLaunchKernelGGL(mhd_trace_kernel<true>, dim3(grid_for(N, 128)), dim3(128), 0, s, A);
-  else hipLaunchKernelGGL(mhd_trace_kernel<false>, dim3(grid_for(N, 128)), dim3(128), 0, s, A);
+  // (the stencil kernels: one cell per thread in the XCD-slab order of mhd_cell_of)
+  const CellMap cm{nx, ny, nz, (nz + 7) / 8};
+  auto remap_grid = [&](int tpb) { return dim3((unsigned)(8 * ((cm.slab_cells(0) + tpb - 1) / tpb))); };
+  if (remap_grid(128).x > 0x7fffffffu / 2) return failf(RAMSES_AMD_EUNSUPPORTED, "MHD sweep: level too large for one launch");
+  if (A.P.slope_type == 3) hipLaunchKernelGGL(mhd_trace_kernel<true>, remap_grid(128), dim3(128), 0, s, A);
+  else hipLaunchKernelGGL(mhd_trace_kernel<false>, remap_grid(128), dim3(128), 0, s, A);
   // the flux / EMF kernels: one general instance (the solver is a run-time switch) and one for the Roe solver, whose
   // eigenmatrices would otherwise cost every solver its registers.  (One instance per solver was measured too: fewer
   // registers -- hlld: flux 136 instead of 156, EMF 188 instead of 214 -- but 10.95 instead of 10.08 ms per sweep at 256^3.)
-  const dim3 g128(grid_for(N, 128)), b128(128);
+  const dim3 g128(remap_grid(128)), b128(128);
   if (A.P.riemann == RIEMANN_ROE) hipLaunchKernelGGL(mhd_flux_kernel<RIEMANN_ROE>, g128, b128, 0, s, A);
   else hipLaunchKernelGGL(mhd_flux_kernel<-2>, g128, b128, 0, s, A);
   if (A.P.riemann2d == RIEMANN2D_ROE) hipLaunchKernelGGL(mhd_emf_kernel<RIEMANN2D_ROE>, g128, b128, 0, s, A);
   else hipLaunchKernelGGL(mhd_emf_kernel<-2>, g128, b128, 0, s, A);
-  hipLaunchKernelGGL(mhd_update_kernel, dim3(grid_for(N, 256)), dim3(256), 0, s, A);
+  hipLaunchKernelGGL(mhd_update_kernel, remap_grid(256), dim3(256), 0, s, A);
   HCHK(hipGetLastError(), "MHD sweep launch");
   int bad = 0;
   HCHK(hipMemcpyAsync(&bad, A.bad, sizeof(int), hipMemcpyDeviceToHost, s), "D2H");

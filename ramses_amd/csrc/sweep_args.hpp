@@ -64,7 +64,7 @@ struct SurfArgs {
   const double *uold = nullptr, *grav = nullptr;     // the device's cell vectors
   const unsigned char *stat = nullptr;
   const int *dir = nullptr, *tileid = nullptr;       // the level's tile directory / the tile of every 512-oct slab of its index range
-  const int *events = nullptr;                       // list position * 6 + face
+  const int *events = nullptr;                       // list position * 6 + face, sorted by (face, device oct)
   const int *ig = nullptr;                           // the call's list, device octs (1-based)
   double *rec = nullptr;                             // [nevent][4][nvar + 2]
   int nevent = 0;

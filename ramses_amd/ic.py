@@ -133,7 +133,7 @@ def _morton_rank(no):
     return np.argsort(np.argsort(key.reshape(-1))).reshape(no, no, no)
 
 
-def uniform_tree(L, slack=7, order="scrambled", refine_box=None, refine_mask=None, refine_mask2=None):
+def uniform_tree(L, slack=7, order="scrambled", refine_box=None, refine_mask=None, refine_mask2=None, refine_mask3=None):
     """RAMSES tree arrays (amr/amr_commons.f90:67-75) of a periodic nx=ny=nz=1 box
     whose levels 1..L are fully refined; octs are numbered level by level in a
     scrambled order (the reference's lists are not lexicographic either).
@@ -150,6 +150,8 @@ def uniform_tree(L, slack=7, order="scrambled", refine_box=None, refine_mask=Non
         nextra = int(np.count_nonzero(refine_mask))
     if refine_mask2 is not None:
         nextra += int(np.count_nonzero(refine_mask2))
+    if refine_mask3 is not None:
+        nextra += int(np.count_nonzero(refine_mask3))
     ngridmax = sum(counts) + nextra + slack
     ncell = ncoarse + 8 * ngridmax
     son = np.zeros(ncell, np.int32)
@@ -229,21 +231,26 @@ def uniform_tree(L, slack=7, order="scrambled", refine_box=None, refine_mask=Non
             nbor[d, idf - 1] = cell_of(L, c[0], c[1], c[2])
         out["igrid_fine"] = idf.copy() if order == "morton" else rng.permutation(idf).astype(np.int32)
         out["fine_cells"] = lambda: np.concatenate([ncoarse + ind * ngridmax + idf for ind in range(8)])
-        if refine_mask2 is not None:
-            # a third level: level L+2 octs in the level-(L+1) cells of refine_mask2[z,y,x] ((2n)^3, cells that exist and whose
-            # 3^3 neighbours exist: the caller keeps the mask inside the refined region)
-            used += cx.size
-            idsf = np.zeros((n, n, n), np.int32)
-            idsf[cz, cy, cx] = idf
-            ez, ey, ex = np.nonzero(refine_mask2)
+        # further levels: level L+1+k octs in the level-(L+k) cells of a mask over that level's (2^k n)^3 cell grid (cells that
+        # exist and whose 3^3 neighbours exist: the caller keeps each mask inside the level below)
+        used += cx.size
+        prev_pos, prev_id, npos = (cz, cy, cx), idf, n          # oct positions of the level below, in units of its octs
+        for k, (mk, name) in enumerate(((refine_mask2, "igrid_fine2"), (refine_mask3, "igrid_fine3")), start=1):
+            if mk is None:
+                break
+            assert mk.shape == (2 * npos,) * 3
+            idsf = np.zeros((npos, npos, npos), np.int32)
+            idsf[prev_pos[0], prev_pos[1], prev_pos[2]] = prev_id
+            ez, ey, ex = np.nonzero(mk)
+            nn = 2 * npos
 
-            def cell_f(fx, fy, fz):
-                g = idsf[(fz >> 1) % n, (fy >> 1) % n, (fx >> 1) % n].astype(np.int64)
-                assert (g > 0).all(), "refine_mask2 reaches outside level L+1"
+            def cell_f(fx, fy, fz, idsf=idsf, npos=npos):
+                g = idsf[(fz >> 1) % npos, (fy >> 1) % npos, (fx >> 1) % npos].astype(np.int64)
+                assert (g > 0).all(), "a refinement mask reaches outside the level below"
                 return ncoarse + ((fx & 1) + 2 * (fy & 1) + 4 * (fz & 1)) * ngridmax + g
             if order == "morton":
                 key = np.zeros(ex.size, dtype=np.int64)
-                for b in range(L + 1):
+                for b in range(L + k):
                     key |= ((ex >> b) & 1) << (3 * b) | ((ey >> b) & 1) << (3 * b + 1) | ((ez >> b) & 1) << (3 * b + 2)
                 o = np.argsort(key, kind="stable")
                 ez, ey, ex = ez[o], ey[o], ex[o]
@@ -256,7 +263,9 @@ def uniform_tree(L, slack=7, order="scrambled", refine_box=None, refine_mask=Non
             for d in range(6):
                 axis, up = d >> 1, d & 1
                 c = [ex.copy(), ey.copy(), ez.copy()]
-                c[axis] = (c[axis] + (1 if up else -1)) % (2 * n)
+                c[axis] = (c[axis] + (1 if up else -1)) % nn
                 nbor[d, idg - 1] = cell_f(c[0], c[1], c[2])
-            out["igrid_fine2"] = idg.copy() if order == "morton" else rng.permutation(idg).astype(np.int32)
+            out[name] = idg.copy() if order == "morton" else rng.permutation(idg).astype(np.int32)
+            used += ex.size
+            prev_pos, prev_id, npos = (ez, ey, ex), idg, nn
     return out

@@ -93,8 +93,7 @@ end subroutine phi_fine_cg
 ! The iteration loop of phi_fine_cg (poisson/phi_fine_cg.f90:88-187) with several MPI ranks: the loop and its two
 ! MPI_ALLREDUCEs per iteration (:108,154) here; every loop body -- the recurrence on p, cmp_Ap_cg with the local p.Ap,
 ! the recurrences on x and r with the local r.r -- on the rank's GPU (ramses_amd_cgmpi_*), and the halo exchange of p
-! (:134) on the device vector (ramses_amd_cg_p_halo: RCCL, or MPI on pinned buffers; round 2's detour through the host
-! array f(:,2) and the reference's make_virtual_fine_dp with RAMSES_AMD_CG_HOST_HALO=1).  alpha and beta are formed on the
+! (:134) on the device vector (ramses_amd_cg_p_halo: RCCL, or MPI on pinned buffers).  alpha and beta are formed on the
 ! device from the device scalars this routine keeps global.  The local sums run in the reference's order (default) and
 ! the same MPI library reduces them: the run equals the MPI reference bit for bit.
 !------------------------------------------------------------------------------
@@ -111,9 +110,6 @@ subroutine phi_fine_cg_mpi(ilevel,fact,itermax,iter,err)
   integer,allocatable,dimension(:)::em_n,em_ig,rc_n,rc_ig
   real(kind=8)::error,error_ini,rhs_norm,r2,pAp,x_all
   real(kind=8),dimension(2)::out2,out2_all
-  logical::host_halo
-  character(len=16)::val
-  integer::stat
 
   call ramses_amd_comm_lists(ilevel,em_n,em_ig,rc_n,rc_ig)
   nem=sum(em_n); nrc=sum(rc_n)
@@ -126,15 +122,8 @@ subroutine phi_fine_cg_mpi(ilevel,fact,itermax,iter,err)
   rc=ramses_amd_cgmpi_set(0,r2)
   if(rc/=0)call ramses_amd_fatal('phi_fine_cg (r2)')
   ! the halo of p (:134) runs on the device vector: the level's communicators go there once per solve
-  host_halo=.false.
-  call get_environment_variable('RAMSES_AMD_CG_HOST_HALO',val,status=stat)
-  if(stat==0)then
-     if(trim(val)=='1')host_halo=.true.
-  end if
-  if(.not.host_halo)then
-     rc=ramses_amd_cgmpi_comm_set(ncpu,em_n,em_ig,rc_n,rc_ig)
-     if(rc/=0)call ramses_amd_fatal('phi_fine_cg (communicators)')
-  end if
+  rc=ramses_amd_cgmpi_comm_set(ncpu,em_n,em_ig,rc_n,rc_ig)
+  if(rc/=0)call ramses_amd_fatal('phi_fine_cg (communicators)')
 
   iter=0
   error=1.0D0; error_ini=1.0D0
@@ -143,16 +132,8 @@ subroutine phi_fine_cg_mpi(ilevel,fact,itermax,iter,err)
      ! recurrence on p (beta = r2/r2_old on the device), then its virtual cells
      rc=ramses_amd_cgmpi_step(0,iter)
      if(rc/=0)call ramses_amd_fatal('phi_fine_cg (recurrence on p)')
-     if(host_halo)then
-        ! (RAMSES_AMD_CG_HOST_HALO=1, round 2: p's emission cells to the host array, the reference's exchange, reception cells back)
-        rc=ramses_amd_cgmpi_p_cells(nem,em_ig,1)
-        if(rc/=0)call ramses_amd_fatal('phi_fine_cg (cells of p)')
-        call make_virtual_fine_dp(f(1,2),ilevel)
-        rc=ramses_amd_cgmpi_p_cells(nrc,rc_ig,0)
-     else
-        call ramses_amd_cg_p_halo()
-        rc=0
-     end if
+     call ramses_amd_cg_p_halo()
+     rc=0
      ! z = A p and p.Ap
      if(rc==0)rc=ramses_amd_cgmpi_step(1,iter)
      if(rc==0)rc=ramses_amd_cgmpi_get(2,pAp)

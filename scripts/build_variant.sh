@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 tag=$1; shift
 mkdir -p ramses_amd/lib/ab ramses_amd/build/ab
-C="hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -I include -ffp-contract=off -DSWEEP_FLAGSHIP_ONLY $*"
+C="hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math --offload-compress -I include -ffp-contract=off -DSWEEP_FLAGSHIP_ONLY $*"
 $C -c ramses_amd/csrc/hydro_sweep.hip -o ramses_amd/build/ab/sweep_${tag}_strict.o &
 $C -DRAMSES_AMD_FAST=1 -c ramses_amd/csrc/hydro_sweep.hip -o ramses_amd/build/ab/sweep_${tag}_fast.o &
 wait

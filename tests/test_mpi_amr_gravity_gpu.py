@@ -8,7 +8,8 @@ prolongation -- runs on the rank's GPU, over the rank's own octs followed by the
                              the residual, make_virtual_mg_dp and make_reverse_mg_dp exchange the device arrays
                              (ramses_amd_mgamr_halo_*): no level array crosses PCIe after the upload -- asserted on the
                              transfer counters the library prints with RAMSES_AMD_MG_STATS=1
-  RAMSES_AMD_MG_MPI_SYNC=1   (round 2) the arrays cross PCIe around every routine and the reference's host exchanges run.
+  (round 2's path -- the arrays across PCIe around every routine, the reference's host exchanges in between -- and its switch
+  RAMSES_AMD_MG_MPI_SYNC were retired in round 6.)
 phi, f, the hydro state of every leaf cell and the V-cycle counts must equal the untouched MPI reference
 (oracle/_ref/ramses3d_mpi, same rank count) bit for bit."""
 import importlib.util
@@ -51,12 +52,12 @@ def _sorted(snap):
     return snap["level"][order], snap["x"][order], snap["prim"][:, order], snap["grav"][:, order]
 
 
-@pytest.mark.parametrize("nproc,resident,mgsync", [(2, "1", "0"), (4, "1", "0"), (8, "1", "0"), (2, "0", "0"), (2, "1", "1"), (4, "1", "1")])
+@pytest.mark.parametrize("nproc,resident,mgsync", [(2, "1", "0"), (4, "1", "0"), (8, "1", "0"), (2, "0", "0")])
 def test_amr_multigrid_under_mpi_equals_the_mpi_reference(gpu_lib, nproc, resident, mgsync):
     """resident=1 (default): the hydro state and the tree stay on every rank's GPU as well (virtual-boundary
     exchanges of uold / unew on the device, the acceleration mirrored incl. the virtual octs, density back for
     rho_fine); resident=0 (RAMSES_AMD_RESIDENT_AMR_MPI=0): hydro arrays staged around every call.
-    mgsync=0 (default): the multigrid levels stay on the device during a solve; 1: RAMSES_AMD_MG_MPI_SYNC=1."""
+    The multigrid levels stay on the device during a solve (mgsync is always "0" since round 6)."""
     if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED_MPI)):
         pytest.skip("oracle/_ref/ramses3d_mpi[_patch] not built")
     if nproc > (os.cpu_count() or 1):
@@ -64,8 +65,6 @@ def test_amr_multigrid_under_mpi_equals_the_mpi_reference(gpu_lib, nproc, reside
     from oracle import ramses_snapshot as rs
     nml = _mka().selfgrav_namelist().replace("ngridtot=6000 !", "ngridtot=60000 !")
     env = {"RAMSES_AMD": "1", "RAMSES_AMD_RESIDENT_AMR_MPI": resident, "RAMSES_AMD_MG_STATS": "1"}
-    if mgsync == "1":
-        env["RAMSES_AMD_MG_MPI_SYNC"] = "1"
     workp, outp = _run(nml, PATCHED_MPI, nproc, env)
     try:
         assert ("AMR levels stay resident on the GPU" in outp) == (resident == "1"), outp[-1500:]
@@ -95,7 +94,7 @@ def test_amr_multigrid_under_mpi_equals_the_mpi_reference(gpu_lib, nproc, reside
     assert np.array_equal(got[2], ref[2]), np.abs(got[2] - ref[2]).max()     # hydro state
 
 
-@pytest.mark.parametrize("nproc,ordered", [(2, "default"), (4, "default"), (8, "default"), (2, "hosthalo"), (2, "0")])
+@pytest.mark.parametrize("nproc,ordered", [(2, "default"), (4, "default"), (8, "default"), (2, "0")])
 def test_cg_levels_under_mpi_equal_the_mpi_reference(gpu_lib, nproc, ordered):
     """phi_fine_cg under MPI: cg_levelmin=4, so levels 4 and 5 of the self-gravitating AMR run
     are solved by the conjugate-gradient loop -- every loop body on the rank's GPU (ramses_amd_cgmpi_*), the two
@@ -111,14 +110,12 @@ def test_cg_levels_under_mpi_equal_the_mpi_reference(gpu_lib, nproc, ordered):
     nml = mk.cg_namelist().replace("ngridtot=6000 !", "ngridtot=60000 !")
     pat = r"==> Level=\s*(\d+) Step=\s*(\d+)"
     # default: dot products in the reference's order (parity scan), the halo of p exchanged from the device vector;
-    # hosthalo: round 2's detour of p's virtual cells through the host array; "0": parallel-tree sums (equal to rounding)
+    # "0": parallel-tree sums (equal to rounding)
     if nproc > (os.cpu_count() or 1):
         pytest.skip("fewer cores than ranks")
     env = {"RAMSES_AMD": "1"}
     if ordered == "0":
         env["RAMSES_AMD_CG_ORDERED"] = "0"
-    if ordered == "hosthalo":
-        env["RAMSES_AMD_CG_HOST_HALO"] = "1"
     workp, outp = _run(nml, PATCHED_MPI, nproc, env)
     try:
         assert "Entering phi_fine_cg" not in outp or "MI355X" in outp
