@@ -589,7 +589,8 @@ def mhd_sweep_bench(level=7, steps=5):
     return {"metric": "cell-updates/s (MHD godunov_fine, SOLVER=mhd, constrained transport)", "value": cells / (ms * 1e-3),
             "unit": "cell-updates/s", "ms_per_sweep": ms, "cells": cells, "solver": "hlld + hlld (2-D), moncen",
             "arithmetic": "strict (bit-identical to the reference)", "workload": "uniform periodic %d^3, magnetised blast" % n,
-            "kernels": "mhd_prim / efield / trace / flux / emf / update (first correct path: intermediates in HBM)",
+            "kernels": "mhd_prim_trace (ctoprim + edge fields + trace fused over LDS tiles, round 6) / flux / emf / update; the 47 predicted numbers, "
+                       "the fluxes and the EMFs still cross HBM",
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "bytes_per_cell": BYTES_PER_CELL_UPDATE_MHD}}
 

@@ -230,6 +230,12 @@ case "$cmd" in
        fi
        bg r_mhd
        if [ -f "$HERE/../ramses_amd/lib/libramses_amd.so" ]; then bg r_mhd "$HERE/../ramses_amd/patch_mhd"; fi
+       # SOLVER=mhd with MPI (the AMR levels of an MHD run on several ranks: tests/test_mhd_amr_gpu.py)
+       r_mhd_mpi() { REF_SOLVER=mhd REF_TAG=mhd build_ramses 3 mpi "$@"; }
+       if [ -d /opt/conda/include ] && [ -f /opt/conda/lib/libmpifort.so ]; then
+         bg r_mhd_mpi
+         if [ -f "$HERE/../ramses_amd/lib/libramses_amd.so" ]; then bg r_mhd_mpi "$HERE/../ramses_amd/patch_mhd"; fi
+       fi
        bg r 3 serial "$HERE/dump_patch"
        bg r_v7
        if [ -f "$HERE/../ramses_amd/lib/libramses_amd.so" ]; then

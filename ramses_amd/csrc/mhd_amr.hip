@@ -87,6 +87,7 @@ __device__ __forceinline__ int tree_nbor_cell(const MhdAmrArgs &A, int c, int di
   const int bit = (pos >> axis) & 1;
   if (bit != up) return c + (up ? 1 : -1) * (int)((1 << axis) * A.ngridmax);
   const int nb = A.nbor[(long)dir * A.ngridmax + g - 1];
+  if (nb <= 0) return -c;               // beyond the outermost boundary layer (the reference reads uold(0,:) there: never used)
   const int g2 = A.son[nb - 1];
   if (g2 == 0) return -nb;
   return (int)(A.ncoarse + (long)(pos ^ (1 << axis)) * A.ngridmax + g2);

@@ -176,6 +176,80 @@ __global__ __launch_bounds__(128) void mhd_trace_kernel(MhdArgs A) {
   }
 }
 
+// ---- ctoprim + the edge fields + uslope / trace3d's predictor in ONE launch (round 6) ---------------------------------------
+// The three kernels above hand q (8 numbers per cell) and E (3) through HBM and the trace then gathers them back: seven (or 27)
+// cells x 8 + 30 face fields + 12 edge fields per cell through the L1 -- 4.1 of the sweep's 10.2 ms at 256^3 for 0.9 ms of
+// arithmetic.  Here a workgroup owns a tile of 32 x 4 x 4 cells: it converts the 34 x 6 x 6 cells around it once into LDS (q and
+// the left-face fields: 108 KB), forms the edge fields of the 33 x 5 x 5 edges the tile's traces read (20 KB), and every thread
+// traces its cell from LDS.  What reaches HBM is what the flux and EMF kernels need: the 47 predicted numbers per cell.  The
+// same functions on the same values as the three kernels (which stay for the A/B: RAMSES_AMD_MHD_FUSED=0).
+constexpr int FT_X = 32, FT_Y = 4, FT_Z = 4;
+struct FusedLds {
+  double Q[8][FT_Z + 2][FT_Y + 2][FT_X + 2];
+  double BF[3][FT_Z + 2][FT_Y + 2][FT_X + 2];
+  double Ef[3][FT_Z + 1][FT_Y + 1][FT_X + 1];
+};
+struct TileAcc {
+  const FusedLds *L;
+  int ox, oy, oz;             // global coordinates of the tile's first interior cell
+  __device__ __forceinline__ double q(int n, int i, int j, int k) const { return L->Q[n][k - oz + 1][j - oy + 1][i - ox + 1]; }
+  __device__ __forceinline__ double bf(int c, int i, int j, int k) const { return L->BF[c][k - oz + 1][j - oy + 1][i - ox + 1]; }
+  __device__ __forceinline__ double E(int c, int i, int j, int k) const { return L->Ef[c][k - oz][j - oy][i - ox]; }
+};
+__device__ __forceinline__ int wrapn(int i, int n) { i %= n; return i < 0 ? i + n : i; }
+template <bool S3>
+__global__ __launch_bounds__(FT_X * FT_Y * FT_Z) void mhd_prim_trace_kernel(MhdArgs A, int ntx, int nty) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fused_raw[];
+  FusedLds &L = *reinterpret_cast<FusedLds *>(fused_raw);
+  const int tid = threadIdx.x;
+  const int bx = blockIdx.x % ntx, by = (blockIdx.x / ntx) % nty, bz = blockIdx.x / (ntx * nty);
+  const int ox = bx * FT_X, oy = by * FT_Y, oz = bz * FT_Z;
+  const long N = A.ncell;
+  // ---- 1. ctoprim of the tile and one cell around it
+  constexpr int HX = FT_X + 2, HY = FT_Y + 2, HZ = FT_Z + 2;
+  for (int t = tid; t < HX * HY * HZ; t += FT_X * FT_Y * FT_Z) {
+    const int li = t % HX, lj = (t / HX) % HY, lk = t / (HX * HY);
+    const long c = wrapn(ox + li - 1, A.nx) + (long)A.nx * (wrapn(oy + lj - 1, A.ny) + (long)A.ny * wrapn(oz + lk - 1, A.nz));
+    const double u[5] = {A.uold[c], A.uold[N + c], A.uold[2 * N + c], A.uold[3 * N + c], A.uold[4 * N + c]};
+    const double bl[3] = {A.uold[5 * N + c], A.uold[6 * N + c], A.uold[7 * N + c]};
+    const double br[3] = {A.uold[8 * N + c], A.uold[9 * N + c], A.uold[10 * N + c]};
+    double q[8];
+    ctoprim_cell(u, bl, br, nullptr, A.dt, A.P, q);
+#pragma unroll
+    for (int n = 0; n < 8; n++) L.Q[n][lk][lj][li] = q[n];
+#pragma unroll
+    for (int n = 0; n < 3; n++) L.BF[n][lk][lj][li] = bl[n];
+  }
+  __syncthreads();
+  const TileAcc a{&L, ox, oy, oz};
+  // ---- 2. the edge fields on the low edges of the cells (ox .. ox+FT_X) x (oy .. oy+FT_Y) x (oz .. oz+FT_Z)
+  constexpr int EX = FT_X + 1, EY = FT_Y + 1, EZ = FT_Z + 1;
+  for (int t = tid; t < 3 * EX * EY * EZ; t += FT_X * FT_Y * FT_Z) {
+    const int c = t / (EX * EY * EZ), r = t % (EX * EY * EZ);
+    const int li = r % EX, lj = (r / EX) % EY, lk = r / (EX * EY);
+    L.Ef[c][lk][lj][li] = efield(a, c, ox + li, oy + lj, oz + lk);
+  }
+  __syncthreads();
+  // ---- 3. the trace of the thread's cell; the face-consistency check of the prim kernel
+  const int i = ox + tid % FT_X, j = oy + (tid / FT_X) % FT_Y, k = oz + tid / (FT_X * FT_Y);
+  if (i >= A.nx || j >= A.ny || k >= A.nz) return;
+  const long c_ = i + (long)A.nx * (j + (long)A.ny * k);
+  {
+    int bad = 0;
+    if (!(A.uold[8 * N + c_] == a.bf(0, i + 1, j, k))) bad++;
+    if (!(A.uold[9 * N + c_] == a.bf(1, i, j + 1, k))) bad++;
+    if (!(A.uold[10 * N + c_] == a.bf(2, i, j, k + 1))) bad++;
+    if (bad) atomicAdd(A.bad, bad);
+  }
+  TraceIn I;
+  trace_inputs<S3>(a, i, j, k, A.P, I);
+  TracePred T;
+  const double dtdx = A.dt / A.dx;
+  trace_predict(I, dtdx, dtdx, dtdx, A.P, T);
+#pragma unroll
+  for (int n = 0; n < NPRED; n++) A.tr[pred_at(n, c_)] = T.v[n];
+}
+
 // flux[d][0..4] through the LOW face of direction d of the cell, scaled as mag_unsplit does (fx*dt/dx, :105-111): the +d
 // state of the cell below and the -d state of the cell, each rebuilt from its predicted state and half slopes
 template <int D, int RS>
@@ -384,13 +458,31 @@ int ramses_amd_mhd_godunov_brick(const ramses_amd_mhd_params *p, int nx, int ny,
   A.bad = reinterpret_cast<int *>(w);
   A.nx = nx; A.ny = ny; A.nz = nz; A.ncell = N; A.dt = dt; A.dx = dx;
   HCHK(hipMemsetAsync(A.bad, 0, sizeof(int), s), "memset");
-  hipLaunchKernelGGL(mhd_prim_kernel, dim3(grid_for(N, 256)), dim3(256), 0, s, A);
-  hipLaunchKernelGGL(mhd_efield_kernel, dim3(grid_for(N, 256)), dim3(256), 0, s, A);
+  // ctoprim, the edge fields and the trace: one launch over tiles of 32 x 4 x 4 cells (RAMSES_AMD_MHD_FUSED=0: the three kernels)
+  static int fused = -1;
+  if (fused < 0) { const char *e = getenv("RAMSES_AMD_MHD_FUSED"); fused = (e && e[0] == '0') ? 0 : 1; }
+  if (!fused) {
+    hipLaunchKernelGGL(mhd_prim_kernel, dim3(grid_for(N, 256)), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(mhd_efield_kernel, dim3(grid_for(N, 256)), dim3(256), 0, s, A);
+  }
   // (the stencil kernels: one cell per thread in the XCD-slab order of mhd_cell_of)
   const CellMap cm{nx, ny, nz, (nz + 7) / 8};
   auto remap_grid = [&](int tpb) { return dim3((unsigned)(8 * ((cm.slab_cells(0) + tpb - 1) / tpb))); };
   if (remap_grid(128).x > 0x7fffffffu / 2) return failf(RAMSES_AMD_EUNSUPPORTED, "MHD sweep: level too large for one launch");
-  if (A.P.slope_type == 3) hipLaunchKernelGGL(mhd_trace_kernel<true>, remap_grid(128), dim3(128), 0, s, A);
+  if (fused) {
+    const int ntx = (nx + FT_X - 1) / FT_X, nty = (ny + FT_Y - 1) / FT_Y, ntz = (nz + FT_Z - 1) / FT_Z;
+    const dim3 fg((unsigned)((long)ntx * nty * ntz)), fb(FT_X * FT_Y * FT_Z);
+    const size_t lds = sizeof(FusedLds);
+    if (A.P.slope_type == 3) {
+      auto kf = mhd_prim_trace_kernel<true>;
+      HCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS");
+      hipLaunchKernelGGL(kf, fg, fb, lds, s, A, ntx, nty);
+    } else {
+      auto kf = mhd_prim_trace_kernel<false>;
+      HCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS");
+      hipLaunchKernelGGL(kf, fg, fb, lds, s, A, ntx, nty);
+    }
+  } else if (A.P.slope_type == 3) hipLaunchKernelGGL(mhd_trace_kernel<true>, remap_grid(128), dim3(128), 0, s, A);
   else hipLaunchKernelGGL(mhd_trace_kernel<false>, remap_grid(128), dim3(128), 0, s, A);
   // the flux / EMF kernels: one general instance (the solver is a run-time switch) and one for the Roe solver, whose
   // eigenmatrices would otherwise cost every solver its registers.  (One instance per solver was measured too: fewer
@@ -398,6 +490,7 @@ int ramses_amd_mhd_godunov_brick(const ramses_amd_mhd_params *p, int nx, int ny,
   const dim3 g128(remap_grid(128)), b128(128);
   if (A.P.riemann == RIEMANN_ROE) hipLaunchKernelGGL(mhd_flux_kernel<RIEMANN_ROE>, g128, b128, 0, s, A);
   else hipLaunchKernelGGL(mhd_flux_kernel<-2>, g128, b128, 0, s, A);
+  // (one launch per edge direction -- 164 VGPRs and three waves per SIMD instead of 212 and two -- was measured: 9.00 against 8.87 ms)
   if (A.P.riemann2d == RIEMANN2D_ROE) hipLaunchKernelGGL(mhd_emf_kernel<RIEMANN2D_ROE>, g128, b128, 0, s, A);
   else hipLaunchKernelGGL(mhd_emf_kernel<-2>, g128, b128, 0, s, A);
   hipLaunchKernelGGL(mhd_update_kernel, remap_grid(256), dim3(256), 0, s, A);

@@ -115,8 +115,8 @@ contains
   end function ramses_amd_mhd_device_config
 
   ! godfine1 of ANY level of an AMR tree on the device (csrc/mhd_amr.hip, staged): what the brick sweep asks for, except that
-  ! self-gravity is allowed (ctoprim's half kick from f; the source terms stay the reference's host routines) -- one rank,
-  ! periodic box, no pressure_fix
+  ! self-gravity is allowed (ctoprim's half kick from f; the source terms stay the reference's host routines) -- any number of
+  ! ranks, periodic or walled box, no pressure_fix
   logical function ramses_amd_mhd_amr_config()
     use amr_commons
     use hydro_commons
@@ -132,8 +132,12 @@ contains
        end if
     end if
     nx_loc = icoarse_max - icoarse_min + 1
-    ramses_amd_mhd_amr_config = on .and. ramses_amd_mhd_enabled() .and. hydro .and. ndim == 3 .and. nvar == 8 .and. ncpu == 1 &
-         & .and. nboundary == 0 .and. nx_loc == 1 .and. jcoarse_max == jcoarse_min .and. kcoarse_max == kcoarse_min &
+    ! (several ranks: every rank sweeps its own active octs; the virtual octs of its neighbours are ordinary octs of its tree, kept
+    !  current by the reference's make_virtual_fine_dp, and what the sweep owes to coarse cells of other ranks travels home through
+    !  the reference's make_virtual_reverse_dp on unew, as with the reference's own godfine1)
+    ! (physical boundaries: the boundary octs are ordinary octs of the tree, filled by the reference's make_boundary_hydro
+    !  (mhd/hydro_boundary.f90) before godunov_fine reads them -- as for the reference's own godfine1)
+    ramses_amd_mhd_amr_config = on .and. ramses_amd_mhd_enabled() .and. hydro .and. ndim == 3 .and. nvar == 8 &
          & .and. .not. pressure_fix .and. ischeme == 0 .and. .not. allow_switch_solver &
          & .and. .not. allow_switch_solver2D .and. .not. MC_tracer &
          & .and. iriemann >= 0 .and. iriemann <= 5 .and. iriemann2d >= 0 .and. iriemann2d <= 5 &

@@ -93,3 +93,98 @@ def test_patched_mhd_program_on_an_amr_tree_equals_the_reference(gpu_lib, monkey
     dxl = 0.5 ** lg
     div = ((pg[7] - pg[4]) + (pg[8] - pg[5]) + (pg[9] - pg[6])) / dxl
     assert np.abs(div).max() < 1e-10 * np.abs(pg[4:10]).max() / dxl.min(), np.abs(div).max()
+
+
+REF_MPI = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi_mhd")
+PATCHED_MPI = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi_patch_mhd_mhd")
+
+
+@pytest.mark.parametrize("nproc,lmin,lmax,nstep,riemann,riemann2d,slope_type,ivar,itype", [
+    (2, 5, 7, 5, "hlld", "hlld", 1, 0, 1),
+    (4, 4, 6, 6, "hll", "hll", 2, 1, 2),
+])
+def test_patched_mhd_program_on_an_amr_tree_under_mpi_equals_the_mpi_reference(gpu_lib, monkeypatch, nproc, lmin, lmax, nstep, riemann, riemann2d,
+                                                                               slope_type, ivar, itype):
+    """Several ranks (they share this box's one GPU): every rank sweeps its own active octs on the device; the virtual octs of its
+    neighbours are ordinary octs of its tree and what the sweep owes to coarse cells of other ranks goes home through the reference's
+    own make_virtual_reverse_dp on unew -- the patched MPI program of SOLVER=mhd against the MPI reference on the same ranks, leaf cell
+    by leaf cell, bit for bit."""
+    if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED_MPI)):
+        pytest.skip("oracle/_ref/ramses3d_mpi_mhd / ramses3d_mpi_patch_mhd_mhd not built")
+    if nproc > (os.cpu_count() or 1):
+        pytest.skip("fewer cores than ranks")
+    from oracle import ramses_snapshot as rs
+    nml = amr_namelist(lmin, lmax, nstep, riemann, riemann2d, slope_type, ivar, itype)
+    monkeypatch.setenv("RAMSES_AMD", "1")
+    work, out = rs.run_reference(nml, binary=PATCHED_MPI, nproc=nproc)
+    try:
+        assert "MHD godunov_fine of AMR levels on the MI355X (staged)" in out, out[-2500:]
+        ms = re.findall(r"MHD godunov_fine of AMR levels: (\d+) sweeps on the device \((\d+) octs\), (\d+) through the reference's host routine", out)
+        assert len(ms) == nproc, out[-2500:]                      # every rank reports
+        assert all(int(m[0]) > nstep and int(m[2]) == 0 for m in ms), ms
+        got = rs.load_leaf_cells(os.path.join(work, "output_00002"))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    monkeypatch.setenv("RAMSES_AMD", "0")
+    work, out = rs.run_reference(nml, binary=REF_MPI, nproc=nproc)
+    try:
+        ref = rs.load_leaf_cells(os.path.join(work, "output_00002"))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    lg, xg, pg = _sorted(got)
+    lr, xr, pr = _sorted(ref)
+    counts = [int((lr == l).sum()) for l in range(lmin, lmax + 1)]
+    print("MHD AMR %d-%d on %d ranks, %s/%s: device sweeps per rank %s, leaves per level %s" % (lmin, lmax, nproc, riemann, riemann2d, [int(m[0]) for m in ms], counts))
+    assert min(counts) > 100, counts
+    assert float(np.ravel(got["info"]["t"])[0]) == float(np.ravel(ref["info"]["t"])[0])
+    assert np.array_equal(lg, lr) and np.array_equal(xg, xr), "the two runs refined different cells"
+    bad = np.nonzero((pg != pr).any(axis=0))[0]
+    assert bad.size == 0, (bad.size, lg[bad[:5]], xg[bad[:5]], (pg - pr)[:, bad[:5]])
+
+
+WALLS = """&BOUNDARY_PARAMS
+nboundary=6
+ibound_min=-1,+1,-1,-1,-1,-1
+ibound_max=-1,+1,+1,+1,+1,+1
+jbound_min= 0, 0,-1,+1,-1,-1
+jbound_max= 0, 0,-1,+1,+1,+1
+kbound_min= 0, 0, 0, 0,-1,+1
+kbound_max= 0, 0, 0, 0,-1,+1
+bound_type= 1, 1, 1, 2, 2, 2
+/
+"""
+
+
+def test_patched_mhd_program_on_an_amr_tree_between_walls_equals_the_reference(gpu_lib, monkeypatch):
+    """&BOUNDARY_PARAMS (three reflexive, three outflow faces) on the AMR run: the boundary octs are ordinary octs of the tree,
+    filled by the reference's make_boundary_hydro (mhd/hydro_boundary.f90) on the host before every sweep; the box's coarse grid is
+    3 x 3 x 3 cells.  Patched program == reference, leaf cell by leaf cell."""
+    if not (os.path.exists(REF) and os.path.exists(PATCHED)):
+        pytest.skip("oracle/_ref/ramses3d_mhd / ramses3d_patch_mhd_mhd not built")
+    from oracle import ramses_snapshot as rs
+    lmin, lmax, nstep = 4, 6, 8
+    nml = amr_namelist(lmin, lmax, nstep, "hlld", "hlld", 1, 0, 1) + WALLS
+    monkeypatch.setenv("RAMSES_AMD", "1")
+    work, out = rs.run_reference(nml, binary=PATCHED)
+    try:
+        m = re.search(r"MHD godunov_fine of AMR levels: (\d+) sweeps on the device \((\d+) octs\), (\d+) through the reference's host routine", out)
+        assert m, out[-2500:]
+        assert int(m.group(1)) > nstep and int(m.group(3)) == 0, m.group(0)
+        got = rs.load_leaf_cells(os.path.join(work, "output_00002"))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    monkeypatch.setenv("RAMSES_AMD", "0")
+    work, out = rs.run_reference(nml, binary=REF)
+    try:
+        ref = rs.load_leaf_cells(os.path.join(work, "output_00002"))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    lg, xg, pg = _sorted(got)
+    lr, xr, pr = _sorted(ref)
+    counts = [int((lr == l).sum()) for l in range(lmin, lmax + 1)]
+    print("MHD AMR %d-%d between walls: %s device sweeps, leaves per level %s" % (lmin, lmax, m.group(1), counts))
+    assert min(counts) > 50, counts
+    assert float(np.ravel(got["info"]["t"])[0]) == float(np.ravel(ref["info"]["t"])[0])
+    assert np.array_equal(lg, lr) and np.array_equal(xg, xr), "the two runs refined different cells"
+    bad = np.nonzero((pg != pr).any(axis=0))[0]
+    assert bad.size == 0, (bad.size, lg[bad[:5]], xg[bad[:5]], (pg - pr)[:, bad[:5]])
