@@ -1354,6 +1354,24 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
     }
   }
   const int nw = (int)(items.size() / 4);
+  {
+    // the items of one slab of planes next to each other -- x first, then y, then the slabs (RAMSES_AMD_TILE_ORDER=column keeps a
+    // column's pieces together: the round-5 order): the 32 workgroups an XCD runs at a time are then neighbours in x AND y
+    // marching the same planes, and the four halo rows of a 12-row tile are asked of the L2 their neighbour filled
+    const char *e = getenv("RAMSES_AMD_TILE_ORDER");
+    if (!(e && e[0] == 'c')) {
+      std::vector<int> idx((size_t)nw), sorted(items.size());
+      for (int k = 0; k < nw; k++) idx[(size_t)k] = k;
+      std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+        const int *A = &items[(size_t)a * 4], *B = &items[(size_t)b * 4];
+        if (A[2] != B[2]) return A[2] < B[2];
+        if (A[1] != B[1]) return A[1] < B[1];
+        return A[0] < B[0];
+      });
+      for (int k = 0; k < nw; k++) for (int q = 0; q < 4; q++) sorted[(size_t)k * 4 + q] = items[(size_t)idx[(size_t)k] * 4 + q];
+      items.swap(sorted);
+    }
+  }
   // workgroup b runs on XCD b mod 8: give each XCD a contiguous run of the list (neighbouring columns re-read each other's
   // halo from ONE L2)
   std::vector<int> order((size_t)nw * 4);

@@ -245,7 +245,10 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #ifndef SWEEP_KEEP_PLAIN
 #define SWEEP_KEEP_PLAIN 1     // the plain fast 12-row kernel holds the plane too instead of re-reading it from L2 (profiles/r06_ab_sweep.txt)
 #endif
-#ifdef RAMSES_AMD_FAST
+#ifndef SWEEP_KEEP_STRICT
+#define SWEEP_KEEP_STRICT 0    // (A/B knob: the strict build holds the plane too)
+#endif
+#if defined(RAMSES_AMD_FAST) || SWEEP_KEEP_STRICT
   constexpr bool KEEP = (MASK || (SWEEP_KEEP_PLAIN && BY == 12)) && NV == 5 && !LATE;
 #else
   constexpr bool KEEP = false;
