@@ -484,6 +484,11 @@ int ramses_amd_poisamr_force(int ilevel, int ngrid, const int *igrid, int ngrid_
 int ramses_amd_poisamr_force_mpi(int ilevel, int ngrid_own, int ngrid_all, const int *igrid_all, int ngrid_c_all, const int *igrid_c_all,
                                  const double *phi, const double *phi_old, const double *rho, double *f, double tfrac, int interp,
                                  double fact, double *diag);
+/* The same, f of the own cells going into the resident acceleration on the device instead of the host array
+ * (ramses_amd_amrres_take_f_device); the caller exchanges the virtual octs on the device. */
+int ramses_amd_poisamr_force_mpi_resident(int ilevel, int ngrid_own, int ngrid_all, const int *igrid_all, int ngrid_c_all,
+                                          const int *igrid_c_all, const double *phi, const double *phi_old, const double *rho,
+                                          double tfrac, int interp, double fact, double *diag);
 /* create the HIP context and load the device code of every kernel now (one-time ~0.2 s, otherwise paid by the
  * first call of each kernel family inside the reference's timed loop) */
 int ramses_amd_warmup(void);
@@ -725,6 +730,12 @@ int ramses_amd_mgdist_oct_box(int ilevel, int ngrid, const int *igrid, const dou
 int ramses_amd_mgdist_force_f90(ramses_amd_mgdist *ctx, int ilevel, int ngrid, const int *igrid, const double *xg,
                                 int64_t ngridmax, int64_t ncoarse, const int *lo, double *f, const double *rho, const int *son,
                                 int nvector, double fact, double *diag);
+/* The same for a run whose cell vectors are resident, on a level without finer octs: f goes from the brick into the resident
+ * acceleration on the device (ramses_amd_amrres_take_f_device) and the potential-energy sum of
+ * /root/reference/poisson/force_fine.f90:150-176 runs there in the reference's order; nothing of f crosses PCIe.  The caller
+ * exchanges the virtual octs on the device (ramses_amd_amrres_halo_*, direction 7). */
+int ramses_amd_mgdist_force_resident_f90(ramses_amd_mgdist *M, int ilevel, int ngrid, const int *igrid, int64_t ngridmax,
+                                         int64_t ncoarse, const double *rho, int nvector, double fact, double *diag);
 /* host only (no device): the deep-halo plan ramses_amd_mgdist_create builds for one rank and a level whose bricks have
  * dims[3] cells inside ng ghost layers -- 26 send / receive regions (org x,y,z + ext x,y,z in allocated coordinates) with
  * their positions in the message buffers, and the messages (one per peer; the caller's own rank where the box wraps onto
@@ -816,6 +827,18 @@ int ramses_amd_amrres_courant(const ramses_amd_hydro_params *p, int ngrid, const
  * (hydro/godunov_fine.f90:237-289, set_uold_grav).  sync_density: uold(:,1) of one level back to the host for rho_fine's
  * multipole_fine (pm/rho_fine.f90:666-770), which reads nothing else of the hydro state. */
 int ramses_amd_amrres_load_f(int ngrid, const int *igrid, const double *f);
+/* The acceleration of a resident run with several ranks without a visit to the host (round 6): force_fine's kernel leaves f of
+ * the rank's own cells in a device buffer d_fpack[3][8][ngrid] (octs in the order of igrid), ramses_amd_amrres_take_f_device
+ * files it into the resident f, the virtual octs follow with ramses_amd_amrres_halo_* (direction 7: make_virtual_fine_dp on
+ * f(:,1:3), /root/reference/poisson/force_fine.f90:137-139).  ramses_amd_amrres_sync_f brings f of the listed octs back into the
+ * host array for the two host readers left (backup_poisson, load_balance); ramses_amd_amrres_f_traffic reports the bytes of f
+ * that crossed PCIe since the start (out2[0] host -> device, out2[1] device -> host). */
+int ramses_amd_amrres_take_f_device(int ngrid, const int *igrid, const double *d_fpack);
+int ramses_amd_amrres_sync_f(int ngrid, const int *igrid, double *f);
+int ramses_amd_amrres_f_traffic(int64_t *out2);
+/* Diagnostic (RAMSES_AMD_F_CHECK=1 in patch/force_fine.f90): the largest |device f - host f| over the listed octs and the
+ * number of cells that differ. */
+int ramses_amd_amrres_compare_f(int ngrid, const int *igrid, const double *f, double *maxdiff, int64_t *ndiff);
 int ramses_amd_amrres_has_gravity(void);
 int ramses_amd_amrres_sync_density(int ngrid, const int *igrid, double *uold);
 int ramses_amd_amrres_synchro(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double dteff);

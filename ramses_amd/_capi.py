@@ -110,6 +110,7 @@ SYMBOLS = [
     ("ramses_amd_poisamr_levelmin_mg", _i, []),
     ("ramses_amd_poisamr_force", _i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _d, _vp]),
     ("ramses_amd_poisamr_force_mpi", _i, [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _i, _d, _vp]),
+    ("ramses_amd_poisamr_force_mpi_resident", _i, [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _d, _i, _d, _vp]),
     ("ramses_amd_prof_add", _i, [C.c_char_p, _i, _d]),
     ("ramses_amd_warmup", _i, []),
     ("ramses_amd_host_register", _i, [_vp, _i64]),
@@ -164,6 +165,7 @@ SYMBOLS = [
     ("ramses_amd_mgdist_oct_box", _i, [_i, _i, _vp, _vp, _i64, _vp, _vp]),
     ("ramses_amd_mgdist_plan", _i, [_vp, _i, _vp, _vp, _i] + [_vp] * 11),
     ("ramses_amd_mgdist_force_f90", _i, [_vp, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i, _d, _vp]),
+    ("ramses_amd_mgdist_force_resident_f90", _i, [_vp, _i, _i, _vp, _i64, _i64, _vp, _i, _d, _vp]),
     ("ramses_amd_mgdist_multigrid_f90", _i, [_vp, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _vp]),
     ("ramses_amd_halo_plan", _i, [_i, _i, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     ("ramses_amd_mpires_setup", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
@@ -196,6 +198,10 @@ SYMBOLS = [
     ("ramses_amd_amrres_upload_fine", _i, [_PP, _i, _vp, _i]),
     ("ramses_amd_amrres_courant", _i, [_PP, _i, _vp, _d, _d, _vp]),
     ("ramses_amd_amrres_load_f", _i, [_i, _vp, _vp]),
+    ("ramses_amd_amrres_take_f_device", _i, [_i, _vp, _vp]),
+    ("ramses_amd_amrres_sync_f", _i, [_i, _vp, _vp]),
+    ("ramses_amd_amrres_f_traffic", _i, [_vp]),
+    ("ramses_amd_amrres_compare_f", _i, [_i, _vp, _vp, _vp, _vp]),
     ("ramses_amd_amrres_has_gravity", _i, []),
     ("ramses_amd_amrres_sync_density", _i, [_i, _vp, _vp]),
     ("ramses_amd_amrres_synchro", _i, [_PP, _i, _vp, _d]),

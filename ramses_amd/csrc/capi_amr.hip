@@ -793,6 +793,7 @@ struct AmrRes {
   int *cur_ig = nullptr;                       // the list of the routine under way (device indices)
   std::vector<LevelPlan> plan;
   long tile_sweeps = 0, tree_sweeps = 0;
+  int64_t f_up_bytes = 0, f_down_bytes = 0;    // bytes of the acceleration that crossed PCIe (ramses_amd_amrres_f_traffic)
   long relayouts = 0;                          // regrids that had to lay the kept levels out again (tiles in the way of the finer levels)
   int err_pending = 0;                         // a tree-walking sweep has run since R.err was last read (the finest level it swept)
   bool announced = false;
@@ -930,7 +931,9 @@ extern "C" {
 static void amrres_report(void) {
   const char *e = getenv("RAMSES_AMD_STATS");
   if (!e || e[0] == '0') return;
-  if (g_ar.tile_sweeps + g_ar.tree_sweeps == 0) return;
+  if (g_ar.f_up_bytes + g_ar.f_down_bytes > 0)
+    fprintf(stdout, " ramses_amd: acceleration f over PCIe: %lld bytes to the device, %lld bytes back\n", (long long)g_ar.f_up_bytes, (long long)g_ar.f_down_bytes);
+  if (g_ar.tile_sweeps + g_ar.tree_sweeps == 0) { fflush(stdout); return; }
   fprintf(stdout, " ramses_amd: godunov_fine of AMR levels: %ld sweeps through the dense kernel on tiles (%ld of them fully refined levels), %ld through the tree-walking kernel; %ld levels in tiles at the end\n",
           g_ar.tile_sweeps, g_ar.covered_sweeps, g_ar.tree_sweeps, g_ar.map.on ? g_ar.map.tiles_levels : 0L);
   fflush(stdout);
@@ -1552,6 +1555,7 @@ int ramses_amd_amrres_load_f(int ngrid, const int *igrid, const double *f) {
     }
   HCHK(R.pack.ensure(sizeof(double) * (size_t)tot * 3), "hipMalloc");
   HCHK(hipMemcpy(R.pack.p, R.hpack.data(), sizeof(double) * (size_t)tot * 3, hipMemcpyHostToDevice), "H2D f");
+  R.f_up_bytes += (int64_t)sizeof(double) * tot * 3;
   hipLaunchKernelGGL(lvl_pack_comp_kernel<false>, dim3(grid_for(tot)), dim3(256), 0, nullptr, R.f.as<double>(), R.pack.as<double>(), R.cur_ig, ngrid, 3,
                      R.ncell, R.ncoarse, R.ngridmax);
   HCHK(hipGetLastError(), "f unpack launch");
@@ -1559,6 +1563,83 @@ int ramses_amd_amrres_load_f(int ngrid, const int *igrid, const double *f) {
   return 0;
 }
 int ramses_amd_amrres_has_gravity(void) { return g_ar.valid && g_ar.grav ? 1 : 0; }
+
+// f of a level's own cells straight from the device buffer force_fine's kernel filled (d_fpack[3][8][ngrid], the octs in the order
+// of igrid: csrc/pois_amr.hip) -- the acceleration of a resident run with several ranks never visits the host (round 6); the
+// virtual octs follow with the exchange of direction 7
+int ramses_amd_amrres_take_f_device(int ngrid, const int *igrid, const double *d_fpack) {
+  AmrRes &R = g_ar;
+  LvlArgs A;
+  if (!d_fpack) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  if (int rc = set_level(R, ngrid, igrid, A)) return rc;
+  if (!R.grav) {
+    HCHK(R.f.ensure(sizeof(double) * 3 * (size_t)R.ncell), "hipMalloc f");
+    HCHK(hipMemsetAsync(R.f.p, 0, sizeof(double) * 3 * (size_t)R.ncell, nullptr), "memset f");
+    R.grav = true;
+  }
+  if (ngrid == 0) return 0;
+  hipLaunchKernelGGL(lvl_pack_comp_kernel<false>, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, R.f.as<double>(), const_cast<double *>(d_fpack), R.cur_ig,
+                     ngrid, 3, R.ncell, R.ncoarse, R.ngridmax);
+  HCHK(hipGetLastError(), "f unpack launch");
+  return 0;
+}
+// f of the listed octs back into the host array (backup_poisson, load_balance: the only host readers of a resident run)
+int ramses_amd_amrres_sync_f(int ngrid, const int *igrid, double *f) {
+  AmrRes &R = g_ar;
+  LvlArgs A;
+  if (!f) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  if (!R.grav) return failf(RAMSES_AMD_EINVAL, "sync_f: no acceleration on the device");
+  if (int rc = set_level(R, ngrid, igrid, A)) return rc;
+  if (ngrid == 0) return 0;
+  const long tot = (long)ngrid * 8;
+  HCHK(R.pack.ensure(sizeof(double) * (size_t)tot * 3), "hipMalloc");
+  hipLaunchKernelGGL(lvl_pack_comp_kernel<true>, dim3(grid_for(tot)), dim3(256), 0, nullptr, R.f.as<double>(), R.pack.as<double>(), R.cur_ig, ngrid, 3,
+                     R.ncell, R.ncoarse, R.ngridmax);
+  HCHK(hipGetLastError(), "f pack launch");
+  R.hpack.resize((size_t)tot * 3);
+  HCHK(hipMemcpy(R.hpack.data(), R.pack.p, sizeof(double) * (size_t)tot * 3, hipMemcpyDeviceToHost), "D2H f");
+  R.f_down_bytes += (int64_t)sizeof(double) * tot * 3;
+  for (int k = 0; k < 3; k++)
+    for (int ind = 0; ind < 8; ind++) {
+      double *dst = f + (size_t)k * R.ncell_h + R.ncoarse + (size_t)ind * R.ngh - 1;
+      const double *src = R.hpack.data() + (size_t)k * tot + (size_t)ind * ngrid;
+      for (int i = 0; i < ngrid; i++) dst[igrid[i]] = src[i];
+    }
+  return 0;
+}
+// RAMSES_AMD_F_CHECK=1 (patch/force_fine.f90): the largest |device f - host f| over the listed octs, and how many cells differ
+int ramses_amd_amrres_compare_f(int ngrid, const int *igrid, const double *f, double *maxdiff, int64_t *ndiff) {
+  AmrRes &R = g_ar;
+  LvlArgs A;
+  if (!f || !maxdiff || !ndiff) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  *maxdiff = 0.0; *ndiff = 0;
+  if (!R.grav) return failf(RAMSES_AMD_EINVAL, "compare_f: no acceleration on the device");
+  if (int rc = set_level(R, ngrid, igrid, A)) return rc;
+  if (ngrid == 0) return 0;
+  const long tot = (long)ngrid * 8;
+  HCHK(R.pack.ensure(sizeof(double) * (size_t)tot * 3), "hipMalloc");
+  hipLaunchKernelGGL(lvl_pack_comp_kernel<true>, dim3(grid_for(tot)), dim3(256), 0, nullptr, R.f.as<double>(), R.pack.as<double>(), R.cur_ig, ngrid, 3,
+                     R.ncell, R.ncoarse, R.ngridmax);
+  HCHK(hipGetLastError(), "f pack launch");
+  std::vector<double> h((size_t)tot * 3);
+  HCHK(hipMemcpy(h.data(), R.pack.p, sizeof(double) * (size_t)tot * 3, hipMemcpyDeviceToHost), "D2H f");
+  for (int k = 0; k < 3; k++)
+    for (int ind = 0; ind < 8; ind++) {
+      const double *ref = f + (size_t)k * R.ncell_h + R.ncoarse + (size_t)ind * R.ngh - 1;
+      const double *dev = h.data() + (size_t)k * tot + (size_t)ind * ngrid;
+      for (int i = 0; i < ngrid; i++) {
+        const double d = std::fabs(dev[i] - ref[igrid[i]]);
+        if (d > 0.0 || dev[i] != ref[igrid[i]]) { (*ndiff)++; if (d > *maxdiff) *maxdiff = d; }
+      }
+    }
+  return 0;
+}
+// bytes of f that crossed PCIe since the start: out[0] host -> device (ramses_amd_amrres_load_f), out[1] device -> host
+int ramses_amd_amrres_f_traffic(int64_t *out2) {
+  if (!out2) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  out2[0] = g_ar.f_up_bytes; out2[1] = g_ar.f_down_bytes;
+  return 0;
+}
 
 // the oct centres xg(1:ngridmax,1:3) (after refine_fine, with the tree): what rho_fine's deposit needs beyond the tree
 int ramses_amd_amrres_xg(const double *xg) {
@@ -1874,6 +1955,7 @@ int comm_of(AmrRes &R, int ilevel, CommLevel *&L) {
 }
 // dir 0: make_virtual_fine_dp on uold(:,1:nvar); 1: make_virtual_reverse_dp on unew(:,1:nvar); 2 / 3: the same on enew / divu;
 // rho_fine with several ranks: 4 make_virtual_reverse_dp(rho), 5 make_virtual_fine_dp(rho), 6 make_virtual_fine_dp on the multipoles
+// force_fine with several ranks: 7 make_virtual_fine_dp on f(:,1:3) (poisson/force_fine.f90:137-139), one exchange for the three
 struct HaloSpec { double *vec; int ncomp; bool reverse; };
 int halo_spec(AmrRes &R, int dir, HaloSpec &S) {
   switch (dir) {
@@ -1882,6 +1964,9 @@ int halo_spec(AmrRes &R, int dir, HaloSpec &S) {
     case 2: case 3:
       if (!R.pfix) return failf(RAMSES_AMD_EINVAL, "halo on enew/divu: pressure_fix is not enabled");
       S = {dir == 2 ? R.enew.as<double>() : R.divu.as<double>(), 1, true}; return 0;
+    case 7:
+      if (!R.grav) return failf(RAMSES_AMD_EINVAL, "halo on f: no acceleration on the device");
+      S = {R.f.as<double>(), 3, false}; return 0;
     case 4: case 5: case 6:
       if (!R.rho.p || !R.mp.p) return failf(RAMSES_AMD_EINVAL, "halo on rho / the multipoles: rho_fine has not run on the device");
       if (dir == 6) S = {R.mp.as<double>(), 4, false};

@@ -793,4 +793,70 @@ int ramses_amd_mgdist_force_f90(ramses_amd_mgdist *M, int ilevel, int ngrid, con
   return 0;
 }
 
+
+// The same for a run whose cell vectors are resident (ramses_amd_amrres_*), on a level without finer octs (every cell a leaf:
+// a uniform self-gravitating run): f goes from the brick into the resident acceleration ON THE DEVICE -- gathered into the
+// packed order [3][8][ngrid] through the order list of the solve (ramses_amd_mgdist_set_order: octant by octant over igrid) and
+// filed by ramses_amd_amrres_take_f_device -- and the potential-energy sum runs there too, term by term in the reference's
+// order (batches of nvector octs, octant by octant, direction by direction: poisson/force_fine.f90:150-176) through the
+// order-exact device sum.  max |rho| is read off the host's rho (no transfer).  Nothing of f crosses PCIe; the caller
+// exchanges the virtual octs on the device (ramses_amd_amrres_halo_*, direction 7).
+extern "C" int ramses_amd_amrres_take_f_device(int ngrid, const int *igrid, const double *d_fpack);
+namespace {
+__global__ __launch_bounds__(256) void mgdist_f_pack_kernel(const double *__restrict__ fb, const int *__restrict__ order, long N, double *__restrict__ fp) {
+  const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < N) {
+    const long c = order[k];
+#pragma unroll
+    for (int d = 0; d < 3; d++) fp[(long)d * N + k] = fb[(long)d * N + c];
+  }
+}
+// term t of the reference's loop: batch c of nvector octs, octant ind, direction d, oct i of the batch
+__global__ __launch_bounds__(256) void mgdist_epot_terms_kernel(const double *__restrict__ fp, long ngrid, int nvector, double fact, double *__restrict__ x) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long N = 8 * ngrid;
+  if (t >= 3 * N) return;
+  const long c = t / (24L * nvector);
+  const long g0 = c * nvector;
+  const int nb = (int)(ngrid - g0 < nvector ? ngrid - g0 : nvector);
+  const long r = t - c * 24L * nvector;
+  const int ind = (int)(r / (3L * nb)), d = (int)((r / nb) % 3), i = (int)(r % nb);
+  const double v = fp[(long)d * N + (long)ind * ngrid + g0 + i];
+  x[t] = fact * (v * v);
+}
+}  // namespace
+int ramses_amd_mgdist_force_resident_f90(ramses_amd_mgdist *M, int ilevel, int ngrid, const int *igrid, int64_t ngridmax, int64_t ncoarse,
+                                         const double *rho, int nvector, double fact, double *diag) {
+  if (!M || !igrid || !rho || !diag || nvector < 1) return failf(RAMSES_AMD_EINVAL, "bad argument");
+  if (ilevel != M->level) return failf(RAMSES_AMD_EINVAL, "context built for level %d, called for level %d", M->level, ilevel);
+  if (!M->phi_fresh) return failf(RAMSES_AMD_EINVAL, "force_fine: the context holds no potential (ramses_amd_mgdist_multigrid_f90 first)");
+  const long N = (long)M->dims[0] * M->dims[1] * M->dims[2];
+  if ((long)ngrid * 8 != N) return failf(RAMSES_AMD_EINVAL, "the rank holds %d octs, its brick %ld cells", ngrid, N);
+  if (M->order_n != N || !M->d_order) return failf(RAMSES_AMD_EINVAL, "force_fine (resident): the solve left no oct order (ramses_amd_mgdist_set_order)");
+  hipStream_t s = nullptr;
+  static DevArr d_f, d_fp, d_x, d_scr, d_out;
+  HCHK(d_f.ensure(sizeof(double) * 3 * N), "hipMalloc"); HCHK(d_fp.ensure(sizeof(double) * 3 * N), "hipMalloc");
+  HCHK(d_x.ensure(sizeof(double) * 3 * N), "hipMalloc"); HCHK(d_scr.ensure(ramses_amd_ordered_sum_scratch(3 * N)), "hipMalloc");
+  HCHK(d_out.ensure(sizeof(double)), "hipMalloc");
+  RCHK(ramses_amd_mgdist_force(M, reinterpret_cast<double *>(d_f.p), s));
+  const dim3 b(256);
+  hipLaunchKernelGGL(mgdist_f_pack_kernel, dim3((unsigned)((N + 255) / 256)), b, 0, s, reinterpret_cast<const double *>(d_f.p), M->d_order, N, reinterpret_cast<double *>(d_fp.p));
+  hipLaunchKernelGGL(mgdist_epot_terms_kernel, dim3((unsigned)((3 * N + 255) / 256)), b, 0, s, reinterpret_cast<const double *>(d_fp.p), (long)ngrid, nvector, fact,
+                     reinterpret_cast<double *>(d_x.p));
+  HCHK(hipGetLastError(), "force_fine (resident) launch");
+  RCHK(ramses_amd_ordered_sum_device(reinterpret_cast<const double *>(d_x.p), 3 * N, reinterpret_cast<double *>(d_out.p), d_scr.p, s));
+  RCHK(ramses_amd_amrres_take_f_device(ngrid, igrid, reinterpret_cast<const double *>(d_fp.p)));
+  double epot = 0.0;
+  HCHK(hipMemcpyAsync(&epot, d_out.p, sizeof(double), hipMemcpyDeviceToHost, s), "D2H epot");
+  double rmax = 0.0;
+  for (int ind = 0; ind < 8; ind++) {
+    const double *r = rho + ncoarse + (long)ind * ngridmax - 1;
+    for (int g = 0; g < ngrid; g++) rmax = std::max(rmax, std::fabs(r[igrid[g]]));
+  }
+  HCHK(hipStreamSynchronize(s), "sync");
+  diag[0] = epot;
+  diag[1] = rmax;
+  return 0;
+}
+
 }  // extern "C"

@@ -183,7 +183,16 @@ __global__ __launch_bounds__(128) void mhd_trace_kernel(MhdArgs A) {
 // the left-face fields: 108 KB), forms the edge fields of the 33 x 5 x 5 edges the tile's traces read (20 KB), and every thread
 // traces its cell from LDS.  What reaches HBM is what the flux and EMF kernels need: the 47 predicted numbers per cell.  The
 // same functions on the same values as the three kernels (which stay for the A/B: RAMSES_AMD_MHD_FUSED=0).
-constexpr int FT_X = 32, FT_Y = 4, FT_Z = 4;
+// (tile shapes measured at 256^3, round 6, ms per sweep: 32x4x4 8.89, 16x4x4 9.13, 16x8x4 9.12, 16x4x8 9.23, 32x4x2 10.43;
+//  profiles/r06_mhd_pmc.txt)
+#ifndef MHD_FT
+#define MHD_FT 32, 4, 4
+#endif
+constexpr int FT_DIMS[3] = {MHD_FT};
+constexpr int FT_X = FT_DIMS[0], FT_Y = FT_DIMS[1], FT_Z = FT_DIMS[2];
+#ifndef MHD_BATCH_LOADS
+#define MHD_BATCH_LOADS 1
+#endif
 struct FusedLds {
   double Q[8][FT_Z + 2][FT_Y + 2][FT_X + 2];
   double BF[3][FT_Z + 2][FT_Y + 2][FT_X + 2];
@@ -207,7 +216,39 @@ __global__ __launch_bounds__(FT_X * FT_Y * FT_Z) void mhd_prim_trace_kernel(MhdA
   const long N = A.ncell;
   // ---- 1. ctoprim of the tile and one cell around it
   constexpr int HX = FT_X + 2, HY = FT_Y + 2, HZ = FT_Z + 2;
-  for (int t = tid; t < HX * HY * HZ; t += FT_X * FT_Y * FT_Z) {
+  // (all the loads of the thread's two or three cells are issued before the first conversion: one block of eight wavefronts
+  //  owns the CU, nothing else hides the latency of this phase)
+  constexpr int NT = FT_X * FT_Y * FT_Z, NIT = (HX * HY * HZ + NT - 1) / NT;
+#if MHD_BATCH_LOADS
+  {
+    double w[NIT][NF];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int t = min(tid + it * NT, HX * HY * HZ - 1);
+      const int li = t % HX, lj = (t / HX) % HY, lk = t / (HX * HY);
+      const long c = wrapn(ox + li - 1, A.nx) + (long)A.nx * (wrapn(oy + lj - 1, A.ny) + (long)A.ny * wrapn(oz + lk - 1, A.nz));
+#pragma unroll
+      for (int n = 0; n < NF; n++) w[it][n] = A.uold[(long)n * N + c];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int t = tid + it * NT;
+      if (t < HX * HY * HZ) {
+        const int li = t % HX, lj = (t / HX) % HY, lk = t / (HX * HY);
+        const double u[5] = {w[it][0], w[it][1], w[it][2], w[it][3], w[it][4]};
+        const double bl[3] = {w[it][5], w[it][6], w[it][7]};
+        const double br[3] = {w[it][8], w[it][9], w[it][10]};
+        double q[8];
+        ctoprim_cell(u, bl, br, nullptr, A.dt, A.P, q);
+#pragma unroll
+        for (int n = 0; n < 8; n++) L.Q[n][lk][lj][li] = q[n];
+#pragma unroll
+        for (int n = 0; n < 3; n++) L.BF[n][lk][lj][li] = bl[n];
+      }
+    }
+  }
+#else
+  for (int t = tid; t < HX * HY * HZ; t += NT) {
     const int li = t % HX, lj = (t / HX) % HY, lk = t / (HX * HY);
     const long c = wrapn(ox + li - 1, A.nx) + (long)A.nx * (wrapn(oy + lj - 1, A.ny) + (long)A.ny * wrapn(oz + lk - 1, A.nz));
     const double u[5] = {A.uold[c], A.uold[N + c], A.uold[2 * N + c], A.uold[3 * N + c], A.uold[4 * N + c]};
@@ -220,6 +261,7 @@ __global__ __launch_bounds__(FT_X * FT_Y * FT_Z) void mhd_prim_trace_kernel(MhdA
 #pragma unroll
     for (int n = 0; n < 3; n++) L.BF[n][lk][lj][li] = bl[n];
   }
+#endif
   __syncthreads();
   const TileAcc a{&L, ox, oy, oz};
   // ---- 2. the edge fields on the low edges of the cells (ox .. ox+FT_X) x (oy .. oy+FT_Y) x (oz .. oz+FT_Z)
@@ -488,6 +530,8 @@ int ramses_amd_mhd_godunov_brick(const ramses_amd_mhd_params *p, int nx, int ny,
   // eigenmatrices would otherwise cost every solver its registers.  (One instance per solver was measured too: fewer
   // registers -- hlld: flux 136 instead of 156, EMF 188 instead of 214 -- but 10.95 instead of 10.08 ms per sweep at 256^3.)
   const dim3 g128(remap_grid(128)), b128(128);
+  // (fluxes and EMFs in ONE launch -- the predicted numbers read once -- was measured in round 6: 256 VGPRs + 44 B of scratch at two
+  //  waves per SIMD, 9.33 against 8.89 ms; the EMF kernel compiled for three waves per SIMD: 124 B of scratch, 9.83 ms)
   if (A.P.riemann == RIEMANN_ROE) hipLaunchKernelGGL(mhd_flux_kernel<RIEMANN_ROE>, g128, b128, 0, s, A);
   else hipLaunchKernelGGL(mhd_flux_kernel<-2>, g128, b128, 0, s, A);
   // (one launch per edge direction -- 164 VGPRs and three waves per SIMD instead of 212 and two -- was measured: 9.00 against 8.87 ms)

@@ -666,6 +666,23 @@ int ramses_amd_poisamr_force_mpi(int ilevel, int ngrid_own, int ngrid_all, const
   if (ngrid_own == 0) { if (diag) { diag[0] = 0.0; diag[1] = 0.0; } return 0; }
   return poisamr_force_impl(ilevel, ngrid_own, ngrid_all, igrid_all, ngrid_c_all, igrid_c_all, phi, phi_old, rho, f, tfrac, interp, 0, fact, diag);
 }
+// The same for a run whose cell vectors are resident (ramses_amd_amrres_*): f of the rank's own cells goes from the kernel's
+// buffer into the resident acceleration on the device (ramses_amd_amrres_take_f_device) and nowhere else; the caller exchanges
+// the virtual octs there (ramses_amd_amrres_halo_*, direction 7) instead of the reference's three host exchanges
+// (poisson/force_fine.f90:137-139).
+extern "C" int ramses_amd_amrres_take_f_device(int ngrid, const int *igrid, const double *d_fpack);
+static bool g_force_to_resident = false;
+int ramses_amd_poisamr_force_mpi_resident(int ilevel, int ngrid_own, int ngrid_all, const int *igrid_all, int ngrid_c_all, const int *igrid_c_all,
+                                          const double *phi, const double *phi_old, const double *rho, double tfrac, int interp, double fact,
+                                          double *diag) {
+  if (ngrid_own < 0 || ngrid_own > ngrid_all) return failf(RAMSES_AMD_EINVAL, "poisamr_force_mpi: bad own / total oct counts");
+  if (ngrid_own == 0) { if (diag) { diag[0] = 0.0; diag[1] = 0.0; } return 0; }
+  g_force_to_resident = true;
+  double dummy = 0.0;
+  const int rc = poisamr_force_impl(ilevel, ngrid_own, ngrid_all, igrid_all, ngrid_c_all, igrid_c_all, phi, phi_old, rho, &dummy, tfrac, interp, 0, fact, diag);
+  g_force_to_resident = false;
+  return rc;
+}
 static int poisamr_force_impl(int ilevel, int ngrid_own, int ngrid, const int *igrid, int ngrid_c, const int *igrid_c, const double *phi,
                               const double *phi_old, const double *rho, double *f, double tfrac, int interp, int fresh, double fact,
                               double *diag) {
@@ -728,6 +745,12 @@ static int poisamr_force_impl(int ilevel, int ngrid_own, int ngrid, const int *i
   // diagnostics over the level's cells (rho packed from the device vector)
   hipLaunchKernelGGL(vec_gather_kernel, dim3(grid_for(nfo)), dim3(256), 0, s, P.rho.as<double>(), P.pack.as<double>(), F.igrid.as<int>(), ngrid_own, ncoarse, ngridmax);
   HCHK(launch_force_diag(P.fpack.as<double>(), P.pack.as<double>(), P.leaf.as<int>(), nfo, fact, P.diag.as<double>() + 2, P.diag.as<double>(), s), "diag launch");
+  if (g_force_to_resident) {
+    HCHK(hipMemcpyAsync(diag, P.diag.p, sizeof(double) * 2, hipMemcpyDeviceToHost, s), "D2H diag");
+    if (int rc = ramses_amd_amrres_take_f_device(ngrid_own, igrid, P.fpack.as<double>())) return rc;    // (same stream: ordered behind the force kernel)
+    HCHK(hipStreamSynchronize(s), "sync");
+    return 0;
+  }
   hipLaunchKernelGGL(vec3_scatter_kernel, dim3(grid_for(nfo)), dim3(256), 0, s, P.f.as<double>(), P.fpack.as<double>(), F.igrid.as<int>(), ngrid_own, ncoarse, ngridmax, P.ncell);
   HCHK(hipMemcpyAsync(hs, P.fpack.p, sizeof(double) * 3 * (size_t)nfo, hipMemcpyDeviceToHost, s), "D2H f");
   HCHK(hipMemcpyAsync(diag, P.diag.p, sizeof(double) * 2, hipMemcpyDeviceToHost, s), "D2H diag");

@@ -144,7 +144,11 @@ subroutine ramses_amd_force_fine_mpi(ilevel,icount)
   integer,allocatable,dimension(:)::list,listc
   real(dp)::dx,dx_loc,scale,fact,fourpi,tfrac
   real(kind=8),dimension(2)::diag
-  real(kind=8)::epot_loc,epot_all,rho_loc,rho_all
+  real(kind=8)::epot_loc,epot_all,rho_loc,rho_all,dmax
+  real(kind=8),dimension(2)::diag2
+  integer(8)::nbad
+  character(len=16)::val
+  integer::stat
   nx_loc=(icoarse_max-icoarse_min+1)
   ! a regrid or a load balance since the tree went to the device: ramses_amd_tree_epoch has moved
   rc=ramses_amd_poisamr_tree(ramses_amd_tree_epoch,int(ngridmax,8),int(ncoarse,8),son,nbor,father)
@@ -164,12 +168,37 @@ subroutine ramses_amd_force_fine_mpi(ilevel,icount)
   call ramses_amd_amr_level_octs(ilevel,nl,list)
   call ramses_amd_amr_level_octs(ilevel-1,nlc,listc)
   diag=0d0
-  rc=ramses_amd_poisamr_force_mpi(ilevel,active(ilevel)%ngrid,nl,list,nlc,listc,phi,phi_old,rho,f,tfrac,1,fact,diag)
-  if(rc/=0)call ramses_amd_fatal('force_fine (MPI, AMR level)')
-  deallocate(list,listc)
-  do idim=1,ndim
-     call make_virtual_fine_dp(f(1,idim),ilevel)
-  end do
+  if(ramses_amd_amrres_active()/=0.and.ramses_amd_f_resident_on())then
+     ! the hydro state is resident: f of the own cells goes from the kernel's buffer into the resident acceleration, the
+     ! virtual octs follow with ONE exchange of the device arrays (the reference's three, poisson/force_fine.f90:137-139);
+     ! the host array f is not written (backup_poisson and load_balance fetch it: ramses_amd_amr_sync_f)
+     call ramses_amd_amr_ensure()      ! (a level the host rebuilt since the last device routine goes up first, its stale f with it)
+     rc=ramses_amd_poisamr_force_mpi_resident(ilevel,active(ilevel)%ngrid,nl,list,nlc,listc,phi,phi_old,rho,tfrac,1,fact,diag)
+     if(rc/=0)call ramses_amd_fatal('force_fine (MPI, AMR level, resident f)')
+     call ramses_amd_amr_halo(ilevel,7)
+     ramses_amd_f_on_device(ilevel)=.true.
+     call get_environment_variable('RAMSES_AMD_F_CHECK',val,status=stat)
+     if(stat==0.and.trim(val)=='1')then
+        ! diagnostic: the path through the host array beside it, cell by cell (own and virtual octs)
+        rc=ramses_amd_poisamr_force_mpi(ilevel,active(ilevel)%ngrid,nl,list,nlc,listc,phi,phi_old,rho,f,tfrac,1,fact,diag2)
+        if(rc/=0)call ramses_amd_fatal('force_fine (MPI, AMR level, check)')
+        do idim=1,ndim
+           call make_virtual_fine_dp(f(1,idim),ilevel)
+        end do
+        rc=ramses_amd_amrres_compare_f(nl,list,f,dmax,nbad)
+        if(rc/=0)call ramses_amd_fatal('force_fine (MPI, AMR level, compare)')
+        write(*,'(A,I3,A,I3,A,I10,A,ES12.4,A,I8,A,I8)')' ramses_amd: f check, level ',ilevel,' rank ',myid,': ',nbad, &
+             & ' cells differ, max ',dmax,' own octs ',active(ilevel)%ngrid,' all ',nl
+     end if
+     deallocate(list,listc)
+  else
+     rc=ramses_amd_poisamr_force_mpi(ilevel,active(ilevel)%ngrid,nl,list,nlc,listc,phi,phi_old,rho,f,tfrac,1,fact,diag)
+     if(rc/=0)call ramses_amd_fatal('force_fine (MPI, AMR level)')
+     deallocate(list,listc)
+     do idim=1,ndim
+        call make_virtual_fine_dp(f(1,idim),ilevel)
+     end do
+  end if
   epot_loc=diag(1); rho_loc=diag(2)
   call MPI_ALLREDUCE(epot_loc,epot_all,1,MPI_DOUBLE_PRECISION,MPI_SUM,MPI_COMM_WORLD,info)
   call MPI_ALLREDUCE(rho_loc ,rho_all ,1,MPI_DOUBLE_PRECISION,MPI_MAX,MPI_COMM_WORLD,info)
@@ -185,10 +214,14 @@ subroutine force_fine(ilevel,icount)
   integer::ilevel,icount
   integer(8)::t0
   call ramses_amd_tic(t0)
+  if(ilevel>=1.and.ilevel<=64)ramses_amd_f_on_device(ilevel)=.false.
   call force_fine_amd(ilevel,icount)
-  ! AMR run with the hydro state on the device: its copy of the acceleration follows
+  ! AMR run with the hydro state on the device: its copy of the acceleration follows (unless force_fine has just left f
+  ! there and nowhere else: ramses_amd_force_fine_mpi)
   if(ramses_amd_amr_resident())then
-     if(ramses_amd_amrres_active()/=0.and.numbtot(1,ilevel)>0)call ramses_amd_amr_load_f(ilevel)
+     if(ramses_amd_amrres_active()/=0.and.numbtot(1,ilevel)>0)then
+        if(.not.ramses_amd_f_on_device(min(max(ilevel,1),64)))call ramses_amd_amr_load_f(ilevel)
+     end if
   end if
   call ramses_amd_toc('force_fine',ilevel,t0)
 end subroutine force_fine

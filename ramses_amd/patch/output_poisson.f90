@@ -21,6 +21,8 @@ subroutine backup_poisson(filename)
   if(ramses_amd_enabled())then
      rc=ramses_amd_resident_sync_poisson_f90(phi,f,rho)
      if(rc/=0)call ramses_amd_fatal('backup_poisson (sync of the resident level)')
+     ! the acceleration of the levels force_fine left on the device only (several ranks: patch/force_fine.f90)
+     if(ramses_amd_amr_resident())call ramses_amd_amr_sync_f()
   end if
   call backup_poisson_reference(filename)
 end subroutine backup_poisson

@@ -90,6 +90,18 @@ module ramses_amd_cabi
        real(c_double) :: diag(2)
        integer(c_int) :: rc
      end function ramses_amd_mgdist_force_f90
+     function ramses_amd_mgdist_force_resident_f90(ctx, ilevel, ngrid, igrid, ngridmax, ncoarse, rho, nvec, fact, diag) &
+          & bind(C, name='ramses_amd_mgdist_force_resident_f90') result(rc)
+       import :: c_int, c_int64_t, c_double, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: ilevel, ngrid, nvec
+       integer(c_int) :: igrid(*)
+       real(c_double) :: rho(*)
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       real(c_double), value :: fact
+       real(c_double) :: diag(2)
+       integer(c_int) :: rc
+     end function ramses_amd_mgdist_force_resident_f90
 
      function ramses_amd_abi_check(sz_params, sz_brick) bind(C, name='ramses_amd_abi_check') result(rc)
        import :: c_size_t, c_int
@@ -429,6 +441,15 @@ module ramses_amd_cabi
        real(c_double), value :: tfrac, fact
        integer(c_int) :: rc
      end function ramses_amd_poisamr_force_mpi
+     function ramses_amd_poisamr_force_mpi_resident(ilevel, ngrid_own, ngrid_all, igrid_all, ngrid_c_all, igrid_c_all, phi, phi_old, &
+          & rho, tfrac, interp, fact, diag) bind(C, name='ramses_amd_poisamr_force_mpi_resident') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: ilevel, ngrid_own, ngrid_all, ngrid_c_all, interp
+       integer(c_int) :: igrid_all(*), igrid_c_all(*)
+       real(c_double) :: phi(*), phi_old(*), rho(*), diag(2)
+       real(c_double), value :: tfrac, fact
+       integer(c_int) :: rc
+     end function ramses_amd_poisamr_force_mpi_resident
      function ramses_amd_prof_add(name, level, seconds) bind(C, name='ramses_amd_prof_add') result(rc)
        import :: c_int, c_double, c_char
        character(kind=c_char) :: name(*)
@@ -718,6 +739,27 @@ module ramses_amd_cabi
        real(c_double) :: f(*)
        integer(c_int) :: rc
      end function ramses_amd_amrres_load_f
+     function ramses_amd_amrres_sync_f(ngrid, igrid, f) bind(C, name='ramses_amd_amrres_sync_f') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: f(*)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_sync_f
+     function ramses_amd_amrres_compare_f(ngrid, igrid, f, maxdiff, ndiff) bind(C, name='ramses_amd_amrres_compare_f') result(rc)
+       import :: c_int, c_double, c_int64_t
+       integer(c_int), value :: ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: f(*)
+       real(c_double) :: maxdiff
+       integer(c_int64_t) :: ndiff
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_compare_f
+     function ramses_amd_amrres_f_traffic(out2) bind(C, name='ramses_amd_amrres_f_traffic') result(rc)
+       import :: c_int, c_int64_t
+       integer(c_int64_t) :: out2(2)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_f_traffic
      function ramses_amd_amrres_sync_density(ngrid, igrid, uold) bind(C, name='ramses_amd_amrres_sync_density') result(rc)
        import :: c_int, c_double
        integer(c_int), value :: ngrid

@@ -44,6 +44,8 @@ module ramses_amd_iface
   ! AMR residency with several MPI ranks: count of build_comm calls per level (the device copy of a level's
   ! communicators is re-sent when its epoch is behind); the transport has been chosen (ramses_amd_halo_init)
   integer, save :: ramses_amd_comm_epoch(1:64) = 1
+  ! levels whose acceleration force_fine left on the device only (several ranks, resident cell vectors: patch/force_fine.f90)
+  logical, save :: ramses_amd_f_on_device(1:64) = .false.
   logical, save :: ramses_amd_amr_halo_ready = .false.
   ! the AMR level whose potential the device multigrid driver has just left on the device (0: none)
   integer, save :: ramses_amd_pois_amr_level = 0
@@ -702,6 +704,54 @@ contains
     ramses_amd_force_mpi_on = on
   end function ramses_amd_force_mpi_on
 
+  ! RAMSES_AMD_F_RESIDENT=0: force_fine of AMR levels with several ranks returns f to the host array and the device copy is
+  ! refreshed from there (the path before round 6)
+  logical function ramses_amd_f_resident_on()
+    character(len=16) :: val
+    integer :: stat
+    logical, save :: first = .true., on = .true.
+    if (first) then
+       call get_environment_variable('RAMSES_AMD_F_RESIDENT', val, status=stat)
+       if (stat == 0) then
+          if (trim(val) == '0') on = .false.
+       end if
+       first = .false.
+    end if
+    ramses_amd_f_resident_on = on
+  end function ramses_amd_f_resident_on
+
+  ! f of the levels whose acceleration lives on the device only, back into the host array (backup_poisson, load_balance;
+  ! one level: refine_fine, whose new octs inherit their father cell's f)
+  subroutine ramses_amd_amr_sync_f()
+    use amr_commons
+    integer :: l
+    if (.not. poisson) return
+    if (ramses_amd_amrres_active() == 0) return
+    do l = 1, min(nlevelmax, 64)
+       if (ramses_amd_f_on_device(l)) call ramses_amd_amr_sync_f_level(l)
+    end do
+  end subroutine ramses_amd_amr_sync_f
+
+  subroutine ramses_amd_amr_sync_f_level(l)
+    use amr_commons
+    use poisson_commons, only: f
+    integer, intent(in) :: l
+    integer :: rc, nl
+    integer, allocatable :: list(:)
+    if (ramses_amd_amrres_active() == 0) return
+    if (numbtot(1, l) > 0) then
+       if (ncpu > 1 .or. nboundary > 0) then
+          call ramses_amd_amr_level_octs(l, nl, list)
+          rc = ramses_amd_amrres_sync_f(nl, list, f)
+          deallocate(list)
+       else
+          rc = ramses_amd_amrres_sync_f(active(l)%ngrid, ramses_amd_octs(l), f)
+       end if
+       if (rc /= 0) call ramses_amd_fatal('AMR residency (acceleration back to the host)')
+    end if
+    ramses_amd_f_on_device(l) = .false.
+  end subroutine ramses_amd_amr_sync_f_level
+
   logical function ramses_amd_amr_resident()
     ramses_amd_amr_resident = .false.
     if (ramses_amd_amr_armed) ramses_amd_amr_resident = ramses_amd_amr_config()
@@ -806,6 +856,11 @@ contains
           if (rc /= 0) call ramses_amd_fatal('AMR residency (level sync before refine_fine)')
        end if
     end do
+    ! make_grid_fine gives every new oct the acceleration of its father cell (amr/refine_utils.f90:918-927): f of level ilevel
+    ! comes back if force_fine left it on the device only
+    if (poisson .and. ilevel <= 64) then
+       if (ramses_amd_f_on_device(ilevel)) call ramses_amd_amr_sync_f_level(ilevel)
+    end if
     ramses_amd_amr_host_from = min(ramses_amd_amr_host_from, max(ilevel - 1, levelmin))
     ramses_amd_amr_reload_from = min(ramses_amd_amr_reload_from, ilevel + 1)      ! refine_fine(ilevel) rebuilds level ilevel+1
   end subroutine ramses_amd_amr_refine_hook
@@ -832,6 +887,7 @@ contains
           if (rc /= 0) call ramses_amd_fatal('AMR residency (level sync before '//where//')')
        end if
     end do
+    call ramses_amd_amr_sync_f()
     rc = ramses_amd_amrres_invalidate()
     if (rc /= 0) call ramses_amd_fatal('AMR residency (invalidate before '//where//')')
     ramses_amd_amr_reload_from = 1000
@@ -1470,6 +1526,7 @@ contains
     integer :: rc, info, idim, nx_loc
     real(dp) :: dx, scale, dx_loc, fourpi, fact
     real(kind=8) :: diag(2), epot_all, rho_all
+    logical :: resident_f
     nx_loc = icoarse_max - icoarse_min + 1
     dx = 0.5D0**ilevel
     scale = boxlen/dble(nx_loc)
@@ -1477,12 +1534,31 @@ contains
     fourpi = 2*twopi
     if (cosmo) fourpi = 1.5D0*omega_m*aexp
     fact = -dx_loc**ndim/fourpi/2.0D0
-    rc = ramses_amd_mgdist_force_f90(ramses_amd_mgdist_ctx, ilevel, active(ilevel)%ngrid, ramses_amd_octs(ilevel), xg, &
-         & int(ngridmax, 8), int(ncoarse, 8), ramses_amd_mgdist_lo, f, rho, son, nvector, fact, diag)
-    if (rc /= 0) call ramses_amd_fatal('force_fine (distributed dense multigrid)')
-    do idim = 1, ndim
-       call make_virtual_fine_dp(f(1, idim), ilevel)
-    end do
+    resident_f = .false.
+    if (ramses_amd_amr_resident() .and. ramses_amd_f_resident_on() .and. ilevel >= 1 .and. ilevel <= 64) then
+       ! the cell vectors are resident and the level has no finer octs (a uniform run): f goes from the brick into the resident
+       ! acceleration on the device, the energy sum runs there in the reference's order, the virtual octs follow with one
+       ! exchange of the device arrays -- nothing of f crosses PCIe (the host array is fetched by backup_poisson)
+       resident_f = ramses_amd_amrres_active() /= 0
+       if (ilevel < nlevelmax) then
+          if (numbtot(1, ilevel + 1) > 0) resident_f = .false.
+       end if
+    end if
+    if (resident_f) then
+       call ramses_amd_amr_ensure()
+       rc = ramses_amd_mgdist_force_resident_f90(ramses_amd_mgdist_ctx, ilevel, active(ilevel)%ngrid, ramses_amd_octs(ilevel), &
+            & int(ngridmax, 8), int(ncoarse, 8), rho, nvector, fact, diag)
+       if (rc /= 0) call ramses_amd_fatal('force_fine (distributed dense multigrid, resident f)')
+       call ramses_amd_amr_halo(ilevel, 7)
+       ramses_amd_f_on_device(ilevel) = .true.
+    else
+       rc = ramses_amd_mgdist_force_f90(ramses_amd_mgdist_ctx, ilevel, active(ilevel)%ngrid, ramses_amd_octs(ilevel), xg, &
+            & int(ngridmax, 8), int(ncoarse, 8), ramses_amd_mgdist_lo, f, rho, son, nvector, fact, diag)
+       if (rc /= 0) call ramses_amd_fatal('force_fine (distributed dense multigrid)')
+       do idim = 1, ndim
+          call make_virtual_fine_dp(f(1, idim), ilevel)
+       end do
+    end if
     call MPI_ALLREDUCE(diag(1), epot_all, 1, MPI_DOUBLE_PRECISION, MPI_SUM, MPI_COMM_WORLD, info)
     call MPI_ALLREDUCE(diag(2), rho_all, 1, MPI_DOUBLE_PRECISION, MPI_MAX, MPI_COMM_WORLD, info)
     epot_tot = epot_tot + epot_all

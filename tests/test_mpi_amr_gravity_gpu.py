@@ -94,6 +94,46 @@ def test_amr_multigrid_under_mpi_equals_the_mpi_reference(gpu_lib, nproc, reside
     assert np.array_equal(got[2], ref[2]), np.abs(got[2] - ref[2]).max()     # hydro state
 
 
+def test_force_fine_under_mpi_leaves_the_acceleration_on_the_device(gpu_lib):
+    """Round 6 (the f half): force_fine of the AMR levels of a resident run with several ranks files f
+    of the rank's own cells into the resident acceleration on the device and exchanges the virtual octs there
+    (ramses_amd_poisamr_force_mpi_resident + ramses_amd_amrres_halo_* direction 7); the host array sees f again only in
+    backup_poisson.  Counters of the library's exit line: what still goes up is the first load and the levels a regrid
+    rebuilt; RAMSES_AMD_F_RESIDENT=0 (f back to the host, the reference's three exchanges, the whole level up again) moves
+    several times that.  Both equal the MPI reference bit for bit."""
+    if not (os.path.exists(REF_MPI) and os.path.exists(PATCHED_MPI)):
+        pytest.skip("oracle/_ref/ramses3d_mpi[_patch] not built")
+    from oracle import ramses_snapshot as rs
+    nproc = 2
+    nml = _mka().selfgrav_namelist().replace("ngridtot=6000 !", "ngridtot=60000 !")
+    pat = r"acceleration f over PCIe:\s*(\d+) bytes to the device,\s*(\d+) bytes back"
+    res = {}
+    for mode in ("1", "0"):
+        work, out = _run(nml, PATCHED_MPI, nproc, {"RAMSES_AMD": "1", "RAMSES_AMD_STATS": "1", "RAMSES_AMD_F_RESIDENT": mode})
+        try:
+            assert "AMR levels stay resident on the GPU" in out, out[-1500:]
+            traffic = [[int(a), int(b)] for a, b in re.findall(pat, out)]
+            assert len(traffic) == nproc, out[-2000:]
+            res[mode] = (traffic, _sorted(rs.load_leaf_cells(os.path.join(work, "output_00002"), with_grav=True)))
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    workr, _ = _run(nml, REF_MPI, nproc, {})
+    try:
+        ref = _sorted(rs.load_leaf_cells(os.path.join(workr, "output_00002"), with_grav=True))
+    finally:
+        shutil.rmtree(workr, ignore_errors=True)
+    for mode in ("1", "0"):
+        got = res[mode][1]
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+        assert np.array_equal(got[3], ref[3]), (mode, np.abs(got[3] - ref[3]).max())     # phi, f
+        assert np.array_equal(got[2], ref[2]), (mode, np.abs(got[2] - ref[2]).max())     # hydro state
+    up_new, up_old = sum(t[0] for t in res["1"][0]), sum(t[0] for t in res["0"][0])
+    down_old = sum(t[1] for t in res["0"][0])
+    assert down_old == 0          # (the old path's way back is poisamr_force_mpi's own copy, not counted here)
+    assert 0 < up_new < 0.5 * up_old, (up_new, up_old)
+    assert sum(t[1] for t in res["1"][0]) > 0         # backup_poisson fetched f for the snapshot
+
+
 @pytest.mark.parametrize("nproc,ordered", [(2, "default"), (4, "default"), (8, "default"), (2, "0")])
 def test_cg_levels_under_mpi_equal_the_mpi_reference(gpu_lib, nproc, ordered):
     """phi_fine_cg under MPI: cg_levelmin=4, so levels 4 and 5 of the self-gravitating AMR run

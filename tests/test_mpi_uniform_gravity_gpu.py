@@ -68,12 +68,23 @@ def test_uniform_self_gravity_under_mpi_equals_the_mpi_reference(gpu_lib, level,
     mkb = _mkb()
     nml = mkb.c4_namelist(level=level).replace("ngridtot=", "ngridtot=%d !" % (3 * sum(8 ** l for l in range(level)) + 1000))
     ref, ref_solves = _reference(nml, nproc, level)
-    work, out = _run(nml, PATCHED_MPI, nproc, {"RAMSES_AMD": "1", "RAMSES_AMD_MG_DIST": dist})
+    work, out = _run(nml, PATCHED_MPI, nproc, {"RAMSES_AMD": "1", "RAMSES_AMD_MG_DIST": dist, "RAMSES_AMD_STATS": "1"})
     try:
         got = rs.load_uniform_level(os.path.join(work, "output_00002"), level, with_grav=True)
         got_solves = mkb.solves(out)
     finally:
         shutil.rmtree(work, ignore_errors=True)
+    # round 6: the acceleration of a uniform self-gravitating run never crosses PCIe after the
+    # first load -- force_fine files it from the brick (or from the force kernel's buffer) into the resident array, the
+    # virtual octs are exchanged there; what goes down is backup_poisson's fetch for the snapshot, once per oct and output
+    import re
+    traffic = [[int(a), int(b)] for a, b in re.findall(r"acceleration f over PCIe:\s*(\d+) bytes to the device,\s*(\d+) bytes back", out)]
+    assert len(traffic) == nproc, out[-2000:]
+    octs = 8 ** (level - 1)
+    up, down = sum(t[0] for t in traffic), sum(t[1] for t in traffic)
+    # (own + virtual octs: the virtual ones are a shell around each rank's box, < 60 % on top at these sizes)
+    assert up <= 1.6 * octs * 8 * 3 * 8, (up, octs)          # the first load and nothing after it, whatever the number of steps
+    assert 0 < down <= 1.6 * octs * 8 * 3 * 8 * 2, (down, octs)      # at most the two snapshots
     said = "distributed over" in out
     assert said == (dist == "1"), out[-2000:]
     # round 4: the hydro state of a uniform self-gravitating level stays on the ranks' GPUs too (cell vectors + tree resident,
