@@ -27,6 +27,11 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-fast-mat
 UNITS = [
     ("hydro_sweep_strict.o", "hydro_sweep.hip", ["-ffp-contract=off"]),
     ("hydro_sweep_fast.o", "hydro_sweep.hip", ["-ffp-contract=off", "-DRAMSES_AMD_FAST=1"]),
+] + [
+    # (one unit per slope type and arithmetic; 3 stands for 3, 4, 5, 6: csrc/hydro_sweep.hip)
+    ("hydro_sweep_%s_st%d.o" % (mode, st), "hydro_sweep.hip", ["-ffp-contract=off", "-DSWEEP_ST=%d" % st] + flag)
+    for st in (1, 2, 0, 7, 8, 3) for mode, flag in (("strict", []), ("fast", ["-DRAMSES_AMD_FAST=1"]))
+] + [
     ("hydro_misc.o", "hydro_misc.hip", ["-ffp-contract=off"]),
     ("mg_kernels.o", "mg_kernels.hip", ["-ffp-contract=off"]),
     ("octree_pack.o", "octree_pack.hip", ["-ffp-contract=off"]),

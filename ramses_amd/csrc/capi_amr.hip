@@ -765,6 +765,7 @@ struct LevelPlan {
   int version = -1, ngrid = -1, ig_first = 0, ig_last = 0;      // the layout version of the level and the list the plan was made for
   int ig_sample[10] = {0};                                        // (ten entries of it, spread over the list: the fingerprint of the list cache)
   int nghost = 0, nwork = 0, nevent = 0;
+  int rows = 0;                                                   // interior rows of its work items (8, or 4 for the 8-row kernels)
   Buf gfather, gslot, gcell, gsten, work, corr, corr_tgt, evt_of, flag, events;
   void release() {
     for (Buf *b : {&gfather, &gslot, &gcell, &gsten, &work, &corr, &corr_tgt, &evt_of, &flag, &events}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
@@ -1231,7 +1232,7 @@ int ramses_amd_amrres_hydro_flag(const ramses_amd_hydro_params *p, int ngrid, co
 namespace {
 
 // the plan of a level in tiles for the list of the call (R.cur_ig; see plan_* above); rebuilt when the layout or the list changed
-int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &P) {
+int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, int rows, LevelPlan &P) {
   amrlayout::LevelMap &L = R.map.lev[ilevel];
   hipStream_t s = nullptr;
   P.version = -1;
@@ -1262,7 +1263,7 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   HCHK(hipMemsetAsync(P.events.p, 0, sizeof(int), s), "memset");
   hipLaunchKernelGGL(plan_events_kernel, dim3((unsigned)(((long)ngrid * 6 + 255) / 256)), dim3(256), 0, s, A, P.corr_tgt.as<int>(), P.events.as<int>() + 1, P.events.as<int>(), P.evt_of.as<int>());
   // work items: columns of 60 x 8 cells, runs of 8-plane chunks up to 128 planes
-  const int rows = strictmode::tile_sweep_rows();       // interior rows of a work item (even: an oct never straddles two)
+  // (rows: interior rows of a work item -- 8, or 4 for the kernels of 8 rows; even: an oct never straddles two)
   const int n = 2 * L.no, wtx = (n + 59) / 60, wty = n / rows, wz = n / 8;
   const size_t nflag = (size_t)wtx * wty * wz;
   HCHK(P.flag.ensure(nflag), "hipMalloc");
@@ -1390,6 +1391,7 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, LevelPlan &
   HCHK(P.work.ensure(sizeof(int) * 4 * (size_t)(nw > 0 ? nw : 1)), "hipMalloc");
   if (nw > 0) HCHK(hipMemcpy(P.work.p, order.data(), sizeof(int) * 4 * (size_t)nw, hipMemcpyHostToDevice), "H2D work list");
   P.nwork = nw;
+  P.rows = rows;
   P.ngrid = ngrid; P.ig_first = ngrid > 0 ? h_igrid[0] : 0; P.ig_last = ngrid > 0 ? h_igrid[ngrid - 1] : 0;
   for (int k = 0; k < 10; k++) P.ig_sample[k] = h_igrid[(long)k * (ngrid - 1) / 9];
   P.version = L.version;
@@ -1411,9 +1413,12 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
     if (const char *e = getenv("RAMSES_AMD_TILE_MIN_OCTS")) { const long v = atol(e); if (v >= 0) min_octs = v; }
     if (ngrid < min_octs) return 0;
   }
-  if (R.nvar != 5 || p->nvar != 5 || p->ndim != 3 || p->scheme != RAMSES_AMD_SCHEME_MUSCL || p->difmag > 0.0 || R.pfix) return 0;
+  // (round 6: runs with one or two passive scalars and the Newton solver too -- kernels of 8 rows, work items of 4)
+  const int nvar = R.nvar;
+  if (nvar < 5 || nvar > 7 || p->nvar != nvar || p->ndim != 3 || p->scheme != RAMSES_AMD_SCHEME_MUSCL || p->difmag > 0.0 || R.pfix) return 0;
   const int st = p->slope_type;
-  if (!(st == 0 || st == 1 || st == 2 || st == 7 || st == 8) || p->riemann == RAMSES_AMD_RIEMANN_EXACT) return 0;
+  if (!(st == 0 || st == 1 || st == 2 || st == 7 || st == 8)) return 0;
+  const int rows = strictmode::tile_sweep_rows(p->riemann, nvar);
   if (interpol_var < 0 || interpol_var > 2 || interpol_type < 0 || interpol_type > 4) return 0;
   if ((unsigned long)R.ncell * 8ul >= (1ul << 31)) {      // lane offsets into a cell vector are 31-bit byte offsets
     static bool told = false;
@@ -1426,14 +1431,17 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
   // (the plan of a level that kept its layout survives a regrid of the finer levels: its octs, ghosts and work items are the same.
   //  The list of a level must not change between two regrids without its first or last entry or its length changing: it is
   //  active(ilevel)%igrid, which only build_comm / refine_fine / load_balance rewrite.)
-  bool same_list = P.version == L.version && P.ngrid == ngrid && P.ig_first == h_igrid[0] && P.ig_last == h_igrid[ngrid - 1];
+  bool same_list = P.version == L.version && P.rows == rows && P.ngrid == ngrid && P.ig_first == h_igrid[0] && P.ig_last == h_igrid[ngrid - 1];
   for (int k = 0; same_list && k < 10; k++) same_list = P.ig_sample[k] == h_igrid[(long)k * (ngrid - 1) / 9];
   if (!same_list)
-    if (int rc = build_plan(R, ilevel, ngrid, h_igrid, P)) return rc;
+    if (int rc = build_plan(R, ilevel, ngrid, h_igrid, rows, P)) return rc;
   if (P.nwork == 0) { done = true; return 0; }
   if (P.nghost > 0) {
-    hipLaunchKernelGGL(plan_ghost_fill_kernel<5>, dim3((P.nghost + 127) / 128), dim3(128), 0, s, R.uold.as<double>(), R.grav ? R.f.as<double>() : nullptr,
-                       P.gslot.as<int>(), P.gsten.as<int>(), P.nghost, R.ncell, R.ncoarse, R.ngridmax, interpol_var, interpol_type, p->smallr);
+    const dim3 gg((P.nghost + 127) / 128), gb(128);
+    double *gf = R.grav ? R.f.as<double>() : nullptr;
+    if (nvar == 5) hipLaunchKernelGGL(plan_ghost_fill_kernel<5>, gg, gb, 0, s, R.uold.as<double>(), gf, P.gslot.as<int>(), P.gsten.as<int>(), P.nghost, R.ncell, R.ncoarse, R.ngridmax, interpol_var, interpol_type, p->smallr);
+    else if (nvar == 6) hipLaunchKernelGGL(plan_ghost_fill_kernel<6>, gg, gb, 0, s, R.uold.as<double>(), gf, P.gslot.as<int>(), P.gsten.as<int>(), P.nghost, R.ncell, R.ncoarse, R.ngridmax, interpol_var, interpol_type, p->smallr);
+    else hipLaunchKernelGGL(plan_ghost_fill_kernel<7>, gg, gb, 0, s, R.uold.as<double>(), gf, P.gslot.as<int>(), P.gsten.as<int>(), P.nghost, R.ncell, R.ncoarse, R.ngridmax, interpol_var, interpol_type, p->smallr);
     HCHK(hipGetLastError(), "ghost octs");
   }
   SweepArgs A;
@@ -1465,12 +1473,12 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
     S.base = L.base; S.ncoarse = R.ncoarse; S.ngd = R.ngridmax; S.ncell = R.ncell;
     S.no = L.no; S.ntx = L.ntx; S.nty = L.nty; S.ntz = L.ntz;
     S.dt = A.dt; S.dx = A.dx; S.rdx = A.rdx; S.pow2 = A.pow2; S.P = A.P;
-    hipError_t es = fast ? fastmode::launch_surface_flux(S, st, p->riemann, R.grav, s) : strictmode::launch_surface_flux(S, st, p->riemann, R.grav, s);
+    hipError_t es = fast ? fastmode::launch_surface_flux(S, st, p->riemann, nvar, R.grav, s) : strictmode::launch_surface_flux(S, st, p->riemann, nvar, R.grav, s);
     if (es == hipErrorInvalidValue) { (void)hipGetLastError(); return 0; }     // a variant the tile kernels do not cover
     HCHK(es, "surface pass of a level in tiles");
   }
-  hipError_t e = fast ? fastmode::launch_godunov_sweep(A, st, p->riemann, 12, p->scheme, 5, R.grav, s)
-                      : strictmode::launch_godunov_sweep(A, st, p->riemann, 12, p->scheme, 5, R.grav, s);
+  hipError_t e = fast ? fastmode::launch_godunov_sweep(A, st, p->riemann, rows + 4, p->scheme, nvar, R.grav, s)
+                      : strictmode::launch_godunov_sweep(A, st, p->riemann, rows + 4, p->scheme, nvar, R.grav, s);
   if (e == hipErrorInvalidValue) { (void)hipGetLastError(); return 0; }     // a variant the tile kernels do not cover
   HCHK(e, "dense sweep of a level in tiles");
   // what the level owes to the leaf cells of the coarser one, replayed in the reference's order
@@ -1482,7 +1490,7 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
     Q.dir = L.dir.as<int>(); Q.tileid = L.tileid.as<int>(); Q.base = L.base; Q.no = L.no; Q.ntx = L.ntx; Q.nty = L.nty; Q.ntz = L.ntz;
     if (P.nevent > 0) {
       hipLaunchKernelGGL(tile_coarse_update_kernel, dim3((P.nevent + 255) / 256), dim3(256), 0, s, Q, R.unew.as<double>(), P.corr.as<double>(), P.corr_tgt.as<int>(),
-                         P.evt_of.as<int>(), P.events.as<int>() + 1, P.nevent, nvector, 5);
+                         P.evt_of.as<int>(), P.events.as<int>() + 1, P.nevent, nvector, nvar);
       HCHK(hipGetLastError(), "coarse corrections");
     }
   }

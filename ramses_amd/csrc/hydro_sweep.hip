@@ -509,7 +509,7 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
           // (LATE: the state the update starts from joins in phase B of the next iteration -- a whole trace after its load)
           px[n] = LATE ? (fx[n] - fxh[n]) : ucur[n] + (fx[n] - fxh[n]);
         }
-        if (NV > 5) {
+        if (NV > 5 && !MASK) {
           rnew = ucur[0];
 #pragma unroll
           for (int n = 5; n < NV; n++) snew[n - 5] = ucur[n];
@@ -564,9 +564,10 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
         const double part = (LATE ? bcar[n] + pxn : pxn) + (fyn - fyh[n]);
         un[n] = part + dz[n];
       }
-      if (NV > 5) {
+      if (NV > 5 && !MASK) {
         // set_uold's passive-scalar fix near the density floor
         // (hydro/godunov_fine.f90:176-190), fused: the kernel's output is the new uold
+        // (MASK: the kernel's output is unew; set_uold of the resident level applies the fix, csrc/capi_amr.hip lvl_set_uold)
         if (rold < P.smallr && un[0] > rold) {
 #pragma unroll
           for (int n = 5; n < NV; n++) un[n] = sold[n - 5] * dmaxd(un[0], P.smallr) / P.smallr;
@@ -718,42 +719,67 @@ __global__ __launch_bounds__(128) void surface_flux_kernel(SurfArgs A) {
   for (int n = 0; n < NV; n++) dst[n] = zero ? 0.0 : fl[n];
 }
 
+template <int ST, int RS, int NV>
+static hipError_t surface2(const SurfArgs &A, bool grav, hipStream_t s) {
+  const dim3 grid((unsigned)(((long)A.nevent * 4 + 127) / 128)), block(128);
+  if (grav) hipLaunchKernelGGL((surface_flux_kernel<ST, RS, NV, true>), grid, block, 0, s, A);
+  else hipLaunchKernelGGL((surface_flux_kernel<ST, RS, NV, false>), grid, block, 0, s, A);
+  return hipGetLastError();
+}
 template <int ST, int RS>
-static hipError_t surface1(const SurfArgs &A, bool grav, hipStream_t s) {
-  if constexpr (ST == 3 || ST == 4 || ST == 5 || ST == 6 || RS == RIEMANN_EXACT) {
+static hipError_t surface1(const SurfArgs &A, int nvar, bool grav, hipStream_t s) {
+  if constexpr (ST == 3 || ST == 4 || ST == 5 || ST == 6) {
     return hipErrorInvalidValue;
   } else {
-    const dim3 grid((unsigned)(((long)A.nevent * 4 + 127) / 128)), block(128);
-    if (grav) hipLaunchKernelGGL((surface_flux_kernel<ST, RS, 5, true>), grid, block, 0, s, A);
-    else hipLaunchKernelGGL((surface_flux_kernel<ST, RS, 5, false>), grid, block, 0, s, A);
-    return hipGetLastError();
+    if (nvar == 5) return surface2<ST, RS, 5>(A, grav, s);
+#ifndef SWEEP_FLAGSHIP_ONLY
+    if (nvar == 6) return surface2<ST, RS, 6>(A, grav, s);
+    if (nvar == 7) return surface2<ST, RS, 7>(A, grav, s);
+#endif
+    return hipErrorInvalidValue;
   }
 }
 template <int ST>
-static hipError_t surface0(const SurfArgs &A, int rs, bool grav, hipStream_t s) {
+hipError_t surface0(const SurfArgs &A, int rs, int nvar, bool grav, hipStream_t s) {
   switch (rs) {
-    case RIEMANN_LLF: return surface1<ST, RIEMANN_LLF>(A, grav, s);
+    case RIEMANN_LLF: return surface1<ST, RIEMANN_LLF>(A, nvar, grav, s);
 #ifndef SWEEP_FLAGSHIP_ONLY
-    case RIEMANN_HLLC: return surface1<ST, RIEMANN_HLLC>(A, grav, s);
-    case RIEMANN_HLL: return surface1<ST, RIEMANN_HLL>(A, grav, s);
-    case RIEMANN_ACOUSTIC: return surface1<ST, RIEMANN_ACOUSTIC>(A, grav, s);
+    case RIEMANN_HLLC: return surface1<ST, RIEMANN_HLLC>(A, nvar, grav, s);
+    case RIEMANN_HLL: return surface1<ST, RIEMANN_HLL>(A, nvar, grav, s);
+    case RIEMANN_ACOUSTIC: return surface1<ST, RIEMANN_ACOUSTIC>(A, nvar, grav, s);
+    case RIEMANN_EXACT: return surface1<ST, RIEMANN_EXACT>(A, nvar, grav, s);
 #endif
   }
   return hipErrorInvalidValue;
 }
-hipError_t launch_surface_flux(const SurfArgs &A, int slope_type, int riemann, bool grav, hipStream_t s) {
+// One translation unit per slope type (ramses_amd/build.py compiles this file once without SWEEP_ST -- the dispatchers -- and once
+// per slope type with -DSWEEP_ST=<type>, 3 standing for 3, 4, 5 and 6, for each arithmetic: the instantiations of the option
+// matrix build side by side instead of in two nine-minute compiles; the variant builds of scripts/build_variant.sh --
+// SWEEP_FLAGSHIP_ONLY -- keep one unit)
+#if defined(SWEEP_ST)
+#if SWEEP_ST != 3
+template hipError_t surface0<SWEEP_ST>(const SurfArgs &, int, int, bool, hipStream_t);
+#endif
+#elif !defined(SWEEP_FLAGSHIP_ONLY)
+#define SWEEP_EXTERN_ST(K) extern template hipError_t surface0<K>(const SurfArgs &, int, int, bool, hipStream_t);
+SWEEP_EXTERN_ST(0) SWEEP_EXTERN_ST(1) SWEEP_EXTERN_ST(2) SWEEP_EXTERN_ST(7) SWEEP_EXTERN_ST(8)
+#undef SWEEP_EXTERN_ST
+#endif
+#ifndef SWEEP_ST
+hipError_t launch_surface_flux(const SurfArgs &A, int slope_type, int riemann, int nvar, bool grav, hipStream_t s) {
   if (A.nevent <= 0) return hipSuccess;
   switch (slope_type) {
-    case 1: return surface0<1>(A, riemann, grav, s);
+    case 1: return surface0<1>(A, riemann, nvar, grav, s);
 #ifndef SWEEP_FLAGSHIP_ONLY
-    case 0: return surface0<0>(A, riemann, grav, s);
-    case 2: return surface0<2>(A, riemann, grav, s);
-    case 7: return surface0<7>(A, riemann, grav, s);
-    case 8: return surface0<8>(A, riemann, grav, s);
+    case 0: return surface0<0>(A, riemann, nvar, grav, s);
+    case 2: return surface0<2>(A, riemann, nvar, grav, s);
+    case 7: return surface0<7>(A, riemann, nvar, grav, s);
+    case 8: return surface0<8>(A, riemann, nvar, grav, s);
 #endif
   }
   return hipErrorInvalidValue;
 }
+#endif   // SWEEP_ST
 
 // ---------------------------------------------------------------------------
 // host-side dispatch
@@ -824,11 +850,26 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
   if (A.stat) {
     // a level of a resident AMR run in tiles: the 12-row muscl kernels on the periodic box of the level, one workgroup per
     // work item (anything else: the caller keeps the tree-walking sweep)
-    if constexpr (ST != 3 && ST != 4 && ST != 5 && ST != 6 && RS != RIEMANN_EXACT) {
-      if (!A.dir || !A.work || A.ng != 0 || nvar != 5 || scheme != 0 || A.nwork <= 0) return hipErrorInvalidValue;
+    if constexpr (ST != 3 && ST != 4 && ST != 5 && ST != 6) {
+      if (!A.dir || !A.work || A.ng != 0 || scheme != 0 || A.nwork <= 0) return hipErrorInvalidValue;
       A.nblocks = A.nwork;
       A.nbox = 1;          // (the box decode runs, its result is replaced by the work item)
-      return grav ? launch3<ST, RS, TILE_SWEEP_BY, true, 0, 5, true>(A, s) : launch3<ST, RS, TILE_SWEEP_BY, false, 0, 5, true>(A, s);
+      // the plan's work items were cut for tile_sweep_rows(riemann, nvar) interior rows: 8 (12-row workgroups), or 4 for the
+      // variants that need 256 registers -- the Newton solver and runs with passive scalars (round 6)
+      if (by == 8) {
+        if (nvar == 5) {
+          if constexpr (RS == RIEMANN_EXACT) return grav ? launch3<ST, RS, 8, true, 0, 5, true>(A, s) : launch3<ST, RS, 8, false, 0, 5, true>(A, s);
+          else return hipErrorInvalidValue;
+        }
+        if (nvar == 6) return grav ? launch3<ST, RS, 8, true, 0, 6, true>(A, s) : launch3<ST, RS, 8, false, 0, 6, true>(A, s);
+        if (nvar == 7) return grav ? launch3<ST, RS, 8, true, 0, 7, true>(A, s) : launch3<ST, RS, 8, false, 0, 7, true>(A, s);
+        return hipErrorInvalidValue;
+      }
+      if constexpr (RS != RIEMANN_EXACT) {
+        if (by == TILE_SWEEP_BY && nvar == 5)
+          return grav ? launch3<ST, RS, TILE_SWEEP_BY, true, 0, 5, true>(A, s) : launch3<ST, RS, TILE_SWEEP_BY, false, 0, 5, true>(A, s);
+      }
+      return hipErrorInvalidValue;
     } else {
       return hipErrorInvalidValue;
     }
@@ -851,7 +892,7 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
 }
 
 template <int ST>
-static hipError_t launch0(SweepArgs &A, int rs, int by, int scheme, int nvar, bool grav, hipStream_t s) {
+hipError_t launch0(SweepArgs &A, int rs, int by, int scheme, int nvar, bool grav, hipStream_t s) {
   switch (rs) {
     case RIEMANN_LLF: return launch1<ST, RIEMANN_LLF>(A, by, scheme, nvar, grav, s);
 #ifndef SWEEP_FLAGSHIP_ONLY   // (scripts/sweep_regs.sh, build_ab.py: the LLF + minmod instantiations only, a one-minute compile)
@@ -864,8 +905,23 @@ static hipError_t launch0(SweepArgs &A, int rs, int by, int scheme, int nvar, bo
   return hipErrorInvalidValue;
 }
 
+#if defined(SWEEP_ST)
+template hipError_t launch0<SWEEP_ST>(SweepArgs &, int, int, int, int, bool, hipStream_t);
+#if SWEEP_ST == 3
+template hipError_t launch0<4>(SweepArgs &, int, int, int, int, bool, hipStream_t);
+template hipError_t launch0<5>(SweepArgs &, int, int, int, int, bool, hipStream_t);
+template hipError_t launch0<6>(SweepArgs &, int, int, int, int, bool, hipStream_t);
+#endif
+#elif !defined(SWEEP_FLAGSHIP_ONLY)
+#define SWEEP_EXTERN_ST(K) extern template hipError_t launch0<K>(SweepArgs &, int, int, int, int, bool, hipStream_t);
+SWEEP_EXTERN_ST(0) SWEEP_EXTERN_ST(1) SWEEP_EXTERN_ST(2) SWEEP_EXTERN_ST(3) SWEEP_EXTERN_ST(4) SWEEP_EXTERN_ST(5) SWEEP_EXTERN_ST(6)
+SWEEP_EXTERN_ST(7) SWEEP_EXTERN_ST(8)
+#undef SWEEP_EXTERN_ST
+#endif
+
+#ifndef SWEEP_ST
 // interior rows of a work item of the sweep of a level in tiles (the plan of csrc/capi_amr.hip cuts the level accordingly)
-int tile_sweep_rows() { return TILE_SWEEP_BY - 4; }
+int tile_sweep_rows(int riemann, int nvar) { return ((riemann == RIEMANN_EXACT || nvar != 5) ? 8 : TILE_SWEEP_BY) - 4; }
 
 hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme, int nvar,
                                 bool grav, hipStream_t s) {
@@ -888,11 +944,15 @@ hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int b
   return hipErrorInvalidValue;
 }
 
+#endif   // SWEEP_ST
+
 }  // namespace SWEEP_NS
 }  // namespace ramses_amd
 
+// (the units of one slope type are not warmed up: a run uses one of the twelve, which loads with its first sweep)
 #include "warm.hpp"
-#if RAMSES_AMD_FAST
+#if defined(SWEEP_ST)
+#elif RAMSES_AMD_FAST
 RAMSES_AMD_TU_WARM(hydro_sweep_fast)
 #else
 RAMSES_AMD_TU_WARM(hydro_sweep_strict)

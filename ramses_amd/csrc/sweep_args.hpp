@@ -76,16 +76,16 @@ struct SurfArgs {
 };
 
 namespace strictmode {
-hipError_t launch_surface_flux(const SurfArgs &A, int slope_type, int riemann, bool grav, hipStream_t s);
+hipError_t launch_surface_flux(const SurfArgs &A, int slope_type, int riemann, int nvar, bool grav, hipStream_t s);
 hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme, int nvar,
                                 bool grav, hipStream_t s);
-int tile_sweep_rows();
+int tile_sweep_rows(int riemann, int nvar);
 }
 namespace fastmode {
-hipError_t launch_surface_flux(const SurfArgs &A, int slope_type, int riemann, bool grav, hipStream_t s);
+hipError_t launch_surface_flux(const SurfArgs &A, int slope_type, int riemann, int nvar, bool grav, hipStream_t s);
 hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme, int nvar,
                                 bool grav, hipStream_t s);
-int tile_sweep_rows();
+int tile_sweep_rows(int riemann, int nvar);
 }
 
 }  // namespace ramses_amd

@@ -858,8 +858,12 @@ contains
     end do
     ! make_grid_fine gives every new oct the acceleration of its father cell (amr/refine_utils.f90:918-927): f of level ilevel
     ! comes back if force_fine left it on the device only
-    if (poisson .and. ilevel <= 64) then
-       if (ramses_amd_f_on_device(ilevel)) call ramses_amd_amr_sync_f_level(ilevel)
+    ! -- and of every finer level now, while the device's oct numbering still matches the host's lists (refine_fine(ilevel)
+    ! rebuilds level ilevel+1 before refine_fine(ilevel+1) asks for it)
+    if (poisson) then
+       do l = ilevel, min(nlevelmax, 64)
+          if (ramses_amd_f_on_device(l)) call ramses_amd_amr_sync_f_level(l)
+       end do
     end if
     ramses_amd_amr_host_from = min(ramses_amd_amr_host_from, max(ilevel - 1, levelmin))
     ramses_amd_amr_reload_from = min(ramses_amd_amr_reload_from, ilevel + 1)      ! refine_fine(ilevel) rebuilds level ilevel+1
@@ -1235,6 +1239,7 @@ contains
     end if
     write(*,*) 'ramses_amd: FATAL in ', where, ': ', trim(msg)
     write(*,*) 'ramses_amd: no CPU fallback is taken; set RAMSES_AMD=0 to run the reference path'
+    flush(6)          ! (clean_stop ends in MPI_Abort: what sits in the buffer of a piped stdout would be lost)
     call clean_stop
   end subroutine ramses_amd_fatal
 

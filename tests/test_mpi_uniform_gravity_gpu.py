@@ -83,8 +83,16 @@ def test_uniform_self_gravity_under_mpi_equals_the_mpi_reference(gpu_lib, level,
     octs = 8 ** (level - 1)
     up, down = sum(t[0] for t in traffic), sum(t[1] for t in traffic)
     # (own + virtual octs: the virtual ones are a shell around each rank's box, < 60 % on top at these sizes)
-    assert up <= 1.6 * octs * 8 * 3 * 8, (up, octs)          # the first load and nothing after it, whatever the number of steps
+    assert up <= 2 * 1.6 * octs * 8 * 3 * 8, (up, octs)      # the load of the start-up (the image is built twice there), nothing per step
     assert 0 < down <= 1.6 * octs * 8 * 3 * 8 * 2, (down, octs)      # at most the two snapshots
+    if (level, nproc, dist) == (7, 2, "1"):
+        # ... whatever the number of steps: twice as many steps, the same bytes
+        work2, out2 = _run(nml.replace("nstepmax=3", "nstepmax=6").replace("foutput=3", "foutput=6"), PATCHED_MPI, nproc,
+                           {"RAMSES_AMD": "1", "RAMSES_AMD_MG_DIST": dist, "RAMSES_AMD_STATS": "1"})
+        shutil.rmtree(work2, ignore_errors=True)
+        assert "nstepmax=3" in nml and "Main step=      6" in out2, out2[-1500:]
+        traffic2 = [[int(a), int(b)] for a, b in re.findall(r"acceleration f over PCIe:\s*(\d+) bytes to the device,\s*(\d+) bytes back", out2)]
+        assert sum(t[0] for t in traffic2) == up, (traffic2, traffic)
     said = "distributed over" in out
     assert said == (dist == "1"), out[-2000:]
     # round 4: the hydro state of a uniform self-gravitating level stays on the ranks' GPUs too (cell vectors + tree resident,
