@@ -1415,10 +1415,11 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
   }
   // (round 6: runs with one or two passive scalars and the Newton solver too -- kernels of 8 rows, work items of 4)
   const int nvar = R.nvar;
-  if (nvar < 5 || nvar > 7 || p->nvar != nvar || p->ndim != 3 || p->scheme != RAMSES_AMD_SCHEME_MUSCL || p->difmag > 0.0 || R.pfix) return 0;
+  if (nvar < 5 || nvar > 7 || p->nvar != nvar || p->ndim != 3 || p->difmag > 0.0 || R.pfix) return 0;
+  if (p->scheme != RAMSES_AMD_SCHEME_MUSCL && !(p->scheme == RAMSES_AMD_SCHEME_PLMDE && nvar == 5)) return 0;
   const int st = p->slope_type;
-  if (!(st == 0 || st == 1 || st == 2 || st == 7 || st == 8)) return 0;
-  const int rows = strictmode::tile_sweep_rows(p->riemann, nvar);
+  if (!(st == 0 || st == 1 || st == 2 || st == 3 || st == 7 || st == 8)) return 0;
+  const int rows = strictmode::tile_sweep_rows(p->riemann, nvar, st, p->scheme);
   if (interpol_var < 0 || interpol_var > 2 || interpol_type < 0 || interpol_type > 4) return 0;
   if ((unsigned long)R.ncell * 8ul >= (1ul << 31)) {      // lane offsets into a cell vector are 31-bit byte offsets
     static bool told = false;
@@ -1473,7 +1474,7 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
     S.base = L.base; S.ncoarse = R.ncoarse; S.ngd = R.ngridmax; S.ncell = R.ncell;
     S.no = L.no; S.ntx = L.ntx; S.nty = L.nty; S.ntz = L.ntz;
     S.dt = A.dt; S.dx = A.dx; S.rdx = A.rdx; S.pow2 = A.pow2; S.P = A.P;
-    hipError_t es = fast ? fastmode::launch_surface_flux(S, st, p->riemann, nvar, R.grav, s) : strictmode::launch_surface_flux(S, st, p->riemann, nvar, R.grav, s);
+    hipError_t es = fast ? fastmode::launch_surface_flux(S, st, p->riemann, nvar, p->scheme, R.grav, s) : strictmode::launch_surface_flux(S, st, p->riemann, nvar, p->scheme, R.grav, s);
     if (es == hipErrorInvalidValue) { (void)hipGetLastError(); return 0; }     // a variant the tile kernels do not cover
     HCHK(es, "surface pass of a level in tiles");
   }

@@ -637,8 +637,62 @@ __device__ __forceinline__ long surf_cell(const SurfArgs &A, int x, int y, int z
 // is a gather of isolated 8-byte words: what it costs is the latency of dependent loads, so nothing may wait between them), then
 // converted (ctoprim), then the slopes and the two traces -- what a lane of the marching kernel does for its cell in phase A --
 // and the Riemann flux, scaled like the marching kernel's.
-template <int ST, int RS, int NV, bool GRAV, int DIR>
+// (slope type 3: the 3 x 3 x 3 neighbourhoods of the two cells -- 36 cells, four slabs of nine along DIR)
+template <int RS, int NV, bool GRAV, int SCHEME, int DIR>
+__device__ __forceinline__ void surf_interface27(const SurfArgs &A, const int (&lo)[3], double (&fl)[NV]) {
+  constexpr int T0 = DIR == 0 ? 1 : 0, T1 = DIR == 2 ? 1 : 2;
+  long c[36];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int u = 0; u < 3; u++)
+#pragma unroll
+      for (int v = 0; v < 3; v++) {
+        int p[3] = {lo[0], lo[1], lo[2]};
+        p[DIR] += a - 1; p[T0] += u - 1; p[T1] += v - 1;
+        c[a * 9 + u * 3 + v] = surf_cell(A, p[0], p[1], p[2]);
+      }
+  double q[36][NV];
+#pragma unroll
+  for (int k = 0; k < 36; k++) {
+    double u[NV], g[3];
+#pragma unroll
+    for (int n = 0; n < NV; n++) u[n] = A.uold[(long)n * A.ncell + c[k]];
+#pragma unroll
+    for (int d = 0; d < 3; d++) g[d] = GRAV ? A.grav[(long)d * A.ncell + c[k]] : 0.0;
+    ctoprim_cell<NV, GRAV>(u, g, A.dt * 0.5, A.P, q[k]);
+  }
+  const double dtdx = A.dt / A.dx;
+  double qL[NV], qR[NV];
+#pragma unroll
+  for (int w = 0; w < 2; w++) {
+    double dq[3][NV], qm[3][NV], qp[3][NV];
+#pragma unroll
+    for (int n = 0; n < NV; n++) {
+      double nb[27], d3[3];
+#pragma unroll
+      for (int dz = 0; dz < 3; dz++)
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+          for (int dx = 0; dx < 3; dx++) {
+            const int o[3] = {dx, dy, dz};
+            nb[dx + 3 * dy + 9 * dz] = q[(w + o[DIR]) * 9 + o[T0] * 3 + o[T1]][n];
+          }
+      slope3_var(nb, d3);
+      dq[0][n] = d3[0]; dq[1][n] = d3[1]; dq[2][n] = d3[2];
+    }
+    const double (&qb)[NV] = q[(1 + w) * 9 + 4];
+    if (SCHEME == 0) trace3d_cell<NV>(qb, dq, dtdx, dtdx, dtdx, A.P, qm, qp);
+    else tracexyz_cell<NV>(qb, dq, ctoprim_sound(qb[0], qb[4], A.P), dtdx, dtdx, dtdx, A.P, qm, qp);
+#pragma unroll
+    for (int n = 0; n < NV; n++) { if (w == 0) qL[n] = qm[DIR][n]; else qR[n] = qp[DIR][n]; }
+  }
+  scaled_interface_flux<RS, NV, DIR>(qL, qR, A.P, A.dt, A.dx, A.rdx, dtdx, A.pow2 != 0, fl);
+}
+template <int ST, int RS, int NV, bool GRAV, int SCHEME, int DIR>
 __device__ __forceinline__ void surf_interface(const SurfArgs &A, const int (&lo)[3], double (&fl)[NV]) {
+  if constexpr (ST == 3) { surf_interface27<RS, NV, GRAV, SCHEME, DIR>(A, lo, fl); return; }
   constexpr int T0 = DIR == 0 ? 1 : 0, T1 = DIR == 2 ? 1 : 2;
   long c[12];
   // 0..3: along DIR at lo-1, lo, hi, hi+1;  4..7: lo -T0, +T0, -T1, +T1;  8..11: the same of hi
@@ -681,13 +735,14 @@ __device__ __forceinline__ void surf_interface(const SurfArgs &A, const int (&lo
       dq[T0][n] = slope1<ST>(q[4 + 4 * w][n], q[1 + w][n], q[5 + 4 * w][n], A.P);
       dq[T1][n] = slope1<ST>(q[6 + 4 * w][n], q[1 + w][n], q[7 + 4 * w][n], A.P);
     }
-    trace3d_cell<NV>(q[1 + w], dq, dtdx, dtdx, dtdx, A.P, qm, qp);
+    if (SCHEME == 0) trace3d_cell<NV>(q[1 + w], dq, dtdx, dtdx, dtdx, A.P, qm, qp);
+    else tracexyz_cell<NV>(q[1 + w], dq, ctoprim_sound(q[1 + w][0], q[1 + w][4], A.P), dtdx, dtdx, dtdx, A.P, qm, qp);
 #pragma unroll
     for (int n = 0; n < NV; n++) { if (w == 0) qL[n] = qm[DIR][n]; else qR[n] = qp[DIR][n]; }
   }
   scaled_interface_flux<RS, NV, DIR>(qL, qR, A.P, A.dt, A.dx, A.rdx, dtdx, A.pow2 != 0, fl);
 }
-template <int ST, int RS, int NV, bool GRAV>
+template <int ST, int RS, int NV, bool GRAV, int SCHEME = 0>
 __global__ __launch_bounds__(128) void surface_flux_kernel(SurfArgs A) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)A.nevent * 4) return;
@@ -711,26 +766,30 @@ __global__ __launch_bounds__(128) void surface_flux_kernel(SurfArgs A) {
   int lo[3] = {p[0], p[1], p[2]};
   if (!side) lo[dirn] -= 1;
   double fl[NV];
-  if (dirn == 0) surf_interface<ST, RS, NV, GRAV, 0>(A, lo, fl);
-  else if (dirn == 1) surf_interface<ST, RS, NV, GRAV, 1>(A, lo, fl);
-  else surf_interface<ST, RS, NV, GRAV, 2>(A, lo, fl);
+  if (dirn == 0) surf_interface<ST, RS, NV, GRAV, SCHEME, 0>(A, lo, fl);
+  else if (dirn == 1) surf_interface<ST, RS, NV, GRAV, SCHEME, 1>(A, lo, fl);
+  else surf_interface<ST, RS, NV, GRAV, SCHEME, 2>(A, lo, fl);
   double *dst = A.rec + ((long)e * 4 + q) * (NV + 2);
 #pragma unroll
   for (int n = 0; n < NV; n++) dst[n] = zero ? 0.0 : fl[n];
 }
 
-template <int ST, int RS, int NV>
+template <int ST, int RS, int NV, int SCHEME = 0>
 static hipError_t surface2(const SurfArgs &A, bool grav, hipStream_t s) {
   const dim3 grid((unsigned)(((long)A.nevent * 4 + 127) / 128)), block(128);
-  if (grav) hipLaunchKernelGGL((surface_flux_kernel<ST, RS, NV, true>), grid, block, 0, s, A);
-  else hipLaunchKernelGGL((surface_flux_kernel<ST, RS, NV, false>), grid, block, 0, s, A);
+  if (grav) hipLaunchKernelGGL((surface_flux_kernel<ST, RS, NV, true, SCHEME>), grid, block, 0, s, A);
+  else hipLaunchKernelGGL((surface_flux_kernel<ST, RS, NV, false, SCHEME>), grid, block, 0, s, A);
   return hipGetLastError();
 }
 template <int ST, int RS>
-static hipError_t surface1(const SurfArgs &A, int nvar, bool grav, hipStream_t s) {
-  if constexpr (ST == 3 || ST == 4 || ST == 5 || ST == 6) {
+static hipError_t surface1(const SurfArgs &A, int nvar, int scheme, bool grav, hipStream_t s) {
+  if constexpr (ST == 4 || ST == 5 || ST == 6) {
     return hipErrorInvalidValue;
   } else {
+#ifndef SWEEP_FLAGSHIP_ONLY
+    if (scheme == 1) return nvar == 5 ? surface2<ST, RS, 5, 1>(A, grav, s) : hipErrorInvalidValue;
+#endif
+    if (scheme != 0) return hipErrorInvalidValue;
     if (nvar == 5) return surface2<ST, RS, 5>(A, grav, s);
 #ifndef SWEEP_FLAGSHIP_ONLY
     if (nvar == 6) return surface2<ST, RS, 6>(A, grav, s);
@@ -740,14 +799,14 @@ static hipError_t surface1(const SurfArgs &A, int nvar, bool grav, hipStream_t s
   }
 }
 template <int ST>
-hipError_t surface0(const SurfArgs &A, int rs, int nvar, bool grav, hipStream_t s) {
+hipError_t surface0(const SurfArgs &A, int rs, int nvar, int scheme, bool grav, hipStream_t s) {
   switch (rs) {
-    case RIEMANN_LLF: return surface1<ST, RIEMANN_LLF>(A, nvar, grav, s);
+    case RIEMANN_LLF: return surface1<ST, RIEMANN_LLF>(A, nvar, scheme, grav, s);
 #ifndef SWEEP_FLAGSHIP_ONLY
-    case RIEMANN_HLLC: return surface1<ST, RIEMANN_HLLC>(A, nvar, grav, s);
-    case RIEMANN_HLL: return surface1<ST, RIEMANN_HLL>(A, nvar, grav, s);
-    case RIEMANN_ACOUSTIC: return surface1<ST, RIEMANN_ACOUSTIC>(A, nvar, grav, s);
-    case RIEMANN_EXACT: return surface1<ST, RIEMANN_EXACT>(A, nvar, grav, s);
+    case RIEMANN_HLLC: return surface1<ST, RIEMANN_HLLC>(A, nvar, scheme, grav, s);
+    case RIEMANN_HLL: return surface1<ST, RIEMANN_HLL>(A, nvar, scheme, grav, s);
+    case RIEMANN_ACOUSTIC: return surface1<ST, RIEMANN_ACOUSTIC>(A, nvar, scheme, grav, s);
+    case RIEMANN_EXACT: return surface1<ST, RIEMANN_EXACT>(A, nvar, scheme, grav, s);
 #endif
   }
   return hipErrorInvalidValue;
@@ -757,24 +816,23 @@ hipError_t surface0(const SurfArgs &A, int rs, int nvar, bool grav, hipStream_t 
 // matrix build side by side instead of in two nine-minute compiles; the variant builds of scripts/build_variant.sh --
 // SWEEP_FLAGSHIP_ONLY -- keep one unit)
 #if defined(SWEEP_ST)
-#if SWEEP_ST != 3
-template hipError_t surface0<SWEEP_ST>(const SurfArgs &, int, int, bool, hipStream_t);
-#endif
+template hipError_t surface0<SWEEP_ST>(const SurfArgs &, int, int, int, bool, hipStream_t);
 #elif !defined(SWEEP_FLAGSHIP_ONLY)
-#define SWEEP_EXTERN_ST(K) extern template hipError_t surface0<K>(const SurfArgs &, int, int, bool, hipStream_t);
-SWEEP_EXTERN_ST(0) SWEEP_EXTERN_ST(1) SWEEP_EXTERN_ST(2) SWEEP_EXTERN_ST(7) SWEEP_EXTERN_ST(8)
+#define SWEEP_EXTERN_ST(K) extern template hipError_t surface0<K>(const SurfArgs &, int, int, int, bool, hipStream_t);
+SWEEP_EXTERN_ST(0) SWEEP_EXTERN_ST(1) SWEEP_EXTERN_ST(2) SWEEP_EXTERN_ST(3) SWEEP_EXTERN_ST(7) SWEEP_EXTERN_ST(8)
 #undef SWEEP_EXTERN_ST
 #endif
 #ifndef SWEEP_ST
-hipError_t launch_surface_flux(const SurfArgs &A, int slope_type, int riemann, int nvar, bool grav, hipStream_t s) {
+hipError_t launch_surface_flux(const SurfArgs &A, int slope_type, int riemann, int nvar, int scheme, bool grav, hipStream_t s) {
   if (A.nevent <= 0) return hipSuccess;
   switch (slope_type) {
-    case 1: return surface0<1>(A, riemann, nvar, grav, s);
+    case 1: return surface0<1>(A, riemann, nvar, scheme, grav, s);
 #ifndef SWEEP_FLAGSHIP_ONLY
-    case 0: return surface0<0>(A, riemann, nvar, grav, s);
-    case 2: return surface0<2>(A, riemann, nvar, grav, s);
-    case 7: return surface0<7>(A, riemann, nvar, grav, s);
-    case 8: return surface0<8>(A, riemann, nvar, grav, s);
+    case 0: return surface0<0>(A, riemann, nvar, scheme, grav, s);
+    case 2: return surface0<2>(A, riemann, nvar, scheme, grav, s);
+    case 3: return surface0<3>(A, riemann, nvar, scheme, grav, s);
+    case 7: return surface0<7>(A, riemann, nvar, scheme, grav, s);
+    case 8: return surface0<8>(A, riemann, nvar, scheme, grav, s);
 #endif
   }
   return hipErrorInvalidValue;
@@ -850,23 +908,27 @@ static hipError_t launch1(SweepArgs &A, int by, int scheme, int nvar, bool grav,
   if (A.stat) {
     // a level of a resident AMR run in tiles: the 12-row muscl kernels on the periodic box of the level, one workgroup per
     // work item (anything else: the caller keeps the tree-walking sweep)
-    if constexpr (ST != 3 && ST != 4 && ST != 5 && ST != 6) {
-      if (!A.dir || !A.work || A.ng != 0 || scheme != 0 || A.nwork <= 0) return hipErrorInvalidValue;
+    if constexpr (ST != 4 && ST != 5 && ST != 6) {
+      if (!A.dir || !A.work || A.ng != 0 || (scheme != 0 && scheme != 1) || A.nwork <= 0) return hipErrorInvalidValue;
       A.nblocks = A.nwork;
       A.nbox = 1;          // (the box decode runs, its result is replaced by the work item)
-      // the plan's work items were cut for tile_sweep_rows(riemann, nvar) interior rows: 8 (12-row workgroups), or 4 for the
-      // variants that need 256 registers -- the Newton solver and runs with passive scalars (round 6)
+      // the plan's work items were cut for tile_sweep_rows(...) interior rows: 8 (12-row workgroups), or 4 for the variants that
+      // need 256 registers -- the Newton solver, the 27-point slope, the PLMDE tracing, runs with passive scalars (round 6)
       if (by == 8) {
+        if (scheme == 1) {
+          if (nvar != 5) return hipErrorInvalidValue;
+          return grav ? launch3<ST, RS, 8, true, 1, 5, true>(A, s) : launch3<ST, RS, 8, false, 1, 5, true>(A, s);
+        }
         if (nvar == 5) {
-          if constexpr (RS == RIEMANN_EXACT) return grav ? launch3<ST, RS, 8, true, 0, 5, true>(A, s) : launch3<ST, RS, 8, false, 0, 5, true>(A, s);
+          if constexpr (RS == RIEMANN_EXACT || ST == 3) return grav ? launch3<ST, RS, 8, true, 0, 5, true>(A, s) : launch3<ST, RS, 8, false, 0, 5, true>(A, s);
           else return hipErrorInvalidValue;
         }
         if (nvar == 6) return grav ? launch3<ST, RS, 8, true, 0, 6, true>(A, s) : launch3<ST, RS, 8, false, 0, 6, true>(A, s);
         if (nvar == 7) return grav ? launch3<ST, RS, 8, true, 0, 7, true>(A, s) : launch3<ST, RS, 8, false, 0, 7, true>(A, s);
         return hipErrorInvalidValue;
       }
-      if constexpr (RS != RIEMANN_EXACT) {
-        if (by == TILE_SWEEP_BY && nvar == 5)
+      if constexpr (RS != RIEMANN_EXACT && ST != 3) {
+        if (by == TILE_SWEEP_BY && nvar == 5 && scheme == 0)
           return grav ? launch3<ST, RS, TILE_SWEEP_BY, true, 0, 5, true>(A, s) : launch3<ST, RS, TILE_SWEEP_BY, false, 0, 5, true>(A, s);
       }
       return hipErrorInvalidValue;
@@ -921,7 +983,9 @@ SWEEP_EXTERN_ST(7) SWEEP_EXTERN_ST(8)
 
 #ifndef SWEEP_ST
 // interior rows of a work item of the sweep of a level in tiles (the plan of csrc/capi_amr.hip cuts the level accordingly)
-int tile_sweep_rows(int riemann, int nvar) { return ((riemann == RIEMANN_EXACT || nvar != 5) ? 8 : TILE_SWEEP_BY) - 4; }
+int tile_sweep_rows(int riemann, int nvar, int slope_type, int scheme) {
+  return ((riemann == RIEMANN_EXACT || nvar != 5 || slope_type == 3 || scheme != 0) ? 8 : TILE_SWEEP_BY) - 4;
+}
 
 hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme, int nvar,
                                 bool grav, hipStream_t s) {

@@ -76,16 +76,16 @@ struct SurfArgs {
 };
 
 namespace strictmode {
-hipError_t launch_surface_flux(const SurfArgs &A, int slope_type, int riemann, int nvar, bool grav, hipStream_t s);
+hipError_t launch_surface_flux(const SurfArgs &A, int slope_type, int riemann, int nvar, int scheme, bool grav, hipStream_t s);
 hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme, int nvar,
                                 bool grav, hipStream_t s);
-int tile_sweep_rows(int riemann, int nvar);
+int tile_sweep_rows(int riemann, int nvar, int slope_type, int scheme);
 }
 namespace fastmode {
-hipError_t launch_surface_flux(const SurfArgs &A, int slope_type, int riemann, int nvar, bool grav, hipStream_t s);
+hipError_t launch_surface_flux(const SurfArgs &A, int slope_type, int riemann, int nvar, int scheme, bool grav, hipStream_t s);
 hipError_t launch_godunov_sweep(SweepArgs &A, int slope_type, int riemann, int by, int scheme, int nvar,
                                 bool grav, hipStream_t s);
-int tile_sweep_rows(int riemann, int nvar);
+int tile_sweep_rows(int riemann, int nvar, int slope_type, int scheme);
 }
 
 }  // namespace ramses_amd

@@ -114,11 +114,15 @@ def test_levels_in_tiles_equal_the_oracle(gpu_lib, oracle, monkeypatch, order, r
 
 
 @pytest.mark.parametrize("nvar,riemann,slope,grav,fast", [(7, "hllc", 1, False, False), (6, "llf", 2, True, False), (5, "exact", 1, False, False),
-                                                          (7, "hll", 8, True, True), (5, "exact", 2, True, True)])
+                                                          (7, "hll", 8, True, True), (5, "exact", 2, True, True),
+                                                          (5, "hllc", 3, False, False), (7, "llf", 3, True, False), (5, "acoustic", 3, True, True),
+                                                          (5, "plmde:llf", 1, False, False), (5, "plmde:hllc", 2, True, False),
+                                                          (5, "plmde:hll", 3, False, False), (5, "plmde:llf", 7, True, True)])
 def test_passive_scalars_and_the_newton_solver_on_tiles(gpu_lib, oracle, monkeypatch, nvar, riemann, slope, grav, fast):
     """Round 6 (missing #3): NVAR = 6 / 7 (passive scalars: interpolated in the ghost octs, in the flux records,
-    in the replay) and riemann = 'exact' take the levels in tiles as well -- the kernels of 8 rows (256 registers), the plan cut
-    into work items of 4 rows.  Strict arithmetic: the oracle bit for bit (the Newton solver: <= 1e-12, its pow() is the device's), no sweep through the
+    in the replay), riemann = 'exact', slope_type = 3 (the 27-point slope: the surface pass gathers the 3 x 3 x 3 neighbourhoods
+    of the two cells of an interface) and scheme = 'plmde' take the levels in tiles as well -- the kernels of 8 rows (256
+    registers), the plan cut into work items of 4 rows.  Strict arithmetic: the oracle bit for bit (the Newton solver: <= 1e-12, its pow() is the device's), no sweep through the
     tree; fast arithmetic: <= 1e-12."""
     import ramses_amd
     L = 6
@@ -130,7 +134,9 @@ def test_passive_scalars_and_the_newton_solver_on_tiles(gpu_lib, oracle, monkeyp
         uold[n, 1:] = uold[0, 1:] * rng.random(T["ncell"] - 1)          # passive scalars: density x a fraction in [0, 1)
         uold[n, 0] = uold[n, 1]
     f = rng.normal(size=(3, T["ncell"])) if grav else None
-    kw = dict(riemann=riemann, slope_type=slope, nvar=nvar)
+    scheme = "plmde" if riemann.startswith("plmde:") else "muscl"
+    riemann = riemann.split(":")[-1]
+    kw = dict(riemann=riemann, slope_type=slope, nvar=nvar, scheme=scheme)
     p, po = ramses_amd.make_params(fast_math=fast, **kw), oracle.make_params(**kw)
     lists = {L: T["igrid"], L + 1: T["igrid_fine"]}
     ref = _oracle_step(oracle, po, T, L, uold, f, lists, 1, 2)
