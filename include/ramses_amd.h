@@ -736,6 +736,20 @@ int ramses_amd_mgdist_force_f90(ramses_amd_mgdist *ctx, int ilevel, int ngrid, c
  * exchanges the virtual octs on the device (ramses_amd_amrres_halo_*, direction 7). */
 int ramses_amd_mgdist_force_resident_f90(ramses_amd_mgdist *M, int ilevel, int ngrid, const int *igrid, int64_t ngridmax,
                                          int64_t ncoarse, const double *rho, int nvector, double fact, double *diag);
+/* multigrid_fine of that level for a resident run with ONE level (levelmin = nlevelmax) and several ranks (round 6): the right-hand
+ * side is gathered on the device from rho_fine's deposit (ramses_amd_amrres_rho_keep(1) keeps it there;
+ * ramses_amd_amrres_rho_to_brick), the potential stays on the rank's brick for force_fine; ramses_amd_mgdist_fetch_phi_f90
+ * writes it into the host vector for backup_poisson (/root/reference/poisson/output_poisson.f90).  No level array crosses PCIe
+ * in a step.  ramses_amd_mgdist_traffic: bytes of rho (out2[0], host -> device) and phi (out2[1], device -> host) the Fortran
+ * entries of the distributed solve moved since the start. */
+int ramses_amd_mgdist_multigrid_resident_f90(ramses_amd_mgdist *M, int ilevel, int ngrid, const int *igrid, const double *xg,
+                                             int64_t ngridmax, const int *lo, double rho_tot, double fourpi, double epsilon,
+                                             int *safe_mode, int *iters, double *err);
+int ramses_amd_mgdist_fetch_phi_f90(ramses_amd_mgdist *M, int ngrid, const int *igrid, int64_t ngridmax, int64_t ncoarse, double *phi);
+int ramses_amd_mgdist_traffic(int64_t *out2);
+/* ramses_amd_mgdist_force_resident_f90 with the deposit on the device (rho = NULL there): the Fortran binding */
+int ramses_amd_mgdist_force_resident_dev_f90(ramses_amd_mgdist *M, int ilevel, int ngrid, const int *igrid, int64_t ngridmax,
+                                             int64_t ncoarse, int nvector, double fact, double *diag);
 /* host only (no device): the deep-halo plan ramses_amd_mgdist_create builds for one rank and a level whose bricks have
  * dims[3] cells inside ng ghost layers -- 26 send / receive regions (org x,y,z + ext x,y,z in allocated coordinates) with
  * their positions in the message buffers, and the messages (one per peer; the caller's own rank where the box wraps onto
@@ -839,6 +853,16 @@ int ramses_amd_amrres_f_traffic(int64_t *out2);
 /* Diagnostic (RAMSES_AMD_F_CHECK=1 in patch/force_fine.f90): the largest |device f - host f| over the listed octs and the
  * number of cells that differ. */
 int ramses_amd_amrres_compare_f(int ngrid, const int *igrid, const double *f, double *maxdiff, int64_t *ndiff);
+/* rho_fine's deposit of a resident run with several ranks (ramses_amd_amrres_rho_mpi_*): _rho_keep(1) leaves it on the device
+ * (ramses_amd_amrres_rho_mpi_finish skips the copy into the host vector), _sync_rho brings the listed octs back (backup_poisson),
+ * _rho_to_brick gathers the rank's own cells into a dense brick through an order list on the device
+ * (d_brick[d_order[ind * ngrid + g]] = rho of cell ind of oct igrid[g]), _rho_absmax returns max |rho| over them
+ * (/root/reference/poisson/force_fine.f90:177-181), _rho_traffic the bytes of rho that went back to the host since the start. */
+int ramses_amd_amrres_rho_keep(int on);
+int ramses_amd_amrres_sync_rho(int ngrid, const int *igrid, double *rho);
+int ramses_amd_amrres_rho_to_brick(int ngrid, const int *igrid, const int *d_order, double *d_brick);
+int ramses_amd_amrres_rho_absmax(int ngrid, const int *igrid, double *out);
+int64_t ramses_amd_amrres_rho_traffic(void);
 int ramses_amd_amrres_has_gravity(void);
 int ramses_amd_amrres_sync_density(int ngrid, const int *igrid, double *uold);
 int ramses_amd_amrres_synchro(const ramses_amd_hydro_params *p, int ngrid, const int *igrid, double dteff);

@@ -166,6 +166,10 @@ SYMBOLS = [
     ("ramses_amd_mgdist_plan", _i, [_vp, _i, _vp, _vp, _i] + [_vp] * 11),
     ("ramses_amd_mgdist_force_f90", _i, [_vp, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i, _d, _vp]),
     ("ramses_amd_mgdist_force_resident_f90", _i, [_vp, _i, _i, _vp, _i64, _i64, _vp, _i, _d, _vp]),
+    ("ramses_amd_mgdist_multigrid_resident_f90", _i, [_vp, _i, _i, _vp, _vp, _i64, _vp, _d, _d, _d, _vp, _vp, _vp]),
+    ("ramses_amd_mgdist_fetch_phi_f90", _i, [_vp, _i, _vp, _i64, _i64, _vp]),
+    ("ramses_amd_mgdist_traffic", _i, [_vp]),
+    ("ramses_amd_mgdist_force_resident_dev_f90", _i, [_vp, _i, _i, _vp, _i64, _i64, _i, _d, _vp]),
     ("ramses_amd_mgdist_multigrid_f90", _i, [_vp, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _vp]),
     ("ramses_amd_halo_plan", _i, [_i, _i, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     ("ramses_amd_mpires_setup", _i, [_PP, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
@@ -202,6 +206,11 @@ SYMBOLS = [
     ("ramses_amd_amrres_sync_f", _i, [_i, _vp, _vp]),
     ("ramses_amd_amrres_f_traffic", _i, [_vp]),
     ("ramses_amd_amrres_compare_f", _i, [_i, _vp, _vp, _vp, _vp]),
+    ("ramses_amd_amrres_rho_keep", _i, [_i]),
+    ("ramses_amd_amrres_sync_rho", _i, [_i, _vp, _vp]),
+    ("ramses_amd_amrres_rho_to_brick", _i, [_i, _vp, _vp, _vp]),
+    ("ramses_amd_amrres_rho_absmax", _i, [_i, _vp, _vp]),
+    ("ramses_amd_amrres_rho_traffic", _i64, []),
     ("ramses_amd_amrres_has_gravity", _i, []),
     ("ramses_amd_amrres_sync_density", _i, [_i, _vp, _vp]),
     ("ramses_amd_amrres_synchro", _i, [_PP, _i, _vp, _d]),

@@ -795,6 +795,8 @@ struct AmrRes {
   std::vector<LevelPlan> plan;
   long tile_sweeps = 0, tree_sweeps = 0;
   int64_t f_up_bytes = 0, f_down_bytes = 0;    // bytes of the acceleration that crossed PCIe (ramses_amd_amrres_f_traffic)
+  int64_t rho_down_bytes = 0;                  // bytes of the density deposit that went back to the host vector
+  bool rho_keep = false;                       // ramses_amd_amrres_rho_keep: rho_fine's deposit stays on the device
   long relayouts = 0;                          // regrids that had to lay the kept levels out again (tiles in the way of the finer levels)
   int err_pending = 0;                         // a tree-walking sweep has run since R.err was last read (the finest level it swept)
   bool announced = false;
@@ -928,12 +930,19 @@ static HydroConst make_const_amr(const ramses_amd_hydro_params *p) {
 
 extern "C" {
 
+extern "C" int ramses_amd_mgdist_traffic(int64_t *out2);
 // RAMSES_AMD_STATS=1: one line at exit with how godunov_fine of the AMR levels ran (tests and timing scripts read it)
 static void amrres_report(void) {
   const char *e = getenv("RAMSES_AMD_STATS");
   if (!e || e[0] == '0') return;
   if (g_ar.f_up_bytes + g_ar.f_down_bytes > 0)
     fprintf(stdout, " ramses_amd: acceleration f over PCIe: %lld bytes to the device, %lld bytes back\n", (long long)g_ar.f_up_bytes, (long long)g_ar.f_down_bytes);
+  {
+    int64_t t[2] = {0, 0};
+    if (ramses_amd_mgdist_traffic(t) == 0 && t[0] + t[1] > 0)
+      fprintf(stdout, " ramses_amd: distributed multigrid over PCIe: rho %lld bytes to the device, phi %lld bytes back\n", (long long)t[0], (long long)t[1]);
+  }
+  if (g_ar.rho_down_bytes > 0) fprintf(stdout, " ramses_amd: density deposit rho over PCIe: %lld bytes back\n", (long long)g_ar.rho_down_bytes);
   if (g_ar.tile_sweeps + g_ar.tree_sweeps == 0) { fflush(stdout); return; }
   fprintf(stdout, " ramses_amd: godunov_fine of AMR levels: %ld sweeps through the dense kernel on tiles (%ld of them fully refined levels), %ld through the tree-walking kernel; %ld levels in tiles at the end\n",
           g_ar.tile_sweeps, g_ar.covered_sweeps, g_ar.tree_sweeps, g_ar.map.on ? g_ar.map.tiles_levels : 0L);
@@ -1783,7 +1792,9 @@ int ramses_amd_amrres_rho_mpi_finish(int ilevel, int levelmin, int nvector, cons
       HCHK(hipMemcpyAsync(multipole4, R.red.p, sizeof(double) * 4, hipMemcpyDeviceToHost, s), "D2H multipole");
     }
   }
-  if (n > 0) {
+  // (ramses_amd_amrres_rho_keep(1): the solver and force_fine of this level read the deposit on the device -- the distributed
+  //  dense multigrid of a uniform run, round 6 -- and the host vector is fetched by ramses_amd_amrres_sync_rho when somebody asks)
+  if (n > 0 && !R.rho_keep) {
     const long tot = (long)n * 8;
     HCHK(R.pack.ensure(sizeof(double) * (size_t)tot), "hipMalloc");
     hipLaunchKernelGGL(lvl_pack_comp_kernel<true>, dim3(grid_for(tot)), dim3(256), 0, s, R.rho.as<double>(), R.pack.as<double>(), R.lists.as<int>(), n, 1,
@@ -1791,6 +1802,7 @@ int ramses_amd_amrres_rho_mpi_finish(int ilevel, int levelmin, int nvector, cons
     HCHK(hipGetLastError(), "rho pack launch");
     R.hpack.resize((size_t)tot);
     HCHK(hipMemcpy(R.hpack.data(), R.pack.p, sizeof(double) * (size_t)tot, hipMemcpyDeviceToHost), "D2H rho");
+    R.rho_down_bytes += (int64_t)sizeof(double) * tot;
     for (int ind = 0; ind < 8; ind++) {
       double *dst = rho + R.ncoarse + (size_t)ind * R.ngh - 1;
       const double *src = R.hpack.data() + (size_t)ind * n;
@@ -1800,6 +1812,79 @@ int ramses_amd_amrres_rho_mpi_finish(int ilevel, int levelmin, int nvector, cons
   HCHK(hipStreamSynchronize(s), "sync");
   return 0;
 }
+int ramses_amd_amrres_rho_keep(int on) { g_ar.rho_keep = on != 0; return 0; }
+// rho of the listed octs back into the host vector (backup_poisson; a solver that reads the host vector after all)
+int ramses_amd_amrres_sync_rho(int ngrid, const int *igrid, double *rho) {
+  AmrRes &R = g_ar;
+  LvlArgs A;
+  if (!rho) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  if (!R.rho.p) return failf(RAMSES_AMD_EINVAL, "sync_rho: rho_fine has not run on the device");
+  if (int rc = set_level(R, ngrid, igrid, A)) return rc;
+  if (ngrid == 0) return 0;
+  const long tot = (long)ngrid * 8;
+  HCHK(R.pack.ensure(sizeof(double) * (size_t)tot), "hipMalloc");
+  hipLaunchKernelGGL(lvl_pack_comp_kernel<true>, dim3(grid_for(tot)), dim3(256), 0, nullptr, R.rho.as<double>(), R.pack.as<double>(), R.cur_ig, ngrid, 1,
+                     R.ncell, R.ncoarse, R.ngridmax);
+  HCHK(hipGetLastError(), "rho pack launch");
+  R.hpack.resize((size_t)tot);
+  HCHK(hipMemcpy(R.hpack.data(), R.pack.p, sizeof(double) * (size_t)tot, hipMemcpyDeviceToHost), "D2H rho");
+  R.rho_down_bytes += (int64_t)sizeof(double) * tot;
+  for (int ind = 0; ind < 8; ind++) {
+    double *dst = rho + R.ncoarse + (size_t)ind * R.ngh - 1;
+    const double *src = R.hpack.data() + (size_t)ind * ngrid;
+    for (int i = 0; i < ngrid; i++) dst[igrid[i]] = src[i];
+  }
+  return 0;
+}
+// the deposit of the rank's own octs into a dense brick on the device: brick[order[ind * ngrid + g]] = rho(cell ind of oct igrid[g])
+// (order: the list of ramses_amd_mgdist_set_order); and max |rho| over those cells (force_fine's diagnostic, :177-181)
+namespace {
+__global__ __launch_bounds__(256) void rho_to_brick_kernel(const double *__restrict__ rho, const int *__restrict__ ig, const int *__restrict__ order, long ngrid,
+                                                           long ncoarse, long ngridmax, double *__restrict__ brick) {
+  const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < 8 * ngrid) brick[order[k]] = rho[ncoarse + (k / ngrid) * ngridmax + ig[k % ngrid] - 1];
+}
+__global__ __launch_bounds__(256) void rho_absmax_kernel(const double *__restrict__ rho, const int *__restrict__ ig, long ngrid, long ncoarse, long ngridmax,
+                                                         unsigned long long *__restrict__ out) {
+  double m = 0.0;
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < 8 * ngrid; k += (long)gridDim.x * blockDim.x)
+    m = fmax(m, fabs(rho[ncoarse + (k / ngrid) * ngridmax + ig[k % ngrid] - 1]));
+  // (non-negative doubles order like their bit patterns)
+  atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+}  // namespace
+int ramses_amd_amrres_rho_to_brick(int ngrid, const int *igrid, const int *d_order, double *d_brick) {
+  AmrRes &R = g_ar;
+  LvlArgs A;
+  if (!d_order || !d_brick) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  if (!R.rho.p) return failf(RAMSES_AMD_EINVAL, "rho_to_brick: rho_fine has not run on the device");
+  if (int rc = set_level(R, ngrid, igrid, A)) return rc;
+  if (ngrid == 0) return 0;
+  hipLaunchKernelGGL(rho_to_brick_kernel, dim3((unsigned)(((long)ngrid * 8 + 255) / 256)), dim3(256), 0, nullptr, R.rho.as<double>(), R.cur_ig, d_order, (long)ngrid,
+                     R.ncoarse, R.ngridmax, d_brick);
+  HCHK(hipGetLastError(), "rho -> brick launch");
+  return 0;
+}
+int ramses_amd_amrres_rho_absmax(int ngrid, const int *igrid, double *out) {
+  AmrRes &R = g_ar;
+  LvlArgs A;
+  if (!out) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  *out = 0.0;
+  if (!R.rho.p) return failf(RAMSES_AMD_EINVAL, "rho_absmax: rho_fine has not run on the device");
+  if (int rc = set_level(R, ngrid, igrid, A)) return rc;
+  if (ngrid == 0) return 0;
+  HCHK(R.okbuf.ensure(sizeof(unsigned long long) * 2), "hipMalloc");
+  unsigned long long *d = reinterpret_cast<unsigned long long *>(R.okbuf.p);
+  HCHK(hipMemsetAsync(d, 0, sizeof(unsigned long long), nullptr), "memset");
+  hipLaunchKernelGGL(rho_absmax_kernel, dim3(grid_for((long)ngrid * 8)), dim3(256), 0, nullptr, R.rho.as<double>(), R.cur_ig, (long)ngrid, R.ncoarse, R.ngridmax, d);
+  HCHK(hipGetLastError(), "max |rho| launch");
+  unsigned long long bits = 0;
+  HCHK(hipMemcpy(&bits, d, sizeof(bits), hipMemcpyDeviceToHost), "D2H");
+  memcpy(out, &bits, sizeof(double));
+  return 0;
+}
+// bytes of rho_fine's deposit that went back to the host vector since the start
+int64_t ramses_amd_amrres_rho_traffic(void) { return g_ar.rho_down_bytes; }
 
 // the density uold(:,1) of one level's cells back into the host array (rho_fine's multipole_fine reads nothing else)
 int ramses_amd_amrres_sync_density(int ngrid, const int *igrid, double *uold) {

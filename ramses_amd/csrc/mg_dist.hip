@@ -590,6 +590,8 @@ int ramses_amd_mgdist_force(ramses_amd_mgdist *M, double *d_f, void *stream) {
 // The Fortran shim's side: the reference's own arrays (rho, phi as cell vectors; the rank's octs of the level).
 // ---------------------------------------------------------------------------
 namespace {
+std::vector<int> g_h_order;          // the order list as the host built it last (uploaded again only when it changes)
+int64_t g_phi_bytes = 0, g_rho_up_bytes = 0;   // what the Fortran entries moved over PCIe (ramses_amd_mgdist_traffic)
 // integer position (in cells of the level) of an oct's first cell, from its centre xg (amr/amr_commons.f90:67-75)
 inline bool oct_cell_origin(const double *xg, int64_t ngridmax, int ig, int n, int *o) {
   for (int d = 0; d < 3; d++) {
@@ -709,6 +711,7 @@ int ramses_amd_mgdist_multigrid_f90(ramses_amd_mgdist *M, int ilevel, int ngrid,
   HCHK(d_rho.ensure(sizeof(double) * N), "hipMalloc");
   HCHK(d_phi.ensure(sizeof(double) * N), "hipMalloc");
   HCHK(hipMemcpyAsync(d_rho.p, h_brick.data(), sizeof(double) * N, hipMemcpyHostToDevice, s), "H2D rho");
+  g_rho_up_bytes += (int64_t)sizeof(double) * N;
   {
     // the convergence test sums the squared residuals as cmp_residual_norm2_fine does: octant by octant over this very list
     static std::vector<int> order;
@@ -717,12 +720,14 @@ int ramses_amd_mgdist_multigrid_f90(ramses_amd_mgdist *M, int ilevel, int ngrid,
       for (int g = 0; g < ngrid; g++)
         order[(size_t)ind * ngrid + g] = (int)(org[g] + (ind & 1) + py * ((ind >> 1) & 1) + pz * ((ind >> 2) & 1));
     RCHK(ramses_amd_mgdist_set_order(M, order.data(), N));
+    g_h_order = order;
   }
   M->safe_mode = *safe_mode ? 1 : 0;
   RCHK(ramses_amd_mgdist_solve(M, reinterpret_cast<const double *>(d_rho.p), rho_tot, fourpi, epsilon, iters, err, s));
   *safe_mode = M->safe_mode;
   RCHK(ramses_amd_mgdist_get_phi(M, reinterpret_cast<double *>(d_phi.p), s));
   HCHK(hipMemcpyAsync(h_brick.data(), d_phi.p, sizeof(double) * N, hipMemcpyDeviceToHost, s), "D2H phi");
+  g_phi_bytes += (int64_t)sizeof(double) * N;
   HCHK(hipStreamSynchronize(s), "sync");
   // phi of the rank's own cells into the cell vector (the other cells keep the host's values)
   for (int g = 0; g < ngrid; g++)
@@ -794,6 +799,81 @@ int ramses_amd_mgdist_force_f90(ramses_amd_mgdist *M, int ilevel, int ngrid, con
 }
 
 
+// multigrid_fine of the same level for a run whose cell vectors are resident and that has ONE level (levelmin = nlevelmax: nobody
+// interpolates from this potential, nobody refines it): the right-hand side comes from rho_fine's deposit on the device
+// (ramses_amd_amrres_rho_to_brick through the order list), the potential stays on the rank's brick -- force_fine differentiates
+// it there, ramses_amd_mgdist_fetch_phi_f90 brings it to the host vector for backup_poisson.  No level array crosses PCIe.
+extern "C" int ramses_amd_amrres_rho_to_brick(int ngrid, const int *igrid, const int *d_order, double *d_brick);
+extern "C" int ramses_amd_amrres_rho_absmax(int ngrid, const int *igrid, double *out);
+namespace {
+int build_order(ramses_amd_mgdist *M, int ilevel, int ngrid, const int *igrid, const double *xg, int64_t ngridmax, const int *lo) {
+  const int n = 1 << ilevel;
+  const long N = (long)ngrid * 8;
+  const long py = M->dims[0], pz = (long)M->dims[0] * M->dims[1];
+  static std::vector<int> order;
+  order.resize((size_t)N);
+  for (int g = 0; g < ngrid; g++) {
+    int o[3];
+    if (!oct_cell_origin(xg, ngridmax, igrid[g], n, o)) return failf(RAMSES_AMD_EINVAL, "oct %d of level %d does not sit on the level lattice", igrid[g], ilevel);
+    for (int d = 0; d < 3; d++) {
+      o[d] -= lo[d];
+      if (o[d] < 0 || o[d] + 2 > M->dims[d]) return failf(RAMSES_AMD_EINVAL, "oct %d lies outside the rank's box", igrid[g]);
+    }
+    const long org = o[0] + py * o[1] + pz * o[2];
+    for (int ind = 0; ind < 8; ind++) order[(size_t)ind * ngrid + g] = (int)(org + (ind & 1) + py * ((ind >> 1) & 1) + pz * ((ind >> 2) & 1));
+  }
+  if (M->order_n == N && M->d_order && g_h_order.size() == (size_t)N && memcmp(g_h_order.data(), order.data(), sizeof(int) * (size_t)N) == 0) return 0;
+  RCHK(ramses_amd_mgdist_set_order(M, order.data(), N));
+  g_h_order = order;
+  return 0;
+}
+}  // namespace
+int ramses_amd_mgdist_multigrid_resident_f90(ramses_amd_mgdist *M, int ilevel, int ngrid, const int *igrid, const double *xg, int64_t ngridmax,
+                                             const int *lo, double rho_tot, double fourpi, double epsilon, int *safe_mode, int *iters, double *err) {
+  if (!M || !igrid || !xg || !lo || !safe_mode) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  if (ilevel != M->level) return failf(RAMSES_AMD_EINVAL, "context built for level %d, called for level %d", M->level, ilevel);
+  const long N = (long)M->dims[0] * M->dims[1] * M->dims[2];
+  if ((long)ngrid * 8 != N) return failf(RAMSES_AMD_EINVAL, "the rank holds %d octs, its brick %ld cells", ngrid, N);
+  for (int d = 0; d < 3; d++)
+    if (lo[d] != M->coords[d] * M->dims[d]) return failf(RAMSES_AMD_EINVAL, "the rank's box does not start where its brick does");
+  hipStream_t s = nullptr;
+  static DevArr d_rho;
+  HCHK(d_rho.ensure(sizeof(double) * N), "hipMalloc");
+  if (int rc = build_order(M, ilevel, ngrid, igrid, xg, ngridmax, lo)) return rc;
+  RCHK(ramses_amd_amrres_rho_to_brick(ngrid, igrid, M->d_order, reinterpret_cast<double *>(d_rho.p)));
+  M->safe_mode = *safe_mode ? 1 : 0;
+  RCHK(ramses_amd_mgdist_solve(M, reinterpret_cast<const double *>(d_rho.p), rho_tot, fourpi, epsilon, iters, err, s));
+  *safe_mode = M->safe_mode;
+  HCHK(hipStreamSynchronize(s), "sync");
+  return 0;
+}
+// phi of the rank's own cells from the brick into the host vector (backup_poisson; the caller refreshes the virtual octs)
+int ramses_amd_mgdist_fetch_phi_f90(ramses_amd_mgdist *M, int ngrid, const int *igrid, int64_t ngridmax, int64_t ncoarse, double *phi) {
+  if (!M || !igrid || !phi) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  const long N = (long)M->dims[0] * M->dims[1] * M->dims[2];
+  if ((long)ngrid * 8 != N || g_h_order.size() != (size_t)N) return failf(RAMSES_AMD_EINVAL, "fetch_phi: not the list of the last solve");
+  hipStream_t s = nullptr;
+  static DevArr d_phi;
+  static std::vector<double> h;
+  HCHK(d_phi.ensure(sizeof(double) * N), "hipMalloc");
+  h.resize((size_t)N);
+  RCHK(ramses_amd_mgdist_get_phi(M, reinterpret_cast<double *>(d_phi.p), s));
+  HCHK(hipMemcpyAsync(h.data(), d_phi.p, sizeof(double) * N, hipMemcpyDeviceToHost, s), "D2H phi");
+  HCHK(hipStreamSynchronize(s), "sync");
+  g_phi_bytes += (int64_t)sizeof(double) * N;
+  for (int ind = 0; ind < 8; ind++)
+    for (int g = 0; g < ngrid; g++) phi[ncoarse + (long)ind * ngridmax + (igrid[g] - 1)] = h[(size_t)g_h_order[(size_t)ind * ngrid + g]];
+  return 0;
+}
+int ramses_amd_mgdist_force_resident_dev_f90(ramses_amd_mgdist *M, int ilevel, int ngrid, const int *igrid, int64_t ngridmax, int64_t ncoarse,
+                                             int nvector, double fact, double *diag);
+// bytes of rho (host -> device) and phi (device -> host) the Fortran entries of the distributed solve moved since the start
+int ramses_amd_mgdist_traffic(int64_t *out2) {
+  if (!out2) return failf(RAMSES_AMD_EINVAL, "NULL argument");
+  out2[0] = g_rho_up_bytes; out2[1] = g_phi_bytes;
+  return 0;
+}
+
 // The same for a run whose cell vectors are resident (ramses_amd_amrres_*), on a level without finer octs (every cell a leaf:
 // a uniform self-gravitating run): f goes from the brick into the resident acceleration ON THE DEVICE -- gathered into the
 // packed order [3][8][ngrid] through the order list of the solve (ramses_amd_mgdist_set_order: octant by octant over igrid) and
@@ -827,7 +907,8 @@ __global__ __launch_bounds__(256) void mgdist_epot_terms_kernel(const double *__
 }  // namespace
 int ramses_amd_mgdist_force_resident_f90(ramses_amd_mgdist *M, int ilevel, int ngrid, const int *igrid, int64_t ngridmax, int64_t ncoarse,
                                          const double *rho, int nvector, double fact, double *diag) {
-  if (!M || !igrid || !rho || !diag || nvector < 1) return failf(RAMSES_AMD_EINVAL, "bad argument");
+  // (rho = NULL: the deposit lives on the device -- ramses_amd_amrres_rho_keep -- and max |rho| is taken there)
+  if (!M || !igrid || !diag || nvector < 1) return failf(RAMSES_AMD_EINVAL, "bad argument");
   if (ilevel != M->level) return failf(RAMSES_AMD_EINVAL, "context built for level %d, called for level %d", M->level, ilevel);
   if (!M->phi_fresh) return failf(RAMSES_AMD_EINVAL, "force_fine: the context holds no potential (ramses_amd_mgdist_multigrid_f90 first)");
   const long N = (long)M->dims[0] * M->dims[1] * M->dims[2];
@@ -849,14 +930,24 @@ int ramses_amd_mgdist_force_resident_f90(ramses_amd_mgdist *M, int ilevel, int n
   double epot = 0.0;
   HCHK(hipMemcpyAsync(&epot, d_out.p, sizeof(double), hipMemcpyDeviceToHost, s), "D2H epot");
   double rmax = 0.0;
-  for (int ind = 0; ind < 8; ind++) {
-    const double *r = rho + ncoarse + (long)ind * ngridmax - 1;
-    for (int g = 0; g < ngrid; g++) rmax = std::max(rmax, std::fabs(r[igrid[g]]));
+  if (rho) {
+    for (int ind = 0; ind < 8; ind++) {
+      const double *r = rho + ncoarse + (long)ind * ngridmax - 1;
+      for (int g = 0; g < ngrid; g++) rmax = std::max(rmax, std::fabs(r[igrid[g]]));
+    }
+  } else {
+    RCHK(ramses_amd_amrres_rho_absmax(ngrid, igrid, &rmax));
   }
   HCHK(hipStreamSynchronize(s), "sync");
   diag[0] = epot;
   diag[1] = rmax;
   return 0;
+}
+
+// (the Fortran binding of the case rho = NULL: the deposit lives on the device)
+int ramses_amd_mgdist_force_resident_dev_f90(ramses_amd_mgdist *M, int ilevel, int ngrid, const int *igrid, int64_t ngridmax, int64_t ncoarse,
+                                             int nvector, double fact, double *diag) {
+  return ramses_amd_mgdist_force_resident_f90(M, ilevel, ngrid, igrid, ngridmax, ncoarse, nullptr, nvector, fact, diag);
 }
 
 }  // extern "C"

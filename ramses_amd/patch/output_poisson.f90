@@ -22,7 +22,11 @@ subroutine backup_poisson(filename)
      rc=ramses_amd_resident_sync_poisson_f90(phi,f,rho)
      if(rc/=0)call ramses_amd_fatal('backup_poisson (sync of the resident level)')
      ! the acceleration of the levels force_fine left on the device only (several ranks: patch/force_fine.f90)
-     if(ramses_amd_amr_resident())call ramses_amd_amr_sync_f()
+     if(ramses_amd_amr_resident())then
+        call ramses_amd_amr_sync_f()
+        ! rho and phi of a one-level run under the distributed dense multigrid (ramses_amd_iface: ramses_amd_pois_mpi_dev)
+        call ramses_amd_pois_mpi_sync_host(.false.)
+     end if
   end if
   call backup_poisson_reference(filename)
 end subroutine backup_poisson

@@ -90,6 +90,53 @@ module ramses_amd_cabi
        real(c_double) :: diag(2)
        integer(c_int) :: rc
      end function ramses_amd_mgdist_force_f90
+     function ramses_amd_mgdist_multigrid_resident_f90(ctx, ilevel, ngrid, igrid, xg, ngridmax, lo, rho_tot, fourpi, epsilon, &
+          & safe_mode, iters, err) bind(C, name='ramses_amd_mgdist_multigrid_resident_f90') result(rc)
+       import :: c_int, c_int64_t, c_double, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: ilevel, ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: xg(*)
+       integer(c_int64_t), value :: ngridmax
+       integer(c_int) :: lo(3)
+       real(c_double), value :: rho_tot, fourpi, epsilon
+       integer(c_int) :: safe_mode, iters
+       real(c_double) :: err
+       integer(c_int) :: rc
+     end function ramses_amd_mgdist_multigrid_resident_f90
+     function ramses_amd_mgdist_fetch_phi_f90(ctx, ngrid, igrid, ngridmax, ncoarse, phi) &
+          & bind(C, name='ramses_amd_mgdist_fetch_phi_f90') result(rc)
+       import :: c_int, c_int64_t, c_double, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: ngrid
+       integer(c_int) :: igrid(*)
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       real(c_double) :: phi(*)
+       integer(c_int) :: rc
+     end function ramses_amd_mgdist_fetch_phi_f90
+     function ramses_amd_mgdist_force_resident_dev_f90(ctx, ilevel, ngrid, igrid, ngridmax, ncoarse, nvec, fact, diag) &
+          & bind(C, name='ramses_amd_mgdist_force_resident_dev_f90') result(rc)
+       import :: c_int, c_int64_t, c_double, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: ilevel, ngrid, nvec
+       integer(c_int) :: igrid(*)
+       integer(c_int64_t), value :: ngridmax, ncoarse
+       real(c_double), value :: fact
+       real(c_double) :: diag(2)
+       integer(c_int) :: rc
+     end function ramses_amd_mgdist_force_resident_dev_f90
+     function ramses_amd_amrres_rho_keep(on) bind(C, name='ramses_amd_amrres_rho_keep') result(rc)
+       import :: c_int
+       integer(c_int), value :: on
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_rho_keep
+     function ramses_amd_amrres_sync_rho(ngrid, igrid, rho) bind(C, name='ramses_amd_amrres_sync_rho') result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: ngrid
+       integer(c_int) :: igrid(*)
+       real(c_double) :: rho(*)
+       integer(c_int) :: rc
+     end function ramses_amd_amrres_sync_rho
      function ramses_amd_mgdist_force_resident_f90(ctx, ilevel, ngrid, igrid, ngridmax, ncoarse, rho, nvec, fact, diag) &
           & bind(C, name='ramses_amd_mgdist_force_resident_f90') result(rc)
        import :: c_int, c_int64_t, c_double, c_ptr

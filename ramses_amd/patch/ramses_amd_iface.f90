@@ -46,6 +46,11 @@ module ramses_amd_iface
   integer, save :: ramses_amd_comm_epoch(1:64) = 1
   ! levels whose acceleration force_fine left on the device only (several ranks, resident cell vectors: patch/force_fine.f90)
   logical, save :: ramses_amd_f_on_device(1:64) = .false.
+  ! a run with ONE level (levelmin = nlevelmax), several ranks, the distributed dense multigrid and resident cell vectors, from its
+  ! second solve on: rho_fine's deposit stays on the device, the solve reads it there, phi stays on the rank's brick
+  ! (ramses_amd_mgdist_multigrid); ramses_amd_pois_mpi_sync_host brings both to the host vectors for backup_poisson / load_balance
+  logical, save :: ramses_amd_pois_mpi_dev = .false.
+  logical, save :: ramses_amd_phi_on_device = .false.
   logical, save :: ramses_amd_amr_halo_ready = .false.
   ! the AMR level whose potential the device multigrid driver has just left on the device (0: none)
   integer, save :: ramses_amd_pois_amr_level = 0
@@ -752,6 +757,48 @@ contains
     ramses_amd_f_on_device(l) = .false.
   end subroutine ramses_amd_amr_sync_f_level
 
+  ! RAMSES_AMD_PHI_RESIDENT=0: rho and phi of such a run keep crossing PCIe around every solve (the path before round 6)
+  logical function ramses_amd_phi_resident_on()
+    character(len=16) :: val
+    integer :: stat
+    logical, save :: first = .true., on = .true.
+    if (first) then
+       call get_environment_variable('RAMSES_AMD_PHI_RESIDENT', val, status=stat)
+       if (stat == 0) then
+          if (trim(val) == '0') on = .false.
+       end if
+       first = .false.
+    end if
+    ramses_amd_phi_resident_on = on
+  end function ramses_amd_phi_resident_on
+
+  ! rho and phi of levelmin back into the host vectors (backup_poisson, load_balance, a solve that reads the host vectors after
+  ! all); off = .true.: the steady state ends here (rho_fine copies its deposit back again, the solve takes the host vectors)
+  subroutine ramses_amd_pois_mpi_sync_host(off)
+    use amr_commons
+    use poisson_commons, only: rho, phi
+    logical, intent(in) :: off
+    integer :: rc, nl
+    integer, allocatable :: list(:)
+    if (ramses_amd_pois_mpi_dev .and. ramses_amd_amrres_active() /= 0 .and. numbtot(1, levelmin) > 0) then
+       call ramses_amd_amr_level_octs(levelmin, nl, list)
+       rc = ramses_amd_amrres_sync_rho(nl, list, rho)
+       deallocate(list)
+       if (rc /= 0) call ramses_amd_fatal('density deposit back to the host vector')
+    end if
+    if (ramses_amd_phi_on_device .and. c_associated(ramses_amd_mgdist_ctx)) then
+       rc = ramses_amd_mgdist_fetch_phi_f90(ramses_amd_mgdist_ctx, active(levelmin)%ngrid, ramses_amd_octs(levelmin), &
+            & int(ngridmax, 8), int(ncoarse, 8), phi)
+       if (rc /= 0) call ramses_amd_fatal('potential back to the host vector')
+       call make_virtual_fine_dp(phi(1), levelmin)
+    end if
+    if (off) then
+       ramses_amd_pois_mpi_dev = .false.
+       ramses_amd_phi_on_device = .false.
+       rc = ramses_amd_amrres_rho_keep(0)
+    end if
+  end subroutine ramses_amd_pois_mpi_sync_host
+
   logical function ramses_amd_amr_resident()
     ramses_amd_amr_resident = .false.
     if (ramses_amd_amr_armed) ramses_amd_amr_resident = ramses_amd_amr_config()
@@ -892,6 +939,7 @@ contains
        end if
     end do
     call ramses_amd_amr_sync_f()
+    call ramses_amd_pois_mpi_sync_host(.true.)
     rc = ramses_amd_amrres_invalidate()
     if (rc /= 0) call ramses_amd_fatal('AMR residency (invalidate before '//where//')')
     ramses_amd_amr_reload_from = 1000
@@ -1434,6 +1482,7 @@ contains
     call MPI_ALLGATHER(mine, 7, MPI_INTEGER, every, 7, MPI_INTEGER, MPI_COMM_WORLD, info)
     if (any(every(7, :) == -1)) then
        deallocate(every, rob)
+       call ramses_amd_pois_mpi_sync_host(.true.)
        return
     end if
     fit = all(every(7, :) == 1)
@@ -1466,6 +1515,7 @@ contains
             & ' are not equal power-of-two boxes of >= 64 cells: multigrid of AMR levels'
        ramses_amd_mgdist_said = .true.
        deallocate(every, rob)
+       call ramses_amd_pois_mpi_sync_host(.true.)
        return
     end if
     ! (re)build the context when the decomposition changed (load balancing)
@@ -1502,11 +1552,26 @@ contains
     if (cosmo) fourpi = 1.5D0*omega_m*aexp*scale
     isafe = 0
     if (safe_mode(ilevel)) isafe = 1
-    rc = ramses_amd_mgdist_multigrid_f90(ramses_amd_mgdist_ctx, ilevel, active(ilevel)%ngrid, ramses_amd_octs(ilevel), xg, &
-         & int(ngridmax, 8), int(ncoarse, 8), lo, rho, phi, rho_tot, fourpi, epsilon, isafe, iters, err)
-    if (rc /= 0) call ramses_amd_fatal('multigrid_fine (distributed dense multigrid)')
-    safe_mode(ilevel) = (isafe /= 0)
-    call make_virtual_fine_dp(phi(1), ilevel)
+    if (ramses_amd_pois_mpi_dev) then
+       ! the steady state of a one-level run: the right-hand side from the deposit on the device, phi stays on the brick
+       rc = ramses_amd_mgdist_multigrid_resident_f90(ramses_amd_mgdist_ctx, ilevel, active(ilevel)%ngrid, ramses_amd_octs(ilevel), xg, &
+            & int(ngridmax, 8), lo, rho_tot, fourpi, epsilon, isafe, iters, err)
+       if (rc /= 0) call ramses_amd_fatal('multigrid_fine (distributed dense multigrid, resident rho / phi)')
+       safe_mode(ilevel) = (isafe /= 0)
+       ramses_amd_phi_on_device = .true.
+    else
+       rc = ramses_amd_mgdist_multigrid_f90(ramses_amd_mgdist_ctx, ilevel, active(ilevel)%ngrid, ramses_amd_octs(ilevel), xg, &
+            & int(ngridmax, 8), int(ncoarse, 8), lo, rho, phi, rho_tot, fourpi, epsilon, isafe, iters, err)
+       if (rc /= 0) call ramses_amd_fatal('multigrid_fine (distributed dense multigrid)')
+       safe_mode(ilevel) = (isafe /= 0)
+       call make_virtual_fine_dp(phi(1), ilevel)
+       ramses_amd_phi_on_device = .false.
+       ! from the next solve on (the deposit of THIS step is already in the host vector)
+       if (levelmin == nlevelmax .and. ramses_amd_amr_resident() .and. ramses_amd_f_resident_on() &
+            & .and. ramses_amd_phi_resident_on()) then
+          if (ramses_amd_amrres_active() /= 0) ramses_amd_pois_mpi_dev = .true.
+       end if
+    end if
     ramses_amd_mgdist_phi_level = ilevel
     ramses_amd_mgdist_lo = lo
     ok = .true.
@@ -1551,8 +1616,13 @@ contains
     end if
     if (resident_f) then
        call ramses_amd_amr_ensure()
-       rc = ramses_amd_mgdist_force_resident_f90(ramses_amd_mgdist_ctx, ilevel, active(ilevel)%ngrid, ramses_amd_octs(ilevel), &
-            & int(ngridmax, 8), int(ncoarse, 8), rho, nvector, fact, diag)
+       if (ramses_amd_pois_mpi_dev .and. ramses_amd_phi_on_device) then
+          rc = ramses_amd_mgdist_force_resident_dev_f90(ramses_amd_mgdist_ctx, ilevel, active(ilevel)%ngrid, &
+               & ramses_amd_octs(ilevel), int(ngridmax, 8), int(ncoarse, 8), nvector, fact, diag)
+       else
+          rc = ramses_amd_mgdist_force_resident_f90(ramses_amd_mgdist_ctx, ilevel, active(ilevel)%ngrid, ramses_amd_octs(ilevel), &
+               & int(ngridmax, 8), int(ncoarse, 8), rho, nvector, fact, diag)
+       end if
        if (rc /= 0) call ramses_amd_fatal('force_fine (distributed dense multigrid, resident f)')
        call ramses_amd_amr_halo(ilevel, 7)
        ramses_amd_f_on_device(ilevel) = .true.

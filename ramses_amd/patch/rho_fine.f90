@@ -226,6 +226,11 @@ subroutine ramses_amd_rho_fine_mpi(ilevel,icount)
   type(ramses_amd_hydro_params)::p
   if(ilevel==levelmin.or.icount>1)then
      call ramses_amd_fill_hydro_params(p)
+     ! (the steady state of a one-level run under the distributed dense multigrid: the deposit stays on the device, where the
+     !  solve and force_fine read it -- ramses_amd_iface: ramses_amd_pois_mpi_dev)
+     k=0
+     if(ramses_amd_pois_mpi_dev)k=1
+     rc=ramses_amd_amrres_rho_keep(k)
      do l=nlevelmax,ilevel,-1
         if(numbtot(1,l)==0)cycle
         call ramses_amd_amr_level_octs(l,nl,list)

@@ -85,6 +85,20 @@ def test_uniform_self_gravity_under_mpi_equals_the_mpi_reference(gpu_lib, level,
     # (own + virtual octs: the virtual ones are a shell around each rank's box, < 60 % on top at these sizes)
     assert up <= 2 * 1.6 * octs * 8 * 3 * 8, (up, octs)      # the load of the start-up (the image is built twice there), nothing per step
     assert 0 < down <= 1.6 * octs * 8 * 3 * 8 * 2, (down, octs)      # at most the two snapshots
+    def poisson_traffic(text):
+        """(rho to the device, phi back, rho back) summed over the ranks: the exit lines of RAMSES_AMD_STATS=1"""
+        mg = [[int(a), int(b)] for a, b in re.findall(r"distributed multigrid over PCIe: rho\s*(\d+) bytes to the device, phi\s*(\d+) bytes back", text)]
+        rd = [int(a) for a in re.findall(r"density deposit rho over PCIe:\s*(\d+) bytes back", text)]
+        return sum(t[0] for t in mg), sum(t[1] for t in mg), sum(rd)
+
+    if dist == "1":
+        # rho and phi of this one-level run: the solves of the start-up take the host vectors (initialisation, the step that
+        # builds the device image, the step after it: a brick of rho up and one of phi back each), every later one reads the
+        # deposit on the device and leaves phi on the brick; backup_poisson fetches both once
+        rho_up, phi_down, rho_down = poisson_traffic(out)
+        cells = 8 ** level
+        assert 0 < rho_up <= 3 * 8 * cells and 0 < phi_down <= 4 * 8 * cells, (rho_up, phi_down, cells)
+        assert rho_down <= 3 * 1.6 * 8 * cells, (rho_down, cells)
     if (level, nproc, dist) == (7, 2, "1"):
         # ... whatever the number of steps: twice as many steps, the same bytes
         work2, out2 = _run(nml.replace("nstepmax=3", "nstepmax=6").replace("foutput=3", "foutput=6"), PATCHED_MPI, nproc,
@@ -93,6 +107,15 @@ def test_uniform_self_gravity_under_mpi_equals_the_mpi_reference(gpu_lib, level,
         assert "nstepmax=3" in nml and "Main step=      6" in out2, out2[-1500:]
         traffic2 = [[int(a), int(b)] for a, b in re.findall(r"acceleration f over PCIe:\s*(\d+) bytes to the device,\s*(\d+) bytes back", out2)]
         assert sum(t[0] for t in traffic2) == up, (traffic2, traffic)
+        assert poisson_traffic(out2) == poisson_traffic(out), (poisson_traffic(out2), poisson_traffic(out))
+        # and the switch gives the path before round 6 back: a brick of rho up and one of phi back per solve
+        work3, out3 = _run(nml, PATCHED_MPI, nproc, {"RAMSES_AMD": "1", "RAMSES_AMD_MG_DIST": dist, "RAMSES_AMD_STATS": "1", "RAMSES_AMD_PHI_RESIDENT": "0"})
+        try:
+            got3 = rs.load_uniform_level(os.path.join(work3, "output_00002"), level, with_grav=True)
+        finally:
+            shutil.rmtree(work3, ignore_errors=True)
+        assert poisson_traffic(out3)[0] >= 3 * 8 * cells
+        assert np.array_equal(got3["grav"], ref["grav"]) and np.array_equal(got3["prim"], ref["prim"])
     said = "distributed over" in out
     assert said == (dist == "1"), out[-2000:]
     # round 4: the hydro state of a uniform self-gravitating level stays on the ranks' GPUs too (cell vectors + tree resident,
