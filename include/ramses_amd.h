@@ -827,6 +827,11 @@ int ramses_amd_amrres_active(void);
 int ramses_amd_amrres_load(int nvar, int64_t ngridmax, int64_t ncoarse, const double *uold, const int *son, const int *nbor,
                            const int *father);
 int ramses_amd_amrres_tree(const int *son, const int *nbor, const int *father);
+/* The coarsest level the last ramses_amd_amrres_tree (or _load) numbered again on the device: its octs and those of every finer
+ * level have new device indices and NO data -- the caller sends them again (ramses_amd_amrres_load_level, _load_f) before
+ * anything reads them, as refine_fine's shim does (patch/ramses_amd_iface.f90: ramses_amd_amr_reload_from); the coarser
+ * levels keep indices, data and sweep plans.  nlev + 1: nothing changed; 0: the host's numbering is in force. */
+int ramses_amd_amrres_first_changed(void);
 int ramses_amd_amrres_invalidate(void);
 int ramses_amd_amrres_sync_level(int ngrid, const int *igrid, double *uold);
 int ramses_amd_amrres_load_level(int ngrid, const int *igrid, const double *uold);

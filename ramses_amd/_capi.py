@@ -193,6 +193,7 @@ SYMBOLS = [
     ("ramses_amd_amrres_active", _i, []),
     ("ramses_amd_amrres_load", _i, [_i, _i64, _i64, _vp, _vp, _vp, _vp]),
     ("ramses_amd_amrres_tree", _i, [_vp, _vp, _vp]),
+    ("ramses_amd_amrres_first_changed", _i, []),
     ("ramses_amd_amrres_invalidate", _i, []),
     ("ramses_amd_amrres_sync_level", _i, [_i, _vp, _vp]),
     ("ramses_amd_amrres_load_level", _i, [_i, _vp, _vp]),

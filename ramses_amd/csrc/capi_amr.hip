@@ -1517,6 +1517,10 @@ extern "C" int64_t ramses_amd_amrres_tile_sweeps(void) { return g_ar.tile_sweeps
 extern "C" int64_t ramses_amd_amrres_tree_sweeps(void) { return g_ar.tree_sweeps; }
 // regrids after which the levels that had kept their layout were laid out again, their state moved on the device
 extern "C" int64_t ramses_amd_amrres_relayouts(void) { return g_ar.relayouts; }
+// the coarsest level the last ramses_amd_amrres_tree / _load numbered again (its octs and those of every finer level have new device
+// indices: the caller reloads them -- ramses_amd_amrres_load_level, _load_f -- before anything reads them; the levels below keep
+// indices and data); nlev + 1: none.  0: the host's numbering is in force (every call keeps every index).
+extern "C" int ramses_amd_amrres_first_changed(void) { return g_ar.valid && g_ar.map.on ? g_ar.map.first_changed : 0; }
 // levels the device stores in tiles (0: the host's numbering is in force)
 extern "C" int ramses_amd_amrres_tiled_levels(void) { return g_ar.valid && g_ar.map.on ? (int)g_ar.map.tiles_levels : 0; }
 

@@ -181,9 +181,15 @@ def run_grav_mpi(tag, binary, env, level, nstep, nproc):
     pcie = {"level_array_bytes": sum(int(a) for a, _, _, _ in stats), "halo_bytes": sum(int(c) for _, _, c, _ in stats),
             "halo_exchanges": sum(int(d) for _, _, _, d in stats)} if stats else None
     sweeps = [l.strip()[11:] for l in out.splitlines() if "godunov_fine of AMR levels" in l]
+    # bytes of the Poisson level arrays over PCIe, all ranks (exit lines of RAMSES_AMD_STATS=1; round 6)
+    ftr = re.findall(r"acceleration f over PCIe:\s*(\d+) bytes to the device,\s*(\d+) bytes back", out)
+    mtr = re.findall(r"distributed multigrid over PCIe: rho\s*(\d+) bytes to the device, phi\s*(\d+) bytes back", out)
+    rtr = re.findall(r"density deposit rho over PCIe:\s*(\d+) bytes back", out)
+    level_arrays = {"f_up": sum(int(a) for a, _ in ftr), "f_down": sum(int(b) for _, b in ftr), "rho_up": sum(int(a) for a, _ in mtr),
+                    "phi_down": sum(int(b) for _, b in mtr), "rho_down": sum(int(a) for a in rtr)} if (ftr or mtr or rtr) else None
     print(json.dumps({"config": tag, "level": level, "steps": nstep, "ranks": nproc, "wall_s": round(wall, 3),
                       "vcycles": [int(b) for _, b, _ in solves], "timers_max_s": rows, "multigrid_pcie_all_ranks": pcie,
-                      "sweeps_of_rank": sweeps[:2]}), flush=True)
+                      "poisson_level_array_bytes_all_ranks": level_arrays, "sweeps_of_rank": sweeps[:2]}), flush=True)
 
 
 if __name__ == "__main__":
@@ -193,6 +199,14 @@ if __name__ == "__main__":
         which = sys.argv[5] if len(sys.argv) > 5 else "all"
         ref = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi")
         pat = os.path.join(ROOT, "oracle", "_ref", "ramses3d_mpi_patch")
+        if which == "pcie":
+            # round 6: what the Poisson level arrays (rho, phi, f) cost on the bus, steady state on / off, for nstep and 2 nstep steps
+            base = {"RAMSES_AMD": "1", "RAMSES_AMD_STATS": "1"}
+            for n in (nstep, 2 * nstep):
+                run_grav_mpi("patched (default): rho, phi, f resident from the second solve of the steady state on", pat, dict(base), level, n, nproc)
+            run_grav_mpi("patched, RAMSES_AMD_PHI_RESIDENT=0 RAMSES_AMD_F_RESIDENT=0: the paths before round 6", pat,
+                         dict(base, RAMSES_AMD_PHI_RESIDENT="0", RAMSES_AMD_F_RESIDENT="0"), level, 2 * nstep, nproc)
+            run_grav_mpi("reference (MPI)", ref, {"RAMSES_AMD": "0"}, level, 2 * nstep, nproc)
         if which == "tiles":
             base = {"RAMSES_AMD": "1", "RAMSES_AMD_STATS": "1"}
             run_grav_mpi("patched (default): the rank's octs in tiles, dense sweep in place; distributed dense V-cycles", pat, dict(base), level, nstep, nproc)

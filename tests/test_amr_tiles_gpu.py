@@ -250,6 +250,7 @@ def test_a_regrid_keeps_the_levels_that_did_not_change(gpu_lib, oracle, monkeypa
     c_l = np.concatenate([T2["ncoarse"] + ind * T2["ngridmax"] + T2["igrid"] - 1 for ind in range(8)])
     u[:, c_l] = -7.0                     # if the device read level L from the host again, the result would show it
     check(gpu_lib.ramses_amd_amrres_tree(_vp(T2["son"]), _vp(T2["nbor"]), _vp(T2["father"])))
+    assert gpu_lib.ramses_amd_amrres_first_changed() == L + 1      # what the caller has to send again: level L + 1, nothing coarser
     igf = np.ascontiguousarray(np.sort(T2["igrid_fine"]))
     check(gpu_lib.ramses_amd_amrres_load_level(len(igf), _vp(igf), _vp(u)))
     t0 = gpu_lib.ramses_amd_amrres_tile_sweeps()
