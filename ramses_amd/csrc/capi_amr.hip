@@ -535,11 +535,13 @@ __global__ __launch_bounds__(256) void plan_events_kernel(PlanArgs A, const int 
 }
 // the events by (face, device oct): neighbouring threads of the surface pass then read neighbouring octs of a tile row -- its
 // gathers are isolated 8-byte words otherwise, a cache line each (profiles/r06_tile_sweep_pmc.txt: 3 GB fetched for 35 MB of records)
-__global__ __launch_bounds__(256) void plan_event_keys_kernel(PlanArgs A, const int *__restrict__ events, int nevent, unsigned long long *__restrict__ keys) {
+// (order 0: (face, oct); 1: (tile of 512 octs, face, oct in the tile); 2: (oct, face) -- all keys below 2^35)
+__global__ __launch_bounds__(256) void plan_event_keys_kernel(PlanArgs A, const int *__restrict__ events, int nevent, unsigned long long *__restrict__ keys, int order) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nevent) return;
   const int ev = events[e];
-  keys[e] = ((unsigned long long)(ev % 6) << 32) | (unsigned)A.ig[ev / 6];
+  const unsigned long long ig = (unsigned)A.ig[ev / 6], f = (unsigned)(ev % 6);
+  keys[e] = order == 0 ? (f << 32) | ig : (order == 1 ? ((ig >> 9) << 12) | (f << 9) | (ig & 511) : (ig << 3) | f);
 }
 __global__ __launch_bounds__(256) void plan_event_index_kernel(PlanArgs A, const int *__restrict__ events, int nevent, int *__restrict__ evt_of) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -761,6 +763,12 @@ struct CommLevel {
 };
 
 // what the dense sweep of a level in tiles needs beyond the cell vectors (see plan_* above), valid for one layout and one list
+#ifndef EVENT_ORDER_DEFAULT
+#define EVENT_ORDER_DEFAULT 2      // (oct, face): measured on the shell level, profiles/r06_event_order.txt
+#endif
+#ifndef EVENT_QMINOR_DEFAULT
+#define EVENT_QMINOR_DEFAULT 1      // RAMSES_AMD_EVENT_LANES=q: the four fine faces of an event in neighbouring lanes; e: 64 events of one fine face
+#endif
 struct LevelPlan {
   int version = -1, ngrid = -1, ig_first = 0, ig_last = 0;      // the layout version of the level and the list the plan was made for
   int ig_sample[10] = {0};                                        // (ten entries of it, spread over the list: the fingerprint of the list cache)
@@ -825,6 +833,12 @@ inline int grid_for(long n) {
   return (int)g;
 }
 
+// RAMSES_AMD_EVENT_ORDER (A/B of the order the surface pass visits the (oct, face) events in): face | tile | oct
+int event_order() {
+  const char *e = getenv("RAMSES_AMD_EVENT_ORDER");
+  if (!e) return EVENT_ORDER_DEFAULT;
+  return e[0] == 'f' ? 0 : (e[0] == 't' ? 1 : 2);
+}
 bool env_on(const char *name) {      // (read on every sweep: the A/B tests flip the switches inside one process)
   const char *e = getenv(name);
   return !(e && e[0] == '0');
@@ -1291,7 +1305,7 @@ int build_plan(AmrRes &R, int ilevel, int ngrid, const int *h_igrid, int rows, L
     amrlayout::Buf &k1 = P.corr, &k2 = P.gfather, &v2 = P.flag;        // (free here: the records are written by the first sweep, the ghost table and the flags have done their job)
     HCHK(k1.ensure(sizeof(unsigned long long) * (size_t)P.nevent), "hipMalloc"); HCHK(k2.ensure(sizeof(unsigned long long) * (size_t)P.nevent), "hipMalloc");
     HCHK(v2.ensure(sizeof(int) * (size_t)P.nevent), "hipMalloc");
-    hipLaunchKernelGGL(plan_event_keys_kernel, dim3((P.nevent + 255) / 256), dim3(256), 0, s, A, P.events.as<int>() + 1, P.nevent, k1.as<unsigned long long>());
+    hipLaunchKernelGGL(plan_event_keys_kernel, dim3((P.nevent + 255) / 256), dim3(256), 0, s, A, P.events.as<int>() + 1, P.nevent, k1.as<unsigned long long>(), event_order());
     size_t bytes = 0;
     HCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k1.as<unsigned long long>(), k2.as<unsigned long long>(), P.events.as<int>() + 1, v2.as<int>(), P.nevent, 0, 35, s), "sort");
     HCHK(R.work.ensure(bytes), "hipMalloc");
@@ -1483,6 +1497,7 @@ int tile_level_sweep(AmrRes &R, const ramses_amd_hydro_params *p, int ilevel, in
     S.base = L.base; S.ncoarse = R.ncoarse; S.ngd = R.ngridmax; S.ncell = R.ncell;
     S.no = L.no; S.ntx = L.ntx; S.nty = L.nty; S.ntz = L.ntz;
     S.dt = A.dt; S.dx = A.dx; S.rdx = A.rdx; S.pow2 = A.pow2; S.P = A.P;
+    { const char *e = getenv("RAMSES_AMD_EVENT_LANES"); S.qminor = e ? (e[0] == 'q' ? 1 : 0) : EVENT_QMINOR_DEFAULT; }
     // (the pass on a stream of its own beside the marching kernel was measured in round 6 -- 2.62 -> 2.54 ms strict, 2.09 -> 2.08 fast
     //  on the shell level: a CU the marching kernel fills has no registers left for it, the two take turns; dropped)
     hipError_t es = fast ? fastmode::launch_surface_flux(S, st, p->riemann, nvar, p->scheme, R.grav, s) : strictmode::launch_surface_flux(S, st, p->riemann, nvar, p->scheme, R.grav, s);

@@ -72,6 +72,7 @@ struct SurfArgs {
   int no = 0, ntx = 0, nty = 0, ntz = 0;
   double dt = 0, dx = 0, rdx = 0;
   int pow2 = 0;
+  int qminor = 0;               // thread t -> (event, fine face): 0: (t % nevent, t / nevent), 1: (t / 4, t % 4)
   HydroConst P;
 };
 
