@@ -586,7 +586,31 @@ def mhd_sweep_bench(level=7, steps=5):
     assert bool(torch.isfinite(lev.uold).all().item())
     cells = n ** 3
     gbs = cells * BYTES_PER_CELL_UPDATE_MHD / (ms * 1e-3) / 1e9
+    # the same sweep in the fast arithmetic (ramses_amd_mhd_godunov_brick_fast; RAMSES_AMD_MHD_FAST=1 routes the entry point)
+    fast = None
+    saved = os.environ.get("RAMSES_AMD_MHD_FAST")
+    os.environ["RAMSES_AMD_MHD_FAST"] = "1"
+    try:
+        for _ in range(2):
+            lev.step(dt)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(steps):
+            lev.step(dt)
+        e.record()
+        torch.cuda.synchronize()
+        msf = a.elapsed_time(e) / steps
+        assert bool(torch.isfinite(lev.uold).all().item())
+        fast = {"ms_per_sweep": msf, "value": cells / (msf * 1e-3), "frac": cells * BYTES_PER_CELL_UPDATE_MHD / (msf * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "arithmetic": "fast (v_rcp_f64 + Newton divisions, contracted multiply-adds; <= 1e-12 of the reference program: "
+                              "tests/test_mhd_fast_certificate_gpu.py)"}
+    finally:
+        if saved is None:
+            os.environ.pop("RAMSES_AMD_MHD_FAST", None)
+        else:
+            os.environ["RAMSES_AMD_MHD_FAST"] = saved
     return {"metric": "cell-updates/s (MHD godunov_fine, SOLVER=mhd, constrained transport)", "value": cells / (ms * 1e-3),
+            "fast_arithmetic": fast,
             "unit": "cell-updates/s", "ms_per_sweep": ms, "cells": cells, "solver": "hlld + hlld (2-D), moncen",
             "arithmetic": "strict (bit-identical to the reference)", "workload": "uniform periodic %d^3, magnetised blast" % n,
             "kernels": "mhd_prim_trace (ctoprim + edge fields + trace fused over LDS tiles, round 6) / flux / emf / update; the 47 predicted numbers, "

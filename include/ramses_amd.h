@@ -967,7 +967,10 @@ int ramses_amd_amrres_halo_stage_in(int ilevel, int dir);
  * d_uold / d_unew: [11][nz][ny][nx] device doubles -- rho, rho u, rho v, rho w, E, the three left-face fields (uold(:,6:8)),
  * the three right-face fields (uold(:,nvar+1:nvar+3)) -- periodic, distinct buffers; the right-face field of a cell must equal
  * the left-face field of its neighbour bit for bit (it does on any level the scheme has advanced; RAMSES_AMD_EINVAL if not).
- * d_work: ramses_amd_mhd_workspace_bytes(nx,ny,nz) bytes of device scratch.  Bit-identical to the reference. */
+ * d_work: ramses_amd_mhd_workspace_bytes(nx,ny,nz) bytes of device scratch.  Bit-identical to the reference.
+ * ramses_amd_mhd_godunov_brick_fast: the same sweep in the fast arithmetic (divisions as v_rcp_f64 + Newton steps, contracted
+ * multiply-adds; <= 1e-12 relative L-infinity of the reference, div B at rounding all the same); RAMSES_AMD_MHD_FAST=1 in the
+ * environment routes ramses_amd_mhd_godunov_brick -- and the drop-in's staged and resident sweeps -- to it. */
 typedef struct ramses_amd_mhd_params {
   double gamma, smallr, smallc, slope_theta;
   int32_t slope_type, slope_mag_type, riemann, riemann2d;
@@ -975,6 +978,8 @@ typedef struct ramses_amd_mhd_params {
 int64_t ramses_amd_mhd_workspace_bytes(int nx, int ny, int nz);
 int ramses_amd_mhd_godunov_brick(const ramses_amd_mhd_params *p, int nx, int ny, int nz, const double *d_uold, double *d_unew,
                                  double dx, double dt, void *d_work, int64_t work_bytes, void *stream);
+int ramses_amd_mhd_godunov_brick_fast(const ramses_amd_mhd_params *p, int nx, int ny, int nz, const double *d_uold, double *d_unew,
+                                      double dx, double dt, void *d_work, int64_t work_bytes, void *stream);
 /* godunov_fine(ilevel) of a SOLVER=mhd run on the reference's own arrays uold / unew (1:ncell,1:nvar+3), staged through the
  * device: the level's cells go up, unew of the level's cells comes back (ramses_amd/patch_mhd/godunov_fine.f90). */
 int ramses_amd_mhd_godunov_fine_f90(const ramses_amd_mhd_params *p, int ilevel, int ngrid, const int *igrid, const double *xg,

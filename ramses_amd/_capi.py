@@ -229,6 +229,7 @@ SYMBOLS = [
     ("ramses_amd_amrres_boundary_hydro", _i, [_i, _vp, _vp, _vp, _i, _d, _i, _vp]),
     ("ramses_amd_mhd_workspace_bytes", _i64, [_i, _i, _i]),
     ("ramses_amd_mhd_godunov_brick", _i, [_vp, _i, _i, _i, _vp, _vp, _d, _d, _vp, _i64, _vp]),
+    ("ramses_amd_mhd_godunov_brick_fast", _i, [_vp, _i, _i, _i, _vp, _vp, _d, _d, _vp, _i64, _vp]),
     ("ramses_amd_mhd_godunov_fine_f90", _i, [_vp, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _vp, _d, _d]),
     ("ramses_amd_mhd_resident_active", _i, []),
     ("ramses_amd_mhd_resident_courant_f90", _i, [_vp, _i, _i, _vp, _vp, _i64, _i64, _i, _vp, _d, _d, _d, _vp]),

@@ -54,6 +54,8 @@ UNITS = [
     ("pois_amr.o", "pois_amr.hip", ["-ffp-contract=off"]),
     ("mg_dist.o", "mg_dist.hip", ["-ffp-contract=off"]),
     ("mhd_sweep.o", "mhd_sweep.hip", ["-ffp-contract=off"]),
+    # (the fast arithmetic of the MHD sweep: csrc/mhd_sweep.hip header; the flags come after COMMON's and win)
+    ("mhd_sweep_fast.o", "mhd_sweep.hip", ["-DRAMSES_AMD_MHD_FAST_TU=1", "-fapprox-func", "-ffp-contract=fast"]),
     ("mhd_amr.o", "mhd_amr.hip", ["-ffp-contract=off"]),
 ]
 
