@@ -23,13 +23,21 @@ ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "--offload-compress",
           "-I", os.path.join(HERE, "..", "include")]
 
+# The fast minmod unit (the flagship kernel of the bench line and the tile sweep of sedov3d.nml's AMR levels) is scheduled for
+# instruction-level parallelism instead of occupancy: its occupancy is set by LDS (one 12-wave workgroup per CU) whatever the
+# register count, so the default strategy's register economy buys nothing.  Measured at 512^3 (profiles/r06_codegen_ab.txt):
+# 3.08 -> 2.98 ms (43.5 -> 45.0 % of the roofline); the shell level in tiles 1.65 -> 1.55 ms; same instructions, same bits.
+# Neutral or worse on the strict units (5.40 ms either way), the tree-walking sweep (2.87 -> 3.02), the multigrid and MHD units.
+ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-schedule-relaxed-occupancy"]
+
 # (object name, source, extra flags)
 UNITS = [
     ("hydro_sweep_strict.o", "hydro_sweep.hip", ["-ffp-contract=off"]),
     ("hydro_sweep_fast.o", "hydro_sweep.hip", ["-ffp-contract=off", "-DRAMSES_AMD_FAST=1"]),
 ] + [
     # (one unit per slope type and arithmetic; 3 stands for 3, 4, 5, 6: csrc/hydro_sweep.hip)
-    ("hydro_sweep_%s_st%d.o" % (mode, st), "hydro_sweep.hip", ["-ffp-contract=off", "-DSWEEP_ST=%d" % st] + flag)
+    ("hydro_sweep_%s_st%d.o" % (mode, st), "hydro_sweep.hip", ["-ffp-contract=off", "-DSWEEP_ST=%d" % st] + flag
+     + (ILP if (mode, st) == ("fast", 1) else []))
     for st in (1, 2, 0, 7, 8, 3) for mode, flag in (("strict", []), ("fast", ["-DRAMSES_AMD_FAST=1"]))
 ] + [
     ("hydro_misc.o", "hydro_misc.hip", ["-ffp-contract=off"]),

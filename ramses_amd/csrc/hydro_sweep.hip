@@ -114,13 +114,16 @@ enum { ROLE_HALO = 0, ROLE_LOW = 1, ROLE_HIGH = 2, ROLE_FULL = 3, ROLE_HALO_HI =
 typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
 constexpr unsigned BUF_RANGE = 0x7fffffffu;     // lane offsets below this are in range
 constexpr unsigned BUF_OOB = 0xffffffffu;       // dropped by the range check
+#ifndef SWEEP_STORE_AUX
+#define SWEEP_STORE_AUX 0     // cache policy of the stores of unew (gfx950: 1 sc0, 2 nt, 16 sc1); A/B knob, profiles/r06_store_policy.txt
+#endif
 __device__ __forceinline__ double plane_load(const double *var_base, unsigned plane_bytes, unsigned off) {
   __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(var_base), 0, BUF_RANGE, 0x00020000);
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, plane_bytes, 0));
 }
 __device__ __forceinline__ void plane_store(double *var_base, unsigned plane_bytes, unsigned off, double x) {
   __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(var_base, 0, BUF_RANGE, 0x00020000);
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, x), r, off, plane_bytes, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, x), r, off, plane_bytes, SWEEP_STORE_AUX);
 }
 
 __device__ __forceinline__ int wave_shr1_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
@@ -179,8 +182,16 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
       lb = (lb % nxcd) * per + lb / nxcd;
     }
   }
+#ifndef SWEEP_TILE_YFAST
+#define SWEEP_TILE_YFAST 0     // A/B knob: tiles of a box in y-first order (profiles/r06_store_policy.txt)
+#endif
+#if SWEEP_TILE_YFAST
+  const int tiy = B.ty0 + lb % B.nty;
+  const int tix = B.tx0 + (lb / B.nty) % B.ntx;
+#else
   const int tix = B.tx0 + lb % B.ntx;
   const int tiy = B.ty0 + (lb / B.ntx) % B.nty;
+#endif
   const int tiz = lb / (B.ntx * B.nty);
   int x0 = tix * (BX - 4);
   int y0 = tiy * (BY - 4);
