@@ -300,13 +300,52 @@ __global__ __launch_bounds__(FT_X * FT_Y * FT_Z) void mhd_prim_trace_kernel(MhdA
   for (int n = 0; n < NPRED; n++) A.tr[pred_at(n, c_)] = T.v[n];
 }
 
+// A/B knob (round 6, measured and OFF): a traced state of the cell to the LEFT (i-1) of a cell whose own numbers the thread reads
+// anyway can come from the lane of that cell by a wavefront shift instead of from the left cell's predicted numbers -- three of
+// the seven cells around an edge triple and one of the four around a face triple are then never loaded (EMF 228 -> 160 wave-wide
+// loads per cell, flux 90 -> 70); the first lane of a wave and the first cell of a row rebuild the state from memory as before.
+// Same function on the same numbers: same bits (the parity tests pass with it).  At 256^3 it is SLOWER: EMF 3.63 -> 3.80 ms,
+// flux 1.72 -> 1.86, the sweep 8.78 -> 9.27 ms strict, 8.09 -> 8.40 fast (profiles/r06_mhd_xshare.txt) -- the one-lane pass of
+// every wave and the shifts in front of the solver cost more than the loads they replace; the kernels are not bound by the
+// number of loads.
+#ifndef MHD_XSHARE
+#define MHD_XSHARE 0
+#endif
+__device__ __forceinline__ double mhd_wave_shr1(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int KIND, int D>
+__device__ __forceinline__ void state_of_left(const PredSrc &own, const double *tr, long left_cell, bool left_in_wave, const MhdConst &P,
+                                              double (&s)[8]) {
+#if MHD_XSHARE
+  double t[8];
+  trace_state<KIND, D>(own, P, t);
+#pragma unroll
+  for (int n = 0; n < 8; n++) s[n] = mhd_wave_shr1(t[n]);
+  if (!left_in_wave) {
+    const PredSrc l{tr, left_cell};
+    trace_state<KIND, D>(l, P, s);
+  }
+#else
+  const PredSrc l{tr, left_cell};
+  trace_state<KIND, D>(l, P, s);
+#endif
+}
+
 // flux[d][0..4] through the LOW face of direction d of the cell, scaled as mag_unsplit does (fx*dt/dx, :105-111): the +d
 // state of the cell below and the -d state of the cell, each rebuilt from its predicted state and half slopes
 template <int D, int RS>
-__device__ __forceinline__ void mhd_face_flux(const MhdArgs &A, const Grid &g, int i, int j, int k, long c_) {
-  const PredSrc lo{A.tr, g.at(i - (D == 0), j - (D == 1), k - (D == 2))}, me{A.tr, c_};
+__device__ __forceinline__ void mhd_face_flux(const MhdArgs &A, const Grid &g, int i, int j, int k, long c_, bool left_in_wave) {
+  const PredSrc me{A.tr, c_};
   double qm_[8], qp_[8], f[8];
-  trace_state<T_QM, D>(lo, A.P, qm_);
+  if constexpr (D == 0) state_of_left<T_QM, 0>(me, A.tr, g.at(i - 1, j, k), left_in_wave, A.P, qm_);
+  else {
+    const PredSrc lo{A.tr, g.at(i, j - (D == 1), k - (D == 2))};
+    trace_state<T_QM, D>(lo, A.P, qm_);
+  }
   trace_state<T_QP, D>(me, A.P, qp_);
   cmpflxm_face<RS>(qm_, qp_, D, A.P, f);
 #pragma unroll
@@ -316,25 +355,32 @@ template <int RS>
 __global__ __launch_bounds__(128) void mhd_flux_kernel(MhdArgs A) {
   const Grid g{A.nx, A.ny, A.nz};
   MHD_CELL_REMAP(A, 128) {
-    mhd_face_flux<0, RS>(A, g, i, j, k, c_);
-    mhd_face_flux<1, RS>(A, g, i, j, k, c_);
-    mhd_face_flux<2, RS>(A, g, i, j, k, c_);
+    const bool left_in_wave = (threadIdx.x & 63) > 0 && i > 0;      // (consecutive threads of a block: consecutive cells of a row)
+    mhd_face_flux<0, RS>(A, g, i, j, k, c_, left_in_wave);
+    mhd_face_flux<1, RS>(A, g, i, j, k, c_, left_in_wave);
+    mhd_face_flux<2, RS>(A, g, i, j, k, c_, left_in_wave);
   }
 }
 
 // emf[e] on the LOW edge of direction e of the cell, scaled as mag_unsplit does (emf*dt/dx, :171-177); which cell's corner
 // state plays which part: mhd_assemble.hpp edge_sources
 template <int E, int R2>
-__device__ __forceinline__ void mhd_edge_emf(const MhdArgs &A, const Grid &g, int i, int j, int k, long c_) {
+__device__ __forceinline__ void mhd_edge_emf(const MhdArgs &A, const Grid &g, int i, int j, int k, long c_, bool left_in_wave) {
   double rt[8], rb[8], lt[8], lb[8];
   using Src = PredSrc;
   const Src me{A.tr, c_};
   if constexpr (E == 2) {
-    const Src a{A.tr, g.at(i - 1, j - 1, k)}, b{A.tr, g.at(i - 1, j, k)}, c{A.tr, g.at(i, j - 1, k)};
-    trace_state<T_QRT, 2>(a, A.P, rt); trace_state<T_QRB, 2>(b, A.P, rb); trace_state<T_QLT, 2>(c, A.P, lt);
+    // a = (i-1, j-1, k): the left neighbour of c; b = (i-1, j, k): the left neighbour of the cell itself
+    const Src c{A.tr, g.at(i, j - 1, k)};
+    state_of_left<T_QRT, 2>(c, A.tr, g.at(i - 1, j - 1, k), left_in_wave, A.P, rt);
+    state_of_left<T_QRB, 2>(me, A.tr, g.at(i - 1, j, k), left_in_wave, A.P, rb);
+    trace_state<T_QLT, 2>(c, A.P, lt);
   } else if constexpr (E == 1) {
-    const Src a{A.tr, g.at(i - 1, j, k - 1)}, b{A.tr, g.at(i, j, k - 1)}, c{A.tr, g.at(i - 1, j, k)};
-    trace_state<T_QRT, 1>(a, A.P, rt); trace_state<T_QLT, 1>(b, A.P, rb); trace_state<T_QRB, 1>(c, A.P, lt);
+    // a = (i-1, j, k-1): the left neighbour of b; c = (i-1, j, k): the left neighbour of the cell itself
+    const Src b{A.tr, g.at(i, j, k - 1)};
+    state_of_left<T_QRT, 1>(b, A.tr, g.at(i - 1, j, k - 1), left_in_wave, A.P, rt);
+    trace_state<T_QLT, 1>(b, A.P, rb);
+    state_of_left<T_QRB, 1>(me, A.tr, g.at(i - 1, j, k), left_in_wave, A.P, lt);
   } else {
     const Src a{A.tr, g.at(i, j - 1, k - 1)}, b{A.tr, g.at(i, j - 1, k)}, c{A.tr, g.at(i, j, k - 1)};
     trace_state<T_QRT, 0>(a, A.P, rt); trace_state<T_QRB, 0>(b, A.P, rb); trace_state<T_QLT, 0>(c, A.P, lt);
@@ -346,9 +392,10 @@ template <int R2>
 __global__ __launch_bounds__(128) void mhd_emf_kernel(MhdArgs A) {
   const Grid g{A.nx, A.ny, A.nz};
   MHD_CELL_REMAP(A, 128) {
-    mhd_edge_emf<0, R2>(A, g, i, j, k, c_);
-    mhd_edge_emf<1, R2>(A, g, i, j, k, c_);
-    mhd_edge_emf<2, R2>(A, g, i, j, k, c_);
+    const bool left_in_wave = (threadIdx.x & 63) > 0 && i > 0;
+    mhd_edge_emf<0, R2>(A, g, i, j, k, c_, left_in_wave);
+    mhd_edge_emf<1, R2>(A, g, i, j, k, c_, left_in_wave);
+    mhd_edge_emf<2, R2>(A, g, i, j, k, c_, left_in_wave);
   }
 }
 
