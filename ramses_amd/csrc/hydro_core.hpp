@@ -448,7 +448,7 @@ RA_DEV void riemann_hll(const double (&ql)[NV], const double (&qr)[NV],
   for (int n = 3; n <= NV; n++) { fL[n] = ql[1] * uL[n]; fR[n] = qr[1] * uR[n]; }
 #pragma unroll
   for (int n = 0; n <= NV; n++)
-    f[n] = (SR * fL[n] - SL * fR[n] + SR * SL * (uR[n] - uL[n])) / (SR - SL);
+    f[n] = ddiv(SR * fL[n] - SL * fR[n] + SR * SL * (uR[n] - uL[n]), SR - SL);
 }
 
 template <int NV>
@@ -477,14 +477,16 @@ RA_DEV void riemann_hllc(const double (&ql)[NV], const double (&qr)[NV],
   const double SR = dmaxd(ul, ur) + dmaxd(cfastl, cfastr);
   const double rcl = rl * (ul - SL);
   const double rcr = rr * (SR - ur);
-  const double ustar = (rcr * ur + rcl * ul + (Pl - Pr)) / (rcr + rcl);
-  const double Ptotstar = (rcr * Pl + rcl * Pr + rcl * rcr * (ul - ur)) / (rcr + rcl);
-  const double rstarl = rl * (SL - ul) / (SL - ustar);
-  const double etotstarl = ((SL - ul) * etotl - Pl * ul + Ptotstar * ustar) / (SL - ustar);
-  const double estarl = el * (SL - ul) / (SL - ustar);
-  const double rstarr = rr * (SR - ur) / (SR - ustar);
-  const double etotstarr = ((SR - ur) * etotr - Pr * ur + Ptotstar * ustar) / (SR - ustar);
-  const double estarr = er * (SR - ur) / (SR - ustar);
+  // (ddiv: the IEEE division in the strict build, v_rcp_f64 + a Newton step in the fast one -- the passive-scalar
+  //  instantiations of the fast build come through here; NV = 5 takes hllc_flux_fast below)
+  const double ustar = ddiv(rcr * ur + rcl * ul + (Pl - Pr), rcr + rcl);
+  const double Ptotstar = ddiv(rcr * Pl + rcl * Pr + rcl * rcr * (ul - ur), rcr + rcl);
+  const double rstarl = ddiv(rl * (SL - ul), SL - ustar);
+  const double etotstarl = ddiv((SL - ul) * etotl - Pl * ul + Ptotstar * ustar, SL - ustar);
+  const double estarl = ddiv(el * (SL - ul), SL - ustar);
+  const double rstarr = ddiv(rr * (SR - ur), SR - ustar);
+  const double etotstarr = ddiv((SR - ur) * etotr - Pr * ur + Ptotstar * ustar, SR - ustar);
+  const double estarr = ddiv(er * (SR - ur), SR - ustar);
   double ro, uo, Ptoto, etoto, eo;
   if (SL > 0.0) { ro = rl; uo = ul; Ptoto = Pl; etoto = etotl; eo = el; }
   else if (ustar > 0.0) { ro = rstarl; uo = ustar; Ptoto = Ptotstar; etoto = etotstarl; eo = estarl; }
@@ -701,6 +703,54 @@ RA_DEV void llf_flux_fast(const double (&qL)[5], const double (&qR)[5],
   flux[lt2] = __builtin_fma(hc, t2L - t2R, hs * __builtin_fma(ul, t2L, ur * t2R));
   flux[4] = __builtin_fma(hc, eL - eR, hs * fesum);
 }
+// HLLC the same way -- A/B knob RAMSES_AMD_HLLC_FUSED, measured in round 6 and OFF.  The fast build ran HLLC through the generic
+// routine with eight IEEE divisions (5.24 ms per 512^3 sweep against LLF's 2.97); what pays is those divisions through ddiv
+// (riemann_hllc / riemann_hll above: 5.24 -> 4.23 ms, HLL 4.69 -> 3.91).  This fused form -- one reciprocal of the wave-speed
+// sum, ONE star state (the side the contact speed points to) with one reciprocal, FMA forms, rsq-based sound speeds, dt/dx
+// folded in; <= 5e-15 of the strict build over 40 steps -- has 20 % fewer instructions still, but its selects keep both sides'
+// values alive up to the choice: the 12-row kernels, at their 168-register limit, spill 100 - 150 B per lane and the sweep takes
+// 7.3 ms (profiles/r06_hllc_fast.txt).
+// The selection is the reference's chain (SL > 0: left state; else u* > 0: left star; else SR > 0: right star; else right
+// state; transverse momentum and scalars by the sign of u* alone, godunov_utils.f90:1149-1203).
+template <int DIR>
+RA_DEV void hllc_flux_fast(const double (&qL)[5], const double (&qR)[5],
+                           const HydroConst &P, double dtdx, double (&flux)[5]) {
+  constexpr int ln = DIR == 0 ? 1 : (DIR == 1 ? 2 : 3);
+  constexpr int lt1 = DIR == 0 ? 2 : 1;
+  constexpr int lt2 = DIR == 2 ? 2 : 3;
+  const double rl = dmaxd(qL[0], P.smallr), Pl = dmaxd(qL[4], rl * P.smallp);
+  const double rr = dmaxd(qR[0], P.smallr), Pr = dmaxd(qR[4], rr * P.smallp);
+  const double ul = qL[ln], ur = qR[ln];
+  const double gl = P.gamma * Pl, gr = P.gamma * Pr;
+  const double cl = dmaxd(gl * rsqrt_fast(gl * rl), P.smallc);   // sqrt(max(gamma P / rho, smallc^2))
+  const double cr = dmaxd(gr * rsqrt_fast(gr * rr), P.smallc);
+  const double cm = dmaxd(cl, cr);
+  const double SL = dmind(ul, ur) - cm, SR = dmaxd(ul, ur) + cm;
+  const double rcl = rl * (ul - SL), rcr = rr * (SR - ur);
+  const double rsum = rcp_fast(rcr + rcl);
+  const double ustar = __builtin_fma(rcr, ur, __builtin_fma(rcl, ul, Pl - Pr)) * rsum;
+  const double Pstar = __builtin_fma(rcl * rcr, ul - ur, __builtin_fma(rcr, Pl, rcl * Pr)) * rsum;
+  const bool up = ustar > 0.0;
+  const bool left = (SL > 0.0) || up;
+  const bool star = left ? !(SL > 0.0) : (SR > 0.0);
+  const double rk = left ? rl : rr, uk = left ? ul : ur, Pk = left ? Pl : Pr, S = left ? SL : SR;
+  // (values first: a conditional between two array ELEMENTS is a conditional between two addresses, which parks the arrays in scratch)
+  const double vl1 = qL[lt1], vr1 = qR[lt1], vl2 = qL[lt2], vr2 = qR[lt2];
+  const double w1 = left ? vl1 : vr1, w2 = left ? vl2 : vr2;
+  double k2 = uk * uk; k2 = __builtin_fma(w1, w1, k2); k2 = __builtin_fma(w2, w2, k2);
+  const double etk = __builtin_fma(0.5 * rk, k2, Pk * P.entho);
+  const double inv = rcp_fast(S - ustar);
+  const double dS = S - uk;
+  const double rst = rk * dS * inv;
+  const double ets = __builtin_fma(Pstar, ustar, __builtin_fma(dS, etk, -(Pk * uk))) * inv;
+  const double ro = star ? rst : rk, uo = star ? ustar : uk, Po = star ? Pstar : Pk, eto = star ? ets : etk;
+  const double m = ro * uo * dtdx;
+  flux[0] = m;
+  flux[ln] = __builtin_fma(m, uo, Po * dtdx);
+  flux[lt1] = m * (up ? vl1 : vr1);
+  flux[lt2] = m * (up ? vl2 : vr2);
+  flux[4] = (eto + Po) * (uo * dtdx);
+}
 #endif
 
 template <int RS, int NV, int DIR>
@@ -710,6 +760,13 @@ RA_DEV void scaled_interface_flux(const double (&qL)[NV], const double (&qR)[NV]
 #ifdef RAMSES_AMD_FAST
   if constexpr (RS == RIEMANN_LLF && NV == 5) {
     llf_flux_fast<DIR>(qL, qR, P, dtdx, flux);
+    return;
+  }
+#ifndef RAMSES_AMD_HLLC_FUSED
+#define RAMSES_AMD_HLLC_FUSED 0     // measured and OFF (profiles/r06_hllc_fast.txt): see hllc_flux_fast
+#endif
+  if constexpr (RAMSES_AMD_HLLC_FUSED && RS == RIEMANN_HLLC && NV == 5) {
+    hllc_flux_fast<DIR>(qL, qR, P, dtdx, flux);
     return;
   }
 #endif

@@ -260,7 +260,10 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #define SWEEP_KEEP_STRICT 0    // (A/B knob: the strict build holds the plane too)
 #endif
 #if defined(RAMSES_AMD_FAST) || SWEEP_KEEP_STRICT
-  constexpr bool KEEP = (MASK || (SWEEP_KEEP_PLAIN && BY == 12)) && NV == 5 && !LATE;
+#ifndef SWEEP_KEEP_LLF_ONLY
+#define SWEEP_KEEP_LLF_ONLY 0   // A/B knob: only the LLF kernels hold the plane (the others are at the register limit without it)
+#endif
+  constexpr bool KEEP = (MASK || (SWEEP_KEEP_PLAIN && BY == 12)) && NV == 5 && !LATE && (!SWEEP_KEEP_LLF_ONLY || RS == RIEMANN_LLF);
 #else
   constexpr bool KEEP = false;
 #endif

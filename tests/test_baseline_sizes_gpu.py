@@ -70,6 +70,34 @@ def test_fast_build_multistep_within_tolerance(gpu_lib, n, nsteps):
     print("fast vs strict, %d^3, %d steps: worst rel-Linf per variable %s" % (n, nsteps, worst))
 
 
+@pytest.mark.parametrize("slope_type,nsteps", [(1, 40), (2, 40), (8, 24)])
+def test_fast_hllc_multistep_within_tolerance(gpu_lib, slope_type, nsteps):
+    """the fused fast HLLC flux (hydro_core.hpp hllc_flux_fast, round 6: one reciprocal per wave-speed sum, one star state,
+    FMA forms) against the strict build -- the reference's own operations -- each on its own Courant dt, after EVERY step of a
+    developing blast at 64^3 (the live certificates against the reference PROGRAM: tests/test_fast_certificate_gpu.py)"""
+    import ramses_amd
+    from ramses_amd import ic
+    from ramses_amd.hydro import HydroLevel
+    n = 64
+    u, dx = ic.sedov3d(n)
+    mk = lambda fm: HydroLevel(n, n, n, dx, params=ramses_amd.make_params(courant_factor=0.8, fast_math=fm, riemann="hllc", slope_type=slope_type))  # noqa: E731
+    strict, fast = mk(0), mk(1)
+    strict.upload(u)
+    fast.upload(u)
+    worst = np.zeros(5)
+    for step in range(nsteps):
+        dts = strict.courant_fine()[0]
+        dtf = fast.courant_fine()[0]
+        assert abs(dtf - dts) <= TOL * dts, (step, dts, dtf)
+        strict.step(dts)
+        fast.step(dtf)
+        err = _rel_linf_per_var(fast.download(), strict.download())
+        worst = np.maximum(worst, err)
+        assert (err <= TOL).all(), "step %d: rel-Linf (rho, mx, my, mz, E) = %s" % (step + 1, err)
+    assert worst.max() > 0.0          # (the fast build did run)
+    print("fast vs strict HLLC, slope %d, %d^3, %d steps: worst rel-Linf per variable %s" % (slope_type, n, nsteps, worst))
+
+
 def test_fast_build_at_the_size_of_the_bench_line(gpu_lib):
     """the certificate at the bench's OWN size (VERDICT round 4, next #7 i): 512^3, 20 steps of sedov3d.nml, the fast and the
     strict build stepping on their own Courant dt; relative L-infinity per variable after EVERY step <= 1e-12, on the device
