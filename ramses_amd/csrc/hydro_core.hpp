@@ -523,14 +523,14 @@ RA_DEV void riemann_acoustic(const double (&ql)[NV], const double (&qr)[NV],
   const double cl = dsqrt(ddiv(P.gamma * pl, rl));
   const double cr = dsqrt(ddiv(P.gamma * pr, rr));
   const double wl = cl * rl, wr = cr * rr;
-  const double pstar = ((wr * pl + wl * pr) + wl * wr * (ul - ur)) / (wl + wr);
-  const double ustar = ((wr * ur + wl * ul) + (pl - pr)) / (wl + wr);
+  const double pstar = ddiv((wr * pl + wl * pr) + wl * wr * (ul - ur), wl + wr);   // (ddiv / dsqrt: IEEE in the strict build)
+  const double ustar = ddiv((wr * ur + wl * ul) + (pl - pr), wl + wr);
   const double sgnm = fsignd(1.0, ustar);
   const bool left = sgnm == 1.0;
   const double ro = left ? rl : rr, uo = left ? ul : ur, po = left ? pl : pr, co = left ? cl : cr;
-  double rstar = ro + (pstar - po) / (co * co);
+  double rstar = ro + ddiv(pstar - po, co * co);
   rstar = dmaxd(rstar, P.smallr);
-  double cstar = __builtin_sqrt(__builtin_fabs(P.gamma * pstar / rstar));
+  double cstar = dsqrt(__builtin_fabs(ddiv(P.gamma * pstar, rstar)));
   cstar = dmaxd(cstar, P.smallc);
   double spout = co - sgnm * uo;
   double spin = cstar - sgnm * ustar;
@@ -541,14 +541,14 @@ RA_DEV void riemann_acoustic(const double (&ql)[NV], const double (&qr)[NV],
   if (spout < 0.0) { qg[0] = ro; qg[1] = uo; qg[2] = po; }
   else if (spin >= 0.0) { qg[0] = rstar; qg[1] = ustar; qg[2] = pstar; }
   else {
-    const double frac = spout / (spout - spin);
+    const double frac = ddiv(spout, spout - spin);
     qg[0] = frac * rstar + (1.0 - frac) * ro;
     qg[1] = frac * ustar + (1.0 - frac) * uo;
     qg[2] = frac * pstar + (1.0 - frac) * po;
   }
 #pragma unroll
   for (int n = 3; n < NV; n++) qg[n] = left ? ql[n] : qr[n];
-  qg[NV] = po / ro * P.entho;
+  qg[NV] = ddiv(po, ro) * P.entho;
   gdnv_to_flux<NV>(qg, P, f);
 }
 
