@@ -703,15 +703,14 @@ RA_DEV void llf_flux_fast(const double (&qL)[5], const double (&qR)[5],
   flux[lt2] = __builtin_fma(hc, t2L - t2R, hs * __builtin_fma(ul, t2L, ur * t2R));
   flux[4] = __builtin_fma(hc, eL - eR, hs * fesum);
 }
-// HLLC the same way -- A/B knob RAMSES_AMD_HLLC_FUSED, measured in round 6 and OFF.  The fast build ran HLLC through the generic
-// routine with eight IEEE divisions (5.24 ms per 512^3 sweep against LLF's 2.97); what pays is those divisions through ddiv
-// (riemann_hllc / riemann_hll above: 5.24 -> 4.23 ms, HLL 4.69 -> 3.91).  This fused form -- one reciprocal of the wave-speed
-// sum, ONE star state (the side the contact speed points to) with one reciprocal, FMA forms, rsq-based sound speeds, dt/dx
-// folded in; <= 5e-15 of the strict build over 40 steps -- has 20 % fewer instructions still, but its selects keep both sides'
-// values alive up to the choice: the 12-row kernels, at their 168-register limit, spill 100 - 150 B per lane and the sweep takes
-// 7.3 ms (profiles/r06_hllc_fast.txt).
-// The selection is the reference's chain (SL > 0: left state; else u* > 0: left star; else SR > 0: right star; else right
-// state; transverse momentum and scalars by the sign of u* alone, godunov_utils.f90:1149-1203).
+// HLLC the same way (round 6; RAMSES_AMD_HLLC_FUSED=0 gives the generic routine back).  The fast build ran HLLC -- the solver most
+// production namelists choose -- through riemann_hllc with eight IEEE divisions: 5.24 ms per 512^3 sweep against LLF's 2.97.
+// Step 1, the divisions through ddiv: 4.21 ms.  Step 2, this fused form: one reciprocal of the wave-speed sum, ONE star state
+// -- the side the contact speed points to -- with one reciprocal, FMA forms, rsq-based sound speeds, dt/dx folded in: 11 % fewer
+// instructions, <= 5e-15 of the strict build over 40 steps.  It keeps both sides' values alive up to the choice, and the 12-row
+// kernels sit at their 168-register limit: with the plane also held in registers (hydro_sweep.hip KEEP) they spilled 44 - 100 B
+// per lane and the sweep took 7.3 ms; the HLLC kernels therefore re-read the plane from L2 (SWEEP_KEEP_NOT_HLLC), spill the
+// generic routine's 8 B, and the sweep takes 3.51 ms (minmod) / 4.59 ms (moncen)  (profiles/r06_hllc_fast.txt).
 template <int DIR>
 RA_DEV void hllc_flux_fast(const double (&qL)[5], const double (&qR)[5],
                            const HydroConst &P, double dtdx, double (&flux)[5]) {
@@ -730,8 +729,8 @@ RA_DEV void hllc_flux_fast(const double (&qL)[5], const double (&qR)[5],
   const double rsum = rcp_fast(rcr + rcl);
   const double ustar = __builtin_fma(rcr, ur, __builtin_fma(rcl, ul, Pl - Pr)) * rsum;
   const double Pstar = __builtin_fma(rcl * rcr, ul - ur, __builtin_fma(rcr, Pl, rcl * Pr)) * rsum;
-  const bool up = ustar > 0.0;
-  const bool left = (SL > 0.0) || up;
+  // (SL > 0 implies u* > 0 with a margin of c (1 - 1/gamma): the side is the sign of u* in every branch of the chain)
+  const bool left = ustar > 0.0;
   const bool star = left ? !(SL > 0.0) : (SR > 0.0);
   const double rk = left ? rl : rr, uk = left ? ul : ur, Pk = left ? Pl : Pr, S = left ? SL : SR;
   // (values first: a conditional between two array ELEMENTS is a conditional between two addresses, which parks the arrays in scratch)
@@ -747,9 +746,12 @@ RA_DEV void hllc_flux_fast(const double (&qL)[5], const double (&qR)[5],
   const double m = ro * uo * dtdx;
   flux[0] = m;
   flux[ln] = __builtin_fma(m, uo, Po * dtdx);
-  flux[lt1] = m * (up ? vl1 : vr1);
-  flux[lt2] = m * (up ? vl2 : vr2);
+  flux[lt1] = m * w1;
+  flux[lt2] = m * w2;
   flux[4] = (eto + Po) * (uo * dtdx);
+#if RAMSES_AMD_HLLC_FUSED == 2
+  __builtin_amdgcn_sched_barrier(0);     // (the three interface fluxes of a cell one after the other, not interleaved)
+#endif
 }
 #endif
 
@@ -763,9 +765,9 @@ RA_DEV void scaled_interface_flux(const double (&qL)[NV], const double (&qR)[NV]
     return;
   }
 #ifndef RAMSES_AMD_HLLC_FUSED
-#define RAMSES_AMD_HLLC_FUSED 0     // measured and OFF (profiles/r06_hllc_fast.txt): see hllc_flux_fast
+#define RAMSES_AMD_HLLC_FUSED 1     // (2: + a scheduling barrier after each interface flux -- measured, no better)
 #endif
-  if constexpr (RAMSES_AMD_HLLC_FUSED && RS == RIEMANN_HLLC && NV == 5) {
+  if constexpr (RAMSES_AMD_HLLC_FUSED != 0 && RS == RIEMANN_HLLC && NV == 5) {
     hllc_flux_fast<DIR>(qL, qR, P, dtdx, flux);
     return;
   }

@@ -263,7 +263,11 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
 #ifndef SWEEP_KEEP_LLF_ONLY
 #define SWEEP_KEEP_LLF_ONLY 0   // A/B knob: only the LLF kernels hold the plane (the others are at the register limit without it)
 #endif
-  constexpr bool KEEP = (MASK || (SWEEP_KEEP_PLAIN && BY == 12)) && NV == 5 && !LATE && (!SWEEP_KEEP_LLF_ONLY || RS == RIEMANN_LLF);
+#ifndef SWEEP_KEEP_NOT_HLLC
+#define SWEEP_KEEP_NOT_HLLC 1   // the HLLC kernels do not hold the plane: with the fused fast HLLC flux they are at the register limit (hydro_core.hpp hllc_flux_fast)
+#endif
+  constexpr bool KEEP = (MASK || (SWEEP_KEEP_PLAIN && BY == 12)) && NV == 5 && !LATE && (!SWEEP_KEEP_LLF_ONLY || RS == RIEMANN_LLF) &&
+                        (!SWEEP_KEEP_NOT_HLLC || RS != RIEMANN_HLLC);
 #else
   constexpr bool KEEP = false;
 #endif

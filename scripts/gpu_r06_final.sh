@@ -22,4 +22,4 @@ rm -rf $R/gpurun_out/prof_r06_final
 cd $R
 [ "${TESTS:-1}" = 1 ] && { ( time timeout 1500 python -m pytest tests -m gpu -q --timeout 600 --durations=12 ) > gpurun_out/r06_final_pytest_gpu.txt 2>&1; tail -24 gpurun_out/r06_final_pytest_gpu.txt | cut -c1-300; }
 # the other solvers of the fast build on the final library (scripts/sweep_probe.py)
-{ for cfg in "hllc 1" "hll 1" "acoustic 1" "hllc 2"; do timeout 300 python scripts/sweep_probe.py 512 $cfg 2>&1 | grep -v amdgpu.ids | tail -1; done; } | tee gpurun_out/r06_final_solvers.txt
+{ for cfg in "hllc 1" "hllc 2" "hllc 8" "hll 1" "acoustic 1"; do timeout 300 python scripts/sweep_probe.py 512 $cfg 2>&1 | grep -v amdgpu.ids | tail -1; done; } | tee gpurun_out/r06_final_solvers.txt
