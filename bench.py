@@ -554,6 +554,39 @@ def amr_c5_shape_bench(steps=5):
 BYTES_PER_CELL_UPDATE_MHD = 176   # 11 fields (5 Euler + 3 left-face + 3 right-face fields) read and written, FP64
 
 
+def solver_sweep_bench(n, riemann="hllc", slope_type=1, steps=10):
+    """The dense sweep of the same uniform level with another solver of the fast (default) build -- HLLC is what most production
+    namelists choose; the headline line is sedov3d.nml's own LLF + minmod.  Timed with HIP events on torch's stream after 20
+    untimed sweeps; sedov3d.nml's initial state (csrc/hydro_core.hpp hllc_flux_fast; profiles/r06_hllc_fast.txt)."""
+    import torch
+    import ramses_amd
+    from ramses_amd import ic
+    from ramses_amd.hydro import HydroLevel
+    p = ramses_amd.make_params(courant_factor=0.8, fast_math=True, riemann=riemann, slope_type=slope_type)
+    lev = HydroLevel(n, n, n, 0.5 / n, params=p, ng=0)
+    corner, back, dx = ic.sedov3d_corner_and_background(n)
+    for v in range(5):
+        lev.uold[v].fill_(float(back[v]))
+        lev.uold[v, 0, 0, 0] = float(corner[v])
+    dt = lev.courant_fine()[0]
+    for _ in range(20):
+        lev.step(dt)
+    torch.cuda.synchronize()
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps):
+        lev.step(dt)
+    e.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(e) / steps
+    assert bool(torch.isfinite(lev.uold).all().item())
+    gbs = n ** 3 * BYTES_PER_CELL_UPDATE / (ms * 1e-3) / 1e9
+    return {"metric": "cell-updates/s (Godunov sweep)", "value": n ** 3 / (ms * 1e-3), "unit": "cell-updates/s", "ms_per_sweep": ms,
+            "solver": "%s, slope_type %d" % (riemann, slope_type), "arithmetic": "fast (the patched program's default)",
+            "workload": "sedov3d.nml uniform %d^3, 20 sweeps in" % n,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}}
+
+
 def mhd_sweep_bench(level=7, steps=5):
     """SOLVER=mhd: the constrained-transport MHD sweep of a uniform periodic 2^level^3 level through
     ramses_amd_mhd_godunov_brick (csrc/mhd_sweep.hip: the first correct path, one kernel per stage of mag_unsplit with the
@@ -990,6 +1023,12 @@ def main():
                 out["amr_sweep_partial_tree_walking"] = amr_sweep_bench(args.amr_level + 1, partial=True)
             except Exception as exc:     # noqa: BLE001  (an extra line, never a reason to lose the headline)
                 out.setdefault("amr_sweep", {"value": None})["error"] = str(exc)[:300]
+        if world == 1 and args.stress_steps > 0:      # (with the other extra legs of a default run)
+            try:
+                torch.cuda.empty_cache()
+                out["hllc_sweep"] = solver_sweep_bench(n, "hllc", 1)
+            except Exception as exc:     # noqa: BLE001  (an extra line, never a reason to lose the headline)
+                out["hllc_sweep"] = {"value": None, "error": str(exc)[:300]}
         if world == 1 and args.mhd_level > 0:
             try:
                 torch.cuda.empty_cache()
