@@ -423,7 +423,7 @@ def amr_resident_bench(level=8, steps=5, kind="covered"):
     L = lib()
     out = {}
     for tag, env, fast in (("dense", "1", False), ("dense_fast", "1", True), ("tree", "0", False)):
-        p = ramses_amd.make_params(courant_factor=0.8, fast_math=fast)
+        p = ramses_amd.make_params(courant_factor=0.8, fast_math=fast, riemann=os.environ.get("RAMSES_AMD_BENCH_AMR_RIEMANN", "llf"))   # (probe: another solver on the tiles)
         os.environ["RAMSES_AMD_COVERED_DENSE"] = env
         os.environ["RAMSES_AMD_TILE_DENSE"] = env
         check(L.ramses_amd_amrres_invalidate())

@@ -507,9 +507,9 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
         double qL[NV], fx[NV], fz[NV];
 #pragma unroll
         for (int n = 0; n < NV; n++) qL[n] = wave_shr1(qm[0][n]);  // +x state of column tx-1
-        scaled_interface_flux<RS, NV, 0>(qL, qp[0], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fx);
+        scaled_interface_flux<RS, NV, 0, !MASK>(qL, qp[0], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fx);
         // z flux through the face between planes c-1 and c
-        scaled_interface_flux<RS, NV, 2>(qmz, qp[2], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fz);
+        scaled_interface_flux<RS, NV, 2, !MASK>(qmz, qp[2], P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fz);
         if (MASK) {
           // hydro/godunov_fine.f90:720-747: the flux through a face is reset when the cell on either side is refined
           const int s_xm = wave_shr1_i(okc);
@@ -557,7 +557,7 @@ __device__ __forceinline__ void sweep_march(const SweepArgs &A, unsigned char *s
       double qL[NV];
 #pragma unroll
       for (int n = 0; n < NV; n++) qL[n] = M.v[n][tym - M0][tx];
-      scaled_interface_flux<RS, NV, 1>(qL, qpy, P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fy);
+      scaled_interface_flux<RS, NV, 1, !MASK>(qL, qpy, P, A.dt, A.dx, A.rdx, dtdx, DXPOW2, fy);
       if (MASK) {
         ok_ym = smask[((c + 3) % 3 * BY + tym) * BX + tx];
         const bool zy = ((okc | ok_ym) & CELL_REFINED) != 0;
@@ -706,7 +706,7 @@ __device__ __forceinline__ void surf_interface27(const SurfArgs &A, const int (&
 #pragma unroll
     for (int n = 0; n < NV; n++) { if (w == 0) qL[n] = qm[DIR][n]; else qR[n] = qp[DIR][n]; }
   }
-  scaled_interface_flux<RS, NV, DIR>(qL, qR, A.P, A.dt, A.dx, A.rdx, dtdx, A.pow2 != 0, fl);
+  scaled_interface_flux<RS, NV, DIR, false>(qL, qR, A.P, A.dt, A.dx, A.rdx, dtdx, A.pow2 != 0, fl);   // (as the marching kernel of a level in tiles does)
 }
 template <int ST, int RS, int NV, bool GRAV, int SCHEME, int DIR>
 __device__ __forceinline__ void surf_interface(const SurfArgs &A, const int (&lo)[3], double (&fl)[NV]) {
@@ -758,7 +758,7 @@ __device__ __forceinline__ void surf_interface(const SurfArgs &A, const int (&lo
 #pragma unroll
     for (int n = 0; n < NV; n++) { if (w == 0) qL[n] = qm[DIR][n]; else qR[n] = qp[DIR][n]; }
   }
-  scaled_interface_flux<RS, NV, DIR>(qL, qR, A.P, A.dt, A.dx, A.rdx, dtdx, A.pow2 != 0, fl);
+  scaled_interface_flux<RS, NV, DIR, false>(qL, qR, A.P, A.dt, A.dx, A.rdx, dtdx, A.pow2 != 0, fl);   // (as the marching kernel of a level in tiles does)
 }
 template <int ST, int RS, int NV, bool GRAV, int SCHEME = 0>
 __global__ __launch_bounds__(128) void surface_flux_kernel(SurfArgs A) {

@@ -117,7 +117,8 @@ def test_levels_in_tiles_equal_the_oracle(gpu_lib, oracle, monkeypatch, order, r
                                                           (7, "hll", 8, True, True), (5, "exact", 2, True, True),
                                                           (5, "hllc", 3, False, False), (7, "llf", 3, True, False), (5, "acoustic", 3, True, True),
                                                           (5, "plmde:llf", 1, False, False), (5, "plmde:hllc", 2, True, False),
-                                                          (5, "plmde:hll", 3, False, False), (5, "plmde:llf", 7, True, True)])
+                                                          (5, "plmde:hll", 3, False, False), (5, "plmde:llf", 7, True, True),
+                                                          (5, "hllc", 1, False, True), (5, "hllc", 2, True, True)])     # (fast HLLC on tiles: round 6)
 def test_passive_scalars_and_the_newton_solver_on_tiles(gpu_lib, oracle, monkeypatch, nvar, riemann, slope, grav, fast):
     """Round 6 (missing #3): NVAR = 6 / 7 (passive scalars: interpolated in the ghost octs, in the flux records,
     in the replay), riemann = 'exact', slope_type = 3 (the 27-point slope: the surface pass gathers the 3 x 3 x 3 neighbourhoods
